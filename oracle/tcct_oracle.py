@@ -1,0 +1,380 @@
+"""ORACLE (test infrastructure, not product): CPU fp32 restatement of the TCCT `stc_tt` training hot path.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this file.  The
+product path (`tcct_amd/`) never does: it runs HIP kernels or fails loudly.
+
+Everything here is a *functional* restatement driven by a reference-keyed state_dict (`sd`), written from
+the behaviour of the reference (file:line cited per function, paths relative to /root/reference/task1).
+Hidden RNG draws of the reference (DropPath masks, `rand_like` in `regular_reg`) are explicit arguments.
+Pinned against the real reference by `oracle/make_golden.py` (run in the build container, where the
+reference imports) -> `tests/golden/*.npz`; `tests/test_oracle_golden.py` re-checks it anywhere.
+"""
+import math
+import torch
+import torch.nn.functional as F
+
+KSIZES = (13, 11, 9, 7, 5)            # nets/tcct.py:866
+VIT_DIMS = (64, 96, 128, 160)         # nets/tcct.py:771
+VIT_OUT = (96, 128, 160, 160)         # nets/tcct.py:705-706
+DROP_PATH = (0.0, 0.1 / 3, 0.2 / 3, 0.1)   # nets/tcct.py:635-647 with drop_path_rate=0.1 (tcct.py:660)
+
+
+def _conv(sd, p, x, stride=1, pad=0, groups=1):
+    return F.conv2d(x, sd[p + '.weight'], sd.get(p + '.bias'), stride, pad, 1, groups)
+
+
+def _bn(sd, p, x, train, eps=1e-5):
+    """BatchNorm2d; train mode uses batch stats and updates running stats (momentum .1, unbiased var)."""
+    if train and (p + '.num_batches_tracked') in sd:
+        sd[p + '.num_batches_tracked'] += 1
+    return F.batch_norm(x, sd[p + '.running_mean'], sd[p + '.running_var'], sd[p + '.weight'],
+                        sd[p + '.bias'], train, 0.1, eps)
+
+
+def cross_block(sd, p, x, k, train):
+    """CrossCNNBlock.forward, nets/tcct.py:804-828 (activation BEFORE the BatchNorm)."""
+    a = _conv(sd, p + '.block12.0', x, pad=1)
+    a = _conv(sd, p + '.block12.1', a, pad=1)
+    a = _bn(sd, p + '.block12.3', F.leaky_relu(a, 0.01), train)
+    b = _conv(sd, p + '.block34.0', x, pad=(0, k // 2))
+    b = _conv(sd, p + '.block34.1', b, pad=(k // 2, 0))
+    b = _conv(sd, p + '.block34.2', b, pad=1)
+    b = _bn(sd, p + '.block34.4', F.leaky_relu(b, 0.01), train)
+    c = F.gelu(a + b)
+    c = _conv(sd, p + '.block5.0', c, pad=1)
+    return _bn(sd, p + '.block5.2', F.leaky_relu(c, 0.01), train)
+
+
+def cnn_branch(sd, p, x, train):
+    """CrossResNet.forward, nets/tcct.py:877-885."""
+    x = _bn(sd, p + '.cnn.1', _conv(sd, p + '.cnn.0', x, pad=1), train)
+    outs = []
+    for i, k in enumerate(KSIZES):
+        x = cross_block(sd, f'{p}.path_estan.{i}', x, k, train)
+        outs.append(x)
+        x = F.max_pool2d(x, 2)
+    return outs
+
+
+def _conv_bn(sd, p, x, train, stride=1, pad=0, act=True):
+    """Conv2d_BN, nets/tcct.py:55-97 (conv has no bias)."""
+    y = _bn(sd, p + '.bn', _conv(sd, p + '.conv', x, stride, pad), train)
+    return F.hardswish(y) if act else y
+
+
+def metapool(t):
+    """MetaPool.forward nets/tcct.py:405-415 applied to a 3-D [B,N,C] tensor: AvgPool2d sees it as an
+    unbatched image (C=B, H=N, W=C) -> 3x3 box over (token, channel), valid-count divisor, minus identity."""
+    return F.avg_pool2d(t, 3, 1, 1, count_include_pad=False) - t
+
+
+def vit_stage(sd, p_pe, p_st, x, s, train, dp_masks):
+    """Patch_Embed_stage (tcct.py:173-195) + MHCA_stage.forward (tcct.py:604-616) for stage s.
+    dp_masks: None (no DropPath) or (mask_a[B], mask_b[B]) 0/1 tensors for the two residual branches."""
+    C = VIT_DIMS[s]
+    pe = p_pe + '.patch_embeds.0.patch_conv'
+    y = _conv(sd, pe + '.dwconv', x, stride=2 if s > 0 else 1, pad=1, groups=C)
+    y = _conv(sd, pe + '.pwconv', y)
+    pch = F.hardswish(_bn(sd, pe + '.bn', y, train))
+    # InvRes (ResBlock.forward tcct.py:563-572)
+    r = _conv_bn(sd, p_st + '.InvRes.conv1', pch, train)
+    r = _conv(sd, p_st + '.InvRes.dwconv', r, pad=1, groups=C)
+    r = F.hardswish(_bn(sd, p_st + '.InvRes.norm', r, train))
+    r = pch + _conv_bn(sd, p_st + '.InvRes.conv2', r, train, act=False)
+    # MHCABlock.forward tcct.py:457-469 on tokens [B,N,C]
+    B, _, H, W = pch.shape
+    blk = p_st + '.mhca_blks.0.MHCA_layers.0'
+    # shared ConvPosEnc (tcct.py:491,502,208-217): canonical parameter name is mhca_blks.0.cpe (the
+    # MHCA_layers.0.cpe.* state_dict keys alias the same tensors)
+    img = pch + _conv(sd, p_st + '.mhca_blks.0.cpe.proj', pch, pad=1, groups=C)
+    t = img.flatten(2).transpose(1, 2)
+    keep = 1.0 - DROP_PATH[s]
+
+    def dp(v, m):
+        if m is None or DROP_PATH[s] == 0.0 or not train:
+            return v
+        return v * (m.to(v.dtype).view(B, 1, 1) / keep)
+
+    ma, mb = dp_masks if dp_masks is not None else (None, None)
+    cur = F.layer_norm(t, (C,), sd[blk + '.norm1.weight'], sd[blk + '.norm1.bias'], 1e-6)
+    t = t + dp(metapool(cur), ma)
+    cur = F.layer_norm(t, (C,), sd[blk + '.norm2.weight'], sd[blk + '.norm2.bias'], 1e-6)
+    h = F.gelu(F.linear(cur, sd[blk + '.mlp.fc1.weight'], sd[blk + '.mlp.fc1.bias']))
+    t = t + dp(F.linear(h, sd[blk + '.mlp.fc2.weight'], sd[blk + '.mlp.fc2.bias']), mb)
+    e = t.reshape(B, H, W, C).permute(0, 3, 1, 2)
+    return _conv_bn(sd, p_st + '.aggregate', torch.cat([r, e], 1), train)
+
+
+def vit_branch(sd, p, x, train, dp_masks=None):
+    """MPViT.forward_features tcct.py:733-745 for mpvit_tiny (tcct.py:766-776).
+    dp_masks: list of 6 [B] 0/1 masks in draw order (stages 1,2,3 x two branches) or None."""
+    x = _conv_bn(sd, p + '.stem.0', x, train, stride=2, pad=1)
+    x = _conv_bn(sd, p + '.stem.1', x, train, pad=1)
+    outs = []
+    for s in range(4):
+        m = None
+        if dp_masks is not None and s > 0:
+            m = (dp_masks[2 * (s - 1)], dp_masks[2 * (s - 1) + 1])
+        x = vit_stage(sd, f'{p}.patch_embed_stages.{s}', f'{p}.mhca_stages.{s}', x, s, train, m)
+        outs.append(x)
+    return outs
+
+
+def _up_block(sd, p, x1, x2, train):
+    """MPUpBlock.forward tcct.py:902-914."""
+    y = F.leaky_relu(_bn(sd, p + '.prep.1', _conv(sd, p + '.prep.0', x1, pad=1), train), 0.01)
+    y = F.interpolate(y, scale_factor=2, mode='bilinear', align_corners=True)
+    return _conv(sd, p + '.post.0', y + x2)
+
+
+def norm_add(xs):
+    """norm_add tcct.py:937-942."""
+    xs = [F.normalize(x, dim=1, p=2) for x in xs]
+    xs = [F.interpolate(x, size=xs[0].shape[-2:], mode='bilinear', align_corners=False) for x in xs]
+    return sum(xs) / len(xs)
+
+
+def ftc_forward(sd, x, train=True, dp_masks=None, p='base', want=None):
+    """FTC.forward tcct.py:999-1046 -> ([y0,y1,y2,y4] logits at input size, feats [B,32,H,W]).
+    `want`: optional dict that receives named intermediates (for fixtures)."""
+    c = cnn_branch(sd, p + '.base_cnn', x, train)
+    v = vit_branch(sd, p + '.base_vit', x, train, dp_masks)
+    f = [c[0]]
+    for j in range(4):
+        tv = _bn(sd, f'{p}.tran_vit{j}.1', _conv(sd, f'{p}.tran_vit{j}.0', v[j]), train)
+        tc = _bn(sd, f'{p}.tran_cnn{j}.1', _conv(sd, f'{p}.tran_cnn{j}.0', c[j + 1]), train)
+        f.append(tv + tc)
+    y8 = F.leaky_relu(_bn(sd, p + '.head.1', _conv(sd, p + '.head.0', f[4], pad=1), train), 0.01)
+    d3 = _up_block(sd, p + '.dec1', y8, f[3], train)
+    d2 = _up_block(sd, p + '.dec2', d3, f[2], train)
+    d1 = _up_block(sd, p + '.dec3', d2, f[1], train)
+    d0 = _up_block(sd, p + '.dec4', d1, f[0], train)
+    g0 = _conv(sd, p + '.t324', f[0] + d0)
+    g1 = _conv(sd, p + '.t323', f[1] + d1)
+    g2 = _conv(sd, p + '.t322', f[2] + d2)
+    g3 = _conv(sd, p + '.t321', f[3] + d3)
+    feats = norm_add([g0, g1, g2])
+    size = x.shape[-2:]
+    outs = [_conv(sd, p + '.aux0', g0)]
+    for name, g in (('aux1', g1), ('aux2', g2), ('aux4', g3)):
+        outs.append(F.interpolate(_conv(sd, f'{p}.{name}', g), size=size, mode='bilinear',
+                                  align_corners=False))
+    if want is not None:
+        want.update(c1=c[0], c3=c[2], c5=c[4], v2=v[0], v5=v[3], f4=f[4], y8=y8, d0=d0, g0=g0, g2=g2)
+    return outs, feats
+
+
+# ----------------------------------------------------------------------------------------- losses
+def dice_multi(logits, onehot):
+    """MultiLoss.forward + DiceLoss.dice, kite/losses/loss.py:83-99,15-32: per class 1-(1+2I)/(1+P+G) with
+    sums over the whole batch, summed over classes."""
+    pr = torch.softmax(logits, dim=1)
+    gt = onehot.to(pr.dtype)
+    inter = (pr * gt).sum(dim=(0, 2, 3))
+    union = pr.sum(dim=(0, 2, 3)) + gt.sum(dim=(0, 2, 3))
+    return (1 - (1 + 2 * inter) / (1 + union)).sum()
+
+
+def deep_supervision(outs, onehot, coff_ds=1.0):
+    """KiteBack.grad_calc kite/loopback.py:62-73."""
+    los = 0
+    for i in range(len(outs) - 1, 0, -1):
+        los = los + dice_multi(outs[i], onehot) * coff_ds
+    return los + dice_multi(outs[0], onehot)
+
+
+def fpl_select(feat, prob, true):
+    """FeatConSuper.select1 + points_selection_bins, nets/fcs.py:82-96,25-50.  feat [B,L,H,W], prob/true
+    [B,1,H,W] -> [32,L] bin means over rank ranges of the descending-prob order (tail dropped)."""
+    L = feat.shape[1]
+    fl = feat.permute(0, 2, 3, 1).reshape(-1, L)
+    sel = true.float().round().reshape(-1) > .5
+    fl = fl[sel]
+    pr = prob.reshape(-1)[sel]
+    _, idx = torch.sort(pr, descending=True)
+    n = fl.shape[0] // 32
+    return torch.stack([fl[idx[b * n:(b + 1) * n]].mean(0) for b in range(32)], 0)
+
+
+def fpl_loss(sd, feats, logits, onehot, want=None):
+    """RegNet.regular_udh nets/reg.py:86-105 with FeatConSuper.cosinesim fcs.py:63-80 and
+    FeatConPolar.choice fcp.py:72-75.  The trailing MSE uses only the LAST class's (pro,tgt) (reg.py:102)."""
+    pred = torch.softmax(logits.detach(), dim=1)
+    los = 0
+    pros = []
+    for i in range(onehot.shape[1]):
+        pro = fpl_select(feats, pred[:, i:i + 1], onehot[:, i:i + 1])
+        tgt = sd['fcp.buf_grad'][i:i + 1].expand(pro.shape[0], -1)
+        los = los - torch.einsum('nc,kc->nk', pro, tgt).mean() / pro.shape[-1]
+        pros.append(pro)
+    los = los + F.mse_loss(pro, tgt)
+    if want is not None:
+        want['emb'] = torch.stack(pros, 0)
+    return los
+
+
+def reg_loss(sd, logits, onehot, eps_pred, eps_true, jit_true, jit_pred, train=True, want=None):
+    """RegNet.regular_reg nets/reg.py:109-156.  Explicit noise (reference draw order reg.py:120 x2 via
+    :128-129, then :147-148): eps_pred, eps_true ~U(0,1) [B,4,H,W]; jit_true, jit_pred ~U(0,1) [1,1,H,1]."""
+    pred = logits[:, 1:]
+    true = onehot[:, 1:].float()
+    H = pred.shape[2]
+    prob_true = F.pad((true[:, :, 1:] - true[:, :, :-1]).abs(), (0, 0, 1, 0))
+    prob_true = prob_true.sum(1, keepdim=True).clamp_max(1)
+
+    def lap_reg(x):
+        x = _conv(sd, 'lap_reg.0', x, pad=1, groups=4)
+        return _conv(sd, 'lap_reg.1', x, pad=1, groups=4).abs()
+
+    def sampling_softmax(x, eps):
+        g = F.softmax(x - torch.log(-torch.log(eps)) / 2, dim=-2)
+        return g / (1e-6 + g.sum(-2, keepdim=True))
+
+    def lap_map(x):
+        x = _conv(sd, 'lap_map.0', x, pad=1)
+        x = _bn(sd, 'lap_map.1', x, train, eps=1.0)            # BatchNorm2d(1, 1): eps = 1 (reg.py:73)
+        return torch.sigmoid(_conv(sd, 'lap_map.2', x, pad=1))
+
+    m_pred = lap_map(sampling_softmax(lap_reg(pred), eps_pred).sum(1, keepdim=True))
+    m_true = lap_map(sampling_softmax(lap_reg(true), eps_true).sum(1, keepdim=True))
+    idx = torch.arange(0, H, dtype=torch.float32).reshape(1, 1, -1, 1)
+    edge_true = (m_true * (idx + jit_true - 0.5)).sum(-2) / H
+    edge_pred = (m_pred * (idx + jit_pred - 0.5)).sum(-2) / H
+    los_edge = F.mse_loss(edge_pred, edge_true.detach()) + F.mse_loss(edge_pred.detach(), edge_true)
+    los_prob = F.mse_loss(prob_true, m_true.softmax(-2)) + F.mse_loss(prob_true, m_pred.softmax(-2))
+    if want is not None:
+        want.update(edge_pred=edge_pred, edge_true=edge_true, prob_true=prob_true, map_pred=m_pred)
+    return los_edge + los_prob
+
+
+def total_loss(sd, img, onehot, udh=False, reg=False, coff_ds=1.0, coff_udh=1.0, coff_reg=0.1,
+               dp_masks=None, noise=None, train=True, want=None):
+    """KiteSeg.calc_loss kite/loop_seg.py:146-171: forward -> Dice(ds) -> udh -> reg."""
+    outs, feats = ftc_forward(sd, img, train, dp_masks, want=want)
+    parts = {'dice': deep_supervision(outs, onehot, coff_ds)}
+    if udh:
+        parts['udh'] = fpl_loss(sd, feats, outs[0], onehot, want) * coff_udh
+    if reg:
+        parts['reg'] = reg_loss(sd, outs[0], onehot, *noise, train=train, want=want) * coff_reg
+    return sum(parts.values()), parts, outs, feats
+
+
+# --------------------------------------------------------------------------------- optimizer step
+def clip_adamw_step(params, grads, m, v, step, lr, max_norm=12.0, wd=2e-4, b1=0.9, b2=0.999, eps=1e-8):
+    """clip_grad_norm_(…,12) + AdamW step, kite/loop_seg.py:128-130, kite/loopback.py:127 (torch semantics:
+    coef = min(1, max_norm/(total+1e-6)); decoupled decay; bias correction).  In-place on params/m/v lists.
+    Returns the pre-clip total norm."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    with torch.no_grad():
+        for p, g, mi, vi in zip(params, grads, m, v):
+            g = g * coef
+            p.mul_(1 - lr * wd)
+            mi.mul_(b1).add_(g, alpha=1 - b1)
+            vi.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (vi.sqrt() / math.sqrt(bc2)).add_(eps)
+            p.addcdiv_(mi, denom, value=-lr / bc1)
+    return total
+
+
+# ------------------------------------------------------------------------------------ eval metrics
+def predict_mask(logits):
+    """KiteSeg.predict kite/loop_seg.py:21-33: one_hot(argmax(softmax)) as float NCHW."""
+    C = logits.shape[1]
+    return F.one_hot(torch.argmax(F.softmax(logits, 1), 1), C).permute(0, 3, 1, 2).float()
+
+
+def dice_score(pr, gt, smooth=1):
+    """MDiceLoss.score kite/losses/miou.py:69-80 (mean over batch of per-sample Dice)."""
+    pr = pr.reshape(pr.shape[0], -1).float()
+    gt = gt.reshape(pr.shape[0], -1).float()
+    inter = (pr * gt).sum(-1)
+    return ((2 * inter + smooth) / (pr.sum(-1) + gt.sum(-1) + smooth)).mean()
+
+
+def dice_scorem(pr, gt, start_idx=0):
+    """MDiceLoss.scorem miou.py:87-91."""
+    C = pr.shape[1]
+    return sum(dice_score(pr[:, i:i + 1], gt[:, i:i + 1]) for i in range(start_idx, C)) / (C - start_idx)
+
+
+def iou_scorem(pr, gt, start_idx=0, smooth=1):
+    """MIouLoss.score/scorem miou.py:28-44."""
+    C = pr.shape[1]
+    tot = 0
+    for i in range(start_idx, C):
+        p = pr[:, i].reshape(pr.shape[0], -1).float()
+        g = gt[:, i].reshape(pr.shape[0], -1).float()
+        inter = (p * g).sum(-1)
+        tot = tot + ((inter + smooth) / (p.sum(-1) + g.sum(-1) - inter + smooth)).mean()
+    return tot / (C - start_idx)
+
+
+# ------------------------------------------------------------------- formula weights & synthetic data
+def _crc(name):
+    import zlib
+    return zlib.crc32(name.encode()) % 1000
+
+
+def formula_tensor(name, shape):
+    """Closed-form, name-keyed fill (SURVEY §8(c) 'weights by formula'): independent of any RNG."""
+    n = 1
+    for s in shape:
+        n *= s
+    t = torch.sin(0.37 * torch.arange(n, dtype=torch.float64) + _crc(name)).float().reshape(shape)
+    if name.endswith('num_batches_tracked'):
+        return torch.zeros((), dtype=torch.int64)
+    if name.endswith('running_mean'):
+        return 0.05 * t
+    if name.endswith('running_var'):
+        return 1.0 + 0.2 * t
+    if name == 'tau':
+        return torch.full(shape, 100.0)
+    if name == 'fcp.cos_dist':
+        return torch.full(shape, -0.25)
+    if name in ('fcp.vec_grad',):
+        return 0.5 + 0.5 * t
+    if name == 'fcp.buf_grad':
+        return F.normalize(0.5 + 0.5 * formula_tensor('fcp.vec_grad', shape), p=2, dim=-1)
+    if len(shape) == 1:
+        is_norm_w = name.endswith('.weight')
+        return (1.0 + 0.1 * t) if is_norm_w else 0.1 * t
+    fan_in = n // shape[0]
+    return t * (1.2 / math.sqrt(fan_in))
+
+
+def canonical_key(k):
+    """state_dict keys `…mhca_blks.0.MHCA_layers.0.{cpe,crpe}.*` alias the shared `…mhca_blks.0.{cpe,crpe}.*`
+    modules (tcct.py:491-505)."""
+    return k.replace('.MHCA_layers.0.cpe.', '.cpe.').replace('.MHCA_layers.0.crpe.', '.crpe.')
+
+
+def formula_state_dict(key_shapes):
+    """key_shapes: iterable of (name, shape).  1-D '.weight' tensors are norm scales (≈1); conv/linear
+    biases are 1-D '.bias' (≈0.1·sin)."""
+    return {k: formula_tensor(canonical_key(k), tuple(s)) for k, s in key_shapes}
+
+
+def synth_batch(B, H, W, seed=2023, classes=5):
+    """Synthetic OCT-like batch: img [B,3,H,W] in [0,1) (1 channel replicated), labels [B,H,W]
+    int64 from 4 sorted smooth per-column boundaries, every class present with >= 32 px."""
+    g = torch.Generator().manual_seed(seed)
+    xs = torch.arange(W, dtype=torch.float32) / max(W - 1, 1)
+    lab = torch.zeros(B, H, W, dtype=torch.int64)
+    img = torch.zeros(B, 1, H, W)
+    rows = torch.arange(H, dtype=torch.float32).view(H, 1)
+    for b in range(B):
+        ph = torch.rand(classes - 1, generator=g) * 6.28
+        amp = 0.03 + 0.02 * torch.rand(classes - 1, generator=g)
+        base = torch.linspace(0.15, 0.8, classes - 1)
+        bnd = (base.view(-1, 1) + amp.view(-1, 1) * torch.sin(6.28 * xs.view(1, -1) * (1 + b) + ph.view(-1, 1)))
+        bnd, _ = torch.sort(bnd * H, dim=0)
+        l = torch.zeros(H, W, dtype=torch.int64)
+        for k in range(classes - 1):
+            l = l + (rows >= bnd[k].view(1, W)).long()
+        lab[b] = l
+        inten = 0.2 + 0.15 * l.float()
+        img[b, 0] = inten * (0.5 + 0.5 * torch.rand(H, W, generator=g))
+    return img.clamp(0, 0.999).repeat(1, 3, 1, 1), lab
