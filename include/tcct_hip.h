@@ -1,0 +1,116 @@
+/* libtcct_hip.so — C-ABI of the MI355X (gfx950) kernels for the TCCT `stc_tt` training hot path.
+ *
+ * The reference (tyb311/TCCT, task1) has NO native/FFI layer: every op of the path is a stock ATen call made
+ * from Python (nets/tcct.py, nets/reg.py, nets/fcs.py, nets/fcp.py, kite/losses/loss.py, kite/loopback.py).
+ * Each entry below therefore cites the reference *call site(s)* whose ATen op family it replaces
+ * (paths relative to /root/reference/task1).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - activations are NHWC ("channels-last") device buffers, dtype TCCT_F32 or TCCT_BF16; a token tensor
+ *     [B,N,C] of the ViT branch is the same memory as the NHWC image [B,H,W,C] (N = H*W).
+ *   - parameters, statistics, gradients of parameters and loss scalars are fp32 (BN sums fp64).
+ *   - the caller owns every buffer (library never allocates or frees); all calls are asynchronous on
+ *     `stream` (a hipStream_t passed as void*), never synchronise, and are hipGraph-capturable.
+ *   - return 0 on success, <0 on error; tcct_last_error() gives a thread-local message.
+ *   - no RNG inside: DropPath masks / Gumbel noise / jitter are inputs.
+ */
+#ifndef TCCT_HIP_H
+#define TCCT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tcct_stream_t;
+
+enum { TCCT_F32 = 0, TCCT_BF16 = 1 };
+enum { TCCT_ACT_NONE = 0, TCCT_ACT_LRELU = 1, TCCT_ACT_HSWISH = 2, TCCT_ACT_GELU = 3, TCCT_ACT_SIGMOID = 4,
+       TCCT_ACT_ABS = 5 };
+
+int tcct_version(void);
+const char* tcct_last_error(void);
+
+/* ---- layout: loader-side `img.to(device)` (kite/loop_seg.py:116) + 1->3 channel replicate / W pad ---------
+ * img [N,Csrc,H,Wsrc] fp32 NCHW (Csrc 1 or 3) -> out [N,H,Wdst,4] NHWC (channel 3 and columns >= Wsrc zero). */
+int tcct_image_to_nhwc4(const float* img, void* out, int N, int Csrc, int H, int Wsrc, int Wdst, int dtype,
+                        tcct_stream_t stream);
+/* labels: one-hot int64 [N,C,H,W] (kite/loop_seg.py:119) -> class index uint8 [N,H,W] */
+int tcct_onehot_to_index(const int64_t* onehot, uint8_t* lab, int N, int C, int64_t HW, tcct_stream_t stream);
+/* int64 [N,H,Wsrc] class labels -> uint8 [N,H,Wdst] (columns >= Wsrc get class 0) */
+int tcct_labels_to_u8(const int64_t* lab, uint8_t* out, int N, int H, int Wsrc, int Wdst, tcct_stream_t stream);
+/* NHWC [M,C] -> NCHW-contiguous fp32 copy and back (API-boundary materialisation only) */
+int tcct_nhwc_to_nchw_f32(const void* x, float* y, int N, int64_t HW, int C, int dtype, tcct_stream_t stream);
+
+/* ---- elementwise: nn.LeakyReLU / nn.Hardswish / nn.GELU / F.gelu / abs / sigmoid and residual adds
+ * (nets/tcct.py:35,89,126,811,817,822,826,894,980; nets/reg.py:75,115) ------------------------------------ */
+int tcct_act_fwd(const void* x, void* y, int64_t n, int kind, int dtype, tcct_stream_t stream);
+int tcct_act_bwd(const void* x, const void* dy, void* dx, int64_t n, int kind, int dtype, tcct_stream_t stream);
+int tcct_add(const void* a, const void* b, void* y, int64_t n, int dtype, tcct_stream_t stream);
+int tcct_add_act_fwd(const void* a, const void* b, void* y, int64_t n, int kind, int dtype, tcct_stream_t stream);
+int tcct_add_act_bwd(const void* a, const void* b, const void* dy, void* dx, int64_t n, int kind, int dtype,
+                     tcct_stream_t stream);
+/* y = x + scale[b] * z   (DropPath residual, nets/tcct.py:465,468; scale NULL -> 1) */
+int tcct_residual_fwd(const void* x, const void* z, const float* scale, void* y, int B, int64_t per_sample,
+                      int dtype, tcct_stream_t stream);
+/* y[b,:] = scale[b] * x[b,:] */
+int tcct_scale_rows(const void* x, const float* scale, void* y, int B, int64_t per_sample, int dtype,
+                    tcct_stream_t stream);
+/* y = alpha * (a + b + c)  (norm_add mean, nets/tcct.py:942);  y = alpha * x */
+int tcct_add3_scale(const void* a, const void* b, const void* c, void* y, int64_t n, float alpha, int dtype,
+                    tcct_stream_t stream);
+int tcct_scale(const void* x, void* y, int64_t n, float alpha, int dtype, tcct_stream_t stream);
+/* torch.cat(dim=1) on NHWC rows (nets/tcct.py:614) and its backward */
+int tcct_concat2(const void* a, const void* b, void* y, int64_t M, int Ca, int Cb, int dtype, tcct_stream_t stream);
+int tcct_split2(const void* dy, void* da, void* db, int64_t M, int Ca, int Cb, int dtype, tcct_stream_t stream);
+/* fp32 accumulate: y += x  (gradient accumulation of parameter grads) */
+int tcct_axpy_f32(const float* x, float* y, int64_t n, float alpha, tcct_stream_t stream);
+
+/* ---- BatchNorm2d, train mode (nets/tcct.py:80,125,544,811,817,822,874,893,966-974,979; reg.py:73) with the
+ * neighbouring activation fused: y = post( a[c]*pre(x) + b[c] ).  x viewed as [M,C], M = N*H*W. ----------- */
+int tcct_bn_stats(const void* x, int64_t M, int C, int pre_act, double* sums /*[2C]*/, int dtype, tcct_stream_t stream);
+int tcct_bn_finalize(const double* sums, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                     float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     float* mean_rstd /*[2C]*/, float* ab /*[2C]*/, tcct_stream_t stream);
+/* eval mode: ab from running stats (KiteSeg.val, kite/loop_seg.py:68) */
+int tcct_bn_eval_ab(int C, const float* gamma, const float* beta, float eps, const float* running_mean,
+                    const float* running_var, float* mean_rstd, float* ab, tcct_stream_t stream);
+int tcct_bn_apply(const void* x, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act, int dtype,
+                  tcct_stream_t stream);
+int tcct_bn_bwd_reduce(const void* x, const void* dy, int64_t M, int C, const float* mean_rstd, const float* ab,
+                       int pre_act, int post_act, double* sums /*[2C]*/, int dtype, tcct_stream_t stream);
+int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_t M, int C, const float* mean_rstd,
+                      const float* ab, const float* gamma, const double* sums, int pre_act, int post_act,
+                      float* dgamma, float* dbeta, int dtype, tcct_stream_t stream);
+
+/* ---- nn.LayerNorm(C, eps=1e-6) over the channel dim of tokens [M,C] (nets/tcct.py:427,454-455,461,467) ---- */
+int tcct_layernorm_fwd(const void* x, void* y, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                       float* mean_rstd /*[M,2]*/, int dtype, tcct_stream_t stream);
+int tcct_layernorm_bwd(const void* x, const void* dy, void* dx, int64_t M, int C, const float* gamma,
+                       const float* mean_rstd, float* dgamma, float* dbeta, int dtype, tcct_stream_t stream);
+
+/* ---- dense conv2d / nn.Linear (nets/tcct.py:41-43,72,124,809-821,873,892,897,966-997) ------------------- */
+/* x [N,H,W,Cin] (Cin % 4 == 0; weight input channels Cin_w <= Cin, extra channels ignored),
+ * w OIHW fp32 [Cout,Cin_w,KH,KW], y [N,Ho,Wo,Cout]. */
+int tcct_conv2d_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin,
+                    int Cin_w, int Cout, int KH, int KW, int stride, int padh, int padw, int in_dtype, int out_dtype,
+                    tcct_stream_t stream);
+/* stride-1 input gradient: dy [N,H,W,Cout] -> dx [N,H,W,Cin] (Cin == Cin_w here) */
+int tcct_conv2d_dgrad(const void* dy, const float* w, void* dx, int N, int H, int W, int Cin, int Cout, int KH,
+                      int KW, int padh, int padw, int dy_dtype, int dx_dtype, tcct_stream_t stream);
+/* dw OIHW fp32 (overwritten), dbias fp32 [Cout] (nullable, overwritten) */
+int tcct_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cin,
+                      int Cin_w, int Cout, int KH, int KW, int stride, int padh, int padw, int x_dtype, int dy_dtype,
+                      tcct_stream_t stream);
+
+/* ---- depthwise 3x3 (nets/tcct.py:114-122,206,535-543; nets/reg.py:66-67,72,74 as C=1 / groups=C) -------- */
+int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
+                       int stride, int add_input, int dtype, tcct_stream_t stream);
+int tcct_dwconv3x3_dgrad(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride,
+                         int add_input, int dtype, tcct_stream_t stream);
+int tcct_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C,
+                         int stride, int dtype, tcct_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,127 @@
+// Shared device helpers for the TCCT gfx950 kernels.  CDNA4 only: 64-wide wavefronts are assumed throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/tcct_hip.h"
+
+typedef __hip_bfloat16 bf16;
+
+void tcct_set_error(const char* fmt, ...);
+
+#define TCCT_CHECK(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            tcct_set_error(__VA_ARGS__);                        \
+            return -1;                                          \
+        }                                                       \
+    } while (0)
+
+#define TCCT_LAUNCH_OK()                                                        \
+    do {                                                                        \
+        hipError_t e__ = hipGetLastError();                                     \
+        if (e__ != hipSuccess) {                                                \
+            tcct_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+            return -2;                                                          \
+        }                                                                       \
+        return 0;                                                               \
+    } while (0)
+
+// dtype dispatch: F is a generic lambda-like macro body using type T
+#define TCCT_DISPATCH(dtype, ...)                                               \
+    do {                                                                        \
+        if ((dtype) == TCCT_F32) { typedef float T; __VA_ARGS__; }              \
+        else if ((dtype) == TCCT_BF16) { typedef bf16 T; __VA_ARGS__; }         \
+        else { tcct_set_error("%s: bad dtype %d", __func__, (int)(dtype)); return -1; } \
+    } while (0)
+
+static inline int tcct_grid(int64_t work_items, int block, int cap = 256 * 16) {
+    int64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------- scalar / vec4 loads (compute is fp32)
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16* p) { return __bfloat162float(*p); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16* p, float v) { *p = __float2bfloat16(v); }
+
+struct f4 { float v[4]; };
+
+__device__ __forceinline__ f4 ld4(const float* p) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    f4 r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
+}
+__device__ __forceinline__ f4 ld4(const bf16* p) {
+    uint2 t = *reinterpret_cast<const uint2*>(p);
+    f4 r;
+    r.v[0] = __uint_as_float(t.x << 16); r.v[1] = __uint_as_float(t.x & 0xffff0000u);
+    r.v[2] = __uint_as_float(t.y << 16); r.v[3] = __uint_as_float(t.y & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ void st4(float* p, const f4& a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    bf16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
+    return (uint32_t)(*reinterpret_cast<unsigned short*>(&a)) |
+           ((uint32_t)(*reinterpret_cast<unsigned short*>(&b)) << 16);
+}
+__device__ __forceinline__ void st4(bf16* p, const f4& a) {
+    uint2 t; t.x = pack_bf16x2(a.v[0], a.v[1]); t.y = pack_bf16x2(a.v[2], a.v[3]);
+    *reinterpret_cast<uint2*>(p) = t;
+}
+__device__ __forceinline__ f4 f4zero() { f4 r; r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f; return r; }
+
+// ---------------------------------------------------------------- activations (kinds: TCCT_ACT_*)
+__device__ __forceinline__ float act_fwd(int kind, float x) {
+    switch (kind) {
+        case TCCT_ACT_LRELU: return x > 0.f ? x : 0.01f * x;
+        case TCCT_ACT_HSWISH: return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+        case TCCT_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+        case TCCT_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+        case TCCT_ACT_ABS: return fabsf(x);
+        default: return x;
+    }
+}
+// derivative w.r.t. the pre-activation x
+__device__ __forceinline__ float act_grad(int kind, float x) {
+    switch (kind) {
+        case TCCT_ACT_LRELU: return x > 0.f ? 1.f : 0.01f;
+        case TCCT_ACT_HSWISH: return x < -3.f ? 0.f : (x <= 3.f ? (2.f * x + 3.f) * (1.f / 6.f) : 1.f);
+        case TCCT_ACT_GELU: {
+            float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+            float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+            return cdf + x * pdf;
+        }
+        case TCCT_ACT_SIGMOID: { float s = 1.f / (1.f + __expf(-x)); return s * (1.f - s); }
+        case TCCT_ACT_ABS: return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+        default: return 1.f;
+    }
+}
+
+// ---------------------------------------------------------------- wave / block reductions (wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// sum over the whole block (blockDim.x multiple of 64, <= 1024); result valid in every thread
+__device__ __forceinline__ float block_sum(float v, float* sm /* >= 16 floats */) {
+    v = wave_sum(v);
+    int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += sm[i];
+    return r;
+}

@@ -1,0 +1,264 @@
+// Elementwise / layout kernels (HBM-bound; 16 B (fp32) or 8 B (bf16) per lane, grid-stride).
+#include "common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void tcct_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* tcct_last_error(void) { return g_err; }
+extern "C" int tcct_version(void) { return 100; }
+
+#define EW_BLOCK 256
+
+// ------------------------------------------------------------------------------------------- layout
+template <typename T>
+__global__ void k_image_to_nhwc4(const float* __restrict__ img, T* __restrict__ out, int N, int Csrc, int H,
+                                 int Wsrc, int Wdst) {
+    int64_t total = (int64_t)N * H * Wdst;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int w = (int)(i % Wdst);
+        int64_t t = i / Wdst;
+        int h = (int)(t % H);
+        int n = (int)(t / H);
+        f4 v = f4zero();
+        if (w < Wsrc) {
+            int64_t plane = (int64_t)H * Wsrc;
+            const float* p = img + (int64_t)n * Csrc * plane + (int64_t)h * Wsrc + w;
+            if (Csrc == 1) { v.v[0] = v.v[1] = v.v[2] = p[0]; }
+            else { v.v[0] = p[0]; v.v[1] = p[plane]; v.v[2] = p[2 * plane]; }
+        }
+        st4(out + i * 4, v);
+    }
+}
+
+extern "C" int tcct_image_to_nhwc4(const float* img, void* out, int N, int Csrc, int H, int Wsrc, int Wdst,
+                                   int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(Csrc == 1 || Csrc == 3, "image_to_nhwc4: Csrc must be 1 or 3, got %d", Csrc);
+    TCCT_CHECK(Wdst >= Wsrc && N > 0 && H > 0, "image_to_nhwc4: bad shape");
+    int64_t total = (int64_t)N * H * Wdst;
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_image_to_nhwc4<T>, dim3(tcct_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0,
+                                            (hipStream_t)stream, img, (T*)out, N, Csrc, H, Wsrc, Wdst));
+    TCCT_LAUNCH_OK();
+}
+
+__global__ void k_onehot_to_index(const int64_t* __restrict__ oh, uint8_t* __restrict__ lab, int N, int C, int64_t HW) {
+    int64_t total = (int64_t)N * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t n = i / HW, p = i % HW;
+        int best = 0;
+        for (int c = 0; c < C; ++c)
+            if (oh[(n * C + c) * HW + p] > 0) { best = c; break; }
+        lab[i] = (uint8_t)best;
+    }
+}
+extern "C" int tcct_onehot_to_index(const int64_t* onehot, uint8_t* lab, int N, int C, int64_t HW, tcct_stream_t stream) {
+    TCCT_CHECK(C > 0 && C < 256, "onehot_to_index: bad C");
+    hipLaunchKernelGGL(k_onehot_to_index, dim3(tcct_grid((int64_t)N * HW, EW_BLOCK)), dim3(EW_BLOCK), 0,
+                       (hipStream_t)stream, onehot, lab, N, C, HW);
+    TCCT_LAUNCH_OK();
+}
+
+__global__ void k_labels_to_u8(const int64_t* __restrict__ lab, uint8_t* __restrict__ out, int N, int H, int Wsrc, int Wdst) {
+    int64_t total = (int64_t)N * H * Wdst;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int w = (int)(i % Wdst);
+        int64_t r = i / Wdst;
+        out[i] = w < Wsrc ? (uint8_t)lab[r * Wsrc + w] : (uint8_t)0;
+    }
+}
+extern "C" int tcct_labels_to_u8(const int64_t* lab, uint8_t* out, int N, int H, int Wsrc, int Wdst, tcct_stream_t stream) {
+    TCCT_CHECK(Wdst >= Wsrc, "labels_to_u8: Wdst < Wsrc");
+    hipLaunchKernelGGL(k_labels_to_u8, dim3(tcct_grid((int64_t)N * H * Wdst, EW_BLOCK)), dim3(EW_BLOCK), 0,
+                       (hipStream_t)stream, lab, out, N, H, Wsrc, Wdst);
+    TCCT_LAUNCH_OK();
+}
+
+// NHWC -> NCHW fp32 through an LDS tile (32 pixels x C)
+template <typename T>
+__global__ void k_nhwc_to_nchw(const T* __restrict__ x, float* __restrict__ y, int64_t HW, int C) {
+    extern __shared__ float tile[];   // [64][C+1]
+    int n = blockIdx.y;
+    int64_t p0 = (int64_t)blockIdx.x * 64;
+    int np = (int)min((int64_t)64, HW - p0);
+    const T* xs = x + ((int64_t)n * HW + p0) * C;
+    for (int i = threadIdx.x; i < np * C; i += blockDim.x) tile[(i / C) * (C + 1) + (i % C)] = ldf(xs + i);
+    __syncthreads();
+    for (int i = threadIdx.x; i < np * C; i += blockDim.x) {
+        int c = i / np, p = i % np;
+        y[((int64_t)n * C + c) * HW + p0 + p] = tile[p * (C + 1) + c];
+    }
+}
+extern "C" int tcct_nhwc_to_nchw_f32(const void* x, float* y, int N, int64_t HW, int C, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(C > 0 && C <= 512, "nhwc_to_nchw: bad C %d", C);
+    dim3 grid((unsigned)((HW + 63) / 64), N);
+    size_t lds = (size_t)64 * (C + 1) * sizeof(float);
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_nhwc_to_nchw<T>, grid, dim3(256), lds, (hipStream_t)stream,
+                                            (const T*)x, y, HW, C));
+    TCCT_LAUNCH_OK();
+}
+
+// ------------------------------------------------------------------------------------ generic vec4 maps
+// OP(i, lambda over 4 lanes).  n must be a multiple of 4 for the vector body; the tail is scalar.
+template <typename T, typename F>
+__global__ void k_map1(const T* __restrict__ x, T* __restrict__ y, int64_t n, F f) {
+    int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f4 a = ld4(x + i * 4), r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.v[k] = f(a.v[k]);
+        st4(y + i * 4, r);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        int64_t i = (n4 << 2) + threadIdx.x;
+        stf(y + i, f(ldf(x + i)));
+    }
+}
+template <typename T, typename F>
+__global__ void k_map2(const T* __restrict__ x, const T* __restrict__ z, T* __restrict__ y, int64_t n, F f) {
+    int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f4 a = ld4(x + i * 4), b = ld4(z + i * 4), r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.v[k] = f(a.v[k], b.v[k]);
+        st4(y + i * 4, r);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        int64_t i = (n4 << 2) + threadIdx.x;
+        stf(y + i, f(ldf(x + i), ldf(z + i)));
+    }
+}
+template <typename T, typename F>
+__global__ void k_map3(const T* __restrict__ x, const T* __restrict__ z, const T* __restrict__ u, T* __restrict__ y,
+                       int64_t n, F f) {
+    int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f4 a = ld4(x + i * 4), b = ld4(z + i * 4), c = ld4(u + i * 4), r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.v[k] = f(a.v[k], b.v[k], c.v[k]);
+        st4(y + i * 4, r);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        int64_t i = (n4 << 2) + threadIdx.x;
+        stf(y + i, f(ldf(x + i), ldf(z + i), ldf(u + i)));
+    }
+}
+
+struct FAct { int kind; __device__ float operator()(float x) const { return act_fwd(kind, x); } };
+struct FActBwd { int kind; __device__ float operator()(float x, float dy) const { return dy * act_grad(kind, x); } };
+struct FAdd { __device__ float operator()(float a, float b) const { return a + b; } };
+struct FAddAct { int kind; __device__ float operator()(float a, float b) const { return act_fwd(kind, a + b); } };
+struct FAddActBwd { int kind; __device__ float operator()(float a, float b, float dy) const { return dy * act_grad(kind, a + b); } };
+struct FAdd3 { float alpha; __device__ float operator()(float a, float b, float c) const { return alpha * (a + b + c); } };
+struct FScale { float alpha; __device__ float operator()(float a) const { return alpha * a; } };
+
+#define EW_GRID(n) dim3(tcct_grid(((n) >> 2) + 1, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream
+
+extern "C" int tcct_act_fwd(const void* x, void* y, int64_t n, int kind, int dtype, tcct_stream_t stream) {
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_map1<T, FAct>), EW_GRID(n), (const T*)x, (T*)y, n, FAct{kind}));
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_act_bwd(const void* x, const void* dy, void* dx, int64_t n, int kind, int dtype, tcct_stream_t stream) {
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_map2<T, FActBwd>), EW_GRID(n), (const T*)x, (const T*)dy, (T*)dx, n, FActBwd{kind}));
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_add(const void* a, const void* b, void* y, int64_t n, int dtype, tcct_stream_t stream) {
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_map2<T, FAdd>), EW_GRID(n), (const T*)a, (const T*)b, (T*)y, n, FAdd{}));
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_add_act_fwd(const void* a, const void* b, void* y, int64_t n, int kind, int dtype, tcct_stream_t stream) {
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_map2<T, FAddAct>), EW_GRID(n), (const T*)a, (const T*)b, (T*)y, n, FAddAct{kind}));
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_add_act_bwd(const void* a, const void* b, const void* dy, void* dx, int64_t n, int kind, int dtype,
+                                tcct_stream_t stream) {
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_map3<T, FAddActBwd>), EW_GRID(n), (const T*)a, (const T*)b, (const T*)dy,
+                                            (T*)dx, n, FAddActBwd{kind}));
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_add3_scale(const void* a, const void* b, const void* c, void* y, int64_t n, float alpha, int dtype,
+                               tcct_stream_t stream) {
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_map3<T, FAdd3>), EW_GRID(n), (const T*)a, (const T*)b, (const T*)c, (T*)y, n,
+                                            FAdd3{alpha}));
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_scale(const void* x, void* y, int64_t n, float alpha, int dtype, tcct_stream_t stream) {
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_map1<T, FScale>), EW_GRID(n), (const T*)x, (T*)y, n, FScale{alpha}));
+    TCCT_LAUNCH_OK();
+}
+
+// ------------------------------------------------------------------------ per-sample scaled residual
+template <typename T>
+__global__ void k_residual(const T* __restrict__ x, const T* __restrict__ z, const float* __restrict__ scale,
+                           T* __restrict__ y, int64_t per4, int64_t total4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = scale ? scale[i / per4] : 1.f;
+        f4 b = ld4(z + i * 4), r;
+        if (x) {
+            f4 a = ld4(x + i * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r.v[k] = a.v[k] + s * b.v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r.v[k] = s * b.v[k];
+        }
+        st4(y + i * 4, r);
+    }
+}
+extern "C" int tcct_residual_fwd(const void* x, const void* z, const float* scale, void* y, int B, int64_t per_sample,
+                                 int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(per_sample % 4 == 0, "residual_fwd: per_sample %% 4 != 0");
+    int64_t total4 = (int64_t)B * per_sample / 4;
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_residual<T>, dim3(tcct_grid(total4, EW_BLOCK)), dim3(EW_BLOCK), 0,
+                                            (hipStream_t)stream, (const T*)x, (const T*)z, scale, (T*)y, per_sample / 4, total4));
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_scale_rows(const void* x, const float* scale, void* y, int B, int64_t per_sample, int dtype,
+                               tcct_stream_t stream) {
+    TCCT_CHECK(per_sample % 4 == 0, "scale_rows: per_sample %% 4 != 0");
+    int64_t total4 = (int64_t)B * per_sample / 4;
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_residual<T>, dim3(tcct_grid(total4, EW_BLOCK)), dim3(EW_BLOCK), 0,
+                                            (hipStream_t)stream, (const T*)nullptr, (const T*)x, scale, (T*)y, per_sample / 4, total4));
+    TCCT_LAUNCH_OK();
+}
+
+// ------------------------------------------------------------------------------------- concat / split
+template <typename T, bool SPLIT>
+__global__ void k_concat2(T* __restrict__ a, T* __restrict__ b, T* __restrict__ y, int64_t M, int Ca4, int Cb4) {
+    int C4 = Ca4 + Cb4;
+    int64_t total = M * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t m = i / C4;
+        int c = (int)(i % C4);
+        T* src = c < Ca4 ? a + (m * Ca4 + c) * 4 : b + (m * Cb4 + (c - Ca4)) * 4;
+        if (SPLIT) st4(src, ld4(y + i * 4)); else st4(y + i * 4, ld4(src));
+    }
+}
+extern "C" int tcct_concat2(const void* a, const void* b, void* y, int64_t M, int Ca, int Cb, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(Ca % 4 == 0 && Cb % 4 == 0, "concat2: channels must be multiples of 4");
+    int64_t total = M * (Ca + Cb) / 4;
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_concat2<T, false>), dim3(tcct_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0,
+                                            (hipStream_t)stream, (T*)a, (T*)b, (T*)y, M, Ca / 4, Cb / 4));
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_split2(const void* dy, void* da, void* db, int64_t M, int Ca, int Cb, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(Ca % 4 == 0 && Cb % 4 == 0, "split2: channels must be multiples of 4");
+    int64_t total = M * (Ca + Cb) / 4;
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_concat2<T, true>), dim3(tcct_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0,
+                                            (hipStream_t)stream, (T*)da, (T*)db, (T*)dy, M, Ca / 4, Cb / 4));
+    TCCT_LAUNCH_OK();
+}
+
+__global__ void k_axpy_f32(const float* __restrict__ x, float* __restrict__ y, int64_t n, float alpha) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] += alpha * x[i];
+}
+extern "C" int tcct_axpy_f32(const float* x, float* y, int64_t n, float alpha, tcct_stream_t stream) {
+    hipLaunchKernelGGL(k_axpy_f32, dim3(tcct_grid(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, y, n, alpha);
+    TCCT_LAUNCH_OK();
+}

@@ -1,0 +1,366 @@
+// Train-mode BatchNorm2d (two-stage per-channel reductions, fp64 block combine) and LayerNorm over C.
+// All tensors are [M, C] row-major (NHWC with M = N*H*W).  HBM-bound: every kernel streams x (and dy) once.
+#include "common.h"
+
+#define NB 256
+
+// ------------------------------------------------------------------ BN forward statistics: sum, sum of squares
+template <typename T, int VEC>
+__global__ void k_bn_stats(const T* __restrict__ x, int64_t M, int C, int pre_act, double* __restrict__ sums) {
+    __shared__ float sm[2 * NB * VEC];
+    const int CV = C / VEC;            // vectors per row
+    const int R = NB / CV;             // rows per block pass
+    const int t = threadIdx.x;
+    const bool active = t < R * CV;
+    const int cv = t % CV, r = t / CV;
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s[k] = q[k] = 0.f;
+    if (active) {
+        for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += (int64_t)gridDim.x * R) {
+            const T* p = x + m * C + cv * VEC;
+            if (VEC == 4) {
+                f4 a = ld4(p);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) { float u = act_fwd(pre_act, a.v[k]); s[k] += u; q[k] += u * u; }
+            } else {
+                float u = act_fwd(pre_act, ldf(p)); s[0] += u; q[0] += u * u;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { sm[t * VEC + k] = s[k]; sm[(NB + t) * VEC + k] = q[k]; }
+    __syncthreads();
+    if (t < C) {
+        // channel c = t lives at vector cv=t/VEC, lane k=t%VEC of rows r=0..R-1
+        double a = 0.0, b = 0.0;
+        int cvv = t / VEC, k = t % VEC;
+        for (int rr = 0; rr < R; ++rr) {
+            int tt = rr * CV + cvv;
+            a += (double)sm[tt * VEC + k];
+            b += (double)sm[(NB + tt) * VEC + k];
+        }
+        atomicAdd(&sums[t], a);
+        atomicAdd(&sums[C + t], b);
+    }
+}
+
+extern "C" int tcct_bn_stats(const void* x, int64_t M, int C, int pre_act, double* sums, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(C >= 1 && C <= NB, "bn_stats: C=%d unsupported (1..%d)", C, NB);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { tcct_set_error("bn_stats: memset failed"); return -2; }
+    int vec = (C % 4 == 0) ? 4 : 1;
+    int R = NB / (C / vec);
+    int grid = tcct_grid(M, R, 256 * 8);
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_stats<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, M, C, pre_act, sums)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_stats<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, M, C, pre_act, sums)); }
+    TCCT_LAUNCH_OK();
+}
+
+__global__ void k_bn_finalize(const double* __restrict__ sums, int64_t M, int C, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+                              float* running_var, int64_t* nbt, float* __restrict__ mean_rstd, float* __restrict__ ab) {
+    int c = threadIdx.x;
+    if (c < C) {
+        double mean = sums[c] / (double)M;
+        double var = sums[C + c] / (double)M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        mean_rstd[c] = (float)mean;
+        mean_rstd[C + c] = rstd;
+        float a = gamma[c] * rstd;
+        ab[c] = a;
+        ab[C + c] = beta[c] - (float)mean * a;
+        if (running_mean) {
+            double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+    if (c == 0 && nbt) *nbt += 1;
+}
+extern "C" int tcct_bn_finalize(const double* sums, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                                float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                float* mean_rstd, float* ab, tcct_stream_t stream) {
+    TCCT_CHECK(C >= 1 && C <= NB, "bn_finalize: C=%d unsupported", C);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(NB), 0, (hipStream_t)stream, sums, M, C, gamma, beta, eps, momentum,
+                       running_mean, running_var, num_batches_tracked, mean_rstd, ab);
+    TCCT_LAUNCH_OK();
+}
+
+__global__ void k_bn_eval_ab(int C, const float* gamma, const float* beta, float eps, const float* rm, const float* rv,
+                             float* mean_rstd, float* ab) {
+    int c = threadIdx.x;
+    if (c < C) {
+        float rstd = 1.f / sqrtf(rv[c] + eps);
+        mean_rstd[c] = rm[c]; mean_rstd[C + c] = rstd;
+        float a = gamma[c] * rstd;
+        ab[c] = a; ab[C + c] = beta[c] - rm[c] * a;
+    }
+}
+extern "C" int tcct_bn_eval_ab(int C, const float* gamma, const float* beta, float eps, const float* running_mean,
+                               const float* running_var, float* mean_rstd, float* ab, tcct_stream_t stream) {
+    TCCT_CHECK(C >= 1 && C <= NB, "bn_eval_ab: C=%d unsupported", C);
+    hipLaunchKernelGGL(k_bn_eval_ab, dim3(1), dim3(NB), 0, (hipStream_t)stream, C, gamma, beta, eps, running_mean,
+                       running_var, mean_rstd, ab);
+    TCCT_LAUNCH_OK();
+}
+
+// ------------------------------------------------------------------ BN apply: y = post(a*pre(x)+b)
+template <typename T, int VEC>
+__global__ void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t total, int C, const float* __restrict__ ab,
+                           int pre_act, int post_act) {
+    const int CV = C / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % CV) * VEC;
+        if (VEC == 4) {
+            f4 v = ld4(x + i * 4), r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r.v[k] = act_fwd(post_act, ab[c + k] * act_fwd(pre_act, v.v[k]) + ab[C + c + k]);
+            st4(y + i * 4, r);
+        } else {
+            stf(y + i, act_fwd(post_act, ab[c] * act_fwd(pre_act, ldf(x + i)) + ab[C + c]));
+        }
+    }
+}
+extern "C" int tcct_bn_apply(const void* x, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act,
+                             int dtype, tcct_stream_t stream) {
+    int vec = (C % 4 == 0) ? 4 : 1;
+    int64_t total = M * C / vec;
+    hipStream_t st = (hipStream_t)stream;
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 4>), dim3(tcct_grid(total, NB)), dim3(NB), 0, st, (const T*)x, (T*)y, total, C, ab, pre_act, post_act)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 1>), dim3(tcct_grid(total, NB)), dim3(NB), 0, st, (const T*)x, (T*)y, total, C, ab, pre_act, post_act)); }
+    TCCT_LAUNCH_OK();
+}
+
+// ------------------------------------------------------------------ BN backward: reductions then apply
+template <typename T, int VEC>
+__global__ void k_bn_bwd_reduce(const T* __restrict__ x, const T* __restrict__ dy, int64_t M, int C,
+                                const float* __restrict__ mean_rstd, const float* __restrict__ ab, int pre_act,
+                                int post_act, double* __restrict__ sums) {
+    __shared__ float sm[2 * NB * VEC];
+    const int CV = C / VEC;
+    const int R = NB / CV;
+    const int t = threadIdx.x;
+    const bool active = t < R * CV;
+    const int cv = t % CV, r = t / CV;
+    float s[VEC], q[VEC], mu[VEC], rs[VEC], a_[VEC], b_[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        s[k] = q[k] = 0.f;
+        int c = active ? cv * VEC + k : 0;
+        mu[k] = mean_rstd[c]; rs[k] = mean_rstd[C + c]; a_[k] = ab[c]; b_[k] = ab[C + c];
+    }
+    if (active) {
+        for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += (int64_t)gridDim.x * R) {
+            int64_t off = m * C + cv * VEC;
+            float xv[VEC], gv[VEC];
+            if (VEC == 4) {
+                f4 a = ld4(x + off), g = ld4(dy + off);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) { xv[k] = a.v[k]; gv[k] = g.v[k]; }
+            } else { xv[0] = ldf(x + off); gv[0] = ldf(dy + off); }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float u = act_fwd(pre_act, xv[k]);
+                float dz = gv[k] * act_grad(post_act, a_[k] * u + b_[k]);
+                s[k] += dz; q[k] += dz * (u - mu[k]) * rs[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { sm[t * VEC + k] = s[k]; sm[(NB + t) * VEC + k] = q[k]; }
+    __syncthreads();
+    if (t < C) {
+        double a = 0.0, b = 0.0;
+        int cvv = t / VEC, k = t % VEC;
+        for (int rr = 0; rr < R; ++rr) {
+            int tt = rr * CV + cvv;
+            a += (double)sm[tt * VEC + k];
+            b += (double)sm[(NB + tt) * VEC + k];
+        }
+        atomicAdd(&sums[t], a);
+        atomicAdd(&sums[C + t], b);
+    }
+}
+extern "C" int tcct_bn_bwd_reduce(const void* x, const void* dy, int64_t M, int C, const float* mean_rstd, const float* ab,
+                                  int pre_act, int post_act, double* sums, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(C >= 1 && C <= NB, "bn_bwd_reduce: C=%d unsupported", C);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { tcct_set_error("bn_bwd_reduce: memset failed"); return -2; }
+    int vec = (C % 4 == 0) ? 4 : 1;
+    int R = NB / (C / vec);
+    int grid = tcct_grid(M, R, 256 * 8);
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (const T*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (const T*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
+    TCCT_LAUNCH_OK();
+}
+
+template <typename T, int VEC>
+__global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t total,
+                               int64_t M, int C, const float* __restrict__ mean_rstd, const float* __restrict__ ab,
+                               const double* __restrict__ sums, int pre_act, int post_act, float* __restrict__ dgamma,
+                               float* __restrict__ dbeta) {
+    const int CV = C / VEC;
+    const float invM = 1.f / (float)M;
+    if (blockIdx.x == 0 && threadIdx.x < C) {
+        dbeta[threadIdx.x] = (float)sums[threadIdx.x];
+        dgamma[threadIdx.x] = (float)sums[C + threadIdx.x];
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int c0 = (int)(i % CV) * VEC;
+        float xv[VEC], gv[VEC], r[VEC];
+        if (VEC == 4) {
+            f4 a = ld4(x + i * 4), g = ld4(dy + i * 4);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { xv[k] = a.v[k]; gv[k] = g.v[k]; }
+        } else { xv[0] = ldf(x + i); gv[0] = ldf(dy + i); }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            int c = c0 + k;
+            float a = ab[c], b = ab[C + c], mu = mean_rstd[c], rs = mean_rstd[C + c];
+            float u = act_fwd(pre_act, xv[k]);
+            float dz = gv[k] * act_grad(post_act, a * u + b);
+            float xh = (u - mu) * rs;
+            float du = a * (dz - (float)sums[c] * invM - xh * (float)sums[C + c] * invM);
+            r[k] = du * act_grad(pre_act, xv[k]);
+        }
+        if (VEC == 4) { f4 o; o.v[0] = r[0]; o.v[1] = r[1]; o.v[2] = r[2]; o.v[3] = r[3]; st4(dx + i * 4, o); }
+        else stf(dx + i, r[0]);
+    }
+}
+extern "C" int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_t M, int C, const float* mean_rstd,
+                                 const float* ab, const float* gamma, const double* sums, int pre_act, int post_act,
+                                 float* dgamma, float* dbeta, int dtype, tcct_stream_t stream) {
+    (void)gamma;
+    int vec = (C % 4 == 0) ? 4 : 1;
+    int64_t total = M * C / vec;
+    hipStream_t st = (hipStream_t)stream;
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<T, 4>), dim3(tcct_grid(total, NB)), dim3(NB), 0, st, (const T*)x, (const T*)dy, (T*)dx, total, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<T, 1>), dim3(tcct_grid(total, NB)), dim3(NB), 0, st, (const T*)x, (const T*)dy, (T*)dx, total, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
+    TCCT_LAUNCH_OK();
+}
+
+// ------------------------------------------------------------------ LayerNorm over C (<= 192), 16 lanes per row
+#define LN_MAXCH 3   // vec4 chunks per lane: C <= 16*4*3 = 192
+template <typename T>
+__global__ void k_ln_fwd(const T* __restrict__ x, T* __restrict__ y, int64_t M, int C, const float* __restrict__ gamma,
+                         const float* __restrict__ beta, float eps, float* __restrict__ mean_rstd) {
+    const int C4 = C >> 2;
+    const int lane = threadIdx.x & 15;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (int64_t m = grp; m < M; m += ngrp) {     // all 16 lanes of a group share m: no divergence inside shuffles
+        f4 v[LN_MAXCH];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXCH; ++j) {
+            int ch = lane + 16 * j;
+            if (ch < C4) { v[j] = ld4(x + m * C + ch * 4); s += v[j].v[0] + v[j].v[1] + v[j].v[2] + v[j].v[3]; }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        float mean = s / (float)C, q = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXCH; ++j) {
+            int ch = lane + 16 * j;
+            if (ch < C4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { float d = v[j].v[k] - mean; q += d * d; }
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        float rstd = rsqrtf(q / (float)C + eps);
+        if (lane == 0) { mean_rstd[2 * m] = mean; mean_rstd[2 * m + 1] = rstd; }
+#pragma unroll
+        for (int j = 0; j < LN_MAXCH; ++j) {
+            int ch = lane + 16 * j;
+            if (ch < C4) {
+                f4 r;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r.v[k] = (v[j].v[k] - mean) * rstd * gamma[ch * 4 + k] + beta[ch * 4 + k];
+                st4(y + m * C + ch * 4, r);
+            }
+        }
+    }
+}
+extern "C" int tcct_layernorm_fwd(const void* x, void* y, int64_t M, int C, const float* gamma, const float* beta,
+                                  float eps, float* mean_rstd, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(C % 4 == 0 && C <= 64 * LN_MAXCH, "layernorm_fwd: C=%d unsupported", C);
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_ln_fwd<T>, dim3(tcct_grid(M * 16, NB)), dim3(NB), 0, (hipStream_t)stream,
+                                            (const T*)x, (T*)y, M, C, gamma, beta, eps, mean_rstd));
+    TCCT_LAUNCH_OK();
+}
+
+template <typename T>
+__global__ void k_ln_bwd(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t M, int C,
+                         const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float sm[2 * 192];
+    const int C4 = C >> 2;
+    const int lane = threadIdx.x & 15;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    f4 ag[LN_MAXCH], abt[LN_MAXCH];
+#pragma unroll
+    for (int j = 0; j < LN_MAXCH; ++j) { ag[j] = f4zero(); abt[j] = f4zero(); }
+    for (int i = threadIdx.x; i < 2 * 192; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    for (int64_t m = grp; m < M; m += ngrp) {
+        float mean = mean_rstd[2 * m], rstd = mean_rstd[2 * m + 1];
+        f4 xh[LN_MAXCH], g[LN_MAXCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXCH; ++j) {
+            int ch = lane + 16 * j;
+            if (ch < C4) {
+                f4 xv = ld4(x + m * C + ch * 4), d = ld4(dy + m * C + ch * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float h = (xv.v[k] - mean) * rstd;
+                    xh[j].v[k] = h;
+                    ag[j].v[k] += d.v[k] * h;
+                    abt[j].v[k] += d.v[k];
+                    float dg = d.v[k] * gamma[ch * 4 + k];
+                    g[j].v[k] = dg;
+                    s1 += dg; s2 += dg * h;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s1 /= (float)C; s2 /= (float)C;
+#pragma unroll
+        for (int j = 0; j < LN_MAXCH; ++j) {
+            int ch = lane + 16 * j;
+            if (ch < C4) {
+                f4 r;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r.v[k] = rstd * (g[j].v[k] - s1 - xh[j].v[k] * s2);
+                st4(dx + m * C + ch * 4, r);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LN_MAXCH; ++j) {
+        int ch = lane + 16 * j;
+        if (ch < C4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { atomicAdd(&sm[ch * 4 + k], ag[j].v[k]); atomicAdd(&sm[192 + ch * 4 + k], abt[j].v[k]); }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { atomicAdd(&dgamma[c], sm[c]); atomicAdd(&dbeta[c], sm[192 + c]); }
+}
+extern "C" int tcct_layernorm_bwd(const void* x, const void* dy, void* dx, int64_t M, int C, const float* gamma,
+                                  const float* mean_rstd, float* dgamma, float* dbeta, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(C % 4 == 0 && C <= 64 * LN_MAXCH, "layernorm_bwd: C=%d unsupported", C);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess) {
+        tcct_set_error("layernorm_bwd: memset failed"); return -2;
+    }
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_ln_bwd<T>, dim3(tcct_grid(M * 16, NB, 1024)), dim3(NB), 0, st, (const T*)x,
+                                            (const T*)dy, (T*)dx, M, C, gamma, mean_rstd, dgamma, dbeta));
+    TCCT_LAUNCH_OK();
+}

@@ -1,0 +1,191 @@
+"""HIP kernel parity (through the C-ABI) against plain PyTorch CPU fp32 references of the same op."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return dict(rtol=2e-4, atol=2e-4) if dt == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+
+
+def nhwc(x, dt):   # NCHW cpu -> NHWC cuda
+    return x.permute(0, 2, 3, 1).contiguous().to('cuda', dt)
+
+
+def nchw(y):       # NHWC cuda -> NCHW cpu fp32
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(*shape, seed=0, dt=torch.float32):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    x = torch.randn(*shape, generator=g)
+    return x.to(dt).float() if dt != torch.float32 else x   # values representable in dt
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('cfg', [
+    # Cin_w, Cout, KH, KW, stride, ph, pw, H, W
+    (32, 32, 3, 3, 1, 1, 1, 17, 23), (32, 32, 1, 13, 1, 0, 6, 9, 40), (32, 32, 13, 1, 1, 6, 0, 40, 9),
+    (3, 32, 3, 3, 1, 1, 1, 16, 16), (3, 32, 3, 3, 2, 1, 1, 16, 20), (32, 64, 3, 3, 1, 1, 1, 8, 12),
+    (128, 96, 1, 1, 1, 0, 0, 6, 10), (32, 5, 1, 1, 1, 0, 0, 12, 8), (320, 160, 1, 1, 1, 0, 0, 4, 6),
+    (160, 32, 1, 1, 1, 0, 0, 4, 6)])
+def test_conv2d(dt, cfg):
+    from tcct_amd import ops
+    Cw, Co, KH, KW, s, ph, pw, H, W = cfg
+    N = 2
+    x = rnd(N, Cw, H, W, dt=dt).requires_grad_(True)
+    w = (rnd(Co, Cw, KH, KW, seed=1) / (Cw * KH * KW) ** 0.5).requires_grad_(True)
+    b = rnd(Co, seed=2).requires_grad_(True)
+    y = F.conv2d(x, w, b, s, (ph, pw))
+    gy = rnd(*y.shape, seed=3, dt=dt)
+    y.backward(gy)
+    xp = x.detach()
+    if Cw % 4:
+        xp = F.pad(xp, (0, 0, 0, 0, 0, 4 - Cw % 4))
+    xd = nhwc(xp, dt).requires_grad_(Cw % 4 == 0)
+    wd = w.detach().cuda().requires_grad_(True)
+    bd = b.detach().cuda().requires_grad_(True)
+    yd = ops.conv2d(xd, wd, bd, stride=s, pad=(ph, pw))
+    assert yd.shape == (N, y.shape[2], y.shape[3], Co)
+    torch.testing.assert_close(nchw(yd), y.detach(), **tol(dt))
+    yd.backward(nhwc(gy, dt))
+    t = tol(dt)
+    scale = max(1.0, w.grad.abs().max().item())
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=t['rtol'], atol=t['atol'] * scale)
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, b.grad.abs().max().item()))
+    if Cw % 4 == 0:
+        torch.testing.assert_close(nchw(xd.grad), x.grad, **t)
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('cfg', [(64, 1, True, False), (96, 2, False, False), (64, 1, True, True), (4, 1, True, False),
+                                 (1, 1, True, False), (160, 2, False, False)])
+def test_dwconv(dt, cfg):
+    from tcct_amd import ops
+    C, s, has_b, addin = cfg
+    N, H, W = 2, 10, 14
+    x = rnd(N, C, H, W, dt=dt).requires_grad_(True)
+    w = rnd(C, 1, 3, 3, seed=1).requires_grad_(True)
+    b = rnd(C, seed=2).requires_grad_(True) if has_b else None
+    y = F.conv2d(x, w, b, s, 1, 1, C)
+    if addin:
+        y = y + x
+    gy = rnd(*y.shape, seed=3, dt=dt)
+    y.backward(gy)
+    xd = nhwc(x.detach(), dt).requires_grad_(True)
+    wd = w.detach().cuda().requires_grad_(True)
+    bd = b.detach().cuda().requires_grad_(True) if has_b else None
+    yd = ops.dwconv3x3(xd, wd, bd, stride=s, add_input=addin)
+    torch.testing.assert_close(nchw(yd), y.detach(), **tol(dt))
+    yd.backward(nhwc(gy, dt))
+    t = tol(dt)
+    torch.testing.assert_close(nchw(xd.grad), x.grad, **t)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, w.grad.abs().max().item()))
+    if has_b:
+        torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, b.grad.abs().max().item()))
+
+
+ACTS = {'none': lambda v: v, 'lrelu': lambda v: F.leaky_relu(v, 0.01), 'hswish': F.hardswish}
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('cfg', [(32, 'lrelu', 'none', 1e-5), (64, 'none', 'hswish', 1e-5), (32, 'none', 'lrelu', 1e-5),
+                                 (96, 'none', 'none', 1e-5), (1, 'none', 'none', 1.0), (160, 'none', 'hswish', 1e-5)])
+def test_batchnorm_train(dt, cfg):
+    from tcct_amd import ops
+    C, pre, post, eps = cfg
+    N, H, W = 2, 9, 13
+    x = (rnd(N, C, H, W, dt=dt) * 1.5 + 0.3).to(dt).float().requires_grad_(True)
+    g = (1 + 0.1 * rnd(C, seed=1)).requires_grad_(True)
+    b = (0.1 * rnd(C, seed=2)).requires_grad_(True)
+    rm, rv = 0.05 * rnd(C, seed=3), 1 + 0.2 * rnd(C, seed=4).abs()
+    rm_d, rv_d, nbt = rm.clone().cuda(), rv.clone().cuda(), torch.zeros((), dtype=torch.int64, device='cuda')
+    y = ACTS[post](F.batch_norm(ACTS[pre](x), rm, rv, g, b, True, 0.1, eps))
+    gy = rnd(*y.shape, seed=5, dt=dt)
+    y.backward(gy)
+    xd = nhwc(x.detach(), dt).requires_grad_(True)
+    gd = g.detach().cuda().requires_grad_(True)
+    bd = b.detach().cuda().requires_grad_(True)
+    yd = ops.batchnorm(xd, gd, bd, rm_d, rv_d, nbt, eps=eps, pre_act=pre, post_act=post, training=True)
+    t = tol(dt)
+    torch.testing.assert_close(nchw(yd), y.detach(), **t)
+    torch.testing.assert_close(rm_d.cpu(), rm, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rv_d.cpu(), rv, rtol=1e-4, atol=1e-5)
+    assert nbt.item() == 1
+    yd.backward(nhwc(gy, dt))
+    torch.testing.assert_close(nchw(xd.grad), x.grad, **t)
+    torch.testing.assert_close(gd.grad.cpu(), g.grad, rtol=t['rtol'], atol=t['atol'] * 10)
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=t['rtol'], atol=t['atol'] * 10)
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('C', [64, 96, 128, 160])
+def test_layernorm(dt, C):
+    from tcct_amd import ops
+    B, Nn = 2, 37
+    x = rnd(B, Nn, C, dt=dt).requires_grad_(True)
+    g = (1 + 0.1 * rnd(C, seed=1)).requires_grad_(True)
+    b = (0.1 * rnd(C, seed=2)).requires_grad_(True)
+    y = F.layer_norm(x, (C,), g, b, 1e-6)
+    gy = rnd(*y.shape, seed=3, dt=dt)
+    y.backward(gy)
+    xd = x.detach().to('cuda', dt).requires_grad_(True)
+    gd, bd = g.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    yd = ops.layernorm(xd, gd, bd, 1e-6)
+    t = tol(dt)
+    torch.testing.assert_close(yd.float().cpu(), y.detach(), **t)
+    yd.backward(gy.to('cuda', dt))
+    torch.testing.assert_close(xd.grad.float().cpu(), x.grad, **t)
+    torch.testing.assert_close(gd.grad.cpu(), g.grad, rtol=t['rtol'], atol=t['atol'] * 10)
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=t['rtol'], atol=t['atol'] * 10)
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_elementwise(dt):
+    from tcct_amd import ops
+    a = rnd(2, 5, 7, 32, dt=dt).requires_grad_(True)
+    b = rnd(2, 5, 7, 32, seed=1, dt=dt).requires_grad_(True)
+    y = F.gelu(a + b)
+    gy = rnd(*y.shape, seed=2, dt=dt)
+    y.backward(gy)
+    ad, bd = a.detach().to('cuda', dt).requires_grad_(True), b.detach().to('cuda', dt).requires_grad_(True)
+    yd = ops.add_act(ad, bd, 'gelu')
+    t = tol(dt)
+    torch.testing.assert_close(yd.float().cpu(), y.detach(), **t)
+    yd.backward(gy.to('cuda', dt))
+    torch.testing.assert_close(ad.grad.float().cpu(), a.grad, **t)
+    torch.testing.assert_close(bd.grad.float().cpu(), b.grad, **t)
+    for kind, fn in (('gelu', F.gelu), ('hswish', F.hardswish), ('lrelu', lambda v: F.leaky_relu(v, 0.01)),
+                     ('sigmoid', torch.sigmoid), ('abs', torch.abs)):
+        a2 = a.detach().clone().requires_grad_(True)
+        y = fn(a2)
+        y.backward(gy)
+        ad = a.detach().to('cuda', dt).requires_grad_(True)
+        yd = ops.act(ad, kind)
+        torch.testing.assert_close(yd.float().cpu(), y.detach(), **t)
+        yd.backward(gy.to('cuda', dt))
+        torch.testing.assert_close(ad.grad.float().cpu(), a2.grad, **t)
+    # per-sample scaled residual + concat
+    s = torch.tensor([0.0, 1.0 / 0.9])
+    a3, b3 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    y = a3 + s.view(2, 1, 1, 1) * b3
+    y.backward(gy)
+    ad, bd = a.detach().to('cuda', dt).requires_grad_(True), b.detach().to('cuda', dt).requires_grad_(True)
+    yd = ops.residual(ad, bd, s.cuda())
+    torch.testing.assert_close(yd.float().cpu(), y.detach(), **t)
+    yd.backward(gy.to('cuda', dt))
+    torch.testing.assert_close(ad.grad.float().cpu(), a3.grad, **t)
+    torch.testing.assert_close(bd.grad.float().cpu(), b3.grad, **t)
+    c = rnd(2, 5, 7, 64, seed=4, dt=dt)
+    cd = c.to('cuda', dt).requires_grad_(True)
+    ad = a.detach().to('cuda', dt).requires_grad_(True)
+    yd = ops.concat2(ad, cd)
+    torch.testing.assert_close(yd.float().cpu(), torch.cat([a.detach(), c], -1), **t)
+    g2 = rnd(2, 5, 7, 96, seed=5, dt=dt)
+    yd.backward(g2.to('cuda', dt))
+    torch.testing.assert_close(ad.grad.float().cpu(), g2[..., :32], **t)
+    torch.testing.assert_close(cd.grad.float().cpu(), g2[..., 32:], **t)
