@@ -110,6 +110,80 @@ int tcct_dwconv3x3_dgrad(const void* dy, const float* w, void* dx, int N, int H,
 int tcct_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C,
                          int stride, int dtype, tcct_stream_t stream);
 
+/* ---- MetaPool on tokens [B,N,C] (nets/tcct.py:405-415,463): AvgPool2d(3,1,1,count_include_pad=False)(x) - x
+ * taken over the (token, channel) plane, exactly as torch treats the 3-D tensor --------------------------- */
+int tcct_metapool_fwd(const void* x, void* y, int B, int64_t N, int C, int dtype, tcct_stream_t stream);
+int tcct_metapool_bwd(const void* dy, void* dx, int B, int64_t N, int C, int dtype, tcct_stream_t stream);
+/* ---- nn.MaxPool2d(2) (nets/tcct.py:867,883); even H, W ---------------------------------------------------- */
+int tcct_maxpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, tcct_stream_t stream);
+int tcct_maxpool2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int dtype, tcct_stream_t stream);
+/* ---- bilinear resize: nn.Upsample(x2, align_corners=True) (tcct.py:890) and F.interpolate(size, align_corners=False)
+ * (tcct.py:941,1042-1044).  bwd: dy [N,Ho,Wo,C] -> dx [N,H,W,C], gather form (no atomics) ------------------ */
+int tcct_bilinear_fwd(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int align_corners, int dtype,
+                      tcct_stream_t stream);
+int tcct_bilinear_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int align_corners, int dtype,
+                      tcct_stream_t stream);
+/* ---- F.normalize(dim=channel, p=2, eps) (nets/tcct.py:940) ------------------------------------------------ */
+int tcct_l2norm_fwd(const void* x, void* y, int64_t M, int C, float eps, int dtype, tcct_stream_t stream);
+int tcct_l2norm_bwd(const void* x, const void* dy, void* dx, int64_t M, int C, float eps, int dtype, tcct_stream_t stream);
+
+/* ---- MultiLoss(DiceLoss) (kite/losses/loss.py:83-99,15-32): softmax over C fused with the batch-global sums
+ * sums[3][C] = {sum p*g, sum p, sum g}; loss = sum_c 1 - (1+2I)/(1+P+G).  labels: class index uint8 [M] ----- */
+int tcct_softmax_dice_fwd(const void* logits, const uint8_t* labels, int64_t M, int C, double* sums, float* loss,
+                          int dtype, tcct_stream_t stream);
+/* dlogits = grad_scale * (*grad_out) * dLoss/dlogits  (grad_out: device scalar, NULL -> 1) */
+int tcct_softmax_dice_bwd(const void* logits, const uint8_t* labels, int64_t M, int C, const double* sums,
+                          const float* grad_out, float grad_scale, void* dlogits, int dtype, tcct_stream_t stream);
+/* softmax prob of the labelled class (regular_udh sort key, nets/reg.py:89) and/or argmax class (KiteSeg.predict,
+ * kite/loop_seg.py:32); either output may be NULL */
+int tcct_softmax_pick(const void* logits, const uint8_t* labels, int64_t M, int C, float* prob_lab, uint8_t* argmax,
+                      int dtype, tcct_stream_t stream);
+/* out[N][C][3] = per-sample {|pred&lab|, |pred|, |lab|} per class (MDiceLoss/MIouLoss.score, kite/losses/miou.py:28-91) */
+int tcct_confusion_counts(const uint8_t* pred, const uint8_t* labels, int N, int64_t HW, int C, float* out,
+                          tcct_stream_t stream);
+
+/* ---- boundary-regression loss pieces (RegNet.regular_reg, nets/reg.py:109-156); this pipeline is fp32 -------- */
+int tcct_slice_channels_fwd(const void* x, float* y, int64_t M, int C, int start, int n, int dtype, tcct_stream_t stream);
+int tcct_slice_channels_bwd(const float* dy, void* dx, int64_t M, int C, int start, int n, int dtype, tcct_stream_t stream);
+/* onehot [M,n] fp32 of classes start..start+n-1 (NULL to skip) and edge[N,H,W] = clamp1(sum_c |onehot[h]-onehot[h-1]|) */
+int tcct_label_planes(const uint8_t* labels, float* onehot, float* edge, int N, int H, int W, int start, int n,
+                      tcct_stream_t stream);
+/* sampling_softmax summed over channels (reg.py:118-128): x, eps fp32 [N,H,W,CH]; out [N,H,W]; stats [N,W,CH,3] */
+int tcct_gumbel_colsoftmax_fwd(const float* x, const float* eps, float* out, float* stats, int N, int H, int W, int CH,
+                               tcct_stream_t stream);
+int tcct_gumbel_colsoftmax_bwd(const float* x, const float* eps, const float* stats, const float* dout, float* dx, int N,
+                               int H, int W, int CH, tcct_stream_t stream);
+/* softmax over H of fp32 [N,H,W] (reg.py:155) */
+int tcct_colsoftmax_fwd(const float* x, float* y, int N, int H, int W, tcct_stream_t stream);
+int tcct_colsoftmax_bwd(const float* y, const float* dy, float* dx, int N, int H, int W, tcct_stream_t stream);
+/* column soft-argmax edge[n,w] = sum_h x[n,h,w]*wts[h] (reg.py:146-150) */
+int tcct_colwsum_fwd(const float* x, const float* wts, float* out, int N, int H, int W, tcct_stream_t stream);
+int tcct_colwsum_bwd(const float* dout, const float* wts, float* dx, int N, int H, int W, tcct_stream_t stream);
+/* nn.MSELoss (reg.py:108,154-155): out = mean((a-b)^2); bwd da = 2/n*(a-b)*g, db = -da (either may be NULL) */
+int tcct_mse_fwd(const float* a, const float* b, int64_t n, double* acc, float* out, tcct_stream_t stream);
+int tcct_mse_bwd(const float* a, const float* b, int64_t n, const float* grad_out, float grad_scale, float* da, float* db,
+                 tcct_stream_t stream);
+
+/* ---- feature-polarization loss (RegNet.regular_udh nets/reg.py:86-105; points_selection_bins nets/fcs.py:25-50;
+ * cosinesim fcs.py:63-80; FeatConPolar.choice nets/fcp.py:72-75) ------------------------------------------- */
+int64_t tcct_fpl_sort_workspace_bytes(int64_t M);
+int tcct_fpl_sort(const uint8_t* labels, const float* prob, int64_t M, uint64_t* keys_in, uint32_t* vals_in,
+                  uint64_t* keys_out, uint32_t* vals_out, uint32_t* counts /*[8]*/, void* workspace,
+                  int64_t workspace_bytes, tcct_stream_t stream);
+/* feat [M,32]; pro_sum/pro/dpro_over_n fp32 [C,32,32]; binmap uint8 [M] (bin 0..31, 255 = not selected) */
+int tcct_fpl_forward(const void* feat, const uint64_t* keys_sorted, const uint32_t* vals_sorted, const uint32_t* counts,
+                     int64_t M, int C, const float* buf_grad, float* pro_sum, float* pro, float* loss,
+                     float* dpro_over_n, uint8_t* binmap, int dtype, tcct_stream_t stream);
+int tcct_fpl_backward(const uint8_t* labels, const uint8_t* binmap, const float* dpro_over_n, const float* grad_out,
+                      float grad_scale, int64_t M, void* dfeat, int dtype, tcct_stream_t stream);
+
+/* ---- clip_grad_norm_(12) + AdamW on flat fp32 buffers (kite/loop_seg.py:128-130, kite/loopback.py:127) ------ */
+int tcct_grad_sumsq(const float* g, int64_t n, double* acc, tcct_stream_t stream);
+/* grad_mul pre-scales the raw gradient (1/world_size after a sum all-reduce); total_norm_out nullable */
+int tcct_clip_adamw(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm,
+                    float grad_mul, float lr, double beta1, double beta2, float eps, float weight_decay, int step,
+                    float* total_norm_out, tcct_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

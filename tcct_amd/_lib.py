@@ -23,7 +23,7 @@ def parse_header(path=HEADER):
     src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
     src = re.sub(r'//[^\n]*', ' ', src)
     protos = {}
-    for m in re.finditer(r'(const\s+char\s*\*|int)\s+(tcct_\w+)\s*\(([^)]*)\)\s*;', src):
+    for m in re.finditer(r'(const\s+char\s*\*|int64_t|int)\s+(tcct_\w+)\s*\(([^)]*)\)\s*;', src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         sig = []
         if args and args != 'void':
@@ -34,7 +34,7 @@ def parse_header(path=HEADER):
                 else:
                     ty, nm = a.rsplit(' ', 1)
                     sig.append((_CT[ty.replace('const ', '').strip()], nm))
-        protos[name] = (ctypes.c_char_p if 'char' in ret else ctypes.c_int, sig)
+        protos[name] = (ctypes.c_char_p if 'char' in ret else (ctypes.c_int64 if 'int64' in ret else ctypes.c_int), sig)
     return protos
 
 
@@ -71,6 +71,7 @@ class _Lib:
         dll = self.load()
         fn = getattr(dll, full)
         sig = self.protos[full][1]
+        res_is_value = self.protos[full][0] is not ctypes.c_int
 
         def call(*args):
             if len(args) == len(sig) - 1 and sig and sig[-1][1] == 'stream':
@@ -89,6 +90,8 @@ class _Lib:
                 else:
                     conv.append(a)
             rc = fn(*conv)
+            if res_is_value:
+                return rc
             if rc != 0:
                 raise TcctError(f'{full} failed (rc={rc}): {dll.tcct_last_error().decode()}')
         call.__name__ = full

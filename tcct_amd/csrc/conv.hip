@@ -15,10 +15,12 @@ template <typename Tin, typename Tout>
 __global__ void __launch_bounds__(CB)
 k_conv_fwd(const Tin* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, Tout* __restrict__ y,
            int N, int H, int W, int Cin, int Cin_w, int Cout, int KH, int KW, int stride, int padh, int padw, int Ho,
-           int Wo, int transposed, int KC) {
+           int Wo, int transposed, int KC, int CoutC) {
+    // CoutC: output channels handled per block (multiple of 8, <= 256); blockIdx.y selects the channel chunk
     __shared__ __attribute__((aligned(16))) float wl[WLDS_FLOATS];
-    const int CG = (Cout + COT - 1) / COT;
-    const int CoutP = CG * COT;
+    const int CG = CoutC / COT;
+    const int CoutP = CoutC;
+    const int co_base = blockIdx.y * CoutC;
     const int PIXB = CB / CG;
     const int t = threadIdx.x;
     const int cg = t % CG, pl = t / CG;
@@ -52,7 +54,7 @@ k_conv_fwd(const Tin* __restrict__ x, const float* __restrict__ w, const float* 
         const int kc = min(KC, Ktot - k0);
         __syncthreads();
         for (int i = t; i < kc * CoutP; i += CB) {
-            int kk = i / CoutP, co = i % CoutP;
+            int kk = i / CoutP, co = co_base + i % CoutP;
             int k = k0 + kk;
             int tap = k / Cin, ci = k % Cin;
             int dy = tap / KW, dx = tap % KW;
@@ -88,7 +90,7 @@ k_conv_fwd(const Tin* __restrict__ x, const float* __restrict__ w, const float* 
             }
         }
     }
-    const int co0 = cg * COT;
+    const int co0 = co_base + cg * COT;
     float bv[COT];
 #pragma unroll
     for (int c = 0; c < COT; ++c) bv[c] = (bias && co0 + c < Cout) ? bias[co0 + c] : 0.f;
@@ -152,19 +154,21 @@ static int conv_fwd_launch(const void* x, const float* w, const float* bias, voi
         if (e0 != hipSuccess) { tcct_set_error("%s: launch failed: %s", who, hipGetErrorString(e0)); return -2; }
         return 0;
     }
-    if (!(Cin % 4 == 0 && Cin_w <= Cin && Cin_w > 0 && Cout > 0 && Cout <= 256 && stride >= 1)) {
+    if (!(Cin % 4 == 0 && Cin_w <= Cin && Cin_w > 0 && Cout > 0 && Cout <= 1024 && stride >= 1)) {
         tcct_set_error("%s: unsupported shape Cin=%d Cin_w=%d Cout=%d stride=%d", who, Cin, Cin_w, Cout, stride);
         return -1;
     }
     int Ho = (H + 2 * padh - KH) / stride + 1, Wo = (W + 2 * padw - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0 || N <= 0) { tcct_set_error("%s: empty output", who); return -1; }
-    int CG = (Cout + COT - 1) / COT, CoutP = CG * COT, PIXB = CB / CG;
-    int KC = (WLDS_FLOATS / CoutP) & ~3;
+    int nchunk = (Cout + 255) / 256;
+    int CoutC = (((Cout + nchunk - 1) / nchunk) + COT - 1) / COT * COT;
+    int CG = CoutC / COT, PIXB = CB / CG;
+    int KC = (WLDS_FLOATS / CoutC) & ~3;
     int64_t NP = (int64_t)N * Ho * Wo;
     int64_t tiles = (NP + PIXB * PPT - 1) / (PIXB * PPT);
     if (tiles > 0x7fffffffLL) { tcct_set_error("%s: grid too large", who); return -1; }
-    dim3 grid((unsigned)tiles), block(CB);
-#define LAUNCH(TI, TO) hipLaunchKernelGGL((k_conv_fwd<TI, TO>), grid, block, 0, st, (const TI*)x, w, bias, (TO*)y, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, Ho, Wo, transposed, KC)
+    dim3 grid((unsigned)tiles, (unsigned)nchunk), block(CB);
+#define LAUNCH(TI, TO) hipLaunchKernelGGL((k_conv_fwd<TI, TO>), grid, block, 0, st, (const TI*)x, w, bias, (TO*)y, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, Ho, Wo, transposed, KC, CoutC)
     if (in_dtype == TCCT_F32 && out_dtype == TCCT_F32) LAUNCH(float, float);
     else if (in_dtype == TCCT_BF16 && out_dtype == TCCT_BF16) LAUNCH(bf16, bf16);
     else if (in_dtype == TCCT_BF16 && out_dtype == TCCT_F32) LAUNCH(bf16, float);

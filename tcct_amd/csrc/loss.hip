@@ -1,0 +1,400 @@
+// Loss-side kernels: fused softmax + batch-global Dice sums (+ backward), the column-wise (over H) pieces of the
+// boundary-regression loss, and small fp32 helpers.  Labels are class indices (uint8), never one-hot.
+#include "common.h"
+
+#define LB 256
+#define MAXC 8
+
+// ----------------------------------------------------------------------- softmax + Dice sums (kite/losses/loss.py:28-32,83-99)
+template <typename T>
+__global__ void k_dice_sums(const T* __restrict__ logits, const uint8_t* __restrict__ lab, int64_t M, int C,
+                            double* __restrict__ sums /*[3][C]: I, P, G*/) {
+    __shared__ float sm[3 * MAXC][LB / 64];
+    float I[MAXC], P[MAXC], G[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) I[c] = P[c] = G[c] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+        float z[MAXC], mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) { z[c] = c < C ? ldf(logits + i * C + c) : -INFINITY; mx = fmaxf(mx, z[c]); }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) { z[c] = c < C ? __expf(z[c] - mx) : 0.f; s += z[c]; }
+        float inv = 1.f / s;
+        int l = lab[i];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            float p = z[c] * inv;
+            P[c] += p;
+            if (c == l) { I[c] += p; G[c] += 1.f; }
+        }
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        float a = wave_sum(I[c]), b = wave_sum(P[c]), g = wave_sum(G[c]);
+        if (lane == 0) { sm[c][w] = a; sm[MAXC + c][w] = b; sm[2 * MAXC + c][w] = g; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * MAXC) {
+        int q = threadIdx.x / MAXC, c = threadIdx.x % MAXC;
+        if (c < C) {
+            double a = 0.0;
+            for (int k = 0; k < LB / 64; ++k) a += (double)sm[threadIdx.x][k];
+            atomicAdd(&sums[q * C + c], a);
+        }
+    }
+}
+__global__ void k_dice_finalize(const double* __restrict__ sums, int C, float* __restrict__ loss) {
+    if (threadIdx.x == 0) {
+        double l = 0.0;
+        for (int c = 0; c < C; ++c) l += 1.0 - (1.0 + 2.0 * sums[c]) / (1.0 + sums[C + c] + sums[2 * C + c]);
+        *loss = (float)l;
+    }
+}
+extern "C" int tcct_softmax_dice_fwd(const void* logits, const uint8_t* labels, int64_t M, int C, double* sums, float* loss,
+                                     int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(C >= 2 && C <= MAXC, "softmax_dice_fwd: C=%d unsupported (2..%d)", C, MAXC);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 3 * C, st) != hipSuccess) { tcct_set_error("softmax_dice_fwd: memset failed"); return -2; }
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_dice_sums<T>, dim3(tcct_grid(M, LB, 2048)), dim3(LB), 0, st, (const T*)logits, labels, M, C, sums));
+    hipLaunchKernelGGL(k_dice_finalize, dim3(1), dim3(64), 0, st, sums, C, loss);
+    TCCT_LAUNCH_OK();
+}
+
+template <typename T>
+__global__ void k_dice_bwd(const T* __restrict__ logits, const uint8_t* __restrict__ lab, int64_t M, int C,
+                           const double* __restrict__ sums, const float* __restrict__ gout, float gscale,
+                           T* __restrict__ dlogits) {
+    float a[MAXC], b[MAXC];
+    const float gs = gscale * (gout ? *gout : 1.f);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < C) {
+            double U = 1.0 + sums[C + c] + sums[2 * C + c];
+            a[c] = (float)(-2.0 / U);
+            b[c] = (float)((1.0 + 2.0 * sums[c]) / (U * U));
+        } else a[c] = b[c] = 0.f;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+        float z[MAXC], mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) { z[c] = c < C ? ldf(logits + i * C + c) : -INFINITY; mx = fmaxf(mx, z[c]); }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) { z[c] = c < C ? __expf(z[c] - mx) : 0.f; s += z[c]; }
+        float inv = 1.f / s;
+        int l = lab[i];
+        float dp[MAXC], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) { z[c] *= inv; dp[c] = b[c] + (c == l ? a[c] : 0.f); dot += z[c] * dp[c]; }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) stf(dlogits + i * C + c, gs * z[c] * (dp[c] - dot));
+    }
+}
+extern "C" int tcct_softmax_dice_bwd(const void* logits, const uint8_t* labels, int64_t M, int C, const double* sums,
+                                     const float* grad_out, float grad_scale, void* dlogits, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(C >= 2 && C <= MAXC, "softmax_dice_bwd: C=%d unsupported", C);
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_dice_bwd<T>, dim3(tcct_grid(M, LB, 1 << 16)), dim3(LB), 0, (hipStream_t)stream, (const T*)logits, labels, M, C, sums, grad_out, grad_scale, (T*)dlogits));
+    TCCT_LAUNCH_OK();
+}
+
+// softmax probability of the labelled class (FPL sort key, nets/reg.py:89) and argmax class (predict, loop_seg.py:32)
+template <typename T>
+__global__ void k_softmax_pick(const T* __restrict__ logits, const uint8_t* __restrict__ lab, int64_t M, int C,
+                               float* __restrict__ prob_lab, uint8_t* __restrict__ argmax) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+        float z[MAXC], mx = -INFINITY;
+        int am = 0;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            z[c] = c < C ? ldf(logits + i * C + c) : -INFINITY;
+            if (z[c] > mx) { mx = z[c]; am = c; }
+        }
+        if (argmax) argmax[i] = (uint8_t)am;
+        if (prob_lab) {
+            float s = 0.f, pl = 0.f;
+            int l = lab[i];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) { float e = c < C ? __expf(z[c] - mx) : 0.f; s += e; if (c == l) pl = e; }
+            prob_lab[i] = pl / s;
+        }
+    }
+}
+extern "C" int tcct_softmax_pick(const void* logits, const uint8_t* labels, int64_t M, int C, float* prob_lab,
+                                 uint8_t* argmax, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(C >= 2 && C <= MAXC, "softmax_pick: C=%d unsupported", C);
+    TCCT_CHECK(!(prob_lab && !labels), "softmax_pick: prob_lab needs labels");
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_softmax_pick<T>, dim3(tcct_grid(M, LB, 1 << 16)), dim3(LB), 0, (hipStream_t)stream, (const T*)logits, labels, M, C, prob_lab, argmax));
+    TCCT_LAUNCH_OK();
+}
+
+// per-sample per-class {intersection, pred count, label count} for MDiceLoss/MIouLoss scores (kite/losses/miou.py:28-91)
+__global__ void k_confusion(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ lab, int64_t HW, int C,
+                            float* __restrict__ out /*[N][C][3]*/) {
+    __shared__ float sm[3 * MAXC];
+    const int n = blockIdx.y;
+    if (threadIdx.x < 3 * MAXC) sm[threadIdx.x] = 0.f;
+    __syncthreads();
+    float I[MAXC], P[MAXC], G[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) I[c] = P[c] = G[c] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (int64_t)gridDim.x * blockDim.x) {
+        int p = pred[n * HW + i], l = lab[n * HW + i];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) { P[c] += (p == c); G[c] += (l == c); I[c] += (p == c && l == c); }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        float a = wave_sum(I[c]), b = wave_sum(P[c]), g = wave_sum(G[c]);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&sm[c * 3], a); atomicAdd(&sm[c * 3 + 1], b); atomicAdd(&sm[c * 3 + 2], g); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * C) atomicAdd(&out[(int64_t)n * C * 3 + threadIdx.x], sm[threadIdx.x]);
+}
+extern "C" int tcct_confusion_counts(const uint8_t* pred, const uint8_t* labels, int N, int64_t HW, int C, float* out,
+                                     tcct_stream_t stream) {
+    TCCT_CHECK(C >= 1 && C <= MAXC, "confusion_counts: C=%d unsupported", C);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * N * C * 3, st) != hipSuccess) { tcct_set_error("confusion_counts: memset failed"); return -2; }
+    dim3 grid(tcct_grid(HW, LB, 256), N);
+    hipLaunchKernelGGL(k_confusion, grid, dim3(LB), 0, st, pred, labels, HW, C, out);
+    TCCT_LAUNCH_OK();
+}
+
+// ----------------------------------------------------------------------- channel slice  T [M,C] -> fp32 [M,n] and back
+template <typename T>
+__global__ void k_slice_fwd(const T* __restrict__ x, float* __restrict__ y, int64_t M, int C, int start, int n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = ldf(x + (i / n) * C + start + (i % n));
+}
+template <typename T>
+__global__ void k_slice_bwd(const float* __restrict__ dy, T* __restrict__ dx, int64_t M, int C, int start, int n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * C; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C) - start;
+        stf(dx + i, (c >= 0 && c < n) ? dy[(i / C) * n + c] : 0.f);
+    }
+}
+extern "C" int tcct_slice_channels_fwd(const void* x, float* y, int64_t M, int C, int start, int n, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(start >= 0 && n > 0 && start + n <= C, "slice_channels_fwd: bad range");
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_slice_fwd<T>, dim3(tcct_grid(M * n, LB, 1 << 16)), dim3(LB), 0, (hipStream_t)stream, (const T*)x, y, M, C, start, n));
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_slice_channels_bwd(const float* dy, void* dx, int64_t M, int C, int start, int n, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(start >= 0 && n > 0 && start + n <= C, "slice_channels_bwd: bad range");
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_slice_bwd<T>, dim3(tcct_grid(M * C, LB, 1 << 16)), dim3(LB), 0, (hipStream_t)stream, dy, (T*)dx, M, C, start, n));
+    TCCT_LAUNCH_OK();
+}
+
+// labels -> fp32 one-hot slice [M,n] (classes start..start+n-1) and the vertical label-edge map prob_true (nets/reg.py:111-114)
+__global__ void k_label_planes(const uint8_t* __restrict__ lab, float* __restrict__ onehot, float* __restrict__ edge, int N,
+                               int H, int W, int start, int n) {
+    const int64_t total = (int64_t)N * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int l = lab[i];
+        if (onehot)
+            for (int c = 0; c < n; ++c) onehot[i * n + c] = (l == start + c) ? 1.f : 0.f;
+        if (edge) {
+            int h = (int)((i / W) % H);
+            float e = 0.f;
+            if (h > 0) {
+                int lp = lab[i - W];
+                // sum_c |onehot_c[h] - onehot_c[h-1]| over classes start..start+n-1, clamped at 1
+                int cnt = 0;
+                if (l != lp) { cnt += (l >= start && l < start + n); cnt += (lp >= start && lp < start + n); }
+                e = cnt > 0 ? 1.f : 0.f;
+            }
+            edge[i] = e;
+        }
+    }
+}
+extern "C" int tcct_label_planes(const uint8_t* labels, float* onehot, float* edge, int N, int H, int W, int start, int n,
+                                 tcct_stream_t stream) {
+    hipLaunchKernelGGL(k_label_planes, dim3(tcct_grid((int64_t)N * H * W, LB, 1 << 16)), dim3(LB), 0, (hipStream_t)stream, labels, onehot, edge, N, H, W, start, n);
+    TCCT_LAUNCH_OK();
+}
+
+// ----------------------------------------------------------------------- Gumbel column softmax over H, summed over CH channels
+// x, eps: fp32 [N,H,W,CH]; thread = one (n, w, ch) column; lanes run over (w,ch) => coalesced rows.
+// out[n,h,w] = sum_ch g/(1e-6 + S) with g = softmax_H(x - log(-log(eps))/2), S = sum_H g   (nets/reg.py:118-128)
+// stats[n,w,ch] = {m, Z, S}
+template <int CH>
+__global__ void k_gumbel_fwd(const float* __restrict__ x, const float* __restrict__ eps, float* __restrict__ out,
+                             float* __restrict__ stats, int N, int H, int W) {
+    const int WC = W * CH;
+    const int64_t cols = (int64_t)N * WC;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t rounds = (cols + stride - 1) / stride;
+    int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t it = 0; it < rounds; ++it, col += stride) {
+        const bool ok = col < cols;
+        const int64_t cc = ok ? col : 0;
+        const int64_t n = cc / WC;
+        const int wc = (int)(cc % WC);
+        const float* xp = x + n * (int64_t)H * WC + wc;
+        const float* ep = eps + n * (int64_t)H * WC + wc;
+        float m = -INFINITY, Z = 0.f;
+        for (int h = 0; h < H; ++h) {
+            float z = xp[(int64_t)h * WC] - 0.5f * logf(-logf(ep[(int64_t)h * WC]));
+            float mn = fmaxf(m, z);
+            Z = Z * __expf(m - mn) + __expf(z - mn);
+            m = mn;
+        }
+        float S = 0.f;
+        for (int h = 0; h < H; ++h) {
+            float z = xp[(int64_t)h * WC] - 0.5f * logf(-logf(ep[(int64_t)h * WC]));
+            S += __expf(z - m) / Z;
+        }
+        if (ok) { stats[cc * 3] = m; stats[cc * 3 + 1] = Z; stats[cc * 3 + 2] = S; }
+        const float den = 1.f / (1e-6f + S);
+        for (int h = 0; h < H; ++h) {
+            float z = xp[(int64_t)h * WC] - 0.5f * logf(-logf(ep[(int64_t)h * WC]));
+            float v = __expf(z - m) / Z * den;
+#pragma unroll
+            for (int o = CH >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (ok && (wc % CH) == 0) out[(n * H + h) * (int64_t)W + wc / CH] = v;
+        }
+    }
+}
+// dx[n,h,w,ch] = g * ((dout[h] - D)/(eps+S) - D (1-S)/(eps+S)^2),  D = sum_h dout[h] g[h]
+template <int CH>
+__global__ void k_gumbel_bwd(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ stats,
+                             const float* __restrict__ dout, float* __restrict__ dx, int N, int H, int W) {
+    const int WC = W * CH;
+    const int64_t cols = (int64_t)N * WC;
+    for (int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; col < cols; col += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = col / WC;
+        const int wc = (int)(col % WC);
+        const int w = wc / CH;
+        const float* xp = x + n * (int64_t)H * WC + wc;
+        const float* ep = eps + n * (int64_t)H * WC + wc;
+        const float* dp = dout + n * (int64_t)H * W + w;
+        float* dxp = dx + n * (int64_t)H * WC + wc;
+        const float m = stats[col * 3], Z = stats[col * 3 + 1], S = stats[col * 3 + 2];
+        float D = 0.f;
+        for (int h = 0; h < H; ++h) {
+            float z = xp[(int64_t)h * WC] - 0.5f * logf(-logf(ep[(int64_t)h * WC]));
+            D += dp[(int64_t)h * W] * (__expf(z - m) / Z);
+        }
+        const float den = 1.f / (1e-6f + S);
+        const float k2 = D * (1.f - S) * den * den;
+        for (int h = 0; h < H; ++h) {
+            float z = xp[(int64_t)h * WC] - 0.5f * logf(-logf(ep[(int64_t)h * WC]));
+            float g = __expf(z - m) / Z;
+            dxp[(int64_t)h * WC] = g * ((dp[(int64_t)h * W] - D) * den - k2);
+        }
+    }
+}
+extern "C" int tcct_gumbel_colsoftmax_fwd(const float* x, const float* eps, float* out, float* stats, int N, int H, int W,
+                                          int CH, tcct_stream_t stream) {
+    TCCT_CHECK(CH == 4, "gumbel_colsoftmax_fwd: CH=%d unsupported (4)", CH);
+    int64_t cols = (int64_t)N * W * CH;
+    hipLaunchKernelGGL(k_gumbel_fwd<4>, dim3(tcct_grid(cols, 64, 1 << 16)), dim3(64), 0, (hipStream_t)stream, x, eps, out, stats, N, H, W);
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_gumbel_colsoftmax_bwd(const float* x, const float* eps, const float* stats, const float* dout, float* dx,
+                                          int N, int H, int W, int CH, tcct_stream_t stream) {
+    TCCT_CHECK(CH == 4, "gumbel_colsoftmax_bwd: CH=%d unsupported (4)", CH);
+    int64_t cols = (int64_t)N * W * CH;
+    hipLaunchKernelGGL(k_gumbel_bwd<4>, dim3(tcct_grid(cols, 64, 1 << 16)), dim3(64), 0, (hipStream_t)stream, x, eps, stats, dout, dx, N, H, W);
+    TCCT_LAUNCH_OK();
+}
+
+// ----------------------------------------------------------------------- column (over H) softmax and weighted column sum, fp32 [N,H,W]
+__global__ void k_colsoftmax_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W) {
+    const int64_t cols = (int64_t)N * W;
+    for (int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; col < cols; col += (int64_t)gridDim.x * blockDim.x) {
+        const float* xp = x + (col / W) * (int64_t)H * W + (col % W);
+        float* yp = y + (col / W) * (int64_t)H * W + (col % W);
+        float m = -INFINITY, Z = 0.f;
+        for (int h = 0; h < H; ++h) {
+            float z = xp[(int64_t)h * W];
+            float mn = fmaxf(m, z);
+            Z = Z * __expf(m - mn) + __expf(z - mn);
+            m = mn;
+        }
+        float inv = 1.f / Z;
+        for (int h = 0; h < H; ++h) yp[(int64_t)h * W] = __expf(xp[(int64_t)h * W] - m) * inv;
+    }
+}
+__global__ void k_colsoftmax_bwd(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W) {
+    const int64_t cols = (int64_t)N * W;
+    for (int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; col < cols; col += (int64_t)gridDim.x * blockDim.x) {
+        int64_t off = (col / W) * (int64_t)H * W + (col % W);
+        float dot = 0.f;
+        for (int h = 0; h < H; ++h) dot += y[off + (int64_t)h * W] * dy[off + (int64_t)h * W];
+        for (int h = 0; h < H; ++h) dx[off + (int64_t)h * W] = y[off + (int64_t)h * W] * (dy[off + (int64_t)h * W] - dot);
+    }
+}
+extern "C" int tcct_colsoftmax_fwd(const float* x, float* y, int N, int H, int W, tcct_stream_t stream) {
+    hipLaunchKernelGGL(k_colsoftmax_fwd, dim3(tcct_grid((int64_t)N * W, 64, 1 << 16)), dim3(64), 0, (hipStream_t)stream, x, y, N, H, W);
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_colsoftmax_bwd(const float* y, const float* dy, float* dx, int N, int H, int W, tcct_stream_t stream) {
+    hipLaunchKernelGGL(k_colsoftmax_bwd, dim3(tcct_grid((int64_t)N * W, 64, 1 << 16)), dim3(64), 0, (hipStream_t)stream, y, dy, dx, N, H, W);
+    TCCT_LAUNCH_OK();
+}
+
+// edge[n,w] = sum_h x[n,h,w] * wts[h]   (column soft-argmax, nets/reg.py:146-150; wts = (h + jitter - .5)/H)
+__global__ void k_colwsum_fwd(const float* __restrict__ x, const float* __restrict__ wts, float* __restrict__ out, int N, int H, int W) {
+    const int64_t cols = (int64_t)N * W;
+    for (int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; col < cols; col += (int64_t)gridDim.x * blockDim.x) {
+        const float* xp = x + (col / W) * (int64_t)H * W + (col % W);
+        float s = 0.f;
+        for (int h = 0; h < H; ++h) s += xp[(int64_t)h * W] * wts[h];
+        out[col] = s;
+    }
+}
+__global__ void k_colwsum_bwd(const float* __restrict__ dout, const float* __restrict__ wts, float* __restrict__ dx, int N, int H, int W) {
+    const int64_t total = (int64_t)N * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int w = (int)(i % W);
+        int64_t r = i / W;
+        int h = (int)(r % H);
+        dx[i] = dout[(r / H) * W + w] * wts[h];
+    }
+}
+extern "C" int tcct_colwsum_fwd(const float* x, const float* wts, float* out, int N, int H, int W, tcct_stream_t stream) {
+    hipLaunchKernelGGL(k_colwsum_fwd, dim3(tcct_grid((int64_t)N * W, 64, 1 << 16)), dim3(64), 0, (hipStream_t)stream, x, wts, out, N, H, W);
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_colwsum_bwd(const float* dout, const float* wts, float* dx, int N, int H, int W, tcct_stream_t stream) {
+    hipLaunchKernelGGL(k_colwsum_bwd, dim3(tcct_grid((int64_t)N * H * W, LB, 1 << 16)), dim3(LB), 0, (hipStream_t)stream, dout, wts, dx, N, H, W);
+    TCCT_LAUNCH_OK();
+}
+
+// ----------------------------------------------------------------------- mean squared error on fp32 vectors (nn.MSELoss, reg.py:108)
+__global__ void k_mse_fwd(const float* __restrict__ a, const float* __restrict__ b, int64_t n, double* __restrict__ acc) {
+    __shared__ float sm[16];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float d = a[i] - b[i];
+        s += d * d;
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) atomicAdd(acc, (double)s);
+}
+__global__ void k_mse_fin(const double* acc, int64_t n, float* out) { if (threadIdx.x == 0) *out = (float)(*acc / (double)n); }
+// da = coef * (a-b), db = -da  with coef = 2/n * gscale * (*gout); either output may be NULL
+__global__ void k_mse_bwd(const float* __restrict__ a, const float* __restrict__ b, int64_t n, const float* __restrict__ gout,
+                          float gscale, float* __restrict__ da, float* __restrict__ db) {
+    const float coef = 2.f / (float)n * gscale * (gout ? *gout : 1.f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float d = coef * (a[i] - b[i]);
+        if (da) da[i] = d;
+        if (db) db[i] = -d;
+    }
+}
+extern "C" int tcct_mse_fwd(const float* a, const float* b, int64_t n, double* acc, float* out, tcct_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(acc, 0, sizeof(double), st) != hipSuccess) { tcct_set_error("mse_fwd: memset failed"); return -2; }
+    hipLaunchKernelGGL(k_mse_fwd, dim3(tcct_grid(n, LB, 1024)), dim3(LB), 0, st, a, b, n, acc);
+    hipLaunchKernelGGL(k_mse_fin, dim3(1), dim3(64), 0, st, acc, n, out);
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_mse_bwd(const float* a, const float* b, int64_t n, const float* grad_out, float grad_scale, float* da,
+                            float* db, tcct_stream_t stream) {
+    hipLaunchKernelGGL(k_mse_bwd, dim3(tcct_grid(n, LB, 1 << 16)), dim3(LB), 0, (hipStream_t)stream, a, b, n, grad_out, grad_scale, da, db);
+    TCCT_LAUNCH_OK();
+}

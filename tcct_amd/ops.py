@@ -299,3 +299,336 @@ class _Concat2(torch.autograd.Function):
 
 def concat2(a, b):
     return _Concat2.apply(a, b)
+
+
+class _Add3Scale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, c, alpha):
+        _chk(a, b, c)
+        y = torch.empty_like(a)
+        lib.add3_scale(a, b, c, y, a.numel(), alpha, dtype_code(a.dtype))
+        ctx.alpha = alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        d = torch.empty_like(dy)
+        lib.scale(dy, d, dy.numel(), ctx.alpha, dtype_code(dy.dtype))
+        return d, d, d, None
+
+
+def add3_scale(a, b, c, alpha):
+    return _Add3Scale.apply(a, b, c, float(alpha))
+
+
+# -------------------------------------------------------------------------------------- pooling / resize
+class _MetaPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        B, N, C = x.shape
+        y = torch.empty_like(x)
+        lib.metapool_fwd(x, y, B, N, C, dtype_code(x.dtype))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        B, N, C = dy.shape
+        dx = torch.empty_like(dy)
+        lib.metapool_bwd(dy, dx, B, N, C, dtype_code(dy.dtype))
+        return dx
+
+
+def metapool(x):
+    """x tokens [B,N,C]"""
+    return _MetaPool.apply(x)
+
+
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        N, H, W, C = x.shape
+        y = torch.empty((N, H // 2, W // 2, C), device=x.device, dtype=x.dtype)
+        lib.maxpool2_fwd(x, y, N, H, W, C, dtype_code(x.dtype))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _as(dy, x.dtype)
+        N, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        lib.maxpool2_bwd(x, dy, dx, N, H, W, C, dtype_code(x.dtype))
+        return dx
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(x)
+
+
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, align):
+        _chk(x)
+        N, H, W, C = x.shape
+        y = torch.empty((N, Ho, Wo, C), device=x.device, dtype=x.dtype)
+        lib.bilinear_fwd(x, y, N, H, W, C, Ho, Wo, int(align), dtype_code(x.dtype))
+        ctx.cfg = (N, H, W, C, Ho, Wo, int(align))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C, Ho, Wo, align = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty((N, H, W, C), device=dy.device, dtype=dy.dtype)
+        lib.bilinear_bwd(dy, dx, N, H, W, C, Ho, Wo, align, dtype_code(dy.dtype))
+        return dx, None, None, None
+
+
+def bilinear(x, size, align_corners):
+    if tuple(x.shape[1:3]) == tuple(size):
+        return x                       # identity resize (torch returns the same values)
+    return _Bilinear.apply(x, int(size[0]), int(size[1]), bool(align_corners))
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        _chk(x)
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        lib.l2norm_fwd(x, y, x.numel() // C, C, eps, dtype_code(x.dtype))
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _as(dy, x.dtype)
+        C = x.shape[-1]
+        dx = torch.empty_like(x)
+        lib.l2norm_bwd(x, dy, dx, x.numel() // C, C, ctx.eps, dtype_code(x.dtype))
+        return dx, None
+
+
+def l2norm(x, eps=1e-12):
+    return _L2Norm.apply(x, float(eps))
+
+
+# ------------------------------------------------------------------------------------------------ losses
+class _SoftmaxDice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        _chk(logits, labels)
+        C = logits.shape[-1]
+        M = logits.numel() // C
+        sums = torch.empty(3 * C, device=logits.device, dtype=torch.float64)
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        lib.softmax_dice_fwd(logits, labels, M, C, sums, loss, dtype_code(logits.dtype))
+        ctx.save_for_backward(logits, labels, sums)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, sums = ctx.saved_tensors
+        C = logits.shape[-1]
+        M = logits.numel() // C
+        g = _as(g, torch.float32)
+        d = torch.empty_like(logits)
+        lib.softmax_dice_bwd(logits, labels, M, C, sums, g, 1.0, d, dtype_code(logits.dtype))
+        return d, None
+
+
+def softmax_dice(logits, labels):
+    """MultiLoss(DiceLoss): logits NHWC [N,H,W,C], labels uint8 [N,H,W] -> scalar (sum over classes of 1-dice)."""
+    return _SoftmaxDice.apply(logits, labels)
+
+
+class _Slice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, start, n):
+        _chk(x)
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty(x.shape[:-1] + (n,), device=x.device, dtype=torch.float32)
+        lib.slice_channels_fwd(x, y, M, C, start, n, dtype_code(x.dtype))
+        ctx.cfg = (C, start, n, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        C, start, n, dt = ctx.cfg
+        dy = _as(dy, torch.float32)
+        M = dy.numel() // n
+        dx = torch.empty(dy.shape[:-1] + (C,), device=dy.device, dtype=dt)
+        lib.slice_channels_bwd(dy, dx, M, C, start, n, dtype_code(dt))
+        return dx, None, None
+
+
+def slice_channels_f32(x, start, n):
+    return _Slice.apply(x, start, n)
+
+
+class _GumbelColSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        _chk(x, eps)
+        N, H, W, CH = x.shape
+        out = torch.empty((N, H, W, 1), device=x.device, dtype=torch.float32)
+        stats = torch.empty((N, W, CH, 3), device=x.device, dtype=torch.float32)
+        lib.gumbel_colsoftmax_fwd(x, eps, out, stats, N, H, W, CH)
+        ctx.save_for_backward(x, eps, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, eps, stats = ctx.saved_tensors
+        N, H, W, CH = x.shape
+        dout = _as(dout, torch.float32)
+        dx = torch.empty_like(x)
+        lib.gumbel_colsoftmax_bwd(x, eps, stats, dout, dx, N, H, W, CH)
+        return dx, None
+
+
+def gumbel_colsoftmax_sum(x, eps):
+    """x, eps fp32 [N,H,W,4] -> [N,H,W,1]: sum_c sampling_softmax over H (reg.py:118-128)"""
+    return _GumbelColSoftmax.apply(x, eps)
+
+
+class _ColSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        N, H, W = x.shape[:3]
+        y = torch.empty_like(x)
+        lib.colsoftmax_fwd(x, y, N, H, W)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        N, H, W = y.shape[:3]
+        dy = _as(dy, torch.float32)
+        dx = torch.empty_like(y)
+        lib.colsoftmax_bwd(y, dy, dx, N, H, W)
+        return dx
+
+
+def colsoftmax(x):
+    """softmax over H of fp32 [N,H,W,1]"""
+    return _ColSoftmax.apply(x)
+
+
+class _ColWSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wts):
+        _chk(x, wts)
+        N, H, W = x.shape[:3]
+        out = torch.empty((N, W), device=x.device, dtype=torch.float32)
+        lib.colwsum_fwd(x, wts, out, N, H, W)
+        ctx.save_for_backward(wts)
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (wts,) = ctx.saved_tensors
+        N, H, W = ctx.shape[:3]
+        dout = _as(dout, torch.float32)
+        dx = torch.empty(ctx.shape, device=dout.device, dtype=torch.float32)
+        lib.colwsum_bwd(dout, wts, dx, N, H, W)
+        return dx, None
+
+
+def colwsum(x, wts):
+    """edge[n,w] = sum_h x[n,h,w]*wts[h]"""
+    return _ColWSum.apply(x, wts)
+
+
+class _Mse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _chk(a, b)
+        acc = torch.empty((), device=a.device, dtype=torch.float64)
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        lib.mse_fwd(a, b, a.numel(), acc, out)
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _as(g, torch.float32)
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        lib.mse_bwd(a, b, a.numel(), g, 1.0, da, db)
+        return da, db
+
+
+def mse(a, b):
+    return _Mse.apply(a, b)
+
+
+def label_planes(labels, start, n, want_onehot=True, want_edge=True):
+    """labels uint8 [N,H,W] -> (onehot fp32 [N,H,W,n] of classes start.., edge fp32 [N,H,W,1])"""
+    _chk(labels)
+    N, H, W = labels.shape
+    oh = torch.empty((N, H, W, n), device=labels.device, dtype=torch.float32) if want_onehot else None
+    ed = torch.empty((N, H, W, 1), device=labels.device, dtype=torch.float32) if want_edge else None
+    lib.label_planes(labels, oh, ed, N, H, W, start, n)
+    return oh, ed
+
+
+class _Fpl(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, logits, labels, buf_grad):
+        _chk(feat, logits, labels, buf_grad)
+        C = logits.shape[-1]
+        M = logits.numel() // C
+        dev = feat.device
+        if feat.shape[-1] != 32:
+            raise TcctError('fpl: feature width must be 32')
+        prob = torch.empty(M, device=dev, dtype=torch.float32)
+        lib.softmax_pick(logits, labels, M, C, prob, None, dtype_code(logits.dtype))
+        keys_in = torch.empty(M, device=dev, dtype=torch.int64)
+        keys_out = torch.empty(M, device=dev, dtype=torch.int64)
+        vals_in = torch.empty(M, device=dev, dtype=torch.int32)
+        vals_out = torch.empty(M, device=dev, dtype=torch.int32)
+        counts = torch.empty(8, device=dev, dtype=torch.int32)
+        wsb = lib.fpl_sort_workspace_bytes(M)
+        if wsb < 0:
+            raise TcctError('fpl_sort_workspace_bytes failed')
+        ws = torch.empty(max(int(wsb), 16), device=dev, dtype=torch.uint8)
+        lib.fpl_sort(labels, prob, M, keys_in, vals_in, keys_out, vals_out, counts, ws, int(wsb))
+        pro_sum = torch.empty((C, 32, 32), device=dev, dtype=torch.float32)
+        pro = torch.empty((C, 32, 32), device=dev, dtype=torch.float32)
+        dpro = torch.empty((C, 32, 32), device=dev, dtype=torch.float32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        binmap = torch.empty(M, device=dev, dtype=torch.uint8)
+        lib.fpl_forward(feat, keys_out, vals_out, counts, M, C, buf_grad, pro_sum, pro, loss, dpro, binmap,
+                        dtype_code(feat.dtype))
+        ctx.save_for_backward(labels, binmap, dpro)
+        ctx.cfg = (feat.shape, feat.dtype, M)
+        ctx.mark_non_differentiable(pro)
+        return loss, pro
+
+    @staticmethod
+    def backward(ctx, g, _gpro):
+        labels, binmap, dpro = ctx.saved_tensors
+        shape, dt, M = ctx.cfg
+        g = _as(g, torch.float32)
+        dfeat = torch.empty(shape, device=g.device, dtype=dt)
+        lib.fpl_backward(labels, binmap, dpro, g, 1.0, M, dfeat, dtype_code(dt))
+        return dfeat, None, None, None
+
+
+def fpl(feat, logits, labels, buf_grad):
+    """regular_udh: feat NHWC [N,H,W,32], logits NHWC [N,H,W,C] (no grad flows to them), labels uint8 [N,H,W],
+    buf_grad fp32 [C,32] -> (loss, prototypes [C,32,32])"""
+    return _Fpl.apply(feat, logits.detach(), labels, buf_grad)

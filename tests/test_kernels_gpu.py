@@ -189,3 +189,79 @@ def test_elementwise(dt):
     yd.backward(g2.to('cuda', dt))
     torch.testing.assert_close(ad.grad.float().cpu(), g2[..., :32], **t)
     torch.testing.assert_close(cd.grad.float().cpu(), g2[..., 32:], **t)
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_metapool_maxpool_l2norm(dt):
+    from tcct_amd import ops
+    t = tol(dt)
+    for (B, Nn, C) in [(2, 35, 64), (2, 1, 96), (1, 7, 160)]:
+        x = rnd(B, Nn, C, dt=dt).requires_grad_(True)
+        y = F.avg_pool2d(x, 3, 1, 1, count_include_pad=False) - x
+        gy = rnd(*y.shape, seed=1, dt=dt)
+        y.backward(gy)
+        xd = x.detach().to('cuda', dt).requires_grad_(True)
+        yd = ops.metapool(xd)
+        torch.testing.assert_close(yd.float().cpu(), y.detach(), **t)
+        yd.backward(gy.to('cuda', dt))
+        torch.testing.assert_close(xd.grad.float().cpu(), x.grad, **t)
+    x = rnd(2, 32, 8, 12, dt=dt).requires_grad_(True)
+    y = F.max_pool2d(x, 2)
+    gy = rnd(*y.shape, seed=2, dt=dt)
+    y.backward(gy)
+    xd = nhwc(x.detach(), dt).requires_grad_(True)
+    yd = ops.maxpool2(xd)
+    torch.testing.assert_close(nchw(yd), y.detach(), **t)
+    yd.backward(nhwc(gy, dt))
+    torch.testing.assert_close(nchw(xd.grad), x.grad, **t)
+    x = rnd(2, 32, 5, 7, dt=dt)
+    x[0, :, 0, 0] = 0
+    x.requires_grad_(True)
+    y = F.normalize(x, dim=1, p=2)
+    gy = rnd(*y.shape, seed=3, dt=dt)
+    y.backward(gy)
+    xd = nhwc(x.detach(), dt).requires_grad_(True)
+    yd = ops.l2norm(xd)
+    torch.testing.assert_close(nchw(yd), y.detach(), **t)
+    yd.backward(nhwc(gy, dt))
+    m = torch.ones(2, 1, 5, 7, dtype=torch.bool); m[0, :, 0, 0] = False     # zero vector: subgradient conventions differ
+    torch.testing.assert_close(nchw(xd.grad) * m, x.grad * m, **t)
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('cfg', [(32, 4, 6, 8, 12, True), (32, 8, 10, 16, 20, False), (5, 4, 6, 32, 48, False),
+                                 (5, 8, 12, 16, 24, False), (32, 2, 3, 8, 12, False), (32, 1, 1, 2, 2, True),
+                                 (5, 2, 2, 32, 32, False)])
+def test_bilinear(dt, cfg):
+    from tcct_amd import ops
+    C, H, W, Ho, Wo, align = cfg
+    x = rnd(2, C, H, W, dt=dt).requires_grad_(True)
+    y = F.interpolate(x, size=(Ho, Wo), mode='bilinear', align_corners=align)
+    gy = rnd(*y.shape, seed=1, dt=dt)
+    y.backward(gy)
+    xd = nhwc(x.detach(), dt).requires_grad_(True)
+    yd = ops.bilinear(xd, (Ho, Wo), align)
+    t = tol(dt)
+    torch.testing.assert_close(nchw(yd), y.detach(), **t)
+    yd.backward(nhwc(gy, dt))
+    torch.testing.assert_close(nchw(xd.grad), x.grad, rtol=t['rtol'], atol=t['atol'] * 4)
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_softmax_dice(dt):
+    from tcct_amd import ops
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    import tcct_oracle as O
+    N, C, H, W = 2, 5, 12, 20
+    x = (rnd(N, C, H, W, dt=dt) * 2).to(dt).float().requires_grad_(True)
+    lab = torch.randint(0, C, (N, H, W), generator=torch.Generator().manual_seed(1))
+    oh = F.one_hot(lab, C).permute(0, 3, 1, 2)
+    loss = O.dice_multi(x, oh)
+    (loss * 0.7).backward()
+    xd = nhwc(x.detach(), dt).requires_grad_(True)
+    ld = ops.softmax_dice(xd, lab.to(torch.uint8).cuda())
+    torch.testing.assert_close(ld.cpu(), loss.detach(), rtol=1e-5, atol=1e-5)
+    (ld * 0.7).backward()
+    t = tol(dt)
+    torch.testing.assert_close(nchw(xd.grad), x.grad, rtol=t['rtol'], atol=1e-6 if dt == torch.float32 else 1e-4)
