@@ -1,0 +1,129 @@
+"""KiteSeg — mirror of reference kite/loop_seg.py:10-171 (fit / train / val / predict / calc_loss), native backend.
+
+Behavioural parity with the reference's *intent*; its defects are not reproduced (NameError at the first validation,
+`.squeeze()` breaking bs=1, the call to the missing `regular_epl`).  Labels are carried as class indices
+(uint8 on device) instead of int64 one-hot; `calc_loss` still accepts the reference's one-hot tensor."""
+import time
+
+import numpy as np
+import torch
+
+from .loopback import KiteBack, setup_seed
+from .losses import MDiceLoss, MIouLoss, MaskOneHot
+from .._lib import lib, TcctError
+from ..nets.reg import as_nhwc
+
+
+class KiteSeg(KiteBack):
+    useValSet = True
+    cnt_val = 0
+    udh_out = None
+    udh_lab = None
+
+    def __init__(self, args, **_args):
+        self.args = args
+        super().__init__(**_args)
+        self.set_backend(gpu=args.gpu, parallel=args.pl)
+        self.set_superes(loss=args.los, lr=args.lr)
+        self.NB_CLASS = self.dataset.out_channels
+        self.criterion.NB_CLASS = self.NB_CLASS
+        self.best_dice = -1.0
+
+    def predict(self, img, softmax=True, *args):
+        """reference loop_seg.py:21-33: one_hot(argmax(softmax(out[0]))).  Returns a lazy MaskOneHot (class-index map;
+        `.dense()` gives the reference's float [B,C,H,W]) when softmax=True, else the raw logits."""
+        with torch.no_grad():
+            pred = self.model(self.cuda(img))
+            if isinstance(pred, (list, tuple)):
+                pred = pred[0]
+            pred = pred.detach()
+            if softmax:
+                lg = as_nhwc(pred)
+                B, H, W, C = lg.shape
+                idx = torch.empty((B, H, W), device=lg.device, dtype=torch.uint8)
+                lib.softmax_pick(lg, None, B * H * W, C, None, idx, 0 if lg.dtype == torch.float32 else 1)
+                pred = MaskOneHot(idx, self.NB_CLASS)
+        return pred
+
+    def fit(self, epochs=169):
+        t0 = time.time()
+        for i in range(self.epoch, epochs):
+            ts = time.time()
+            self.train(i)
+            self.schedG.step()
+            if i % 10 == 0 or (i > 0.5 * epochs and i % 5 == 0):
+                logs = self.val(epoch=i)
+                if logs['val_f1s'] > self.best_dice:
+                    self.best_dice = logs['val_f1s']
+                    torch.save(self.model.state_dict(), self.root + '/val_top.pt')
+            self.grad_dump(i)
+            dt = time.time() - ts
+            print('{:03}* {:.2f} mins, left {:.2f} hours to run'.format(i, dt / 60, dt / 3600 * (epochs - i)))
+        print('\nRunning {:.2f} hours for {} epochs!'.format((time.time() - t0) / 3600, epochs))
+
+    def val(self, epoch=0, flagDebug=False):
+        """reference loop_seg.py:66-106: eval mode, bs=1, MDice/MIoU over classes 1..C-1"""
+        prev = torch.is_grad_enabled()
+        torch.set_grad_enabled(False)
+        self.model.eval()
+        sum_iou = sum_f1s = 0.0
+        scores, n = [], 0
+        for i, imgs in enumerate(self.dataset.valSet(bs=1)):
+            img, lab, _, _ = self.dataset.parse(imgs)
+            lab = self.cuda(lab)
+            out = self.predict(img, softmax=True)
+            f1s = MDiceLoss.scorem(out, lab, start_idx=1).item()
+            iou = MIouLoss.scorem(out, lab, start_idx=1).item()
+            scores.append(np.array(MDiceLoss.scores(out, lab), dtype=np.float32))
+            sum_iou += iou
+            sum_f1s += f1s
+            n += 1
+            if (self.args.bug or flagDebug) and i > 8:
+                break
+        torch.set_grad_enabled(prev)
+        logs = {'val_iou': sum_iou / max(n, 1), 'val_f1s': sum_f1s / max(n, 1)}
+        sc = np.round(np.stack(scores, 0).mean(0), 4)
+        print('*SCORES:*', sc, '->', sc[1:].mean())
+        return logs
+
+    def train_step(self, img, lab):
+        """one optimisation step (reference loop_seg.py:121-130); returns the loss TENSOR (no host sync)"""
+        self.optimG.zero_grad(set_to_none=True)
+        losSum, _ = self.calc_loss(img, lab, want_log=False)
+        losSum.backward()
+        self.optimG.step()          # clip_grad_norm_(12) is fused into the step kernel
+        return losSum.detach()
+
+    def train(self, epoch, alpha=.9):
+        setup_seed(epoch * 311 + 2023)
+        torch.set_grad_enabled(True)
+        self.model.train()
+        tot = torch.zeros((), device=self.device)
+        for i, imgs in enumerate(self.dataset.trainSet(bs=self.args.bs)):
+            img, lab, _, _ = self.dataset.parse(imgs)
+            tot += self.train_step(self.cuda(img), self.cuda(lab))
+            if self.args.bug and i > 12:
+                break
+        losItem = tot.item()        # ONE device->host sync per epoch (the reference syncs 3-4x per step)
+        print('\r{:03}# {}={:.4f},'.format(epoch, self.lossName, losItem), end='')
+        return losItem
+
+    def calc_loss(self, img, lab, want_log=True):
+        """reference loop_seg.py:146-171: forward -> Dice (deep supervision) -> udh -> reg; returns (tensor, log string)"""
+        out = self.model(img)
+        losSum = self.grad_calc(out, lab, ds=True, criterion=self.criterion)
+        parts = [('los', losSum)]
+        if isinstance(out, (list, tuple)):
+            out = out[0]
+        self.udh_out, self.udh_lab = out, lab
+        if self.args.udh:
+            parts.append(('udh', self.model.regular_udh(out, lab) * self.args.coff_udh))
+        if self.args.reg:
+            parts.append(('reg', self.model.regular_reg(out, lab) * self.args.coff_reg))
+        if getattr(self.args, 'epl', False):
+            raise TcctError('--epl=true: RegNet.regular_epl does not exist in the reference either (loop_seg.py:167)')
+        total = parts[0][1]
+        for _, p in parts[1:]:
+            total = total + p
+        logStr = ','.join('{}={:.4f}'.format(k, v.item()) for k, v in parts) if want_log else ''
+        return total, logStr

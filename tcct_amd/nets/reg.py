@@ -1,0 +1,130 @@
+"""RegNet — wrapper that owns the boundary-regression and feature-polarization losses (reference nets/reg.py:38-157).
+
+Same constructor, attributes (`base`, `fcs`, `fcp`, `lap_epl`, `lap_reg`, `lap_map`, `tau`, class-level `tmp`, `emb_list`,
+`tgt_list`) and methods (`forward`, `regular_udh`, `regular_reg`) as the reference; both losses accept the reference's
+arguments (raw logits [B,C,H,W], one-hot int64 labels [B,C,H,W]) and additionally class-index labels [B,H,W].
+Hidden RNG of the reference (`rand_like`, reg.py:120,147-148) becomes the optional `noise=` argument."""
+import torch
+from torch import nn
+
+from .. import ops
+from .._lib import TcctError, lib
+from .fcs import FeatConSuper
+from .fcp import FeatConPolar
+
+_LABEL_CACHE = {}
+
+
+def as_label_index(true):
+    """one-hot int64 [B,C,H,W] (kite/loop_seg.py:119) or class indices [B,H,W] -> uint8 [B,H,W] on device."""
+    if not true.is_cuda:
+        raise TcctError('labels must live on the GPU (no CPU fallback)')
+    key = (true.data_ptr(), tuple(true.shape), true.dtype, true._version)
+    hit = _LABEL_CACHE.get('k')
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if true.dim() == 3:
+        if true.dtype == torch.uint8:
+            out = true.contiguous()
+        else:
+            t = true.contiguous().long()
+            B, H, W = t.shape
+            out = torch.empty((B, H, W), device=t.device, dtype=torch.uint8)
+            lib.labels_to_u8(t, out, B, H, W, W)
+    elif true.dim() == 4:
+        t = true.contiguous()
+        if t.dtype != torch.int64:
+            t = t.long()
+        B, C, H, W = t.shape
+        out = torch.empty((B, H, W), device=t.device, dtype=torch.uint8)
+        lib.onehot_to_index(t, out, B, C, H * W)
+    else:
+        raise TcctError(f'labels must be [B,H,W] or one-hot [B,C,H,W], got {tuple(true.shape)}')
+    _LABEL_CACHE['k'] = (key, out)
+    return out
+
+
+def as_nhwc(pred):
+    """NCHW-shaped logits/feature tensor -> NHWC-contiguous tensor (free when it is already a view of NHWC memory)."""
+    return pred.permute(0, 2, 3, 1).contiguous()
+
+
+class RegNet(nn.Module):
+    __name__ = 'reg'
+    tmp = {}
+
+    def __init__(self, base, out_channels=5, con='cor', num_emb=32):
+        super().__init__()
+        self.base = base
+        self.__name__ = base.__name__
+        self.out_channels = out_channels
+        self.fcs = FeatConSuper(con=con)
+        self.fcp = FeatConPolar(num_cls=out_channels, num_emb=32, init=False)
+        self.lap_epl = nn.Sequential(nn.Conv2d(out_channels, 1, 3, 1, 1), nn.Conv2d(1, 1, 3, 1, 1), nn.Sigmoid())   # unused
+        dim_reg = out_channels - 1
+        self.lap_reg = nn.Sequential(nn.Conv2d(dim_reg, dim_reg, 3, 1, 1, groups=dim_reg),
+                                     nn.Conv2d(dim_reg, dim_reg, 3, 1, 1, groups=dim_reg))
+        self.lap_map = nn.Sequential(nn.Conv2d(1, 1, 3, 1, 1), nn.BatchNorm2d(1, 1), nn.Conv2d(1, 1, 3, 1, 1), nn.Sigmoid())
+        self.tau = nn.Parameter(torch.ones(1) * 100)             # unused by the loss (reference reg.py:77,119)
+        self.emb_list = None
+        self.tgt_list = None
+
+    def forward(self, x):
+        return self.base(x)
+
+    # ------------------------------------------------------------------ feature polarization (reference reg.py:86-105)
+    def regular_udh(self, pred, true, tau=5):
+        lab = as_label_index(true)
+        logits = as_nhwc(pred)
+        los = 0
+        for feat in self.base.feats:
+            f = as_nhwc(feat)
+            l, pro = ops.fpl(f, logits, lab, self.fcp.buf_grad)
+            los = los + l
+            self.emb_list = [pro[i] for i in range(pro.shape[0])]
+            self.tgt_list = [self.fcp.choice(pro[i], i) for i in range(pro.shape[0])]
+        return los
+
+    # ------------------------------------------------------------------ boundary regression (reference reg.py:109-156)
+    def _lap_reg(self, x):
+        x = ops.dwconv3x3(x, self.lap_reg[0].weight, self.lap_reg[0].bias)
+        return ops.act(ops.dwconv3x3(x, self.lap_reg[1].weight, self.lap_reg[1].bias), 'abs')
+
+    def _lap_map(self, x):
+        bn = self.lap_map[1]
+        x = ops.dwconv3x3(x, self.lap_map[0].weight, self.lap_map[0].bias)
+        x = ops.batchnorm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, eps=bn.eps,
+                          momentum=bn.momentum, training=bn.training)
+        return ops.act(ops.dwconv3x3(x, self.lap_map[2].weight, self.lap_map[2].bias), 'sigmoid')
+
+    def regular_reg(self, pred, true, tau=100, noise=None):
+        """noise: optional (eps_pred [B,4,H,W], eps_true [B,4,H,W], jit_true [1,1,H,1], jit_pred [1,1,H,1]) U(0,1) draws in
+        the reference's order; drawn on the device when omitted."""
+        lab = as_label_index(true)
+        logits = as_nhwc(pred)
+        B, H, W, C = logits.shape
+        n = C - 1
+        dev = logits.device
+        if noise is None:
+            eps_p = torch.rand((B, H, W, n), device=dev)
+            eps_t = torch.rand((B, H, W, n), device=dev)
+            jit_t = torch.rand(H, device=dev)
+            jit_p = torch.rand(H, device=dev)
+        else:
+            eps_p, eps_t = (e.to(dev, torch.float32).permute(0, 2, 3, 1).contiguous() for e in noise[:2])
+            jit_t, jit_p = (j.to(dev, torch.float32).reshape(H).contiguous() for j in noise[2:])
+        x_pred = ops.slice_channels_f32(logits, 1, n)                 # pred[:,1:]
+        x_true, prob_true = ops.label_planes(lab, 1, n)               # true[:,1:].float(), |d/dh| edge map
+        m_pred = self._lap_map(ops.gumbel_colsoftmax_sum(self._lap_reg(x_pred), eps_p))
+        m_true = self._lap_map(ops.gumbel_colsoftmax_sum(self._lap_reg(x_true), eps_t))
+        RegNet.tmp['reg_pred'] = m_pred[0].detach().permute(2, 0, 1).unsqueeze(1)
+        RegNet.tmp['reg_true'] = prob_true[0].permute(2, 0, 1).unsqueeze(1)
+        idx = torch.arange(0, H, device=dev, dtype=torch.float32)
+        wt = ((idx + jit_t - 0.5) / H).contiguous()
+        wp = ((idx + jit_p - 0.5) / H).contiguous()
+        edge_true = ops.colwsum(m_true, wt)
+        edge_pred = ops.colwsum(m_pred, wp)
+        self.edge_pred, self.edge_true = edge_pred.detach(), edge_true.detach()      # boundary coordinate per column
+        los_edge = ops.mse(edge_pred, edge_true.detach()) + ops.mse(edge_pred.detach(), edge_true)
+        los_prob = ops.mse(prob_true, ops.colsoftmax(m_true)) + ops.mse(prob_true, ops.colsoftmax(m_pred))
+        return los_edge + los_prob

@@ -1,0 +1,417 @@
+"""`stc_tt` ("TCCT"): CrossResNet(tiny) + MPViT(tiny, pooling token mixer) + FTC fusion/decoder, MI355X-native.
+
+Drop-in for the reference's model factory (reference nets/tcct.py:1090-1096): same factory names, same attribute
+names (`base_cnn`, `base_vit`, `feats`), same state_dict keys/shapes (checked against tests/golden/state_dict_keys.json)
+and the same forward contract `model(x[B,3,H,W]) -> [y0,y1,y2,y4]` of `[B,n_class,H,W]` logits — but every op is a
+HIP kernel on NHWC tensors (tcct_amd.ops); `nn.Conv2d/BatchNorm2d/LayerNorm/Linear` objects are used only as
+parameter holders (their forward is never called).  Returned logits / feats are NCHW-shaped *views* of NHWC memory.
+
+Reference call sites are cited per method (paths relative to /root/reference/task1).
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+from .._lib import TcctError
+
+KSIZES = (13, 11, 9, 7, 5)
+
+
+def _conv(m, x, out_dtype=None):
+    return ops.conv2d(x, m.weight, m.bias, stride=m.stride[0], pad=tuple(m.padding), out_dtype=out_dtype)
+
+
+def _dw(m, x, add_input=False):
+    return ops.dwconv3x3(x, m.weight, m.bias, stride=m.stride[0], add_input=add_input)
+
+
+def _bn(m, x, pre=None, post=None):
+    return ops.batchnorm(x, m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked, eps=m.eps,
+                         momentum=m.momentum, pre_act=pre, post_act=post, training=m.training)
+
+
+def _nchw_view(y):
+    return y.permute(0, 3, 1, 2)
+
+
+# --------------------------------------------------------------------------------------------- CNN branch
+class CrossCNNBlock(nn.Module):
+    """reference nets/tcct.py:803-828: gelu(block12(x)+block34(x)) -> block5; conv->conv->LeakyReLU->BN ordering."""
+
+    def __init__(self, in_c, out_c, ksize):
+        super().__init__()
+        self.block12 = nn.Sequential(nn.Conv2d(in_c, out_c, 3, padding=1), nn.Conv2d(out_c, out_c, 3, padding=1),
+                                     nn.LeakyReLU(), nn.BatchNorm2d(out_c))
+        self.block34 = nn.Sequential(nn.Conv2d(in_c, out_c, (1, ksize), padding=(0, ksize // 2)),
+                                     nn.Conv2d(out_c, out_c, (ksize, 1), padding=(ksize // 2, 0)),
+                                     nn.Conv2d(out_c, out_c, 3, padding=1), nn.LeakyReLU(), nn.BatchNorm2d(out_c))
+        self.block5 = nn.Sequential(nn.Conv2d(out_c, out_c, 3, padding=1), nn.LeakyReLU(), nn.BatchNorm2d(out_c))
+
+    def forward(self, x):
+        a = _conv(self.block12[1], _conv(self.block12[0], x))
+        a = _bn(self.block12[3], a, pre='lrelu')
+        b = _conv(self.block34[2], _conv(self.block34[1], _conv(self.block34[0], x)))
+        b = _bn(self.block34[4], b, pre='lrelu')
+        c = ops.add_act(a, b, 'gelu')
+        return _bn(self.block5[2], _conv(self.block5[0], c), pre='lrelu')
+
+
+class CrossResNet(nn.Module):
+    """reference nets/tcct.py:857-885 (flag_tiny widths 32x5, ksizes 13/11/9/7/5)."""
+    __name__ = 'crnet'
+
+    def __init__(self, in_ch=3, flag_tiny=True):
+        super().__init__()
+        if not flag_tiny:
+            raise TcctError('only the flag_tiny=True CrossResNet of stc_tt is on the hot path')
+        layers = (32, 32, 32, 32, 32)
+        self.layer_dims = layers
+        self.pool = nn.MaxPool2d(kernel_size=2)
+        self.path_estan = nn.ModuleList([CrossCNNBlock(layers[0], layers[0], KSIZES[0])])
+        for i in range(len(layers) - 1):
+            self.path_estan.append(CrossCNNBlock(layers[i], layers[i + 1], KSIZES[i + 1]))
+        self.cnn = nn.Sequential(nn.Conv2d(3, layers[0], 3, 1, 1), nn.BatchNorm2d(layers[0]))
+
+    def forward(self, x):
+        """x: NHWC [B,H,W,4] (3 image channels + zero pad)."""
+        xs = []
+        x = _bn(self.cnn[1], _conv(self.cnn[0], x))
+        n = len(self.path_estan)
+        for i, enc in enumerate(self.path_estan):
+            x = enc(x)
+            xs.append(x)
+            if i + 1 < n:               # the reference also pools after the last level; that result is unused
+                x = ops.maxpool2(x)
+        return xs
+
+
+# --------------------------------------------------------------------------------------------- ViT branch
+class Conv2d_BN(nn.Module):
+    """reference nets/tcct.py:55-97"""
+
+    def __init__(self, in_ch, out_ch, kernel_size=1, stride=1, pad=0, act=False):
+        super().__init__()
+        self.conv = nn.Conv2d(in_ch, out_ch, kernel_size, stride, pad, bias=False)
+        self.bn = nn.BatchNorm2d(out_ch)
+        fan_out = kernel_size * kernel_size * out_ch
+        self.conv.weight.data.normal_(0.0, math.sqrt(2.0 / fan_out))
+        self.act = act
+
+    def forward(self, x):
+        return _bn(self.bn, _conv(self.conv, x), post='hswish' if self.act else None)
+
+
+class DWConv2d_BN(nn.Module):
+    """reference nets/tcct.py:99-147: dw3x3 -> pw1x1 -> BN -> Hardswish"""
+
+    def __init__(self, in_ch, out_ch, kernel_size=3, stride=1):
+        super().__init__()
+        self.dwconv = nn.Conv2d(in_ch, out_ch, kernel_size, stride, (kernel_size - 1) // 2, groups=out_ch, bias=False)
+        self.pwconv = nn.Conv2d(out_ch, out_ch, 1, 1, 0, bias=False)
+        self.bn = nn.BatchNorm2d(out_ch)
+        for m in (self.dwconv, self.pwconv):
+            n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+            m.weight.data.normal_(0, math.sqrt(2.0 / n))
+
+    def forward(self, x):
+        return _bn(self.bn, _conv(self.pwconv, _dw(self.dwconv, x)), post='hswish')
+
+
+class DWCPatchEmbed(nn.Module):
+    """reference nets/tcct.py:149-171"""
+
+    def __init__(self, embed_dim, stride):
+        super().__init__()
+        self.patch_conv = DWConv2d_BN(embed_dim, embed_dim, 3, stride)
+
+    def forward(self, x):
+        return self.patch_conv(x)
+
+
+class Patch_Embed_stage(nn.Module):
+    """reference nets/tcct.py:173-195 (num_path = 1)"""
+
+    def __init__(self, embed_dim, isPool=False):
+        super().__init__()
+        self.patch_embeds = nn.ModuleList([DWCPatchEmbed(embed_dim, 2 if isPool else 1)])
+
+    def forward(self, x):
+        return self.patch_embeds[0](x)
+
+
+class ConvPosEnc(nn.Module):
+    """reference nets/tcct.py:197-217"""
+
+    def __init__(self, dim, k=3):
+        super().__init__()
+        self.proj = nn.Conv2d(dim, dim, k, 1, k // 2, groups=dim)
+
+
+class ConvRelPosEnc(nn.Module):
+    """reference nets/tcct.py:219-287 — parameters only (never executed by stc_tt; kept for checkpoint parity)."""
+
+    def __init__(self, Ch, h, window):
+        super().__init__()
+        self.conv_list = nn.ModuleList()
+        for k, split in window.items():
+            self.conv_list.append(nn.Conv2d(split * Ch, split * Ch, (k, k), padding=(k // 2, k // 2), groups=split * Ch))
+
+
+class Mlp(nn.Module):
+    """reference nets/tcct.py:29-53"""
+
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class MHCABlock(nn.Module):
+    """reference nets/tcct.py:417-469 with `att = MetaPool()` (tcct.py:449): cpe -> x+dp(pool(LN1 x)) -> x+dp(mlp(LN2 x))"""
+
+    def __init__(self, dim, mlp_ratio, drop_path, shared_cpe, shared_crpe):
+        super().__init__()
+        self.cpe = shared_cpe
+        self.crpe = shared_crpe
+        self.mlp = Mlp(dim, dim * mlp_ratio)
+        self.drop_prob = float(drop_path)
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+
+    def forward(self, x, scales):
+        """x: NHWC image [B,H,W,C] == tokens [B,N,C]; scales: None or (s1,s2) fp32 [B] DropPath mask/keep."""
+        B, H, W, C = x.shape
+        x = _dw(self.cpe.proj, x, add_input=True)
+        t = x.view(B, H * W, C)
+        s1, s2 = scales if scales is not None else (None, None)
+        cur = ops.layernorm(t, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        t = ops.residual(t, ops.metapool(cur), s1)
+        cur = ops.layernorm(t, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        h = ops.act(ops.conv2d(cur, self.mlp.fc1.weight, self.mlp.fc1.bias), 'gelu')
+        t = ops.residual(t, ops.conv2d(h, self.mlp.fc2.weight, self.mlp.fc2.bias), s2)
+        return t.view(B, H, W, C)
+
+
+class MHCAEncoder(nn.Module):
+    """reference nets/tcct.py:471-516 (num_layers = 1)"""
+
+    def __init__(self, dim, num_heads, mlp_ratio, drop_path):
+        super().__init__()
+        self.cpe = ConvPosEnc(dim, k=3)
+        self.crpe = ConvRelPosEnc(Ch=dim // num_heads, h=num_heads, window={3: 2, 5: 3, 7: 3})
+        self.MHCA_layers = nn.ModuleList([MHCABlock(dim, mlp_ratio, drop_path, self.cpe, self.crpe)])
+
+    def forward(self, x, scales):
+        return self.MHCA_layers[0](x, scales)
+
+
+class ResBlock(nn.Module):
+    """reference nets/tcct.py:518-572 (InvRes)"""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.conv1 = Conv2d_BN(dim, dim, act=True)
+        self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=False, groups=dim)
+        self.norm = nn.BatchNorm2d(dim)
+        self.conv2 = Conv2d_BN(dim, dim)
+        for m in (self.conv1.conv, self.dwconv, self.conv2.conv):
+            fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
+            m.weight.data.normal_(0, math.sqrt(2.0 / fan_out))
+
+    def forward(self, x):
+        f = self.conv1(x)
+        f = _bn(self.norm, _dw(self.dwconv, f), post='hswish')
+        return ops.add(x, self.conv2(f))
+
+
+class MHCA_stage(nn.Module):
+    """reference nets/tcct.py:574-616 (num_path = 1): cat[InvRes(x), Encoder(x)] -> 1x1 -> BN -> Hardswish"""
+
+    def __init__(self, embed_dim, out_embed_dim, num_heads, mlp_ratio, drop_path):
+        super().__init__()
+        self.mhca_blks = nn.ModuleList([MHCAEncoder(embed_dim, num_heads, mlp_ratio, drop_path)])
+        self.InvRes = ResBlock(embed_dim)
+        self.aggregate = Conv2d_BN(embed_dim * 2, out_embed_dim, act=True)
+
+    def forward(self, x, scales):
+        r = self.InvRes(x)
+        e = self.mhca_blks[0](x, scales)
+        return self.aggregate(ops.concat2(r, e))
+
+
+class Cls_head(nn.Module):
+    """reference nets/tcct.py:618-633 — parameters only (MPViT.forward is not on the path)."""
+
+    def __init__(self, embed_dim, num_classes):
+        super().__init__()
+        self.cls = nn.Linear(embed_dim, num_classes)
+
+
+class MPViT(nn.Module):
+    """reference nets/tcct.py:649-753, configuration of mpvit_tiny (tcct.py:766-776)."""
+    __name__ = 'mpvit'
+
+    def __init__(self, embed_dims=(64, 96, 128, 160), mlp_ratios=(1, 1, 1, 1), num_heads=(4, 4, 4, 4),
+                 drop_path_rate=0.1, num_classes=1000):
+        super().__init__()
+        self.num_stages = 4
+        self.embed_dims = list(embed_dims)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, 4)]
+        self.drop_probs = dpr
+        self.stem = nn.Sequential(Conv2d_BN(3, embed_dims[0] // 2, 3, 2, 1, act=True),
+                                  Conv2d_BN(embed_dims[0] // 2, embed_dims[0], 3, 1, 1, act=True))
+        self.patch_embed_stages = nn.ModuleList([Patch_Embed_stage(embed_dims[i], isPool=i > 0) for i in range(4)])
+        self.mhca_stages = nn.ModuleList([
+            MHCA_stage(embed_dims[i], embed_dims[i + 1] if i + 1 < 4 else embed_dims[i], num_heads[i], mlp_ratios[i],
+                       dpr[i]) for i in range(4)])
+        self.cls_head = Cls_head(embed_dims[-1], num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+        self.forced_dp_masks = None     # list of 6 [B] 0/1 tensors (draw order of the reference) for parity tests
+
+    def _dp_scales(self, B, device):
+        """DropPath (timm, reference tcct.py:452,465,468): per-sample Bernoulli(keep)/keep, train mode only."""
+        out = []
+        forced = list(self.forced_dp_masks) if self.forced_dp_masks is not None else None
+        for s in range(4):
+            p = self.drop_probs[s]
+            if p == 0.0 or not self.training:
+                out.append(None)
+                continue
+            pair = []
+            for _ in range(2):
+                if forced is not None:
+                    m = forced.pop(0).to(device=device, dtype=torch.float32)
+                else:
+                    m = torch.empty(B, device=device, dtype=torch.float32).bernoulli_(1 - p)
+                pair.append((m / (1 - p)).contiguous())
+            out.append(tuple(pair))
+        return out
+
+    def forward_features(self, x):
+        """x NHWC [B,H,W,4] -> [x2,x3,x4,x5] NHWC (reference tcct.py:733-745)."""
+        scales = self._dp_scales(x.shape[0], x.device)
+        x = self.stem[1](self.stem[0](x))
+        xs = []
+        for i in range(4):
+            x = self.mhca_stages[i](self.patch_embed_stages[i](x), scales[i])
+            xs.append(x)
+        return xs
+
+
+def mpvit_tiny(**kw):
+    return MPViT(**kw)
+
+
+# ------------------------------------------------------------------------------------- fusion + decoder
+class MPUpBlock(nn.Module):
+    """reference nets/tcct.py:887-914: conv3x3-BN-LeakyReLU -> x2 bilinear (align_corners=True) -> +skip -> 1x1"""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.prep = nn.Sequential(nn.Conv2d(in_ch, out_ch, 3, 1, 1), nn.BatchNorm2d(out_ch), nn.LeakyReLU(inplace=True))
+        self.post = nn.Sequential(nn.Conv2d(out_ch, out_ch, 1, 1, 0))
+
+    def forward(self, x1, x2):
+        y = _bn(self.prep[1], _conv(self.prep[0], x1), post='lrelu')
+        y = ops.bilinear(y, (x1.shape[1] * 2, x1.shape[2] * 2), True)
+        return _conv(self.post[0], ops.add(y, x2))
+
+
+class FTC(nn.Module):
+    """reference nets/tcct.py:944-1046 with SimpleFusion (flag_gate=False)."""
+    __name__ = 'gtc'
+
+    def __init__(self, base_cnn, base_vit, out_channels=5, filters=32, compute_dtype=torch.float32):
+        super().__init__()
+        self.base_vit = base_vit
+        self.base_cnn = base_cnn
+        ed, ld = base_vit.embed_dims, base_cnn.layer_dims
+        for j, cin in enumerate((ed[1], ed[2], ed[3], ed[3])):
+            setattr(self, f'tran_vit{j}', nn.Sequential(nn.Conv2d(cin, ld[j + 1], 1, 1, 0), nn.BatchNorm2d(ld[j + 1])))
+        for j in range(4):
+            setattr(self, f'tran_cnn{j}', nn.Sequential(nn.Conv2d(ld[j + 1], ld[j + 1], 1, 1, 0), nn.BatchNorm2d(ld[j + 1])))
+        self.head = nn.Sequential(nn.Conv2d(ld[-1], ld[-1], 3, 1, 1), nn.BatchNorm2d(ld[-1]), nn.LeakyReLU())
+        self.fuse = nn.Conv2d(ld[4], filters, kernel_size=1)          # never executed (reference tcct.py:982)
+        self.dec1 = MPUpBlock(ld[-1], ld[-2])
+        self.dec2 = MPUpBlock(ld[-2], ld[-3])
+        self.dec3 = MPUpBlock(ld[-3], ld[-4])
+        self.dec4 = MPUpBlock(ld[-4], filters)
+        self.t321 = nn.Conv2d(ld[-2], filters, 1)
+        self.t322 = nn.Conv2d(ld[-3], filters, 1)
+        self.t323 = nn.Conv2d(ld[-4], filters, 1)
+        self.t324 = nn.Conv2d(filters, filters, 1)
+        self.aux0 = nn.Conv2d(filters, out_channels, 1)
+        self.aux1 = nn.Conv2d(filters, out_channels, 1)
+        self.aux2 = nn.Conv2d(filters, out_channels, 1)
+        self.aux4 = nn.Conv2d(filters, out_channels, 1)
+        self.compute_dtype = compute_dtype
+        self.feats = None
+
+    def set_compute_dtype(self, dt):
+        if dt not in (torch.float32, torch.bfloat16):
+            raise TcctError('compute dtype must be float32 or bfloat16')
+        self.compute_dtype = dt
+        return self
+
+    def _to_nhwc4(self, x):
+        if x.dim() != 4 or x.shape[1] not in (1, 3):
+            raise TcctError(f'expected image batch [B,3,H,W] (or [B,1,H,W]), got {tuple(x.shape)}')
+        if not x.is_cuda:
+            raise TcctError('tcct_amd model needs a CUDA(HIP) input; there is no CPU fallback')
+        B, Cs, H, W = x.shape
+        if H % 16 or W % 16:
+            raise TcctError(f'H and W must be multiples of 16 (got {H}x{W}); pad first (see tcct_amd.data.synth)')
+        x = x.contiguous().float()
+        out = torch.empty((B, H, W, 4), device=x.device, dtype=self.compute_dtype)
+        ops.lib.image_to_nhwc4(x, out, B, Cs, H, W, W, ops.dtype_code(self.compute_dtype))
+        return out
+
+    def forward(self, x):
+        size = (x.shape[2], x.shape[3])
+        x = self._to_nhwc4(x)
+        c1, c2, c3, c4, c5 = self.base_cnn(x)
+        v2, v3, v4, v5 = self.base_vit.forward_features(x)
+        f = [c1]
+        for j, (v, c) in enumerate(((v2, c2), (v3, c3), (v4, c4), (v5, c5))):
+            tv, tc = getattr(self, f'tran_vit{j}'), getattr(self, f'tran_cnn{j}')
+            f.append(ops.add(_bn(tv[1], _conv(tv[0], v)), _bn(tc[1], _conv(tc[0], c))))
+        y8 = _bn(self.head[1], _conv(self.head[0], f[4]), post='lrelu')
+        d3 = self.dec1(y8, f[3])
+        d2 = self.dec2(d3, f[2])
+        d1 = self.dec3(d2, f[1])
+        d0 = self.dec4(d1, f[0])
+        g0 = _conv(self.t324, ops.add(f[0], d0))
+        g1 = _conv(self.t323, ops.add(f[1], d1))
+        g2 = _conv(self.t322, ops.add(f[2], d2))
+        g3 = _conv(self.t321, ops.add(f[3], d3))
+        # norm_add([y0,y1,y2]) (reference tcct.py:937-942,1035)
+        n0 = ops.l2norm(g0)
+        n1 = ops.bilinear(ops.l2norm(g1), size, False)
+        n2 = ops.bilinear(ops.l2norm(g2), size, False)
+        self.feats = [_nchw_view(ops.add3_scale(n0, n1, n2, 1.0 / 3.0))]
+        # aux heads: logits are produced and resized in fp32 in every mode (loss-side precision)
+        f32 = torch.float32
+        y0 = _conv(self.aux0, g0, out_dtype=f32)
+        y1 = ops.bilinear(_conv(self.aux1, g1, out_dtype=f32), size, False)
+        y2 = ops.bilinear(_conv(self.aux2, g2, out_dtype=f32), size, False)
+        y4 = ops.bilinear(_conv(self.aux4, g3, out_dtype=f32), size, False)
+        return [_nchw_view(y0), _nchw_view(y1), _nchw_view(y2), _nchw_view(y4)]
+
+
+def stc_tt(n_class=8, **args):
+    """reference nets/tcct.py:1090-1095"""
+    model = FTC(base_vit=mpvit_tiny(), base_cnn=CrossResNet(flag_tiny=True), out_channels=n_class,
+                compute_dtype=args.get('compute_dtype', torch.float32))
+    model.__name__ = 'stctt'
+    return model
+
+
+tcct = stc_tt

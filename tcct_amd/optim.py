@@ -1,0 +1,65 @@
+"""Flat-buffer AdamW with fused clip_grad_norm_ — the native counterpart of reference kite/loop_seg.py:128-130
+(`clip_grad_norm_(params, 12)` + `AdamW.step()`, kite/loopback.py:126-127: lr from the scheduler, wd 2e-4, betas .9/.999).
+
+All parameters that receive gradients live as views of ONE fp32 buffer; their gradients are gathered into one flat buffer
+(3.2 MB for stc_tt), optionally all-reduced across ranks (RCCL via torch.distributed, see tcct_amd/dist.py), then two HIP
+kernels do sum-of-squares and clip+AdamW.  Parameters whose `.grad is None` are skipped exactly like torch.optim.AdamW
+does (so unused parameters — crpe, cls_head, fuse, lap_epl, tau — never decay)."""
+import torch
+
+from ._lib import lib, TcctError
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=2e-4, max_norm=12.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.max_norm = float(max_norm)
+        self._flat = None            # (plist, flat_p, flat_g, m, v, sumsq, total_norm)
+        self._step = 0
+        self.world = 1
+        self.allreduce = None        # callable(flat_g) -> None, set by tcct_amd.dist.attach
+        self.last_total_norm = None
+
+    def _build(self):
+        plist = [p for g in self.param_groups for p in g['params'] if p.grad is not None]
+        if not plist:
+            raise TcctError('FlatAdamW.step(): no parameter has a gradient')
+        dev = plist[0].device
+        if dev.type != 'cuda':
+            raise TcctError('FlatAdamW needs parameters on the GPU (no CPU fallback)')
+        n = sum(p.numel() for p in plist)
+        flat_p = torch.empty(n, device=dev, dtype=torch.float32)
+        off = 0
+        for p in plist:
+            k = p.numel()
+            flat_p[off:off + k].copy_(p.data.reshape(-1))
+            p.data = flat_p[off:off + k].view_as(p.data)
+            off += k
+        z = lambda: torch.zeros(n, device=dev, dtype=torch.float32)   # noqa: E731
+        self._flat = dict(plist=plist, p=flat_p, g=z(), m=z(), v=z(),
+                          sumsq=torch.zeros((), device=dev, dtype=torch.float64),
+                          norm=torch.zeros((), device=dev, dtype=torch.float32), n=n)
+
+    @property
+    def flat_numel(self):
+        return self._flat['n'] if self._flat else 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if self._flat is None:
+            self._build()
+        f = self._flat
+        for p in f['plist']:
+            if p.grad is None:
+                raise TcctError('a parameter that had a gradient at the first step has none now; the set of trained '
+                                'parameters must be static (rebuild the optimizer after changing loss flags)')
+        torch.cat([p.grad.reshape(-1) for p in f['plist']], out=f['g'])
+        if self.allreduce is not None:
+            self.allreduce(f['g'])
+        self._step += 1
+        g0 = self.param_groups[0]
+        lib.grad_sumsq(f['g'], f['n'], f['sumsq'])
+        lib.clip_adamw(f['p'], f['g'], f['m'], f['v'], f['n'], f['sumsq'], self.max_norm, 1.0 / self.world, float(g0['lr']),
+                       float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']), float(g0['weight_decay']),
+                       self._step, f['norm'])
+        self.last_total_norm = f['norm']
