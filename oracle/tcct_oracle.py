@@ -217,7 +217,7 @@ def reg_loss(sd, logits, onehot, eps_pred, eps_true, jit_true, jit_pred, train=T
     """RegNet.regular_reg nets/reg.py:109-156.  Explicit noise (reference draw order reg.py:120 x2 via
     :128-129, then :147-148): eps_pred, eps_true ~U(0,1) [B,4,H,W]; jit_true, jit_pred ~U(0,1) [1,1,H,1]."""
     pred = logits[:, 1:]
-    true = onehot[:, 1:].float()
+    true = onehot[:, 1:].to(pred.dtype)      # .float() in the reference (fp32 path); dtype-generic for fp64 checks
     H = pred.shape[2]
     prob_true = F.pad((true[:, :, 1:] - true[:, :, :-1]).abs(), (0, 0, 1, 0))
     prob_true = prob_true.sum(1, keepdim=True).clamp_max(1)
@@ -237,7 +237,7 @@ def reg_loss(sd, logits, onehot, eps_pred, eps_true, jit_true, jit_pred, train=T
 
     m_pred = lap_map(sampling_softmax(lap_reg(pred), eps_pred).sum(1, keepdim=True))
     m_true = lap_map(sampling_softmax(lap_reg(true), eps_true).sum(1, keepdim=True))
-    idx = torch.arange(0, H, dtype=torch.float32).reshape(1, 1, -1, 1)
+    idx = torch.arange(0, H, dtype=pred.dtype).reshape(1, 1, -1, 1)
     edge_true = (m_true * (idx + jit_true - 0.5)).sum(-2) / H
     edge_pred = (m_pred * (idx + jit_pred - 0.5)).sum(-2) / H
     los_edge = F.mse_loss(edge_pred, edge_true.detach()) + F.mse_loss(edge_pred.detach(), edge_true)

@@ -265,3 +265,83 @@ def test_softmax_dice(dt):
     (ld * 0.7).backward()
     t = tol(dt)
     torch.testing.assert_close(nchw(xd.grad), x.grad, rtol=t['rtol'], atol=1e-6 if dt == torch.float32 else 1e-4)
+
+
+def test_clip_adamw():
+    """fused clip_grad_norm_(12)+AdamW kernel vs torch.optim.AdamW + clip_grad_norm_ on CPU, 3 steps, flat buffers"""
+    from tcct_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(0)
+    shapes = [(32, 32, 3, 3), (32,), (5, 32, 1, 1), (160, 320)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    pd = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ps]
+    ref = torch.optim.AdamW(ps, lr=3e-3, weight_decay=2e-4)
+    opt = FlatAdamW(pd, lr=3e-3, weight_decay=2e-4, max_norm=12.0)
+    for step in range(3):
+        for p, q in zip(ps, pd):
+            gr = torch.randn(p.shape, generator=g) * (20.0 if step == 0 else 0.01)    # step 0 clips, later ones do not
+            p.grad = gr.clone()
+            q.grad = gr.clone().cuda()
+        tn = torch.nn.utils.clip_grad_norm_(ps, 12)
+        ref.step()
+        opt.step()
+        torch.testing.assert_close(opt.last_total_norm.cpu(), tn, rtol=1e-5, atol=1e-6)
+        for p, q in zip(ps, pd):
+            torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_fpl_matches_oracle():
+    """fused FPL (sort + bin means + loss + backward) vs the oracle on a size where bins hold ~190 pixels"""
+    from tcct_amd import ops
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    import tcct_oracle as O
+    B, H, W, C = 2, 96, 160, 5
+    _, lab = O.synth_batch(B, H, W, seed=5)
+    g = torch.Generator().manual_seed(1)
+    feats = torch.randn(B, 32, H, W, generator=g).requires_grad_(True)
+    logits = torch.randn(B, C, H, W, generator=g) * 2
+    buf = F.normalize(torch.rand(C, 32, generator=g), dim=-1)
+    oh = F.one_hot(lab, C).permute(0, 3, 1, 2)
+    want = {}
+    los = O.fpl_loss({'fcp.buf_grad': buf}, feats, logits, oh, want)
+    (los * 1.3).backward()
+    fd = nhwc(feats.detach(), torch.float32).requires_grad_(True)
+    ld, pro = ops.fpl(fd, nhwc(logits, torch.float32), lab.to(torch.uint8).cuda(), buf.cuda())
+    torch.testing.assert_close(ld.cpu(), los.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(pro.cpu(), want['emb'].detach(), rtol=1e-4, atol=1e-5)
+    (ld * 1.3).backward()
+    torch.testing.assert_close(nchw(fd.grad), feats.grad, rtol=1e-4, atol=1e-9)
+
+
+def test_reg_loss_matches_oracle():
+    """boundary-regression loss (fp32 pipeline) vs the oracle incl. gradients to logits and lap_* parameters"""
+    import sys, os, json
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    import tcct_oracle as O
+    from tcct_amd.nets import RegNet
+    B, H, W, C = 2, 48, 64, 5
+    _, lab = O.synth_batch(B, H, W, seed=7)
+    g = torch.Generator().manual_seed(2)
+    logits = (torch.randn(B, C, H, W, generator=g) * 2).requires_grad_(True)
+    noise = (torch.rand(B, 4, H, W, generator=g), torch.rand(B, 4, H, W, generator=g), torch.rand(1, 1, H, 1, generator=g),
+             torch.rand(1, 1, H, 1, generator=g))
+
+    class Base(torch.nn.Module):
+        __name__ = 'b'
+    m = RegNet(Base(), out_channels=5, con='cos').cuda().train()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    pn = [n for n, _ in m.named_parameters() if n.startswith('lap_reg') or n.startswith('lap_map')]
+    for n in pn:
+        sd[n].requires_grad_(True)
+    oh = F.one_hot(lab, C).permute(0, 3, 1, 2)
+    los = O.reg_loss(sd, logits, oh, *noise)
+    los.backward()
+    lg = nhwc(logits.detach(), torch.float32).requires_grad_(True)
+    ld = m.regular_reg(lg.permute(0, 3, 1, 2), lab.cuda(), noise=noise)
+    torch.testing.assert_close(ld.cpu(), los.detach(), rtol=1e-5, atol=1e-7)
+    ld.backward()
+    torch.testing.assert_close(nchw(lg.grad), logits.grad, rtol=1e-3, atol=1e-9)
+    named = dict(m.named_parameters())
+    for n in pn:
+        torch.testing.assert_close(named[n].grad.cpu(), sd[n].grad, rtol=2e-3, atol=1e-6)   # lap_map.0.bias feeds a BN: true grad 0
+    torch.testing.assert_close(m.lap_map[1].running_var.cpu(), sd['lap_map.1.running_var'], rtol=1e-5, atol=1e-7)
