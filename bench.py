@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py — TCCT `stc_tt` training hot path on MI355X: OCT B-scans/s, forward + losses + backward + clip + AdamW.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one pass of the hot path over one synthetic minibatch of `--bs` B-scans (1x800x1100 each, already resident in
+HBM; loader-side prep = 1->3 channel replicate inside the NHWC conversion kernel + W zero-pad 1100->1104).  Workload at
+N=1 = BASELINE.json configs[1]: `stc_tt --los=di bs=8 1x800x1100 bf16`; other configs via --los=di+reg / di+reg+fpl.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed) and
+`cpu_baseline` (the oracle = CPU port of the reference path, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=10)
+    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--bs', type=int, default=8, help='per-GPU minibatch (weak scaling: global = bs * gpus)')
+    p.add_argument('--height', type=int, default=800)
+    p.add_argument('--width', type=int, default=1100)
+    p.add_argument('--los', type=str, default='di', help="di | di+reg | di+reg+fpl")
+    p.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'fp32'])
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-roofline', action='store_true')
+    return p.parse_args()
+
+
+def build_trainer(a, world):
+    from tcct_amd.kite.main import parse_args
+    from tcct_amd.data import SynthOCT
+    from tcct_amd import nets
+    from tcct_amd.kite.loop_seg import KiteSeg
+    args = parse_args([f'--los={a.los}', f'--bs={a.bs}', '--db=synth', f'--pl={"true" if world > 1 else "false"}',
+                       f'--dtype={a.dtype}', '--root=/tmp/tcct_bench_root'])
+    ds = SynthOCT(height=a.height, width=a.width, device='cuda')
+    net = nets.stc_tt(ds.out_channels, compute_dtype=torch.bfloat16 if a.dtype == 'bf16' else torch.float32)
+    net = nets.RegNet(net, con=args.type_udh, out_channels=ds.out_channels)
+    k = KiteSeg(model=net, dataset=ds, root=args.root, args=args)
+    return k, ds, args
+
+
+def dominant_kernel_roofline(a, iters=10):
+    """HIP-event timing of the dominant kernel of the step at the bench shapes, on the stream it is launched on (torch's
+    current stream == the stream every tcct_* call receives).  Dominant kernel (profiles/): the dense 3x3 32->32
+    convolution at level 0 ([bs,800,1104,32]).  Algorithmic bytes per launch = read x once + write y once
+    (SURVEY §8(d) layer-granular model) = 2 * bs*H*W*32 * sizeof(dtype); weights (36 KB) are noise."""
+    from tcct_amd import ops
+    dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+    Wp = (a.width + 15) // 16 * 16
+    x = torch.randn((a.bs, a.height, Wp, 32), device='cuda', dtype=torch.float32).to(dt)
+    w = torch.randn((32, 32, 3, 3), device='cuda') * 0.06
+    b = torch.zeros(32, device='cuda')
+    with torch.no_grad():
+        for _ in range(2):
+            ops.conv2d(x, w, b, 1, 1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.conv2d(x, w, b, 1, 1)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    bytes_alg = 2.0 * x.numel() * x.element_size()
+    ach = bytes_alg / (ms * 1e-3) / 1e9
+    flops = 2.0 * 9 * 32 * 32 * a.bs * a.height * Wp
+    return {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+            'traffic': None, 'kernel': 'conv2d_fwd 3x3 32->32 @L0', 'ms_per_launch': round(ms, 4),
+            'algorithmic_bytes': int(bytes_alg), 'tflops': round(flops / (ms * 1e-3) / 1e12, 2)}
+
+
+def cpu_baseline(a):
+    """oracle (CPU port of the reference path, pinned to the reference by tests/golden) on the host cores: ONE full step
+    (fwd + Dice deep supervision [+reg+fpl] + bwd + clip + AdamW) on ONE full-size B-scan (3x800x1104 fp32)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import tcct_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    keys = [(k, tuple(s)) for k, s in json.load(open(os.path.join(ROOT, 'tests', 'golden', 'state_dict_keys.json')))]
+    sd = O.formula_state_dict(keys)
+    Wp = (a.width + 15) // 16 * 16
+    img, lab = O.synth_batch(1, a.height, Wp, seed=2023)
+    oh = torch.nn.functional.one_hot(lab, 5).permute(0, 3, 1, 2)
+    udh, reg = 'fpl' in a.los or 'udh' in a.los, 'reg' in a.los
+    names = [k for k, v in sd.items() if v.is_floating_point() and not k.endswith(('running_mean', 'running_var'))
+             and not k.startswith('fcp.')]        # unused parameters simply end up with grad None
+    for n in names:
+        sd[n].requires_grad_(True)
+    noise = None
+    if reg:
+        noise = (torch.rand(1, 4, a.height, Wp), torch.rand(1, 4, a.height, Wp), torch.rand(1, 1, a.height, 1), torch.rand(1, 1, a.height, 1))
+    t0 = time.time()
+    tot, _, _, _ = O.total_loss(sd, img, oh, udh=udh, reg=reg, noise=noise)
+    tot.backward()
+    P = [sd[n] for n in names if sd[n].grad is not None]
+    G = [p.grad for p in P]
+    M = [torch.zeros_like(p) for p in P]
+    V = [torch.zeros_like(p) for p in P]
+    O.clip_adamw_step(P, G, M, V, 1, 1e-6)
+    dt = time.time() - t0
+    return {'value': round(1.0 / dt, 4), 'unit': 'B-scans/s', 'cores': cores, 'kind': 'port',
+            'sample': f'1 step, bs=1, 3x{a.height}x{Wp} fp32, --los={a.los} (oracle/tcct_oracle.py, torch CPU {torch.__version__}), {dt:.1f}s'}
+
+
+def main():
+    a = parse()
+    from tcct_amd import dist as tdist
+    world, rank, local = tdist.env_world()
+    if world != a.gpus and world > 1:
+        raise SystemExit(f'--gpus={a.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X')
+    torch.cuda.set_device(local)
+    k, ds, args = build_trainer(a, world)
+    k.model.train()
+    batch = ds.make_batch(a.bs, seed=2023 + rank)
+    img, lab, _, _ = ds.parse(batch)
+    img, lab = img.contiguous(), lab.contiguous()
+    torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        k.train_step(img, lab)
+    torch.cuda.synchronize()
+    tdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(a.steps):
+        loss = k.train_step(img, lab)
+    torch.cuda.synchronize()
+    tdist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = tdist.max_over_ranks(dt, torch.device('cuda', local))
+    lossv = float(loss.item())
+    if rank != 0:
+        return
+    value = a.bs * world * a.steps / dt
+    out = {
+        'metric': 'OCT B-scans/sec fwd+bwd(+clip+AdamW), stc_tt bs=8 1x800x1100', 'value': round(value, 3), 'unit': 'B-scans/s',
+        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+        'config': {'workload': f'stc_tt --los={a.los} bs={a.bs}/GPU 1x{a.height}x{a.width} (net tensors 3x{a.height}x{(a.width + 15) // 16 * 16})',
+                   'global_batch': a.bs * world, 'parallelism': f'dp{world}', 'loss_last': round(lossv, 4),
+                   'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2**30, 2)},
+    }
+    if not a.no_roofline:
+        out['roofline'] = dominant_kernel_roofline(a)
+        # whole-step view against the layer-granular traffic model of SURVEY §8(d): 7.38 GB (bf16) / 14.8 GB (fp32) per B-scan
+        per_img = 7.38e9 if a.dtype == 'bf16' else 14.8e9
+        out['roofline']['step_model_GBs'] = round(per_img * value / world / 1e9, 1)
+    if world == 1 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(a)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,142 @@
+"""CPU: C-ABI library loads and exports every declared symbol; host-side mirror (state_dict keys, CLI, dataset protocol);
+the product path refuses to run without a GPU; data-parallel plumbing over gloo (world_size 2)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_library_exports_every_declared_symbol():
+    from tcct_amd._lib import lib, parse_header
+    protos = parse_header()
+    assert len(protos) >= 60
+    dll = lib.load()
+    for name in protos:
+        assert hasattr(dll, name), name
+    assert dll.tcct_version() >= 100
+    # every prototype in the header is extern "C" int / int64_t / const char*; argument parsing keeps arity
+    assert len(protos['tcct_conv2d_fwd'][1]) == 18
+    assert len(protos['tcct_clip_adamw'][1]) == 16
+
+
+def test_build_entry_point_is_idempotent():
+    import __graft_entry__ as g
+    g.build()
+
+
+def test_state_dict_keys_match_reference():
+    from tcct_amd.nets import stc_tt, RegNet, tcct
+    assert tcct is stc_tt
+    m = RegNet(stc_tt(5), con='cos', out_channels=5)
+    ref = {k: tuple(s) for k, s in json.load(open(os.path.join(HERE, 'golden', 'state_dict_keys.json')))}
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert mine == ref
+    assert sum(p.numel() for p in m.base.parameters()) == 992028
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 992187
+    assert m.__name__ == 'stctt' and hasattr(m.base, 'base_cnn') and hasattr(m.base, 'base_vit')
+    # shared ConvPosEnc aliases (reference tcct.py:491-505)
+    st = m.base.base_vit.mhca_stages[0].mhca_blks[0]
+    assert st.cpe is st.MHCA_layers[0].cpe
+    # loading a reference-keyed checkpoint works with strict=True
+    m.load_state_dict({k: torch.zeros(s) if 'num_batches' not in k else torch.zeros((), dtype=torch.int64) for k, s in ref.items()}, strict=True)
+
+
+def test_product_path_has_no_cpu_fallback():
+    from tcct_amd.nets import stc_tt
+    from tcct_amd._lib import TcctError
+    m = stc_tt(5)
+    with pytest.raises(TcctError):
+        m(torch.zeros(1, 3, 32, 32))
+    from tcct_amd import ops
+    with pytest.raises(TcctError):
+        ops.act(torch.zeros(4, 4), 'gelu')
+    # and the package never imports the oracle
+    src = subprocess.run(['grep', '-rl', 'tcct_oracle', os.path.join(ROOT, 'tcct_amd')], capture_output=True, text=True).stdout
+    assert src.strip() == ''
+
+
+def test_cli_flags_match_reference_surface():
+    from tcct_amd.kite.main import parse_args, build_parser, str2bool
+    a = parse_args([])
+    for f in ('db lr wd inc gpu los net pth bs epochs root resume reg coff_reg epl coff_epl udh coff_udh type_udh ds coff_ds '
+              'pl bug').split():
+        assert hasattr(a, f), f
+    assert (a.coff_reg, a.coff_udh, a.coff_ds, a.type_udh, a.net) == (0.1, 1, 1, 'cos', 'stc_tt')
+    b = parse_args(['--los=di+reg+fpl', '--bs=8', '--pl=true'])
+    assert b.los == 'di' and b.reg and b.udh and b.pl and b.bs == 8
+    assert str2bool('Yes') and not str2bool('0')
+    import argparse
+    with pytest.raises(argparse.ArgumentTypeError):
+        str2bool('maybe')
+    assert isinstance(build_parser(), argparse.ArgumentParser)
+
+
+def test_synthetic_dataset_protocol():
+    from tcct_amd.data import EyeSetGenerator
+    ds = EyeSetGenerator('synth', height=64, width=100, device='cpu', n_train=4)
+    assert ds.out_channels == 5
+    batches = list(ds.trainSet(bs=2))
+    assert len(batches) == 2
+    img, lab, tag, _ = ds.parse(batches[0])
+    assert img.shape == (2, 1, 64, 112) and lab.shape == (2, 64, 112) and lab.dtype == torch.int64
+    assert 0 <= img.min() and img.max() < 1 and len(tag) == 2
+    assert (img[..., 100:] == 0).all() and (lab[..., 100:] == 0).all()
+    for c in range(5):
+        assert (batches[0]['lab'] == c).sum() > 32 * 2
+    # deterministic in the seed
+    assert torch.equal(ds.make_batch(2, 7)['lab'], ds.make_batch(2, 7)['lab'])
+
+
+def test_lazy_mask_and_loss_factory():
+    from tcct_amd.kite.losses import get_loss, MaskOneHot
+    from tcct_amd._lib import TcctError
+    crit = get_loss('di')
+    assert crit.__class__.__name__ == 'MultiLoss'
+    with pytest.raises(TcctError):
+        get_loss('ce')
+    m = MaskOneHot(torch.tensor([[[0, 1], [2, 4]]], dtype=torch.uint8), 5)
+    d = m.dense()
+    assert d.shape == (1, 5, 2, 2) and d.sum().item() == 4 and d[0, 4, 1, 1] == 1
+
+
+DDP_SCRIPT = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+from tcct_amd import dist as tdist
+world, rank, local = tdist.init(backend='gloo')
+assert world == 2
+# shard a global batch of 8 and all-reduce a flat "gradient" buffer; every rank must end with the sum over ranks
+sl = tdist.shard_batch(8, world, rank)
+assert (sl.start, sl.stop) == (rank * 4, rank * 4 + 4)
+g = torch.Generator().manual_seed(123)
+per_sample = torch.randn(8, 1000, generator=g)            # identical on both ranks
+flat = per_sample[sl].sum(0).clone()
+tdist.allreduce_sum_(flat)
+assert torch.allclose(flat, per_sample.sum(0), atol=1e-5)
+# parameters broadcast from rank 0
+lin = torch.nn.Linear(4, 4)
+with torch.no_grad():
+    lin.weight.fill_(float(rank + 1))
+tdist.broadcast_params_(lin)
+assert lin.weight.eq(1.0).all()
+t = tdist.max_over_ranks(float(rank), torch.device('cpu'))
+assert t == 1.0
+tdist.barrier()
+print('rank', rank, 'ok')
+'''
+
+
+def test_data_parallel_plumbing_gloo_world2(tmp_path):
+    script = tmp_path / 'ddp.py'
+    script.write_text(DDP_SCRIPT % ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29613', str(script)], capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'rank 0 ok' in r.stdout and 'rank 1 ok' in r.stdout

@@ -1,0 +1,111 @@
+"""CPU: the oracle (oracle/tcct_oracle.py) reproduces the fixtures generated from the real reference (tests/golden/*.npz,
+made by oracle/make_golden.py in the build container).  This pins the checker itself."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '..', 'oracle'))
+GOLD = os.path.join(HERE, 'golden')
+import tcct_oracle as O  # noqa: E402
+
+
+def keys():
+    return [(k, tuple(s)) for k, s in json.load(open(os.path.join(GOLD, 'state_dict_keys.json')))]
+
+
+@pytest.mark.parametrize('name', ['full_2x32x32', 'full_2x64x64', 'di_2x64x64'])
+def test_oracle_reproduces_reference_fixture(name):
+    torch.set_num_threads(4)
+    fx = dict(np.load(os.path.join(GOLD, name + '.npz')))
+    sd = O.formula_state_dict(keys())
+    names = [str(n) for n in fx['grad_names']]
+    for n in names:
+        sd[n].requires_grad_(True)
+    img = torch.tensor(fx['img']).repeat(1, 3, 1, 1)
+    lab = torch.tensor(fx['lab']).long()
+    oh = torch.nn.functional.one_hot(lab, 5).permute(0, 3, 1, 2)
+    udh, reg = bool(fx['flags'][0]), bool(fx['flags'][1])
+    masks = [torch.tensor(m, dtype=torch.float32) for m in fx['dp_masks']] if 'dp_masks' in fx else None
+    noise = tuple(torch.tensor(fx[f'noise{i}']) for i in range(4)) if reg else None
+    want = {}
+    tot, parts, outs, feats = O.total_loss(sd, img, oh, udh=udh, reg=reg, dp_masks=masks, noise=noise, want=want)
+    H = img.shape[2]
+    sub = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4)) if H > 32 else (Ellipsis,)
+
+    def close(a, b, tol=2e-5):
+        a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+        assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+    close(outs[0], fx['out0'])
+    for i in (1, 2, 3):
+        close(outs[i][sub], fx[f'out{i}'])
+    close(feats[sub], fx['feats'])
+    close(tot, fx['loss_total'])
+    close(parts['dice'], fx['loss_dice'])
+    if udh:
+        close(parts['udh'], fx['loss_udh'])
+        close(want['emb'], fx['emb'], 1e-4)
+    if reg:
+        close(parts['reg'], fx['loss_reg'])
+        close(want['edge_pred'], fx['edge_pred'])
+        close(want['edge_true'], fx['edge_true'])
+    tot.backward()
+    have = sorted(n for n in sd if getattr(sd[n], 'grad', None) is not None)
+    assert have == sorted(names)
+    for n, l2, sm in zip(names, fx['grad_l2'], fx['grad_sum']):
+        if n.endswith('.bias') and l2 < 2e-2:        # mathematically-zero gradients (bias in front of a train-mode BN)
+            continue
+        g = sd[n].grad.double()
+        assert abs(g.norm().item() - l2) <= 1e-4 * max(1.0, l2), n
+    for key in fx:
+        if key.startswith('grad:'):
+            close(sd[key[5:]].grad, fx[key], 5e-5)
+        if key.startswith('buf:'):
+            close(sd[key[4:]].float(), fx[key].astype(np.float32), 1e-5)
+    mask = O.predict_mask(torch.tensor(fx['out0']))
+    close(O.dice_scorem(mask, oh, 1), fx['dice_scorem'], 1e-6)
+    close(O.iou_scorem(mask, oh, 1), fx['iou_scorem'], 1e-6)
+
+
+def test_oracle_known_answers():
+    """known-answer checks that need no reference"""
+    # MetaPool == 3x3 box over (token, channel) with valid-count divisor, minus identity
+    t = torch.arange(2 * 5 * 8, dtype=torch.float32).reshape(2, 5, 8)
+    y = O.metapool(t)
+    n, c = 2, 3
+    box = t[0, n - 1:n + 2, c - 1:c + 2].mean()
+    assert abs(y[0, n, c].item() - (box - t[0, n, c]).item()) < 1e-5
+    assert abs(y[1, 0, 0].item() - (t[1, 0:2, 0:2].mean() - t[1, 0, 0]).item()) < 1e-5
+    # Dice of a perfect (one-hot-certain) prediction is 0 per class; uniform softmax at init gives ~0.8 per class and head
+    lab = torch.randint(0, 5, (2, 16, 16), generator=torch.Generator().manual_seed(0))
+    oh = torch.nn.functional.one_hot(lab, 5).permute(0, 3, 1, 2)
+    assert O.dice_multi(oh.float() * 100, oh).item() < 1e-4
+    z = torch.zeros(2, 5, 16, 16)
+    assert abs(O.deep_supervision([z, z, z, z], oh).item() - 16.0) < 0.3
+    # prob_true has exactly k ones in a column with k label boundaries
+    _, lab = O.synth_batch(1, 64, 16, seed=3)
+    oh = torch.nn.functional.one_hot(lab, 5).permute(0, 3, 1, 2)
+    true = oh[:, 1:].float()
+    pt = torch.nn.functional.pad((true[:, :, 1:] - true[:, :, :-1]).abs(), (0, 0, 1, 0)).sum(1).clamp_max(1)
+    nb = (lab[:, 1:] != lab[:, :-1]).sum(1)
+    assert torch.equal(pt.sum(1).long(), nb)
+    # AdamW+clip restatement vs torch.optim.AdamW
+    g = torch.Generator().manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(7, 5, generator=g)), torch.nn.Parameter(torch.randn(11, generator=g))]
+    qs = [p.detach().clone() for p in ps]
+    M, V = [torch.zeros_like(q) for q in qs], [torch.zeros_like(q) for q in qs]
+    opt = torch.optim.AdamW(ps, lr=1e-3, weight_decay=2e-4)
+    for step in range(1, 4):
+        gr = [torch.randn(p.shape, generator=g) * 10 for p in ps]
+        for p, x in zip(ps, gr):
+            p.grad = x.clone()
+        tn = torch.nn.utils.clip_grad_norm_(ps, 12)
+        opt.step()
+        on = O.clip_adamw_step(qs, [x.clone() for x in gr], M, V, step, 1e-3)
+        assert abs(on.item() - tn.item()) < 1e-4
+        for p, q in zip(ps, qs):
+            assert (p.detach() - q).abs().max().item() < 1e-6
