@@ -102,6 +102,19 @@ int tcct_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, in
                       int Cin_w, int Cout, int KH, int KW, int stride, int padh, int padw, int x_dtype, int dy_dtype,
                       tcct_stream_t stream);
 
+/* MFMA implicit-GEMM path for the hot family: 32 -> 32 channels, stride 1, 'same' padding, bf16 NHWC, any KHxKW
+ * (the 3x3 and 1xk / kx1 cross-convolutions of CrossCNNBlock, reference nets/tcct.py:808-822, and the decoder 3x3s).
+ * wp = weights packed by tcct_conv32_pack_weights to bf16 [KH*KW][32 co][32 ci]; transposed=1 packs the flipped/transposed
+ * weights so that the same kernel computes the input gradient (dx = conv32_fwd(dy, wp_T, NULL)). */
+int tcct_conv32_pack_weights(const float* w, void* wp, int KH, int KW, int transposed, tcct_stream_t stream);
+int tcct_conv32_fwd(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
+                    int PW, tcct_stream_t stream);
+
+/* weight/bias gradient of the same family (ds_read_b64_tr_b16 transposing LDS reads feed the pixel-contraction MFMA);
+ * dw OIHW fp32 [32,32,KH,KW] and dbias fp32 [32] (nullable) are overwritten */
+int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH,
+                      int PW, tcct_stream_t stream);
+
 /* ---- depthwise 3x3 (nets/tcct.py:114-122,206,535-543; nets/reg.py:66-67,72,74 as C=1 / groups=C) -------- */
 int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
                        int stride, int add_input, int dtype, tcct_stream_t stream);

@@ -1,0 +1,321 @@
+// MFMA implicit-GEMM convolution for the hot family of the path: dense 32 -> 32 channels, stride 1, bf16 NHWC,
+// any KH x KW (3x3, 1xk "cross" row convs, kx1 column convs; reference nets/tcct.py:808-822).
+//
+// GEMM view per tap: D[co][pixel] += Wt[tap][co][ci] * X[pixel@tap][ci]   (M = 32 co, N = 32 pixels, K = 32 ci)
+//   v_mfma_f32_32x32x16_bf16, A = weights (rows = co), B = activations (cols = pixels): each lane then owns ONE pixel
+//   and 16 of its output channels, so the epilogue packs 4 bf16 -> 8-byte stores and per-pixel fusions are lane-local.
+// LDS image: one 64-byte row per pixel (32 ch bf16), 16-byte chunks XOR-swizzled with ((p>>2)&3) so that the
+//   ds_read_b128 of 16 consecutive pixels (one MFMA lane group) hits 16 distinct 16-byte slots (conflict-free); the
+//   weights use the same image with row = tap*32+co.  HORZ tiles (8 rows x 64 cols, M-tiles along W) serve 3x3 and 1xk;
+//   VERT tiles (64 rows x 8 cols, column-major LDS image, M-tiles along H) serve kx1 with a 1.19x halo instead of 2.5x.
+// Each block stages the packed weights once and walks tiles grid-stride; 2 blocks/CU overlap staging with MFMA.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define MB 256
+
+// OIHW fp32 -> [tap][co][ci] bf16 (optionally flipped + transposed: the weights of the input-gradient convolution)
+__global__ void k_pack_w32(const float* __restrict__ w, bf16* __restrict__ wp, int KH, int KW, int transposed) {
+    int total = KH * KW * 32 * 32;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int ci = i & 31, co = (i >> 5) & 31, tap = i >> 10;
+        int dy = tap / KW, dx = tap % KW;
+        float v = transposed ? w[((ci * 32 + co) * KH + (KH - 1 - dy)) * KW + (KW - 1 - dx)]
+                             : w[((co * 32 + ci) * KH + dy) * KW + dx];
+        wp[i] = __float2bfloat16(v);
+    }
+}
+extern "C" int tcct_conv32_pack_weights(const float* w, void* wp, int KH, int KW, int transposed, tcct_stream_t stream) {
+    int total = KH * KW * 1024;
+    hipLaunchKernelGGL(k_pack_w32, dim3((total + MB - 1) / MB), dim3(MB), 0, (hipStream_t)stream, w, (bf16*)wp, KH, KW, transposed);
+    TCCT_LAUNCH_OK();
+}
+
+template <bool VERT>
+__global__ void __launch_bounds__(MB, 2)
+k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
+              int N, int H, int W, int KH, int KW, int PH, int PW, int tilesH, int tilesW, int ntiles) {
+    constexpr int TH = VERT ? 64 : 8, TW = VERT ? 8 : 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int LH = TH + KH - 1, LW = TW + KW - 1;
+    const int TAPS = KH * KW;
+    unsigned char* sW = smem;
+    unsigned char* sX = smem + TAPS * 32 * 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+
+    for (int i = tid; i < TAPS * 32 * 4; i += MB) {
+        int row = i >> 2, c = i & 3;
+        uint4 v = reinterpret_cast<const uint4*>(wp)[i];
+        *reinterpret_cast<uint4*>(sW + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = v;
+    }
+    float bv[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bv[q * 4 + k] = bias ? bias[8 * q + 4 * hh + k] : 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tw = tile % tilesW;
+        const int t2 = tile / tilesW;
+        const int th = t2 % tilesH;
+        const int n = t2 / tilesH;
+        const int h0 = th * TH, w0 = tw * TW;
+        __syncthreads();
+        const int npix = LH * LW;
+        for (int i = tid; i < npix * 4; i += MB) {
+            int c = i & 3, pl = i >> 2;
+            int lr = pl / LW, lc = pl - lr * LW;
+            int hi = h0 + lr - PH, wi = w0 + lc - PW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (hi >= 0 && hi < H && wi >= 0 && wi < W)
+                v = *reinterpret_cast<const uint4*>(x + (((int64_t)n * H + hi) * W + wi) * 32 + c * 8);
+            int p = VERT ? lc * LH + lr : pl;
+            *reinterpret_cast<uint4*>(sX + p * 64 + ((c ^ ((p >> 2) & 3)) << 4)) = v;
+        }
+        __syncthreads();
+
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+        // per-M-tile base pixel (tap 0,0) in the LDS image
+        int pb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int mt = wave * 4 + t;
+            int a = mt >> 1, seg = mt & 1;           // HORZ: a = row; VERT: a = col
+            pb[t] = VERT ? a * LH + seg * 32 + r : a * LW + seg * 32 + r;
+        }
+        for (int dy = 0; dy < KH; ++dy) {
+            for (int dx = 0; dx < KW; ++dx) {
+                const int wrow = (dy * KW + dx) * 32 + r;
+                const int wsw = (wrow >> 2) & 3;
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sW + wrow * 64 + ((hh ^ wsw) << 4));
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sW + wrow * 64 + (((2 + hh) ^ wsw) << 4));
+                const int poff = VERT ? dx * LH + dy : dy * LW + dx;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int p = pb[t] + poff;
+                    const int sw = (p >> 2) & 3;
+                    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sX + p * 64 + ((hh ^ sw) << 4));
+                    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sX + p * 64 + (((2 + hh) ^ sw) << 4));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: lane owns pixel r of each M-tile and channels co = 8q + 4*hh + k
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int mt = wave * 4 + t;
+            int a = mt >> 1, seg = mt & 1;
+            int ho = VERT ? h0 + seg * 32 + r : h0 + a;
+            int wo = VERT ? w0 + a : w0 + seg * 32 + r;
+            if (ho < H && wo < W) {
+                bf16* yp = y + (((int64_t)n * H + ho) * W + wo) * 32 + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint2 o;
+                    o.x = pack_bf16x2(acc[t][4 * q] + bv[4 * q], acc[t][4 * q + 1] + bv[4 * q + 1]);
+                    o.y = pack_bf16x2(acc[t][4 * q + 2] + bv[4 * q + 2], acc[t][4 * q + 3] + bv[4 * q + 3]);
+                    *reinterpret_cast<uint2*>(yp + 8 * q) = o;
+                }
+            }
+        }
+    }
+}
+
+/* x, y: bf16 NHWC [N,H,W,32]; wp: packed bf16 [KH*KW][32][32] from tcct_conv32_pack_weights; stride 1; output size == input
+ * size requires PH = (KH-1)/2 etc. but any PH <= KH-1, PW <= KW-1 with "same" output extent H x W is accepted. */
+extern "C" int tcct_conv32_fwd(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
+                               int PH, int PW, tcct_stream_t stream) {
+    TCCT_CHECK(KH >= 1 && KW >= 1 && KH * KW <= 13 * 13, "conv32_fwd: bad kernel %dx%d", KH, KW);
+    TCCT_CHECK(2 * PH == KH - 1 && 2 * PW == KW - 1, "conv32_fwd: only 'same' padding (got pad %d,%d for %dx%d)", PH, PW, KH, KW);
+    const bool vert = (KW == 1 && KH > 1);
+    const int TH = vert ? 64 : 8, TW = vert ? 8 : 64;
+    const int LH = TH + KH - 1, LW = TW + KW - 1;
+    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * 64;
+    TCCT_CHECK(lds <= 80 * 1024, "conv32_fwd: %dx%d needs %zu B of LDS (> 80 KiB for 2 blocks/CU)", KH, KW, lds);
+    int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
+    int64_t nt = (int64_t)N * tilesH * tilesW;
+    TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32_fwd: bad tile count");
+    int grid = (int)(nt < 512 ? nt : 512);
+    hipStream_t st = (hipStream_t)stream;
+    if (vert) {
+        static bool attr_v = false;
+        if (!attr_v) { (void)hipFuncSetAttribute((const void*)k_conv32_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_v = true; }
+        hipLaunchKernelGGL(k_conv32_mfma<true>, dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt);
+    } else {
+        static bool attr_h = false;
+        if (!attr_h) { (void)hipFuncSetAttribute((const void*)k_conv32_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_h = true; }
+        hipLaunchKernelGGL(k_conv32_mfma<false>, dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt);
+    }
+    TCCT_LAUNCH_OK();
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[tap][co][ci] = sum_pixels dy[p][co] * x[p@tap][ci]  ->  per tap one 32x32 MFMA accumulator, K = pixels.
+// Both operands need "8 consecutive pixels of one channel" per lane, i.e. the TRANSPOSE of the pixel-major NHWC rows:
+// gfx950's ds_read_b64_tr_b16 does that transpose on the LDS read (4 pixels x 16 channels per 16-lane group), so the
+// tiles are staged exactly like in the forward kernel (64 B per pixel, XOR-swizzled chunks) and any tap shift keeps the
+// 8-byte alignment the instruction needs.  4 consecutive pixels = 256 contiguous bytes -> every bank once: conflict-free.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ bf16x8 tr_load8(const unsigned char* base, int P, int lane) {
+    // 16 consecutive LDS pixels P..P+15; returns pixels P+8*(lane>>5)+j (j=0..7) of channel (lane&31)
+    const int i = lane & 15, q = i >> 2, pp = i & 3, g = lane >> 4;
+    const int hh = g >> 1, cb = g & 1;
+    const int chunk = 2 * cb + (pp >> 1), inner = (pp & 1) * 8;
+    const int p0 = P + 8 * hh + q, p1 = p0 + 4;
+    const unsigned char* a0 = base + p0 * 64 + ((chunk ^ ((p0 >> 2) & 3)) << 4) + inner;
+    const unsigned char* a1 = base + p1 * 64 + ((chunk ^ ((p1 >> 2) & 3)) << 4) + inner;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TPW, bool VERT>
+__global__ void __launch_bounds__(MB, 2)
+k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
+               int N, int H, int W, int KH, int KW, int PH, int PW, int TG, int tilesH, int tilesW, int ntiles) {
+    constexpr int TH = VERT ? 64 : 8, TW = VERT ? 8 : 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int LH = TH + KH - 1, LW = TW + KW - 1;
+    const int TAPS = KH * KW;
+    unsigned char* sX = smem;
+    unsigned char* sD = smem + LH * LW * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int WPG = 4 / TG;
+    const int tg = wave / WPG, wi = wave % WPG;
+    const int tap0 = tg * TPW;
+    int poff[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        int tap = tap0 + t;
+        int dy_ = tap / KW, dx_ = tap - dy_ * KW;
+        poff[t] = VERT ? dx_ * LH + dy_ : dy_ * LW + dx_;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    float bsum = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tw = tile % tilesW;
+        const int t2 = tile / tilesW;
+        const int th = t2 % tilesH;
+        const int n = t2 / tilesH;
+        const int h0 = th * TH, w0 = tw * TW;
+        __syncthreads();
+        for (int i = tid; i < LH * LW * 4; i += MB) {
+            int c = i & 3, pl = i >> 2;
+            int lr = pl / LW, lc = pl - lr * LW;
+            int hi = h0 + lr - PH, wi_ = w0 + lc - PW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (hi >= 0 && hi < H && wi_ >= 0 && wi_ < W)
+                v = *reinterpret_cast<const uint4*>(x + (((int64_t)n * H + hi) * W + wi_) * 32 + c * 8);
+            int p = VERT ? lc * LH + lr : pl;
+            *reinterpret_cast<uint4*>(sX + p * 64 + ((c ^ ((p >> 2) & 3)) << 4)) = v;
+        }
+        for (int i = tid; i < TH * TW * 4; i += MB) {
+            int c = i & 3, pl = i >> 2;
+            int lr = pl / TW, lc = pl - lr * TW;
+            int ho = h0 + lr, wo = w0 + lc;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ho < H && wo < W)
+                v = *reinterpret_cast<const uint4*>(dy + (((int64_t)n * H + ho) * W + wo) * 32 + c * 8);
+            int p = VERT ? lc * TH + lr : pl;
+            *reinterpret_cast<uint4*>(sD + p * 64 + ((c ^ ((p >> 2) & 3)) << 4)) = v;
+        }
+        __syncthreads();
+        for (int ch = wi; ch < 32; ch += WPG) {
+            const int a_ = ch >> 2, s16 = (ch & 3) * 16;      // HORZ: row / col offset; VERT: col / row offset
+            const int Pd = VERT ? a_ * TH + s16 : a_ * TW + s16;
+            const int Px = VERT ? a_ * LH + s16 : a_ * LW + s16;
+            const bf16x8 a = tr_load8(sD, Pd, lane);
+            if (tg == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += (float)a[j];
+            }
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                if (tap0 + t < TAPS) {
+                    const bf16x8 b = tr_load8(sX, Px + poff[t], lane);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // block-level reduction of the 4/TG partial accumulators per tap in LDS, then one fp32 atomic per element per block
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    for (int i = tid; i < TAPS * 1024; i += MB) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = tap0 + t;
+        if (tap < TAPS) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
+                atomicAdd(&red[tap * 1024 + co * 32 + r], acc[t][k]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < TAPS * 1024; i += MB) {
+        const int tap = i >> 10, co = (i >> 5) & 31, ci = i & 31;
+        const int dy_ = tap / KW, dx_ = tap - dy_ * KW;
+        atomicAdd(&dw[((co * 32 + ci) * KH + dy_) * KW + dx_], red[i]);
+    }
+    if (dbias && tg == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lane < 32) atomicAdd(&dbias[r], bsum);
+    }
+}
+
+/* dw OIHW fp32 [32,32,KH,KW] and dbias fp32 [32] (nullable) are overwritten. */
+extern "C" int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW,
+                                 int PH, int PW, tcct_stream_t stream) {
+    TCCT_CHECK(2 * PH == KH - 1 && 2 * PW == KW - 1, "conv32_wgrad: only 'same' padding");
+    const int TAPS = KH * KW;
+    TCCT_CHECK(TAPS >= 1 && TAPS <= 14, "conv32_wgrad: %dx%d unsupported (<= 14 taps)", KH, KW);
+    const bool vert = (KW == 1 && KH > 1);
+    const int TH = vert ? 64 : 8, TW = vert ? 8 : 64;
+    const int LH = TH + KH - 1, LW = TW + KW - 1;
+    size_t lds = (size_t)LH * LW * 64 + (size_t)TH * TW * 64;
+    size_t red = (size_t)TAPS * 4096;
+    if (red > lds) lds = red;
+    TCCT_CHECK(lds <= 80 * 1024, "conv32_wgrad: %dx%d needs %zu B of LDS", KH, KW, lds);
+    int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
+    int64_t nt = (int64_t)N * tilesH * tilesW;
+    TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32_wgrad: bad tile count");
+    int grid = (int)(nt < 512 ? nt : 512);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, sizeof(float) * TAPS * 1024, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
+    if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
+    const int TG = TAPS > 9 ? 2 : 1;
+    const int tpw = (TAPS + TG - 1) / TG;
+#define WG_LAUNCH(TPW, V)                                                                                                   \
+    do {                                                                                                                    \
+        static bool attr = false;                                                                                           \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad<TPW, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+        hipLaunchKernelGGL((k_conv32_wgrad<TPW, V>), dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W, KH, \
+                           KW, PH, PW, TG, tilesH, tilesW, (int)nt);                                                        \
+    } while (0)
+    if (tpw <= 5) { if (vert) WG_LAUNCH(5, true); else WG_LAUNCH(5, false); }
+    else if (tpw <= 7) { if (vert) WG_LAUNCH(7, true); else WG_LAUNCH(7, false); }
+    else { if (vert) WG_LAUNCH(9, true); else WG_LAUNCH(9, false); }
+#undef WG_LAUNCH
+    TCCT_LAUNCH_OK();
+}

@@ -31,6 +31,12 @@ def _as(t, dtype):
 
 
 # ------------------------------------------------------------------------------------------------- conv
+def _mfma32_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+    """the MFMA implicit-GEMM kernel covers bf16 32->32 stride-1 'same' convolutions (3x3, 1xk, kx1)"""
+    return (in_dt == torch.bfloat16 and out_dt == torch.bfloat16 and Cin == 32 and Cin_w == 32 and Cout == 32 and stride == 1
+            and 2 * padh == KH - 1 and 2 * padw == KW - 1 and KH * KW > 1 and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, padh, padw, out_dtype):
@@ -41,8 +47,14 @@ class _Conv2d(torch.autograd.Function):
         Wo = (W + 2 * padw - KW) // stride + 1
         odt = out_dtype or x.dtype
         y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=odt)
-        lib.conv2d_fwd(x, w, bias, y, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
-                       dtype_code(odt))
+        mfma = _mfma32_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw)
+        if mfma:
+            wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
+            lib.conv32_pack_weights(w, wp, KH, KW, 0)
+            lib.conv32_fwd(x, wp, bias, y, N, H, W, KH, KW, padh, padw)
+        else:
+            lib.conv2d_fwd(x, w, bias, y, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
+                           dtype_code(odt))
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, padh, padw, bias is not None)
         return y
@@ -59,12 +71,20 @@ class _Conv2d(torch.autograd.Function):
             if stride != 1 or Cin != Cin_w:
                 raise TcctError('conv2d dgrad: only stride-1 convs with unpadded channels need an input gradient')
             dx = torch.empty_like(x)
-            lib.conv2d_dgrad(dy, w, dx, N, H, W, Cin, Cout, KH, KW, padh, padw, dtype_code(dy.dtype), dtype_code(x.dtype))
+            if _mfma32_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
+                wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
+                lib.conv32_pack_weights(w, wp, KH, KW, 1)
+                lib.conv32_fwd(dy, wp, None, dx, N, H, W, KH, KW, KH - 1 - padh, KW - 1 - padw)
+            else:
+                lib.conv2d_dgrad(dy, w, dx, N, H, W, Cin, Cout, KH, KW, padh, padw, dtype_code(dy.dtype), dtype_code(x.dtype))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
             db = torch.empty(Cout, device=w.device, dtype=torch.float32) if has_bias else None
-            lib.conv2d_wgrad(x, dy, dw, db, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
-                             dtype_code(dy.dtype))
+            if _mfma32_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+                lib.conv32_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
+            else:
+                lib.conv2d_wgrad(x, dy, dw, db, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
+                                 dtype_code(dy.dtype))
         return dx, dw, db, None, None, None, None
 
 

@@ -32,7 +32,9 @@ def rnd(*shape, seed=0, dt=torch.float32):
     (32, 32, 3, 3, 1, 1, 1, 17, 23), (32, 32, 1, 13, 1, 0, 6, 9, 40), (32, 32, 13, 1, 1, 6, 0, 40, 9),
     (3, 32, 3, 3, 1, 1, 1, 16, 16), (3, 32, 3, 3, 2, 1, 1, 16, 20), (32, 64, 3, 3, 1, 1, 1, 8, 12),
     (128, 96, 1, 1, 1, 0, 0, 6, 10), (32, 5, 1, 1, 1, 0, 0, 12, 8), (320, 160, 1, 1, 1, 0, 0, 4, 6),
-    (160, 32, 1, 1, 1, 0, 0, 4, 6)])
+    (160, 32, 1, 1, 1, 0, 0, 4, 6), (32, 32, 3, 3, 1, 1, 1, 70, 130), (32, 32, 1, 11, 1, 0, 5, 20, 150),
+    (32, 32, 9, 1, 1, 4, 0, 150, 20), (32, 32, 5, 1, 1, 2, 0, 64, 8), (32, 32, 1, 5, 1, 0, 2, 8, 64), (32, 32, 7, 1, 1, 3, 0, 33, 9),
+    (32, 32, 1, 7, 1, 0, 3, 9, 33)])
 def test_conv2d(dt, cfg):
     from tcct_amd import ops
     Cw, Co, KH, KW, s, ph, pw, H, W = cfg

@@ -1,0 +1,68 @@
+"""Micro-benchmark of individual kernels at the level-0 bench shapes (HIP events on the launch stream)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tcct_amd import ops
+from tcct_amd._lib import lib
+
+B, H, W = 8, 800, 1104
+dt = torch.bfloat16
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    which = sys.argv[1:] or ['conv']
+    x = torch.randn(B, H, W, 32, device='cuda').to(dt)
+    dy = torch.randn(B, H, W, 32, device='cuda').to(dt)
+    gb = x.numel() * 2 / 1e9
+    for (kh, kw) in [(3, 3), (1, 13), (13, 1)]:
+        w = torch.randn(32, 32, kh, kw, device='cuda') * 0.05
+        b = torch.zeros(32, device='cuda')
+        y = torch.empty_like(x)
+        wp = torch.empty(kh * kw * 1024, device='cuda', dtype=dt)
+        lib.conv32_pack_weights(w, wp, kh, kw, 0)
+        fl = 2 * kh * kw * 32 * 32 * B * H * W / 1e12
+        if 'conv' in which:
+            ms = timeit(lambda: lib.conv32_fwd(x, wp, b, y, B, H, W, kh, kw, (kh - 1) // 2, (kw - 1) // 2))
+            print(f'conv32_fwd {kh}x{kw}: {ms:.3f} ms  {fl / ms * 1e3:.1f} TFLOP/s  {2 * gb / ms * 1e3:.0f} GB/s algorithmic')
+        if 'wgrad' in which:
+            dw = torch.empty_like(w)
+            db = torch.empty(32, device='cuda')
+            ms = timeit(lambda: lib.conv2d_wgrad(x, dy, dw, db, B, H, W, 32, 32, 32, kh, kw, 1, (kh - 1) // 2, (kw - 1) // 2, 1, 1), iters=3, warm=1)
+            print(f'conv2d_wgrad(valu) {kh}x{kw}: {ms:.3f} ms  {fl / ms * 1e3:.1f} TFLOP/s')
+        if 'wgrad32' in which:
+            dw = torch.empty_like(w)
+            db = torch.empty(32, device='cuda')
+            ms = timeit(lambda: lib.conv32_wgrad(x, dy, dw, db, B, H, W, kh, kw, (kh - 1) // 2, (kw - 1) // 2))
+            print(f'conv32_wgrad {kh}x{kw}: {ms:.3f} ms  {fl / ms * 1e3:.1f} TFLOP/s  {2 * gb / ms * 1e3:.0f} GB/s algorithmic')
+    if 'ew' in which:
+        y = torch.empty_like(x)
+        ms = timeit(lambda: lib.act_fwd(x, y, x.numel(), 3, 1))
+        print(f'act_fwd gelu: {ms:.3f} ms {2 * gb / ms * 1e3:.0f} GB/s')
+        ab = torch.ones(64, device='cuda')
+        ms = timeit(lambda: lib.bn_apply(x, y, B * H * W, 32, ab, 1, 0, 1))
+        print(f'bn_apply: {ms:.3f} ms {2 * gb / ms * 1e3:.0f} GB/s')
+        sums = torch.empty(64, device='cuda', dtype=torch.float64)
+        ms = timeit(lambda: lib.bn_stats(x, B * H * W, 32, 1, sums, 1))
+        print(f'bn_stats: {ms:.3f} ms {gb / ms * 1e3:.0f} GB/s')
+        mr = torch.zeros(64, device='cuda'); mr[32:] = 1
+        ms = timeit(lambda: lib.bn_bwd_reduce(x, dy, B * H * W, 32, mr, ab, 1, 0, sums, 1))
+        print(f'bn_bwd_reduce: {ms:.3f} ms {2 * gb / ms * 1e3:.0f} GB/s')
+        dg = torch.empty(32, device='cuda'); db = torch.empty(32, device='cuda')
+        ms = timeit(lambda: lib.bn_bwd_apply(x, dy, y, B * H * W, 32, mr, ab, ab, sums, 1, 0, dg, db, 1))
+        print(f'bn_bwd_apply: {ms:.3f} ms {3 * gb / ms * 1e3:.0f} GB/s')
+
+
+if __name__ == '__main__':
+    main()
