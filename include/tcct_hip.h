@@ -115,6 +115,13 @@ int tcct_conv32_fwd(const void* x, const void* wp, const float* bias, void* y, i
 int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH,
                       int PW, tcct_stream_t stream);
 
+/* MFMA pointwise (1x1 conv / nn.Linear) path, bf16 rows [M,K] with K % 32 == 0 (ViT 1x1s and MLPs, FTC tran_x, t32x and
+ * aux heads; reference nets/tcct.py:41-43,124,532-546,600,966-997).  w fp32 [N,K] (transposed=0) or [K,N] (transposed=1,
+ * i.e. dx = dy * W for the input gradient); y [M,N] bf16 or fp32.  wgrad: dw fp32 [N,K], dbias [N] nullable, N <= 160. */
+int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
+                int out_dtype, tcct_stream_t stream);
+int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
+
 /* ---- depthwise 3x3 (nets/tcct.py:114-122,206,535-543; nets/reg.py:66-67,72,74 as C=1 / groups=C) -------- */
 int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
                        int stride, int add_input, int dtype, tcct_stream_t stream);

@@ -1,0 +1,250 @@
+// MFMA pointwise (1x1) convolution / nn.Linear on bf16 NHWC rows: Y[M,N] = X[M,K] * Wt + bias   (reference
+// nets/tcct.py:41-43,124,532-546,600,966-997).  K, N multiples of 32 (N may be < 32 for the 5-class aux heads).
+//   D[co][pixel] per 32-pixel M-tile and 32-channel N-tile with v_mfma_f32_32x32x16_bf16; A = weights from LDS (staged once
+//   per block as bf16 [N][K], row stride 2K+16 B => conflict-free ds_read_b128), B = activations straight from global
+//   memory (every X element is used by exactly one wave, so an LDS round trip would be pure overhead): the K order inside
+//   each 32-channel group is permuted so that a lane's two k-steps are 32 CONTIGUOUS bytes of its pixel row.
+// wgrad: dW[co][ci] = sum_p dy[p][co] x[p][ci] with both tiles staged pixel-major in LDS and transposed on read by
+//   ds_read_b64_tr_b16 (same scheme as conv_mfma.hip).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+#define PWB 256
+
+__device__ __forceinline__ void st_out4(bf16* p, float a, float b, float c, float d) {
+    uint2 o; o.x = pack_bf16x2(a, b); o.y = pack_bf16x2(c, d);
+    *reinterpret_cast<uint2*>(p) = o;
+}
+__device__ __forceinline__ void st_out4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+
+// NT = number of 32-channel output tiles handled per block (N chunk = NT*32 starting at blockIdx.y*NT*32)
+template <int NT, typename Tout>
+__global__ void __launch_bounds__(PWB, 2)
+k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, Tout* __restrict__ y,
+         int64_t M, int K, int N, int transposed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int SW = 2 * K + 16;                 // LDS row stride (bytes)
+    const int n_base = blockIdx.y * NT * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    // stage weights: rows n_base .. n_base+NT*32-1 (zero beyond N), bf16 [row][K]
+    for (int i = tid; i < NT * 32 * K; i += PWB) {
+        int row = i / K, k = i - row * K;
+        int n = n_base + row;
+        float v = 0.f;
+        if (n < N) v = transposed ? w[(int64_t)k * N + n] : w[(int64_t)n * K + k];
+        *reinterpret_cast<bf16*>(smem + row * SW + k * 2) = __float2bfloat16(v);
+    }
+    __syncthreads();
+    const int KT = K >> 5;
+    const int64_t mtiles = (M + 31) >> 5;
+    for (int64_t mt = (int64_t)blockIdx.x * 4 + wave; mt < mtiles; mt += (int64_t)gridDim.x * 4) {
+        const int64_t m = mt * 32 + r;
+        const bool ok = m < M;
+        const bf16* xr = x + (ok ? m : 0) * K + 16 * hh;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[nt][k] = 0.f;
+        for (int t = 0; t < KT; ++t) {
+            // channels 32t + 16hh + [0,16): two k-steps
+            uint4 u0 = make_uint4(0, 0, 0, 0), u1 = u0;
+            if (ok) {
+                u0 = *reinterpret_cast<const uint4*>(xr + 32 * t);
+                u1 = *reinterpret_cast<const uint4*>(xr + 32 * t + 8);
+            }
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, u0), b1 = __builtin_bit_cast(bf16x8, u1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned char* wr = smem + (nt * 32 + r) * SW + (32 * t + 16 * hh) * 2;
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(wr);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(wr + 16);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[nt], 0, 0, 0);
+            }
+        }
+        if (ok) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = n_base + nt * 32 + 8 * q + 4 * hh;
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = acc[nt][4 * q + k] + ((bias && co + k < N) ? bias[co + k] : 0.f);
+                    if (co + 3 < N && (N & 3) == 0) st_out4(y + m * N + co, v[0], v[1], v[2], v[3]);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (co + k < N) stf(y + m * N + co + k, v[k]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* x bf16 [M,K]; w fp32: [N,K] (transposed=0) or [K,N] (transposed=1: the input-gradient GEMM dx = dy * W);
+ * y [M,N] bf16 or fp32. */
+extern "C" int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
+                           int out_dtype, tcct_stream_t stream) {
+    TCCT_CHECK(K % 32 == 0 && K >= 32 && K <= 512, "pw_fwd: K=%d must be a multiple of 32 (<=512)", K);
+    TCCT_CHECK(N >= 1 && N <= 1024, "pw_fwd: N=%d", N);
+    const int ntiles = (N + 31) / 32;
+    // tiles per block: largest NT <= 5 dividing the work evenly enough and fitting 2 blocks/CU when possible
+    int NT = ntiles <= 5 ? ntiles : (ntiles % 5 == 0 ? 5 : (ntiles % 4 == 0 ? 4 : (ntiles % 3 == 0 ? 3 : (ntiles % 2 == 0 ? 2 : 1))));
+    const int gy = (ntiles + NT - 1) / NT;
+    size_t lds = (size_t)NT * 32 * (2 * K + 16);
+    TCCT_CHECK(lds <= 160 * 1024, "pw_fwd: weights need %zu B of LDS", lds);
+    const int64_t mtiles = (M + 31) / 32;
+    int64_t gx = (mtiles + 3) / 4;
+    const int cap = lds <= 80 * 1024 ? 512 : 256;
+    if (gx > cap) gx = cap;
+    hipStream_t st = (hipStream_t)stream;
+#define PW_L(NTV, TO)                                                                                                        \
+    do {                                                                                                                     \
+        static bool attr = false;                                                                                            \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_pw_fwd<NTV, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((k_pw_fwd<NTV, TO>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (TO*)y, M, K, N, transposed); \
+    } while (0)
+#define PW_D(TO)                                                                  \
+    switch (NT) {                                                                 \
+        case 1: PW_L(1, TO); break; case 2: PW_L(2, TO); break; case 3: PW_L(3, TO); break; \
+        case 4: PW_L(4, TO); break; default: PW_L(5, TO); break;                  \
+    }
+    if (out_dtype == TCCT_BF16) { PW_D(bf16); }
+    else if (out_dtype == TCCT_F32) { PW_D(float); }
+    else { tcct_set_error("pw_fwd: bad out dtype"); return -1; }
+#undef PW_D
+#undef PW_L
+    TCCT_LAUNCH_OK();
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+__device__ __forceinline__ bf16x8 tr_load8g(const unsigned char* base, int stride, int P, int chan0, int lane) {
+    // 16 consecutive LDS pixel rows P..P+15 (row stride `stride` bytes); returns pixels P+8*(lane>>5)+j (j=0..7) of
+    // channel chan0 + (lane&31)
+    const int i = lane & 15, q = i >> 2, pp = i & 3, g = lane >> 4;
+    const int hh = g >> 1, cb = g & 1;
+    const unsigned char* a0 = base + (P + 8 * hh + q) * stride + (chan0 + 16 * cb + 4 * pp) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * stride));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+#define PW_P 64     // pixels per staged tile
+template <int NT, int KTB>
+__global__ void __launch_bounds__(PWB, 2)
+k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias, int64_t M,
+           int K, int N, int SX, int SD) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;
+    unsigned char* sD = smem + PW_P * SX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int ci_base = blockIdx.y * KTB * 32;
+    const int xc = KTB * 4, dc = N >> 3;            // 16-byte chunks per staged pixel row
+    f32x16 acc[NT][KTB];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < KTB; ++b)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[a][b][k] = 0.f;
+    float bsum[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) bsum[a] = 0.f;
+    const int64_t tiles = (M + PW_P - 1) / PW_P;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t m0 = tile * PW_P;
+        __syncthreads();
+        for (int i = tid; i < PW_P * xc; i += PWB) {
+            int p = i / xc, c = i - p * xc;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m0 + p < M && ci_base + c * 8 < K) v = *reinterpret_cast<const uint4*>(x + (m0 + p) * K + ci_base + c * 8);
+            *reinterpret_cast<uint4*>(sX + p * SX + c * 16) = v;
+        }
+        for (int i = tid; i < PW_P * dc; i += PWB) {
+            int p = i / dc, c = i - p * dc;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m0 + p < M) v = *reinterpret_cast<const uint4*>(dy + (m0 + p) * N + c * 8);
+            *reinterpret_cast<uint4*>(sD + p * SD + c * 16) = v;
+        }
+        __syncthreads();
+        const int P = wave * 16;
+        bf16x8 a[NT];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            a[ct] = tr_load8g(sD, SD, P, 32 * ct, lane);
+            if (blockIdx.y == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum[ct] += (float)a[ct][j];
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < KTB; ++kt) {
+            const bf16x8 b = tr_load8g(sX, SX, P, 32 * kt, lane);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) acc[ct][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct], b, acc[ct][kt], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);          // [NT*32][KTB*32]
+    for (int i = tid; i < NT * 32 * KTB * 32; i += PWB) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int kt = 0; kt < KTB; ++kt)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int co = ct * 32 + (k & 3) + 8 * (k >> 2) + 4 * hh;
+                atomicAdd(&red[co * (KTB * 32) + kt * 32 + r], acc[ct][kt][k]);
+            }
+    __syncthreads();
+    for (int i = tid; i < NT * 32 * KTB * 32; i += PWB) {
+        const int co = i / (KTB * 32), cl = i - co * (KTB * 32);
+        if (co < N && ci_base + cl < K) atomicAdd(&dw[(int64_t)co * K + ci_base + cl], red[i]);
+    }
+    if (dbias && blockIdx.y == 0) {
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            float s = bsum[ct] + __shfl_xor(bsum[ct], 32, 64);
+            if (lane < 32 && ct * 32 + r < N) atomicAdd(&dbias[ct * 32 + r], s);
+        }
+    }
+}
+
+/* x bf16 [M,K], dy bf16 [M,N] -> dw fp32 [N,K] and dbias fp32 [N] (nullable); both overwritten.  K, N multiples of 32, N <= 160 */
+extern "C" int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream) {
+    TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && N <= 160 && K <= 1024, "pw_wgrad: unsupported K=%d N=%d", K, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)N * K, st) != hipSuccess) { tcct_set_error("pw_wgrad: memset failed"); return -2; }
+    if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * N, st) != hipSuccess) { tcct_set_error("pw_wgrad: memset failed"); return -2; }
+    const int NT = N / 32, ktiles = K / 32;
+    const int KTB = (ktiles % 2 == 0) ? 2 : 1;
+    const int gy = ktiles / KTB;
+    // row strides: S mod 256 in {64,192} keeps the 4-pixel x 64-byte footprint of a transposing read on distinct banks
+    const int SX = KTB == 1 ? 64 : 192;
+    const int SD = 2 * N + ((NT & 1) ? 0 : 64);
+    size_t lds = (size_t)PW_P * (SX + SD);
+    size_t red = (size_t)NT * 32 * KTB * 32 * 4;
+    if (red > lds) lds = red;
+    const int64_t tiles = (M + PW_P - 1) / PW_P;
+    int gx = (int)(tiles < 512 ? tiles : 512);
+    if (gy > 1) { gx = (int)(tiles < (1024 / gy) ? tiles : (1024 / gy)); if (gx < 1) gx = 1; }
+#define WL(NTV, KV) hipLaunchKernelGGL((k_pw_wgrad<NTV, KV>), dim3(gx, gy), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias, M, K, N, SX, SD)
+#define WD(KV) switch (NT) { case 1: WL(1, KV); break; case 2: WL(2, KV); break; case 3: WL(3, KV); break; case 4: WL(4, KV); break; default: WL(5, KV); break; }
+    if (KTB == 2) { WD(2); } else { WD(1); }
+#undef WD
+#undef WL
+    TCCT_LAUNCH_OK();
+}

@@ -34,7 +34,13 @@ def _as(t, dtype):
 def _mfma32_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
     """the MFMA implicit-GEMM kernel covers bf16 32->32 stride-1 'same' convolutions (3x3, 1xk, kx1)"""
     return (in_dt == torch.bfloat16 and out_dt == torch.bfloat16 and Cin == 32 and Cin_w == 32 and Cout == 32 and stride == 1
-            and 2 * padh == KH - 1 and 2 * padw == KW - 1 and KH * KW > 1 and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
+            and 2 * padh == KH - 1 and 2 * padw == KW - 1 and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
+
+
+def _pw_ok(in_dt, Cin, Cin_w, KH, KW, stride, padh, padw):
+    """the MFMA pointwise kernels cover bf16 1x1 convs / Linear with Cin % 32 == 0"""
+    return (in_dt == torch.bfloat16 and KH == 1 and KW == 1 and stride == 1 and padh == 0 and padw == 0 and Cin == Cin_w
+            and Cin % 32 == 0)
 
 
 class _Conv2d(torch.autograd.Function):
@@ -48,7 +54,9 @@ class _Conv2d(torch.autograd.Function):
         odt = out_dtype or x.dtype
         y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=odt)
         mfma = _mfma32_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw)
-        if mfma:
+        if _pw_ok(x.dtype, Cin, Cin_w, KH, KW, stride, padh, padw) and not mfma:
+            lib.pw_fwd(x, w, bias, y, N * H * W, Cin, Cout, 0, dtype_code(odt))
+        elif mfma:
             wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
             lib.conv32_pack_weights(w, wp, KH, KW, 0)
             lib.conv32_fwd(x, wp, bias, y, N, H, W, KH, KW, padh, padw)
@@ -71,7 +79,10 @@ class _Conv2d(torch.autograd.Function):
             if stride != 1 or Cin != Cin_w:
                 raise TcctError('conv2d dgrad: only stride-1 convs with unpadded channels need an input gradient')
             dx = torch.empty_like(x)
-            if _mfma32_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
+            if (_pw_ok(dy.dtype, Cout, Cout, KH, KW, stride, padh, padw) and x.dtype == torch.bfloat16
+                    and not _mfma32_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw)):
+                lib.pw_fwd(dy, w, None, dx, N * H * W, Cout, Cin, 1, dtype_code(x.dtype))
+            elif _mfma32_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
                 wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
                 lib.conv32_pack_weights(w, wp, KH, KW, 1)
                 lib.conv32_fwd(dy, wp, None, dx, N, H, W, KH, KW, KH - 1 - padh, KW - 1 - padw)
@@ -82,6 +93,9 @@ class _Conv2d(torch.autograd.Function):
             db = torch.empty(Cout, device=w.device, dtype=torch.float32) if has_bias else None
             if _mfma32_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
                 lib.conv32_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
+            elif (_pw_ok(x.dtype, Cin, Cin_w, KH, KW, stride, padh, padw) and dy.dtype == torch.bfloat16 and Cout % 32 == 0
+                  and Cout <= 160):
+                lib.pw_wgrad(x, dy, dw, db, N * H * W, Cin, Cout)
             else:
                 lib.conv2d_wgrad(x, dy, dw, db, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
                                  dtype_code(dy.dtype))

@@ -34,7 +34,8 @@ def rnd(*shape, seed=0, dt=torch.float32):
     (128, 96, 1, 1, 1, 0, 0, 6, 10), (32, 5, 1, 1, 1, 0, 0, 12, 8), (320, 160, 1, 1, 1, 0, 0, 4, 6),
     (160, 32, 1, 1, 1, 0, 0, 4, 6), (32, 32, 3, 3, 1, 1, 1, 70, 130), (32, 32, 1, 11, 1, 0, 5, 20, 150),
     (32, 32, 9, 1, 1, 4, 0, 150, 20), (32, 32, 5, 1, 1, 2, 0, 64, 8), (32, 32, 1, 5, 1, 0, 2, 8, 64), (32, 32, 7, 1, 1, 3, 0, 33, 9),
-    (32, 32, 1, 7, 1, 0, 3, 9, 33)])
+    (32, 32, 1, 7, 1, 0, 3, 9, 33), (32, 32, 1, 1, 1, 0, 0, 19, 70), (64, 64, 1, 1, 1, 0, 0, 21, 33), (96, 32, 1, 1, 1, 0, 0, 9, 50),
+    (192, 128, 1, 1, 1, 0, 0, 10, 17), (256, 160, 1, 1, 1, 0, 0, 7, 9), (64, 96, 1, 1, 1, 0, 0, 40, 55)])
 def test_conv2d(dt, cfg):
     from tcct_amd import ops
     Cw, Co, KH, KW, s, ph, pw, H, W = cfg
