@@ -15,40 +15,92 @@ __device__ __forceinline__ void stv(T* p, const float* o) {
     else stf(p, o[0]);
 }
 
-template <typename T, int VEC>
+// Sliding-window form: thread = (channel vector, strip of SEG output pixels along W); the 3x3 window of input columns and
+// the 9 per-channel taps stay in registers, so each output costs `stride` new column loads (3 rows) instead of 9 loads.
+// FLIP=1 uses w[2-ky][2-kx]: with stride 1 that is exactly the input-gradient convolution.
+#define DW_SEG 16
+template <typename T, int VEC, int STRIDE, bool FLIP>
 __global__ void k_dw_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                         T* __restrict__ y, int N, int H, int W, int C, int stride, int Ho, int Wo, int add_input) {
+                         T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, int add_input) {
     const int CV = C / VEC;
-    const int64_t total = (int64_t)N * Ho * Wo * CV;
+    const int segs = (Wo + DW_SEG - 1) / DW_SEG;
+    const int64_t total = (int64_t)N * Ho * segs * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int c = (int)(i % CV) * VEC;
-        int64_t p = i / CV;
-        int wo = (int)(p % Wo);
-        int64_t r = p / Wo;
-        int ho = (int)(r % Ho);
-        int64_t n = r / Ho;
-        float acc[VEC];
+        const int c = (int)(i % CV) * VEC;
+        int64_t q = i / CV;
+        const int sg = (int)(q % segs);
+        q /= segs;
+        const int ho = (int)(q % Ho);
+        const int64_t n = q / Ho;
+        float wk[9][VEC], bv[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = bias ? bias[c + k] : 0.f;
+        for (int k = 0; k < VEC; ++k) {
+            bv[k] = bias ? bias[c + k] : 0.f;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) wk[tp][k] = w[(c + k) * 9 + (FLIP ? 8 - tp : tp)];
+        }
+        const int wo0 = sg * DW_SEG, wo1 = min(Wo, wo0 + DW_SEG);
+        const int hi0 = ho * STRIDE - 1;
+        const T* rows[3];
+        bool rok[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            int hi = ho * stride + ky - 1;
-            if (hi < 0 || hi >= H) continue;
+            int hi = hi0 + ky;
+            rok[ky] = hi >= 0 && hi < H;
+            rows[ky] = x + ((n * H + (rok[ky] ? hi : 0)) * (int64_t)W) * C + c;
+        }
+        float col[3][3][VEC];      // [kx][ky]
+        auto load_col = [&](int kxslot, int wi) {
+            bool cok = wi >= 0 && wi < W;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                int wi = wo * stride + kx - 1;
-                if (wi < 0 || wi >= W) continue;
-                float v[VEC];
-                ldv<T, VEC>(x + ((n * H + hi) * (int64_t)W + wi) * C + c, v);
+            for (int ky = 0; ky < 3; ++ky) {
+                if (cok && rok[ky]) ldv<T, VEC>(rows[ky] + (int64_t)wi * C, col[kxslot][ky]);
+                else {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    acc[k] += v[k] * w[(c + k) * 9 + ky * 3 + kx];
-                    if (add_input && ky == 1 && kx == 1) acc[k] += v[k];
+                    for (int k = 0; k < VEC; ++k) col[kxslot][ky][k] = 0.f;
                 }
             }
+        };
+        int wi = wo0 * STRIDE - 1;
+        load_col(0, wi); load_col(1, wi + 1);
+        for (int wo = wo0; wo < wo1; ++wo) {
+            load_col(2, wo * STRIDE + 1);
+            float acc[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float a = bv[k];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) a += col[kx][ky][k] * wk[ky * 3 + kx][k];
+                if (add_input) a += col[1][1][k];
+                acc[k] = a;
+            }
+            stv<T, VEC>(y + ((n * Ho + ho) * (int64_t)Wo + wo) * C + c, acc);
+            if (STRIDE == 1) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) { col[0][ky][k] = col[1][ky][k]; col[1][ky][k] = col[2][ky][k]; }
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) col[0][ky][k] = col[2][ky][k];
+                load_col(1, (wo + 1) * STRIDE);
+            }
         }
-        stv<T, VEC>(y + p * C + c, acc);
     }
+}
+
+template <typename T, int VEC, bool FLIP>
+static void dw_fwd_launch(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C, int stride,
+                          int Ho, int Wo, int add_input, hipStream_t st) {
+    int segs = (Wo + DW_SEG - 1) / DW_SEG;
+    int64_t total = (int64_t)N * Ho * segs * (C / VEC);
+    dim3 g(tcct_grid(total, DB, 1 << 16)), b(DB);
+    if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input);
+    else hipLaunchKernelGGL((k_dw_fwd<T, VEC, 2, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input);
 }
 
 extern "C" int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
@@ -57,10 +109,9 @@ extern "C" int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bi
     TCCT_CHECK(!(add_input && stride != 1), "dwconv3x3_fwd: add_input needs stride 1");
     int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     int vec = (C % 4 == 0) ? 4 : 1;
-    int64_t total = (int64_t)N * Ho * Wo * (C / vec);
     hipStream_t st = (hipStream_t)stream;
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_fwd<T, 4>), dim3(tcct_grid(total, DB, 1 << 16)), dim3(DB), 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, stride, Ho, Wo, add_input)); }
-    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_fwd<T, 1>), dim3(tcct_grid(total, DB, 1 << 16)), dim3(DB), 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, stride, Ho, Wo, add_input)); }
+    if (vec == 4) { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, false>(x, w, bias, y, N, H, W, C, stride, Ho, Wo, add_input, st))); }
+    else { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 1, false>(x, w, bias, y, N, H, W, C, stride, Ho, Wo, add_input, st))); }
     TCCT_LAUNCH_OK();
 }
 
@@ -113,6 +164,11 @@ extern "C" int tcct_dwconv3x3_dgrad(const void* dy, const float* w, void* dx, in
     int vec = (C % 4 == 0) ? 4 : 1;
     int64_t total = (int64_t)N * H * W * (C / vec);
     hipStream_t st = (hipStream_t)stream;
+    if (stride == 1) {      // dx = conv(dy, flipped taps) (+ dy when the forward added its input)
+        if (vec == 4) { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, add_input, st))); }
+        else { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 1, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, add_input, st))); }
+        TCCT_LAUNCH_OK();
+    }
     if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_dgrad<T, 4>), dim3(tcct_grid(total, DB, 1 << 16)), dim3(DB), 0, st, (const T*)dy, w, (T*)dx, N, H, W, C, stride, Ho, Wo, add_input)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_dgrad<T, 1>), dim3(tcct_grid(total, DB, 1 << 16)), dim3(DB), 0, st, (const T*)dy, w, (T*)dx, N, H, W, C, stride, Ho, Wo, add_input)); }
     TCCT_LAUNCH_OK();
@@ -120,9 +176,9 @@ extern "C" int tcct_dwconv3x3_dgrad(const void* dy, const float* w, void* dx, in
 
 // dw[c][ky][kx] = sum_p x[p@tap][c] * dy[p][c];  dbias[c] = sum_p dy[p][c].  Thread = (row slot, channel vector),
 // 10*VEC register sums, LDS combine per block, fp32 atomics out.
-template <typename T, int VEC>
+template <typename T, int VEC, int STRIDE>
 __global__ void k_dw_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
-                           int N, int H, int W, int C, int stride, int Ho, int Wo) {
+                           int N, int H, int W, int C, int Ho, int Wo) {
     extern __shared__ float sm[];   // [DB][10*VEC]
     const int CV = C / VEC;
     const int R = DB / CV;
@@ -130,34 +186,65 @@ __global__ void k_dw_wgrad(const T* __restrict__ x, const T* __restrict__ dy, fl
     const bool active = t < R * CV;
     const int cv = t % CV, r = t / CV;
     const int c = cv * VEC;
-    const int64_t NP = (int64_t)N * Ho * Wo;
+    const int segs = (Wo + DW_SEG - 1) / DW_SEG;
+    const int64_t strips = (int64_t)N * Ho * segs;
     float acc[10][VEC];
 #pragma unroll
     for (int a = 0; a < 10; ++a)
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[a][k] = 0.f;
     if (active) {
-        for (int64_t p = (int64_t)blockIdx.x * R + r; p < NP; p += (int64_t)gridDim.x * R) {
-            int wo = (int)(p % Wo);
-            int64_t q = p / Wo;
-            int ho = (int)(q % Ho);
-            int64_t n = q / Ho;
-            float g[VEC];
-            ldv<T, VEC>(dy + p * C + c, g);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[9][k] += g[k];
+        for (int64_t sidx = (int64_t)blockIdx.x * R + r; sidx < strips; sidx += (int64_t)gridDim.x * R) {
+            const int sg = (int)(sidx % segs);
+            int64_t q = sidx / segs;
+            const int ho = (int)(q % Ho);
+            const int64_t n = q / Ho;
+            const int wo0 = sg * DW_SEG, wo1 = min(Wo, wo0 + DW_SEG);
+            const int hi0 = ho * STRIDE - 1;
+            const T* rows[3];
+            bool rok[3];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                int hi = ho * stride + ky - 1;
-                if (hi < 0 || hi >= H) continue;
+                int hi = hi0 + ky;
+                rok[ky] = hi >= 0 && hi < H;
+                rows[ky] = x + ((n * H + (rok[ky] ? hi : 0)) * (int64_t)W) * C + c;
+            }
+            float col[3][3][VEC];
+            auto load_col = [&](int slot, int wi) {
+                bool cok = wi >= 0 && wi < W;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    int wi = wo * stride + kx - 1;
-                    if (wi < 0 || wi >= W) continue;
-                    float v[VEC];
-                    ldv<T, VEC>(x + ((n * H + hi) * (int64_t)W + wi) * C + c, v);
+                for (int ky = 0; ky < 3; ++ky) {
+                    if (cok && rok[ky]) ldv<T, VEC>(rows[ky] + (int64_t)wi * C, col[slot][ky]);
+                    else {
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[ky * 3 + kx][k] += v[k] * g[k];
+                        for (int k = 0; k < VEC; ++k) col[slot][ky][k] = 0.f;
+                    }
+                }
+            };
+            load_col(0, wo0 * STRIDE - 1); load_col(1, wo0 * STRIDE);
+            for (int wo = wo0; wo < wo1; ++wo) {
+                load_col(2, wo * STRIDE + 1);
+                float g[VEC];
+                ldv<T, VEC>(dy + ((n * Ho + ho) * (int64_t)Wo + wo) * C + c, g);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    acc[9][k] += g[k];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx][k] += col[kx][ky][k] * g[k];
+                }
+                if (STRIDE == 1) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) { col[0][ky][k] = col[1][ky][k]; col[1][ky][k] = col[2][ky][k]; }
+                } else {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) col[0][ky][k] = col[2][ky][k];
+                    load_col(1, (wo + 1) * STRIDE);
                 }
             }
         }
@@ -167,7 +254,6 @@ __global__ void k_dw_wgrad(const T* __restrict__ x, const T* __restrict__ dy, fl
 #pragma unroll
         for (int k = 0; k < VEC; ++k) sm[(t * 10 + a) * VEC + k] = acc[a][k];
     __syncthreads();
-    // outputs: C channels x 10 values
     for (int o = t; o < C * 10; o += DB) {
         int ch = o / 10, a = o % 10;
         int cvv = ch / VEC, k = ch % VEC;
@@ -189,10 +275,12 @@ extern "C" int tcct_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, fl
     if (hipMemsetAsync(dw, 0, sizeof(float) * C * 9, st) != hipSuccess) { tcct_set_error("dwconv3x3_wgrad: memset failed"); return -2; }
     if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) { tcct_set_error("dwconv3x3_wgrad: memset failed"); return -2; }
     int R = DB / (C / vec);
-    int64_t NP = (int64_t)N * Ho * Wo;
-    int grid = tcct_grid(NP, R, 1024);
+    int64_t strips = (int64_t)N * Ho * ((Wo + DW_SEG - 1) / DW_SEG);
+    int grid = tcct_grid(strips, R, 2048);
     size_t lds = sizeof(float) * DB * 10 * vec;
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_wgrad<T, 4>), dim3(grid), dim3(DB), lds, st, (const T*)x, (const T*)dy, dw, dbias, N, H, W, C, stride, Ho, Wo)); }
-    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_wgrad<T, 1>), dim3(grid), dim3(DB), lds, st, (const T*)x, (const T*)dy, dw, dbias, N, H, W, C, stride, Ho, Wo)); }
+#define DWG(V, S) hipLaunchKernelGGL((k_dw_wgrad<T, V, S>), dim3(grid), dim3(DB), lds, st, (const T*)x, (const T*)dy, dw, dbias, N, H, W, C, Ho, Wo)
+    if (vec == 4) { TCCT_DISPATCH(dtype, if (stride == 1) DWG(4, 1); else DWG(4, 2)); }
+    else { TCCT_DISPATCH(dtype, if (stride == 1) DWG(1, 1); else DWG(1, 2)); }
+#undef DWG
     TCCT_LAUNCH_OK();
 }

@@ -108,28 +108,45 @@ extern "C" int tcct_bn_eval_ab(int C, const float* gamma, const float* beta, flo
 
 // ------------------------------------------------------------------ BN apply: y = post(a*pre(x)+b)
 template <typename T, int VEC>
-__global__ void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t total, int C, const float* __restrict__ ab,
+__global__ void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t M, int C, const float* __restrict__ ab,
                            int pre_act, int post_act) {
+    // thread = fixed channel vector (per-channel scale/shift live in registers), rows strided over the grid
     const int CV = C / VEC;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int c = (int)(i % CV) * VEC;
-        if (VEC == 4) {
-            f4 v = ld4(x + i * 4), r;
+    const int R = NB / CV;
+    const int t = threadIdx.x;
+    if (t >= R * CV) return;
+    const int cv = t % CV, r = t / CV;
+    float a_[VEC], b_[VEC];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) r.v[k] = act_fwd(post_act, ab[c + k] * act_fwd(pre_act, v.v[k]) + ab[C + c + k]);
-            st4(y + i * 4, r);
+    for (int k = 0; k < VEC; ++k) { a_[k] = ab[cv * VEC + k]; b_[k] = ab[C + cv * VEC + k]; }
+    const int64_t step = (int64_t)gridDim.x * R;
+    for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += 2 * step) {
+        const int64_t m2 = m + step;
+        const int64_t o1 = m * C + cv * VEC, o2 = m2 * C + cv * VEC;
+        if (VEC == 4) {
+            f4 v1 = ld4(x + o1), v2 = m2 < M ? ld4(x + o2) : f4zero(), r1, r2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r1.v[k] = act_fwd(post_act, a_[k] * act_fwd(pre_act, v1.v[k]) + b_[k]);
+                r2.v[k] = act_fwd(post_act, a_[k] * act_fwd(pre_act, v2.v[k]) + b_[k]);
+            }
+            st4(y + o1, r1);
+            if (m2 < M) st4(y + o2, r2);
         } else {
-            stf(y + i, act_fwd(post_act, ab[c] * act_fwd(pre_act, ldf(x + i)) + ab[C + c]));
+            stf(y + o1, act_fwd(post_act, a_[0] * act_fwd(pre_act, ldf(x + o1)) + b_[0]));
+            if (m2 < M) stf(y + o2, act_fwd(post_act, a_[0] * act_fwd(pre_act, ldf(x + o2)) + b_[0]));
         }
     }
 }
 extern "C" int tcct_bn_apply(const void* x, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act,
                              int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(C >= 1 && C <= NB, "bn_apply: C=%d unsupported", C);
     int vec = (C % 4 == 0) ? 4 : 1;
-    int64_t total = M * C / vec;
+    int R = NB / (C / vec);
+    int grid = tcct_grid(M, 2 * R, 256 * 16);
     hipStream_t st = (hipStream_t)stream;
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 4>), dim3(tcct_grid(total, NB)), dim3(NB), 0, st, (const T*)x, (T*)y, total, C, ab, pre_act, post_act)); }
-    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 1>), dim3(tcct_grid(total, NB)), dim3(NB), 0, st, (const T*)x, (T*)y, total, C, ab, pre_act, post_act)); }
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act)); }
     TCCT_LAUNCH_OK();
 }
 
@@ -197,47 +214,56 @@ extern "C" int tcct_bn_bwd_reduce(const void* x, const void* dy, int64_t M, int 
 }
 
 template <typename T, int VEC>
-__global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t total,
-                               int64_t M, int C, const float* __restrict__ mean_rstd, const float* __restrict__ ab,
+__global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t M, int C,
+                               const float* __restrict__ mean_rstd, const float* __restrict__ ab,
                                const double* __restrict__ sums, int pre_act, int post_act, float* __restrict__ dgamma,
                                float* __restrict__ dbeta) {
     const int CV = C / VEC;
+    const int R = NB / CV;
+    const int t = threadIdx.x;
+    if (blockIdx.x == 0 && t < C) { dbeta[t] = (float)sums[t]; dgamma[t] = (float)sums[C + t]; }
+    if (t >= R * CV) return;
+    const int cv = t % CV, r = t / CV;
     const float invM = 1.f / (float)M;
-    if (blockIdx.x == 0 && threadIdx.x < C) {
-        dbeta[threadIdx.x] = (float)sums[threadIdx.x];
-        dgamma[threadIdx.x] = (float)sums[C + threadIdx.x];
+    float a_[VEC], b_[VEC], mu[VEC], rs[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        int c = cv * VEC + k;
+        a_[k] = ab[c]; b_[k] = ab[C + c]; mu[k] = mean_rstd[c]; rs[k] = mean_rstd[C + c];
+        s1[k] = (float)sums[c] * invM; s2[k] = (float)sums[C + c] * invM;
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int c0 = (int)(i % CV) * VEC;
-        float xv[VEC], gv[VEC], r[VEC];
+    const int64_t step = (int64_t)gridDim.x * R;
+    for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += step) {
+        const int64_t off = m * C + cv * VEC;
+        float xv[VEC], gv[VEC], o[VEC];
         if (VEC == 4) {
-            f4 a = ld4(x + i * 4), g = ld4(dy + i * 4);
+            f4 a = ld4(x + off), g = ld4(dy + off);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) { xv[k] = a.v[k]; gv[k] = g.v[k]; }
-        } else { xv[0] = ldf(x + i); gv[0] = ldf(dy + i); }
+        } else { xv[0] = ldf(x + off); gv[0] = ldf(dy + off); }
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            int c = c0 + k;
-            float a = ab[c], b = ab[C + c], mu = mean_rstd[c], rs = mean_rstd[C + c];
             float u = act_fwd(pre_act, xv[k]);
-            float dz = gv[k] * act_grad(post_act, a * u + b);
-            float xh = (u - mu) * rs;
-            float du = a * (dz - (float)sums[c] * invM - xh * (float)sums[C + c] * invM);
-            r[k] = du * act_grad(pre_act, xv[k]);
+            float dz = gv[k] * act_grad(post_act, a_[k] * u + b_[k]);
+            float xh = (u - mu[k]) * rs[k];
+            float du = a_[k] * (dz - s1[k] - xh * s2[k]);
+            o[k] = du * act_grad(pre_act, xv[k]);
         }
-        if (VEC == 4) { f4 o; o.v[0] = r[0]; o.v[1] = r[1]; o.v[2] = r[2]; o.v[3] = r[3]; st4(dx + i * 4, o); }
-        else stf(dx + i, r[0]);
+        if (VEC == 4) { f4 q; q.v[0] = o[0]; q.v[1] = o[1]; q.v[2] = o[2]; q.v[3] = o[3]; st4(dx + off, q); }
+        else stf(dx + off, o[0]);
     }
 }
 extern "C" int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_t M, int C, const float* mean_rstd,
                                  const float* ab, const float* gamma, const double* sums, int pre_act, int post_act,
                                  float* dgamma, float* dbeta, int dtype, tcct_stream_t stream) {
     (void)gamma;
+    TCCT_CHECK(C >= 1 && C <= NB, "bn_bwd_apply: C=%d unsupported", C);
     int vec = (C % 4 == 0) ? 4 : 1;
-    int64_t total = M * C / vec;
+    int R = NB / (C / vec);
+    int grid = tcct_grid(M, R, 256 * 16);
     hipStream_t st = (hipStream_t)stream;
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<T, 4>), dim3(tcct_grid(total, NB)), dim3(NB), 0, st, (const T*)x, (const T*)dy, (T*)dx, total, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
-    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<T, 1>), dim3(tcct_grid(total, NB)), dim3(NB), 0, st, (const T*)x, (const T*)dy, (T*)dx, total, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (const T*)dy, (T*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (const T*)dy, (T*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
     TCCT_LAUNCH_OK();
 }
 
