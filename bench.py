@@ -35,6 +35,7 @@ def parse():
     p.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'fp32'])
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--roofline-only', action='store_true', help='only run the dominant-kernel timing loop (for rocprofv3)')
     return p.parse_args()
 
 
@@ -52,32 +53,39 @@ def build_trainer(a, world):
     return k, ds, args
 
 
-def dominant_kernel_roofline(a, iters=10):
+def dominant_kernel_roofline(a, iters=20):
     """HIP-event timing of the dominant kernel of the step at the bench shapes, on the stream it is launched on (torch's
-    current stream == the stream every tcct_* call receives).  Dominant kernel (profiles/): the dense 3x3 32->32
-    convolution at level 0 ([bs,800,1104,32]).  Algorithmic bytes per launch = read x once + write y once
-    (SURVEY §8(d) layer-granular model) = 2 * bs*H*W*32 * sizeof(dtype); weights (36 KB) are noise."""
-    from tcct_amd import ops
+    current stream == the stream every tcct_* call receives).  Dominant kernel (profiles/r01_*): the weight gradient of the
+    dense 3x3 32->32 convolution at level 0 (k_conv32_wgrad<9,false> on [bs,800,1104,32]; fp32 mode: the VALU k_conv_wgrad).
+    Algorithmic bytes per launch = read x once + read dy once (SURVEY §8(d) layer-granular model: wgrad reads x and dy)
+    = 2 * bs*H*W*32 * sizeof(dtype); the 36 KB of dW are noise."""
+    from tcct_amd._lib import lib
     dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     Wp = (a.width + 15) // 16 * 16
     x = torch.randn((a.bs, a.height, Wp, 32), device='cuda', dtype=torch.float32).to(dt)
-    w = torch.randn((32, 32, 3, 3), device='cuda') * 0.06
-    b = torch.zeros(32, device='cuda')
-    with torch.no_grad():
-        for _ in range(2):
-            ops.conv2d(x, w, b, 1, 1)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            ops.conv2d(x, w, b, 1, 1)
-        e1.record()
-        torch.cuda.synchronize()
+    dy = torch.randn((a.bs, a.height, Wp, 32), device='cuda', dtype=torch.float32).to(dt)
+    dw = torch.empty((32, 32, 3, 3), device='cuda')
+    db = torch.empty(32, device='cuda')
+    if a.dtype == 'bf16':
+        name = 'k_conv32_wgrad<9,false> 3x3 32->32 @L0'
+        fn = lambda: lib.conv32_wgrad(x, dy, dw, db, a.bs, a.height, Wp, 3, 3, 1, 1)          # noqa: E731
+    else:
+        name = 'k_conv_wgrad<float,float> 3x3 32->32 @L0'
+        fn = lambda: lib.conv2d_wgrad(x, dy, dw, db, a.bs, a.height, Wp, 32, 32, 32, 3, 3, 1, 1, 1, 0, 0)   # noqa: E731
+    for _ in range(2):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     bytes_alg = 2.0 * x.numel() * x.element_size()
     ach = bytes_alg / (ms * 1e-3) / 1e9
     flops = 2.0 * 9 * 32 * 32 * a.bs * a.height * Wp
     return {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-            'traffic': None, 'kernel': 'conv2d_fwd 3x3 32->32 @L0', 'ms_per_launch': round(ms, 4),
+            'traffic': None, 'kernel': name, 'ms_per_launch': round(ms, 4), 'launches_timed': iters,
             'algorithmic_bytes': int(bytes_alg), 'tflops': round(flops / (ms * 1e-3) / 1e12, 2)}
 
 
@@ -123,6 +131,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X')
     torch.cuda.set_device(local)
+    if a.roofline_only:
+        print(json.dumps({'roofline': dominant_kernel_roofline(a)}))
+        return
     k, ds, args = build_trainer(a, world)
     k.model.train()
     batch = ds.make_batch(a.bs, seed=2023 + rank)
