@@ -33,6 +33,10 @@ extern "C" int tcct_conv32_pack_weights(const float* w, void* wp, int KH, int KW
     TCCT_LAUNCH_OK();
 }
 
+// Staging is software-pipelined across tiles: every thread owns up to MAXL fixed 16-byte slots of the LDS image (slot
+// geometry precomputed once), issues ALL its global loads for the NEXT tile into registers before the MFMA phase of the
+// current tile (one memory latency per tile instead of one per slot), and writes them to LDS after the barrier.
+#define MAXL 11
 template <bool VERT>
 __global__ void __launch_bounds__(MB, 2)
 k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
@@ -58,32 +62,55 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
 #pragma unroll
         for (int k = 0; k < 4; ++k) bv[q * 4 + k] = bias ? bias[8 * q + 4 * hh + k] : 0.f;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // slot geometry (tile independent): slot j covers 16-byte chunk c of tile-local pixel (lr, lc)
+    const int c = tid & 3;
+    const int npix = LH * LW;
+    int s_lr[MAXL], s_lc[MAXL], s_off[MAXL];
+#pragma unroll
+    for (int j = 0; j < MAXL; ++j) {
+        int pl = (tid >> 2) + j * (MB / 4);
+        bool in = pl < npix;
+        int lr = in ? pl / LW : -100000, lc = in ? pl - (pl / LW) * LW : 0;
+        int p = VERT ? lc * LH + lr : pl;
+        s_lr[j] = lr; s_lc[j] = lc;
+        s_off[j] = in ? p * 64 + ((c ^ ((p >> 2) & 3)) << 4) : -1;
+    }
+    uint4 pre[MAXL];
+    auto prefetch = [&](int tile) {
+        const int tw = tile % tilesW;
+        const int t2 = tile / tilesW;
+        const int th = t2 % tilesH;
+        const int n = t2 / tilesH;
+        const int hb = th * TH - PH, wb = tw * TW - PW;
+        const bf16* xb = x + (int64_t)n * H * W * 32 + c * 8;
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j) {
+            int hi = hb + s_lr[j], wi = wb + s_lc[j];
+            pre[j] = make_uint4(0, 0, 0, 0);
+            if (hi >= 0 && hi < H && wi >= 0 && wi < W)
+                pre[j] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hi * W + wi) * 32);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
         const int tw = tile % tilesW;
         const int t2 = tile / tilesW;
         const int th = t2 % tilesH;
         const int n = t2 / tilesH;
         const int h0 = th * TH, w0 = tw * TW;
         __syncthreads();
-        const int npix = LH * LW;
-        for (int i = tid; i < npix * 4; i += MB) {
-            int c = i & 3, pl = i >> 2;
-            int lr = pl / LW, lc = pl - lr * LW;
-            int hi = h0 + lr - PH, wi = w0 + lc - PW;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (hi >= 0 && hi < H && wi >= 0 && wi < W)
-                v = *reinterpret_cast<const uint4*>(x + (((int64_t)n * H + hi) * W + wi) * 32 + c * 8);
-            int p = VERT ? lc * LH + lr : pl;
-            *reinterpret_cast<uint4*>(sX + p * 64 + ((c ^ ((p >> 2) & 3)) << 4)) = v;
-        }
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j)
+            if (s_off[j] >= 0) *reinterpret_cast<uint4*>(sX + s_off[j]) = pre[j];
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
 
         f32x16 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
-        // per-M-tile base pixel (tap 0,0) in the LDS image
         int pb[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -141,6 +168,7 @@ extern "C" int tcct_conv32_fwd(const void* x, const void* wp, const float* bias,
     const int LH = TH + KH - 1, LW = TW + KW - 1;
     size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * 64;
     TCCT_CHECK(lds <= 80 * 1024, "conv32_fwd: %dx%d needs %zu B of LDS (> 80 KiB for 2 blocks/CU)", KH, KW, lds);
+    TCCT_CHECK(LH * LW * 4 <= MAXL * MB, "conv32_fwd: %dx%d tile image exceeds the staging slots", KH, KW);
     int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
     int64_t nt = (int64_t)N * tilesH * tilesW;
     TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32_fwd: bad tile count");
@@ -186,6 +214,7 @@ __global__ void __launch_bounds__(MB, 2)
 k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
                int N, int H, int W, int KH, int KW, int PH, int PW, int TG, int tilesH, int tilesW, int ntiles) {
     constexpr int TH = VERT ? 64 : 8, TW = VERT ? 8 : 64;
+    constexpr int DSL = TH * TW * 4 / MB;          // dy slots per thread (8)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int LH = TH + KH - 1, LW = TW + KW - 1;
     const int TAPS = KH * KW;
@@ -210,34 +239,61 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
         for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
     float bsum = 0.f;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // staging slots (see k_conv32_mfma): x image slots and dy image slots, geometry fixed per thread
+    const int c = tid & 3;
+    const int npix = LH * LW;
+    int s_lr[MAXL], s_lc[MAXL], s_off[MAXL], d_lr[DSL], d_lc[DSL], d_off[DSL];
+#pragma unroll
+    for (int j = 0; j < MAXL; ++j) {
+        int pl = (tid >> 2) + j * (MB / 4);
+        bool in = pl < npix;
+        int lr = in ? pl / LW : -100000, lc = in ? pl - (pl / LW) * LW : 0;
+        int p = VERT ? lc * LH + lr : pl;
+        s_lr[j] = lr; s_lc[j] = lc;
+        s_off[j] = in ? p * 64 + ((c ^ ((p >> 2) & 3)) << 4) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < DSL; ++j) {
+        int pl = (tid >> 2) + j * (MB / 4);
+        int lr = pl / TW, lc = pl - lr * TW;
+        int p = VERT ? lc * TH + lr : pl;
+        d_lr[j] = lr; d_lc[j] = lc;
+        d_off[j] = p * 64 + ((c ^ ((p >> 2) & 3)) << 4);
+    }
+    uint4 prex[MAXL], pred[DSL];
+    auto prefetch = [&](int tile) {
         const int tw = tile % tilesW;
         const int t2 = tile / tilesW;
         const int th = t2 % tilesH;
         const int n = t2 / tilesH;
         const int h0 = th * TH, w0 = tw * TW;
-        __syncthreads();
-        for (int i = tid; i < LH * LW * 4; i += MB) {
-            int c = i & 3, pl = i >> 2;
-            int lr = pl / LW, lc = pl - lr * LW;
-            int hi = h0 + lr - PH, wi_ = w0 + lc - PW;
-            uint4 v = make_uint4(0, 0, 0, 0);
+        const bf16* xb = x + (int64_t)n * H * W * 32 + c * 8;
+        const bf16* db = dy + (int64_t)n * H * W * 32 + c * 8;
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j) {
+            int hi = h0 - PH + s_lr[j], wi_ = w0 - PW + s_lc[j];
+            prex[j] = make_uint4(0, 0, 0, 0);
             if (hi >= 0 && hi < H && wi_ >= 0 && wi_ < W)
-                v = *reinterpret_cast<const uint4*>(x + (((int64_t)n * H + hi) * W + wi_) * 32 + c * 8);
-            int p = VERT ? lc * LH + lr : pl;
-            *reinterpret_cast<uint4*>(sX + p * 64 + ((c ^ ((p >> 2) & 3)) << 4)) = v;
+                prex[j] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hi * W + wi_) * 32);
         }
-        for (int i = tid; i < TH * TW * 4; i += MB) {
-            int c = i & 3, pl = i >> 2;
-            int lr = pl / TW, lc = pl - lr * TW;
-            int ho = h0 + lr, wo = w0 + lc;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ho < H && wo < W)
-                v = *reinterpret_cast<const uint4*>(dy + (((int64_t)n * H + ho) * W + wo) * 32 + c * 8);
-            int p = VERT ? lc * TH + lr : pl;
-            *reinterpret_cast<uint4*>(sD + p * 64 + ((c ^ ((p >> 2) & 3)) << 4)) = v;
+#pragma unroll
+        for (int j = 0; j < DSL; ++j) {
+            int ho = h0 + d_lr[j], wo = w0 + d_lc[j];
+            pred[j] = make_uint4(0, 0, 0, 0);
+            if (ho < H && wo < W) pred[j] = *reinterpret_cast<const uint4*>(db + ((int64_t)ho * W + wo) * 32);
         }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j)
+            if (s_off[j] >= 0) *reinterpret_cast<uint4*>(sX + s_off[j]) = prex[j];
+#pragma unroll
+        for (int j = 0; j < DSL; ++j) *reinterpret_cast<uint4*>(sD + d_off[j]) = pred[j];
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
         for (int ch = wi; ch < 32; ch += WPG) {
             const int a_ = ch >> 2, s16 = (ch & 3) * 16;      // HORZ: row / col offset; VERT: col / row offset
             const int Pd = VERT ? a_ * TH + s16 : a_ * TW + s16;
@@ -273,10 +329,11 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
         }
     }
     __syncthreads();
+    // OIHW-linear order: consecutive lanes add to consecutive addresses (256 contiguous bytes per wave instruction; a
+    // tap-major walk would scatter every lane into its own 64-byte segment: 8x the atomic traffic, PMC WRITE_SIZE 151 MB)
     for (int i = tid; i < TAPS * 1024; i += MB) {
-        const int tap = i >> 10, co = (i >> 5) & 31, ci = i & 31;
-        const int dy_ = tap / KW, dx_ = tap - dy_ * KW;
-        atomicAdd(&dw[((co * 32 + ci) * KH + dy_) * KW + dx_], red[i]);
+        const int tap = i % TAPS, cc = i / TAPS;          // cc = co*32 + ci
+        atomicAdd(&dw[i], red[tap * 1024 + cc]);
     }
     if (dbias && tg == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
@@ -304,8 +361,9 @@ extern "C" int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(dw, 0, sizeof(float) * TAPS * 1024, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
     if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
-    const int TG = TAPS > 9 ? 2 : 1;
+    const int TG = TAPS > 5 ? 2 : 1;          // <= 7 accumulators per wave keeps room for the prefetch registers
     const int tpw = (TAPS + TG - 1) / TG;
+    TCCT_CHECK(LH * LW * 4 <= MAXL * MB, "conv32_wgrad: %dx%d tile image exceeds the staging slots", KH, KW);
 #define WG_LAUNCH(TPW, V)                                                                                                   \
     do {                                                                                                                    \
         static bool attr = false;                                                                                           \
@@ -314,8 +372,7 @@ extern "C" int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float
                            KW, PH, PW, TG, tilesH, tilesW, (int)nt);                                                        \
     } while (0)
     if (tpw <= 5) { if (vert) WG_LAUNCH(5, true); else WG_LAUNCH(5, false); }
-    else if (tpw <= 7) { if (vert) WG_LAUNCH(7, true); else WG_LAUNCH(7, false); }
-    else { if (vert) WG_LAUNCH(9, true); else WG_LAUNCH(9, false); }
+    else { if (vert) WG_LAUNCH(7, true); else WG_LAUNCH(7, false); }
 #undef WG_LAUNCH
     TCCT_LAUNCH_OK();
 }
