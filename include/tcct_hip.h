@@ -110,6 +110,15 @@ int tcct_conv32_pack_weights(const float* w, void* wp, int KH, int KW, int trans
 int tcct_conv32_fwd(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
                     int PW, tcct_stream_t stream);
 
+/* the same kernels on 32-channel slabs of wider NHWC tensors (x: xs channels/pixel, slab at xo; y: ys, yo; accumulate adds
+ * into y) and on 32x32 sub-blocks (o_off, i_off) of an OIHW weight with cin_total input channels: 32->64 / 64->32 convolutions
+ * (MPViT stem[1], nets/tcct.py:682-689) run as 32x32 sub-GEMMs.  wgrad_strided ACCUMULATES: zero dw/dbias first. */
+int tcct_conv32_pack_weights_sub(const float* w, void* wp, int KH, int KW, int transposed, int cin_total, int o_off, int i_off,
+                                 tcct_stream_t stream);
+int tcct_conv32_fwd_strided(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
+                            int PW, int xs, int xo, int ys, int yo, int accumulate, tcct_stream_t stream);
+int tcct_conv32_wgrad_strided(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH,
+                              int PW, int xs, int xo, int ds, int dof, int cin_total, int o_off, int i_off, tcct_stream_t stream);
 /* weight/bias gradient of the same family (ds_read_b64_tr_b16 transposing LDS reads feed the pixel-contraction MFMA);
  * dw OIHW fp32 [32,32,KH,KW] and dbias fp32 [32] (nullable) are overwritten */
 int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH,
@@ -121,6 +130,13 @@ int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float* dbias, in
 int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                 int out_dtype, tcct_stream_t stream);
 int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
+
+/* first-layer helper: 4-channel NHWC image -> 32-channel 3x3 patch pixels (k = (ky*3+kx)*3+ch, zero for k >= 27) so that
+ * CrossResNet.cnn[0] (nets/tcct.py:873) and MPViT stem[0] (stride 2, :674-681) run as 32->32 pointwise MFMA GEMMs */
+int tcct_im2col3x3_c3(const void* x4, void* out, int N, int H, int W, int stride, int dtype, tcct_stream_t stream);
+/* weight gradient of 1x1 convs with <= 8 outputs (5-class aux heads, nets/tcct.py:994-997); dy fp32 or bf16 */
+int tcct_pw_wgrad_smalln(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, int x_dtype,
+                         int dy_dtype, tcct_stream_t stream);
 
 /* ---- depthwise 3x3 (nets/tcct.py:114-122,206,535-543; nets/reg.py:66-67,72,74 as C=1 / groups=C) -------- */
 int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,

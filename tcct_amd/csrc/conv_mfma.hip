@@ -17,19 +17,29 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define MB 256
 
 // OIHW fp32 -> [tap][co][ci] bf16 (optionally flipped + transposed: the weights of the input-gradient convolution)
-__global__ void k_pack_w32(const float* __restrict__ w, bf16* __restrict__ wp, int KH, int KW, int transposed) {
+// The 32x32 block (o_off.., i_off..) of an OIHW weight with `ldi` input channels is selected, so 32->64 / 64->32 convolutions
+// decompose into 32x32 sub-GEMMs of the same kernels.
+__global__ void k_pack_w32(const float* __restrict__ w, bf16* __restrict__ wp, int KH, int KW, int transposed, int ldi,
+                           int o_off, int i_off) {
     int total = KH * KW * 32 * 32;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         int ci = i & 31, co = (i >> 5) & 31, tap = i >> 10;
         int dy = tap / KW, dx = tap % KW;
-        float v = transposed ? w[((ci * 32 + co) * KH + (KH - 1 - dy)) * KW + (KW - 1 - dx)]
-                             : w[((co * 32 + ci) * KH + dy) * KW + dx];
+        float v = transposed ? w[(((int64_t)(o_off + ci) * ldi + i_off + co) * KH + (KH - 1 - dy)) * KW + (KW - 1 - dx)]
+                             : w[(((int64_t)(o_off + co) * ldi + i_off + ci) * KH + dy) * KW + dx];
         wp[i] = __float2bfloat16(v);
     }
 }
 extern "C" int tcct_conv32_pack_weights(const float* w, void* wp, int KH, int KW, int transposed, tcct_stream_t stream) {
     int total = KH * KW * 1024;
-    hipLaunchKernelGGL(k_pack_w32, dim3((total + MB - 1) / MB), dim3(MB), 0, (hipStream_t)stream, w, (bf16*)wp, KH, KW, transposed);
+    hipLaunchKernelGGL(k_pack_w32, dim3((total + MB - 1) / MB), dim3(MB), 0, (hipStream_t)stream, w, (bf16*)wp, KH, KW, transposed, 32, 0, 0);
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_conv32_pack_weights_sub(const float* w, void* wp, int KH, int KW, int transposed, int cin_total, int o_off,
+                                            int i_off, tcct_stream_t stream) {
+    int total = KH * KW * 1024;
+    hipLaunchKernelGGL(k_pack_w32, dim3((total + MB - 1) / MB), dim3(MB), 0, (hipStream_t)stream, w, (bf16*)wp, KH, KW, transposed,
+                       cin_total, o_off, i_off);
     TCCT_LAUNCH_OK();
 }
 
@@ -40,7 +50,9 @@ extern "C" int tcct_conv32_pack_weights(const float* w, void* wp, int KH, int KW
 template <bool VERT>
 __global__ void __launch_bounds__(MB, 2)
 k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
-              int N, int H, int W, int KH, int KW, int PH, int PW, int tilesH, int tilesW, int ntiles) {
+              int N, int H, int W, int KH, int KW, int PH, int PW, int tilesH, int tilesW, int ntiles, int xs, int xo, int ys,
+              int yo, int accum) {
+    // xs/xo, ys/yo: channels per pixel in memory and channel offset of the 32-channel slab read / written; accum: y += result
     constexpr int TH = VERT ? 64 : 8, TW = VERT ? 8 : 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int LH = TH + KH - 1, LW = TW + KW - 1;
@@ -82,13 +94,13 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         const int th = t2 % tilesH;
         const int n = t2 / tilesH;
         const int hb = th * TH - PH, wb = tw * TW - PW;
-        const bf16* xb = x + (int64_t)n * H * W * 32 + c * 8;
+        const bf16* xb = x + (int64_t)n * H * W * xs + xo + c * 8;
 #pragma unroll
         for (int j = 0; j < MAXL; ++j) {
             int hi = hb + s_lr[j], wi = wb + s_lc[j];
             pre[j] = make_uint4(0, 0, 0, 0);
             if (hi >= 0 && hi < H && wi >= 0 && wi < W)
-                pre[j] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hi * W + wi) * 32);
+                pre[j] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hi * W + wi) * xs);
         }
     };
     int tile = blockIdx.x;
@@ -144,12 +156,15 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
             int ho = VERT ? h0 + seg * 32 + r : h0 + a;
             int wo = VERT ? w0 + a : w0 + seg * 32 + r;
             if (ho < H && wo < W) {
-                bf16* yp = y + (((int64_t)n * H + ho) * W + wo) * 32 + 4 * hh;
+                bf16* yp = y + (((int64_t)n * H + ho) * W + wo) * ys + yo + 4 * hh;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    float v0 = acc[t][4 * q] + bv[4 * q], v1 = acc[t][4 * q + 1] + bv[4 * q + 1];
+                    float v2 = acc[t][4 * q + 2] + bv[4 * q + 2], v3 = acc[t][4 * q + 3] + bv[4 * q + 3];
+                    if (accum) { f4 old = ld4(yp + 8 * q); v0 += old.v[0]; v1 += old.v[1]; v2 += old.v[2]; v3 += old.v[3]; }
                     uint2 o;
-                    o.x = pack_bf16x2(acc[t][4 * q] + bv[4 * q], acc[t][4 * q + 1] + bv[4 * q + 1]);
-                    o.y = pack_bf16x2(acc[t][4 * q + 2] + bv[4 * q + 2], acc[t][4 * q + 3] + bv[4 * q + 3]);
+                    o.x = pack_bf16x2(v0, v1);
+                    o.y = pack_bf16x2(v2, v3);
                     *reinterpret_cast<uint2*>(yp + 8 * q) = o;
                 }
             }
@@ -159,8 +174,22 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
 
 /* x, y: bf16 NHWC [N,H,W,32]; wp: packed bf16 [KH*KW][32][32] from tcct_conv32_pack_weights; stride 1; output size == input
  * size requires PH = (KH-1)/2 etc. but any PH <= KH-1, PW <= KW-1 with "same" output extent H x W is accepted. */
+static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
+                           int PH, int PW, int xs, int xo, int ys, int yo, int accum, tcct_stream_t stream);
 extern "C" int tcct_conv32_fwd(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
                                int PH, int PW, tcct_stream_t stream) {
+    return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, 0, stream);
+}
+/* same kernel on 32-channel slabs of wider tensors: x has xs channels/pixel (slab at xo), y has ys (slab at yo); accumulate=1
+ * adds into y.  Used to run 32->64 / 64->32 convolutions (MPViT stem[1], nets/tcct.py:682-689) as 32x32 sub-GEMMs. */
+extern "C" int tcct_conv32_fwd_strided(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH,
+                                       int KW, int PH, int PW, int xs, int xo, int ys, int yo, int accumulate,
+                                       tcct_stream_t stream) {
+    TCCT_CHECK(xs % 8 == 0 && xo % 8 == 0 && ys % 4 == 0 && yo % 4 == 0 && xo + 32 <= xs && yo + 32 <= ys, "conv32_fwd_strided: bad slab");
+    return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, xs, xo, ys, yo, accumulate, stream);
+}
+static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
+                           int PH, int PW, int xs, int xo, int ys, int yo, int accum, tcct_stream_t stream) {
     TCCT_CHECK(KH >= 1 && KW >= 1 && KH * KW <= 13 * 13, "conv32_fwd: bad kernel %dx%d", KH, KW);
     TCCT_CHECK(2 * PH == KH - 1 && 2 * PW == KW - 1, "conv32_fwd: only 'same' padding (got pad %d,%d for %dx%d)", PH, PW, KH, KW);
     const bool vert = (KW == 1 && KH > 1);
@@ -177,11 +206,11 @@ extern "C" int tcct_conv32_fwd(const void* x, const void* wp, const float* bias,
     if (vert) {
         static bool attr_v = false;
         if (!attr_v) { (void)hipFuncSetAttribute((const void*)k_conv32_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_v = true; }
-        hipLaunchKernelGGL(k_conv32_mfma<true>, dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt);
+        hipLaunchKernelGGL(k_conv32_mfma<true>, dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum);
     } else {
         static bool attr_h = false;
         if (!attr_h) { (void)hipFuncSetAttribute((const void*)k_conv32_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_h = true; }
-        hipLaunchKernelGGL(k_conv32_mfma<false>, dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt);
+        hipLaunchKernelGGL(k_conv32_mfma<false>, dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum);
     }
     TCCT_LAUNCH_OK();
 }
@@ -212,7 +241,8 @@ __device__ __forceinline__ bf16x8 tr_load8(const unsigned char* base, int P, int
 template <int TPW, bool VERT>
 __global__ void __launch_bounds__(MB, 2)
 k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
-               int N, int H, int W, int KH, int KW, int PH, int PW, int TG, int tilesH, int tilesW, int ntiles) {
+               int N, int H, int W, int KH, int KW, int PH, int PW, int TG, int tilesH, int tilesW, int ntiles, int xs, int xo,
+               int ds, int dof, int ldi, int o_off, int i_off) {
     constexpr int TH = VERT ? 64 : 8, TW = VERT ? 8 : 64;
     constexpr int DSL = TH * TW * 4 / MB;          // dy slots per thread (8)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -267,20 +297,20 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
         const int th = t2 % tilesH;
         const int n = t2 / tilesH;
         const int h0 = th * TH, w0 = tw * TW;
-        const bf16* xb = x + (int64_t)n * H * W * 32 + c * 8;
-        const bf16* db = dy + (int64_t)n * H * W * 32 + c * 8;
+        const bf16* xb = x + (int64_t)n * H * W * xs + xo + c * 8;
+        const bf16* db = dy + (int64_t)n * H * W * ds + dof + c * 8;
 #pragma unroll
         for (int j = 0; j < MAXL; ++j) {
             int hi = h0 - PH + s_lr[j], wi_ = w0 - PW + s_lc[j];
             prex[j] = make_uint4(0, 0, 0, 0);
             if (hi >= 0 && hi < H && wi_ >= 0 && wi_ < W)
-                prex[j] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hi * W + wi_) * 32);
+                prex[j] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hi * W + wi_) * xs);
         }
 #pragma unroll
         for (int j = 0; j < DSL; ++j) {
             int ho = h0 + d_lr[j], wo = w0 + d_lc[j];
             pred[j] = make_uint4(0, 0, 0, 0);
-            if (ho < H && wo < W) pred[j] = *reinterpret_cast<const uint4*>(db + ((int64_t)ho * W + wo) * 32);
+            if (ho < H && wo < W) pred[j] = *reinterpret_cast<const uint4*>(db + ((int64_t)ho * W + wo) * ds);
         }
     };
     int tile = blockIdx.x;
@@ -333,17 +363,32 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
     // tap-major walk would scatter every lane into its own 64-byte segment: 8x the atomic traffic, PMC WRITE_SIZE 151 MB)
     for (int i = tid; i < TAPS * 1024; i += MB) {
         const int tap = i % TAPS, cc = i / TAPS;          // cc = co*32 + ci
-        atomicAdd(&dw[i], red[tap * 1024 + cc]);
+        const int co = cc >> 5, ci = cc & 31;
+        atomicAdd(&dw[((int64_t)(o_off + co) * ldi + i_off + ci) * TAPS + tap], red[tap * 1024 + cc]);
     }
     if (dbias && tg == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
-        if (lane < 32) atomicAdd(&dbias[r], bsum);
+        if (lane < 32) atomicAdd(&dbias[o_off + r], bsum);
     }
 }
 
 /* dw OIHW fp32 [32,32,KH,KW] and dbias fp32 [32] (nullable) are overwritten. */
+static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH,
+                             int PW, int xs, int xo, int ds, int dof, int ldi, int o_off, int i_off, int zero, tcct_stream_t stream);
 extern "C" int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW,
                                  int PH, int PW, tcct_stream_t stream) {
+    return conv32_wgrad_impl(x, dy, dw, dbias, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, 32, 0, 0, 1, stream);
+}
+/* 32x32 sub-block (o_off.., i_off..) of the gradient of an OIHW weight with cin_total input channels, from the x slab (xs, xo)
+ * and the dy slab (ds, dof).  This entry ACCUMULATES with atomics and clears nothing: zero dw / dbias once before the sub-calls. */
+extern "C" int tcct_conv32_wgrad_strided(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW,
+                                         int PH, int PW, int xs, int xo, int ds, int dof, int cin_total, int o_off, int i_off,
+                                         tcct_stream_t stream) {
+    TCCT_CHECK(xs % 8 == 0 && xo % 8 == 0 && ds % 8 == 0 && dof % 8 == 0 && xo + 32 <= xs && dof + 32 <= ds, "conv32_wgrad_strided: bad slab");
+    return conv32_wgrad_impl(x, dy, dw, dbias, N, H, W, KH, KW, PH, PW, xs, xo, ds, dof, cin_total, o_off, i_off, 0, stream);
+}
+static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH,
+                             int PW, int xs, int xo, int ds, int dof, int ldi, int o_off, int i_off, int zero, tcct_stream_t stream) {
     TCCT_CHECK(2 * PH == KH - 1 && 2 * PW == KW - 1, "conv32_wgrad: only 'same' padding");
     const int TAPS = KH * KW;
     TCCT_CHECK(TAPS >= 1 && TAPS <= 14, "conv32_wgrad: %dx%d unsupported (<= 14 taps)", KH, KW);
@@ -359,8 +404,10 @@ extern "C" int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float
     TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32_wgrad: bad tile count");
     int grid = (int)(nt < 512 ? nt : 512);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dw, 0, sizeof(float) * TAPS * 1024, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
-    if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
+    if (zero) {
+        if (hipMemsetAsync(dw, 0, sizeof(float) * TAPS * 1024, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
+        if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
+    }
     const int TG = TAPS > 5 ? 2 : 1;          // <= 7 accumulators per wave keeps room for the prefetch registers
     const int tpw = (TAPS + TG - 1) / TG;
     TCCT_CHECK(LH * LW * 4 <= MAXL * MB, "conv32_wgrad: %dx%d tile image exceeds the staging slots", KH, KW);
@@ -369,7 +416,7 @@ extern "C" int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float
         static bool attr = false;                                                                                           \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad<TPW, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
         hipLaunchKernelGGL((k_conv32_wgrad<TPW, V>), dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W, KH, \
-                           KW, PH, PW, TG, tilesH, tilesW, (int)nt);                                                        \
+                           KW, PH, PW, TG, tilesH, tilesW, (int)nt, xs, xo, ds, dof, ldi, o_off, i_off);                                                        \
     } while (0)
     if (tpw <= 5) { if (vert) WG_LAUNCH(5, true); else WG_LAUNCH(5, false); }
     else { if (vert) WG_LAUNCH(7, true); else WG_LAUNCH(7, false); }

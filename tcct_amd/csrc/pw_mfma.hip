@@ -248,3 +248,108 @@ extern "C" int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* db
 #undef WL
     TCCT_LAUNCH_OK();
 }
+
+
+// ------------------------------------------------------------------------------------------------ first-layer im2col
+// The two 3-channel 3x3 convolutions (CrossResNet.cnn[0], reference nets/tcct.py:873; MPViT stem[0] stride 2, :674-681) have
+// K = 27: expand the 4-channel NHWC image once into 32-channel "patch pixels" (k = (ky*3+kx)*3 + ch, k >= 27 zero) so that
+// both run as 32->32 pointwise MFMA GEMMs (forward AND weight gradient); the image itself needs no gradient.
+template <typename T>
+__global__ void k_im2col3x3_c3(const T* __restrict__ x4, T* __restrict__ out, int N, int H, int W, int stride, int Ho, int Wo) {
+    const int64_t total = (int64_t)N * Ho * Wo * 8;       // 8 lanes per output pixel, 4 patch channels each
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int sub = (int)(i & 7);
+        int64_t p = i >> 3;
+        const int wo = (int)(p % Wo);
+        int64_t q = p / Wo;
+        const int ho = (int)(q % Ho);
+        const int64_t n = q / Ho;
+        f4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = sub * 4 + j;
+            float v = 0.f;
+            if (k < 27) {
+                const int tap = k / 3, ch = k - tap * 3;
+                const int hi = ho * stride + tap / 3 - 1, wi = wo * stride + tap % 3 - 1;
+                if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = ldf(x4 + ((n * H + hi) * (int64_t)W + wi) * 4 + ch);
+            }
+            o.v[j] = v;
+        }
+        st4(out + p * 32 + sub * 4, o);
+    }
+}
+extern "C" int tcct_im2col3x3_c3(const void* x4, void* out, int N, int H, int W, int stride, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(stride == 1 || stride == 2, "im2col3x3_c3: stride %d", stride);
+    int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    int64_t total = (int64_t)N * Ho * Wo * 8;
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_im2col3x3_c3<T>, dim3(tcct_grid(total, PWB, 1 << 16)), dim3(PWB), 0, (hipStream_t)stream, (const T*)x4, (T*)out, N, H, W, stride, Ho, Wo));
+    TCCT_LAUNCH_OK();
+}
+
+// ------------------------------------------------------------------------------------------------ small-N weight gradient
+// dW[n][k] (N <= 8 outputs: the 5-class aux heads, reference nets/tcct.py:994-997,1041-1044) with fp32 or bf16 dy: HBM-bound
+// streaming reduction; thread = (4 input channels, pixel slot), N x 4 register sums, LDS combine, fp32 atomics.
+template <typename Tx, typename Td>
+__global__ void k_pw_wgrad_smalln(const Tx* __restrict__ x, const Td* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
+                                  int64_t M, int K, int N) {
+    extern __shared__ float smf[];                     // [R][N*K]
+    const int KV = K >> 2, R = PWB / KV;
+    const int t = threadIdx.x, kv = t % KV, r = t / KV;
+    float acc[8][4], bs[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { bs[n] = 0.f; acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.f; }
+    if (r < R) {
+        for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += (int64_t)gridDim.x * R) {
+            f4 xv = ld4(x + m * K + kv * 4);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                if (n < N) {
+                    float d = ldf(dy + m * N + n);
+                    bs[n] += d;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[n][j] += d * xv.v[j];
+                }
+            }
+        }
+    }
+    for (int i = t; i < R * N * K; i += PWB) smf[i] = 0.f;
+    __syncthreads();
+    if (r < R) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            if (n < N) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) smf[(r * N + n) * K + kv * 4 + j] = acc[n][j];
+            }
+    }
+    __syncthreads();
+    for (int i = t; i < N * K; i += PWB) {
+        float a = 0.f;
+        for (int rr = 0; rr < R; ++rr) a += smf[rr * N * K + i];
+        atomicAdd(&dw[i], a);
+    }
+    if (dbias && kv == 0 && r < R) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            if (n < N) atomicAdd(&dbias[n], bs[n]);
+    }
+}
+/* x [M,K] (K % 4 == 0, K <= 256), dy [M,N] fp32 or bf16 (N <= 8) -> dw fp32 [N,K], dbias [N] (nullable); overwritten */
+extern "C" int tcct_pw_wgrad_smalln(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, int x_dtype,
+                                    int dy_dtype, tcct_stream_t stream) {
+    TCCT_CHECK(K % 4 == 0 && K >= 4 && K <= 256 && N >= 1 && N <= 8, "pw_wgrad_smalln: unsupported K=%d N=%d", K, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, sizeof(float) * N * K, st) != hipSuccess) { tcct_set_error("pw_wgrad_smalln: memset failed"); return -2; }
+    if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * N, st) != hipSuccess) { tcct_set_error("pw_wgrad_smalln: memset failed"); return -2; }
+    int R = PWB / (K / 4);
+    size_t lds = sizeof(float) * (size_t)R * N * K;
+    int grid = tcct_grid(M, R, 1024);
+#define SL(TX, TD) hipLaunchKernelGGL((k_pw_wgrad_smalln<TX, TD>), dim3(grid), dim3(PWB), lds, st, (const TX*)x, (const TD*)dy, dw, dbias, M, K, N)
+    if (x_dtype == TCCT_BF16 && dy_dtype == TCCT_F32) SL(bf16, float);
+    else if (x_dtype == TCCT_BF16 && dy_dtype == TCCT_BF16) SL(bf16, bf16);
+    else if (x_dtype == TCCT_F32 && dy_dtype == TCCT_F32) SL(float, float);
+    else { tcct_set_error("pw_wgrad_smalln: bad dtypes"); return -1; }
+#undef SL
+    TCCT_LAUNCH_OK();
+}

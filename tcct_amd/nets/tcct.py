@@ -77,7 +77,7 @@ class CrossResNet(nn.Module):
     def forward(self, x):
         """x: NHWC [B,H,W,4] (3 image channels + zero pad)."""
         xs = []
-        x = _bn(self.cnn[1], _conv(self.cnn[0], x))
+        x = _bn(self.cnn[1], ops.conv3x3_c3(x, self.cnn[0].weight, self.cnn[0].bias, 1))
         n = len(self.path_estan)
         for i, enc in enumerate(self.path_estan):
             x = enc(x)
@@ -100,7 +100,11 @@ class Conv2d_BN(nn.Module):
         self.act = act
 
     def forward(self, x):
-        return _bn(self.bn, _conv(self.conv, x), post='hswish' if self.act else None)
+        if self.conv.in_channels == 3:          # stem[0]: 3-channel input -> im2col + pointwise MFMA
+            y = ops.conv3x3_c3(x, self.conv.weight, None, self.conv.stride[0])
+        else:
+            y = _conv(self.conv, x)
+        return _bn(self.bn, y, post='hswish' if self.act else None)
 
 
 class DWConv2d_BN(nn.Module):

@@ -37,6 +37,28 @@ def _mfma32_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
             and 2 * padh == KH - 1 and 2 * padw == KW - 1 and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
 
 
+def _mfma_slabs_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+    """32->64 / 64->32 / 64->64 bf16 3x3 'same' convolutions as 32x32 sub-GEMMs of the conv32 kernels (MPViT stem[1])"""
+    return (in_dt == torch.bfloat16 and out_dt == torch.bfloat16 and Cin == Cin_w and Cin in (32, 64) and Cout in (32, 64)
+            and (Cin, Cout) != (32, 32) and stride == 1 and KH == 3 and KW == 3 and padh == 1 and padw == 1)
+
+
+def _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, transposed):
+    """y[..., Cout] = conv(x[..., Cin]) via 32x32 sub-GEMMs; transposed=True computes the input gradient (x=dy, w OIHW [Cin_orig=Cout
+    here][...]) i.e. roles of the weight's O/I dims swap"""
+    wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
+    for oh in range(Cout // 32):
+        for ih in range(Cin // 32):
+            if not transposed:
+                lib.conv32_pack_weights_sub(w, wp, KH, KW, 0, Cin, 32 * oh, 32 * ih)
+            else:       # w is OIHW [Cin(this call's input = orig Cout)][Cout(this call's output = orig Cin)]
+                lib.conv32_pack_weights_sub(w, wp, KH, KW, 1, Cout, 32 * ih, 32 * oh)
+            b = bias[32 * oh:32 * oh + 32] if (bias is not None and ih == 0) else None
+            lib.conv32_fwd_strided(x, wp, b, y, N, H, W, KH, KW, padh, padw, Cin, 32 * ih, Cout, 32 * oh, 1 if ih > 0 else 0)
+            if ih + 1 < Cin // 32 or oh + 1 < Cout // 32:
+                wp = torch.empty_like(wp)
+
+
 def _pw_ok(in_dt, Cin, Cin_w, KH, KW, stride, padh, padw):
     """the MFMA pointwise kernels cover bf16 1x1 convs / Linear with Cin % 32 == 0"""
     return (in_dt == torch.bfloat16 and KH == 1 and KW == 1 and stride == 1 and padh == 0 and padw == 0 and Cin == Cin_w
@@ -56,6 +78,8 @@ class _Conv2d(torch.autograd.Function):
         mfma = _mfma32_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw)
         if _pw_ok(x.dtype, Cin, Cin_w, KH, KW, stride, padh, padw) and not mfma:
             lib.pw_fwd(x, w, bias, y, N * H * W, Cin, Cout, 0, dtype_code(odt))
+        elif _mfma_slabs_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+            _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, False)
         elif mfma:
             wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
             lib.conv32_pack_weights(w, wp, KH, KW, 0)
@@ -82,6 +106,8 @@ class _Conv2d(torch.autograd.Function):
             if (_pw_ok(dy.dtype, Cout, Cout, KH, KW, stride, padh, padw) and x.dtype == torch.bfloat16
                     and not _mfma32_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw)):
                 lib.pw_fwd(dy, w, None, dx, N * H * W, Cout, Cin, 1, dtype_code(x.dtype))
+            elif _mfma_slabs_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
+                _conv_slabs_fwd(dy, w, None, dx, N, H, W, Cout, Cin, KH, KW, KH - 1 - padh, KW - 1 - padw, True)
             elif _mfma32_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
                 wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
                 lib.conv32_pack_weights(w, wp, KH, KW, 1)
@@ -93,9 +119,20 @@ class _Conv2d(torch.autograd.Function):
             db = torch.empty(Cout, device=w.device, dtype=torch.float32) if has_bias else None
             if _mfma32_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
                 lib.conv32_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
+            elif _mfma_slabs_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+                dw.zero_()
+                if db is not None:
+                    db.zero_()
+                for oh in range(Cout // 32):
+                    for ih in range(Cin // 32):
+                        lib.conv32_wgrad_strided(x, dy, dw, db if ih == 0 else None, N, H, W, KH, KW, padh, padw, Cin, 32 * ih, Cout,
+                                                 32 * oh, Cin, 32 * oh, 32 * ih)
             elif (_pw_ok(x.dtype, Cin, Cin_w, KH, KW, stride, padh, padw) and dy.dtype == torch.bfloat16 and Cout % 32 == 0
                   and Cout <= 160):
                 lib.pw_wgrad(x, dy, dw, db, N * H * W, Cin, Cout)
+            elif KH == 1 and KW == 1 and stride == 1 and Cout <= 8 and Cin == Cin_w and Cin <= 256 and (
+                    x.dtype == torch.bfloat16 or dy.dtype == torch.float32):
+                lib.pw_wgrad_smalln(x, dy, dw, db, N * H * W, Cin, Cout, dtype_code(x.dtype), dtype_code(dy.dtype))
             else:
                 lib.conv2d_wgrad(x, dy, dw, db, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
                                  dtype_code(dy.dtype))
@@ -112,6 +149,25 @@ def conv2d(x, w, bias=None, stride=1, pad=0, out_dtype=None):
         w = w.view(w.shape[0], w.shape[1], 1, 1)
     y = _Conv2d.apply(x, w, bias, stride, ph, pw, out_dtype)
     return y.squeeze(2) if tok else y
+
+
+def im2col3x3_c3(x4, stride=1):
+    """x4 NHWC [N,H,W,4] (3 image channels + zero pad) -> 3x3 patch pixels [N,Ho,Wo,32]; no gradient (the image needs none)"""
+    _chk(x4)
+    N, H, W, C = x4.shape
+    if C != 4:
+        raise TcctError('im2col3x3_c3 expects the 4-channel NHWC image')
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((N, Ho, Wo, 32), device=x4.device, dtype=x4.dtype)
+    lib.im2col3x3_c3(x4.detach(), out, N, H, W, stride, dtype_code(x4.dtype))
+    return out
+
+
+def conv3x3_c3(x4, w, bias, stride=1):
+    """3-channel 3x3 conv (pad 1) as im2col + 32->32 pointwise GEMM: w [32,3,3,3] is re-laid out to [32, 27->32] by view ops
+    (differentiable plumbing on 864 elements), so forward and weight gradient both run on the MFMA pointwise kernels"""
+    w2 = torch.nn.functional.pad(w.permute(0, 2, 3, 1).reshape(w.shape[0], 27), (0, 5)).contiguous()
+    return conv2d(im2col3x3_c3(x4, stride), w2.view(w.shape[0], 32, 1, 1), bias)
 
 
 class _DwConv(torch.autograd.Function):

@@ -35,7 +35,8 @@ def rnd(*shape, seed=0, dt=torch.float32):
     (160, 32, 1, 1, 1, 0, 0, 4, 6), (32, 32, 3, 3, 1, 1, 1, 70, 130), (32, 32, 1, 11, 1, 0, 5, 20, 150),
     (32, 32, 9, 1, 1, 4, 0, 150, 20), (32, 32, 5, 1, 1, 2, 0, 64, 8), (32, 32, 1, 5, 1, 0, 2, 8, 64), (32, 32, 7, 1, 1, 3, 0, 33, 9),
     (32, 32, 1, 7, 1, 0, 3, 9, 33), (32, 32, 1, 1, 1, 0, 0, 19, 70), (64, 64, 1, 1, 1, 0, 0, 21, 33), (96, 32, 1, 1, 1, 0, 0, 9, 50),
-    (192, 128, 1, 1, 1, 0, 0, 10, 17), (256, 160, 1, 1, 1, 0, 0, 7, 9), (64, 96, 1, 1, 1, 0, 0, 40, 55)])
+    (192, 128, 1, 1, 1, 0, 0, 10, 17), (256, 160, 1, 1, 1, 0, 0, 7, 9), (64, 96, 1, 1, 1, 0, 0, 40, 55), (32, 64, 3, 3, 1, 1, 1, 19, 70), (64, 32, 3, 3, 1, 1, 1, 19, 70),
+    (64, 64, 3, 3, 1, 1, 1, 9, 40)])
 def test_conv2d(dt, cfg):
     from tcct_amd import ops
     Cw, Co, KH, KW, s, ph, pw, H, W = cfg
@@ -62,6 +63,28 @@ def test_conv2d(dt, cfg):
     torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, b.grad.abs().max().item()))
     if Cw % 4 == 0:
         torch.testing.assert_close(nchw(xd.grad), x.grad, **t)
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('stride', [1, 2])
+def test_first_layer_im2col_conv(dt, stride):
+    """3-channel 3x3 conv as im2col + pointwise GEMM (cnn[0], stem[0]) incl. the weight-gradient remapping"""
+    from tcct_amd import ops
+    N, H, W = 2, 18, 26
+    x = rnd(N, 3, H, W, dt=dt)
+    w = (rnd(32, 3, 3, 3, seed=1) / 27 ** 0.5).requires_grad_(True)
+    b = rnd(32, seed=2).requires_grad_(True)
+    y = F.conv2d(x, w, b, stride, 1)
+    gy = rnd(*y.shape, seed=3, dt=dt)
+    y.backward(gy)
+    xd = nhwc(F.pad(x, (0, 0, 0, 0, 0, 1)), dt)
+    wd, bd = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    yd = ops.conv3x3_c3(xd, wd, bd, stride)
+    t = tol(dt)
+    torch.testing.assert_close(nchw(yd), y.detach(), **t)
+    yd.backward(nhwc(gy, dt))
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, w.grad.abs().max().item()))
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, b.grad.abs().max().item()))
 
 
 @pytest.mark.parametrize('dt', DT)
