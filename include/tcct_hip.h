@@ -110,6 +110,10 @@ int tcct_conv32_pack_weights(const float* w, void* wp, int KH, int KW, int trans
 int tcct_conv32_fwd(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
                     int PW, tcct_stream_t stream);
 
+/* forward + fused train-mode BatchNorm statistics of the consumer: stats[64] fp64 (zero on entry) += per-channel {sum, sum of
+ * squares} of pre_act(y), y as stored -- replaces the tcct_bn_stats pass (conv -> [LeakyReLU ->] BN, nets/tcct.py:808-822,892) */
+int tcct_conv32_fwd_bnstats(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
+                            int PW, double* stats, int pre_act, tcct_stream_t stream);
 /* the same kernels on 32-channel slabs of wider NHWC tensors (x: xs channels/pixel, slab at xo; y: ys, yo; accumulate adds
  * into y) and on 32x32 sub-blocks (o_off, i_off) of an OIHW weight with cin_total input channels: 32->64 / 64->32 convolutions
  * (MPViT stem[1], nets/tcct.py:682-689) run as 32x32 sub-GEMMs.  wgrad_strided ACCUMULATES: zero dw/dbias first. */

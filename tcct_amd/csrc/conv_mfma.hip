@@ -47,11 +47,13 @@ extern "C" int tcct_conv32_pack_weights_sub(const float* w, void* wp, int KH, in
 // geometry precomputed once), issues ALL its global loads for the NEXT tile into registers before the MFMA phase of the
 // current tile (one memory latency per tile instead of one per slot), and writes them to LDS after the barrier.
 #define MAXL 11
-template <bool VERT>
+template <bool VERT, bool STATS>
 __global__ void __launch_bounds__(MB, 2)
 k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
               int N, int H, int W, int KH, int KW, int PH, int PW, int tilesH, int tilesW, int ntiles, int xs, int xo, int ys,
-              int yo, int accum) {
+              int yo, int accum, double* __restrict__ stats, int stat_pre) {
+    // stats != NULL: also accumulate per-channel sum / sum-of-squares of pre_act(y) (y as stored, i.e. bf16-rounded) into
+    // stats[0..31] / stats[32..63] -- the train-mode BatchNorm statistics of the consumer, fused into this epilogue
     // xs/xo, ys/yo: channels per pixel in memory and channel offset of the 32-channel slab read / written; accum: y += result
     constexpr int TH = VERT ? 64 : 8, TW = VERT ? 8 : 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -68,23 +70,21 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         uint4 v = reinterpret_cast<const uint4*>(wp)[i];
         *reinterpret_cast<uint4*>(sW + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = v;
     }
-    float bv[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) bv[q * 4 + k] = bias ? bias[8 * q + 4 * hh + k] : 0.f;
+    // bias lives in LDS (behind the input image) and is re-read in the epilogue: 16 fewer live VGPRs in the MFMA loop
+    float* sB = reinterpret_cast<float*>(sX + LH * LW * 64);
+    if (tid < 32) sB[tid] = bias ? bias[tid] : 0.f;
 
-    // slot geometry (tile independent): slot j covers 16-byte chunk c of tile-local pixel (lr, lc)
+    // slot geometry (tile independent): slot j covers 16-byte chunk c of tile-local pixel (lr, lc); (lr,lc) packed in one int
     const int c = tid & 3;
     const int npix = LH * LW;
-    int s_lr[MAXL], s_lc[MAXL], s_off[MAXL];
+    int s_rc[MAXL], s_off[MAXL];
 #pragma unroll
     for (int j = 0; j < MAXL; ++j) {
         int pl = (tid >> 2) + j * (MB / 4);
         bool in = pl < npix;
-        int lr = in ? pl / LW : -100000, lc = in ? pl - (pl / LW) * LW : 0;
+        int lr = in ? pl / LW : 0x3fff, lc = in ? pl - (pl / LW) * LW : 0;
         int p = VERT ? lc * LH + lr : pl;
-        s_lr[j] = lr; s_lc[j] = lc;
+        s_rc[j] = (lr << 16) | lc;
         s_off[j] = in ? p * 64 + ((c ^ ((p >> 2) & 3)) << 4) : -1;
     }
     uint4 pre[MAXL];
@@ -97,12 +97,15 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         const bf16* xb = x + (int64_t)n * H * W * xs + xo + c * 8;
 #pragma unroll
         for (int j = 0; j < MAXL; ++j) {
-            int hi = hb + s_lr[j], wi = wb + s_lc[j];
+            int hi = hb + (s_rc[j] >> 16), wi = wb + (s_rc[j] & 0xffff);
             pre[j] = make_uint4(0, 0, 0, 0);
             if (hi >= 0 && hi < H && wi >= 0 && wi < W)
                 pre[j] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hi * W + wi) * xs);
         }
     };
+    float ss[STATS ? 16 : 1], sq[STATS ? 16 : 1];
+#pragma unroll
+    for (int k = 0; k < (STATS ? 16 : 1); ++k) ss[k] = sq[k] = 0.f;
     int tile = blockIdx.x;
     if (tile < ntiles) prefetch(tile);
     for (; tile < ntiles; tile += gridDim.x) {
@@ -159,26 +162,59 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
                 bf16* yp = y + (((int64_t)n * H + ho) * W + wo) * ys + yo + 4 * hh;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float v0 = acc[t][4 * q] + bv[4 * q], v1 = acc[t][4 * q + 1] + bv[4 * q + 1];
-                    float v2 = acc[t][4 * q + 2] + bv[4 * q + 2], v3 = acc[t][4 * q + 3] + bv[4 * q + 3];
+                    const float4 bq = *reinterpret_cast<const float4*>(sB + 8 * q + 4 * hh);
+                    float v0 = acc[t][4 * q] + bq.x, v1 = acc[t][4 * q + 1] + bq.y;
+                    float v2 = acc[t][4 * q + 2] + bq.z, v3 = acc[t][4 * q + 3] + bq.w;
                     if (accum) { f4 old = ld4(yp + 8 * q); v0 += old.v[0]; v1 += old.v[1]; v2 += old.v[2]; v3 += old.v[3]; }
                     uint2 o;
                     o.x = pack_bf16x2(v0, v1);
                     o.y = pack_bf16x2(v2, v3);
                     *reinterpret_cast<uint2*>(yp + 8 * q) = o;
+                    if (STATS) {
+                        float u0 = act_fwd(stat_pre, __uint_as_float(o.x << 16)), u1 = act_fwd(stat_pre, __uint_as_float(o.x & 0xffff0000u));
+                        float u2 = act_fwd(stat_pre, __uint_as_float(o.y << 16)), u3 = act_fwd(stat_pre, __uint_as_float(o.y & 0xffff0000u));
+                        ss[4 * q] += u0; sq[4 * q] += u0 * u0; ss[4 * q + 1] += u1; sq[4 * q + 1] += u1 * u1;
+                        ss[4 * q + 2] += u2; sq[4 * q + 2] += u2 * u2; ss[4 * q + 3] += u3; sq[4 * q + 3] += u3 * u3;
+                    }
                 }
             }
         }
+    }
+    if (STATS) {
+        // lanes r = 0..31 of each half hold different pixels of the same 16 channels: butterfly over r, then LDS, then fp64 atomics
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(sX);
+        if (tid < 64) red[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a = ss[k], b = sq[k];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            if (r == 0) {
+                const int co = 8 * (k >> 2) + 4 * hh + (k & 3);
+                atomicAdd(&red[co], a);
+                atomicAdd(&red[32 + co], b);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) atomicAdd(&stats[tid], (double)red[tid]);
     }
 }
 
 /* x, y: bf16 NHWC [N,H,W,32]; wp: packed bf16 [KH*KW][32][32] from tcct_conv32_pack_weights; stride 1; output size == input
  * size requires PH = (KH-1)/2 etc. but any PH <= KH-1, PW <= KW-1 with "same" output extent H x W is accepted. */
 static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
-                           int PH, int PW, int xs, int xo, int ys, int yo, int accum, tcct_stream_t stream);
+                           int PH, int PW, int xs, int xo, int ys, int yo, int accum, double* stats, int stat_pre, tcct_stream_t stream);
 extern "C" int tcct_conv32_fwd(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
                                int PH, int PW, tcct_stream_t stream) {
-    return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, 0, stream);
+    return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, 0, nullptr, 0, stream);
+}
+/* forward + fused BatchNorm statistics of the consumer: stats[64] (fp64, must be zero on entry) += {sum, sum of squares} per
+ * output channel of pre_act(y) with y as stored (bf16) -- replaces a separate tcct_bn_stats pass over y */
+extern "C" int tcct_conv32_fwd_bnstats(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
+                                       int PH, int PW, double* stats, int pre_act, tcct_stream_t stream) {
+    return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, 0, stats, pre_act, stream);
 }
 /* same kernel on 32-channel slabs of wider tensors: x has xs channels/pixel (slab at xo), y has ys (slab at yo); accumulate=1
  * adds into y.  Used to run 32->64 / 64->32 convolutions (MPViT stem[1], nets/tcct.py:682-689) as 32x32 sub-GEMMs. */
@@ -186,16 +222,16 @@ extern "C" int tcct_conv32_fwd_strided(const void* x, const void* wp, const floa
                                        int KW, int PH, int PW, int xs, int xo, int ys, int yo, int accumulate,
                                        tcct_stream_t stream) {
     TCCT_CHECK(xs % 8 == 0 && xo % 8 == 0 && ys % 4 == 0 && yo % 4 == 0 && xo + 32 <= xs && yo + 32 <= ys, "conv32_fwd_strided: bad slab");
-    return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, xs, xo, ys, yo, accumulate, stream);
+    return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, xs, xo, ys, yo, accumulate, nullptr, 0, stream);
 }
 static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
-                           int PH, int PW, int xs, int xo, int ys, int yo, int accum, tcct_stream_t stream) {
+                           int PH, int PW, int xs, int xo, int ys, int yo, int accum, double* stats, int stat_pre, tcct_stream_t stream) {
     TCCT_CHECK(KH >= 1 && KW >= 1 && KH * KW <= 13 * 13, "conv32_fwd: bad kernel %dx%d", KH, KW);
     TCCT_CHECK(2 * PH == KH - 1 && 2 * PW == KW - 1, "conv32_fwd: only 'same' padding (got pad %d,%d for %dx%d)", PH, PW, KH, KW);
     const bool vert = (KW == 1 && KH > 1);
     const int TH = vert ? 64 : 8, TW = vert ? 8 : 64;
     const int LH = TH + KH - 1, LW = TW + KW - 1;
-    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * 64;
+    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * 64 + 128;
     TCCT_CHECK(lds <= 80 * 1024, "conv32_fwd: %dx%d needs %zu B of LDS (> 80 KiB for 2 blocks/CU)", KH, KW, lds);
     TCCT_CHECK(LH * LW * 4 <= MAXL * MB, "conv32_fwd: %dx%d tile image exceeds the staging slots", KH, KW);
     int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
@@ -203,15 +239,16 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
     TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32_fwd: bad tile count");
     int grid = (int)(nt < 512 ? nt : 512);
     hipStream_t st = (hipStream_t)stream;
-    if (vert) {
-        static bool attr_v = false;
-        if (!attr_v) { (void)hipFuncSetAttribute((const void*)k_conv32_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_v = true; }
-        hipLaunchKernelGGL(k_conv32_mfma<true>, dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum);
-    } else {
-        static bool attr_h = false;
-        if (!attr_h) { (void)hipFuncSetAttribute((const void*)k_conv32_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_h = true; }
-        hipLaunchKernelGGL(k_conv32_mfma<false>, dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum);
-    }
+#define CF_LAUNCH(V, S)                                                                                                     \
+    do {                                                                                                                    \
+        static bool attr = false;                                                                                           \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_mfma<V, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+        hipLaunchKernelGGL((k_conv32_mfma<V, S>), dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, KH, \
+                           KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum, stats, stat_pre);                    \
+    } while (0)
+    if (vert) { if (stats) CF_LAUNCH(true, true); else CF_LAUNCH(true, false); }
+    else { if (stats) CF_LAUNCH(false, true); else CF_LAUNCH(false, false); }
+#undef CF_LAUNCH
     TCCT_LAUNCH_OK();
 }
 
@@ -272,23 +309,15 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
     // staging slots (see k_conv32_mfma): x image slots and dy image slots, geometry fixed per thread
     const int c = tid & 3;
     const int npix = LH * LW;
-    int s_lr[MAXL], s_lc[MAXL], s_off[MAXL], d_lr[DSL], d_lc[DSL], d_off[DSL];
+    int s_rc[MAXL], s_off[MAXL];
 #pragma unroll
     for (int j = 0; j < MAXL; ++j) {
         int pl = (tid >> 2) + j * (MB / 4);
         bool in = pl < npix;
-        int lr = in ? pl / LW : -100000, lc = in ? pl - (pl / LW) * LW : 0;
+        int lr = in ? pl / LW : 0x3fff, lc = in ? pl - (pl / LW) * LW : 0;
         int p = VERT ? lc * LH + lr : pl;
-        s_lr[j] = lr; s_lc[j] = lc;
+        s_rc[j] = (lr << 16) | lc;
         s_off[j] = in ? p * 64 + ((c ^ ((p >> 2) & 3)) << 4) : -1;
-    }
-#pragma unroll
-    for (int j = 0; j < DSL; ++j) {
-        int pl = (tid >> 2) + j * (MB / 4);
-        int lr = pl / TW, lc = pl - lr * TW;
-        int p = VERT ? lc * TH + lr : pl;
-        d_lr[j] = lr; d_lc[j] = lc;
-        d_off[j] = p * 64 + ((c ^ ((p >> 2) & 3)) << 4);
     }
     uint4 prex[MAXL], pred[DSL];
     auto prefetch = [&](int tile) {
@@ -301,14 +330,15 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
         const bf16* db = dy + (int64_t)n * H * W * ds + dof + c * 8;
 #pragma unroll
         for (int j = 0; j < MAXL; ++j) {
-            int hi = h0 - PH + s_lr[j], wi_ = w0 - PW + s_lc[j];
+            int hi = h0 - PH + (s_rc[j] >> 16), wi_ = w0 - PW + (s_rc[j] & 0xffff);
             prex[j] = make_uint4(0, 0, 0, 0);
             if (hi >= 0 && hi < H && wi_ >= 0 && wi_ < W)
                 prex[j] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hi * W + wi_) * xs);
         }
 #pragma unroll
         for (int j = 0; j < DSL; ++j) {
-            int ho = h0 + d_lr[j], wo = w0 + d_lc[j];
+            const int pl = (tid >> 2) + j * (MB / 4);           // TW is a power of two: shifts, no tables
+            int ho = h0 + pl / TW, wo = w0 + (pl & (TW - 1));
             pred[j] = make_uint4(0, 0, 0, 0);
             if (ho < H && wo < W) pred[j] = *reinterpret_cast<const uint4*>(db + ((int64_t)ho * W + wo) * ds);
         }
@@ -321,7 +351,11 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
         for (int j = 0; j < MAXL; ++j)
             if (s_off[j] >= 0) *reinterpret_cast<uint4*>(sX + s_off[j]) = prex[j];
 #pragma unroll
-        for (int j = 0; j < DSL; ++j) *reinterpret_cast<uint4*>(sD + d_off[j]) = pred[j];
+        for (int j = 0; j < DSL; ++j) {
+            const int pl = (tid >> 2) + j * (MB / 4);
+            const int p = VERT ? (pl & (TW - 1)) * TH + pl / TW : pl;
+            *reinterpret_cast<uint4*>(sD + p * 64 + ((c ^ ((p >> 2) & 3)) << 4)) = pred[j];
+        }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
         for (int ch = wi; ch < 32; ch += WPG) {
@@ -391,7 +425,7 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
                              int PW, int xs, int xo, int ds, int dof, int ldi, int o_off, int i_off, int zero, tcct_stream_t stream) {
     TCCT_CHECK(2 * PH == KH - 1 && 2 * PW == KW - 1, "conv32_wgrad: only 'same' padding");
     const int TAPS = KH * KW;
-    TCCT_CHECK(TAPS >= 1 && TAPS <= 14, "conv32_wgrad: %dx%d unsupported (<= 14 taps)", KH, KW);
+    TCCT_CHECK(TAPS >= 1 && TAPS <= 16, "conv32_wgrad: %dx%d unsupported (<= 16 taps)", KH, KW);
     const bool vert = (KW == 1 && KH > 1);
     const int TH = vert ? 64 : 8, TW = vert ? 8 : 64;
     const int LH = TH + KH - 1, LW = TW + KW - 1;
@@ -408,8 +442,10 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
         if (hipMemsetAsync(dw, 0, sizeof(float) * TAPS * 1024, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
         if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
     }
-    const int TG = TAPS > 5 ? 2 : 1;          // <= 7 accumulators per wave keeps room for the prefetch registers
+    // taps are split over TG wave groups so that <= 5 accumulators (80 VGPRs) live next to the prefetch registers: no spills
+    const int TG = TAPS > 10 ? 4 : (TAPS > 5 ? 2 : 1);
     const int tpw = (TAPS + TG - 1) / TG;
+    TCCT_CHECK(TAPS <= 16, "conv32_wgrad: %d taps unsupported", TAPS);
     TCCT_CHECK(LH * LW * 4 <= MAXL * MB, "conv32_wgrad: %dx%d tile image exceeds the staging slots", KH, KW);
 #define WG_LAUNCH(TPW, V)                                                                                                   \
     do {                                                                                                                    \
@@ -418,8 +454,8 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
         hipLaunchKernelGGL((k_conv32_wgrad<TPW, V>), dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W, KH, \
                            KW, PH, PW, TG, tilesH, tilesW, (int)nt, xs, xo, ds, dof, ldi, o_off, i_off);                                                        \
     } while (0)
-    if (tpw <= 5) { if (vert) WG_LAUNCH(5, true); else WG_LAUNCH(5, false); }
-    else { if (vert) WG_LAUNCH(7, true); else WG_LAUNCH(7, false); }
+    if (tpw <= 4) { if (vert) WG_LAUNCH(4, true); else WG_LAUNCH(4, false); }
+    else { if (vert) WG_LAUNCH(5, true); else WG_LAUNCH(5, false); }
 #undef WG_LAUNCH
     TCCT_LAUNCH_OK();
 }

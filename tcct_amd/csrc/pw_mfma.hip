@@ -300,17 +300,26 @@ __global__ void k_pw_wgrad_smalln(const Tx* __restrict__ x, const Td* __restrict
 #pragma unroll
     for (int n = 0; n < 8; ++n) { bs[n] = 0.f; acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.f; }
     if (r < R) {
-        for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += (int64_t)gridDim.x * R) {
-            f4 xv = ld4(x + m * K + kv * 4);
+        const int64_t step = (int64_t)gridDim.x * R;
+        for (int64_t m0 = (int64_t)blockIdx.x * R + r; m0 < M; m0 += 2 * step) {
+            f4 xv[2];
+            float d[2][8];
 #pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                if (n < N) {
-                    float d = ldf(dy + m * N + n);
-                    bs[n] += d;
+            for (int u = 0; u < 2; ++u) {               // 2 rows in flight per thread
+                const int64_t m = m0 + u * step;
+                const bool ok = m < M;
+                xv[u] = ok ? ld4(x + m * K + kv * 4) : f4zero();
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[n][j] += d * xv.v[j];
-                }
+                for (int n = 0; n < 8; ++n) d[u][n] = (ok && n < N) ? ldf(dy + m * N + n) : 0.f;
             }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    bs[n] += d[u][n];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[n][j] += d[u][n] * xv[u].v[j];
+                }
         }
     }
     for (int i = t; i < R * N * K; i += PWB) smf[i] = 0.f;

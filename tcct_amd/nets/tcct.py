@@ -19,8 +19,8 @@ from .._lib import TcctError
 KSIZES = (13, 11, 9, 7, 5)
 
 
-def _conv(m, x, out_dtype=None):
-    return ops.conv2d(x, m.weight, m.bias, stride=m.stride[0], pad=tuple(m.padding), out_dtype=out_dtype)
+def _conv(m, x, out_dtype=None, stats_pre=None):
+    return ops.conv2d(x, m.weight, m.bias, stride=m.stride[0], pad=tuple(m.padding), out_dtype=out_dtype, stats_pre=stats_pre)
 
 
 def _dw(m, x, add_input=False):
@@ -50,12 +50,13 @@ class CrossCNNBlock(nn.Module):
         self.block5 = nn.Sequential(nn.Conv2d(out_c, out_c, 3, padding=1), nn.LeakyReLU(), nn.BatchNorm2d(out_c))
 
     def forward(self, x):
-        a = _conv(self.block12[1], _conv(self.block12[0], x))
+        tr = self.training
+        a = _conv(self.block12[1], _conv(self.block12[0], x), stats_pre='lrelu' if tr else None)
         a = _bn(self.block12[3], a, pre='lrelu')
-        b = _conv(self.block34[2], _conv(self.block34[1], _conv(self.block34[0], x)))
+        b = _conv(self.block34[2], _conv(self.block34[1], _conv(self.block34[0], x)), stats_pre='lrelu' if tr else None)
         b = _bn(self.block34[4], b, pre='lrelu')
         c = ops.add_act(a, b, 'gelu')
-        return _bn(self.block5[2], _conv(self.block5[0], c), pre='lrelu')
+        return _bn(self.block5[2], _conv(self.block5[0], c, stats_pre='lrelu' if tr else None), pre='lrelu')
 
 
 class CrossResNet(nn.Module):
@@ -324,7 +325,7 @@ class MPUpBlock(nn.Module):
         self.post = nn.Sequential(nn.Conv2d(out_ch, out_ch, 1, 1, 0))
 
     def forward(self, x1, x2):
-        y = _bn(self.prep[1], _conv(self.prep[0], x1), post='lrelu')
+        y = _bn(self.prep[1], _conv(self.prep[0], x1, stats_pre='none' if self.training else None), post='lrelu')
         y = ops.bilinear(y, (x1.shape[1] * 2, x1.shape[2] * 2), True)
         return _conv(self.post[0], ops.add(y, x2))
 
@@ -387,7 +388,7 @@ class FTC(nn.Module):
         for j, (v, c) in enumerate(((v2, c2), (v3, c3), (v4, c4), (v5, c5))):
             tv, tc = getattr(self, f'tran_vit{j}'), getattr(self, f'tran_cnn{j}')
             f.append(ops.add(_bn(tv[1], _conv(tv[0], v)), _bn(tc[1], _conv(tc[0], c))))
-        y8 = _bn(self.head[1], _conv(self.head[0], f[4]), post='lrelu')
+        y8 = _bn(self.head[1], _conv(self.head[0], f[4], stats_pre='none' if self.training else None), post='lrelu')
         d3 = self.dec1(y8, f[3])
         d2 = self.dec2(d3, f[2])
         d1 = self.dec3(d2, f[1])

@@ -67,7 +67,7 @@ def _pw_ok(in_dt, Cin, Cin_w, KH, KW, stride, padh, padw):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, padh, padw, out_dtype):
+    def forward(ctx, x, w, bias, stride, padh, padw, out_dtype, stats_box):
         _chk(x, w, bias)
         N, H, W, Cin = x.shape
         Cout, Cin_w, KH, KW = w.shape
@@ -83,7 +83,12 @@ class _Conv2d(torch.autograd.Function):
         elif mfma:
             wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
             lib.conv32_pack_weights(w, wp, KH, KW, 0)
-            lib.conv32_fwd(x, wp, bias, y, N, H, W, KH, KW, padh, padw)
+            if stats_box is not None:       # fused train-mode BN statistics of the consumer (stats_box = [pre_act_code, None])
+                sums = torch.zeros(64, device=x.device, dtype=torch.float64)
+                lib.conv32_fwd_bnstats(x, wp, bias, y, N, H, W, KH, KW, padh, padw, sums, stats_box[0])
+                stats_box[1] = sums
+            else:
+                lib.conv32_fwd(x, wp, bias, y, N, H, W, KH, KW, padh, padw)
         else:
             lib.conv2d_fwd(x, w, bias, y, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
                            dtype_code(odt))
@@ -136,19 +141,26 @@ class _Conv2d(torch.autograd.Function):
             else:
                 lib.conv2d_wgrad(x, dy, dw, db, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
                                  dtype_code(dy.dtype))
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, out_dtype=None):
-    """x [N,H,W,Cin] (or tokens [B,N,C]); w OIHW fp32 (or [Cout,Cin] for nn.Linear)."""
+def conv2d(x, w, bias=None, stride=1, pad=0, out_dtype=None, stats_pre=None):
+    """x [N,H,W,Cin] (or tokens [B,N,C]); w OIHW fp32 (or [Cout,Cin] for nn.Linear).
+    stats_pre: None, or the pre-activation name ('none', 'lrelu', ...) of a train-mode BatchNorm that consumes the output: kernels
+    that can, accumulate the BN statistics in their epilogue and tag the result (`_bn_sums`) so `batchnorm` skips its own pass."""
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
     tok = x.dim() == 3
     if tok:
         x = x.unsqueeze(2)
     if w.dim() == 2:
         w = w.view(w.shape[0], w.shape[1], 1, 1)
-    y = _Conv2d.apply(x, w, bias, stride, ph, pw, out_dtype)
-    return y.squeeze(2) if tok else y
+    box = [ACT[stats_pre], None] if stats_pre is not None else None
+    y = _Conv2d.apply(x, w, bias, stride, ph, pw, out_dtype, box)
+    if tok:
+        y = y.squeeze(2)
+    if box is not None and box[1] is not None:
+        y._bn_sums = (box[1], box[0])
+    return y
 
 
 def im2col3x3_c3(x4, stride=1):
@@ -214,8 +226,12 @@ class _BatchNorm(torch.autograd.Function):
         mean_rstd = torch.empty(2 * C, device=x.device, dtype=torch.float32)
         ab = torch.empty(2 * C, device=x.device, dtype=torch.float32)
         if training:
-            sums = torch.empty(2 * C, device=x.device, dtype=torch.float64)
-            lib.bn_stats(x, M, C, pre, sums, dc)
+            fused = getattr(x, '_bn_sums', None)
+            if fused is not None and fused[1] == pre and fused[0].numel() == 2 * C:
+                sums = fused[0]             # statistics were accumulated by the producing conv's epilogue
+            else:
+                sums = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+                lib.bn_stats(x, M, C, pre, sums, dc)
             lib.bn_finalize(sums, M, C, gamma, beta, eps, momentum, rm, rv, nbt, mean_rstd, ab)
         else:
             lib.bn_eval_ab(C, gamma, beta, eps, rm, rv, mean_rstd, ab)
