@@ -56,7 +56,7 @@ def build_trainer(a, world):
 def dominant_kernel_roofline(a, iters=20):
     """HIP-event timing of the dominant kernel of the step at the bench shapes, on the stream it is launched on (torch's
     current stream == the stream every tcct_* call receives).  Dominant kernel (profiles/r01_*): the weight gradient of the
-    dense 3x3 32->32 convolution at level 0 (k_conv32_wgrad<9,false> on [bs,800,1104,32]; fp32 mode: the VALU k_conv_wgrad).
+    dense 3x3 32->32 convolution at level 0 (k_conv32_wgrad<5,false> on [bs,800,1104,32]; fp32 mode: the VALU k_conv_wgrad).
     Algorithmic bytes per launch = read x once + read dy once (SURVEY §8(d) layer-granular model: wgrad reads x and dy)
     = 2 * bs*H*W*32 * sizeof(dtype); the 36 KB of dW are noise."""
     from tcct_amd._lib import lib
@@ -67,7 +67,7 @@ def dominant_kernel_roofline(a, iters=20):
     dw = torch.empty((32, 32, 3, 3), device='cuda')
     db = torch.empty(32, device='cuda')
     if a.dtype == 'bf16':
-        name = 'k_conv32_wgrad<9,false> 3x3 32->32 @L0'
+        name = 'k_conv32_wgrad<5,false> (3x3 32->32 @L0, 2 tap groups)'
         fn = lambda: lib.conv32_wgrad(x, dy, dw, db, a.bs, a.height, Wp, 3, 3, 1, 1)          # noqa: E731
     else:
         name = 'k_conv_wgrad<float,float> 3x3 32->32 @L0'
