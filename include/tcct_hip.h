@@ -29,6 +29,9 @@ enum { TCCT_ACT_NONE = 0, TCCT_ACT_LRELU = 1, TCCT_ACT_HSWISH = 2, TCCT_ACT_GELU
 
 int tcct_version(void);
 const char* tcct_last_error(void);
+/* process-wide switch: 1 = accumulation outputs (dw, dbias, BN/LN sums) handed to the calls are already zero, so the
+ * entry points skip their own hipMemsetAsync (the caller clears one pooled buffer per step instead); returns 0 */
+int tcct_set_outputs_prezeroed(int on);
 
 /* ---- layout: loader-side `img.to(device)` (kite/loop_seg.py:116) + 1->3 channel replicate / W pad ---------
  * img [N,Csrc,H,Wsrc] fp32 NCHW (Csrc 1 or 3) -> out [N,H,Wdst,4] NHWC (channel 3 and columns >= Wsrc zero). */

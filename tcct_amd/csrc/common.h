@@ -9,6 +9,7 @@
 typedef __hip_bfloat16 bf16;
 
 void tcct_set_error(const char* fmt, ...);
+int tcct_skip_zero_fill();      // 1: the caller guarantees accumulation outputs are already zero (tcct_set_outputs_prezeroed)
 
 #define TCCT_CHECK(cond, ...)                                   \
     do {                                                        \

@@ -284,7 +284,7 @@ extern "C" int tcct_conv2d_wgrad(const void* x, const void* dy, float* dw, float
     TCCT_CHECK(Ho > 0 && Wo > 0 && N > 0, "conv2d_wgrad: empty output");
     int64_t NP = (int64_t)N * Ho * Wo;
     size_t wbytes = sizeof(float) * (size_t)Cout * Cin_w * KH * KW;
-    if (hipMemsetAsync(dw, 0, wbytes, st) != hipSuccess) { tcct_set_error("conv2d_wgrad: memset failed"); return -2; }
+    if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, wbytes, st) != hipSuccess) { tcct_set_error("conv2d_wgrad: memset failed"); return -2; }
     int CG = (Cout + COT - 1) / COT, KGB = CB / CG, KG = KH * KW * Cin / 4;
     int gy = (KG + KGB - 1) / KGB;
     int64_t prange = 1024;
@@ -299,7 +299,7 @@ extern "C" int tcct_conv2d_wgrad(const void* x, const void* dy, float* dw, float
     else { tcct_set_error("conv2d_wgrad: bad dtypes"); return -1; }
 #undef LAUNCH
     if (dbias) {
-        if (hipMemsetAsync(dbias, 0, sizeof(float) * Cout, st) != hipSuccess) { tcct_set_error("conv2d_wgrad: memset failed"); return -2; }
+        if (!tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, st) != hipSuccess) { tcct_set_error("conv2d_wgrad: memset failed"); return -2; }
         int R = CB / Cout;
         int g = tcct_grid(NP, R, 2048);
         if (dy_dtype == TCCT_F32) hipLaunchKernelGGL(k_colsum<float>, dim3(g), dim3(CB), 0, st, (const float*)dy, NP, Cout, dbias);

@@ -439,8 +439,8 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
     int grid = (int)(nt < 512 ? nt : 512);
     hipStream_t st = (hipStream_t)stream;
     if (zero) {
-        if (hipMemsetAsync(dw, 0, sizeof(float) * TAPS * 1024, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
-        if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
+        if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * TAPS * 1024, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
+        if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
     }
     // taps are split over TG wave groups so that <= 5 accumulators (80 VGPRs) live next to the prefetch registers: no spills
     const int TG = TAPS > 10 ? 4 : (TAPS > 5 ? 2 : 1);

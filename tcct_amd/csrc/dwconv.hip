@@ -272,8 +272,8 @@ extern "C" int tcct_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, fl
     int vec = (C % 4 == 0) ? 4 : 1;
     TCCT_CHECK(C / vec <= DB, "dwconv3x3_wgrad: C=%d too large", C);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dw, 0, sizeof(float) * C * 9, st) != hipSuccess) { tcct_set_error("dwconv3x3_wgrad: memset failed"); return -2; }
-    if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) { tcct_set_error("dwconv3x3_wgrad: memset failed"); return -2; }
+    if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * C * 9, st) != hipSuccess) { tcct_set_error("dwconv3x3_wgrad: memset failed"); return -2; }
+    if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) { tcct_set_error("dwconv3x3_wgrad: memset failed"); return -2; }
     int R = DB / (C / vec);
     int64_t strips = (int64_t)N * Ho * ((Wo + DW_SEG - 1) / DW_SEG);
     int grid = tcct_grid(strips, R, 2048);

@@ -12,6 +12,13 @@ void tcct_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* tcct_last_error(void) { return g_err; }
+
+// Accumulation outputs (weight/bias gradients, BN/LN partial sums) are normally cleared by the entry point itself (one
+// hipMemsetAsync per call, ~270 per training step).  A caller that hands out slices of ONE buffer it clears once per step
+// can switch that off.  Process-wide on purpose: torch runs backward kernels from its autograd worker thread.
+static volatile int g_skip_zero = 0;
+int tcct_skip_zero_fill() { return g_skip_zero; }
+extern "C" int tcct_set_outputs_prezeroed(int on) { g_skip_zero = on ? 1 : 0; return 0; }
 extern "C" int tcct_version(void) { return 100; }
 
 #define EW_BLOCK 256

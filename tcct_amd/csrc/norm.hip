@@ -48,7 +48,7 @@ __global__ void k_bn_stats(const T* __restrict__ x, int64_t M, int C, int pre_ac
 extern "C" int tcct_bn_stats(const void* x, int64_t M, int C, int pre_act, double* sums, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(C >= 1 && C <= NB, "bn_stats: C=%d unsupported (1..%d)", C, NB);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { tcct_set_error("bn_stats: memset failed"); return -2; }
+    if (!tcct_skip_zero_fill() && hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { tcct_set_error("bn_stats: memset failed"); return -2; }
     int vec = (C % 4 == 0) ? 4 : 1;
     int R = NB / (C / vec);
     int grid = tcct_grid(M, R, 256 * 8);
@@ -204,7 +204,7 @@ extern "C" int tcct_bn_bwd_reduce(const void* x, const void* dy, int64_t M, int 
                                   int pre_act, int post_act, double* sums, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(C >= 1 && C <= NB, "bn_bwd_reduce: C=%d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { tcct_set_error("bn_bwd_reduce: memset failed"); return -2; }
+    if (!tcct_skip_zero_fill() && hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { tcct_set_error("bn_bwd_reduce: memset failed"); return -2; }
     int vec = (C % 4 == 0) ? 4 : 1;
     int R = NB / (C / vec);
     int grid = tcct_grid(M, R, 256 * 8);
@@ -383,7 +383,7 @@ extern "C" int tcct_layernorm_bwd(const void* x, const void* dy, void* dx, int64
                                   const float* mean_rstd, float* dgamma, float* dbeta, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(C % 4 == 0 && C <= 64 * LN_MAXCH, "layernorm_bwd: C=%d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess) {
+    if (!tcct_skip_zero_fill() && (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess)) {
         tcct_set_error("layernorm_bwd: memset failed"); return -2;
     }
     TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_ln_bwd<T>, dim3(tcct_grid(M * 16, NB, 1024)), dim3(NB), 0, st, (const T*)x,

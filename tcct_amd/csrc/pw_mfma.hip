@@ -227,8 +227,8 @@ k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __res
 extern "C" int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream) {
     TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && N <= 160 && K <= 1024, "pw_wgrad: unsupported K=%d N=%d", K, N);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)N * K, st) != hipSuccess) { tcct_set_error("pw_wgrad: memset failed"); return -2; }
-    if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * N, st) != hipSuccess) { tcct_set_error("pw_wgrad: memset failed"); return -2; }
+    if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)N * K, st) != hipSuccess) { tcct_set_error("pw_wgrad: memset failed"); return -2; }
+    if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * N, st) != hipSuccess) { tcct_set_error("pw_wgrad: memset failed"); return -2; }
     const int NT = N / 32, ktiles = K / 32;
     const int KTB = (ktiles % 2 == 0) ? 2 : 1;
     const int gy = ktiles / KTB;
@@ -349,8 +349,8 @@ extern "C" int tcct_pw_wgrad_smalln(const void* x, const void* dy, float* dw, fl
                                     int dy_dtype, tcct_stream_t stream) {
     TCCT_CHECK(K % 4 == 0 && K >= 4 && K <= 256 && N >= 1 && N <= 8, "pw_wgrad_smalln: unsupported K=%d N=%d", K, N);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dw, 0, sizeof(float) * N * K, st) != hipSuccess) { tcct_set_error("pw_wgrad_smalln: memset failed"); return -2; }
-    if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * N, st) != hipSuccess) { tcct_set_error("pw_wgrad_smalln: memset failed"); return -2; }
+    if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * N * K, st) != hipSuccess) { tcct_set_error("pw_wgrad_smalln: memset failed"); return -2; }
+    if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * N, st) != hipSuccess) { tcct_set_error("pw_wgrad_smalln: memset failed"); return -2; }
     int R = PWB / (K / 4);
     size_t lds = sizeof(float) * (size_t)R * N * K;
     int grid = tcct_grid(M, R, 1024);

@@ -88,9 +88,14 @@ class KiteSeg(KiteBack):
 
     def train_step(self, img, lab):
         """one optimisation step (reference loop_seg.py:121-130); returns the loss TENSOR (no host sync)"""
+        from .. import ops
         self.optimG.zero_grad(set_to_none=True)
-        losSum, _ = self.calc_loss(img, lab, want_log=False)
-        losSum.backward()
+        ops.begin_step(self.device)             # one zero-filled pool per step for all accumulation outputs
+        try:
+            losSum, _ = self.calc_loss(img, lab, want_log=False)
+            losSum.backward()
+        finally:
+            ops.end_step()
         self.optimG.step()          # clip_grad_norm_(12) is fused into the step kernel
         return losSum.detach()
 

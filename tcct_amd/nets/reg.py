@@ -68,6 +68,9 @@ class RegNet(nn.Module):
         self.tau = nn.Parameter(torch.ones(1) * 100)             # unused by the loss (reference reg.py:77,119)
         self.emb_list = None
         self.tgt_list = None
+        for m in (self.lap_reg, self.lap_map):          # applied to pred AND true every step: gradients accumulate via autograd
+            for p in m.parameters():
+                p._tcct_multi_use = True
 
     def forward(self, x):
         return self.base(x)

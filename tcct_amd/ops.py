@@ -11,6 +11,76 @@ from ._lib import lib, dtype_code, TcctError, F32, BF16  # noqa: F401
 ACT = {None: 0, 'none': 0, 'lrelu': 1, 'hswish': 2, 'gelu': 3, 'sigmoid': 4, 'abs': 5}
 
 
+class _ZeroPool:
+    """One pre-zeroed buffer per training step for every accumulation output (BN/LN partial sums, parameter-gradient buffers that
+    have no slot in the optimizer's flat gradient): ONE memset per step instead of ~270 hipMemsetAsync calls.  Active between
+    `begin_step()` and `end_step()`; otherwise the entry points clear their outputs themselves."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.active = False
+
+    def begin(self, device, nbytes=8 << 20):
+        if self.buf is None or self.buf.device != device or self.buf.numel() < nbytes:
+            self.buf = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        self.buf.zero_()
+        self.off = 0
+        self.active = True
+        lib.set_outputs_prezeroed(1)
+
+    def end(self):
+        if self.active:
+            self.active = False
+            lib.set_outputs_prezeroed(0)
+
+    def get(self, shape, dtype, device):
+        """zero-initialised tensor when the pool is active, uninitialised otherwise (the entry point clears it then)"""
+        n = 1
+        for d in shape:
+            n *= d
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        if not self.active:
+            return torch.empty(shape, device=device, dtype=dtype)
+        start = (self.off + 255) // 256 * 256
+        if self.buf.device != device or start + nbytes > self.buf.numel():
+            return torch.zeros(shape, device=device, dtype=dtype)
+        self.off = start + nbytes
+        return self.buf[start:start + nbytes].view(dtype).view(shape)
+
+
+ZERO = _ZeroPool()
+
+
+def begin_step(device):
+    """call once per training step before the forward (KiteSeg.train_step does): arms the zero pool"""
+    ZERO.begin(torch.device(device))
+
+
+def end_step():
+    ZERO.end()
+
+
+def _grad_out(param, shape=None):
+    """destination of a parameter gradient: the parameter's slot in the optimizer's flat gradient buffer (pre-zeroed by
+    zero_grad; written in place, so the optimizer needs no gather) or a pooled / fresh tensor"""
+    slot = getattr(param, '_grad_slot', None)
+    if slot is not None and ZERO.active:
+        return slot.view(shape if shape is not None else slot.shape)
+    return ZERO.get(tuple(shape if shape is not None else param.shape), torch.float32, param.device)
+
+
+def _ret(t, param):
+    """what a backward returns for a parameter gradient: None when the kernel already wrote it into the parameter's slot of the
+    flat gradient buffer (autograd must not clone/accumulate it again; the optimizer reads the slot), else the tensor itself"""
+    if t is None:
+        return None
+    slot = getattr(param, '_grad_slot', None)
+    if slot is not None and t.data_ptr() == slot.data_ptr():
+        return None
+    return t
+
+
 def _chk(*ts):
     for t in ts:
         if t is None:
@@ -84,7 +154,7 @@ class _Conv2d(torch.autograd.Function):
             wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
             lib.conv32_pack_weights(w, wp, KH, KW, 0)
             if stats_box is not None:       # fused train-mode BN statistics of the consumer (stats_box = [pre_act_code, None])
-                sums = torch.zeros(64, device=x.device, dtype=torch.float64)
+                sums = ZERO.get((64,), torch.float64, x.device) if ZERO.active else torch.zeros(64, device=x.device, dtype=torch.float64)
                 lib.conv32_fwd_bnstats(x, wp, bias, y, N, H, W, KH, KW, padh, padw, sums, stats_box[0])
                 stats_box[1] = sums
             else:
@@ -94,12 +164,16 @@ class _Conv2d(torch.autograd.Function):
                            dtype_code(odt))
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, padh, padw, bias is not None)
+        # gradient destinations: w may be a view of the nn.Linear weight (conv2d wrapper) -> look through ._base
+        wsrc = w if hasattr(w, '_grad_slot') or w._base is None else w._base
+        ctx.params = (wsrc, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         stride, padh, padw, has_bias = ctx.cfg
+        wsrc, bsrc = ctx.params
         dy = _c(dy)
         N, H, W, Cin = x.shape
         Cout, Cin_w, KH, KW = w.shape
@@ -120,14 +194,15 @@ class _Conv2d(torch.autograd.Function):
             else:
                 lib.conv2d_dgrad(dy, w, dx, N, H, W, Cin, Cout, KH, KW, padh, padw, dtype_code(dy.dtype), dtype_code(x.dtype))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty_like(w)
-            db = torch.empty(Cout, device=w.device, dtype=torch.float32) if has_bias else None
+            dw = _grad_out(wsrc, tuple(w.shape))
+            db = _grad_out(bsrc) if has_bias else None
             if _mfma32_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
                 lib.conv32_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
             elif _mfma_slabs_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
-                dw.zero_()
-                if db is not None:
-                    db.zero_()
+                if not ZERO.active:
+                    dw.zero_()
+                    if db is not None:
+                        db.zero_()
                 for oh in range(Cout // 32):
                     for ih in range(Cin // 32):
                         lib.conv32_wgrad_strided(x, dy, dw, db if ih == 0 else None, N, H, W, KH, KW, padh, padw, Cin, 32 * ih, Cout,
@@ -141,7 +216,7 @@ class _Conv2d(torch.autograd.Function):
             else:
                 lib.conv2d_wgrad(x, dy, dw, db, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
                                  dtype_code(dy.dtype))
-        return dx, dw, db, None, None, None, None, None
+        return dx, _ret(dw, wsrc), _ret(db, bsrc), None, None, None, None, None
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, out_dtype=None, stats_pre=None):
@@ -192,6 +267,7 @@ class _DwConv(torch.autograd.Function):
         lib.dwconv3x3_fwd(x, w, bias, y, N, H, W, C, stride, int(add_input), dtype_code(x.dtype))
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, add_input, bias is not None)
+        ctx.bias_param = bias
         return y
 
     @staticmethod
@@ -205,10 +281,10 @@ class _DwConv(torch.autograd.Function):
             dx = torch.empty_like(x)
             lib.dwconv3x3_dgrad(dy, w, dx, N, H, W, C, stride, int(add_input), dtype_code(x.dtype))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty_like(w)
-            db = torch.empty(C, device=w.device, dtype=torch.float32) if has_bias else None
+            dw = _grad_out(w)
+            db = _grad_out(ctx.bias_param) if has_bias else None
             lib.dwconv3x3_wgrad(x, dy, dw, db, N, H, W, C, stride, dtype_code(x.dtype))
-        return dx, dw, db, None, None
+        return dx, _ret(dw, w), _ret(db, ctx.bias_param), None, None
 
 
 def dwconv3x3(x, w, bias=None, stride=1, add_input=False):
@@ -230,7 +306,7 @@ class _BatchNorm(torch.autograd.Function):
             if fused is not None and fused[1] == pre and fused[0].numel() == 2 * C:
                 sums = fused[0]             # statistics were accumulated by the producing conv's epilogue
             else:
-                sums = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+                sums = ZERO.get((2 * C,), torch.float64, x.device)
                 lib.bn_stats(x, M, C, pre, sums, dc)
             lib.bn_finalize(sums, M, C, gamma, beta, eps, momentum, rm, rv, nbt, mean_rstd, ab)
         else:
@@ -240,6 +316,7 @@ class _BatchNorm(torch.autograd.Function):
         if training:
             ctx.save_for_backward(x, gamma, mean_rstd, ab)
             ctx.cfg = (pre, post)
+            ctx.beta_param = beta
         return y
 
     @staticmethod
@@ -250,13 +327,13 @@ class _BatchNorm(torch.autograd.Function):
         C = x.shape[-1]
         M = x.numel() // C
         dc = dtype_code(x.dtype)
-        sums = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+        sums = ZERO.get((2 * C,), torch.float64, x.device)
         lib.bn_bwd_reduce(x, dy, M, C, mean_rstd, ab, pre, post, sums, dc)
         dx = torch.empty_like(x)
-        dg = torch.empty(C, device=x.device, dtype=torch.float32)
-        db = torch.empty(C, device=x.device, dtype=torch.float32)
+        dg = _grad_out(gamma) if ZERO.active and getattr(gamma, '_grad_slot', None) is not None else torch.empty(C, device=x.device, dtype=torch.float32)
+        db = _grad_out(ctx.beta_param) if ZERO.active and getattr(ctx.beta_param, '_grad_slot', None) is not None else torch.empty(C, device=x.device, dtype=torch.float32)
         lib.bn_bwd_apply(x, dy, dx, M, C, mean_rstd, ab, gamma, sums, pre, post, dg, db, dc)
-        return dx, dg, db, None, None, None, None, None, None, None, None
+        return dx, _ret(dg, gamma), _ret(db, ctx.beta_param), None, None, None, None, None, None, None, None
 
 
 def batchnorm(x, gamma, beta, running_mean, running_var, num_batches_tracked=None, eps=1e-5, momentum=0.1,
@@ -278,6 +355,7 @@ class _LayerNorm(torch.autograd.Function):
         mr = torch.empty(2 * M, device=x.device, dtype=torch.float32)
         lib.layernorm_fwd(x, y, M, C, gamma, beta, eps, mr, dtype_code(x.dtype))
         ctx.save_for_backward(x, gamma, mr)
+        ctx.beta_param = beta
         return y
 
     @staticmethod
@@ -287,10 +365,10 @@ class _LayerNorm(torch.autograd.Function):
         C = x.shape[-1]
         M = x.numel() // C
         dx = torch.empty_like(x)
-        dg = torch.empty(C, device=x.device, dtype=torch.float32)
-        db = torch.empty(C, device=x.device, dtype=torch.float32)
+        dg = _grad_out(gamma)
+        db = _grad_out(ctx.beta_param)
         lib.layernorm_bwd(x, dy, dx, M, C, gamma, mr, dg, db, dtype_code(x.dtype))
-        return dx, dg, db, None
+        return dx, _ret(dg, gamma), _ret(db, ctx.beta_param), None
 
 
 def layernorm(x, gamma, beta, eps=1e-6):

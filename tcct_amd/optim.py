@@ -19,6 +19,12 @@ class FlatAdamW(torch.optim.Optimizer):
         self.world = 1
         self.allreduce = None        # callable(flat_g) -> None, set by tcct_amd.dist.attach
         self.last_total_norm = None
+        self._slots_live = False
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=True)
+        if self._flat is not None:
+            self._flat['g'].zero_()     # one memset: the slots that backward kernels accumulate into
 
     def _build(self):
         plist = [p for g in self.param_groups for p in g['params'] if p.grad is not None]
@@ -36,7 +42,14 @@ class FlatAdamW(torch.optim.Optimizer):
             p.data = flat_p[off:off + k].view_as(p.data)
             off += k
         z = lambda: torch.zeros(n, device=dev, dtype=torch.float32)   # noqa: E731
-        self._flat = dict(plist=plist, p=flat_p, g=z(), m=z(), v=z(),
+        flat_g = z()
+        off = 0
+        for p in plist:             # gradient slots: backward kernels write parameter gradients straight into the flat buffer
+            k = p.numel()
+            if not getattr(p, '_tcct_multi_use', False):     # parameters used twice per step accumulate through autograd
+                p._grad_slot = flat_g[off:off + k].view_as(p)
+            off += k
+        self._flat = dict(plist=plist, p=flat_p, g=flat_g, m=z(), v=z(),
                           sumsq=torch.zeros((), device=dev, dtype=torch.float64),
                           norm=torch.zeros((), device=dev, dtype=torch.float32), n=n)
 
@@ -49,11 +62,27 @@ class FlatAdamW(torch.optim.Optimizer):
         if self._flat is None:
             self._build()
         f = self._flat
-        for p in f['plist']:
-            if p.grad is None:
-                raise TcctError('a parameter that had a gradient at the first step has none now; the set of trained '
-                                'parameters must be static (rebuild the optimizer after changing loss flags)')
-        torch.cat([p.grad.reshape(-1) for p in f['plist']], out=f['g'])
+        if not self._slots_live:
+            for p in f['plist']:
+                if p.grad is None:
+                    raise TcctError('a parameter that had a gradient at the first step has none now; the set of trained '
+                                    'parameters must be static (rebuild the optimizer after changing loss flags)')
+        if self._slots_live:
+            off = 0
+            for p in f['plist']:        # kernels wrote most gradients straight into their slots (p.grad stays None then)
+                k = p.numel()
+                slot = getattr(p, '_grad_slot', None)
+                if p.grad is not None and (slot is None or p.grad.data_ptr() != slot.data_ptr()):
+                    if slot is None:
+                        f['g'][off:off + k].copy_(p.grad.reshape(-1))
+                    else:                           # produced outside the pooled step (plain backward): add to the zeroed slot
+                        f['g'][off:off + k].add_(p.grad.reshape(-1))
+                if slot is not None:
+                    p.grad = slot                   # keep the torch contract: p.grad holds the gradient after step()
+                off += k
+        else:
+            torch.cat([p.grad.reshape(-1) for p in f['plist']], out=f['g'])
+        self._slots_live = True
         if self.allreduce is not None:
             self.allreduce(f['g'])
         self._step += 1

@@ -205,3 +205,38 @@ def test_bf16_close_to_fixture(tmp_path):
     total.backward()
     k.optimG.step()
     assert torch.isfinite(k.optimG.last_total_norm).item()
+
+
+def test_train_step_pool_and_slots_match_plain(tmp_path):
+    """KiteSeg.train_step (zero pool + in-place gradient slots: no per-op memsets, no gradient gather) must produce the same flat
+    gradient as the plain zero_grad / calc_loss / backward / step sequence AT THE SAME PARAMETERS (lr = 0 keeps them fixed)"""
+    import tcct_oracle as O
+    img, lab = O.synth_batch(2, 64, 64, seed=5)
+    img, lab = img[:, :1].cuda(), lab.cuda()
+    model, _ = build(torch.float32)
+    model.base.base_vit.drop_probs = [0.0] * 4
+    k = make_kite(model, tmp_path, True, True)
+    k.optimG.param_groups[0]['lr'] = 0.0
+    k.optimG.param_groups[0]['weight_decay'] = 0.0
+    torch.manual_seed(0)
+    noise_state = torch.cuda.get_rng_state()
+    grads, losses = [], []
+    for mode in ('plain', 'plain', 'pooled', 'pooled'):
+        torch.cuda.set_rng_state(noise_state)            # same Gumbel / jitter draws in regular_reg
+        if mode == 'plain':
+            k.optimG.zero_grad(set_to_none=True)
+            loss, _ = k.calc_loss(img, lab, want_log=False)
+            loss.backward()
+            k.optimG.step()
+        else:
+            loss = k.train_step(img, lab)
+        grads.append(k.optimG._flat['g'].clone())
+        losses.append(loss.item())
+    ref = grads[1]
+    scale = ref.abs().max().item()
+    for g, l in zip(grads[2:], losses[2:]):
+        assert abs(l - losses[1]) / abs(losses[1]) < 1e-6
+        assert (g - ref).abs().max().item() < 2e-3 * scale, ((g - ref).abs().max().item(), scale)
+    # the in-place path really is in place: gradients alias their slots
+    named = [p for p in model.parameters() if getattr(p, '_grad_slot', None) is not None]
+    assert len(named) > 250 and all(p.grad is not None and p.grad.data_ptr() == p._grad_slot.data_ptr() for p in named)
