@@ -1,0 +1,101 @@
+"""Full-size (BASELINE.json: bs 8, 1x800x1100 -> 3x800x1104) checks through size-independent properties: the oracle cannot run
+8 full B-scans in seconds, so the HIP kernels are checked against each other (MFMA vs the fp32 VALU formulation), against
+closed-form answers and through linearity / statistics identities."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+B, H, W = 8, 800, 1104
+
+
+def _x(c=32, seed=0, dt=torch.bfloat16):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    return torch.randn((B, H, W, c), device='cuda', generator=g).to(dt)
+
+
+@pytest.mark.parametrize('k', [(3, 3), (1, 13), (13, 1)])
+def test_conv32_mfma_equals_valu_formulation_fullsize(k):
+    from tcct_amd._lib import lib
+    kh, kw = k
+    x = _x()
+    g = torch.Generator(device='cuda').manual_seed(1)
+    w = torch.randn((32, 32, kh, kw), device='cuda', generator=g) / (32 * kh * kw) ** 0.5
+    b = torch.randn(32, device='cuda', generator=g)
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    wp = torch.empty(kh * kw * 1024, device='cuda', dtype=torch.bfloat16)
+    lib.conv32_pack_weights(w, wp, kh, kw, 0)
+    lib.conv32_fwd(x, wp, b, y1, B, H, W, kh, kw, (kh - 1) // 2, (kw - 1) // 2)
+    lib.conv2d_fwd(x, w.to(torch.bfloat16).float(), b, y2, B, H, W, 32, 32, 32, kh, kw, 1, (kh - 1) // 2, (kw - 1) // 2, 1, 1)
+    d = (y1.float() - y2.float()).abs().max().item()
+    assert d <= 2 ** -6 * max(1.0, y2.float().abs().max().item()), d          # both round the same fp32 sums to bf16
+    # weight gradient: MFMA (transposing LDS reads) vs VALU, and linearity in dy
+    dy1, dy2 = _x(seed=2), _x(seed=3)
+    dw1, dw2, dw12, dwv = (torch.empty_like(w) for _ in range(4))
+    db = torch.empty(32, device='cuda')
+    lib.conv32_wgrad(x, dy1, dw1, db, B, H, W, kh, kw, (kh - 1) // 2, (kw - 1) // 2)
+    lib.conv32_wgrad(x, dy2, dw2, None, B, H, W, kh, kw, (kh - 1) // 2, (kw - 1) // 2)
+    dys = (dy1.float() + dy2.float())
+    lib.conv2d_wgrad(x, dy1, dwv, None, B, H, W, 32, 32, 32, kh, kw, 1, (kh - 1) // 2, (kw - 1) // 2, 1, 1)
+    scale = dwv.abs().max().item()
+    assert (dw1 - dwv).abs().max().item() < 2e-3 * scale
+    torch.testing.assert_close(db, dy1.float().sum((0, 1, 2)), rtol=2e-3, atol=2e-3 * dy1.float().sum((0, 1, 2)).abs().max().item())
+    lib.conv2d_wgrad(x.float(), dys, dw12, None, B, H, W, 32, 32, 32, kh, kw, 1, (kh - 1) // 2, (kw - 1) // 2, 0, 0)
+    assert (dw1 + dw2 - dw12).abs().max().item() < 3e-3 * dw12.abs().max().item()
+
+
+def test_batchnorm_statistics_fullsize():
+    from tcct_amd import ops
+    x = (_x(seed=4).float() * 1.7 + 0.4).to(torch.bfloat16)
+    gamma = torch.linspace(0.5, 1.5, 32, device='cuda')
+    beta = torch.linspace(-0.3, 0.3, 32, device='cuda')
+    rm, rv = torch.zeros(32, device='cuda'), torch.ones(32, device='cuda')
+    nbt = torch.zeros((), device='cuda', dtype=torch.int64)
+    y = ops.batchnorm(x, gamma, beta, rm, rv, nbt, training=True).float()
+    m, v = y.mean((0, 1, 2)), y.var((0, 1, 2), unbiased=False)
+    assert (m - beta).abs().max().item() < 5e-3 and (v - gamma ** 2).abs().max().item() < 2e-2
+    assert (rm - 0.1 * 0.4).abs().max().item() < 2e-3 and (rv - (0.9 + 0.1 * 1.7 ** 2)).abs().max().item() < 2e-2
+
+
+def test_dice_closed_forms_fullsize():
+    from tcct_amd import ops
+    lab = torch.randint(0, 5, (B, H, W), device='cuda', dtype=torch.uint8)
+    onehot = torch.nn.functional.one_hot(lab.long(), 5).float()
+    perfect = ops.softmax_dice((onehot * 60).contiguous(), lab)
+    assert perfect.item() < 1e-4                                   # DiceLoss.dice(g, g) == 1 for every class
+    uniform = ops.softmax_dice(torch.zeros((B, H, W, 5), device='cuda'), lab)
+    # p = 1/5 everywhere: 1 - (1 + 2 n_c/5) / (1 + M/5 + n_c) summed over classes
+    M = B * H * W
+    nc = torch.bincount(lab.flatten().long(), minlength=5).double()
+    ref = (1 - (1 + 2 * nc / 5) / (1 + M / 5 + nc)).sum().item()
+    assert abs(uniform.item() - ref) < 1e-4
+
+
+def test_full_step_runs_at_bench_shape(tmp_path):
+    """one full training step at the bench configuration (bf16, full loss): finite loss ~16 at random init, finite clip norm,
+    every trained parameter receives a gradient, BN buffers move"""
+    import argparse
+    from tcct_amd.nets import stc_tt, RegNet
+    from tcct_amd.kite import KiteSeg
+    from tcct_amd.data import SynthOCT
+    torch.manual_seed(0)
+    ds = SynthOCT(device='cuda')
+    model = RegNet(stc_tt(5, compute_dtype=torch.bfloat16), con='cos', out_channels=5)
+    args = argparse.Namespace(los='di', lr=1e-2, gpu='0', pl=False, bs=8, coff_ds=1, udh=True, reg=True, epl=False, coff_udh=1,
+                              coff_reg=.1, coff_epl=.1, bug=True)
+    k = KiteSeg(model=model, dataset=ds, root=str(tmp_path), args=args)
+    k.model.train()
+    img, lab, _, _ = ds.parse(ds.make_batch(8, 7))
+    assert img.shape == (8, 1, 800, 1104)
+    l1 = k.train_step(img, lab).item()
+    l2 = k.train_step(img, lab).item()
+    assert 10.0 < l1 < 25.0 and 10.0 < l2 < 25.0
+    n = k.optimG.last_total_norm.item()
+    assert n == n and 0 < n < 1e7
+    assert k.optimG.flat_numel == 802298                       # elements that receive gradients with reg on
+    assert model.base.base_cnn.cnn[1].num_batches_tracked.item() == 2 and model.lap_map[1].num_batches_tracked.item() == 4
+    # eval path on the same weights: masks + metrics
+    k.model.eval()
+    from tcct_amd.kite.losses import MDiceLoss
+    mask = k.predict(img[:1])
+    d = MDiceLoss.scorem(mask, lab[:1], start_idx=1).item()
+    assert 0.0 <= d <= 1.0
