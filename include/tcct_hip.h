@@ -85,6 +85,18 @@ int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_t M, int C,
                       const float* ab, const float* gamma, const double* sums, int pre_act, int post_act,
                       float* dgamma, float* dbeta, int dtype, tcct_stream_t stream);
 
+/* fused CrossCNNBlock junction y = act(BN_A(pre(xa)) + BN_B(pre(xb))) (nets/tcct.py:811,817,825-826: LeakyReLU -> BN on both
+ * branches, then F.gelu of the sum), train mode; abA, abB and mean_rstdA, mean_rstdB come from tcct_bn_finalize; sums fp64 [4C] */
+int tcct_bn2_add_act_fwd(const void* xa, const void* xb, void* y, int64_t M, int C, const float* abA, const float* abB, int pre_act,
+                         int act, int dtype, tcct_stream_t stream);
+int tcct_bn2_add_act_bwd_reduce(const void* xa, const void* xb, const void* dy, int64_t M, int C, const float* mean_rstdA,
+                                const float* abA, const float* mean_rstdB, const float* abB, int pre_act, int act, double* sums,
+                                int dtype, tcct_stream_t stream);
+int tcct_bn2_add_act_bwd_apply(const void* xa, const void* xb, const void* dy, void* dxa, void* dxb, int64_t M, int C,
+                               const float* mean_rstdA, const float* abA, const float* mean_rstdB, const float* abB,
+                               const double* sums, int pre_act, int act, float* dgammaA, float* dbetaA, float* dgammaB,
+                               float* dbetaB, int dtype, tcct_stream_t stream);
+
 /* ---- nn.LayerNorm(C, eps=1e-6) over the channel dim of tokens [M,C] (nets/tcct.py:427,454-455,461,467) ---- */
 int tcct_layernorm_fwd(const void* x, void* y, int64_t M, int C, const float* gamma, const float* beta, float eps,
                        float* mean_rstd /*[M,2]*/, int dtype, tcct_stream_t stream);

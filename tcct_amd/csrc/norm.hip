@@ -390,3 +390,136 @@ extern "C" int tcct_layernorm_bwd(const void* x, const void* dy, void* dx, int64
                                             (const T*)dy, (T*)dx, M, C, gamma, mean_rstd, dgamma, dbeta));
     TCCT_LAUNCH_OK();
 }
+
+// ------------------------------------------------------------------ fused CrossCNNBlock junction (reference nets/tcct.py:825-826)
+//   y = act( BN_A(pre(xa)) + BN_B(pre(xb)) )       with act = GELU, pre = LeakyReLU, both BNs in train mode.
+// Forward reads the two raw conv outputs once and writes y once (instead of 2 x bn_apply + add_act: 7 tensor passes -> 3);
+// backward recomputes the junction from xa, xb: one reduction pass (4 per-channel sums) + one apply pass writing both input
+// gradients (13 tensor passes -> 8).  Same fixed-channel-thread layout as the plain BN kernels.
+template <typename T>
+__global__ void k_bn2_add_act_fwd(const T* __restrict__ xa, const T* __restrict__ xb, T* __restrict__ y, int64_t M, int C,
+                                  const float* __restrict__ abA, const float* __restrict__ abB, int pre_act, int act) {
+    const int CV = C >> 2, R = NB / CV, t = threadIdx.x;
+    if (t >= R * CV) return;
+    const int cv = t % CV, r = t / CV;
+    float aA[4], bA[4], aB[4], bB[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { aA[k] = abA[cv * 4 + k]; bA[k] = abA[C + cv * 4 + k]; aB[k] = abB[cv * 4 + k]; bB[k] = abB[C + cv * 4 + k]; }
+    const int64_t step = (int64_t)gridDim.x * R;
+    for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += step) {
+        const int64_t o = m * C + cv * 4;
+        f4 va = ld4(xa + o), vb = ld4(xb + o), q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            q.v[k] = act_fwd(act, aA[k] * act_fwd(pre_act, va.v[k]) + bA[k] + aB[k] * act_fwd(pre_act, vb.v[k]) + bB[k]);
+        st4(y + o, q);
+    }
+}
+extern "C" int tcct_bn2_add_act_fwd(const void* xa, const void* xb, void* y, int64_t M, int C, const float* abA, const float* abB,
+                                    int pre_act, int act, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(C % 4 == 0 && C >= 4 && C <= NB, "bn2_add_act_fwd: C=%d unsupported", C);
+    int R = NB / (C / 4);
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_bn2_add_act_fwd<T>, dim3(tcct_grid(M, R, 256 * 16)), dim3(NB), 0, (hipStream_t)stream,
+                                            (const T*)xa, (const T*)xb, (T*)y, M, C, abA, abB, pre_act, act));
+    TCCT_LAUNCH_OK();
+}
+
+// sums[4C] = { sum g, sum g*xhatA, (unused alias of sum g), sum g*xhatB } laid out as [C]:g, [C]:g*xhatA, [C]:g, [C]:g*xhatB
+template <typename T>
+__global__ void k_bn2_add_act_bwd_reduce(const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ dy, int64_t M, int C,
+                                         const float* __restrict__ mrA, const float* __restrict__ abA, const float* __restrict__ mrB,
+                                         const float* __restrict__ abB, int pre_act, int act, double* __restrict__ sums) {
+    __shared__ float sm[3 * NB * 4];
+    const int CV = C >> 2, R = NB / CV, t = threadIdx.x;
+    const bool active = t < R * CV;
+    const int cv = t % CV, r = t / CV;
+    float aA[4], bA[4], aB[4], bB[4], muA[4], rsA[4], muB[4], rsB[4], s0[4], s1[4], s2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int c = active ? cv * 4 + k : 0;
+        aA[k] = abA[c]; bA[k] = abA[C + c]; aB[k] = abB[c]; bB[k] = abB[C + c];
+        muA[k] = mrA[c]; rsA[k] = mrA[C + c]; muB[k] = mrB[c]; rsB[k] = mrB[C + c];
+        s0[k] = s1[k] = s2[k] = 0.f;
+    }
+    if (active) {
+        for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += (int64_t)gridDim.x * R) {
+            const int64_t o = m * C + cv * 4;
+            f4 va = ld4(xa + o), vb = ld4(xb + o), g = ld4(dy + o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float ua = act_fwd(pre_act, va.v[k]), ub = act_fwd(pre_act, vb.v[k]);
+                float dz = g.v[k] * act_grad(act, aA[k] * ua + bA[k] + aB[k] * ub + bB[k]);
+                s0[k] += dz; s1[k] += dz * (ua - muA[k]) * rsA[k]; s2[k] += dz * (ub - muB[k]) * rsB[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sm[t * 4 + k] = s0[k]; sm[(NB + t) * 4 + k] = s1[k]; sm[(2 * NB + t) * 4 + k] = s2[k]; }
+    __syncthreads();
+    if (t < C) {
+        double a = 0.0, b = 0.0, c2 = 0.0;
+        int cvv = t >> 2, k = t & 3;
+        for (int rr = 0; rr < R; ++rr) {
+            int tt = rr * CV + cvv;
+            a += (double)sm[tt * 4 + k]; b += (double)sm[(NB + tt) * 4 + k]; c2 += (double)sm[(2 * NB + tt) * 4 + k];
+        }
+        atomicAdd(&sums[t], a); atomicAdd(&sums[C + t], b); atomicAdd(&sums[2 * C + t], a); atomicAdd(&sums[3 * C + t], c2);
+    }
+}
+extern "C" int tcct_bn2_add_act_bwd_reduce(const void* xa, const void* xb, const void* dy, int64_t M, int C, const float* mean_rstdA,
+                                           const float* abA, const float* mean_rstdB, const float* abB, int pre_act, int act,
+                                           double* sums, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(C % 4 == 0 && C >= 4 && C <= NB, "bn2_add_act_bwd_reduce: C=%d unsupported", C);
+    hipStream_t st = (hipStream_t)stream;
+    if (!tcct_skip_zero_fill() && hipMemsetAsync(sums, 0, sizeof(double) * 4 * C, st) != hipSuccess) { tcct_set_error("bn2_add_act_bwd_reduce: memset failed"); return -2; }
+    int R = NB / (C / 4);
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_bn2_add_act_bwd_reduce<T>, dim3(tcct_grid(M, R, 256 * 8)), dim3(NB), 0, st, (const T*)xa,
+                                            (const T*)xb, (const T*)dy, M, C, mean_rstdA, abA, mean_rstdB, abB, pre_act, act, sums));
+    TCCT_LAUNCH_OK();
+}
+
+template <typename T>
+__global__ void k_bn2_add_act_bwd_apply(const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ dy, T* __restrict__ dxa,
+                                        T* __restrict__ dxb, int64_t M, int C, const float* __restrict__ mrA, const float* __restrict__ abA,
+                                        const float* __restrict__ mrB, const float* __restrict__ abB, const double* __restrict__ sums,
+                                        int pre_act, int act, float* __restrict__ dgA, float* __restrict__ dbA, float* __restrict__ dgB,
+                                        float* __restrict__ dbB) {
+    const int CV = C >> 2, R = NB / CV, t = threadIdx.x;
+    if (blockIdx.x == 0 && t < C) {
+        dbA[t] = (float)sums[t]; dgA[t] = (float)sums[C + t]; dbB[t] = (float)sums[2 * C + t]; dgB[t] = (float)sums[3 * C + t];
+    }
+    if (t >= R * CV) return;
+    const int cv = t % CV, r = t / CV;
+    const float invM = 1.f / (float)M;
+    float aA[4], bA[4], aB[4], bB[4], muA[4], rsA[4], muB[4], rsB[4], s0[4], s1[4], s2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int c = cv * 4 + k;
+        aA[k] = abA[c]; bA[k] = abA[C + c]; aB[k] = abB[c]; bB[k] = abB[C + c];
+        muA[k] = mrA[c]; rsA[k] = mrA[C + c]; muB[k] = mrB[c]; rsB[k] = mrB[C + c];
+        s0[k] = (float)sums[c] * invM; s1[k] = (float)sums[C + c] * invM; s2[k] = (float)sums[3 * C + c] * invM;
+    }
+    for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += (int64_t)gridDim.x * R) {
+        const int64_t o = m * C + cv * 4;
+        f4 va = ld4(xa + o), vb = ld4(xb + o), g = ld4(dy + o), qa, qb;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float ua = act_fwd(pre_act, va.v[k]), ub = act_fwd(pre_act, vb.v[k]);
+            float dz = g.v[k] * act_grad(act, aA[k] * ua + bA[k] + aB[k] * ub + bB[k]);
+            qa.v[k] = aA[k] * (dz - s0[k] - (ua - muA[k]) * rsA[k] * s1[k]) * act_grad(pre_act, va.v[k]);
+            qb.v[k] = aB[k] * (dz - s0[k] - (ub - muB[k]) * rsB[k] * s2[k]) * act_grad(pre_act, vb.v[k]);
+        }
+        st4(dxa + o, qa); st4(dxb + o, qb);
+    }
+}
+extern "C" int tcct_bn2_add_act_bwd_apply(const void* xa, const void* xb, const void* dy, void* dxa, void* dxb, int64_t M, int C,
+                                          const float* mean_rstdA, const float* abA, const float* mean_rstdB, const float* abB,
+                                          const double* sums, int pre_act, int act, float* dgammaA, float* dbetaA, float* dgammaB,
+                                          float* dbetaB, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(C % 4 == 0 && C >= 4 && C <= NB, "bn2_add_act_bwd_apply: C=%d unsupported", C);
+    int R = NB / (C / 4);
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_bn2_add_act_bwd_apply<T>, dim3(tcct_grid(M, R, 256 * 16)), dim3(NB), 0, (hipStream_t)stream,
+                                            (const T*)xa, (const T*)xb, (const T*)dy, (T*)dxa, (T*)dxb, M, C, mean_rstdA, abA, mean_rstdB,
+                                            abB, sums, pre_act, act, dgammaA, dbetaA, dgammaB, dbetaB));
+    TCCT_LAUNCH_OK();
+}

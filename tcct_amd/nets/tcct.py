@@ -52,10 +52,13 @@ class CrossCNNBlock(nn.Module):
     def forward(self, x):
         tr = self.training
         a = _conv(self.block12[1], _conv(self.block12[0], x), stats_pre='lrelu' if tr else None)
-        a = _bn(self.block12[3], a, pre='lrelu')
         b = _conv(self.block34[2], _conv(self.block34[1], _conv(self.block34[0], x)), stats_pre='lrelu' if tr else None)
-        b = _bn(self.block34[4], b, pre='lrelu')
-        c = ops.add_act(a, b, 'gelu')
+        if tr:      # fused junction: gelu(BN(lrelu(a)) + BN(lrelu(b))) in one pass over a, b (and one fused backward)
+            m1, m2 = self.block12[3], self.block34[4]
+            c = ops.bn2_add_act(a, (m1.weight, m1.bias, m1.running_mean, m1.running_var, m1.num_batches_tracked, m1.eps, m1.momentum),
+                                b, (m2.weight, m2.bias, m2.running_mean, m2.running_var, m2.num_batches_tracked, m2.eps, m2.momentum))
+        else:
+            c = ops.add_act(_bn(self.block12[3], a, pre='lrelu'), _bn(self.block34[4], b, pre='lrelu'), 'gelu')
         return _bn(self.block5[2], _conv(self.block5[0], c, stats_pre='lrelu' if tr else None), pre='lrelu')
 
 

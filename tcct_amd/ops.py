@@ -345,6 +345,63 @@ def batchnorm(x, gamma, beta, running_mean, running_var, num_batches_tracked=Non
                             ACT[pre_act], ACT[post_act], bool(training))
 
 
+class _Bn2AddAct(torch.autograd.Function):
+    """y = act(BN_A(pre(xa)) + BN_B(pre(xb))), both BatchNorms in train mode (CrossCNNBlock junction)"""
+
+    @staticmethod
+    def forward(ctx, xa, gA, bA, xb, gB, bB, bufs, eps, momentum, pre, act_kind):
+        _chk(xa, xb, gA, bA, gB, bB)
+        C = xa.shape[-1]
+        M = xa.numel() // C
+        dc = dtype_code(xa.dtype)
+        st = []
+        for x, g, b, (rm, rv, nbt) in ((xa, gA, bA, bufs[0]), (xb, gB, bB, bufs[1])):
+            fused = getattr(x, '_bn_sums', None)
+            if fused is not None and fused[1] == pre and fused[0].numel() == 2 * C:
+                sums = fused[0]
+            else:
+                sums = ZERO.get((2 * C,), torch.float64, x.device)
+                lib.bn_stats(x, M, C, pre, sums, dc)
+            mr = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+            ab = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+            lib.bn_finalize(sums, M, C, g, b, eps, momentum, rm, rv, nbt, mr, ab)
+            st += [mr, ab]
+        y = torch.empty_like(xa)
+        lib.bn2_add_act_fwd(xa, xb, y, M, C, st[1], st[3], pre, act_kind, dc)
+        ctx.save_for_backward(xa, xb, *st)
+        ctx.cfg = (pre, act_kind)
+        ctx.params = (gA, bA, gB, bB)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, xb, mrA, abA, mrB, abB = ctx.saved_tensors
+        pre, act_kind = ctx.cfg
+        gA, bA, gB, bB = ctx.params
+        dy = _as(dy, xa.dtype)
+        C = xa.shape[-1]
+        M = xa.numel() // C
+        dc = dtype_code(xa.dtype)
+        sums = ZERO.get((4 * C,), torch.float64, xa.device)
+        lib.bn2_add_act_bwd_reduce(xa, xb, dy, M, C, mrA, abA, mrB, abB, pre, act_kind, sums, dc)
+        dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
+        outs = []
+        for p in (gA, bA, gB, bB):
+            use_slot = ZERO.active and getattr(p, '_grad_slot', None) is not None
+            outs.append(_grad_out(p) if use_slot else torch.empty(C, device=xa.device, dtype=torch.float32))
+        lib.bn2_add_act_bwd_apply(xa, xb, dy, dxa, dxb, M, C, mrA, abA, mrB, abB, sums, pre, act_kind, outs[0], outs[1], outs[2],
+                                  outs[3], dc)
+        return (dxa, _ret(outs[0], gA), _ret(outs[1], bA), dxb, _ret(outs[2], gB), _ret(outs[3], bB), None, None, None, None, None)
+
+
+def bn2_add_act(xa, bnA, xb, bnB, pre_act='lrelu', act_kind='gelu'):
+    """bnA/bnB: (gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum) of the two train-mode BatchNorms"""
+    gA, bA, rmA, rvA, nbtA, eps, mom = bnA
+    gB, bB, rmB, rvB, nbtB, _, _ = bnB
+    return _Bn2AddAct.apply(xa, gA, bA, xb, gB, bB, ((rmA, rvA, nbtA), (rmB, rvB, nbtB)), float(eps), float(mom), ACT[pre_act],
+                            ACT[act_kind])
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
