@@ -219,85 +219,110 @@ extern "C" int tcct_label_planes(const uint8_t* labels, float* onehot, float* ed
 // x, eps: fp32 [N,H,W,CH]; thread = one (n, w, ch) column; lanes run over (w,ch) => coalesced rows.
 // out[n,h,w] = sum_ch g/(1e-6 + S) with g = softmax_H(x - log(-log(eps))/2), S = sum_H g   (nets/reg.py:118-128)
 // stats[n,w,ch] = {m, Z, S}
+// Block = 64 columns (lanes, so the 4 channels of a pixel sit in adjacent lanes) x GSEG row segments: each thread walks H/GSEG
+// rows of its column (online max/sum), segment partials are merged through LDS.  z is recomputed per pass (2 x logf per element
+// is cheaper than a third tensor round trip).
+#define GSEG 4
+__device__ __forceinline__ float gumbel_z(float x, float e) { return x - 0.5f * logf(-logf(e)); }
+
 template <int CH>
-__global__ void k_gumbel_fwd(const float* __restrict__ x, const float* __restrict__ eps, float* __restrict__ out,
-                             float* __restrict__ stats, int N, int H, int W) {
+__global__ void __launch_bounds__(64 * GSEG)
+k_gumbel_fwd(const float* __restrict__ x, const float* __restrict__ eps, float* __restrict__ out,
+             float* __restrict__ stats, int N, int H, int W) {
+    __shared__ float sm[GSEG][64], sz[GSEG][64];
     const int WC = W * CH;
     const int64_t cols = (int64_t)N * WC;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t rounds = (cols + stride - 1) / stride;
-    int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (int64_t it = 0; it < rounds; ++it, col += stride) {
-        const bool ok = col < cols;
-        const int64_t cc = ok ? col : 0;
-        const int64_t n = cc / WC;
-        const int wc = (int)(cc % WC);
-        const float* xp = x + n * (int64_t)H * WC + wc;
-        const float* ep = eps + n * (int64_t)H * WC + wc;
-        float m = -INFINITY, Z = 0.f;
-        for (int h = 0; h < H; ++h) {
-            float z = xp[(int64_t)h * WC] - 0.5f * logf(-logf(ep[(int64_t)h * WC]));
-            float mn = fmaxf(m, z);
-            Z = Z * __expf(m - mn) + __expf(z - mn);
-            m = mn;
-        }
-        float S = 0.f;
-        for (int h = 0; h < H; ++h) {
-            float z = xp[(int64_t)h * WC] - 0.5f * logf(-logf(ep[(int64_t)h * WC]));
-            S += __expf(z - m) / Z;
-        }
-        if (ok) { stats[cc * 3] = m; stats[cc * 3 + 1] = Z; stats[cc * 3 + 2] = S; }
-        const float den = 1.f / (1e-6f + S);
-        for (int h = 0; h < H; ++h) {
-            float z = xp[(int64_t)h * WC] - 0.5f * logf(-logf(ep[(int64_t)h * WC]));
-            float v = __expf(z - m) / Z * den;
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + lane;
+    const bool ok = col < cols;
+    const int64_t cc = ok ? col : 0;
+    const int64_t n = cc / WC;
+    const int wc = (int)(cc % WC);
+    const float* xp = x + n * (int64_t)H * WC + wc;
+    const float* ep = eps + n * (int64_t)H * WC + wc;
+    const int hs = (H + GSEG - 1) / GSEG;
+    const int h0 = seg * hs, h1 = min(H, h0 + hs);
+    float m = -INFINITY, Z = 0.f;
+    for (int h = h0; h < h1; ++h) {
+        float z = gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]);
+        float mn = fmaxf(m, z);
+        Z = Z * __expf(m - mn) + __expf(z - mn);
+        m = mn;
+    }
+    sm[seg][lane] = m; sz[seg][lane] = Z;
+    __syncthreads();
+    m = -INFINITY;
 #pragma unroll
-            for (int o = CH >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (ok && (wc % CH) == 0) out[(n * H + h) * (int64_t)W + wc / CH] = v;
-        }
+    for (int g = 0; g < GSEG; ++g) m = fmaxf(m, sm[g][lane]);
+    Z = 0.f;
+#pragma unroll
+    for (int g = 0; g < GSEG; ++g) Z += sz[g][lane] * __expf(sm[g][lane] - m);
+    __syncthreads();
+    float S = 0.f;
+    for (int h = h0; h < h1; ++h) S += __expf(gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]) - m) / Z;
+    sm[seg][lane] = S;
+    __syncthreads();
+    S = 0.f;
+#pragma unroll
+    for (int g = 0; g < GSEG; ++g) S += sm[g][lane];
+    if (ok && seg == 0) { stats[cc * 3] = m; stats[cc * 3 + 1] = Z; stats[cc * 3 + 2] = S; }
+    const float den = 1.f / (1e-6f + S);
+    for (int h = h0; h < h1; ++h) {
+        float v = __expf(gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]) - m) / Z * den;
+#pragma unroll
+        for (int o = CH >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (ok && (wc % CH) == 0) out[(n * H + h) * (int64_t)W + wc / CH] = v;
     }
 }
 // dx[n,h,w,ch] = g * ((dout[h] - D)/(eps+S) - D (1-S)/(eps+S)^2),  D = sum_h dout[h] g[h]
 template <int CH>
-__global__ void k_gumbel_bwd(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ stats,
-                             const float* __restrict__ dout, float* __restrict__ dx, int N, int H, int W) {
+__global__ void __launch_bounds__(64 * GSEG)
+k_gumbel_bwd(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ stats,
+             const float* __restrict__ dout, float* __restrict__ dx, int N, int H, int W) {
+    __shared__ float sd[GSEG][64];
     const int WC = W * CH;
     const int64_t cols = (int64_t)N * WC;
-    for (int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; col < cols; col += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = col / WC;
-        const int wc = (int)(col % WC);
-        const int w = wc / CH;
-        const float* xp = x + n * (int64_t)H * WC + wc;
-        const float* ep = eps + n * (int64_t)H * WC + wc;
-        const float* dp = dout + n * (int64_t)H * W + w;
-        float* dxp = dx + n * (int64_t)H * WC + wc;
-        const float m = stats[col * 3], Z = stats[col * 3 + 1], S = stats[col * 3 + 2];
-        float D = 0.f;
-        for (int h = 0; h < H; ++h) {
-            float z = xp[(int64_t)h * WC] - 0.5f * logf(-logf(ep[(int64_t)h * WC]));
-            D += dp[(int64_t)h * W] * (__expf(z - m) / Z);
-        }
-        const float den = 1.f / (1e-6f + S);
-        const float k2 = D * (1.f - S) * den * den;
-        for (int h = 0; h < H; ++h) {
-            float z = xp[(int64_t)h * WC] - 0.5f * logf(-logf(ep[(int64_t)h * WC]));
-            float g = __expf(z - m) / Z;
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + lane;
+    const bool ok = col < cols;
+    const int64_t cc = ok ? col : 0;
+    const int64_t n = cc / WC;
+    const int wc = (int)(cc % WC);
+    const int w = wc / CH;
+    const float* xp = x + n * (int64_t)H * WC + wc;
+    const float* ep = eps + n * (int64_t)H * WC + wc;
+    const float* dp = dout + n * (int64_t)H * W + w;
+    float* dxp = dx + n * (int64_t)H * WC + wc;
+    const float m = stats[cc * 3], Z = stats[cc * 3 + 1], S = stats[cc * 3 + 2];
+    const int hs = (H + GSEG - 1) / GSEG;
+    const int h0 = seg * hs, h1 = min(H, h0 + hs);
+    float D = 0.f;
+    for (int h = h0; h < h1; ++h) D += dp[(int64_t)h * W] * (__expf(gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]) - m) / Z);
+    sd[seg][lane] = D;
+    __syncthreads();
+    D = 0.f;
+#pragma unroll
+    for (int g = 0; g < GSEG; ++g) D += sd[g][lane];
+    const float den = 1.f / (1e-6f + S);
+    const float k2 = D * (1.f - S) * den * den;
+    if (ok)
+        for (int h = h0; h < h1; ++h) {
+            float g = __expf(gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]) - m) / Z;
             dxp[(int64_t)h * WC] = g * ((dp[(int64_t)h * W] - D) * den - k2);
         }
-    }
 }
 extern "C" int tcct_gumbel_colsoftmax_fwd(const float* x, const float* eps, float* out, float* stats, int N, int H, int W,
                                           int CH, tcct_stream_t stream) {
     TCCT_CHECK(CH == 4, "gumbel_colsoftmax_fwd: CH=%d unsupported (4)", CH);
     int64_t cols = (int64_t)N * W * CH;
-    hipLaunchKernelGGL(k_gumbel_fwd<4>, dim3(tcct_grid(cols, 64, 1 << 16)), dim3(64), 0, (hipStream_t)stream, x, eps, out, stats, N, H, W);
+    hipLaunchKernelGGL(k_gumbel_fwd<4>, dim3((unsigned)((cols + 63) / 64)), dim3(64 * GSEG), 0, (hipStream_t)stream, x, eps, out, stats, N, H, W);
     TCCT_LAUNCH_OK();
 }
 extern "C" int tcct_gumbel_colsoftmax_bwd(const float* x, const float* eps, const float* stats, const float* dout, float* dx,
                                           int N, int H, int W, int CH, tcct_stream_t stream) {
     TCCT_CHECK(CH == 4, "gumbel_colsoftmax_bwd: CH=%d unsupported (4)", CH);
     int64_t cols = (int64_t)N * W * CH;
-    hipLaunchKernelGGL(k_gumbel_bwd<4>, dim3(tcct_grid(cols, 64, 1 << 16)), dim3(64), 0, (hipStream_t)stream, x, eps, stats, dout, dx, N, H, W);
+    hipLaunchKernelGGL(k_gumbel_bwd<4>, dim3((unsigned)((cols + 63) / 64)), dim3(64 * GSEG), 0, (hipStream_t)stream, x, eps, stats, dout, dx, N, H, W);
     TCCT_LAUNCH_OK();
 }
 
