@@ -44,7 +44,7 @@ def build_trainer(a, world):
     from tcct_amd.data import SynthOCT
     from tcct_amd import nets
     from tcct_amd.kite.loop_seg import KiteSeg
-    args = parse_args([f'--los={a.los}', f'--bs={a.bs}', '--db=synth', f'--pl={"true" if world > 1 else "false"}',
+    args = parse_args([f'--los={a.los}', f'--bs={a.bs}', '--db=synth', f'--pl={"true" if (world > 1 or os.environ.get("TCCT_FORCE_DIST") == "1") else "false"}',
                        f'--dtype={a.dtype}', '--root=/tmp/tcct_bench_root'])
     ds = SynthOCT(height=a.height, width=a.width, device='cuda')
     net = nets.stc_tt(ds.out_channels, compute_dtype=torch.bfloat16 if a.dtype == 'bf16' else torch.float32)
@@ -198,6 +198,7 @@ def main():
     dt = time.perf_counter() - t0
     dt = tdist.max_over_ranks(dt, torch.device('cuda', local))
     lossv = float(loss.item())
+    tdist.barrier()
     if rank != 0:
         return
     value = a.bs * world * a.steps / dt
@@ -216,8 +217,17 @@ def main():
         out['roofline']['step_model_GBs'] = round(per_img * value / world / 1e9, 1)
     if world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(a)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+
+
+def _shutdown():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    finally:
+        _shutdown()

@@ -16,7 +16,8 @@ def env_world():
 def init(backend=None):
     """Initialise torch.distributed from the torchrun environment; returns (world, rank, local_rank)."""
     world, rank, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('TCCT_FORCE_DIST', '0') == '1'      # exercise the RCCL path on a single GPU (tests)
+    if (world > 1 or (force and 'RANK' in os.environ)) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
@@ -37,14 +38,14 @@ def shard_batch(n_global, world, rank):
 
 def allreduce_sum_(flat):
     """in-place sum all-reduce of a flat gradient buffer (no-op for a single process)"""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('TCCT_FORCE_DIST', '0') == '1'):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
 def attach(optimizer):
     """make a FlatAdamW average gradients over the process group before the clip+AdamW kernel"""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('TCCT_FORCE_DIST', '0') == '1'):
         optimizer.world = dist.get_world_size()
         optimizer.allreduce = allreduce_sum_
     return optimizer
