@@ -47,15 +47,21 @@ extern "C" int tcct_conv32_pack_weights_sub(const float* w, void* wp, int KH, in
 // geometry precomputed once), issues ALL its global loads for the NEXT tile into registers before the MFMA phase of the
 // current tile (one memory latency per tile instead of one per slot), and writes them to LDS after the barrier.
 #define MAXL 11
-template <bool VERT, bool STATS>
+#define IPS 80      // LDS bytes per image pixel: 64 B of channels + 16 B pad => conflict-free ds_read_b128 with LINEAR addressing
+// An ablation of the first version showed the kernel was instruction-bound, not memory-bound: with loads, stores and MFMAs all
+// removed it still took 0.20 of 0.29 ms -- XOR-swizzle address arithmetic (6 VALU ops per fragment read, ~1000 per tile and wave)
+// in front of every ds_read.  Now the image rows are padded instead of swizzled and KH/KW are template constants, so a B
+// fragment read is `ds_read_b128 v, base_t offset:imm` with NO per-read VALU work (KH_ = 0 keeps a runtime-tap fallback).
+template <bool VERT, bool STATS, int KH_, int KW_>
 __global__ void __launch_bounds__(MB, 2)
 k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
-              int N, int H, int W, int KH, int KW, int PH, int PW, int tilesH, int tilesW, int ntiles, int xs, int xo, int ys,
+              int N, int H, int W, int KHr, int KWr, int PH, int PW, int tilesH, int tilesW, int ntiles, int xs, int xo, int ys,
               int yo, int accum, double* __restrict__ stats, int stat_pre) {
-    // stats != NULL: also accumulate per-channel sum / sum-of-squares of pre_act(y) (y as stored, i.e. bf16-rounded) into
-    // stats[0..31] / stats[32..63] -- the train-mode BatchNorm statistics of the consumer, fused into this epilogue
     // xs/xo, ys/yo: channels per pixel in memory and channel offset of the 32-channel slab read / written; accum: y += result
+    // stats != NULL (STATS): also accumulate per-channel sum / sum-of-squares of pre_act(y) (y as stored, i.e. bf16-rounded) into
+    // stats[0..31] / stats[32..63] -- the train-mode BatchNorm statistics of the consumer, fused into this epilogue
     constexpr int TH = VERT ? 64 : 8, TW = VERT ? 8 : 64;
+    const int KH = KH_ ? KH_ : KHr, KW = KH_ ? KW_ : KWr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int LH = TH + KH - 1, LW = TW + KW - 1;
     const int TAPS = KH * KW;
@@ -71,7 +77,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         *reinterpret_cast<uint4*>(sW + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = v;
     }
     // bias lives in LDS (behind the input image) and is re-read in the epilogue: 16 fewer live VGPRs in the MFMA loop
-    float* sB = reinterpret_cast<float*>(sX + LH * LW * 64);
+    float* sB = reinterpret_cast<float*>(sX + LH * LW * IPS);
     if (tid < 32) sB[tid] = bias ? bias[tid] : 0.f;
 
     // slot geometry (tile independent): slot j covers 16-byte chunk c of tile-local pixel (lr, lc); (lr,lc) packed in one int
@@ -85,7 +91,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         int lr = in ? pl / LW : 0x3fff, lc = in ? pl - (pl / LW) * LW : 0;
         int p = VERT ? lc * LH + lr : pl;
         s_rc[j] = (lr << 16) | lc;
-        s_off[j] = in ? p * 64 + ((c ^ ((p >> 2) & 3)) << 4) : -1;
+        s_off[j] = in ? p * IPS + c * 16 : -1;
     }
     uint4 pre[MAXL];
     auto prefetch = [&](int tile) {
@@ -103,6 +109,18 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
                 pre[j] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hi * W + wi) * xs);
         }
     };
+    // per-lane fragment bases: weights (swizzled 64-byte rows, row = tap*32 + r: the swizzle term only depends on r) and image
+    const int wsw = (r >> 2) & 3;
+    const unsigned char* wA0 = sW + r * 64 + ((hh ^ wsw) << 4);
+    const unsigned char* wA1 = sW + r * 64 + (((2 + hh) ^ wsw) << 4);
+    const unsigned char* xB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int mt = wave * 4 + t;
+        int a = mt >> 1, seg = mt & 1;           // HORZ: a = row; VERT: a = col
+        int pb = VERT ? a * LH + seg * 32 + r : a * LW + seg * 32 + r;
+        xB[t] = sX + pb * IPS + hh * 16;
+    }
     float ss[STATS ? 16 : 1], sq[STATS ? 16 : 1];
 #pragma unroll
     for (int k = 0; k < (STATS ? 16 : 1); ++k) ss[k] = sq[k] = 0.f;
@@ -126,30 +144,48 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
-        int pb[4];
+        // Fragment reads are software-pipelined one tap ahead of the MFMAs that consume them: left to itself hipcc emits
+        // `ds_read; s_waitcnt lgkmcnt(0); v_mfma` per MFMA, exposing the full LDS latency 72 times per tile.
+        struct Frag { bf16x8 a0, a1, b0[4], b1[4]; };
+        auto load_tap = [&](Frag& f, int dy, int dx) {
+            const int woff = (dy * KW + dx) * 2048;                        // 32 rows x 64 B per tap
+            f.a0 = *reinterpret_cast<const bf16x8*>(wA0 + woff);
+            f.a1 = *reinterpret_cast<const bf16x8*>(wA1 + woff);
+            const int poff = (VERT ? dx * LH + dy : dy * LW + dx) * IPS;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            int mt = wave * 4 + t;
-            int a = mt >> 1, seg = mt & 1;           // HORZ: a = row; VERT: a = col
-            pb[t] = VERT ? a * LH + seg * 32 + r : a * LW + seg * 32 + r;
-        }
-        for (int dy = 0; dy < KH; ++dy) {
-            for (int dx = 0; dx < KW; ++dx) {
-                const int wrow = (dy * KW + dx) * 32 + r;
-                const int wsw = (wrow >> 2) & 3;
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sW + wrow * 64 + ((hh ^ wsw) << 4));
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sW + wrow * 64 + (((2 + hh) ^ wsw) << 4));
-                const int poff = VERT ? dx * LH + dy : dy * LW + dx;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int p = pb[t] + poff;
-                    const int sw = (p >> 2) & 3;
-                    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sX + p * 64 + ((hh ^ sw) << 4));
-                    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sX + p * 64 + (((2 + hh) ^ sw) << 4));
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
-                }
+            for (int t = 0; t < 4; ++t) {
+                f.b0[t] = *reinterpret_cast<const bf16x8*>(xB[t] + poff);
+                f.b1[t] = *reinterpret_cast<const bf16x8*>(xB[t] + poff + 32);
             }
+        };
+        auto mma_tap = [&](const Frag& f) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a0, f.b0[t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a1, f.b1[t], acc[t], 0, 0, 0);
+            }
+        };
+        if (KH_ && !STATS) {          // (the STATS variant has 32 more live VGPRs: double-buffered fragments would spill)
+            constexpr int NT = (KH_ ? KH_ : 1) * (KW_ ? KW_ : 1);
+            Frag f[2];
+            load_tap(f[0], 0, 0);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                if (k + 1 < NT) load_tap(f[(k + 1) & 1], (k + 1) / (KW_ ? KW_ : 1), (k + 1) % (KW_ ? KW_ : 1));
+                __builtin_amdgcn_sched_barrier(0);          // keep the next tap's reads ahead of this tap's MFMAs
+                mma_tap(f[k & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (KH_) {
+            Frag f;
+#pragma unroll
+            for (int dy = 0; dy < (KH_ ? KH_ : 1); ++dy)
+#pragma unroll
+                for (int dx = 0; dx < (KW_ ? KW_ : 1); ++dx) { load_tap(f, dy, dx); mma_tap(f); }
+        } else {
+            Frag f;
+            for (int dy = 0; dy < KH; ++dy)
+                for (int dx = 0; dx < KW; ++dx) { load_tap(f, dy, dx); mma_tap(f); }
         }
         // epilogue: lane owns pixel r of each M-tile and channels co = 8q + 4*hh + k
 #pragma unroll
@@ -231,7 +267,7 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
     const bool vert = (KW == 1 && KH > 1);
     const int TH = vert ? 64 : 8, TW = vert ? 8 : 64;
     const int LH = TH + KH - 1, LW = TW + KW - 1;
-    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * 64 + 128;
+    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * IPS + 128;
     TCCT_CHECK(lds <= 80 * 1024, "conv32_fwd: %dx%d needs %zu B of LDS (> 80 KiB for 2 blocks/CU)", KH, KW, lds);
     TCCT_CHECK(LH * LW * 4 <= MAXL * MB, "conv32_fwd: %dx%d tile image exceeds the staging slots", KH, KW);
     int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
@@ -239,15 +275,24 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
     TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32_fwd: bad tile count");
     int grid = (int)(nt < 512 ? nt : 512);
     hipStream_t st = (hipStream_t)stream;
-#define CF_LAUNCH(V, S)                                                                                                     \
+#define CF_LAUNCH(V, S, KHT, KWT)                                                                                           \
     do {                                                                                                                    \
         static bool attr = false;                                                                                           \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_mfma<V, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
-        hipLaunchKernelGGL((k_conv32_mfma<V, S>), dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, KH, \
-                           KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum, stats, stat_pre);                    \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_mfma<V, S, KHT, KWT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+        hipLaunchKernelGGL((k_conv32_mfma<V, S, KHT, KWT>), dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, \
+                           KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum, stats, stat_pre);                \
     } while (0)
-    if (vert) { if (stats) CF_LAUNCH(true, true); else CF_LAUNCH(true, false); }
-    else { if (stats) CF_LAUNCH(false, true); else CF_LAUNCH(false, false); }
+#define CF_S(V, KHT, KWT) do { if (stats) CF_LAUNCH(V, true, KHT, KWT); else CF_LAUNCH(V, false, KHT, KWT); } while (0)
+    // compile-time taps for the shapes that carry the time (3x3 everywhere; the level-0/1 cross convolutions); generic otherwise
+    if (KH == 3 && KW == 3) CF_S(false, 3, 3);
+    else if (KH == 1 && KW == 13) CF_S(false, 1, 13);
+    else if (KH == 13 && KW == 1) CF_S(true, 13, 1);
+    else if (KH == 1 && KW == 11) CF_S(false, 1, 11);
+    else if (KH == 11 && KW == 1) CF_S(true, 11, 1);
+    else if (KH == 1 && KW == 1) CF_S(false, 1, 1);
+    else if (vert) CF_S(true, 0, 0);
+    else CF_S(false, 0, 0);
+#undef CF_S
 #undef CF_LAUNCH
     TCCT_LAUNCH_OK();
 }

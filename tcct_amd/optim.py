@@ -73,10 +73,9 @@ class FlatAdamW(torch.optim.Optimizer):
                 k = p.numel()
                 slot = getattr(p, '_grad_slot', None)
                 if p.grad is not None and (slot is None or p.grad.data_ptr() != slot.data_ptr()):
-                    if slot is None:
-                        f['g'][off:off + k].copy_(p.grad.reshape(-1))
-                    else:                           # produced outside the pooled step (plain backward): add to the zeroed slot
-                        f['g'][off:off + k].add_(p.grad.reshape(-1))
+                    # produced through autograd (multi-use parameter, or a plain backward outside the pooled step): the
+                    # kernels did not touch this slot, so the autograd result IS the gradient
+                    f['g'][off:off + k].copy_(p.grad.reshape(-1))
                 if slot is not None:
                     p.grad = slot                   # keep the torch contract: p.grad holds the gradient after step()
                 off += k
