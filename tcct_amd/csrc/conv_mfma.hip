@@ -306,16 +306,19 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-__device__ __forceinline__ bf16x8 tr_load8(const unsigned char* base, int P, int lane) {
-    // 16 consecutive LDS pixels P..P+15; returns pixels P+8*(lane>>5)+j (j=0..7) of channel (lane&31)
+// Both wgrad images are read ONLY through transposing reads, which need no swizzle (4 consecutive pixels = 256 contiguous bytes
+// hit every bank once): pixel rows stay linear (64 B), so a read address is `lane base + pixel*64` and the second half of the
+// fragment (+4 pixels) is an immediate offset.  (PMC of the first version: 1690 VALU instructions per tile and wave, mostly
+// swizzle arithmetic in front of the reads.)
+__device__ __forceinline__ const unsigned char* tr_lane_base(const unsigned char* img, int lane) {
     const int i = lane & 15, q = i >> 2, pp = i & 3, g = lane >> 4;
     const int hh = g >> 1, cb = g & 1;
-    const int chunk = 2 * cb + (pp >> 1), inner = (pp & 1) * 8;
-    const int p0 = P + 8 * hh + q, p1 = p0 + 4;
-    const unsigned char* a0 = base + p0 * 64 + ((chunk ^ ((p0 >> 2) & 3)) << 4) + inner;
-    const unsigned char* a1 = base + p1 * 64 + ((chunk ^ ((p1 >> 2) & 3)) << 4) + inner;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+    return img + (8 * hh + q) * 64 + (16 * cb + 4 * pp) * 2;
+}
+__device__ __forceinline__ bf16x8 tr_load8p(const unsigned char* p) {
+    // p = tr_lane_base(img) + P*64 for 16 consecutive LDS pixels P..P+15; returns pixels P+8*(lane>>5)+j (j=0..7) of channel lane&31
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 256));
     s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
@@ -342,7 +345,7 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
     for (int t = 0; t < TPW; ++t) {
         int tap = tap0 + t;
         int dy_ = tap / KW, dx_ = tap - dy_ * KW;
-        poff[t] = VERT ? dx_ * LH + dy_ : dy_ * LW + dx_;
+        poff[t] = (tap < KH * KW) ? (VERT ? dx_ * LH + dy_ : dy_ * LW + dx_) * 64 : 0;
     }
     f32x16 acc[TPW];
 #pragma unroll
@@ -350,6 +353,8 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
     float bsum = 0.f;
+    const unsigned char* lbX = tr_lane_base(sX, lane);
+    const unsigned char* lbD = tr_lane_base(sD, lane);
 
     // staging slots (see k_conv32_mfma): x image slots and dy image slots, geometry fixed per thread
     const int c = tid & 3;
@@ -362,7 +367,7 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
         int lr = in ? pl / LW : 0x3fff, lc = in ? pl - (pl / LW) * LW : 0;
         int p = VERT ? lc * LH + lr : pl;
         s_rc[j] = (lr << 16) | lc;
-        s_off[j] = in ? p * 64 + ((c ^ ((p >> 2) & 3)) << 4) : -1;
+        s_off[j] = in ? p * 64 + c * 16 : -1;
     }
     uint4 prex[MAXL], pred[DSL];
     auto prefetch = [&](int tile) {
@@ -399,25 +404,50 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
         for (int j = 0; j < DSL; ++j) {
             const int pl = (tid >> 2) + j * (MB / 4);
             const int p = VERT ? (pl & (TW - 1)) * TH + pl / TW : pl;
-            *reinterpret_cast<uint4*>(sD + p * 64 + ((c ^ ((p >> 2) & 3)) << 4)) = pred[j];
+            *reinterpret_cast<uint4*>(sD + p * 64 + c * 16) = pred[j];
         }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
-        for (int ch = wi; ch < 32; ch += WPG) {
+        // chunks of 16 pixels; fragments of chunk i+1 are read while the MFMAs of chunk i run (sched_barrier pins the order)
+        struct WFrag { bf16x8 a, b[TPW]; };
+        auto load_chunk = [&](WFrag& f, int ch) {
             const int a_ = ch >> 2, s16 = (ch & 3) * 16;      // HORZ: row / col offset; VERT: col / row offset
             const int Pd = VERT ? a_ * TH + s16 : a_ * TW + s16;
             const int Px = VERT ? a_ * LH + s16 : a_ * LW + s16;
-            const bf16x8 a = tr_load8(sD, Pd, lane);
+            f.a = tr_load8p(lbD + Pd * 64);
+            const unsigned char* px = lbX + Px * 64;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) f.b[t] = tr_load8p(px + poff[t]);
+        };
+        auto mma_chunk = [&](const WFrag& f) {
             if (tg == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bsum += (float)a[j];
+                for (int j = 0; j < 8; ++j) bsum += (float)f.a[j];
             }
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                if (tap0 + t < TAPS) {
-                    const bf16x8 b = tr_load8(sX, Px + poff[t], lane);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
-                }
+            for (int t = 0; t < TPW; ++t)
+                if (tap0 + t < TAPS) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a, f.b[t], acc[t], 0, 0, 0);
+        };
+        if (TPW <= 4) {
+            WFrag f0, f1;                   // named buffers: a runtime-indexed array of fragments would live in scratch
+            load_chunk(f0, wi);
+            for (int ch = wi; ch < 32; ch += 2 * WPG) {           // 32 / WPG is even
+                load_chunk(f1, ch + WPG);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_chunk(f0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ch + 2 * WPG < 32) load_chunk(f0, ch + 2 * WPG);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_chunk(f1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {                            // 5 accumulators: a second fragment set would spill; read all 12 fragments, then 5 MFMAs
+            WFrag f0;
+            for (int ch = wi; ch < 32; ch += WPG) {
+                load_chunk(f0, ch);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_chunk(f0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
