@@ -66,3 +66,25 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+def pw_bench():
+    """pointwise GEMM shapes of the ViT branch at the bench batch"""
+    shapes = [(8 * 400 * 552, 64, 64), (8 * 400 * 552, 128, 96), (8 * 400 * 552, 96, 32), (8 * 200 * 276, 96, 96), (8 * 200 * 276, 192, 128),
+              (8 * 800 * 1104, 32, 32)]
+    for (M, K, N) in shapes:
+        x = torch.randn(M, K, device='cuda').to(dt)
+        dy = torch.randn(M, N, device='cuda').to(dt)
+        w = torch.randn(N, K, device='cuda') * 0.1
+        b = torch.zeros(N, device='cuda')
+        y = torch.empty(M, N, device='cuda', dtype=dt)
+        dw = torch.empty_like(w)
+        db = torch.empty(N, device='cuda')
+        gb = M * (K + N) * 2 / 1e9
+        ms = timeit(lambda: lib.pw_fwd(x, w, b, y, M, K, N, 0, 1))
+        ms2 = timeit(lambda: lib.pw_wgrad(x, dy, dw, db, M, K, N))
+        print(f'pw M={M} K={K} N={N}: fwd {ms:.3f} ms {gb / ms * 1e3:.0f} GB/s | wgrad {ms2:.3f} ms {gb / ms2 * 1e3:.0f} GB/s')
+
+
+if 'pw' in sys.argv[1:]:
+    pw_bench()
