@@ -140,7 +140,11 @@ __device__ __forceinline__ bf16x8 tr_load8g(const unsigned char* base, int strid
     return __builtin_bit_cast(bf16x8, v);
 }
 
-#define PW_P 64     // pixels per staged tile
+#define PW_P 128    // pixels per staged tile (8 chunks of 16: two per wave)
+#define PW_XS 4     // max x staging slots per thread (128 px * 8 chunks / 256)
+#define PW_DS 10    // max dy staging slots per thread (128 px * 20 chunks / 256)
+// Tiles are staged through registers one tile ahead (all global loads of tile i+1 are in flight while tile i is multiplied),
+// fragments are read with immediate offsets from per-lane bases and the two chunks of a wave are double-buffered.
 template <int NT, int KTB>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias, int64_t M,
@@ -162,39 +166,78 @@ k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __res
     float bsum[NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a) bsum[a] = 0.f;
-    const int64_t tiles = (M + PW_P - 1) / PW_P;
-    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    // staging slots: slot j of the x image = (pixel xp[j], chunk xq[j]); packed as pixel<<8 | chunk, -1 = unused
+    int xsl[PW_XS], dsl[PW_DS];
+#pragma unroll
+    for (int j = 0; j < PW_XS; ++j) { int i = tid + j * PWB; xsl[j] = i < PW_P * xc ? ((i / xc) << 8) | (i % xc) : -1; }
+#pragma unroll
+    for (int j = 0; j < PW_DS; ++j) { int i = tid + j * PWB; dsl[j] = i < PW_P * dc ? ((i / dc) << 8) | (i % dc) : -1; }
+    uint4 px[PW_XS], pd[PW_DS];
+    auto prefetch = [&](int64_t tile) {
         const int64_t m0 = tile * PW_P;
+#pragma unroll
+        for (int j = 0; j < PW_XS; ++j) {
+            px[j] = make_uint4(0, 0, 0, 0);
+            if (xsl[j] >= 0 && m0 + (xsl[j] >> 8) < M)
+                px[j] = *reinterpret_cast<const uint4*>(x + (m0 + (xsl[j] >> 8)) * K + ci_base + (xsl[j] & 255) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < PW_DS; ++j) {
+            pd[j] = make_uint4(0, 0, 0, 0);
+            if (dsl[j] >= 0 && m0 + (dsl[j] >> 8) < M)
+                pd[j] = *reinterpret_cast<const uint4*>(dy + (m0 + (dsl[j] >> 8)) * N + (dsl[j] & 255) * 8);
+        }
+    };
+    // per-lane transposing-read bases (see conv_mfma.hip): address = base + pixel*stride (+ 4*stride for the second half)
+    const int li = lane & 15, lq = li >> 2, lpp = li & 3, lg = lane >> 4;
+    const int lrow = 8 * (lg >> 1) + lq, lcol = (16 * (lg & 1) + 4 * lpp) * 2;
+    const unsigned char* lbX = sX + lrow * SX + lcol;
+    const unsigned char* lbD = sD + lrow * SD + lcol;
+    auto tr2 = [&](const unsigned char* p, int stride) {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * stride));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    struct WF { bf16x8 a[NT], b[KTB]; };
+    auto load_chunk = [&](WF& f, int ch) {
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) f.a[ct] = tr2(lbD + ch * 16 * SD + 64 * ct, SD);
+#pragma unroll
+        for (int kt = 0; kt < KTB; ++kt) f.b[kt] = tr2(lbX + ch * 16 * SX + 64 * kt, SX);
+    };
+    auto mma_chunk = [&](const WF& f) {
+        if (blockIdx.y == 0) {
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum[ct] += (float)f.a[ct][j];
+        }
+#pragma unroll
+        for (int kt = 0; kt < KTB; ++kt)
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) acc[ct][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ct], f.b[kt], acc[ct][kt], 0, 0, 0);
+    };
+    const int64_t tiles = (M + PW_P - 1) / PW_P;
+    int64_t tile = blockIdx.x;
+    if (tile < tiles) prefetch(tile);
+    for (; tile < tiles; tile += gridDim.x) {
         __syncthreads();
-        for (int i = tid; i < PW_P * xc; i += PWB) {
-            int p = i / xc, c = i - p * xc;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (m0 + p < M && ci_base + c * 8 < K) v = *reinterpret_cast<const uint4*>(x + (m0 + p) * K + ci_base + c * 8);
-            *reinterpret_cast<uint4*>(sX + p * SX + c * 16) = v;
-        }
-        for (int i = tid; i < PW_P * dc; i += PWB) {
-            int p = i / dc, c = i - p * dc;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (m0 + p < M) v = *reinterpret_cast<const uint4*>(dy + (m0 + p) * N + c * 8);
-            *reinterpret_cast<uint4*>(sD + p * SD + c * 16) = v;
-        }
+#pragma unroll
+        for (int j = 0; j < PW_XS; ++j)
+            if (xsl[j] >= 0) *reinterpret_cast<uint4*>(sX + (xsl[j] >> 8) * SX + (xsl[j] & 255) * 16) = px[j];
+#pragma unroll
+        for (int j = 0; j < PW_DS; ++j)
+            if (dsl[j] >= 0) *reinterpret_cast<uint4*>(sD + (dsl[j] >> 8) * SD + (dsl[j] & 255) * 16) = pd[j];
         __syncthreads();
-        const int P = wave * 16;
-        bf16x8 a[NT];
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-            a[ct] = tr_load8g(sD, SD, P, 32 * ct, lane);
-            if (blockIdx.y == 0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bsum[ct] += (float)a[ct][j];
-            }
-        }
-#pragma unroll
-        for (int kt = 0; kt < KTB; ++kt) {
-            const bf16x8 b = tr_load8g(sX, SX, P, 32 * kt, lane);
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct) acc[ct][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct], b, acc[ct][kt], 0, 0, 0);
-        }
+        if (tile + gridDim.x < tiles) prefetch(tile + gridDim.x);
+        WF f0, f1;
+        load_chunk(f0, wave);
+        load_chunk(f1, wave + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chunk(f0);
+        mma_chunk(f1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);          // [NT*32][KTB*32]
@@ -230,7 +273,7 @@ extern "C" int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* db
     if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)N * K, st) != hipSuccess) { tcct_set_error("pw_wgrad: memset failed"); return -2; }
     if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * N, st) != hipSuccess) { tcct_set_error("pw_wgrad: memset failed"); return -2; }
     const int NT = N / 32, ktiles = K / 32;
-    const int KTB = (ktiles % 2 == 0) ? 2 : 1;
+    const int KTB = (ktiles % 2 == 0 && NT <= 2) ? 2 : 1;       // <= 5 accumulators per wave next to the prefetch registers
     const int gy = ktiles / KTB;
     // row strides: S mod 256 in {64,192} keeps the 4-pixel x 64-byte footprint of a transposing read on distinct banks
     const int SX = KTB == 1 ? 64 : 192;
@@ -239,12 +282,17 @@ extern "C" int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* db
     size_t red = (size_t)NT * 32 * KTB * 32 * 4;
     if (red > lds) lds = red;
     const int64_t tiles = (M + PW_P - 1) / PW_P;
-    int gx = (int)(tiles < 512 ? tiles : 512);
-    if (gy > 1) { gx = (int)(tiles < (1024 / gy) ? tiles : (1024 / gy)); if (gx < 1) gx = 1; }
-#define WL(NTV, KV) hipLaunchKernelGGL((k_pw_wgrad<NTV, KV>), dim3(gx, gy), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias, M, K, N, SX, SD)
-#define WD(KV) switch (NT) { case 1: WL(1, KV); break; case 2: WL(2, KV); break; case 3: WL(3, KV); break; case 4: WL(4, KV); break; default: WL(5, KV); break; }
-    if (KTB == 2) { WD(2); } else { WD(1); }
-#undef WD
+    (void)hipFuncSetAttribute;
+    int per_cu = (int)((160 * 1024) / (lds + 512));
+    if (per_cu > 2) per_cu = 2;                                   // __launch_bounds__(256, 2)
+    if (per_cu < 1) per_cu = 1;
+    int gx = 256 * per_cu / gy;
+    if (gx < 64) gx = 64;
+    if (gx > tiles) gx = (int)tiles;
+    if (gx < 1) gx = 1;
+#define WL(NTV, KV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_wgrad<NTV, KV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } } hipLaunchKernelGGL((k_pw_wgrad<NTV, KV>), dim3(gx, gy), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias, M, K, N, SX, SD)
+    if (KTB == 2) { switch (NT) { case 1: WL(1, 2); break; default: WL(2, 2); break; } }
+    else { switch (NT) { case 1: WL(1, 1); break; case 2: WL(2, 1); break; case 3: WL(3, 1); break; case 4: WL(4, 1); break; default: WL(5, 1); break; } }
 #undef WL
     TCCT_LAUNCH_OK();
 }

@@ -104,7 +104,7 @@ def _as(t, dtype):
 def _mfma32_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
     """the MFMA implicit-GEMM kernel covers bf16 32->32 stride-1 'same' convolutions (3x3, 1xk, kx1)"""
     return (in_dt == torch.bfloat16 and out_dt == torch.bfloat16 and Cin == 32 and Cin_w == 32 and Cout == 32 and stride == 1
-            and 2 * padh == KH - 1 and 2 * padw == KW - 1 and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
+            and 2 * padh == KH - 1 and 2 * padw == KW - 1 and KH * KW > 1 and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
 
 
 def _mfma_slabs_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
