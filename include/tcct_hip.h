@@ -149,6 +149,9 @@ int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float* dbias, in
 int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                 int out_dtype, tcct_stream_t stream);
 int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
+/* pw_fwd + fused train-mode BatchNorm statistics of the consumer (bf16 output, N in {32,64,96}); stats fp64 [2N], zero on entry */
+int tcct_pw_fwd_bnstats(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats, int pre_act,
+                        tcct_stream_t stream);
 
 /* first-layer helper: 4-channel NHWC image -> 32-channel 3x3 patch pixels (k = (ky*3+kx)*3+ch, zero for k >= 27) so that
  * CrossResNet.cnn[0] (nets/tcct.py:873) and MPViT stem[0] (stride 2, :674-681) run as 32->32 pointwise MFMA GEMMs */

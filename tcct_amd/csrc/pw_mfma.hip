@@ -24,10 +24,15 @@ __device__ __forceinline__ void st_out4(float* p, float a, float b, float c, flo
 }
 
 // NT = number of 32-channel output tiles handled per block (N chunk = NT*32 starting at blockIdx.y*NT*32)
-template <int NT, typename Tout>
+__device__ __forceinline__ float rnd_out(float v, const bf16*) { return __bfloat162float(__float2bfloat16(v)); }
+__device__ __forceinline__ float rnd_out(float v, const float*) { return v; }
+
+// STATS: also accumulate per-channel sum / sum of squares of pre_act(y) (y as stored) into stats[0..N) / stats[N..2N): the
+// train-mode BatchNorm statistics of the consumer (Conv2d_BN, DWConv2d_BN.pwconv, tran_*; reference nets/tcct.py:80,125,966-974)
+template <int NT, typename Tout, bool STATS>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, Tout* __restrict__ y,
-         int64_t M, int K, int N, int transposed) {
+         int64_t M, int K, int N, int transposed, double* __restrict__ stats, int stat_pre) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int SW = 2 * K + 16;                 // LDS row stride (bytes)
     const int n_base = blockIdx.y * NT * 32;
@@ -42,6 +47,11 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
         *reinterpret_cast<bf16*>(smem + row * SW + k * 2) = __float2bfloat16(v);
     }
     __syncthreads();
+    float ss[STATS ? NT : 1][16], sq[STATS ? NT : 1][16];
+#pragma unroll
+    for (int a = 0; a < (STATS ? NT : 1); ++a)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ss[a][k] = sq[a][k] = 0.f;
     const int KT = K >> 5;
     const int64_t mtiles = (M + 31) >> 5;
     for (int64_t mt = (int64_t)blockIdx.x * 4 + wave; mt < mtiles; mt += (int64_t)gridDim.x * 4) {
@@ -79,6 +89,13 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                     float v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = acc[nt][4 * q + k] + ((bias && co + k < N) ? bias[co + k] : 0.f);
+                    if (STATS) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float u = act_fwd(stat_pre, rnd_out(v[k], y));
+                            ss[nt][4 * q + k] += u; sq[nt][4 * q + k] += u * u;
+                        }
+                    }
                     if (co + 3 < N && (N & 3) == 0) st_out4(y + m * N + co, v[0], v[1], v[2], v[3]);
                     else {
 #pragma unroll
@@ -89,12 +106,48 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
             }
         }
     }
+    if (STATS) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);           // [2][NT*32] (weights are no longer needed)
+        for (int i2 = tid; i2 < 2 * NT * 32; i2 += PWB) red[i2] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float a = ss[nt][k], b = sq[nt][k];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (r == 0) {
+                    const int cl = nt * 32 + 8 * (k >> 2) + 4 * hh + (k & 3);
+                    atomicAdd(&red[cl], a);
+                    atomicAdd(&red[NT * 32 + cl], b);
+                }
+            }
+        __syncthreads();
+        for (int i2 = tid; i2 < NT * 32; i2 += PWB) {
+            const int co = n_base + i2;
+            if (co < N) { atomicAdd(&stats[co], (double)red[i2]); atomicAdd(&stats[N + co], (double)red[NT * 32 + i2]); }
+        }
+    }
 }
 
 /* x bf16 [M,K]; w fp32: [N,K] (transposed=0) or [K,N] (transposed=1: the input-gradient GEMM dx = dy * W);
  * y [M,N] bf16 or fp32. */
+static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
+                       int out_dtype, double* stats, int stat_pre, tcct_stream_t stream);
 extern "C" int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                            int out_dtype, tcct_stream_t stream) {
+    return pw_fwd_impl(x, w, bias, y, M, K, N, transposed, out_dtype, nullptr, 0, stream);
+}
+/* forward + fused BatchNorm statistics of the consumer (bf16 output, N <= 96): stats fp64 [2N], zero on entry */
+extern "C" int tcct_pw_fwd_bnstats(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
+                                   int pre_act, tcct_stream_t stream) {
+    TCCT_CHECK(N % 32 == 0 && N <= 96, "pw_fwd_bnstats: N=%d unsupported (32, 64, 96)", N);
+    return pw_fwd_impl(x, w, bias, y, M, K, N, 0, TCCT_BF16, stats, pre_act, stream);
+}
+static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
+                       int out_dtype, double* stats, int stat_pre, tcct_stream_t stream) {
     TCCT_CHECK(K % 32 == 0 && K >= 32 && K <= 512, "pw_fwd: K=%d must be a multiple of 32 (<=512)", K);
     TCCT_CHECK(N >= 1 && N <= 1024, "pw_fwd: N=%d", N);
     const int ntiles = (N + 31) / 32;
@@ -111,15 +164,21 @@ extern "C" int tcct_pw_fwd(const void* x, const float* w, const float* bias, voi
 #define PW_L(NTV, TO)                                                                                                        \
     do {                                                                                                                     \
         static bool attr = false;                                                                                            \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k_pw_fwd<NTV, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-        hipLaunchKernelGGL((k_pw_fwd<NTV, TO>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (TO*)y, M, K, N, transposed); \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_pw_fwd<NTV, TO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((k_pw_fwd<NTV, TO, false>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (TO*)y, M, K, N, transposed, nullptr, 0); \
     } while (0)
 #define PW_D(TO)                                                                  \
     switch (NT) {                                                                 \
         case 1: PW_L(1, TO); break; case 2: PW_L(2, TO); break; case 3: PW_L(3, TO); break; \
         case 4: PW_L(4, TO); break; default: PW_L(5, TO); break;                  \
     }
-    if (out_dtype == TCCT_BF16) { PW_D(bf16); }
+    if (stats) {
+#define PW_S(NTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd<NTV, bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_fwd<NTV, bf16, true>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (bf16*)y, M, K, N, transposed, stats, stat_pre); }
+        if (NT == 1) PW_S(1) else if (NT == 2) PW_S(2) else PW_S(3)
+#undef PW_S
+    }
+    else if (out_dtype == TCCT_BF16) { PW_D(bf16); }
     else if (out_dtype == TCCT_F32) { PW_D(float); }
     else { tcct_set_error("pw_fwd: bad out dtype"); return -1; }
 #undef PW_D

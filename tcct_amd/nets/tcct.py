@@ -81,7 +81,7 @@ class CrossResNet(nn.Module):
     def forward(self, x):
         """x: NHWC [B,H,W,4] (3 image channels + zero pad)."""
         xs = []
-        x = _bn(self.cnn[1], ops.conv3x3_c3(x, self.cnn[0].weight, self.cnn[0].bias, 1))
+        x = _bn(self.cnn[1], ops.conv3x3_c3(x, self.cnn[0].weight, self.cnn[0].bias, 1, stats_pre='none' if self.training else None))
         n = len(self.path_estan)
         for i, enc in enumerate(self.path_estan):
             x = enc(x)
@@ -104,10 +104,11 @@ class Conv2d_BN(nn.Module):
         self.act = act
 
     def forward(self, x):
+        sp = 'none' if self.training else None
         if self.conv.in_channels == 3:          # stem[0]: 3-channel input -> im2col + pointwise MFMA
-            y = ops.conv3x3_c3(x, self.conv.weight, None, self.conv.stride[0])
+            y = ops.conv3x3_c3(x, self.conv.weight, None, self.conv.stride[0], stats_pre=sp)
         else:
-            y = _conv(self.conv, x)
+            y = _conv(self.conv, x, stats_pre=sp)
         return _bn(self.bn, y, post='hswish' if self.act else None)
 
 
@@ -124,7 +125,7 @@ class DWConv2d_BN(nn.Module):
             m.weight.data.normal_(0, math.sqrt(2.0 / n))
 
     def forward(self, x):
-        return _bn(self.bn, _conv(self.pwconv, _dw(self.dwconv, x)), post='hswish')
+        return _bn(self.bn, _conv(self.pwconv, _dw(self.dwconv, x), stats_pre='none' if self.training else None), post='hswish')
 
 
 class DWCPatchEmbed(nn.Module):
@@ -390,7 +391,8 @@ class FTC(nn.Module):
         f = [c1]
         for j, (v, c) in enumerate(((v2, c2), (v3, c3), (v4, c4), (v5, c5))):
             tv, tc = getattr(self, f'tran_vit{j}'), getattr(self, f'tran_cnn{j}')
-            f.append(ops.add(_bn(tv[1], _conv(tv[0], v)), _bn(tc[1], _conv(tc[0], c))))
+            sp = 'none' if self.training else None
+            f.append(ops.add(_bn(tv[1], _conv(tv[0], v, stats_pre=sp)), _bn(tc[1], _conv(tc[0], c, stats_pre=sp))))
         y8 = _bn(self.head[1], _conv(self.head[0], f[4], stats_pre='none' if self.training else None), post='lrelu')
         d3 = self.dec1(y8, f[3])
         d2 = self.dec2(d3, f[2])

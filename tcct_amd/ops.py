@@ -147,7 +147,12 @@ class _Conv2d(torch.autograd.Function):
         y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=odt)
         mfma = _mfma32_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw)
         if _pw_ok(x.dtype, Cin, Cin_w, KH, KW, stride, padh, padw) and not mfma:
-            lib.pw_fwd(x, w, bias, y, N * H * W, Cin, Cout, 0, dtype_code(odt))
+            if stats_box is not None and odt == torch.bfloat16 and Cout in (32, 64, 96):
+                sums = ZERO.get((2 * Cout,), torch.float64, x.device) if ZERO.active else torch.zeros(2 * Cout, device=x.device, dtype=torch.float64)
+                lib.pw_fwd_bnstats(x, w, bias, y, N * H * W, Cin, Cout, sums, stats_box[0])
+                stats_box[1] = sums
+            else:
+                lib.pw_fwd(x, w, bias, y, N * H * W, Cin, Cout, 0, dtype_code(odt))
         elif _mfma_slabs_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
             _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, False)
         elif mfma:
@@ -250,11 +255,11 @@ def im2col3x3_c3(x4, stride=1):
     return out
 
 
-def conv3x3_c3(x4, w, bias, stride=1):
+def conv3x3_c3(x4, w, bias, stride=1, stats_pre=None):
     """3-channel 3x3 conv (pad 1) as im2col + 32->32 pointwise GEMM: w [32,3,3,3] is re-laid out to [32, 27->32] by view ops
     (differentiable plumbing on 864 elements), so forward and weight gradient both run on the MFMA pointwise kernels"""
     w2 = torch.nn.functional.pad(w.permute(0, 2, 3, 1).reshape(w.shape[0], 27), (0, 5)).contiguous()
-    return conv2d(im2col3x3_c3(x4, stride), w2.view(w.shape[0], 32, 1, 1), bias)
+    return conv2d(im2col3x3_c3(x4, stride), w2.view(w.shape[0], 32, 1, 1), bias, stats_pre=stats_pre)
 
 
 class _DwConv(torch.autograd.Function):
