@@ -240,3 +240,50 @@ def test_train_step_pool_and_slots_match_plain(tmp_path):
     # the in-place path really is in place: gradients alias their slots
     named = [p for p in model.parameters() if getattr(p, '_grad_slot', None) is not None]
     assert len(named) > 250 and all(p.grad is not None and p.grad.data_ptr() == p._grad_slot.data_ptr() for p in named)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_eval_mode_predict_matches_oracle(dtype, tmp_path):
+    """KiteSeg.predict / val path (reference kite/loop_seg.py:21-33,66-106): eval-mode BatchNorm (running statistics), no DropPath;
+    logits vs the oracle's eval forward, masks and Dice/IoU metrics vs the oracle's metric restatement"""
+    import tcct_oracle as O
+    from tcct_amd.kite.losses import MDiceLoss, MIouLoss
+    model, sd = build(dtype)
+    k = make_kite(model, tmp_path, False, False)
+    k.model.eval()
+    img, lab = O.synth_batch(2, 64, 96, seed=9)
+    with torch.no_grad():
+        outs_o, _ = O.ftc_forward({kk: v.clone() for kk, v in sd.items()}, img, train=False)
+        outs = k.model(img.cuda())
+    e = relerr(outs[0], outs_o[0])
+    print('eval logits rel err', dtype, e)
+    assert e < (1e-3 if dtype == torch.float32 else 0.25)
+    mask = k.predict(img.cuda())
+    dense = mask.dense().cpu()
+    assert dense.shape == (2, 5, 64, 96) and torch.all(dense.sum(1) == 1)
+    oh = torch.nn.functional.one_hot(lab, 5).permute(0, 3, 1, 2)
+    if dtype == torch.float32:
+        ref_mask = O.predict_mask(outs_o[0])
+        agree = (dense.argmax(1) == ref_mask.argmax(1)).float().mean().item()
+        assert agree > 0.999, agree                      # argmax ties / 1e-4 logit noise may flip isolated pixels
+    f1 = MDiceLoss.scorem(mask, lab.cuda(), start_idx=1).item()
+    io = MIouLoss.scorem(mask, lab.cuda(), start_idx=1).item()
+    assert abs(f1 - O.dice_scorem(dense, oh, 1).item()) < 1e-5 and abs(io - O.iou_scorem(dense, oh, 1).item()) < 1e-5
+    # running statistics are NOT touched in eval mode
+    assert model.base.base_cnn.cnn[1].num_batches_tracked.item() == 0
+
+
+def test_val_loop_runs(tmp_path):
+    """KiteSeg.val over the synthetic validation set returns the reference's {'val_iou','val_f1s'} dict"""
+    import argparse
+    from tcct_amd.nets import stc_tt, RegNet
+    from tcct_amd.kite import KiteSeg
+    from tcct_amd.data import SynthOCT
+    ds = SynthOCT(height=64, width=100, device='cuda', n_val=2)
+    model = RegNet(stc_tt(5), con='cos', out_channels=5)
+    args = argparse.Namespace(los='di', lr=1e-2, gpu='0', pl=False, bs=2, coff_ds=1, udh=False, reg=False, epl=False, coff_udh=1,
+                              coff_reg=.1, coff_epl=.1, bug=True)
+    k = KiteSeg(model=model, dataset=ds, root=str(tmp_path), args=args)
+    logs = k.val(epoch=0)
+    assert set(logs) == {'val_iou', 'val_f1s'} and 0.0 <= logs['val_f1s'] <= 1.0 and 0.0 <= logs['val_iou'] <= 1.0
+    assert torch.is_grad_enabled()
