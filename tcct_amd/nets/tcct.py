@@ -362,7 +362,24 @@ class FTC(nn.Module):
         self.aux2 = nn.Conv2d(filters, out_channels, 1)
         self.aux4 = nn.Conv2d(filters, out_channels, 1)
         self.compute_dtype = compute_dtype
-        self.feats = None
+        self._feats_src = None
+        self._feats = None
+
+    @property
+    def feats(self):
+        if self._feats is None and self._feats_src is not None:
+            g0, g1, g2, size = self._feats_src
+            n0 = ops.l2norm(g0)
+            n1 = ops.bilinear(ops.l2norm(g1), size, False)
+            n2 = ops.bilinear(ops.l2norm(g2), size, False)
+            self._feats = [_nchw_view(ops.add3_scale(n0, n1, n2, 1.0 / 3.0))]
+            self._feats_src = None
+        return self._feats
+
+    @feats.setter
+    def feats(self, v):
+        self._feats = v
+        self._feats_src = None
 
     def set_compute_dtype(self, dt):
         if dt not in (torch.float32, torch.bfloat16):
@@ -402,11 +419,10 @@ class FTC(nn.Module):
         g1 = _conv(self.t323, ops.add(f[1], d1))
         g2 = _conv(self.t322, ops.add(f[2], d2))
         g3 = _conv(self.t321, ops.add(f[3], d3))
-        # norm_add([y0,y1,y2]) (reference tcct.py:937-942,1035)
-        n0 = ops.l2norm(g0)
-        n1 = ops.bilinear(ops.l2norm(g1), size, False)
-        n2 = ops.bilinear(ops.l2norm(g2), size, False)
-        self.feats = [_nchw_view(ops.add3_scale(n0, n1, n2, 1.0 / 3.0))]
+        # norm_add([y0,y1,y2]) (reference tcct.py:937-942,1035) -> `self.feats`: evaluated lazily on first access (only the
+        # feature-polarization loss reads it; with --udh=false the six level-0 passes are simply never launched)
+        self._feats_src = (g0, g1, g2, size)
+        self._feats = None
         # aux heads: logits are produced and resized in fp32 in every mode (loss-side precision)
         f32 = torch.float32
         y0 = _conv(self.aux0, g0, out_dtype=f32)
