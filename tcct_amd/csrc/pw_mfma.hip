@@ -451,6 +451,85 @@ __global__ void k_pw_wgrad_smalln(const Tx* __restrict__ x, const Td* __restrict
             if (n < N) atomicAdd(&dbias[n], bs[n]);
     }
 }
+// MFMA form for the hot case (bf16 x with K = 32, fp32 dy, N <= 8: the aux heads): dy rows are converted to bf16 and padded to 32
+// channels in LDS (chunks 1..3 of every row are written once: they stay zero), then the 32x32 transposing-read MFMA of
+// k_pw_wgrad does the pixel contraction; only rows < N of the accumulator are written back.  HBM-bound streaming of x.
+__global__ void __launch_bounds__(PWB, 2)
+k_pw_wgrad_smalln_mfma(const bf16* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
+                       int64_t M, int N) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PW_P * 64];
+    unsigned char* sX = smem;
+    unsigned char* sD = smem + PW_P * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    for (int i = tid; i < PW_P * 4; i += PWB) *reinterpret_cast<uint4*>(sD + i * 16) = make_uint4(0, 0, 0, 0);
+    f32x16 acc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    float bsum = 0.f;
+    uint4 px[2];
+    float pdv[8];
+    const int dp = tid;                                   // dy pixel handled by this thread (tid < PW_P)
+    auto prefetch = [&](int64_t tile) {
+        const int64_t m0 = tile * PW_P;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + j * PWB, p = i >> 2, c = i & 3;
+            px[j] = make_uint4(0, 0, 0, 0);
+            if (m0 + p < M) px[j] = *reinterpret_cast<const uint4*>(x + (m0 + p) * 32 + c * 8);
+        }
+#pragma unroll
+        for (int n = 0; n < 8; ++n) pdv[n] = (dp < PW_P && n < N && m0 + dp < M) ? dy[(m0 + dp) * N + n] : 0.f;
+    };
+    const int li = lane & 15, lq = li >> 2, lpp = li & 3, lg = lane >> 4;
+    const int loff = (8 * (lg >> 1) + lq) * 64 + (16 * (lg & 1) + 4 * lpp) * 2;
+    auto tr2 = [&](const unsigned char* p) {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 256));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    const int64_t tiles = (M + PW_P - 1) / PW_P;
+    int64_t tile = blockIdx.x;
+    if (tile < tiles) prefetch(tile);
+    for (; tile < tiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int i = tid + j * PWB; *reinterpret_cast<uint4*>(sX + (i >> 2) * 64 + (i & 3) * 16) = px[j]; }
+        if (dp < PW_P) {
+            uint4 o;
+            o.x = pack_bf16x2(pdv[0], pdv[1]); o.y = pack_bf16x2(pdv[2], pdv[3]); o.z = pack_bf16x2(pdv[4], pdv[5]); o.w = pack_bf16x2(pdv[6], pdv[7]);
+            *reinterpret_cast<uint4*>(sD + dp * 64) = o;
+        }
+        __syncthreads();
+        if (tile + gridDim.x < tiles) prefetch(tile + gridDim.x);
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int ch = wave + 4 * c2;
+            const bf16x8 a = tr2(sD + loff + ch * 1024);
+            const bf16x8 b = tr2(sX + loff + ch * 1024);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum += (float)a[j];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);          // [8][32]
+    if (tid < 256) red[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
+        if (co < 8) atomicAdd(&red[co * 32 + r], acc[k]);
+    }
+    __syncthreads();
+    if (tid < N * 32) atomicAdd(&dw[tid], red[tid]);
+    if (dbias) {
+        float s = bsum + __shfl_xor(bsum, 32, 64);
+        if (lane < N) atomicAdd(&dbias[lane], s);
+    }
+}
+
 /* x [M,K] (K % 4 == 0, K <= 256), dy [M,N] fp32 or bf16 (N <= 8) -> dw fp32 [N,K], dbias [N] (nullable); overwritten */
 extern "C" int tcct_pw_wgrad_smalln(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, int x_dtype,
                                     int dy_dtype, tcct_stream_t stream) {
@@ -458,6 +537,12 @@ extern "C" int tcct_pw_wgrad_smalln(const void* x, const void* dy, float* dw, fl
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * N * K, st) != hipSuccess) { tcct_set_error("pw_wgrad_smalln: memset failed"); return -2; }
     if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * N, st) != hipSuccess) { tcct_set_error("pw_wgrad_smalln: memset failed"); return -2; }
+    if (K == 32 && x_dtype == TCCT_BF16 && dy_dtype == TCCT_F32) {
+        const int64_t tiles = (M + PW_P - 1) / PW_P;
+        hipLaunchKernelGGL(k_pw_wgrad_smalln_mfma, dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(PWB), 0, st, (const bf16*)x, (const float*)dy, dw,
+                           dbias, M, N);
+        TCCT_LAUNCH_OK();
+    }
     int R = PWB / (K / 4);
     size_t lds = sizeof(float) * (size_t)R * N * K;
     int grid = tcct_grid(M, R, 1024);

@@ -371,3 +371,24 @@ def test_reg_loss_matches_oracle():
     for n in pn:
         torch.testing.assert_close(named[n].grad.cpu(), sd[n].grad, rtol=2e-3, atol=1e-6)   # lap_map.0.bias feeds a BN: true grad 0
     torch.testing.assert_close(m.lap_map[1].running_var.cpu(), sd['lap_map.1.running_var'], rtol=1e-5, atol=1e-7)
+
+
+def test_aux_head_conv_bf16_in_f32_out():
+    """5-class aux head exactly as the model runs it in bf16 mode: bf16 activations, fp32 logits and fp32 dy (MFMA small-N wgrad)"""
+    from tcct_amd import ops
+    N, H, W = 2, 37, 53
+    x = rnd(N, 32, H, W, dt=torch.bfloat16).requires_grad_(True)
+    w = (rnd(5, 32, 1, 1, seed=1) / 32 ** 0.5).requires_grad_(True)
+    b = rnd(5, seed=2).requires_grad_(True)
+    y = F.conv2d(x, w, b)
+    gy = rnd(*y.shape, seed=3) * 1e-3
+    y.backward(gy)
+    xd = nhwc(x.detach(), torch.bfloat16).requires_grad_(True)
+    wd, bd = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    yd = ops.conv2d(xd, wd, bd, out_dtype=torch.float32)
+    assert yd.dtype == torch.float32
+    torch.testing.assert_close(nchw(yd), y.detach(), rtol=2e-2, atol=2e-2)
+    yd.backward(nhwc(gy, torch.float32))
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=2e-2, atol=2e-2 * w.grad.abs().max().item())
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=2e-2, atol=2e-2 * b.grad.abs().max().item())
+    torch.testing.assert_close(nchw(xd.grad), x.grad, rtol=3e-2, atol=3e-2 * x.grad.abs().max().item())
