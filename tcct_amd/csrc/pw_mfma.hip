@@ -35,6 +35,7 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
          int64_t M, int K, int N, int transposed, double* __restrict__ stats, int stat_pre) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int SW = 2 * K + 16;                 // LDS row stride (bytes)
+    const int scr_off = (NT * 32 * SW + 15) & ~15;   // per-wave epilogue transpose scratch (4 x 2560 B) behind the weights
     const int n_base = blockIdx.y * NT * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -80,7 +81,39 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[nt], 0, 0, 0);
             }
         }
-        if (ok) {
+        // epilogue.  bf16 output with N % 32 == 0: each 32x32 tile goes through a per-wave LDS transpose (80-byte pixel rows) so that
+        // every lane stores 16 contiguous bytes and a wave instruction covers 16 whole 64-byte pixel segments; the direct form
+        // (four 8-byte stores per lane, 16 B of every 64-B line per instruction) held store-heavy shapes at 2.7 TB/s.
+        constexpr bool kBf16 = sizeof(Tout) == 2;
+        if (kBf16 && (N & 31) == 0) {
+            unsigned char* sc = smem + scr_off + wave * 2560;          // 32 pixels x 80 B
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = n_base + nt * 32 + 8 * q + 4 * hh;
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = acc[nt][4 * q + k] + (bias ? bias[co + k] : 0.f);
+                    uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+                    if (STATS && ok) {
+                        float u0 = act_fwd(stat_pre, __uint_as_float(o.x << 16)), u1 = act_fwd(stat_pre, __uint_as_float(o.x & 0xffff0000u));
+                        float u2 = act_fwd(stat_pre, __uint_as_float(o.y << 16)), u3 = act_fwd(stat_pre, __uint_as_float(o.y & 0xffff0000u));
+                        ss[nt][4 * q] += u0; sq[nt][4 * q] += u0 * u0; ss[nt][4 * q + 1] += u1; sq[nt][4 * q + 1] += u1 * u1;
+                        ss[nt][4 * q + 2] += u2; sq[nt][4 * q + 2] += u2 * u2; ss[nt][4 * q + 3] += u3; sq[nt][4 * q + 3] += u3 * u3;
+                    }
+                    *reinterpret_cast<uint2*>(sc + r * 80 + (8 * q + 4 * hh) * 2) = o;
+                }
+                // same wave wrote and reads: LDS operations of one wave complete in order
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int p = (lane >> 2) + 16 * h2, cch = lane & 3;
+                    const uint4 o = *reinterpret_cast<const uint4*>(sc + p * 80 + cch * 16);
+                    const int64_t mm = mt * 32 + p;
+                    if (mm < M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(y) + mm * N + n_base + nt * 32 + cch * 8) = o;
+                }
+            }
+        } else if (ok) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -154,7 +187,7 @@ static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y
     // tiles per block: largest NT <= 5 dividing the work evenly enough and fitting 2 blocks/CU when possible
     int NT = ntiles <= 5 ? ntiles : (ntiles % 5 == 0 ? 5 : (ntiles % 4 == 0 ? 4 : (ntiles % 3 == 0 ? 3 : (ntiles % 2 == 0 ? 2 : 1))));
     const int gy = (ntiles + NT - 1) / NT;
-    size_t lds = (size_t)NT * 32 * (2 * K + 16);
+    size_t lds = (((size_t)NT * 32 * (2 * K + 16) + 15) & ~(size_t)15) + 4 * 2560;
     TCCT_CHECK(lds <= 160 * 1024, "pw_fwd: weights need %zu B of LDS", lds);
     const int64_t mtiles = (M + 31) / 32;
     int64_t gx = (mtiles + 3) / 4;
