@@ -79,6 +79,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
     // bias lives in LDS (behind the input image) and is re-read in the epilogue: 16 fewer live VGPRs in the MFMA loop
     float* sB = reinterpret_cast<float*>(sX + LH * LW * IPS);
     if (tid < 32) sB[tid] = bias ? bias[tid] : 0.f;
+    unsigned char* sS = reinterpret_cast<unsigned char*>(sB + 32);          // epilogue transpose scratch: 4 waves x 1 KB
 
     // slot geometry (tile independent): slot j covers 16-byte chunk c of tile-local pixel (lr, lc); (lr,lc) packed in one int
     const int c = tid & 3;
@@ -121,9 +122,9 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         int pb = VERT ? a * LH + seg * 32 + r : a * LW + seg * 32 + r;
         xB[t] = sX + pb * IPS + hh * 16;
     }
-    float ss[STATS ? 16 : 1], sq[STATS ? 16 : 1];
+    float ss[STATS ? 8 : 1], sq[STATS ? 8 : 1];        // after the transpose a lane owns channels 8*(lane&3)..+7
 #pragma unroll
-    for (int k = 0; k < (STATS ? 16 : 1); ++k) ss[k] = sq[k] = 0.f;
+    for (int k = 0; k < (STATS ? 8 : 1); ++k) ss[k] = sq[k] = 0.f;
     int tile = blockIdx.x;
     if (tile < ntiles) prefetch(tile);
     for (; tile < ntiles; tile += gridDim.x) {
@@ -187,50 +188,72 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
             for (int dy = 0; dy < KH; ++dy)
                 for (int dx = 0; dx < KW; ++dx) { load_tap(f, dy, dx); mma_tap(f); }
         }
-        // epilogue: lane owns pixel r of each M-tile and channels co = 8q + 4*hh + k
+        // epilogue: lane owns pixel r of each M-tile and channels co = 8q + 4*hh + k.  The packed bf16 values go through a per-wave
+        // LDS transpose (16 pixels x 64 B per round, chunks XOR-swizzled) so that every lane stores 16 contiguous bytes and one
+        // wave instruction writes 16 whole pixels (1 KB contiguous for HORZ tiles) -- four 8-byte stores per lane, i.e. 16 B of
+        // every 64-B line per instruction, were the throughput limit of the store-heavy kernels.
+        unsigned char* sc = sS + wave * 1024;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             int mt = wave * 4 + t;
             int a = mt >> 1, seg = mt & 1;
-            int ho = VERT ? h0 + seg * 32 + r : h0 + a;
-            int wo = VERT ? w0 + a : w0 + seg * 32 + r;
-            if (ho < H && wo < W) {
-                bf16* yp = y + (((int64_t)n * H + ho) * W + wo) * ys + yo + 4 * hh;
+            uint2 o[4];
+            {
+                int ho = VERT ? h0 + seg * 32 + r : h0 + a;
+                int wo = VERT ? w0 + a : w0 + seg * 32 + r;
+                const bool inb = ho < H && wo < W;
+                const bf16* yold = y + (((int64_t)n * H + (inb ? ho : 0)) * W + (inb ? wo : 0)) * ys + yo + 4 * hh;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 bq = *reinterpret_cast<const float4*>(sB + 8 * q + 4 * hh);
                     float v0 = acc[t][4 * q] + bq.x, v1 = acc[t][4 * q + 1] + bq.y;
                     float v2 = acc[t][4 * q + 2] + bq.z, v3 = acc[t][4 * q + 3] + bq.w;
-                    if (accum) { f4 old = ld4(yp + 8 * q); v0 += old.v[0]; v1 += old.v[1]; v2 += old.v[2]; v3 += old.v[3]; }
-                    uint2 o;
-                    o.x = pack_bf16x2(v0, v1);
-                    o.y = pack_bf16x2(v2, v3);
-                    *reinterpret_cast<uint2*>(yp + 8 * q) = o;
+                    if (accum) { f4 old = ld4(yold + 8 * q); v0 += old.v[0]; v1 += old.v[1]; v2 += old.v[2]; v3 += old.v[3]; }
+                    o[q].x = pack_bf16x2(v0, v1);
+                    o[q].y = pack_bf16x2(v2, v3);
+                }
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                if ((r >> 4) == h2) {
+                    const int rr = r & 15, f = (rr >> 1) & 3;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(sc + rr * 64 + ((q ^ f) << 4) + hh * 8) = o[q];
+                }
+                // one wave writes and reads its own scratch: LDS operations of a wave complete in order
+                const int p16 = lane >> 2, cch = lane & 3;
+                const uint4 ov = *reinterpret_cast<const uint4*>(sc + p16 * 64 + ((cch ^ ((p16 >> 1) & 3)) << 4));
+                const int pr = 16 * h2 + p16;                                   // pixel index inside the M-tile
+                const int ho = VERT ? h0 + seg * 32 + pr : h0 + a;
+                const int wo = VERT ? w0 + a : w0 + seg * 32 + pr;
+                if (ho < H && wo < W) {
+                    *reinterpret_cast<uint4*>(y + (((int64_t)n * H + ho) * W + wo) * ys + yo + cch * 8) = ov;
                     if (STATS) {
-                        float u0 = act_fwd(stat_pre, __uint_as_float(o.x << 16)), u1 = act_fwd(stat_pre, __uint_as_float(o.x & 0xffff0000u));
-                        float u2 = act_fwd(stat_pre, __uint_as_float(o.y << 16)), u3 = act_fwd(stat_pre, __uint_as_float(o.y & 0xffff0000u));
-                        ss[4 * q] += u0; sq[4 * q] += u0 * u0; ss[4 * q + 1] += u1; sq[4 * q + 1] += u1 * u1;
-                        ss[4 * q + 2] += u2; sq[4 * q + 2] += u2 * u2; ss[4 * q + 3] += u3; sq[4 * q + 3] += u3 * u3;
+                        const uint32_t wv[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float u0 = act_fwd(stat_pre, __uint_as_float(wv[k] << 16)), u1 = act_fwd(stat_pre, __uint_as_float(wv[k] & 0xffff0000u));
+                            ss[2 * k] += u0; sq[2 * k] += u0 * u0; ss[2 * k + 1] += u1; sq[2 * k + 1] += u1 * u1;
+                        }
                     }
                 }
             }
         }
     }
     if (STATS) {
-        // lanes r = 0..31 of each half hold different pixels of the same 16 channels: butterfly over r, then LDS, then fp64 atomics
+        // lanes with equal (lane & 3) hold different pixels of the same 8 channels: butterfly over lane bits 2..5, LDS, fp64 atomics
         __syncthreads();
         float* red = reinterpret_cast<float*>(sX);
         if (tid < 64) red[tid] = 0.f;
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < 8; ++k) {
             float a = ss[k], b = sq[k];
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-            if (r == 0) {
-                const int co = 8 * (k >> 2) + 4 * hh + (k & 3);
-                atomicAdd(&red[co], a);
-                atomicAdd(&red[32 + co], b);
+            for (int o = 32; o > 2; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            if (lane < 4) {
+                atomicAdd(&red[8 * lane + k], a);
+                atomicAdd(&red[32 + 8 * lane + k], b);
             }
         }
         __syncthreads();
@@ -267,7 +290,7 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
     const bool vert = (KW == 1 && KH > 1);
     const int TH = vert ? 64 : 8, TW = vert ? 8 : 64;
     const int LH = TH + KH - 1, LW = TW + KW - 1;
-    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * IPS + 128;
+    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * IPS + 128 + 4096;
     TCCT_CHECK(lds <= 80 * 1024, "conv32_fwd: %dx%d needs %zu B of LDS (> 80 KiB for 2 blocks/CU)", KH, KW, lds);
     TCCT_CHECK(LH * LW * 4 <= MAXL * MB, "conv32_fwd: %dx%d tile image exceeds the staging slots", KH, KW);
     int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
