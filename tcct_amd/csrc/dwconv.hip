@@ -1,5 +1,13 @@
 // Depthwise 3x3 convolution (pad 1, stride 1 or 2) on NHWC, HBM-bound VALU stencil.  VEC=4 channels per lane when
 // C % 4 == 0, scalar otherwise (the 1-channel lap_map convs of the boundary-regression loss).
+//
+// All kernels march DOWN the image: a thread owns (output column, channel vector) and a strip of output rows, keeps the
+// 3x3 input window in registers (three row buffers rotated by unrolling, a fourth one prefetching the next row) and the nine
+// taps of its channels in registers.  Lanes of a wave cover consecutive channel vectors of consecutive pixels, so every
+// load/store instruction touches one contiguous run of a row; the left/right neighbours a lane needs are the centre loads
+// of the adjacent lanes (L1 hits).  Every input row is fetched from HBM once per strip (+2 halo rows per strip); the first
+// version slid along W instead, one output row per thread, and fetched every input row three times from three different
+// XCDs (1.4-1.8 TB/s effective).
 #include "common.h"
 
 #define DB 256
@@ -15,144 +23,212 @@ __device__ __forceinline__ void stv(T* p, const float* o) {
     else stf(p, o[0]);
 }
 
-// Sliding-window form: thread = (channel vector, strip of SEG output pixels along W); the 3x3 window of input columns and
-// the 9 per-channel taps stay in registers, so each output costs `stride` new column loads (3 rows) instead of 9 loads.
-// FLIP=1 uses w[2-ky][2-kx]: with stride 1 that is exactly the input-gradient convolution.
-#define DW_SEG 16
-template <typename T, int VEC, int STRIDE, bool FLIP>
-__global__ void k_dw_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                         T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, int add_input) {
-    const int CV = C / VEC;
-    const int segs = (Wo + DW_SEG - 1) / DW_SEG;
-    const int64_t total = (int64_t)N * Ho * segs * CV;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % CV) * VEC;
-        int64_t q = i / CV;
-        const int sg = (int)(q % segs);
-        q /= segs;
-        const int ho = (int)(q % Ho);
-        const int64_t n = q / Ho;
-        float wk[9][VEC], bv[VEC];
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            bv[k] = bias ? bias[c + k] : 0.f;
-#pragma unroll
-            for (int tp = 0; tp < 9; ++tp) wk[tp][k] = w[(c + k) * 9 + (FLIP ? 8 - tp : tp)];
-        }
-        const int wo0 = sg * DW_SEG, wo1 = min(Wo, wo0 + DW_SEG);
-        const int hi0 = ho * STRIDE - 1;
-        const T* rows[3];
-        bool rok[3];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            int hi = hi0 + ky;
-            rok[ky] = hi >= 0 && hi < H;
-            rows[ky] = x + ((n * H + (rok[ky] ? hi : 0)) * (int64_t)W) * C + c;
-        }
-        float col[3][3][VEC];      // [kx][ky]
-        auto load_col = [&](int kxslot, int wi) {
-            bool cok = wi >= 0 && wi < W;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                if (cok && rok[ky]) ldv<T, VEC>(rows[ky] + (int64_t)wi * C, col[kxslot][ky]);
-                else {
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) col[kxslot][ky][k] = 0.f;
-                }
-            }
-        };
-        int wi = wo0 * STRIDE - 1;
-        load_col(0, wi); load_col(1, wi + 1);
-        for (int wo = wo0; wo < wo1; ++wo) {
-            load_col(2, wo * STRIDE + 1);
-            float acc[VEC];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                float a = bv[k];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) a += col[kx][ky][k] * wk[ky * 3 + kx][k];
-                if (add_input) a += col[1][1][k];
-                acc[k] = a;
-            }
-            stv<T, VEC>(y + ((n * Ho + ho) * (int64_t)Wo + wo) * C + c, acc);
-            if (STRIDE == 1) {
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) { col[0][ky][k] = col[1][ky][k]; col[1][ky][k] = col[2][ky][k]; }
-            } else {
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) col[0][ky][k] = col[2][ky][k];
-                load_col(1, (wo + 1) * STRIDE);
-            }
-        }
+// block -> (image n, row strip hs, column block wb); thread -> (column offset, channel vector).  false: thread has no work.
+struct DwPos { int n, ho0, ho1, wo, c; };
+__device__ __forceinline__ bool dw_pos(int C, int VEC, int Ho, int Wo, int segh, int wblocks, int hstrips, DwPos& p) {
+    const int CV = C / VEC, PW = DB / CV, t = threadIdx.x;
+    if (t >= PW * CV) return false;
+    int bid = blockIdx.x;
+    const int wb = bid % wblocks; bid /= wblocks;
+    const int hs = bid % hstrips;
+    p.n = bid / hstrips;
+    p.wo = wb * PW + t / CV;
+    p.c = (t % CV) * VEC;
+    p.ho0 = hs * segh;
+    p.ho1 = min(Ho, p.ho0 + segh);
+    return p.wo < Wo && p.ho0 < p.ho1;
+}
+
+// raw (as loaded) channel vector: kept packed in registers and unpacked at use, so that a chunk of rows fits in few VGPRs
+template <typename T, int VEC> struct Raw;
+template <> struct Raw<bf16, 4> {
+    uint2 v;
+    __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const uint2*>(p); }
+    __device__ __forceinline__ void zero() { v.x = 0u; v.y = 0u; }
+    __device__ __forceinline__ float get(int k) const {
+        const uint32_t w = k < 2 ? v.x : v.y;
+        return (k & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
     }
+};
+template <> struct Raw<float, 4> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ float get(int k) const { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+};
+template <typename T> struct Raw<T, 1> {
+    float v;
+    __device__ __forceinline__ void load(const T* p) { v = ldf(p); }
+    __device__ __forceinline__ void zero() { v = 0.f; }
+    __device__ __forceinline__ float get(int) const { return v; }
+};
+
+// one input row: the three columns wi0, wi0+1, wi0+2 of input row hi (zeros outside the image)
+template <typename T, int VEC>
+__device__ __forceinline__ void dw_load_row(Raw<T, VEC> (&r)[3], const T* __restrict__ img, int hi, int H, int W, int C, int wi0) {
+    const bool rok = hi >= 0 && hi < H;
+    const T* row = img + (int64_t)(rok ? hi : 0) * W * C;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int wi = wi0 + kx;
+        if (rok && wi >= 0 && wi < W) r[kx].load(row + (int64_t)wi * C);
+        else r[kx].zero();
+    }
+}
+
+// Chunked marching window: a chunk produces RB output rows from CARRY rows kept from the previous chunk + NEW = RB*STRIDE
+// freshly loaded rows; the NEW rows of the *next* chunk are requested before the current chunk is computed, so 3*NEW
+// independent loads per lane are in flight during the arithmetic (a one-row-ahead window left the kernel latency-bound).
+template <int STRIDE> struct DwChunk {
+    static constexpr int RB = STRIDE == 1 ? 4 : 2;      // output rows per chunk
+    static constexpr int NEW = RB * STRIDE;             // input rows loaded per chunk
+    static constexpr int CARRY = 3 - STRIDE;            // input rows shared with the previous chunk
+    static constexpr int ROWS = CARRY + NEW;
+};
+
+template <typename T, int VEC, int STRIDE, bool FLIP>
+__global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                               T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, int add_input,
+                                               int segh, int wblocks, int hstrips) {
+    typedef DwChunk<STRIDE> K;
+    DwPos p;
+    if (!dw_pos(C, VEC, Ho, Wo, segh, wblocks, hstrips, p)) return;
+    float wk[9][VEC], bv[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        bv[k] = bias ? bias[p.c + k] : 0.f;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) wk[tp][k] = w[(p.c + k) * 9 + (FLIP ? 8 - tp : tp)];
+    }
+    const T* img = x + (int64_t)p.n * H * W * C + p.c;
+    T* out = y + (int64_t)p.n * Ho * Wo * C + p.c;
+    const int wi0 = p.wo * STRIDE - 1;
+    Raw<T, VEC> R[K::ROWS][3], NX[K::NEW][3];
+#pragma unroll
+    for (int i = 0; i < K::ROWS; ++i) dw_load_row<T, VEC>(R[i], img, p.ho0 * STRIDE - 1 + i, H, W, C, wi0);
+    for (int ho = p.ho0; ho < p.ho1; ho += K::RB) {
+        if (ho + K::RB < p.ho1) {
+#pragma unroll
+            for (int i = 0; i < K::NEW; ++i) dw_load_row<T, VEC>(NX[i], img, (ho + K::RB) * STRIDE - 1 + K::CARRY + i, H, W, C, wi0);
+        }
+#pragma unroll
+        for (int j = 0; j < K::RB; ++j) {
+            if (ho + j < p.ho1) {
+                float acc[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float a = bv[k];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) a += R[j * STRIDE + ky][kx].get(k) * wk[ky * 3 + kx][k];
+                    if (add_input) a += R[j * STRIDE + 1][1].get(k);
+                    acc[k] = a;
+                }
+                stv<T, VEC>(out + ((int64_t)(ho + j) * Wo + p.wo) * C, acc);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < K::CARRY; ++i)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) R[i][kx] = R[K::NEW + i][kx];
+#pragma unroll
+        for (int i = 0; i < K::NEW; ++i)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) R[K::CARRY + i][kx] = NX[i][kx];
+    }
+}
+
+// strip height: 32 output rows when that still leaves >= 1024 blocks, else 16, else 8 (the halo re-read is 2/segh)
+static void dw_geometry(int N, int Ho, int Wo, int C, int vec, int target_blocks, int max_segh, int& segh, int& wblocks, int& hstrips) {
+    const int PW = DB / (C / vec);
+    wblocks = (Wo + PW - 1) / PW;
+    segh = max_segh;
+    while (segh > 8 && (int64_t)N * wblocks * ((Ho + segh - 1) / segh) < target_blocks) segh >>= 1;
+    hstrips = (Ho + segh - 1) / segh;
 }
 
 template <typename T, int VEC, bool FLIP>
 static void dw_fwd_launch(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C, int stride,
                           int Ho, int Wo, int add_input, hipStream_t st) {
-    int segs = (Wo + DW_SEG - 1) / DW_SEG;
-    int64_t total = (int64_t)N * Ho * segs * (C / VEC);
-    dim3 g(tcct_grid(total, DB, 1 << 16)), b(DB);
-    if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input);
-    else hipLaunchKernelGGL((k_dw_fwd<T, VEC, 2, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input);
+    int segh, wblocks, hstrips;
+    dw_geometry(N, Ho, Wo, C, VEC, 1024, 32, segh, wblocks, hstrips);
+    dim3 g((unsigned)((int64_t)N * wblocks * hstrips)), b(DB);
+    if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips);
+    else hipLaunchKernelGGL((k_dw_fwd<T, VEC, 2, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips);
 }
 
 extern "C" int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
                                   int stride, int add_input, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(stride == 1 || stride == 2, "dwconv3x3_fwd: stride %d", stride);
     TCCT_CHECK(!(add_input && stride != 1), "dwconv3x3_fwd: add_input needs stride 1");
+    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1 && C >= 1, "dwconv3x3_fwd: empty tensor");
     int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     int vec = (C % 4 == 0) ? 4 : 1;
+    TCCT_CHECK(C / vec <= DB, "dwconv3x3_fwd: C=%d too large", C);
     hipStream_t st = (hipStream_t)stream;
     if (vec == 4) { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, false>(x, w, bias, y, N, H, W, C, stride, Ho, Wo, add_input, st))); }
     else { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 1, false>(x, w, bias, y, N, H, W, C, stride, Ho, Wo, add_input, st))); }
     TCCT_LAUNCH_OK();
 }
 
-// dx[hi,wi] = sum over taps (ky,kx) with (hi+1-ky) % stride == 0 ... of dy[(hi+1-ky)/stride, (wi+1-kx)/stride] * w[ky,kx]
+// stride-2 input gradient.  With hi = 2a + pa, wi = 2b + pb the transposed convolution splits by parity:
+//   dx[2a  ][2b  ] = dy[a][b] w11
+//   dx[2a  ][2b+1] = dy[a][b] w12 + dy[a][b+1] w10
+//   dx[2a+1][2b  ] = dy[a][b] w21 + dy[a+1][b] w01
+//   dx[2a+1][2b+1] = dy[a][b] w22 + dy[a][b+1] w20 + dy[a+1][b] w02 + dy[a+1][b+1] w00
+// A thread owns the 2x2 quad (a, b) of one channel vector and marches down a: two new dy loads per quad, four dx stores.
 template <typename T, int VEC>
-__global__ void k_dw_dgrad(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, int N, int H, int W,
-                           int C, int stride, int Ho, int Wo, int add_input) {
-    const int CV = C / VEC;
-    const int64_t total = (int64_t)N * H * W * CV;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int c = (int)(i % CV) * VEC;
-        int64_t p = i / CV;
-        int wi = (int)(p % W);
-        int64_t r = p / W;
-        int hi = (int)(r % H);
-        int64_t n = r / H;
-        float acc[VEC];
+__global__ void __launch_bounds__(DB) k_dw_dgrad_s2(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx,
+                                                    int N, int H, int W, int C, int Ho, int Wo, int segh, int wblocks, int hstrips) {
+    // quads cover a = 0 .. ceil(H/2)-1, b = 0 .. ceil(W/2)-1 (>= Ho, Wo when H or W is odd ... they are equal: Ho = ceil(H/2))
+    const int Qh = (H + 1) / 2, Qw = (W + 1) / 2;
+    DwPos p;
+    if (!dw_pos(C, VEC, Qh, Qw, segh, wblocks, hstrips, p)) return;
+    float wk[9][VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int k = 0; k < VEC; ++k)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            int th = hi + 1 - ky;
-            if (th < 0 || (th % stride) != 0) continue;
-            int ho = th / stride;
-            if (ho >= Ho) continue;
+        for (int tp = 0; tp < 9; ++tp) wk[tp][k] = w[(p.c + k) * 9 + tp];
+    const T* g = dy + (int64_t)p.n * Ho * Wo * C + p.c;
+    T* out = dx + (int64_t)p.n * H * W * C + p.c;
+    const int b = p.wo;
+    auto ld = [&](float (&d)[2][VEC], int a) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                int tw = wi + 1 - kx;
-                if (tw < 0 || (tw % stride) != 0) continue;
-                int wo = tw / stride;
-                if (wo >= Wo) continue;
-                float v[VEC];
-                ldv<T, VEC>(dy + ((n * Ho + ho) * (int64_t)Wo + wo) * C + c, v);
+        for (int j = 0; j < 2; ++j) {
+            if (a < Ho && b + j < Wo) ldv<T, VEC>(g + ((int64_t)a * Wo + b + j) * C, d[j]);
+            else {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    acc[k] += v[k] * w[(c + k) * 9 + ky * 3 + kx];
-                    if (add_input && ky == 1 && kx == 1) acc[k] += v[k];
-                }
+                for (int k = 0; k < VEC; ++k) d[j][k] = 0.f;
             }
         }
-        stv<T, VEC>(dx + p * C + c, acc);
+    };
+    auto emit = [&](const float (&u)[2][VEC], const float (&v)[2][VEC], int a) {      // u = dy[a][b..b+1], v = dy[a+1][b..b+1]
+        float o00[VEC], o01[VEC], o10[VEC], o11[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            o00[k] = u[0][k] * wk[4][k];
+            o01[k] = u[0][k] * wk[5][k] + u[1][k] * wk[3][k];
+            o10[k] = u[0][k] * wk[7][k] + v[0][k] * wk[1][k];
+            o11[k] = u[0][k] * wk[8][k] + u[1][k] * wk[6][k] + v[0][k] * wk[2][k] + v[1][k] * wk[0][k];
+        }
+        const int hi = 2 * a, wi = 2 * b;
+        T* o = out + ((int64_t)hi * W + wi) * C;
+        stv<T, VEC>(o, o00);
+        if (wi + 1 < W) stv<T, VEC>(o + C, o01);
+        if (hi + 1 < H) {
+            stv<T, VEC>(o + (int64_t)W * C, o10);
+            if (wi + 1 < W) stv<T, VEC>(o + (int64_t)W * C + C, o11);
+        }
+    };
+    float d0[2][VEC], d1[2][VEC];
+    ld(d0, p.ho0);
+    for (int a = p.ho0; a < p.ho1; a += 2) {
+        ld(d1, a + 1);
+        emit(d0, d1, a);
+        if (a + 1 >= p.ho1) break;
+        ld(d0, a + 2);
+        emit(d1, d0, a + 1);
     }
 }
 
@@ -160,93 +236,86 @@ extern "C" int tcct_dwconv3x3_dgrad(const void* dy, const float* w, void* dx, in
                                     int add_input, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(stride == 1 || stride == 2, "dwconv3x3_dgrad: stride %d", stride);
     TCCT_CHECK(!(add_input && stride != 1), "dwconv3x3_dgrad: add_input needs stride 1");
+    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1 && C >= 1, "dwconv3x3_dgrad: empty tensor");
     int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     int vec = (C % 4 == 0) ? 4 : 1;
-    int64_t total = (int64_t)N * H * W * (C / vec);
+    TCCT_CHECK(C / vec <= DB, "dwconv3x3_dgrad: C=%d too large", C);
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1) {      // dx = conv(dy, flipped taps) (+ dy when the forward added its input)
         if (vec == 4) { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, add_input, st))); }
         else { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 1, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, add_input, st))); }
         TCCT_LAUNCH_OK();
     }
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_dgrad<T, 4>), dim3(tcct_grid(total, DB, 1 << 16)), dim3(DB), 0, st, (const T*)dy, w, (T*)dx, N, H, W, C, stride, Ho, Wo, add_input)); }
-    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_dgrad<T, 1>), dim3(tcct_grid(total, DB, 1 << 16)), dim3(DB), 0, st, (const T*)dy, w, (T*)dx, N, H, W, C, stride, Ho, Wo, add_input)); }
+    int segh, wblocks, hstrips;
+    dw_geometry(N, (H + 1) / 2, (W + 1) / 2, C, vec, 1024, 32, segh, wblocks, hstrips);
+    dim3 g((unsigned)((int64_t)N * wblocks * hstrips)), b(DB);
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_dgrad_s2<T, 4>), g, b, 0, st, (const T*)dy, w, (T*)dx, N, H, W, C, Ho, Wo, segh, wblocks, hstrips)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_dgrad_s2<T, 1>), g, b, 0, st, (const T*)dy, w, (T*)dx, N, H, W, C, Ho, Wo, segh, wblocks, hstrips)); }
     TCCT_LAUNCH_OK();
 }
 
-// dw[c][ky][kx] = sum_p x[p@tap][c] * dy[p][c];  dbias[c] = sum_p dy[p][c].  Thread = (row slot, channel vector),
-// 10*VEC register sums, LDS combine per block, fp32 atomics out.
+// dw[c][ky][kx] = sum_p x[p@tap][c] * dy[p][c];  dbias[c] = sum_p dy[p][c].  Same marching window as the forward kernel with
+// 10*VEC register sums per thread; LDS combine over the columns of the block, then one fp32 atomic per (channel, tap) per block.
+// Few, tall strips (about 1024 blocks) keep the number of same-address atomics low.
 template <typename T, int VEC, int STRIDE>
-__global__ void k_dw_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
-                           int N, int H, int W, int C, int Ho, int Wo) {
+__global__ void __launch_bounds__(DB) k_dw_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
+                                                 float* __restrict__ dbias, int N, int H, int W, int C, int Ho, int Wo, int segh,
+                                                 int wblocks, int hstrips) {
     extern __shared__ float sm[];   // [DB][10*VEC]
-    const int CV = C / VEC;
-    const int R = DB / CV;
+    const int CV = C / VEC, PW = DB / CV;
     const int t = threadIdx.x;
-    const bool active = t < R * CV;
-    const int cv = t % CV, r = t / CV;
-    const int c = cv * VEC;
-    const int segs = (Wo + DW_SEG - 1) / DW_SEG;
-    const int64_t strips = (int64_t)N * Ho * segs;
     float acc[10][VEC];
 #pragma unroll
     for (int a = 0; a < 10; ++a)
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[a][k] = 0.f;
-    if (active) {
-        for (int64_t sidx = (int64_t)blockIdx.x * R + r; sidx < strips; sidx += (int64_t)gridDim.x * R) {
-            const int sg = (int)(sidx % segs);
-            int64_t q = sidx / segs;
-            const int ho = (int)(q % Ho);
-            const int64_t n = q / Ho;
-            const int wo0 = sg * DW_SEG, wo1 = min(Wo, wo0 + DW_SEG);
-            const int hi0 = ho * STRIDE - 1;
-            const T* rows[3];
-            bool rok[3];
+    typedef DwChunk<STRIDE> K;
+    DwPos p;
+    if (dw_pos(C, VEC, Ho, Wo, segh, wblocks, hstrips, p)) {
+        const T* img = x + (int64_t)p.n * H * W * C + p.c;
+        const T* gimg = dy + (int64_t)p.n * Ho * Wo * C + p.c;
+        const int wi0 = p.wo * STRIDE - 1;
+        Raw<T, VEC> R[K::ROWS][3], NX[K::NEW][3], G[K::RB], GX[K::RB];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                int hi = hi0 + ky;
-                rok[ky] = hi >= 0 && hi < H;
-                rows[ky] = x + ((n * H + (rok[ky] ? hi : 0)) * (int64_t)W) * C + c;
-            }
-            float col[3][3][VEC];
-            auto load_col = [&](int slot, int wi) {
-                bool cok = wi >= 0 && wi < W;
+        for (int i = 0; i < K::ROWS; ++i) dw_load_row<T, VEC>(R[i], img, p.ho0 * STRIDE - 1 + i, H, W, C, wi0);
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    if (cok && rok[ky]) ldv<T, VEC>(rows[ky] + (int64_t)wi * C, col[slot][ky]);
-                    else {
+        for (int j = 0; j < K::RB; ++j) {
+            if (p.ho0 + j < p.ho1) G[j].load(gimg + ((int64_t)(p.ho0 + j) * Wo + p.wo) * C);
+            else G[j].zero();
+        }
+        for (int ho = p.ho0; ho < p.ho1; ho += K::RB) {
+            if (ho + K::RB < p.ho1) {
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) col[slot][ky][k] = 0.f;
-                    }
+                for (int i = 0; i < K::NEW; ++i) dw_load_row<T, VEC>(NX[i], img, (ho + K::RB) * STRIDE - 1 + K::CARRY + i, H, W, C, wi0);
+#pragma unroll
+                for (int j = 0; j < K::RB; ++j) {
+                    if (ho + K::RB + j < p.ho1) GX[j].load(gimg + ((int64_t)(ho + K::RB + j) * Wo + p.wo) * C);
+                    else GX[j].zero();
                 }
-            };
-            load_col(0, wo0 * STRIDE - 1); load_col(1, wo0 * STRIDE);
-            for (int wo = wo0; wo < wo1; ++wo) {
-                load_col(2, wo * STRIDE + 1);
-                float g[VEC];
-                ldv<T, VEC>(dy + ((n * Ho + ho) * (int64_t)Wo + wo) * C + c, g);
+            }
+            // rows past the end of the strip carry a zero gradient, so they need no guard here
+#pragma unroll
+            for (int j = 0; j < K::RB; ++j) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    acc[9][k] += g[k];
+                    const float g = G[j].get(k);
+                    acc[9][k] += g;
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx][k] += col[kx][ky][k] * g[k];
-                }
-                if (STRIDE == 1) {
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) { col[0][ky][k] = col[1][ky][k]; col[1][ky][k] = col[2][ky][k]; }
-                } else {
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) col[0][ky][k] = col[2][ky][k];
-                    load_col(1, (wo + 1) * STRIDE);
+                        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx][k] += R[j * STRIDE + ky][kx].get(k) * g;
                 }
             }
+#pragma unroll
+            for (int i = 0; i < K::CARRY; ++i)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) R[i][kx] = R[K::NEW + i][kx];
+#pragma unroll
+            for (int i = 0; i < K::NEW; ++i)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) R[K::CARRY + i][kx] = NX[i][kx];
+#pragma unroll
+            for (int j = 0; j < K::RB; ++j) G[j] = GX[j];
         }
     }
 #pragma unroll
@@ -258,7 +327,7 @@ __global__ void k_dw_wgrad(const T* __restrict__ x, const T* __restrict__ dy, fl
         int ch = o / 10, a = o % 10;
         int cvv = ch / VEC, k = ch % VEC;
         float s = 0.f;
-        for (int rr = 0; rr < R; ++rr) s += sm[((rr * CV + cvv) * 10 + a) * VEC + k];
+        for (int pp = 0; pp < PW; ++pp) s += sm[((pp * CV + cvv) * 10 + a) * VEC + k];
         if (a < 9) atomicAdd(&dw[ch * 9 + a], s);
         else if (dbias) atomicAdd(&dbias[ch], s);
     }
@@ -267,18 +336,18 @@ __global__ void k_dw_wgrad(const T* __restrict__ x, const T* __restrict__ dy, fl
 extern "C" int tcct_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C,
                                     int stride, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(stride == 1 || stride == 2, "dwconv3x3_wgrad: stride %d", stride);
-    TCCT_CHECK(C >= 1 && C <= DB * 4, "dwconv3x3_wgrad: C=%d", C);
+    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1 && C >= 1, "dwconv3x3_wgrad: empty tensor");
     int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     int vec = (C % 4 == 0) ? 4 : 1;
     TCCT_CHECK(C / vec <= DB, "dwconv3x3_wgrad: C=%d too large", C);
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * C * 9, st) != hipSuccess) { tcct_set_error("dwconv3x3_wgrad: memset failed"); return -2; }
     if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) { tcct_set_error("dwconv3x3_wgrad: memset failed"); return -2; }
-    int R = DB / (C / vec);
-    int64_t strips = (int64_t)N * Ho * ((Wo + DW_SEG - 1) / DW_SEG);
-    int grid = tcct_grid(strips, R, 2048);
+    int segh, wblocks, hstrips;
+    dw_geometry(N, Ho, Wo, C, vec, 512, 128, segh, wblocks, hstrips);
+    dim3 grid((unsigned)((int64_t)N * wblocks * hstrips));
     size_t lds = sizeof(float) * DB * 10 * vec;
-#define DWG(V, S) hipLaunchKernelGGL((k_dw_wgrad<T, V, S>), dim3(grid), dim3(DB), lds, st, (const T*)x, (const T*)dy, dw, dbias, N, H, W, C, Ho, Wo)
+#define DWG(V, S) hipLaunchKernelGGL((k_dw_wgrad<T, V, S>), grid, dim3(DB), lds, st, (const T*)x, (const T*)dy, dw, dbias, N, H, W, C, Ho, Wo, segh, wblocks, hstrips)
     if (vec == 4) { TCCT_DISPATCH(dtype, if (stride == 1) DWG(4, 1); else DWG(4, 2)); }
     else { TCCT_DISPATCH(dtype, if (stride == 1) DWG(1, 1); else DWG(1, 2)); }
 #undef DWG

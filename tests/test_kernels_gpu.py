@@ -90,10 +90,12 @@ def test_first_layer_im2col_conv(dt, stride):
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('cfg', [(64, 1, True, False), (96, 2, False, False), (64, 1, True, True), (4, 1, True, False),
                                  (1, 1, True, False), (160, 2, False, False)])
-def test_dwconv(dt, cfg):
+@pytest.mark.parametrize('hw', [(10, 14), (37, 45), (70, 33)])
+def test_dwconv(dt, cfg, hw):
+    """small image, and images taller than one row strip / wider than one column block with odd extents"""
     from tcct_amd import ops
     C, s, has_b, addin = cfg
-    N, H, W = 2, 10, 14
+    N, (H, W) = 2, hw
     x = rnd(N, C, H, W, dt=dt).requires_grad_(True)
     w = rnd(C, 1, 3, 3, seed=1).requires_grad_(True)
     b = rnd(C, seed=2).requires_grad_(True) if has_b else None

@@ -64,7 +64,27 @@ def main():
         print(f'bn_bwd_apply: {ms:.3f} ms {3 * gb / ms * 1e3:.0f} GB/s')
 
 
+def dw_bench():
+    for (N, H, W, C, st) in [(8, 400, 552, 64, 1), (8, 400, 552, 96, 2), (8, 200, 276, 96, 1), (8, 800, 1104, 4, 1)]:
+        x = torch.randn(N, H, W, C, device='cuda').to(dt)
+        Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+        y = torch.empty(N, Ho, Wo, C, device='cuda', dtype=dt)
+        dy = torch.randn(N, Ho, Wo, C, device='cuda').to(dt)
+        dx = torch.empty_like(x)
+        w = torch.randn(C, 1, 3, 3, device='cuda')
+        b = torch.zeros(C, device='cuda')
+        dw = torch.empty_like(w); db = torch.empty_like(b)
+        gx, gy = x.numel() * 2 / 1e9, y.numel() * 2 / 1e9
+        m1 = timeit(lambda: lib.dwconv3x3_fwd(x, w, b, y, N, H, W, C, st, 0, 1))
+        m2 = timeit(lambda: lib.dwconv3x3_dgrad(dy, w, dx, N, H, W, C, st, 0, 1))
+        m3 = timeit(lambda: lib.dwconv3x3_wgrad(x, dy, dw, db, N, H, W, C, st, 1))
+        print(f'dw {N}x{H}x{W}x{C} s{st}: fwd {m1:.3f} ms {(gx + gy) / m1 * 1e3:.0f} GB/s | dgrad {m2:.3f} ms {(gx + gy) / m2 * 1e3:.0f} GB/s | wgrad {m3:.3f} ms {(gx + gy) / m3 * 1e3:.0f} GB/s')
+
+
 if __name__ == '__main__':
+    if 'dw' in sys.argv[1:]:
+        dw_bench()
+        sys.exit(0)
     main()
 
 
