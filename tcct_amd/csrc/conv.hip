@@ -112,24 +112,53 @@ k_conv_fwd(const Tin* __restrict__ x, const float* __restrict__ w, const float* 
     }
 }
 
-// 1x1 conv whose *input* channel count is not a multiple of 4 (only the dgrad of the 32->5 aux heads): thread =
-// (pixel, 4 output channels), weights straight from global (<= a few hundred floats, cache-resident).
+// 1x1 conv whose *input* channel count is not a multiple of 4 (only the dgrad of the 32->5 aux heads): thread = fixed
+// vector of 8 output channels (no per-element index division, 16-byte bf16 stores), pixels strided over the grid two at a
+// time; the <= 16 x Cout weights sit in LDS as [ci][co] so a lane reads its taps of one input channel with two ds_read_b128.
+template <typename Tout> __device__ __forceinline__ void st8(Tout* p, const float* a);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float* a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(a[4], a[5], a[6], a[7]);
+}
+template <> __device__ __forceinline__ void st8<bf16>(bf16* p, const float* a) {
+    uint4 v;
+    v.x = pack_bf16x2(a[0], a[1]); v.y = pack_bf16x2(a[2], a[3]); v.z = pack_bf16x2(a[4], a[5]); v.w = pack_bf16x2(a[6], a[7]);
+    *reinterpret_cast<uint4*>(p) = v;
+}
 template <typename Tin, typename Tout>
 __global__ void k_conv1x1_smallcin(const Tin* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                    Tout* __restrict__ y, int64_t NP, int Cin, int Cout, int transposed) {
-    const int C4 = Cout >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NP * C4; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t p = i / C4;
-        int co = (int)(i % C4) * 4;
-        f4 a;
+    __shared__ __attribute__((aligned(16))) float sw[16 * 256];
+    for (int i = threadIdx.x; i < Cin * Cout; i += blockDim.x) {
+        int ci = i / Cout, co = i - ci * Cout;
+        sw[i] = transposed ? w[i] : w[co * Cin + ci];
+    }
+    __syncthreads();
+    const int C8 = Cout >> 3, R = CB / C8, t = threadIdx.x;
+    if (t >= R * C8) return;
+    const int co = (t % C8) * 8, r = t / C8;
+    float b8[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) a.v[c] = bias ? bias[co + c] : 0.f;
+    for (int c = 0; c < 8; ++c) b8[c] = bias ? bias[co + c] : 0.f;
+    const int64_t step = (int64_t)gridDim.x * R;
+    for (int64_t p = (int64_t)blockIdx.x * R + r; p < NP; p += 2 * step) {
+        const int64_t p2 = p + step;
+        const bool ok2 = p2 < NP;
+        float a[8], a2[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = a2[c] = b8[c];
+        const Tin* x1 = x + p * Cin;
+        const Tin* x2 = x + (ok2 ? p2 : p) * Cin;
         for (int ci = 0; ci < Cin; ++ci) {
-            float xv = ldf(x + p * Cin + ci);
+            const float xv = ldf(x1 + ci), xv2 = ldf(x2 + ci);
+            const float4 w0 = *reinterpret_cast<const float4*>(sw + ci * Cout + co);
+            const float4 w1 = *reinterpret_cast<const float4*>(sw + ci * Cout + co + 4);
+            const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) a.v[c] += xv * (transposed ? w[(int64_t)ci * Cout + co + c] : w[(int64_t)(co + c) * Cin + ci]);
+            for (int c = 0; c < 8; ++c) { a[c] += xv * wv[c]; a2[c] += xv2 * wv[c]; }
         }
-        st4(y + p * Cout + co, a);
+        st8<Tout>(y + p * Cout + co, a);
+        if (ok2) st8<Tout>(y + p2 * Cout + co, a2);
     }
 }
 
@@ -137,12 +166,12 @@ static int conv_fwd_launch(const void* x, const float* w, const float* bias, voi
                            int Cin_w, int Cout, int KH, int KW, int stride, int padh, int padw, int transposed,
                            int in_dtype, int out_dtype, hipStream_t st, const char* who) {
     if (Cin % 4 != 0) {
-        if (!(KH == 1 && KW == 1 && stride == 1 && padh == 0 && padw == 0 && Cin_w == Cin && Cout % 4 == 0 && Cin <= 16)) {
+        if (!(KH == 1 && KW == 1 && stride == 1 && padh == 0 && padw == 0 && Cin_w == Cin && Cout % 8 == 0 && Cin <= 16 && Cout <= 256)) {
             tcct_set_error("%s: Cin=%d not a multiple of 4 is only supported for small 1x1 convs", who, Cin);
             return -1;
         }
         int64_t NPs = (int64_t)N * H * W;
-        dim3 g(tcct_grid(NPs * (Cout / 4), CB)), b(CB);
+        dim3 g(tcct_grid(NPs, 2 * (CB / (Cout / 8)), 256 * 16)), b(CB);
 #define LAUNCHS(TI, TO) hipLaunchKernelGGL((k_conv1x1_smallcin<TI, TO>), g, b, 0, st, (const TI*)x, w, bias, (TO*)y, NPs, Cin, Cout, transposed)
         if (in_dtype == TCCT_F32 && out_dtype == TCCT_F32) LAUNCHS(float, float);
         else if (in_dtype == TCCT_BF16 && out_dtype == TCCT_BF16) LAUNCHS(bf16, bf16);

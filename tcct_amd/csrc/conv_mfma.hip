@@ -122,9 +122,9 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         int pb = VERT ? a * LH + seg * 32 + r : a * LW + seg * 32 + r;
         xB[t] = sX + pb * IPS + hh * 16;
     }
-    float ss[STATS ? 8 : 1], sq[STATS ? 8 : 1];        // after the transpose a lane owns channels 8*(lane&3)..+7
-#pragma unroll
-    for (int k = 0; k < (STATS ? 8 : 1); ++k) ss[k] = sq[k] = 0.f;
+    // BN statistics: per-tile register partials (live only in the epilogue), flushed into 64 LDS accumulators once per tile
+    float* sR = reinterpret_cast<float*>(sS + 4096);
+    if (STATS && tid < 64) sR[tid] = 0.f;
     int tile = blockIdx.x;
     if (tile < ntiles) prefetch(tile);
     for (; tile < ntiles; tile += gridDim.x) {
@@ -166,7 +166,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a1, f.b1[t], acc[t], 0, 0, 0);
             }
         };
-        if (KH_ && !STATS) {          // (the STATS variant has 32 more live VGPRs: double-buffered fragments would spill)
+        if (KH_) {
             constexpr int NT = (KH_ ? KH_ : 1) * (KW_ ? KW_ : 1);
             Frag f[2];
             load_tap(f[0], 0, 0);
@@ -177,12 +177,6 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
                 mma_tap(f[k & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        } else if (KH_) {
-            Frag f;
-#pragma unroll
-            for (int dy = 0; dy < (KH_ ? KH_ : 1); ++dy)
-#pragma unroll
-                for (int dx = 0; dx < (KW_ ? KW_ : 1); ++dx) { load_tap(f, dy, dx); mma_tap(f); }
         } else {
             Frag f;
             for (int dy = 0; dy < KH; ++dy)
@@ -193,6 +187,9 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         // wave instruction writes 16 whole pixels (1 KB contiguous for HORZ tiles) -- four 8-byte stores per lane, i.e. 16 B of
         // every 64-B line per instruction, were the throughput limit of the store-heavy kernels.
         unsigned char* sc = sS + wave * 1024;
+        float ss[STATS ? 8 : 1], sq[STATS ? 8 : 1];        // after the transpose a lane owns channels 8*(lane&3)..+7
+#pragma unroll
+        for (int k = 0; k < (STATS ? 8 : 1); ++k) ss[k] = sq[k] = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             int mt = wave * 4 + t;
@@ -239,25 +236,17 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
                 }
             }
         }
-    }
-    if (STATS) {
-        // lanes with equal (lane & 3) hold different pixels of the same 8 channels: butterfly over lane bits 2..5, LDS, fp64 atomics
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(sX);
-        if (tid < 64) red[tid] = 0.f;
-        __syncthreads();
+        if (STATS) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float a = ss[k], b = sq[k];
-#pragma unroll
-            for (int o = 32; o > 2; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-            if (lane < 4) {
-                atomicAdd(&red[8 * lane + k], a);
-                atomicAdd(&red[32 + 8 * lane + k], b);
+            for (int k = 0; k < 8; ++k) {
+                atomicAdd(&sR[8 * (lane & 3) + k], ss[k]);
+                atomicAdd(&sR[32 + 8 * (lane & 3) + k], sq[k]);
             }
         }
+    }
+    if (STATS) {
         __syncthreads();
-        if (tid < 64) atomicAdd(&stats[tid], (double)red[tid]);
+        if (tid < 64) atomicAdd(&stats[tid], (double)sR[tid]);
     }
 }
 
@@ -290,7 +279,7 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
     const bool vert = (KW == 1 && KH > 1);
     const int TH = vert ? 64 : 8, TW = vert ? 8 : 64;
     const int LH = TH + KH - 1, LW = TW + KW - 1;
-    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * IPS + 128 + 4096;
+    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * IPS + 128 + 4096 + 256;
     TCCT_CHECK(lds <= 80 * 1024, "conv32_fwd: %dx%d needs %zu B of LDS (> 80 KiB for 2 blocks/CU)", KH, KW, lds);
     TCCT_CHECK(LH * LW * 4 <= MAXL * MB, "conv32_fwd: %dx%d tile image exceeds the staging slots", KH, KW);
     int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;

@@ -7,73 +7,85 @@
 
 // ------------------------------------------------------------------------------------------ MetaPool
 // x [B, N, C]; BWD=false: y = box3x3_validcount(x) - x ; BWD=true: dx = box^T(dy) - dy
+// thread = fixed vector of 4 channels (the per-column divisors are computed once), rows strided over grid.x, batch on grid.y:
+// no per-element index division (the first version spent most of its time in 64-bit div/mod).
 template <typename T, bool BWD>
-__global__ void k_metapool(const T* __restrict__ x, T* __restrict__ y, int B, int64_t N, int C) {
-    const int C4 = C >> 2;
-    const int64_t total = (int64_t)B * N * C4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int c0 = (int)(i % C4) * 4;
-        int64_t bn = i / C4;
-        int64_t n = bn % N;
-        const T* base = x + bn * C;            // row n
+__global__ void k_metapool(const T* __restrict__ x, T* __restrict__ y, int B, int N, int C) {
+    const int C4 = C >> 2, R = PB / C4, t = threadIdx.x;
+    if (t >= R * C4) return;
+    const int c0 = (t % C4) * 4, r = t / C4, lane = t & 63;
+    float cs[6];                 // BWD: 1/rc of source columns c0-1..c0+4 ; FWD: 1/rc of output columns c0..c0+3 in cs[0..3]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        int c = BWD ? c0 - 1 + j : c0 + j;
+        int rc = 1 + (c > 0) + (c < C - 1);
+        cs[j] = 1.f / (float)rc;
+    }
+    const bool hasl = c0 > 0, hasr = c0 + 4 < C;
+    const T* xb = x + (int64_t)blockIdx.y * N * C + c0;
+    T* yb = y + (int64_t)blockIdx.y * N * C + c0;
+    for (int n = blockIdx.x * R + r; n < N; n += gridDim.x * R) {
+        const T* base = xb + (int64_t)n * C;
         float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f4 ctr = f4zero();
 #pragma unroll
         for (int dn = -1; dn <= 1; ++dn) {
-            int64_t nn = n + dn;
+            int nn = n + dn;
             if (nn < 0 || nn >= N) continue;
-            const T* row = base + (int64_t)dn * C;
+            const T* row = base + dn * C;
             float rw = 1.f;
             if (BWD) { int rn = 1 + (nn > 0) + (nn < N - 1); rw = 1.f / (float)rn; }
-            f4 m = ld4(row + c0);
-            float l = c0 > 0 ? ldf(row + c0 - 1) : 0.f;
-            float r = c0 + 4 < C ? ldf(row + c0 + 4) : 0.f;
+            f4 m = ld4(row);
+            // channel neighbours c0-1 / c0+4 live in the adjacent lanes (same row): take them by shuffle; the first / last lane of a
+            // wave may have its neighbour in another wave (C/4 not a divisor of 64) and loads it instead
+            const float ls = __shfl_up(m.v[3], 1, 64), rs = __shfl_down(m.v[0], 1, 64);
+            float l = hasl ? (lane == 0 ? ldf(row - 1) : ls) : 0.f;
+            float rr = hasr ? (lane == 63 ? ldf(row + 4) : rs) : 0.f;
             if (dn == 0) ctr = m;
-            float g[6] = {l, m.v[0], m.v[1], m.v[2], m.v[3], r};
+            float g[6] = {l, m.v[0], m.v[1], m.v[2], m.v[3], rr};
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                float s = rw;
-                if (BWD) { int c = c0 - 1 + j; int rc = 1 + (c > 0) + (c < C - 1); s = rw / (float)rc; }
-                v[j] += g[j] * s;
-            }
+            for (int j = 0; j < 6; ++j) v[j] += g[j] * (BWD ? rw * cs[j] : 1.f);
         }
         f4 o;
-        int rn = 1 + (n > 0) + (n < N - 1);
+        const int rn = 1 + (n > 0) + (n < N - 1);
+        const float rinv = 1.f / (float)rn;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float s = v[k] + v[k + 1] + v[k + 2];
-            if (!BWD) { int c = c0 + k; int rc = 1 + (c > 0) + (c < C - 1); s /= (float)(rn * rc); }
+            if (!BWD) s *= rinv * cs[k];
             o.v[k] = s - ctr.v[k];
         }
-        st4(y + bn * C + c0, o);
+        st4(yb + (int64_t)n * C, o);
     }
 }
-extern "C" int tcct_metapool_fwd(const void* x, void* y, int B, int64_t N, int C, int dtype, tcct_stream_t stream) {
-    TCCT_CHECK(C % 4 == 0 && C >= 4, "metapool_fwd: C=%d", C);
-    int64_t total = (int64_t)B * N * (C / 4);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_metapool<T, false>), dim3(tcct_grid(total, PB, 1 << 16)), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, N, C));
+static int metapool_launch(const void* x, void* y, int B, int64_t N, int C, int dtype, bool bwd, tcct_stream_t stream, const char* who) {
+    if (!(C % 4 == 0 && C >= 4 && C / 4 <= PB)) { tcct_set_error("%s: C=%d", who, C); return -1; }
+    if (!(B >= 1 && B <= 65535 && N >= 1 && N < (1LL << 30))) { tcct_set_error("%s: B=%d N=%lld out of range", who, B, (long long)N); return -1; }
+    const int R = PB / (C / 4);
+    dim3 g((unsigned)tcct_grid(N, R, 4096), (unsigned)B);
+    if (bwd) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_metapool<T, true>), g, dim3(PB), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, (int)N, C)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_metapool<T, false>), g, dim3(PB), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, (int)N, C)); }
     TCCT_LAUNCH_OK();
 }
+extern "C" int tcct_metapool_fwd(const void* x, void* y, int B, int64_t N, int C, int dtype, tcct_stream_t stream) {
+    return metapool_launch(x, y, B, N, C, dtype, false, stream, "metapool_fwd");
+}
 extern "C" int tcct_metapool_bwd(const void* dy, void* dx, int B, int64_t N, int C, int dtype, tcct_stream_t stream) {
-    TCCT_CHECK(C % 4 == 0 && C >= 4, "metapool_bwd: C=%d", C);
-    int64_t total = (int64_t)B * N * (C / 4);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_metapool<T, true>), dim3(tcct_grid(total, PB, 1 << 16)), dim3(PB), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, B, N, C));
-    TCCT_LAUNCH_OK();
+    return metapool_launch(dy, dx, B, N, C, dtype, true, stream, "metapool_bwd");
 }
 
 // ------------------------------------------------------------------------------------------ MaxPool2d(2)
+// grid.y strides over output rows (n, ho); threads of a row cover (wo, channel vector): 32-bit index arithmetic only
 template <typename T, bool BWD>
 __global__ void k_maxpool2(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, int N, int H, int W, int C) {
     const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
-    const int64_t total = (int64_t)N * Ho * Wo * C4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int c0 = (int)(i % C4) * 4;
-        int64_t p = i / C4;
-        int wo = (int)(p % Wo);
-        int64_t r = p / Wo;
-        int ho = (int)(r % Ho);
-        int64_t n = r / Ho;
-        int64_t b00 = ((n * H + 2 * ho) * (int64_t)W + 2 * wo) * C + c0;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Wo * C4) return;
+    const int wo = i / C4, c0 = (i - wo * C4) * 4;
+    for (int row = blockIdx.y; row < N * Ho; row += gridDim.y) {
+        const int n = row / Ho, ho = row - n * Ho;
+        const int64_t p = (int64_t)row * Wo + wo;
+        int64_t b00 = (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + c0;
         int64_t offs[4] = {b00, b00 + C, b00 + (int64_t)W * C, b00 + (int64_t)W * C + C};
         f4 v[4];
 #pragma unroll
@@ -98,16 +110,24 @@ __global__ void k_maxpool2(const T* __restrict__ x, const T* __restrict__ dy, T*
         }
     }
 }
+// grid.x covers one row of (pixel, channel-vector) items, grid.y strides over rows: about 8192 blocks in total, so every block
+// loops over several rows (one row per block left the resize kernels bound by block dispatch, not by HBM)
+static inline dim3 row_grid(int per_row, int64_t rows, int target_blocks = 8192) {
+    const int gx = (per_row + PB - 1) / PB;
+    int64_t gy = (target_blocks + gx - 1) / gx;
+    if (gy > rows) gy = rows;
+    if (gy > 65535) gy = 65535;
+    if (gy < 1) gy = 1;
+    return dim3((unsigned)gx, (unsigned)gy);
+}
 extern "C" int tcct_maxpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, tcct_stream_t stream) {
-    TCCT_CHECK(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool2_fwd: needs C%%4==0 and even H,W (got %d,%d,%d)", C, H, W);
-    int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_maxpool2<T, false>), dim3(tcct_grid(total, PB, 1 << 16)), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, (T*)y, N, H, W, C));
+    TCCT_CHECK(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2 && N >= 1, "maxpool2_fwd: needs C%%4==0 and even H,W (got %d,%d,%d)", C, H, W);
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_maxpool2<T, false>), row_grid((W / 2) * (C / 4), (int64_t)N * (H / 2), 1 << 22), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, (T*)y, N, H, W, C));
     TCCT_LAUNCH_OK();
 }
 extern "C" int tcct_maxpool2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int dtype, tcct_stream_t stream) {
-    TCCT_CHECK(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool2_bwd: needs C%%4==0 and even H,W (got %d,%d,%d)", C, H, W);
-    int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_maxpool2<T, true>), dim3(tcct_grid(total, PB, 1 << 16)), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, N, H, W, C));
+    TCCT_CHECK(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2 && N >= 1, "maxpool2_bwd: needs C%%4==0 and even H,W (got %d,%d,%d)", C, H, W);
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_maxpool2<T, true>), row_grid((W / 2) * (C / 4), (int64_t)N * (H / 2), 1 << 22), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, N, H, W, C));
     TCCT_LAUNCH_OK();
 }
 
@@ -123,34 +143,31 @@ __device__ __forceinline__ Lerp src_index(int o, float scale, int in, int align)
     return r;
 }
 
+// grid.y strides over output rows (n, ho) -- the row interpolation is block-uniform; threads of a row cover (wo, channel vector)
 template <typename T, int VEC>
 __global__ void k_bilinear_fwd(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo,
                                float sh, float sw, int align) {
     const int CV = C / VEC;
-    const int64_t total = (int64_t)N * Ho * Wo * CV;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int c = (int)(i % CV) * VEC;
-        int64_t p = i / CV;
-        int wo = (int)(p % Wo);
-        int64_t r = p / Wo;
-        int ho = (int)(r % Ho);
-        int64_t n = r / Ho;
-        Lerp a = src_index(ho, sh, H, align), b = src_index(wo, sw, W, align);
-        const T* r0 = x + ((n * H + a.i0) * (int64_t)W) * C + c;
-        const T* r1 = x + ((n * H + a.i1) * (int64_t)W) * C + c;
-        float o[VEC];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Wo * CV) return;
+    const int wo = i / CV, c = (i - wo * CV) * VEC;
+    const Lerp b = src_index(wo, sw, W, align);
+    const int o0 = b.i0 * C + c, o1 = b.i1 * C + c;
+    for (int row = blockIdx.y; row < N * Ho; row += gridDim.y) {
+        const int n = row / Ho, ho = row - n * Ho;
+        const Lerp a = src_index(ho, sh, H, align);
+        const T* r0 = x + ((int64_t)n * H + a.i0) * W * C;
+        const T* r1 = x + ((int64_t)n * H + a.i1) * W * C;
+        T* yo = y + ((int64_t)row * Wo + wo) * C + c;
         if (VEC == 4) {
-            f4 v00 = ld4(r0 + (int64_t)b.i0 * C), v01 = ld4(r0 + (int64_t)b.i1 * C);
-            f4 v10 = ld4(r1 + (int64_t)b.i0 * C), v11 = ld4(r1 + (int64_t)b.i1 * C);
+            f4 v00 = ld4(r0 + o0), v01 = ld4(r0 + o1), v10 = ld4(r1 + o0), v11 = ld4(r1 + o1), t;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                o[k] = a.l0 * (b.l0 * v00.v[k] + b.l1 * v01.v[k]) + a.l1 * (b.l0 * v10.v[k] + b.l1 * v11.v[k]);
-            f4 t; t.v[0] = o[0]; t.v[1] = o[1]; t.v[2] = o[2]; t.v[3] = o[3];
-            st4(y + p * C + c, t);
+                t.v[k] = a.l0 * (b.l0 * v00.v[k] + b.l1 * v01.v[k]) + a.l1 * (b.l0 * v10.v[k] + b.l1 * v11.v[k]);
+            st4(yo, t);
         } else {
-            float v00 = ldf(r0 + (int64_t)b.i0 * C), v01 = ldf(r0 + (int64_t)b.i1 * C);
-            float v10 = ldf(r1 + (int64_t)b.i0 * C), v11 = ldf(r1 + (int64_t)b.i1 * C);
-            stf(y + p * C + c, a.l0 * (b.l0 * v00 + b.l1 * v01) + a.l1 * (b.l0 * v10 + b.l1 * v11));
+            float v00 = ldf(r0 + o0), v01 = ldf(r0 + o1), v10 = ldf(r1 + o0), v11 = ldf(r1 + o1);
+            stf(yo, a.l0 * (b.l0 * v00 + b.l1 * v01) + a.l1 * (b.l0 * v10 + b.l1 * v11));
         }
     }
 }
@@ -205,16 +222,85 @@ __global__ void k_bilinear_bwd(const T* __restrict__ dy, T* __restrict__ dx, int
     }
 }
 
+// Tiled backward (the one the step uses): block = one DH x DW tile of dx.  The outputs that interpolate from a given input row
+// (column) and their weights are found ONCE per tile row (column) and kept as small tables in LDS; every dx element then
+// gathers exactly its contributing dy elements (rows x columns of the two tables) -- no per-element candidate search, no
+// atomics.  The plain gather kernel above searches ~8x8 candidates with a float->int conversion each per dx element.
+#define BT_DH 8
+template <typename T, int VEC>
+__global__ void __launch_bounds__(PB) k_bilinear_bwd_tab(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C,
+                                                         int Ho, int Wo, float sh, float sw, int align, int DW, int KT,
+                                                         int tilesW, int tilesH) {
+    extern __shared__ int smem_i[];             // idx[(DH+DW)][KT], then weights[(DH+DW)][KT], then counts[DH+DW]
+    int* tidx = smem_i;
+    float* twt = reinterpret_cast<float*>(smem_i + (BT_DH + DW) * KT);
+    int* tcnt = smem_i + 2 * (BT_DH + DW) * KT;
+    const int CV = C / VEC, t = threadIdx.x;
+    int bid = blockIdx.x;
+    const int tw = bid % tilesW; bid /= tilesW;
+    const int th = bid % tilesH;
+    const int n = bid / tilesH;
+    const int hi0 = th * BT_DH, wi0 = tw * DW;
+    if (t < BT_DH + DW) {
+        const bool isrow = t < BT_DH;
+        const int i = isrow ? hi0 + t : wi0 + (t - BT_DH);
+        const int in = isrow ? H : W, out = isrow ? Ho : Wo;
+        const float sc = isrow ? sh : sw;
+        int cnt = 0;
+        if (i < in) {
+            int lo, hi;
+            cand_range(i, sc, out, align, lo, hi);
+            for (int o = lo; o <= hi && cnt < KT; ++o) {
+                Lerp a = src_index(o, sc, in, align);
+                float wgt = (a.i0 == i ? a.l0 : 0.f) + (a.i1 == i ? a.l1 : 0.f);
+                if (wgt != 0.f) { tidx[t * KT + cnt] = o; twt[t * KT + cnt] = wgt; ++cnt; }
+            }
+        }
+        tcnt[t] = cnt;
+    }
+    __syncthreads();
+    const T* g = dy + (int64_t)n * Ho * Wo * C;
+    T* out = dx + (int64_t)n * H * W * C;
+    for (int i = t; i < BT_DH * DW * CV; i += PB) {
+        const int cv = i % CV, pix = i / CV;
+        const int r = pix / DW, cc = pix - r * DW;
+        const int hi = hi0 + r, wi = wi0 + cc;
+        if (hi >= H || wi >= W) continue;
+        const int nr = tcnt[r], nc = tcnt[BT_DH + cc];
+        const int* ri = tidx + r * KT;
+        const float* rw = twt + r * KT;
+        const int* ci = tidx + (BT_DH + cc) * KT;
+        const float* cw = twt + (BT_DH + cc) * KT;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        for (int a = 0; a < nr; ++a) {
+            const T* row = g + (int64_t)ri[a] * Wo * C + cv * VEC;
+            const float wh = rw[a];
+            for (int b = 0; b < nc; ++b) {
+                const float gw = wh * cw[b];
+                if (VEC == 4) {
+                    f4 v = ld4(row + (int64_t)ci[b] * C);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] += gw * v.v[k];
+                } else acc[0] += gw * ldf(row + (int64_t)ci[b] * C);
+            }
+        }
+        T* o = out + ((int64_t)hi * W + wi) * C + cv * VEC;
+        if (VEC == 4) { f4 q; q.v[0] = acc[0]; q.v[1] = acc[1]; q.v[2] = acc[2]; q.v[3] = acc[3]; st4(o, q); }
+        else stf(o, acc[0]);
+    }
+}
+
 extern "C" int tcct_bilinear_fwd(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int align_corners,
                                  int dtype, tcct_stream_t stream) {
     TCCT_CHECK(H > 0 && W > 0 && Ho > 0 && Wo > 0, "bilinear_fwd: bad sizes");
     float sh = align_corners ? (Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f) : (float)H / (float)Ho;
     float sw = align_corners ? (Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f) : (float)W / (float)Wo;
     int vec = (C % 4 == 0) ? 4 : 1;
-    int64_t total = (int64_t)N * Ho * Wo * (C / vec);
     hipStream_t st = (hipStream_t)stream;
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_fwd<T, 4>), dim3(tcct_grid(total, PB, 1 << 16)), dim3(PB), 0, st, (const T*)x, (T*)y, N, H, W, C, Ho, Wo, sh, sw, align_corners)); }
-    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_fwd<T, 1>), dim3(tcct_grid(total, PB, 1 << 16)), dim3(PB), 0, st, (const T*)x, (T*)y, N, H, W, C, Ho, Wo, sh, sw, align_corners)); }
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_fwd<T, 4>), row_grid(Wo * (C / 4), (int64_t)N * Ho), dim3(PB), 0, st, (const T*)x, (T*)y, N, H, W, C, Ho, Wo, sh, sw, align_corners)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_fwd<T, 1>), row_grid(Wo * C, (int64_t)N * Ho), dim3(PB), 0, st, (const T*)x, (T*)y, N, H, W, C, Ho, Wo, sh, sw, align_corners)); }
     TCCT_LAUNCH_OK();
 }
 /* dy [N,Ho,Wo,C] -> dx [N,H,W,C] (H,W = forward input size) */
@@ -224,8 +310,21 @@ extern "C" int tcct_bilinear_bwd(const void* dy, void* dx, int N, int H, int W, 
     float sh = align_corners ? (Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f) : (float)H / (float)Ho;
     float sw = align_corners ? (Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f) : (float)W / (float)Wo;
     int vec = (C % 4 == 0) ? 4 : 1;
-    int64_t total = (int64_t)N * H * W * (C / vec);
     hipStream_t st = (hipStream_t)stream;
+    // entries per table row: outputs within +-1 source pixel of an input index = 2/scale (+ slack); beyond BL_MAXC use the search kernel
+    const float smin = fminf(sh, sw);
+    const int KT = smin > 0.f ? (int)(2.f / smin) + 3 : BL_MAXC + 1;
+    if (KT <= BL_MAXC) {
+        const int DW = 32;
+        const int tilesW = (W + DW - 1) / DW, tilesH = (H + BT_DH - 1) / BT_DH;
+        const int64_t blocks = (int64_t)N * tilesW * tilesH;
+        TCCT_CHECK(blocks < 0x7fffffffLL, "bilinear_bwd: grid too large");
+        const size_t lds = sizeof(int) * ((size_t)2 * (BT_DH + DW) * KT + BT_DH + DW);
+        if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_bwd_tab<T, 4>), dim3((unsigned)blocks), dim3(PB), lds, st, (const T*)dy, (T*)dx, N, H, W, C, Ho, Wo, sh, sw, align_corners, DW, KT, tilesW, tilesH)); }
+        else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_bwd_tab<T, 1>), dim3((unsigned)blocks), dim3(PB), lds, st, (const T*)dy, (T*)dx, N, H, W, C, Ho, Wo, sh, sw, align_corners, DW, KT, tilesW, tilesH)); }
+        TCCT_LAUNCH_OK();
+    }
+    int64_t total = (int64_t)N * H * W * (C / vec);
     if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_bwd<T, 4>), dim3(tcct_grid(total, PB, 1 << 16)), dim3(PB), 0, st, (const T*)dy, (T*)dx, N, H, W, C, Ho, Wo, sh, sw, align_corners)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_bwd<T, 1>), dim3(tcct_grid(total, PB, 1 << 16)), dim3(PB), 0, st, (const T*)dy, (T*)dx, N, H, W, C, Ho, Wo, sh, sw, align_corners)); }
     TCCT_LAUNCH_OK();

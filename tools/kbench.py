@@ -64,6 +64,30 @@ def main():
         print(f'bn_bwd_apply: {ms:.3f} ms {3 * gb / ms * 1e3:.0f} GB/s')
 
 
+def misc_bench():
+    import torch.nn.functional as F
+    for (C, H, W, Ho, Wo, al, tdt) in [(32, 400, 552, 800, 1104, 1, dt), (5, 400, 552, 800, 1104, 0, torch.float32),
+                                        (5, 200, 276, 800, 1104, 0, torch.float32), (5, 100, 138, 800, 1104, 0, torch.float32)]:
+        code = 1 if tdt == torch.bfloat16 else 0
+        x = torch.randn(8, H, W, C, device='cuda').to(tdt); y = torch.empty(8, Ho, Wo, C, device='cuda', dtype=tdt)
+        dy = torch.randn(8, Ho, Wo, C, device='cuda').to(tdt); dx = torch.empty_like(x)
+        gb = (x.numel() + y.numel()) * x.element_size() / 1e9
+        m1 = timeit(lambda: lib.bilinear_fwd(x, y, 8, H, W, C, Ho, Wo, al, code))
+        m2 = timeit(lambda: lib.bilinear_bwd(dy, dx, 8, H, W, C, Ho, Wo, al, code))
+        print(f'bilinear C={C} {H}x{W}->{Ho}x{Wo}: fwd {m1:.3f} ms {gb / m1 * 1e3:.0f} GB/s | bwd {m2:.3f} ms {gb / m2 * 1e3:.0f} GB/s')
+    x = torch.randn(8, 220800, 64, device='cuda').to(dt); y = torch.empty_like(x)
+    gb = 2 * x.numel() * 2 / 1e9
+    m1 = timeit(lambda: lib.metapool_fwd(x, y, 8, 220800, 64, 1)); m2 = timeit(lambda: lib.metapool_bwd(x, y, 8, 220800, 64, 1))
+    print(f'metapool 8x220800x64: fwd {m1:.3f} ms {gb / m1 * 1e3:.0f} GB/s | bwd {m2:.3f} ms {gb / m2 * 1e3:.0f} GB/s')
+    x = torch.randn(8, 800, 1104, 32, device='cuda').to(dt); y = torch.empty(8, 400, 552, 32, device='cuda', dtype=dt); dx = torch.empty_like(x)
+    gb = (x.numel() + y.numel()) * 2 / 1e9
+    m1 = timeit(lambda: lib.maxpool2_fwd(x, y, 8, 800, 1104, 32, 1)); m2 = timeit(lambda: lib.maxpool2_bwd(x, y, dx, 8, 800, 1104, 32, 1))
+    print(f'maxpool2 L0: fwd {m1:.3f} ms {gb / m1 * 1e3:.0f} GB/s | bwd {m2:.3f} ms')
+    dl = torch.randn(8, 800, 1104, 5, device='cuda'); w = torch.randn(5, 32, 1, 1, device='cuda'); dx = torch.empty(8, 800, 1104, 32, device='cuda', dtype=dt)
+    m1 = timeit(lambda: lib.conv2d_dgrad(dl, w, dx, 8, 800, 1104, 32, 5, 1, 1, 0, 0, 0, 1))
+    print(f'aux dgrad 5->32 @L0: {m1:.3f} ms {(dl.numel() * 4 + dx.numel() * 2) / 1e9 / m1 * 1e3:.0f} GB/s')
+
+
 def dw_bench():
     for (N, H, W, C, st) in [(8, 400, 552, 64, 1), (8, 400, 552, 96, 2), (8, 200, 276, 96, 1), (8, 800, 1104, 4, 1)]:
         x = torch.randn(N, H, W, C, device='cuda').to(dt)
@@ -84,6 +108,9 @@ def dw_bench():
 if __name__ == '__main__':
     if 'dw' in sys.argv[1:]:
         dw_bench()
+        sys.exit(0)
+    if 'misc' in sys.argv[1:]:
+        misc_bench()
         sys.exit(0)
     main()
 
