@@ -52,7 +52,7 @@ extern "C" int tcct_conv32_pack_weights_sub(const float* w, void* wp, int KH, in
 // removed it still took 0.20 of 0.29 ms -- XOR-swizzle address arithmetic (6 VALU ops per fragment read, ~1000 per tile and wave)
 // in front of every ds_read.  Now the image rows are padded instead of swizzled and KH/KW are template constants, so a B
 // fragment read is `ds_read_b128 v, base_t offset:imm` with NO per-read VALU work (KH_ = 0 keeps a runtime-tap fallback).
-template <bool VERT, bool STATS, int KH_, int KW_>
+template <bool VERT, int STATS, int KH_, int KW_>      // STATS: 0 none, 1 stats of y, 2 stats of LeakyReLU(y), 3 stats of act(stat_pre, y)
 __global__ void __launch_bounds__(MB, 2)
 k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
               int N, int H, int W, int KHr, int KWr, int PH, int PW, int tilesH, int tilesW, int ntiles, int xs, int xo, int ys,
@@ -84,15 +84,13 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
     // slot geometry (tile independent): slot j covers 16-byte chunk c of tile-local pixel (lr, lc); (lr,lc) packed in one int
     const int c = tid & 3;
     const int npix = LH * LW;
-    int s_rc[MAXL], s_off[MAXL];
+    int s_rc[MAXL];              // the LDS offset of a slot is recomputed from (lr, lc) when it is stored: 11 fewer live VGPRs
 #pragma unroll
     for (int j = 0; j < MAXL; ++j) {
         int pl = (tid >> 2) + j * (MB / 4);
         bool in = pl < npix;
         int lr = in ? pl / LW : 0x3fff, lc = in ? pl - (pl / LW) * LW : 0;
-        int p = VERT ? lc * LH + lr : pl;
         s_rc[j] = (lr << 16) | lc;
-        s_off[j] = in ? p * IPS + c * 16 : -1;
     }
     uint4 pre[MAXL];
     auto prefetch = [&](int tile) {
@@ -122,9 +120,9 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         int pb = VERT ? a * LH + seg * 32 + r : a * LW + seg * 32 + r;
         xB[t] = sX + pb * IPS + hh * 16;
     }
-    // BN statistics: per-tile register partials (live only in the epilogue), flushed into 64 LDS accumulators once per tile
-    float* sR = reinterpret_cast<float*>(sS + 4096);
-    if (STATS && tid < 64) sR[tid] = 0.f;
+    float ss[STATS ? 8 : 1], sq[STATS ? 8 : 1];        // BN statistics: after the transpose a lane owns channels 8*(lane&3)..+7
+#pragma unroll
+    for (int k = 0; k < (STATS ? 8 : 1); ++k) ss[k] = sq[k] = 0.f;
     int tile = blockIdx.x;
     if (tile < ntiles) prefetch(tile);
     for (; tile < ntiles; tile += gridDim.x) {
@@ -135,8 +133,10 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         const int h0 = th * TH, w0 = tw * TW;
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < MAXL; ++j)
-            if (s_off[j] >= 0) *reinterpret_cast<uint4*>(sX + s_off[j]) = pre[j];
+        for (int j = 0; j < MAXL; ++j) {
+            const int lr = s_rc[j] >> 16, lc = s_rc[j] & 0xffff;
+            if (lr != 0x3fff) *reinterpret_cast<uint4*>(sX + (VERT ? lc * LH + lr : lr * LW + lc) * IPS + c * 16) = pre[j];
+        }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
 
@@ -145,51 +145,47 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
-        // Fragment reads are software-pipelined one tap ahead of the MFMAs that consume them: left to itself hipcc emits
-        // `ds_read; s_waitcnt lgkmcnt(0); v_mfma` per MFMA, exposing the full LDS latency 72 times per tile.
-        struct Frag { bf16x8 a0, a1, b0[4], b1[4]; };
-        auto load_tap = [&](Frag& f, int dy, int dx) {
+        // Fragment reads are software-pipelined one stage (= half a tap: 16 of the 32 input channels, 4 MFMAs) ahead of the MFMAs
+        // that consume them: left to itself hipcc emits `ds_read; s_waitcnt lgkmcnt(0); v_mfma` per MFMA, exposing the full LDS
+        // latency 72 times per tile.  Half-tap stages keep the double buffer at 2 x 20 VGPRs (whole taps: 2 x 40, which spilled
+        // in the BN-statistics variant).
+        struct Frag { bf16x8 a, b[4]; };
+        auto load_stage = [&](Frag& f, int dy, int dx, int half) {
             const int woff = (dy * KW + dx) * 2048;                        // 32 rows x 64 B per tap
-            f.a0 = *reinterpret_cast<const bf16x8*>(wA0 + woff);
-            f.a1 = *reinterpret_cast<const bf16x8*>(wA1 + woff);
-            const int poff = (VERT ? dx * LH + dy : dy * LW + dx) * IPS;
+            f.a = *reinterpret_cast<const bf16x8*>((half ? wA1 : wA0) + woff);
+            const int poff = (VERT ? dx * LH + dy : dy * LW + dx) * IPS + half * 32;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                f.b0[t] = *reinterpret_cast<const bf16x8*>(xB[t] + poff);
-                f.b1[t] = *reinterpret_cast<const bf16x8*>(xB[t] + poff + 32);
-            }
+            for (int t = 0; t < 4; ++t) f.b[t] = *reinterpret_cast<const bf16x8*>(xB[t] + poff);
         };
-        auto mma_tap = [&](const Frag& f) {
+        auto mma_stage = [&](const Frag& f) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a0, f.b0[t], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a1, f.b1[t], acc[t], 0, 0, 0);
-            }
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a, f.b[t], acc[t], 0, 0, 0);
         };
         if (KH_) {
-            constexpr int NT = (KH_ ? KH_ : 1) * (KW_ ? KW_ : 1);
+            constexpr int KWc = KW_ ? KW_ : 1;
+            constexpr int NS = 2 * (KH_ ? KH_ : 1) * KWc;
             Frag f[2];
-            load_tap(f[0], 0, 0);
+            load_stage(f[0], 0, 0, 0);
 #pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                if (k + 1 < NT) load_tap(f[(k + 1) & 1], (k + 1) / (KW_ ? KW_ : 1), (k + 1) % (KW_ ? KW_ : 1));
-                __builtin_amdgcn_sched_barrier(0);          // keep the next tap's reads ahead of this tap's MFMAs
-                mma_tap(f[k & 1]);
+            for (int k = 0; k < NS; ++k) {
+                if (k + 1 < NS) load_stage(f[(k + 1) & 1], ((k + 1) >> 1) / KWc, ((k + 1) >> 1) % KWc, (k + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);          // keep the next stage's reads ahead of this stage's MFMAs
+                mma_stage(f[k & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             Frag f;
             for (int dy = 0; dy < KH; ++dy)
-                for (int dx = 0; dx < KW; ++dx) { load_tap(f, dy, dx); mma_tap(f); }
+                for (int dx = 0; dx < KW; ++dx) {
+                    load_stage(f, dy, dx, 0); mma_stage(f);
+                    load_stage(f, dy, dx, 1); mma_stage(f);
+                }
         }
         // epilogue: lane owns pixel r of each M-tile and channels co = 8q + 4*hh + k.  The packed bf16 values go through a per-wave
         // LDS transpose (16 pixels x 64 B per round, chunks XOR-swizzled) so that every lane stores 16 contiguous bytes and one
         // wave instruction writes 16 whole pixels (1 KB contiguous for HORZ tiles) -- four 8-byte stores per lane, i.e. 16 B of
         // every 64-B line per instruction, were the throughput limit of the store-heavy kernels.
         unsigned char* sc = sS + wave * 1024;
-        float ss[STATS ? 8 : 1], sq[STATS ? 8 : 1];        // after the transpose a lane owns channels 8*(lane&3)..+7
-#pragma unroll
-        for (int k = 0; k < (STATS ? 8 : 1); ++k) ss[k] = sq[k] = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             int mt = wave * 4 + t;
@@ -229,24 +225,35 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
                         const uint32_t wv[4] = {ov.x, ov.y, ov.z, ov.w};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            float u0 = act_fwd(stat_pre, __uint_as_float(wv[k] << 16)), u1 = act_fwd(stat_pre, __uint_as_float(wv[k] & 0xffff0000u));
+                            float u0 = __uint_as_float(wv[k] << 16), u1 = __uint_as_float(wv[k] & 0xffff0000u);
+                            if (STATS == 2) { u0 = u0 > 0.f ? u0 : 0.01f * u0; u1 = u1 > 0.f ? u1 : 0.01f * u1; }
+                            else if (STATS == 3) { u0 = act_fwd(stat_pre, u0); u1 = act_fwd(stat_pre, u1); }
                             ss[2 * k] += u0; sq[2 * k] += u0 * u0; ss[2 * k + 1] += u1; sq[2 * k + 1] += u1 * u1;
                         }
                     }
                 }
             }
         }
-        if (STATS) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                atomicAdd(&sR[8 * (lane & 3) + k], ss[k]);
-                atomicAdd(&sR[32 + 8 * (lane & 3) + k], sq[k]);
-            }
-        }
     }
     if (STATS) {
+        // lanes with equal (lane & 3) hold different pixels of the same 8 channels: butterfly over lane bits 2..5, LDS, fp64 atomics
+        // (once per block: LDS float atomics are slow, a per-tile flush of the partials cost +70 % kernel time)
         __syncthreads();
-        if (tid < 64) atomicAdd(&stats[tid], (double)sR[tid]);
+        float* red = reinterpret_cast<float*>(sX);
+        if (tid < 64) red[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float a = ss[k], b = sq[k];
+#pragma unroll
+            for (int o = 32; o > 2; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            if (lane < 4) {
+                atomicAdd(&red[8 * lane + k], a);
+                atomicAdd(&red[32 + 8 * lane + k], b);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) atomicAdd(&stats[tid], (double)red[tid]);
     }
 }
 
@@ -279,7 +286,7 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
     const bool vert = (KW == 1 && KH > 1);
     const int TH = vert ? 64 : 8, TW = vert ? 8 : 64;
     const int LH = TH + KH - 1, LW = TW + KW - 1;
-    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * IPS + 128 + 4096 + 256;
+    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * IPS + 128 + 4096;
     TCCT_CHECK(lds <= 80 * 1024, "conv32_fwd: %dx%d needs %zu B of LDS (> 80 KiB for 2 blocks/CU)", KH, KW, lds);
     TCCT_CHECK(LH * LW * 4 <= MAXL * MB, "conv32_fwd: %dx%d tile image exceeds the staging slots", KH, KW);
     int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
@@ -294,7 +301,13 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
         hipLaunchKernelGGL((k_conv32_mfma<V, S, KHT, KWT>), dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, \
                            KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum, stats, stat_pre);                \
     } while (0)
-#define CF_S(V, KHT, KWT) do { if (stats) CF_LAUNCH(V, true, KHT, KWT); else CF_LAUNCH(V, false, KHT, KWT); } while (0)
+#define CF_S(V, KHT, KWT)                                                                                   \
+    do {                                                                                                    \
+        if (!stats) CF_LAUNCH(V, 0, KHT, KWT);                                                              \
+        else if (stat_pre == TCCT_ACT_NONE) CF_LAUNCH(V, 1, KHT, KWT);                                      \
+        else if (stat_pre == TCCT_ACT_LRELU) CF_LAUNCH(V, 2, KHT, KWT);                                     \
+        else CF_LAUNCH(V, 3, KHT, KWT);                                                                     \
+    } while (0)
     // compile-time taps for the shapes that carry the time (3x3 everywhere; the level-0/1 cross convolutions); generic otherwise
     if (KH == 3 && KW == 3) CF_S(false, 3, 3);
     else if (KH == 1 && KW == 13) CF_S(false, 1, 13);

@@ -36,6 +36,9 @@ def main():
         if 'conv' in which:
             ms = timeit(lambda: lib.conv32_fwd(x, wp, b, y, B, H, W, kh, kw, (kh - 1) // 2, (kw - 1) // 2))
             print(f'conv32_fwd {kh}x{kw}: {ms:.3f} ms  {fl / ms * 1e3:.1f} TFLOP/s  {2 * gb / ms * 1e3:.0f} GB/s algorithmic')
+            st = torch.zeros(64, device='cuda', dtype=torch.float64)
+            ms = timeit(lambda: lib.conv32_fwd_bnstats(x, wp, b, y, B, H, W, kh, kw, (kh - 1) // 2, (kw - 1) // 2, st, 1))
+            print(f'conv32_fwd_bnstats {kh}x{kw}: {ms:.3f} ms')
         if 'wgrad' in which:
             dw = torch.empty_like(w)
             db = torch.empty(32, device='cuda')
