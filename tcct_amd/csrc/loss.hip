@@ -222,7 +222,7 @@ extern "C" int tcct_label_planes(const uint8_t* labels, float* onehot, float* ed
 // Block = 64 columns (lanes, so the 4 channels of a pixel sit in adjacent lanes) x GSEG row segments: each thread walks H/GSEG
 // rows of its column (online max/sum), segment partials are merged through LDS.  z is recomputed per pass (2 x logf per element
 // is cheaper than a third tensor round trip).
-#define GSEG 4
+#define GSEG 8
 __device__ __forceinline__ float gumbel_z(float x, float e) { return x - 0.5f * logf(-logf(e)); }
 
 template <int CH>
@@ -327,65 +327,102 @@ extern "C" int tcct_gumbel_colsoftmax_bwd(const float* x, const float* eps, cons
 }
 
 // ----------------------------------------------------------------------- column (over H) softmax and weighted column sum, fp32 [N,H,W]
-__global__ void k_colsoftmax_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W) {
-    const int64_t cols = (int64_t)N * W;
-    for (int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; col < cols; col += (int64_t)gridDim.x * blockDim.x) {
-        const float* xp = x + (col / W) * (int64_t)H * W + (col % W);
-        float* yp = y + (col / W) * (int64_t)H * W + (col % W);
-        float m = -INFINITY, Z = 0.f;
-        for (int h = 0; h < H; ++h) {
-            float z = xp[(int64_t)h * W];
-            float mn = fmaxf(m, z);
-            Z = Z * __expf(m - mn) + __expf(z - mn);
-            m = mn;
-        }
-        float inv = 1.f / Z;
-        for (int h = 0; h < H; ++h) yp[(int64_t)h * W] = __expf(xp[(int64_t)h * W] - m) * inv;
-    }
+// N*W columns only (8 832 at the bench shape): one thread per column leaves the chip empty and every thread walking 800 dependent
+// rows.  Block = 64 adjacent columns x CSEG row segments (lanes run along W => coalesced rows), segment partials combined in LDS.
+#define CSEG 16
+struct ColPos { int64_t off; int h0, h1, lane, seg; bool ok; };
+__device__ __forceinline__ ColPos col_pos(int N, int H, int W) {
+    ColPos p;
+    p.lane = threadIdx.x & 63; p.seg = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + p.lane;
+    p.ok = col < (int64_t)N * W;
+    const int64_t cc = p.ok ? col : 0;
+    p.off = (cc / W) * (int64_t)H * W + (cc % W);
+    const int hs = (H + CSEG - 1) / CSEG;
+    p.h0 = p.seg * hs; p.h1 = min(H, p.h0 + hs);
+    return p;
 }
-__global__ void k_colsoftmax_bwd(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W) {
-    const int64_t cols = (int64_t)N * W;
-    for (int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; col < cols; col += (int64_t)gridDim.x * blockDim.x) {
-        int64_t off = (col / W) * (int64_t)H * W + (col % W);
-        float dot = 0.f;
-        for (int h = 0; h < H; ++h) dot += y[off + (int64_t)h * W] * dy[off + (int64_t)h * W];
-        for (int h = 0; h < H; ++h) dx[off + (int64_t)h * W] = y[off + (int64_t)h * W] * (dy[off + (int64_t)h * W] - dot);
+__global__ void __launch_bounds__(64 * CSEG) k_colsoftmax_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W) {
+    __shared__ float sm[CSEG][64], sz[CSEG][64];
+    const ColPos p = col_pos(N, H, W);
+    const float* xp = x + p.off;
+    float m = -INFINITY, Z = 0.f;
+    for (int h = p.h0; h < p.h1; ++h) {
+        float z = xp[(int64_t)h * W];
+        float mn = fmaxf(m, z);
+        Z = Z * __expf(m - mn) + __expf(z - mn);
+        m = mn;
     }
+    sm[p.seg][p.lane] = m; sz[p.seg][p.lane] = Z;
+    __syncthreads();
+    m = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < CSEG; ++g) m = fmaxf(m, sm[g][p.lane]);
+    Z = 0.f;
+#pragma unroll
+    for (int g = 0; g < CSEG; ++g) { float mg = sm[g][p.lane]; Z += mg == -INFINITY ? 0.f : sz[g][p.lane] * __expf(mg - m); }
+    const float inv = 1.f / Z;
+    if (p.ok)
+        for (int h = p.h0; h < p.h1; ++h) y[p.off + (int64_t)h * W] = __expf(xp[(int64_t)h * W] - m) * inv;
+}
+__global__ void __launch_bounds__(64 * CSEG) k_colsoftmax_bwd(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W) {
+    __shared__ float sd[CSEG][64];
+    const ColPos p = col_pos(N, H, W);
+    float dot = 0.f;
+    for (int h = p.h0; h < p.h1; ++h) dot += y[p.off + (int64_t)h * W] * dy[p.off + (int64_t)h * W];
+    sd[p.seg][p.lane] = dot;
+    __syncthreads();
+    dot = 0.f;
+#pragma unroll
+    for (int g = 0; g < CSEG; ++g) dot += sd[g][p.lane];
+    if (p.ok)
+        for (int h = p.h0; h < p.h1; ++h) dx[p.off + (int64_t)h * W] = y[p.off + (int64_t)h * W] * (dy[p.off + (int64_t)h * W] - dot);
 }
 extern "C" int tcct_colsoftmax_fwd(const float* x, float* y, int N, int H, int W, tcct_stream_t stream) {
-    hipLaunchKernelGGL(k_colsoftmax_fwd, dim3(tcct_grid((int64_t)N * W, 64, 1 << 16)), dim3(64), 0, (hipStream_t)stream, x, y, N, H, W);
+    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1, "colsoftmax_fwd: empty tensor");
+    hipLaunchKernelGGL(k_colsoftmax_fwd, dim3((unsigned)(((int64_t)N * W + 63) / 64)), dim3(64 * CSEG), 0, (hipStream_t)stream, x, y, N, H, W);
     TCCT_LAUNCH_OK();
 }
 extern "C" int tcct_colsoftmax_bwd(const float* y, const float* dy, float* dx, int N, int H, int W, tcct_stream_t stream) {
-    hipLaunchKernelGGL(k_colsoftmax_bwd, dim3(tcct_grid((int64_t)N * W, 64, 1 << 16)), dim3(64), 0, (hipStream_t)stream, y, dy, dx, N, H, W);
+    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1, "colsoftmax_bwd: empty tensor");
+    hipLaunchKernelGGL(k_colsoftmax_bwd, dim3((unsigned)(((int64_t)N * W + 63) / 64)), dim3(64 * CSEG), 0, (hipStream_t)stream, y, dy, dx, N, H, W);
     TCCT_LAUNCH_OK();
 }
 
 // edge[n,w] = sum_h x[n,h,w] * wts[h]   (column soft-argmax, nets/reg.py:146-150; wts = (h + jitter - .5)/H)
-__global__ void k_colwsum_fwd(const float* __restrict__ x, const float* __restrict__ wts, float* __restrict__ out, int N, int H, int W) {
-    const int64_t cols = (int64_t)N * W;
-    for (int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; col < cols; col += (int64_t)gridDim.x * blockDim.x) {
-        const float* xp = x + (col / W) * (int64_t)H * W + (col % W);
-        float s = 0.f;
-        for (int h = 0; h < H; ++h) s += xp[(int64_t)h * W] * wts[h];
-        out[col] = s;
+__global__ void __launch_bounds__(64 * CSEG) k_colwsum_fwd(const float* __restrict__ x, const float* __restrict__ wts, float* __restrict__ out, int N, int H, int W) {
+    __shared__ float sd[CSEG][64];
+    const ColPos p = col_pos(N, H, W);
+    float s = 0.f;
+    for (int h = p.h0; h < p.h1; ++h) s += x[p.off + (int64_t)h * W] * wts[h];
+    sd[p.seg][p.lane] = s;
+    __syncthreads();
+    if (p.seg == 0 && p.ok) {
+        s = 0.f;
+#pragma unroll
+        for (int g = 0; g < CSEG; ++g) s += sd[g][p.lane];
+        out[(int64_t)blockIdx.x * 64 + p.lane] = s;
     }
 }
 __global__ void k_colwsum_bwd(const float* __restrict__ dout, const float* __restrict__ wts, float* __restrict__ dx, int N, int H, int W) {
-    const int64_t total = (int64_t)N * H * W;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int w = (int)(i % W);
-        int64_t r = i / W;
-        int h = (int)(r % H);
-        dx[i] = dout[(r / H) * W + w] * wts[h];
+    // grid.y strides over rows (n, h); threads run along W: no per-element index division
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    for (int row = blockIdx.y; row < N * H; row += gridDim.y) {
+        const int n = row / H, h = row - n * H;
+        dx[(int64_t)row * W + w] = dout[(int64_t)n * W + w] * wts[h];
     }
 }
 extern "C" int tcct_colwsum_fwd(const float* x, const float* wts, float* out, int N, int H, int W, tcct_stream_t stream) {
-    hipLaunchKernelGGL(k_colwsum_fwd, dim3(tcct_grid((int64_t)N * W, 64, 1 << 16)), dim3(64), 0, (hipStream_t)stream, x, wts, out, N, H, W);
+    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1, "colwsum_fwd: empty tensor");
+    hipLaunchKernelGGL(k_colwsum_fwd, dim3((unsigned)(((int64_t)N * W + 63) / 64)), dim3(64 * CSEG), 0, (hipStream_t)stream, x, wts, out, N, H, W);
     TCCT_LAUNCH_OK();
 }
 extern "C" int tcct_colwsum_bwd(const float* dout, const float* wts, float* dx, int N, int H, int W, tcct_stream_t stream) {
-    hipLaunchKernelGGL(k_colwsum_bwd, dim3(tcct_grid((int64_t)N * H * W, LB, 1 << 16)), dim3(LB), 0, (hipStream_t)stream, dout, wts, dx, N, H, W);
+    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1, "colwsum_bwd: empty tensor");
+    const int64_t rows = (int64_t)N * H;
+    dim3 g((unsigned)((W + LB - 1) / LB), (unsigned)(rows < 2048 ? rows : 2048));
+    hipLaunchKernelGGL(k_colwsum_bwd, g, dim3(LB), 0, (hipStream_t)stream, dout, wts, dx, N, H, W);
     TCCT_LAUNCH_OK();
 }
 
