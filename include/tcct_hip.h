@@ -129,6 +129,13 @@ int tcct_conv32_fwd(const void* x, const void* wp, const float* bias, void* y, i
  * squares} of pre_act(y), y as stored -- replaces the tcct_bn_stats pass (conv -> [LeakyReLU ->] BN, nets/tcct.py:808-822,892) */
 int tcct_conv32_fwd_bnstats(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
                             int PW, double* stats, int pre_act, tcct_stream_t stream);
+/* Inference epilogues (eval-mode nn.BatchNorm2d folded into the producing convolution; reference kite/loop_seg.py:21-33
+ * runs the same modules under model.eval()):  y = post_act(a[c] * pre_act(conv(x) + bias[c]) + b[c]),  ab = {a[C], b[C]} from
+ * tcct_bn_eval_ab (NULL: a = 1, b = 0, activations only).  Same operands as tcct_conv32_fwd / tcct_pw_fwd. */
+int tcct_conv32_fwd_affine(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
+                           int PH, int PW, const float* ab, int pre_act, int post_act, tcct_stream_t stream);
+int tcct_pw_fwd_affine(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, const float* ab,
+                       int pre_act, int post_act, int out_dtype, tcct_stream_t stream);
 /* the same kernels on 32-channel slabs of wider NHWC tensors (x: xs channels/pixel, slab at xo; y: ys, yo; accumulate adds
  * into y) and on 32x32 sub-blocks (o_off, i_off) of an OIHW weight with cin_total input channels: 32->64 / 64->32 convolutions
  * (MPViT stem[1], nets/tcct.py:682-689) run as 32x32 sub-GEMMs.  wgrad_strided ACCUMULATES: zero dw/dbias first. */
@@ -149,7 +156,7 @@ int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float* dbias, in
 int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                 int out_dtype, tcct_stream_t stream);
 int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
-/* pw_fwd + fused train-mode BatchNorm statistics of the consumer (bf16 output, N in {32,64,96}); stats fp64 [2N], zero on entry */
+/* pw_fwd + fused train-mode BatchNorm statistics of the consumer (bf16 output, N in {32,64,96,128}); stats fp64 [2N], zero on entry */
 int tcct_pw_fwd_bnstats(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats, int pre_act,
                         tcct_stream_t stream);
 
@@ -199,6 +206,11 @@ int tcct_softmax_pick(const void* logits, const uint8_t* labels, int64_t M, int 
 /* out[N][C][3] = per-sample {|pred&lab|, |pred|, |lab|} per class (MDiceLoss/MIouLoss.score, kite/losses/miou.py:28-91) */
 int tcct_confusion_counts(const uint8_t* pred, const uint8_t* labels, int N, int64_t HW, int C, float* out,
                           tcct_stream_t stream);
+
+/* layer-boundary coordinates of a class-index mask [N,H,W] (KiteSeg.predict output): out int32 [N][C-1][W],
+ * out[n][k-1][w] = number of rows h with mask[n,h,w] < k = the row where layer k starts in column w of a layered segmentation
+ * (the boundary-coordinate extractor the reference lacks -- it only carries the unused soft_argmax, nets/reg.py:27-35) */
+int tcct_mask_boundaries(const uint8_t* mask, int32_t* out, int N, int H, int W, int C, tcct_stream_t stream);
 
 /* ---- boundary-regression loss pieces (RegNet.regular_reg, nets/reg.py:109-156); this pipeline is fp32 -------- */
 int tcct_slice_channels_fwd(const void* x, float* y, int64_t M, int C, int start, int n, int dtype, tcct_stream_t stream);

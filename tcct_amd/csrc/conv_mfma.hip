@@ -52,11 +52,12 @@ extern "C" int tcct_conv32_pack_weights_sub(const float* w, void* wp, int KH, in
 // removed it still took 0.20 of 0.29 ms -- XOR-swizzle address arithmetic (6 VALU ops per fragment read, ~1000 per tile and wave)
 // in front of every ds_read.  Now the image rows are padded instead of swizzled and KH/KW are template constants, so a B
 // fragment read is `ds_read_b128 v, base_t offset:imm` with NO per-read VALU work (KH_ = 0 keeps a runtime-tap fallback).
-template <bool VERT, int STATS, int KH_, int KW_>      // STATS: 0 none, 1 stats of y, 2 stats of LeakyReLU(y), 3 stats of act(stat_pre, y)
+template <bool VERT, int STATS, int KH_, int KW_>      // STATS: 0 none, 1 stats of y, 2 stats of LeakyReLU(y), 3 stats of act(stat_pre, y),
+                                                           // 4: inference epilogue y = post(a[c] * pre(conv + bias) + b[c]) (eval-mode BatchNorm folded in)
 __global__ void __launch_bounds__(MB, 2)
 k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
               int N, int H, int W, int KHr, int KWr, int PH, int PW, int tilesH, int tilesW, int ntiles, int xs, int xo, int ys,
-              int yo, int accum, double* __restrict__ stats, int stat_pre) {
+              int yo, int accum, double* __restrict__ stats, int stat_pre, const float* __restrict__ aff, int aff_post) {
     // xs/xo, ys/yo: channels per pixel in memory and channel offset of the 32-channel slab read / written; accum: y += result
     // stats != NULL (STATS): also accumulate per-channel sum / sum-of-squares of pre_act(y) (y as stored, i.e. bf16-rounded) into
     // stats[0..31] / stats[32..63] -- the train-mode BatchNorm statistics of the consumer, fused into this epilogue
@@ -79,7 +80,8 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
     // bias lives in LDS (behind the input image) and is re-read in the epilogue: 16 fewer live VGPRs in the MFMA loop
     float* sB = reinterpret_cast<float*>(sX + LH * LW * IPS);
     if (tid < 32) sB[tid] = bias ? bias[tid] : 0.f;
-    unsigned char* sS = reinterpret_cast<unsigned char*>(sB + 32);          // epilogue transpose scratch: 4 waves x 1 KB
+    if (STATS == 4 && tid < 64) sB[32 + tid] = aff ? aff[tid] : (tid < 32 ? 1.f : 0.f);     // a[32], b[32] of the folded BatchNorm
+    unsigned char* sS = reinterpret_cast<unsigned char*>(sB + 96);          // epilogue transpose scratch: 4 waves x 1 KB
 
     // slot geometry (tile independent): slot j covers 16-byte chunk c of tile-local pixel (lr, lc); (lr,lc) packed in one int
     const int c = tid & 3;
@@ -120,9 +122,9 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         int pb = VERT ? a * LH + seg * 32 + r : a * LW + seg * 32 + r;
         xB[t] = sX + pb * IPS + hh * 16;
     }
-    float ss[STATS ? 8 : 1], sq[STATS ? 8 : 1];        // BN statistics: after the transpose a lane owns channels 8*(lane&3)..+7
+    float ss[(STATS >= 1 && STATS <= 3) ? 8 : 1], sq[(STATS >= 1 && STATS <= 3) ? 8 : 1];        // BN statistics: after the transpose a lane owns channels 8*(lane&3)..+7
 #pragma unroll
-    for (int k = 0; k < (STATS ? 8 : 1); ++k) ss[k] = sq[k] = 0.f;
+    for (int k = 0; k < ((STATS >= 1 && STATS <= 3) ? 8 : 1); ++k) ss[k] = sq[k] = 0.f;
     int tile = blockIdx.x;
     if (tile < ntiles) prefetch(tile);
     for (; tile < ntiles; tile += gridDim.x) {
@@ -202,6 +204,14 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
                     float v0 = acc[t][4 * q] + bq.x, v1 = acc[t][4 * q + 1] + bq.y;
                     float v2 = acc[t][4 * q + 2] + bq.z, v3 = acc[t][4 * q + 3] + bq.w;
                     if (accum) { f4 old = ld4(yold + 8 * q); v0 += old.v[0]; v1 += old.v[1]; v2 += old.v[2]; v3 += old.v[3]; }
+                    if (STATS == 4) {
+                        const float4 aq = *reinterpret_cast<const float4*>(sB + 32 + 8 * q + 4 * hh);
+                        const float4 cq = *reinterpret_cast<const float4*>(sB + 64 + 8 * q + 4 * hh);
+                        float v4[4] = {v0, v1, v2, v3};
+                        const float a4[4] = {aq.x, aq.y, aq.z, aq.w}, b4[4] = {cq.x, cq.y, cq.z, cq.w};
+                        affine4(v4, a4, b4, stat_pre, aff_post);
+                        v0 = v4[0]; v1 = v4[1]; v2 = v4[2]; v3 = v4[3];
+                    }
                     o[q].x = pack_bf16x2(v0, v1);
                     o[q].y = pack_bf16x2(v2, v3);
                 }
@@ -221,7 +231,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
                 const int wo = VERT ? w0 + a : w0 + seg * 32 + pr;
                 if (ho < H && wo < W) {
                     *reinterpret_cast<uint4*>(y + (((int64_t)n * H + ho) * W + wo) * ys + yo + cch * 8) = ov;
-                    if (STATS) {
+                    if (STATS >= 1 && STATS <= 3) {
                         const uint32_t wv[4] = {ov.x, ov.y, ov.z, ov.w};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -235,7 +245,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
             }
         }
     }
-    if (STATS) {
+    if (STATS >= 1 && STATS <= 3) {
         // lanes with equal (lane & 3) hold different pixels of the same 8 channels: butterfly over lane bits 2..5, LDS, fp64 atomics
         // (once per block: LDS float atomics are slow, a per-tile flush of the partials cost +70 % kernel time)
         __syncthreads();
@@ -260,7 +270,8 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
 /* x, y: bf16 NHWC [N,H,W,32]; wp: packed bf16 [KH*KW][32][32] from tcct_conv32_pack_weights; stride 1; output size == input
  * size requires PH = (KH-1)/2 etc. but any PH <= KH-1, PW <= KW-1 with "same" output extent H x W is accepted. */
 static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
-                           int PH, int PW, int xs, int xo, int ys, int yo, int accum, double* stats, int stat_pre, tcct_stream_t stream);
+                           int PH, int PW, int xs, int xo, int ys, int yo, int accum, double* stats, int stat_pre, tcct_stream_t stream,
+                           const float* aff = nullptr, int aff_post = 0, bool affine = false);
 extern "C" int tcct_conv32_fwd(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
                                int PH, int PW, tcct_stream_t stream) {
     return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, 0, nullptr, 0, stream);
@@ -271,6 +282,12 @@ extern "C" int tcct_conv32_fwd_bnstats(const void* x, const void* wp, const floa
                                        int PH, int PW, double* stats, int pre_act, tcct_stream_t stream) {
     return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, 0, stats, pre_act, stream);
 }
+/* inference: y = post_act(a[c] * pre_act(conv(x) + bias[c]) + b[c]) with ab = {a[32], b[32]} (eval-mode BatchNorm folded into
+ * the epilogue, tcct_bn_eval_ab; ab == NULL: a = 1, b = 0, i.e. only the activations) -- no separate normalisation pass */
+extern "C" int tcct_conv32_fwd_affine(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
+                                      int PH, int PW, const float* ab, int pre_act, int post_act, tcct_stream_t stream) {
+    return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, 0, nullptr, pre_act, stream, ab, post_act, true);
+}
 /* same kernel on 32-channel slabs of wider tensors: x has xs channels/pixel (slab at xo), y has ys (slab at yo); accumulate=1
  * adds into y.  Used to run 32->64 / 64->32 convolutions (MPViT stem[1], nets/tcct.py:682-689) as 32x32 sub-GEMMs. */
 extern "C" int tcct_conv32_fwd_strided(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH,
@@ -280,13 +297,14 @@ extern "C" int tcct_conv32_fwd_strided(const void* x, const void* wp, const floa
     return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, xs, xo, ys, yo, accumulate, nullptr, 0, stream);
 }
 static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
-                           int PH, int PW, int xs, int xo, int ys, int yo, int accum, double* stats, int stat_pre, tcct_stream_t stream) {
+                           int PH, int PW, int xs, int xo, int ys, int yo, int accum, double* stats, int stat_pre, tcct_stream_t stream,
+                           const float* aff, int aff_post, bool affine) {
     TCCT_CHECK(KH >= 1 && KW >= 1 && KH * KW <= 13 * 13, "conv32_fwd: bad kernel %dx%d", KH, KW);
     TCCT_CHECK(2 * PH == KH - 1 && 2 * PW == KW - 1, "conv32_fwd: only 'same' padding (got pad %d,%d for %dx%d)", PH, PW, KH, KW);
     const bool vert = (KW == 1 && KH > 1);
     const int TH = vert ? 64 : 8, TW = vert ? 8 : 64;
     const int LH = TH + KH - 1, LW = TW + KW - 1;
-    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * IPS + 128 + 4096;
+    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * IPS + 384 + 4096;
     TCCT_CHECK(lds <= 80 * 1024, "conv32_fwd: %dx%d needs %zu B of LDS (> 80 KiB for 2 blocks/CU)", KH, KW, lds);
     TCCT_CHECK(LH * LW * 4 <= MAXL * MB, "conv32_fwd: %dx%d tile image exceeds the staging slots", KH, KW);
     int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
@@ -299,11 +317,12 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
         static bool attr = false;                                                                                           \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_mfma<V, S, KHT, KWT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
         hipLaunchKernelGGL((k_conv32_mfma<V, S, KHT, KWT>), dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, \
-                           KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum, stats, stat_pre);                \
+                           KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum, stats, stat_pre, aff, aff_post);                \
     } while (0)
 #define CF_S(V, KHT, KWT)                                                                                   \
     do {                                                                                                    \
-        if (!stats) CF_LAUNCH(V, 0, KHT, KWT);                                                              \
+        if (affine) CF_LAUNCH(V, 4, KHT, KWT);                                                              \
+        else if (!stats) CF_LAUNCH(V, 0, KHT, KWT);                                                           \
         else if (stat_pre == TCCT_ACT_NONE) CF_LAUNCH(V, 1, KHT, KWT);                                      \
         else if (stat_pre == TCCT_ACT_LRELU) CF_LAUNCH(V, 2, KHT, KWT);                                     \
         else CF_LAUNCH(V, 3, KHT, KWT);                                                                     \

@@ -426,6 +426,41 @@ extern "C" int tcct_colwsum_bwd(const float* dout, const float* wts, float* dx, 
     TCCT_LAUNCH_OK();
 }
 
+// ----------------------------------------------------------------------- layer-boundary coordinates from a class-index mask
+// out[n][k-1][w] = #{h : mask[n,h,w] < k}, k = 1..C-1: for a layered (top-to-bottom monotone) segmentation this is the row at which
+// layer k starts in column w; counting instead of searching the first switch keeps isolated mislabelled pixels from moving the
+// boundary by more than one row each (the reference only has the unused soft_argmax, nets/reg.py:27-35).
+__global__ void __launch_bounds__(64 * CSEG) k_mask_boundaries(const uint8_t* __restrict__ mask, int32_t* __restrict__ out, int N, int H, int W, int C) {
+    __shared__ int sc[CSEG][MAXC][64];
+    const ColPos p = col_pos(N, H, W);
+    int cnt[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) cnt[k] = 0;
+    for (int h = p.h0; h < p.h1; ++h) {
+        const int l = mask[p.off + (int64_t)h * W];
+#pragma unroll
+        for (int k = 1; k < MAXC; ++k) cnt[k] += (l < k);
+    }
+#pragma unroll
+    for (int k = 1; k < MAXC; ++k) sc[p.seg][k][p.lane] = cnt[k];
+    __syncthreads();
+    if (p.ok)
+        for (int k = 1 + p.seg; k < C; k += CSEG) {
+            int s = 0;
+#pragma unroll
+            for (int g = 0; g < CSEG; ++g) s += sc[g][k][p.lane];
+            const int64_t col = (int64_t)blockIdx.x * 64 + p.lane;
+            const int64_t n = col / W, w = col % W;
+            out[(n * (C - 1) + (k - 1)) * W + w] = s;
+        }
+}
+extern "C" int tcct_mask_boundaries(const uint8_t* mask, int32_t* out, int N, int H, int W, int C, tcct_stream_t stream) {
+    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1, "mask_boundaries: empty tensor");
+    TCCT_CHECK(C >= 2 && C <= MAXC, "mask_boundaries: C=%d unsupported (2..%d)", C, MAXC);
+    hipLaunchKernelGGL(k_mask_boundaries, dim3((unsigned)(((int64_t)N * W + 63) / 64)), dim3(64 * CSEG), 0, (hipStream_t)stream, mask, out, N, H, W, C);
+    TCCT_LAUNCH_OK();
+}
+
 // ----------------------------------------------------------------------- mean squared error on fp32 vectors (nn.MSELoss, reg.py:108)
 __global__ void k_mse_fwd(const float* __restrict__ a, const float* __restrict__ b, int64_t n, double* __restrict__ acc) {
     __shared__ float sm[16];

@@ -29,10 +29,12 @@ __device__ __forceinline__ float rnd_out(float v, const float*) { return v; }
 
 // STATS: also accumulate per-channel sum / sum of squares of pre_act(y) (y as stored) into stats[0..N) / stats[N..2N): the
 // train-mode BatchNorm statistics of the consumer (Conv2d_BN, DWConv2d_BN.pwconv, tran_*; reference nets/tcct.py:80,125,966-974)
-template <int NT, typename Tout, bool STATS>
+template <int NT, typename Tout, bool STATS, bool AFF>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, Tout* __restrict__ y,
-         int64_t M, int K, int N, int transposed, double* __restrict__ stats, int stat_pre) {
+         int64_t M, int K, int N, int transposed, double* __restrict__ stats, int stat_pre, const float* __restrict__ aff,
+         int aff_pre, int aff_post) {
+    // aff != NULL or aff_pre/aff_post != 0 (inference only): y = post(a[c] * pre(x W + bias) + b[c]), aff = {a[N], b[N]}
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int SW = 2 * K + 16;                 // LDS row stride (bytes)
     const int scr_off = (NT * 32 * SW + 15) & ~15;   // per-wave epilogue transpose scratch (4 x 2560 B) behind the weights
@@ -48,11 +50,13 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
         *reinterpret_cast<bf16*>(smem + row * SW + k * 2) = __float2bfloat16(v);
     }
     __syncthreads();
-    float ss[STATS ? NT : 1][16], sq[STATS ? NT : 1][16];
+    // statistics are taken after the epilogue transpose, where a lane owns 8 channels of each N-tile: 16 registers per tile
+    // (32 before the transpose, which spilled for NT = 3); STATS implies bf16 output with N % 32 == 0
+    float ss[STATS ? NT : 1][8], sq[STATS ? NT : 1][8];
 #pragma unroll
     for (int a = 0; a < (STATS ? NT : 1); ++a)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) ss[a][k] = sq[a][k] = 0.f;
+        for (int k = 0; k < 8; ++k) ss[a][k] = sq[a][k] = 0.f;
     const int KT = K >> 5;
     const int64_t mtiles = (M + 31) >> 5;
     for (int64_t mt = (int64_t)blockIdx.x * 4 + wave; mt < mtiles; mt += (int64_t)gridDim.x * 4) {
@@ -95,13 +99,13 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                     float v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = acc[nt][4 * q + k] + (bias ? bias[co + k] : 0.f);
-                    uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-                    if (STATS && ok) {
-                        float u0 = act_fwd(stat_pre, __uint_as_float(o.x << 16)), u1 = act_fwd(stat_pre, __uint_as_float(o.x & 0xffff0000u));
-                        float u2 = act_fwd(stat_pre, __uint_as_float(o.y << 16)), u3 = act_fwd(stat_pre, __uint_as_float(o.y & 0xffff0000u));
-                        ss[nt][4 * q] += u0; sq[nt][4 * q] += u0 * u0; ss[nt][4 * q + 1] += u1; sq[nt][4 * q + 1] += u1 * u1;
-                        ss[nt][4 * q + 2] += u2; sq[nt][4 * q + 2] += u2 * u2; ss[nt][4 * q + 3] += u3; sq[nt][4 * q + 3] += u3 * u3;
+                    if (AFF) {
+                        float a4[4], b4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { a4[k] = aff ? aff[co + k] : 1.f; b4[k] = aff ? aff[N + co + k] : 0.f; }
+                        affine4(v, a4, b4, aff_pre, aff_post);
                     }
+                    uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
                     *reinterpret_cast<uint2*>(sc + r * 80 + (8 * q + 4 * hh) * 2) = o;
                 }
                 // same wave wrote and reads: LDS operations of one wave complete in order
@@ -110,7 +114,17 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                     const int p = (lane >> 2) + 16 * h2, cch = lane & 3;
                     const uint4 o = *reinterpret_cast<const uint4*>(sc + p * 80 + cch * 16);
                     const int64_t mm = mt * 32 + p;
-                    if (mm < M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(y) + mm * N + n_base + nt * 32 + cch * 8) = o;
+                    if (mm < M) {
+                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(y) + mm * N + n_base + nt * 32 + cch * 8) = o;
+                        if (STATS) {
+                            const uint32_t wv[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float u0 = act_fwd(stat_pre, __uint_as_float(wv[k] << 16)), u1 = act_fwd(stat_pre, __uint_as_float(wv[k] & 0xffff0000u));
+                                ss[nt][2 * k] += u0; sq[nt][2 * k] += u0 * u0; ss[nt][2 * k + 1] += u1; sq[nt][2 * k + 1] += u1 * u1;
+                            }
+                        }
+                    }
                 }
             }
         } else if (ok) {
@@ -122,12 +136,11 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                     float v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = acc[nt][4 * q + k] + ((bias && co + k < N) ? bias[co + k] : 0.f);
-                    if (STATS) {
+                    if (AFF) {
+                        float a4[4], b4[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            float u = act_fwd(stat_pre, rnd_out(v[k], y));
-                            ss[nt][4 * q + k] += u; sq[nt][4 * q + k] += u * u;
-                        }
+                        for (int k = 0; k < 4; ++k) { a4[k] = (aff && co + k < N) ? aff[co + k] : 1.f; b4[k] = (aff && co + k < N) ? aff[N + co + k] : 0.f; }
+                        affine4(v, a4, b4, aff_pre, aff_post);
                     }
                     if (co + 3 < N && (N & 3) == 0) st_out4(y + m * N + co, v[0], v[1], v[2], v[3]);
                     else {
@@ -147,14 +160,13 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < 8; ++k) {       // lanes with equal (lane & 3) hold different pixels of channels 8*(lane&3)+k
                 float a = ss[nt][k], b = sq[nt][k];
 #pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-                if (r == 0) {
-                    const int cl = nt * 32 + 8 * (k >> 2) + 4 * hh + (k & 3);
-                    atomicAdd(&red[cl], a);
-                    atomicAdd(&red[NT * 32 + cl], b);
+                for (int o = 32; o > 2; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (lane < 4) {
+                    atomicAdd(&red[nt * 32 + 8 * lane + k], a);
+                    atomicAdd(&red[NT * 32 + nt * 32 + 8 * lane + k], b);
                 }
             }
         __syncthreads();
@@ -168,19 +180,26 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
 /* x bf16 [M,K]; w fp32: [N,K] (transposed=0) or [K,N] (transposed=1: the input-gradient GEMM dx = dy * W);
  * y [M,N] bf16 or fp32. */
 static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
-                       int out_dtype, double* stats, int stat_pre, tcct_stream_t stream);
+                       int out_dtype, double* stats, int stat_pre, tcct_stream_t stream, const float* aff = nullptr, int aff_pre = 0,
+                       int aff_post = 0);
 extern "C" int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                            int out_dtype, tcct_stream_t stream) {
     return pw_fwd_impl(x, w, bias, y, M, K, N, transposed, out_dtype, nullptr, 0, stream);
 }
-/* forward + fused BatchNorm statistics of the consumer (bf16 output, N <= 96): stats fp64 [2N], zero on entry */
+/* forward + fused BatchNorm statistics of the consumer (bf16 output, N <= 128): stats fp64 [2N], zero on entry */
 extern "C" int tcct_pw_fwd_bnstats(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
                                    int pre_act, tcct_stream_t stream) {
-    TCCT_CHECK(N % 32 == 0 && N <= 96, "pw_fwd_bnstats: N=%d unsupported (32, 64, 96)", N);
+    TCCT_CHECK(N % 32 == 0 && N <= 128, "pw_fwd_bnstats: N=%d unsupported (32, 64, 96, 128)", N);
     return pw_fwd_impl(x, w, bias, y, M, K, N, 0, TCCT_BF16, stats, pre_act, stream);
 }
+/* inference: y = post_act(a[c] * pre_act(x W^T + bias[c]) + b[c]), ab = {a[N], b[N]} from tcct_bn_eval_ab (NULL: a = 1, b = 0):
+ * eval-mode BatchNorm and the adjacent activation(s) folded into the GEMM epilogue (Conv2d_BN, Mlp.fc1 + GELU, tran_*) */
+extern "C" int tcct_pw_fwd_affine(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, const float* ab,
+                                  int pre_act, int post_act, int out_dtype, tcct_stream_t stream) {
+    return pw_fwd_impl(x, w, bias, y, M, K, N, 0, out_dtype, nullptr, 0, stream, ab, pre_act, post_act);
+}
 static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
-                       int out_dtype, double* stats, int stat_pre, tcct_stream_t stream) {
+                       int out_dtype, double* stats, int stat_pre, tcct_stream_t stream, const float* aff, int aff_pre, int aff_post) {
     TCCT_CHECK(K % 32 == 0 && K >= 32 && K <= 512, "pw_fwd: K=%d must be a multiple of 32 (<=512)", K);
     TCCT_CHECK(N >= 1 && N <= 1024, "pw_fwd: N=%d", N);
     const int ntiles = (N + 31) / 32;
@@ -197,18 +216,25 @@ static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y
 #define PW_L(NTV, TO)                                                                                                        \
     do {                                                                                                                     \
         static bool attr = false;                                                                                            \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k_pw_fwd<NTV, TO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-        hipLaunchKernelGGL((k_pw_fwd<NTV, TO, false>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (TO*)y, M, K, N, transposed, nullptr, 0); \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_pw_fwd<NTV, TO, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((k_pw_fwd<NTV, TO, false, false>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (TO*)y, M, K, N, transposed, nullptr, 0, aff, aff_pre, aff_post); \
     } while (0)
 #define PW_D(TO)                                                                  \
     switch (NT) {                                                                 \
         case 1: PW_L(1, TO); break; case 2: PW_L(2, TO); break; case 3: PW_L(3, TO); break; \
         case 4: PW_L(4, TO); break; default: PW_L(5, TO); break;                  \
     }
-    if (stats) {
-#define PW_S(NTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd<NTV, bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
-        hipLaunchKernelGGL((k_pw_fwd<NTV, bf16, true>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (bf16*)y, M, K, N, transposed, stats, stat_pre); }
-        if (NT == 1) PW_S(1) else if (NT == 2) PW_S(2) else PW_S(3)
+    if (aff || aff_pre || aff_post) {       // inference epilogue: separate instantiations, the training kernels stay as they are
+        TCCT_CHECK(out_dtype == TCCT_BF16 && !stats, "pw_fwd_affine: bf16 output only");
+#define PW_A(NTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd<NTV, bf16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_fwd<NTV, bf16, false, true>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (bf16*)y, M, K, N, transposed, nullptr, 0, aff, aff_pre, aff_post); }
+        if (NT == 1) PW_A(1) else if (NT == 2) PW_A(2) else if (NT == 3) PW_A(3) else if (NT == 4) PW_A(4) else PW_A(5)
+#undef PW_A
+    }
+    else if (stats) {
+#define PW_S(NTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd<NTV, bf16, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_fwd<NTV, bf16, true, false>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (bf16*)y, M, K, N, transposed, stats, stat_pre, nullptr, 0, 0); }
+        if (NT == 1) PW_S(1) else if (NT == 2) PW_S(2) else if (NT == 3) PW_S(3) else PW_S(4)
 #undef PW_S
     }
     else if (out_dtype == TCCT_BF16) { PW_D(bf16); }

@@ -39,6 +39,14 @@ class MaskOneHot:
     def detach(self):
         return self
 
+    def boundaries(self):
+        """int32 [B, n_class-1, W]: row at which layer k = 1..n_class-1 starts in every column (number of pixels of the column
+        labelled < k) -- the boundary coordinates of a layered OCT segmentation, straight from the class-index mask on the GPU."""
+        B, H, W = self.index.shape
+        out = torch.empty((B, self.n_class - 1, W), device=self.index.device, dtype=torch.int32)
+        lib.mask_boundaries(self.index.contiguous(), out, B, H, W, self.n_class)
+        return out
+
 
 class MDiceLoss(nn.Module):
     @staticmethod

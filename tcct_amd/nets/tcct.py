@@ -32,6 +32,15 @@ def _bn(m, x, pre=None, post=None):
                          momentum=m.momentum, pre_act=pre, post_act=post, training=m.training)
 
 
+def _conv_bn(mc, mb, x, pre=None, post=None):
+    """post(BN(pre(conv(x)))).  Training: convolution with the BatchNorm statistics fused into its epilogue, then the BN pass;
+    eval under no_grad: one kernel, BatchNorm and activations folded into the convolution epilogue (ops.conv_bn_act)."""
+    if mb.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
+        return _bn(mb, _conv(mc, x, stats_pre=(pre or 'none') if mb.training else None), pre=pre, post=post)
+    return ops.conv_bn_act(x, mc.weight, mc.bias, mc.stride[0], tuple(mc.padding),
+                           (mb.weight, mb.bias, mb.running_mean, mb.running_var, mb.eps), pre, post)
+
+
 def _nchw_view(y):
     return y.permute(0, 3, 1, 2)
 
@@ -58,8 +67,13 @@ class CrossCNNBlock(nn.Module):
             c = ops.bn2_add_act(a, (m1.weight, m1.bias, m1.running_mean, m1.running_var, m1.num_batches_tracked, m1.eps, m1.momentum),
                                 b, (m2.weight, m2.bias, m2.running_mean, m2.running_var, m2.num_batches_tracked, m2.eps, m2.momentum))
         else:
-            c = ops.add_act(_bn(self.block12[3], a, pre='lrelu'), _bn(self.block34[4], b, pre='lrelu'), 'gelu')
-        return _bn(self.block5[2], _conv(self.block5[0], c, stats_pre='lrelu' if tr else None), pre='lrelu')
+            if torch.is_grad_enabled() or not ops.INFER_FUSE:
+                c = ops.add_act(_bn(self.block12[3], a, pre='lrelu'), _bn(self.block34[4], b, pre='lrelu'), 'gelu')
+            else:
+                m1, m2 = self.block12[3], self.block34[4]
+                c = ops.bn2_add_act_eval(a, (m1.weight, m1.bias, m1.running_mean, m1.running_var, m1.eps),
+                                         b, (m2.weight, m2.bias, m2.running_mean, m2.running_var, m2.eps))
+        return _conv_bn(self.block5[0], self.block5[2], c, pre='lrelu')
 
 
 class CrossResNet(nn.Module):
@@ -81,7 +95,11 @@ class CrossResNet(nn.Module):
     def forward(self, x):
         """x: NHWC [B,H,W,4] (3 image channels + zero pad)."""
         xs = []
-        x = _bn(self.cnn[1], ops.conv3x3_c3(x, self.cnn[0].weight, self.cnn[0].bias, 1, stats_pre='none' if self.training else None))
+        m = self.cnn[1]
+        if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
+            x = _bn(m, ops.conv3x3_c3(x, self.cnn[0].weight, self.cnn[0].bias, 1, stats_pre='none' if self.training else None))
+        else:
+            x = ops.conv3x3_c3(x, self.cnn[0].weight, self.cnn[0].bias, 1, infer_bn=(m.weight, m.bias, m.running_mean, m.running_var, m.eps))
         n = len(self.path_estan)
         for i, enc in enumerate(self.path_estan):
             x = enc(x)
@@ -106,10 +124,13 @@ class Conv2d_BN(nn.Module):
     def forward(self, x):
         sp = 'none' if self.training else None
         if self.conv.in_channels == 3:          # stem[0]: 3-channel input -> im2col + pointwise MFMA
-            y = ops.conv3x3_c3(x, self.conv.weight, None, self.conv.stride[0], stats_pre=sp)
-        else:
-            y = _conv(self.conv, x, stats_pre=sp)
-        return _bn(self.bn, y, post='hswish' if self.act else None)
+            if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
+                y = ops.conv3x3_c3(x, self.conv.weight, None, self.conv.stride[0], stats_pre=sp)
+                return _bn(self.bn, y, post='hswish' if self.act else None)
+            m = self.bn
+            return ops.conv3x3_c3(x, self.conv.weight, None, self.conv.stride[0], post_act='hswish' if self.act else None,
+                                  infer_bn=(m.weight, m.bias, m.running_mean, m.running_var, m.eps))
+        return _conv_bn(self.conv, self.bn, x, post='hswish' if self.act else None)
 
 
 class DWConv2d_BN(nn.Module):
@@ -125,7 +146,7 @@ class DWConv2d_BN(nn.Module):
             m.weight.data.normal_(0, math.sqrt(2.0 / n))
 
     def forward(self, x):
-        return _bn(self.bn, _conv(self.pwconv, _dw(self.dwconv, x), stats_pre='none' if self.training else None), post='hswish')
+        return _conv_bn(self.pwconv, self.bn, _dw(self.dwconv, x), post='hswish')
 
 
 class DWCPatchEmbed(nn.Module):
@@ -198,7 +219,10 @@ class MHCABlock(nn.Module):
         cur = ops.layernorm(t, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         t = ops.residual(t, ops.metapool(cur), s1)
         cur = ops.layernorm(t, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        h = ops.act(ops.conv2d(cur, self.mlp.fc1.weight, self.mlp.fc1.bias), 'gelu')
+        if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
+            h = ops.act(ops.conv2d(cur, self.mlp.fc1.weight, self.mlp.fc1.bias), 'gelu')
+        else:               # inference: GELU in the GEMM epilogue
+            h = ops.conv_bn_act(cur, self.mlp.fc1.weight, self.mlp.fc1.bias, post_act='gelu')
         t = ops.residual(t, ops.conv2d(h, self.mlp.fc2.weight, self.mlp.fc2.bias), s2)
         return t.view(B, H, W, C)
 
@@ -329,7 +353,7 @@ class MPUpBlock(nn.Module):
         self.post = nn.Sequential(nn.Conv2d(out_ch, out_ch, 1, 1, 0))
 
     def forward(self, x1, x2):
-        y = _bn(self.prep[1], _conv(self.prep[0], x1, stats_pre='none' if self.training else None), post='lrelu')
+        y = _conv_bn(self.prep[0], self.prep[1], x1, post='lrelu')
         y = ops.bilinear(y, (x1.shape[1] * 2, x1.shape[2] * 2), True)
         return _conv(self.post[0], ops.add(y, x2))
 
@@ -408,9 +432,8 @@ class FTC(nn.Module):
         f = [c1]
         for j, (v, c) in enumerate(((v2, c2), (v3, c3), (v4, c4), (v5, c5))):
             tv, tc = getattr(self, f'tran_vit{j}'), getattr(self, f'tran_cnn{j}')
-            sp = 'none' if self.training else None
-            f.append(ops.add(_bn(tv[1], _conv(tv[0], v, stats_pre=sp)), _bn(tc[1], _conv(tc[0], c, stats_pre=sp))))
-        y8 = _bn(self.head[1], _conv(self.head[0], f[4], stats_pre='none' if self.training else None), post='lrelu')
+            f.append(ops.add(_conv_bn(tv[0], tv[1], v), _conv_bn(tc[0], tc[1], c)))
+        y8 = _conv_bn(self.head[0], self.head[1], f[4], post='lrelu')
         d3 = self.dec1(y8, f[3])
         d2 = self.dec2(d3, f[2])
         d1 = self.dec3(d2, f[1])

@@ -147,7 +147,7 @@ class _Conv2d(torch.autograd.Function):
         y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=odt)
         mfma = _mfma32_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw)
         if _pw_ok(x.dtype, Cin, Cin_w, KH, KW, stride, padh, padw) and not mfma:
-            if stats_box is not None and odt == torch.bfloat16 and Cout in (32, 64, 96):
+            if stats_box is not None and odt == torch.bfloat16 and Cout % 32 == 0 and Cout <= 128:
                 sums = ZERO.get((2 * Cout,), torch.float64, x.device) if ZERO.active else torch.zeros(2 * Cout, device=x.device, dtype=torch.float64)
                 lib.pw_fwd_bnstats(x, w, bias, y, N * H * W, Cin, Cout, sums, stats_box[0])
                 stats_box[1] = sums
@@ -243,6 +243,65 @@ def conv2d(x, w, bias=None, stride=1, pad=0, out_dtype=None, stats_pre=None):
     return y
 
 
+INFER_FUSE = True       # eval-mode forward under no_grad folds BatchNorm / activations into the convolution epilogues (False: op by op)
+
+
+def conv_bn_act(x, w, bias=None, stride=1, pad=0, bn=None, pre_act=None, post_act=None):
+    """Inference only: post_act(BN_eval(pre_act(conv(x) + bias))) with the eval-mode BatchNorm and the activations
+    folded into the epilogue of the MFMA kernels -- no separate normalisation / activation pass over the output.
+    bn: None or (gamma, beta, running_mean, running_var, eps).  bf16 1x1 / 32->32 convolutions take the fused kernels; every
+    other shape (and the fp32 parity mode) runs convolution, `batchnorm(training=False)` and `act` one after the other."""
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        raise TcctError('conv_bn_act is inference-only (call it under torch.no_grad())')
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    tok = x.dim() == 3
+    x4 = x.unsqueeze(2) if tok else x
+    w4 = w.view(w.shape[0], w.shape[1], 1, 1) if w.dim() == 2 else w
+    _chk(x4, w4, bias)
+    N, H, W, Cin = x4.shape
+    Cout, Cin_w, KH, KW = w4.shape
+    pre, post = ACT[pre_act], ACT[post_act]
+    mfma = _mfma32_ok(x4.dtype, x4.dtype, Cin, Cin_w, Cout, KH, KW, stride, ph, pw)
+    pwk = _pw_ok(x4.dtype, Cin, Cin_w, KH, KW, stride, ph, pw) and not mfma and (bn is not None or pre != 0 or post != 0)
+    if not (mfma or pwk):
+        y = conv2d(x, w, bias, stride, pad)
+        if bn is not None:
+            return batchnorm(y, bn[0], bn[1], bn[2], bn[3], None, bn[4], 0.1, pre_act, post_act, training=False)
+        if pre != 0:
+            y = act(y, pre_act)
+        return act(y, post_act) if post != 0 else y
+    ab = None
+    if bn is not None:
+        ab = torch.empty(2 * Cout, device=x.device, dtype=torch.float32)
+        lib.bn_eval_ab(Cout, bn[0], bn[1], float(bn[4]), bn[2], bn[3], torch.empty(2 * Cout, device=x.device, dtype=torch.float32), ab)
+    y = torch.empty((N, H, W, Cout), device=x.device, dtype=x.dtype)
+    if pwk:
+        lib.pw_fwd_affine(x4, w4, bias, y, N * H * W, Cin, Cout, ab, pre, post, dtype_code(y.dtype))
+    else:
+        wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
+        lib.conv32_pack_weights(w4, wp, KH, KW, 0)
+        lib.conv32_fwd_affine(x4, wp, bias, y, N, H, W, KH, KW, ph, pw, ab, pre, post)
+    return y.squeeze(2) if tok else y
+
+
+def bn2_add_act_eval(xa, bnA, xb, bnB, pre_act='lrelu', act_kind='gelu'):
+    """Inference only: act(BN_A(pre(xa)) + BN_B(pre(xb))) with running statistics, one pass (CrossCNNBlock junction).
+    bnA/bnB: (gamma, beta, running_mean, running_var, eps)."""
+    if torch.is_grad_enabled() and (xa.requires_grad or xb.requires_grad):
+        raise TcctError('bn2_add_act_eval is inference-only')
+    _chk(xa, xb)
+    C = xa.shape[-1]
+    M = xa.numel() // C
+    abs_ = []
+    for bn in (bnA, bnB):
+        ab = torch.empty(2 * C, device=xa.device, dtype=torch.float32)
+        lib.bn_eval_ab(C, bn[0], bn[1], float(bn[4]), bn[2], bn[3], torch.empty(2 * C, device=xa.device, dtype=torch.float32), ab)
+        abs_.append(ab)
+    y = torch.empty_like(xa)
+    lib.bn2_add_act_fwd(xa, xb, y, M, C, abs_[0], abs_[1], ACT[pre_act], ACT[act_kind], dtype_code(xa.dtype))
+    return y
+
+
 def im2col3x3_c3(x4, stride=1):
     """x4 NHWC [N,H,W,4] (3 image channels + zero pad) -> 3x3 patch pixels [N,Ho,Wo,32]; no gradient (the image needs none)"""
     _chk(x4)
@@ -255,10 +314,13 @@ def im2col3x3_c3(x4, stride=1):
     return out
 
 
-def conv3x3_c3(x4, w, bias, stride=1, stats_pre=None):
+def conv3x3_c3(x4, w, bias, stride=1, stats_pre=None, infer_bn=None, post_act=None):
     """3-channel 3x3 conv (pad 1) as im2col + 32->32 pointwise GEMM: w [32,3,3,3] is re-laid out to [32, 27->32] by view ops
-    (differentiable plumbing on 864 elements), so forward and weight gradient both run on the MFMA pointwise kernels"""
+    (differentiable plumbing on 864 elements), so forward and weight gradient both run on the MFMA pointwise kernels.
+    infer_bn (inference only): eval-mode BatchNorm tuple folded, with post_act, into the GEMM epilogue (see conv_bn_act)."""
     w2 = torch.nn.functional.pad(w.permute(0, 2, 3, 1).reshape(w.shape[0], 27), (0, 5)).contiguous()
+    if infer_bn is not None:
+        return conv_bn_act(im2col3x3_c3(x4, stride), w2.view(w.shape[0], 32, 1, 1), bias, bn=infer_bn, post_act=post_act)
     return conv2d(im2col3x3_c3(x4, stride), w2.view(w.shape[0], 32, 1, 1), bias, stats_pre=stats_pre)
 
 

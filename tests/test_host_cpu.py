@@ -128,7 +128,7 @@ assert lin.weight.eq(1.0).all()
 t = tdist.max_over_ranks(float(rank), torch.device('cpu'))
 assert t == 1.0
 tdist.barrier()
-print('rank', rank, 'ok')
+os.write(1, ('rank %%d ok\n' %% rank).encode())      # one atomic write: the two ranks share stdout
 '''
 
 

@@ -395,3 +395,58 @@ def test_aux_head_conv_bf16_in_f32_out():
     torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=2e-2, atol=2e-2 * w.grad.abs().max().item())
     torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=2e-2, atol=2e-2 * b.grad.abs().max().item())
     torch.testing.assert_close(nchw(xd.grad), x.grad, rtol=3e-2, atol=3e-2 * x.grad.abs().max().item())
+
+
+@pytest.mark.parametrize('cfg', [
+    # Cin, Cout, KH, KW, pre, post, has_bn, tokens
+    (64, 64, 1, 1, None, 'hswish', True, False), (32, 32, 3, 3, 'lrelu', None, True, False), (32, 32, 1, 13, None, 'lrelu', True, False),
+    (96, 32, 1, 1, None, None, True, False), (64, 64, 1, 1, None, 'gelu', False, True), (128, 96, 1, 1, None, 'hswish', True, False),
+    (32, 32, 13, 1, None, None, False, False), (32, 5, 1, 1, None, None, False, False)])
+def test_conv_bn_act_inference(cfg):
+    """inference epilogues: eval-mode BatchNorm + activations folded into the MFMA convolution kernels (bf16) vs torch fp32"""
+    from tcct_amd import ops
+    Cin, Cout, KH, KW, pre, post, has_bn, tokens = cfg
+    dt = torch.bfloat16
+    N, H, W = 2, 19, 70
+    x = rnd(N, Cin, H, W, dt=dt)
+    w = rnd(Cout, Cin, KH, KW, seed=1) / (Cin * KH * KW) ** 0.5
+    b = rnd(Cout, seed=2)
+    y = F.conv2d(x, w.to(dt).float(), b, 1, (KH // 2, KW // 2))
+    y = ACTS[pre or 'none'](y)
+    bn = None
+    if has_bn:
+        g, be = 1 + 0.3 * rnd(Cout, seed=3), 0.2 * rnd(Cout, seed=4)
+        rm, rv = 0.5 * rnd(Cout, seed=5), 0.5 + rnd(Cout, seed=6).abs()
+        y = F.batch_norm(y, rm, rv, g, be, False, 0.1, 1e-5)
+        bn = (g.cuda(), be.cuda(), rm.cuda(), rv.cuda(), 1e-5)
+    y = (F.gelu if post == 'gelu' else ACTS[post or 'none'])(y)
+    xd = nhwc(x, dt)
+    wd = w.cuda()
+    if tokens:
+        xd, wd = xd.view(N, H * W, Cin), wd.view(Cout, Cin)
+    with torch.no_grad():
+        yd = ops.conv_bn_act(xd, wd, b.cuda(), 1, (KH // 2, KW // 2), bn, pre, post)
+    if tokens:
+        yd = yd.view(N, H, W, Cout)
+    torch.testing.assert_close(nchw(yd), y, rtol=2e-2, atol=2e-2)
+    with pytest.raises(Exception):          # inference only
+        ops.conv_bn_act(xd.requires_grad_(True), wd, b.cuda(), 1, (KH // 2, KW // 2), bn, pre, post)
+
+
+@pytest.mark.parametrize('shape', [(2, 37, 45, 5), (1, 800, 1104, 5), (3, 16, 64, 2), (2, 5, 130, 8)])
+def test_mask_boundaries(shape):
+    """boundary rows of a layered class-index mask: bit-exact against the numpy counting definition, incl. noisy columns"""
+    import numpy as np
+    from tcct_amd.kite.losses.miou import MaskOneHot
+    N, H, W, C = shape
+    g = np.random.default_rng(sum(shape))
+    cuts = np.sort(g.integers(0, H + 1, size=(N, C - 1, W)), axis=1)                    # layered columns
+    lab = (np.arange(H)[None, :, None, None] >= cuts.transpose(0, 2, 1)[:, None]).sum(-1).astype(np.uint8)   # [N,H,W]
+    noise = g.random((N, H, W)) < 0.02
+    lab = np.where(noise, g.integers(0, C, size=(N, H, W)), lab).astype(np.uint8)
+    want = np.stack([(lab < k).sum(1) for k in range(1, C)], 1).astype(np.int32)       # [N,C-1,W]
+    got = MaskOneHot(torch.from_numpy(lab).cuda(), C).boundaries().cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+    clean = (np.arange(H)[None, :, None, None] >= cuts.transpose(0, 2, 1)[:, None]).sum(-1).astype(np.uint8)
+    got2 = MaskOneHot(torch.from_numpy(clean).cuda(), C).boundaries().cpu().numpy()
+    assert np.array_equal(got2, cuts.astype(np.int32))                                # monotone mask: exactly the layer starts
