@@ -249,21 +249,19 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         // lanes with equal (lane & 3) hold different pixels of the same 8 channels: butterfly over lane bits 2..5, LDS, fp64 atomics
         // (once per block: LDS float atomics are slow, a per-tile flush of the partials cost +70 % kernel time)
         __syncthreads();
-        float* red = reinterpret_cast<float*>(sX);
-        if (tid < 64) red[tid] = 0.f;
-        __syncthreads();
+        float* red = reinterpret_cast<float*>(sX);          // [4 waves][64]
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float a = ss[k], b = sq[k];
 #pragma unroll
             for (int o = 32; o > 2; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-            if (lane < 4) {
-                atomicAdd(&red[8 * lane + k], a);
-                atomicAdd(&red[32 + 8 * lane + k], b);
+            if (lane < 4) {             // per-wave slots, summed below: no LDS atomics
+                red[wave * 64 + 8 * lane + k] = a;
+                red[wave * 64 + 32 + 8 * lane + k] = b;
             }
         }
         __syncthreads();
-        if (tid < 64) atomicAdd(&stats[tid], (double)red[tid]);
+        if (tid < 64) atomicAdd(&stats[tid], (double)red[tid] + (double)red[64 + tid] + (double)red[128 + tid] + (double)red[192 + tid]);
     }
 }
 
@@ -495,23 +493,28 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
             }
         }
     }
-    // block-level reduction of the 4/TG partial accumulators per tap in LDS, then one fp32 atomic per element per block
+    // block-level reduction of the WPG = 4/TG partial accumulators per tap in LDS: the waves of a tap group take turns (plain
+    // stores / read-add-write, one barrier per turn).  LDS float atomics did this before and cost ~25 us per BLOCK (a one-tile
+    // launch took 37 us against 9 us for the forward kernel), i.e. most of the time of every call below level 1.
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
-    for (int i = tid; i < TAPS * 1024; i += MB) red[i] = 0.f;
-    __syncthreads();
+    for (int turn = 0; turn < WPG; ++turn) {
+        if (wi == turn) {
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int tap = tap0 + t;
-        if (tap < TAPS) {
+            for (int t = 0; t < TPW; ++t) {
+                const int tap = tap0 + t;
+                if (tap < TAPS) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
-                atomicAdd(&red[tap * 1024 + co * 32 + r], acc[t][k]);
+                    for (int k = 0; k < 16; ++k) {
+                        const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
+                        float* dst = &red[tap * 1024 + co * 32 + r];
+                        *dst = turn == 0 ? acc[t][k] : *dst + acc[t][k];
+                    }
+                }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
     // OIHW-linear order: consecutive lanes add to consecutive addresses (256 contiguous bytes per wave instruction; a
     // tap-major walk would scatter every lane into its own 64-byte segment: 8x the atomic traffic, PMC WRITE_SIZE 151 MB)
     for (int i = tid; i < TAPS * 1024; i += MB) {

@@ -6,10 +6,12 @@
 #define MAXC 8
 
 // ----------------------------------------------------------------------- softmax + Dice sums (kite/losses/loss.py:28-32,83-99)
+// 1024-thread blocks on <= 512 blocks: the fp64 atomics at the end of every block serialise per address (see norm.hip)
+#define DSB 1024
 template <typename T>
-__global__ void k_dice_sums(const T* __restrict__ logits, const uint8_t* __restrict__ lab, int64_t M, int C,
+__global__ void __launch_bounds__(DSB) k_dice_sums(const T* __restrict__ logits, const uint8_t* __restrict__ lab, int64_t M, int C,
                             double* __restrict__ sums /*[3][C]: I, P, G*/) {
-    __shared__ float sm[3 * MAXC][LB / 64];
+    __shared__ float sm[3 * MAXC][DSB / 64];
     float I[MAXC], P[MAXC], G[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) I[c] = P[c] = G[c] = 0.f;
@@ -40,7 +42,7 @@ __global__ void k_dice_sums(const T* __restrict__ logits, const uint8_t* __restr
         int q = threadIdx.x / MAXC, c = threadIdx.x % MAXC;
         if (c < C) {
             double a = 0.0;
-            for (int k = 0; k < LB / 64; ++k) a += (double)sm[threadIdx.x][k];
+            for (int k = 0; k < DSB / 64; ++k) a += (double)sm[threadIdx.x][k];
             atomicAdd(&sums[q * C + c], a);
         }
     }
@@ -57,7 +59,7 @@ extern "C" int tcct_softmax_dice_fwd(const void* logits, const uint8_t* labels, 
     TCCT_CHECK(C >= 2 && C <= MAXC, "softmax_dice_fwd: C=%d unsupported (2..%d)", C, MAXC);
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(sums, 0, sizeof(double) * 3 * C, st) != hipSuccess) { tcct_set_error("softmax_dice_fwd: memset failed"); return -2; }
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_dice_sums<T>, dim3(tcct_grid(M, LB, 2048)), dim3(LB), 0, st, (const T*)logits, labels, M, C, sums));
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_dice_sums<T>, dim3(tcct_grid(M, DSB, 512)), dim3(DSB), 0, st, (const T*)logits, labels, M, C, sums));
     hipLaunchKernelGGL(k_dice_finalize, dim3(1), dim3(64), 0, st, sums, C, loss);
     TCCT_LAUNCH_OK();
 }

@@ -3,13 +3,17 @@
 #include "common.h"
 
 #define NB 256
+// The per-channel reduction kernels run 1024-thread blocks on a grid of at most 512: every block ends with one fp64 atomic per
+// channel sum and same-address atomics are serialised at L2, so the tail grows with the NUMBER of blocks (2048 blocks of 256:
+// +40 us on every call, 4096: +80 us) while the streaming rate needs ~32 waves per CU -- big blocks give both.
+#define NBR 1024
 
 // ------------------------------------------------------------------ BN forward statistics: sum, sum of squares
 template <typename T, int VEC>
-__global__ void k_bn_stats(const T* __restrict__ x, int64_t M, int C, int pre_act, double* __restrict__ sums) {
-    __shared__ float sm[2 * NB * VEC];
+__global__ void __launch_bounds__(NBR) k_bn_stats(const T* __restrict__ x, int64_t M, int C, int pre_act, double* __restrict__ sums) {
+    __shared__ float sm[2 * NBR * VEC];
     const int CV = C / VEC;            // vectors per row
-    const int R = NB / CV;             // rows per block pass
+    const int R = NBR / CV;             // rows per block pass
     const int t = threadIdx.x;
     const bool active = t < R * CV;
     const int cv = t % CV, r = t / CV;
@@ -29,7 +33,7 @@ __global__ void k_bn_stats(const T* __restrict__ x, int64_t M, int C, int pre_ac
         }
     }
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) { sm[t * VEC + k] = s[k]; sm[(NB + t) * VEC + k] = q[k]; }
+    for (int k = 0; k < VEC; ++k) { sm[t * VEC + k] = s[k]; sm[(NBR + t) * VEC + k] = q[k]; }
     __syncthreads();
     if (t < C) {
         // channel c = t lives at vector cv=t/VEC, lane k=t%VEC of rows r=0..R-1
@@ -38,7 +42,7 @@ __global__ void k_bn_stats(const T* __restrict__ x, int64_t M, int C, int pre_ac
         for (int rr = 0; rr < R; ++rr) {
             int tt = rr * CV + cvv;
             a += (double)sm[tt * VEC + k];
-            b += (double)sm[(NB + tt) * VEC + k];
+            b += (double)sm[(NBR + tt) * VEC + k];
         }
         atomicAdd(&sums[t], a);
         atomicAdd(&sums[C + t], b);
@@ -50,10 +54,10 @@ extern "C" int tcct_bn_stats(const void* x, int64_t M, int C, int pre_act, doubl
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { tcct_set_error("bn_stats: memset failed"); return -2; }
     int vec = (C % 4 == 0) ? 4 : 1;
-    int R = NB / (C / vec);
-    int grid = tcct_grid(M, R, 256 * 8);
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_stats<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, M, C, pre_act, sums)); }
-    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_stats<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, M, C, pre_act, sums)); }
+    int R = NBR / (C / vec);
+    int grid = tcct_grid(M, R, 512);
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_stats<T, 4>), dim3(grid), dim3(NBR), 0, st, (const T*)x, M, C, pre_act, sums)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_stats<T, 1>), dim3(grid), dim3(NBR), 0, st, (const T*)x, M, C, pre_act, sums)); }
     TCCT_LAUNCH_OK();
 }
 
@@ -152,12 +156,12 @@ extern "C" int tcct_bn_apply(const void* x, void* y, int64_t M, int C, const flo
 
 // ------------------------------------------------------------------ BN backward: reductions then apply
 template <typename T, int VEC>
-__global__ void k_bn_bwd_reduce(const T* __restrict__ x, const T* __restrict__ dy, int64_t M, int C,
+__global__ void __launch_bounds__(NBR) k_bn_bwd_reduce(const T* __restrict__ x, const T* __restrict__ dy, int64_t M, int C,
                                 const float* __restrict__ mean_rstd, const float* __restrict__ ab, int pre_act,
                                 int post_act, double* __restrict__ sums) {
-    __shared__ float sm[2 * NB * VEC];
+    __shared__ float sm[2 * NBR * VEC];
     const int CV = C / VEC;
-    const int R = NB / CV;
+    const int R = NBR / CV;
     const int t = threadIdx.x;
     const bool active = t < R * CV;
     const int cv = t % CV, r = t / CV;
@@ -186,7 +190,7 @@ __global__ void k_bn_bwd_reduce(const T* __restrict__ x, const T* __restrict__ d
         }
     }
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) { sm[t * VEC + k] = s[k]; sm[(NB + t) * VEC + k] = q[k]; }
+    for (int k = 0; k < VEC; ++k) { sm[t * VEC + k] = s[k]; sm[(NBR + t) * VEC + k] = q[k]; }
     __syncthreads();
     if (t < C) {
         double a = 0.0, b = 0.0;
@@ -194,7 +198,7 @@ __global__ void k_bn_bwd_reduce(const T* __restrict__ x, const T* __restrict__ d
         for (int rr = 0; rr < R; ++rr) {
             int tt = rr * CV + cvv;
             a += (double)sm[tt * VEC + k];
-            b += (double)sm[(NB + tt) * VEC + k];
+            b += (double)sm[(NBR + tt) * VEC + k];
         }
         atomicAdd(&sums[t], a);
         atomicAdd(&sums[C + t], b);
@@ -206,10 +210,10 @@ extern "C" int tcct_bn_bwd_reduce(const void* x, const void* dy, int64_t M, int 
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { tcct_set_error("bn_bwd_reduce: memset failed"); return -2; }
     int vec = (C % 4 == 0) ? 4 : 1;
-    int R = NB / (C / vec);
-    int grid = tcct_grid(M, R, 256 * 8);
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (const T*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
-    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (const T*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
+    int R = NBR / (C / vec);
+    int grid = tcct_grid(M, R, 512);
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce<T, 4>), dim3(grid), dim3(NBR), 0, st, (const T*)x, (const T*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce<T, 1>), dim3(grid), dim3(NBR), 0, st, (const T*)x, (const T*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
     TCCT_LAUNCH_OK();
 }
 
@@ -320,10 +324,10 @@ extern "C" int tcct_layernorm_fwd(const void* x, void* y, int64_t M, int C, cons
 }
 
 template <typename T>
-__global__ void k_ln_bwd(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t M, int C,
+__global__ void __launch_bounds__(NBR) k_ln_bwd(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t M, int C,
                          const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float sm[2 * 192];
+    __shared__ float swv[(NBR / 64) * 384];         // per wave: dgamma partials [192], dbeta partials [192]
     const int C4 = C >> 2;
     const int lane = threadIdx.x & 15;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -331,8 +335,6 @@ __global__ void k_ln_bwd(const T* __restrict__ x, const T* __restrict__ dy, T* _
     f4 ag[LN_MAXCH], abt[LN_MAXCH];
 #pragma unroll
     for (int j = 0; j < LN_MAXCH; ++j) { ag[j] = f4zero(); abt[j] = f4zero(); }
-    for (int i = threadIdx.x; i < 2 * 192; i += blockDim.x) sm[i] = 0.f;
-    __syncthreads();
     for (int64_t m = grp; m < M; m += ngrp) {
         float mean = mean_rstd[2 * m], rstd = mean_rstd[2 * m + 1];
         f4 xh[LN_MAXCH], g[LN_MAXCH];
@@ -368,16 +370,26 @@ __global__ void k_ln_bwd(const T* __restrict__ x, const T* __restrict__ dy, T* _
             }
         }
     }
+    // the four 16-lane row groups of a wave hold the same channels: butterfly over lane bits 4,5, then one LDS slot per wave (no
+    // LDS float atomics: they cost tens of microseconds per block), summed over the waves by the first 2C threads
+    const int wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
 #pragma unroll
     for (int j = 0; j < LN_MAXCH; ++j) {
         int ch = lane + 16 * j;
-        if (ch < C4) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { atomicAdd(&sm[ch * 4 + k], ag[j].v[k]); atomicAdd(&sm[192 + ch * 4 + k], abt[j].v[k]); }
+        for (int k = 0; k < 4; ++k) {
+            float a = ag[j].v[k], b = abt[j].v[k];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if ((threadIdx.x & 63) < 16 && ch < C4) { swv[wv * 384 + ch * 4 + k] = a; swv[wv * 384 + 192 + ch * 4 + k] = b; }
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) { atomicAdd(&dgamma[c], sm[c]); atomicAdd(&dbeta[c], sm[192 + c]); }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int w2 = 0; w2 < nwv; ++w2) { a += swv[w2 * 384 + c]; b += swv[w2 * 384 + 192 + c]; }
+        atomicAdd(&dgamma[c], a); atomicAdd(&dbeta[c], b);
+    }
 }
 extern "C" int tcct_layernorm_bwd(const void* x, const void* dy, void* dx, int64_t M, int C, const float* gamma,
                                   const float* mean_rstd, float* dgamma, float* dbeta, int dtype, tcct_stream_t stream) {
@@ -386,7 +398,7 @@ extern "C" int tcct_layernorm_bwd(const void* x, const void* dy, void* dx, int64
     if (!tcct_skip_zero_fill() && (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess)) {
         tcct_set_error("layernorm_bwd: memset failed"); return -2;
     }
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_ln_bwd<T>, dim3(tcct_grid(M * 16, NB, 1024)), dim3(NB), 0, st, (const T*)x,
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_ln_bwd<T>, dim3(tcct_grid(M * 16, NBR, 512)), dim3(NBR), 0, st, (const T*)x,
                                             (const T*)dy, (T*)dx, M, C, gamma, mean_rstd, dgamma, dbeta));
     TCCT_LAUNCH_OK();
 }
@@ -426,11 +438,11 @@ extern "C" int tcct_bn2_add_act_fwd(const void* xa, const void* xb, void* y, int
 
 // sums[4C] = { sum g, sum g*xhatA, (unused alias of sum g), sum g*xhatB } laid out as [C]:g, [C]:g*xhatA, [C]:g, [C]:g*xhatB
 template <typename T>
-__global__ void k_bn2_add_act_bwd_reduce(const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ dy, int64_t M, int C,
+__global__ void __launch_bounds__(NBR) k_bn2_add_act_bwd_reduce(const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ dy, int64_t M, int C,
                                          const float* __restrict__ mrA, const float* __restrict__ abA, const float* __restrict__ mrB,
                                          const float* __restrict__ abB, int pre_act, int act, double* __restrict__ sums) {
-    __shared__ float sm[3 * NB * 4];
-    const int CV = C >> 2, R = NB / CV, t = threadIdx.x;
+    __shared__ float sm[3 * NBR * 4];
+    const int CV = C >> 2, R = NBR / CV, t = threadIdx.x;
     const bool active = t < R * CV;
     const int cv = t % CV, r = t / CV;
     float aA[4], bA[4], aB[4], bB[4], muA[4], rsA[4], muB[4], rsB[4], s0[4], s1[4], s2[4];
@@ -454,14 +466,14 @@ __global__ void k_bn2_add_act_bwd_reduce(const T* __restrict__ xa, const T* __re
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { sm[t * 4 + k] = s0[k]; sm[(NB + t) * 4 + k] = s1[k]; sm[(2 * NB + t) * 4 + k] = s2[k]; }
+    for (int k = 0; k < 4; ++k) { sm[t * 4 + k] = s0[k]; sm[(NBR + t) * 4 + k] = s1[k]; sm[(2 * NBR + t) * 4 + k] = s2[k]; }
     __syncthreads();
     if (t < C) {
         double a = 0.0, b = 0.0, c2 = 0.0;
         int cvv = t >> 2, k = t & 3;
         for (int rr = 0; rr < R; ++rr) {
             int tt = rr * CV + cvv;
-            a += (double)sm[tt * 4 + k]; b += (double)sm[(NB + tt) * 4 + k]; c2 += (double)sm[(2 * NB + tt) * 4 + k];
+            a += (double)sm[tt * 4 + k]; b += (double)sm[(NBR + tt) * 4 + k]; c2 += (double)sm[(2 * NBR + tt) * 4 + k];
         }
         atomicAdd(&sums[t], a); atomicAdd(&sums[C + t], b); atomicAdd(&sums[2 * C + t], a); atomicAdd(&sums[3 * C + t], c2);
     }
@@ -472,8 +484,8 @@ extern "C" int tcct_bn2_add_act_bwd_reduce(const void* xa, const void* xb, const
     TCCT_CHECK(C % 4 == 0 && C >= 4 && C <= NB, "bn2_add_act_bwd_reduce: C=%d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && hipMemsetAsync(sums, 0, sizeof(double) * 4 * C, st) != hipSuccess) { tcct_set_error("bn2_add_act_bwd_reduce: memset failed"); return -2; }
-    int R = NB / (C / 4);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_bn2_add_act_bwd_reduce<T>, dim3(tcct_grid(M, R, 256 * 8)), dim3(NB), 0, st, (const T*)xa,
+    int R = NBR / (C / 4);
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_bn2_add_act_bwd_reduce<T>, dim3(tcct_grid(M, R, 512)), dim3(NBR), 0, st, (const T*)xa,
                                             (const T*)xb, (const T*)dy, M, C, mean_rstdA, abA, mean_rstdB, abB, pre_act, act, sums));
     TCCT_LAUNCH_OK();
 }

@@ -154,9 +154,7 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
     }
     if (STATS) {
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);           // [2][NT*32] (weights are no longer needed)
-        for (int i2 = tid; i2 < 2 * NT * 32; i2 += PWB) red[i2] = 0.f;
-        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][NT*32] (weights are no longer needed)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -164,15 +162,20 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                 float a = ss[nt][k], b = sq[nt][k];
 #pragma unroll
                 for (int o = 32; o > 2; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-                if (lane < 4) {
-                    atomicAdd(&red[nt * 32 + 8 * lane + k], a);
-                    atomicAdd(&red[NT * 32 + nt * 32 + 8 * lane + k], b);
+                if (lane < 4) {                 // per-wave slots, summed below: no LDS atomics
+                    red[wave * 2 * NT * 32 + nt * 32 + 8 * lane + k] = a;
+                    red[wave * 2 * NT * 32 + NT * 32 + nt * 32 + 8 * lane + k] = b;
                 }
             }
         __syncthreads();
         for (int i2 = tid; i2 < NT * 32; i2 += PWB) {
             const int co = n_base + i2;
-            if (co < N) { atomicAdd(&stats[co], (double)red[i2]); atomicAdd(&stats[N + co], (double)red[NT * 32 + i2]); }
+            if (co < N) {
+                double a = 0.0, b = 0.0;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) { a += (double)red[wv * 2 * NT * 32 + i2]; b += (double)red[wv * 2 * NT * 32 + NT * 32 + i2]; }
+                atomicAdd(&stats[co], a); atomicAdd(&stats[N + co], b);
+            }
         }
     }
 }
@@ -357,20 +360,25 @@ k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __res
         mma_chunk(f1);
         __builtin_amdgcn_sched_barrier(0);
     }
+    // the four waves hold partial sums of the same tiles: they take turns adding them into LDS (plain read-add-write, one barrier
+    // per turn) -- LDS float atomics here cost ~20 us per block (see k_conv32_wgrad)
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);          // [NT*32][KTB*32]
-    for (int i = tid; i < NT * 32 * KTB * 32; i += PWB) red[i] = 0.f;
-    __syncthreads();
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
+            for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-        for (int kt = 0; kt < KTB; ++kt)
+                for (int kt = 0; kt < KTB; ++kt)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int co = ct * 32 + (k & 3) + 8 * (k >> 2) + 4 * hh;
-                atomicAdd(&red[co * (KTB * 32) + kt * 32 + r], acc[ct][kt][k]);
-            }
-    __syncthreads();
+                    for (int k = 0; k < 16; ++k) {
+                        const int co = ct * 32 + (k & 3) + 8 * (k >> 2) + 4 * hh;
+                        float* dst = &red[co * (KTB * 32) + kt * 32 + r];
+                        *dst = turn == 0 ? acc[ct][kt][k] : *dst + acc[ct][kt][k];
+                    }
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < NT * 32 * KTB * 32; i += PWB) {
         const int co = i / (KTB * 32), cl = i - co * (KTB * 32);
         if (co < N && ci_base + cl < K) atomicAdd(&dw[(int64_t)co * K + ci_base + cl], red[i]);
@@ -573,15 +581,17 @@ k_pw_wgrad_smalln_mfma(const bf16* __restrict__ x, const float* __restrict__ dy,
         }
     }
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);          // [8][32]
-    if (tid < 256) red[tid] = 0.f;
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);          // [8][32]; the four waves take turns (no LDS float atomics)
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
-        if (co < 8) atomicAdd(&red[co * 32 + r], acc[k]);
+            for (int k = 0; k < 4; ++k) {                   // k < 4 <=> co = k + 4*hh < 8
+                float* dst = &red[(k + 4 * hh) * 32 + r];
+                *dst = turn == 0 ? acc[k] : *dst + acc[k];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (tid < N * 32) atomicAdd(&dw[tid], red[tid]);
     if (dbias) {
         float s = bsum + __shfl_xor(bsum, 32, 64);
