@@ -41,13 +41,36 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
     const int n_base = blockIdx.y * NT * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    // stage weights: rows n_base .. n_base+NT*32-1 (zero beyond N), bf16 [row][K]
-    for (int i = tid; i < NT * 32 * K; i += PWB) {
-        int row = i / K, k = i - row * K;
-        int n = n_base + row;
-        float v = 0.f;
-        if (n < N) v = transposed ? w[(int64_t)k * N + n] : w[(int64_t)n * K + k];
-        *reinterpret_cast<bf16*>(smem + row * SW + k * 2) = __float2bfloat16(v);
+    // stage weights: rows n_base .. n_base+NT*32-1 (zero beyond N), bf16 [row][K]; eight elements per thread and iteration, read
+    // along the contiguous direction of w (the element-wise loop with a division per element was most of a small-M launch)
+    if (!transposed) {
+        const int K8 = K >> 3;
+        for (int i = tid; i < NT * 32 * K8; i += PWB) {
+            const int row = i / K8, c8 = i - row * K8, n = n_base + row;
+            uint4 o = make_uint4(0, 0, 0, 0);
+            if (n < N) {
+                const float4 a = *reinterpret_cast<const float4*>(w + (int64_t)n * K + c8 * 8);
+                const float4 b = *reinterpret_cast<const float4*>(w + (int64_t)n * K + c8 * 8 + 4);
+                o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(a.z, a.w); o.z = pack_bf16x2(b.x, b.y); o.w = pack_bf16x2(b.z, b.w);
+            }
+            *reinterpret_cast<uint4*>(smem + row * SW + c8 * 16) = o;
+        }
+    } else {
+        const int R8 = NT * 4;                      // groups of 8 output rows
+        for (int i = tid; i < K * R8; i += PWB) {
+            const int k = i / R8, c8 = i - k * R8, n0 = n_base + c8 * 8;
+            float v[8];
+            if (n0 + 7 < N && (N & 3) == 0) {
+                const float4 a = *reinterpret_cast<const float4*>(w + (int64_t)k * N + n0);
+                const float4 b = *reinterpret_cast<const float4*>(w + (int64_t)k * N + n0 + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = n0 + j < N ? w[(int64_t)k * N + n0 + j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16*>(smem + (c8 * 8 + j) * SW + k * 2) = __float2bfloat16(v[j]);
+        }
     }
     __syncthreads();
     // statistics are taken after the epilogue transpose, where a lane owns 8 channels of each N-tile: 16 registers per tile
@@ -208,6 +231,14 @@ static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y
     const int ntiles = (N + 31) / 32;
     // tiles per block: largest NT <= 5 dividing the work evenly enough and fitting 2 blocks/CU when possible
     int NT = ntiles <= 5 ? ntiles : (ntiles % 5 == 0 ? 5 : (ntiles % 4 == 0 ? 4 : (ntiles % 3 == 0 ? 3 : (ntiles % 2 == 0 ? 2 : 1))));
+    const int64_t mblocks = ((M + 31) / 32 + 3) / 4;
+    // small M (levels 3-4): fewer N-tiles per block so that the launch has >= 512 blocks and every block stages a fraction of the
+    // weights (with NT = 5 a 27 600-pixel call ran 216 blocks, one per CU, each converting the whole 160 x K matrix first)
+    while (NT > 1 && mblocks * ((ntiles + NT - 1) / NT) < 512) {
+        int nn = NT - 1;
+        while (nn > 1 && ntiles % nn != 0) --nn;
+        NT = nn;
+    }
     const int gy = (ntiles + NT - 1) / NT;
     size_t lds = (((size_t)NT * 32 * (2 * K + 16) + 15) & ~(size_t)15) + 4 * 2560;
     TCCT_CHECK(lds <= 160 * 1024, "pw_fwd: weights need %zu B of LDS", lds);
