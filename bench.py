@@ -79,7 +79,7 @@ def dominant_kernel_roofline(a, iters=20):
     if a.dtype == 'bf16':
         wp = torch.empty(9 * 1024, device='cuda', dtype=torch.bfloat16)
         lib.conv32_pack_weights(w, wp, 3, 3, 0)
-        name, name2 = 'k_conv32_mfma<false,false,3,3> (3x3 32->32 fwd/dgrad @L0)', 'k_conv32_wgrad<5,false> (3x3 32->32 @L0)'
+        name, name2 = 'k_conv32_mfma<false,0,3,3> (3x3 32->32 fwd/dgrad @L0)', 'k_conv32_wgrad<5,false> (3x3 32->32 @L0)'
         fn = lambda: lib.conv32_fwd(x, wp, b, y, a.bs, a.height, Wp, 3, 3, 1, 1)                              # noqa: E731
         fn2 = lambda: lib.conv32_wgrad(x, dy, dw, db, a.bs, a.height, Wp, 3, 3, 1, 1)                         # noqa: E731
     else:
@@ -98,6 +98,25 @@ def dominant_kernel_roofline(a, iters=20):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters
     ms, ms2 = timed(fn), timed(fn2)
+    # the two other kernels at the top of the per-symbol ranking (profiles/r01_q_summary.md), same live timing: the BatchNorm
+    # backward reduction (reads x and dy of a level-0 tensor) and the pointwise GEMM at its heaviest shape (64->64 at level 1)
+    others = []
+    if a.dtype == 'bf16':
+        M0, C0 = a.bs * a.height * Wp, 32
+        mr = torch.zeros(2 * C0, device='cuda'); mr[C0:] = 1
+        ab = torch.ones(2 * C0, device='cuda')
+        sums = torch.zeros(2 * C0, device='cuda', dtype=torch.float64)
+        t3 = timed(lambda: lib.bn_bwd_reduce(x, dy, M0, C0, mr, ab, 1, 0, sums, 1))
+        b3 = 2.0 * x.numel() * 2
+        others.append({'kernel': 'k_bn_bwd_reduce<bf16,4> (32 ch @L0)', 'ms_per_launch': round(t3, 4), 'algorithmic_bytes': int(b3),
+                       'achieved': round(b3 / (t3 * 1e-3) / 1e9, 1), 'frac': round(b3 / (t3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        M1 = a.bs * (a.height // 2) * (Wp // 2)
+        x1 = torch.randn((M1, 64), device='cuda').to(dt); y1 = torch.empty_like(x1)
+        w1 = torch.randn((64, 64), device='cuda') * 0.1; b1 = torch.zeros(64, device='cuda')
+        t4 = timed(lambda: lib.pw_fwd(x1, w1, b1, y1, M1, 64, 64, 0, 1))
+        b4 = 2.0 * x1.numel() * 2
+        others.append({'kernel': 'k_pw_fwd<2,bf16> (64->64 @L1)', 'ms_per_launch': round(t4, 4), 'algorithmic_bytes': int(b4),
+                       'achieved': round(b4 / (t4 * 1e-3) / 1e9, 1), 'frac': round(b4 / (t4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     bytes_alg = 2.0 * x.numel() * x.element_size()
     ach, ach2 = bytes_alg / (ms * 1e-3) / 1e9, bytes_alg / (ms2 * 1e-3) / 1e9
     flops = 2.0 * 9 * 32 * 32 * a.bs * a.height * Wp
@@ -105,7 +124,7 @@ def dominant_kernel_roofline(a, iters=20):
             'traffic': PMC_TRAFFIC_BYTES.get((a.dtype, a.bs, a.height, a.width)), 'kernel': name, 'ms_per_launch': round(ms, 4),
             'launches_timed': iters, 'algorithmic_bytes': int(bytes_alg), 'tflops': round(flops / (ms * 1e-3) / 1e12, 2),
             'second': {'kernel': name2, 'achieved': round(ach2, 1), 'frac': round(ach2 / HBM_PEAK_GBS, 4), 'ms_per_launch': round(ms2, 4),
-                       'algorithmic_bytes': int(bytes_alg)}}
+                       'algorithmic_bytes': int(bytes_alg)}, 'others': others}
 
 
 def cpu_baseline(a):

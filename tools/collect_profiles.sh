@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collect the judged measurement artifacts on the GPU box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh TAG   -> gpurun_out/TAG_*  (kernel traces as CSV, PMC passes of the roofline loop, bench lines)
+TAG=${1:-r01_x}
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_step -o step -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_step.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_roof -o roof -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $OUT/${TAG}_roof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -o fetch -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $OUT/${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -o write -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $OUT/${TAG}_write.log 2>&1
+cd $GRAFT_REPO_ROOT
+python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-roofline --los=di+reg+fpl > $OUT/${TAG}_bench_fullloss.json 2>> $OUT/${TAG}_bench.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --dtype fp32 > $OUT/${TAG}_bench_fp32.json 2>> $OUT/${TAG}_bench.err
+python tools/infer_bench.py > $OUT/${TAG}_infer.txt 2>> $OUT/${TAG}_bench.err
+tail -c 600 $OUT/${TAG}_bench.json
+# keep only the small summaries
+find $OUT/${TAG}_step $OUT/${TAG}_roof $OUT/${TAG}_fetch $OUT/${TAG}_write -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null

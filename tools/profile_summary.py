@@ -1,0 +1,65 @@
+"""Turn the files written by tools/collect_profiles.sh (gpurun_out/TAG_*) into the committed profiles/TAG_* summaries."""
+import csv, collections, json, re, shutil, sys, os
+tag = sys.argv[1]
+G, P = 'gpurun_out', 'profiles'
+step = list(csv.DictReader(open(f'{G}/{tag}_step/step_kernel_stats.csv')))
+roof = list(csv.DictReader(open(f'{G}/{tag}_roof/roof_kernel_stats.csv')))
+shutil.copy(f'{G}/{tag}_step/step_kernel_stats.csv', f'{P}/{tag}_kernel_stats.csv')
+shutil.copy(f'{G}/{tag}_roof/roof_kernel_stats.csv', f'{P}/{tag}_roofline_only_kernel_stats.csv')
+for n in ('bench', 'bench_fullloss', 'bench_fp32'):
+    shutil.copy(f'{G}/{tag}_{n}.json', f'{P}/{tag}_{n}.json')
+shutil.copy(f'{G}/{tag}_infer.txt', f'{P}/{tag}_infer.txt')
+nsteps = 3
+tot = sum(float(r['TotalDurationNs']) for r in step)
+fams = [('BatchNorm (k_bn*)', r'k_bn'), ('pointwise fwd/dgrad (k_pw_fwd)', r'k_pw_fwd'), ('conv32 fwd/dgrad (k_conv32_mfma)', r'k_conv32_mfma'),
+        ('conv32 wgrad (k_conv32_wgrad)', r'k_conv32_wgrad'), ('pointwise wgrad (k_pw_wgrad*)', r'k_pw_wgrad'), ('depthwise (k_dw*)', r'k_dw'),
+        ('bilinear', r'k_bilinear'), ('LayerNorm', r'k_ln_'), ('softmax-Dice', r'k_dice'), ('elementwise (k_map*, residual, concat)', r'k_map|k_residual|k_concat|k_split'),
+        ('torch (autograd grad accumulation adds etc.)', r'at::native'), ('memset/copy (rocclr)', r'rocclr')]
+acc = collections.OrderedDict((n, 0.0) for n, _ in fams)
+other = 0.0
+for r in step:
+    t = float(r['TotalDurationNs'])
+    for n, pat in fams:
+        if re.search(pat, r['Name']):
+            acc[n] += t
+            break
+    else:
+        other += t
+acc['other (pool, im2col, pack, optimizer, ...)'] = other
+b = json.load(open(f'{G}/{tag}_bench.json'))
+bf = json.load(open(f'{G}/{tag}_bench_fullloss.json'))
+b32 = json.load(open(f'{G}/{tag}_bench_fp32.json'))
+pm = {}
+for kind in ('fetch', 'write'):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(f'{G}/{tag}_{kind}/{kind}_counter_collection.csv')):
+        d[r['Kernel_Name']].append(float(r['Counter_Value']))
+    pm[kind] = {k: sum(v) / len(v) for k, v in d.items()}
+L = []
+L.append(f'# {tag}: MI355X, bf16, bs=8 1x800x1100\n')
+L.append(f'Un-profiled bench lines: `profiles/{tag}_bench.json` ({b["value"]} B-scans/s, {b["ms_per_step"]} ms/step, `--los=di`); '
+         f'`--los=di+reg+fpl`: {bf["value"]} B-scans/s, {bf["ms_per_step"]} ms/step; fp32 parity mode: {b32["value"]} B-scans/s; '
+         f'inference (`tools/infer_bench.py`): `profiles/{tag}_infer.txt`.\n')
+L.append(f'## whole step — `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline`')
+L.append(f'{nsteps} steps traced; GPU busy {tot / 1e6:.1f} ms = {tot / 1e6 / nsteps:.2f} ms/step.\n')
+L.append('| family | ms/step | % |\n|---|---|---|')
+for n, t in sorted(acc.items(), key=lambda x: -x[1]):
+    L.append(f'| {n} | {t / 1e6 / nsteps:.2f} | {100 * t / tot:.1f} |')
+L.append('\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|')
+for r in sorted(step, key=lambda r: -float(r['TotalDurationNs']))[:28]:
+    L.append(f'| `{r["Name"].split("(")[0][:72]}` | {r["Calls"]} | {float(r["TotalDurationNs"]) / 1e6:.2f} | {float(r["AverageNs"]) / 1e3:.1f} | {float(r["Percentage"]):.1f} |')
+L.append(f'\n## roofline kernels alone — `rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-only` and, in separate passes, `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`\n')
+L.append('HBM bytes = 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE, counters in KiB, per launch.\n')
+L.append('| kernel | calls | avg us (rocprof) | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM MB / launch | algorithmic MB | ratio |\n|---|---|---|---|---|---|---|---|')
+alg = {'k_conv32_mfma': 904.3968, 'k_conv32_wgrad': 904.3968, 'k_bn_bwd_reduce': 904.3968, 'k_pw_fwd': 452.1984}
+for r in roof:
+    for key, a in alg.items():
+        if key + '<' in r['Name']:
+            f = pm['fetch'].get(r['Name']); w = pm['write'].get(r['Name'])
+            hbm = (2 * f + w) * 1024 / 1e6
+            L.append(f'| `{r["Name"].split("(")[0]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e3:.1f} | {f:.1f} | {w:.1f} | {hbm:.1f} | {a:.1f} | {hbm / a:.2f} |')
+L.append(f'\nbench.py\'s own HIP-event timing of the same loops (un-profiled run): `roofline.ms_per_launch` = {b["roofline"]["ms_per_launch"]} ms '
+         f'({b["roofline"]["achieved"]} GB/s algorithmic, frac {b["roofline"]["frac"]}), second = {b["roofline"]["second"]["ms_per_launch"]} ms, '
+         f'others = {[(o["kernel"], o["ms_per_launch"]) for o in b["roofline"].get("others", [])]}.')
+open(f'{P}/{tag}_summary.md', 'w').write('\n'.join(L) + '\n')
+print('\n'.join(L)[:3000])
