@@ -37,6 +37,13 @@ int tcct_set_outputs_prezeroed(int on);
  * img [N,Csrc,H,Wsrc] fp32 NCHW (Csrc 1 or 3) -> out [N,H,Wdst,4] NHWC (channel 3 and columns >= Wsrc zero). */
 int tcct_image_to_nhwc4(const float* img, void* out, int N, int Csrc, int H, int Wsrc, int Wdst, int dtype,
                         tcct_stream_t stream);
+/* GOALS B-scan / label-map preprocessing on uint8 HWC images (reference data/octnpy.py:82-85,91-112,119-130 and
+ * data/octgen.py:9-24 do this with OpenCV + albumentations on the CPU): dst[n, dy0+y, dx0+x, c] = src[n, sy0 + ny(y), sx0 + nx(x), c] * mul / div
+ * for (y, x) in the dh x dw destination window, `fill` elsewhere; ny/nx = cv2.INTER_NEAREST source index of a sh x sw -> dh x dw resize
+ * (min(floor(d * (1.0 / (dn / sn))), sn - 1) in double precision), applied after the optional vertical / horizontal flip of the window.
+ * Covers row crop, nearest resize, flips, label code changes (//30, *30) and pasting into the 800 x 1100 canvas in one gather. */
+int tcct_u8_gather2d(const uint8_t* src, uint8_t* dst, int N, int SH, int SW, int C, int sy0, int sx0, int sh, int sw, int DH, int DW,
+                     int dy0, int dx0, int dh, int dw, int flipy, int flipx, int mul, int div, int fill, tcct_stream_t stream);
 /* labels: one-hot int64 [N,C,H,W] (kite/loop_seg.py:119) -> class index uint8 [N,H,W] */
 int tcct_onehot_to_index(const int64_t* onehot, uint8_t* lab, int N, int C, int64_t HW, tcct_stream_t stream);
 /* int64 [N,H,Wsrc] class labels -> uint8 [N,H,Wdst] (columns >= Wsrc get class 0) */

@@ -54,6 +54,51 @@ extern "C" int tcct_image_to_nhwc4(const float* img, void* out, int N, int Csrc,
     TCCT_LAUNCH_OK();
 }
 
+// ------------------------------------------------------------------------------------------- GOALS image preprocessing (uint8)
+// One gather covers the reference's OpenCV/albumentations steps on B-scans and label maps (data/octnpy.py:82-85,91-112,119-130,
+// data/octgen.py:9-24): row/column crop (source ROI), cv2.INTER_NEAREST resize (ROI -> dh x dw), horizontal/vertical flip, the label
+// code change v*mul/div (gray level // 30 on the way in, class * 30 on the way out), and pasting into a larger canvas (destination
+// offset, everything else = fill).  Nearest-neighbour index exactly as OpenCV's resizeNN: s = min(floor(d * (1.0 / (dn / sn))), sn-1)
+// evaluated in double precision.  src [N,SH,SW,C] -> dst [N,DH,DW,C], both uint8 HWC (what cv2.imread returns).
+__global__ void k_u8_gather2d(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int N, int SH, int SW, int C, int sy0, int sx0,
+                              int sh, int sw, int DH, int DW, int dy0, int dx0, int dh, int dw, int flipy, int flipx, int mul, int div,
+                              int fill) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= DW) return;
+    const double ify = 1.0 / ((double)dh / (double)sh), ifx = 1.0 / ((double)dw / (double)sw);
+    int rx = x - dx0;
+    const bool xin = rx >= 0 && rx < dw;
+    if (flipx) rx = dw - 1 - rx;
+    const int sx = xin ? sx0 + min((int)floor((double)rx * ifx), sw - 1) : 0;
+    for (int row = blockIdx.y; row < N * DH; row += gridDim.y) {
+        const int n = row / DH, y = row - n * DH;
+        int ry = y - dy0;
+        const bool in = xin && ry >= 0 && ry < dh;
+        if (flipy) ry = dh - 1 - ry;
+        uint8_t* o = dst + ((int64_t)row * DW + x) * C;
+        if (in) {
+            const int sy = sy0 + min((int)floor((double)ry * ify), sh - 1);
+            const uint8_t* p = src + (((int64_t)n * SH + sy) * SW + sx) * C;
+            for (int c = 0; c < C; ++c) o[c] = (uint8_t)((int)p[c] * mul / div);
+        } else {
+            for (int c = 0; c < C; ++c) o[c] = (uint8_t)fill;
+        }
+    }
+}
+extern "C" int tcct_u8_gather2d(const uint8_t* src, uint8_t* dst, int N, int SH, int SW, int C, int sy0, int sx0, int sh, int sw, int DH,
+                                int DW, int dy0, int dx0, int dh, int dw, int flipy, int flipx, int mul, int div, int fill,
+                                tcct_stream_t stream) {
+    TCCT_CHECK(N >= 1 && SH >= 1 && SW >= 1 && C >= 1 && C <= 4 && DH >= 1 && DW >= 1, "u8_gather2d: bad shape");
+    TCCT_CHECK(sy0 >= 0 && sx0 >= 0 && sh >= 1 && sw >= 1 && sy0 + sh <= SH && sx0 + sw <= SW, "u8_gather2d: source ROI outside the image");
+    TCCT_CHECK(dh >= 1 && dw >= 1 && dy0 >= 0 && dx0 >= 0 && dy0 + dh <= DH && dx0 + dw <= DW, "u8_gather2d: destination ROI outside the canvas");
+    TCCT_CHECK(mul >= 1 && div >= 1 && mul <= 255 && fill >= 0 && fill <= 255, "u8_gather2d: bad value map");      // v*mul/div wraps to uint8 like numpy astype
+    const int64_t rows = (int64_t)N * DH;
+    dim3 g((unsigned)((DW + EW_BLOCK - 1) / EW_BLOCK), (unsigned)(rows < 4096 ? rows : 4096));
+    hipLaunchKernelGGL(k_u8_gather2d, g, dim3(EW_BLOCK), 0, (hipStream_t)stream, src, dst, N, SH, SW, C, sy0, sx0, sh, sw, DH, DW, dy0, dx0,
+                       dh, dw, flipy, flipx, mul, div, fill);
+    TCCT_LAUNCH_OK();
+}
+
 __global__ void k_onehot_to_index(const int64_t* __restrict__ oh, uint8_t* __restrict__ lab, int N, int C, int64_t HW) {
     int64_t total = (int64_t)N * HW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {

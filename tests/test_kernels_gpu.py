@@ -450,3 +450,33 @@ def test_mask_boundaries(shape):
     clean = (np.arange(H)[None, :, None, None] >= cuts.transpose(0, 2, 1)[:, None]).sum(-1).astype(np.uint8)
     got2 = MaskOneHot(torch.from_numpy(clean).cuda(), C).boundaries().cpu().numpy()
     assert np.array_equal(got2, cuts.astype(np.int32))                                # monotone mask: exactly the layer starts
+
+
+@pytest.mark.parametrize('shape', [(2, 800, 1100), (1, 650, 777), (3, 608, 512)])
+def test_goals_preprocessing_matches_oracle(shape):
+    """GOALS uint8 preprocessing on the GPU (crop rows, cv2.INTER_NEAREST resizes, label //30 and *30, canvas paste, crops, flips):
+    bit-exact against oracle/goals_oracle.py"""
+    import numpy as np, sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    import goals_oracle as G
+    from tcct_amd.data import goals
+    B, H, W = shape
+    g = np.random.default_rng(B * H + W)
+    img = g.integers(0, 256, size=(B, H, W, 3), dtype=np.uint8)
+    lab = (g.integers(0, 5, size=(B, H, W)) * 30 + g.integers(0, 30, size=(B, H, W))).astype(np.uint8)     # gray levels incl. off-grid values
+    im_o, lab_o = G.goals_prep(img, lab)
+    im_d, lab_d = goals.prep(torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda())
+    assert np.array_equal(im_d.cpu().numpy(), im_o) and np.array_equal(lab_d.cpu().numpy(), lab_o)
+    post_o = G.goals_post(lab_o)
+    post_d = goals.post(lab_d)
+    assert np.array_equal(post_d.cpu().numpy(), post_o)
+    for (y0, x0, fx, fy) in [(0, 0, False, False), (17, 33, True, False), (608 - 256, 512 - 256, True, True), (100, 7, False, True)]:
+        assert np.array_equal(goals.crop_flip(im_d, y0, x0, 256, 256, fx, fy).cpu().numpy(), G.crop_flip(im_o, True, y0, x0, 256, 256, fx, fy))
+        assert np.array_equal(goals.crop_flip(lab_d, y0, x0, 256, 256, fx, fy).cpu().numpy(), G.crop_flip(lab_o, False, y0, x0, 256, 256, fx, fy))
+    x = goals.to_model_input(goals.crop_flip(im_d, 0, 0, 256, 256))
+    assert x.shape == (B, 3, 256, 256) and x.dtype == torch.float32 and 0 <= x.min() and x.max() <= 1
+    from tcct_amd._lib import TcctError
+    with pytest.raises(TcctError):
+        goals.prep(torch.from_numpy(img), torch.from_numpy(lab))          # CPU tensors: no fallback
+    with pytest.raises(TcctError):
+        goals.crop_flip(im_d, 600, 0, 256, 256)                            # ROI outside the image

@@ -109,3 +109,25 @@ def test_oracle_known_answers():
         assert abs(on.item() - tn.item()) < 1e-4
         for p, q in zip(ps, qs):
             assert (p.detach() - q).abs().max().item() < 1e-6
+
+
+def test_goals_preprocessing_oracle_known_answers():
+    """numpy restatement of the GOALS image preprocessing (parity unpinned: OpenCV / albumentations are absent): known answers of
+    the nearest-neighbour rule and the round trip prep -> post"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    import goals_oracle as G
+    assert list(G.nn_index(8, 4)) == [0, 0, 1, 1, 2, 2, 3, 3]                      # 2x upsample repeats
+    assert list(G.nn_index(4, 8)) == [0, 2, 4, 6]                                  # 2x downsample takes every other sample
+    assert list(G.nn_index(5, 5)) == [0, 1, 2, 3, 4]                               # identity
+    assert G.nn_index(512, 1100)[-1] == int(np.floor(511 * (1.0 / (512 / 1100)))) and G.nn_index(1100, 512).max() == 511
+    g = np.random.default_rng(0)
+    img = g.integers(0, 256, size=(2, 800, 1100, 3), dtype=np.uint8)
+    cls = np.sort(g.integers(0, 5, size=(2, 800, 1100)), axis=1).astype(np.uint8)
+    im2, lab2 = G.goals_prep(img, cls * 30)
+    assert im2.shape == (2, 608, 512, 3) and lab2.shape == (2, 608, 512) and lab2.max() <= 4
+    assert np.array_equal(lab2[0, :, 0], cls[0, :608, 0]) and np.array_equal(im2[1, 5, 0], img[1, 5, 0])
+    back = G.goals_post(lab2)
+    assert back.shape == (2, 800, 1100) and (back[:, 608:] == 0).all() and set(np.unique(back)) <= {0, 30, 60, 90, 120}
+    c = G.crop_flip(img, True, 3, 5, 256, 256, True, False)
+    assert c.shape == (2, 256, 256, 3) and np.array_equal(c[0, 0, 0], img[0, 3, 5 + 255])
