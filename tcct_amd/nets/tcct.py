@@ -362,8 +362,11 @@ class FTC(nn.Module):
     """reference nets/tcct.py:944-1046 with SimpleFusion (flag_gate=False)."""
     __name__ = 'gtc'
 
-    def __init__(self, base_cnn, base_vit, out_channels=5, filters=32, compute_dtype=torch.float32):
+    def __init__(self, base_cnn, base_vit, out_channels=5, filters=32, compute_dtype=torch.float32, legacy_heads=False):
+        """legacy_heads: the older layout of the reference's shipped GOALS/HCMS/HEG checkpoints (task1/onnx/tcct_goals.py:949-1036):
+        no t32x convolutions, the aux heads read the decoder outputs directly"""
         super().__init__()
+        self.legacy_heads = bool(legacy_heads)
         self.base_vit = base_vit
         self.base_cnn = base_cnn
         ed, ld = base_vit.embed_dims, base_cnn.layer_dims
@@ -377,10 +380,11 @@ class FTC(nn.Module):
         self.dec2 = MPUpBlock(ld[-2], ld[-3])
         self.dec3 = MPUpBlock(ld[-3], ld[-4])
         self.dec4 = MPUpBlock(ld[-4], filters)
-        self.t321 = nn.Conv2d(ld[-2], filters, 1)
-        self.t322 = nn.Conv2d(ld[-3], filters, 1)
-        self.t323 = nn.Conv2d(ld[-4], filters, 1)
-        self.t324 = nn.Conv2d(filters, filters, 1)
+        if not self.legacy_heads:
+            self.t321 = nn.Conv2d(ld[-2], filters, 1)
+            self.t322 = nn.Conv2d(ld[-3], filters, 1)
+            self.t323 = nn.Conv2d(ld[-4], filters, 1)
+            self.t324 = nn.Conv2d(filters, filters, 1)
         self.aux0 = nn.Conv2d(filters, out_channels, 1)
         self.aux1 = nn.Conv2d(filters, out_channels, 1)
         self.aux2 = nn.Conv2d(filters, out_channels, 1)
@@ -392,6 +396,9 @@ class FTC(nn.Module):
     @property
     def feats(self):
         if self._feats is None and self._feats_src is not None:
+            if self.legacy_heads:
+                raise TcctError('the legacy-head layout (onnx/tcct_goals.py) is supported for inference and Dice/boundary training; its '
+                                'six-tensor `feats` (tcct_goals.py:1021) is not built')
             g0, g1, g2, size = self._feats_src
             n0 = ops.l2norm(g0)
             n1 = ops.bilinear(ops.l2norm(g1), size, False)
@@ -438,10 +445,13 @@ class FTC(nn.Module):
         d2 = self.dec2(d3, f[2])
         d1 = self.dec3(d2, f[1])
         d0 = self.dec4(d1, f[0])
-        g0 = _conv(self.t324, ops.add(f[0], d0))
-        g1 = _conv(self.t323, ops.add(f[1], d1))
-        g2 = _conv(self.t322, ops.add(f[2], d2))
-        g3 = _conv(self.t321, ops.add(f[3], d3))
+        if self.legacy_heads:       # tcct_goals.py:1027-1033: heads on the decoder outputs
+            g0, g1, g2, g3 = d0, d1, d2, d3
+        else:
+            g0 = _conv(self.t324, ops.add(f[0], d0))
+            g1 = _conv(self.t323, ops.add(f[1], d1))
+            g2 = _conv(self.t322, ops.add(f[2], d2))
+            g3 = _conv(self.t321, ops.add(f[3], d3))
         # norm_add([y0,y1,y2]) (reference tcct.py:937-942,1035) -> `self.feats`: evaluated lazily on first access (only the
         # feature-polarization loss reads it; with --udh=false the six level-0 passes are simply never launched)
         self._feats_src = (g0, g1, g2, size)
@@ -458,7 +468,7 @@ class FTC(nn.Module):
 def stc_tt(n_class=8, **args):
     """reference nets/tcct.py:1090-1095"""
     model = FTC(base_vit=mpvit_tiny(), base_cnn=CrossResNet(flag_tiny=True), out_channels=n_class,
-                compute_dtype=args.get('compute_dtype', torch.float32))
+                compute_dtype=args.get('compute_dtype', torch.float32), legacy_heads=args.get('legacy_heads', False))
     model.__name__ = 'stctt'
     return model
 

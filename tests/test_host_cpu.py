@@ -140,3 +140,30 @@ def test_data_parallel_plumbing_gloo_world2(tmp_path):
                         '--master-port', '29613', str(script)], capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'rank 0 ok' in r.stdout and 'rank 1 ok' in r.stdout
+
+
+def test_reference_checkpoint_layouts():
+    """the two checkpoint layouts the reference ships (tests/golden/ckpt_*.npz = real trained weights of task1/onnx/*.pt, bf16-rounded):
+    layout / class-count detection, strict=False key report identical to the reference's own for the current layout, loud errors"""
+    import numpy as np
+    from tcct_amd import checkpoint as C
+    from tcct_amd.nets import stc_tt, RegNet
+    from tcct_amd._lib import TcctError
+    duke = C.read_checkpoint(os.path.join(HERE, 'golden', 'ckpt_duke.npz'))
+    goals = C.read_checkpoint(os.path.join(HERE, 'golden', 'ckpt_goals_legacy.npz'))
+    assert C.describe(duke) == dict(n_class=9, legacy_heads=False) and C.describe(goals) == dict(n_class=5, legacy_heads=True)
+    z = np.load(os.path.join(HERE, 'golden', 'ckpt_duke.npz'))
+    net = RegNet(stc_tt(9), out_channels=9)
+    missing, unexpected = C.load_reference_checkpoint(net, duke)
+    assert missing == sorted(str(k) for k in z['missing']) and unexpected == sorted(str(k) for k in z['unexpected'])
+    assert torch.equal(net.base.aux0.weight.detach(), duke['base.aux0.weight']) and net.base.base_cnn.cnn[1].num_batches_tracked.item() > 0
+    leg = RegNet(stc_tt(5, legacy_heads=True), out_channels=5)
+    assert not any(k.startswith('base.t32') for k in leg.state_dict())
+    m2, u2 = C.load_reference_checkpoint(leg, goals)
+    assert all(k.startswith(('lap_map', 'tau')) for k in m2) and all(k.startswith(('aug.', 'lap_reg.2')) for k in u2)
+    with pytest.raises(TcctError):
+        C.load_reference_checkpoint(RegNet(stc_tt(5), out_channels=5), goals)           # current-layout model, legacy file
+    with pytest.raises(TcctError):
+        C.load_reference_checkpoint(RegNet(stc_tt(5), out_channels=5), duke)            # 9-class file, 5-class model
+    with pytest.raises(TcctError):
+        C.describe({'x': torch.zeros(1)})

@@ -287,3 +287,31 @@ def test_val_loop_runs(tmp_path):
     logs = k.val(epoch=0)
     assert set(logs) == {'val_iou', 'val_f1s'} and 0.0 <= logs['val_f1s'] <= 1.0 and 0.0 <= logs['val_iou'] <= 1.0
     assert torch.is_grad_enabled()
+
+
+@pytest.mark.parametrize('name', ['duke', 'goals_legacy'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_real_checkpoint_inference_matches_reference(name, dtype):
+    """REAL trained weights shipped with the reference (task1/onnx/tcct_duke.pt: current layout, 9 classes; tcct_goals.pt: legacy
+    layout, 5 classes; bf16-rounded in the fixture) on the B-scan crop the reference's own inference script reads
+    (onnx/oct_duke.png[:160,:160]): eval logits and argmax masks of all four heads vs the reference model's, generated by
+    oracle/make_golden_ckpt.py from the real reference code"""
+    import numpy as np
+    from tcct_amd import checkpoint as C
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', f'ckpt_{name}.npz'))
+    net = C.model_from_checkpoint(os.path.join(os.path.dirname(__file__), 'golden', f'ckpt_{name}.npz'), compute_dtype=dtype)
+    assert net.load_report['n_class'] == int(z['n_class']) and net.load_report['legacy_heads'] == (name == 'goals_legacy')
+    x = torch.from_numpy(z['input_u8']).permute(2, 0, 1)[None].float().div(255).cuda()
+    with torch.no_grad():
+        outs = net(x)
+    ref = torch.from_numpy(z['logits0'])
+    got = outs[0][0].float().cpu()
+    e = ((got - ref).abs().max() / ref.abs().max()).item()
+    masks = np.stack([o.float().softmax(1).argmax(1)[0].cpu().numpy() for o in outs])
+    agree = [(masks[i] == z['masks'][i]).mean() for i in range(4)]
+    print(name, dtype, 'logit rel err', e, 'mask agreement', agree)
+    if dtype == torch.float32:
+        assert e < 1e-3 and min(agree) > 0.999, (e, agree)
+    else:
+        assert e < 0.02 and min(agree) > 0.998, (e, agree)
+    assert len(np.unique(masks[0])) >= 4            # a real multi-layer segmentation, not a constant map
