@@ -86,6 +86,10 @@ int tcct_bn_eval_ab(int C, const float* gamma, const float* beta, float eps, con
                     const float* running_var, float* mean_rstd, float* ab, tcct_stream_t stream);
 int tcct_bn_apply(const void* x, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act, int dtype,
                   tcct_stream_t stream);
+/* y = post(a*pre(x)+b) + res (res, y like x): the normalisation pass with the residual / branch sum that follows it folded in
+ * (InvRes `x + conv2(f)`, nets/tcct.py:563-572; `tran_vit(x) + tran_cnn(c)`, :1012-1015) */
+int tcct_bn_apply_add(const void* x, const void* res, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act, int dtype,
+                      tcct_stream_t stream);
 int tcct_bn_bwd_reduce(const void* x, const void* dy, int64_t M, int C, const float* mean_rstd, const float* ab,
                        int pre_act, int post_act, double* sums /*[2C]*/, int dtype, tcct_stream_t stream);
 int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_t M, int C, const float* mean_rstd,
@@ -193,6 +197,9 @@ int tcct_maxpool2_bwd(const void* x, const void* dy, void* dx, int N, int H, int
  * (tcct.py:941,1042-1044).  bwd: dy [N,Ho,Wo,C] -> dx [N,H,W,C], gather form (no atomics) ------------------ */
 int tcct_bilinear_fwd(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int align_corners, int dtype,
                       tcct_stream_t stream);
+/* y = resize(x) + res (res, y [N,Ho,Wo,C]): upsampling with the decoder's skip-connection add folded in (nets/tcct.py:908-912) */
+int tcct_bilinear_add_fwd(const void* x, const void* res, void* y, int N, int H, int W, int C, int Ho, int Wo, int align_corners,
+                          int dtype, tcct_stream_t stream);
 int tcct_bilinear_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int align_corners, int dtype,
                       tcct_stream_t stream);
 /* ---- F.normalize(dim=channel, p=2, eps) (nets/tcct.py:940) ------------------------------------------------ */

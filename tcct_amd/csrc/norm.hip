@@ -113,7 +113,8 @@ extern "C" int tcct_bn_eval_ab(int C, const float* gamma, const float* beta, flo
 // ------------------------------------------------------------------ BN apply: y = post(a*pre(x)+b)
 template <typename T, int VEC>
 __global__ void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t M, int C, const float* __restrict__ ab,
-                           int pre_act, int post_act) {
+                           int pre_act, int post_act, const T* __restrict__ res) {
+    // res != NULL: y = post(a*pre(x)+b) + res  (InvRes `x + conv2(f)` and the tran_vit + tran_cnn sum without a separate add pass)
     // thread = fixed channel vector (per-channel scale/shift live in registers), rows strided over the grid
     const int CV = C / VEC;
     const int R = NB / CV;
@@ -129,28 +130,42 @@ __global__ void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t M
         const int64_t o1 = m * C + cv * VEC, o2 = m2 * C + cv * VEC;
         if (VEC == 4) {
             f4 v1 = ld4(x + o1), v2 = m2 < M ? ld4(x + o2) : f4zero(), r1, r2;
+            f4 e1 = f4zero(), e2 = f4zero();
+            if (res) { e1 = ld4(res + o1); if (m2 < M) e2 = ld4(res + o2); }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                r1.v[k] = act_fwd(post_act, a_[k] * act_fwd(pre_act, v1.v[k]) + b_[k]);
-                r2.v[k] = act_fwd(post_act, a_[k] * act_fwd(pre_act, v2.v[k]) + b_[k]);
+                r1.v[k] = act_fwd(post_act, a_[k] * act_fwd(pre_act, v1.v[k]) + b_[k]) + e1.v[k];
+                r2.v[k] = act_fwd(post_act, a_[k] * act_fwd(pre_act, v2.v[k]) + b_[k]) + e2.v[k];
             }
             st4(y + o1, r1);
             if (m2 < M) st4(y + o2, r2);
         } else {
-            stf(y + o1, act_fwd(post_act, a_[0] * act_fwd(pre_act, ldf(x + o1)) + b_[0]));
-            if (m2 < M) stf(y + o2, act_fwd(post_act, a_[0] * act_fwd(pre_act, ldf(x + o2)) + b_[0]));
+            stf(y + o1, act_fwd(post_act, a_[0] * act_fwd(pre_act, ldf(x + o1)) + b_[0]) + (res ? ldf(res + o1) : 0.f));
+            if (m2 < M) stf(y + o2, act_fwd(post_act, a_[0] * act_fwd(pre_act, ldf(x + o2)) + b_[0]) + (res ? ldf(res + o2) : 0.f));
         }
     }
 }
+static int bn_apply_impl(const void* x, const void* res, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act,
+                         int dtype, tcct_stream_t stream);
 extern "C" int tcct_bn_apply(const void* x, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act,
                              int dtype, tcct_stream_t stream) {
+    return bn_apply_impl(x, nullptr, y, M, C, ab, pre_act, post_act, dtype, stream);
+}
+/* y = post(a*pre(x)+b) + res: the normalisation pass with the residual / branch sum that follows it folded in */
+extern "C" int tcct_bn_apply_add(const void* x, const void* res, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act,
+                                 int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(res != nullptr, "bn_apply_add: res is NULL");
+    return bn_apply_impl(x, res, y, M, C, ab, pre_act, post_act, dtype, stream);
+}
+static int bn_apply_impl(const void* x, const void* res, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act,
+                         int dtype, tcct_stream_t stream) {
     TCCT_CHECK(C >= 1 && C <= NB, "bn_apply: C=%d unsupported", C);
     int vec = (C % 4 == 0) ? 4 : 1;
     int R = NB / (C / vec);
     int grid = tcct_grid(M, 2 * R, 256 * 16);
     hipStream_t st = (hipStream_t)stream;
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act)); }
-    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act)); }
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act, (const T*)res)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act, (const T*)res)); }
     TCCT_LAUNCH_OK();
 }
 

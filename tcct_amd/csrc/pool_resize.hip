@@ -146,7 +146,8 @@ __device__ __forceinline__ Lerp src_index(int o, float scale, int in, int align)
 // grid.y strides over output rows (n, ho) -- the row interpolation is block-uniform; threads of a row cover (wo, channel vector)
 template <typename T, int VEC>
 __global__ void k_bilinear_fwd(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo,
-                               float sh, float sw, int align) {
+                               float sh, float sw, int align, const T* __restrict__ res) {
+    // res != NULL: y = resize(x) + res  (decoder skip connection, tcct.py:908-912, without a separate add pass)
     const int CV = C / VEC;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Wo * CV) return;
@@ -164,10 +165,17 @@ __global__ void k_bilinear_fwd(const T* __restrict__ x, T* __restrict__ y, int N
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 t.v[k] = a.l0 * (b.l0 * v00.v[k] + b.l1 * v01.v[k]) + a.l1 * (b.l0 * v10.v[k] + b.l1 * v11.v[k]);
+            if (res) {
+                const f4 e = ld4(res + ((int64_t)row * Wo + wo) * C + c);       // one rounding for resize + add
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t.v[k] += e.v[k];
+            }
             st4(yo, t);
         } else {
             float v00 = ldf(r0 + o0), v01 = ldf(r0 + o1), v10 = ldf(r1 + o0), v11 = ldf(r1 + o1);
-            stf(yo, a.l0 * (b.l0 * v00 + b.l1 * v01) + a.l1 * (b.l0 * v10 + b.l1 * v11));
+            float v = a.l0 * (b.l0 * v00 + b.l1 * v01) + a.l1 * (b.l0 * v10 + b.l1 * v11);
+            if (res) v += ldf(res + ((int64_t)row * Wo + wo) * C + c);
+            stf(yo, v);
         }
     }
 }
@@ -292,15 +300,27 @@ __global__ void __launch_bounds__(PB) k_bilinear_bwd_tab(const T* __restrict__ d
     }
 }
 
+static int bilinear_fwd_impl(const void* x, const void* res, void* y, int N, int H, int W, int C, int Ho, int Wo, int align_corners,
+                             int dtype, tcct_stream_t stream);
 extern "C" int tcct_bilinear_fwd(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int align_corners,
                                  int dtype, tcct_stream_t stream) {
+    return bilinear_fwd_impl(x, nullptr, y, N, H, W, C, Ho, Wo, align_corners, dtype, stream);
+}
+/* y = resize(x) + res with res, y [N,Ho,Wo,C]: upsampling with the skip-connection add folded in */
+extern "C" int tcct_bilinear_add_fwd(const void* x, const void* res, void* y, int N, int H, int W, int C, int Ho, int Wo,
+                                     int align_corners, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(res != nullptr, "bilinear_add_fwd: res is NULL");
+    return bilinear_fwd_impl(x, res, y, N, H, W, C, Ho, Wo, align_corners, dtype, stream);
+}
+static int bilinear_fwd_impl(const void* x, const void* res, void* y, int N, int H, int W, int C, int Ho, int Wo, int align_corners,
+                             int dtype, tcct_stream_t stream) {
     TCCT_CHECK(H > 0 && W > 0 && Ho > 0 && Wo > 0, "bilinear_fwd: bad sizes");
     float sh = align_corners ? (Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f) : (float)H / (float)Ho;
     float sw = align_corners ? (Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f) : (float)W / (float)Wo;
     int vec = (C % 4 == 0) ? 4 : 1;
     hipStream_t st = (hipStream_t)stream;
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_fwd<T, 4>), row_grid(Wo * (C / 4), (int64_t)N * Ho), dim3(PB), 0, st, (const T*)x, (T*)y, N, H, W, C, Ho, Wo, sh, sw, align_corners)); }
-    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_fwd<T, 1>), row_grid(Wo * C, (int64_t)N * Ho), dim3(PB), 0, st, (const T*)x, (T*)y, N, H, W, C, Ho, Wo, sh, sw, align_corners)); }
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_fwd<T, 4>), row_grid(Wo * (C / 4), (int64_t)N * Ho), dim3(PB), 0, st, (const T*)x, (T*)y, N, H, W, C, Ho, Wo, sh, sw, align_corners, (const T*)res)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_fwd<T, 1>), row_grid(Wo * C, (int64_t)N * Ho), dim3(PB), 0, st, (const T*)x, (T*)y, N, H, W, C, Ho, Wo, sh, sw, align_corners, (const T*)res)); }
     TCCT_LAUNCH_OK();
 }
 /* dy [N,Ho,Wo,C] -> dx [N,H,W,C] (H,W = forward input size) */

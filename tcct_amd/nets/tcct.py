@@ -27,18 +27,19 @@ def _dw(m, x, add_input=False):
     return ops.dwconv3x3(x, m.weight, m.bias, stride=m.stride[0], add_input=add_input)
 
 
-def _bn(m, x, pre=None, post=None):
+def _bn(m, x, pre=None, post=None, residual=None):
     return ops.batchnorm(x, m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked, eps=m.eps,
-                         momentum=m.momentum, pre_act=pre, post_act=post, training=m.training)
+                         momentum=m.momentum, pre_act=pre, post_act=post, training=m.training, residual=residual)
 
 
-def _conv_bn(mc, mb, x, pre=None, post=None):
+def _conv_bn(mc, mb, x, pre=None, post=None, residual=None):
     """post(BN(pre(conv(x)))).  Training: convolution with the BatchNorm statistics fused into its epilogue, then the BN pass;
     eval under no_grad: one kernel, BatchNorm and activations folded into the convolution epilogue (ops.conv_bn_act)."""
     if mb.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
-        return _bn(mb, _conv(mc, x, stats_pre=(pre or 'none') if mb.training else None), pre=pre, post=post)
-    return ops.conv_bn_act(x, mc.weight, mc.bias, mc.stride[0], tuple(mc.padding),
-                           (mb.weight, mb.bias, mb.running_mean, mb.running_var, mb.eps), pre, post)
+        return _bn(mb, _conv(mc, x, stats_pre=(pre or 'none') if mb.training else None), pre=pre, post=post, residual=residual)
+    y = ops.conv_bn_act(x, mc.weight, mc.bias, mc.stride[0], tuple(mc.padding),
+                        (mb.weight, mb.bias, mb.running_mean, mb.running_var, mb.eps), pre, post)
+    return y if residual is None else ops.add(y, residual)
 
 
 def _nchw_view(y):
@@ -121,7 +122,7 @@ class Conv2d_BN(nn.Module):
         self.conv.weight.data.normal_(0.0, math.sqrt(2.0 / fan_out))
         self.act = act
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         sp = 'none' if self.training else None
         if self.conv.in_channels == 3:          # stem[0]: 3-channel input -> im2col + pointwise MFMA
             if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
@@ -130,7 +131,7 @@ class Conv2d_BN(nn.Module):
             m = self.bn
             return ops.conv3x3_c3(x, self.conv.weight, None, self.conv.stride[0], post_act='hswish' if self.act else None,
                                   infer_bn=(m.weight, m.bias, m.running_mean, m.running_var, m.eps))
-        return _conv_bn(self.conv, self.bn, x, post='hswish' if self.act else None)
+        return _conv_bn(self.conv, self.bn, x, post='hswish' if self.act else None, residual=residual)
 
 
 class DWConv2d_BN(nn.Module):
@@ -256,7 +257,7 @@ class ResBlock(nn.Module):
     def forward(self, x):
         f = self.conv1(x)
         f = _bn(self.norm, _dw(self.dwconv, f), post='hswish')
-        return ops.add(x, self.conv2(f))
+        return self.conv2(f, residual=x)          # x + BN(conv2(f)): the add rides on the normalisation pass
 
 
 class MHCA_stage(nn.Module):
@@ -354,8 +355,7 @@ class MPUpBlock(nn.Module):
 
     def forward(self, x1, x2):
         y = _conv_bn(self.prep[0], self.prep[1], x1, post='lrelu')
-        y = ops.bilinear(y, (x1.shape[1] * 2, x1.shape[2] * 2), True)
-        return _conv(self.post[0], ops.add(y, x2))
+        return _conv(self.post[0], ops.bilinear(y, (x1.shape[1] * 2, x1.shape[2] * 2), True, residual=x2))
 
 
 class FTC(nn.Module):
@@ -439,7 +439,7 @@ class FTC(nn.Module):
         f = [c1]
         for j, (v, c) in enumerate(((v2, c2), (v3, c3), (v4, c4), (v5, c5))):
             tv, tc = getattr(self, f'tran_vit{j}'), getattr(self, f'tran_cnn{j}')
-            f.append(ops.add(_conv_bn(tv[0], tv[1], v), _conv_bn(tc[0], tc[1], c)))
+            f.append(_conv_bn(tc[0], tc[1], c, residual=_conv_bn(tv[0], tv[1], v)))
         y8 = _conv_bn(self.head[0], self.head[1], f[4], post='lrelu')
         d3 = self.dec1(y8, f[3])
         d2 = self.dec2(d3, f[2])

@@ -361,7 +361,7 @@ def dwconv3x3(x, w, bias=None, stride=1, add_input=False):
 # ------------------------------------------------------------------------------------------------- norms
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, nbt, eps, momentum, pre, post, training):
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, eps, momentum, pre, post, training, res=None):
         _chk(x, gamma, beta)
         C = x.shape[-1]
         M = x.numel() // C
@@ -379,11 +379,18 @@ class _BatchNorm(torch.autograd.Function):
         else:
             lib.bn_eval_ab(C, gamma, beta, eps, rm, rv, mean_rstd, ab)
         y = torch.empty_like(x)
-        lib.bn_apply(x, y, M, C, ab, pre, post, dc)
+        if res is not None:
+            _chk(res)
+            if res.shape != x.shape or res.dtype != x.dtype:
+                raise TcctError('batchnorm: residual must have the shape and dtype of the input')
+            lib.bn_apply_add(x, res, y, M, C, ab, pre, post, dc)
+        else:
+            lib.bn_apply(x, y, M, C, ab, pre, post, dc)
         if training:
             ctx.save_for_backward(x, gamma, mean_rstd, ab)
             ctx.cfg = (pre, post)
             ctx.beta_param = beta
+            ctx.has_res = res is not None
         return y
 
     @staticmethod
@@ -400,16 +407,16 @@ class _BatchNorm(torch.autograd.Function):
         dg = _grad_out(gamma) if ZERO.active and getattr(gamma, '_grad_slot', None) is not None else torch.empty(C, device=x.device, dtype=torch.float32)
         db = _grad_out(ctx.beta_param) if ZERO.active and getattr(ctx.beta_param, '_grad_slot', None) is not None else torch.empty(C, device=x.device, dtype=torch.float32)
         lib.bn_bwd_apply(x, dy, dx, M, C, mean_rstd, ab, gamma, sums, pre, post, dg, db, dc)
-        return dx, _ret(dg, gamma), _ret(db, ctx.beta_param), None, None, None, None, None, None, None, None
+        return dx, _ret(dg, gamma), _ret(db, ctx.beta_param), None, None, None, None, None, None, None, None, (dy if ctx.has_res else None)
 
 
 def batchnorm(x, gamma, beta, running_mean, running_var, num_batches_tracked=None, eps=1e-5, momentum=0.1,
-              pre_act=None, post_act=None, training=True):
-    """y = post_act(BN(pre_act(x))) over the last (channel) dim, torch train-mode semantics incl. running stats."""
+              pre_act=None, post_act=None, training=True, residual=None):
+    """y = post_act(BN(pre_act(x))) [+ residual] over the last (channel) dim, torch train-mode semantics incl. running stats."""
     if not training and torch.is_grad_enabled() and x.requires_grad:
         raise TcctError('eval-mode batchnorm is inference-only here')
     return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, float(eps), float(momentum),
-                            ACT[pre_act], ACT[post_act], bool(training))
+                            ACT[pre_act], ACT[post_act], bool(training), residual)
 
 
 class _Bn2AddAct(torch.autograd.Function):
@@ -680,12 +687,19 @@ def maxpool2(x):
 
 class _Bilinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, Ho, Wo, align):
+    def forward(ctx, x, Ho, Wo, align, res=None):
         _chk(x)
         N, H, W, C = x.shape
         y = torch.empty((N, Ho, Wo, C), device=x.device, dtype=x.dtype)
-        lib.bilinear_fwd(x, y, N, H, W, C, Ho, Wo, int(align), dtype_code(x.dtype))
+        if res is not None:
+            _chk(res)
+            if tuple(res.shape) != (N, Ho, Wo, C) or res.dtype != x.dtype:
+                raise TcctError('bilinear: residual must have the output shape and the input dtype')
+            lib.bilinear_add_fwd(x, res, y, N, H, W, C, Ho, Wo, int(align), dtype_code(x.dtype))
+        else:
+            lib.bilinear_fwd(x, y, N, H, W, C, Ho, Wo, int(align), dtype_code(x.dtype))
         ctx.cfg = (N, H, W, C, Ho, Wo, int(align))
+        ctx.has_res = res is not None
         return y
 
     @staticmethod
@@ -694,13 +708,14 @@ class _Bilinear(torch.autograd.Function):
         dy = _c(dy)
         dx = torch.empty((N, H, W, C), device=dy.device, dtype=dy.dtype)
         lib.bilinear_bwd(dy, dx, N, H, W, C, Ho, Wo, align, dtype_code(dy.dtype))
-        return dx, None, None, None
+        return dx, None, None, None, (dy if ctx.has_res else None)
 
 
-def bilinear(x, size, align_corners):
+def bilinear(x, size, align_corners, residual=None):
+    """F.interpolate(mode='bilinear') on NHWC; residual (output-shaped) is added in the same pass (decoder skip connections)"""
     if tuple(x.shape[1:3]) == tuple(size):
-        return x                       # identity resize (torch returns the same values)
-    return _Bilinear.apply(x, int(size[0]), int(size[1]), bool(align_corners))
+        return x if residual is None else add(x, residual)      # identity resize (torch returns the same values)
+    return _Bilinear.apply(x, int(size[0]), int(size[1]), bool(align_corners), residual)
 
 
 class _L2Norm(torch.autograd.Function):

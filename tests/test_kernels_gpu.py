@@ -480,3 +480,38 @@ def test_goals_preprocessing_matches_oracle(shape):
         goals.prep(torch.from_numpy(img), torch.from_numpy(lab))          # CPU tensors: no fallback
     with pytest.raises(TcctError):
         goals.crop_flip(im_d, 600, 0, 256, 256)                            # ROI outside the image
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_residual_folded_into_batchnorm_and_bilinear(dt):
+    """y = post(BN(x)) + r and y = resize(x) + r in one pass each (InvRes / tran sums / decoder skips): values and all gradients"""
+    from tcct_amd import ops
+    N, C, H, W = 2, 64, 9, 14
+    x = rnd(N, C, H, W, dt=dt).requires_grad_(True)
+    r = rnd(N, C, H, W, seed=5, dt=dt).requires_grad_(True)
+    g, b = (1 + 0.2 * rnd(C, seed=1)).requires_grad_(True), (0.1 * rnd(C, seed=2)).requires_grad_(True)
+    y = F.hardswish(F.batch_norm(x, None, None, g, b, True, 0.1, 1e-5)) + r
+    gy = rnd(*y.shape, seed=3, dt=dt)
+    y.backward(gy)
+    xd, rd = nhwc(x.detach(), dt).requires_grad_(True), nhwc(r.detach(), dt).requires_grad_(True)
+    gd, bd = g.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    rm, rv, nb = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.zeros((), device='cuda', dtype=torch.int64)
+    yd = ops.batchnorm(xd, gd, bd, rm, rv, nb, 1e-5, 0.1, None, 'hswish', True, residual=rd)
+    t = tol(dt)
+    torch.testing.assert_close(nchw(yd), y.detach(), **t)
+    yd.backward(nhwc(gy, dt))
+    torch.testing.assert_close(nchw(xd.grad), x.grad, rtol=t['rtol'], atol=t['atol'] * 2)
+    torch.testing.assert_close(nchw(rd.grad), r.grad, **t)
+    torch.testing.assert_close(gd.grad.cpu(), g.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, g.grad.abs().max().item()))
+    # bilinear + skip
+    x2 = rnd(N, 32, 6, 10, dt=dt).requires_grad_(True)
+    s2 = rnd(N, 32, 12, 20, seed=7, dt=dt).requires_grad_(True)
+    y2 = F.interpolate(x2, size=(12, 20), mode='bilinear', align_corners=True) + s2
+    gy2 = rnd(*y2.shape, seed=8, dt=dt)
+    y2.backward(gy2)
+    x2d, s2d = nhwc(x2.detach(), dt).requires_grad_(True), nhwc(s2.detach(), dt).requires_grad_(True)
+    y2d = ops.bilinear(x2d, (12, 20), True, residual=s2d)
+    torch.testing.assert_close(nchw(y2d), y2.detach(), **t)
+    y2d.backward(nhwc(gy2, dt))
+    torch.testing.assert_close(nchw(x2d.grad), x2.grad, rtol=t['rtol'], atol=t['atol'] * 4)
+    torch.testing.assert_close(nchw(s2d.grad), s2.grad, **t)
