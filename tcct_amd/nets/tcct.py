@@ -434,8 +434,7 @@ class FTC(nn.Module):
     def forward(self, x):
         size = (x.shape[2], x.shape[3])
         x = self._to_nhwc4(x)
-        c1, c2, c3, c4, c5 = self.base_cnn(x)
-        v2, v3, v4, v5 = self.base_vit.forward_features(x)
+        (c1, c2, c3, c4, c5), (v2, v3, v4, v5) = ops.run_parallel('vit', lambda: self.base_cnn(x), lambda: self.base_vit.forward_features(x))
         f = [c1]
         for j, (v, c) in enumerate(((v2, c2), (v3, c3), (v4, c4), (v5, c5))):
             tv, tc = getattr(self, f'tran_vit{j}'), getattr(self, f'tran_cnn{j}')

@@ -4,6 +4,8 @@ PyTorch here is plumbing only (device memory via the caching allocator, the curr
 every arithmetic op of the hot path is a HIP kernel behind `tcct_amd._lib.lib`.  No CPU fallback exists: a CPU tensor
 or a missing .so raises.  Activations are NHWC-contiguous (`[N,H,W,C]`, tokens `[B,N,C]` are the same memory).
 """
+import os
+
 import torch
 
 from ._lib import lib, dtype_code, TcctError, F32, BF16  # noqa: F401
@@ -241,6 +243,41 @@ def conv2d(x, w, bias=None, stride=1, pad=0, out_dtype=None, stats_pre=None):
     if box is not None and box[1] is not None:
         y._bn_sums = (box[1], box[0])
     return y
+
+
+# The two encoders (CNN / ViT) only share the input and are issued on separate HIP streams:
+# the launch-latency-bound kernels of the coarse levels then overlap other work instead of running one after another on an
+# otherwise idle chip (-2.5 ms/step; forking block12/block34 and InvRes/token-mixer
+# as well gained nothing more).  Autograd replays every node on the stream of its forward, so
+# the backward pass overlaps the same way.  TCCT_STREAMS=0 issues everything on one stream.
+PARALLEL_BRANCHES = os.environ.get('TCCT_STREAMS', '1') != '0'
+_SIDE_STREAMS = {}
+
+
+def _tensors(o):
+    if torch.is_tensor(o):
+        yield o
+    elif isinstance(o, (list, tuple)):
+        for e in o:
+            yield from _tensors(e)
+
+
+def run_parallel(tag, fa, fb):
+    """(fa(), fb()) with fb issued on the side stream `tag` and joined before returning"""
+    if not (PARALLEL_BRANCHES and torch.cuda.is_available()):
+        return fa(), fb()
+    cur = torch.cuda.current_stream()
+    side = _SIDE_STREAMS.get((tag, cur.device.index))
+    if side is None:
+        side = _SIDE_STREAMS[(tag, cur.device.index)] = torch.cuda.Stream(device=cur.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        rb = fb()
+    ra = fa()
+    cur.wait_stream(side)
+    for t in _tensors(rb):
+        t.record_stream(cur)        # allocated on the side stream, consumed on the current one
+    return ra, rb
 
 
 INFER_FUSE = True       # eval-mode forward under no_grad folds BatchNorm / activations into the convolution epilogues (False: op by op)
