@@ -61,6 +61,48 @@ def begin_step(device):
 
 def end_step():
     ZERO.end()
+    if _WGRAD_USED:             # weight gradients were issued on the side stream: the optimizer (current stream) must see them
+        cur = torch.cuda.current_stream()
+        for st in _WGRAD_USED.values():
+            cur.wait_stream(st)
+        _WGRAD_USED.clear()
+
+
+# Weight-gradient kernels only feed the optimizer, so inside a pooled step they are issued on a side stream and joined in
+# end_step(): the input-gradient chain (the critical path of backward) continues without waiting for them and the
+# latency-bound weight gradients of the coarse levels overlap it.  TCCT_STREAMS=0 disables.
+_WGRAD_USED = {}
+
+
+class _wgrad_stream:
+    def __init__(self, enable, *tensors):
+        self.enable, self.tensors = enable, tensors
+
+    def __enter__(self):
+        if not self.enable:
+            return self
+        self.cur = torch.cuda.current_stream()
+        key = ('wgrad', self.cur.device.index)
+        self.side = _SIDE_STREAMS.get(key)
+        if self.side is None:
+            self.side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=self.cur.device)
+        self.side.wait_stream(self.cur)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if not self.enable:
+            return False
+        self.ctx.__exit__(*exc)
+        for t in self.tensors:
+            t.record_stream(self.side)      # autograd may free x / dy as soon as this node returns
+        _WGRAD_USED[id(self.side)] = self.side
+        return False
+
+
+def _slot_written(*params):
+    return PARALLEL_BRANCHES and ZERO.active and all(p is None or getattr(p, '_grad_slot', None) is not None for p in params)
 
 
 def _grad_out(param, shape=None):
@@ -201,28 +243,29 @@ class _Conv2d(torch.autograd.Function):
             else:
                 lib.conv2d_dgrad(dy, w, dx, N, H, W, Cin, Cout, KH, KW, padh, padw, dtype_code(dy.dtype), dtype_code(x.dtype))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw = _grad_out(wsrc, tuple(w.shape))
-            db = _grad_out(bsrc) if has_bias else None
-            if _mfma32_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
-                lib.conv32_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
-            elif _mfma_slabs_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
-                if not ZERO.active:
-                    dw.zero_()
-                    if db is not None:
-                        db.zero_()
-                for oh in range(Cout // 32):
-                    for ih in range(Cin // 32):
-                        lib.conv32_wgrad_strided(x, dy, dw, db if ih == 0 else None, N, H, W, KH, KW, padh, padw, Cin, 32 * ih, Cout,
-                                                 32 * oh, Cin, 32 * oh, 32 * ih)
-            elif (_pw_ok(x.dtype, Cin, Cin_w, KH, KW, stride, padh, padw) and dy.dtype == torch.bfloat16 and Cout % 32 == 0
-                  and Cout <= 160):
-                lib.pw_wgrad(x, dy, dw, db, N * H * W, Cin, Cout)
-            elif KH == 1 and KW == 1 and stride == 1 and Cout <= 8 and Cin == Cin_w and Cin <= 256 and (
-                    x.dtype == torch.bfloat16 or dy.dtype == torch.float32):
-                lib.pw_wgrad_smalln(x, dy, dw, db, N * H * W, Cin, Cout, dtype_code(x.dtype), dtype_code(dy.dtype))
-            else:
-                lib.conv2d_wgrad(x, dy, dw, db, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
-                                 dtype_code(dy.dtype))
+            with _wgrad_stream(_slot_written(wsrc, bsrc if has_bias else None), x, dy):
+                dw = _grad_out(wsrc, tuple(w.shape))
+                db = _grad_out(bsrc) if has_bias else None
+                if _mfma32_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+                    lib.conv32_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
+                elif _mfma_slabs_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+                    if not ZERO.active:
+                        dw.zero_()
+                        if db is not None:
+                            db.zero_()
+                    for oh in range(Cout // 32):
+                        for ih in range(Cin // 32):
+                            lib.conv32_wgrad_strided(x, dy, dw, db if ih == 0 else None, N, H, W, KH, KW, padh, padw, Cin, 32 * ih, Cout,
+                                                     32 * oh, Cin, 32 * oh, 32 * ih)
+                elif (_pw_ok(x.dtype, Cin, Cin_w, KH, KW, stride, padh, padw) and dy.dtype == torch.bfloat16 and Cout % 32 == 0
+                      and Cout <= 160):
+                    lib.pw_wgrad(x, dy, dw, db, N * H * W, Cin, Cout)
+                elif KH == 1 and KW == 1 and stride == 1 and Cout <= 8 and Cin == Cin_w and Cin <= 256 and (
+                        x.dtype == torch.bfloat16 or dy.dtype == torch.float32):
+                    lib.pw_wgrad_smalln(x, dy, dw, db, N * H * W, Cin, Cout, dtype_code(x.dtype), dtype_code(dy.dtype))
+                else:
+                    lib.conv2d_wgrad(x, dy, dw, db, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
+                                     dtype_code(dy.dtype))
         return dx, _ret(dw, wsrc), _ret(db, bsrc), None, None, None, None, None
 
 
