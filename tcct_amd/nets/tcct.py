@@ -93,16 +93,16 @@ class CrossResNet(nn.Module):
             self.path_estan.append(CrossCNNBlock(layers[i], layers[i + 1], KSIZES[i + 1]))
         self.cnn = nn.Sequential(nn.Conv2d(3, layers[0], 3, 1, 1), nn.BatchNorm2d(layers[0]))
 
-    def forward(self, x):
-        """x: NHWC [B,H,W,4] (3 image channels + zero pad)."""
+    def forward(self, x, levels=None):
+        """x: NHWC [B,H,W,4] (3 image channels + zero pad); levels: only the first `levels` resolutions (vitu needs level 0 only)."""
         xs = []
         m = self.cnn[1]
         if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
             x = _bn(m, ops.conv3x3_c3(x, self.cnn[0].weight, self.cnn[0].bias, 1, stats_pre='none' if self.training else None))
         else:
             x = ops.conv3x3_c3(x, self.cnn[0].weight, self.cnn[0].bias, 1, infer_bn=(m.weight, m.bias, m.running_mean, m.running_var, m.eps))
-        n = len(self.path_estan)
-        for i, enc in enumerate(self.path_estan):
+        n = len(self.path_estan) if levels is None else int(levels)
+        for i, enc in enumerate(self.path_estan[:n]):
             x = enc(x)
             xs.append(x)
             if i + 1 < n:               # the reference also pools after the last level; that result is unused
@@ -362,11 +362,17 @@ class FTC(nn.Module):
     """reference nets/tcct.py:944-1046 with SimpleFusion (flag_gate=False)."""
     __name__ = 'gtc'
 
-    def __init__(self, base_cnn, base_vit, out_channels=5, filters=32, compute_dtype=torch.float32, legacy_heads=False):
+    def __init__(self, base_cnn, base_vit, out_channels=5, filters=32, compute_dtype=torch.float32, legacy_heads=False,
+                 flag_gate=False, flag_cnn=True, flag_vit=True):
         """legacy_heads: the older layout of the reference's shipped GOALS/HCMS/HEG checkpoints (task1/onnx/tcct_goals.py:949-1036):
         no t32x convolutions, the aux heads read the decoder outputs directly"""
         super().__init__()
         self.legacy_heads = bool(legacy_heads)
+        # sibling variants of the reference (nets/tcct.py:1090-1136): gtc_* fuse with GateFusion (:916-932), cnnu / vitu drop one
+        # encoder from the fusion (:1016-1019).  All modules (and state_dict keys) exist in every variant, as in the reference.
+        self.flag_gate, self.flag_cnn, self.flag_vit = bool(flag_gate), bool(flag_cnn), bool(flag_vit)
+        if not (self.flag_cnn or self.flag_vit):
+            raise TcctError('FTC needs at least one of flag_cnn / flag_vit')
         self.base_vit = base_vit
         self.base_cnn = base_cnn
         ed, ld = base_vit.embed_dims, base_cnn.layer_dims
@@ -434,11 +440,28 @@ class FTC(nn.Module):
     def forward(self, x):
         size = (x.shape[2], x.shape[3])
         x = self._to_nhwc4(x)
-        (c1, c2, c3, c4, c5), (v2, v3, v4, v5) = ops.run_parallel('vit', lambda: self.base_cnn(x), lambda: self.base_vit.forward_features(x))
-        f = [c1]
-        for j, (v, c) in enumerate(((v2, c2), (v3, c3), (v4, c4), (v5, c5))):
-            tv, tc = getattr(self, f'tran_vit{j}'), getattr(self, f'tran_cnn{j}')
-            f.append(_conv_bn(tc[0], tc[1], c, residual=_conv_bn(tv[0], tv[1], v)))
+        if self.flag_vit and self.flag_cnn:
+            (c1, c2, c3, c4, c5), (v2, v3, v4, v5) = ops.run_parallel('vit', lambda: self.base_cnn(x), lambda: self.base_vit.forward_features(x))
+            f = [c1]
+            for j, (v, c) in enumerate(((v2, c2), (v3, c3), (v4, c4), (v5, c5))):
+                tv, tc = getattr(self, f'tran_vit{j}'), getattr(self, f'tran_cnn{j}')
+                if self.flag_gate:
+                    if self.training:
+                        raise TcctError('GateFusion training (random bicubic alpha field, tcct.py:922-929) is not built; gtc_* models '
+                                        'run in eval mode, where alpha = 0.5')
+                    sm = _conv_bn(tc[0], tc[1], c, residual=_conv_bn(tv[0], tv[1], v))      # x1*0.5 + x2*0.5 == (x1+x2)*0.5 exactly
+                    half = torch.empty_like(sm)
+                    ops.lib.scale(sm, half, sm.numel(), 0.5, ops.dtype_code(sm.dtype))
+                    f.append(half)
+                else:
+                    f.append(_conv_bn(tc[0], tc[1], c, residual=_conv_bn(tv[0], tv[1], v)))
+        elif self.flag_cnn:
+            # the reference also runs the ViT encoder and discards it (only its BatchNorm running statistics move); skipped here
+            f = list(self.base_cnn(x))
+        else:
+            # only level 0 of the CNN encoder is consumed (c1 is the decoder's last skip); the deeper CNN levels are skipped
+            (c1,), (v2, v3, v4, v5) = ops.run_parallel('vit', lambda: self.base_cnn(x, levels=1), lambda: self.base_vit.forward_features(x))
+            f = [c1] + [_conv_bn(getattr(self, f'tran_vit{j}')[0], getattr(self, f'tran_vit{j}')[1], v) for j, v in enumerate((v2, v3, v4, v5))]
         y8 = _conv_bn(self.head[0], self.head[1], f[4], post='lrelu')
         d3 = self.dec1(y8, f[3])
         d2 = self.dec2(d3, f[2])
@@ -473,3 +496,25 @@ def stc_tt(n_class=8, **args):
 
 
 tcct = stc_tt
+
+
+def _variant(name, n_class, args, **flags):
+    model = FTC(base_vit=mpvit_tiny(), base_cnn=CrossResNet(flag_tiny=True), out_channels=n_class,
+                compute_dtype=args.get('compute_dtype', torch.float32), **flags)
+    model.__name__ = name
+    return model
+
+
+def gtc_tt(n_class=8, **args):
+    """reference nets/tcct.py:1048-1053 (GateFusion; eval only here)"""
+    return _variant('gtctt', n_class, args, flag_gate=True)
+
+
+def cnnu(n_class=8, **args):
+    """reference nets/tcct.py:1120-1126: CNN encoder + decoder, no ViT fusion"""
+    return _variant('cnnu', n_class, args, flag_vit=False, flag_cnn=True)
+
+
+def vitu(n_class=8, **args):
+    """reference nets/tcct.py:1128-1134: ViT encoder features (+ the level-0 CNN skip) + decoder"""
+    return _variant('vitu', n_class, args, flag_vit=True, flag_cnn=False)

@@ -315,3 +315,44 @@ def test_real_checkpoint_inference_matches_reference(name, dtype):
     else:
         assert e < 0.02 and min(agree) > 0.998, (e, agree)
     assert len(np.unique(masks[0])) >= 4            # a real multi-layer segmentation, not a constant map
+
+
+@pytest.mark.parametrize('name', ['gtc_tt', 'cnnu', 'vitu'])
+def test_sibling_variants_match_reference(name, tmp_path):
+    """gtc_tt (GateFusion, eval), cnnu, vitu (reference nets/tcct.py:1048-1053,1120-1134): logits of all four heads vs the real
+    reference forward on formula weights (tests/golden/variants_2x32x64.npz, oracle/make_golden_variants.py); same state_dict keys"""
+    import numpy as np
+    import tcct_oracle as O
+    from tcct_amd import nets
+    from tcct_amd._lib import TcctError
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'variants_2x32x64.npz'))
+    model = nets.RegNet(getattr(nets, name)(5), con='cos', out_channels=5)
+    ref_keys = {k: tuple(s) for k, s in json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'state_dict_keys.json')))}
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == ref_keys
+    model.load_state_dict(O.formula_state_dict(list(ref_keys.items())), strict=True)
+    model = model.cuda()
+    model.base.base_vit.drop_probs = [0.0] * 4
+    x = torch.from_numpy(z['img']).cuda()
+    model.eval()
+    with torch.no_grad():
+        ev = model(x)
+    for i in range(4):
+        e = relerr(ev[i], torch.from_numpy(z[f'{name}_eval'][i]))
+        assert e < 1e-3, (name, 'eval head', i, e)
+    if name == 'gtc_tt':
+        model.train()
+        with pytest.raises(TcctError):
+            model(x)
+        return
+    model.train()
+    with torch.no_grad():
+        tr = model(x)
+    e0 = relerr(tr[0], torch.from_numpy(z[f'{name}_train'][0]))
+    assert e0 < 1e-3, (name, 'train head 0', e0)
+    # and the variant trains: loss decreases over a few steps of the fused optimizer
+    k = make_kite(model, tmp_path, False, False)
+    img, lab = O.synth_batch(2, 32, 64, seed=3)
+    l0 = k.train_step(img.cuda(), lab.cuda()).item()
+    for _ in range(6):
+        l1 = k.train_step(img.cuda(), lab.cuda()).item()
+    assert l1 < l0, (l0, l1)
