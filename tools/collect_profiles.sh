@@ -4,7 +4,8 @@
 TAG=${1:-r01_x}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_step -o step -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_step.log 2>&1
+# single-stream trace: with the two encoder streams kernels overlap and their individual durations no longer add up to the step
+TCCT_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_step -o step -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_step.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_roof -o roof -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $OUT/${TAG}_roof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -o fetch -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $OUT/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -o write -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $OUT/${TAG}_write.log 2>&1

@@ -40,7 +40,8 @@ L.append(f'# {tag}: MI355X, bf16, bs=8 1x800x1100\n')
 L.append(f'Un-profiled bench lines: `profiles/{tag}_bench.json` ({b["value"]} B-scans/s, {b["ms_per_step"]} ms/step, `--los=di`); '
          f'`--los=di+reg+fpl`: {bf["value"]} B-scans/s, {bf["ms_per_step"]} ms/step; fp32 parity mode: {b32["value"]} B-scans/s; '
          f'inference (`tools/infer_bench.py`): `profiles/{tag}_infer.txt`.\n')
-L.append(f'## whole step — `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline`')
+L.append(f'## whole step — `TCCT_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline`')
+L.append('(traced on ONE stream so that kernel durations add up; the bench lines above run the CNN / ViT encoders and the weight gradients on side streams, which hides ~2.5 ms of this sum)')
 L.append(f'{nsteps} steps traced; GPU busy {tot / 1e6:.1f} ms = {tot / 1e6 / nsteps:.2f} ms/step.\n')
 L.append('| family | ms/step | % |\n|---|---|---|')
 for n, t in sorted(acc.items(), key=lambda x: -x[1]):
