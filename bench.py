@@ -219,6 +219,7 @@ def main():
     lossv = float(loss.item())
     tdist.barrier()
     if rank != 0:
+        tdist.barrier()         # leave together with rank 0 (which still times the roofline kernels): no rank tears the group down early
         return
     value = a.bs * world * a.steps / dt
     out = {
@@ -237,6 +238,7 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(a)
     print(json.dumps(out), flush=True)
+    tdist.barrier()
 
 
 def _shutdown():
