@@ -469,14 +469,25 @@ __global__ void __launch_bounds__(NBR) k_bn2_add_act_bwd_reduce(const T* __restr
         s0[k] = s1[k] = s2[k] = 0.f;
     }
     if (active) {
-        for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += (int64_t)gridDim.x * R) {
-            const int64_t o = m * C + cv * 4;
-            f4 va = ld4(xa + o), vb = ld4(xb + o), g = ld4(dy + o);
+        // two rows per iteration: three input streams and one resident 1024-thread block per CU need the extra loads in flight
+        const int64_t step = (int64_t)gridDim.x * R;
+        for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += 2 * step) {
+            f4 va[2], vb[2], g[2];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float ua = act_fwd(pre_act, va.v[k]), ub = act_fwd(pre_act, vb.v[k]);
-                float dz = g.v[k] * act_grad(act, aA[k] * ua + bA[k] + aB[k] * ub + bB[k]);
-                s0[k] += dz; s1[k] += dz * (ua - muA[k]) * rsA[k]; s2[k] += dz * (ub - muB[k]) * rsB[k];
+            for (int j = 0; j < 2; ++j) {
+                const int64_t mj = m + j * step;
+                if (mj < M) { const int64_t o = mj * C + cv * 4; va[j] = ld4(xa + o); vb[j] = ld4(xb + o); g[j] = ld4(dy + o); }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (m + j * step < M) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float ua = act_fwd(pre_act, va[j].v[k]), ub = act_fwd(pre_act, vb[j].v[k]);
+                        float dz = g[j].v[k] * act_grad(act, aA[k] * ua + bA[k] + aB[k] * ub + bB[k]);
+                        s0[k] += dz; s1[k] += dz * (ua - muA[k]) * rsA[k]; s2[k] += dz * (ub - muB[k]) * rsB[k];
+                    }
+                }
             }
         }
     }
