@@ -244,7 +244,12 @@ static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y
     TCCT_CHECK(lds <= 160 * 1024, "pw_fwd: weights need %zu B of LDS", lds);
     const int64_t mtiles = (M + 31) / 32;
     int64_t gx = (mtiles + 3) / 4;
-    const int cap = lds <= 80 * 1024 ? 512 : 256;
+    // persistent blocks: 4 per CU when LDS allows (measured sweep 2/3/4/6/8: the kernel is latency-bound with only 2 x 4 waves per
+    // CU in flight -- 32->32 at level 0 went 0.204 -> 0.160 ms, 64->64 0.127 -> 0.119 ms; more than 4 gains nothing)
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    const int cap = 256 * per_cu;
     if (gx > cap) gx = cap;
     hipStream_t st = (hipStream_t)stream;
 #define PW_L(NTV, TO)                                                                                                        \
