@@ -19,6 +19,8 @@ class KiteSeg(KiteBack):
     cnt_val = 0
     udh_out = None
     udh_lab = None
+    use_graph = True        # hipGraph replay of the eval forward for batches of <= 2 images (TCCT_GRAPH=0 disables)
+    _graphed = None
 
     def __init__(self, args, **_args):
         self.args = args
@@ -28,12 +30,22 @@ class KiteSeg(KiteBack):
         self.NB_CLASS = self.dataset.out_channels
         self.criterion.NB_CLASS = self.NB_CLASS
         self.best_dice = -1.0
+        import os
+        self.use_graph = os.environ.get('TCCT_GRAPH', '1') != '0'
 
     def predict(self, img, softmax=True, *args):
         """reference loop_seg.py:21-33: one_hot(argmax(softmax(out[0]))).  Returns a lazy MaskOneHot (class-index map;
         `.dense()` gives the reference's float [B,C,H,W]) when softmax=True, else the raw logits."""
         with torch.no_grad():
-            pred = self.model(self.cuda(img))
+            img = self.cuda(img)
+            if softmax and self.use_graph and not self.model.training and img.is_cuda and img.shape[0] <= 2:
+                # launch-bound regime (validation runs bs=1): replay the captured kernel sequence (tcct_amd/graph.py)
+                if self._graphed is None:
+                    from ..graph import GraphedPredict
+                    self._graphed = GraphedPredict(self.model)
+                _, idx = self._graphed(img.float() if img.dtype != torch.float32 else img)
+                return MaskOneHot(idx.clone(), self.NB_CLASS)
+            pred = self.model(img)
             if isinstance(pred, (list, tuple)):
                 pred = pred[0]
             pred = pred.detach()

@@ -356,3 +356,37 @@ def test_sibling_variants_match_reference(name, tmp_path):
     for _ in range(6):
         l1 = k.train_step(img.cuda(), lab.cuda()).item()
     assert l1 < l0, (l0, l1)
+
+
+def test_graphed_predict_equals_eager_and_tracks_weight_updates(tmp_path):
+    """hipGraph replay of the eval forward (tcct_amd/graph.py, used by KiteSeg.predict for bs <= 2): identical logits and masks to
+    the eager path, and in-place weight updates (an optimizer step) are seen by the already captured graph"""
+    import tcct_oracle as O
+    from tcct_amd.graph import GraphedPredict
+    model, sd = build(torch.bfloat16)
+    k = make_kite(model, tmp_path, False, False)
+    img, lab = O.synth_batch(1, 64, 96, seed=4)
+    img2, _ = O.synth_batch(1, 64, 96, seed=5)
+    k.model.eval()
+    gp = GraphedPredict(k.model)
+    with torch.no_grad():
+        for x in (img.cuda(), img2.cuda(), img.cuda()):
+            lg, idx = gp(x)
+            ref = k.model(x)[0]
+            assert torch.equal(lg.float(), ref.float()) and torch.equal(idx.long(), ref.float().softmax(1).argmax(1))
+    m_eager = k.predict(img.cuda()).index
+    with torch.no_grad():
+        assert torch.equal(m_eager, gp(img.cuda())[1])
+    # one training step changes the weights in place; the captured graph must follow
+    k.model.train()
+    b2, l2 = O.synth_batch(2, 64, 96, seed=6)
+    for step in range(2):       # step 1 re-binds the parameters into the optimizer's flat buffer (new capture), step 2 updates in place
+        k.model.train()
+        k.train_step(b2.cuda(), l2.cuda())
+        k.model.eval()
+        ncap = len(gp._cache)
+        with torch.no_grad():
+            lg, _ = gp(img.cuda())
+            ref = k.model(img.cuda())[0]
+        assert torch.equal(lg.float(), ref.float()), step
+    assert len(gp._cache) == ncap           # the in-place update of step 2 reused the graph captured after step 1

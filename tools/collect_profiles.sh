@@ -14,6 +14,7 @@ python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_b
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-roofline --los=di+reg+fpl > $OUT/${TAG}_bench_fullloss.json 2>> $OUT/${TAG}_bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --dtype fp32 > $OUT/${TAG}_bench_fp32.json 2>> $OUT/${TAG}_bench.err
 python tools/infer_bench.py > $OUT/${TAG}_infer.txt 2>> $OUT/${TAG}_bench.err
+python tools/infer_bench.py --bs 1 >> $OUT/${TAG}_infer.txt 2>> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
 # keep only the small summaries
 find $OUT/${TAG}_step $OUT/${TAG}_roof $OUT/${TAG}_fetch $OUT/${TAG}_write -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null

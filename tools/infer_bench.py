@@ -31,6 +31,19 @@ for fuse in ([False] if a.unfused else [True, False]):
     res[fuse] = (m.index.clone(), dt)
     print(f'predict (eval forward + argmax mask), bs={a.bs} {a.dtype}, epilogue fusion {"on" if fuse else "off"}: {1e3 * dt:.2f} ms/batch = {a.bs / dt:.1f} B-scans/s; '
           f'boundaries {tuple(b.shape)}')
+if a.bs <= 2:            # launch-bound regime: hipGraph replay (default) vs eager launches
+    ops.INFER_FUSE = True
+    for graph in (True, False):
+        k.use_graph = graph
+        for _ in range(3):
+            m = k.predict(img)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            m = k.predict(img)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        print(f'predict bs={a.bs}: hipGraph replay {"on" if graph else "off"}: {1e3 * dt:.2f} ms/batch = {a.bs / dt:.1f} B-scans/s')
 if len(res) == 2:
     agree = (res[True][0] == res[False][0]).float().mean().item()
     print(f'mask agreement fused vs op-by-op: {100 * agree:.4f} %')
