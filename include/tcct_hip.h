@@ -268,6 +268,12 @@ int tcct_clip_adamw(float* p, const float* g, float* m, float* v, int64_t n, con
                     float grad_mul, float lr, double beta1, double beta2, float eps, float weight_decay, int step,
                     float* total_norm_out, tcct_stream_t stream);
 
+/* the same step with its two per-step scalars in device memory -- state[0] = learning rate (host-written), state[1] = steps taken so far
+ * (float, incremented here) -- so that the launch arguments are constant and the whole training step can be replayed from a hipGraph */
+int tcct_clip_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm,
+                        float grad_mul, float* state, double beta1, double beta2, float eps, float weight_decay,
+                        float* total_norm_out, tcct_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -196,6 +196,38 @@ __global__ void k_clip_adamw(float* __restrict__ p, const float* __restrict__ g,
         p[i] = pi - step * mi / (sqrtf(vi) * isq2 + eps);
     }
 }
+// same update with the two per-step scalars in device memory, so that the launch has constant arguments and can be replayed from a
+// hipGraph: state[0] = learning rate (written by the host between replays), state[1] = number of steps taken so far (as a float,
+// exact up to 2^24; incremented by this kernel).  The increment is done by a second one-thread kernel so that every block of the
+// update reads the same value.
+__global__ void k_clip_adamw_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                 int64_t n, const double* __restrict__ sumsq, float max_norm, float gmul, const float* __restrict__ state,
+                                 float b1, float b2, float eps, float wd, float* __restrict__ total_norm_out) {
+    const float lr = state[0], t = state[1] + 1.f;
+    const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+    const float total = sqrtf((float)(*sumsq)) * gmul;
+    const float coef = fminf(max_norm / (total + 1e-6f), 1.f) * gmul;
+    if (total_norm_out && blockIdx.x == 0 && threadIdx.x == 0) *total_norm_out = total;
+    const float step = lr / bc1, isq2 = 1.f / sqrtf(bc2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * coef;
+        float pi = p[i] * (1.f - lr * wd);
+        float mi = b1 * m[i] + (1.f - b1) * gi;
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = pi - step * mi / (sqrtf(vi) * isq2 + eps);
+    }
+}
+__global__ void k_step_inc(float* state) { state[1] += 1.f; }
+extern "C" int tcct_clip_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm,
+                                   float grad_mul, float* state, double beta1, double beta2, float eps, float weight_decay,
+                                   float* total_norm_out, tcct_stream_t stream) {
+    TCCT_CHECK(state != nullptr, "clip_adamw_dev: state is NULL");
+    hipLaunchKernelGGL(k_clip_adamw_dev, dim3(tcct_grid(n, FB, 2048)), dim3(FB), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm,
+                       grad_mul, state, (float)beta1, (float)beta2, eps, weight_decay, total_norm_out);
+    hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+    TCCT_LAUNCH_OK();
+}
 extern "C" int tcct_clip_adamw(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm,
                                float grad_mul, float lr, double beta1, double beta2, float eps, float weight_decay, int step,
                                float* total_norm_out, tcct_stream_t stream) {

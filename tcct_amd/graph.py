@@ -58,3 +58,60 @@ class GraphedPredict:
         static_in.copy_(img)
         g.replay()
         return outs
+
+
+class GraphedTrainStep:
+    """hipGraph replay of the WHOLE training step (forward, losses, backward, clip + AdamW) for launch-bound batch shapes -- the
+    reference trains on 256x256 crops (data/octgen.py:8-19), where 8 x 256 x 256 pixels keep the GPU busy for a fraction of the
+    ~17 ms the host needs to enqueue the ~800 kernels of a step.
+
+    Protocol: the first `warmup` calls run eagerly ON THE CAPTURE STREAM (they are real optimisation steps), the next call captures
+    the step (capture does not execute it) and replays it, later calls copy the batch into the static input buffers and replay.
+    Random draws (DropPath masks, the boundary loss's noise) come from torch's graph-safe generator and advance on every replay; the
+    optimizer's step count and learning rate live in device memory (FlatAdamW.enable_device_state).  A step that ran on another
+    stream earlier would leave autograd AccumulateGrad nodes bound to that stream (kept alive by `KiteSeg.udh_out`), which breaks
+    capture -- the references are dropped before capturing."""
+
+    def __init__(self, kite, warmup=3):
+        self.k, self.warmup = kite, warmup
+        self.calls = 0
+        self.graph = None
+        self.stream = torch.cuda.Stream()
+        self.shape = None
+
+    def __call__(self, img, lab):
+        k = self.k
+        if self.k.optimG.allreduce is not None:
+            raise TcctError('GraphedTrainStep: single-process only (the RCCL all-reduce is not captured)')
+        key = (tuple(img.shape), tuple(lab.shape), img.dtype, lab.dtype)
+        if self.shape is not None and key != self.shape:
+            raise TcctError(f'GraphedTrainStep was captured for {self.shape}, got {key}: batches must keep one shape')
+        self.shape = key
+        cur = torch.cuda.current_stream()
+        if self.graph is None:
+            if self.calls < self.warmup:
+                self.calls += 1
+                k.udh_out = None
+                self.stream.wait_stream(cur)
+                with torch.cuda.stream(self.stream):
+                    loss = k.train_step(img, lab)
+                cur.wait_stream(self.stream)
+                loss.record_stream(cur)
+                return loss
+            k.optimG.enable_device_state()
+            k.udh_out = None
+            self.s_img, self.s_lab = img.clone(), lab.clone()
+            self.stream.wait_stream(cur)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                self.s_loss = k.train_step(self.s_img, self.s_lab)
+            k.udh_out = None
+            k.optimG._step -= 1         # the Python side of step() ran once while capturing; the replay below is the real step
+            self.graph = g
+        else:
+            self.s_img.copy_(img)
+            self.s_lab.copy_(lab)
+        k.optimG.sync_lr()
+        self.graph.replay()
+        k.optimG._step += 1
+        return self.s_loss

@@ -21,6 +21,7 @@ class KiteSeg(KiteBack):
     udh_lab = None
     use_graph = True        # hipGraph replay of the eval forward for batches of <= 2 images (TCCT_GRAPH=0 disables)
     _graphed = None
+    _graphed_step = None    # --graph=true: tcct_amd.graph.GraphedTrainStep
 
     def __init__(self, args, **_args):
         self.args = args
@@ -118,7 +119,16 @@ class KiteSeg(KiteBack):
         tot = torch.zeros((), device=self.device)
         for i, imgs in enumerate(self.dataset.trainSet(bs=self.args.bs)):
             img, lab, _, _ = self.dataset.parse(imgs)
-            tot += self.train_step(self.cuda(img), self.cuda(lab))
+            img, lab = self.cuda(img), self.cuda(lab)
+            if getattr(self.args, 'graph', False) and self.optimG.allreduce is None:
+                if self._graphed_step is None:
+                    from ..graph import GraphedTrainStep
+                    self._graphed_step = GraphedTrainStep(self)
+            gs = self._graphed_step
+            if gs is not None and gs.shape in (None, (tuple(img.shape), tuple(lab.shape), img.dtype, lab.dtype)):
+                tot += gs(img, lab)
+            else:                           # eager launches (default; also a ragged last batch under --graph=true)
+                tot += self.train_step(img, lab)
             if self.args.bug and i > 12:
                 break
         losItem = tot.item()        # ONE device->host sync per epoch (the reference syncs 3-4x per step)

@@ -45,6 +45,9 @@ def build_parser():
     p.add_argument('--pl', type=str2bool, default=False, help='Parallel: one process per GPU (torchrun)')
     p.add_argument('--bug', type=str2bool, default=False, help='Debug Mode!')
     p.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'fp32'], help='compute dtype of activations')
+    p.add_argument('--graph', type=str2bool, default=False,
+                   help='replay the training step from a hipGraph (launch-bound crop sizes such as the 256x256 of the reference recipe; '
+                        'single process, fixed batch shape)')
     return p
 
 

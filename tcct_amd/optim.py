@@ -20,6 +20,24 @@ class FlatAdamW(torch.optim.Optimizer):
         self.allreduce = None        # callable(flat_g) -> None, set by tcct_amd.dist.attach
         self.last_total_norm = None
         self._slots_live = False
+        self.device_state = None     # [lr, steps taken] on the device once enable_device_state() was called (hipGraph-replayable step)
+
+    def enable_device_state(self):
+        """Keep the learning rate and the step count in device memory (tcct_clip_adamw_dev): the step then launches with constant
+        arguments and can be captured into a hipGraph; `sync_lr()` pushes the scheduler's current lr before a replay."""
+        if self._flat is None:
+            raise TcctError('enable_device_state(): take one eager step first (the flat buffers are built at the first step)')
+        if self.device_state is None:
+            self.device_state = torch.tensor([float(self.param_groups[0]['lr']), float(self._step)], device=self._flat['p'].device,
+                                             dtype=torch.float32)
+            self._lr_pushed = float(self.param_groups[0]['lr'])
+        return self
+
+    def sync_lr(self):
+        lr = float(self.param_groups[0]['lr'])
+        if self.device_state is not None and lr != self._lr_pushed:
+            self.device_state[0:1].fill_(lr)
+            self._lr_pushed = lr
 
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none=True)
@@ -87,7 +105,11 @@ class FlatAdamW(torch.optim.Optimizer):
         self._step += 1
         g0 = self.param_groups[0]
         lib.grad_sumsq(f['g'], f['n'], f['sumsq'])
-        lib.clip_adamw(f['p'], f['g'], f['m'], f['v'], f['n'], f['sumsq'], self.max_norm, 1.0 / self.world, float(g0['lr']),
-                       float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']), float(g0['weight_decay']),
-                       self._step, f['norm'])
+        if self.device_state is not None:
+            lib.clip_adamw_dev(f['p'], f['g'], f['m'], f['v'], f['n'], f['sumsq'], self.max_norm, 1.0 / self.world, self.device_state,
+                               float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']), float(g0['weight_decay']), f['norm'])
+        else:
+            lib.clip_adamw(f['p'], f['g'], f['m'], f['v'], f['n'], f['sumsq'], self.max_norm, 1.0 / self.world, float(g0['lr']),
+                           float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']), float(g0['weight_decay']),
+                           self._step, f['norm'])
         self.last_total_norm = f['norm']

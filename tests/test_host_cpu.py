@@ -67,7 +67,7 @@ def test_cli_flags_match_reference_surface():
     for f in ('db lr wd inc gpu los net pth bs epochs root resume reg coff_reg epl coff_epl udh coff_udh type_udh ds coff_ds '
               'pl bug').split():
         assert hasattr(a, f), f
-    assert (a.coff_reg, a.coff_udh, a.coff_ds, a.type_udh, a.net) == (0.1, 1, 1, 'cos', 'stc_tt')
+    assert (a.coff_reg, a.coff_udh, a.coff_ds, a.type_udh, a.net) == (0.1, 1, 1, 'cos', 'stc_tt') and a.graph is False
     b = parse_args(['--los=di+reg+fpl', '--bs=8', '--pl=true'])
     assert b.los == 'di' and b.reg and b.udh and b.pl and b.bs == 8
     assert str2bool('Yes') and not str2bool('0')
