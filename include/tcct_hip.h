@@ -86,6 +86,11 @@ int tcct_bn_eval_ab(int C, const float* gamma, const float* beta, float eps, con
                     const float* running_var, float* mean_rstd, float* ab, tcct_stream_t stream);
 int tcct_bn_apply(const void* x, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act, int dtype,
                   tcct_stream_t stream);
+/* train-mode apply straight from the batch sums: tcct_bn_finalize + tcct_bn_apply[_add] in one launch (res nullable) */
+int tcct_bn_apply_train(const void* x, const void* res, void* y, int64_t M, int C, const double* sums, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float* mean_rstd, float* ab, int pre_act, int post_act, int dtype,
+                        tcct_stream_t stream);
 /* y = post(a*pre(x)+b) + res (res, y like x): the normalisation pass with the residual / branch sum that follows it folded in
  * (InvRes `x + conv2(f)`, nets/tcct.py:563-572; `tran_vit(x) + tran_cnn(c)`, :1012-1015) */
 int tcct_bn_apply_add(const void* x, const void* res, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act, int dtype,
@@ -100,6 +105,12 @@ int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_t M, int C,
  * branches, then F.gelu of the sum), train mode; abA, abB and mean_rstdA, mean_rstdB come from tcct_bn_finalize; sums fp64 [4C] */
 int tcct_bn2_add_act_fwd(const void* xa, const void* xb, void* y, int64_t M, int C, const float* abA, const float* abB, int pre_act,
                          int act, int dtype, tcct_stream_t stream);
+/* train-mode junction straight from the two sets of batch sums: 2 x tcct_bn_finalize + tcct_bn2_add_act_fwd in one launch */
+int tcct_bn2_add_act_train(const void* xa, const void* xb, void* y, int64_t M, int C, const double* sumsA, const float* gammaA,
+                           const float* betaA, float* running_meanA, float* running_varA, int64_t* nbtA, float* mean_rstdA,
+                           float* abA, const double* sumsB, const float* gammaB, const float* betaB, float* running_meanB,
+                           float* running_varB, int64_t* nbtB, float* mean_rstdB, float* abB, float eps, float momentum,
+                           int pre_act, int act, int dtype, tcct_stream_t stream);
 int tcct_bn2_add_act_bwd_reduce(const void* xa, const void* xb, const void* dy, int64_t M, int C, const float* mean_rstdA,
                                 const float* abA, const float* mean_rstdB, const float* abB, int pre_act, int act, double* sums,
                                 int dtype, tcct_stream_t stream);

@@ -111,9 +111,25 @@ extern "C" int tcct_bn_eval_ab(int C, const float* gamma, const float* beta, flo
 }
 
 // ------------------------------------------------------------------ BN apply: y = post(a*pre(x)+b)
+// train-mode coefficients of channel c from the batch sums (what k_bn_finalize computes), in double like it
+__device__ __forceinline__ void bn_coeff(const double* __restrict__ sums, int64_t M, int C, int c, float gamma, float beta, float eps,
+                                         float& mean_f, float& rstd, float& a, float& b, double& var_out) {
+    const double mean = sums[c] / (double)M;
+    double var = sums[C + c] / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    mean_f = (float)mean;
+    a = gamma * rstd;
+    b = beta - mean_f * a;
+    var_out = var;
+}
+struct BnTrain {        // sums != NULL: train-mode apply with the statistics finalisation folded in (no separate k_bn_finalize launch)
+    const double* sums; const float* gamma; const float* beta; float eps, momentum;
+    float* running_mean; float* running_var; int64_t* nbt; float* mean_rstd; float* ab_out;
+};
 template <typename T, int VEC>
 __global__ void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t M, int C, const float* __restrict__ ab,
-                           int pre_act, int post_act, const T* __restrict__ res) {
+                           int pre_act, int post_act, const T* __restrict__ res, BnTrain tr) {
     // res != NULL: y = post(a*pre(x)+b) + res  (InvRes `x + conv2(f)` and the tran_vit + tran_cnn sum without a separate add pass)
     // thread = fixed channel vector (per-channel scale/shift live in registers), rows strided over the grid
     const int CV = C / VEC;
@@ -123,7 +139,22 @@ __global__ void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t M
     const int cv = t % CV, r = t / CV;
     float a_[VEC], b_[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) { a_[k] = ab[cv * VEC + k]; b_[k] = ab[C + cv * VEC + k]; }
+    for (int k = 0; k < VEC; ++k) {
+        const int c = cv * VEC + k;
+        if (tr.sums) {
+            float mean, rstd; double var;
+            bn_coeff(tr.sums, M, C, c, tr.gamma[c], tr.beta[c], tr.eps, mean, rstd, a_[k], b_[k], var);
+            if (blockIdx.x == 0 && r == 0) {            // one thread per channel publishes the coefficients and moves the running stats
+                tr.mean_rstd[c] = mean; tr.mean_rstd[C + c] = rstd; tr.ab_out[c] = a_[k]; tr.ab_out[C + c] = b_[k];
+                if (tr.running_mean) {
+                    const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+                    tr.running_mean[c] = (1.f - tr.momentum) * tr.running_mean[c] + tr.momentum * mean;
+                    tr.running_var[c] = (1.f - tr.momentum) * tr.running_var[c] + tr.momentum * (float)unb;
+                }
+                if (c == 0 && tr.nbt) *tr.nbt += 1;
+            }
+        } else { a_[k] = ab[c]; b_[k] = ab[C + c]; }
+    }
     const int64_t step = (int64_t)gridDim.x * R;
     for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += 2 * step) {
         const int64_t m2 = m + step;
@@ -146,7 +177,18 @@ __global__ void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t M
     }
 }
 static int bn_apply_impl(const void* x, const void* res, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act,
-                         int dtype, tcct_stream_t stream);
+                         int dtype, tcct_stream_t stream, BnTrain tr = BnTrain{nullptr, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr});
+/* train-mode BatchNorm apply straight from the batch sums: tcct_bn_finalize + tcct_bn_apply[_add] in ONE launch.  sums [2C] fp64
+ * (from tcct_bn_stats or a fused convolution epilogue); running_mean/var/num_batches_tracked are updated (nullable), mean_rstd [2C] and
+ * ab [2C] are written for the backward kernels; res nullable (y = post(BN(pre(x))) + res). */
+extern "C" int tcct_bn_apply_train(const void* x, const void* res, void* y, int64_t M, int C, const double* sums, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, float* mean_rstd, float* ab, int pre_act, int post_act, int dtype,
+                                   tcct_stream_t stream) {
+    TCCT_CHECK(sums && gamma && beta && mean_rstd && ab, "bn_apply_train: NULL argument");
+    return bn_apply_impl(x, res, y, M, C, nullptr, pre_act, post_act, dtype, stream,
+                         BnTrain{sums, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean_rstd, ab});
+}
 extern "C" int tcct_bn_apply(const void* x, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act,
                              int dtype, tcct_stream_t stream) {
     return bn_apply_impl(x, nullptr, y, M, C, ab, pre_act, post_act, dtype, stream);
@@ -158,14 +200,14 @@ extern "C" int tcct_bn_apply_add(const void* x, const void* res, void* y, int64_
     return bn_apply_impl(x, res, y, M, C, ab, pre_act, post_act, dtype, stream);
 }
 static int bn_apply_impl(const void* x, const void* res, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act,
-                         int dtype, tcct_stream_t stream) {
+                         int dtype, tcct_stream_t stream, BnTrain tr) {
     TCCT_CHECK(C >= 1 && C <= NB, "bn_apply: C=%d unsupported", C);
     int vec = (C % 4 == 0) ? 4 : 1;
     int R = NB / (C / vec);
     int grid = tcct_grid(M, 2 * R, 256 * 16);
     hipStream_t st = (hipStream_t)stream;
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act, (const T*)res)); }
-    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act, (const T*)res)); }
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act, (const T*)res, tr)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act, (const T*)res, tr)); }
     TCCT_LAUNCH_OK();
 }
 
@@ -423,15 +465,34 @@ extern "C" int tcct_layernorm_bwd(const void* x, const void* dy, void* dx, int64
 // Forward reads the two raw conv outputs once and writes y once (instead of 2 x bn_apply + add_act: 7 tensor passes -> 3);
 // backward recomputes the junction from xa, xb: one reduction pass (4 per-channel sums) + one apply pass writing both input
 // gradients (13 tensor passes -> 8).  Same fixed-channel-thread layout as the plain BN kernels.
+__device__ __forceinline__ void bn_train_coeff(const BnTrain& tr, int64_t M, int C, int c, bool publish, float& a, float& b) {
+    float mean, rstd; double var;
+    bn_coeff(tr.sums, M, C, c, tr.gamma[c], tr.beta[c], tr.eps, mean, rstd, a, b, var);
+    if (publish) {
+        tr.mean_rstd[c] = mean; tr.mean_rstd[C + c] = rstd; tr.ab_out[c] = a; tr.ab_out[C + c] = b;
+        if (tr.running_mean) {
+            const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            tr.running_mean[c] = (1.f - tr.momentum) * tr.running_mean[c] + tr.momentum * mean;
+            tr.running_var[c] = (1.f - tr.momentum) * tr.running_var[c] + tr.momentum * (float)unb;
+        }
+        if (c == 0 && tr.nbt) *tr.nbt += 1;
+    }
+}
 template <typename T>
 __global__ void k_bn2_add_act_fwd(const T* __restrict__ xa, const T* __restrict__ xb, T* __restrict__ y, int64_t M, int C,
-                                  const float* __restrict__ abA, const float* __restrict__ abB, int pre_act, int act) {
+                                  const float* __restrict__ abA, const float* __restrict__ abB, int pre_act, int act, BnTrain trA, BnTrain trB) {
     const int CV = C >> 2, R = NB / CV, t = threadIdx.x;
     if (t >= R * CV) return;
     const int cv = t % CV, r = t / CV;
     float aA[4], bA[4], aB[4], bB[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { aA[k] = abA[cv * 4 + k]; bA[k] = abA[C + cv * 4 + k]; aB[k] = abB[cv * 4 + k]; bB[k] = abB[C + cv * 4 + k]; }
+    for (int k = 0; k < 4; ++k) {
+        const int c = cv * 4 + k;
+        if (trA.sums) {         // train mode: both statistics finalisations folded into this launch
+            bn_train_coeff(trA, M, C, c, blockIdx.x == 0 && r == 0, aA[k], bA[k]);
+            bn_train_coeff(trB, M, C, c, blockIdx.x == 0 && r == 0, aB[k], bB[k]);
+        } else { aA[k] = abA[c]; bA[k] = abA[C + c]; aB[k] = abB[c]; bB[k] = abB[C + c]; }
+    }
     const int64_t step = (int64_t)gridDim.x * R;
     for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += step) {
         const int64_t o = m * C + cv * 4;
@@ -442,13 +503,30 @@ __global__ void k_bn2_add_act_fwd(const T* __restrict__ xa, const T* __restrict_
         st4(y + o, q);
     }
 }
-extern "C" int tcct_bn2_add_act_fwd(const void* xa, const void* xb, void* y, int64_t M, int C, const float* abA, const float* abB,
-                                    int pre_act, int act, int dtype, tcct_stream_t stream) {
+static int bn2_fwd_impl(const void* xa, const void* xb, void* y, int64_t M, int C, const float* abA, const float* abB,
+                        int pre_act, int act, int dtype, tcct_stream_t stream, BnTrain trA, BnTrain trB) {
     TCCT_CHECK(C % 4 == 0 && C >= 4 && C <= NB, "bn2_add_act_fwd: C=%d unsupported", C);
     int R = NB / (C / 4);
     TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_bn2_add_act_fwd<T>, dim3(tcct_grid(M, R, 256 * 16)), dim3(NB), 0, (hipStream_t)stream,
-                                            (const T*)xa, (const T*)xb, (T*)y, M, C, abA, abB, pre_act, act));
+                                            (const T*)xa, (const T*)xb, (T*)y, M, C, abA, abB, pre_act, act, trA, trB));
     TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_bn2_add_act_fwd(const void* xa, const void* xb, void* y, int64_t M, int C, const float* abA, const float* abB,
+                                    int pre_act, int act, int dtype, tcct_stream_t stream) {
+    const BnTrain none{nullptr, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return bn2_fwd_impl(xa, xb, y, M, C, abA, abB, pre_act, act, dtype, stream, none, none);
+}
+/* train-mode junction straight from the two sets of batch sums (2 x tcct_bn_finalize + tcct_bn2_add_act_fwd in one launch);
+ * statsX = {running_mean, running_var} [2][C] pointers are passed separately; mean_rstdX / abX [2C] are written for the backward */
+extern "C" int tcct_bn2_add_act_train(const void* xa, const void* xb, void* y, int64_t M, int C, const double* sumsA, const float* gammaA,
+                                      const float* betaA, float* running_meanA, float* running_varA, int64_t* nbtA, float* mean_rstdA,
+                                      float* abA, const double* sumsB, const float* gammaB, const float* betaB, float* running_meanB,
+                                      float* running_varB, int64_t* nbtB, float* mean_rstdB, float* abB, float eps, float momentum,
+                                      int pre_act, int act, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(sumsA && sumsB && gammaA && gammaB && betaA && betaB && mean_rstdA && mean_rstdB && abA && abB, "bn2_add_act_train: NULL argument");
+    return bn2_fwd_impl(xa, xb, y, M, C, nullptr, nullptr, pre_act, act, dtype, stream,
+                        BnTrain{sumsA, gammaA, betaA, eps, momentum, running_meanA, running_varA, nbtA, mean_rstdA, abA},
+                        BnTrain{sumsB, gammaB, betaB, eps, momentum, running_meanB, running_varB, nbtB, mean_rstdB, abB});
 }
 
 // sums[4C] = { sum g, sum g*xhatA, (unused alias of sum g), sum g*xhatB } laid out as [C]:g, [C]:g*xhatA, [C]:g, [C]:g*xhatB

@@ -455,7 +455,6 @@ class _BatchNorm(torch.autograd.Function):
             else:
                 sums = ZERO.get((2 * C,), torch.float64, x.device)
                 lib.bn_stats(x, M, C, pre, sums, dc)
-            lib.bn_finalize(sums, M, C, gamma, beta, eps, momentum, rm, rv, nbt, mean_rstd, ab)
         else:
             lib.bn_eval_ab(C, gamma, beta, eps, rm, rv, mean_rstd, ab)
         y = torch.empty_like(x)
@@ -463,6 +462,9 @@ class _BatchNorm(torch.autograd.Function):
             _chk(res)
             if res.shape != x.shape or res.dtype != x.dtype:
                 raise TcctError('batchnorm: residual must have the shape and dtype of the input')
+        if training:            # statistics finalisation (+ running stats) folded into the apply launch
+            lib.bn_apply_train(x, res, y, M, C, sums, gamma, beta, eps, momentum, rm, rv, nbt, mean_rstd, ab, pre, post, dc)
+        elif res is not None:
             lib.bn_apply_add(x, res, y, M, C, ab, pre, post, dc)
         else:
             lib.bn_apply(x, y, M, C, ab, pre, post, dc)
@@ -508,7 +510,7 @@ class _Bn2AddAct(torch.autograd.Function):
         C = xa.shape[-1]
         M = xa.numel() // C
         dc = dtype_code(xa.dtype)
-        st = []
+        st, ss = [], []
         for x, g, b, (rm, rv, nbt) in ((xa, gA, bA, bufs[0]), (xb, gB, bB, bufs[1])):
             fused = getattr(x, '_bn_sums', None)
             if fused is not None and fused[1] == pre and fused[0].numel() == 2 * C:
@@ -518,10 +520,12 @@ class _Bn2AddAct(torch.autograd.Function):
                 lib.bn_stats(x, M, C, pre, sums, dc)
             mr = torch.empty(2 * C, device=x.device, dtype=torch.float32)
             ab = torch.empty(2 * C, device=x.device, dtype=torch.float32)
-            lib.bn_finalize(sums, M, C, g, b, eps, momentum, rm, rv, nbt, mr, ab)
             st += [mr, ab]
+            ss.append(sums)
         y = torch.empty_like(xa)
-        lib.bn2_add_act_fwd(xa, xb, y, M, C, st[1], st[3], pre, act_kind, dc)
+        (rmA, rvA, nbtA), (rmB, rvB, nbtB) = bufs       # both statistics finalisations ride on the junction launch
+        lib.bn2_add_act_train(xa, xb, y, M, C, ss[0], gA, bA, rmA, rvA, nbtA, st[0], st[1], ss[1], gB, bB, rmB, rvB, nbtB, st[2], st[3],
+                              eps, momentum, pre, act_kind, dc)
         ctx.save_for_backward(xa, xb, *st)
         ctx.cfg = (pre, act_kind)
         ctx.params = (gA, bA, gB, bB)
