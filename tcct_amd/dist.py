@@ -20,10 +20,12 @@ def init(backend=None):
     if (world > 1 or (force and 'RANK' in os.environ)) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend is None:         # TCCT_DIST_BACKEND=gloo: several ranks on ONE GPU (tests; RCCL refuses to share a device)
+            backend = os.environ.get('TCCT_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
+        elif torch.cuda.is_available():
+            local = local % max(torch.cuda.device_count(), 1)
         dist.init_process_group(backend=backend, world_size=world, rank=rank)
     return world, rank, local
 

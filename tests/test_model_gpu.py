@@ -452,3 +452,46 @@ def test_cli_training_with_graph_flag(tmp_path):
     l1 = k.train(1)
     assert k._graphed_step is not None and k._graphed_step.graph is not None
     assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0, (l0, l1)
+
+
+DDP_GPU_SCRIPT = r"""
+import os, sys, argparse, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'oracle'))
+import tcct_oracle as O
+from tcct_amd import dist as tdist
+from tcct_amd.nets import stc_tt, RegNet
+from tcct_amd.kite import KiteSeg
+rank = int(os.environ['RANK'])
+torch.manual_seed(100 + rank)                     # different initial weights per rank: broadcast_params_ must make them equal
+class DS: out_channels = 5
+args = argparse.Namespace(los='di', lr=1e-3, gpu='0', pl=True, bs=2, coff_ds=1, udh=False, reg=False, epl=False, coff_udh=1, coff_reg=.1,
+                          coff_epl=.1, bug=True)
+model = RegNet(stc_tt(5, compute_dtype=torch.bfloat16), con='cos', out_channels=5)
+k = KiteSeg(model=model, dataset=DS(), root=%r, args=args)
+assert k.optimG.allreduce is not None and k.optimG.world == 2
+k.model.train()
+k.model.base.base_vit.drop_probs = [0.0] * 4
+for s in range(3):
+    img, lab = O.synth_batch(2, 64, 96, seed=50 + 10 * s + rank)      # every rank trains on its own shard
+    loss = k.train_step(img.cuda(), lab.cuda())
+torch.cuda.synchronize()
+torch.save({'p': k.optimG._flat['p'].cpu(), 'g': k.optimG._flat['g'].cpu(), 'loss': loss.item()}, os.path.join(%r, 'rank%%d.pt' %% rank))
+tdist.barrier()
+"""
+
+
+def test_two_ranks_on_one_gpu_stay_in_sync(tmp_path):
+    """the real data-parallel training path with world_size 2 (two processes sharing this GPU, gloo transport because RCCL does not
+    share a device): parameters broadcast from rank 0, one all-reduce of the flat gradient per step, identical weights on both
+    ranks after 3 steps on different shards"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'ddp_gpu.py'
+    script.write_text(DDP_GPU_SCRIPT % (root, root, str(tmp_path), str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', TCCT_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29617', str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    a, b = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
+    assert torch.equal(a['p'], b['p']) and torch.equal(a['g'], b['g'])          # same averaged gradient, same update, bit for bit
+    assert a['loss'] != b['loss'] and np.isfinite(a['loss']) and np.isfinite(b['loss'])   # different shards, per-replica losses
