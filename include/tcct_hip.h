@@ -208,6 +208,10 @@ int tcct_maxpool2_bwd(const void* x, const void* dy, void* dx, int N, int H, int
  * (tcct.py:941,1042-1044).  bwd: dy [N,Ho,Wo,C] -> dx [N,H,W,C], gather form (no atomics) ------------------ */
 int tcct_bilinear_fwd(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int align_corners, int dtype,
                       tcct_stream_t stream);
+/* separable form of tcct_bilinear_bwd for narrow fp32 tensors (the 5-class aux logits): a pass along W into `workspace`
+ * (N*Ho*W*C floats, caller-allocated), then a pass along H; same result up to fp32 summation order */
+int tcct_bilinear_bwd_separable(const float* dy, float* dx, float* workspace, int N, int H, int W, int C, int Ho, int Wo,
+                                int align_corners, tcct_stream_t stream);
 /* y = resize(x) + res (res, y [N,Ho,Wo,C]): upsampling with the decoder's skip-connection add folded in (nets/tcct.py:908-912) */
 int tcct_bilinear_add_fwd(const void* x, const void* res, void* y, int N, int H, int W, int C, int Ho, int Wo, int align_corners,
                           int dtype, tcct_stream_t stream);

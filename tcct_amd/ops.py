@@ -791,7 +791,13 @@ class _Bilinear(torch.autograd.Function):
         N, H, W, C, Ho, Wo, align = ctx.cfg
         dy = _c(dy)
         dx = torch.empty((N, H, W, C), device=dy.device, dtype=dy.dtype)
-        lib.bilinear_bwd(dy, dx, N, H, W, C, Ho, Wo, align, dtype_code(dy.dtype))
+        if dy.dtype == torch.float32 and C % 4 != 0 and Ho >= 4 * H and Wo >= 4 * W and (2 * Wo) // W + 3 <= 40 and Wo * C * 4 <= 65536:
+            # narrow fp32 maps enlarged >= 4x (the coarse aux logits): separable transpose, one coalesced pass over dy (x8: 0.28 -> 0.08 ms;
+            # at x2 the 2-D table gather is still faster)
+            ws = torch.empty(N * Ho * W * C, device=dy.device, dtype=torch.float32)
+            lib.bilinear_bwd_separable(dy, dx, ws, N, H, W, C, Ho, Wo, align)
+        else:
+            lib.bilinear_bwd(dy, dx, N, H, W, C, Ho, Wo, align, dtype_code(dy.dtype))
         return dx, None, None, None, (dy if ctx.has_res else None)
 
 

@@ -78,6 +78,10 @@ def misc_bench():
         m1 = timeit(lambda: lib.bilinear_fwd(x, y, 8, H, W, C, Ho, Wo, al, code))
         m2 = timeit(lambda: lib.bilinear_bwd(dy, dx, 8, H, W, C, Ho, Wo, al, code))
         print(f'bilinear C={C} {H}x{W}->{Ho}x{Wo}: fwd {m1:.3f} ms {gb / m1 * 1e3:.0f} GB/s | bwd {m2:.3f} ms {gb / m2 * 1e3:.0f} GB/s')
+        if tdt == torch.float32:
+            ws = torch.empty(8 * Ho * W * C, device='cuda')
+            m3 = timeit(lambda: lib.bilinear_bwd_separable(dy, dx, ws, 8, H, W, C, Ho, Wo, al))
+            print(f'   separable bwd {m3:.3f} ms')
     x = torch.randn(8, 220800, 64, device='cuda').to(dt); y = torch.empty_like(x)
     gb = 2 * x.numel() * 2 / 1e9
     m1 = timeit(lambda: lib.metapool_fwd(x, y, 8, 220800, 64, 1)); m2 = timeit(lambda: lib.metapool_bwd(x, y, 8, 220800, 64, 1))
