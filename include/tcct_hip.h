@@ -178,6 +178,13 @@ int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float* dbias, in
 int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                 int out_dtype, tcct_stream_t stream);
 int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
+/* Concatenation-free pointwise convolution over [x1 | x2] (MHCA_stage.aggregate, nets/tcct.py:600-616): forward (+ optional fused
+ * BN statistics), input gradient written to two tensors, weight gradient -- the channel concatenation is never materialised */
+int tcct_pw_fwd_cat2(const void* x1, const void* x2, int K1, const float* w, const float* bias, void* y, int64_t M, int K, int N,
+                     double* stats, int pre_act, tcct_stream_t stream);
+int tcct_pw_dgrad_split2(const void* dy, const float* w, void* dx1, void* dx2, int K1, int64_t M, int Nout, int K, tcct_stream_t stream);
+int tcct_pw_wgrad_cat2(const void* x1, const void* x2, int K1, const void* dy, float* dw, float* dbias, int64_t M, int K, int N,
+                       tcct_stream_t stream);
 /* pw_fwd + fused train-mode BatchNorm statistics of the consumer (bf16 output, N in {32,64,96,128}); stats fp64 [2N], zero on entry */
 int tcct_pw_fwd_bnstats(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats, int pre_act,
                         tcct_stream_t stream);

@@ -27,13 +27,17 @@ __device__ __forceinline__ void st_out4(float* p, float a, float b, float c, flo
 __device__ __forceinline__ float rnd_out(float v, const bf16*) { return __bfloat162float(__float2bfloat16(v)); }
 __device__ __forceinline__ float rnd_out(float v, const float*) { return v; }
 
+// Concatenation-free operands (MHCA_stage.aggregate, reference nets/tcct.py:600-616: `cat([InvRes(x), Encoder(x)], 1)` -> 1x1 conv): the
+// input rows may live in TWO tensors (channels [0,K1) in x, [K1,K) in x2) and, for the input-gradient GEMM, the output rows may go
+// to two tensors (channels [0,N1) to y, [N1,N) to y2).  K1 / N1 are multiples of 32; x2 == NULL / y2 == NULL: ordinary operands.
+struct PwSplit { const bf16* x2; int K1; void* y2; int N1; };
 // STATS: also accumulate per-channel sum / sum of squares of pre_act(y) (y as stored) into stats[0..N) / stats[N..2N): the
 // train-mode BatchNorm statistics of the consumer (Conv2d_BN, DWConv2d_BN.pwconv, tran_*; reference nets/tcct.py:80,125,966-974)
 template <int NT, typename Tout, bool STATS, bool AFF>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, Tout* __restrict__ y,
          int64_t M, int K, int N, int transposed, double* __restrict__ stats, int stat_pre, const float* __restrict__ aff,
-         int aff_pre, int aff_post) {
+         int aff_pre, int aff_post, PwSplit sp) {
     // aff != NULL or aff_pre/aff_post != 0 (inference only): y = post(a[c] * pre(x W + bias) + b[c]), aff = {a[N], b[N]}
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int SW = 2 * K + 16;                 // LDS row stride (bytes)
@@ -85,7 +89,10 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
     for (int64_t mt = (int64_t)blockIdx.x * 4 + wave; mt < mtiles; mt += (int64_t)gridDim.x * 4) {
         const int64_t m = mt * 32 + r;
         const bool ok = m < M;
-        const bf16* xr = x + (ok ? m : 0) * K + 16 * hh;
+        const int64_t mrow = ok ? m : 0;
+        const int KA = sp.x2 ? sp.K1 : K;              // row length of the first source
+        const bf16* xr = x + mrow * KA + 16 * hh;
+        const bf16* xr2 = sp.x2 ? sp.x2 + mrow * (K - KA) + 16 * hh - KA : xr;    // indexed with the global channel offset 32t
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -95,8 +102,9 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
             // channels 32t + 16hh + [0,16): two k-steps
             uint4 u0 = make_uint4(0, 0, 0, 0), u1 = u0;
             if (ok) {
-                u0 = *reinterpret_cast<const uint4*>(xr + 32 * t);
-                u1 = *reinterpret_cast<const uint4*>(xr + 32 * t + 8);
+                const bf16* src = 32 * t < KA ? xr : xr2;
+                u0 = *reinterpret_cast<const uint4*>(src + 32 * t);
+                u1 = *reinterpret_cast<const uint4*>(src + 32 * t + 8);
             }
             const bf16x8 b0 = __builtin_bit_cast(bf16x8, u0), b1 = __builtin_bit_cast(bf16x8, u1);
 #pragma unroll
@@ -138,7 +146,10 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                     const uint4 o = *reinterpret_cast<const uint4*>(sc + p * 80 + cch * 16);
                     const int64_t mm = mt * 32 + p;
                     if (mm < M) {
-                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(y) + mm * N + n_base + nt * 32 + cch * 8) = o;
+                        const int n0 = n_base + nt * 32;
+                        bf16* dst = (sp.y2 && n0 >= sp.N1) ? reinterpret_cast<bf16*>(sp.y2) + mm * (N - sp.N1) + (n0 - sp.N1)
+                                                           : reinterpret_cast<bf16*>(y) + mm * (sp.y2 ? sp.N1 : N) + n0;
+                        *reinterpret_cast<uint4*>(dst + cch * 8) = o;
                         if (STATS) {
                             const uint32_t wv[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
@@ -207,7 +218,7 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
  * y [M,N] bf16 or fp32. */
 static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                        int out_dtype, double* stats, int stat_pre, tcct_stream_t stream, const float* aff = nullptr, int aff_pre = 0,
-                       int aff_post = 0);
+                       int aff_post = 0, PwSplit sp = PwSplit{nullptr, 0, nullptr, 0});
 extern "C" int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                            int out_dtype, tcct_stream_t stream) {
     return pw_fwd_impl(x, w, bias, y, M, K, N, transposed, out_dtype, nullptr, 0, stream);
@@ -218,6 +229,19 @@ extern "C" int tcct_pw_fwd_bnstats(const void* x, const float* w, const float* b
     TCCT_CHECK(N % 32 == 0 && N <= 128, "pw_fwd_bnstats: N=%d unsupported (32, 64, 96, 128)", N);
     return pw_fwd_impl(x, w, bias, y, M, K, N, 0, TCCT_BF16, stats, pre_act, stream);
 }
+/* y = [x1 | x2] W^T + bias without materialising the concatenation (x1 [M,K1], x2 [M,K-K1]); stats nullable (fused BN statistics) */
+extern "C" int tcct_pw_fwd_cat2(const void* x1, const void* x2, int K1, const float* w, const float* bias, void* y, int64_t M, int K, int N,
+                                double* stats, int pre_act, tcct_stream_t stream) {
+    TCCT_CHECK(x2 != nullptr, "pw_fwd_cat2: x2 is NULL");
+    if (stats) TCCT_CHECK(N % 32 == 0 && N <= 128, "pw_fwd_cat2: fused statistics need N in {32,64,96,128} (got %d)", N);
+    return pw_fwd_impl(x1, w, bias, y, M, K, N, 0, TCCT_BF16, stats, pre_act, stream, nullptr, 0, 0, PwSplit{(const bf16*)x2, K1, nullptr, 0});
+}
+/* input gradient of the same convolution: [dx1 | dx2] = dy W with w [Nout, K] (the weight as stored), dy [M, Nout]; dx1 [M,K1], dx2 [M,K-K1] */
+extern "C" int tcct_pw_dgrad_split2(const void* dy, const float* w, void* dx1, void* dx2, int K1, int64_t M, int Nout, int K,
+                                    tcct_stream_t stream) {
+    TCCT_CHECK(dx2 != nullptr, "pw_dgrad_split2: dx2 is NULL");
+    return pw_fwd_impl(dy, w, nullptr, dx1, M, Nout, K, 1, TCCT_BF16, nullptr, 0, stream, nullptr, 0, 0, PwSplit{nullptr, 0, dx2, K1});
+}
 /* inference: y = post_act(a[c] * pre_act(x W^T + bias[c]) + b[c]), ab = {a[N], b[N]} from tcct_bn_eval_ab (NULL: a = 1, b = 0):
  * eval-mode BatchNorm and the adjacent activation(s) folded into the GEMM epilogue (Conv2d_BN, Mlp.fc1 + GELU, tran_*) */
 extern "C" int tcct_pw_fwd_affine(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, const float* ab,
@@ -225,7 +249,9 @@ extern "C" int tcct_pw_fwd_affine(const void* x, const float* w, const float* bi
     return pw_fwd_impl(x, w, bias, y, M, K, N, 0, out_dtype, nullptr, 0, stream, ab, pre_act, post_act);
 }
 static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
-                       int out_dtype, double* stats, int stat_pre, tcct_stream_t stream, const float* aff, int aff_pre, int aff_post) {
+                       int out_dtype, double* stats, int stat_pre, tcct_stream_t stream, const float* aff, int aff_pre, int aff_post, PwSplit sp) {
+    if (sp.x2) TCCT_CHECK(sp.K1 % 32 == 0 && sp.K1 > 0 && sp.K1 < K, "pw_fwd_cat2: K1=%d must be a multiple of 32 inside (0, K)", sp.K1);
+    if (sp.y2) TCCT_CHECK(sp.N1 % 32 == 0 && sp.N1 > 0 && sp.N1 < N && N % 32 == 0 && out_dtype == TCCT_BF16, "pw_dgrad_split2: N1=%d must be a multiple of 32 inside (0, N), bf16 output", sp.N1);
     TCCT_CHECK(K % 32 == 0 && K >= 32 && K <= 512, "pw_fwd: K=%d must be a multiple of 32 (<=512)", K);
     TCCT_CHECK(N >= 1 && N <= 1024, "pw_fwd: N=%d", N);
     const int ntiles = (N + 31) / 32;
@@ -256,7 +282,7 @@ static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y
     do {                                                                                                                     \
         static bool attr = false;                                                                                            \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k_pw_fwd<NTV, TO, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-        hipLaunchKernelGGL((k_pw_fwd<NTV, TO, false, false>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (TO*)y, M, K, N, transposed, nullptr, 0, aff, aff_pre, aff_post); \
+        hipLaunchKernelGGL((k_pw_fwd<NTV, TO, false, false>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (TO*)y, M, K, N, transposed, nullptr, 0, aff, aff_pre, aff_post, sp); \
     } while (0)
 #define PW_D(TO)                                                                  \
     switch (NT) {                                                                 \
@@ -266,13 +292,13 @@ static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y
     if (aff || aff_pre || aff_post) {       // inference epilogue: separate instantiations, the training kernels stay as they are
         TCCT_CHECK(out_dtype == TCCT_BF16 && !stats, "pw_fwd_affine: bf16 output only");
 #define PW_A(NTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd<NTV, bf16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
-        hipLaunchKernelGGL((k_pw_fwd<NTV, bf16, false, true>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (bf16*)y, M, K, N, transposed, nullptr, 0, aff, aff_pre, aff_post); }
+        hipLaunchKernelGGL((k_pw_fwd<NTV, bf16, false, true>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (bf16*)y, M, K, N, transposed, nullptr, 0, aff, aff_pre, aff_post, sp); }
         if (NT == 1) PW_A(1) else if (NT == 2) PW_A(2) else if (NT == 3) PW_A(3) else if (NT == 4) PW_A(4) else PW_A(5)
 #undef PW_A
     }
     else if (stats) {
 #define PW_S(NTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd<NTV, bf16, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
-        hipLaunchKernelGGL((k_pw_fwd<NTV, bf16, true, false>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (bf16*)y, M, K, N, transposed, stats, stat_pre, nullptr, 0, 0); }
+        hipLaunchKernelGGL((k_pw_fwd<NTV, bf16, true, false>), dim3((unsigned)gx, gy), dim3(PWB), lds, st, (const bf16*)x, w, bias, (bf16*)y, M, K, N, transposed, stats, stat_pre, nullptr, 0, 0, sp); }
         if (NT == 1) PW_S(1) else if (NT == 2) PW_S(2) else if (NT == 3) PW_S(3) else PW_S(4)
 #undef PW_S
     }
@@ -305,13 +331,16 @@ __device__ __forceinline__ bf16x8 tr_load8g(const unsigned char* base, int strid
 template <int NT, int KTB>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias, int64_t M,
-           int K, int N, int SX, int SD) {
+           int K, int N, int SX, int SD, const bf16* __restrict__ x2, int K1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sX = smem;
     unsigned char* sD = smem + PW_P * SX;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int ci_base = blockIdx.y * KTB * 32;
+    // concatenation-free x: channels [0,K1) from x, [K1,K) from x2 (block-uniform choice: K1 is a multiple of KTB*32)
+    const bf16* xsrc = (x2 && ci_base >= K1) ? x2 + (ci_base - K1) : x + ci_base;
+    const int ldx = x2 ? (ci_base >= K1 ? K - K1 : K1) : K;
     const int xc = KTB * 4, dc = N >> 3;            // 16-byte chunks per staged pixel row
     f32x16 acc[NT][KTB];
 #pragma unroll
@@ -336,7 +365,7 @@ k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __res
         for (int j = 0; j < PW_XS; ++j) {
             px[j] = make_uint4(0, 0, 0, 0);
             if (xsl[j] >= 0 && m0 + (xsl[j] >> 8) < M)
-                px[j] = *reinterpret_cast<const uint4*>(x + (m0 + (xsl[j] >> 8)) * K + ci_base + (xsl[j] & 255) * 8);
+                px[j] = *reinterpret_cast<const uint4*>(xsrc + (m0 + (xsl[j] >> 8)) * ldx + (xsl[j] & 255) * 8);
         }
 #pragma unroll
         for (int j = 0; j < PW_DS; ++j) {
@@ -429,7 +458,17 @@ k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __res
 }
 
 /* x bf16 [M,K], dy bf16 [M,N] -> dw fp32 [N,K] and dbias fp32 [N] (nullable); both overwritten.  K, N multiples of 32, N <= 160 */
+static int pw_wgrad_impl(const void* x, const void* x2, int K1, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
 extern "C" int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream) {
+    return pw_wgrad_impl(x, nullptr, 0, dy, dw, dbias, M, K, N, stream);
+}
+/* weight gradient with x = [x1 | x2] given as two tensors (x1 [M,K1], x2 [M,K-K1]); dw [N,K] as for the concatenated input */
+extern "C" int tcct_pw_wgrad_cat2(const void* x1, const void* x2, int K1, const void* dy, float* dw, float* dbias, int64_t M, int K, int N,
+                                  tcct_stream_t stream) {
+    TCCT_CHECK(x2 != nullptr && K1 % 32 == 0 && K1 > 0 && K1 < K, "pw_wgrad_cat2: K1=%d must be a multiple of 32 inside (0, K)", K1);
+    return pw_wgrad_impl(x1, x2, K1, dy, dw, dbias, M, K, N, stream);
+}
+static int pw_wgrad_impl(const void* x, const void* x2, int K1, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream) {
     TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && N <= 160 && K <= 1024, "pw_wgrad: unsupported K=%d N=%d", K, N);
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)N * K, st) != hipSuccess) { tcct_set_error("pw_wgrad: memset failed"); return -2; }
@@ -437,6 +476,7 @@ extern "C" int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* db
     const int NT = N / 32, ktiles = K / 32;
     const int KTB = (ktiles % 2 == 0 && NT <= 2) ? 2 : 1;       // <= 5 accumulators per wave next to the prefetch registers
     const int gy = ktiles / KTB;
+    TCCT_CHECK(!x2 || K1 % (KTB * 32) == 0, "pw_wgrad_cat2: K1=%d must be a multiple of %d for this shape", K1, KTB * 32);
     // row strides: S mod 256 in {64,192} keeps the 4-pixel x 64-byte footprint of a transposing read on distinct banks
     const int SX = KTB == 1 ? 64 : 192;
     const int SD = 2 * N + ((NT & 1) ? 0 : 64);
@@ -452,7 +492,7 @@ extern "C" int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* db
     if (gx < 64) gx = 64;
     if (gx > tiles) gx = (int)tiles;
     if (gx < 1) gx = 1;
-#define WL(NTV, KV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_wgrad<NTV, KV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } } hipLaunchKernelGGL((k_pw_wgrad<NTV, KV>), dim3(gx, gy), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias, M, K, N, SX, SD)
+#define WL(NTV, KV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_wgrad<NTV, KV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } } hipLaunchKernelGGL((k_pw_wgrad<NTV, KV>), dim3(gx, gy), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias, M, K, N, SX, SD, (const bf16*)x2, K1)
     if (KTB == 2) { switch (NT) { case 1: WL(1, 2); break; default: WL(2, 2); break; } }
     else { switch (NT) { case 1: WL(1, 1); break; case 2: WL(2, 1); break; case 3: WL(3, 1); break; case 4: WL(4, 1); break; default: WL(5, 1); break; } }
 #undef WL

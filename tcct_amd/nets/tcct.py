@@ -272,7 +272,12 @@ class MHCA_stage(nn.Module):
     def forward(self, x, scales):
         r = self.InvRes(x)
         e = self.mhca_blks[0](x, scales)
-        return self.aggregate(ops.concat2(r, e))
+        ag = self.aggregate
+        if ag.bn.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
+            # cat([r, e]) -> 1x1 -> BN -> Hardswish with the concatenation folded into the GEMM operands (no concat / split passes)
+            y = ops.conv1x1_cat2(r, e, ag.conv.weight, stats_pre='none' if ag.bn.training else None)
+            return _bn(ag.bn, y, post='hswish')
+        return ag(ops.concat2(r, e))
 
 
 class Cls_head(nn.Module):

@@ -382,6 +382,57 @@ def bn2_add_act_eval(xa, bnA, xb, bnB, pre_act='lrelu', act_kind='gelu'):
     return y
 
 
+class _PwCat2(torch.autograd.Function):
+    """1x1 convolution over the channel concatenation [a | b] without materialising it (MHCA_stage.aggregate)"""
+
+    @staticmethod
+    def forward(ctx, a, b, w, stats_box):
+        _chk(a, b, w)
+        N_, H, W_, Ca = a.shape
+        Cb = b.shape[-1]
+        Cout = w.shape[0]
+        M = N_ * H * W_
+        y = torch.empty((N_, H, W_, Cout), device=a.device, dtype=a.dtype)
+        sums = None
+        if stats_box is not None and Cout % 32 == 0 and Cout <= 128:
+            sums = ZERO.get((2 * Cout,), torch.float64, a.device) if ZERO.active else torch.zeros(2 * Cout, device=a.device, dtype=torch.float64)
+            stats_box[1] = sums
+        lib.pw_fwd_cat2(a, b, Ca, w, None, y, M, Ca + Cb, Cout, sums, stats_box[0] if sums is not None else 0)
+        ctx.save_for_backward(a, b, w)
+        wsrc = w if hasattr(w, '_grad_slot') or w._base is None else w._base
+        ctx.wsrc = wsrc
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b, w = ctx.saved_tensors
+        dy = _c(dy)
+        N_, H, W_, Ca = a.shape
+        Cb, Cout, M = b.shape[-1], w.shape[0], N_ * H * W_
+        da, db_ = torch.empty_like(a), torch.empty_like(b)
+        lib.pw_dgrad_split2(dy, w, da, db_, Ca, M, Cout, Ca + Cb)
+        with _wgrad_stream(_slot_written(ctx.wsrc), a, b, dy):
+            dw = _grad_out(ctx.wsrc, tuple(w.shape))
+            lib.pw_wgrad_cat2(a, b, Ca, dy, dw, None, M, Ca + Cb, Cout)
+        return da, db_, _ret(dw, ctx.wsrc), None
+
+
+def conv1x1_cat2(a, b, w, stats_pre=None):
+    """conv1x1(cat([a, b], channel)) with weight w [Cout, Ca+Cb, 1, 1] (no bias): forward, both input gradients and the weight gradient
+    read / write the two halves in place -- no concat / split passes.  bf16 with Ca, Cb multiples of 32 and Cout <= 160; any other
+    case takes concat2 + conv2d."""
+    Ca, Cb, Cout = a.shape[-1], b.shape[-1], w.shape[0]
+    ok = (a.dtype == torch.bfloat16 and b.dtype == a.dtype and a.shape[:-1] == b.shape[:-1] and Ca % 32 == 0 and Cb % 32 == 0
+          and Cout % 32 == 0 and Cout <= 160 and tuple(w.shape[1:]) == (Ca + Cb, 1, 1) and a.dim() == 4)
+    if not ok:
+        return conv2d(concat2(a, b), w, None, stats_pre=stats_pre)
+    box = [ACT[stats_pre], None] if stats_pre is not None else None
+    y = _PwCat2.apply(a, b, w, box)
+    if box is not None and box[1] is not None:
+        y._bn_sums = (box[1], box[0])
+    return y
+
+
 def im2col3x3_c3(x4, stride=1):
     """x4 NHWC [N,H,W,4] (3 image channels + zero pad) -> 3x3 patch pixels [N,Ho,Wo,32]; no gradient (the image needs none)"""
     _chk(x4)

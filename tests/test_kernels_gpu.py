@@ -515,3 +515,33 @@ def test_residual_folded_into_batchnorm_and_bilinear(dt):
     y2d.backward(nhwc(gy2, dt))
     torch.testing.assert_close(nchw(x2d.grad), x2.grad, rtol=t['rtol'], atol=t['atol'] * 4)
     torch.testing.assert_close(nchw(s2d.grad), s2.grad, **t)
+
+
+@pytest.mark.parametrize('cfg', [(64, 64, 96), (96, 96, 128), (160, 160, 160), (32, 64, 32)])
+def test_conv1x1_over_concatenation(cfg):
+    """1x1 convolution over cat([a, b]) with the concatenation folded into the GEMM operands: forward, both input gradients, weight
+    gradient and the fused BatchNorm statistics vs torch"""
+    from tcct_amd import ops
+    Ca, Cb, Co = cfg
+    dt = torch.bfloat16
+    N, H, W = 2, 19, 70
+    a = rnd(N, Ca, H, W, dt=dt).requires_grad_(True)
+    b = rnd(N, Cb, H, W, seed=1, dt=dt).requires_grad_(True)
+    w = (rnd(Co, Ca + Cb, 1, 1, seed=2) / (Ca + Cb) ** 0.5).requires_grad_(True)
+    y = F.conv2d(torch.cat([a, b], 1), w.to(dt).float())
+    gy = rnd(*y.shape, seed=3, dt=dt)
+    y.backward(gy)
+    ad, bd = nhwc(a.detach(), dt).requires_grad_(True), nhwc(b.detach(), dt).requires_grad_(True)
+    wd = w.detach().cuda().requires_grad_(True)
+    yd = ops.conv1x1_cat2(ad, bd, wd, stats_pre='none')
+    t = tol(dt)
+    torch.testing.assert_close(nchw(yd), y.detach(), **t)
+    if Co <= 128:
+        sums = yd._bn_sums[0].cpu()
+        yq = nchw(yd).double()
+        torch.testing.assert_close(sums[:Co], yq.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+        torch.testing.assert_close(sums[Co:], (yq * yq).sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    yd.backward(nhwc(gy, dt))
+    torch.testing.assert_close(nchw(ad.grad), a.grad, **t)
+    torch.testing.assert_close(nchw(bd.grad), b.grad, **t)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, w.grad.abs().max().item()))
