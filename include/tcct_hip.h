@@ -178,6 +178,10 @@ int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float* dbias, in
 int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                 int out_dtype, tcct_stream_t stream);
 int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
+/* Linear + residual: y = res + scale[m / per_sample] * (x W^T + bias), bf16, N % 32 == 0, scale fp32 [M / per_sample] nullable
+ * (Mlp.fc2 followed by `x + drop_path(...)`, nets/tcct.py:468) */
+int tcct_pw_fwd_residual(const void* x, const float* w, const float* bias, const void* res, const float* scale, int64_t per_sample,
+                         void* y, int64_t M, int K, int N, tcct_stream_t stream);
 /* Concatenation-free pointwise convolution over [x1 | x2] (MHCA_stage.aggregate, nets/tcct.py:600-616): forward (+ optional fused
  * BN statistics), input gradient written to two tensors, weight gradient -- the channel concatenation is never materialised */
 int tcct_pw_fwd_cat2(const void* x1, const void* x2, int K1, const float* w, const float* bias, void* y, int64_t M, int K, int N,
@@ -208,6 +212,11 @@ int tcct_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias,
  * taken over the (token, channel) plane, exactly as torch treats the 3-D tensor --------------------------- */
 int tcct_metapool_fwd(const void* x, void* y, int B, int64_t N, int C, int dtype, tcct_stream_t stream);
 int tcct_metapool_bwd(const void* dy, void* dx, int B, int64_t N, int C, int dtype, tcct_stream_t stream);
+/* MHCABlock mixer branch with its residual: y = res + scale[b] * metapool(x) (nets/tcct.py:464-465; scale = DropPath mask / keep, fp32 [B],
+ * NULL = 1) and its input gradient dx = scale[b] * metapool^T(dy) -- no separate residual / scale passes */
+int tcct_metapool_residual_fwd(const void* x, const void* res, const float* scale, void* y, int B, int64_t N, int C, int dtype,
+                               tcct_stream_t stream);
+int tcct_metapool_scaled_bwd(const void* dy, const float* scale, void* dx, int B, int64_t N, int C, int dtype, tcct_stream_t stream);
 /* ---- nn.MaxPool2d(2) (nets/tcct.py:867,883); even H, W ---------------------------------------------------- */
 int tcct_maxpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, tcct_stream_t stream);
 int tcct_maxpool2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int dtype, tcct_stream_t stream);

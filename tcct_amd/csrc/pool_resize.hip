@@ -9,8 +9,12 @@
 // x [B, N, C]; BWD=false: y = box3x3_validcount(x) - x ; BWD=true: dx = box^T(dy) - dy
 // thread = fixed vector of 4 channels (the per-column divisors are computed once), rows strided over grid.x, batch on grid.y:
 // no per-element index division (the first version spent most of its time in 64-bit div/mod).
+// res / scale (both nullable): forward y = res + scale[b] * (box(x) - x) -- the token-mixer branch of MHCABlock with its residual add
+// and DropPath scale folded in (reference nets/tcct.py:464-465); backward dx = scale[b] * (box^T(dy) - dy) (the residual itself
+// passes dy through unchanged).
 template <typename T, bool BWD>
-__global__ void k_metapool(const T* __restrict__ x, T* __restrict__ y, int B, int N, int C) {
+__global__ void k_metapool(const T* __restrict__ x, T* __restrict__ y, int B, int N, int C, const T* __restrict__ res,
+                           const float* __restrict__ scale) {
     const int C4 = C >> 2, R = PB / C4, t = threadIdx.x;
     if (t >= R * C4) return;
     const int c0 = (t % C4) * 4, r = t / C4, lane = t & 63;
@@ -24,6 +28,8 @@ __global__ void k_metapool(const T* __restrict__ x, T* __restrict__ y, int B, in
     const bool hasl = c0 > 0, hasr = c0 + 4 < C;
     const T* xb = x + (int64_t)blockIdx.y * N * C + c0;
     T* yb = y + (int64_t)blockIdx.y * N * C + c0;
+    const T* rb = res ? res + (int64_t)blockIdx.y * N * C + c0 : nullptr;
+    const float sc = scale ? scale[blockIdx.y] : 1.f;
     for (int n = blockIdx.x * R + r; n < N; n += gridDim.x * R) {
         const T* base = xb + (int64_t)n * C;
         float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -53,18 +59,24 @@ __global__ void k_metapool(const T* __restrict__ x, T* __restrict__ y, int B, in
         for (int k = 0; k < 4; ++k) {
             float s = v[k] + v[k + 1] + v[k + 2];
             if (!BWD) s *= rinv * cs[k];
-            o.v[k] = s - ctr.v[k];
+            o.v[k] = sc * (s - ctr.v[k]);
+        }
+        if (rb) {
+            const f4 e = ld4(rb + (int64_t)n * C);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o.v[k] += e.v[k];
         }
         st4(yb + (int64_t)n * C, o);
     }
 }
-static int metapool_launch(const void* x, void* y, int B, int64_t N, int C, int dtype, bool bwd, tcct_stream_t stream, const char* who) {
+static int metapool_launch(const void* x, void* y, int B, int64_t N, int C, int dtype, bool bwd, tcct_stream_t stream, const char* who,
+                           const void* res = nullptr, const float* scale = nullptr) {
     if (!(C % 4 == 0 && C >= 4 && C / 4 <= PB)) { tcct_set_error("%s: C=%d", who, C); return -1; }
     if (!(B >= 1 && B <= 65535 && N >= 1 && N < (1LL << 30))) { tcct_set_error("%s: B=%d N=%lld out of range", who, B, (long long)N); return -1; }
     const int R = PB / (C / 4);
     dim3 g((unsigned)tcct_grid(N, R, 4096), (unsigned)B);
-    if (bwd) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_metapool<T, true>), g, dim3(PB), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, (int)N, C)); }
-    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_metapool<T, false>), g, dim3(PB), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, (int)N, C)); }
+    if (bwd) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_metapool<T, true>), g, dim3(PB), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, (int)N, C, (const T*)res, scale)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_metapool<T, false>), g, dim3(PB), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, (int)N, C, (const T*)res, scale)); }
     TCCT_LAUNCH_OK();
 }
 extern "C" int tcct_metapool_fwd(const void* x, void* y, int B, int64_t N, int C, int dtype, tcct_stream_t stream) {
@@ -72,6 +84,16 @@ extern "C" int tcct_metapool_fwd(const void* x, void* y, int B, int64_t N, int C
 }
 extern "C" int tcct_metapool_bwd(const void* dy, void* dx, int B, int64_t N, int C, int dtype, tcct_stream_t stream) {
     return metapool_launch(dy, dx, B, N, C, dtype, true, stream, "metapool_bwd");
+}
+/* y = res + scale[b] * metapool(x) (scale fp32 [B] nullable = 1): token mixer + DropPath scale + residual add in one pass */
+extern "C" int tcct_metapool_residual_fwd(const void* x, const void* res, const float* scale, void* y, int B, int64_t N, int C, int dtype,
+                                          tcct_stream_t stream) {
+    TCCT_CHECK(res != nullptr, "metapool_residual_fwd: res is NULL");
+    return metapool_launch(x, y, B, N, C, dtype, false, stream, "metapool_residual_fwd", res, scale);
+}
+/* dx = scale[b] * metapool^T(dy): the input gradient of the mixer branch (the residual branch receives dy itself) */
+extern "C" int tcct_metapool_scaled_bwd(const void* dy, const float* scale, void* dx, int B, int64_t N, int C, int dtype, tcct_stream_t stream) {
+    return metapool_launch(dy, dx, B, N, C, dtype, true, stream, "metapool_scaled_bwd", nullptr, scale);
 }
 
 // ------------------------------------------------------------------------------------------ MaxPool2d(2)

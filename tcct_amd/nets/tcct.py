@@ -218,13 +218,13 @@ class MHCABlock(nn.Module):
         t = x.view(B, H * W, C)
         s1, s2 = scales if scales is not None else (None, None)
         cur = ops.layernorm(t, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        t = ops.residual(t, ops.metapool(cur), s1)
+        t = ops.metapool_residual(cur, t, s1)           # t + dp(pool(LN1 t)): mixer, DropPath scale and residual in one pass
         cur = ops.layernorm(t, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
             h = ops.act(ops.conv2d(cur, self.mlp.fc1.weight, self.mlp.fc1.bias), 'gelu')
         else:               # inference: GELU in the GEMM epilogue
             h = ops.conv_bn_act(cur, self.mlp.fc1.weight, self.mlp.fc1.bias, post_act='gelu')
-        t = ops.residual(t, ops.conv2d(h, self.mlp.fc2.weight, self.mlp.fc2.bias), s2)
+        t = ops.linear_residual(h, self.mlp.fc2.weight, self.mlp.fc2.bias, t, s2)      # t + dp(fc2(h)) in the GEMM epilogue
         return t.view(B, H, W, C)
 
 

@@ -382,6 +382,49 @@ def bn2_add_act_eval(xa, bnA, xb, bnB, pre_act='lrelu', act_kind='gelu'):
     return y
 
 
+class _LinearResidual(torch.autograd.Function):
+    """res + scale[b] * (x W^T + bias) on tokens [B,N,C] (Mlp.fc2 + DropPath scale + residual add in the GEMM epilogue)"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, res, scale):
+        _chk(x, w, bias, res, scale)
+        B, Nt, K = x.shape
+        Cout = w.shape[0]
+        y = torch.empty((B, Nt, Cout), device=x.device, dtype=x.dtype)
+        lib.pw_fwd_residual(x, w, bias, res, scale, Nt, y, B * Nt, K, Cout)
+        ctx.save_for_backward(x, w)
+        ctx.scale, ctx.params = scale, (w, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        wsrc, bsrc = ctx.params
+        dy = _c(dy)
+        B, Nt, K = x.shape
+        Cout, M = w.shape[0], B * Nt
+        dz = dy
+        if ctx.scale is not None:
+            dz = torch.empty_like(dy)
+            lib.scale_rows(dy, ctx.scale, dz, B, dy.numel() // B, dtype_code(dy.dtype))
+        dx = torch.empty_like(x)
+        lib.pw_fwd(dz, w, None, dx, M, Cout, K, 1, dtype_code(x.dtype))
+        with _wgrad_stream(_slot_written(wsrc, bsrc), x, dz):
+            dw = _grad_out(wsrc, tuple(w.shape))
+            db = _grad_out(bsrc)
+            lib.pw_wgrad(x, dz, dw, db, M, K, Cout)
+        return dx, _ret(dw, wsrc), _ret(db, bsrc), dy, None
+
+
+def linear_residual(x, w, bias, res, scale=None):
+    """res + scale[b] * Linear(x) for token tensors [B,N,C]; bf16 with C multiples of 32 takes the fused epilogue"""
+    ok = (x.dtype == torch.bfloat16 and x.dim() == 3 and w.dim() == 2 and x.shape[-1] % 32 == 0 and w.shape[0] % 32 == 0
+          and w.shape[0] <= 160 and bias is not None and res.shape == x.shape[:-1] + (w.shape[0],))
+    if not ok:
+        return residual(res, conv2d(x, w, bias), scale)
+    return _LinearResidual.apply(x, w, bias, res, scale)
+
+
 class _PwCat2(torch.autograd.Function):
     """1x1 convolution over the channel concatenation [a | b] without materialising it (MHCA_stage.aggregate)"""
 
@@ -789,6 +832,32 @@ class _MetaPool(torch.autograd.Function):
         dx = torch.empty_like(dy)
         lib.metapool_bwd(dy, dx, B, N, C, dtype_code(dy.dtype))
         return dx
+
+
+class _MetaPoolResidual(torch.autograd.Function):
+    """t + scale[b] * metapool(cur): mixer branch, DropPath scale and residual add in one pass (and one pass backward)"""
+
+    @staticmethod
+    def forward(ctx, cur, t, scale):
+        _chk(cur, t, scale)
+        B, N, C = cur.shape
+        y = torch.empty_like(cur)
+        lib.metapool_residual_fwd(cur, t, scale, y, B, N, C, dtype_code(cur.dtype))
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        B, N, C = dy.shape
+        dcur = torch.empty_like(dy)
+        lib.metapool_scaled_bwd(dy, ctx.scale, dcur, B, N, C, dtype_code(dy.dtype))
+        return dcur, dy, None
+
+
+def metapool_residual(cur, t, scale=None):
+    """t + scale[b] * MetaPool(cur) on tokens [B,N,C] (scale: fp32 [B] or None)"""
+    return _MetaPoolResidual.apply(cur, t, scale)
 
 
 def metapool(x):

@@ -545,3 +545,53 @@ def test_conv1x1_over_concatenation(cfg):
     torch.testing.assert_close(nchw(ad.grad), a.grad, **t)
     torch.testing.assert_close(nchw(bd.grad), b.grad, **t)
     torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, w.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('scaled', [False, True])
+def test_metapool_with_residual(dt, scaled):
+    """t + s[b] * MetaPool(cur) in one pass (reference nets/tcct.py:405-415,464-465) and its two gradients"""
+    from tcct_amd import ops
+    B, H, W, C = 3, 6, 10, 64
+    cur = rnd(B, H * W, C, dt=dt).requires_grad_(True)
+    t = rnd(B, H * W, C, seed=1, dt=dt).requires_grad_(True)
+    sc = torch.tensor([0.0, 1.25, 1.25]) if scaled else None
+    pooled = F.avg_pool2d(cur[:, None], 3, 1, 1, count_include_pad=False)[:, 0] - cur
+    y = t + (pooled * sc.view(B, 1, 1) if scaled else pooled)
+    gy = rnd(*y.shape, seed=2, dt=dt)
+    y.backward(gy)
+    cd, td = cur.detach().to('cuda', dt).requires_grad_(True), t.detach().to('cuda', dt).requires_grad_(True)
+    yd = ops.metapool_residual(cd, td, sc.cuda() if scaled else None)
+    tl = tol(dt)
+    torch.testing.assert_close(yd.float().cpu(), y.detach(), **tl)
+    yd.backward(gy.to('cuda', dt))
+    torch.testing.assert_close(cd.grad.float().cpu(), cur.grad, **tl)
+    torch.testing.assert_close(td.grad.float().cpu(), t.grad, **tl)
+
+
+@pytest.mark.parametrize('scaled', [False, True])
+@pytest.mark.parametrize('C', [64, 160])
+def test_linear_with_residual(scaled, C):
+    """t + s[b] * fc2(h) with the residual and DropPath scale in the GEMM epilogue (reference nets/tcct.py:41-43,468) + all gradients"""
+    from tcct_amd import ops
+    dt = torch.bfloat16
+    B, Nt = 3, 230
+    h = rnd(B, Nt, C, dt=dt).requires_grad_(True)
+    t = rnd(B, Nt, C, seed=1, dt=dt).requires_grad_(True)
+    w = (rnd(C, C, seed=2) / C ** 0.5).requires_grad_(True)
+    b = rnd(C, seed=3).requires_grad_(True)
+    sc = torch.tensor([1.25, 0.0, 1.25]) if scaled else None
+    z = F.linear(h, w.to(dt).float(), b)
+    y = t + (z * sc.view(B, 1, 1) if scaled else z)
+    gy = rnd(*y.shape, seed=4, dt=dt)
+    y.backward(gy)
+    hd, td = h.detach().to('cuda', dt).requires_grad_(True), t.detach().to('cuda', dt).requires_grad_(True)
+    wd, bd = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    yd = ops.linear_residual(hd, wd, bd, td, sc.cuda() if scaled else None)
+    tl = tol(dt)
+    torch.testing.assert_close(yd.float().cpu(), y.detach(), **tl)
+    yd.backward(gy.to('cuda', dt))
+    torch.testing.assert_close(hd.grad.float().cpu(), h.grad, **tl)
+    torch.testing.assert_close(td.grad.float().cpu(), t.grad, **tl)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=tl['rtol'], atol=tl['atol'] * max(1.0, w.grad.abs().max().item()))
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=tl['rtol'], atol=tl['atol'] * max(1.0, b.grad.abs().max().item()))
