@@ -179,9 +179,10 @@ int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64
                 int out_dtype, tcct_stream_t stream);
 int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
 /* Linear + residual: y = res + scale[m / per_sample] * (x W^T + bias), bf16, N % 32 == 0, scale fp32 [M / per_sample] nullable
- * (Mlp.fc2 followed by `x + drop_path(...)`, nets/tcct.py:468) */
+ * (Mlp.fc2 followed by `x + drop_path(...)`, nets/tcct.py:468); y_plain (nullable) additionally receives x W^T + bias itself: the decoder's
+ * `post` convolution whose output feeds both the next stage and `x_i + y_i` (nets/tcct.py:1028-1031) */
 int tcct_pw_fwd_residual(const void* x, const float* w, const float* bias, const void* res, const float* scale, int64_t per_sample,
-                         void* y, int64_t M, int K, int N, tcct_stream_t stream);
+                         void* y, void* y_plain, int64_t M, int K, int N, tcct_stream_t stream);
 /* Concatenation-free pointwise convolution over [x1 | x2] (MHCA_stage.aggregate, nets/tcct.py:600-616): forward (+ optional fused
  * BN statistics), input gradient written to two tensors, weight gradient -- the channel concatenation is never materialised */
 int tcct_pw_fwd_cat2(const void* x1, const void* x2, int K1, const float* w, const float* bias, void* y, int64_t M, int K, int N,

@@ -30,7 +30,7 @@ __device__ __forceinline__ float rnd_out(float v, const float*) { return v; }
 // Concatenation-free operands (MHCA_stage.aggregate, reference nets/tcct.py:600-616: `cat([InvRes(x), Encoder(x)], 1)` -> 1x1 conv): the
 // input rows may live in TWO tensors (channels [0,K1) in x, [K1,K) in x2) and, for the input-gradient GEMM, the output rows may go
 // to two tensors (channels [0,N1) to y, [N1,N) to y2).  K1 / N1 are multiples of 32; x2 == NULL / y2 == NULL: ordinary operands.
-struct PwSplit { const bf16* x2; int K1; void* y2; int N1; const bf16* res; const float* rscale; int64_t per_sample; };
+struct PwSplit { const bf16* x2; int K1; void* y2; int N1; const bf16* res; const float* rscale; int64_t per_sample; bf16* yplain; };
 // res (inference-epilogue kernel only): y = res + rscale[m / per_sample] * (x W^T + bias), rscale nullable -- Mlp.fc2 with the
 // residual add and the DropPath scale of MHCABlock folded in (reference nets/tcct.py:468)
 // STATS: also accumulate per-channel sum / sum of squares of pre_act(y) (y as stored) into stats[0..N) / stats[N..2N): the
@@ -152,6 +152,7 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                         bf16* dst = (sp.y2 && n0 >= sp.N1) ? reinterpret_cast<bf16*>(sp.y2) + mm * (N - sp.N1) + (n0 - sp.N1)
                                                            : reinterpret_cast<bf16*>(y) + mm * (sp.y2 ? sp.N1 : N) + n0;
                         if (AFF && sp.res) {                    // y = res + s * y (values already rounded to bf16, like the op-by-op path)
+                            if (sp.yplain) *reinterpret_cast<uint4*>(sp.yplain + mm * N + n0 + cch * 8) = o;     // the Linear output itself
                             const uint4 rv = *reinterpret_cast<const uint4*>(sp.res + mm * N + n0 + cch * 8);
                             const float sc_ = sp.rscale ? sp.rscale[mm / sp.per_sample] : 1.f;
                             const uint32_t ov[4] = {o.x, o.y, o.z, o.w}, rr[4] = {rv.x, rv.y, rv.z, rv.w};
@@ -231,7 +232,7 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
  * y [M,N] bf16 or fp32. */
 static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                        int out_dtype, double* stats, int stat_pre, tcct_stream_t stream, const float* aff = nullptr, int aff_pre = 0,
-                       int aff_post = 0, PwSplit sp = PwSplit{nullptr, 0, nullptr, 0, nullptr, nullptr, 1});
+                       int aff_post = 0, PwSplit sp = PwSplit{nullptr, 0, nullptr, 0, nullptr, nullptr, 1, nullptr});
 extern "C" int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                            int out_dtype, tcct_stream_t stream) {
     return pw_fwd_impl(x, w, bias, y, M, K, N, transposed, out_dtype, nullptr, 0, stream);
@@ -247,21 +248,21 @@ extern "C" int tcct_pw_fwd_cat2(const void* x1, const void* x2, int K1, const fl
                                 double* stats, int pre_act, tcct_stream_t stream) {
     TCCT_CHECK(x2 != nullptr, "pw_fwd_cat2: x2 is NULL");
     if (stats) TCCT_CHECK(N % 32 == 0 && N <= 128, "pw_fwd_cat2: fused statistics need N in {32,64,96,128} (got %d)", N);
-    return pw_fwd_impl(x1, w, bias, y, M, K, N, 0, TCCT_BF16, stats, pre_act, stream, nullptr, 0, 0, PwSplit{(const bf16*)x2, K1, nullptr, 0, nullptr, nullptr, 1});
+    return pw_fwd_impl(x1, w, bias, y, M, K, N, 0, TCCT_BF16, stats, pre_act, stream, nullptr, 0, 0, PwSplit{(const bf16*)x2, K1, nullptr, 0, nullptr, nullptr, 1, nullptr});
 }
 /* input gradient of the same convolution: [dx1 | dx2] = dy W with w [Nout, K] (the weight as stored), dy [M, Nout]; dx1 [M,K1], dx2 [M,K-K1] */
 extern "C" int tcct_pw_dgrad_split2(const void* dy, const float* w, void* dx1, void* dx2, int K1, int64_t M, int Nout, int K,
                                     tcct_stream_t stream) {
     TCCT_CHECK(dx2 != nullptr, "pw_dgrad_split2: dx2 is NULL");
-    return pw_fwd_impl(dy, w, nullptr, dx1, M, Nout, K, 1, TCCT_BF16, nullptr, 0, stream, nullptr, 0, 0, PwSplit{nullptr, 0, dx2, K1, nullptr, nullptr, 1});
+    return pw_fwd_impl(dy, w, nullptr, dx1, M, Nout, K, 1, TCCT_BF16, nullptr, 0, stream, nullptr, 0, 0, PwSplit{nullptr, 0, dx2, K1, nullptr, nullptr, 1, nullptr});
 }
 /* y = res + scale[m / per_sample] * (x W^T + bias)  (bf16, N % 32 == 0; scale fp32 nullable): a Linear with the residual add and the
  * per-sample DropPath scale that follow it folded into the epilogue */
 extern "C" int tcct_pw_fwd_residual(const void* x, const float* w, const float* bias, const void* res, const float* scale,
-                                    int64_t per_sample, void* y, int64_t M, int K, int N, tcct_stream_t stream) {
+                                    int64_t per_sample, void* y, void* y_plain, int64_t M, int K, int N, tcct_stream_t stream) {
     TCCT_CHECK(res != nullptr && N % 32 == 0 && per_sample >= 1, "pw_fwd_residual: needs res, N %% 32 == 0, per_sample >= 1");
     return pw_fwd_impl(x, w, bias, y, M, K, N, 0, TCCT_BF16, nullptr, 0, stream, nullptr, 0, 0,
-                       PwSplit{nullptr, 0, nullptr, 0, (const bf16*)res, scale, per_sample});
+                       PwSplit{nullptr, 0, nullptr, 0, (const bf16*)res, scale, per_sample, (bf16*)y_plain});
 }
 /* inference: y = post_act(a[c] * pre_act(x W^T + bias[c]) + b[c]), ab = {a[N], b[N]} from tcct_bn_eval_ab (NULL: a = 1, b = 0):
  * eval-mode BatchNorm and the adjacent activation(s) folded into the GEMM epilogue (Conv2d_BN, Mlp.fc1 + GELU, tran_*) */

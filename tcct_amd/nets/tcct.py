@@ -358,9 +358,13 @@ class MPUpBlock(nn.Module):
         self.prep = nn.Sequential(nn.Conv2d(in_ch, out_ch, 3, 1, 1), nn.BatchNorm2d(out_ch), nn.LeakyReLU(inplace=True))
         self.post = nn.Sequential(nn.Conv2d(out_ch, out_ch, 1, 1, 0))
 
-    def forward(self, x1, x2):
+    def forward(self, x1, x2, with_sum=False):
+        """with_sum: also return x2 + output (the `x_i + y_i` of FTC.forward, tcct.py:1028-1031) from the same GEMM epilogue"""
         y = _conv_bn(self.prep[0], self.prep[1], x1, post='lrelu')
-        return _conv(self.post[0], ops.bilinear(y, (x1.shape[1] * 2, x1.shape[2] * 2), True, residual=x2))
+        u = ops.bilinear(y, (x1.shape[1] * 2, x1.shape[2] * 2), True, residual=x2)
+        if with_sum:
+            return ops.conv1x1_and_sum(u, self.post[0].weight, self.post[0].bias, x2)
+        return _conv(self.post[0], u)
 
 
 class FTC(nn.Module):
@@ -468,17 +472,18 @@ class FTC(nn.Module):
             (c1,), (v2, v3, v4, v5) = ops.run_parallel('vit', lambda: self.base_cnn(x, levels=1), lambda: self.base_vit.forward_features(x))
             f = [c1] + [_conv_bn(getattr(self, f'tran_vit{j}')[0], getattr(self, f'tran_vit{j}')[1], v) for j, v in enumerate((v2, v3, v4, v5))]
         y8 = _conv_bn(self.head[0], self.head[1], f[4], post='lrelu')
-        d3 = self.dec1(y8, f[3])
-        d2 = self.dec2(d3, f[2])
-        d1 = self.dec3(d2, f[1])
-        d0 = self.dec4(d1, f[0])
         if self.legacy_heads:       # tcct_goals.py:1027-1033: heads on the decoder outputs
+            d3 = self.dec1(y8, f[3])
+            d2 = self.dec2(d3, f[2])
+            d1 = self.dec3(d2, f[1])
+            d0 = self.dec4(d1, f[0])
             g0, g1, g2, g3 = d0, d1, d2, d3
-        else:
-            g0 = _conv(self.t324, ops.add(f[0], d0))
-            g1 = _conv(self.t323, ops.add(f[1], d1))
-            g2 = _conv(self.t322, ops.add(f[2], d2))
-            g3 = _conv(self.t321, ops.add(f[3], d3))
+        else:                       # x_i + y_i comes out of the decoder's last GEMM epilogue together with y_i
+            d3, s3 = self.dec1(y8, f[3], with_sum=True)
+            d2, s2 = self.dec2(d3, f[2], with_sum=True)
+            d1, s1 = self.dec3(d2, f[1], with_sum=True)
+            d0, s0 = self.dec4(d1, f[0], with_sum=True)
+            g0, g1, g2, g3 = _conv(self.t324, s0), _conv(self.t323, s1), _conv(self.t322, s2), _conv(self.t321, s3)
         # norm_add([y0,y1,y2]) (reference tcct.py:937-942,1035) -> `self.feats`: evaluated lazily on first access (only the
         # feature-polarization loss reads it; with --udh=false the six level-0 passes are simply never launched)
         self._feats_src = (g0, g1, g2, size)

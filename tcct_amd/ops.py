@@ -391,7 +391,7 @@ class _LinearResidual(torch.autograd.Function):
         B, Nt, K = x.shape
         Cout = w.shape[0]
         y = torch.empty((B, Nt, Cout), device=x.device, dtype=x.dtype)
-        lib.pw_fwd_residual(x, w, bias, res, scale, Nt, y, B * Nt, K, Cout)
+        lib.pw_fwd_residual(x, w, bias, res, scale, Nt, y, None, B * Nt, K, Cout)
         ctx.save_for_backward(x, w)
         ctx.scale, ctx.params = scale, (w, bias)
         return y
@@ -414,6 +414,54 @@ class _LinearResidual(torch.autograd.Function):
             db = _grad_out(bsrc)
             lib.pw_wgrad(x, dz, dw, db, M, K, Cout)
         return dx, _ret(dw, wsrc), _ret(db, bsrc), dy, None
+
+
+class _Conv1x1AndSum(torch.autograd.Function):
+    """(d, d + res) with d = conv1x1(x): both written by one GEMM epilogue (decoder `post` convolution + the `x_i + y_i` that follows)"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, res):
+        _chk(x, w, bias, res)
+        N_, H, W_, K = x.shape
+        Cout = w.shape[0]
+        d = torch.empty((N_, H, W_, Cout), device=x.device, dtype=x.dtype)
+        s_ = torch.empty_like(d)
+        lib.pw_fwd_residual(x, w, bias, res, None, 1, s_, d, N_ * H * W_, K, Cout)
+        ctx.save_for_backward(x, w)
+        ctx.params = (w, bias)
+        return d, s_
+
+    @staticmethod
+    def backward(ctx, gd, gs):
+        x, w = ctx.saved_tensors
+        wsrc, bsrc = ctx.params
+        if gd is None and gs is None:
+            return None, None, None, None
+        if gd is None or gs is None:
+            dz = _c(gd if gs is None else gs)
+        else:
+            dz = torch.empty_like(gs)
+            lib.add(_c(gd), _c(gs), dz, dz.numel(), dtype_code(dz.dtype))
+        N_, H, W_, K = x.shape
+        Cout, M = w.shape[0], N_ * H * W_
+        dx = torch.empty_like(x)
+        lib.pw_fwd(dz, w, None, dx, M, Cout, K, 1, dtype_code(x.dtype))
+        with _wgrad_stream(_slot_written(wsrc, bsrc), x, dz):
+            dw = _grad_out(wsrc, tuple(w.shape))
+            db = _grad_out(bsrc)
+            lib.pw_wgrad(x, dz, dw, db, M, K, Cout)
+        return dx, _ret(dw, wsrc), _ret(db, bsrc), (None if gs is None else _c(gs))
+
+
+def conv1x1_and_sum(x, w, bias, res):
+    """(conv1x1(x), conv1x1(x) + res); bf16 NHWC with channel counts multiples of 32 takes the double-store epilogue"""
+    ok = (x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] % 32 == 0 and w.shape[0] % 32 == 0 and w.shape[0] <= 160
+          and tuple(w.shape[2:]) == (1, 1) and w.shape[1] == x.shape[-1] and bias is not None and res.shape == x.shape[:-1] + (w.shape[0],)
+          and res.dtype == x.dtype)
+    if not ok:
+        d = conv2d(x, w, bias)
+        return d, add(res, d)
+    return _Conv1x1AndSum.apply(x, w, bias, res)
 
 
 def linear_residual(x, w, bias, res, scale=None):

@@ -595,3 +595,30 @@ def test_linear_with_residual(scaled, C):
     torch.testing.assert_close(td.grad.float().cpu(), t.grad, **tl)
     torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=tl['rtol'], atol=tl['atol'] * max(1.0, w.grad.abs().max().item()))
     torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=tl['rtol'], atol=tl['atol'] * max(1.0, b.grad.abs().max().item()))
+
+
+def test_conv1x1_and_sum():
+    """(d, d + res) from one GEMM epilogue (decoder `post` convolution + `x_i + y_i`) and the gradients when both outputs are used"""
+    from tcct_amd import ops
+    dt = torch.bfloat16
+    N, C, H, W = 2, 32, 21, 37
+    x = rnd(N, C, H, W, dt=dt).requires_grad_(True)
+    r = rnd(N, C, H, W, seed=1, dt=dt).requires_grad_(True)
+    w = (rnd(C, C, 1, 1, seed=2) / C ** 0.5).requires_grad_(True)
+    b = rnd(C, seed=3).requires_grad_(True)
+    d = F.conv2d(x, w.to(dt).float(), b)
+    s_ = d + r
+    g1, g2 = rnd(*d.shape, seed=4, dt=dt), rnd(*d.shape, seed=5, dt=dt)
+    (d * g1).sum().backward(retain_graph=True)
+    (s_ * g2).sum().backward()
+    xd, rd = nhwc(x.detach(), dt).requires_grad_(True), nhwc(r.detach(), dt).requires_grad_(True)
+    wd, bd = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    dd, sd = ops.conv1x1_and_sum(xd, wd, bd, rd)
+    t = tol(dt)
+    torch.testing.assert_close(nchw(dd), d.detach(), **t)
+    torch.testing.assert_close(nchw(sd), s_.detach(), **t)
+    ((dd.float() * nhwc(g1, torch.float32)).sum() + (sd.float() * nhwc(g2, torch.float32)).sum()).backward()
+    torch.testing.assert_close(nchw(xd.grad), x.grad, rtol=t['rtol'], atol=t['atol'] * 2)
+    torch.testing.assert_close(nchw(rd.grad), r.grad, **t)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, w.grad.abs().max().item()))
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, b.grad.abs().max().item()))
