@@ -372,12 +372,13 @@ __device__ __forceinline__ bf16x8 tr_load8p(const unsigned char* p) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TPW, bool VERT>
+template <int TPW, bool VERT, bool SQ = false>      // SQ: 16 x 32 tiles (3x3; smaller x halo, fewer wasted pixel slots), else 8 x 64 / 64 x 8
 __global__ void __launch_bounds__(MB, 2)
 k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
                int N, int H, int W, int KH, int KW, int PH, int PW, int TG, int tilesH, int tilesW, int ntiles, int xs, int xo,
                int ds, int dof, int ldi, int o_off, int i_off) {
-    constexpr int TH = VERT ? 64 : 8, TW = VERT ? 8 : 64;
+    constexpr int TH = VERT ? 64 : (SQ ? 16 : 8), TW = VERT ? 8 : (SQ ? 32 : 64);
+    constexpr int CPR = (VERT ? TH : TW) / 16;     // 16-pixel chunks per tile row (HORZ) / column (VERT)
     constexpr int DSL = TH * TW * 4 / MB;          // dy slots per thread (8)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int LH = TH + KH - 1, LW = TW + KW - 1;
@@ -460,7 +461,7 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
         // chunks of 16 pixels; fragments of chunk i+1 are read while the MFMAs of chunk i run (sched_barrier pins the order)
         struct WFrag { bf16x8 a, b[TPW]; };
         auto load_chunk = [&](WFrag& f, int ch) {
-            const int a_ = ch >> 2, s16 = (ch & 3) * 16;      // HORZ: row / col offset; VERT: col / row offset
+            const int a_ = ch / CPR, s16 = (ch % CPR) * 16;   // HORZ: row / col offset; VERT: col / row offset
             const int Pd = VERT ? a_ * TH + s16 : a_ * TW + s16;
             const int Px = VERT ? a_ * LH + s16 : a_ * LW + s16;
             f.a = tr_load8p(lbD + Pd * 64);
@@ -556,7 +557,8 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
     const int TAPS = KH * KW;
     TCCT_CHECK(TAPS >= 1 && TAPS <= 16, "conv32_wgrad: %dx%d unsupported (<= 16 taps)", KH, KW);
     const bool vert = (KW == 1 && KH > 1);
-    const int TH = vert ? 64 : 8, TW = vert ? 8 : 64;
+    const bool sq = !vert && KH == 3 && KW == 3 && xs == 32 && ds == 32;      // plain 3x3: 16 x 32 tiles
+    const int TH = vert ? 64 : (sq ? 16 : 8), TW = vert ? 8 : (sq ? 32 : 64);
     const int LH = TH + KH - 1, LW = TW + KW - 1;
     size_t lds = (size_t)LH * LW * 64 + (size_t)TH * TW * 64;
     size_t red = (size_t)TAPS * 4096;
@@ -576,15 +578,16 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
     const int tpw = (TAPS + TG - 1) / TG;
     TCCT_CHECK(TAPS <= 16, "conv32_wgrad: %d taps unsupported", TAPS);
     TCCT_CHECK(LH * LW * 4 <= MAXL * MB, "conv32_wgrad: %dx%d tile image exceeds the staging slots", KH, KW);
-#define WG_LAUNCH(TPW, V)                                                                                                   \
+#define WG_LAUNCH(TPW, V, Q)                                                                                                 \
     do {                                                                                                                    \
         static bool attr = false;                                                                                           \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad<TPW, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
-        hipLaunchKernelGGL((k_conv32_wgrad<TPW, V>), dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W, KH, \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad<TPW, V, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+        hipLaunchKernelGGL((k_conv32_wgrad<TPW, V, Q>), dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W, KH, \
                            KW, PH, PW, TG, tilesH, tilesW, (int)nt, xs, xo, ds, dof, ldi, o_off, i_off);                                                        \
     } while (0)
-    if (tpw <= 4) { if (vert) WG_LAUNCH(4, true); else WG_LAUNCH(4, false); }
-    else { if (vert) WG_LAUNCH(5, true); else WG_LAUNCH(5, false); }
+    if (sq) WG_LAUNCH(5, false, true);
+    else if (tpw <= 4) { if (vert) WG_LAUNCH(4, true, false); else WG_LAUNCH(4, false, false); }
+    else { if (vert) WG_LAUNCH(5, true, false); else WG_LAUNCH(5, false, false); }
 #undef WG_LAUNCH
     TCCT_LAUNCH_OK();
 }
