@@ -253,6 +253,14 @@ int tcct_softmax_pick(const void* logits, const uint8_t* labels, int64_t M, int 
 int tcct_confusion_counts(const uint8_t* pred, const uint8_t* labels, int N, int64_t HW, int C, float* out,
                           tcct_stream_t stream);
 
+/* GateFusion in training mode (nets/tcct.py:916-932, gtc_* variants): y = x1*alpha + x2*(1-alpha) with
+ * alpha = clamp(bicubic_upsample(field -> H x W), 0, 1), field fp32 NHWC [N,hs,ws,C] = the caller's torch.rand draw; torch's bicubic
+ * (align_corners=False, A = -0.75, clamped border) is evaluated on the fly.  bwd: dx1 = dy*alpha, dx2 = dy*(1-alpha). */
+int tcct_gate_fusion_fwd(const void* x1, const void* x2, const float* field, void* y, int N, int H, int W, int C, int hs, int ws,
+                         int dtype, tcct_stream_t stream);
+int tcct_gate_fusion_bwd(const void* dy, const float* field, void* dx1, void* dx2, int N, int H, int W, int C, int hs, int ws,
+                         int dtype, tcct_stream_t stream);
+
 /* layer-boundary coordinates of a class-index mask [N,H,W] (KiteSeg.predict output): out int32 [N][C-1][W],
  * out[n][k-1][w] = number of rows h with mask[n,h,w] < k = the row where layer k starts in column w of a layered segmentation
  * (the boundary-coordinate extractor the reference lacks -- it only carries the unused soft_argmax, nets/reg.py:27-35) */

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE (build container only, needs /root/reference): fixtures for the sibling variants of stc_tt that the
 reference defines next to it (nets/tcct.py:1048-1053 gtc_tt, :1120-1134 cnnu / vitu).  Formula weights (oracle.formula_state_dict),
 formula input, REAL reference forward: eval-mode logits of all four heads for every variant, train-mode logits (batch-statistics
-BatchNorm, DropPath off) for cnnu / vitu (GateFusion's training branch draws a random field and is not restated)."""
+BatchNorm, DropPath off) for all three; GateFusion's four random alpha fields (torch.rand, nets/tcct.py:925) are recorded as inputs."""
 import contextlib, io, os, sys
 import numpy as np
 import torch
@@ -28,11 +28,25 @@ if __name__ == '__main__':
         with torch.no_grad():
             ev = model(img)
         out[f'{name}_eval'] = np.stack([o.numpy() for o in ev])
-        if name != 'gtc_tt':
-            model.train()
+        model.train()
+        draws = []
+        real_rand = torch.rand
+
+        def rec_rand(*a, **k):             # GateFusion draws its alpha field with torch.rand (nets/tcct.py:925): record the draws
+            r = real_rand(*a, **k)
+            draws.append(r.clone())
+            return r
+        torch.rand = rec_rand
+        try:
             with torch.no_grad():
                 tr = model(img)
-            out[f'{name}_train'] = np.stack([o.numpy() for o in tr])
+        finally:
+            torch.rand = real_rand
+        out[f'{name}_train'] = np.stack([o.numpy() for o in tr])
+        if name == 'gtc_tt':
+            assert len(draws) == 4
+            for j, d in enumerate(draws):
+                out[f'gtc_tt_field{j}'] = d.numpy()
         print(name, 'eval logit range', float(ev[0].min()), float(ev[0].max()))
     path = os.path.join(HERE, '..', 'tests', 'golden', 'variants_2x32x64.npz')
     np.savez_compressed(path, **out)

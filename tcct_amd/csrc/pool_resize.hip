@@ -438,6 +438,83 @@ extern "C" int tcct_bilinear_bwd(const void* dy, void* dx, int N, int H, int W, 
     TCCT_LAUNCH_OK();
 }
 
+// ------------------------------------------------------------------------------------------ GateFusion (training)
+// reference nets/tcct.py:916-932: alpha = clamp(F.interpolate(rand(B,C,hs,ws), size=(H,W), mode='bicubic'), 0, 1) (align_corners=False,
+// cubic convolution with A = -0.75, border indices clamped -- torch's upsample_bicubic2d); out = x1*alpha + x2*(1-alpha).  The small
+// random field `a` ([B,hs,ws,C] fp32, NHWC, drawn by the caller) is expanded on the fly: alpha is never materialised.
+// MODE 0: y = x1*alpha + x2*(1-alpha);  MODE 1 (backward): y = dy*alpha, y2 = dy*(1-alpha).
+__device__ __forceinline__ void cubic_w(float t, float* w) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+template <typename T, int MODE>
+__global__ void k_gate_fusion(const T* __restrict__ x1, const T* __restrict__ x2, const float* __restrict__ a, T* __restrict__ y,
+                              T* __restrict__ y2, int N, int H, int W, int C, int hs, int ws, float sh, float sw) {
+    const int C4 = C >> 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * C4) return;
+    const int wo = i / C4, c = (i - wo * C4) * 4;
+    const float fx = sw * ((float)wo + 0.5f) - 0.5f;
+    const int ix = (int)floorf(fx);
+    float wx[4];
+    cubic_w(fx - (float)ix, wx);
+    int cx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cx[k] = min(max(ix - 1 + k, 0), ws - 1) * C + c;
+    for (int row = blockIdx.y; row < N * H; row += gridDim.y) {
+        const int n = row / H, ho = row - n * H;
+        const float fy = sh * ((float)ho + 0.5f) - 0.5f;
+        const int iy = (int)floorf(fy);
+        float wy[4];
+        cubic_w(fy - (float)iy, wy);
+        float al[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* ar = a + ((int64_t)n * hs + min(max(iy - 1 + r, 0), hs - 1)) * ws * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(ar + cx[k]);
+                const float wgt = wy[r] * wx[k];
+                al[0] += wgt * v.x; al[1] += wgt * v.y; al[2] += wgt * v.z; al[3] += wgt * v.w;
+            }
+        }
+        const int64_t off = ((int64_t)row * W + wo) * C + c;
+        const f4 u = ld4(x1 + off);
+        f4 o, o2;
+        if (MODE == 0) {
+            const f4 v = ld4(x2 + off);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float t = fminf(fmaxf(al[k], 0.f), 1.f); o.v[k] = u.v[k] * t + v.v[k] * (1.f - t); }
+            st4(y + off, o);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float t = fminf(fmaxf(al[k], 0.f), 1.f); o.v[k] = u.v[k] * t; o2.v[k] = u.v[k] * (1.f - t); }
+            st4(y + off, o); st4(y2 + off, o2);
+        }
+    }
+}
+static int gate_launch(const void* x1, const void* x2, const float* a, void* y, void* y2, int N, int H, int W, int C, int hs, int ws,
+                       int dtype, int mode, tcct_stream_t stream, const char* who) {
+    if (!(C % 4 == 0 && C >= 4 && N >= 1 && H >= 1 && W >= 1 && hs >= 1 && ws >= 1)) { tcct_set_error("%s: bad shape", who); return -1; }
+    const float sh = (float)hs / (float)H, sw = (float)ws / (float)W;        // align_corners=False: scale = in / out
+    dim3 g = row_grid(W * (C / 4), (int64_t)N * H);
+    if (mode == 0) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_gate_fusion<T, 0>), g, dim3(PB), 0, (hipStream_t)stream, (const T*)x1, (const T*)x2, a, (T*)y, (T*)y2, N, H, W, C, hs, ws, sh, sw)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_gate_fusion<T, 1>), g, dim3(PB), 0, (hipStream_t)stream, (const T*)x1, (const T*)x2, a, (T*)y, (T*)y2, N, H, W, C, hs, ws, sh, sw)); }
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_gate_fusion_fwd(const void* x1, const void* x2, const float* field, void* y, int N, int H, int W, int C, int hs, int ws,
+                                    int dtype, tcct_stream_t stream) {
+    return gate_launch(x1, x2, field, y, nullptr, N, H, W, C, hs, ws, dtype, 0, stream, "gate_fusion_fwd");
+}
+extern "C" int tcct_gate_fusion_bwd(const void* dy, const float* field, void* dx1, void* dx2, int N, int H, int W, int C, int hs, int ws,
+                                    int dtype, tcct_stream_t stream) {
+    return gate_launch(dy, nullptr, field, dx1, dx2, N, H, W, C, hs, ws, dtype, 1, stream, "gate_fusion_bwd");
+}
+
 // ------------------------------------------------------------------------------------------ L2 normalise over C
 // LP = C/4 lanes per pixel (power of two <= 64)
 template <typename T, bool BWD>

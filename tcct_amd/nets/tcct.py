@@ -380,6 +380,7 @@ class FTC(nn.Module):
         # sibling variants of the reference (nets/tcct.py:1090-1136): gtc_* fuse with GateFusion (:916-932), cnnu / vitu drop one
         # encoder from the fusion (:1016-1019).  All modules (and state_dict keys) exist in every variant, as in the reference.
         self.flag_gate, self.flag_cnn, self.flag_vit = bool(flag_gate), bool(flag_cnn), bool(flag_vit)
+        self.forced_gate_fields = None      # parity tests: list of 4 NHWC alpha fields in draw order (reference: torch.rand on the CPU)
         if not (self.flag_cnn or self.flag_vit):
             raise TcctError('FTC needs at least one of flag_cnn / flag_vit')
         self.base_vit = base_vit
@@ -454,10 +455,14 @@ class FTC(nn.Module):
             f = [c1]
             for j, (v, c) in enumerate(((v2, c2), (v3, c3), (v4, c4), (v5, c5))):
                 tv, tc = getattr(self, f'tran_vit{j}'), getattr(self, f'tran_cnn{j}')
-                if self.flag_gate:
-                    if self.training:
-                        raise TcctError('GateFusion training (random bicubic alpha field, tcct.py:922-929) is not built; gtc_* models '
-                                        'run in eval mode, where alpha = 0.5')
+                if self.flag_gate and self.training:
+                    # tcct.py:922-929: alpha = clamp(bicubic(rand(B,C,max(3,H/32),max(3,W/32))), 0, 1); the draw is an input here
+                    a1, a2 = _conv_bn(tv[0], tv[1], v), _conv_bn(tc[0], tc[1], c)
+                    B_, Hh, Ww, Cc = a1.shape
+                    fields = self.forced_gate_fields
+                    field = fields.pop(0) if fields else torch.rand((B_, max(3, Hh // 32), max(3, Ww // 32), Cc), device=a1.device)
+                    f.append(ops.gate_fusion(a1, a2, field.to(device=a1.device, dtype=torch.float32).contiguous()))
+                elif self.flag_gate:
                     sm = _conv_bn(tc[0], tc[1], c, residual=_conv_bn(tv[0], tv[1], v))      # x1*0.5 + x2*0.5 == (x1+x2)*0.5 exactly
                     half = torch.empty_like(sm)
                     ops.lib.scale(sm, half, sm.numel(), 0.5, ops.dtype_code(sm.dtype))

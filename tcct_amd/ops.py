@@ -859,6 +859,34 @@ class _Add3Scale(torch.autograd.Function):
         return d, d, d, None
 
 
+class _GateFusion(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, field):
+        _chk(x1, x2, field)
+        N, H, W, C = x1.shape
+        hs, ws = field.shape[1], field.shape[2]
+        if field.dtype != torch.float32 or tuple(field.shape) != (N, hs, ws, C) or x2.shape != x1.shape:
+            raise TcctError('gate_fusion: field must be fp32 NHWC [N,hs,ws,C] and x2 like x1')
+        y = torch.empty_like(x1)
+        lib.gate_fusion_fwd(x1, x2, field, y, N, H, W, C, hs, ws, dtype_code(x1.dtype))
+        ctx.save_for_backward(field)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (field,) = ctx.saved_tensors
+        dy = _c(dy)
+        N, H, W, C = dy.shape
+        d1, d2 = torch.empty_like(dy), torch.empty_like(dy)
+        lib.gate_fusion_bwd(dy, field, d1, d2, N, H, W, C, field.shape[1], field.shape[2], dtype_code(dy.dtype))
+        return d1, d2, None
+
+
+def gate_fusion(x1, x2, field):
+    """GateFusion training branch: x1*alpha + x2*(1-alpha), alpha = clamp(bicubic(field -> H x W), 0, 1); field fp32 NHWC [N,hs,ws,C]"""
+    return _GateFusion.apply(x1, x2, field)
+
+
 def add3_scale(a, b, c, alpha):
     return _Add3Scale.apply(a, b, c, float(alpha))
 

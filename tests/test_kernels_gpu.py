@@ -622,3 +622,26 @@ def test_conv1x1_and_sum():
     torch.testing.assert_close(nchw(rd.grad), r.grad, **t)
     torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, w.grad.abs().max().item()))
     torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, b.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('shape', [(2, 32, 50, 70, 3, 3), (1, 32, 128, 160, 4, 5), (2, 64, 9, 7, 3, 3)])
+def test_gate_fusion_training_branch(dt, shape):
+    """GateFusion (reference nets/tcct.py:916-932, training): x1*alpha + x2*(1-alpha), alpha = clamp(bicubic(rand field), 0, 1) evaluated on
+    the fly vs torch's F.interpolate(mode='bicubic') + both gradients"""
+    from tcct_amd import ops
+    N, C, H, W, hs, ws = shape
+    x1 = rnd(N, C, H, W, dt=dt).requires_grad_(True)
+    x2 = rnd(N, C, H, W, seed=1, dt=dt).requires_grad_(True)
+    field = torch.rand(N, C, hs, ws, generator=torch.Generator().manual_seed(5)) * 1.6 - 0.3      # exercises both clamps
+    alpha = F.interpolate(field, size=(H, W), mode='bicubic').clamp(0, 1)
+    y = x1 * alpha + x2 * (1 - alpha)
+    gy = rnd(*y.shape, seed=2, dt=dt)
+    y.backward(gy)
+    a, b = nhwc(x1.detach(), dt).requires_grad_(True), nhwc(x2.detach(), dt).requires_grad_(True)
+    yd = ops.gate_fusion(a, b, field.permute(0, 2, 3, 1).contiguous().cuda())
+    t = tol(dt)
+    torch.testing.assert_close(nchw(yd), y.detach(), **t)
+    yd.backward(nhwc(gy, dt))
+    torch.testing.assert_close(nchw(a.grad), x1.grad, **t)
+    torch.testing.assert_close(nchw(b.grad), x2.grad, **t)
