@@ -1,8 +1,9 @@
 """TEST INFRASTRUCTURE (build container only, needs /root/reference): fixtures for the sibling variants of stc_tt that the
-reference defines next to it (nets/tcct.py:1048-1053 gtc_tt, :1120-1134 cnnu / vitu).  Formula weights (oracle.formula_state_dict),
+reference defines next to it (nets/tcct.py:1048-1061 gtc_tt / gtc_tb, :1097-1102 stc_tb, :1117-1134 pnnu / cnnu / vitu).  Formula weights (oracle.formula_state_dict),
 formula input, REAL reference forward: eval-mode logits of all four heads for every variant, train-mode logits (batch-statistics
-BatchNorm, DropPath off) for all three; GateFusion's four random alpha fields (torch.rand, nets/tcct.py:925) are recorded as inputs."""
-import contextlib, io, os, sys
+BatchNorm, DropPath off) for all of them; GateFusion's four random alpha fields (torch.rand, nets/tcct.py:925) are recorded as inputs.  Variants whose parameter
+shapes differ from stc_tt's (wide CNN encoder, 3-tap PlainCNNBlock) get their state_dict key/shape list in variants_keys.json."""
+import contextlib, io, json, os, sys
 import numpy as np
 import torch
 
@@ -16,11 +17,14 @@ if __name__ == '__main__':
     import nets
     img, lab = O.synth_batch(2, 32, 64, seed=11)
     out = {'img': img.numpy()}
-    for name in ('gtc_tt', 'cnnu', 'vitu'):
+    keys_out = {}
+    for name in ('gtc_tt', 'cnnu', 'vitu', 'stc_tb', 'gtc_tb', 'pnnu'):
         with contextlib.redirect_stdout(io.StringIO()):
             model = nets.RegNet(getattr(nets, name)(5), con='cos', out_channels=5)
         keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
         model.load_state_dict(O.formula_state_dict(keys), strict=True)
+        if name in ('stc_tb', 'gtc_tb', 'pnnu'):
+            keys_out[name] = [[k, list(s)] for k, s in keys]
         for m in model.modules():
             if isinstance(m, _refimport.DropPath):
                 m.drop_prob = 0.
@@ -43,11 +47,12 @@ if __name__ == '__main__':
         finally:
             torch.rand = real_rand
         out[f'{name}_train'] = np.stack([o.numpy() for o in tr])
-        if name == 'gtc_tt':
+        if name.startswith('gtc'):
             assert len(draws) == 4
             for j, d in enumerate(draws):
-                out[f'gtc_tt_field{j}'] = d.numpy()
+                out[f'{name}_field{j}'] = d.numpy()
         print(name, 'eval logit range', float(ev[0].min()), float(ev[0].max()))
     path = os.path.join(HERE, '..', 'tests', 'golden', 'variants_2x32x64.npz')
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path) // 1024, 'KiB')
+    json.dump(keys_out, open(os.path.join(HERE, '..', 'tests', 'golden', 'variants_keys.json'), 'w'))

@@ -74,7 +74,7 @@ def main(argv=None):
     dataset = EyeSetGenerator(dbname=args.db)
     factory = getattr(nets, args.net, None)
     if factory is None:
-        raise SystemExit(f'--net={args.net}: unknown network (available: stc_tt, tcct)')
+        raise SystemExit(f'--net={args.net}: unknown network (available: stc_tt / tcct, stc_tb, gtc_tt, gtc_tb, cnnu, pnnu, vitu)')
     net = factory(dataset.out_channels, compute_dtype=torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
     net = nets.RegNet(net, con=args.type_udh, out_channels=dataset.out_channels)
     keras = KiteSeg(model=net, dataset=dataset, root=args.root, args=args)

@@ -52,12 +52,17 @@ class CrossCNNBlock(nn.Module):
 
     def __init__(self, in_c, out_c, ksize):
         super().__init__()
+        ksize = self._ksize(ksize)
         self.block12 = nn.Sequential(nn.Conv2d(in_c, out_c, 3, padding=1), nn.Conv2d(out_c, out_c, 3, padding=1),
                                      nn.LeakyReLU(), nn.BatchNorm2d(out_c))
         self.block34 = nn.Sequential(nn.Conv2d(in_c, out_c, (1, ksize), padding=(0, ksize // 2)),
                                      nn.Conv2d(out_c, out_c, (ksize, 1), padding=(ksize // 2, 0)),
                                      nn.Conv2d(out_c, out_c, 3, padding=1), nn.LeakyReLU(), nn.BatchNorm2d(out_c))
         self.block5 = nn.Sequential(nn.Conv2d(out_c, out_c, 3, padding=1), nn.LeakyReLU(), nn.BatchNorm2d(out_c))
+
+    @staticmethod
+    def _ksize(ksize):
+        return ksize
 
     def forward(self, x):
         tr = self.training
@@ -77,20 +82,26 @@ class CrossCNNBlock(nn.Module):
         return _conv_bn(self.block5[0], self.block5[2], c, pre='lrelu')
 
 
+class PlainCNNBlock(CrossCNNBlock):
+    """reference nets/tcct.py:830-855: the same block with every cross convolution shrunk to 1x3 / 3x1 (pnnu)"""
+
+    @staticmethod
+    def _ksize(ksize):
+        return 3
+
+
 class CrossResNet(nn.Module):
-    """reference nets/tcct.py:857-885 (flag_tiny widths 32x5, ksizes 13/11/9/7/5)."""
+    """reference nets/tcct.py:857-885: widths 32x5 (flag_tiny, stc_tt) or 32-64-96-128-256 (stc_tb / gtc_tb), ksizes 13/11/9/7/5."""
     __name__ = 'crnet'
 
-    def __init__(self, in_ch=3, flag_tiny=True):
+    def __init__(self, in_ch=3, out_ch=6, flag_tiny=False, Block=CrossCNNBlock):
         super().__init__()
-        if not flag_tiny:
-            raise TcctError('only the flag_tiny=True CrossResNet of stc_tt is on the hot path')
-        layers = (32, 32, 32, 32, 32)
+        layers = (32, 32, 32, 32, 32) if flag_tiny else (32, 64, 96, 128, 256)
         self.layer_dims = layers
         self.pool = nn.MaxPool2d(kernel_size=2)
-        self.path_estan = nn.ModuleList([CrossCNNBlock(layers[0], layers[0], KSIZES[0])])
+        self.path_estan = nn.ModuleList([Block(layers[0], layers[0], KSIZES[0])])
         for i in range(len(layers) - 1):
-            self.path_estan.append(CrossCNNBlock(layers[i], layers[i + 1], KSIZES[i + 1]))
+            self.path_estan.append(Block(layers[i], layers[i + 1], KSIZES[i + 1]))
         self.cnn = nn.Sequential(nn.Conv2d(3, layers[0], 3, 1, 1), nn.BatchNorm2d(layers[0]))
 
     def forward(self, x, levels=None):
@@ -513,11 +524,26 @@ def stc_tt(n_class=8, **args):
 tcct = stc_tt
 
 
-def _variant(name, n_class, args, **flags):
-    model = FTC(base_vit=mpvit_tiny(), base_cnn=CrossResNet(flag_tiny=True), out_channels=n_class,
+def _variant(name, n_class, args, flag_tiny=True, Block=CrossCNNBlock, **flags):
+    model = FTC(base_vit=mpvit_tiny(), base_cnn=CrossResNet(flag_tiny=flag_tiny, Block=Block), out_channels=n_class,
                 compute_dtype=args.get('compute_dtype', torch.float32), **flags)
     model.__name__ = name
     return model
+
+
+def stc_tb(n_class=8, **args):
+    """reference nets/tcct.py:1097-1102: stc_tt with the wide CNN encoder (32-64-96-128-256)"""
+    return _variant('stctb', n_class, args, flag_tiny=False)
+
+
+def gtc_tb(n_class=8, **args):
+    """reference nets/tcct.py:1056-1061: GateFusion + wide CNN encoder"""
+    return _variant('gtctb', n_class, args, flag_tiny=False, flag_gate=True)
+
+
+def pnnu(n_class=8, **args):
+    """reference nets/tcct.py:1117-1122: cnnu with PlainCNNBlock (3-tap cross convolutions)"""
+    return _variant('pnnu', n_class, args, Block=PlainCNNBlock, flag_vit=False, flag_cnn=True)
 
 
 def gtc_tt(n_class=8, **args):

@@ -152,9 +152,12 @@ def _mfma32_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
 
 
 def _mfma_slabs_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
-    """32->64 / 64->32 / 64->64 bf16 3x3 'same' convolutions as 32x32 sub-GEMMs of the conv32 kernels (MPViT stem[1])"""
-    return (in_dt == torch.bfloat16 and out_dt == torch.bfloat16 and Cin == Cin_w and Cin in (32, 64) and Cout in (32, 64)
-            and (Cin, Cout) != (32, 32) and stride == 1 and KH == 3 and KW == 3 and padh == 1 and padw == 1)
+    """wider bf16 stride-1 'same' convolutions (3x3, 1xk, kx1 with channel counts that are multiples of 32) as 32x32 sub-GEMMs of the
+    conv32 kernels: MPViT stem[1] (32->64) and the wide CNN encoder of stc_tb / gtc_tb (32-64-96-128-256, nets/tcct.py:861-864)"""
+    return (in_dt == torch.bfloat16 and out_dt == torch.bfloat16 and Cin == Cin_w and Cin % 32 == 0 and Cout % 32 == 0
+            and 32 <= Cin <= 256 and 32 <= Cout <= 256 and (Cin, Cout) != (32, 32) and stride == 1
+            and 2 * padh == KH - 1 and 2 * padw == KW - 1 and KH * KW > 1 and max(KH, KW) <= 13
+            and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
 
 
 def _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, transposed):

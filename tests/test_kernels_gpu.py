@@ -36,7 +36,11 @@ def rnd(*shape, seed=0, dt=torch.float32):
     (32, 32, 9, 1, 1, 4, 0, 150, 20), (32, 32, 5, 1, 1, 2, 0, 64, 8), (32, 32, 1, 5, 1, 0, 2, 8, 64), (32, 32, 7, 1, 1, 3, 0, 33, 9),
     (32, 32, 1, 7, 1, 0, 3, 9, 33), (32, 32, 1, 1, 1, 0, 0, 19, 70), (64, 64, 1, 1, 1, 0, 0, 21, 33), (96, 32, 1, 1, 1, 0, 0, 9, 50),
     (192, 128, 1, 1, 1, 0, 0, 10, 17), (256, 160, 1, 1, 1, 0, 0, 7, 9), (64, 96, 1, 1, 1, 0, 0, 40, 55), (32, 64, 3, 3, 1, 1, 1, 19, 70), (64, 32, 3, 3, 1, 1, 1, 19, 70),
-    (64, 64, 3, 3, 1, 1, 1, 9, 40)])
+    (64, 64, 3, 3, 1, 1, 1, 9, 40),
+    # wide CNN encoder of stc_tb / gtc_tb (32-64-96-128-256): every kernel shape as 32x32 sub-GEMMs
+    (32, 64, 1, 11, 1, 0, 5, 12, 40), (64, 64, 11, 1, 1, 5, 0, 40, 12), (64, 96, 1, 9, 1, 0, 4, 9, 33), (96, 96, 9, 1, 1, 4, 0, 33, 9),
+    (96, 128, 3, 3, 1, 1, 1, 10, 14), (128, 128, 7, 1, 1, 3, 0, 20, 6), (128, 256, 1, 5, 1, 0, 2, 5, 9), (256, 256, 3, 3, 1, 1, 1, 4, 6),
+    (256, 128, 3, 3, 1, 1, 1, 6, 8)])
 def test_conv2d(dt, cfg):
     from tcct_amd import ops
     Cw, Co, KH, KW, s, ph, pw, H, W = cfg

@@ -317,17 +317,20 @@ def test_real_checkpoint_inference_matches_reference(name, dtype):
     assert len(np.unique(masks[0])) >= 4            # a real multi-layer segmentation, not a constant map
 
 
-@pytest.mark.parametrize('name', ['gtc_tt', 'cnnu', 'vitu'])
+@pytest.mark.parametrize('name', ['gtc_tt', 'cnnu', 'vitu', 'stc_tb', 'gtc_tb', 'pnnu'])
 def test_sibling_variants_match_reference(name, tmp_path):
-    """gtc_tt (GateFusion, eval), cnnu, vitu (reference nets/tcct.py:1048-1053,1120-1134): logits of all four heads vs the real
-    reference forward on formula weights (tests/golden/variants_2x32x64.npz, oracle/make_golden_variants.py); same state_dict keys"""
+    """gtc_tt / gtc_tb (GateFusion), stc_tb (wide CNN encoder), cnnu, pnnu, vitu (reference nets/tcct.py:1048-1061,1097-1102,
+    1117-1134): logits of all four heads vs the real reference forward on formula weights (tests/golden/variants_2x32x64.npz,
+    oracle/make_golden_variants.py); same state_dict keys and shapes"""
     import numpy as np
     import tcct_oracle as O
     from tcct_amd import nets
     from tcct_amd._lib import TcctError
     z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'variants_2x32x64.npz'))
     model = nets.RegNet(getattr(nets, name)(5), con='cos', out_channels=5)
-    ref_keys = {k: tuple(s) for k, s in json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'state_dict_keys.json')))}
+    gold = os.path.join(os.path.dirname(__file__), 'golden')
+    own_keys = json.load(open(os.path.join(gold, 'variants_keys.json')))       # variants whose parameter shapes differ from stc_tt's
+    ref_keys = {k: tuple(s) for k, s in (own_keys[name] if name in own_keys else json.load(open(os.path.join(gold, 'state_dict_keys.json'))))}
     assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == ref_keys
     model.load_state_dict(O.formula_state_dict(list(ref_keys.items())), strict=True)
     model = model.cuda()
@@ -340,12 +343,22 @@ def test_sibling_variants_match_reference(name, tmp_path):
         e = relerr(ev[i], torch.from_numpy(z[f'{name}_eval'][i]))
         assert e < 1e-3, (name, 'eval head', i, e)
     model.train()
-    if name == 'gtc_tt':        # the reference's four torch.rand alpha fields (NCHW) are inputs
-        model.base.forced_gate_fields = [torch.from_numpy(z[f'gtc_tt_field{j}']).permute(0, 2, 3, 1).contiguous() for j in range(4)]
+    if name.startswith('gtc'):  # the reference's four torch.rand alpha fields (NCHW) are inputs
+        model.base.forced_gate_fields = [torch.from_numpy(z[f'{name}_field{j}']).permute(0, 2, 3, 1).contiguous() for j in range(4)]
     with torch.no_grad():
         tr = model(x)
     e0 = relerr(tr[0], torch.from_numpy(z[f'{name}_train'][0]))
-    assert e0 < 1e-3, (name, 'train head 0', e0)
+    # wide encoder: 256 BatchNorm channels over 2x2x4 = 16 samples at level 4.  The reference's own fp32 result moves by 7e-4 when the
+    # input is scaled by (1 + 1e-6) in channels_last and sits 3.6e-4 from the fp64 evaluation of the same graph (measured with the
+    # oracle, which is bit-identical to the reference here), so two fp32 implementations agree to ~2x that; eval mode keeps 1e-3.
+    assert e0 < (3e-3 if name in ('stc_tb', 'gtc_tb') else 1e-3), (name, 'train head 0', e0)
+    if name in own_keys:        # bf16 mode takes other kernels (the wide convolutions run as 32x32 MFMA sub-GEMMs): loose bound
+        model.base.set_compute_dtype(torch.bfloat16)
+        model.eval()
+        with torch.no_grad():
+            eb = relerr(model(x)[0], torch.from_numpy(z[f'{name}_eval'][0]))
+        assert eb < 0.03, (name, 'bf16 eval head 0', eb)
+        model.train()
     # and the variant trains: loss decreases over a few steps of the fused optimizer
     k = make_kite(model, tmp_path, False, False)
     for g in k.optimG.param_groups:
