@@ -158,6 +158,10 @@ int tcct_conv32_fwd_affine(const void* x, const void* wp, const float* bias, voi
                            int PH, int PW, const float* ab, int pre_act, int post_act, tcct_stream_t stream);
 int tcct_pw_fwd_affine(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, const float* ab,
                        int pre_act, int post_act, int out_dtype, tcct_stream_t stream);
+/* y = conv(x) + bias + res, res bf16 NHWC [N,H,W,32] (not overlapping y): used as the input gradient of a convolution whose input has
+ * a second consumer (CrossCNNBlock: x feeds block12 and block34, nets/tcct.py:826) -- no separate gradient accumulation pass */
+int tcct_conv32_fwd_add(const void* x, const void* wp, const float* bias, const void* res, void* y, int N, int H, int W, int KH, int KW,
+                        int PH, int PW, tcct_stream_t stream);
 /* the same kernels on 32-channel slabs of wider NHWC tensors (x: xs channels/pixel, slab at xo; y: ys, yo; accumulate adds
  * into y) and on 32x32 sub-blocks (o_off, i_off) of an OIHW weight with cin_total input channels: 32->64 / 64->32 convolutions
  * (MPViT stem[1], nets/tcct.py:682-689) run as 32x32 sub-GEMMs.  wgrad_strided ACCUMULATES: zero dw/dbias first. */
@@ -221,6 +225,10 @@ int tcct_metapool_scaled_bwd(const void* dy, const float* scale, void* dx, int B
 /* ---- nn.MaxPool2d(2) (nets/tcct.py:867,883); even H, W ---------------------------------------------------- */
 int tcct_maxpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, tcct_stream_t stream);
 int tcct_maxpool2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int dtype, tcct_stream_t stream);
+/* dx = maxpool_bwd(dy) + res: res [N,H,W,C] is the gradient reaching x through its other consumers (c_i also feeds tran_cnn / the
+ * decoder skip, tcct.py:1012-1031), folded into the scatter pass instead of a separate accumulation pass */
+int tcct_maxpool2_bwd_add(const void* x, const void* dy, const void* res, void* dx, int N, int H, int W, int C, int dtype,
+                          tcct_stream_t stream);
 /* ---- bilinear resize: nn.Upsample(x2, align_corners=True) (tcct.py:890) and F.interpolate(size, align_corners=False)
  * (tcct.py:941,1042-1044).  bwd: dy [N,Ho,Wo,C] -> dx [N,H,W,C], gather form (no atomics) ------------------ */
 int tcct_bilinear_fwd(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int align_corners, int dtype,

@@ -57,8 +57,10 @@ template <bool VERT, int STATS, int KH_, int KW_>      // STATS: 0 none, 1 stats
 __global__ void __launch_bounds__(MB, 2)
 k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
               int N, int H, int W, int KHr, int KWr, int PH, int PW, int tilesH, int tilesW, int ntiles, int xs, int xo, int ys,
-              int yo, int accum, double* __restrict__ stats, int stat_pre, const float* __restrict__ aff, int aff_post) {
-    // xs/xo, ys/yo: channels per pixel in memory and channel offset of the 32-channel slab read / written; accum: y += result
+              int yo, int accum, double* __restrict__ stats, int stat_pre, const float* __restrict__ aff, int aff_post,
+              const bf16* yadd) {
+    // xs/xo, ys/yo: channels per pixel in memory and channel offset of the 32-channel slab read / written; accum: y = result + yadd
+    // (yadd == NULL: + the previous contents of y; same layout as y)
     // stats != NULL (STATS): also accumulate per-channel sum / sum-of-squares of pre_act(y) (y as stored, i.e. bf16-rounded) into
     // stats[0..31] / stats[32..63] -- the train-mode BatchNorm statistics of the consumer, fused into this epilogue
     // tile: 16 M-tiles of 32 pixels.  1xk: 8 rows x 64; kx1: 64 x 8 (column-major image); 3x3: 16 rows x 32 -- a squarer tile reads a
@@ -202,7 +204,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
                 int ho = VERT ? h0 + seg * 32 + r : h0 + a;
                 int wo = VERT ? w0 + a : w0 + seg * 32 + r;
                 const bool inb = ho < H && wo < W;
-                const bf16* yold = y + (((int64_t)n * H + (inb ? ho : 0)) * W + (inb ? wo : 0)) * ys + yo + 4 * hh;
+                const bf16* yold = (yadd ? yadd : y) + (((int64_t)n * H + (inb ? ho : 0)) * W + (inb ? wo : 0)) * ys + yo + 4 * hh;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 bq = *reinterpret_cast<const float4*>(sB + 8 * q + 4 * hh);
@@ -274,7 +276,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
  * size requires PH = (KH-1)/2 etc. but any PH <= KH-1, PW <= KW-1 with "same" output extent H x W is accepted. */
 static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
                            int PH, int PW, int xs, int xo, int ys, int yo, int accum, double* stats, int stat_pre, tcct_stream_t stream,
-                           const float* aff = nullptr, int aff_post = 0, bool affine = false);
+                           const float* aff = nullptr, int aff_post = 0, bool affine = false, const void* yadd = nullptr);
 extern "C" int tcct_conv32_fwd(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
                                int PH, int PW, tcct_stream_t stream) {
     return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, 0, nullptr, 0, stream);
@@ -291,6 +293,13 @@ extern "C" int tcct_conv32_fwd_affine(const void* x, const void* wp, const float
                                       int PH, int PW, const float* ab, int pre_act, int post_act, tcct_stream_t stream) {
     return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, 0, nullptr, pre_act, stream, ab, post_act, true);
 }
+/* y = conv(x) + bias + res (res: bf16 NHWC [N,H,W,32], may not overlap y): the input gradient of a convolution whose input has a
+ * second consumer -- that consumer's gradient is added in this epilogue instead of in a separate accumulation pass */
+extern "C" int tcct_conv32_fwd_add(const void* x, const void* wp, const float* bias, const void* res, void* y, int N, int H, int W,
+                                   int KH, int KW, int PH, int PW, tcct_stream_t stream) {
+    TCCT_CHECK(res != nullptr && res != y, "conv32_fwd_add: res must be a separate tensor");
+    return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, 1, nullptr, 0, stream, nullptr, 0, false, res);
+}
 /* same kernel on 32-channel slabs of wider tensors: x has xs channels/pixel (slab at xo), y has ys (slab at yo); accumulate=1
  * adds into y.  Used to run 32->64 / 64->32 convolutions (MPViT stem[1], nets/tcct.py:682-689) as 32x32 sub-GEMMs. */
 extern "C" int tcct_conv32_fwd_strided(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH,
@@ -301,7 +310,7 @@ extern "C" int tcct_conv32_fwd_strided(const void* x, const void* wp, const floa
 }
 static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
                            int PH, int PW, int xs, int xo, int ys, int yo, int accum, double* stats, int stat_pre, tcct_stream_t stream,
-                           const float* aff, int aff_post, bool affine) {
+                           const float* aff, int aff_post, bool affine, const void* yadd) {
     TCCT_CHECK(KH >= 1 && KW >= 1 && KH * KW <= 13 * 13, "conv32_fwd: bad kernel %dx%d", KH, KW);
     TCCT_CHECK(2 * PH == KH - 1 && 2 * PW == KW - 1, "conv32_fwd: only 'same' padding (got pad %d,%d for %dx%d)", PH, PW, KH, KW);
     const bool vert = (KW == 1 && KH > 1);
@@ -322,7 +331,7 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
         static bool attr = false;                                                                                           \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_mfma<V, S, KHT, KWT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
         hipLaunchKernelGGL((k_conv32_mfma<V, S, KHT, KWT>), dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, \
-                           KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum, stats, stat_pre, aff, aff_post);                \
+                           KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum, stats, stat_pre, aff, aff_post, (const bf16*)yadd);                \
     } while (0)
 #define CF_S(V, KHT, KWT)                                                                                   \
     do {                                                                                                    \

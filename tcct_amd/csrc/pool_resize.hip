@@ -99,7 +99,10 @@ extern "C" int tcct_metapool_scaled_bwd(const void* dy, const float* scale, void
 // ------------------------------------------------------------------------------------------ MaxPool2d(2)
 // grid.y strides over output rows (n, ho); threads of a row cover (wo, channel vector): 32-bit index arithmetic only
 template <typename T, bool BWD>
-__global__ void k_maxpool2(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, int N, int H, int W, int C) {
+__global__ void k_maxpool2(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, int N, int H, int W, int C,
+                           const T* __restrict__ res) {
+    // BWD with res != NULL: dx = scatter(dy) + res -- the gradient that reaches x through its other consumers (the encoder level
+    // also feeds the fusion / decoder skip, tcct.py:880-883,1012-1031) is added here instead of in a separate pass
     const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Wo * C4) return;
@@ -127,6 +130,11 @@ __global__ void k_maxpool2(const T* __restrict__ x, const T* __restrict__ dy, T*
                 f4 o;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o.v[k] = am[k] == q ? g.v[k] : 0.f;
+                if (res) {
+                    const f4 rv = ld4(res + offs[q]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o.v[k] += rv.v[k];
+                }
                 st4(out + offs[q], o);
             }
         }
@@ -144,12 +152,19 @@ static inline dim3 row_grid(int per_row, int64_t rows, int target_blocks = 8192)
 }
 extern "C" int tcct_maxpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2 && N >= 1, "maxpool2_fwd: needs C%%4==0 and even H,W (got %d,%d,%d)", C, H, W);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_maxpool2<T, false>), row_grid((W / 2) * (C / 4), (int64_t)N * (H / 2), 1 << 22), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, (T*)y, N, H, W, C));
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_maxpool2<T, false>), row_grid((W / 2) * (C / 4), (int64_t)N * (H / 2), 1 << 22), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, (T*)y, N, H, W, C, (const T*)nullptr));
     TCCT_LAUNCH_OK();
 }
 extern "C" int tcct_maxpool2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2 && N >= 1, "maxpool2_bwd: needs C%%4==0 and even H,W (got %d,%d,%d)", C, H, W);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_maxpool2<T, true>), row_grid((W / 2) * (C / 4), (int64_t)N * (H / 2), 1 << 22), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, N, H, W, C));
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_maxpool2<T, true>), row_grid((W / 2) * (C / 4), (int64_t)N * (H / 2), 1 << 22), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, N, H, W, C, (const T*)nullptr));
+    TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_maxpool2_bwd_add(const void* x, const void* dy, const void* res, void* dx, int N, int H, int W, int C, int dtype,
+                                     tcct_stream_t stream) {
+    TCCT_CHECK(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2 && N >= 1, "maxpool2_bwd_add: needs C%%4==0 and even H,W (got %d,%d,%d)", C, H, W);
+    TCCT_CHECK(res != nullptr, "maxpool2_bwd_add: res is NULL");
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_maxpool2<T, true>), row_grid((W / 2) * (C / 4), (int64_t)N * (H / 2), 1 << 22), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, N, H, W, C, (const T*)res));
     TCCT_LAUNCH_OK();
 }
 

@@ -66,8 +66,10 @@ class CrossCNNBlock(nn.Module):
 
     def forward(self, x):
         tr = self.training
-        a = _conv(self.block12[1], _conv(self.block12[0], x), stats_pre='lrelu' if tr else None)
-        b = _conv(self.block34[2], _conv(self.block34[1], _conv(self.block34[0], x)), stats_pre='lrelu' if tr else None)
+        m0 = self.block12[0]       # x feeds both branches: block34 reads the alias, its gradient is added in block12[0]'s dgrad epilogue
+        a0, x2 = ops.conv2d_fork(x, m0.weight, m0.bias, m0.stride[0], tuple(m0.padding))
+        a = _conv(self.block12[1], a0, stats_pre='lrelu' if tr else None)
+        b = _conv(self.block34[2], _conv(self.block34[1], _conv(self.block34[0], x2)), stats_pre='lrelu' if tr else None)
         if tr:      # fused junction: gelu(BN(lrelu(a)) + BN(lrelu(b))) in one pass over a, b (and one fused backward)
             m1, m2 = self.block12[3], self.block34[4]
             c = ops.bn2_add_act(a, (m1.weight, m1.bias, m1.running_mean, m1.running_var, m1.num_batches_tracked, m1.eps, m1.momentum),
@@ -115,9 +117,11 @@ class CrossResNet(nn.Module):
         n = len(self.path_estan) if levels is None else int(levels)
         for i, enc in enumerate(self.path_estan[:n]):
             x = enc(x)
-            xs.append(x)
             if i + 1 < n:               # the reference also pools after the last level; that result is unused
-                x = ops.maxpool2(x)
+                x, skip = ops.maxpool2_fork(x)      # skip aliases the level's output: its gradient is added inside the pooling backward
+                xs.append(skip)
+            else:
+                xs.append(x)
         return xs
 
 

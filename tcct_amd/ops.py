@@ -184,7 +184,9 @@ def _pw_ok(in_dt, Cin, Cin_w, KH, KW, stride, padh, padw):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, padh, padw, out_dtype, stats_box):
+    def forward(ctx, x, w, bias, stride, padh, padw, out_dtype, stats_box, fork=False):
+        """fork: also return an alias of x for the OTHER consumers of x -- their gradient then arrives in backward() and is added
+        inside the input-gradient kernel's epilogue (tcct_conv32_fwd_add) instead of by an autograd accumulation pass"""
         _chk(x, w, bias)
         N, H, W, Cin = x.shape
         Cout, Cin_w, KH, KW = w.shape
@@ -219,14 +221,18 @@ class _Conv2d(torch.autograd.Function):
         # gradient destinations: w may be a view of the nn.Linear weight (conv2d wrapper) -> look through ._base
         wsrc = w if hasattr(w, '_grad_slot') or w._base is None else w._base
         ctx.params = (wsrc, bias)
-        return y
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, w = ctx.saved_tensors
         stride, padh, padw, has_bias = ctx.cfg
         wsrc, bsrc = ctx.params
+        if dy is None:          # only the alias was used downstream
+            return dskip, None, None, None, None, None, None, None, None
         dy = _c(dy)
+        if dskip is not None:
+            dskip = _as(dskip, x.dtype)
         N, H, W, Cin = x.shape
         Cout, Cin_w, KH, KW = w.shape
         dx = dw = db = None
@@ -242,9 +248,19 @@ class _Conv2d(torch.autograd.Function):
             elif _mfma32_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
                 wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
                 lib.conv32_pack_weights(w, wp, KH, KW, 1)
-                lib.conv32_fwd(dy, wp, None, dx, N, H, W, KH, KW, KH - 1 - padh, KW - 1 - padw)
+                if dskip is not None:
+                    lib.conv32_fwd_add(dy, wp, None, dskip, dx, N, H, W, KH, KW, KH - 1 - padh, KW - 1 - padw)
+                    dskip = None
+                else:
+                    lib.conv32_fwd(dy, wp, None, dx, N, H, W, KH, KW, KH - 1 - padh, KW - 1 - padw)
             else:
                 lib.conv2d_dgrad(dy, w, dx, N, H, W, Cin, Cout, KH, KW, padh, padw, dtype_code(dy.dtype), dtype_code(x.dtype))
+            if dskip is not None:       # kernels without the fused epilogue: one explicit pass
+                tot = torch.empty_like(dx)
+                lib.add(dx, dskip, tot, tot.numel(), dtype_code(tot.dtype))
+                dx = tot
+        elif dskip is not None:
+            dx = dskip
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             with _wgrad_stream(_slot_written(wsrc, bsrc if has_bias else None), x, dy):
                 dw = _grad_out(wsrc, tuple(w.shape))
@@ -269,7 +285,15 @@ class _Conv2d(torch.autograd.Function):
                 else:
                     lib.conv2d_wgrad(x, dy, dw, db, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
                                      dtype_code(dy.dtype))
-        return dx, _ret(dw, wsrc), _ret(db, bsrc), None, None, None, None, None
+        return dx, _ret(dw, wsrc), _ret(db, bsrc), None, None, None, None, None, None
+
+
+def conv2d_fork(x, w, bias=None, stride=1, pad=0):
+    """(conv2d(x), x'): x' aliases x and is to be read by the other consumers of x (see _Conv2d.forward `fork`)"""
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return conv2d(x, w, bias, stride, pad), x
+    return _Conv2d.apply(x, w, bias, stride, ph, pw, None, None, True)
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, out_dtype=None, stats_pre=None):
@@ -283,7 +307,7 @@ def conv2d(x, w, bias=None, stride=1, pad=0, out_dtype=None, stats_pre=None):
     if w.dim() == 2:
         w = w.view(w.shape[0], w.shape[1], 1, 1)
     box = [ACT[stats_pre], None] if stats_pre is not None else None
-    y = _Conv2d.apply(x, w, bias, stride, ph, pw, out_dtype, box)
+    y = _Conv2d.apply(x, w, bias, stride, ph, pw, out_dtype, box, False)
     if tok:
         y = y.squeeze(2)
     if box is not None and box[1] is not None:
@@ -964,8 +988,43 @@ class _MaxPool2(torch.autograd.Function):
         return dx
 
 
+class _MaxPool2Fork(torch.autograd.Function):
+    """(maxpool2(x), x): the second output aliases x and is what the OTHER consumers of x read, so that in the backward pass their
+    gradient arrives here and is added inside the pooling scatter kernel (autograd would otherwise run an accumulation pass)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        N, H, W, C = x.shape
+        y = torch.empty((N, H // 2, W // 2, C), device=x.device, dtype=x.dtype)
+        lib.maxpool2_fwd(x, y, N, H, W, C, dtype_code(x.dtype))
+        ctx.save_for_backward(x)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        (x,) = ctx.saved_tensors
+        N, H, W, C = x.shape
+        if dy is None:
+            return dskip
+        dy = _as(dy, x.dtype)
+        dx = torch.empty_like(x)
+        if dskip is None:
+            lib.maxpool2_bwd(x, dy, dx, N, H, W, C, dtype_code(x.dtype))
+        else:
+            lib.maxpool2_bwd_add(x, dy, _as(dskip, x.dtype), dx, N, H, W, C, dtype_code(x.dtype))
+        return dx
+
+
 def maxpool2(x):
     return _MaxPool2.apply(x)
+
+
+def maxpool2_fork(x):
+    """(maxpool2(x), x'): use x' (an alias of x) for every other consumer of x; see _MaxPool2Fork"""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return _MaxPool2.apply(x), x
+    return _MaxPool2Fork.apply(x)
 
 
 class _Bilinear(torch.autograd.Function):

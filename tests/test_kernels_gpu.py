@@ -649,3 +649,49 @@ def test_gate_fusion_training_branch(dt, shape):
     yd.backward(nhwc(gy, dt))
     torch.testing.assert_close(nchw(a.grad), x1.grad, **t)
     torch.testing.assert_close(nchw(b.grad), x2.grad, **t)
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('cfg', [(32, 32, 3, 3, 20, 46), (32, 32, 1, 7, 10, 34), (32, 64, 3, 3, 10, 12), (16, 16, 3, 3, 8, 8)])
+def test_forked_consumers_fold_the_gradient_accumulation(dt, cfg):
+    """a tensor with two consumers (CrossCNNBlock input -> block12 / block34, encoder level -> maxpool / skip; nets/tcct.py:826,880-883):
+    conv2d_fork / maxpool2_fork hand the second consumer an alias and add its gradient inside their own backward kernel
+    (tcct_conv32_fwd_add, tcct_maxpool2_bwd_add); result and gradients equal the plain two-consumer graph"""
+    from tcct_amd import ops
+    Ci, Co, KH, KW, H, W = cfg
+    N = 2
+    x = rnd(N, Ci, H, W, dt=dt).requires_grad_(True)
+    w = (rnd(Co, Ci, KH, KW, seed=1) / (Ci * KH * KW) ** 0.5).requires_grad_(True)
+    b = rnd(Co, seed=2).requires_grad_(True)
+    y = F.conv2d(x, w, b, 1, (KH // 2, KW // 2))
+    p = F.max_pool2d(x, 2)
+    other = x * x * 0.5                     # the second consumer (gradient x * g)
+    gy, gp, go = rnd(*y.shape, seed=3, dt=dt), rnd(*p.shape, seed=4, dt=dt), rnd(*x.shape, seed=5, dt=dt)
+    ((y * gy).sum() + (other * go).sum()).backward()
+    gx_conv = x.grad.clone()
+    x.grad = None
+    ((p * gp).sum() + (x * x * 0.5 * go).sum()).backward()
+    gx_pool = x.grad.clone()
+    t = tol(dt)
+    # convolution fork
+    xd = nhwc(x.detach(), dt).requires_grad_(True)
+    wd, bd = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    yd, alias = ops.conv2d_fork(xd, wd, bd, 1, (KH // 2, KW // 2))
+    assert alias.data_ptr() == xd.data_ptr()
+    torch.testing.assert_close(nchw(yd), y.detach(), **t)
+    od = alias.float() * alias.float()
+    ((yd.float() * nhwc(gy, torch.float32)).sum() + (od.float() * 0.5 * nhwc(go, torch.float32)).sum()).backward()
+    torch.testing.assert_close(nchw(xd.grad), gx_conv, rtol=t['rtol'], atol=t['atol'] * 2)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, w.grad.abs().max().item()))
+    # pooling fork
+    xd = nhwc(x.detach(), dt).requires_grad_(True)
+    pd, alias = ops.maxpool2_fork(xd)
+    torch.testing.assert_close(nchw(pd), p.detach(), **t)
+    od = alias.float() * alias.float()
+    ((pd.float() * nhwc(gp, torch.float32)).sum() + (od * 0.5 * nhwc(go, torch.float32)).sum()).backward()
+    torch.testing.assert_close(nchw(xd.grad), gx_pool, rtol=t['rtol'], atol=t['atol'] * 2)
+    # alias unused / pooled output unused: plain gradients
+    xd = nhwc(x.detach(), dt).requires_grad_(True)
+    pd, alias = ops.maxpool2_fork(xd)
+    (alias.float() * nhwc(go, torch.float32)).sum().backward()
+    torch.testing.assert_close(nchw(xd.grad), go, **t)

@@ -9,6 +9,9 @@ TCCT_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TA
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_roof -o roof -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $OUT/${TAG}_roof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -o fetch -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $OUT/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -o write -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $OUT/${TAG}_write.log 2>&1
+# MFMA utilisation of the same loops (secondary evidence): busy cycles of the matrix pipes vs the GPU-active cycles
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_mfma -o mfma -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $OUT/${TAG}_mfma.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/${TAG}_sq -o sq -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $OUT/${TAG}_sq.log 2>&1
 cd $GRAFT_REPO_ROOT
 python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-roofline --los=di+reg+fpl > $OUT/${TAG}_bench_fullloss.json 2>> $OUT/${TAG}_bench.err
@@ -17,4 +20,4 @@ python tools/infer_bench.py > $OUT/${TAG}_infer.txt 2>> $OUT/${TAG}_bench.err
 python tools/infer_bench.py --bs 1 >> $OUT/${TAG}_infer.txt 2>> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
 # keep only the small summaries
-find $OUT/${TAG}_step $OUT/${TAG}_roof $OUT/${TAG}_fetch $OUT/${TAG}_write -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null
+find $OUT/${TAG}_step $OUT/${TAG}_roof $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_mfma $OUT/${TAG}_sq -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null

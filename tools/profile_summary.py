@@ -59,6 +59,31 @@ for r in roof:
             f = pm['fetch'].get(r['Name']); w = pm['write'].get(r['Name'])
             hbm = (2 * f + w) * 1024 / 1e6
             L.append(f'| `{r["Name"].split("(")[0]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e3:.1f} | {f:.1f} | {w:.1f} | {hbm:.1f} | {a:.1f} | {hbm / a:.2f} |')
+def pmc_table(kind):
+    """kernel -> counter -> mean per launch, from a rocprofv3 --pmc pass (None if the pass is missing)"""
+    path = f'{G}/{tag}_{kind}/{kind}_counter_collection.csv'
+    if not os.path.exists(path):
+        return None
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        d[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in d.items()}
+mf, sq = pmc_table('mfma'), pmc_table('sq')
+if mf:
+    L.append('\n### matrix-pipe occupancy of the same loops — `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` and `--pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY`\n')
+    L.append('MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs) (the gfx94x `MfmaUtil` formula; ROCm 7.2 ships no gfx950 derived metrics). '
+             'These kernels are HBM-bound (SURVEY 8(d)): the matrix pipes are idle most of the time by construction; the wave-cycle split shows where waves wait.\n')
+    L.append('| kernel | MFMA busy cycles | GUI active cycles | MFMA busy % | wave cycles: waiting (s_waitcnt/barrier) % | issue-stalled % | issuing % |\n|---|---|---|---|---|---|---|')
+    for r in roof:
+        if any(key + '<' in r['Name'] for key in alg):
+            m = mf.get(r['Name'])
+            if not m:
+                continue
+            busy, act = m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0), m.get('GRBM_GUI_ACTIVE', 0.0)
+            q = (sq or {}).get(r['Name'], {})
+            wc = q.get('SQ_WAVE_CYCLES', 0.0)
+            pct = lambda v: f'{100 * v / wc:.1f}' if wc else '-'
+            L.append(f'| `{r["Name"].split("(")[0]}` | {busy:.3g} | {act:.3g} | {100 * busy / (act * 1024) if act else 0:.1f} | {pct(q.get("SQ_WAIT_ANY", 0))} | {pct(q.get("SQ_WAIT_INST_ANY", 0))} | {pct(q.get("SQ_ACTIVE_INST_ANY", 0))} |')
 L.append(f'\nbench.py\'s own HIP-event timing of the same loops (un-profiled run): `roofline.ms_per_launch` = {b["roofline"]["ms_per_launch"]} ms '
          f'({b["roofline"]["achieved"]} GB/s algorithmic, frac {b["roofline"]["frac"]}), second = {b["roofline"]["second"]["ms_per_launch"]} ms, '
          f'others = {[(o["kernel"], o["ms_per_launch"]) for o in b["roofline"].get("others", [])]}.')
