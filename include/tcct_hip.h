@@ -124,6 +124,9 @@ int tcct_layernorm_fwd(const void* x, void* y, int64_t M, int C, const float* ga
                        float* mean_rstd /*[M,2]*/, int dtype, tcct_stream_t stream);
 int tcct_layernorm_bwd(const void* x, const void* dy, void* dx, int64_t M, int C, const float* gamma,
                        const float* mean_rstd, float* dgamma, float* dbeta, int dtype, tcct_stream_t stream);
+/* dx = LN_bwd(dy) + res, res [M,C]: gradient of the residual path around the normalisation (x + f(LN(x)), tcct.py:461-468) */
+int tcct_layernorm_bwd_add(const void* x, const void* dy, const void* res, void* dx, int64_t M, int C, const float* gamma,
+                           const float* mean_rstd, float* dgamma, float* dbeta, int dtype, tcct_stream_t stream);
 
 /* ---- dense conv2d / nn.Linear (nets/tcct.py:41-43,72,124,809-821,873,892,897,966-997) ------------------- */
 /* x [N,H,W,Cin] (Cin % 4 == 0; weight input channels Cin_w <= Cin, extra channels ignored),
@@ -187,6 +190,10 @@ int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_
  * `post` convolution whose output feeds both the next stage and `x_i + y_i` (nets/tcct.py:1028-1031) */
 int tcct_pw_fwd_residual(const void* x, const float* w, const float* bias, const void* res, const float* scale, int64_t per_sample,
                          void* y, void* y_plain, int64_t M, int K, int N, tcct_stream_t stream);
+/* input gradient with a second gradient folded in: dx_plain = dy W, dx_sum = dy W + res (w [Nout,K] as stored; res, dx_* [M,K] bf16):
+ * backward of the decoder block tail (MPUpBlock, tcct.py:908-914): dx_plain continues into the resize, dx_sum is the skip's gradient */
+int tcct_pw_dgrad_residual(const void* dy, const float* w, const void* res, void* dx_sum, void* dx_plain, int64_t M, int Nout, int K,
+                           tcct_stream_t stream);
 /* Concatenation-free pointwise convolution over [x1 | x2] (MHCA_stage.aggregate, nets/tcct.py:600-616): forward (+ optional fused
  * BN statistics), input gradient written to two tensors, weight gradient -- the channel concatenation is never materialised */
 int tcct_pw_fwd_cat2(const void* x1, const void* x2, int K1, const float* w, const float* bias, void* y, int64_t M, int K, int N,

@@ -383,7 +383,8 @@ extern "C" int tcct_layernorm_fwd(const void* x, void* y, int64_t M, int C, cons
 template <typename T>
 __global__ void __launch_bounds__(NBR) k_ln_bwd(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t M, int C,
                          const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
-                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                         float* __restrict__ dgamma, float* __restrict__ dbeta, const T* __restrict__ res) {
+    // res != NULL: dx = LN_bwd(dy) + res -- the gradient of the residual path around the normalisation (x + f(LN(x)), tcct.py:461-468)
     __shared__ float swv[(NBR / 64) * 384];         // per wave: dgamma partials [192], dbeta partials [192]
     const int C4 = C >> 2;
     const int lane = threadIdx.x & 15;
@@ -423,6 +424,11 @@ __global__ void __launch_bounds__(NBR) k_ln_bwd(const T* __restrict__ x, const T
                 f4 r;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) r.v[k] = rstd * (g[j].v[k] - s1 - xh[j].v[k] * s2);
+                if (res) {
+                    const f4 rv = ld4(res + m * C + ch * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r.v[k] += rv.v[k];
+                }
                 st4(dx + m * C + ch * 4, r);
             }
         }
@@ -448,15 +454,27 @@ __global__ void __launch_bounds__(NBR) k_ln_bwd(const T* __restrict__ x, const T
         atomicAdd(&dgamma[c], a); atomicAdd(&dbeta[c], b);
     }
 }
+static int layernorm_bwd_impl(const void* x, const void* dy, void* dx, int64_t M, int C, const float* gamma, const float* mean_rstd,
+                              float* dgamma, float* dbeta, int dtype, tcct_stream_t stream, const void* res);
 extern "C" int tcct_layernorm_bwd(const void* x, const void* dy, void* dx, int64_t M, int C, const float* gamma,
                                   const float* mean_rstd, float* dgamma, float* dbeta, int dtype, tcct_stream_t stream) {
+    return layernorm_bwd_impl(x, dy, dx, M, C, gamma, mean_rstd, dgamma, dbeta, dtype, stream, nullptr);
+}
+/* dx = LN_bwd(dy) + res: res [M,C] is the gradient of the residual path around the normalisation, added in the same pass */
+extern "C" int tcct_layernorm_bwd_add(const void* x, const void* dy, const void* res, void* dx, int64_t M, int C, const float* gamma,
+                                      const float* mean_rstd, float* dgamma, float* dbeta, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(res != nullptr, "layernorm_bwd_add: res is NULL");
+    return layernorm_bwd_impl(x, dy, dx, M, C, gamma, mean_rstd, dgamma, dbeta, dtype, stream, res);
+}
+static int layernorm_bwd_impl(const void* x, const void* dy, void* dx, int64_t M, int C, const float* gamma, const float* mean_rstd,
+                              float* dgamma, float* dbeta, int dtype, tcct_stream_t stream, const void* res) {
     TCCT_CHECK(C % 4 == 0 && C <= 64 * LN_MAXCH, "layernorm_bwd: C=%d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess)) {
         tcct_set_error("layernorm_bwd: memset failed"); return -2;
     }
     TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_ln_bwd<T>, dim3(tcct_grid(M * 16, NBR, 512)), dim3(NBR), 0, st, (const T*)x,
-                                            (const T*)dy, (T*)dx, M, C, gamma, mean_rstd, dgamma, dbeta));
+                                            (const T*)dy, (T*)dx, M, C, gamma, mean_rstd, dgamma, dbeta, (const T*)res));
     TCCT_LAUNCH_OK();
 }
 

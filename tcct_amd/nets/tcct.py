@@ -232,9 +232,10 @@ class MHCABlock(nn.Module):
         x = _dw(self.cpe.proj, x, add_input=True)
         t = x.view(B, H * W, C)
         s1, s2 = scales if scales is not None else (None, None)
-        cur = ops.layernorm(t, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        # (the residual paths read aliases of t: their gradients are added inside the LayerNorm backward kernels)
+        cur, t = ops.layernorm_fork(t, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         t = ops.metapool_residual(cur, t, s1)           # t + dp(pool(LN1 t)): mixer, DropPath scale and residual in one pass
-        cur = ops.layernorm(t, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        cur, t = ops.layernorm_fork(t, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
             h = ops.act(ops.conv2d(cur, self.mlp.fc1.weight, self.mlp.fc1.bias), 'gelu')
         else:               # inference: GELU in the GEMM epilogue
@@ -376,9 +377,9 @@ class MPUpBlock(nn.Module):
     def forward(self, x1, x2, with_sum=False):
         """with_sum: also return x2 + output (the `x_i + y_i` of FTC.forward, tcct.py:1028-1031) from the same GEMM epilogue"""
         y = _conv_bn(self.prep[0], self.prep[1], x1, post='lrelu')
-        u = ops.bilinear(y, (x1.shape[1] * 2, x1.shape[2] * 2), True, residual=x2)
         if with_sum:
-            return ops.conv1x1_and_sum(u, self.post[0].weight, self.post[0].bias, x2)
+            return ops.up_skip_conv(y, x2, self.post[0].weight, self.post[0].bias, True)
+        u = ops.bilinear(y, (x1.shape[1] * 2, x1.shape[2] * 2), True, residual=x2)
         return _conv(self.post[0], u)
 
 

@@ -480,6 +480,67 @@ class _Conv1x1AndSum(torch.autograd.Function):
         return dx, _ret(dw, wsrc), _ret(db, bsrc), (None if gs is None else _c(gs))
 
 
+class _UpSkipConv(torch.autograd.Function):
+    """decoder block tail (MPUpBlock, reference tcct.py:908-914 + the `x_i + y_i` of FTC.forward :1028-1031) as one node:
+         u = resize_x2(y) + skip;  d = conv1x1(u);  s = d + skip        -> (d, s)
+    One node instead of bilinear + conv1x1_and_sum so that the skip tensor's two gradients (through u and through s) leave the
+    input-gradient GEMM already summed (tcct_pw_dgrad_residual) -- autograd would otherwise add them in a separate pass."""
+
+    @staticmethod
+    def forward(ctx, y, skip, w, bias, align):
+        _chk(y, skip, w, bias)
+        N_, H, W_, C = y.shape
+        _, Ho, Wo, _ = skip.shape
+        Cout = w.shape[0]
+        u = torch.empty_like(skip)
+        lib.bilinear_add_fwd(y, skip, u, N_, H, W_, C, Ho, Wo, int(align), dtype_code(y.dtype))
+        d = torch.empty((N_, Ho, Wo, Cout), device=y.device, dtype=y.dtype)
+        s_ = torch.empty_like(d)
+        lib.pw_fwd_residual(u, w, bias, skip, None, 1, s_, d, N_ * Ho * Wo, C, Cout)
+        ctx.save_for_backward(u, w)
+        ctx.params = (w, bias)
+        ctx.cfg = (N_, H, W_, C, Ho, Wo, int(align))
+        return d, s_
+
+    @staticmethod
+    def backward(ctx, gd, gs):
+        u, w = ctx.saved_tensors
+        wsrc, bsrc = ctx.params
+        N_, H, W_, C, Ho, Wo, align = ctx.cfg
+        if gd is None and gs is None:
+            return None, None, None, None, None
+        if gd is None or gs is None:
+            dz = _c(gd if gs is None else gs)
+        else:
+            dz = torch.empty_like(gs)
+            lib.add(_c(gd), _c(gs), dz, dz.numel(), dtype_code(dz.dtype))
+        Cout, M = w.shape[0], N_ * Ho * Wo
+        du = torch.empty_like(u)
+        if gs is not None:
+            dskip = torch.empty_like(u)
+            lib.pw_dgrad_residual(dz, w, _c(gs), dskip, du, M, Cout, C)
+        else:
+            lib.pw_fwd(dz, w, None, du, M, Cout, C, 1, dtype_code(u.dtype))
+            dskip = du
+        dy = torch.empty((N_, H, W_, C), device=u.device, dtype=u.dtype)
+        lib.bilinear_bwd(du, dy, N_, H, W_, C, Ho, Wo, align, dtype_code(u.dtype))
+        with _wgrad_stream(_slot_written(wsrc, bsrc), u, dz):
+            dw = _grad_out(wsrc, tuple(w.shape))
+            db = _grad_out(bsrc)
+            lib.pw_wgrad(u, dz, dw, db, M, C, Cout)
+        return dy, dskip, _ret(dw, wsrc), _ret(db, bsrc), None
+
+
+def up_skip_conv(y, skip, w, bias, align_corners=True):
+    """(d, d + skip) with d = conv1x1(resize(y -> skip's size) + skip); the fused node needs bf16 with square 1x1 weights"""
+    ok = (y.dtype == torch.bfloat16 and skip.dtype == y.dtype and y.dim() == 4 and y.shape[-1] % 32 == 0 and y.shape[-1] <= 160
+          and w.shape[0] == y.shape[-1] and w.shape[1] == y.shape[-1] and tuple(w.shape[2:]) == (1, 1) and bias is not None
+          and skip.shape[-1] == y.shape[-1] and tuple(skip.shape[1:3]) != tuple(y.shape[1:3]) and torch.is_grad_enabled())
+    if not ok:
+        return conv1x1_and_sum(bilinear(y, tuple(skip.shape[1:3]), align_corners, residual=skip), w, bias, skip)
+    return _UpSkipConv.apply(y, skip, w, bias, bool(align_corners))
+
+
 def conv1x1_and_sum(x, w, bias, res):
     """(conv1x1(x), conv1x1(x) + res); bf16 NHWC with channel counts multiples of 32 takes the double-store epilogue"""
     ok = (x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] % 32 == 0 and w.shape[0] % 32 == 0 and w.shape[0] <= 160
@@ -731,7 +792,9 @@ def bn2_add_act(xa, bnA, xb, bnB, pre_act='lrelu', act_kind='gelu'):
 
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, fork=False):
+        """fork: also return an alias of x for the residual path around the normalisation; its gradient is then added inside the
+        LayerNorm backward kernel (tcct_layernorm_bwd_add) instead of by an autograd accumulation pass"""
         _chk(x, gamma, beta)
         C = x.shape[-1]
         M = x.numel() // C
@@ -740,23 +803,35 @@ class _LayerNorm(torch.autograd.Function):
         lib.layernorm_fwd(x, y, M, C, gamma, beta, eps, mr, dtype_code(x.dtype))
         ctx.save_for_backward(x, gamma, mr)
         ctx.beta_param = beta
-        return y
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, gamma, mr = ctx.saved_tensors
+        if dy is None:
+            return dskip, None, None, None, None
         dy = _as(dy, x.dtype)
         C = x.shape[-1]
         M = x.numel() // C
         dx = torch.empty_like(x)
         dg = _grad_out(gamma)
         db = _grad_out(ctx.beta_param)
-        lib.layernorm_bwd(x, dy, dx, M, C, gamma, mr, dg, db, dtype_code(x.dtype))
-        return dx, _ret(dg, gamma), _ret(db, ctx.beta_param), None
+        if dskip is None:
+            lib.layernorm_bwd(x, dy, dx, M, C, gamma, mr, dg, db, dtype_code(x.dtype))
+        else:
+            lib.layernorm_bwd_add(x, dy, _as(dskip, x.dtype), dx, M, C, gamma, mr, dg, db, dtype_code(x.dtype))
+        return dx, _ret(dg, gamma), _ret(db, ctx.beta_param), None, None
 
 
 def layernorm(x, gamma, beta, eps=1e-6):
-    return _LayerNorm.apply(x, gamma, beta, float(eps))
+    return _LayerNorm.apply(x, gamma, beta, float(eps), False)
+
+
+def layernorm_fork(x, gamma, beta, eps=1e-6):
+    """(LayerNorm(x), x'): x' aliases x and is to be read by the residual path (see _LayerNorm.forward `fork`)"""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return layernorm(x, gamma, beta, eps), x
+    return _LayerNorm.apply(x, gamma, beta, float(eps), True)
 
 
 # ------------------------------------------------------------------------------------------- elementwise

@@ -695,3 +695,49 @@ def test_forked_consumers_fold_the_gradient_accumulation(dt, cfg):
     pd, alias = ops.maxpool2_fork(xd)
     (alias.float() * nhwc(go, torch.float32)).sum().backward()
     torch.testing.assert_close(nchw(xd.grad), go, **t)
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('cfg', [(32, 9, 14), (64, 6, 10), (96, 5, 4)])
+def test_decoder_tail_node_and_layernorm_fork(dt, cfg):
+    """up_skip_conv = conv1x1(resize_x2(y) + skip) and + skip as one autograd node (MPUpBlock tail, reference tcct.py:908-914,1028-1031):
+    outputs and all four gradients vs torch; layernorm_fork: x + f(LN(x)) with the residual gradient added in the LN backward kernel"""
+    from tcct_amd import ops
+    C, H, W = cfg
+    N = 2
+    y = rnd(N, C, H, W, dt=dt).requires_grad_(True)
+    skip = rnd(N, C, 2 * H, 2 * W, seed=1, dt=dt).requires_grad_(True)
+    w = (rnd(C, C, 1, 1, seed=2) / C ** 0.5).requires_grad_(True)
+    b = rnd(C, seed=3).requires_grad_(True)
+    u = F.interpolate(y, scale_factor=2, mode='bilinear', align_corners=True) + skip
+    d = F.conv2d(u, w, b)
+    s_ = d + skip
+    g1, g2 = rnd(*d.shape, seed=4, dt=dt), rnd(*d.shape, seed=5, dt=dt)
+    ((d * g1).sum() + (s_ * g2).sum()).backward()
+    yd, sd = nhwc(y.detach(), dt).requires_grad_(True), nhwc(skip.detach(), dt).requires_grad_(True)
+    wd, bd = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    dd, ssd = ops.up_skip_conv(yd, sd, wd, bd, True)
+    t = tol(dt)
+    torch.testing.assert_close(nchw(dd), d.detach(), **t)
+    torch.testing.assert_close(nchw(ssd), s_.detach(), **t)
+    ((dd.float() * nhwc(g1, torch.float32)).sum() + (ssd.float() * nhwc(g2, torch.float32)).sum()).backward()
+    torch.testing.assert_close(nchw(yd.grad), y.grad, rtol=t['rtol'], atol=t['atol'] * 4)
+    torch.testing.assert_close(nchw(sd.grad), skip.grad, rtol=t['rtol'], atol=t['atol'] * 2)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, w.grad.abs().max().item()))
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, b.grad.abs().max().item()))
+    # LayerNorm with the residual path on the alias
+    x = rnd(N, H * W, C, seed=6, dt=dt).requires_grad_(True)
+    ga = (1 + 0.1 * rnd(C, seed=7)).requires_grad_(True)
+    be = rnd(C, seed=8).requires_grad_(True)
+    out = x + 0.5 * F.layer_norm(x, (C,), ga, be, 1e-6) ** 2
+    go = rnd(*out.shape, seed=9, dt=dt)
+    out.backward(go)
+    xd = x.detach().to('cuda', dt).requires_grad_(True)
+    gd_, bd_ = ga.detach().cuda().requires_grad_(True), be.detach().cuda().requires_grad_(True)
+    ln, alias = ops.layernorm_fork(xd, gd_, bd_, 1e-6)
+    assert alias.data_ptr() == xd.data_ptr()
+    od = alias.float() + 0.5 * ln.float() ** 2
+    od.backward(go.cuda())
+    torch.testing.assert_close(od.detach().cpu(), out.detach(), **t)
+    torch.testing.assert_close(xd.grad.float().cpu(), x.grad, rtol=t['rtol'], atol=t['atol'] * 4)
+    torch.testing.assert_close(gd_.grad.cpu(), ga.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, ga.grad.abs().max().item()))
