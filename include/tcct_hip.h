@@ -190,7 +190,7 @@ int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_
  * `post` convolution whose output feeds both the next stage and `x_i + y_i` (nets/tcct.py:1028-1031) */
 int tcct_pw_fwd_residual(const void* x, const float* w, const float* bias, const void* res, const float* scale, int64_t per_sample,
                          void* y, void* y_plain, int64_t M, int K, int N, tcct_stream_t stream);
-/* input gradient with a second gradient folded in: dx_plain = dy W, dx_sum = dy W + res (w [Nout,K] as stored; res, dx_* [M,K] bf16):
+/* input gradient with a second gradient folded in: dx_plain = dy W, dx_sum = dy W + res (w [Nout,K] as stored; res, dx_* [M,K] bf16; dx_plain nullable):
  * backward of the decoder block tail (MPUpBlock, tcct.py:908-914): dx_plain continues into the resize, dx_sum is the skip's gradient */
 int tcct_pw_dgrad_residual(const void* dy, const float* w, const void* res, void* dx_sum, void* dx_plain, int64_t M, int Nout, int K,
                            tcct_stream_t stream);
@@ -217,6 +217,10 @@ int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y
                        int stride, int add_input, int dtype, tcct_stream_t stream);
 int tcct_dwconv3x3_dgrad(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride,
                          int add_input, int dtype, tcct_stream_t stream);
+/* stride-1 input gradient + res [N,H,W,C]: the gradient reaching the convolution's input through its other consumers (the stage input
+ * feeds ConvPosEnc, InvRes.conv1 and the InvRes residual, tcct.py:563-572,604-616) is added in the same pass */
+int tcct_dwconv3x3_dgrad_add(const void* dy, const float* w, const void* res, void* dx, int N, int H, int W, int C, int add_input,
+                             int dtype, tcct_stream_t stream);
 int tcct_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C,
                          int stride, int dtype, tcct_stream_t stream);
 

@@ -89,7 +89,8 @@ template <int STRIDE> struct DwChunk {
 template <typename T, int VEC, int STRIDE, bool FLIP>
 __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, int add_input,
-                                               int segh, int wblocks, int hstrips) {
+                                               int segh, int wblocks, int hstrips, const T* __restrict__ res) {
+    // res != NULL (output-shaped): y += res -- as input gradient: the gradient reaching the convolution's input through its other consumers
     typedef DwChunk<STRIDE> K;
     DwPos p;
     if (!dw_pos(C, VEC, Ho, Wo, segh, wblocks, hstrips, p)) return;
@@ -102,6 +103,7 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
     }
     const T* img = x + (int64_t)p.n * H * W * C + p.c;
     T* out = y + (int64_t)p.n * Ho * Wo * C + p.c;
+    const T* rin = res ? res + (int64_t)p.n * Ho * Wo * C + p.c : nullptr;
     const int wi0 = p.wo * STRIDE - 1;
     Raw<T, VEC> R[K::ROWS][3], NX[K::NEW][3];
 #pragma unroll
@@ -115,9 +117,11 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
         for (int j = 0; j < K::RB; ++j) {
             if (ho + j < p.ho1) {
                 float acc[VEC];
+                Raw<T, VEC> rr;
+                if (rin) rr.load(rin + ((int64_t)(ho + j) * Wo + p.wo) * C); else rr.zero();
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    float a = bv[k];
+                    float a = bv[k] + rr.get(k);
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -150,12 +154,12 @@ static void dw_geometry(int N, int Ho, int Wo, int C, int vec, int target_blocks
 
 template <typename T, int VEC, bool FLIP>
 static void dw_fwd_launch(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C, int stride,
-                          int Ho, int Wo, int add_input, hipStream_t st) {
+                          int Ho, int Wo, int add_input, hipStream_t st, const void* res = nullptr) {
     int segh, wblocks, hstrips;
     dw_geometry(N, Ho, Wo, C, VEC, 1024, 32, segh, wblocks, hstrips);
     dim3 g((unsigned)((int64_t)N * wblocks * hstrips)), b(DB);
-    if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips);
-    else hipLaunchKernelGGL((k_dw_fwd<T, VEC, 2, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips);
+    if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res);
+    else hipLaunchKernelGGL((k_dw_fwd<T, VEC, 2, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res);
 }
 
 extern "C" int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
@@ -232,6 +236,17 @@ __global__ void __launch_bounds__(DB) k_dw_dgrad_s2(const T* __restrict__ dy, co
     }
 }
 
+/* stride-1 input gradient with a second gradient folded in: dx = conv(dy, flipped taps) (+ dy if add_input) + res, res [N,H,W,C] */
+extern "C" int tcct_dwconv3x3_dgrad_add(const void* dy, const float* w, const void* res, void* dx, int N, int H, int W, int C,
+                                        int add_input, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1 && C >= 1 && res != nullptr, "dwconv3x3_dgrad_add: empty tensor / NULL res");
+    int vec = (C % 4 == 0) ? 4 : 1;
+    TCCT_CHECK(C / vec <= DB, "dwconv3x3_dgrad_add: C=%d too large", C);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec == 4) { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, add_input, st, res))); }
+    else { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 1, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, add_input, st, res))); }
+    TCCT_LAUNCH_OK();
+}
 extern "C" int tcct_dwconv3x3_dgrad(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride,
                                     int add_input, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(stride == 1 || stride == 2, "dwconv3x3_dgrad: stride %d", stride);

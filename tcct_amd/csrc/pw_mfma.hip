@@ -265,10 +265,10 @@ extern "C" int tcct_pw_fwd_residual(const void* x, const float* w, const float* 
                        PwSplit{nullptr, 0, nullptr, 0, (const bf16*)res, scale, per_sample, (bf16*)y_plain});
 }
 /* input gradient with a second gradient folded in: dx_plain = dy W, dx_sum = dy W + res (w [Nout, K] as stored, dy [M, Nout], res and
- * both outputs [M, K] bf16).  Decoder block backward: dx_plain continues into the bilinear resize, dx_sum is the skip tensor's gradient */
+ * both outputs [M, K] bf16; dx_plain nullable).  Decoder block backward: dx_plain continues into the bilinear resize, dx_sum is the skip tensor's gradient */
 extern "C" int tcct_pw_dgrad_residual(const void* dy, const float* w, const void* res, void* dx_sum, void* dx_plain, int64_t M, int Nout,
                                       int K, tcct_stream_t stream) {
-    TCCT_CHECK(res != nullptr && dx_plain != nullptr && K % 32 == 0, "pw_dgrad_residual: needs res, dx_plain, K %% 32 == 0");
+    TCCT_CHECK(res != nullptr && K % 32 == 0, "pw_dgrad_residual: needs res, K %% 32 == 0");
     return pw_fwd_impl(dy, w, nullptr, dx_sum, M, Nout, K, 1, TCCT_BF16, nullptr, 0, stream, nullptr, 0, 0,
                        PwSplit{nullptr, 0, nullptr, 0, (const bf16*)res, nullptr, 1, (bf16*)dx_plain});
 }

@@ -226,10 +226,15 @@ class MHCABlock(nn.Module):
         self.norm1 = nn.LayerNorm(dim, eps=1e-6)
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
 
-    def forward(self, x, scales):
-        """x: NHWC image [B,H,W,C] == tokens [B,N,C]; scales: None or (s1,s2) fp32 [B] DropPath mask/keep."""
+    def forward(self, x, scales, fork=False):
+        """x: NHWC image [B,H,W,C] == tokens [B,N,C]; scales: None or (s1,s2) fp32 [B] DropPath mask/keep.
+        fork: also return an alias of the input for its other consumers (gradient added inside the ConvPosEnc input-gradient kernel)"""
         B, H, W, C = x.shape
-        x = _dw(self.cpe.proj, x, add_input=True)
+        m = self.cpe.proj
+        if fork:
+            x, x_alias = ops.dwconv3x3_fork(x, m.weight, m.bias, stride=m.stride[0], add_input=True)
+        else:
+            x = _dw(m, x, add_input=True)
         t = x.view(B, H * W, C)
         s1, s2 = scales if scales is not None else (None, None)
         # (the residual paths read aliases of t: their gradients are added inside the LayerNorm backward kernels)
@@ -241,7 +246,7 @@ class MHCABlock(nn.Module):
         else:               # inference: GELU in the GEMM epilogue
             h = ops.conv_bn_act(cur, self.mlp.fc1.weight, self.mlp.fc1.bias, post_act='gelu')
         t = ops.linear_residual(h, self.mlp.fc2.weight, self.mlp.fc2.bias, t, s2)      # t + dp(fc2(h)) in the GEMM epilogue
-        return t.view(B, H, W, C)
+        return (t.view(B, H, W, C), x_alias) if fork else t.view(B, H, W, C)
 
 
 class MHCAEncoder(nn.Module):
@@ -253,8 +258,8 @@ class MHCAEncoder(nn.Module):
         self.crpe = ConvRelPosEnc(Ch=dim // num_heads, h=num_heads, window={3: 2, 5: 3, 7: 3})
         self.MHCA_layers = nn.ModuleList([MHCABlock(dim, mlp_ratio, drop_path, self.cpe, self.crpe)])
 
-    def forward(self, x, scales):
-        return self.MHCA_layers[0](x, scales)
+    def forward(self, x, scales, fork=False):
+        return self.MHCA_layers[0](x, scales, fork)
 
 
 class ResBlock(nn.Module):
@@ -271,7 +276,9 @@ class ResBlock(nn.Module):
             m.weight.data.normal_(0, math.sqrt(2.0 / fan_out))
 
     def forward(self, x):
-        f = self.conv1(x)
+        return self.tail(self.conv1(x), x)
+
+    def tail(self, f, x):
         f = _bn(self.norm, _dw(self.dwconv, f), post='hswish')
         return self.conv2(f, residual=x)          # x + BN(conv2(f)): the add rides on the normalisation pass
 
@@ -286,8 +293,17 @@ class MHCA_stage(nn.Module):
         self.aggregate = Conv2d_BN(embed_dim * 2, out_embed_dim, act=True)
 
     def forward(self, x, scales):
-        r = self.InvRes(x)
-        e = self.mhca_blks[0](x, scales)
+        if torch.is_grad_enabled() and x.requires_grad:
+            # x has three consumers (InvRes.conv1, ConvPosEnc, the InvRes residual).  They read a chain of aliases so that each
+            # input-gradient kernel adds the gradient of the consumers behind it: no separate accumulation passes over x
+            c1 = self.InvRes.conv1
+            f, x1 = ops.conv2d_fork(x, c1.conv.weight, None, 1, 0, stats_pre='none' if c1.bn.training else None)
+            f = _bn(c1.bn, f, post='hswish')
+            e, x2 = self.mhca_blks[0](x1, scales, fork=True)
+            r = self.InvRes.tail(f, x2)
+        else:
+            r = self.InvRes(x)
+            e = self.mhca_blks[0](x, scales)
         ag = self.aggregate
         if ag.bn.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
             # cat([r, e]) -> 1x1 -> BN -> Hardswish with the concatenation folded into the GEMM operands (no concat / split passes)

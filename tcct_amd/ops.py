@@ -242,7 +242,11 @@ class _Conv2d(torch.autograd.Function):
             dx = torch.empty_like(x)
             if (_pw_ok(dy.dtype, Cout, Cout, KH, KW, stride, padh, padw) and x.dtype == torch.bfloat16
                     and not _mfma32_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw)):
-                lib.pw_fwd(dy, w, None, dx, N * H * W, Cout, Cin, 1, dtype_code(x.dtype))
+                if dskip is not None and Cin % 32 == 0:
+                    lib.pw_dgrad_residual(dy, w, dskip, dx, None, N * H * W, Cout, Cin)
+                    dskip = None
+                else:
+                    lib.pw_fwd(dy, w, None, dx, N * H * W, Cout, Cin, 1, dtype_code(x.dtype))
             elif _mfma_slabs_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
                 _conv_slabs_fwd(dy, w, None, dx, N, H, W, Cout, Cin, KH, KW, KH - 1 - padh, KW - 1 - padw, True)
             elif _mfma32_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
@@ -288,12 +292,16 @@ class _Conv2d(torch.autograd.Function):
         return dx, _ret(dw, wsrc), _ret(db, bsrc), None, None, None, None, None, None
 
 
-def conv2d_fork(x, w, bias=None, stride=1, pad=0):
+def conv2d_fork(x, w, bias=None, stride=1, pad=0, stats_pre=None):
     """(conv2d(x), x'): x' aliases x and is to be read by the other consumers of x (see _Conv2d.forward `fork`)"""
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
-    if not (torch.is_grad_enabled() and x.requires_grad):
-        return conv2d(x, w, bias, stride, pad), x
-    return _Conv2d.apply(x, w, bias, stride, ph, pw, None, None, True)
+    if not (torch.is_grad_enabled() and x.requires_grad and x.dim() == 4):
+        return conv2d(x, w, bias, stride, pad, stats_pre=stats_pre), x
+    box = [ACT[stats_pre], None] if stats_pre is not None else None
+    y, alias = _Conv2d.apply(x, w, bias, stride, ph, pw, None, box, True)
+    if box is not None and box[1] is not None:
+        y._bn_sums = (box[1], box[0])
+    return y, alias
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, out_dtype=None, stats_pre=None):
@@ -636,7 +644,8 @@ def conv3x3_c3(x4, w, bias, stride=1, stats_pre=None, infer_bn=None, post_act=No
 
 class _DwConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, add_input):
+    def forward(ctx, x, w, bias, stride, add_input, fork=False):
+        """fork (stride 1): also return an alias of x for its other consumers; their gradient is added inside the input-gradient kernel"""
         _chk(x, w, bias)
         N, H, W, C = x.shape
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -645,27 +654,43 @@ class _DwConv(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, add_input, bias is not None)
         ctx.bias_param = bias
-        return y
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, w = ctx.saved_tensors
         stride, add_input, has_bias = ctx.cfg
+        if dy is None:
+            return dskip, None, None, None, None, None
         dy = _as(dy, x.dtype)
         N, H, W, C = x.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            lib.dwconv3x3_dgrad(dy, w, dx, N, H, W, C, stride, int(add_input), dtype_code(x.dtype))
+            if dskip is not None and stride == 1:
+                lib.dwconv3x3_dgrad_add(dy, w, _as(dskip, x.dtype), dx, N, H, W, C, int(add_input), dtype_code(x.dtype))
+            else:
+                lib.dwconv3x3_dgrad(dy, w, dx, N, H, W, C, stride, int(add_input), dtype_code(x.dtype))
+                if dskip is not None:
+                    tot = torch.empty_like(dx)
+                    lib.add(dx, _as(dskip, x.dtype), tot, tot.numel(), dtype_code(tot.dtype))
+                    dx = tot
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw = _grad_out(w)
             db = _grad_out(ctx.bias_param) if has_bias else None
             lib.dwconv3x3_wgrad(x, dy, dw, db, N, H, W, C, stride, dtype_code(x.dtype))
-        return dx, _ret(dw, w), _ret(db, ctx.bias_param), None, None
+        return dx, _ret(dw, w), _ret(db, ctx.bias_param), None, None, None
 
 
 def dwconv3x3(x, w, bias=None, stride=1, add_input=False):
-    return _DwConv.apply(x, w, bias, stride, add_input)
+    return _DwConv.apply(x, w, bias, stride, add_input, False)
+
+
+def dwconv3x3_fork(x, w, bias=None, stride=1, add_input=False):
+    """(dwconv3x3(x), x'): x' aliases x for the other consumers of x (see _DwConv.forward `fork`)"""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return dwconv3x3(x, w, bias, stride, add_input), x
+    return _DwConv.apply(x, w, bias, stride, add_input, True)
 
 
 # ------------------------------------------------------------------------------------------------- norms

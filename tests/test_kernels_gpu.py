@@ -652,7 +652,7 @@ def test_gate_fusion_training_branch(dt, shape):
 
 
 @pytest.mark.parametrize('dt', DT)
-@pytest.mark.parametrize('cfg', [(32, 32, 3, 3, 20, 46), (32, 32, 1, 7, 10, 34), (32, 64, 3, 3, 10, 12), (16, 16, 3, 3, 8, 8)])
+@pytest.mark.parametrize('cfg', [(32, 32, 3, 3, 20, 46), (32, 32, 1, 7, 10, 34), (32, 64, 3, 3, 10, 12), (16, 16, 3, 3, 8, 8), (64, 64, 1, 1, 10, 12), (96, 96, 1, 1, 6, 8)])
 def test_forked_consumers_fold_the_gradient_accumulation(dt, cfg):
     """a tensor with two consumers (CrossCNNBlock input -> block12 / block34, encoder level -> maxpool / skip; nets/tcct.py:826,880-883):
     conv2d_fork / maxpool2_fork hand the second consumer an alias and add its gradient inside their own backward kernel
@@ -690,6 +690,18 @@ def test_forked_consumers_fold_the_gradient_accumulation(dt, cfg):
     od = alias.float() * alias.float()
     ((pd.float() * nhwc(gp, torch.float32)).sum() + (od * 0.5 * nhwc(go, torch.float32)).sum()).backward()
     torch.testing.assert_close(nchw(xd.grad), gx_pool, rtol=t['rtol'], atol=t['atol'] * 2)
+    # depthwise fork (ConvPosEnc: x + dw3x3(x), the stage input's third consumer)
+    wdw = rnd(Ci, 1, 3, 3, seed=6).requires_grad_(True)
+    x.grad = None
+    q = x + F.conv2d(x, wdw, None, 1, 1, groups=Ci)
+    ((q * go).sum() + (x * x * 0.5 * go).sum()).backward()
+    xd = nhwc(x.detach(), dt).requires_grad_(True)
+    wq = wdw.detach().cuda().requires_grad_(True)
+    qd, alias = ops.dwconv3x3_fork(xd, wq, None, 1, True)
+    torch.testing.assert_close(nchw(qd), q.detach(), **t)
+    ((qd.float() * nhwc(go, torch.float32)).sum() + (alias.float() * alias.float() * 0.5 * nhwc(go, torch.float32)).sum()).backward()
+    torch.testing.assert_close(nchw(xd.grad), x.grad, rtol=t['rtol'], atol=t['atol'] * 4)
+    torch.testing.assert_close(wq.grad.cpu(), wdw.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, wdw.grad.abs().max().item()))
     # alias unused / pooled output unused: plain gradients
     xd = nhwc(x.detach(), dt).requires_grad_(True)
     pd, alias = ops.maxpool2_fork(xd)
