@@ -217,10 +217,10 @@ int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y
                        int stride, int add_input, int dtype, tcct_stream_t stream);
 int tcct_dwconv3x3_dgrad(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride,
                          int add_input, int dtype, tcct_stream_t stream);
-/* stride-1 input gradient + res [N,H,W,C]: the gradient reaching the convolution's input through its other consumers (the stage input
+/* input gradient + res [N,H,W,C]: the gradient reaching the convolution's input through its other consumers (the stage input
  * feeds ConvPosEnc, InvRes.conv1 and the InvRes residual, tcct.py:563-572,604-616) is added in the same pass */
-int tcct_dwconv3x3_dgrad_add(const void* dy, const float* w, const void* res, void* dx, int N, int H, int W, int C, int add_input,
-                             int dtype, tcct_stream_t stream);
+int tcct_dwconv3x3_dgrad_add(const void* dy, const float* w, const void* res, void* dx, int N, int H, int W, int C, int stride,
+                             int add_input, int dtype, tcct_stream_t stream);
 int tcct_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C,
                          int stride, int dtype, tcct_stream_t stream);
 

@@ -184,8 +184,9 @@ extern "C" int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bi
 // A thread owns the 2x2 quad (a, b) of one channel vector and marches down a: two new dy loads per quad, four dx stores.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(DB) k_dw_dgrad_s2(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx,
-                                                    int N, int H, int W, int C, int Ho, int Wo, int segh, int wblocks, int hstrips) {
-    // quads cover a = 0 .. ceil(H/2)-1, b = 0 .. ceil(W/2)-1 (>= Ho, Wo when H or W is odd ... they are equal: Ho = ceil(H/2))
+                                                    int N, int H, int W, int C, int Ho, int Wo, int segh, int wblocks, int hstrips,
+                                                    const T* __restrict__ res) {
+    // res != NULL ([N,H,W,C]): dx += res (gradient of the input's other consumers); quads cover a = 0 .. ceil(H/2)-1, b = 0 .. ceil(W/2)-1 (>= Ho, Wo when H or W is odd ... they are equal: Ho = ceil(H/2))
     const int Qh = (H + 1) / 2, Qw = (W + 1) / 2;
     DwPos p;
     if (!dw_pos(C, VEC, Qh, Qw, segh, wblocks, hstrips, p)) return;
@@ -196,6 +197,7 @@ __global__ void __launch_bounds__(DB) k_dw_dgrad_s2(const T* __restrict__ dy, co
         for (int tp = 0; tp < 9; ++tp) wk[tp][k] = w[(p.c + k) * 9 + tp];
     const T* g = dy + (int64_t)p.n * Ho * Wo * C + p.c;
     T* out = dx + (int64_t)p.n * H * W * C + p.c;
+    const T* rin = res ? res + (int64_t)p.n * H * W * C + p.c : nullptr;
     const int b = p.wo;
     auto ld = [&](float (&d)[2][VEC], int a) {
 #pragma unroll
@@ -218,6 +220,28 @@ __global__ void __launch_bounds__(DB) k_dw_dgrad_s2(const T* __restrict__ dy, co
         }
         const int hi = 2 * a, wi = 2 * b;
         T* o = out + ((int64_t)hi * W + wi) * C;
+        if (rin) {
+            const T* ri = rin + ((int64_t)hi * W + wi) * C;
+            float r[VEC];
+            ldv<T, VEC>(ri, r);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o00[k] += r[k];
+            if (wi + 1 < W) {
+                ldv<T, VEC>(ri + C, r);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o01[k] += r[k];
+            }
+            if (hi + 1 < H) {
+                ldv<T, VEC>(ri + (int64_t)W * C, r);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o10[k] += r[k];
+                if (wi + 1 < W) {
+                    ldv<T, VEC>(ri + (int64_t)W * C + C, r);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) o11[k] += r[k];
+                }
+            }
+        }
         stv<T, VEC>(o, o00);
         if (wi + 1 < W) stv<T, VEC>(o + C, o01);
         if (hi + 1 < H) {
@@ -236,19 +260,8 @@ __global__ void __launch_bounds__(DB) k_dw_dgrad_s2(const T* __restrict__ dy, co
     }
 }
 
-/* stride-1 input gradient with a second gradient folded in: dx = conv(dy, flipped taps) (+ dy if add_input) + res, res [N,H,W,C] */
-extern "C" int tcct_dwconv3x3_dgrad_add(const void* dy, const float* w, const void* res, void* dx, int N, int H, int W, int C,
-                                        int add_input, int dtype, tcct_stream_t stream) {
-    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1 && C >= 1 && res != nullptr, "dwconv3x3_dgrad_add: empty tensor / NULL res");
-    int vec = (C % 4 == 0) ? 4 : 1;
-    TCCT_CHECK(C / vec <= DB, "dwconv3x3_dgrad_add: C=%d too large", C);
-    hipStream_t st = (hipStream_t)stream;
-    if (vec == 4) { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, add_input, st, res))); }
-    else { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 1, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, add_input, st, res))); }
-    TCCT_LAUNCH_OK();
-}
-extern "C" int tcct_dwconv3x3_dgrad(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride,
-                                    int add_input, int dtype, tcct_stream_t stream) {
+static int dw_dgrad_impl(const void* dy, const float* w, const void* res, void* dx, int N, int H, int W, int C, int stride,
+                         int add_input, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(stride == 1 || stride == 2, "dwconv3x3_dgrad: stride %d", stride);
     TCCT_CHECK(!(add_input && stride != 1), "dwconv3x3_dgrad: add_input needs stride 1");
     TCCT_CHECK(N >= 1 && H >= 1 && W >= 1 && C >= 1, "dwconv3x3_dgrad: empty tensor");
@@ -256,17 +269,27 @@ extern "C" int tcct_dwconv3x3_dgrad(const void* dy, const float* w, void* dx, in
     int vec = (C % 4 == 0) ? 4 : 1;
     TCCT_CHECK(C / vec <= DB, "dwconv3x3_dgrad: C=%d too large", C);
     hipStream_t st = (hipStream_t)stream;
-    if (stride == 1) {      // dx = conv(dy, flipped taps) (+ dy when the forward added its input)
-        if (vec == 4) { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, add_input, st))); }
-        else { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 1, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, add_input, st))); }
+    if (stride == 1) {      // dx = conv(dy, flipped taps) (+ dy when the forward added its input) (+ res)
+        if (vec == 4) { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, add_input, st, res))); }
+        else { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 1, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, add_input, st, res))); }
         TCCT_LAUNCH_OK();
     }
     int segh, wblocks, hstrips;
     dw_geometry(N, (H + 1) / 2, (W + 1) / 2, C, vec, 1024, 32, segh, wblocks, hstrips);
     dim3 g((unsigned)((int64_t)N * wblocks * hstrips)), b(DB);
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_dgrad_s2<T, 4>), g, b, 0, st, (const T*)dy, w, (T*)dx, N, H, W, C, Ho, Wo, segh, wblocks, hstrips)); }
-    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_dgrad_s2<T, 1>), g, b, 0, st, (const T*)dy, w, (T*)dx, N, H, W, C, Ho, Wo, segh, wblocks, hstrips)); }
+    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_dgrad_s2<T, 4>), g, b, 0, st, (const T*)dy, w, (T*)dx, N, H, W, C, Ho, Wo, segh, wblocks, hstrips, (const T*)res)); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_dw_dgrad_s2<T, 1>), g, b, 0, st, (const T*)dy, w, (T*)dx, N, H, W, C, Ho, Wo, segh, wblocks, hstrips, (const T*)res)); }
     TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_dwconv3x3_dgrad(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride,
+                                    int add_input, int dtype, tcct_stream_t stream) {
+    return dw_dgrad_impl(dy, w, nullptr, dx, N, H, W, C, stride, add_input, dtype, stream);
+}
+/* input gradient with a second gradient folded in: dx = dgrad(dy) (+ dy if add_input) + res, res [N,H,W,C] */
+extern "C" int tcct_dwconv3x3_dgrad_add(const void* dy, const float* w, const void* res, void* dx, int N, int H, int W, int C,
+                                        int stride, int add_input, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(res != nullptr, "dwconv3x3_dgrad_add: res is NULL");
+    return dw_dgrad_impl(dy, w, res, dx, N, H, W, C, stride, add_input, dtype, stream);
 }
 
 // dw[c][ky][kx] = sum_p x[p@tap][c] * dy[p][c];  dbias[c] = sum_p dy[p][c].  Same marching window as the forward kernel with

@@ -246,9 +246,11 @@ k_gumbel_fwd(const float* __restrict__ x, const float* __restrict__ eps, float* 
     const int h0 = seg * hs, h1 = min(H, h0 + hs);
     float m = -INFINITY, Z = 0.f;
     for (int h = h0; h < h1; ++h) {
+        // eps == 0 (probability 2^-24 per draw, i.e. a few per step at 8x800x1104x4) gives z = -inf: such an element contributes
+        // exp(-inf) = 0, as in torch.softmax; while the running maximum is still -inf the rescale exp(m - mn) would be exp(NaN)
         float z = gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]);
         float mn = fmaxf(m, z);
-        Z = Z * __expf(m - mn) + __expf(z - mn);
+        if (mn > -INFINITY) Z = Z * __expf(m - mn) + __expf(z - mn);
         m = mn;
     }
     sm[seg][lane] = m; sz[seg][lane] = Z;
@@ -258,7 +260,7 @@ k_gumbel_fwd(const float* __restrict__ x, const float* __restrict__ eps, float* 
     for (int g = 0; g < GSEG; ++g) m = fmaxf(m, sm[g][lane]);
     Z = 0.f;
 #pragma unroll
-    for (int g = 0; g < GSEG; ++g) Z += sz[g][lane] * __expf(sm[g][lane] - m);
+    for (int g = 0; g < GSEG; ++g) if (sm[g][lane] > -INFINITY) Z += sz[g][lane] * __expf(sm[g][lane] - m);
     __syncthreads();
     float S = 0.f;
     for (int h = h0; h < h1; ++h) S += __expf(gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]) - m) / Z;

@@ -161,7 +161,13 @@ class DWConv2d_BN(nn.Module):
             n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
             m.weight.data.normal_(0, math.sqrt(2.0 / n))
 
-    def forward(self, x):
+    def forward(self, x, fork=False):
+        """fork: also return an alias of x for its other consumer (the stage output also feeds FTC's tran_vit convolution): that
+        gradient is added inside the depthwise input-gradient kernel"""
+        if fork:
+            m = self.dwconv
+            d, alias = ops.dwconv3x3_fork(x, m.weight, m.bias, stride=m.stride[0])
+            return _conv_bn(self.pwconv, self.bn, d, post='hswish'), alias
         return _conv_bn(self.pwconv, self.bn, _dw(self.dwconv, x), post='hswish')
 
 
@@ -172,8 +178,8 @@ class DWCPatchEmbed(nn.Module):
         super().__init__()
         self.patch_conv = DWConv2d_BN(embed_dim, embed_dim, 3, stride)
 
-    def forward(self, x):
-        return self.patch_conv(x)
+    def forward(self, x, fork=False):
+        return self.patch_conv(x, fork)
 
 
 class Patch_Embed_stage(nn.Module):
@@ -183,8 +189,8 @@ class Patch_Embed_stage(nn.Module):
         super().__init__()
         self.patch_embeds = nn.ModuleList([DWCPatchEmbed(embed_dim, 2 if isPool else 1)])
 
-    def forward(self, x):
-        return self.patch_embeds[0](x)
+    def forward(self, x, fork=False):
+        return self.patch_embeds[0](x, fork)
 
 
 class ConvPosEnc(nn.Module):
@@ -372,7 +378,11 @@ class MPViT(nn.Module):
         x = self.stem[1](self.stem[0](x))
         xs = []
         for i in range(4):
-            x = self.mhca_stages[i](self.patch_embed_stages[i](x), scales[i])
+            if i > 0 and torch.is_grad_enabled() and x.requires_grad:
+                p, xs[-1] = self.patch_embed_stages[i](x, fork=True)    # the returned level is the alias (read by FTC.tran_vit)
+            else:
+                p = self.patch_embed_stages[i](x)
+            x = self.mhca_stages[i](p, scales[i])
             xs.append(x)
         return xs
 

@@ -645,7 +645,7 @@ def conv3x3_c3(x4, w, bias, stride=1, stats_pre=None, infer_bn=None, post_act=No
 class _DwConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, add_input, fork=False):
-        """fork (stride 1): also return an alias of x for its other consumers; their gradient is added inside the input-gradient kernel"""
+        """fork: also return an alias of x for its other consumers; their gradient is added inside the input-gradient kernel"""
         _chk(x, w, bias)
         N, H, W, C = x.shape
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -667,14 +667,10 @@ class _DwConv(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            if dskip is not None and stride == 1:
-                lib.dwconv3x3_dgrad_add(dy, w, _as(dskip, x.dtype), dx, N, H, W, C, int(add_input), dtype_code(x.dtype))
+            if dskip is not None:
+                lib.dwconv3x3_dgrad_add(dy, w, _as(dskip, x.dtype), dx, N, H, W, C, stride, int(add_input), dtype_code(x.dtype))
             else:
                 lib.dwconv3x3_dgrad(dy, w, dx, N, H, W, C, stride, int(add_input), dtype_code(x.dtype))
-                if dskip is not None:
-                    tot = torch.empty_like(dx)
-                    lib.add(dx, _as(dskip, x.dtype), tot, tot.numel(), dtype_code(tot.dtype))
-                    dx = tot
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw = _grad_out(w)
             db = _grad_out(ctx.bias_param) if has_bias else None

@@ -702,6 +702,16 @@ def test_forked_consumers_fold_the_gradient_accumulation(dt, cfg):
     ((qd.float() * nhwc(go, torch.float32)).sum() + (alias.float() * alias.float() * 0.5 * nhwc(go, torch.float32)).sum()).backward()
     torch.testing.assert_close(nchw(xd.grad), x.grad, rtol=t['rtol'], atol=t['atol'] * 4)
     torch.testing.assert_close(wq.grad.cpu(), wdw.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, wdw.grad.abs().max().item()))
+    # stride-2 depthwise fork (patch embedding of the next stage; the level also feeds FTC.tran_vit)
+    x.grad = None
+    q2 = F.conv2d(x, wdw, None, 2, 1, groups=Ci)
+    g2 = rnd(*q2.shape, seed=7, dt=dt)
+    ((q2 * g2).sum() + (x * x * 0.5 * go).sum()).backward()
+    xd = nhwc(x.detach(), dt).requires_grad_(True)
+    qd, alias = ops.dwconv3x3_fork(xd, wq.detach().requires_grad_(True), None, 2, False)
+    torch.testing.assert_close(nchw(qd), q2.detach(), **t)
+    ((qd.float() * nhwc(g2, torch.float32)).sum() + (alias.float() * alias.float() * 0.5 * nhwc(go, torch.float32)).sum()).backward()
+    torch.testing.assert_close(nchw(xd.grad), x.grad, rtol=t['rtol'], atol=t['atol'] * 4)
     # alias unused / pooled output unused: plain gradients
     xd = nhwc(x.detach(), dt).requires_grad_(True)
     pd, alias = ops.maxpool2_fork(xd)
@@ -753,3 +763,34 @@ def test_decoder_tail_node_and_layernorm_fork(dt, cfg):
     torch.testing.assert_close(od.detach().cpu(), out.detach(), **t)
     torch.testing.assert_close(xd.grad.float().cpu(), x.grad, rtol=t['rtol'], atol=t['atol'] * 4)
     torch.testing.assert_close(gd_.grad.cpu(), ga.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, ga.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize('hw', [(40, 9), (17, 5), (800, 3)])
+def test_gumbel_colsoftmax_with_zero_draws(hw):
+    """sampling_softmax (reference nets/reg.py:118-126) when a uniform draw is exactly 0 (torch.rand is [0,1): probability 2^-24 per
+    element, a few per step at the bench shape): log(-log 0) = +inf, z = -inf, the element gets probability 0 exactly as in
+    torch.softmax -- also when it is the first element a thread visits (the online max/sum used to turn that into NaN)"""
+    from tcct_amd import ops
+    H, W = hw
+    N, CH = 2, 4
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, H, W, CH, generator=g).requires_grad_(True)
+    eps = torch.rand(N, H, W, CH, generator=g).clamp_(1e-6, 1 - 1e-6)
+    seg = (H + 7) // 8
+    for h in range(0, H, seg):              # the first row of every row segment, in some columns
+        eps[0, h, 0, :] = 0.0
+        eps[1, h, W - 1, 1] = 0.0
+    eps[1, 1:3, 1, 2] = 0.0
+    z = x - torch.log(-torch.log(eps)) / 2
+    p = torch.softmax(z, dim=1)
+    p = p / (p.sum(1, keepdim=True) + 1e-6)
+    ref = p.sum(-1, keepdim=True)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    assert torch.isfinite(ref).all() and torch.isfinite(x.grad).all()
+    xd = x.detach().cuda().requires_grad_(True)
+    out = ops.gumbel_colsoftmax_sum(xd, eps.cuda())
+    out.backward(go.cuda().view_as(out))
+    assert torch.isfinite(out).all() and torch.isfinite(xd.grad).all()
+    torch.testing.assert_close(out.detach().cpu().view_as(ref), ref.detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-3, atol=1e-6)
