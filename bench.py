@@ -210,8 +210,13 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = None
-    for _ in range(a.steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # per-step GPU timeline (diagnostic; no host sync)
+    host = [time.perf_counter()]
+    marks[0].record()
+    for i in range(a.steps):
         loss = k.train_step(img, lab)
+        marks[i + 1].record()
+        host.append(time.perf_counter())
     torch.cuda.synchronize()
     tdist.barrier()
     torch.cuda.synchronize()
@@ -229,6 +234,9 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
         'config': {'workload': f'stc_tt --los={a.los} bs={a.bs}/GPU 1x{a.height}x{a.width} (net tensors 3x{a.height}x{(a.width + 15) // 16 * 16})',
                    'global_batch': a.bs * world, 'parallelism': f'dp{world}', 'loss_last': round(lossv, 4),
+                   'step_ms_gpu_min_med_max': _min_med_max([marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]),
+                   'step_ms_host_enqueue_min_med_max': _min_med_max([1e3 * (host[i + 1] - host[i]) for i in range(a.steps)]),
+                   'slowest_step': max(range(a.steps), key=lambda i: host[i + 1] - host[i]),
                    'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2**30, 2)},
     }
     if not a.no_roofline:
@@ -240,6 +248,11 @@ def main():
         out['cpu_baseline'] = cpu_baseline(a)
     print(json.dumps(out), flush=True)
     tdist.barrier()
+
+
+def _min_med_max(v):
+    v = sorted(v)
+    return [round(v[0], 2), round(v[len(v) // 2], 2), round(v[-1], 2)]
 
 
 def _shutdown():

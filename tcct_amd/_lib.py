@@ -1,6 +1,7 @@
 """ctypes binding of libtcct_hip.so.  The argtypes are parsed from include/tcct_hip.h so the Python side can never
 drift from the C-ABI.  There is NO fallback: if the library is missing or a call fails, this raises."""
 import ctypes
+import threading
 import os
 import re
 
@@ -42,6 +43,27 @@ class TcctError(RuntimeError):
     pass
 
 
+_TLS = threading.local()
+
+
+class launch_on:
+    """with launch_on(stream): every lib.* call of this thread that does not name a stream goes to `stream` (a torch.cuda.Stream).
+    Cheaper than `with torch.cuda.stream(s)` (which re-binds torch's current stream twice) for blocks that only launch kernels of
+    this library into pre-allocated outputs -- torch allocations inside the block would still belong to the current stream."""
+
+    def __init__(self, stream):
+        self.handle = stream.cuda_stream
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, 'stream', None)
+        _TLS.stream = self.handle
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.stream = self.prev
+        return False
+
+
 class _Lib:
     def __init__(self):
         self._dll = None
@@ -73,23 +95,21 @@ class _Lib:
         sig = self.protos[full][1]
         res_is_value = self.protos[full][0] is not ctypes.c_int
 
+        # hot path (about 1800 launches per training step): everything that does not depend on the arguments is resolved here
+        n = len(sig)
+        has_stream = bool(sig) and sig[-1][1] == 'stream'
+        is_ptr = tuple(ct is ctypes.c_void_p for ct, _ in sig)
+        raw_stream, cur_dev, Tensor = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice, torch.Tensor
+
+        tls = _TLS
+
         def call(*args):
-            if len(args) == len(sig) - 1 and sig and sig[-1][1] == 'stream':
-                args = args + (torch.cuda.current_stream().cuda_stream,)
-            if len(args) != len(sig):
-                raise TypeError(f'{full}: expected {len(sig)} args ({[n for _, n in sig]}), got {len(args)}')
-            conv = []
-            for a, (ct, nm) in zip(args, sig):
-                if ct is ctypes.c_void_p:
-                    if a is None:
-                        conv.append(None)
-                    elif isinstance(a, torch.Tensor):
-                        conv.append(a.data_ptr())
-                    else:
-                        conv.append(int(a))
-                else:
-                    conv.append(a)
-            rc = fn(*conv)
+            if has_stream and len(args) == n - 1:
+                # the caller's current HIP stream (torch.cuda.current_stream() costs 8 us), or the stream a `launch_on` block names
+                args = args + (getattr(tls, 'stream', None) or raw_stream(cur_dev()),)
+            elif len(args) != n:
+                raise TypeError(f'{full}: expected {n} args ({[nm for _, nm in sig]}), got {len(args)}')
+            rc = fn(*[(a.data_ptr() if isinstance(a, Tensor) else a) if p and a is not None else a for a, p in zip(args, is_ptr)])
             if res_is_value:
                 return rc
             if rc != 0:

@@ -109,6 +109,12 @@ class CrossResNet(nn.Module):
     def forward(self, x, levels=None):
         """x: NHWC [B,H,W,4] (3 image channels + zero pad); levels: only the first `levels` resolutions (vitu needs level 0 only)."""
         xs = []
+        for _ in self.iter_levels(x, xs, levels):
+            pass
+        return xs
+
+    def iter_levels(self, x, xs, levels=None):
+        """generator form of forward(): appends one resolution level to `xs` per step (ops.run_interleaved alternates it with the ViT stages)"""
         m = self.cnn[1]
         if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
             x = _bn(m, ops.conv3x3_c3(x, self.cnn[0].weight, self.cnn[0].bias, 1, stats_pre='none' if self.training else None))
@@ -122,7 +128,7 @@ class CrossResNet(nn.Module):
                 xs.append(skip)
             else:
                 xs.append(x)
-        return xs
+            yield i
 
 
 # --------------------------------------------------------------------------------------------- ViT branch
@@ -374,9 +380,15 @@ class MPViT(nn.Module):
 
     def forward_features(self, x):
         """x NHWC [B,H,W,4] -> [x2,x3,x4,x5] NHWC (reference tcct.py:733-745)."""
+        xs = []
+        for _ in self.iter_stages(x, xs):
+            pass
+        return xs
+
+    def iter_stages(self, x, xs):
+        """generator form of forward_features(): appends one stage output to `xs` per step"""
         scales = self._dp_scales(x.shape[0], x.device)
         x = self.stem[1](self.stem[0](x))
-        xs = []
         for i in range(4):
             if i > 0 and torch.is_grad_enabled() and x.requires_grad:
                 p, xs[-1] = self.patch_embed_stages[i](x, fork=True)    # the returned level is the alias (read by FTC.tran_vit)
@@ -384,7 +396,7 @@ class MPViT(nn.Module):
                 p = self.patch_embed_stages[i](x)
             x = self.mhca_stages[i](p, scales[i])
             xs.append(x)
-        return xs
+            yield i
 
 
 def mpvit_tiny(**kw):
@@ -493,7 +505,9 @@ class FTC(nn.Module):
         size = (x.shape[2], x.shape[3])
         x = self._to_nhwc4(x)
         if self.flag_vit and self.flag_cnn:
-            (c1, c2, c3, c4, c5), (v2, v3, v4, v5) = ops.run_parallel('vit', lambda: self.base_cnn(x), lambda: self.base_vit.forward_features(x))
+            cs, vs = [], []
+            ops.run_interleaved('vit', self.base_cnn.iter_levels(x, cs), self.base_vit.iter_stages(x, vs), vs)
+            (c1, c2, c3, c4, c5), (v2, v3, v4, v5) = cs, vs
             f = [c1]
             for j, (v, c) in enumerate(((v2, c2), (v3, c3), (v4, c4), (v5, c5))):
                 tv, tc = getattr(self, f'tran_vit{j}'), getattr(self, f'tran_cnn{j}')
@@ -516,7 +530,9 @@ class FTC(nn.Module):
             f = list(self.base_cnn(x))
         else:
             # only level 0 of the CNN encoder is consumed (c1 is the decoder's last skip); the deeper CNN levels are skipped
-            (c1,), (v2, v3, v4, v5) = ops.run_parallel('vit', lambda: self.base_cnn(x, levels=1), lambda: self.base_vit.forward_features(x))
+            cs, vs = [], []
+            ops.run_interleaved('vit', self.base_cnn.iter_levels(x, cs, 1), self.base_vit.iter_stages(x, vs), vs)
+            (c1,), (v2, v3, v4, v5) = cs, vs
             f = [c1] + [_conv_bn(getattr(self, f'tran_vit{j}')[0], getattr(self, f'tran_vit{j}')[1], v) for j, v in enumerate((v2, v3, v4, v5))]
         y8 = _conv_bn(self.head[0], self.head[1], f[4], post='lrelu')
         if self.legacy_heads:       # tcct_goals.py:1027-1033: heads on the decoder outputs

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from ._lib import lib, dtype_code, TcctError, F32, BF16  # noqa: F401
+from ._lib import lib, dtype_code, TcctError, launch_on, F32, BF16  # noqa: F401
 
 ACT = {None: 0, 'none': 0, 'lrelu': 1, 'hswish': 2, 'gelu': 3, 'sigmoid': 4, 'abs': 5}
 
@@ -41,7 +41,7 @@ class _ZeroPool:
         n = 1
         for d in shape:
             n *= d
-        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        nbytes = n * dtype.itemsize
         if not self.active:
             return torch.empty(shape, device=device, dtype=dtype)
         start = (self.off + 255) // 256 * 256
@@ -66,12 +66,15 @@ def end_step():
         for st in _WGRAD_USED.values():
             cur.wait_stream(st)
         _WGRAD_USED.clear()
+    _WGRAD_KEEP.clear()         # after the join: blocks freed from here on are reused by work ordered behind the weight gradients
 
 
 # Weight-gradient kernels only feed the optimizer, so inside a pooled step they are issued on a side stream and joined in
 # end_step(): the input-gradient chain (the critical path of backward) continues without waiting for them and the
 # latency-bound weight gradients of the coarse levels overlap it.  TCCT_STREAMS=0 disables.
 _WGRAD_USED = {}
+_WGRAD_KEEP = []
+_WGRAD_RECORD_STREAM = os.environ.get('TCCT_WGRAD_RECORD_STREAM', '0') == '1'      # the old behaviour, kept for A/B measurements only
 
 
 class _wgrad_stream:
@@ -81,13 +84,17 @@ class _wgrad_stream:
     def __enter__(self):
         if not self.enable:
             return self
-        self.cur = torch.cuda.current_stream()
-        key = ('wgrad', self.cur.device.index)
-        self.side = _SIDE_STREAMS.get(key)
-        if self.side is None:
-            self.side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=self.cur.device)
-        self.side.wait_stream(self.cur)
-        self.ctx = torch.cuda.stream(self.side)
+        cur = torch.cuda.current_stream()
+        key = ('wgrad', cur.device.index)
+        ent = _SIDE_STREAMS.get(key)
+        if ent is None:         # the side stream and ONE reusable event for the cur -> side dependency (a wait captures the state of the
+            ent = _SIDE_STREAMS[key] = (torch.cuda.Stream(device=cur.device), torch.cuda.Event())   # event at the time it is issued)
+        self.side, ev = ent
+        ev.record(cur)
+        self.side.wait_event(ev)
+        # the block only launches this library's kernels into pre-allocated gradient slots: name the stream for them instead of
+        # re-binding torch's current stream (launch_on: ~1 us instead of ~25 us per weight gradient)
+        self.ctx = launch_on(self.side)
         self.ctx.__enter__()
         return self
 
@@ -95,8 +102,15 @@ class _wgrad_stream:
         if not self.enable:
             return False
         self.ctx.__exit__(*exc)
-        for t in self.tensors:
-            t.record_stream(self.side)      # autograd may free x / dy as soon as this node returns
+        # autograd may drop x / dy as soon as this node returns while the side stream still reads them.  They are kept alive until
+        # end_step() has joined the side stream -- NOT tensor.record_stream(side): with every activation and gradient of the step
+        # marked that way the caching allocator could not reuse a block until the side stream caught up, the host runs most of a
+        # step ahead, and the reserved pool grew by ~3.5 GB per step (124 GB after 30 steps, then a multi-second free-and-retry stall)
+        if _WGRAD_RECORD_STREAM:
+            for t in self.tensors:
+                t.record_stream(self.side)
+        else:
+            _WGRAD_KEEP.extend(self.tensors)
         _WGRAD_USED[id(self.side)] = self.side
         return False
 
@@ -356,6 +370,36 @@ def run_parallel(tag, fa, fb):
     for t in _tensors(rb):
         t.record_stream(cur)        # allocated on the side stream, consumed on the current one
     return ra, rb
+
+
+def run_interleaved(tag, ga, gb, outs_b):
+    """Exhaust the generators ga (current stream) and gb (side stream `tag`) ALTERNATELY, gb first, and join.  The two encoders are
+    issued level by level in turn rather than one after the other: the runtime lets the host run only a bounded number of launches
+    ahead of the GPU, so with `ViT then CNN` the second stream received its first kernel when the first was nearly done, and -- autograd
+    replays nodes in reverse creation order -- the backward pass ran the CNN encoder completely before the first ViT kernel.  Alternating
+    creation order keeps both streams fed in both passes.  outs_b: the list gb fills (its tensors are handed to the current stream)."""
+    if not (PARALLEL_BRANCHES and torch.cuda.is_available()):
+        for _ in gb:
+            pass
+        for _ in ga:
+            pass
+        return
+    cur = torch.cuda.current_stream()
+    side = _SIDE_STREAMS.get((tag, cur.device.index))
+    if side is None:
+        side = _SIDE_STREAMS[(tag, cur.device.index)] = torch.cuda.Stream(device=cur.device)
+    side.wait_stream(cur)
+    done_a = done_b = False
+    end = object()
+    while not (done_a and done_b):
+        if not done_b:
+            with torch.cuda.stream(side):
+                done_b = next(gb, end) is end
+        if not done_a:
+            done_a = next(ga, end) is end
+    cur.wait_stream(side)
+    for t in _tensors(outs_b):
+        t.record_stream(cur)        # allocated on the side stream, consumed on the current one
 
 
 INFER_FUSE = True       # eval-mode forward under no_grad folds BatchNorm / activations into the convolution epilogues (False: op by op)

@@ -99,3 +99,33 @@ def test_full_step_runs_at_bench_shape(tmp_path):
     mask = k.predict(img[:1])
     d = MDiceLoss.scorem(mask, lab[:1], start_idx=1).item()
     assert 0.0 <= d <= 1.0
+
+
+def test_allocator_pool_stays_bounded_over_steps_fullsize(tmp_path):
+    """bench shape, 26 training steps: the multi-stream step (encoders on two streams, weight gradients on a third) must not make the
+    caching allocator grow step after step.  Activations / gradients handed to the weight-gradient stream are kept alive until the
+    join instead of record_stream()ed: that grew the reserved pool by ~3.5 GB per step at this shape (124 GB after 30 steps) and
+    ended in multi-second free-and-retry stalls (TCCT_WGRAD_RECORD_STREAM=1 restores the old behaviour for comparison)"""
+    import argparse
+    from tcct_amd.nets import stc_tt, RegNet
+    from tcct_amd.kite import KiteSeg
+    from tcct_amd.data import SynthOCT
+
+    ds = SynthOCT(height=800, width=1100, device='cuda')
+    net = RegNet(stc_tt(ds.out_channels, compute_dtype=torch.bfloat16), con='cos', out_channels=ds.out_channels).cuda()
+    args = argparse.Namespace(los='di', lr=1e-3, gpu='0', pl=False, bs=B, coff_ds=1, udh=False, reg=False, epl=False, coff_udh=1, coff_reg=.1,
+                              coff_epl=.1, bug=True)
+    k = KiteSeg(model=net, dataset=ds, root=str(tmp_path), args=args)
+    k.model.train()
+    img, lab, _, _ = ds.parse(ds.make_batch(B, seed=5))
+    stats = []
+    for it in range(26):
+        loss = k.train_step(img, lab)
+        if it in (7, 25):
+            ms = torch.cuda.memory_stats()
+            stats.append((ms['num_device_alloc'], ms['reserved_bytes.all.current']))
+    assert torch.isfinite(loss).item()
+    (seg0, res0), (seg1, res1) = stats
+    assert seg1 - seg0 <= 12 and res1 <= res0 * 1.2, stats
+    del k, net
+    torch.cuda.empty_cache()

@@ -531,3 +531,4 @@ def test_training_improves_validation_dice(tmp_path):
     after = k.val(epoch=1)['val_f1s']
     print('val Dice before', before, 'after', after)
     assert after > before + 0.15 and after > 0.5, (before, after)
+
