@@ -71,8 +71,10 @@ def pmc_table(kind):
 mf, sq = pmc_table('mfma'), pmc_table('sq')
 if mf:
     L.append('\n### matrix-pipe occupancy of the same loops — `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` and `--pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY`\n')
-    L.append('MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs) (the gfx94x `MfmaUtil` formula; ROCm 7.2 ships no gfx950 derived metrics). '
-             'These kernels are HBM-bound (SURVEY 8(d)): the matrix pipes are idle most of the time by construction; the wave-cycle split shows where waves wait.\n')
+    L.append('MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs): the gfx94x `MfmaUtil` formula (ROCm 7.2 ships no gfx950 derived '
+             'metrics) with GRBM_GUI_ACTIVE divided by 8 because rocprofv3 reports it summed over the 8 XCDs (value / 8 = kernel duration x ~1.6 GHz). Cross-check for the 3x3 '
+             'convolution: 130 GFLOP per launch = 3.97 M `v_mfma_f32_32x32x16_bf16` x 32 cycles = 1.27e8 busy cycles (the counter), and 538 TFLOP/s is 21.5 % of the 2.5 PFLOP/s dense bf16 peak '
+             '(which assumes 2.4 GHz). These kernels are HBM-bound (SURVEY 8(d)): the matrix pipes idle most of the time by construction; the wave-cycle split shows where waves wait.\n')
     L.append('| kernel | MFMA busy cycles | GUI active cycles | MFMA busy % | wave cycles: waiting (s_waitcnt/barrier) % | issue-stalled % | issuing % |\n|---|---|---|---|---|---|---|')
     for r in roof:
         if any(key + '<' in r['Name'] for key in alg):
@@ -83,7 +85,7 @@ if mf:
             q = (sq or {}).get(r['Name'], {})
             wc = q.get('SQ_WAVE_CYCLES', 0.0)
             pct = lambda v: f'{100 * v / wc:.1f}' if wc else '-'
-            L.append(f'| `{r["Name"].split("(")[0]}` | {busy:.3g} | {act:.3g} | {100 * busy / (act * 1024) if act else 0:.1f} | {pct(q.get("SQ_WAIT_ANY", 0))} | {pct(q.get("SQ_WAIT_INST_ANY", 0))} | {pct(q.get("SQ_ACTIVE_INST_ANY", 0))} |')
+            L.append(f'| `{r["Name"].split("(")[0]}` | {busy:.3g} | {act:.3g} | {100 * busy / (act / 8 * 1024) if act else 0:.1f} | {pct(q.get("SQ_WAIT_ANY", 0))} | {pct(q.get("SQ_WAIT_INST_ANY", 0))} | {pct(q.get("SQ_ACTIVE_INST_ANY", 0))} |')
 L.append(f'\nbench.py\'s own HIP-event timing of the same loops (un-profiled run): `roofline.ms_per_launch` = {b["roofline"]["ms_per_launch"]} ms '
          f'({b["roofline"]["achieved"]} GB/s algorithmic, frac {b["roofline"]["frac"]}), second = {b["roofline"]["second"]["ms_per_launch"]} ms, '
          f'others = {[(o["kernel"], o["ms_per_launch"]) for o in b["roofline"].get("others", [])]}.')
