@@ -264,6 +264,14 @@ int tcct_softmax_dice_fwd(const void* logits, const uint8_t* labels, int64_t M, 
 /* dlogits = grad_scale * (*grad_out) * dLoss/dlogits  (grad_out: device scalar, NULL -> 1) */
 int tcct_softmax_dice_bwd(const void* logits, const uint8_t* labels, int64_t M, int C, const double* sums,
                           const float* grad_out, float grad_scale, void* dlogits, int dtype, tcct_stream_t stream);
+/* Deep-supervision heads (FTC.forward, nets/tcct.py:1042-1044 + MultiLoss, kite/losses/loss.py:83-99) without the full-size logits:
+ * low fp32 NHWC [B,h,w,C] is resized to H x W (F.interpolate bilinear, align_corners=False, integer scale 2, 4, 8 or 16) on the fly inside the
+ * softmax-Dice kernels.  fwd: sums[3][C] + loss as tcct_softmax_dice_fwd.  bwd: dlow [B,h,w,C] = grad_scale * (*grad_out) * dLoss/dlow,
+ * ws = fp32 workspace [B,H,w,C] */
+int tcct_updice_fwd(const float* low, const uint8_t* labels, int B, int h, int w, int H, int W, int C, double* sums, float* loss,
+                    tcct_stream_t stream);
+int tcct_updice_bwd(const float* low, const uint8_t* labels, int B, int h, int w, int H, int W, int C, const double* sums,
+                    const float* grad_out, float grad_scale, float* ws, float* dlow, tcct_stream_t stream);
 /* softmax prob of the labelled class (regular_udh sort key, nets/reg.py:89) and/or argmax class (KiteSeg.predict,
  * kite/loop_seg.py:32); either output may be NULL */
 int tcct_softmax_pick(const void* logits, const uint8_t* labels, int64_t M, int C, float* prob_lab, uint8_t* argmax,

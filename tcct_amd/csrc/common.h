@@ -146,6 +146,18 @@ __device__ __forceinline__ void affine4(float* v, const float* a, const float* b
 }
 
 // ---------------------------------------------------------------- wave / block reductions (wave = 64)
+// source index / weights of torch's bilinear resize (F.interpolate / nn.Upsample) for output index o
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp src_index(int o, float scale, int in, int align) {
+    float s = align ? scale * (float)o : fmaxf(scale * ((float)o + 0.5f) - 0.5f, 0.f);
+    Lerp r;
+    r.i0 = min((int)s, in - 1);
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = s - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -169,17 +169,6 @@ extern "C" int tcct_maxpool2_bwd_add(const void* x, const void* dy, const void* 
 }
 
 // ------------------------------------------------------------------------------------------ bilinear
-struct Lerp { int i0, i1; float l0, l1; };
-__device__ __forceinline__ Lerp src_index(int o, float scale, int in, int align) {
-    float s = align ? scale * (float)o : fmaxf(scale * ((float)o + 0.5f) - 0.5f, 0.f);
-    Lerp r;
-    r.i0 = min((int)s, in - 1);
-    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
-    r.l1 = s - (float)r.i0;
-    r.l0 = 1.f - r.l1;
-    return r;
-}
-
 // grid.y strides over output rows (n, ho) -- the row interpolation is block-uniform; threads of a row cover (wo, channel vector)
 template <typename T, int VEC>
 __global__ void k_bilinear_fwd(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo,

@@ -22,6 +22,7 @@ class KiteSeg(KiteBack):
     use_graph = True        # hipGraph replay of the eval forward for batches of <= 2 images (TCCT_GRAPH=0 disables)
     _graphed = None
     _graphed_step = None    # --graph=true: tcct_amd.graph.GraphedTrainStep
+    fuse_aux_loss = True    # training: resize + softmax + Dice of the aux heads in one kernel (TCCT_FUSE_AUX=0 disables)
 
     def __init__(self, args, **_args):
         self.args = args
@@ -33,6 +34,7 @@ class KiteSeg(KiteBack):
         self.best_dice = -1.0
         import os
         self.use_graph = os.environ.get('TCCT_GRAPH', '1') != '0'
+        self.fuse_aux_loss = os.environ.get('TCCT_FUSE_AUX', '1') != '0'
 
     def predict(self, img, softmax=True, *args):
         """reference loop_seg.py:21-33: one_hot(argmax(softmax(out[0]))).  Returns a lazy MaskOneHot (class-index map;
@@ -137,7 +139,15 @@ class KiteSeg(KiteBack):
 
     def calc_loss(self, img, lab, want_log=True):
         """reference loop_seg.py:146-171: forward -> Dice (deep supervision) -> udh -> reg; returns (tensor, log string)"""
-        out = self.model(img)
+        base = getattr(self.model, 'base', None)
+        defer = self.fuse_aux_loss and base is not None and hasattr(base, 'defer_aux_resize') and self.model.training
+        if defer:       # the deep-supervision heads go to the criterion at their own resolution (ops.LowResLogits): no full-size aux logits
+            base.defer_aux_resize = True
+        try:
+            out = self.model(img)
+        finally:
+            if defer:
+                base.defer_aux_resize = False
         losSum = self.grad_calc(out, lab, ds=True, criterion=self.criterion)
         parts = [('los', losSum)]
         if isinstance(out, (list, tuple)):

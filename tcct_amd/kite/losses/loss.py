@@ -32,6 +32,8 @@ class MultiLoss(nn.Module):
         self.WEIGHT = [1, ] * 40
 
     def forward(self, pr, gt, **args):
+        if isinstance(pr, ops.LowResLogits):        # deep-supervision head before its resize: fused resize + softmax + Dice
+            return ops.softmax_dice_upsampled(pr, as_label_index(gt))
         return ops.softmax_dice(as_nhwc(pr), as_label_index(gt))
 
 

@@ -434,6 +434,7 @@ class FTC(nn.Module):
         # sibling variants of the reference (nets/tcct.py:1090-1136): gtc_* fuse with GateFusion (:916-932), cnnu / vitu drop one
         # encoder from the fusion (:1016-1019).  All modules (and state_dict keys) exist in every variant, as in the reference.
         self.flag_gate, self.flag_cnn, self.flag_vit = bool(flag_gate), bool(flag_cnn), bool(flag_vit)
+        self.defer_aux_resize = False       # see forward(): aux heads returned as ops.LowResLogits (set by KiteSeg.calc_loss)
         self.forced_gate_fields = None      # parity tests: list of 4 NHWC alpha fields in draw order (reference: torch.rand on the CPU)
         if not (self.flag_cnn or self.flag_vit):
             raise TcctError('FTC needs at least one of flag_cnn / flag_vit')
@@ -554,6 +555,9 @@ class FTC(nn.Module):
         # aux heads: logits are produced and resized in fp32 in every mode (loss-side precision)
         f32 = torch.float32
         y0 = _conv(self.aux0, g0, out_dtype=f32)
+        if self.defer_aux_resize and torch.is_grad_enabled():
+            # training loop (KiteSeg.calc_loss): the three aux heads stay at their own resolution; the Dice criterion resizes on the fly
+            return [_nchw_view(y0)] + [ops.LowResLogits(_conv(m, g, out_dtype=f32), size) for m, g in ((self.aux1, g1), (self.aux2, g2), (self.aux4, g3))]
         y1 = ops.bilinear(_conv(self.aux1, g1, out_dtype=f32), size, False)
         y2 = ops.bilinear(_conv(self.aux2, g2, out_dtype=f32), size, False)
         y4 = ops.bilinear(_conv(self.aux4, g3, out_dtype=f32), size, False)

@@ -1260,6 +1260,56 @@ def softmax_dice(logits, labels):
     return _SoftmaxDice.apply(logits, labels)
 
 
+class _UpDice(torch.autograd.Function):
+    """MultiLoss(DiceLoss)(F.interpolate(low, size, 'bilinear'), labels) without materialising the resized logits (deep-supervision heads)"""
+
+    @staticmethod
+    def forward(ctx, low, labels, H, W):
+        _chk(low, labels)
+        B, h, w, C = low.shape
+        sums = torch.empty(3 * C, device=low.device, dtype=torch.float64)
+        loss = torch.empty((), device=low.device, dtype=torch.float32)
+        lib.updice_fwd(low, labels, B, h, w, H, W, C, sums, loss)
+        ctx.save_for_backward(low, labels, sums)
+        ctx.size = (H, W)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        low, labels, sums = ctx.saved_tensors
+        B, h, w, C = low.shape
+        H, W = ctx.size
+        g = _as(g, torch.float32)
+        ws = torch.empty((B, H, w, C), device=low.device, dtype=torch.float32)
+        d = torch.empty_like(low)
+        lib.updice_bwd(low, labels, B, h, w, H, W, C, sums, g, 1.0, ws, d)
+        return d, None, None, None
+
+
+class LowResLogits:
+    """A deep-supervision head before its resize: `low` fp32 NHWC [B,h,w,C] + the target size.  FTC.forward returns these instead of
+    the resized tensors when `defer_aux_resize` is set (KiteSeg.calc_loss does, in training); the Dice criterion consumes them with the
+    fused resize + softmax + Dice kernels, anything else calls `.dense()` for the reference's [B,C,H,W] tensor."""
+
+    def __init__(self, low, size):
+        self.low, self.size = low, (int(size[0]), int(size[1]))
+
+    def fusable(self):
+        B, h, w, C = self.low.shape
+        H, W = self.size
+        return (self.low.dtype == torch.float32 and 2 <= C <= 8 and H % h == 0 and W % w == 0 and H // h == W // w and H // h in (2, 4, 8, 16))
+
+    def dense(self):
+        return bilinear(self.low, self.size, False).permute(0, 3, 1, 2)
+
+
+def softmax_dice_upsampled(lr, labels):
+    """Dice criterion of a LowResLogits head"""
+    if not lr.fusable():
+        return softmax_dice(bilinear(lr.low, lr.size, False), labels)
+    return _UpDice.apply(lr.low, labels, lr.size[0], lr.size[1])
+
+
 class _Slice(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, start, n):

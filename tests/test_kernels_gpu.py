@@ -794,3 +794,31 @@ def test_gumbel_colsoftmax_with_zero_draws(hw):
     assert torch.isfinite(out).all() and torch.isfinite(xd.grad).all()
     torch.testing.assert_close(out.detach().cpu().view_as(ref), ref.detach(), rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize('cfg', [(2, 5, 6, 10, 2), (1, 5, 5, 7, 4), (2, 5, 3, 4, 8), (1, 3, 1, 1, 2), (1, 8, 2, 3, 16)])
+def test_upsampled_dice_matches_interpolate_softmax_dice(cfg):
+    """deep-supervision heads (reference nets/tcct.py:1042-1044 + kite/losses/loss.py:83-99): F.interpolate(bilinear, align_corners=False)
+    -> softmax -> batch-global Dice, fused so that the resized logits never exist; loss and the gradient w.r.t. the low-resolution logits"""
+    from tcct_amd import ops
+    B, C, h, w, S = cfg
+    H, W = h * S, w * S
+    g = torch.Generator().manual_seed(7)
+    low = (torch.randn(B, C, h, w, generator=g) * 2).requires_grad_(True)
+    lab = torch.randint(0, C, (B, H, W), generator=g)
+    up = F.interpolate(low, size=(H, W), mode='bilinear', align_corners=False)
+    p = torch.softmax(up, 1)
+    oh = F.one_hot(lab, C).permute(0, 3, 1, 2).float()
+    loss = sum(1 - (1 + 2 * (p[:, c] * oh[:, c]).sum()) / (1 + p[:, c].sum() + oh[:, c].sum()) for c in range(C))
+    (loss * 1.7).backward()
+    ld = low.detach().permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    lr = ops.LowResLogits(ld, (H, W))
+    assert lr.fusable()
+    out = ops.softmax_dice_upsampled(lr, lab.to(torch.uint8).cuda())
+    (out * 1.7).backward()
+    torch.testing.assert_close(out.detach().cpu(), loss.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ld.grad.cpu().permute(0, 3, 1, 2), low.grad, rtol=1e-4, atol=1e-7 + 1e-4 * low.grad.abs().max().item())
+    torch.testing.assert_close(lr.dense().detach().cpu(), up.detach(), rtol=1e-5, atol=1e-5)
+    # and the unfused route (non-integer scale) gives the same criterion through the materialised tensor
+    lr2 = ops.LowResLogits(ld.detach(), (H + 1, W))
+    assert not lr2.fusable()

@@ -532,3 +532,29 @@ def test_training_improves_validation_dice(tmp_path):
     print('val Dice before', before, 'after', after)
     assert after > before + 0.15 and after > 0.5, (before, after)
 
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_aux_heads_equal_the_materialised_route(dtype, tmp_path):
+    """KiteSeg.calc_loss hands the three deep-supervision heads to the criterion at their own resolution (ops.LowResLogits, fused
+    resize + softmax + Dice); with fuse_aux_loss=False the resized logits are materialised as in the reference.  Same loss, same gradients."""
+    import tcct_oracle as O
+    img, lab = O.synth_batch(2, 64, 96, seed=9)
+    img, lab = img.cuda(), lab.cuda()
+    res = []
+    for fuse in (True, False):
+        model, _ = build(dtype)
+        model.base.base_vit.drop_probs = [0.0] * 4
+        k = make_kite(model, tmp_path, False, False)
+        k.fuse_aux_loss = fuse
+        tot, _ = k.calc_loss(img, lab, want_log=False)
+        tot.backward()
+        grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+        res.append((tot.item(), grads))
+    (l1, g1), (l0, g0) = res
+    assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0)), (l1, l0)
+    assert g1.keys() == g0.keys()
+    tol_ = 1e-4 if dtype == torch.float32 else 3e-2      # bf16: the two routes only share the fp32 loss side, upstream grads are re-rounded
+    for n in ('base.aux1.weight', 'base.aux2.bias', 'base.aux4.weight', 'base.t321.weight', 'base.dec1.post.0.weight', 'base.base_cnn.cnn.0.weight'):
+        d = (g1[n] - g0[n]).abs().max().item()
+        assert d <= tol_ * max(1e-6, g0[n].abs().max().item()), (n, d, g0[n].abs().max().item())
