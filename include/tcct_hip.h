@@ -256,6 +256,13 @@ int tcct_bilinear_bwd(const void* dy, void* dx, int N, int H, int W, int C, int 
 /* ---- F.normalize(dim=channel, p=2, eps) (nets/tcct.py:940) ------------------------------------------------ */
 int tcct_l2norm_fwd(const void* x, void* y, int64_t M, int C, float eps, int dtype, tcct_stream_t stream);
 int tcct_l2norm_bwd(const void* x, const void* dy, void* dx, int64_t M, int C, float eps, int dtype, tcct_stream_t stream);
+int tcct_l2norm_bwd_scaled(const void* x, const void* dy, void* dx, int64_t M, int C, float eps, float scale, int dtype,
+                           tcct_stream_t stream);
+/* norm_add (nets/tcct.py:937-942), the `feats` side output of FTC.forward: out = (l2n(g0) + resize(l2n(g1)) + resize(l2n(g2))) / 3 with
+ * F.interpolate(bilinear, align_corners=False) to g0's size, in one pass over g0 / out.  g0 [N,H,W,C], g1 [N,h1,w1,C], g2 [N,h2,w2,C];
+ * inv1 / inv2: fp32 workspaces [N*h1*w1] / [N*h2*w2] (the coarse maps' inverse norms, written by a small pre-pass) */
+int tcct_normadd_fwd(const void* g0, const void* g1, const void* g2, float* inv1, float* inv2, void* out, int N, int H, int W, int C,
+                     int h1, int w1, int h2, int w2, float eps, int dtype, tcct_stream_t stream);
 
 /* ---- MultiLoss(DiceLoss) (kite/losses/loss.py:83-99,15-32): softmax over C fused with the batch-global sums
  * sums[3][C] = {sum p*g, sum p, sum g}; loss = sum_c 1 - (1+2I)/(1+P+G).  labels: class index uint8 [M] ----- */

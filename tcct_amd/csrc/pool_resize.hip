@@ -522,7 +522,7 @@ extern "C" int tcct_gate_fusion_bwd(const void* dy, const float* field, void* dx
 // ------------------------------------------------------------------------------------------ L2 normalise over C
 // LP = C/4 lanes per pixel (power of two <= 64)
 template <typename T, bool BWD>
-__global__ void k_l2norm(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, int64_t M, int C, float eps) {
+__global__ void k_l2norm(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, int64_t M, int C, float eps, float oscale) {
     const int LP = C >> 2;
     const int64_t total = M * LP;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;     // multiple of 64 -> lanes of a pixel stay together
@@ -547,7 +547,7 @@ __global__ void k_l2norm(const T* __restrict__ x, const T* __restrict__ dy, T* _
             // y = x/d ; dx = dy/d - x * (x.dy) / (d^2 * nrm)   when nrm > eps, else dy/eps
             float coef = nrm > eps ? dot / (d * d * nrm) : 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) r.v[k] = g.v[k] / d - v.v[k] * coef;
+            for (int k = 0; k < 4; ++k) r.v[k] = oscale * (g.v[k] / d - v.v[k] * coef);
         }
         if (ok) st4(out + ii * 4, r);
     }
@@ -555,12 +555,90 @@ __global__ void k_l2norm(const T* __restrict__ x, const T* __restrict__ dy, T* _
 extern "C" int tcct_l2norm_fwd(const void* x, void* y, int64_t M, int C, float eps, int dtype, tcct_stream_t stream) {
     int LP = C / 4;
     TCCT_CHECK(C % 4 == 0 && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, "l2norm_fwd: C=%d unsupported", C);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_l2norm<T, false>), dim3(tcct_grid(M * LP, PB, 1 << 16)), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, (T*)y, M, C, eps));
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_l2norm<T, false>), dim3(tcct_grid(M * LP, PB, 1 << 16)), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, (T*)y, M, C, eps, 1.f));
+    TCCT_LAUNCH_OK();
+}
+static int l2norm_bwd_impl(const void* x, const void* dy, void* dx, int64_t M, int C, float eps, float oscale, int dtype, tcct_stream_t stream) {
+    int LP = C / 4;
+    TCCT_CHECK(C % 4 == 0 && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, "l2norm_bwd: C=%d unsupported", C);
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_l2norm<T, true>), dim3(tcct_grid(M * LP, PB, 1 << 16)), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, M, C, eps, oscale));
     TCCT_LAUNCH_OK();
 }
 extern "C" int tcct_l2norm_bwd(const void* x, const void* dy, void* dx, int64_t M, int C, float eps, int dtype, tcct_stream_t stream) {
-    int LP = C / 4;
-    TCCT_CHECK(C % 4 == 0 && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, "l2norm_bwd: C=%d unsupported", C);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_l2norm<T, true>), dim3(tcct_grid(M * LP, PB, 1 << 16)), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, M, C, eps));
+    return l2norm_bwd_impl(x, dy, dx, M, C, eps, 1.f, dtype, stream);
+}
+/* dx = scale * l2norm_bwd(x, dy): the 1/3 of norm_add's mean (nets/tcct.py:937-942) rides on the pass instead of a separate scaling */
+extern "C" int tcct_l2norm_bwd_scaled(const void* x, const void* dy, void* dx, int64_t M, int C, float eps, float scale, int dtype,
+                                      tcct_stream_t stream) {
+    return l2norm_bwd_impl(x, dy, dx, M, C, eps, scale, dtype, stream);
+}
+
+// ------------------------------------------------- norm_add (nets/tcct.py:937-942): mean of three L2-normalised maps at the first one's size
+// out = (l2n(g0) + resize(l2n(g1)) + resize(l2n(g2))) / 3 in ONE pass over g0 / out: the inverse norms of the two coarser maps come from a
+// small pre-pass (fp32 [N,h,w] each), the normalised coarse maps and both resized copies are never written.
+template <typename T>
+__global__ void k_invnorm(const T* __restrict__ x, float* __restrict__ inv, int64_t M, int C, float eps) {
+    const int LP = C >> 2;
+    const int64_t total = M * LP;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t rounds = (total + stride - 1) / stride;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t it = 0; it < rounds; ++it, i += stride) {
+        const bool ok = i < total;
+        const int64_t ii = ok ? i : 0;
+        const f4 v = ld4(x + ii * 4);
+        float ss = v.v[0] * v.v[0] + v.v[1] * v.v[1] + v.v[2] * v.v[2] + v.v[3] * v.v[3];
+        for (int o = LP >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (ok && (ii % LP) == 0) inv[ii / LP] = 1.f / fmaxf(sqrtf(ss), eps);
+    }
+}
+template <typename T>
+__global__ void k_normadd_fwd(const T* __restrict__ g0, const T* __restrict__ g1, const T* __restrict__ g2, const float* __restrict__ inv1,
+                              const float* __restrict__ inv2, T* __restrict__ out, int N, int H, int W, int C, int h1, int w1, int h2, int w2,
+                              float eps) {
+    const int LP = C >> 2;                                  // lanes per pixel (power of two <= 64): the pixel's norm is a lane-group reduce
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;    // blockDim.x is a multiple of 64 -> lane groups stay inside a wave
+    const bool ok = i < W * LP;
+    const int wo = ok ? i / LP : 0, c = ok ? (i - wo * LP) * 4 : 0;
+    const Lerp b1 = src_index(wo, (float)w1 / (float)W, w1, 0), b2 = src_index(wo, (float)w2 / (float)W, w2, 0);
+    for (int row = blockIdx.y; row < N * H; row += gridDim.y) {
+        const int n = row / H, ho = row - n * H;
+        const f4 v = ld4(g0 + ((int64_t)row * W + wo) * C + c);
+        float ss = v.v[0] * v.v[0] + v.v[1] * v.v[1] + v.v[2] * v.v[2] + v.v[3] * v.v[3];
+        for (int o = LP >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float d0 = fmaxf(sqrtf(ss), eps);
+        const Lerp a1 = src_index(ho, (float)h1 / (float)H, h1, 0), a2 = src_index(ho, (float)h2 / (float)H, h2, 0);
+        f4 r;
+        {
+            const int64_t r0 = ((int64_t)n * h1 + a1.i0) * w1, r1 = ((int64_t)n * h1 + a1.i1) * w1;
+            const f4 x00 = ld4(g1 + (r0 + b1.i0) * C + c), x01 = ld4(g1 + (r0 + b1.i1) * C + c);
+            const f4 x10 = ld4(g1 + (r1 + b1.i0) * C + c), x11 = ld4(g1 + (r1 + b1.i1) * C + c);
+            const float i00 = inv1[r0 + b1.i0], i01 = inv1[r0 + b1.i1], i10 = inv1[r1 + b1.i0], i11 = inv1[r1 + b1.i1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r.v[k] = v.v[k] / d0 + (a1.l0 * (b1.l0 * (x00.v[k] * i00) + b1.l1 * (x01.v[k] * i01)) + a1.l1 * (b1.l0 * (x10.v[k] * i10) + b1.l1 * (x11.v[k] * i11)));
+        }
+        {
+            const int64_t r0 = ((int64_t)n * h2 + a2.i0) * w2, r1 = ((int64_t)n * h2 + a2.i1) * w2;
+            const f4 x00 = ld4(g2 + (r0 + b2.i0) * C + c), x01 = ld4(g2 + (r0 + b2.i1) * C + c);
+            const f4 x10 = ld4(g2 + (r1 + b2.i0) * C + c), x11 = ld4(g2 + (r1 + b2.i1) * C + c);
+            const float i00 = inv2[r0 + b2.i0], i01 = inv2[r0 + b2.i1], i10 = inv2[r1 + b2.i0], i11 = inv2[r1 + b2.i1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r.v[k] = (r.v[k] + (a2.l0 * (b2.l0 * (x00.v[k] * i00) + b2.l1 * (x01.v[k] * i01)) + a2.l1 * (b2.l0 * (x10.v[k] * i10) + b2.l1 * (x11.v[k] * i11)))) * (1.f / 3.f);
+        }
+        if (ok) st4(out + ((int64_t)row * W + wo) * C + c, r);
+    }
+}
+/* g0 [N,H,W,C], g1 [N,h1,w1,C], g2 [N,h2,w2,C] -> out [N,H,W,C]; inv1 / inv2: fp32 workspaces [N*h1*w1] / [N*h2*w2] (written here) */
+extern "C" int tcct_normadd_fwd(const void* g0, const void* g1, const void* g2, float* inv1, float* inv2, void* out, int N, int H, int W,
+                                int C, int h1, int w1, int h2, int w2, float eps, int dtype, tcct_stream_t stream) {
+    const int LP = C / 4;
+    TCCT_CHECK(C % 4 == 0 && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, "normadd_fwd: C=%d unsupported", C);
+    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1 && h1 >= 1 && w1 >= 1 && h2 >= 1 && w2 >= 1 && inv1 && inv2, "normadd_fwd: bad shapes / NULL workspace");
+    hipStream_t st = (hipStream_t)stream;
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_invnorm<T>, dim3(tcct_grid((int64_t)N * h1 * w1 * LP, PB, 1 << 16)), dim3(PB), 0, st, (const T*)g1, inv1, (int64_t)N * h1 * w1, C, eps));
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_invnorm<T>, dim3(tcct_grid((int64_t)N * h2 * w2 * LP, PB, 1 << 16)), dim3(PB), 0, st, (const T*)g2, inv2, (int64_t)N * h2 * w2, C, eps));
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_normadd_fwd<T>, row_grid(W * LP, (int64_t)N * H, 8192), dim3(PB), 0, st, (const T*)g0, (const T*)g1, (const T*)g2, inv1, inv2, (T*)out, N, H, W, C, h1, w1, h2, w2, eps));
     TCCT_LAUNCH_OK();
 }

@@ -471,10 +471,7 @@ class FTC(nn.Module):
                 raise TcctError('the legacy-head layout (onnx/tcct_goals.py) is supported for inference and Dice/boundary training; its '
                                 'six-tensor `feats` (tcct_goals.py:1021) is not built')
             g0, g1, g2, size = self._feats_src
-            n0 = ops.l2norm(g0)
-            n1 = ops.bilinear(ops.l2norm(g1), size, False)
-            n2 = ops.bilinear(ops.l2norm(g2), size, False)
-            self._feats = [_nchw_view(ops.add3_scale(n0, n1, n2, 1.0 / 3.0))]
+            self._feats = [_nchw_view(ops.norm_add3(g0, g1, g2))]
             self._feats_src = None
         return self._feats
 

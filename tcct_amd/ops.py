@@ -1231,6 +1231,55 @@ def l2norm(x, eps=1e-12):
     return _L2Norm.apply(x, float(eps))
 
 
+class _NormAdd(torch.autograd.Function):
+    """norm_add([g0, g1, g2]) (reference nets/tcct.py:937-942): mean of the three L2-normalised maps at g0's size.  Forward: one pass
+    (tcct_normadd_fwd); backward: the existing resize / normalise gradients with the 1/3 folded into the last kernel of each chain."""
+
+    @staticmethod
+    def forward(ctx, g0, g1, g2, eps):
+        _chk(g0, g1, g2)
+        N, H, W, C = g0.shape
+        (_, h1, w1, _), (_, h2, w2, _) = g1.shape, g2.shape
+        out = torch.empty_like(g0)
+        inv1 = torch.empty(N * h1 * w1, device=g0.device, dtype=torch.float32)
+        inv2 = torch.empty(N * h2 * w2, device=g0.device, dtype=torch.float32)
+        lib.normadd_fwd(g0, g1, g2, inv1, inv2, out, N, H, W, C, h1, w1, h2, w2, eps, dtype_code(g0.dtype))
+        ctx.save_for_backward(g0, g1, g2)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        g0, g1, g2 = ctx.saved_tensors
+        dy = _as(dy, g0.dtype)
+        N, H, W, C = g0.shape
+        dc = dtype_code(g0.dtype)
+        outs = []
+        for g in (g0, g1, g2):
+            h, w = g.shape[1], g.shape[2]
+            if (h, w) == (H, W):
+                dn = dy
+            else:
+                dn = torch.empty_like(g)
+                lib.bilinear_bwd(dy, dn, N, h, w, C, H, W, 0, dc)
+            d = torch.empty_like(g)
+            lib.l2norm_bwd_scaled(g, dn, d, g.numel() // C, C, ctx.eps, 1.0 / 3.0, dc)
+            outs.append(d)
+        return outs[0], outs[1], outs[2], None
+
+
+def norm_add3(g0, g1, g2, eps=1e-12):
+    """fused norm_add for three maps with the same channel count (C % 4 == 0, C/4 a power of two <= 64); g1 / g2 coarser than g0"""
+    C = g0.shape[-1]
+    lp = C // 4
+    ok = (g0.dim() == 4 and g1.shape[-1] == C and g2.shape[-1] == C and C % 4 == 0 and 1 <= lp <= 64 and lp & (lp - 1) == 0
+          and g0.dtype == g1.dtype == g2.dtype and tuple(g1.shape[1:3]) != tuple(g0.shape[1:3]) and tuple(g2.shape[1:3]) != tuple(g0.shape[1:3]))
+    if not ok:
+        size = tuple(g0.shape[1:3])
+        return add3_scale(l2norm(g0, eps), bilinear(l2norm(g1, eps), size, False), bilinear(l2norm(g2, eps), size, False), 1.0 / 3.0)
+    return _NormAdd.apply(g0, g1, g2, float(eps))
+
+
 # ------------------------------------------------------------------------------------------------ losses
 class _SoftmaxDice(torch.autograd.Function):
     @staticmethod

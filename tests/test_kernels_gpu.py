@@ -822,3 +822,34 @@ def test_upsampled_dice_matches_interpolate_softmax_dice(cfg):
     # and the unfused route (non-integer scale) gives the same criterion through the materialised tensor
     lr2 = ops.LowResLogits(ld.detach(), (H + 1, W))
     assert not lr2.fusable()
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('cfg', [(32, 16, 24), (32, 40, 56), (16, 8, 8)])
+def test_norm_add_fused(dt, cfg):
+    """norm_add (reference nets/tcct.py:937-942): (normalize(g0) + resize(normalize(g1)) + resize(normalize(g2))) / 3 in one pass, and
+    its three input gradients"""
+    from tcct_amd import ops
+    C, H, W = cfg
+    N = 2
+    gs = [rnd(N, C, H >> i, W >> i, seed=i, dt=dt).requires_grad_(True) for i in range(3)]
+    with torch.no_grad():
+        gs[1][0, :, 0, 0] = 0.0                 # a zero vector: normalize() divides by eps, gradient dy / eps
+    ns = [F.normalize(g, p=2, dim=1) for g in gs]
+    ref = (ns[0] + F.interpolate(ns[1], size=(H, W), mode='bilinear', align_corners=False)
+           + F.interpolate(ns[2], size=(H, W), mode='bilinear', align_corners=False)) / 3
+    go = rnd(*ref.shape, seed=5, dt=dt) * 1e-3      # small: the zero vector's gradient is go / 1e-12
+    ref.backward(go)
+    gd = [nhwc(g.detach(), dt).requires_grad_(True) for g in gs]
+    out = ops.norm_add3(*gd)
+    t = tol(dt)
+    torch.testing.assert_close(nchw(out), ref.detach(), **t)
+    out.backward(nhwc(go, dt))
+    for a, b in zip(gd, gs):
+        ga, gb = nchw(a.grad), b.grad
+        mask = torch.ones_like(gb, dtype=torch.bool)
+        if b is gs[1]:
+            mask[0, :, 0, 0] = False              # the 1/eps-scaled entries are compared relatively below
+            z = gb[0, :, 0, 0]                   # (bf16 rounds the resized gradient before the 1/eps: bound relative to the vector)
+            torch.testing.assert_close(ga[0, :, 0, 0], z, rtol=1e-3, atol=(3e-2 if dt != torch.float32 else 1e-4) * z.abs().max().item())
+        torch.testing.assert_close(ga[mask], gb[mask], rtol=t['rtol'], atol=t['atol'] * max(1e-3, gb[mask].abs().max().item()))
