@@ -147,6 +147,8 @@ int tcct_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, in
  * wp = weights packed by tcct_conv32_pack_weights to bf16 [KH*KW][32 co][32 ci]; transposed=1 packs the flipped/transposed
  * weights so that the same kernel computes the input gradient (dx = conv32_fwd(dy, wp_T, NULL)). */
 int tcct_conv32_pack_weights(const float* w, void* wp, int KH, int KW, int transposed, tcct_stream_t stream);
+/* both packs in one launch: wp2 [2][KH*KW*1024] = {forward pack, input-gradient pack}; the backward pass reuses the second half */
+int tcct_conv32_pack_weights_both(const float* w, void* wp2, int KH, int KW, tcct_stream_t stream);
 int tcct_conv32_fwd(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
                     int PW, tcct_stream_t stream);
 

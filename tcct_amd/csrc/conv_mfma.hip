@@ -25,14 +25,22 @@ __global__ void k_pack_w32(const float* __restrict__ w, bf16* __restrict__ wp, i
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         int ci = i & 31, co = (i >> 5) & 31, tap = i >> 10;
         int dy = tap / KW, dx = tap % KW;
-        float v = transposed ? w[(((int64_t)(o_off + ci) * ldi + i_off + co) * KH + (KH - 1 - dy)) * KW + (KW - 1 - dx)]
-                             : w[(((int64_t)(o_off + co) * ldi + i_off + ci) * KH + dy) * KW + dx];
-        wp[i] = __float2bfloat16(v);
+        const float vt = w[(((int64_t)(o_off + ci) * ldi + i_off + co) * KH + (KH - 1 - dy)) * KW + (KW - 1 - dx)];
+        const float vn = w[(((int64_t)(o_off + co) * ldi + i_off + ci) * KH + dy) * KW + dx];
+        if (transposed == 2) { wp[i] = __float2bfloat16(vn); wp[total + i] = __float2bfloat16(vt); }     // both packs, one launch
+        else wp[i] = __float2bfloat16(transposed ? vt : vn);
     }
 }
 extern "C" int tcct_conv32_pack_weights(const float* w, void* wp, int KH, int KW, int transposed, tcct_stream_t stream) {
     int total = KH * KW * 1024;
     hipLaunchKernelGGL(k_pack_w32, dim3((total + MB - 1) / MB), dim3(MB), 0, (hipStream_t)stream, w, (bf16*)wp, KH, KW, transposed, 32, 0, 0);
+    TCCT_LAUNCH_OK();
+}
+/* wp2 [2][KH*KW][32][32]: the forward pack followed by the input-gradient (flipped + transposed) pack -- the backward pass of the same
+ * step reuses the second half instead of launching another pack */
+extern "C" int tcct_conv32_pack_weights_both(const float* w, void* wp2, int KH, int KW, tcct_stream_t stream) {
+    int total = KH * KW * 1024;
+    hipLaunchKernelGGL(k_pack_w32, dim3((total + MB - 1) / MB), dim3(MB), 0, (hipStream_t)stream, w, (bf16*)wp2, KH, KW, 2, 32, 0, 0);
     TCCT_LAUNCH_OK();
 }
 extern "C" int tcct_conv32_pack_weights_sub(const float* w, void* wp, int KH, int KW, int transposed, int cin_total, int o_off,

@@ -219,8 +219,13 @@ class _Conv2d(torch.autograd.Function):
         elif _mfma_slabs_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
             _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, False)
         elif mfma:
-            wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
-            lib.conv32_pack_weights(w, wp, KH, KW, 0)
+            if ctx.needs_input_grad[0]:     # the input-gradient pack of the same weights comes out of the same launch (used by backward())
+                wp2 = torch.empty(2 * KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
+                lib.conv32_pack_weights_both(w, wp2, KH, KW)
+                wp, ctx.wp_t = wp2[:KH * KW * 1024], wp2[KH * KW * 1024:]
+            else:
+                wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
+                lib.conv32_pack_weights(w, wp, KH, KW, 0)
             if stats_box is not None:       # fused train-mode BN statistics of the consumer (stats_box = [pre_act_code, None])
                 sums = ZERO.get((64,), torch.float64, x.device) if ZERO.active else torch.zeros(64, device=x.device, dtype=torch.float64)
                 lib.conv32_fwd_bnstats(x, wp, bias, y, N, H, W, KH, KW, padh, padw, sums, stats_box[0])
@@ -264,8 +269,10 @@ class _Conv2d(torch.autograd.Function):
             elif _mfma_slabs_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
                 _conv_slabs_fwd(dy, w, None, dx, N, H, W, Cout, Cin, KH, KW, KH - 1 - padh, KW - 1 - padw, True)
             elif _mfma32_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
-                wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
-                lib.conv32_pack_weights(w, wp, KH, KW, 1)
+                wp = getattr(ctx, 'wp_t', None)
+                if wp is None:
+                    wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
+                    lib.conv32_pack_weights(w, wp, KH, KW, 1)
                 if dskip is not None:
                     lib.conv32_fwd_add(dy, wp, None, dskip, dx, N, H, W, KH, KW, KH - 1 - padh, KW - 1 - padw)
                     dskip = None
