@@ -193,6 +193,8 @@ def main():
         raise SystemExit(f'--gpus={a.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X')
+    if os.environ.get('TCCT_DIST_BACKEND') == 'gloo':      # test mode: several ranks share the GPUs that exist (RCCL needs one GPU per rank)
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if a.roofline_only:
         print(json.dumps({'roofline': dominant_kernel_roofline(a)}))
