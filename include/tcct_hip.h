@@ -337,6 +337,35 @@ int tcct_fpl_forward(const void* feat, const uint64_t* keys_sorted, const uint32
 int tcct_fpl_backward(const uint8_t* labels, const uint8_t* binmap, const float* dpro_over_n, const float* grad_out,
                       float grad_scale, int64_t M, void* dfeat, int dtype, tcct_stream_t stream);
 
+/* ---- factorised attention with convolutional relative position encoding: FactorAtt_ConvRelPosEnc.forward
+ * nets/tcct.py:311-341 and ConvRelPosEnc.forward nets/tcct.py:265-287, the token mixer the reference keeps commented out in MHCABlock
+ * (tcct.py:436-449).  qkv [B,N,3C] is the output of the qkv Linear (tcct.py:316-318: channel = which*C + head*Ch + ch, Ch = C/heads a
+ * multiple of 4, C <= 256); M, dM fp32 [B,heads,Ch,Ch]; stats fp32 [B,C,2] = (max_n k, 1 / sum_n exp(k - max)); cv [B,N,C] = the crpe
+ * depthwise convolutions of v.  The per-head contractions are Ch x Ch (8..20): VALU with M in LDS; qkv / proj are tcct_pw_* GEMMs. */
+int64_t tcct_fatt_kstats_workspace_bytes(int B, int64_t N, int C);
+/* k.softmax(dim=2) statistics (tcct.py:321) */
+int tcct_fatt_kstats(const void* qkv, void* workspace, float* stats, int B, int64_t N, int C, int heads, int dtype, tcct_stream_t stream);
+/* M = softmax_N(k)^T v (tcct.py:322); accumulation output: cleared here unless tcct_set_outputs_prezeroed(1) */
+int tcct_fatt_ktv(const void* qkv, const float* stats, float* M, int B, int64_t N, int C, int heads, int dtype, tcct_stream_t stream);
+/* dM = scale * q^T dout (gradient of M; same clearing rule) */
+int tcct_fatt_dktv(const void* qkv, const void* dout, float* dM, float scale, int B, int64_t N, int C, int heads, int dtype,
+                   tcct_stream_t stream);
+/* out [B,N,C] = scale * q M + q * cv (tcct.py:323-331, 284-285; already in the transpose(1,2).reshape(B,N,C) layout) */
+int tcct_fatt_apply_fwd(const void* qkv, const float* M, const void* cv, void* out, float scale, int B, int64_t N, int C, int heads,
+                        int dtype, tcct_stream_t stream);
+/* dqkv [B,N,3C] = (scale dout M^T + dout cv | P (v dM^T - D) | P dM), dcv [B,N,C] = dout * q; the crpe convolution's share of dv is added by
+ * tcct_dwk_strided_fwd(flip=1, accumulate=1) on dcv afterwards */
+int tcct_fatt_apply_bwd(const void* qkv, const float* stats, const float* M, const float* dM, const void* cv, const void* dout,
+                        void* dqkv, void* dcv, float scale, int B, int64_t N, int C, int heads, int dtype, tcct_stream_t stream);
+/* depthwise K x K (K in 3,5,7), stride 1, 'same' zero padding on one channel group of NHWC rows (ConvRelPosEnc.conv_list, tcct.py:247-262):
+ * x / y point at the group's first channel, pixel strides ldx / ldy in elements (multiples of 4, like Cg); w fp32 OIHW [Cg,1,K,K]; bias fp32
+ * [Cg] or NULL; flip = taps rotated by 180 degrees (the input gradient); accumulate = add to y */
+int tcct_dwk_strided_fwd(const void* x, int64_t ldx, const float* w, const float* bias, void* y, int64_t ldy, int B, int H, int W, int Cg,
+                         int K, int flip, int accumulate, int dtype, tcct_stream_t stream);
+/* dw [Cg,1,K,K] = sum dy * shifted x, dbias [Cg] = sum dy (nullable); accumulation outputs */
+int tcct_dwk_strided_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, float* dbias, int B, int H, int W, int Cg,
+                           int K, int dtype, tcct_stream_t stream);
+
 /* ---- clip_grad_norm_(12) + AdamW on flat fp32 buffers (kite/loop_seg.py:128-130, kite/loopback.py:127) ------ */
 int tcct_grad_sumsq(const float* g, int64_t n, double* acc, tcct_stream_t stream);
 /* grad_mul pre-scales the raw gradient (1/world_size after a sum all-reduce); total_norm_out nullable */

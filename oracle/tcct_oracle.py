@@ -68,6 +68,35 @@ def metapool(t):
     return F.avg_pool2d(t, 3, 1, 1, count_include_pad=False) - t
 
 
+def factor_att_mix(x, qkv_w, qkv_b, crpe_wb, size, heads, qk_scale=None):
+    """FactorAtt_ConvRelPosEnc.forward up to (not including) the output projection, nets/tcct.py:311-331, with
+    ConvRelPosEnc.forward nets/tcct.py:265-287 inlined.  x [B,N,C] tokens, size = (H, W); crpe_wb = [(weight [Cg,1,k,k], bias [Cg]), ...]
+    in conv_list order (window {3:2, 5:3, 7:3} over 8 heads, tcct.py:484-488).  The reference keeps this mixer commented out
+    (tcct.py:436-449); restated for SURVEY 8(f)4 and pinned by tests/golden/factoratt_*.npz (oracle/make_golden_factoratt.py)."""
+    B, N, C = x.shape
+    H, W = size
+    Ch = C // heads
+    scale = qk_scale or Ch ** -0.5                                                  # tcct.py:305
+    qkv = F.linear(x, qkv_w, qkv_b).reshape(B, N, 3, heads, Ch).permute(2, 0, 3, 1, 4)     # tcct.py:316-317
+    q, k, v = qkv[0], qkv[1], qkv[2]                                                # [B,h,N,Ch]
+    ktv = torch.einsum('bhnk,bhnv->bhkv', k.softmax(dim=2), v)                      # tcct.py:321-322
+    att = torch.einsum('bhnk,bhkv->bhnv', q, ktv)                                   # tcct.py:323-324
+    v_img = v.permute(0, 1, 3, 2).reshape(B, C, H, W)                               # "B h (H W) Ch -> B (h Ch) H W", tcct.py:275
+    parts, off = [], 0
+    for w, b in crpe_wb:                                                            # tcct.py:277-281
+        cg, kk = w.shape[0], w.shape[2]
+        parts.append(F.conv2d(v_img[:, off:off + cg], w, b, 1, kk // 2, 1, cg))
+        off += cg
+    conv_v = torch.cat(parts, 1).reshape(B, heads, Ch, N).permute(0, 1, 3, 2)       # tcct.py:283
+    y = scale * att + q * conv_v                                                    # tcct.py:285, 330
+    return y.transpose(1, 2).reshape(B, N, C)                                       # tcct.py:331
+
+
+def factor_att(x, qkv_w, qkv_b, proj_w, proj_b, crpe_wb, size, heads, qk_scale=None):
+    """FactorAtt_ConvRelPosEnc.forward, nets/tcct.py:311-341 (attn_drop / proj_drop = DROP_RATE = 0, tcct.py:26)."""
+    return F.linear(factor_att_mix(x, qkv_w, qkv_b, crpe_wb, size, heads, qk_scale), proj_w, proj_b)
+
+
 def vit_stage(sd, p_pe, p_st, x, s, train, dp_masks):
     """Patch_Embed_stage (tcct.py:173-195) + MHCA_stage.forward (tcct.py:604-616) for stage s.
     dp_masks: None (no DropPath) or (mask_a[B], mask_b[B]) 0/1 tensors for the two residual branches."""
@@ -97,7 +126,13 @@ def vit_stage(sd, p_pe, p_st, x, s, train, dp_masks):
 
     ma, mb = dp_masks if dp_masks is not None else (None, None)
     cur = F.layer_norm(t, (C,), sd[blk + '.norm1.weight'], sd[blk + '.norm1.bias'], 1e-6)
-    t = t + dp(metapool(cur), ma)
+    if (blk + '.att.qkv.weight') in sd:     # the reference's commented-out mixer (tcct.py:443-448), 8 heads, shared crpe (tcct.py:484-501)
+        crpe = [(sd[f'{p_st}.mhca_blks.0.crpe.conv_list.{i}.weight'], sd[f'{p_st}.mhca_blks.0.crpe.conv_list.{i}.bias']) for i in range(3)]
+        a = factor_att(cur, sd[blk + '.att.qkv.weight'], sd.get(blk + '.att.qkv.bias'), sd[blk + '.att.proj.weight'],
+                       sd[blk + '.att.proj.bias'], crpe, (H, W), 8)
+    else:
+        a = metapool(cur)                   # `self.att = MetaPool()`, tcct.py:449
+    t = t + dp(a, ma)
     cur = F.layer_norm(t, (C,), sd[blk + '.norm2.weight'], sd[blk + '.norm2.bias'], 1e-6)
     h = F.gelu(F.linear(cur, sd[blk + '.mlp.fc1.weight'], sd[blk + '.mlp.fc1.bias']))
     t = t + dp(F.linear(h, sd[blk + '.mlp.fc2.weight'], sd[blk + '.mlp.fc2.bias']), mb)
@@ -348,7 +383,7 @@ def formula_tensor(name, shape):
 def canonical_key(k):
     """state_dict keys `…mhca_blks.0.MHCA_layers.0.{cpe,crpe}.*` alias the shared `…mhca_blks.0.{cpe,crpe}.*`
     modules (tcct.py:491-505)."""
-    return k.replace('.MHCA_layers.0.cpe.', '.cpe.').replace('.MHCA_layers.0.crpe.', '.crpe.')
+    return k.replace('.MHCA_layers.0.cpe.', '.cpe.').replace('.MHCA_layers.0.att.crpe.', '.crpe.').replace('.MHCA_layers.0.crpe.', '.crpe.')
 
 
 def formula_state_dict(key_shapes):

@@ -208,13 +208,47 @@ class ConvPosEnc(nn.Module):
 
 
 class ConvRelPosEnc(nn.Module):
-    """reference nets/tcct.py:219-287 — parameters only (never executed by stc_tt; kept for checkpoint parity)."""
+    """reference nets/tcct.py:219-287.  With the default pooling mixer these are parameters only (never executed by stc_tt; kept for
+    checkpoint parity); with `att='factor'` FactorAtt_ConvRelPosEnc runs them through `ops.factor_att` (depthwise 3/5/7 windows over
+    the head splits of v, times q)."""
 
     def __init__(self, Ch, h, window):
         super().__init__()
+        if isinstance(window, int):
+            window = {window: h}
+        elif not isinstance(window, dict):
+            raise ValueError()          # reference tcct.py:245
         self.conv_list = nn.ModuleList()
+        self.head_splits = []
         for k, split in window.items():
             self.conv_list.append(nn.Conv2d(split * Ch, split * Ch, (k, k), padding=(k // 2, k // 2), groups=split * Ch))
+            self.head_splits.append(split)
+        self.channel_splits = [x * Ch for x in self.head_splits]
+
+
+class FactorAtt_ConvRelPosEnc(nn.Module):
+    """reference nets/tcct.py:289-341: the factorised-attention token mixer the reference keeps commented out in
+    MHCABlock (tcct.py:436-449).  qkv / proj are the pointwise GEMMs; softmax over the tokens, the per-head K^T V and Q (K^T V)
+    contractions and the convolutional relative position term are the `tcct_fatt_*` / `tcct_dwk_*` kernels.  The crpe head splits
+    (2+3+3) need num_heads = 8; attn_drop / proj_drop are 0 in the reference (DROP_RATE, tcct.py:26)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, shared_crpe=None):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.crpe = shared_crpe
+
+    def mix(self, x, size):
+        """everything up to (not including) the output projection: tokens [B,N,C] -> [B,N,C]"""
+        if sum(self.crpe.channel_splits) != x.shape[-1]:
+            raise ValueError(f'crpe head splits {self.crpe.head_splits} do not cover {self.num_heads} heads')
+        qkv = ops.conv2d(x, self.qkv.weight, self.qkv.bias)
+        return ops.factor_att(qkv, size, self.num_heads, self.scale, self.crpe.conv_list)
+
+    def forward(self, x, size):
+        return ops.conv2d(self.mix(x, size), self.proj.weight, self.proj.bias)
 
 
 class Mlp(nn.Module):
@@ -229,10 +263,14 @@ class Mlp(nn.Module):
 class MHCABlock(nn.Module):
     """reference nets/tcct.py:417-469 with `att = MetaPool()` (tcct.py:449): cpe -> x+dp(pool(LN1 x)) -> x+dp(mlp(LN2 x))"""
 
-    def __init__(self, dim, mlp_ratio, drop_path, shared_cpe, shared_crpe):
+    def __init__(self, dim, mlp_ratio, drop_path, shared_cpe, shared_crpe, att='pool', num_heads=8):
         super().__init__()
         self.cpe = shared_cpe
         self.crpe = shared_crpe
+        if att == 'factor':     # the commented-out alternative of the reference (tcct.py:443-448), qkv_bias=True (MHCABlock default :424)
+            self.att = FactorAtt_ConvRelPosEnc(dim, num_heads=num_heads, qkv_bias=True, shared_crpe=shared_crpe)
+        elif att != 'pool':
+            raise ValueError(f"att must be 'pool' (MetaPool, tcct.py:449) or 'factor', got {att!r}")
         self.mlp = Mlp(dim, dim * mlp_ratio)
         self.drop_prob = float(drop_path)
         self.norm1 = nn.LayerNorm(dim, eps=1e-6)
@@ -251,7 +289,11 @@ class MHCABlock(nn.Module):
         s1, s2 = scales if scales is not None else (None, None)
         # (the residual paths read aliases of t: their gradients are added inside the LayerNorm backward kernels)
         cur, t = ops.layernorm_fork(t, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        t = ops.metapool_residual(cur, t, s1)           # t + dp(pool(LN1 t)): mixer, DropPath scale and residual in one pass
+        att = getattr(self, 'att', None)
+        if att is not None:     # t + dp(proj(factor_att(LN1 t))): the projection GEMM carries the DropPath scale and the residual
+            t = ops.linear_residual(att.mix(cur, (H, W)), att.proj.weight, att.proj.bias, t, s1)
+        else:
+            t = ops.metapool_residual(cur, t, s1)       # t + dp(pool(LN1 t)): mixer, DropPath scale and residual in one pass
         cur, t = ops.layernorm_fork(t, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
             h = ops.act(ops.conv2d(cur, self.mlp.fc1.weight, self.mlp.fc1.bias), 'gelu')
@@ -264,11 +306,11 @@ class MHCABlock(nn.Module):
 class MHCAEncoder(nn.Module):
     """reference nets/tcct.py:471-516 (num_layers = 1)"""
 
-    def __init__(self, dim, num_heads, mlp_ratio, drop_path):
+    def __init__(self, dim, num_heads, mlp_ratio, drop_path, att='pool'):
         super().__init__()
         self.cpe = ConvPosEnc(dim, k=3)
         self.crpe = ConvRelPosEnc(Ch=dim // num_heads, h=num_heads, window={3: 2, 5: 3, 7: 3})
-        self.MHCA_layers = nn.ModuleList([MHCABlock(dim, mlp_ratio, drop_path, self.cpe, self.crpe)])
+        self.MHCA_layers = nn.ModuleList([MHCABlock(dim, mlp_ratio, drop_path, self.cpe, self.crpe, att=att, num_heads=num_heads)])
 
     def forward(self, x, scales, fork=False):
         return self.MHCA_layers[0](x, scales, fork)
@@ -298,9 +340,9 @@ class ResBlock(nn.Module):
 class MHCA_stage(nn.Module):
     """reference nets/tcct.py:574-616 (num_path = 1): cat[InvRes(x), Encoder(x)] -> 1x1 -> BN -> Hardswish"""
 
-    def __init__(self, embed_dim, out_embed_dim, num_heads, mlp_ratio, drop_path):
+    def __init__(self, embed_dim, out_embed_dim, num_heads, mlp_ratio, drop_path, att='pool'):
         super().__init__()
-        self.mhca_blks = nn.ModuleList([MHCAEncoder(embed_dim, num_heads, mlp_ratio, drop_path)])
+        self.mhca_blks = nn.ModuleList([MHCAEncoder(embed_dim, num_heads, mlp_ratio, drop_path, att=att)])
         self.InvRes = ResBlock(embed_dim)
         self.aggregate = Conv2d_BN(embed_dim * 2, out_embed_dim, act=True)
 
@@ -337,8 +379,11 @@ class MPViT(nn.Module):
     __name__ = 'mpvit'
 
     def __init__(self, embed_dims=(64, 96, 128, 160), mlp_ratios=(1, 1, 1, 1), num_heads=(4, 4, 4, 4),
-                 drop_path_rate=0.1, num_classes=1000):
+                 drop_path_rate=0.1, num_classes=1000, att='pool'):
         super().__init__()
+        if att == 'factor':     # the crpe windows {3:2, 5:3, 7:3} split 8 heads (tcct.py:484-488); mpvit_tiny's 4 only fit the pooling mixer
+            num_heads = (8, 8, 8, 8)
+        self.att = att
         self.num_stages = 4
         self.embed_dims = list(embed_dims)
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, 4)]
@@ -348,7 +393,7 @@ class MPViT(nn.Module):
         self.patch_embed_stages = nn.ModuleList([Patch_Embed_stage(embed_dims[i], isPool=i > 0) for i in range(4)])
         self.mhca_stages = nn.ModuleList([
             MHCA_stage(embed_dims[i], embed_dims[i + 1] if i + 1 < 4 else embed_dims[i], num_heads[i], mlp_ratios[i],
-                       dpr[i]) for i in range(4)])
+                       dpr[i], att=att) for i in range(4)])
         self.cls_head = Cls_head(embed_dims[-1], num_classes)
         for m in self.modules():
             if isinstance(m, nn.Linear):
@@ -563,7 +608,7 @@ class FTC(nn.Module):
 
 def stc_tt(n_class=8, **args):
     """reference nets/tcct.py:1090-1095"""
-    model = FTC(base_vit=mpvit_tiny(), base_cnn=CrossResNet(flag_tiny=True), out_channels=n_class,
+    model = FTC(base_vit=mpvit_tiny(att=args.get('att', 'pool')), base_cnn=CrossResNet(flag_tiny=True), out_channels=n_class,
                 compute_dtype=args.get('compute_dtype', torch.float32), legacy_heads=args.get('legacy_heads', False))
     model.__name__ = 'stctt'
     return model

@@ -1115,6 +1115,72 @@ def metapool(x):
     return _MetaPool.apply(x)
 
 
+class _FactorAtt(torch.autograd.Function):
+    """FactorAtt_ConvRelPosEnc.forward between the qkv and proj Linear layers (reference nets/tcct.py:316-331 + ConvRelPosEnc.forward
+    :265-287): out [B,N,C] = scale * q (softmax_N(k)^T v) + q * crpe(v), qkv [B,N,3C] (dormant in stc_tt)."""
+
+    @staticmethod
+    def forward(ctx, qkv, H, W, heads, scale, *wb):
+        _chk(qkv, *wb)
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        if C * 3 != C3 or H * W != N or C % heads or (C // heads) % 4:
+            raise TcctError(f'factor_att: qkv {tuple(qkv.shape)} does not fit size ({H},{W}) / heads {heads} (Ch must be a multiple of 4)')
+        if sum(w.shape[0] for w in wb[0::2]) != C:
+            raise TcctError('factor_att: the crpe window splits do not add up to the channel count')
+        Ch, dt, dev = C // heads, dtype_code(qkv.dtype), qkv.device
+        ws = torch.empty(lib.fatt_kstats_workspace_bytes(B, N, C), device=dev, dtype=torch.uint8)
+        stats = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
+        lib.fatt_kstats(qkv, ws, stats, B, N, C, heads, dt)
+        M = ZERO.get((B, heads, Ch, Ch), torch.float32, dev)
+        lib.fatt_ktv(qkv, stats, M, B, N, C, heads, dt)
+        cv = torch.empty((B, N, C), device=dev, dtype=qkv.dtype)
+        off = 0
+        for w, b in zip(wb[0::2], wb[1::2]):
+            Cg, K = w.shape[0], w.shape[2]
+            lib.dwk_strided_fwd(qkv[0, 0, 2 * C + off:], 3 * C, w, b, cv[0, 0, off:], C, B, H, W, Cg, K, 0, 0, dt)
+            off += Cg
+        out = torch.empty((B, N, C), device=dev, dtype=qkv.dtype)
+        lib.fatt_apply_fwd(qkv, M, cv, out, float(scale), B, N, C, heads, dt)
+        ctx.save_for_backward(qkv, stats, M, cv, *wb[0::2])
+        ctx.cfg = (H, W, heads, float(scale))
+        ctx.params = wb
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, stats, M, cv, *ws = ctx.saved_tensors
+        H, W, heads, scale = ctx.cfg
+        wb = ctx.params
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        dt, dev = dtype_code(qkv.dtype), qkv.device
+        dout = _as(dout, qkv.dtype)
+        dM = ZERO.get(tuple(M.shape), torch.float32, dev)
+        lib.fatt_dktv(qkv, dout, dM, scale, B, N, C, heads, dt)
+        dqkv = torch.empty_like(qkv)
+        dcv = torch.empty_like(cv)
+        lib.fatt_apply_bwd(qkv, stats, M, dM, cv, dout, dqkv, dcv, scale, B, N, C, heads, dt)
+        grads, off = [], 0
+        for w, b in zip(wb[0::2], wb[1::2]):
+            Cg, K = w.shape[0], w.shape[2]
+            lib.dwk_strided_fwd(dcv[0, 0, off:], C, w, None, dqkv[0, 0, 2 * C + off:], 3 * C, B, H, W, Cg, K, 1, 1, dt)
+            dw = _grad_out(w)
+            db = _grad_out(b) if b is not None else None
+            lib.dwk_strided_wgrad(qkv[0, 0, 2 * C + off:], 3 * C, dcv[0, 0, off:], C, dw, db, B, H, W, Cg, K, dt)
+            grads += [_ret(dw, w), _ret(db, b)]
+            off += Cg
+        return (dqkv, None, None, None, None) + tuple(grads)
+
+
+def factor_att(qkv, size, heads, scale, crpe_convs):
+    """qkv [B,N,3C] tokens, size = (H, W), crpe_convs = the nn.Conv2d list of ConvRelPosEnc (windows 3/5/7 over head splits)"""
+    wb = []
+    for m in crpe_convs:
+        wb += [m.weight, m.bias]
+    return _FactorAtt.apply(qkv, int(size[0]), int(size[1]), int(heads), float(scale), *wb)
+
+
 class _MaxPool2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -853,3 +853,108 @@ def test_norm_add_fused(dt, cfg):
             z = gb[0, :, 0, 0]                   # (bf16 rounds the resized gradient before the 1/eps: bound relative to the vector)
             torch.testing.assert_close(ga[0, :, 0, 0], z, rtol=1e-3, atol=(3e-2 if dt != torch.float32 else 1e-4) * z.abs().max().item())
         torch.testing.assert_close(ga[mask], gb[mask], rtol=t['rtol'], atol=t['atol'] * max(1e-3, gb[mask].abs().max().item()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# factorised attention with convolutional relative position encoding (reference nets/tcct.py:219-341)
+def _oracle():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle'))
+    import tcct_oracle as O
+    return O
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('cfg', [(2, 6, 10, 64), (1, 5, 7, 96), (3, 9, 13, 128), (2, 4, 6, 160), (1, 1, 1, 64), (2, 40, 72, 64),
+                                 (1, 67, 131, 96)])
+def test_factor_att_core_vs_oracle(dt, cfg):
+    """ops.factor_att (softmax over tokens, K^T V, Q (K^T V), crpe depthwise 3/5/7 windows, all backward kernels) against the oracle's
+    factor_att_mix on the same qkv; ragged token counts (N not a multiple of the 32-row tiles), 1x1 maps, > 1 statistics segment"""
+    from tcct_amd import ops
+    O = _oracle()
+    B, H, W, C = cfg
+    heads, Ch, N = 8, C // 8, H * W
+    qkv = (rnd(B, N, 3 * C, dt=dt) * 1.5).to(dt).float().requires_grad_(True)      # values representable in dt
+    wb = []
+    for i, (k, split) in enumerate(((3, 2), (5, 3), (7, 3))):
+        wb.append(((rnd(split * Ch, 1, k, k, seed=10 + i) / k).requires_grad_(True), rnd(split * Ch, seed=20 + i).requires_grad_(True)))
+    eye = torch.eye(3 * C)
+    y = O.factor_att_mix(qkv, eye, None, wb, (H, W), heads)
+    gy = rnd(B, N, C, seed=5, dt=dt)
+    y.backward(gy)
+
+    convs = []
+    for w, b in wb:
+        m = torch.nn.Conv2d(w.shape[0], w.shape[0], w.shape[2], padding=w.shape[2] // 2, groups=w.shape[0]).cuda()
+        m.weight.data.copy_(w.detach())
+        m.bias.data.copy_(b.detach())
+        convs.append(m)
+    qd = qkv.detach().to('cuda', dt).requires_grad_(True)
+    yd = ops.factor_att(qd, (H, W), heads, Ch ** -0.5, convs)
+    yd.backward(gy.to('cuda', dt))
+    torch.cuda.synchronize()
+
+    def close(a, b, what):
+        a, b = a.float().cpu(), b.float()
+        t = tol(dt)
+        scale = max(1.0, float(b.abs().max()))
+        err = float((a - b).abs().max()) / scale
+        assert err < t['atol'], f'{what}: {err:.3e} (scale {scale:.2f})'
+    close(yd, y.detach(), 'out')
+    close(qd.grad[..., :C], qkv.grad[..., :C], 'dq')
+    close(qd.grad[..., C:2 * C], qkv.grad[..., C:2 * C], 'dk')
+    close(qd.grad[..., 2 * C:], qkv.grad[..., 2 * C:], 'dv')
+    for m, (w, b) in zip(convs, wb):
+        close(m.weight.grad, w.grad, f'dw{w.shape[2]}')
+        close(m.bias.grad, b.grad, f'db{w.shape[2]}')
+
+
+def test_factor_att_softmax_is_stable_for_large_keys():
+    """k.softmax(dim=2) (tcct.py:321) with keys far outside exp's fp32 range: the online max / sum must not overflow"""
+    from tcct_amd import ops
+    O = _oracle()
+    B, H, W, C = 1, 8, 9, 64
+    qkv = rnd(B, H * W, 3 * C)
+    qkv[..., C:2 * C] = qkv[..., C:2 * C] * 60.0 + 200.0
+    wb = [(torch.zeros(s * 8, 1, k, k), torch.zeros(s * 8)) for k, s in ((3, 2), (5, 3), (7, 3))]
+    y = O.factor_att_mix(qkv, torch.eye(3 * C), None, wb, (H, W), 8)
+    convs = [torch.nn.Conv2d(w.shape[0], w.shape[0], w.shape[2], padding=w.shape[2] // 2, groups=w.shape[0]).cuda() for w, _ in wb]
+    for m in convs:
+        m.weight.data.zero_()
+        m.bias.data.zero_()
+    with torch.no_grad():
+        yd = ops.factor_att(qkv.cuda(), (H, W), 8, 8 ** -0.5, convs)
+    assert torch.isfinite(yd).all()
+    assert float((yd.cpu() - y).abs().max()) < 2e-4 * max(1.0, float(y.abs().max()))
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('tag', ['fa64', 'fa96'])
+def test_factor_att_module_matches_reference_fixture(dt, tag):
+    """tcct_amd.nets FactorAtt_ConvRelPosEnc (qkv GEMM -> tcct_fatt_* / tcct_dwk_* kernels -> proj GEMM) against the REAL reference
+    classes' forward and backward (tests/golden/factoratt.npz, oracle/make_golden_factoratt.py)"""
+    import os
+    import numpy as np
+    from tcct_amd.nets.tcct import FactorAtt_ConvRelPosEnc, ConvRelPosEnc
+    fx = {k[len(tag) + 1:]: torch.tensor(v) for k, v in
+          np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'factoratt.npz')).items() if k.startswith(tag + '.')}
+    H, W = (int(v) for v in fx['size'])
+    heads, dim = int(fx['heads']), fx['x'].shape[-1]
+    att = FactorAtt_ConvRelPosEnc(dim, num_heads=heads, qkv_bias=True,
+                                  shared_crpe=ConvRelPosEnc(Ch=dim // heads, h=heads, window={3: 2, 5: 3, 7: 3}))
+    missing = att.load_state_dict({k[2:]: v for k, v in fx.items() if k.startswith('p.')}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys           # same parameter names and shapes as the reference module
+    att = att.cuda().train()
+    x = fx['x'].to('cuda', dt).requires_grad_(True)
+    y = att(x, (H, W))
+    y.backward(fx['gout'].to('cuda', dt))
+    torch.cuda.synchronize()
+    bar = 2e-4 if dt == torch.float32 else 3e-2
+
+    def err(a, b):
+        return float((a.float().cpu() - b).abs().max()) / max(1.0, float(b.abs().max()))
+    assert err(y, fx['y']) < bar
+    assert err(x.grad, fx['dx']) < bar
+    for k, p in att.named_parameters():
+        assert err(p.grad, fx['g.' + k]) < bar, k

@@ -558,3 +558,44 @@ def test_fused_aux_heads_equal_the_materialised_route(dtype, tmp_path):
     for n in ('base.aux1.weight', 'base.aux2.bias', 'base.aux4.weight', 'base.t321.weight', 'base.dec1.post.0.weight', 'base.base_cnn.cnn.0.weight'):
         d = (g1[n] - g0[n]).abs().max().item()
         assert d <= tol_ * max(1e-6, g0[n].abs().max().item()), (n, d, g0[n].abs().max().item())
+
+
+def test_factor_attention_variant_trains_and_matches_oracle(tmp_path):
+    """stc_tt(att='factor'): the reference's commented-out token mixer (FactorAtt_ConvRelPosEnc, nets/tcct.py:289-341, 443-448; SURVEY
+    8(f)4) inside the whole network.  fp32: logits, loss and the gradient norm against the oracle (whose mixer is pinned to the real
+    reference classes by tests/golden/factoratt.npz); bf16: the fused training step runs and the loss falls."""
+    import tcct_oracle as O
+    from tcct_amd.nets import stc_tt, RegNet
+    img, lab = O.synth_batch(2, 32, 64, seed=5)
+    model = RegNet(stc_tt(5, att='factor'), con='cos', out_channels=5)
+    keys_f = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert any('.att.qkv.weight' in k for k, _ in keys_f) and any('.att.crpe.conv_list.2.weight' in k for k, _ in keys_f)
+    sd = O.formula_state_dict(keys_f)
+    model.load_state_dict(sd, strict=True)
+    model.base.base_vit.drop_probs = [0.0] * 4
+    k = make_kite(model.cuda().train(), tmp_path, False, False)
+    loss, _ = k.calc_loss(img.cuda(), lab.cuda())
+    loss.backward()
+    k.optimG.step()
+    torch.cuda.synchronize()
+    osd = {kk: v.clone() for kk, v in sd.items()}
+    for kk, v in osd.items():
+        if v.is_floating_point() and not kk.endswith(('running_mean', 'running_var')) and not kk.startswith('fcp.'):
+            v.requires_grad_(True)
+    oh = torch.nn.functional.one_hot(lab, 5).permute(0, 3, 1, 2)
+    tot, parts, outs, feats = O.total_loss(osd, img, oh, udh=False, reg=False)
+    tot.backward()
+    assert abs(loss.item() - tot.item()) / abs(tot.item()) < 1e-3
+    gn = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in osd.values() if v.grad is not None)).item()
+    assert abs(k.optimG.last_total_norm.item() - gn) / gn < 2e-2, (k.optimG.last_total_norm.item(), gn)
+    gq = [v.grad for kk, v in osd.items() if kk.endswith('mhca_stages.0.mhca_blks.0.MHCA_layers.0.att.qkv.weight')][0]
+    pq = dict(model.named_parameters())['base.base_vit.mhca_stages.0.mhca_blks.0.MHCA_layers.0.att.qkv.weight']
+    assert pq.grad is not None and relerr(pq.grad, gq) < 2e-2 * float(gq.abs().max()) + 1e-3
+
+    m16 = RegNet(stc_tt(5, att='factor', compute_dtype=torch.bfloat16), con='cos', out_channels=5)
+    m16.load_state_dict(sd, strict=True)
+    k16 = make_kite(m16.cuda().train(), tmp_path, False, False, lr=3e-3)
+    for g in k16.optimG.param_groups:
+        g['lr'] = 3e-3
+    losses = [float(k16.train_step(img.cuda(), lab.cuda())) for _ in range(12)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.05, losses

@@ -131,3 +131,29 @@ def test_goals_preprocessing_oracle_known_answers():
     assert back.shape == (2, 800, 1100) and (back[:, 608:] == 0).all() and set(np.unique(back)) <= {0, 30, 60, 90, 120}
     c = G.crop_flip(img, True, 3, 5, 256, 256, True, False)
     assert c.shape == (2, 256, 256, 3) and np.array_equal(c[0, 0, 0], img[0, 3, 5 + 255])
+
+
+@pytest.mark.parametrize('tag', ['fa64', 'fa96'])
+def test_factor_attention_oracle_matches_reference_fixture(tag):
+    """tests/golden/factoratt.npz holds the REAL reference classes' forward / backward (FactorAtt_ConvRelPosEnc + ConvRelPosEnc,
+    nets/tcct.py:219-341; oracle/make_golden_factoratt.py): the restatement must reproduce output and every gradient"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    import tcct_oracle as O
+    fx = {k[len(tag) + 1:]: torch.tensor(v) for k, v in np.load(os.path.join(os.path.dirname(__file__), 'golden', 'factoratt.npz')).items()
+          if k.startswith(tag + '.')}
+    H, W = (int(v) for v in fx['size'])
+    x = fx['x'].clone().requires_grad_(True)
+    ps = {k[2:]: v.clone().requires_grad_(True) for k, v in fx.items() if k.startswith('p.')}
+    wb = [(ps[f'crpe.conv_list.{i}.weight'], ps[f'crpe.conv_list.{i}.bias']) for i in range(3)]
+    y = O.factor_att(x, ps['qkv.weight'], ps['qkv.bias'], ps['proj.weight'], ps['proj.bias'], wb, (H, W), int(fx['heads']))
+    y.backward(fx['gout'])
+    assert torch.allclose(y, fx['y'], rtol=1e-5, atol=1e-5 * float(fx['y'].abs().max()))
+    assert torch.allclose(x.grad, fx['dx'], rtol=1e-5, atol=1e-5 * float(fx['dx'].abs().max()))
+    for k, p in ps.items():
+        g = fx['g.' + k]
+        assert torch.allclose(p.grad, g, rtol=1e-4, atol=1e-5 * float(g.abs().max())), k
+    # known answer: with q = 0 the mixer output is exactly the projection bias (both terms are linear in q)
+    z = O.factor_att(x.detach(), torch.zeros_like(ps['qkv.weight']), None, ps['proj.weight'].detach(), ps['proj.bias'].detach(),
+                     [(w.detach(), b.detach()) for w, b in wb], (H, W), int(fx['heads']))
+    assert torch.allclose(z, ps['proj.bias'].detach().expand_as(z), atol=1e-6)
