@@ -187,6 +187,10 @@ int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float* dbias, in
 int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                 int out_dtype, tcct_stream_t stream);
 int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
+/* the same for an N-column slab of a wider output: dy rows have stride ldy elements (multiple of 8) and dy / dw / dbias point at the slab
+ * (nn.Linear(dim, 3 dim) of FactorAtt_ConvRelPosEnc, nets/tcct.py:307, runs as slabs of <= 160 columns) */
+int tcct_pw_wgrad_strided(const void* x, const void* dy, int64_t ldy, float* dw, float* dbias, int64_t M, int K, int N,
+                          tcct_stream_t stream);
 /* Linear + residual: y = res + scale[m / per_sample] * (x W^T + bias), bf16, N % 32 == 0, scale fp32 [M / per_sample] nullable
  * (Mlp.fc2 followed by `x + drop_path(...)`, nets/tcct.py:468); y_plain (nullable) additionally receives x W^T + bias itself: the decoder's
  * `post` convolution whose output feeds both the next stage and `x_i + y_i` (nets/tcct.py:1028-1031) */

@@ -25,10 +25,11 @@ def case(ref, dim, B, H, W, tag):
     att = ref.FactorAtt_ConvRelPosEnc(dim, num_heads=heads, qkv_bias=True, shared_crpe=crpe)
     keys = [(k, tuple(v.shape)) for k, v in att.state_dict().items()]
     att.load_state_dict({k: O.formula_tensor(f'{tag}.{k}', s) for k, s in keys}, strict=True)
-    with torch.no_grad():                   # formula weights are fan-in scaled; make the softmax over tokens non-trivial
-        att.qkv.weight.mul_(3.0)
-    x = sinfill(f'{tag}.x', (B, H * W, dim), 1.5).requires_grad_(True)
-    gout = sinfill(f'{tag}.gout', (B, H * W, dim), 0.7)
+    with torch.no_grad():                   # balance the two terms of the mixer (formula weights add up coherently with formula inputs)
+        for m in crpe.conv_list:
+            m.weight.mul_(0.15)
+    x = sinfill(f'{tag}.x', (B, H * W, dim), 1.0).requires_grad_(True)
+    gout = sinfill(f'{tag}.gout', (B, H * W, dim), 5.0)
     att.train()
     y = att(x, (H, W))
     y.backward(gout)
@@ -47,6 +48,14 @@ def case(ref, dim, B, H, W, tag):
     assert torch.allclose(xo.grad, x.grad, rtol=1e-5, atol=1e-6)
     for k, p in att.named_parameters():
         assert torch.allclose(ps[k].grad, p.grad, rtol=1e-4, atol=1e-5 * float(p.grad.abs().max())), k
+    with torch.no_grad():                   # how much each term of the mixer contributes, and how peaked the softmax over tokens is
+        wb0 = [(m.weight, m.bias) for m in crpe.conv_list]
+        zero = [(torch.zeros_like(w), torch.zeros_like(b)) for w, b in wb0]
+        a_only = O.factor_att_mix(x, att.qkv.weight, att.qkv.bias, zero, (H, W), heads)
+        both = O.factor_att_mix(x, att.qkv.weight, att.qkv.bias, wb0, (H, W), heads)
+        kk = torch.nn.functional.linear(x, att.qkv.weight, att.qkv.bias)[..., dim:2 * dim]
+        print(tag, 'attention term max', float(a_only.abs().max()), 'crpe term max', float((both - a_only).abs().max()),
+              'k range', float(kk.min()), float(kk.max()), 'max softmax prob', float(kk.softmax(1).max()))
     print(tag, 'y range', float(y.min()), float(y.max()), '|dx| max', float(x.grad.abs().max()), 'oracle == reference')
     return out
 

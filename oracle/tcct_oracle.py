@@ -68,16 +68,23 @@ def metapool(t):
     return F.avg_pool2d(t, 3, 1, 1, count_include_pad=False) - t
 
 
-def factor_att_mix(x, qkv_w, qkv_b, crpe_wb, size, heads, qk_scale=None):
+def _same(t):
+    return t
+
+
+def factor_att_mix(x, qkv_w, qkv_b, crpe_wb, size, heads, qk_scale=None, store=_same, wcast=_same):
     """FactorAtt_ConvRelPosEnc.forward up to (not including) the output projection, nets/tcct.py:311-331, with
     ConvRelPosEnc.forward nets/tcct.py:265-287 inlined.  x [B,N,C] tokens, size = (H, W); crpe_wb = [(weight [Cg,1,k,k], bias [Cg]), ...]
     in conv_list order (window {3:2, 5:3, 7:3} over 8 heads, tcct.py:484-488).  The reference keeps this mixer commented out
-    (tcct.py:436-449); restated for SURVEY 8(f)4 and pinned by tests/golden/factoratt_*.npz (oracle/make_golden_factoratt.py)."""
-    B, N, C = x.shape
+    (tcct.py:436-449); restated for SURVEY 8(f)4 and pinned by tests/golden/factoratt.npz (oracle/make_golden_factoratt.py).
+    store / wcast (identity by default = the reference's arithmetic): applied to every tensor the HIP path keeps in memory (qkv, the crpe
+    convolution, the output) and to the GEMM weights -- the bf16 tests pass a differentiable round-to-bf16 here, which turns the
+    restatement into the error model of bf16 storage with fp32 arithmetic."""
+    B, N, C = x.shape[0], x.shape[1], qkv_w.shape[0] // 3
     H, W = size
     Ch = C // heads
     scale = qk_scale or Ch ** -0.5                                                  # tcct.py:305
-    qkv = F.linear(x, qkv_w, qkv_b).reshape(B, N, 3, heads, Ch).permute(2, 0, 3, 1, 4)     # tcct.py:316-317
+    qkv = store(F.linear(x, wcast(qkv_w), qkv_b)).reshape(B, N, 3, heads, Ch).permute(2, 0, 3, 1, 4)     # tcct.py:316-317
     q, k, v = qkv[0], qkv[1], qkv[2]                                                # [B,h,N,Ch]
     ktv = torch.einsum('bhnk,bhnv->bhkv', k.softmax(dim=2), v)                      # tcct.py:321-322
     att = torch.einsum('bhnk,bhkv->bhnv', q, ktv)                                   # tcct.py:323-324
@@ -87,14 +94,14 @@ def factor_att_mix(x, qkv_w, qkv_b, crpe_wb, size, heads, qk_scale=None):
         cg, kk = w.shape[0], w.shape[2]
         parts.append(F.conv2d(v_img[:, off:off + cg], w, b, 1, kk // 2, 1, cg))
         off += cg
-    conv_v = torch.cat(parts, 1).reshape(B, heads, Ch, N).permute(0, 1, 3, 2)       # tcct.py:283
+    conv_v = store(torch.cat(parts, 1)).reshape(B, heads, Ch, N).permute(0, 1, 3, 2)    # tcct.py:283
     y = scale * att + q * conv_v                                                    # tcct.py:285, 330
-    return y.transpose(1, 2).reshape(B, N, C)                                       # tcct.py:331
+    return store(y.transpose(1, 2).reshape(B, N, C))                                # tcct.py:331
 
 
-def factor_att(x, qkv_w, qkv_b, proj_w, proj_b, crpe_wb, size, heads, qk_scale=None):
+def factor_att(x, qkv_w, qkv_b, proj_w, proj_b, crpe_wb, size, heads, qk_scale=None, store=_same, wcast=_same):
     """FactorAtt_ConvRelPosEnc.forward, nets/tcct.py:311-341 (attn_drop / proj_drop = DROP_RATE = 0, tcct.py:26)."""
-    return F.linear(factor_att_mix(x, qkv_w, qkv_b, crpe_wb, size, heads, qk_scale), proj_w, proj_b)
+    return store(F.linear(factor_att_mix(x, qkv_w, qkv_b, crpe_wb, size, heads, qk_scale, store, wcast), wcast(proj_w), proj_b))
 
 
 def vit_stage(sd, p_pe, p_st, x, s, train, dp_masks):

@@ -304,11 +304,21 @@ __global__ void k_colsum(const T* __restrict__ x, int64_t M, int C, float* __res
     }
 }
 
+// the same for C > CB channels: thread t owns channels t, t + CB, ...
+template <typename T>
+__global__ void k_colsum_wide(const T* __restrict__ x, int64_t M, int C, float* __restrict__ out) {
+    for (int c = threadIdx.x; c < C; c += CB) {
+        float s = 0.f;
+        for (int64_t m = blockIdx.x; m < M; m += gridDim.x) s += ldf(x + m * C + c);
+        atomicAdd(&out[c], s);
+    }
+}
+
 extern "C" int tcct_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int Cin,
                                  int Cin_w, int Cout, int KH, int KW, int stride, int padh, int padw, int x_dtype,
                                  int dy_dtype, tcct_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
-    TCCT_CHECK(Cin % 4 == 0 && Cin_w <= Cin && Cout > 0 && Cout <= 256, "conv2d_wgrad: unsupported shape Cin=%d Cout=%d", Cin, Cout);
+    TCCT_CHECK(Cin % 4 == 0 && Cin_w <= Cin && Cout > 0 && Cout <= 1024, "conv2d_wgrad: unsupported shape Cin=%d Cout=%d", Cin, Cout);
     int Ho = (H + 2 * padh - KH) / stride + 1, Wo = (W + 2 * padw - KW) / stride + 1;
     TCCT_CHECK(Ho > 0 && Wo > 0 && N > 0, "conv2d_wgrad: empty output");
     int64_t NP = (int64_t)N * Ho * Wo;
@@ -329,6 +339,12 @@ extern "C" int tcct_conv2d_wgrad(const void* x, const void* dy, float* dw, float
 #undef LAUNCH
     if (dbias) {
         if (!tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, st) != hipSuccess) { tcct_set_error("conv2d_wgrad: memset failed"); return -2; }
+        if (Cout > CB) {
+            int gw = tcct_grid(NP, 1, 512);
+            if (dy_dtype == TCCT_F32) hipLaunchKernelGGL(k_colsum_wide<float>, dim3(gw), dim3(CB), 0, st, (const float*)dy, NP, Cout, dbias);
+            else hipLaunchKernelGGL(k_colsum_wide<bf16>, dim3(gw), dim3(CB), 0, st, (const bf16*)dy, NP, Cout, dbias);
+            TCCT_LAUNCH_OK();
+        }
         int R = CB / Cout;
         int g = tcct_grid(NP, R, 2048);
         if (dy_dtype == TCCT_F32) hipLaunchKernelGGL(k_colsum<float>, dim3(g), dim3(CB), 0, st, (const float*)dy, NP, Cout, dbias);

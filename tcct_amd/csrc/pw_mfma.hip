@@ -361,7 +361,7 @@ __device__ __forceinline__ bf16x8 tr_load8g(const unsigned char* base, int strid
 template <int NT, int KTB>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias, int64_t M,
-           int K, int N, int SX, int SD, const bf16* __restrict__ x2, int K1) {
+           int K, int N, int SX, int SD, const bf16* __restrict__ x2, int K1, int64_t ldy) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sX = smem;
     unsigned char* sD = smem + PW_P * SX;
@@ -401,7 +401,7 @@ k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __res
         for (int j = 0; j < PW_DS; ++j) {
             pd[j] = make_uint4(0, 0, 0, 0);
             if (dsl[j] >= 0 && m0 + (dsl[j] >> 8) < M)
-                pd[j] = *reinterpret_cast<const uint4*>(dy + (m0 + (dsl[j] >> 8)) * N + (dsl[j] & 255) * 8);
+                pd[j] = *reinterpret_cast<const uint4*>(dy + (m0 + (dsl[j] >> 8)) * ldy + (dsl[j] & 255) * 8);
         }
     };
     // per-lane transposing-read bases (see conv_mfma.hip): address = base + pixel*stride (+ 4*stride for the second half)
@@ -488,17 +488,28 @@ k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __res
 }
 
 /* x bf16 [M,K], dy bf16 [M,N] -> dw fp32 [N,K] and dbias fp32 [N] (nullable); both overwritten.  K, N multiples of 32, N <= 160 */
-static int pw_wgrad_impl(const void* x, const void* x2, int K1, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
+static int pw_wgrad_impl(const void* x, const void* x2, int K1, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream,
+                         int64_t ldy);
 extern "C" int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream) {
-    return pw_wgrad_impl(x, nullptr, 0, dy, dw, dbias, M, K, N, stream);
+    return pw_wgrad_impl(x, nullptr, 0, dy, dw, dbias, M, K, N, stream, 0);
 }
 /* weight gradient with x = [x1 | x2] given as two tensors (x1 [M,K1], x2 [M,K-K1]); dw [N,K] as for the concatenated input */
 extern "C" int tcct_pw_wgrad_cat2(const void* x1, const void* x2, int K1, const void* dy, float* dw, float* dbias, int64_t M, int K, int N,
                                   tcct_stream_t stream) {
     TCCT_CHECK(x2 != nullptr && K1 % 32 == 0 && K1 > 0 && K1 < K, "pw_wgrad_cat2: K1=%d must be a multiple of 32 inside (0, K)", K1);
-    return pw_wgrad_impl(x1, x2, K1, dy, dw, dbias, M, K, N, stream);
+    return pw_wgrad_impl(x1, x2, K1, dy, dw, dbias, M, K, N, stream, 0);
 }
-static int pw_wgrad_impl(const void* x, const void* x2, int K1, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream) {
+/* weight gradient of an N-column slab of a wider GEMM: dy rows have stride ldy (elements, multiple of 8, dy points at the slab's first
+ * column); dw / dbias point at the slab's first row.  Lets outputs wider than 160 (the qkv Linear of the factorised attention, N = 3C) run
+ * as slabs on the same MFMA kernel. */
+extern "C" int tcct_pw_wgrad_strided(const void* x, const void* dy, int64_t ldy, float* dw, float* dbias, int64_t M, int K, int N,
+                                     tcct_stream_t stream) {
+    return pw_wgrad_impl(x, nullptr, 0, dy, dw, dbias, M, K, N, stream, ldy);
+}
+static int pw_wgrad_impl(const void* x, const void* x2, int K1, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream,
+                         int64_t ldy) {
+    if (ldy == 0) ldy = N;
+    TCCT_CHECK(ldy >= N && ldy % 8 == 0, "pw_wgrad: ldy=%lld must be a multiple of 8 and >= N=%d", (long long)ldy, N);
     TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && N <= 160 && K <= 1024, "pw_wgrad: unsupported K=%d N=%d", K, N);
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)N * K, st) != hipSuccess) { tcct_set_error("pw_wgrad: memset failed"); return -2; }
@@ -522,7 +533,7 @@ static int pw_wgrad_impl(const void* x, const void* x2, int K1, const void* dy, 
     if (gx < 64) gx = 64;
     if (gx > tiles) gx = (int)tiles;
     if (gx < 1) gx = 1;
-#define WL(NTV, KV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_wgrad<NTV, KV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } } hipLaunchKernelGGL((k_pw_wgrad<NTV, KV>), dim3(gx, gy), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias, M, K, N, SX, SD, (const bf16*)x2, K1)
+#define WL(NTV, KV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_wgrad<NTV, KV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } } hipLaunchKernelGGL((k_pw_wgrad<NTV, KV>), dim3(gx, gy), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias, M, K, N, SX, SD, (const bf16*)x2, K1, ldy)
     if (KTB == 2) { switch (NT) { case 1: WL(1, 2); break; default: WL(2, 2); break; } }
     else { switch (NT) { case 1: WL(1, 1); break; case 2: WL(2, 1); break; case 3: WL(3, 1); break; case 4: WL(4, 1); break; default: WL(5, 1); break; } }
 #undef WL

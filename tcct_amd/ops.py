@@ -304,6 +304,12 @@ class _Conv2d(torch.autograd.Function):
                 elif (_pw_ok(x.dtype, Cin, Cin_w, KH, KW, stride, padh, padw) and dy.dtype == torch.bfloat16 and Cout % 32 == 0
                       and Cout <= 160):
                     lib.pw_wgrad(x, dy, dw, db, N * H * W, Cin, Cout)
+                elif _pw_ok(x.dtype, Cin, Cin_w, KH, KW, stride, padh, padw) and dy.dtype == torch.bfloat16 and Cout % 32 == 0:
+                    # wider outputs (the qkv Linear of the factorised attention, Cout = 3 dim): slabs of <= 160 columns on the same kernel
+                    dy2, dw2 = dy.view(-1, Cout), dw.view(Cout, Cin)
+                    for c0 in range(0, Cout, 160):
+                        n = min(160, Cout - c0)
+                        lib.pw_wgrad_strided(x, dy2[0, c0:], Cout, dw2[c0:], db[c0:] if db is not None else None, N * H * W, Cin, n)
                 elif KH == 1 and KW == 1 and stride == 1 and Cout <= 8 and Cin == Cin_w and Cin <= 256 and (
                         x.dtype == torch.bfloat16 or dy.dtype == torch.float32):
                     lib.pw_wgrad_smalln(x, dy, dw, db, N * H * W, Cin, Cout, dtype_code(x.dtype), dtype_code(dy.dtype))

@@ -950,11 +950,45 @@ def test_factor_att_module_matches_reference_fixture(dt, tag):
     y = att(x, (H, W))
     y.backward(fx['gout'].to('cuda', dt))
     torch.cuda.synchronize()
-    bar = 2e-4 if dt == torch.float32 else 3e-2
-
     def err(a, b):
         return float((a.float().cpu() - b).abs().max()) / max(1.0, float(b.abs().max()))
-    assert err(y, fx['y']) < bar
-    assert err(x.grad, fx['dx']) < bar
+    if dt == torch.float32:
+        assert err(y, fx['y']) < 2e-4
+        assert err(x.grad, fx['dx']) < 2e-4
+        for k, p in att.named_parameters():
+            assert err(p.grad, fx['g.' + k]) < 2e-4, k
+        return
+    # bf16: activations are stored in bf16 and the MFMA GEMMs take bf16 weights; the projection and the qkv input gradient sum 64-288
+    # terms of magnitude 10-40 with cancelling signs, so against the fp32 fixture the error is 3-4 % (y) and 11 % (dx) of the maximum.  The
+    # oracle with the same rounding points (differentiable round-to-bf16 on stored tensors and GEMM weights) reproduces those figures, and
+    # the HIP path has to agree with THAT model closely; the kernels themselves are held to 3e-2 in test_factor_att_core_vs_oracle.
+    O = _oracle()
+
+    class RoundStore(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.bfloat16().float()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g.bfloat16().float()
+
+    class RoundWeight(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.bfloat16().float()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+    xm = fx['x'].bfloat16().float().requires_grad_(True)
+    ps = {k[2:]: v.clone().requires_grad_(True) for k, v in fx.items() if k.startswith('p.')}
+    wb = [(ps[f'crpe.conv_list.{i}.weight'], ps[f'crpe.conv_list.{i}.bias']) for i in range(3)]
+    ym = O.factor_att(xm, ps['qkv.weight'], ps['qkv.bias'], ps['proj.weight'], ps['proj.bias'], wb, (H, W), heads,
+                      store=RoundStore.apply, wcast=RoundWeight.apply)
+    ym.backward(fx['gout'].bfloat16().float())
+    assert err(y, ym.detach()) < 1e-2 and err(y, fx['y']) < 0.08
+    assert err(x.grad, xm.grad) < 2e-2 and err(x.grad, fx['dx']) < 0.2
     for k, p in att.named_parameters():
-        assert err(p.grad, fx['g.' + k]) < bar, k
+        assert err(p.grad, ps[k].grad) < 3e-2, k
+        assert err(p.grad, fx['g.' + k]) < 0.15, k
