@@ -34,6 +34,8 @@ def parse():
     p.add_argument('--width', type=int, default=1100)
     p.add_argument('--los', type=str, default='di', help="di | di+reg | di+reg+fpl")
     p.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'fp32'])
+    p.add_argument('--att', type=str, default='pool', choices=['pool', 'factor'],
+                   help="token mixer: 'pool' = the reference's stc_tt (headline); 'factor' = its commented-out factorised attention (not the headline)")
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--roofline-only', action='store_true', help='only run the dominant-kernel timing loop (for rocprofv3)')
@@ -48,7 +50,7 @@ def build_trainer(a, world):
     args = parse_args([f'--los={a.los}', f'--bs={a.bs}', '--db=synth', f'--pl={"true" if (world > 1 or os.environ.get("TCCT_FORCE_DIST") == "1") else "false"}',
                        f'--dtype={a.dtype}', '--root=/tmp/tcct_bench_root'])
     ds = SynthOCT(height=a.height, width=a.width, device='cuda')
-    net = nets.stc_tt(ds.out_channels, compute_dtype=torch.bfloat16 if a.dtype == 'bf16' else torch.float32)
+    net = nets.stc_tt(ds.out_channels, compute_dtype=torch.bfloat16 if a.dtype == 'bf16' else torch.float32, att=a.att)
     net = nets.RegNet(net, con=args.type_udh, out_channels=ds.out_channels)
     k = KiteSeg(model=net, dataset=ds, root=args.root, args=args)
     return k, ds, args
@@ -234,7 +236,7 @@ def main():
         'metric': 'OCT B-scans/sec fwd+bwd(+clip+AdamW), stc_tt bs=8 1x800x1100', 'value': round(value, 3), 'unit': 'B-scans/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-        'config': {'workload': f'stc_tt --los={a.los} bs={a.bs}/GPU 1x{a.height}x{a.width} (net tensors 3x{a.height}x{(a.width + 15) // 16 * 16})',
+        'config': {'workload': f'stc_tt{"" if a.att == "pool" else "(att=" + a.att + ")"} --los={a.los} bs={a.bs}/GPU 1x{a.height}x{a.width} (net tensors 3x{a.height}x{(a.width + 15) // 16 * 16})',
                    'global_batch': a.bs * world, 'parallelism': f'dp{world}', 'loss_last': round(lossv, 4),
                    'step_ms_gpu_min_med_max': _min_med_max([marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]),
                    'step_ms_host_enqueue_min_med_max': _min_med_max([1e3 * (host[i + 1] - host[i]) for i in range(a.steps)]),

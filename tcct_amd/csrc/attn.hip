@@ -167,45 +167,82 @@ __global__ void __launch_bounds__(256) k_dwk(const T* __restrict__ x, int64_t ld
     }
 }
 
-// dw[c, tap] += sum_pix dy[pix, c] * x[pix + tap - K/2, c], db[c] += sum_pix dy[pix, c]; block = 32 channels x 8 pixel lanes
+// dw[c, tap] += sum_pix dy[pix, c] * x[pix + tap - K/2, c], db[c] += sum_pix dy[pix, c].
+// Block = 32 channel lanes x 8 image rows of one column segment; a thread walks its row from left to right with the K x K window of x
+// in registers (K new loads per pixel instead of K*K), sums its K*K products in registers, the 8 rows are combined by one wave shuffle and
+// an LDS pass, and the block issues ONE atomic per element.  (The first version let 128 blocks walk 1 700 pixels each with K*K loads per
+// pixel: 21 ms for the 7x7 group at level 1 of the bench shape.)
 template <typename T, int K>
 __global__ void __launch_bounds__(256) k_dwk_wgrad(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t ldy,
-                                                   float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int Cg, int px_per_block) {
-    const int t = threadIdx.x, c = blockIdx.y * 32 + (t & 31), j = t >> 5;
-    const bool live = c < Cg;
-    const int total = B * H * W;
-    const int p0 = blockIdx.x * px_per_block, p1 = min(total, p0 + px_per_block);
-    constexpr int R = K / 2;
-    float acc[K * K];
+                                                   float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int Cg, int segw) {
+    constexpr int R = K / 2, NE = K * K + 1;
+    __shared__ float red[4][NE][32];
+    const int t = threadIdx.x, cl = t & 31, c = blockIdx.y * 32 + cl, j = t >> 5;
+    const int nseg = (W + segw - 1) / segw, rows8 = (H + 7) / 8;
+    int bid = blockIdx.x;
+    const int seg = bid % nseg; bid /= nseg;
+    const int rg = bid % rows8, b = bid / rows8;
+    const int y0 = rg * 8 + j, xb = seg * segw, xe = min(W, xb + segw);
+    const bool live = c < Cg && y0 < H;
+    float acc[K][K], accb = 0.f;
 #pragma unroll
-    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
-    float accb = 0.f;
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) acc[ky][kx] = 0.f;
     if (live) {
-        for (int p = p0 + j; p < p1; p += 8) {
-            const float g = ldf(dy + (int64_t)p * ldy + c);
-            const int x0 = p % W, y0 = (p / W) % H;
-            accb += g;
+        // row pointers of the window (nullptr = outside the image: zero padding)
+        const T* rowp[K];
 #pragma unroll
-            for (int ky = 0; ky < K; ++ky) {
-                const int yy = y0 + ky - R;
-                if (yy < 0 || yy >= H) continue;
+        for (int ky = 0; ky < K; ++ky) {
+            const int yy = y0 + ky - R;
+            rowp[ky] = (yy >= 0 && yy < H) ? x + ((int64_t)(b * H + yy) * W) * ldx + c : nullptr;
+        }
+        const T* dyp = dy + ((int64_t)(b * H + y0) * W) * ldy + c;
+        float win[K][K];        // win[ky][kx] = x[y0 + ky - R][xx + kx - R] once column xx + R has been shifted in
 #pragma unroll
-                for (int kx = 0; kx < K; ++kx) {
-                    const int xx = x0 + kx - R;
-                    if (xx < 0 || xx >= W) continue;
-                    acc[ky * K + kx] += g * ldf(x + (int64_t)(p + (ky - R) * W + (kx - R)) * ldx + c);
-                }
+        for (int ky = 0; ky < K; ++ky) {
+            win[ky][0] = 0.f;
+#pragma unroll
+            for (int kx = 1; kx < K; ++kx) {
+                const int xx = xb + kx - 1 - R;
+                win[ky][kx] = (rowp[ky] && xx >= 0 && xx < W) ? ldf(rowp[ky] + (int64_t)xx * ldx) : 0.f;
             }
         }
+        for (int xx = xb; xx < xe; ++xx) {
+            const int xn = xx + R;
+            const float g = ldf(dyp + (int64_t)xx * ldy);
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const float nv = (rowp[ky] && xn < W) ? ldf(rowp[ky] + (int64_t)xn * ldx) : 0.f;
+#pragma unroll
+                for (int kx = 0; kx < K - 1; ++kx) win[ky][kx] = win[ky][kx + 1];
+                win[ky][K - 1] = nv;
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) acc[ky][kx] += g * win[ky][kx];
+            }
+            accb += g;
+        }
     }
-    // the two pixel lanes of a wave (lanes l and l+32 hold the same channel), then one atomic per wave and element
+    // rows j and j+1 share a wave (lanes l and l+32 hold the same channel); then the four waves through LDS
+    const int wv = t >> 6;
 #pragma unroll
-    for (int i = 0; i < K * K; ++i) acc[i] += __shfl_xor(acc[i], 32, 64);
-    accb += __shfl_xor(accb, 32, 64);
-    if (live && (t & 32) == 0) {
+    for (int ky = 0; ky < K; ++ky)
 #pragma unroll
-        for (int i = 0; i < K * K; ++i) atomicAdd(dw + c * K * K + i, acc[i]);
-        if (db) atomicAdd(db + c, accb);
+        for (int kx = 0; kx < K; ++kx) {
+            const float v = acc[ky][kx] + __shfl_xor(acc[ky][kx], 32, 64);
+            if ((t & 32) == 0) red[wv][ky * K + kx][cl] = v;
+        }
+    {
+        const float v = accb + __shfl_xor(accb, 32, 64);
+        if ((t & 32) == 0) red[wv][K * K][cl] = v;
+    }
+    __syncthreads();
+    if (c < Cg) {
+        for (int e = j; e < NE; e += 8) {
+            const float v = red[0][e][cl] + red[1][e][cl] + red[2][e][cl] + red[3][e][cl];
+            if (e < K * K) atomicAdd(dw + c * K * K + e, v);
+            else if (db) atomicAdd(db + c, v);
+        }
     }
 }
 
@@ -430,11 +467,13 @@ extern "C" int tcct_dwk_strided_wgrad(const void* x, int64_t ldx, const void* dy
         if (hipMemsetAsync(dw, 0, sizeof(float) * Cg * K * K, st) != hipSuccess) { tcct_set_error("dwk_strided_wgrad: memset failed"); return -2; }
         if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * Cg, st) != hipSuccess) { tcct_set_error("dwk_strided_wgrad: memset failed"); return -2; }
     }
-    const int total = B * H * W;
-    int nseg = (total + 255) / 256; if (nseg > 128) nseg = 128;
-    const int ppb = (total + nseg - 1) / nseg;
-    dim3 grid(nseg, (Cg + 31) / 32);
-#define DWKW(KK) hipLaunchKernelGGL((k_dwk_wgrad<T, KK>), grid, dim3(256), 0, st, (const T*)x, ldx, (const T*)dy, ldy, dw, dbias, B, H, W, Cg, ppb)
+    const int rows8 = (H + 7) / 8;
+    int segw = 256;             // column segment per block: as long as possible (halo = K-1 columns) while the grid still fills the chip
+    while (segw > 32 && (int64_t)B * rows8 * ((W + segw - 1) / segw) * ((Cg + 31) / 32) < 1024) segw >>= 1;
+    const int64_t nblk = (int64_t)B * rows8 * ((W + segw - 1) / segw);
+    TCCT_CHECK(nblk < ((int64_t)1 << 31), "dwk_strided_wgrad: grid too large");
+    dim3 grid((unsigned)nblk, (Cg + 31) / 32);
+#define DWKW(KK) hipLaunchKernelGGL((k_dwk_wgrad<T, KK>), grid, dim3(256), 0, st, (const T*)x, ldx, (const T*)dy, ldy, dw, dbias, B, H, W, Cg, segw)
     TCCT_DISPATCH(dtype, if (K == 3) DWKW(3); else if (K == 5) DWKW(5); else DWKW(7));
 #undef DWKW
     TCCT_LAUNCH_OK();

@@ -45,6 +45,9 @@ def build_parser():
     p.add_argument('--pl', type=str2bool, default=False, help='Parallel: one process per GPU (torchrun)')
     p.add_argument('--bug', type=str2bool, default=False, help='Debug Mode!')
     p.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'fp32'], help='compute dtype of activations')
+    p.add_argument('--att', type=str, default='pool', choices=['pool', 'factor'],
+                   help="token mixer of the ViT blocks: 'pool' = MetaPool (reference nets/tcct.py:449); 'factor' = the factorised attention the "
+                        "reference keeps commented out (nets/tcct.py:443-448; --net=stc_tt / tcct only)")
     p.add_argument('--graph', type=str2bool, default=False,
                    help='replay the training step from a hipGraph (launch-bound crop sizes such as the 256x256 of the reference recipe; '
                         'single process, fixed batch shape)')
@@ -75,7 +78,12 @@ def main(argv=None):
     factory = getattr(nets, args.net, None)
     if factory is None:
         raise SystemExit(f'--net={args.net}: unknown network (available: stc_tt / tcct, stc_tb, gtc_tt, gtc_tb, cnnu, pnnu, vitu)')
-    net = factory(dataset.out_channels, compute_dtype=torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+    kw = dict(compute_dtype=torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+    if args.att != 'pool':
+        if args.net not in ('stc_tt', 'tcct'):
+            raise SystemExit(f'--att={args.att} is only offered for --net=stc_tt')
+        kw['att'] = args.att
+    net = factory(dataset.out_channels, **kw)
     net = nets.RegNet(net, con=args.type_udh, out_channels=dataset.out_channels)
     keras = KiteSeg(model=net, dataset=dataset, root=args.root, args=args)
     if args.resume:
