@@ -27,11 +27,17 @@ __global__ void __launch_bounds__(256) k_fatt_kstats_partial(const T* __restrict
     if (r < R) {
         const int n1 = min(N, (seg + 1) * rows_per_seg);
         const T* p = k + (int64_t)b * N * ld + c;
-#pragma unroll 4
-        for (int n = seg * rows_per_seg + r; n < n1; n += R) {
-            const float x = ldf(p + (int64_t)n * ld);
-            if (x > m) { s = s * __expf(m - x) + 1.f; m = x; }
-            else if (x > -INFINITY) s += __expf(x - m);
+        // four rows per step: the loads are independent of the running (max, sum) and go out together
+        for (int n = seg * rows_per_seg + r; n < n1; n += 4 * R) {
+            float xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xv[u] = (n + u * R < n1) ? ldf(p + (int64_t)(n + u * R) * ld) : -INFINITY;
+            const float mx = fmaxf(fmaxf(xv[0], xv[1]), fmaxf(xv[2], xv[3]));
+            if (mx > -INFINITY) {
+                const float mn = fmaxf(m, mx);
+                s = s * __expf(m - mn) + __expf(xv[0] - mn) + __expf(xv[1] - mn) + __expf(xv[2] - mn) + __expf(xv[3] - mn);
+                m = mn;
+            }
         }
     }
     sm_m[t] = m; sm_s[t] = s;
@@ -45,17 +51,20 @@ __global__ void __launch_bounds__(256) k_fatt_kstats_partial(const T* __restrict
         o[0] = M; o[1] = Ssum;
     }
 }
-// stats [B,C,2] = (max, 1 / sum)
-__global__ void k_fatt_kstats_final(const float* __restrict__ part, float* __restrict__ stats, int S, int C) {
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float M = -INFINITY;
-        for (int s = 0; s < S; ++s) M = fmaxf(M, part[(((int64_t)b * S + s) * C + c) * 2]);
-        float sum = 0.f;
-        for (int s = 0; s < S; ++s) {
-            const float* p = part + (((int64_t)b * S + s) * C + c) * 2;
-            if (p[0] > -INFINITY) sum += p[1] * __expf(p[0] - M);
-        }
+// stats [B,C,2] = (max, 1 / sum); grid (B, C/4), one wave per channel, lanes over the segments
+__global__ void __launch_bounds__(256) k_fatt_kstats_final(const float* __restrict__ part, float* __restrict__ stats, int S, int C) {
+    const int b = blockIdx.x, c = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;         // whole waves leave together
+    float M = -INFINITY;
+    for (int s = lane; s < S; s += 64) M = fmaxf(M, part[(((int64_t)b * S + s) * C + c) * 2]);
+    M = wave_max(M);
+    float sum = 0.f;
+    for (int s = lane; s < S; s += 64) {
+        const float* p = part + (((int64_t)b * S + s) * C + c) * 2;
+        if (p[0] > -INFINITY) sum += p[1] * __expf(p[0] - M);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) {
         stats[((int64_t)b * C + c) * 2] = M;
         stats[((int64_t)b * C + c) * 2 + 1] = 1.f / sum;
     }
@@ -144,17 +153,40 @@ __global__ void __launch_bounds__(256) k_dwk(const T* __restrict__ x, int64_t ld
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc.v[e] = bias[c4 + e];
         }
+        // K <= 5, branch-free taps: out-of-image taps read the centre pixel (always valid) and are zeroed, so that the K loads of a window
+        // row are independent straight-line code the compiler issues together (3x3: 181 -> 146 us, 5x5: 364 -> 323 us at level 1 of the
+        // bench shape); the 7x7 window is faster with skipped taps (671 vs 796 us)
+        if constexpr (K > 5) {
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const int yy = y0 + ky - R;
+                if (yy < 0 || yy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int xx = x0 + kx - R;
+                    if (xx < 0 || xx >= W) continue;
+                    const f4 xv = ld4(x + (int64_t)(pix + (ky - R) * W + (kx - R)) * ldx + c4);
+                    const float4 wv = *reinterpret_cast<const float4*>(sw + (ky * K + kx) * Cg + c4);
+                    acc.v[0] += wv.x * xv.v[0]; acc.v[1] += wv.y * xv.v[1]; acc.v[2] += wv.z * xv.v[2]; acc.v[3] += wv.w * xv.v[3];
+                }
+            }
+        } else
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
             const int yy = y0 + ky - R;
-            if (yy < 0 || yy >= H) continue;
+            const bool oky = yy >= 0 && yy < H;
+            f4 xv[K];
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
                 const int xx = x0 + kx - R;
-                if (xx < 0 || xx >= W) continue;
-                const f4 xv = ld4(x + (int64_t)(pix + (ky - R) * W + (kx - R)) * ldx + c4);
+                const bool ok = oky && xx >= 0 && xx < W;
+                xv[kx] = ld4(x + (int64_t)(ok ? pix + (ky - R) * W + (kx - R) : pix) * ldx + c4);
+                if (!ok) xv[kx] = f4zero();
+            }
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
                 const float4 wv = *reinterpret_cast<const float4*>(sw + (ky * K + kx) * Cg + c4);
-                acc.v[0] += wv.x * xv.v[0]; acc.v[1] += wv.y * xv.v[1]; acc.v[2] += wv.z * xv.v[2]; acc.v[3] += wv.w * xv.v[3];
+                acc.v[0] += wv.x * xv[kx].v[0]; acc.v[1] += wv.y * xv[kx].v[1]; acc.v[2] += wv.z * xv[kx].v[2]; acc.v[3] += wv.w * xv[kx].v[3];
             }
         }
         T* dst = y + (int64_t)pix * ldy + c4;
@@ -358,20 +390,27 @@ static int fatt_shape_ok(const char* who, int B, int64_t N, int C, int heads) {
     return 0;
 }
 
+// token segments of the statistics pass: short segments (>= 256 rows) so that thousands of blocks keep loads in flight; the final
+// kernel combines <= 1024 partials per channel
+static int fatt_segments(int64_t N) {
+    int64_t S = (N + 255) / 256;
+    if (S > 1024) S = 1024;
+    if (S < 1) S = 1;
+    return (int)S;
+}
 extern "C" int64_t tcct_fatt_kstats_workspace_bytes(int B, int64_t N, int C) {
-    int64_t S = (N + 2047) / 2048; if (S > 128) S = 128; if (S < 1) S = 1;
-    return (int64_t)B * S * C * 2 * sizeof(float);
+    return (int64_t)B * fatt_segments(N) * C * 2 * sizeof(float);
 }
 extern "C" int tcct_fatt_kstats(const void* qkv, void* workspace, float* stats, int B, int64_t N, int C, int heads, int dtype,
                                 tcct_stream_t stream) {
     if (fatt_shape_ok("fatt_kstats", B, N, C, heads)) return -1;
     TCCT_CHECK(qkv && workspace && stats, "fatt_kstats: NULL buffer");
-    int S = (int)((N + 2047) / 2048); if (S > 128) S = 128; if (S < 1) S = 1;
+    const int S = fatt_segments(N);
     const int rows = (int)((N + S - 1) / S);
     hipStream_t st = (hipStream_t)stream;
     TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_fatt_kstats_partial<T>), dim3(S, B), dim3(256), 0, st, (const T*)qkv + C, (int64_t)3 * C,
                                             (float*)workspace, (int)N, C, rows));
-    hipLaunchKernelGGL(k_fatt_kstats_final, dim3(B), dim3(256), 0, st, (const float*)workspace, stats, S, C);
+    hipLaunchKernelGGL(k_fatt_kstats_final, dim3(B, (C + 3) / 4), dim3(256), 0, st, (const float*)workspace, stats, S, C);
     TCCT_LAUNCH_OK();
 }
 
