@@ -129,3 +129,48 @@ def test_allocator_pool_stays_bounded_over_steps_fullsize(tmp_path):
     assert seg1 - seg0 <= 12 and res1 <= res0 * 1.2, stats
     del k, net
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_factor_attention_identities_fullsize(dt):
+    """factorised attention (reference nets/tcct.py:311-331) at the size of MPViT stage 0 of the bench batch (8 x 400 x 552 tokens, C = 64, 8
+    heads), through identities that need no oracle:
+      * softmax over the tokens sums to 1 per channel: with v == 1 and zero crpe weights M is all ones, so out[n, h, :] = scale * sum_k q[n, h, k]
+      * with a crpe bias of 1 (zero taps) the second term adds q itself
+      * the output gradient w.r.t. v of sum(out) obeys sum_n dv[n, h, v] = scale * sum_n sum_k q[n, h, k] (columns of P sum to 1)
+      * linearity in q: out(q1 + q2) = out(q1) + out(q2)"""
+    from tcct_amd import ops
+    Bt, Ht, Wt, C, heads = 8, 400, 552, 64, 8
+    N, Ch, scale = Ht * Wt, 8, 8 ** -0.5
+    g = torch.Generator(device='cuda').manual_seed(7)
+    qkv = torch.randn((Bt, N, 3 * C), device='cuda', generator=g).to(dt)
+    qkv[..., 2 * C:] = 1.0
+    convs = []
+    for k, split in ((3, 2), (5, 3), (7, 3)):
+        m = torch.nn.Conv2d(split * Ch, split * Ch, k, padding=k // 2, groups=split * Ch).cuda()
+        m.weight.data.zero_()
+        m.bias.data.zero_()
+        convs.append(m)
+    tolr = 2e-3 if dt == torch.float32 else 2e-2
+    q = qkv[..., :C].float().view(Bt, N, heads, Ch)
+    want = (scale * q.sum(-1, keepdim=True)).expand(Bt, N, heads, Ch).reshape(Bt, N, C)
+    qkv.requires_grad_(True)
+    out = ops.factor_att(qkv, (Ht, Wt), heads, scale, convs)
+    assert (out.float() - want).abs().max().item() < tolr * max(1.0, want.abs().max().item())
+    out.float().sum().backward()
+    dv = qkv.grad[..., 2 * C:].float().view(Bt, N, heads, Ch).sum(1)                    # [B, heads, Ch]
+    want_dv = (scale * q.sum((1, 3))).unsqueeze(-1).expand(Bt, heads, Ch)
+    assert (dv - want_dv).abs().max().item() < 2e-2 * max(1.0, want_dv.abs().max().item())
+    with torch.no_grad():
+        for m in convs:
+            m.bias.data.fill_(1.0)
+        out1 = ops.factor_att(qkv.detach(), (Ht, Wt), heads, scale, convs)
+        assert (out1.float() - (want + qkv.detach()[..., :C].float())).abs().max().item() < tolr * max(1.0, want.abs().max().item())
+        if dt == torch.float32:
+            a = qkv.detach().clone()
+            b2 = qkv.detach().clone()
+            b2[..., :C] = torch.randn((Bt, N, C), device='cuda', generator=g)
+            s = a.clone()
+            s[..., :C] = a[..., :C] + b2[..., :C]
+            oa, ob, os_ = (ops.factor_att(t, (Ht, Wt), heads, scale, convs) for t in (a, b2, s))
+            assert (oa + ob - os_).abs().max().item() < 1e-3 * max(1.0, os_.abs().max().item())

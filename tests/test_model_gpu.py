@@ -599,6 +599,15 @@ def test_factor_attention_variant_trains_and_matches_oracle(tmp_path):
             e = float((params[name].grad.double().cpu() - g.double()).norm() / g.double().norm())
             assert e < 0.1, (name, e)
 
+    # eval mode (running statistics: the well-conditioned comparison): logits of the whole network against the oracle
+    fresh = RegNet(stc_tt(5, att='factor'), con='cos', out_channels=5)
+    fresh.load_state_dict(sd, strict=True)
+    fresh = fresh.cuda().eval()
+    with torch.no_grad():
+        outs_o, _ = O.ftc_forward({kk: v.detach().clone() for kk, v in sd.items()}, img, train=False)
+        outs_e = fresh(img.cuda())
+    assert relerr(outs_e[0], outs_o[0]) < 1e-4, relerr(outs_e[0], outs_o[0])
+
     m16 = RegNet(stc_tt(5, att='factor', compute_dtype=torch.bfloat16), con='cos', out_channels=5)
     m16.load_state_dict(sd, strict=True)
     k16 = make_kite(m16.cuda().train(), tmp_path, False, False, lr=3e-3)
