@@ -187,8 +187,24 @@ def cpu_baseline(a):
                       f'{torch.__version__}; {best} threads = fastest of 8/16/32/64 on this {ncpu}-CPU host; {dt:.2f}s/step'}
 
 
+_RESULT_OUT = None
+
+
+def _reserve_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner on fd 1 when its communicator is created (seen under
+    torchrun on the GPU boxes: "RCCL version : ..." ahead of the result), and any library may do the like: keep the real stdout for
+    the result line and route everything else written to fd 1 during the run to stderr."""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
+    return _RESULT_OUT
+
+
 def main():
     a = parse()
+    out_stream = _reserve_stdout()
     from tcct_amd import dist as tdist
     world, rank, local = tdist.env_world()
     if world != a.gpus and world > 1:
@@ -199,7 +215,7 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if a.roofline_only:
-        print(json.dumps({'roofline': dominant_kernel_roofline(a)}))
+        print(json.dumps({'roofline': dominant_kernel_roofline(a)}), file=out_stream, flush=True)
         return
     k, ds, args = build_trainer(a, world)
     k.model.train()
@@ -250,7 +266,7 @@ def main():
         out['roofline']['step_model_GBs'] = round(per_img * value / world / 1e9, 1)
     if world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(a)
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=out_stream, flush=True)
     tdist.barrier()
 
 
