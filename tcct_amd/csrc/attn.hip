@@ -203,7 +203,8 @@ __global__ void __launch_bounds__(256) k_dwk(const T* __restrict__ x, int64_t ld
 // Block = 32 channel lanes x 8 image rows of one column segment; a thread walks its row from left to right with the K x K window of x
 // in registers (K new loads per pixel instead of K*K), sums its K*K products in registers, the 8 rows are combined by one wave shuffle and
 // an LDS pass, and the block issues ONE atomic per element.  (The first version let 128 blocks walk 1 700 pixels each with K*K loads per
-// pixel: 21 ms for the 7x7 group at level 1 of the bench shape.)
+// pixel: 21 ms for the 7x7 group at level 1 of the bench shape; now 0.97 ms.  Tried without gain: 4 pixels per trip with their loads issued
+// together -- 182 VGPRs, 1.57 ms.)
 template <typename T, int K>
 __global__ void __launch_bounds__(256) k_dwk_wgrad(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t ldy,
                                                    float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int Cg, int segw) {
