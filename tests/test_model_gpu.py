@@ -616,22 +616,3 @@ def test_factor_attention_variant_trains_and_matches_oracle(tmp_path):
     losses = [float(k16.train_step(img.cuda(), lab.cuda())) for _ in range(12)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.05, losses
 
-
-def test_factor_attention_step_replays_from_a_hipgraph(tmp_path):
-    """the att='factor' training step is capturable like the default one (the attention entry points only launch on the stream they are
-    given, their workspace size is a host-side formula): capture after 2 eager steps, then replays on one batch drive the loss down"""
-    import tcct_oracle as O
-    from tcct_amd.graph import GraphedTrainStep
-    from tcct_amd.nets import stc_tt, RegNet
-    model = RegNet(stc_tt(5, att='factor', compute_dtype=torch.bfloat16), con='cos', out_channels=5)
-    sd = O.formula_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()])
-    model.load_state_dict(sd, strict=True)
-    model.base.base_vit.drop_probs = [0.0] * 4
-    k = make_kite(model.cuda().train(), tmp_path, False, False, lr=3e-3)
-    for g in k.optimG.param_groups:
-        g['lr'] = 3e-3
-    gstep = GraphedTrainStep(k, warmup=2)
-    batch = tuple(t.cuda() for t in O.synth_batch(2, 64, 96, seed=31))
-    losses = [gstep(*batch).item() for _ in range(14)]
-    assert gstep.graph is not None and k.optimG._step == 14
-    assert all(np.isfinite(losses)) and losses[-1] < losses[2] - 0.05, losses
