@@ -170,23 +170,24 @@ __global__ void __launch_bounds__(256) k_dwk(const T* __restrict__ x, int64_t ld
                     acc.v[0] += wv.x * xv.v[0]; acc.v[1] += wv.y * xv.v[1]; acc.v[2] += wv.z * xv.v[2]; acc.v[3] += wv.w * xv.v[3];
                 }
             }
-        } else
+        } else {
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            const int yy = y0 + ky - R;
-            const bool oky = yy >= 0 && yy < H;
-            f4 xv[K];
+            for (int ky = 0; ky < K; ++ky) {
+                const int yy = y0 + ky - R;
+                const bool oky = yy >= 0 && yy < H;
+                f4 xv[K];
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const int xx = x0 + kx - R;
-                const bool ok = oky && xx >= 0 && xx < W;
-                xv[kx] = ld4(x + (int64_t)(ok ? pix + (ky - R) * W + (kx - R) : pix) * ldx + c4);
-                if (!ok) xv[kx] = f4zero();
-            }
+                for (int kx = 0; kx < K; ++kx) {
+                    const int xx = x0 + kx - R;
+                    const bool ok = oky && xx >= 0 && xx < W;
+                    xv[kx] = ld4(x + (int64_t)(ok ? pix + (ky - R) * W + (kx - R) : pix) * ldx + c4);
+                    if (!ok) xv[kx] = f4zero();
+                }
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const float4 wv = *reinterpret_cast<const float4*>(sw + (ky * K + kx) * Cg + c4);
-                acc.v[0] += wv.x * xv[kx].v[0]; acc.v[1] += wv.y * xv[kx].v[1]; acc.v[2] += wv.z * xv[kx].v[2]; acc.v[3] += wv.w * xv[kx].v[3];
+                for (int kx = 0; kx < K; ++kx) {
+                    const float4 wv = *reinterpret_cast<const float4*>(sw + (ky * K + kx) * Cg + c4);
+                    acc.v[0] += wv.x * xv[kx].v[0]; acc.v[1] += wv.y * xv[kx].v[1]; acc.v[2] += wv.z * xv[kx].v[2]; acc.v[3] += wv.w * xv[kx].v[3];
+                }
             }
         }
         T* dst = y + (int64_t)pix * ldy + c4;

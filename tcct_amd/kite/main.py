@@ -82,8 +82,6 @@ def main(argv=None):
     if args.att != 'pool':
         if args.net not in ('stc_tt', 'tcct'):
             raise SystemExit(f'--att={args.att} is only offered for --net=stc_tt')
-        if args.graph:
-            raise SystemExit('--graph=true is not validated with --att=factor (see DESIGN 3c); run the attention variant with eager launches')
         kw['att'] = args.att
     net = factory(dataset.out_channels, **kw)
     net = nets.RegNet(net, con=args.type_udh, out_channels=dataset.out_channels)

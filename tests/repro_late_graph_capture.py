@@ -1,0 +1,31 @@
+"""Reproducer, NOT collected by the suite (file name): one more GraphedTrainStep capture at the END of the full GPU suite segfaults inside
+hipGraphLaunch at its first replay -- with either token mixer (FA_ATT=pool|factor) -- while the same test passes alone, after any single test
+file, and after tests/test_model_gpu.py as a whole.  Run:
+    python -X faulthandler -m pytest tests tests/repro_late_graph_capture.py -m gpu -x -q"""
+import os, sys
+import numpy as np
+import pytest
+import torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, '..', 'oracle'))
+pytestmark = pytest.mark.gpu
+
+
+def test_zz_factor_attention_step_replays_from_a_hipgraph(tmp_path):
+    import tcct_oracle as O
+    from test_model_gpu import make_kite
+    from tcct_amd.graph import GraphedTrainStep
+    from tcct_amd.nets import stc_tt, RegNet
+    model = RegNet(stc_tt(5, att=os.environ.get('FA_ATT', 'factor'), compute_dtype=torch.bfloat16), con='cos', out_channels=5)
+    sd = O.formula_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()])
+    model.load_state_dict(sd, strict=True)
+    model.base.base_vit.drop_probs = [0.0] * 4
+    k = make_kite(model.cuda().train(), tmp_path, False, False, lr=3e-3)
+    for g in k.optimG.param_groups:
+        g['lr'] = 3e-3
+    gstep = GraphedTrainStep(k, warmup=2)
+    batch = tuple(t.cuda() for t in O.synth_batch(2, 64, 96, seed=31))
+    losses = [gstep(*batch).item() for _ in range(14)]
+    assert gstep.graph is not None and k.optimG._step == 14
+    assert all(np.isfinite(losses)) and losses[-1] < losses[2] - 0.05, losses
