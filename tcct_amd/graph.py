@@ -33,7 +33,7 @@ class GraphedPredict:
             idx = torch.empty((B, H, W), device=lg.device, dtype=torch.uint8)
             lib.softmax_pick(lg, None, B * H * W, C, None, idx, 0 if lg.dtype == torch.float32 else 1)
             return out, idx
-        side = torch.cuda.Stream()
+        side = ops.fresh_stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):               # warm-up off the capture: first-call attribute setting, allocator warm
             for _ in range(self.warmup):
@@ -76,7 +76,7 @@ class GraphedTrainStep:
         self.k, self.warmup = kite, warmup
         self.calls = 0
         self.graph = None
-        self.stream = torch.cuda.Stream()
+        self.stream = ops.fresh_stream()          # never an alias of the library's side streams (pool of 32 streams, round-robin)
         self.shape = None
 
     def __call__(self, img, lab):

@@ -77,6 +77,23 @@ _WGRAD_KEEP = []
 _WGRAD_RECORD_STREAM = os.environ.get('TCCT_WGRAD_RECORD_STREAM', '0') == '1'      # the old behaviour, kept for A/B measurements only
 
 
+def fresh_stream(device=None, avoid=()):
+    """A torch.cuda.Stream whose HIP stream is none of: the current stream, the library's side streams, `avoid`.  torch hands out streams
+    from a pool of 32 per device, round-robin: in a long process the 33rd `torch.cuda.Stream()` IS the first one again, and a capture
+    stream that aliased the weight-gradient / encoder side stream would turn their fork-join into a wait of a stream on itself.  (A guard:
+    it was written while chasing the late-capture segfault of DESIGN 5b, which it did NOT cure.)"""
+    taken = {torch.cuda.current_stream(device).cuda_stream}
+    for v in _SIDE_STREAMS.values():
+        taken.add((v[0] if isinstance(v, tuple) else v).cuda_stream)
+    for st in avoid:
+        taken.add(st.cuda_stream)
+    for _ in range(64):
+        st = torch.cuda.Stream(device=device)
+        if st.cuda_stream not in taken:
+            return st
+    raise TcctError('fresh_stream: no stream of the pool is free of aliases')
+
+
 class _wgrad_stream:
     def __init__(self, enable, *tensors):
         self.enable, self.tensors = enable, tensors
@@ -88,7 +105,7 @@ class _wgrad_stream:
         key = ('wgrad', cur.device.index)
         ent = _SIDE_STREAMS.get(key)
         if ent is None:         # the side stream and ONE reusable event for the cur -> side dependency (a wait captures the state of the
-            ent = _SIDE_STREAMS[key] = (torch.cuda.Stream(device=cur.device), torch.cuda.Event())   # event at the time it is issued)
+            ent = _SIDE_STREAMS[key] = (fresh_stream(cur.device), torch.cuda.Event())   # event at the time it is issued)
         self.side, ev = ent
         ev.record(cur)
         self.side.wait_event(ev)
@@ -374,7 +391,7 @@ def run_parallel(tag, fa, fb):
     cur = torch.cuda.current_stream()
     side = _SIDE_STREAMS.get((tag, cur.device.index))
     if side is None:
-        side = _SIDE_STREAMS[(tag, cur.device.index)] = torch.cuda.Stream(device=cur.device)
+        side = _SIDE_STREAMS[(tag, cur.device.index)] = fresh_stream(cur.device)
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         rb = fb()
@@ -400,7 +417,7 @@ def run_interleaved(tag, ga, gb, outs_b):
     cur = torch.cuda.current_stream()
     side = _SIDE_STREAMS.get((tag, cur.device.index))
     if side is None:
-        side = _SIDE_STREAMS[(tag, cur.device.index)] = torch.cuda.Stream(device=cur.device)
+        side = _SIDE_STREAMS[(tag, cur.device.index)] = fresh_stream(cur.device)
     side.wait_stream(cur)
     done_a = done_b = False
     end = object()

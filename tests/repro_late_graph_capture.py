@@ -1,7 +1,7 @@
 """Reproducer, NOT collected by the suite (file name): one more GraphedTrainStep capture at the END of the full GPU suite segfaults inside
 hipGraphLaunch at its first replay -- with either token mixer (FA_ATT=pool|factor) -- while the same test passes alone, after any single test
 file, and after tests/test_model_gpu.py as a whole.  Run:
-    python -X faulthandler -m pytest tests tests/repro_late_graph_capture.py -m gpu -x -q"""
+    python -X faulthandler -m pytest tests/test_fullsize_gpu.py tests/test_kernels_gpu.py tests/test_model_gpu.py tests/repro_late_graph_capture.py -m gpu -x -q"""
 import os, sys
 import numpy as np
 import pytest
