@@ -167,3 +167,34 @@ def test_reference_checkpoint_layouts():
         C.load_reference_checkpoint(RegNet(stc_tt(5), out_channels=5), duke)            # 9-class file, 5-class model
     with pytest.raises(TcctError):
         C.describe({'x': torch.zeros(1)})
+
+
+def test_token_mixer_option_mirrors_the_reference_constructor():
+    """att='pool' keeps the reference's 514 state_dict keys; att='factor' adds exactly the parameters the commented-out
+    FactorAtt_ConvRelPosEnc would register (reference nets/tcct.py:289-341, 443-448): qkv (with bias, tcct.py:424) / proj per block and
+    the `att.crpe` aliases of the shared ConvRelPosEnc, whose 2+3+3 head splits now divide 8 heads (tcct.py:484-488)"""
+    import pytest
+    from tcct_amd.nets import stc_tt
+    from tcct_amd.nets.tcct import ConvRelPosEnc
+    from tcct_amd.kite.main import parse_args
+    base = stc_tt(5)
+    fa = stc_tt(5, att='factor')
+    kb, kf = set(base.state_dict()), set(fa.state_dict())
+    extra = kf - kb
+    assert kb <= kf and len(extra) == 4 * (4 + 6)
+    assert all('.MHCA_layers.0.att.' in k for k in extra)
+    for s, dim in enumerate((64, 96, 128, 160)):
+        blk = f'base_vit.mhca_stages.{s}.mhca_blks.0'
+        sd = fa.state_dict()
+        assert tuple(sd[f'{blk}.MHCA_layers.0.att.qkv.weight'].shape) == (3 * dim, dim)
+        assert tuple(sd[f'{blk}.MHCA_layers.0.att.qkv.bias'].shape) == (3 * dim,)
+        Ch = dim // 8
+        assert [tuple(sd[f'{blk}.crpe.conv_list.{i}.weight'].shape) for i in range(3)] == [(2 * Ch, 1, 3, 3), (3 * Ch, 1, 5, 5), (3 * Ch, 1, 7, 7)]
+        # shared module: the alias keys are the same storage
+        assert sd[f'{blk}.MHCA_layers.0.att.crpe.conv_list.0.weight'].data_ptr() == sd[f'{blk}.crpe.conv_list.0.weight'].data_ptr()
+    with pytest.raises(ValueError):
+        stc_tt(5, att='bogus')
+    with pytest.raises(ValueError):
+        ConvRelPosEnc(Ch=8, h=8, window='3')                    # reference tcct.py:245
+    assert ConvRelPosEnc(Ch=8, h=8, window=3).channel_splits == [64]
+    assert parse_args(['--att=factor']).att == 'factor' and parse_args([]).att == 'pool'
