@@ -15,6 +15,11 @@ pytestmark = pytest.mark.gpu
 def test_zz_factor_attention_step_replays_from_a_hipgraph(tmp_path):
     import tcct_oracle as O
     from test_model_gpu import make_kite
+    if os.environ.get('FA_EMPTY_CACHE') == '1':          # hypothesis not yet tested: allocator state left by the full-size tests
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
     from tcct_amd.graph import GraphedTrainStep
     from tcct_amd.nets import stc_tt, RegNet
     model = RegNet(stc_tt(5, att=os.environ.get('FA_ATT', 'factor'), compute_dtype=torch.bfloat16), con='cos', out_channels=5)
