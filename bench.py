@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — TCCT `stc_tt` training hot path on MI355X: OCT B-scans/s, forward + losses + backward + clip + AdamW.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1: one rank per GPU.  Either the caller launches the ranks (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`:
+WORLD_SIZE/RANK/LOCAL_RANK are then in the environment) or, when `--gpus N` arrives WITHOUT that environment, this process becomes a
+launcher: it starts exactly that torch.distributed.run command as a CHILD process before anything here has touched the GPU (never an
+exec), relays the child's one JSON line and exit code.  A line whose `n_gpus` differs from `--gpus` is an error, never printed.
 
 A "step" = one pass of the hot path over one synthetic minibatch of `--bs` B-scans (1x800x1100 each, already resident in
 HBM; loader-side prep = 1->3 channel replicate inside the NHWC conversion kernel + W zero-pad 1100->1104).  Workload at
@@ -56,10 +61,23 @@ def build_trainer(a, world):
     return k, ds, args
 
 
-# HBM traffic per launch of the dominant kernel from rocprofv3 PMC passes (profiles/r01_z_summary.md): separate --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE runs of `bench.py --roofline-only`, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B
-# request on wide streaming reads), both in KiB.  Valid for the bench shape only; None when the shape differs.
-PMC_TRAFFIC_BYTES = {('bf16', 8, 800, 1100): 1022669005}     # 2 x 278550.1 KiB fetched + 441600.0 KiB written (profiles/r01_z_summary.md)
+def pmc_traffic(a, kernel_match):
+    """`roofline.traffic`: HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of `bench.py --roofline-only`
+    (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md), as recorded by
+    tools/pmc_json.py in profiles/TAG_pmc.json TOGETHER WITH a hash of the kernel sources.  Only a file collected on exactly the
+    sources this run was built from (and at this shape) is used; otherwise traffic is null and the note says why."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        import pmc_json
+        table, src = pmc_json.newest_matching(a.dtype, a.bs, a.height, a.width, ROOT)
+    except Exception as e:        # a missing profiles/ directory must not take the bench down
+        return None, f'profiles unreadable: {e}'
+    if table is None:
+        return None, src
+    for name, b in table.items():
+        if kernel_match in name:
+            return int(b), f'profiles/{src}: {name}'
+    return None, f'profiles/{src} has no kernel matching {kernel_match!r}'
 
 
 def dominant_kernel_roofline(a, iters=20):
@@ -83,10 +101,12 @@ def dominant_kernel_roofline(a, iters=20):
         wp = torch.empty(9 * 1024, device='cuda', dtype=torch.bfloat16)
         lib.conv32_pack_weights(w, wp, 3, 3, 0)
         name, name2 = 'k_conv32_mfma<false,0,3,3> (3x3 32->32 fwd/dgrad @L0)', 'k_conv32_wgrad<5,false,true> (3x3 32->32 @L0)'
+        match = 'k_conv32_mfma<false, 0, 3, 3>'                  # the symbol as rocprofv3 prints it
         fn = lambda: lib.conv32_fwd(x, wp, b, y, a.bs, a.height, Wp, 3, 3, 1, 1)                              # noqa: E731
         fn2 = lambda: lib.conv32_wgrad(x, dy, dw, db, a.bs, a.height, Wp, 3, 3, 1, 1)                         # noqa: E731
     else:
         name, name2 = 'k_conv_fwd<float,float> (3x3 32->32 @L0)', 'k_conv_wgrad<float,float> (3x3 32->32 @L0)'
+        match = 'k_conv_fwd<float, float>'
         fn = lambda: lib.conv2d_fwd(x, w, b, y, a.bs, a.height, Wp, 32, 32, 32, 3, 3, 1, 1, 1, 0, 0)          # noqa: E731
         fn2 = lambda: lib.conv2d_wgrad(x, dy, dw, db, a.bs, a.height, Wp, 32, 32, 32, 3, 3, 1, 1, 1, 0, 0)   # noqa: E731
 
@@ -123,8 +143,9 @@ def dominant_kernel_roofline(a, iters=20):
     bytes_alg = 2.0 * x.numel() * x.element_size()
     ach, ach2 = bytes_alg / (ms * 1e-3) / 1e9, bytes_alg / (ms2 * 1e-3) / 1e9
     flops = 2.0 * 9 * 32 * 32 * a.bs * a.height * Wp
+    traffic, traffic_src = pmc_traffic(a, match)
     return {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-            'traffic': PMC_TRAFFIC_BYTES.get((a.dtype, a.bs, a.height, a.width)), 'kernel': name, 'ms_per_launch': round(ms, 4),
+            'traffic': traffic, 'traffic_source': traffic_src, 'kernel': name, 'ms_per_launch': round(ms, 4),
             'launches_timed': iters, 'algorithmic_bytes': int(bytes_alg), 'tflops': round(flops / (ms * 1e-3) / 1e12, 2),
             'second': {'kernel': name2, 'achieved': round(ach2, 1), 'frac': round(ach2 / HBM_PEAK_GBS, 4), 'ms_per_launch': round(ms2, 4),
                        'algorithmic_bytes': int(bytes_alg)}, 'others': others}
@@ -202,13 +223,53 @@ def _reserve_stdout():
     return _RESULT_OUT
 
 
+def launch_ranks(a):
+    """`--gpus N` (N > 1) without a torchrun environment: be the launcher.  The parent makes NO GPU call (no torch.cuda.* that
+    initialises HIP, no tcct_amd import) — it starts `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` as a child
+    process, lets its stderr through, and relays exactly one JSON result line from the child's stdout.  Exit code = the child's."""
+    import socket
+    import subprocess
+    port = os.environ.get('TCCT_BENCH_PORT')
+    if port is None:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', TCCT_BENCH_CHILD='1')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or a.gpus) // a.gpus)))
+    print('bench.py: launching', ' '.join(cmd), file=sys.stderr, flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        ln = ln.strip()
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        elif ln:
+            print(ln, file=sys.stderr)
+    if r.returncode != 0:
+        raise SystemExit(f'bench.py: the {a.gpus}-rank child exited with code {r.returncode}' if r.returncode > 0 else
+                         f'bench.py: the {a.gpus}-rank child was killed by signal {-r.returncode}')
+    if line is None:
+        raise SystemExit('bench.py: the child ranks printed no result line')
+    got = json.loads(line)
+    if got.get('n_gpus') != a.gpus or got.get('config', {}).get('ranks') != a.gpus:
+        raise SystemExit(f"bench.py: asked for --gpus={a.gpus} but the result line says n_gpus={got.get('n_gpus')} "
+                         f"ranks={got.get('config', {}).get('ranks')}")
+    print(line, flush=True)
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(a)              # before ANY GPU call in this process
     out_stream = _reserve_stdout()
     from tcct_amd import dist as tdist
     world, rank, local = tdist.env_world()
-    if world != a.gpus and world > 1:
-        raise SystemExit(f'--gpus={a.gpus} but WORLD_SIZE={world}')
+    if world != a.gpus:
+        raise SystemExit(f'--gpus={a.gpus} but WORLD_SIZE={world}: one rank per GPU, launch with --nproc-per-node={a.gpus}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X')
     if os.environ.get('TCCT_DIST_BACKEND') == 'gloo':      # test mode: several ranks share the GPUs that exist (RCCL needs one GPU per rank)
@@ -243,17 +304,24 @@ def main():
     dt = time.perf_counter() - t0
     dt = tdist.max_over_ranks(dt, torch.device('cuda', local))
     lossv = float(loss.item())
+    devices = tdist.gather_strings(f'cuda:{local} ({torch.cuda.get_device_name(local)})')
     tdist.barrier()
     if rank != 0:
         tdist.barrier()         # leave together with rank 0 (which still times the roofline kernels): no rank tears the group down early
         return
+    import torch.distributed as tdd
+    ranks = tdd.get_world_size() if tdd.is_initialized() else 1
+    if ranks != a.gpus:
+        raise SystemExit(f'--gpus={a.gpus} but the process group has {ranks} ranks')
     value = a.bs * world * a.steps / dt
     out = {
         'metric': 'OCT B-scans/sec fwd+bwd(+clip+AdamW), stc_tt bs=8 1x800x1100', 'value': round(value, 3), 'unit': 'B-scans/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
         'config': {'workload': f'stc_tt{"" if a.att == "pool" else "(att=" + a.att + ")"} --los={a.los} bs={a.bs}/GPU 1x{a.height}x{a.width} (net tensors 3x{a.height}x{(a.width + 15) // 16 * 16})',
-                   'global_batch': a.bs * world, 'parallelism': f'dp{world}', 'loss_last': round(lossv, 4),
+                   'global_batch': a.bs * world, 'parallelism': f'dp{world}', 'ranks': ranks,
+                   'backend': (tdd.get_backend() if tdd.is_initialized() else None), 'rank_devices': devices,
+                   'grad_allreduce': getattr(k.optimG, 'allreduce_mode', 'none'), 'loss_last': round(lossv, 4),
                    'step_ms_gpu_min_med_max': _min_med_max([marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]),
                    'step_ms_host_enqueue_min_med_max': _min_med_max([1e3 * (host[i + 1] - host[i]) for i in range(a.steps)]),
                    'slowest_step': max(range(a.steps), key=lambda i: host[i + 1] - host[i]),

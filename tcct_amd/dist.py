@@ -30,6 +30,13 @@ def init(backend=None):
     return world, rank, local
 
 
+def world_rank():
+    """(world size, rank) of the initialised process group, (1, 0) without one"""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
 def shard_batch(n_global, world, rank):
     """contiguous slice of the global minibatch owned by `rank` (global batch 64 -> 8 x 8)"""
     if n_global % world:
@@ -45,11 +52,119 @@ def allreduce_sum_(flat):
     return flat
 
 
-def attach(optimizer):
-    """make a FlatAdamW average gradients over the process group before the clip+AdamW kernel"""
+N_BUCKETS = 3
+
+
+def bucket_of(name):
+    """Static gradient bucket of a parameter, by the order in which the backward pass finishes with its module:
+       0  fusion + decoder + heads (FTC.tran_*, head, dec*, t32*, aux*): done when the backward pass reaches the encoder outputs
+       1  the deep encoder levels: CrossResNet blocks 1-4, MPViT stages 1-3
+       2  everything that finishes last: CrossResNet level 0 + first conv, MPViT stem + stage 0, and the loss-side RegNet modules
+          (lap_reg / lap_map are applied twice per step: their gradients accumulate through autograd and are copied in at step())"""
+    n = name[5:] if name.startswith('base.') else name
+    if n.startswith('base_cnn.path_estan.'):
+        return 2 if n.split('.')[2] == '0' else 1
+    if n.startswith(('base_vit.mhca_stages.', 'base_vit.patch_embed_stages.')):
+        return 2 if n.split('.')[2] == '0' else 1
+    if n.startswith(('base_cnn.', 'base_vit.')) or not name.startswith('base.'):
+        return 2
+    return 0
+
+
+class GradBuckets:
+    """Bucketed all-reduce of the flat gradient, overlapped with the backward pass.  The model marks the tensor edges that leave a
+    bucket's modules (ops.grad_mark); when the backward pass has crossed all edges of bucket b (and buckets < b have left), the
+    bucket's slice of the flat gradient is all-reduced on a dedicated comm stream that waits for every compute stream of the step
+    (events; no host sync).  FlatAdamW.step() launches whatever is left (always the last bucket) and joins the comm stream before the
+    sum-of-squares kernel.  Launch order is 0,1,2 on every rank by construction, so the collectives match across ranks."""
+
+    KEYS = {'dec': 0, 'deep': 1}
+
+    def __init__(self):
+        self.n_buckets = N_BUCKETS
+        self.ranges = None
+        self.flat = None
+        self.comm = None
+        self.works = []
+        self.launched = 0
+        self.ready = [False] * N_BUCKETS
+        self.armed = False
+        self.overlap = os.environ.get('TCCT_DP_OVERLAP', '1') != '0'
+        self.launch_log = []            # (bucket, 'backward' | 'step') of the last step: tests and bench read it
+
+    def bind(self, flat_g, sizes):
+        self.flat = flat_g
+        self.ranges, off = [], 0
+        for n in sizes:
+            self.ranges.append((off, off + n))
+            off += n
+        if flat_g.is_cuda:
+            from . import ops
+            self.comm = ops.fresh_stream(flat_g.device)
+
+    def begin_step(self, armed):
+        self.works, self.launched = [], 0
+        self.ready = [False] * self.n_buckets
+        self.armed = bool(armed) and self.overlap and self.ranges is not None
+        self.launch_log = []
+
+    def is_launched(self, offset):
+        return self.ranges is not None and any(b < self.launched and s <= offset < e for b, (s, e) in enumerate(self.ranges))
+
+    def on_mark(self, key):
+        """ops.grad_mark listener (autograd's device thread): all edges of `key` crossed"""
+        b = self.KEYS.get(key)
+        if b is None or not self.armed:
+            return
+        self.ready[b] = True
+        while self.launched < self.n_buckets - 1 and self.ready[self.launched]:
+            self._launch(self.launched, 'backward')
+
+    def _launch(self, b, where):
+        s, e = self.ranges[b]
+        self.launched = b + 1
+        self.launch_log.append((b, where))
+        if e <= s:
+            return
+        part = self.flat[s:e]
+        if self.comm is None:
+            self.works.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True))
+            return
+        from . import ops
+        for st in ops.step_streams() + [torch.cuda.current_stream(self.flat.device)]:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.comm.wait_event(ev)
+        with torch.cuda.stream(self.comm):
+            self.works.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        if self.ranges is None:
+            raise RuntimeError('GradBuckets.finish() before bind()')
+        while self.launched < self.n_buckets:
+            self._launch(self.launched, 'step')
+        for w in self.works:
+            w.wait()                    # nccl: the current stream waits for the collective; gloo: the host does
+        if self.comm is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm)
+        self.works = []
+
+
+def attach(optimizer, model=None):
+    """make a FlatAdamW average gradients over the process group before the clip+AdamW kernel.  With `model`, the gradient is
+    all-reduced in N_BUCKETS static buckets overlapped with the backward pass (TCCT_DP_OVERLAP=0: one blocking all-reduce of the whole
+    buffer after the backward pass, the round-1 behaviour, kept for A/B timing)."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('TCCT_FORCE_DIST', '0') == '1'):
         optimizer.world = dist.get_world_size()
         optimizer.allreduce = allreduce_sum_
+        optimizer.allreduce_mode = 'single blocking all-reduce after backward'
+        if model is not None and os.environ.get('TCCT_DP_OVERLAP', '1') != '0':
+            from . import ops
+            for name, p in model.named_parameters():
+                p._tcct_bucket = bucket_of(name)
+            optimizer.buckets = GradBuckets()
+            ops.set_grad_mark_listener(optimizer.buckets.on_mark)
+            optimizer.allreduce_mode = f'{N_BUCKETS} buckets (decoder | deep encoder levels | level 0 + stems) on a comm stream, overlapped with backward'
     return optimizer
 
 
@@ -65,6 +180,15 @@ def max_over_ranks(value, device):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_strings(s):
+    """one string per rank, in rank order (bench.py records each rank's device in its result line)"""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, s)
+        return out
+    return [s]
 
 
 def barrier():

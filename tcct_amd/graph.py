@@ -100,6 +100,12 @@ class GraphedTrainStep:
                 return loss
             k.optimG.enable_device_state()
             k.udh_out = None
+            # a late capture in a long process has crashed inside hipGraphLaunch (cause open): drop every dead autograd
+            # graph / cached block of earlier work before capturing, so the capture sees a quiet allocator
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
             self.s_img, self.s_lab = img.clone(), lab.clone()
             self.stream.wait_stream(cur)
             g = torch.cuda.CUDAGraph()
@@ -108,6 +114,7 @@ class GraphedTrainStep:
             k.udh_out = None
             k.optimG._step -= 1         # the Python side of step() ran once while capturing; the replay below is the real step
             self.graph = g
+            ops.ZERO.frozen = True      # the graph holds pointers into the zero pool
         else:
             self.s_img.copy_(img)
             self.s_lab.copy_(lab)

@@ -19,7 +19,8 @@ class KiteSeg(KiteBack):
     cnt_val = 0
     udh_out = None
     udh_lab = None
-    use_graph = True        # hipGraph replay of the eval forward for batches of <= 2 images (TCCT_GRAPH=0 disables)
+    use_graph = False       # hipGraph replay of the eval forward for batches of <= 2 images: opt-in (TCCT_GRAPH=1) until the late-capture
+                            # crash of DESIGN 5b is root-caused (the first validation of fit() is a capture late in a long process)
     _graphed = None
     _graphed_step = None    # --graph=true: tcct_amd.graph.GraphedTrainStep
     fuse_aux_loss = True    # training: resize + softmax + Dice of the aux heads in one kernel (TCCT_FUSE_AUX=0 disables)
@@ -33,7 +34,9 @@ class KiteSeg(KiteBack):
         self.criterion.NB_CLASS = self.NB_CLASS
         self.best_dice = -1.0
         import os
-        self.use_graph = os.environ.get('TCCT_GRAPH', '1') != '0'
+        self.use_graph = os.environ.get('TCCT_GRAPH', '0') == '1'
+        from .. import dist as tdist
+        self.world, self.rank = (tdist.world_rank() if args.pl else (1, 0))
         self.fuse_aux_loss = os.environ.get('TCCT_FUSE_AUX', '1') != '0'
 
     def predict(self, img, softmax=True, *args):
@@ -67,11 +70,16 @@ class KiteSeg(KiteBack):
             self.train(i)
             self.schedG.step()
             if i % 10 == 0 or (i > 0.5 * epochs and i % 5 == 0):
-                logs = self.val(epoch=i)
+                logs = self.val(epoch=i)            # every rank validates (identical weights): best_dice stays in step without a broadcast
                 if logs['val_f1s'] > self.best_dice:
                     self.best_dice = logs['val_f1s']
-                    torch.save(self.model.state_dict(), self.root + '/val_top.pt')
-            self.grad_dump(i)
+                    if self.rank == 0:              # one writer per file; the others wait so that nobody reads a half-written checkpoint
+                        torch.save(self.model.state_dict(), self.root + '/val_top.pt')
+            if self.rank == 0:
+                self.grad_dump(i)
+            if self.world > 1:
+                from .. import dist as tdist
+                tdist.barrier()
             dt = time.time() - ts
             print('{:03}* {:.2f} mins, left {:.2f} hours to run'.format(i, dt / 60, dt / 3600 * (epochs - i)))
         print('\nRunning {:.2f} hours for {} epochs!'.format((time.time() - t0) / 3600, epochs))
@@ -119,8 +127,17 @@ class KiteSeg(KiteBack):
         torch.set_grad_enabled(True)
         self.model.train()
         tot = torch.zeros((), device=self.device)
-        for i, imgs in enumerate(self.dataset.trainSet(bs=self.args.bs)):
+        # data parallel (--pl=true): the loader is asked for the GLOBAL minibatch (bs per GPU x world) and every rank trains on its own
+        # contiguous slice of it (tcct_amd.dist.shard_batch; SURVEY 8(e): global 64 -> 8 x 8), so the ranks see different B-scans and run
+        # the same number of steps.  A ragged last global batch that does not divide by the world size is dropped on every rank.
+        from .. import dist as tdist
+        for i, imgs in enumerate(self.dataset.trainSet(bs=self.args.bs * self.world)):
             img, lab, _, _ = self.dataset.parse(imgs)
+            if self.world > 1:
+                if img.shape[0] % self.world:
+                    continue
+                sl = tdist.shard_batch(img.shape[0], self.world, self.rank)
+                img, lab = img[sl], lab[sl]
             img, lab = self.cuda(img), self.cuda(lab)
             if getattr(self.args, 'graph', False) and self.optimG.allreduce is None:
                 if self._graphed_step is None:

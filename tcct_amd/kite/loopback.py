@@ -92,7 +92,7 @@ class KiteBack(object):
         self.epoch = epoch
         self.lossName = loss
         params = [p for p in self.model.parameters() if p.requires_grad]
-        self.optimG = tdist.attach(FlatAdamW(params, lr=lr, weight_decay=wd, max_norm=12.0))
+        self.optimG = tdist.attach(FlatAdamW(params, lr=lr, weight_decay=wd, max_norm=12.0), self.model)
         self.schedG = lr_scheduler.CyclicLR(self.optimG, base_lr=1e-6, max_lr=1e-4, cycle_momentum=False, step_size_up=4,
                                             step_size_down=60)
 

@@ -49,8 +49,9 @@ def build_parser():
                    help="token mixer of the ViT blocks: 'pool' = MetaPool (reference nets/tcct.py:449); 'factor' = the factorised attention the "
                         "reference keeps commented out (nets/tcct.py:443-448; --net=stc_tt / tcct only)")
     p.add_argument('--graph', type=str2bool, default=False,
-                   help='replay the training step from a hipGraph (launch-bound crop sizes such as the 256x256 of the reference recipe; '
-                        'single process, fixed batch shape)')
+                   help='EXPERIMENTAL: replay the training step from a hipGraph (launch-bound crop sizes such as the 256x256 of the reference '
+                        'recipe; single process, fixed batch shape).  A capture late in a long process has crashed inside hipGraphLaunch '
+                        '(DESIGN 5b, cause open): use it from a fresh process only')
     return p
 
 

@@ -4,6 +4,8 @@ Same constructor, attributes (`base`, `fcs`, `fcp`, `lap_epl`, `lap_reg`, `lap_m
 `tgt_list`) and methods (`forward`, `regular_udh`, `regular_reg`) as the reference; both losses accept the reference's
 arguments (raw logits [B,C,H,W], one-hot int64 labels [B,C,H,W]) and additionally class-index labels [B,H,W].
 Hidden RNG of the reference (`rand_like`, reg.py:120,147-148) becomes the optional `noise=` argument."""
+import weakref
+
 import torch
 from torch import nn
 
@@ -19,9 +21,13 @@ def as_label_index(true):
     """one-hot int64 [B,C,H,W] (kite/loop_seg.py:119) or class indices [B,H,W] -> uint8 [B,H,W] on device."""
     if not true.is_cuda:
         raise TcctError('labels must live on the GPU (no CPU fallback)')
+    # one-entry cache: calc_loss converts the same label tensor up to three times per step (Dice, udh, reg).  A hit needs the SAME
+    # tensor object (weak reference still alive and identical), unchanged storage, shape, dtype and version counter: a freed source
+    # whose address is reused by a new tensor can no longer alias a stale entry, and the entry pins no device memory beyond the
+    # converted uint8 map of the current step.
     key = (true.data_ptr(), tuple(true.shape), true.dtype, true._version)
     hit = _LABEL_CACHE.get('k')
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and hit[2]() is true:
         return hit[1]
     if true.dim() == 3:
         if true.dtype == torch.uint8:
@@ -40,7 +46,7 @@ def as_label_index(true):
         lib.onehot_to_index(t, out, B, C, H * W)
     else:
         raise TcctError(f'labels must be [B,H,W] or one-hot [B,C,H,W], got {tuple(true.shape)}')
-    _LABEL_CACHE['k'] = (key, out)
+    _LABEL_CACHE['k'] = (key, out, weakref.ref(true))
     return out
 
 

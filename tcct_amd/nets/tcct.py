@@ -126,6 +126,8 @@ class CrossResNet(nn.Module):
             if i + 1 < n:               # the reference also pools after the last level; that result is unused
                 x, skip = ops.maxpool2_fork(x)      # skip aliases the level's output: its gradient is added inside the pooling backward
                 xs.append(skip)
+                if i == 0:              # data-parallel runs: the backward pass crossing this edge has finished levels 1-4 (tcct_amd/dist.py)
+                    x = ops.grad_mark(x, 'deep')
             else:
                 xs.append(x)
             yield i
@@ -435,6 +437,8 @@ class MPViT(nn.Module):
         scales = self._dp_scales(x.shape[0], x.device)
         x = self.stem[1](self.stem[0](x))
         for i in range(4):
+            if i == 1:                  # data-parallel runs: crossing this edge backwards means stages 1-3 are done (tcct_amd/dist.py)
+                x = ops.grad_mark(x, 'deep')
             if i > 0 and torch.is_grad_enabled() and x.requires_grad:
                 p, xs[-1] = self.patch_embed_stages[i](x, fork=True)    # the returned level is the alias (read by FTC.tran_vit)
             else:
@@ -550,7 +554,8 @@ class FTC(nn.Module):
         if self.flag_vit and self.flag_cnn:
             cs, vs = [], []
             ops.run_interleaved('vit', self.base_cnn.iter_levels(x, cs), self.base_vit.iter_stages(x, vs), vs)
-            (c1, c2, c3, c4, c5), (v2, v3, v4, v5) = cs, vs
+            # data-parallel runs: once the backward pass has crossed these nine edges, every fusion / decoder / head gradient is final
+            (c1, c2, c3, c4, c5), (v2, v3, v4, v5) = [ops.grad_mark(t, 'dec') for t in cs], [ops.grad_mark(t, 'dec') for t in vs]
             f = [c1]
             for j, (v, c) in enumerate(((v2, c2), (v3, c3), (v4, c4), (v5, c5))):
                 tv, tc = getattr(self, f'tran_vit{j}'), getattr(self, f'tran_cnn{j}')

@@ -22,9 +22,13 @@ class _ZeroPool:
         self.buf = None
         self.off = 0
         self.active = False
+        self.frozen = False     # set once a hipGraph has captured a step that uses the pool (tcct_amd/graph.py)
 
     def begin(self, device, nbytes=8 << 20):
         if self.buf is None or self.buf.device != device or self.buf.numel() < nbytes:
+            if self.frozen:     # a captured hipGraph holds pointers into the pool: replacing it would leave them dangling
+                raise TcctError('the zero pool cannot be re-allocated after a training step was captured into a hipGraph '
+                                f'(pool on {self.buf.device}, step on {device})')
             self.buf = torch.empty(nbytes, device=device, dtype=torch.uint8)
         self.buf.zero_()
         self.off = 0
@@ -56,7 +60,59 @@ ZERO = _ZeroPool()
 
 def begin_step(device):
     """call once per training step before the forward (KiteSeg.train_step does): arms the zero pool"""
-    ZERO.begin(torch.device(device))
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:          # torch.device('cuda') != torch.device('cuda', 0): never re-allocate the pool for that
+        device = torch.device('cuda', torch.cuda.current_device())
+    ZERO.begin(device)
+    _STEP['main'] = torch.cuda.current_stream(device)
+    for v in _STEP['marks'].values():
+        v[0] = v[1] = 0
+
+
+# ---- gradient-readiness marks (data-parallel overlap, tcct_amd/dist.py) ------------------------------------------------------
+# The optimizer of a data-parallel run all-reduces its flat gradient in buckets while the rest of the backward pass is still running
+# (SURVEY 8(e): decoder/FTC -> deep encoder levels -> level 0).  A bucket is complete when the backward pass has crossed every
+# tensor edge that leads out of its modules; the model marks those edges with grad_mark(x, key): identity in the forward, and its
+# backward node reports "one more edge of `key` crossed".  Without a registered listener grad_mark is a no-op (single-GPU path).
+_STEP = {'main': None, 'marks': {}, 'listener': None}
+
+
+def set_grad_mark_listener(fn):
+    """fn(key) is called (from autograd's device thread) when the backward pass has crossed ALL edges marked `key` in this step"""
+    _STEP['listener'] = fn
+    _STEP['marks'].clear()
+
+
+def step_streams():
+    """every stream this library may have launched kernels of the running step on: the step's main stream + the side streams"""
+    out = [] if _STEP['main'] is None else [_STEP['main']]
+    for v in _SIDE_STREAMS.values():
+        out.append(v[0] if isinstance(v, tuple) else v)
+    return out
+
+
+class _GradMark(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, key):
+        ctx.key = key
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        cnt = _STEP['marks'].get(ctx.key)
+        fn = _STEP['listener']
+        if cnt is not None and fn is not None:
+            cnt[1] += 1
+            if cnt[1] == cnt[0]:
+                fn(ctx.key)
+        return dy, None
+
+
+def grad_mark(x, key):
+    if _STEP['listener'] is None or not ZERO.active or not (torch.is_grad_enabled() and x.requires_grad):
+        return x
+    _STEP['marks'].setdefault(key, [0, 0])[0] += 1
+    return _GradMark.apply(x, key)
 
 
 def end_step():

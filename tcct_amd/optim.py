@@ -18,6 +18,8 @@ class FlatAdamW(torch.optim.Optimizer):
         self._step = 0
         self.world = 1
         self.allreduce = None        # callable(flat_g) -> None, set by tcct_amd.dist.attach
+        self.buckets = None          # tcct_amd.dist.GradBuckets: bucketed all-reduce overlapped with the backward pass
+        self.allreduce_mode = 'none'
         self.last_total_norm = None
         self._slots_live = False
         self.device_state = None     # [lr, steps taken] on the device once enable_device_state() was called (hipGraph-replayable step)
@@ -43,11 +45,46 @@ class FlatAdamW(torch.optim.Optimizer):
         super().zero_grad(set_to_none=True)
         if self._flat is not None:
             self._flat['g'].zero_()     # one memset: the slots that backward kernels accumulate into
+        if self.buckets is not None:
+            self.buckets.begin_step(armed=self._slots_live)
+
+    def state_dict(self):
+        """torch's layout plus the flat AdamW state (exp_avg / exp_avg_sq / step live outside `self.state`): the reference never saves
+        its optimizer (kite/loopback.py:56-59), so this is an addition, not a wire format"""
+        sd = super().state_dict()
+        if self._flat is not None:
+            sd['flat'] = dict(step=self._step, m=self._flat['m'].clone(), v=self._flat['v'].clone(), numel=self._flat['n'])
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        flat = sd.pop('flat', None)
+        super().load_state_dict(sd)
+        if flat is not None:
+            if self._flat is None:
+                raise TcctError('FlatAdamW.load_state_dict(): take one step first (the flat buffers are laid out at the first step)')
+            if int(flat['numel']) != self._flat['n']:
+                raise TcctError(f"FlatAdamW.load_state_dict(): saved state has {flat['numel']} elements, this optimizer {self._flat['n']}")
+            self._flat['m'].copy_(flat['m'])
+            self._flat['v'].copy_(flat['v'])
+            self._step = int(flat['step'])
+            if self.device_state is not None:
+                self.device_state[1:2].fill_(float(self._step))
 
     def _build(self):
         plist = [p for g in self.param_groups for p in g['params'] if p.grad is not None]
         if not plist:
             raise TcctError('FlatAdamW.step(): no parameter has a gradient')
+        if self.buckets is not None:
+            # data-parallel buckets are contiguous ranges of the flat buffer: order the parameters by bucket (stable inside a bucket).
+            # Parameters whose gradient arrives through autograd (no in-place slot: used twice per step) are copied into the flat
+            # buffer in step(), i.e. after the early buckets have left: they belong to the last bucket.
+            last = self.buckets.n_buckets - 1
+            key = lambda p: last if getattr(p, '_tcct_multi_use', False) else min(getattr(p, '_tcct_bucket', last), last)   # noqa: E731
+            plist = sorted(plist, key=key)
+            sizes = [0] * self.buckets.n_buckets
+            for p in plist:
+                sizes[key(p)] += p.numel()
         dev = plist[0].device
         if dev.type != 'cuda':
             raise TcctError('FlatAdamW needs parameters on the GPU (no CPU fallback)')
@@ -70,6 +107,8 @@ class FlatAdamW(torch.optim.Optimizer):
         self._flat = dict(plist=plist, p=flat_p, g=flat_g, m=z(), v=z(),
                           sumsq=torch.zeros((), device=dev, dtype=torch.float64),
                           norm=torch.zeros((), device=dev, dtype=torch.float32), n=n)
+        if self.buckets is not None:
+            self.buckets.bind(flat_g, sizes)
 
     @property
     def flat_numel(self):
@@ -93,6 +132,9 @@ class FlatAdamW(torch.optim.Optimizer):
                 if p.grad is not None and (slot is None or p.grad.data_ptr() != slot.data_ptr()):
                     # produced through autograd (multi-use parameter, or a plain backward outside the pooled step): the
                     # kernels did not touch this slot, so the autograd result IS the gradient
+                    if self.buckets is not None and self.buckets.is_launched(off):
+                        raise TcctError('a gradient arrived through autograd for a parameter whose bucket has already been all-reduced '
+                                        'during the backward pass (mark it _tcct_multi_use, or set TCCT_DP_OVERLAP=0)')
                     f['g'][off:off + k].copy_(p.grad.reshape(-1))
                 if slot is not None:
                     p.grad = slot                   # keep the torch contract: p.grad holds the gradient after step()
@@ -100,12 +142,16 @@ class FlatAdamW(torch.optim.Optimizer):
         else:
             torch.cat([p.grad.reshape(-1) for p in f['plist']], out=f['g'])
         self._slots_live = True
-        if self.allreduce is not None:
+        if self.buckets is not None:
+            self.buckets.finish()           # launches what the backward pass has not launched yet, then joins the comm stream
+        elif self.allreduce is not None:
             self.allreduce(f['g'])
         self._step += 1
         g0 = self.param_groups[0]
         lib.grad_sumsq(f['g'], f['n'], f['sumsq'])
         if self.device_state is not None:
+            if not torch.cuda.is_current_stream_capturing():
+                self.sync_lr()              # an eager step after enable_device_state() must see the scheduler's current lr too
             lib.clip_adamw_dev(f['p'], f['g'], f['m'], f['v'], f['n'], f['sumsq'], self.max_norm, 1.0 / self.world, self.device_state,
                                float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']), float(g0['weight_decay']), f['norm'])
         else:

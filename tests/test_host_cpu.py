@@ -127,6 +127,23 @@ tdist.broadcast_params_(lin)
 assert lin.weight.eq(1.0).all()
 t = tdist.max_over_ranks(float(rank), torch.device('cpu'))
 assert t == 1.0
+assert tdist.world_rank() == (2, rank) and tdist.gather_strings('r%%d' %% rank) == ['r0', 'r1']
+# bucketed all-reduce: readiness marks may arrive out of order, launches never do (0, 1 during "backward", 2 at step())
+gb = tdist.GradBuckets()
+flat = per_sample[sl].sum(0).clone()
+gb.bind(flat, [300, 500, 200])
+gb.begin_step(armed=True)
+gb.on_mark('deep')
+assert gb.launch_log == [] and not gb.is_launched(0)
+gb.on_mark('dec')
+assert gb.launch_log == [(0, 'backward'), (1, 'backward')] and gb.is_launched(799) and not gb.is_launched(800)
+gb.finish()
+assert gb.launch_log[-1] == (2, 'step') and torch.allclose(flat, per_sample.sum(0), atol=1e-5)
+gb.begin_step(armed=False)                               # not armed (first step / plain backward): everything leaves in finish()
+flat.copy_(per_sample[sl].sum(0))
+gb.on_mark('dec')
+gb.finish()
+assert gb.launch_log == [(0, 'step'), (1, 'step'), (2, 'step')] and torch.allclose(flat, per_sample.sum(0), atol=1e-5)
 tdist.barrier()
 os.write(1, ('rank %%d ok\n' %% rank).encode())      # one atomic write: the two ranks share stdout
 '''
@@ -198,3 +215,36 @@ def test_token_mixer_option_mirrors_the_reference_constructor():
         ConvRelPosEnc(Ch=8, h=8, window='3')                    # reference tcct.py:245
     assert ConvRelPosEnc(Ch=8, h=8, window=3).channel_splits == [64]
     assert parse_args(['--att=factor']).att == 'factor' and parse_args([]).att == 'pool'
+
+
+def test_gradient_buckets_follow_the_backward_order():
+    """static bucket of every trained parameter (tcct_amd.dist.bucket_of): decoder / fusion first, deep encoder levels second,
+    level 0 + stems + the loss-side modules last; the three buckets cover the 802 298 trained elements of --reg=true"""
+    import json
+    from tcct_amd.dist import bucket_of, N_BUCKETS
+    keys = json.load(open(os.path.join(HERE, 'golden', 'state_dict_keys.json')))
+    names = [k for k, _ in keys]
+    assert N_BUCKETS == 3
+    assert bucket_of('base.dec1.prep.0.weight') == 0 and bucket_of('base.tran_vit2.1.bias') == 0 and bucket_of('base.aux4.weight') == 0
+    assert bucket_of('base.base_cnn.path_estan.3.block5.0.weight') == 1 and bucket_of('base.base_vit.mhca_stages.2.aggregate.bn.weight') == 1
+    assert bucket_of('base.base_vit.patch_embed_stages.1.patch_embeds.0.patch_conv.pwconv.weight') == 1
+    assert bucket_of('base.base_cnn.path_estan.0.block12.0.weight') == 2 and bucket_of('base.base_cnn.cnn.0.weight') == 2
+    assert bucket_of('base.base_vit.stem.0.conv.weight') == 2 and bucket_of('base.base_vit.mhca_stages.0.InvRes.conv1.conv.weight') == 2
+    assert bucket_of('lap_reg.0.weight') == 2 and bucket_of('lap_map.1.weight') == 2
+    assert {bucket_of(n) for n in names} == {0, 1, 2}
+
+
+def test_bench_launcher_starts_the_ranks_as_children_and_fails_loudly():
+    """`python bench.py --gpus 2` WITHOUT a torchrun environment must start two ranks itself (child process, torch.distributed.run) and
+    relay their exit status: here (no GPU) the ranks refuse to run, and the launcher must report that instead of printing a 1-rank
+    line.  With WORLD_SIZE set the process is a rank: a mismatch with --gpus is an error."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert 'torch.distributed.run' in r.stderr and '--nproc-per-node=2' in r.stderr
+    assert r.stderr.count('bench.py needs an MI355X') >= 1 and 'child exited with code' in r.stderr
+    assert '"metric"' not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'), timeout=300)
+    assert r.returncode != 0 and '--gpus=4 but WORLD_SIZE=2' in r.stderr and '"metric"' not in r.stdout

@@ -346,6 +346,56 @@ def test_fpl_matches_oracle():
     torch.testing.assert_close(nchw(fd.grad), feats.grad, rtol=1e-4, atol=1e-9)
 
 
+def test_featconsuper_methods_mirror_the_reference_surface():
+    """`model.fcs.select1 / cosinesim / foreach_loss` and `points_selection_bins` (reference nets/fcs.py:25-96) called the way
+    reference nets/reg.py:93-102 calls them, one class at a time: prototypes, loss and the feature gradient equal the oracle's and
+    the fused all-classes path (`RegNet.regular_udh` -> ops.fpl)"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    import tcct_oracle as O
+    from tcct_amd import ops
+    from tcct_amd.nets.fcs import FeatConSuper, points_selection_bins
+    from tcct_amd.nets.fcp import FeatConPolar
+    B, H, W, C = 2, 64, 96, 5
+    _, lab = O.synth_batch(B, H, W, seed=3)
+    g = torch.Generator().manual_seed(4)
+    feats = torch.randn(B, 32, H, W, generator=g).requires_grad_(True)
+    logits = torch.randn(B, C, H, W, generator=g) * 2
+    buf = F.normalize(torch.rand(C, 32, generator=g), dim=-1)
+    oh = F.one_hot(lab, C).permute(0, 3, 1, 2)
+    want = {}
+    los = O.fpl_loss({'fcp.buf_grad': buf}, feats, logits, oh, want)
+    los.backward()
+    fcs = FeatConSuper(con='cos').cuda()
+    fcp = FeatConPolar(num_cls=C, num_emb=32)
+    fcp.buf_grad.copy_(buf)
+    fcp = fcp.cuda()
+    fd = nhwc(feats.detach(), torch.float32).requires_grad_(True)
+    feat_nchw = fd.permute(0, 3, 1, 2)                      # what model.base.feats[0] is: an NCHW-shaped view of NHWC memory
+    pred = torch.softmax(logits.cuda(), dim=1)
+    true = oh.cuda()
+    pros, tgts = [], []
+    for i in range(C):                                       # reference reg.py:93-101
+        pro = fcs.select1(feat=feat_nchw, pred=pred[:, i:i + 1], true=true[:, i:i + 1])
+        tgt = fcp.choice(pro, i)
+        pros.append(pro)
+        tgts.append(tgt)
+    losCon = fcs.foreach_loss(pros, tgts) + F.mse_loss(pro, tgt)
+    torch.testing.assert_close(torch.stack(pros, 0).detach().cpu(), want['emb'].detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(losCon.detach().cpu(), los.detach(), rtol=1e-5, atol=1e-6)
+    losCon.backward()
+    torch.testing.assert_close(nchw(fd.grad), feats.grad, rtol=1e-4, atol=1e-9)
+    # the fused all-classes path gives the same loss
+    ld, pro_all = ops.fpl(fd.detach(), nhwc(logits, torch.float32), lab.to(torch.uint8).cuda(), buf.cuda())
+    torch.testing.assert_close(ld.cpu(), losCon.detach().cpu(), rtol=1e-5, atol=1e-6)
+    # fcs(q, k) is cosinesim (reference fcs.py:60), and the free function takes flat [N,32] rows
+    torch.testing.assert_close(fcs(pros[1], tgts[1]), fcs.cosinesim(pros[1], tgts[1]))
+    flat = points_selection_bins(fd.detach().reshape(-1, 32), pred[:, 2].reshape(-1), true[:, 2].reshape(-1).float())
+    torch.testing.assert_close(flat.cpu(), want['emb'][2].detach(), rtol=1e-4, atol=1e-5)
+    with pytest.raises(AssertionError):
+        fcs.select1(feat=feat_nchw, pred=pred[:, :1, :8], true=true[:, :1])
+
+
 def test_reg_loss_matches_oracle():
     """boundary-regression loss (fp32 pipeline) vs the oracle incl. gradients to logits and lap_* parameters"""
     import sys, os, json
@@ -896,7 +946,7 @@ def test_factor_att_core_vs_oracle(dt, cfg):
     torch.cuda.synchronize()
 
     def close(a, b, what):
-        a, b = a.float().cpu(), b.float()
+        a, b = a.detach().float().cpu(), b.detach().float()
         t = tol(dt)
         scale = max(1.0, float(b.abs().max()))
         err = float((a - b).abs().max()) / scale
@@ -951,7 +1001,7 @@ def test_factor_att_module_matches_reference_fixture(dt, tag):
     y.backward(fx['gout'].to('cuda', dt))
     torch.cuda.synchronize()
     def err(a, b):
-        return float((a.float().cpu() - b).abs().max()) / max(1.0, float(b.abs().max()))
+        return float((a.detach().float().cpu() - b).abs().max()) / max(1.0, float(b.abs().max()))
     if dt == torch.float32:
         assert err(y, fx['y']) < 2e-4
         assert err(x.grad, fx['dx']) < 2e-4

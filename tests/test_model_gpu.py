@@ -469,46 +469,117 @@ def test_cli_training_with_graph_flag(tmp_path):
 
 
 DDP_GPU_SCRIPT = r"""
-import os, sys, argparse, torch
-sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'oracle'))
+import os, sys, json, argparse, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'oracle'))
 import tcct_oracle as O
 from tcct_amd import dist as tdist
 from tcct_amd.nets import stc_tt, RegNet
 from tcct_amd.kite import KiteSeg
 rank = int(os.environ['RANK'])
-torch.manual_seed(100 + rank)                     # different initial weights per rank: broadcast_params_ must make them equal
+keys = [(k, tuple(s)) for k, s in json.load(open(os.path.join(%(root)r, 'tests', 'golden', 'state_dict_keys.json')))]
 class DS: out_channels = 5
 args = argparse.Namespace(los='di', lr=1e-3, gpu='0', pl=True, bs=2, coff_ds=1, udh=False, reg=False, epl=False, coff_udh=1, coff_reg=.1,
                           coff_epl=.1, bug=True)
 model = RegNet(stc_tt(5, compute_dtype=torch.bfloat16), con='cos', out_channels=5)
-k = KiteSeg(model=model, dataset=DS(), root=%r, args=args)
-assert k.optimG.allreduce is not None and k.optimG.world == 2
+model.load_state_dict(O.formula_state_dict(keys))
+if rank == 1:                                      # different initial weights on rank 1: broadcast_params_ must overwrite them
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05)
+k = KiteSeg(model=model, dataset=DS(), root=%(tmp)r, args=args)
+assert k.optimG.allreduce is not None and k.optimG.world == 2 and k.world == 2 and k.rank == rank
+overlap = os.environ.get('TCCT_DP_OVERLAP', '1') != '0'
+assert (k.optimG.buckets is not None) == overlap
 k.model.train()
 k.model.base.base_vit.drop_probs = [0.0] * 4
-for s in range(3):
+logs = []
+for s, (lr, wd) in enumerate(((0.0, 0.0), (1e-3, 2e-4))):      # step 1 leaves the weights alone, step 2 is a real update
+    for g in k.optimG.param_groups:
+        g['lr'], g['weight_decay'] = lr, wd
     img, lab = O.synth_batch(2, 64, 96, seed=50 + 10 * s + rank)      # every rank trains on its own shard
     loss = k.train_step(img.cuda(), lab.cuda())
+    logs.append(list(k.optimG.buckets.launch_log) if overlap else None)
 torch.cuda.synchronize()
-torch.save({'p': k.optimG._flat['p'].cpu(), 'g': k.optimG._flat['g'].cpu(), 'loss': loss.item()}, os.path.join(%r, 'rank%%d.pt' %% rank))
+f = k.optimG._flat
+names = {id(p): n for n, p in k.model.named_parameters()}
+torch.save({'p': f['p'].cpu(), 'g': f['g'].cpu(), 'loss': loss.item(), 'norm': k.optimG.last_total_norm.item(),
+            'names': [names[id(p)] for p in f['plist']], 'numels': [p.numel() for p in f['plist']], 'logs': logs,
+            'ranges': k.optimG.buckets.ranges if overlap else None}, os.path.join(%(tmp)r, 'rank%%d.pt' %% rank))
 tdist.barrier()
 """
 
 
-def test_two_ranks_on_one_gpu_stay_in_sync(tmp_path):
-    """the real data-parallel training path with world_size 2 (two processes sharing this GPU, gloo transport because RCCL does not
-    share a device): parameters broadcast from rank 0, one all-reduce of the flat gradient per step, identical weights on both
-    ranks after 3 steps on different shards"""
+def _split(flat, names, numels):
+    out, off = {}, 0
+    for n, k_ in zip(names, numels):
+        out[n] = flat[off:off + k_]
+        off += k_
+    return out
+
+
+@pytest.mark.parametrize('overlap', ['1', '0'])
+def test_two_ranks_average_gradients_like_one_process_on_the_mean(overlap, tmp_path):
+    """The real data-parallel training path with world_size 2 (two processes sharing this GPU; gloo transport because RCCL does not share
+    a device), SURVEY 4(iv): parameters broadcast from rank 0; after a step on two different shards
+      * the all-reduced flat gradient / 2 == the mean of the two SINGLE-PROCESS shard gradients (per parameter, by name),
+      * the optimizer's total norm is the norm of that mean (the 1/world factor folded into k_clip_adamw),
+      * the post-step weights equal the oracle's clip + AdamW applied to the mean gradients,
+      * both ranks hold bit-identical weights,
+    with the bucketed all-reduce overlapped with the backward pass (buckets 0 and 1 leave during backward, TCCT_DP_OVERLAP=1) and
+    with the single blocking all-reduce (TCCT_DP_OVERLAP=0)."""
     import subprocess
+    import tcct_oracle as O
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'ddp_gpu.py'
-    script.write_text(DDP_GPU_SCRIPT % (root, root, str(tmp_path), str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', TCCT_DIST_BACKEND='gloo')
+    script.write_text(DDP_GPU_SCRIPT % dict(root=root, tmp=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', TCCT_DIST_BACKEND='gloo', TCCT_DP_OVERLAP=overlap)
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-                        '--master-port', '29617', str(script)], capture_output=True, text=True, env=env, timeout=600)
+                        '--master-port', '29617' if overlap == '1' else '29619', str(script)], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     a, b = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
-    assert torch.equal(a['p'], b['p']) and torch.equal(a['g'], b['g'])          # same averaged gradient, same update, bit for bit
+    assert torch.equal(a['p'], b['p']) and torch.equal(a['g'], b['g'])          # same summed gradient, same update, bit for bit
     assert a['loss'] != b['loss'] and np.isfinite(a['loss']) and np.isfinite(b['loss'])   # different shards, per-replica losses
+    if overlap == '1':
+        assert a['logs'][0] == [(0, 'step'), (1, 'step'), (2, 'step')]           # first step: gradients are gathered in step()
+        assert a['logs'][1] == [(0, 'backward'), (1, 'backward'), (2, 'step')] == b['logs'][1]
+        assert [e - s_ for s_, e in a['ranges']] == [sum(n for nm, n in zip(a['names'], a['numels']) if _bucket(nm) == q) for q in range(3)]
+    # ---- the same four shard gradients in ONE process, at the same (formula) weights
+    model, sd0 = build(torch.bfloat16)
+    model.base.base_vit.drop_probs = [0.0] * 4
+    k = make_kite(model, tmp_path / 'single', False, False, lr=0.0)
+    for g in k.optimG.param_groups:
+        g['lr'], g['weight_decay'] = 0.0, 0.0
+    grads = {}
+    for s in range(2):
+        for rank in range(2):
+            img, lab = O.synth_batch(2, 64, 96, seed=50 + 10 * s + rank)
+            k.train_step(img.cuda(), lab.cuda())
+            f = k.optimG._flat
+            nm = {id(p): n for n, p in model.named_parameters()}
+            grads[(s, rank)] = {n: t.clone().cpu() for n, t in _split(f['g'], [nm[id(p)] for p in f['plist']], [p.numel() for p in f['plist']]).items()}
+    assert sorted(grads[(0, 0)]) == sorted(a['names'])
+    mean = [{n: 0.5 * (grads[(s, 0)][n] + grads[(s, 1)][n]) for n in a['names']} for s in range(2)]
+    g_dp = _split(a['g'], a['names'], a['numels'])
+    gmax = max(t.abs().max().item() for t in mean[1].values())
+    for n in a['names']:
+        d = (0.5 * g_dp[n] - mean[1][n]).abs().max().item()
+        assert d <= 2e-4 * max(mean[1][n].abs().max().item(), 1e-3 * gmax), (n, d)     # fp32 atomics reorder sums between runs; nothing else differs
+    norm_mean = torch.sqrt(sum((t.double() ** 2).sum() for t in mean[1].values())).item()
+    assert abs(a['norm'] - norm_mean) <= 1e-4 * norm_mean, (a['norm'], norm_mean)          # NOT 2 x: the kernel scales by 1/world
+    # post-step weights: oracle clip + AdamW on the mean gradients (step 1 at lr 0 only moves the moments, step 2 is the update)
+    P = [sd0[n].clone().float().reshape(-1) for n in a['names']]
+    M, V = [torch.zeros_like(t) for t in P], [torch.zeros_like(t) for t in P]
+    O.clip_adamw_step(P, [mean[0][n] for n in a['names']], M, V, 1, 0.0, wd=0.0)
+    O.clip_adamw_step(P, [mean[1][n] for n in a['names']], M, V, 2, 1e-3, wd=2e-4)
+    p_dp = _split(a['p'], a['names'], a['numels'])
+    for n, want in zip(a['names'], P):
+        d = (p_dp[n] - want).abs().max().item()
+        assert d <= 3e-2 * 1e-3, (n, d)                # 3 % of one full-size Adam update (lr 1e-3)
+
+
+def _bucket(name):
+    from tcct_amd.dist import bucket_of
+    return 2 if name.startswith(('lap_reg', 'lap_map')) else bucket_of(name)
 
 
 def test_training_improves_validation_dice(tmp_path):

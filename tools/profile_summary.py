@@ -91,3 +91,8 @@ L.append(f'\nbench.py\'s own HIP-event timing of the same loops (un-profiled run
          f'others = {[(o["kernel"], o["ms_per_launch"]) for o in b["roofline"].get("others", [])]}.')
 open(f'{P}/{tag}_summary.md', 'w').write('\n'.join(L) + '\n')
 print('\n'.join(L)[:3000])
+# HBM traffic of the roofline kernels + the hash of the sources they were collected on -> profiles/TAG_pmc.json (bench.py's roofline.traffic)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pmc_json  # noqa: E402
+sys.argv = [sys.argv[0], tag]
+pmc_json.main()
