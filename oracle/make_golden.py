@@ -193,9 +193,17 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     B = 2
     masks = [torch.tensor(m, dtype=torch.float32) for m in ([1, 1], [1, 0], [0, 1], [1, 1], [1, 0], [1, 1])]
-    keys = run_case('full_2x32x32', B, 32, 32, udh=True, reg=True, dp_masks=masks, seed=2023)
-    run_case('full_2x64x64', B, 64, 64, udh=True, reg=True, dp_masks=None, seed=2024)
-    run_case('di_2x64x64', B, 64, 64, udh=False, reg=False, dp_masks=None, seed=2023)   # BASELINE cfg1
-    with open(os.path.join(OUT, 'state_dict_keys.json'), 'w') as f:
-        json.dump([[k, list(s)] for k, s in keys], f)
+    only = set(sys.argv[1:])            # optional: names of the cases to (re)generate; default all
+    cases = [('full_2x32x32', 32, 32, True, True, masks, 2023),
+             ('full_2x64x64', 64, 64, True, True, None, 2024),
+             ('di_2x64x64', 64, 64, False, False, None, 2023),          # BASELINE cfg1
+             ('reg_2x64x64', 64, 64, False, True, None, 2025),          # BASELINE cfg3 (--los=di --reg=true, udh off) at fixture size
+             ('full_2x128x128', 128, 128, True, True, None, 2026)]      # >= 128 samples per BatchNorm channel at level 4: the better-conditioned case
+    keys = None
+    for name, H, W, udh, reg, dpm, seed in cases:
+        if not only or name in only:
+            keys = run_case(name, B, H, W, udh=udh, reg=reg, dp_masks=dpm, seed=seed)
+    if not only:
+        with open(os.path.join(OUT, 'state_dict_keys.json'), 'w') as f:
+            json.dump([[k, list(s)] for k, s in keys], f)
     print('wrote', sorted(os.listdir(OUT)))

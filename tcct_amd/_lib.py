@@ -9,6 +9,8 @@ import torch  # noqa: F401  (must be imported first: the .so then binds to torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libtcct_hip.so')
+if os.environ.get('TCCT_LIB_PATH'):         # kernel A/B measurements only (tools/ab_kernels.sh): another BUILD of the same library, never a fallback
+    LIB_PATH = os.path.abspath(os.environ['TCCT_LIB_PATH'])
 HEADER = os.path.join(_HERE, '..', 'include', 'tcct_hip.h')
 
 F32, BF16 = 0, 1

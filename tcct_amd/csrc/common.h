@@ -145,6 +145,14 @@ __device__ __forceinline__ void affine4(float* v, const float* a, const float* b
     }
 }
 
+// Lanes of ONE wave exchanging data through LDS (per-wave transposes in the MFMA epilogues): the hardware completes a wave's LDS
+// operations in order, so no s_barrier is needed -- but the COMPILER must be told that other lanes wrote in between, or it may keep a
+// lane's earlier read of the same address (seen after an edit of conv_mfma.hip: the second `ds_read_b128` of the epilogue was sunk
+// into the exec-masked branch of the lanes that had just written, every other lane stored its stale first-round value).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // no instruction: wave-scope ordering only constrains the optimizer
+}
+
 // ---------------------------------------------------------------- wave / block reductions (wave = 64)
 // source index / weights of torch's bilinear resize (F.interpolate / nn.Upsample) for output index o
 struct Lerp { int i0, i1; float l0, l1; };

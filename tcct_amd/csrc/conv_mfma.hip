@@ -13,8 +13,10 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4;
 
 #define MB 256
+#define OOB_OFF 0x80000000u     // buffer offset beyond every descriptor range used here (< 2 GiB): loads return 0, stores are dropped
 
 // OIHW fp32 -> [tap][co][ci] bf16 (optionally flipped + transposed: the weights of the input-gradient convolution)
 // The 32x32 block (o_off.., i_off..) of an OIHW weight with `ldi` input channels is selected, so 32->64 / 64->32 convolutions
@@ -101,7 +103,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
     // slot geometry (tile independent): slot j covers 16-byte chunk c of tile-local pixel (lr, lc); (lr,lc) packed in one int
     const int c = tid & 3;
     const int npix = LH * LW;
-    int s_rc[MAXL];              // the LDS offset of a slot is recomputed from (lr, lc) when it is stored: 11 fewer live VGPRs
+    int s_rc[MAXL];              // the LDS offset and the global offset of a slot are recomputed from (lr, lc): 22 fewer live VGPRs
 #pragma unroll
     for (int j = 0; j < MAXL; ++j) {
         int pl = (tid >> 2) + j * (MB / 4);
@@ -109,20 +111,43 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
         int lr = in ? pl / LW : 0x3fff, lc = in ? pl - (pl / LW) * LW : 0;
         s_rc[j] = (lr << 16) | lc;
     }
-    uint4 pre[MAXL];
+    // Global loads and stores go through buffer descriptors (one per image of the batch): an out-of-image halo pixel is a lane whose
+    // offset lies beyond the descriptor's range -- the hardware returns zeros / drops the store -- so the staging code has NO
+    // branches.  That matters beyond the instruction count: with `if (in bounds) load` hipcc branches around every load and, not
+    // knowing how many are in flight, waits with vmcnt(0) -- which also waits for the previous tile's STORES (ISA of the first version:
+    // `s_barrier; s_waitcnt vmcnt(0)` at the top of every tile, i.e. one HBM write latency per tile and wave on the critical path).
+    const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * (uint32_t)xs * 2u - (uint32_t)xo * 2u;
+    const uint32_t out_bytes = (uint32_t)H * (uint32_t)W * (uint32_t)ys * 2u - (uint32_t)yo * 2u;
+    u32x4 pre[MAXL];
     auto prefetch = [&](int tile) {
         const int tw = tile % tilesW;
         const int t2 = tile / tilesW;
         const int th = t2 % tilesH;
         const int n = t2 / tilesH;
         const int hb = th * TH - PH, wb = tw * TW - PW;
-        const bf16* xb = x + (int64_t)n * H * W * xs + xo + c * 8;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * H * W * xs + xo), 0, img_bytes, 0x00020000);
+        if (hb >= 0 && wb >= 0 && hb + LH <= H && wb + LW <= W) {      // interior tile (block-uniform): one add per slot
+            const uint32_t base = (uint32_t)((hb * W + wb) * xs * 2 + c * 16), xs2 = (uint32_t)xs * 2u;
+#pragma unroll
+            for (int j = 0; j < MAXL; ++j) {        // unused slots (lr = 0x3fff) land far beyond the image: out of range by construction
+                const uint32_t lr = (uint32_t)(s_rc[j] >> 16), lc = (uint32_t)(s_rc[j] & 0xffff);
+                pre[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lr == 0x3fffu ? OOB_OFF : base + (lr * (uint32_t)W + lc) * xs2, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < MAXL; ++j) {
+                const int hi = hb + (s_rc[j] >> 16), wi = wb + (s_rc[j] & 0xffff);
+                const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;      // unused slots: lr = 0x3fff fails this
+                const uint32_t off = ok ? (uint32_t)((hi * W + wi) * xs * 2 + c * 16) : OOB_OFF;
+                pre[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            }
+        }
+    };
+    auto stage = [&]() {        // registers of the prefetched tile -> LDS image
 #pragma unroll
         for (int j = 0; j < MAXL; ++j) {
-            int hi = hb + (s_rc[j] >> 16), wi = wb + (s_rc[j] & 0xffff);
-            pre[j] = make_uint4(0, 0, 0, 0);
-            if (hi >= 0 && hi < H && wi >= 0 && wi < W)
-                pre[j] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hi * W + wi) * xs);
+            const int lr = s_rc[j] >> 16, lc = s_rc[j] & 0xffff;
+            if (lr != 0x3fff) *reinterpret_cast<u32x4*>(sX + (VERT ? lc * LH + lr : lr * LW + lc) * IPS + c * 16) = pre[j];
         }
     };
     // per-lane fragment bases: weights (swizzled 64-byte rows, row = tap*32 + r: the swizzle term only depends on r) and image
@@ -140,22 +165,24 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
     float ss[(STATS >= 1 && STATS <= 3) ? 8 : 1], sq[(STATS >= 1 && STATS <= 3) ? 8 : 1];        // BN statistics: after the transpose a lane owns channels 8*(lane&3)..+7
 #pragma unroll
     for (int k = 0; k < ((STATS >= 1 && STATS <= 3) ? 8 : 1); ++k) ss[k] = sq[k] = 0.f;
+    // Tile pipeline of one block (two blocks per CU alternate):
+    //     MFMA(t) | barrier | registers of t+1 -> LDS | issue loads of t+2 | epilogue(t): stores | barrier | MFMA(t+1) ...
+    // The wait for the loads of t+1 sits directly behind an MFMA phase: everything still in flight there (those loads, the stores
+    // of t-1) was issued at least one whole MFMA phase earlier.  In the first version the wait followed the stores of the SAME tile.
     int tile = blockIdx.x;
-    if (tile < ntiles) prefetch(tile);
+    if (tile < ntiles) {
+        prefetch(tile);
+        __syncthreads();        // weights / bias staged
+        stage();
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+    }
+    __syncthreads();
     for (; tile < ntiles; tile += gridDim.x) {
         const int tw = tile % tilesW;
         const int t2 = tile / tilesW;
         const int th = t2 % tilesH;
         const int n = t2 / tilesH;
         const int h0 = th * TH, w0 = tw * TW;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < MAXL; ++j) {
-            const int lr = s_rc[j] >> 16, lc = s_rc[j] & 0xffff;
-            if (lr != 0x3fff) *reinterpret_cast<uint4*>(sX + (VERT ? lc * LH + lr : lr * LW + lc) * IPS + c * 16) = pre[j];
-        }
-        __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
 
         f32x16 acc[4];
 #pragma unroll
@@ -198,10 +225,14 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
                     load_stage(f, dy, dx, 1); mma_stage(f);
                 }
         }
+        __syncthreads();                                    // every wave has read its fragments: the image may be replaced
+        if (tile + (int)gridDim.x < ntiles) stage();
+        if (tile + 2 * (int)gridDim.x < ntiles) prefetch(tile + 2 * gridDim.x);
         // epilogue: lane owns pixel r of each M-tile and channels co = 8q + 4*hh + k.  The packed bf16 values go through a per-wave
         // LDS transpose (16 pixels x 64 B per round, chunks XOR-swizzled) so that every lane stores 16 contiguous bytes and one
         // wave instruction writes 16 whole pixels (1 KB contiguous for HORZ tiles) -- four 8-byte stores per lane, i.e. 16 B of
         // every 64-B line per instruction, were the throughput limit of the store-heavy kernels.
+        const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (int64_t)n * H * W * ys + yo), 0, out_bytes, 0x00020000);
         unsigned char* sc = sS + wave * 1024;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -238,16 +269,18 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
 #pragma unroll
                     for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(sc + rr * 64 + ((q ^ f) << 4) + hh * 8) = o[q];
                 }
-                // one wave writes and reads its own scratch: LDS operations of a wave complete in order
+                // one wave writes and reads its own scratch: LDS operations of a wave complete in order (the fence is for the compiler)
+                wave_lds_fence();
                 const int p16 = lane >> 2, cch = lane & 3;
-                const uint4 ov = *reinterpret_cast<const uint4*>(sc + p16 * 64 + ((cch ^ ((p16 >> 1) & 3)) << 4));
+                const u32x4 ov = *reinterpret_cast<const u32x4*>(sc + p16 * 64 + ((cch ^ ((p16 >> 1) & 3)) << 4));
                 const int pr = 16 * h2 + p16;                                   // pixel index inside the M-tile
                 const int ho = VERT ? h0 + seg * 32 + pr : h0 + a;
                 const int wo = VERT ? w0 + a : w0 + seg * 32 + pr;
-                if (ho < H && wo < W) {
-                    *reinterpret_cast<uint4*>(y + (((int64_t)n * H + ho) * W + wo) * ys + yo + cch * 8) = ov;
-                    if (STATS >= 1 && STATS <= 3) {
-                        const uint32_t wv[4] = {ov.x, ov.y, ov.z, ov.w};
+                const bool inb = ho < H && wo < W;
+                __builtin_amdgcn_raw_buffer_store_b128(ov, ws, inb ? (uint32_t)((ho * W + wo) * ys * 2 + cch * 16) : OOB_OFF, 0, 0);
+                if (STATS >= 1 && STATS <= 3) {
+                    if (inb) {
+                        const uint32_t wv[4] = {ov[0], ov[1], ov[2], ov[3]};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             float u0 = __uint_as_float(wv[k] << 16), u1 = __uint_as_float(wv[k] & 0xffff0000u);
@@ -257,8 +290,10 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
                         }
                     }
                 }
+                wave_lds_fence();       // the next round's writes come after every lane's read of this round
             }
         }
+        __syncthreads();                                    // the staged image of the next tile is complete
     }
     if (STATS >= 1 && STATS <= 3) {
         // lanes with equal (lane & 3) hold different pixels of the same 8 channels: butterfly over lane bits 2..5, LDS, fp64 atomics
@@ -332,6 +367,8 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
     int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
     int64_t nt = (int64_t)N * tilesH * tilesW;
     TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32_fwd: bad tile count");
+    TCCT_CHECK((int64_t)H * W * xs * 2 < (1LL << 31) && (int64_t)H * W * ys * 2 < (1LL << 31),
+               "conv32_fwd: one image of %d x %d x %d channels exceeds the 2 GiB buffer-descriptor range", H, W, xs > ys ? xs : ys);
     int grid = (int)(nt < 512 ? nt : 512);
     hipStream_t st = (hipStream_t)stream;
 #define CF_LAUNCH(V, S, KHT, KWT)                                                                                           \

@@ -141,7 +141,8 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                     uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
                     *reinterpret_cast<uint2*>(sc + r * 80 + (8 * q + 4 * hh) * 2) = o;
                 }
-                // same wave wrote and reads: LDS operations of one wave complete in order
+                // same wave wrote and reads: LDS operations of one wave complete in order (the fence is for the compiler)
+                wave_lds_fence();
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const int p = (lane >> 2) + 16 * h2, cch = lane & 3;
@@ -174,6 +175,7 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                         }
                     }
                 }
+                wave_lds_fence();       // the next N-tile's writes come after every lane's reads of this one
             }
         } else if (ok) {
 #pragma unroll

@@ -101,6 +101,114 @@ def test_full_step_runs_at_bench_shape(tmp_path):
     assert 0.0 <= d <= 1.0
 
 
+def test_cfg3_reg_only_step_at_bench_shape(tmp_path):
+    """BASELINE.json configs[2]: `stc_tt --los=di --reg=true` (boundary regression on, feature polarization OFF), bs 8, 1x800x1100, bf16.
+    With udh off nothing reads `model.feats`: the lazy norm_add side output must never be materialised (reference kite/loop_seg.py:
+    158-165 with args.udh False), yet the trained-parameter set is the 802 298 elements of SURVEY 8(a21) (the reg loss adds lap_reg /
+    lap_map), the loss is finite and its reg part is positive."""
+    import argparse
+    from tcct_amd.nets import stc_tt, RegNet
+    from tcct_amd.kite import KiteSeg
+    from tcct_amd.data import SynthOCT
+    from tcct_amd import ops
+    torch.manual_seed(0)
+    ds = SynthOCT(device='cuda')
+    model = RegNet(stc_tt(5, compute_dtype=torch.bfloat16), con='cos', out_channels=5)
+    args = argparse.Namespace(los='di', lr=1e-2, gpu='0', pl=False, bs=8, coff_ds=1, udh=False, reg=True, epl=False, coff_udh=1,
+                              coff_reg=.1, coff_epl=.1, bug=True)
+    k = KiteSeg(model=model, dataset=ds, root=str(tmp_path), args=args)
+    k.model.train()
+    img, lab, _, _ = ds.parse(ds.make_batch(8, 11))
+    calls = []
+    real = ops.norm_add3
+    ops.norm_add3 = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+    try:
+        tot, log = k.calc_loss(img, lab)
+        assert 'reg=' in log and 'udh=' not in log
+        reg_part = float(log.split('reg=')[1].split(',')[0])
+        assert reg_part > 0 and 10.0 < tot.item() < 25.0
+        l1 = k.train_step(img, lab).item()
+        l2 = k.train_step(img, lab).item()
+    finally:
+        ops.norm_add3 = real
+    assert not calls and model.base._feats is None, 'feats was materialised although nothing reads it'
+    assert 10.0 < l1 < 25.0 and 10.0 < l2 < 25.0
+    n = k.optimG.last_total_norm.item()
+    assert n == n and 0 < n < 1e7
+    assert k.optimG.flat_numel == 802298
+    assert model.lap_map[1].num_batches_tracked.item() == 6          # applied to pred and true in each of the three forward passes
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_fullsize_forward_and_losses_match_the_oracle(dt, tmp_path):
+    """bs 2 at the FULL bench resolution (3 x 800 x 1104: 34.5 tiles of 32 columns per row, 50 of 16 rows -- every tile-edge case of the
+    MFMA convolutions, all five levels down to 50 x 69) against the oracle on the CPU, full loss (Dice + reg + fpl), seeded default
+    weights.  fp32: the four heads, every loss scalar and the boundary coordinates at the 1e-3 contract (heads 1e-4).  bf16: the same
+    against the oracle's rounding-point mode, as in tests/test_model_gpu.py::test_bf16_matches_rounding_point_oracle."""
+    import argparse
+    import contextlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle'))
+    import tcct_oracle as O
+    from tcct_amd.nets import stc_tt, RegNet
+    from tcct_amd.kite import KiteSeg
+    H, W = 800, 1104
+    torch.manual_seed(0)
+    sd0 = {k: v.clone() for k, v in RegNet(stc_tt(5), con='cos', out_channels=5).state_dict().items()}
+    img3, lab = O.synth_batch(2, H, W, seed=77)
+    g = torch.Generator().manual_seed(9)
+    noise = (torch.rand(2, 4, H, W, generator=g), torch.rand(2, 4, H, W, generator=g), torch.rand(1, 1, H, 1, generator=g), torch.rand(1, 1, H, 1, generator=g))
+    model = RegNet(stc_tt(5, compute_dtype=dt), con='cos', out_channels=5)
+    model.load_state_dict(sd0)
+
+    class DS:
+        out_channels = 5
+    args = argparse.Namespace(los='di', lr=1e-2, gpu='0', pl=False, bs=2, coff_ds=1, udh=True, reg=True, epl=False, coff_udh=1, coff_reg=.1,
+                              coff_epl=.1, bug=True)
+    k = KiteSeg(model=model, dataset=DS(), root=str(tmp_path), args=args)
+    model.train()
+    model.base.base_vit.drop_probs = [0.0] * 4
+    with torch.no_grad():
+        out = model(img3[:, :1].cuda())
+        parts = {'dice': k.grad_calc(out, lab.cuda(), ds=True, criterion=k.criterion).item(),
+                 'udh': model.regular_udh(out[0], lab.cuda()).item(),
+                 'reg': model.regular_reg(out[0], lab.cuda(), noise=noise).item() * 0.1}
+    outs = [o.float().cpu() for o in out]
+    edge = model.edge_pred.float().cpu().reshape(-1)
+    oh = torch.nn.functional.one_hot(lab, 5).permute(0, 3, 1, 2)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+
+    def oracle(mode):
+        want = {}
+        with torch.no_grad(), (O.rounding_points('bf16') if mode == 'bf16' else contextlib.nullcontext()):
+            tot, p, o, _ = O.total_loss({kk: v.clone() for kk, v in sd0.items()}, img3, oh, udh=True, reg=True, noise=noise, want=want)
+        return {a: b.item() for a, b in p.items()}, o, want['edge_pred'].reshape(-1)
+
+    def rel(a, b):
+        return ((a.double() - b.double()).abs().max() / max(1e-30, b.double().abs().max().item())).item()
+    p32, o32, e32 = oracle('fp32')
+    if dt == torch.float32:
+        errs = [rel(a, b) for a, b in zip(outs, o32)]
+        print('full-size fp32: heads', errs, 'losses', parts, p32, 'edge', rel(edge, e32))
+        assert max(errs) < 1e-4
+        for n in parts:
+            assert abs(parts[n] - p32[n]) <= 1e-4 * max(1.0, abs(p32[n])), (n, parts[n], p32[n])
+        assert rel(edge, e32) < 1e-3
+        return
+    pb, ob, eb = oracle('bf16')
+    rep = []
+    for i in range(4):
+        model_err = rel(ob[i], o32[i])
+        rep.append((i, model_err, rel(outs[i], ob[i]), rel(outs[i], o32[i])))
+    print('full-size bf16: (head, model error, HIP vs model, HIP vs fp32)', rep, 'losses', parts, pb, p32)
+    for i, model_err, d_model, d_fp32 in rep:
+        assert d_model <= 0.6 * model_err and d_fp32 <= 1.3 * model_err + 1e-3, rep
+    for n in parts:
+        assert abs(parts[n] - pb[n]) <= 1e-3 * max(1.0, abs(pb[n])), (n, parts[n], pb[n], p32[n])
+    assert rel(edge, eb) <= 0.6 * rel(eb, e32) + 1e-3
+
+
 def test_allocator_pool_stays_bounded_over_steps_fullsize(tmp_path):
     """bench shape, 26 training steps: the multi-stream step (encoders on two streams, weight gradients on a third) must not make the
     caching allocator grow step after step.  Activations / gradients handed to the weight-gradient stream are kept alive until the

@@ -1,6 +1,6 @@
 """Whole-path parity on the GPU: HIP model + losses + optimizer step vs the golden fixtures generated from the
 reference (tests/golden, made by oracle/make_golden.py) and vs the oracle on fresh seeded inputs.  fp32 tolerance 1e-3
-(BASELINE.json north_star); bf16 is reported and only loosely bounded."""
+(BASELINE.json north_star); bf16 (the benchmarked precision) is pinned against the oracle's rounding-point mode."""
 import argparse
 import json
 import os
@@ -62,7 +62,7 @@ def run_losses(k, fx, img, lab):
     return out, parts, total
 
 
-@pytest.mark.parametrize('name', ['full_2x32x32', 'full_2x64x64', 'di_2x64x64'])
+@pytest.mark.parametrize('name', ['full_2x32x32', 'full_2x64x64', 'di_2x64x64', 'reg_2x64x64', 'full_2x128x128'])
 def test_fp32_matches_reference_fixture(name, tmp_path):
     fx = dict(np.load(os.path.join(GOLD, name + '.npz')))
     model, sd0 = build(torch.float32)
@@ -94,6 +94,9 @@ def test_fp32_matches_reference_fixture(name, tmp_path):
     # are additionally checked against the fp64 evaluation below.  `emb` (bin means of ~12-50 pixels) moves by O(1/n_bin)
     # whenever two near-tied probabilities swap rank, exactly as torch.sort's tie order does in the reference.
     tols = {'out1': 3e-3, 'out2': 3e-3, 'out3': 3e-3, 'feats': 3e-3, 'emb': 3e-2}
+    if name == 'full_2x128x128':    # >= 128 samples per BatchNorm channel at level 4: heads 1 and 2 meet the literal 1e-3 too (measured 3.6e-4 / 4.2e-4);
+        tols.update(out1=1e-3, out2=1e-3)   # the x8 head and `feats` stay at 1.0e-3 / 1.6e-3 even here: formula weights, not sample count, set the conditioning
+                                            # (on seeded default weights all four heads agree to 7e-6: test_bf16_matches_rounding_point_oracle)
     for a, b in errs.items():
         assert b < tols.get(a, 1e-3), (a, b)
     # fp64 evaluation of the oracle: HIP fp32 must be as close to the exact result as the reference's fp32 is (x3 slack)
@@ -189,22 +192,186 @@ def test_fp32_matches_reference_fixture(name, tmp_path):
             assert relerr(sd[key[4:]].float(), fx[key].astype(np.float32)) < 1e-4, key
 
 
-def test_bf16_close_to_fixture(tmp_path):
+def _seeded_state_dict(seed=0):
+    """the network's own default initialisation (seeded): a well-conditioned model, unlike the fixtures' formula weights whose train-mode
+    network amplifies any rounding by ~1e3 (fp32 implementations of it agree to 1e-4 only)"""
+    from tcct_amd.nets import stc_tt, RegNet
+    torch.manual_seed(seed)
+    return {k: v.clone() for k, v in RegNet(stc_tt(5), con='cos', out_channels=5).state_dict().items()}
+
+
+def _hip_step(sd0, dt, img, lab, tmp_path, udh, reg, noise, train=True):
+    from tcct_amd.nets import stc_tt, RegNet
+    model = RegNet(stc_tt(5, compute_dtype=dt), con='cos', out_channels=5)
+    model.load_state_dict(sd0)
+    k = make_kite(model, tmp_path, udh, reg)
+    model.train()
+    model.base.base_vit.drop_probs = [0.0] * 4
+    out = model(img.cuda())
+    parts = {'dice': k.grad_calc(out, lab.cuda(), ds=True, criterion=k.criterion)}
+    if udh:
+        parts['udh'] = model.regular_udh(out[0], lab.cuda())
+    if reg:
+        parts['reg'] = model.regular_reg(out[0], lab.cuda(), noise=noise) * 0.1
+    tot = sum(parts.values())
+    tot.backward()
+    edges = (model.edge_pred.float().cpu().reshape(-1), model.edge_true.float().cpu().reshape(-1)) if reg else None
+    return (tot.item(), [o.detach().float().cpu() for o in out],
+            {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}, edges)
+
+
+def _oracle_step(sd0, mode, img3, lab, udh, reg, noise):
+    import contextlib
+    import tcct_oracle as O
+    sd = {k: v.clone() for k, v in sd0.items()}
+    for n, v in sd.items():
+        if v.is_floating_point() and not n.endswith(('running_mean', 'running_var')) and not n.startswith('fcp.'):
+            v.requires_grad_(True)
+    oh = torch.nn.functional.one_hot(lab, 5).permute(0, 3, 1, 2)
+    want = {}
+    with (O.rounding_points('bf16') if mode == 'bf16' else contextlib.nullcontext()):
+        tot, parts, outs, feats = O.total_loss(sd, img3, oh, udh=udh, reg=reg, noise=noise if reg else None, want=want)
+        tot.backward()
+    edges = (want['edge_pred'].detach().reshape(-1), want['edge_true'].detach().reshape(-1)) if reg else None
+    return tot.item(), [o.detach() for o in outs], {n: v.grad for n, v in sd.items() if getattr(v, 'grad', None) is not None}, edges
+
+
+def _relmax(a, b):
+    return ((a.double() - b.double()).abs().max() / max(1e-30, b.double().abs().max().item())).item()
+
+
+def test_bf16_matches_rounding_point_oracle(tmp_path):
+    """The BENCHMARKED precision against its own oracle: `tcct_oracle.rounding_points('bf16')` rounds every tensor the HIP bf16 path
+    stores (and the MFMA weights) to bf16 with fp32 arithmetic in between -- the error model of bf16 storage.  On a seeded
+    default-initialised network (2 x 128 x 128, full loss: Dice + reg + fpl; measured values in profiles/r02_parity.md):
+      * fp32 HIP == fp32 oracle to 1e-4 on all four heads, loss 1e-5 -- the well-conditioned control (measured 7e-6 / 6e-8);
+      * the bf16 loss equals the rounding oracle's loss to 2e-4 (measured 6e-7 .. 5e-5);
+      * bf16 logits are 3-5x closer to the rounding oracle than the bf16 error itself (<= 0.6 x model error asserted), and their distance
+        from the fp32 result is the model's (<= 1.3 x; measured 1.04 x): the kernels add nothing beyond storage rounding;
+      * parameter gradients: the per-tensor relative L2 error against the fp32 oracle has the distribution the rounding model predicts
+        (median and 90th percentile within 1.35 x; a single bf16 step carries ~20 % per-tensor gradient noise on this network, which is
+        why the direct HIP-vs-model distance is reported, not bounded tighter than the noise), total norm within 3 %."""
+    import tcct_oracle as O
+    H = 128
+    sd0 = _seeded_state_dict(0)
+    img3, lab = O.synth_batch(2, H, H, seed=31)
+    g = torch.Generator().manual_seed(5)
+    noise = (torch.rand(2, 4, H, H, generator=g), torch.rand(2, 4, H, H, generator=g), torch.rand(1, 1, H, 1, generator=g), torch.rand(1, 1, H, 1, generator=g))
+    h32 = _hip_step(sd0, torch.float32, img3[:, :1], lab, tmp_path, True, True, noise)
+    hb = _hip_step(sd0, torch.bfloat16, img3[:, :1], lab, tmp_path, True, True, noise)
+    o32 = _oracle_step(sd0, 'fp32', img3, lab, True, True, noise)
+    ob = _oracle_step(sd0, 'bf16', img3, lab, True, True, noise)
+    assert abs(h32[0] - o32[0]) <= 1e-5 * abs(o32[0])
+    for i in range(4):
+        assert _relmax(h32[1][i], o32[1][i]) < 1e-4, i
+    assert _relmax(h32[3][0], o32[3][0]) < 1e-3 and _relmax(h32[3][1], o32[3][1]) < 1e-3          # boundary coordinates, the 1e-3 contract
+    assert abs(hb[0] - ob[0]) <= 2e-4 * abs(ob[0]), (hb[0], ob[0])
+    rep = []
+    for i in range(4):
+        model_err = _relmax(ob[1][i], o32[1][i])
+        d_model, d_fp32 = _relmax(hb[1][i], ob[1][i]), _relmax(hb[1][i], o32[1][i])
+        rep.append((i, model_err, d_model, d_fp32))
+        assert d_model <= 0.6 * model_err, rep
+        assert d_fp32 <= 1.3 * model_err + 1e-3, rep
+    print('bf16 logits: (head, model error, HIP vs model, HIP vs fp32)', [(i, f'{a:.2e}', f'{b:.2e}', f'{c:.2e}') for i, a, b, c in rep])
+    gn = {n: o32[2][n].norm().item() for n in o32[2]}
+    gmax = max(gn.values())
+    names = [n for n in sorted(gn) if gn[n] > 1e-3 * gmax]
+    assert set(hb[2]) == set(ob[2]) == set(o32[2])
+    e_hip = np.array([(hb[2][n] - o32[2][n]).norm().item() / gn[n] for n in names])
+    e_mod = np.array([(ob[2][n] - o32[2][n]).norm().item() / gn[n] for n in names])
+    e_dir = np.array([(hb[2][n] - ob[2][n]).norm().item() / max(ob[2][n].norm().item(), 1e-30) for n in names])
+    e_32 = np.array([(h32[2][n] - o32[2][n]).norm().item() / gn[n] for n in names])
+    print(f'gradients ({len(names)} tensors) rel-L2 median / p90: fp32 HIP {np.median(e_32):.2e} / {np.percentile(e_32, 90):.2e}; bf16 HIP vs fp32 '
+          f'{np.median(e_hip):.3f} / {np.percentile(e_hip, 90):.3f}; model vs fp32 {np.median(e_mod):.3f} / {np.percentile(e_mod, 90):.3f}; HIP vs model '
+          f'{np.median(e_dir):.3f} / {np.percentile(e_dir, 90):.3f}')
+    assert np.median(e_32) < 1e-3 and np.percentile(e_32, 90) < 1e-2
+    assert np.median(e_hip) <= 1.35 * np.median(e_mod) and np.percentile(e_hip, 90) <= 1.35 * np.percentile(e_mod, 90)
+    assert np.median(e_dir) <= np.median(e_mod)
+    tn = lambda d: torch.sqrt(sum((t.double() ** 2).sum() for t in d.values())).item()      # noqa: E731
+    assert abs(tn(hb[2]) - tn(o32[2])) <= 3e-2 * tn(o32[2]) and abs(tn(h32[2]) - tn(o32[2])) <= 2e-3 * tn(o32[2])
+
+
+def test_bf16_on_the_formula_weight_fixture(tmp_path):
+    """The golden fixture (formula weights, train-mode BatchNorm over a handful of samples) is ILL-conditioned: the rounding-point oracle
+    itself moves the logits by 0.3-0.9 of their range against fp32 there.  What can be asserted on it: HIP bf16 sits at the model's
+    distance from the fp32 reference (not further), clearly closer to the model than to fp32, and the loss is the model's loss."""
+    import tcct_oracle as O
     fx = dict(np.load(os.path.join(GOLD, 'full_2x64x64.npz')))
-    model, _ = build(torch.bfloat16)
+    model, sd0 = build(torch.bfloat16)
     k = make_kite(model, tmp_path, True, True)
     img = torch.tensor(fx['img']).cuda()
     lab = torch.tensor(fx['lab']).long().cuda()
     out, parts, total = run_losses(k, fx, img, lab)
-    e = relerr(out[0], fx['out0'])
-    print('bf16 logits rel err', e, 'loss', total.item(), 'ref', float(fx['loss_total']))
-    # formula-weight fixture is ill-conditioned (see the fp64 envelope above): bf16 logits are only loosely bounded, the
-    # loss is the meaningful check
-    assert e < 0.6
+    noise = tuple(torch.tensor(fx[f'noise{i}']) for i in range(4))
+    sdo = O.formula_state_dict(keys())
+    ob = _oracle_step(sdo, 'bf16', torch.tensor(fx['img']).repeat(1, 3, 1, 1), torch.tensor(fx['lab']).long(), True, True, noise)
+    model_err = _relmax(ob[1][0], torch.tensor(fx['out0']))
+    d_model, d_ref = _relmax(out[0].detach().float().cpu(), ob[1][0]), relerr(out[0], fx['out0'])
+    print('formula-weight fixture, head 0: model error', model_err, 'HIP vs model', d_model, 'HIP vs reference', d_ref)
+    assert d_model <= 0.5 * model_err and d_ref <= 1.3 * model_err
+    assert abs(total.item() - ob[0]) <= 1e-2 * abs(ob[0])
     assert abs(total.item() - float(fx['loss_total'])) / float(fx['loss_total']) < 2e-2
     total.backward()
     k.optimG.step()
     assert torch.isfinite(k.optimG.last_total_norm).item()
+
+
+def test_bf16_dice_within_1e3_of_fp32(tmp_path):
+    """BASELINE.json: 'Dice within 1e-3 of reference' for the benchmarked precision, metric = MDiceLoss.scorem(start_idx=1) of KiteSeg.val
+    (reference kite/losses/miou.py:87-91, kite/loop_seg.py:88).
+      (a) the SAME weights evaluated by the fp32 and by the bf16 path: |delta Dice| < 2e-4 asserted (measured 4e-7 .. 3e-5);
+      (b) 60 training steps (lr 1e-3, 2 x 128 x 128) in fp32 twice and in bf16 once from the same start: two fp32 runs already differ by
+          1e-3 .. 3e-3 (the weight-gradient atomics reorder fp32 sums and training amplifies it), so 'within 1e-3' between two
+          TRAINING RUNS is below the floor of the reference precision itself; asserted: bf16 lands within max(3 x that floor, 5e-3) of
+          fp32 and every run reaches Dice > 0.95."""
+    from tcct_amd.nets import stc_tt, RegNet
+    from tcct_amd.kite import KiteSeg
+    from tcct_amd.kite.losses import MDiceLoss
+    from tcct_amd.data import SynthOCT
+    H, lr, steps = 128, 1e-3, 60
+    sd0 = _seeded_state_dict(0)
+    ds = SynthOCT(height=H, width=H, device='cuda', n_train=2 * steps, n_val=16)
+
+    def make(dt, sd, sub):
+        model = RegNet(stc_tt(5, compute_dtype=dt), con='cos', out_channels=5)
+        model.load_state_dict(sd)
+        args = argparse.Namespace(los='di', lr=lr, gpu='0', pl=False, bs=2, coff_ds=1, udh=False, reg=False, epl=False, coff_udh=1, coff_reg=.1,
+                                  coff_epl=.1, bug=False)
+        k = KiteSeg(model=model, dataset=ds, root=str(tmp_path / sub), args=args)
+        k.model.base.base_vit.drop_probs = [0.0] * 4
+        for g in k.optimG.param_groups:
+            g['lr'] = lr
+        return k
+
+    def train(k):
+        k.model.train()
+        for i, b in enumerate(ds.trainSet(bs=2)):
+            img, lab, _, _ = ds.parse(b)
+            k.train_step(img, lab)
+            if i + 1 == steps:
+                break
+        return k
+
+    def dice(k):
+        k.model.eval()
+        tot, n = 0.0, 0
+        with torch.no_grad():
+            for b in ds.valSet(bs=1):
+                img, lab, _, _ = ds.parse(b)
+                tot += MDiceLoss.scorem(k.predict(img), lab, start_idx=1).item()
+                n += 1
+        return tot / n
+    ka, kb, kc = train(make(torch.float32, sd0, 'a')), train(make(torch.float32, sd0, 'b')), train(make(torch.bfloat16, sd0, 'c'))
+    da, db, dc = dice(ka), dice(kb), dice(kc)
+    print(f'Dice after {steps} steps: fp32 {da:.5f} / {db:.5f} (run-to-run {abs(da - db):.2e}), bf16 {dc:.5f} (vs fp32 {abs(da - dc):.2e})')
+    assert min(da, db, dc) > 0.95
+    assert abs(dc - da) <= max(3 * abs(da - db), 5e-3)
+    for tag, kk in (('fp32-trained', ka), ('bf16-trained', kc)):
+        sdt = {n: v.clone() for n, v in kk.model.state_dict().items()}
+        d32, d16 = dice(make(torch.float32, sdt, tag + '32')), dice(make(torch.bfloat16, sdt, tag + '16'))
+        print(f'{tag} weights: eval fp32 {d32:.6f}, eval bf16 {d16:.6f}, |delta| {abs(d32 - d16):.2e}')
+        assert abs(d32 - d16) < 2e-4, (tag, d32, d16)
 
 
 def test_train_step_pool_and_slots_match_plain(tmp_path):
@@ -257,7 +424,14 @@ def test_eval_mode_predict_matches_oracle(dtype, tmp_path):
         outs = k.model(img.cuda())
     e = relerr(outs[0], outs_o[0])
     print('eval logits rel err', dtype, e)
-    assert e < (1e-3 if dtype == torch.float32 else 0.25)
+    if dtype == torch.float32:
+        assert e < 1e-3
+    else:       # bf16: against the rounding-point oracle of the fused inference path (BatchNorm / activations in the producing kernel's epilogue)
+        with torch.no_grad(), O.rounding_points('bf16', fused_eval=True):
+            outs_b, _ = O.ftc_forward({kk: v.clone() for kk, v in sd.items()}, img, train=False)
+        model_err, d_model = relerr(outs_b[0], outs_o[0]), relerr(outs[0], outs_b[0])
+        print('eval bf16: model error', model_err, 'HIP vs model', d_model)
+        assert d_model <= 0.6 * model_err + 1e-4 and e <= 1.3 * model_err + 1e-3
     mask = k.predict(img.cuda())
     dense = mask.dense().cpu()
     assert dense.shape == (2, 5, 64, 96) and torch.all(dense.sum(1) == 1)
@@ -563,7 +737,9 @@ def test_two_ranks_average_gradients_like_one_process_on_the_mean(overlap, tmp_p
     gmax = max(t.abs().max().item() for t in mean[1].values())
     for n in a['names']:
         d = (0.5 * g_dp[n] - mean[1][n]).abs().max().item()
-        assert d <= 2e-4 * max(mean[1][n].abs().max().item(), 1e-3 * gmax), (n, d)     # fp32 atomics reorder sums between runs; nothing else differs
+        # fp32 atomics reorder sums between runs, nothing else differs.  The absolute floor covers the convolution biases in front of a
+        # train-mode BatchNorm: their exact gradient is 0 and what any run returns is cancellation noise (~3e-4 of the largest gradient)
+        assert d <= 2e-4 * mean[1][n].abs().max().item() + 2e-6 * gmax, (n, d)
     norm_mean = torch.sqrt(sum((t.double() ** 2).sum() for t in mean[1].values())).item()
     assert abs(a['norm'] - norm_mean) <= 1e-4 * norm_mean, (a['norm'], norm_mean)          # NOT 2 x: the kernel scales by 1/world
     # post-step weights: oracle clip + AdamW on the mean gradients (step 1 at lr 0 only moves the moments, step 2 is the update)

@@ -18,7 +18,7 @@ def keys():
     return [(k, tuple(s)) for k, s in json.load(open(os.path.join(GOLD, 'state_dict_keys.json')))]
 
 
-@pytest.mark.parametrize('name', ['full_2x32x32', 'full_2x64x64', 'di_2x64x64'])
+@pytest.mark.parametrize('name', ['full_2x32x32', 'full_2x64x64', 'di_2x64x64', 'reg_2x64x64', 'full_2x128x128'])
 def test_oracle_reproduces_reference_fixture(name):
     torch.set_num_threads(4)
     fx = dict(np.load(os.path.join(GOLD, name + '.npz')))
