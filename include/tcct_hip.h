@@ -187,6 +187,11 @@ int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float* dbias, in
 int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                 int out_dtype, tcct_stream_t stream);
 int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
+/* Fused backward of a 1x1 convolution / nn.Linear (autograd of nets/tcct.py:41-43,124,532-546,966-997): dx = dy W (+ res, nullable: the
+ * gradient reaching x through its other consumers), dw += dy^T x, dbias += sum dy in ONE pass over dy.  bf16 rows, w fp32 [N,K],
+ * K and N in {32,64,96,128}; dw / dbias are cleared first unless tcct_set_outputs_prezeroed(1). */
+int tcct_pw_bwd(const void* x, const void* dy, const float* w, const void* res, void* dx, float* dw, float* dbias, int64_t M, int K, int N,
+                tcct_stream_t stream);
 /* the same for an N-column slab of a wider output: dy rows have stride ldy elements (multiple of 8) and dy / dw / dbias point at the slab
  * (nn.Linear(dim, 3 dim) of FactorAtt_ConvRelPosEnc, nets/tcct.py:307, runs as slabs of <= 160 columns) */
 int tcct_pw_wgrad_strided(const void* x, const void* dy, int64_t ldy, float* dw, float* dbias, int64_t M, int K, int N,

@@ -12,6 +12,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4;
 
 #define PWB 256
 
@@ -542,6 +543,208 @@ static int pw_wgrad_impl(const void* x, const void* x2, int K1, const void* dy, 
     TCCT_LAUNCH_OK();
 }
 
+
+// ------------------------------------------------------------------------------------------------ fused backward
+// Input gradient AND weight gradient of a 1x1 convolution / Linear in ONE pass over dy (the separate kernels read dy twice -- the
+// weight-gradient kernel up to K/32 times for wide shapes, its blockIdx.y slices -- and x once):
+//     dx[M,K] = dy[M,N] W[N,K] (+ res),   dW[N,K] += dy^T x,   dbias[N] += sum_m dy.
+// Per 128-pixel tile the x and dy rows are staged in LDS once (register prefetch one tile ahead, out-of-range rows read as zeros
+// through buffer descriptors).  Weight gradient: the NT x KT output tiles are OWNED by waves (tile i -> wave i % 4, K = the 128
+// pixels as eight transposing-read chunks), so no cross-wave reduction and every dy element is read from HBM exactly once.  Input
+// gradient: wave w takes pixels 32w..32w+31, A = W^T from LDS (bf16 [K][N], conflict-free rows of 2N+16 bytes), B = the staged dy
+// rows.  Same tile pipeline as k_conv32_mfma: the staging wait sits behind the MFMA phase, the dx stores of tile t are issued after
+// the loads of tile t+2.  Algorithmic bytes: M (2K + N) 2 B against M (2K + 2N) 2 B (or more) for the two-kernel form.
+#define PB_P 128
+template <int NT, int KT>
+__global__ void __launch_bounds__(PWB, 2)
+k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ w, const bf16* __restrict__ res,
+         bf16* __restrict__ dx, float* __restrict__ dw, float* __restrict__ dbias, int64_t M) {
+    constexpr int K = 32 * KT, N = 32 * NT;
+    constexpr int SX = 64 * KT + ((KT & 1) ? 0 : 64), SD = 64 * NT + ((NT & 1) ? 0 : 64);      // rows == 64 / 192 mod 256: conflict-free transposing reads
+    constexpr int SW = 2 * N + 16;
+    constexpr int XS = K / 16, DS = N / 16;                // 16-byte staging slots per thread (128 px x K/8 chunks / 256 threads)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;
+    unsigned char* sD = sX + PB_P * SX;
+    unsigned char* sW = sD + PB_P * SD;
+    unsigned char* sS = sW + ((K * SW + 15) & ~15);        // per-wave epilogue transpose scratch: 32 px x 80 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    // W^T as bf16 [k][n]: w is [N][K] fp32; consecutive threads read consecutive k of one n (coalesced), transposed on the LDS side
+    for (int i = tid; i < N * K; i += PWB) {
+        const int n = i / K, k = i - n * K;
+        *reinterpret_cast<bf16*>(sW + k * SW + n * 2) = __float2bfloat16(w[i]);
+    }
+    f32x16 accw[(NT * KT + 3) / 4];
+#pragma unroll
+    for (int a = 0; a < (NT * KT + 3) / 4; ++a)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) accw[a][k] = 0.f;
+    float bsum[(NT * KT + 3) / 4];                   // bias gradient: per owned tile with kt == 0
+#pragma unroll
+    for (int a = 0; a < (NT * KT + 3) / 4; ++a) bsum[a] = 0.f;
+    const int64_t tiles = (M + PB_P - 1) / PB_P;
+    const uint32_t xbytes = (uint32_t)(M * K * 2), dbytes = (uint32_t)(M * N * 2);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(res ? res : x), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)dx, 0, xbytes, 0x00020000);
+    u32x4 px[XS], pd[DS];
+    // a tile's rows are one contiguous span of memory: slot i of a thread = bytes [16 (tid + 256 i), +16) of it (fully coalesced);
+    // rows beyond M fall outside the descriptor and read as zeros
+    auto prefetch = [&](int64_t tile) {
+        const uint32_t bx = (uint32_t)(tile * PB_P * K * 2), bd = (uint32_t)(tile * PB_P * N * 2);
+#pragma unroll
+        for (int j = 0; j < XS; ++j) px[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, bx + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
+#pragma unroll
+        for (int j = 0; j < DS; ++j) pd[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, bd + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < XS; ++j) {
+            const int q = tid + j * PWB, p = q / (K / 8), c = q - p * (K / 8);
+            *reinterpret_cast<u32x4*>(sX + p * SX + c * 16) = px[j];
+        }
+#pragma unroll
+        for (int j = 0; j < DS; ++j) {
+            const int q = tid + j * PWB, p = q / (N / 8), c = q - p * (N / 8);
+            *reinterpret_cast<u32x4*>(sD + p * SD + c * 16) = pd[j];
+        }
+    };
+    // transposing-read lane bases (see k_pw_wgrad)
+    const int li = lane & 15, lq = li >> 2, lpp = li & 3, lg = lane >> 4;
+    const int lrow = 8 * (lg >> 1) + lq, lcol = (16 * (lg & 1) + 4 * lpp) * 2;
+    const unsigned char* lbX = sX + lrow * SX + lcol;
+    const unsigned char* lbD = sD + lrow * SD + lcol;
+    auto tr2 = [&](const unsigned char* p, int stride) {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * stride));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < tiles) {
+        prefetch(tile);
+        __syncthreads();            // weights staged
+        stage();
+        prefetch(tile + gridDim.x);                 // beyond the last tile: every row out of range, zeros, never used
+    }
+    __syncthreads();
+    for (; tile < tiles; tile += gridDim.x) {
+        // ---- weight gradient: owned tiles, K-dim = the 128 staged pixels
+#pragma unroll
+        for (int a = 0; a < (NT * KT + 3) / 4; ++a) {
+            const int ti = wave + 4 * a;
+            if (ti < NT * KT) {                       // wave-uniform
+                const int ct = ti / KT, kt = ti - ct * KT;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    const bf16x8 fa = tr2(lbD + ch * 16 * SD + 64 * ct, SD);
+                    const bf16x8 fb = tr2(lbX + ch * 16 * SX + 64 * kt, SX);
+                    if (kt == 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bsum[a] += (float)fa[j];
+                    }
+                    accw[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, accw[a], 0, 0, 0);
+                }
+            }
+        }
+        // ---- input gradient of this wave's 32 pixels: D[k][pixel] = sum_n W^T[k][n] dy[pixel][n]
+        f32x16 accd[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) accd[kt][k] = 0.f;
+        const unsigned char* bB = sD + (32 * wave + r) * SD + hh * 16;
+#pragma unroll
+        for (int st = 0; st < 2 * NT; ++st) {
+            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(bB + st * 32);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(sW + (kt * 32 + r) * SW + st * 32 + hh * 16);
+                accd[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, accd[kt], 0, 0, 0);
+            }
+        }
+        __syncthreads();                              // every wave has read the staged tile
+        if (tile + (int64_t)gridDim.x < tiles) stage();
+        prefetch(tile + 2 * (int64_t)gridDim.x);
+        // ---- dx epilogue: per-wave LDS transpose -> 16-byte stores (16 whole 64-byte pixel segments per wave instruction)
+        unsigned char* sc = sS + wave * 2560;
+        const int64_t m0 = tile * PB_P + 32 * wave;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint2 o;
+                o.x = pack_bf16x2(accd[kt][4 * q], accd[kt][4 * q + 1]);
+                o.y = pack_bf16x2(accd[kt][4 * q + 2], accd[kt][4 * q + 3]);
+                *reinterpret_cast<uint2*>(sc + r * 80 + (8 * q + 4 * hh) * 2) = o;
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int p = (lane >> 2) + 16 * h2, cch = lane & 3;
+                u32x4 o = *reinterpret_cast<const u32x4*>(sc + p * 80 + cch * 16);
+                const int64_t mm = m0 + p;
+                const uint32_t off = mm < M ? (uint32_t)((mm * K + kt * 32 + cch * 8) * 2) : 0x80000000u;
+                if (res) {          // block-uniform: dx = dy W + res (the gradient that reaches x through its other consumers)
+                    const u32x4 rv = __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        o[k] = pack_bf16x2(__uint_as_float(o[k] << 16) + __uint_as_float(rv[k] << 16),
+                                           __uint_as_float(o[k] & 0xffff0000u) + __uint_as_float(rv[k] & 0xffff0000u));
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(o, ro, off, 0, 0);
+            }
+            wave_lds_fence();
+        }
+        __syncthreads();                              // the next tile's image is complete
+    }
+    // ---- weight-gradient tiles straight from the owning wave's registers: lanes r = 0..31 of a register are 128 contiguous bytes
+#pragma unroll
+    for (int a = 0; a < (NT * KT + 3) / 4; ++a) {
+        const int ti = wave + 4 * a;
+        if (ti < NT * KT) {
+            const int ct = ti / KT, kt = ti - ct * KT;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int co = ct * 32 + (k & 3) + 8 * (k >> 2) + 4 * hh;
+                atomicAdd(&dw[(int64_t)co * K + kt * 32 + r], accw[a][k]);
+            }
+            if (dbias && kt == 0) {
+                const float sb = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+                if (lane < 32) atomicAdd(&dbias[ct * 32 + r], sb);
+            }
+        }
+    }
+}
+
+/* Fused backward of y = x W^T + b for bf16 rows: dx [M,K] (= dy W, + res when res != NULL), dw [N,K] fp32 and dbias [N] fp32 (nullable)
+ * are ACCUMULATED into after being cleared here (or by the caller: tcct_set_outputs_prezeroed).  K, N in {32, 64, 96, 128}. */
+extern "C" int tcct_pw_bwd(const void* x, const void* dy, const float* w, const void* res, void* dx, float* dw, float* dbias, int64_t M,
+                           int K, int N, tcct_stream_t stream) {
+    TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && K <= 128 && N <= 128, "pw_bwd: K=%d N=%d unsupported (32..128)", K, N);
+    TCCT_CHECK(M > 0 && M * (int64_t)(K > N ? K : N) * 2 < (1LL << 31), "pw_bwd: tensor exceeds the 2 GiB buffer-descriptor range");
+    hipStream_t st = (hipStream_t)stream;
+    if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)N * K, st) != hipSuccess) { tcct_set_error("pw_bwd: memset failed"); return -2; }
+    if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * N, st) != hipSuccess) { tcct_set_error("pw_bwd: memset failed"); return -2; }
+    const int NT = N / 32, KT = K / 32;
+    const int SX = 64 * KT + ((KT & 1) ? 0 : 64), SD = 64 * NT + ((NT & 1) ? 0 : 64), SW = 2 * N + 16;
+    const size_t lds = (size_t)PB_P * (SX + SD) + (((size_t)K * SW + 15) & ~(size_t)15) + 4 * 2560;
+    TCCT_CHECK(lds <= 160 * 1024, "pw_bwd: %zu B of LDS", lds);
+    const int64_t tiles = (M + PB_P - 1) / PB_P;
+    int per_cu = (int)((160 * 1024) / (lds + 256));
+    if (per_cu > 2) per_cu = 2;
+    int64_t gx = 256 * per_cu;
+    if (gx > tiles) gx = tiles;
+#define BL(NTV, KTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<NTV, KTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_bwd<NTV, KTV>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, dw, dbias, M); }
+#define BLK(NTV) switch (KT) { case 1: BL(NTV, 1) break; case 2: BL(NTV, 2) break; case 3: BL(NTV, 3) break; default: BL(NTV, 4) break; }
+    switch (NT) { case 1: BLK(1) break; case 2: BLK(2) break; case 3: BLK(3) break; default: BLK(4) break; }
+#undef BLK
+#undef BL
+    TCCT_LAUNCH_OK();
+}
 
 // ------------------------------------------------------------------------------------------------ first-layer im2col
 // The two 3-channel 3x3 convolutions (CrossResNet.cnn[0], reference nets/tcct.py:873; MPViT stem[0] stride 2, :674-681) have

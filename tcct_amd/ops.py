@@ -263,6 +263,16 @@ def _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, trans
                 wp = torch.empty_like(wp)
 
 
+FUSED_PW_BWD = os.environ.get('TCCT_FUSED_PW_BWD', '1') != '0'        # =0: separate input-gradient / weight-gradient kernels (A/B timing)
+
+
+def _pw_bwd_ok(x, dy, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+    """shapes of the fused pointwise backward kernel (tcct_pw_bwd): bf16 1x1, channel counts in {32, 64, 96, 128}"""
+    return (x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and KH == 1 and KW == 1 and stride == 1 and padh == 0 and padw == 0
+            and Cin == Cin_w and Cin % 32 == 0 and Cout % 32 == 0 and 32 <= Cin <= 128 and 32 <= Cout <= 128
+            and x.numel() * 2 < 2 ** 31 and dy.numel() * 2 < 2 ** 31)
+
+
 def _pw_ok(in_dt, Cin, Cin_w, KH, KW, stride, padh, padw):
     """the MFMA pointwise kernels cover bf16 1x1 convs / Linear with Cin % 32 == 0"""
     return (in_dt == torch.bfloat16 and KH == 1 and KW == 1 and stride == 1 and padh == 0 and padw == 0 and Cin == Cin_w
@@ -274,6 +284,7 @@ class _Conv2d(torch.autograd.Function):
     def forward(ctx, x, w, bias, stride, padh, padw, out_dtype, stats_box, fork=False):
         """fork: also return an alias of x for the OTHER consumers of x -- their gradient then arrives in backward() and is added
         inside the input-gradient kernel's epilogue (tcct_conv32_fwd_add) instead of by an autograd accumulation pass"""
+        ctx.set_materialize_grads(False)      # an unused output must arrive as None in backward(), not as a zero-filled tensor
         _chk(x, w, bias)
         N, H, W, Cin = x.shape
         Cout, Cin_w, KH, KW = w.shape
@@ -328,6 +339,15 @@ class _Conv2d(torch.autograd.Function):
         N, H, W, Cin = x.shape
         Cout, Cin_w, KH, KW = w.shape
         dx = dw = db = None
+        if (FUSED_PW_BWD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _pw_bwd_ok(x, dy, Cin, Cin_w, Cout, KH, KW, stride, padh, padw)
+                and (dskip is None or dskip.shape == x.shape)):
+            # 1x1 convolution: input gradient, weight gradient and bias gradient in ONE pass over dy (tcct_pw_bwd); a second
+            # consumer's gradient of x (fork) rides on the dx epilogue
+            dx = torch.empty_like(x)
+            dw = _grad_out(wsrc, tuple(w.shape))
+            db = _grad_out(bsrc) if has_bias else None
+            lib.pw_bwd(x, dy, w, dskip, dx, dw, db, N * H * W, Cin, Cout)
+            return dx, _ret(dw, wsrc), _ret(db, bsrc), None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             if stride != 1 or Cin != Cin_w:
                 raise TcctError('conv2d dgrad: only stride-1 convs with unpadded channels need an input gradient')
@@ -573,6 +593,11 @@ class _LinearResidual(torch.autograd.Function):
             dz = torch.empty_like(dy)
             lib.scale_rows(dy, ctx.scale, dz, B, dy.numel() // B, dtype_code(dy.dtype))
         dx = torch.empty_like(x)
+        if FUSED_PW_BWD and _pw_bwd_ok(x, dz, K, K, Cout, 1, 1, 1, 0, 0):
+            dw = _grad_out(wsrc, tuple(w.shape))
+            db = _grad_out(bsrc)
+            lib.pw_bwd(x, dz, w, None, dx, dw, db, M, K, Cout)
+            return dx, _ret(dw, wsrc), _ret(db, bsrc), dy, None
         lib.pw_fwd(dz, w, None, dx, M, Cout, K, 1, dtype_code(x.dtype))
         with _wgrad_stream(_slot_written(wsrc, bsrc), x, dz):
             dw = _grad_out(wsrc, tuple(w.shape))
@@ -586,6 +611,7 @@ class _Conv1x1AndSum(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, res):
+        ctx.set_materialize_grads(False)      # an unused output must arrive as None in backward(), not as a zero-filled tensor
         _chk(x, w, bias, res)
         N_, H, W_, K = x.shape
         Cout = w.shape[0]
@@ -626,6 +652,7 @@ class _UpSkipConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, skip, w, bias, align):
+        ctx.set_materialize_grads(False)      # an unused output must arrive as None in backward(), not as a zero-filled tensor
         _chk(y, skip, w, bias)
         N_, H, W_, C = y.shape
         _, Ho, Wo, _ = skip.shape
@@ -776,6 +803,7 @@ class _DwConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, add_input, fork=False):
         """fork: also return an alias of x for its other consumers; their gradient is added inside the input-gradient kernel"""
+        ctx.set_materialize_grads(False)      # an unused output must arrive as None in backward(), not as a zero-filled tensor
         _chk(x, w, bias)
         N, H, W, C = x.shape
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -946,6 +974,7 @@ class _LayerNorm(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, eps, fork=False):
         """fork: also return an alias of x for the residual path around the normalisation; its gradient is then added inside the
         LayerNorm backward kernel (tcct_layernorm_bwd_add) instead of by an autograd accumulation pass"""
+        ctx.set_materialize_grads(False)      # an unused output must arrive as None in backward(), not as a zero-filled tensor
         _chk(x, gamma, beta)
         C = x.shape[-1]
         M = x.numel() // C
@@ -1286,6 +1315,7 @@ class _MaxPool2Fork(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
+        ctx.set_materialize_grads(False)      # an unused output must arrive as None in backward(), not as a zero-filled tensor
         _chk(x)
         N, H, W, C = x.shape
         y = torch.empty((N, H // 2, W // 2, C), device=x.device, dtype=x.dtype)
@@ -1650,6 +1680,7 @@ def label_planes(labels, start, n, want_onehot=True, want_edge=True):
 class _Fpl(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, logits, labels, buf_grad):
+        ctx.set_materialize_grads(False)      # an unused output must arrive as None in backward(), not as a zero-filled tensor
         _chk(feat, logits, labels, buf_grad)
         C = logits.shape[-1]
         M = logits.numel() // C
@@ -1684,6 +1715,8 @@ class _Fpl(torch.autograd.Function):
     def backward(ctx, g, _gpro):
         labels, binmap, dpro = ctx.saved_tensors
         shape, dt, M = ctx.cfg
+        if g is None:
+            return None, None, None, None
         g = _as(g, torch.float32)
         dfeat = torch.empty(shape, device=g.device, dtype=dt)
         lib.fpl_backward(labels, binmap, dpro, g, 1.0, M, dfeat, dtype_code(dt))

@@ -346,6 +346,36 @@ def test_fpl_matches_oracle():
     torch.testing.assert_close(nchw(fd.grad), feats.grad, rtol=1e-4, atol=1e-9)
 
 
+@pytest.mark.parametrize('K,N', [(32, 32), (64, 64), (96, 96), (128, 128), (128, 96), (96, 32), (32, 128), (64, 128), (128, 32)])
+@pytest.mark.parametrize('M,with_res', [(1000, False), (128 * 3 + 17, True), (70000, False)])
+def test_pw_bwd_fused(K, N, M, with_res):
+    """tcct_pw_bwd: input gradient (+ the second consumer's gradient), weight gradient and bias gradient of a 1x1 convolution in one pass
+    over dy, against fp32 matmuls on the same bf16-rounded operands (ragged last tile, every K / N the kernel is instantiated for)"""
+    from tcct_amd._lib import lib
+    g = torch.Generator().manual_seed(K * 1000 + N + M)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    dy = torch.randn(M, N, generator=g).bfloat16()
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    res = torch.randn(M, K, generator=g).bfloat16() if with_res else None
+    wb = w.bfloat16().float()
+    dx_ref = dy.float() @ wb + (res.float() if with_res else 0)
+    dw_ref = dy.float().t() @ x.float()
+    db_ref = dy.float().sum(0)
+    xd, dyd, wd = x.cuda(), dy.cuda(), w.cuda()
+    dx = torch.empty_like(xd)
+    dw = torch.full((N, K), 7.0, device='cuda')         # must be cleared by the entry point
+    db = torch.full((N,), 7.0, device='cuda')
+    lib.pw_bwd(xd, dyd, wd, res.cuda() if with_res else None, dx, dw, db, M, K, N)
+    torch.testing.assert_close(dx.float().cpu(), dx_ref, rtol=2e-2, atol=2e-2 * max(1.0, dx_ref.abs().max().item() / 4))
+    scale = dw_ref.abs().max().item()
+    assert (dw.cpu() - dw_ref).abs().max().item() <= 2e-4 * scale + 1e-3, (dw.cpu() - dw_ref).abs().max().item()
+    assert (db.cpu() - db_ref).abs().max().item() <= 2e-4 * db_ref.abs().max().item() + 1e-3
+    # dbias is optional
+    dw2 = torch.zeros((N, K), device='cuda')
+    lib.pw_bwd(xd, dyd, wd, None, dx, dw2, None, M, K, N)
+    assert (dw2.cpu() - dw_ref).abs().max().item() <= 2e-4 * scale + 1e-3
+
+
 def test_featconsuper_methods_mirror_the_reference_surface():
     """`model.fcs.select1 / cosinesim / foreach_loss` and `points_selection_bins` (reference nets/fcs.py:25-96) called the way
     reference nets/reg.py:93-102 calls them, one class at a time: prototypes, loss and the feature gradient equal the oracle's and
