@@ -192,6 +192,9 @@ int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_
  * K and N in {32,64,96,128}; dw / dbias are cleared first unless tcct_set_outputs_prezeroed(1). */
 int tcct_pw_bwd(const void* x, const void* dy, const float* w, const void* res, void* dx, float* dw, float* dbias, int64_t M, int K, int N,
                 tcct_stream_t stream);
+/* ... writing both dx_sum = dy W + res and dx_plain = dy W (MPUpBlock tail + the `x_i + y_i` of FTC.forward, nets/tcct.py:908-914,1028-1031) */
+int tcct_pw_bwd_residual2(const void* x, const void* dy, const float* w, const void* res, void* dx_sum, void* dx_plain, float* dw, float* dbias,
+                          int64_t M, int K, int N, tcct_stream_t stream);
 /* the same for an N-column slab of a wider output: dy rows have stride ldy elements (multiple of 8) and dy / dw / dbias point at the slab
  * (nn.Linear(dim, 3 dim) of FactorAtt_ConvRelPosEnc, nets/tcct.py:307, runs as slabs of <= 160 columns) */
 int tcct_pw_wgrad_strided(const void* x, const void* dy, int64_t ldy, float* dw, float* dbias, int64_t M, int K, int N,

@@ -558,7 +558,7 @@ static int pw_wgrad_impl(const void* x, const void* x2, int K1, const void* dy, 
 template <int NT, int KT>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ w, const bf16* __restrict__ res,
-         bf16* __restrict__ dx, float* __restrict__ dw, float* __restrict__ dbias, int64_t M) {
+         bf16* __restrict__ dx, bf16* __restrict__ dx_plain, float* __restrict__ dw, float* __restrict__ dbias, int64_t M) {
     constexpr int K = 32 * KT, N = 32 * NT;
     constexpr int SX = 64 * KT + ((KT & 1) ? 0 : 64), SD = 64 * NT + ((NT & 1) ? 0 : 64);      // rows == 64 / 192 mod 256: conflict-free transposing reads
     constexpr int SW = 2 * N + 16;
@@ -589,6 +589,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(res ? res : x), 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)dx, 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(dx_plain ? dx_plain : dx), 0, xbytes, 0x00020000);
     u32x4 px[XS], pd[DS];
     // a tile's rows are one contiguous span of memory: slot i of a thread = bytes [16 (tid + 256 i), +16) of it (fully coalesced);
     // rows beyond M fall outside the descriptor and read as zeros
@@ -688,6 +689,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
                 const int64_t mm = m0 + p;
                 const uint32_t off = mm < M ? (uint32_t)((mm * K + kt * 32 + cch * 8) * 2) : 0x80000000u;
                 if (res) {          // block-uniform: dx = dy W + res (the gradient that reaches x through its other consumers)
+                    if (dx_plain) __builtin_amdgcn_raw_buffer_store_b128(o, rp, off, 0, 0);      // dy W itself (decoder tail: continues into the resize)
                     const u32x4 rv = __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
@@ -721,8 +723,21 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
 
 /* Fused backward of y = x W^T + b for bf16 rows: dx [M,K] (= dy W, + res when res != NULL), dw [N,K] fp32 and dbias [N] fp32 (nullable)
  * are ACCUMULATED into after being cleared here (or by the caller: tcct_set_outputs_prezeroed).  K, N in {32, 64, 96, 128}. */
+static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
+                       int64_t M, int K, int N, tcct_stream_t stream);
 extern "C" int tcct_pw_bwd(const void* x, const void* dy, const float* w, const void* res, void* dx, float* dw, float* dbias, int64_t M,
                            int K, int N, tcct_stream_t stream) {
+    return pw_bwd_impl(x, dy, w, res, dx, nullptr, dw, dbias, M, K, N, stream);
+}
+/* the same with BOTH input gradients written: dx_sum = dy W + res and dx_plain = dy W (decoder block tail: the skip tensor's gradient and
+ * the gradient that continues into the bilinear resize, reference nets/tcct.py:908-914,1028-1031) */
+extern "C" int tcct_pw_bwd_residual2(const void* x, const void* dy, const float* w, const void* res, void* dx_sum, void* dx_plain, float* dw,
+                                     float* dbias, int64_t M, int K, int N, tcct_stream_t stream) {
+    TCCT_CHECK(res != nullptr && dx_plain != nullptr && dx_plain != dx_sum, "pw_bwd_residual2: needs res and two distinct outputs");
+    return pw_bwd_impl(x, dy, w, res, dx_sum, dx_plain, dw, dbias, M, K, N, stream);
+}
+static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
+                       int64_t M, int K, int N, tcct_stream_t stream) {
     TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && K <= 128 && N <= 128, "pw_bwd: K=%d N=%d unsupported (32..128)", K, N);
     TCCT_CHECK(M > 0 && M * (int64_t)(K > N ? K : N) * 2 < (1LL << 31), "pw_bwd: tensor exceeds the 2 GiB buffer-descriptor range");
     hipStream_t st = (hipStream_t)stream;
@@ -738,7 +753,7 @@ extern "C" int tcct_pw_bwd(const void* x, const void* dy, const float* w, const 
     int64_t gx = 256 * per_cu;
     if (gx > tiles) gx = tiles;
 #define BL(NTV, KTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<NTV, KTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
-        hipLaunchKernelGGL((k_pw_bwd<NTV, KTV>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, dw, dbias, M); }
+        hipLaunchKernelGGL((k_pw_bwd<NTV, KTV>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M); }
 #define BLK(NTV) switch (KT) { case 1: BL(NTV, 1) break; case 2: BL(NTV, 2) break; case 3: BL(NTV, 3) break; default: BL(NTV, 4) break; }
     switch (NT) { case 1: BLK(1) break; case 2: BLK(2) break; case 3: BLK(3) break; default: BLK(4) break; }
 #undef BLK

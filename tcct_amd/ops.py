@@ -636,6 +636,11 @@ class _Conv1x1AndSum(torch.autograd.Function):
         N_, H, W_, K = x.shape
         Cout, M = w.shape[0], N_ * H * W_
         dx = torch.empty_like(x)
+        if FUSED_PW_BWD and _pw_bwd_ok(x, dz, K, K, Cout, 1, 1, 1, 0, 0):
+            dw = _grad_out(wsrc, tuple(w.shape))
+            db = _grad_out(bsrc)
+            lib.pw_bwd(x, dz, w, None, dx, dw, db, M, K, Cout)
+            return dx, _ret(dw, wsrc), _ret(db, bsrc), (None if gs is None else _c(gs))
         lib.pw_fwd(dz, w, None, dx, M, Cout, K, 1, dtype_code(x.dtype))
         with _wgrad_stream(_slot_written(wsrc, bsrc), x, dz):
             dw = _grad_out(wsrc, tuple(w.shape))
@@ -681,7 +686,17 @@ class _UpSkipConv(torch.autograd.Function):
             lib.add(_c(gd), _c(gs), dz, dz.numel(), dtype_code(dz.dtype))
         Cout, M = w.shape[0], N_ * Ho * Wo
         du = torch.empty_like(u)
-        if gs is not None:
+        fused = FUSED_PW_BWD and _pw_bwd_ok(u, dz, C, C, Cout, 1, 1, 1, 0, 0)
+        if fused:       # both input gradients and the weight / bias gradients from ONE pass over dz
+            dw = _grad_out(wsrc, tuple(w.shape))
+            db = _grad_out(bsrc)
+            if gs is not None:
+                dskip = torch.empty_like(u)
+                lib.pw_bwd_residual2(u, dz, w, _c(gs), dskip, du, dw, db, M, C, Cout)
+            else:
+                lib.pw_bwd(u, dz, w, None, du, dw, db, M, C, Cout)
+                dskip = du
+        elif gs is not None:
             dskip = torch.empty_like(u)
             lib.pw_dgrad_residual(dz, w, _c(gs), dskip, du, M, Cout, C)
         else:
@@ -689,10 +704,11 @@ class _UpSkipConv(torch.autograd.Function):
             dskip = du
         dy = torch.empty((N_, H, W_, C), device=u.device, dtype=u.dtype)
         lib.bilinear_bwd(du, dy, N_, H, W_, C, Ho, Wo, align, dtype_code(u.dtype))
-        with _wgrad_stream(_slot_written(wsrc, bsrc), u, dz):
-            dw = _grad_out(wsrc, tuple(w.shape))
-            db = _grad_out(bsrc)
-            lib.pw_wgrad(u, dz, dw, db, M, C, Cout)
+        if not fused:
+            with _wgrad_stream(_slot_written(wsrc, bsrc), u, dz):
+                dw = _grad_out(wsrc, tuple(w.shape))
+                db = _grad_out(bsrc)
+                lib.pw_wgrad(u, dz, dw, db, M, C, Cout)
         return dy, dskip, _ret(dw, wsrc), _ret(db, bsrc), None
 
 

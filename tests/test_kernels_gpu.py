@@ -370,6 +370,13 @@ def test_pw_bwd_fused(K, N, M, with_res):
     scale = dw_ref.abs().max().item()
     assert (dw.cpu() - dw_ref).abs().max().item() <= 2e-4 * scale + 1e-3, (dw.cpu() - dw_ref).abs().max().item()
     assert (db.cpu() - db_ref).abs().max().item() <= 2e-4 * db_ref.abs().max().item() + 1e-3
+    if with_res:       # decoder-tail form: both dy W + res and dy W
+        dxs, dxp = torch.empty_like(xd), torch.empty_like(xd)
+        dw3, db3 = torch.empty((N, K), device='cuda'), torch.empty((N,), device='cuda')
+        lib.pw_bwd_residual2(xd, dyd, wd, res.cuda(), dxs, dxp, dw3, db3, M, K, N)
+        assert torch.equal(dxs, dx)
+        torch.testing.assert_close(dxp.float().cpu(), dy.float() @ wb, rtol=2e-2, atol=2e-2 * max(1.0, dx_ref.abs().max().item() / 4))
+        assert (dw3.cpu() - dw_ref).abs().max().item() <= 2e-4 * scale + 1e-3
     # dbias is optional
     dw2 = torch.zeros((N, K), device='cuda')
     lib.pw_bwd(xd, dyd, wd, None, dx, dw2, None, M, K, N)
