@@ -180,6 +180,11 @@ int tcct_conv32_wgrad_strided(const void* x, const void* dy, float* dw, float* d
  * dw OIHW fp32 [32,32,KH,KW] and dbias fp32 [32] (nullable) are overwritten */
 int tcct_conv32_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH,
                       int PW, tcct_stream_t stream);
+/* Fused backward of a dense 3x3 32->32 'same' convolution (autograd of nets/tcct.py:809-810,816,821,892,978): dx = conv(dy, flipped
+ * weights) (+ dskip, nullable), dw [32,32,3,3] += dy (x) x, dbias [32] += sum dy (nullable) with dy read from HBM once.  wp_t = the
+ * input-gradient weight pack (tcct_conv32_pack_weights_both's second half).  dw / dbias are cleared first unless prezeroed. */
+int tcct_conv32_bwd3x3(const void* x, const void* dy, const void* wp_t, const void* dskip, void* dx, float* dw, float* dbias, int N, int H,
+                       int W, tcct_stream_t stream);
 
 /* MFMA pointwise (1x1 conv / nn.Linear) path, bf16 rows [M,K] with K % 32 == 0 (ViT 1x1s and MLPs, FTC tran_x, t32x and
  * aux heads; reference nets/tcct.py:41-43,124,532-546,600,966-997).  w fp32 [N,K] (transposed=0) or [K,N] (transposed=1,

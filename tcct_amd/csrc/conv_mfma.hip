@@ -645,3 +645,270 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
 #undef WG_LAUNCH
     TCCT_LAUNCH_OK();
 }
+
+// ------------------------------------------------------------------------------------------------ fused backward (3x3)
+// Input gradient AND weight gradient of a dense 3x3 32->32 convolution in ONE pass: the two separate kernels each stage a dy tile
+// (k_conv32_mfma on the flipped weights: dy with halo; k_conv32_wgrad: dy interior + x with halo), i.e. dy crosses HBM twice.
+// Here a block of EIGHT waves stages the x halo tile (linear 64-byte pixel rows, transposing reads) and the dy halo tile (80-byte
+// rows: conflict-free b128 fragment reads for the input gradient, transposing reads for the weight gradient) once per 16 x 32 tile;
+// waves 0-3 run the input-gradient MFMA phase + epilogue of k_conv32_mfma, waves 4-7 the weight-gradient phase of k_conv32_wgrad
+// (taps 0-4 / 5-8 on two wave pairs, 16 of the 32 pixel chunks each).  One block per CU (111 KB of LDS), the two roles share each
+// SIMD's matrix pipe (72 + 80 MFMAs per tile and SIMD).  Algorithmic bytes per image pixel: x + dy + dx = 3 x 64 B (4 x 64 B before).
+#define BWD_T 512
+template <int DUMMY>
+__global__ void __launch_bounds__(BWD_T, 1)
+k_conv32_bwd33(const bf16* __restrict__ x, const bf16* __restrict__ dy, const bf16* __restrict__ wp, const bf16* __restrict__ dskip,
+               bf16* __restrict__ dx, float* __restrict__ dw, float* __restrict__ dbias, int N, int H, int W, int tilesH, int tilesW,
+               int ntiles) {
+    constexpr int TH = 16, TW = 32, LH = 18, LW = 34, NPIX = LH * LW, SLOTS = (NPIX * 4 + BWD_T - 1) / BWD_T;      // 5 slots per thread and image
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sW = smem;                              // input-gradient weights [9][32][32] bf16, swizzled rows (k_conv32_mfma)
+    unsigned char* sXl = smem + 9 * 2048;                  // x halo tile, 64 B per pixel
+    unsigned char* sDp = sXl + NPIX * 64;                  // dy halo tile, IPS = 80 B per pixel
+    unsigned char* sS = sDp + NPIX * IPS;                  // epilogue transpose scratch: 4 waves x 1 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    for (int i = tid; i < 9 * 32 * 4; i += BWD_T) {
+        int row = i >> 2, c4 = i & 3;
+        uint4 v = reinterpret_cast<const uint4*>(wp)[i];
+        *reinterpret_cast<uint4*>(sW + row * 64 + ((c4 ^ ((row >> 2) & 3)) << 4)) = v;
+    }
+    const int c = tid & 3;
+    int s_rc[SLOTS];
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        int pl = (tid >> 2) + j * (BWD_T / 4);
+        bool in = pl < NPIX;
+        int lr = in ? pl / LW : 0x3fff, lc = in ? pl - (pl / LW) * LW : 0;
+        s_rc[j] = (lr << 16) | lc;
+    }
+    const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
+    u32x4 px[SLOTS], pd[SLOTS];
+    auto prefetch = [&](int tile) {                        // x and dy have the same geometry: one offset serves both loads
+        const int tw = tile % tilesW;
+        const int t2 = tile / tilesW;
+        const int th = t2 % tilesH;
+        const int n = t2 / tilesH;
+        const int hb = th * TH - 1, wb = tw * TW - 1;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * H * W * 32), 0, img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)n * H * W * 32), 0, img_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            const int hi = hb + (s_rc[j] >> 16), wi = wb + (s_rc[j] & 0xffff);
+            const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+            const uint32_t off = ok ? (uint32_t)((hi * W + wi) * 64 + c * 16) : OOB_OFF;
+            px[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+            pd[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, off, 0, 0);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            const int lr = s_rc[j] >> 16, lc = s_rc[j] & 0xffff;
+            if (lr != 0x3fff) {
+                const int p = lr * LW + lc;
+                *reinterpret_cast<u32x4*>(sXl + p * 64 + c * 16) = px[j];
+                *reinterpret_cast<u32x4*>(sDp + p * IPS + c * 16) = pd[j];
+            }
+        }
+    };
+    // ---- role state.  Input gradient (waves 0-3): fragment bases as in k_conv32_mfma (SQ tiles: M-tile = one tile row of 32 pixels)
+    const int wsw = (r >> 2) & 3;
+    const unsigned char* wA0 = sW + r * 64 + ((hh ^ wsw) << 4);
+    const unsigned char* wA1 = sW + r * 64 + (((2 + hh) ^ wsw) << 4);
+    const int dwave = wave & 3;
+    const unsigned char* xB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xB[t] = sDp + ((dwave * 4 + t) * LW + r) * IPS + hh * 16;
+    // Weight gradient (waves 4-7): tap group tg (taps 5 tg .. 5 tg + 4), chunk parity wi
+    const int tg = (wave >> 1) & 1, wi = wave & 1;
+    const int tap0 = tg * 5;
+    int poff[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int tap = tap0 + t, ky = tap / 3, kx = tap - ky * 3;
+        poff[t] = tap < 9 ? (ky * LW + kx) * 64 : 0;
+    }
+    // ONE set of five accumulators per wave: the weight-gradient waves keep their taps in it for the whole kernel, the input-gradient
+    // waves re-use the first four as the per-tile output accumulators (a wave never changes role)
+    f32x16 accw[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) accw[t][k] = 0.f;
+    float bsum = 0.f;
+    const int li = lane & 15, lq = li >> 2, lpp = li & 3, lg = lane >> 4;
+    const unsigned char* lbX = sXl + (8 * (lg >> 1) + lq) * 64 + (16 * (lg & 1) + 4 * lpp) * 2;
+    const unsigned char* lbD = sDp + (8 * (lg >> 1) + lq) * IPS + (16 * (lg & 1) + 4 * lpp) * 2;
+    auto tr8 = [&](const unsigned char* p, int stride) {   // 16 consecutive pixels from p: 8 pixel values of channel lane & 31
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * stride));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        prefetch(tile);
+        __syncthreads();
+        stage();
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+    }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int tw = tile % tilesW;
+        const int t2 = tile / tilesW;
+        const int th = t2 % tilesH;
+        const int n = t2 / tilesH;
+        const int h0 = th * TH, w0 = tw * TW;
+        f32x16* const acc = accw;
+        if (wave < 4) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+            struct Frag { bf16x8 a, b[4]; };
+            auto load_stage = [&](Frag& f, int ky, int kx, int half) {
+                f.a = *reinterpret_cast<const bf16x8*>((half ? wA1 : wA0) + (ky * 3 + kx) * 2048);
+                const int po = (ky * LW + kx) * IPS + half * 32;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) f.b[t] = *reinterpret_cast<const bf16x8*>(xB[t] + po);
+            };
+            Frag f[2];
+            load_stage(f[0], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 18; ++k) {
+                if (k + 1 < 18) load_stage(f[(k + 1) & 1], ((k + 1) >> 1) / 3, ((k + 1) >> 1) % 3, (k + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[k & 1].a, f[k & 1].b[t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // 32 chunks of 16 pixels (tile row a = ch / 2, half s = ch % 2); this wave takes the 16 chunks of its parity.  The fragments
+            // of the next chunk are read while the MFMAs of the current one run (two named buffers; sched_barrier pins the order):
+            // unpipelined, every chunk exposed one LDS latency in front of its five MFMAs.
+            struct WF { bf16x8 a, b[5]; };
+            auto load_chunk = [&](WF& f, int ch) {
+                const int a = ch >> 1, s16 = (ch & 1) * 16;
+                f.a = tr8(lbD + ((a + 1) * LW + s16 + 1) * IPS, IPS);
+                const unsigned char* pxb = lbX + (a * LW + s16) * 64;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) f.b[t] = tr8(pxb + poff[t], 64);
+            };
+            auto mma_chunk = [&](const WF& f) {
+                if (tg == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum += (float)f.a[j];
+                }
+#pragma unroll
+                for (int t = 0; t < 5; ++t)
+                    if (tap0 + t < 9) accw[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a, f.b[t], accw[t], 0, 0, 0);
+            };
+            WF f0, f1;
+            load_chunk(f0, wi);
+            for (int ch = wi; ch < 32; ch += 4) {
+                load_chunk(f1, ch + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_chunk(f0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ch + 4 < 32) load_chunk(f0, ch + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_chunk(f1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                                    // both roles are done with the staged tile
+        if (tile + (int)gridDim.x < ntiles) stage();
+        if (tile + 2 * (int)gridDim.x < ntiles) prefetch(tile + 2 * gridDim.x);
+        if (wave < 4) {                                     // input-gradient epilogue (k_conv32_mfma's, + the second consumer's gradient)
+            const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void*)(dx + (int64_t)n * H * W * 32), 0, img_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)((dskip ? dskip : dx) + (int64_t)n * H * W * 32), 0, img_bytes, 0x00020000);
+            unsigned char* sc = sS + dwave * 1024;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int a = dwave * 4 + t;
+                uint2 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o[q].x = pack_bf16x2(acc[t][4 * q], acc[t][4 * q + 1]);
+                    o[q].y = pack_bf16x2(acc[t][4 * q + 2], acc[t][4 * q + 3]);
+                }
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    if ((r >> 4) == h2) {
+                        const int rr = r & 15, fsw = (rr >> 1) & 3;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(sc + rr * 64 + ((q ^ fsw) << 4) + hh * 8) = o[q];
+                    }
+                    wave_lds_fence();
+                    const int p16 = lane >> 2, cch = lane & 3;
+                    u32x4 ov = *reinterpret_cast<const u32x4*>(sc + p16 * 64 + ((cch ^ ((p16 >> 1) & 3)) << 4));
+                    const int ho = h0 + a, wo = w0 + 16 * h2 + p16;
+                    const uint32_t off = (ho < H && wo < W) ? (uint32_t)((ho * W + wo) * 64 + cch * 16) : OOB_OFF;
+                    if (dskip) {                            // block-uniform
+                        const u32x4 sv = __builtin_amdgcn_raw_buffer_load_b128(rsk, off, 0, 0);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            ov[k] = pack_bf16x2(__uint_as_float(ov[k] << 16) + __uint_as_float(sv[k] << 16),
+                                                __uint_as_float(ov[k] & 0xffff0000u) + __uint_as_float(sv[k] & 0xffff0000u));
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, ws, off, 0, 0);
+                    wave_lds_fence();
+                }
+            }
+        }
+        __syncthreads();                                    // the next tile's images are complete
+    }
+    // ---- weight-gradient reduction: the two waves of a tap group take turns in LDS, then OIHW-linear atomics by the whole block
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sXl);             // [9][32][32] floats = 36 KB over the (dead) x image
+    for (int turn = 0; turn < 2; ++turn) {
+        if (wave >= 4 && wi == turn) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int tap = tap0 + t;
+                if (tap < 9) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
+                        float* dst = &red[tap * 1024 + co * 32 + r];
+                        *dst = turn == 0 ? accw[t][k] : *dst + accw[t][k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < 9 * 1024; i += BWD_T) {
+        const int tap = i % 9, cc = i / 9;                  // cc = co*32 + ci: consecutive lanes -> consecutive addresses
+        atomicAdd(&dw[(int64_t)cc * 9 + tap], red[tap * 1024 + cc]);
+    }
+    if (dbias && wave >= 4 && tg == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lane < 32) atomicAdd(&dbias[r], bsum);
+    }
+}
+
+/* Fused backward of a dense 3x3 32->32 'same' convolution (bf16 NHWC [N,H,W,32]): dx = conv(dy, flipped weights) (+ dskip, nullable:
+ * the gradient that reaches x through its other consumers), dw OIHW fp32 [32,32,3,3] += dy (x) x, dbias [32] += sum dy (nullable).
+ * wp_t: the input-gradient pack of the weights (second half of tcct_conv32_pack_weights_both, or pack_weights(transposed=1)).
+ * dw / dbias are cleared first unless tcct_set_outputs_prezeroed(1). */
+extern "C" int tcct_conv32_bwd3x3(const void* x, const void* dy, const void* wp_t, const void* dskip, void* dx, float* dw, float* dbias,
+                                  int N, int H, int W, tcct_stream_t stream) {
+    TCCT_CHECK((int64_t)H * W * 64 < (1LL << 31), "conv32_bwd3x3: image exceeds the 2 GiB buffer-descriptor range");
+    TCCT_CHECK(dskip != dx, "conv32_bwd3x3: dskip must be a separate tensor");
+    hipStream_t st = (hipStream_t)stream;
+    if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * 9 * 1024, st) != hipSuccess) { tcct_set_error("conv32_bwd3x3: memset failed"); return -2; }
+    if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_bwd3x3: memset failed"); return -2; }
+    const int tilesH = (H + 15) / 16, tilesW = (W + 31) / 32;
+    const int64_t nt = (int64_t)N * tilesH * tilesW;
+    TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32_bwd3x3: bad tile count");
+    const size_t lds = 9 * 2048 + (size_t)18 * 34 * 64 + (size_t)18 * 34 * IPS + 4096;
+    const int grid = (int)(nt < 256 ? nt : 256);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_bwd33<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((k_conv32_bwd33<0>), dim3(grid), dim3(BWD_T), lds, st, (const bf16*)x, (const bf16*)dy, (const bf16*)wp_t, (const bf16*)dskip,
+                       (bf16*)dx, dw, dbias, N, H, W, tilesH, tilesW, (int)nt);
+    TCCT_LAUNCH_OK();
+}

@@ -263,6 +263,11 @@ def _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, trans
                 wp = torch.empty_like(wp)
 
 
+# Fused 3x3 conv32 backward (tcct_conv32_bwd3x3): correct and tested, but OFF by default -- alone it takes 0.49 ms against 0.23 + 0.31 ms for
+# the separate input-gradient / weight-gradient kernels at level 0, and inside the step it gains nothing (29.3 vs 29.3 ms, same box): the
+# separate weight gradient runs on the side stream beside the input-gradient chain, the fused kernel sits on the critical path and is
+# bound by the latency of its one 8-wave block per CU (111 KB of LDS), not by HBM.  TCCT_FUSED_CONV_BWD=1 enables it.
+FUSED_CONV_BWD = os.environ.get('TCCT_FUSED_CONV_BWD', '0') == '1'
 FUSED_PW_BWD = os.environ.get('TCCT_FUSED_PW_BWD', '1') != '0'        # =0: separate input-gradient / weight-gradient kernels (A/B timing)
 
 
@@ -347,6 +352,18 @@ class _Conv2d(torch.autograd.Function):
             dw = _grad_out(wsrc, tuple(w.shape))
             db = _grad_out(bsrc) if has_bias else None
             lib.pw_bwd(x, dy, w, dskip, dx, dw, db, N * H * W, Cin, Cout)
+            return dx, _ret(dw, wsrc), _ret(db, bsrc), None, None, None, None, None, None
+        if (FUSED_CONV_BWD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and KH == 3 and KW == 3 and dy.dtype == torch.bfloat16
+                and _mfma32_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw) and H * W * 64 < 2 ** 31):
+            # dense 3x3 32->32: input gradient (+ a second consumer's gradient) and weight / bias gradient from ONE staging of dy
+            wp = getattr(ctx, 'wp_t', None)
+            if wp is None:
+                wp = torch.empty(9 * 1024, device=x.device, dtype=torch.bfloat16)
+                lib.conv32_pack_weights(w, wp, 3, 3, 1)
+            dx = torch.empty_like(x)
+            dw = _grad_out(wsrc, tuple(w.shape))
+            db = _grad_out(bsrc) if has_bias else None
+            lib.conv32_bwd3x3(x, dy, wp, dskip, dx, dw, db, N, H, W)
             return dx, _ret(dw, wsrc), _ret(db, bsrc), None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             if stride != 1 or Cin != Cin_w:

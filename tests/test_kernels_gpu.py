@@ -346,6 +346,36 @@ def test_fpl_matches_oracle():
     torch.testing.assert_close(nchw(fd.grad), feats.grad, rtol=1e-4, atol=1e-9)
 
 
+@pytest.mark.parametrize('shape', [(2, 17, 23), (1, 16, 32), (2, 40, 70), (1, 50, 69), (3, 33, 96)])
+@pytest.mark.parametrize('with_skip', [False, True])
+def test_conv32_bwd3x3_fused(shape, with_skip):
+    """tcct_conv32_bwd3x3: input gradient (+ second consumer's gradient), weight gradient and bias gradient of a dense 3x3 32->32
+    convolution from one staging of dy, against torch autograd on the same bf16-rounded operands; ragged tiles in both directions"""
+    from tcct_amd._lib import lib
+    N, H, W = shape
+    g = torch.Generator().manual_seed(N * 100 + H + W)
+    x = torch.randn(N, 32, H, W, generator=g).bfloat16().float().requires_grad_(True)
+    w = (torch.randn(32, 32, 3, 3, generator=g) / 17.0)
+    wb = w.bfloat16().float().requires_grad_(True)
+    b = torch.zeros(32, requires_grad=True)
+    dy = torch.randn(N, 32, H, W, generator=g).bfloat16().float()
+    skip = torch.randn(N, 32, H, W, generator=g).bfloat16().float() if with_skip else None
+    F.conv2d(x, wb, b, 1, 1).backward(dy)
+    dx_ref = x.grad + (skip if with_skip else 0)
+    xd, dyd = nhwc(x.detach(), torch.bfloat16), nhwc(dy, torch.bfloat16)
+    wd = w.cuda()
+    wp = torch.empty(9 * 1024, device='cuda', dtype=torch.bfloat16)
+    lib.conv32_pack_weights(wd, wp, 3, 3, 1)
+    dx = torch.empty_like(xd)
+    dw = torch.full((32, 32, 3, 3), 5.0, device='cuda')
+    db = torch.full((32,), 5.0, device='cuda')
+    lib.conv32_bwd3x3(xd, dyd, wp, nhwc(skip, torch.bfloat16) if with_skip else None, dx, dw, db, N, H, W)
+    torch.testing.assert_close(nchw(dx), dx_ref, rtol=2e-2, atol=2e-2 * max(1.0, dx_ref.abs().max().item() / 4))
+    scale = wb.grad.abs().max().item()
+    assert (dw.cpu() - wb.grad).abs().max().item() <= 3e-4 * scale + 1e-3, ((dw.cpu() - wb.grad).abs().max().item(), scale)
+    assert (db.cpu() - b.grad).abs().max().item() <= 3e-4 * b.grad.abs().max().item() + 1e-3
+
+
 @pytest.mark.parametrize('K,N', [(32, 32), (64, 64), (96, 96), (128, 128), (128, 96), (96, 32), (32, 128), (64, 128), (128, 32)])
 @pytest.mark.parametrize('M,with_res', [(1000, False), (128 * 3 + 17, True), (70000, False)])
 def test_pw_bwd_fused(K, N, M, with_res):

@@ -112,7 +112,7 @@ def dw_bench():
         print(f'dw {N}x{H}x{W}x{C} s{st}: fwd {m1:.3f} ms {(gx + gy) / m1 * 1e3:.0f} GB/s | dgrad {m2:.3f} ms {(gx + gy) / m2 * 1e3:.0f} GB/s | wgrad {m3:.3f} ms {(gx + gy) / m3 * 1e3:.0f} GB/s')
 
 
-if __name__ == '__main__':
+if __name__ == "__main__" and not ({"pw", "bwd"} & set(sys.argv[1:])):
     if 'dw' in sys.argv[1:]:
         dw_bench()
         sys.exit(0)
@@ -142,3 +142,28 @@ def pw_bench():
 
 if 'pw' in sys.argv[1:]:
     pw_bench()
+
+
+def bwd_bench():
+    """fused conv32 3x3 backward vs the separate input-gradient + weight-gradient kernels; fused pointwise backward vs its parts"""
+    x = torch.randn(B, H, W, 32, device='cuda').to(dt); dy = torch.randn(B, H, W, 32, device='cuda').to(dt)
+    w = torch.randn(32, 32, 3, 3, device='cuda') * 0.05
+    wp = torch.empty(9 * 1024, device='cuda', dtype=dt); lib.conv32_pack_weights(w, wp, 3, 3, 1)
+    dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty(32, device='cuda')
+    t1 = timeit(lambda: lib.conv32_fwd(dy, wp, None, dx, B, H, W, 3, 3, 1, 1))
+    t2 = timeit(lambda: lib.conv32_wgrad(x, dy, dw, db, B, H, W, 3, 3, 1, 1))
+    t3 = timeit(lambda: lib.conv32_bwd3x3(x, dy, wp, None, dx, dw, db, B, H, W))
+    gb = x.numel() * 2 / 1e9
+    print(f'conv32 3x3 @L0: dgrad {t1:.3f} + wgrad {t2:.3f} = {t1 + t2:.3f} ms | fused {t3:.3f} ms ({3 * gb / t3 * 1e3:.0f} GB/s algorithmic)')
+    for (M, K, N) in [(8 * 400 * 552, 64, 64), (8 * 400 * 552, 128, 96), (8 * 400 * 552, 96, 32), (8 * 800 * 1104, 32, 32), (8 * 200 * 276, 96, 96), (8 * 200 * 276, 128, 128)]:
+        x = torch.randn(M, K, device='cuda').to(dt); dy = torch.randn(M, N, device='cuda').to(dt)
+        w = torch.randn(N, K, device='cuda') * 0.1
+        dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty(N, device='cuda')
+        t1 = timeit(lambda: lib.pw_fwd(dy, w, None, dx, M, N, K, 1, 1))
+        t2 = timeit(lambda: lib.pw_wgrad(x, dy, dw, db, M, K, N))
+        t3 = timeit(lambda: lib.pw_bwd(x, dy, w, None, dx, dw, db, M, K, N))
+        print(f'pw M={M} K={K} N={N}: dgrad {t1:.3f} + wgrad {t2:.3f} = {t1 + t2:.3f} ms | fused {t3:.3f} ms ({M * (2 * K + N) * 2 / 1e9 / t3 * 1e3:.0f} GB/s algorithmic)')
+
+
+if 'bwd' in sys.argv[1:]:
+    bwd_bench()
