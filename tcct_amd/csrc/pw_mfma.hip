@@ -7,6 +7,7 @@
 // wgrad: dW[co][ci] = sum_p dy[p][co] x[p][ci] with both tiles staged pixel-major in LDS and transposed on read by
 //   ds_read_b64_tr_b16 (same scheme as conv_mfma.hip).
 #include "common.h"
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -236,6 +237,14 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
 static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                        int out_dtype, double* stats, int stat_pre, tcct_stream_t stream, const float* aff = nullptr, int aff_pre = 0,
                        int aff_post = 0, PwSplit sp = PwSplit{nullptr, 0, nullptr, 0, nullptr, nullptr, 1, nullptr});
+static bool pw_fwd2_ok(int64_t M, int K, int N, int K1, bool has_x2);
+static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
+                          int stat_pre, tcct_stream_t stream);
+static bool pw_fwd2_enabled() {         // TCCT_PW_FWD2=0: the direct-from-global forward kernel for every shape (A/B timing)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("TCCT_PW_FWD2"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on == 1;
+}
 extern "C" int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                            int out_dtype, tcct_stream_t stream) {
     return pw_fwd_impl(x, w, bias, y, M, K, N, transposed, out_dtype, nullptr, 0, stream);
@@ -283,6 +292,9 @@ extern "C" int tcct_pw_fwd_affine(const void* x, const float* w, const float* bi
 }
 static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                        int out_dtype, double* stats, int stat_pre, tcct_stream_t stream, const float* aff, int aff_pre, int aff_post, PwSplit sp) {
+    if (!transposed && out_dtype == TCCT_BF16 && !aff && !aff_pre && !aff_post && !sp.res && !sp.y2 && !sp.yplain && pw_fwd2_enabled()
+        && pw_fwd2_ok(M, K, N, sp.K1, sp.x2 != nullptr) && (!stats || N <= 128))
+        return pw_fwd2_launch(x, sp.x2, w, bias, y, M, K, N, stats, stat_pre, stream);
     if (sp.x2) TCCT_CHECK(sp.K1 % 32 == 0 && sp.K1 > 0 && sp.K1 < K, "pw_fwd_cat2: K1=%d must be a multiple of 32 inside (0, K)", sp.K1);
     if (sp.y2) TCCT_CHECK(sp.N1 % 32 == 0 && sp.N1 > 0 && sp.N1 < N && N % 32 == 0 && out_dtype == TCCT_BF16, "pw_dgrad_split2: N1=%d must be a multiple of 32 inside (0, N), bf16 output", sp.N1);
     TCCT_CHECK(K % 32 == 0 && K >= 32 && K <= 512, "pw_fwd: K=%d must be a multiple of 32 (<=512)", K);
@@ -758,6 +770,178 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
     switch (NT) { case 1: BLK(1) break; case 2: BLK(2) break; case 3: BLK(3) break; default: BLK(4) break; }
 #undef BLK
 #undef BL
+    TCCT_LAUNCH_OK();
+}
+
+// ------------------------------------------------------------------------------------------------ forward, tile-staged
+// Y[M,N] = X[M,K] W^T + bias for K, N <= 128 with the activations staged through LDS: k_pw_fwd reads its B fragments straight from
+// global memory, 16 bytes per lane in the MFMA operand layout, i.e. every wave instruction touches 32 different rows and 25 % (K = 64)
+// or 12.5 % (K = 128) of each 128-byte line -- 3.8 TB/s where the K = 32 case (whole rows per instruction pair) reaches 5.7.  Here a
+// 128-pixel tile is ONE contiguous span of memory, loaded fully coalesced (thread i takes bytes [16 i, 16 i + 16) of it), written to
+// LDS rows of 2K+16 bytes (conflict-free ds_read_b128 for the fragment layout) and prefetched one tile ahead; wave w multiplies pixels
+// 32w..32w+31 against all N-tiles.  Same tile pipeline as k_pw_bwd / k_conv32_mfma (staging wait behind the MFMA phase, stores after
+// the next prefetch).  SPLIT: the rows are the concatenation [x | x2] of two tensors of K/2 channels each (MHCA_stage.aggregate).
+template <int NT, int KT, bool STATS, bool SPLIT>
+__global__ void __launch_bounds__(PWB, 2)
+k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* __restrict__ w, const float* __restrict__ bias,
+          bf16* __restrict__ y, int64_t M, double* __restrict__ stats, int stat_pre) {
+    constexpr int K = 32 * KT, N = 32 * NT;
+    constexpr int SX = 2 * K + 16, SW = 2 * K + 16;
+    constexpr int XS = K / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;
+    unsigned char* sW = sX + PB_P * SX;
+    float* sB = reinterpret_cast<float*>(sW + N * SW);
+    unsigned char* sS = reinterpret_cast<unsigned char*>(sB + N);       // per-wave epilogue transpose scratch: 32 px x 80 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    for (int i = tid; i < N * (K / 8); i += PWB) {
+        const int n = i / (K / 8), c8 = i - n * (K / 8);
+        const float4 a = *reinterpret_cast<const float4*>(w + (int64_t)n * K + c8 * 8);
+        const float4 b = *reinterpret_cast<const float4*>(w + (int64_t)n * K + c8 * 8 + 4);
+        uint4 o;
+        o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(a.z, a.w); o.z = pack_bf16x2(b.x, b.y); o.w = pack_bf16x2(b.z, b.w);
+        *reinterpret_cast<uint4*>(sW + n * SW + c8 * 16) = o;
+    }
+    if (tid < N) sB[tid] = bias ? bias[tid] : 0.f;
+    float ss[STATS ? NT : 1][8], sq[STATS ? NT : 1][8];
+#pragma unroll
+    for (int a = 0; a < (STATS ? NT : 1); ++a)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ss[a][k] = sq[a][k] = 0.f;
+    const int64_t tiles = (M + PB_P - 1) / PB_P;
+    constexpr int KS = SPLIT ? K / 2 : K;                  // channels per source tensor
+    const uint32_t xbytes = (uint32_t)(M * KS * 2), ybytes = (uint32_t)(M * N * 2);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(SPLIT ? x2 : x), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, ybytes, 0x00020000);
+    u32x4 px[XS];
+    auto prefetch = [&](int64_t tile) {
+        const uint32_t bx = (uint32_t)(tile * PB_P * KS * 2);
+#pragma unroll
+        for (int j = 0; j < XS; ++j) {
+            if (SPLIT && j >= XS / 2) px[j] = __builtin_amdgcn_raw_buffer_load_b128(rx2, bx + (uint32_t)(tid + (j - XS / 2) * PWB) * 16u, 0, 0);
+            else px[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, bx + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < XS; ++j) {
+            const int jj = (SPLIT && j >= XS / 2) ? j - XS / 2 : j;
+            const int q = tid + jj * PWB, p = q / (KS / 8), c = q - p * (KS / 8);
+            *reinterpret_cast<u32x4*>(sX + p * SX + ((SPLIT && j >= XS / 2) ? KS * 2 : 0) + c * 16) = px[j];
+        }
+    };
+    const unsigned char* bB = sX + (32 * wave + r) * SX + hh * 16;
+    int64_t tile = blockIdx.x;
+    if (tile < tiles) {
+        prefetch(tile);
+        __syncthreads();
+        stage();
+        prefetch(tile + gridDim.x);                 // beyond the last tile every row is out of range: zeros, never used
+    }
+    __syncthreads();
+    for (; tile < tiles; tile += gridDim.x) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[nt][k] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2 * KT; ++st) {
+            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(bB + st * 32);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(sW + (nt * 32 + r) * SW + st * 32 + hh * 16);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (tile + (int64_t)gridDim.x < tiles) stage();
+        prefetch(tile + 2 * (int64_t)gridDim.x);
+        unsigned char* sc = sS + wave * 2560;
+        const int64_t m0 = tile * PB_P + 32 * wave;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(sB + nt * 32 + 8 * q + 4 * hh);
+                uint2 o;
+                o.x = pack_bf16x2(acc[nt][4 * q] + bq.x, acc[nt][4 * q + 1] + bq.y);
+                o.y = pack_bf16x2(acc[nt][4 * q + 2] + bq.z, acc[nt][4 * q + 3] + bq.w);
+                *reinterpret_cast<uint2*>(sc + r * 80 + (8 * q + 4 * hh) * 2) = o;
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int p = (lane >> 2) + 16 * h2, cch = lane & 3;
+                const u32x4 o = *reinterpret_cast<const u32x4*>(sc + p * 80 + cch * 16);
+                const int64_t mm = m0 + p;
+                const bool inb = mm < M;
+                __builtin_amdgcn_raw_buffer_store_b128(o, ro, inb ? (uint32_t)((mm * N + nt * 32 + cch * 8) * 2) : 0x80000000u, 0, 0);
+                if (STATS) {
+                    if (inb) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float u0 = act_fwd(stat_pre, __uint_as_float(o[k] << 16)), u1 = act_fwd(stat_pre, __uint_as_float(o[k] & 0xffff0000u));
+                            ss[nt][2 * k] += u0; sq[nt][2 * k] += u0 * u0; ss[nt][2 * k + 1] += u1; sq[nt][2 * k + 1] += u1 * u1;
+                        }
+                    }
+                }
+            }
+            wave_lds_fence();
+        }
+        __syncthreads();
+    }
+    if (STATS) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][N] (the staged tile is dead)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {       // lanes with equal (lane & 3) hold different pixels of channels 8*(lane&3)+k
+                float a = ss[nt][k], b = sq[nt][k];
+#pragma unroll
+                for (int o = 32; o > 2; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (lane < 4) {
+                    red[wave * 2 * N + nt * 32 + 8 * lane + k] = a;
+                    red[wave * 2 * N + N + nt * 32 + 8 * lane + k] = b;
+                }
+            }
+        __syncthreads();
+        for (int i2 = tid; i2 < N; i2 += PWB) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) { a += (double)red[wv * 2 * N + i2]; b += (double)red[wv * 2 * N + N + i2]; }
+            atomicAdd(&stats[i2], a); atomicAdd(&stats[N + i2], b);
+        }
+    }
+}
+
+static bool pw_fwd2_ok(int64_t M, int K, int N, int K1, bool has_x2) {
+    if (K % 32 || N % 32 || K < 64 || K > 128 || N < 32 || N > 128) return false;      // K = 32 already streams whole rows in k_pw_fwd
+    if (M * (int64_t)(K > N ? K : N) * 2 >= (1LL << 31)) return false;
+    if (has_x2 && !(K == 128 && K1 == 64)) return false;
+    return true;
+}
+static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
+                          int stat_pre, tcct_stream_t stream) {
+    const int NT = N / 32, KT = K / 32;
+    const size_t lds = (size_t)PB_P * (2 * K + 16) + (size_t)N * (2 * K + 16) + (size_t)N * 4 + 4 * 2560;
+    const int64_t tiles = (M + PB_P - 1) / PB_P;
+    int per_cu = (int)((160 * 1024) / (lds + 256));
+    if (per_cu > 2) per_cu = 2;
+    int64_t gx = 256 * per_cu;
+    if (gx > tiles) gx = tiles;
+    hipStream_t st = (hipStream_t)stream;
+#define F2(NTV, KTV, SV, PV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd2<NTV, KTV, SV, PV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_fwd2<NTV, KTV, SV, PV>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)x2, w, bias, (bf16*)y, M, stats, stat_pre); }
+#define F2K(NTV, SV) switch (KT) { case 2: F2(NTV, 2, SV, false) break; case 3: F2(NTV, 3, SV, false) break; default: if (x2) F2(NTV, 4, SV, true) else F2(NTV, 4, SV, false) break; }
+#define F2N(SV) switch (NT) { case 1: F2K(1, SV) break; case 2: F2K(2, SV) break; case 3: F2K(3, SV) break; default: F2K(4, SV) break; }
+    if (stats) { F2N(true) } else { F2N(false) }
+#undef F2N
+#undef F2K
+#undef F2
     TCCT_LAUNCH_OK();
 }
 
