@@ -198,6 +198,10 @@ int tcct_pw_wgrad(const void* x, const void* dy, float* dw, float* dbias, int64_
 int tcct_pw_bwd(const void* x, const void* dy, const float* w, const void* res, void* dx, float* dw, float* dbias, int64_t M, int K, int N,
                 tcct_stream_t stream);
 /* ... writing both dx_sum = dy W + res and dx_plain = dy W (MPUpBlock tail + the `x_i + y_i` of FTC.forward, nets/tcct.py:908-914,1028-1031) */
+/* ... over a concatenation x = [x1 | x2] (two tensors of 64 channels), dx = [dx1 | dx2]: backward of tcct_pw_fwd_cat2 (MHCA_stage.aggregate,
+ * nets/tcct.py:600-616), no bias */
+int tcct_pw_bwd_cat2(const void* x1, const void* x2, const void* dy, const float* w, void* dx1, void* dx2, float* dw, int64_t M, int K, int N,
+                     tcct_stream_t stream);
 int tcct_pw_bwd_residual2(const void* x, const void* dy, const float* w, const void* res, void* dx_sum, void* dx_plain, float* dw, float* dbias,
                           int64_t M, int K, int N, tcct_stream_t stream);
 /* the same for an N-column slab of a wider output: dy rows have stride ldy elements (multiple of 8) and dy / dw / dbias point at the slab

@@ -238,8 +238,9 @@ static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y
                        int out_dtype, double* stats, int stat_pre, tcct_stream_t stream, const float* aff = nullptr, int aff_pre = 0,
                        int aff_post = 0, PwSplit sp = PwSplit{nullptr, 0, nullptr, 0, nullptr, nullptr, 1, nullptr});
 static bool pw_fwd2_ok(int64_t M, int K, int N, int K1, bool has_x2);
-static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
-                          int stat_pre, tcct_stream_t stream);
+struct PwRes;
+static int pw_fwd2_route(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
+                         int stat_pre, tcct_stream_t stream, const bf16* res, const float* rscale, int64_t per_sample, bf16* yplain);
 static bool pw_fwd2_enabled() {         // TCCT_PW_FWD2=0: the direct-from-global forward kernel for every shape (A/B timing)
     static int on = -1;
     if (on < 0) { const char* e = getenv("TCCT_PW_FWD2"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -292,9 +293,9 @@ extern "C" int tcct_pw_fwd_affine(const void* x, const float* w, const float* bi
 }
 static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                        int out_dtype, double* stats, int stat_pre, tcct_stream_t stream, const float* aff, int aff_pre, int aff_post, PwSplit sp) {
-    if (!transposed && out_dtype == TCCT_BF16 && !aff && !aff_pre && !aff_post && !sp.res && !sp.y2 && !sp.yplain && pw_fwd2_enabled()
-        && pw_fwd2_ok(M, K, N, sp.K1, sp.x2 != nullptr) && (!stats || N <= 128))
-        return pw_fwd2_launch(x, sp.x2, w, bias, y, M, K, N, stats, stat_pre, stream);
+    if (!transposed && out_dtype == TCCT_BF16 && !aff && !aff_pre && !aff_post && !sp.y2 && pw_fwd2_enabled()
+        && pw_fwd2_ok(M, K, N, sp.K1, sp.x2 != nullptr) && (!stats || N <= 128) && !(sp.res && (sp.x2 || stats)))
+        return pw_fwd2_route(x, sp.x2, w, bias, y, M, K, N, stats, stat_pre, stream, sp.res, sp.rscale, sp.per_sample, sp.yplain);
     if (sp.x2) TCCT_CHECK(sp.K1 % 32 == 0 && sp.K1 > 0 && sp.K1 < K, "pw_fwd_cat2: K1=%d must be a multiple of 32 inside (0, K)", sp.K1);
     if (sp.y2) TCCT_CHECK(sp.N1 % 32 == 0 && sp.N1 > 0 && sp.N1 < N && N % 32 == 0 && out_dtype == TCCT_BF16, "pw_dgrad_split2: N1=%d must be a multiple of 32 inside (0, N), bf16 output", sp.N1);
     TCCT_CHECK(K % 32 == 0 && K >= 32 && K <= 512, "pw_fwd: K=%d must be a multiple of 32 (<=512)", K);
@@ -567,7 +568,9 @@ static int pw_wgrad_impl(const void* x, const void* x2, int K1, const void* dy, 
 // rows.  Same tile pipeline as k_conv32_mfma: the staging wait sits behind the MFMA phase, the dx stores of tile t are issued after
 // the loads of tile t+2.  Algorithmic bytes: M (2K + N) 2 B against M (2K + 2N) 2 B (or more) for the two-kernel form.
 #define PB_P 128
-template <int NT, int KT>
+// SPLIT: x = [x | x2] and dx = [dx | dx2] are two tensors of K/2 channels each (the aggregate convolution over a concatenation,
+// MHCA_stage, reference nets/tcct.py:600-616): no concat / split passes; x2 / dx2 then travel in the res / dx_plain arguments.
+template <int NT, int KT, bool SPLIT = false>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ w, const bf16* __restrict__ res,
          bf16* __restrict__ dx, bf16* __restrict__ dx_plain, float* __restrict__ dw, float* __restrict__ dbias, int64_t M) {
@@ -596,7 +599,8 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
 #pragma unroll
     for (int a = 0; a < (NT * KT + 3) / 4; ++a) bsum[a] = 0.f;
     const int64_t tiles = (M + PB_P - 1) / PB_P;
-    const uint32_t xbytes = (uint32_t)(M * K * 2), dbytes = (uint32_t)(M * N * 2);
+    constexpr int KS = SPLIT ? K / 2 : K;                   // channels per x / dx tensor
+    const uint32_t xbytes = (uint32_t)(M * KS * 2), dbytes = (uint32_t)(M * N * 2);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(res ? res : x), 0, xbytes, 0x00020000);
@@ -606,17 +610,21 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
     // a tile's rows are one contiguous span of memory: slot i of a thread = bytes [16 (tid + 256 i), +16) of it (fully coalesced);
     // rows beyond M fall outside the descriptor and read as zeros
     auto prefetch = [&](int64_t tile) {
-        const uint32_t bx = (uint32_t)(tile * PB_P * K * 2), bd = (uint32_t)(tile * PB_P * N * 2);
+        const uint32_t bx = (uint32_t)(tile * PB_P * KS * 2), bd = (uint32_t)(tile * PB_P * N * 2);
 #pragma unroll
-        for (int j = 0; j < XS; ++j) px[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, bx + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
+        for (int j = 0; j < XS; ++j) {
+            if (SPLIT && j >= XS / 2) px[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, bx + (uint32_t)(tid + (j - XS / 2) * PWB) * 16u, 0, 0);      // x2
+            else px[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, bx + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < DS; ++j) pd[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, bd + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
     };
     auto stage = [&]() {
 #pragma unroll
         for (int j = 0; j < XS; ++j) {
-            const int q = tid + j * PWB, p = q / (K / 8), c = q - p * (K / 8);
-            *reinterpret_cast<u32x4*>(sX + p * SX + c * 16) = px[j];
+            const int jj = (SPLIT && j >= XS / 2) ? j - XS / 2 : j;
+            const int q = tid + jj * PWB, p = q / (KS / 8), c = q - p * (KS / 8);
+            *reinterpret_cast<u32x4*>(sX + p * SX + ((SPLIT && j >= XS / 2) ? KS * 2 : 0) + c * 16) = px[j];
         }
 #pragma unroll
         for (int j = 0; j < DS; ++j) {
@@ -699,6 +707,11 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
                 const int p = (lane >> 2) + 16 * h2, cch = lane & 3;
                 u32x4 o = *reinterpret_cast<const u32x4*>(sc + p * 80 + cch * 16);
                 const int64_t mm = m0 + p;
+                if (SPLIT) {        // channels [0, K/2) -> dx, [K/2, K) -> dx2 (= dx_plain argument), rows of K/2 channels each
+                    const uint32_t off2 = mm < M ? (uint32_t)((mm * KS + (kt * 32) % KS + cch * 8) * 2) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, kt * 32 < KS ? ro : rp, off2, 0, 0);
+                    continue;
+                }
                 const uint32_t off = mm < M ? (uint32_t)((mm * K + kt * 32 + cch * 8) * 2) : 0x80000000u;
                 if (res) {          // block-uniform: dx = dy W + res (the gradient that reaches x through its other consumers)
                     if (dx_plain) __builtin_amdgcn_raw_buffer_store_b128(o, rp, off, 0, 0);      // dy W itself (decoder tail: continues into the resize)
@@ -736,7 +749,13 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
 /* Fused backward of y = x W^T + b for bf16 rows: dx [M,K] (= dy W, + res when res != NULL), dw [N,K] fp32 and dbias [N] fp32 (nullable)
  * are ACCUMULATED into after being cleared here (or by the caller: tcct_set_outputs_prezeroed).  K, N in {32, 64, 96, 128}. */
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
-                       int64_t M, int K, int N, tcct_stream_t stream);
+                       int64_t M, int K, int N, tcct_stream_t stream, bool split = false);
+/* the same over a concatenation: x = [x1 | x2], dx = [dx1 | dx2], each [M, K/2] (K = 128): backward of tcct_pw_fwd_cat2 */
+extern "C" int tcct_pw_bwd_cat2(const void* x1, const void* x2, const void* dy, const float* w, void* dx1, void* dx2, float* dw, int64_t M,
+                                int K, int N, tcct_stream_t stream) {
+    TCCT_CHECK(K == 128 && x2 != nullptr && dx2 != nullptr, "pw_bwd_cat2: two halves of 64 channels only (K=%d)", K);
+    return pw_bwd_impl(x1, dy, w, x2, dx1, dx2, dw, nullptr, M, K, N, stream, true);
+}
 extern "C" int tcct_pw_bwd(const void* x, const void* dy, const float* w, const void* res, void* dx, float* dw, float* dbias, int64_t M,
                            int K, int N, tcct_stream_t stream) {
     return pw_bwd_impl(x, dy, w, res, dx, nullptr, dw, dbias, M, K, N, stream);
@@ -749,7 +768,7 @@ extern "C" int tcct_pw_bwd_residual2(const void* x, const void* dy, const float*
     return pw_bwd_impl(x, dy, w, res, dx_sum, dx_plain, dw, dbias, M, K, N, stream);
 }
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
-                       int64_t M, int K, int N, tcct_stream_t stream) {
+                       int64_t M, int K, int N, tcct_stream_t stream, bool split) {
     TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && K <= 128 && N <= 128, "pw_bwd: K=%d N=%d unsupported (32..128)", K, N);
     TCCT_CHECK(M > 0 && M * (int64_t)(K > N ? K : N) * 2 < (1LL << 31), "pw_bwd: tensor exceeds the 2 GiB buffer-descriptor range");
     hipStream_t st = (hipStream_t)stream;
@@ -766,9 +785,12 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
     if (gx > tiles) gx = tiles;
 #define BL(NTV, KTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<NTV, KTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
         hipLaunchKernelGGL((k_pw_bwd<NTV, KTV>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M); }
-#define BLK(NTV) switch (KT) { case 1: BL(NTV, 1) break; case 2: BL(NTV, 2) break; case 3: BL(NTV, 3) break; default: BL(NTV, 4) break; }
+#define BLS(NTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<NTV, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_bwd<NTV, 4, true>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M); }
+#define BLK(NTV) switch (KT) { case 1: BL(NTV, 1) break; case 2: BL(NTV, 2) break; case 3: BL(NTV, 3) break; default: if (split) BLS(NTV) else BL(NTV, 4) break; }
     switch (NT) { case 1: BLK(1) break; case 2: BLK(2) break; case 3: BLK(3) break; default: BLK(4) break; }
 #undef BLK
+#undef BLS
 #undef BL
     TCCT_LAUNCH_OK();
 }
@@ -781,10 +803,13 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
 // LDS rows of 2K+16 bytes (conflict-free ds_read_b128 for the fragment layout) and prefetched one tile ahead; wave w multiplies pixels
 // 32w..32w+31 against all N-tiles.  Same tile pipeline as k_pw_bwd / k_conv32_mfma (staging wait behind the MFMA phase, stores after
 // the next prefetch).  SPLIT: the rows are the concatenation [x | x2] of two tensors of K/2 channels each (MHCA_stage.aggregate).
-template <int NT, int KT, bool STATS, bool SPLIT>
+// RES: y = res + rscale[m / per_sample] * (x W^T + bias) with the product rounded to bf16 first, like the op-by-op path (Mlp.fc2 with the
+// residual add and the DropPath scale of MHCABlock folded in, reference nets/tcct.py:468); yplain (nullable) also receives the product.
+struct PwRes { const bf16* res; const float* rscale; int64_t per_sample; bf16* yplain; };
+template <int NT, int KT, bool STATS, bool SPLIT, bool RES = false>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* __restrict__ w, const float* __restrict__ bias,
-          bf16* __restrict__ y, int64_t M, double* __restrict__ stats, int stat_pre) {
+          bf16* __restrict__ y, int64_t M, double* __restrict__ stats, int stat_pre, PwRes pr) {
     constexpr int K = 32 * KT, N = 32 * NT;
     constexpr int SX = 2 * K + 16, SW = 2 * K + 16;
     constexpr int XS = K / 16;
@@ -815,6 +840,8 @@ k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(SPLIT ? x2 : x), 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? (const void*)pr.res : (const void*)y), 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpl = __builtin_amdgcn_make_buffer_rsrc((void*)((RES && pr.yplain) ? pr.yplain : y), 0, ybytes, 0x00020000);
     u32x4 px[XS];
     auto prefetch = [&](int64_t tile) {
         const uint32_t bx = (uint32_t)(tile * PB_P * KS * 2);
@@ -875,10 +902,20 @@ k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* 
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int p = (lane >> 2) + 16 * h2, cch = lane & 3;
-                const u32x4 o = *reinterpret_cast<const u32x4*>(sc + p * 80 + cch * 16);
+                u32x4 o = *reinterpret_cast<const u32x4*>(sc + p * 80 + cch * 16);
                 const int64_t mm = m0 + p;
                 const bool inb = mm < M;
-                __builtin_amdgcn_raw_buffer_store_b128(o, ro, inb ? (uint32_t)((mm * N + nt * 32 + cch * 8) * 2) : 0x80000000u, 0, 0);
+                const uint32_t off = inb ? (uint32_t)((mm * N + nt * 32 + cch * 8) * 2) : 0x80000000u;
+                if (RES) {
+                    if (pr.yplain) __builtin_amdgcn_raw_buffer_store_b128(o, rpl, off, 0, 0);
+                    const u32x4 rv = __builtin_amdgcn_raw_buffer_load_b128(rres, off, 0, 0);
+                    const float sc_ = pr.rscale ? pr.rscale[(inb ? mm : 0) / pr.per_sample] : 1.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        o[k] = pack_bf16x2(__uint_as_float(rv[k] << 16) + sc_ * __uint_as_float(o[k] << 16),
+                                           __uint_as_float(rv[k] & 0xffff0000u) + sc_ * __uint_as_float(o[k] & 0xffff0000u));
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(o, ro, off, 0, 0);
                 if (STATS) {
                     if (inb) {
 #pragma unroll
@@ -925,7 +962,7 @@ static bool pw_fwd2_ok(int64_t M, int K, int N, int K1, bool has_x2) {
     return true;
 }
 static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
-                          int stat_pre, tcct_stream_t stream) {
+                          int stat_pre, tcct_stream_t stream, PwRes pr) {
     const int NT = N / 32, KT = K / 32;
     const size_t lds = (size_t)PB_P * (2 * K + 16) + (size_t)N * (2 * K + 16) + (size_t)N * 4 + 4 * 2560;
     const int64_t tiles = (M + PB_P - 1) / PB_P;
@@ -935,14 +972,25 @@ static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const f
     if (gx > tiles) gx = tiles;
     hipStream_t st = (hipStream_t)stream;
 #define F2(NTV, KTV, SV, PV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd2<NTV, KTV, SV, PV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
-        hipLaunchKernelGGL((k_pw_fwd2<NTV, KTV, SV, PV>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)x2, w, bias, (bf16*)y, M, stats, stat_pre); }
+        hipLaunchKernelGGL((k_pw_fwd2<NTV, KTV, SV, PV>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)x2, w, bias, (bf16*)y, M, stats, stat_pre, pr); }
+#define F2R(NTV, KTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd2<NTV, KTV, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_fwd2<NTV, KTV, false, false, true>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)x2, w, bias, (bf16*)y, M, stats, stat_pre, pr); }
 #define F2K(NTV, SV) switch (KT) { case 2: F2(NTV, 2, SV, false) break; case 3: F2(NTV, 3, SV, false) break; default: if (x2) F2(NTV, 4, SV, true) else F2(NTV, 4, SV, false) break; }
+#define F2RK(NTV) switch (KT) { case 2: F2R(NTV, 2) break; case 3: F2R(NTV, 3) break; default: F2R(NTV, 4) break; }
 #define F2N(SV) switch (NT) { case 1: F2K(1, SV) break; case 2: F2K(2, SV) break; case 3: F2K(3, SV) break; default: F2K(4, SV) break; }
-    if (stats) { F2N(true) } else { F2N(false) }
+    if (pr.res) { switch (NT) { case 1: F2RK(1) break; case 2: F2RK(2) break; case 3: F2RK(3) break; default: F2RK(4) break; } }
+    else if (stats) { F2N(true) } else { F2N(false) }
+#undef F2RK
+#undef F2R
 #undef F2N
 #undef F2K
 #undef F2
     TCCT_LAUNCH_OK();
+}
+
+static int pw_fwd2_route(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
+                         int stat_pre, tcct_stream_t stream, const bf16* res, const float* rscale, int64_t per_sample, bf16* yplain) {
+    return pw_fwd2_launch(x, x2, w, bias, y, M, K, N, stats, stat_pre, stream, PwRes{res, rscale, per_sample, yplain});
 }
 
 // ------------------------------------------------------------------------------------------------ first-layer im2col

@@ -787,6 +787,11 @@ class _PwCat2(torch.autograd.Function):
         N_, H, W_, Ca = a.shape
         Cb, Cout, M = b.shape[-1], w.shape[0], N_ * H * W_
         da, db_ = torch.empty_like(a), torch.empty_like(b)
+        if (FUSED_PW_BWD and Ca == 64 and Cb == 64 and Cout % 32 == 0 and Cout <= 128 and dy.dtype == torch.bfloat16
+                and a.numel() * 2 < 2 ** 31 and dy.numel() * 2 < 2 ** 31):
+            dw = _grad_out(ctx.wsrc, tuple(w.shape))
+            lib.pw_bwd_cat2(a, b, dy, w, da, db_, dw, M, Ca + Cb, Cout)
+            return da, db_, _ret(dw, ctx.wsrc), None
         lib.pw_dgrad_split2(dy, w, da, db_, Ca, M, Cout, Ca + Cb)
         with _wgrad_stream(_slot_written(ctx.wsrc), a, b, dy):
             dw = _grad_out(ctx.wsrc, tuple(w.shape))
