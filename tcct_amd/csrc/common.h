@@ -77,6 +77,43 @@ __device__ __forceinline__ void st4(bf16* p, const f4& a) {
 }
 __device__ __forceinline__ f4 f4zero() { f4 r; r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f; return r; }
 
+// VEC consecutive elements as fp32 (VEC = 1, 4 or 8).  bf16 with VEC = 8 moves 16 bytes per lane: the streaming kernels were written
+// with 4-element vectors, i.e. 8-byte bf16 accesses (512 B per wave instruction), which holds a pure copy-like kernel at ~4.7 TB/s
+// where 16-byte accesses reach ~5.5 (MI355X_MICROARCH.md: 8-B accesses run at 0.54-0.70 of the 16-B rate)
+template <int VEC> __device__ __forceinline__ void ldv(const float* p, float* o) {
+    if (VEC == 1) { o[0] = *p; return; }
+#pragma unroll
+    for (int j = 0; j < VEC / 4; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(p + 4 * j);
+        o[4 * j] = t.x; o[4 * j + 1] = t.y; o[4 * j + 2] = t.z; o[4 * j + 3] = t.w;
+    }
+}
+template <int VEC> __device__ __forceinline__ void ldv(const bf16* p, float* o) {
+    if (VEC == 1) { o[0] = __bfloat162float(*p); return; }
+    if (VEC == 4) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        o[0] = __uint_as_float(t.x << 16); o[1] = __uint_as_float(t.x & 0xffff0000u);
+        o[2] = __uint_as_float(t.y << 16); o[3] = __uint_as_float(t.y & 0xffff0000u);
+        return;
+    }
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[2 * j] = __uint_as_float(w[j] << 16); o[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+}
+template <int VEC> __device__ __forceinline__ void stv(float* p, const float* v) {
+    if (VEC == 1) { *p = v[0]; return; }
+#pragma unroll
+    for (int j = 0; j < VEC / 4; ++j) *reinterpret_cast<float4*>(p + 4 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+template <int VEC> __device__ __forceinline__ void stv(bf16* p, const float* v) {
+    if (VEC == 1) { *p = __float2bfloat16(v[0]); return; }
+    if (VEC == 4) { uint2 t; t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]); *reinterpret_cast<uint2*>(p) = t; return; }
+    uint4 t;
+    t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]); t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = t;
+}
+
 // ---------------------------------------------------------------- activations (kinds: TCCT_ACT_*)
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 round-off level): 1 rcp + 1 exp + 6 FMAs instead of the ~40
 // instruction libm erff -- the GELU junction kernels of the CNN blocks were VALU-bound on it (0.49 ms for a 1.36 GB reduction).

@@ -1,17 +1,45 @@
 // Train-mode BatchNorm2d (two-stage per-channel reductions, fp64 block combine) and LayerNorm over C.
 // All tensors are [M, C] row-major (NHWC with M = N*H*W).  HBM-bound: every kernel streams x (and dy) once.
 #include "common.h"
+#include <cstdlib>
 
 #define NB 256
 // The per-channel reduction kernels run 1024-thread blocks on a grid of at most 512: every block ends with one fp64 atomic per
 // channel sum and same-address atomics are serialised at L2, so the tail grows with the NUMBER of blocks (2048 blocks of 256:
 // +40 us on every call, 4096: +80 us) while the streaming rate needs ~32 waves per CU -- big blocks give both.
 #define NBR 1024
+// elements per thread.  4 (8-byte bf16 accesses) is what the kernels were tuned with; the 8-element instantiations (16 bytes per lane)
+// exist and are correct but measured NO better on the MI355X at level 0 (32 ch, 452 MB tensors, same box): bn_apply 0.193 vs 0.19 ms,
+// bn_bwd_apply 0.278 vs 0.24, bn_bwd_reduce 0.222 vs 0.172 ms -- twice the per-channel constants in registers costs occupancy in the
+// 1024-thread reduction blocks, and the 8-byte form already streams at 4.7-5.2 TB/s.  TCCT_BN_VEC8=1 selects them for A/B runs.
+static inline int bn_vec(int C, int dtype) {
+    static int v8 = -1;
+    if (v8 < 0) { const char* e = getenv("TCCT_BN_VEC8"); v8 = (e && e[0] == '1') ? 1 : 0; }
+    return (v8 && dtype == TCCT_BF16 && C % 8 == 0) ? 8 : ((C % 4 == 0) ? 4 : 1);
+}
+
+// block-level combine of two per-thread partial vectors (thread t = row r * CV + vector cv) into fp64 atomics on sums[0..C) / sums[C..2C)
+template <int VEC>
+__device__ __forceinline__ void bn_block_reduce2(float* sm, const float* s, const float* q, int t, int C, int CV, int R, double* sums) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) sm[t * VEC + k] = pass ? q[k] : s[k];
+        __syncthreads();
+        if (t < C) {            // channel c = t lives at vector cv = t / VEC, element k = t % VEC of rows r = 0..R-1
+            double a = 0.0;
+            const int cvv = t / VEC, k = t % VEC;
+            for (int rr = 0; rr < R; ++rr) a += (double)sm[(rr * CV + cvv) * VEC + k];
+            atomicAdd(&sums[pass * C + t], a);
+        }
+    }
+}
 
 // ------------------------------------------------------------------ BN forward statistics: sum, sum of squares
 template <typename T, int VEC>
 __global__ void __launch_bounds__(NBR) k_bn_stats(const T* __restrict__ x, int64_t M, int C, int pre_act, double* __restrict__ sums) {
-    __shared__ float sm[2 * NBR * VEC];
+    __shared__ float sm[NBR * VEC];     // one 32 KB array, used for the sums and then for the sums of squares (VEC = 8)
     const int CV = C / VEC;            // vectors per row
     const int R = NBR / CV;             // rows per block pass
     const int t = threadIdx.x;
@@ -22,41 +50,24 @@ __global__ void __launch_bounds__(NBR) k_bn_stats(const T* __restrict__ x, int64
     for (int k = 0; k < VEC; ++k) s[k] = q[k] = 0.f;
     if (active) {
         for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += (int64_t)gridDim.x * R) {
-            const T* p = x + m * C + cv * VEC;
-            if (VEC == 4) {
-                f4 a = ld4(p);
+            float a[VEC];
+            ldv<VEC>(x + m * C + cv * VEC, a);
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) { float u = act_fwd(pre_act, a.v[k]); s[k] += u; q[k] += u * u; }
-            } else {
-                float u = act_fwd(pre_act, ldf(p)); s[0] += u; q[0] += u * u;
-            }
+            for (int k = 0; k < VEC; ++k) { float u = act_fwd(pre_act, a[k]); s[k] += u; q[k] += u * u; }
         }
     }
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) { sm[t * VEC + k] = s[k]; sm[(NBR + t) * VEC + k] = q[k]; }
-    __syncthreads();
-    if (t < C) {
-        // channel c = t lives at vector cv=t/VEC, lane k=t%VEC of rows r=0..R-1
-        double a = 0.0, b = 0.0;
-        int cvv = t / VEC, k = t % VEC;
-        for (int rr = 0; rr < R; ++rr) {
-            int tt = rr * CV + cvv;
-            a += (double)sm[tt * VEC + k];
-            b += (double)sm[(NBR + tt) * VEC + k];
-        }
-        atomicAdd(&sums[t], a);
-        atomicAdd(&sums[C + t], b);
-    }
+    bn_block_reduce2<VEC>(sm, s, q, t, C, CV, R, sums);
 }
 
 extern "C" int tcct_bn_stats(const void* x, int64_t M, int C, int pre_act, double* sums, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(C >= 1 && C <= NB, "bn_stats: C=%d unsupported (1..%d)", C, NB);
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { tcct_set_error("bn_stats: memset failed"); return -2; }
-    int vec = (C % 4 == 0) ? 4 : 1;
+    int vec = bn_vec(C, dtype);
     int R = NBR / (C / vec);
     int grid = tcct_grid(M, R, 512);
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_stats<T, 4>), dim3(grid), dim3(NBR), 0, st, (const T*)x, M, C, pre_act, sums)); }
+    if (vec == 8) hipLaunchKernelGGL((k_bn_stats<bf16, 8>), dim3(grid), dim3(NBR), 0, st, (const bf16*)x, M, C, pre_act, sums);
+    else if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_stats<T, 4>), dim3(grid), dim3(NBR), 0, st, (const T*)x, M, C, pre_act, sums)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_stats<T, 1>), dim3(grid), dim3(NBR), 0, st, (const T*)x, M, C, pre_act, sums)); }
     TCCT_LAUNCH_OK();
 }
@@ -159,21 +170,18 @@ __global__ void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t M
     for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += 2 * step) {
         const int64_t m2 = m + step;
         const int64_t o1 = m * C + cv * VEC, o2 = m2 * C + cv * VEC;
-        if (VEC == 4) {
-            f4 v1 = ld4(x + o1), v2 = m2 < M ? ld4(x + o2) : f4zero(), r1, r2;
-            f4 e1 = f4zero(), e2 = f4zero();
-            if (res) { e1 = ld4(res + o1); if (m2 < M) e2 = ld4(res + o2); }
+        const bool two = m2 < M;
+        float v1[VEC], v2[VEC], e1[VEC], e2[VEC];
+        ldv<VEC>(x + o1, v1);
+        if (two) ldv<VEC>(x + o2, v2);
+        if (res) { ldv<VEC>(res + o1, e1); if (two) ldv<VEC>(res + o2, e2); }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                r1.v[k] = act_fwd(post_act, a_[k] * act_fwd(pre_act, v1.v[k]) + b_[k]) + e1.v[k];
-                r2.v[k] = act_fwd(post_act, a_[k] * act_fwd(pre_act, v2.v[k]) + b_[k]) + e2.v[k];
-            }
-            st4(y + o1, r1);
-            if (m2 < M) st4(y + o2, r2);
-        } else {
-            stf(y + o1, act_fwd(post_act, a_[0] * act_fwd(pre_act, ldf(x + o1)) + b_[0]) + (res ? ldf(res + o1) : 0.f));
-            if (m2 < M) stf(y + o2, act_fwd(post_act, a_[0] * act_fwd(pre_act, ldf(x + o2)) + b_[0]) + (res ? ldf(res + o2) : 0.f));
+        for (int k = 0; k < VEC; ++k) {
+            v1[k] = act_fwd(post_act, a_[k] * act_fwd(pre_act, v1[k]) + b_[k]) + (res ? e1[k] : 0.f);
+            if (two) v2[k] = act_fwd(post_act, a_[k] * act_fwd(pre_act, v2[k]) + b_[k]) + (res ? e2[k] : 0.f);
         }
+        stv<VEC>(y + o1, v1);
+        if (two) stv<VEC>(y + o2, v2);
     }
 }
 static int bn_apply_impl(const void* x, const void* res, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act,
@@ -202,11 +210,12 @@ extern "C" int tcct_bn_apply_add(const void* x, const void* res, void* y, int64_
 static int bn_apply_impl(const void* x, const void* res, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act,
                          int dtype, tcct_stream_t stream, BnTrain tr) {
     TCCT_CHECK(C >= 1 && C <= NB, "bn_apply: C=%d unsupported", C);
-    int vec = (C % 4 == 0) ? 4 : 1;
+    int vec = bn_vec(C, dtype);
     int R = NB / (C / vec);
     int grid = tcct_grid(M, 2 * R, 256 * 16);
     hipStream_t st = (hipStream_t)stream;
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act, (const T*)res, tr)); }
+    if (vec == 8) hipLaunchKernelGGL((k_bn_apply<bf16, 8>), dim3(grid), dim3(NB), 0, st, (const bf16*)x, (bf16*)y, M, C, ab, pre_act, post_act, (const bf16*)res, tr);
+    else if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act, (const T*)res, tr)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act, (const T*)res, tr)); }
     TCCT_LAUNCH_OK();
 }
@@ -216,7 +225,7 @@ template <typename T, int VEC>
 __global__ void __launch_bounds__(NBR) k_bn_bwd_reduce(const T* __restrict__ x, const T* __restrict__ dy, int64_t M, int C,
                                 const float* __restrict__ mean_rstd, const float* __restrict__ ab, int pre_act,
                                 int post_act, double* __restrict__ sums) {
-    __shared__ float sm[2 * NBR * VEC];
+    __shared__ float sm[NBR * VEC];
     const int CV = C / VEC;
     const int R = NBR / CV;
     const int t = threadIdx.x;
@@ -233,11 +242,8 @@ __global__ void __launch_bounds__(NBR) k_bn_bwd_reduce(const T* __restrict__ x, 
         for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += (int64_t)gridDim.x * R) {
             int64_t off = m * C + cv * VEC;
             float xv[VEC], gv[VEC];
-            if (VEC == 4) {
-                f4 a = ld4(x + off), g = ld4(dy + off);
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) { xv[k] = a.v[k]; gv[k] = g.v[k]; }
-            } else { xv[0] = ldf(x + off); gv[0] = ldf(dy + off); }
+            ldv<VEC>(x + off, xv);
+            ldv<VEC>(dy + off, gv);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 float u = act_fwd(pre_act, xv[k]);
@@ -246,30 +252,18 @@ __global__ void __launch_bounds__(NBR) k_bn_bwd_reduce(const T* __restrict__ x, 
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) { sm[t * VEC + k] = s[k]; sm[(NBR + t) * VEC + k] = q[k]; }
-    __syncthreads();
-    if (t < C) {
-        double a = 0.0, b = 0.0;
-        int cvv = t / VEC, k = t % VEC;
-        for (int rr = 0; rr < R; ++rr) {
-            int tt = rr * CV + cvv;
-            a += (double)sm[tt * VEC + k];
-            b += (double)sm[(NBR + tt) * VEC + k];
-        }
-        atomicAdd(&sums[t], a);
-        atomicAdd(&sums[C + t], b);
-    }
+    bn_block_reduce2<VEC>(sm, s, q, t, C, CV, R, sums);
 }
 extern "C" int tcct_bn_bwd_reduce(const void* x, const void* dy, int64_t M, int C, const float* mean_rstd, const float* ab,
                                   int pre_act, int post_act, double* sums, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(C >= 1 && C <= NB, "bn_bwd_reduce: C=%d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { tcct_set_error("bn_bwd_reduce: memset failed"); return -2; }
-    int vec = (C % 4 == 0) ? 4 : 1;
+    int vec = bn_vec(C, dtype);
     int R = NBR / (C / vec);
     int grid = tcct_grid(M, R, 512);
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce<T, 4>), dim3(grid), dim3(NBR), 0, st, (const T*)x, (const T*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
+    if (vec == 8) hipLaunchKernelGGL((k_bn_bwd_reduce<bf16, 8>), dim3(grid), dim3(NBR), 0, st, (const bf16*)x, (const bf16*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums);
+    else if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce<T, 4>), dim3(grid), dim3(NBR), 0, st, (const T*)x, (const T*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce<T, 1>), dim3(grid), dim3(NBR), 0, st, (const T*)x, (const T*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
     TCCT_LAUNCH_OK();
 }
@@ -297,11 +291,8 @@ __global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy
     for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += step) {
         const int64_t off = m * C + cv * VEC;
         float xv[VEC], gv[VEC], o[VEC];
-        if (VEC == 4) {
-            f4 a = ld4(x + off), g = ld4(dy + off);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) { xv[k] = a.v[k]; gv[k] = g.v[k]; }
-        } else { xv[0] = ldf(x + off); gv[0] = ldf(dy + off); }
+        ldv<VEC>(x + off, xv);
+        ldv<VEC>(dy + off, gv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             float u = act_fwd(pre_act, xv[k]);
@@ -310,8 +301,7 @@ __global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy
             float du = a_[k] * (dz - s1[k] - xh * s2[k]);
             o[k] = du * act_grad(pre_act, xv[k]);
         }
-        if (VEC == 4) { f4 q; q.v[0] = o[0]; q.v[1] = o[1]; q.v[2] = o[2]; q.v[3] = o[3]; st4(dx + off, q); }
-        else stf(dx + off, o[0]);
+        stv<VEC>(dx + off, o);
     }
 }
 extern "C" int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_t M, int C, const float* mean_rstd,
@@ -319,11 +309,12 @@ extern "C" int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_
                                  float* dgamma, float* dbeta, int dtype, tcct_stream_t stream) {
     (void)gamma;
     TCCT_CHECK(C >= 1 && C <= NB, "bn_bwd_apply: C=%d unsupported", C);
-    int vec = (C % 4 == 0) ? 4 : 1;
+    int vec = bn_vec(C, dtype);
     int R = NB / (C / vec);
     int grid = tcct_grid(M, R, 256 * 16);
     hipStream_t st = (hipStream_t)stream;
-    if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (const T*)dy, (T*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
+    if (vec == 8) hipLaunchKernelGGL((k_bn_bwd_apply<bf16, 8>), dim3(grid), dim3(NB), 0, st, (const bf16*)x, (const bf16*)dy, (bf16*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta);
+    else if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (const T*)dy, (T*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (const T*)dy, (T*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
     TCCT_LAUNCH_OK();
 }

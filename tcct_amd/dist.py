@@ -89,7 +89,7 @@ class GradBuckets:
         self.launched = 0
         self.ready = [False] * N_BUCKETS
         self.armed = False
-        self.overlap = os.environ.get('TCCT_DP_OVERLAP', '1') != '0'
+        self.overlap = True
         self.launch_log = []            # (bucket, 'backward' | 'step') of the last step: tests and bench read it
 
     def bind(self, flat_g, sizes):
@@ -151,14 +151,20 @@ class GradBuckets:
 
 
 def attach(optimizer, model=None):
-    """make a FlatAdamW average gradients over the process group before the clip+AdamW kernel.  With `model`, the gradient is
-    all-reduced in N_BUCKETS static buckets overlapped with the backward pass (TCCT_DP_OVERLAP=0: one blocking all-reduce of the whole
-    buffer after the backward pass, the round-1 behaviour, kept for A/B timing)."""
+    """make a FlatAdamW average gradients over the process group before the clip+AdamW kernel.
+
+    Default: ONE all-reduce of the whole flat buffer (3.2 MB) right after the backward pass.  TCCT_DP_OVERLAP=1 (needs `model`):
+    N_BUCKETS static buckets on a comm stream, launched while the backward pass is still running (GradBuckets).  Both are tested
+    for gradient equivalence with the single-process mean (tests/test_model_gpu.py).  The overlapped form is NOT the default because
+    it measures slower where it could be measured -- forced process group of one rank over RCCL on one MI355X, bench shape, same box:
+    30.62 ms single all-reduce, 31.68 ms three buckets all launched in step(), 32.02 ms three buckets overlapped with backward
+    (gpurun_out/r02i_dp_ab.log): every extra collective costs ~0.35 ms of stream hand-offs for a transfer that takes tens of
+    microseconds, and there is no bandwidth to hide at this message size."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('TCCT_FORCE_DIST', '0') == '1'):
         optimizer.world = dist.get_world_size()
         optimizer.allreduce = allreduce_sum_
         optimizer.allreduce_mode = 'single blocking all-reduce after backward'
-        if model is not None and os.environ.get('TCCT_DP_OVERLAP', '1') != '0':
+        if model is not None and os.environ.get('TCCT_DP_OVERLAP', '0') == '1':
             from . import ops
             for name, p in model.named_parameters():
                 p._tcct_bucket = bucket_of(name)

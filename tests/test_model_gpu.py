@@ -687,7 +687,7 @@ if rank == 1:                                      # different initial weights o
             p.add_(0.05)
 k = KiteSeg(model=model, dataset=DS(), root=%(tmp)r, args=args)
 assert k.optimG.allreduce is not None and k.optimG.world == 2 and k.world == 2 and k.rank == rank
-overlap = os.environ.get('TCCT_DP_OVERLAP', '1') != '0'
+overlap = os.environ.get('TCCT_DP_OVERLAP', '0') == '1'
 assert (k.optimG.buckets is not None) == overlap
 k.model.train()
 k.model.base.base_vit.drop_probs = [0.0] * 4
