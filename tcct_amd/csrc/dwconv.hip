@@ -9,8 +9,10 @@
 // version slid along W instead, one output row per thread, and fetched every input row three times from three different
 // XCDs (1.4-1.8 TB/s effective).
 #include "common.h"
+#include <cstdlib>
 
 #define DB 256
+// (forcing 4 waves per SIMD with __launch_bounds__(256, 4) spills ~10 registers in the marching loop: 0.166 -> 0.262 ms at level 1)
 
 template <typename T, int VEC>
 __device__ __forceinline__ void ldv(const T* p, float* o) {
@@ -25,14 +27,17 @@ __device__ __forceinline__ void stv(T* p, const float* o) {
 
 // block -> (image n, row strip hs, column block wb); thread -> (column offset, channel vector).  false: thread has no work.
 struct DwPos { int n, ho0, ho1, wo, c; };
-__device__ __forceinline__ bool dw_pos(int C, int VEC, int Ho, int Wo, int segh, int wblocks, int hstrips, DwPos& p) {
+// cpt: consecutive output columns per thread (p.wo = the first).  With one column per thread every input element is requested by
+// three threads (8-byte requests, served by L1 but paid for in the address / tag pipeline): 2.7 TB/s at level 1.  Four columns per
+// thread load six columns for four outputs.
+__device__ __forceinline__ bool dw_pos(int C, int VEC, int Ho, int Wo, int segh, int wblocks, int hstrips, DwPos& p, int cpt = 1) {
     const int CV = C / VEC, PW = DB / CV, t = threadIdx.x;
     if (t >= PW * CV) return false;
     int bid = blockIdx.x;
     const int wb = bid % wblocks; bid /= wblocks;
     const int hs = bid % hstrips;
     p.n = bid / hstrips;
-    p.wo = wb * PW + t / CV;
+    p.wo = (wb * PW + t / CV) * cpt;
     p.c = (t % CV) * VEC;
     p.ho0 = hs * segh;
     p.ho1 = min(Ho, p.ho0 + segh);
@@ -64,12 +69,12 @@ template <typename T> struct Raw<T, 1> {
 };
 
 // one input row: the three columns wi0, wi0+1, wi0+2 of input row hi (zeros outside the image)
-template <typename T, int VEC>
-__device__ __forceinline__ void dw_load_row(Raw<T, VEC> (&r)[3], const T* __restrict__ img, int hi, int H, int W, int C, int wi0) {
+template <typename T, int VEC, int NC = 3>
+__device__ __forceinline__ void dw_load_row(Raw<T, VEC> (&r)[NC], const T* __restrict__ img, int hi, int H, int W, int C, int wi0) {
     const bool rok = hi >= 0 && hi < H;
     const T* row = img + (int64_t)(rok ? hi : 0) * W * C;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
+    for (int kx = 0; kx < NC; ++kx) {
         const int wi = wi0 + kx;
         if (rok && wi >= 0 && wi < W) r[kx].load(row + (int64_t)wi * C);
         else r[kx].zero();
@@ -86,14 +91,17 @@ template <int STRIDE> struct DwChunk {
     static constexpr int ROWS = CARRY + NEW;
 };
 
-template <typename T, int VEC, int STRIDE, bool FLIP>
+template <typename T, int VEC, int STRIDE, bool FLIP, int CPT = 1>
 __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, int add_input,
                                                int segh, int wblocks, int hstrips, const T* __restrict__ res) {
     // res != NULL (output-shaped): y += res -- as input gradient: the gradient reaching the convolution's input through its other consumers
+    // CPT > 1 (stride 1 only): the thread owns CPT consecutive output columns and loads CPT + 2 input columns per row
+    static_assert(CPT == 1 || STRIDE == 1, "several columns per thread: stride 1 only");
+    constexpr int NC = CPT + 2;
     typedef DwChunk<STRIDE> K;
     DwPos p;
-    if (!dw_pos(C, VEC, Ho, Wo, segh, wblocks, hstrips, p)) return;
+    if (!dw_pos(C, VEC, Ho, Wo, segh, wblocks, hstrips, p, CPT)) return;
     float wk[9][VEC], bv[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
@@ -105,47 +113,54 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
     T* out = y + (int64_t)p.n * Ho * Wo * C + p.c;
     const T* rin = res ? res + (int64_t)p.n * Ho * Wo * C + p.c : nullptr;
     const int wi0 = p.wo * STRIDE - 1;
-    Raw<T, VEC> R[K::ROWS][3], NX[K::NEW][3];
+    constexpr int RBC = CPT == 1 ? K::RB : 2;              // output rows per chunk (two with several columns: register budget)
+    constexpr int NEWC = RBC * STRIDE, ROWSC = K::CARRY + NEWC;
+    Raw<T, VEC> R[ROWSC][NC], NX[NEWC][NC];
 #pragma unroll
-    for (int i = 0; i < K::ROWS; ++i) dw_load_row<T, VEC>(R[i], img, p.ho0 * STRIDE - 1 + i, H, W, C, wi0);
-    for (int ho = p.ho0; ho < p.ho1; ho += K::RB) {
-        if (ho + K::RB < p.ho1) {
+    for (int i = 0; i < ROWSC; ++i) dw_load_row<T, VEC, NC>(R[i], img, p.ho0 * STRIDE - 1 + i, H, W, C, wi0);
+    for (int ho = p.ho0; ho < p.ho1; ho += RBC) {
+        if (ho + RBC < p.ho1) {
 #pragma unroll
-            for (int i = 0; i < K::NEW; ++i) dw_load_row<T, VEC>(NX[i], img, (ho + K::RB) * STRIDE - 1 + K::CARRY + i, H, W, C, wi0);
+            for (int i = 0; i < NEWC; ++i) dw_load_row<T, VEC, NC>(NX[i], img, (ho + RBC) * STRIDE - 1 + K::CARRY + i, H, W, C, wi0);
         }
 #pragma unroll
-        for (int j = 0; j < K::RB; ++j) {
+        for (int j = 0; j < RBC; ++j) {
             if (ho + j < p.ho1) {
-                float acc[VEC];
-                Raw<T, VEC> rr;
-                if (rin) rr.load(rin + ((int64_t)(ho + j) * Wo + p.wo) * C); else rr.zero();
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    float a = bv[k] + rr.get(k);
+                for (int cc = 0; cc < CPT; ++cc) {
+                    if (CPT > 1 && p.wo + cc >= Wo) break;
+                    float acc[VEC];
+                    Raw<T, VEC> rr;
+                    if (rin) rr.load(rin + ((int64_t)(ho + j) * Wo + p.wo + cc) * C); else rr.zero();
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
+                    for (int k = 0; k < VEC; ++k) {
+                        float a = bv[k] + rr.get(k);
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) a += R[j * STRIDE + ky][kx].get(k) * wk[ky * 3 + kx][k];
-                    if (add_input) a += R[j * STRIDE + 1][1].get(k);
-                    acc[k] = a;
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) a += R[j * STRIDE + ky][cc + kx].get(k) * wk[ky * 3 + kx][k];
+                        if (add_input) a += R[j * STRIDE + 1][cc + 1].get(k);
+                        acc[k] = a;
+                    }
+                    stv<T, VEC>(out + ((int64_t)(ho + j) * Wo + p.wo + cc) * C, acc);
                 }
-                stv<T, VEC>(out + ((int64_t)(ho + j) * Wo + p.wo) * C, acc);
             }
         }
 #pragma unroll
         for (int i = 0; i < K::CARRY; ++i)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) R[i][kx] = R[K::NEW + i][kx];
+            for (int kx = 0; kx < NC; ++kx) R[i][kx] = R[NEWC + i][kx];
 #pragma unroll
-        for (int i = 0; i < K::NEW; ++i)
+        for (int i = 0; i < NEWC; ++i)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) R[K::CARRY + i][kx] = NX[i][kx];
+            for (int kx = 0; kx < NC; ++kx) R[K::CARRY + i][kx] = NX[i][kx];
     }
 }
 
 // strip height: 32 output rows when that still leaves >= 1024 blocks, else 16, else 8 (the halo re-read is 2/segh)
-static void dw_geometry(int N, int Ho, int Wo, int C, int vec, int target_blocks, int max_segh, int& segh, int& wblocks, int& hstrips) {
-    const int PW = DB / (C / vec);
+static void dw_geometry(int N, int Ho, int Wo, int C, int vec, int target_blocks, int max_segh, int& segh, int& wblocks, int& hstrips,
+                        int cpt = 1) {
+    const int PW = DB / (C / vec) * cpt;
     wblocks = (Wo + PW - 1) / PW;
     segh = max_segh;
     while (segh > 8 && (int64_t)N * wblocks * ((Ho + segh - 1) / segh) < target_blocks) segh >>= 1;
@@ -156,6 +171,15 @@ template <typename T, int VEC, bool FLIP>
 static void dw_fwd_launch(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C, int stride,
                           int Ho, int Wo, int add_input, hipStream_t st, const void* res = nullptr) {
     int segh, wblocks, hstrips;
+    // four columns per thread for the wide bf16 stride-1 images (levels 1-2 of the ViT branch); TCCT_DW_CPT=1 keeps one column (A/B)
+    static int cpt_on = -1;
+    if (cpt_on < 0) { const char* e = getenv("TCCT_DW_CPT"); cpt_on = (e && e[0] == '1') ? 0 : 1; }
+    if (stride == 1 && VEC == 4 && sizeof(T) == 2 && cpt_on && Wo >= 128 && C >= 32) {      // measured +4 % at 64 channels, slower at 4
+        dw_geometry(N, Ho, Wo, C, VEC, 1024, 32, segh, wblocks, hstrips, 4);
+        dim3 g4((unsigned)((int64_t)N * wblocks * hstrips));
+        hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP, (VEC == 4 ? 4 : 1)>), g4, dim3(DB), 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res);
+        return;
+    }
     dw_geometry(N, Ho, Wo, C, VEC, 1024, 32, segh, wblocks, hstrips);
     dim3 g((unsigned)((int64_t)N * wblocks * hstrips)), b(DB);
     if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res);

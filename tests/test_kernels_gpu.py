@@ -94,7 +94,7 @@ def test_first_layer_im2col_conv(dt, stride):
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('cfg', [(64, 1, True, False), (96, 2, False, False), (64, 1, True, True), (4, 1, True, False),
                                  (1, 1, True, False), (160, 2, False, False)])
-@pytest.mark.parametrize('hw', [(10, 14), (37, 45), (70, 33)])
+@pytest.mark.parametrize('hw', [(10, 14), (37, 45), (70, 33), (21, 131), (9, 258)])     # >= 128 columns: four output columns per thread
 def test_dwconv(dt, cfg, hw):
     """small image, and images taller than one row strip / wider than one column block with odd extents"""
     from tcct_amd import ops
