@@ -321,44 +321,60 @@ extern "C" int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_
 
 // ------------------------------------------------------------------ LayerNorm over C (<= 192), 16 lanes per row
 #define LN_MAXCH 3   // vec4 chunks per lane: C <= 16*4*3 = 192
-template <typename T>
+// LN_TOK tokens per 16-lane group and iteration.  Measured at stage 0 (1 766 400 tokens x 64 channels, same box): 1 token 0.119 ms,
+// 2 tokens 0.118 ms, 4 tokens 0.147 ms -- more loads in flight per lane do NOT help this kernel (3.8 TB/s either way); what did help
+// both kernels was sizing the per-lane register arrays by the row width (NCH): k_ln_bwd 0.252 -> 0.20 ms at 64 channels.
+#ifndef LN_TOK
+#define LN_TOK 1
+#endif
+template <typename T, int NCH>          // NCH = vec4 chunks per lane in use: ceil(C / 64) (statically sized register arrays)
 __global__ void k_ln_fwd(const T* __restrict__ x, T* __restrict__ y, int64_t M, int C, const float* __restrict__ gamma,
                          const float* __restrict__ beta, float eps, float* __restrict__ mean_rstd) {
     const int C4 = C >> 2;
     const int lane = threadIdx.x & 15;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
-    for (int64_t m = grp; m < M; m += ngrp) {     // all 16 lanes of a group share m: no divergence inside shuffles
-        f4 v[LN_MAXCH];
-        float s = 0.f;
+    for (int64_t m0 = grp * LN_TOK; m0 < M; m0 += ngrp * LN_TOK) {     // all 16 lanes of a group share m0: no divergence inside shuffles
+        f4 v[LN_TOK][NCH];
 #pragma unroll
-        for (int j = 0; j < LN_MAXCH; ++j) {
-            int ch = lane + 16 * j;
-            if (ch < C4) { v[j] = ld4(x + m * C + ch * 4); s += v[j].v[0] + v[j].v[1] + v[j].v[2] + v[j].v[3]; }
-        }
+        for (int t = 0; t < LN_TOK; ++t)
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        float mean = s / (float)C, q = 0.f;
-#pragma unroll
-        for (int j = 0; j < LN_MAXCH; ++j) {
-            int ch = lane + 16 * j;
-            if (ch < C4) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { float d = v[j].v[k] - mean; q += d * d; }
+            for (int j = 0; j < NCH; ++j) {
+                const int ch = lane + 16 * j;
+                if (ch < C4 && m0 + t < M) v[t][j] = ld4(x + (m0 + t) * C + ch * 4); else v[t][j] = f4zero();
             }
-        }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-        float rstd = rsqrtf(q / (float)C + eps);
-        if (lane == 0) { mean_rstd[2 * m] = mean; mean_rstd[2 * m + 1] = rstd; }
+        for (int t = 0; t < LN_TOK; ++t) {
+            const int64_t m = m0 + t;
+            float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < LN_MAXCH; ++j) {
-            int ch = lane + 16 * j;
-            if (ch < C4) {
-                f4 r;
+            for (int j = 0; j < NCH; ++j) s += v[t][j].v[0] + v[t][j].v[1] + v[t][j].v[2] + v[t][j].v[3];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) r.v[k] = (v[j].v[k] - mean) * rstd * gamma[ch * 4 + k] + beta[ch * 4 + k];
-                st4(y + m * C + ch * 4, r);
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            float mean = s / (float)C, q = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                int ch = lane + 16 * j;
+                if (ch < C4) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { float d = v[t][j].v[k] - mean; q += d * d; }
+                }
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            float rstd = rsqrtf(q / (float)C + eps);
+            if (m < M) {
+                if (lane == 0) { mean_rstd[2 * m] = mean; mean_rstd[2 * m + 1] = rstd; }
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    int ch = lane + 16 * j;
+                    if (ch < C4) {
+                        f4 r;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) r.v[k] = (v[t][j].v[k] - mean) * rstd * gamma[ch * 4 + k] + beta[ch * 4 + k];
+                        st4(y + m * C + ch * 4, r);
+                    }
+                }
             }
         }
     }
@@ -366,12 +382,14 @@ __global__ void k_ln_fwd(const T* __restrict__ x, T* __restrict__ y, int64_t M, 
 extern "C" int tcct_layernorm_fwd(const void* x, void* y, int64_t M, int C, const float* gamma, const float* beta,
                                   float eps, float* mean_rstd, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(C % 4 == 0 && C <= 64 * LN_MAXCH, "layernorm_fwd: C=%d unsupported", C);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_ln_fwd<T>, dim3(tcct_grid(M * 16, NB)), dim3(NB), 0, (hipStream_t)stream,
-                                            (const T*)x, (T*)y, M, C, gamma, beta, eps, mean_rstd));
+    const int nch = (C + 63) / 64;
+#define LNF(NC) hipLaunchKernelGGL((k_ln_fwd<T, NC>), dim3(tcct_grid((M + LN_TOK - 1) / LN_TOK * 16, NB)), dim3(NB), 0, (hipStream_t)stream, (const T*)x, (T*)y, M, C, gamma, beta, eps, mean_rstd)
+    TCCT_DISPATCH(dtype, if (nch == 1) LNF(1); else if (nch == 2) LNF(2); else LNF(3));
+#undef LNF
     TCCT_LAUNCH_OK();
 }
 
-template <typename T>
+template <typename T, int NCH>
 __global__ void __launch_bounds__(NBR) k_ln_bwd(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t M, int C,
                          const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
                          float* __restrict__ dgamma, float* __restrict__ dbeta, const T* __restrict__ res) {
@@ -381,18 +399,39 @@ __global__ void __launch_bounds__(NBR) k_ln_bwd(const T* __restrict__ x, const T
     const int lane = threadIdx.x & 15;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
-    f4 ag[LN_MAXCH], abt[LN_MAXCH];
+    f4 ag[NCH], abt[NCH];
 #pragma unroll
-    for (int j = 0; j < LN_MAXCH; ++j) { ag[j] = f4zero(); abt[j] = f4zero(); }
-    for (int64_t m = grp; m < M; m += ngrp) {
-        float mean = mean_rstd[2 * m], rstd = mean_rstd[2 * m + 1];
-        f4 xh[LN_MAXCH], g[LN_MAXCH];
+    for (int j = 0; j < NCH; ++j) { ag[j] = f4zero(); abt[j] = f4zero(); }
+    constexpr int TB = NCH == 1 ? 2 : 1;      // tokens per iteration (wider rows: one, the 1024-thread blocks have 128 registers per lane)
+    for (int64_t mb = grp * TB; mb < M; mb += ngrp * TB) {
+      // two tokens per iteration: all loads of both tokens are issued before the first reduction (bytes in flight, see k_ln_fwd)
+      f4 xin[TB][NCH], din[TB][NCH], rin[TB][NCH];
+      float mrs[TB][2];
+#pragma unroll
+      for (int t = 0; t < TB; ++t) {
+          const bool tok = mb + t < M;
+          mrs[t][0] = tok ? mean_rstd[2 * (mb + t)] : 0.f; mrs[t][1] = tok ? mean_rstd[2 * (mb + t) + 1] : 0.f;
+#pragma unroll
+          for (int j = 0; j < NCH; ++j) {
+              const int ch = lane + 16 * j;
+              if (ch < C4 && tok) {
+                  xin[t][j] = ld4(x + (mb + t) * C + ch * 4); din[t][j] = ld4(dy + (mb + t) * C + ch * 4);
+                  rin[t][j] = res ? ld4(res + (mb + t) * C + ch * 4) : f4zero();
+              } else { xin[t][j] = f4zero(); din[t][j] = f4zero(); rin[t][j] = f4zero(); }
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < TB; ++t) {
+        const int64_t m = mb + t;
+        if (m >= M) break;
+        float mean = mrs[t][0], rstd = mrs[t][1];
+        f4 xh[NCH], g[NCH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < LN_MAXCH; ++j) {
+        for (int j = 0; j < NCH; ++j) {
             int ch = lane + 16 * j;
             if (ch < C4) {
-                f4 xv = ld4(x + m * C + ch * 4), d = ld4(dy + m * C + ch * 4);
+                f4 xv = xin[t][j], d = din[t][j];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float h = (xv.v[k] - mean) * rstd;
@@ -409,26 +448,26 @@ __global__ void __launch_bounds__(NBR) k_ln_bwd(const T* __restrict__ x, const T
         for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
         s1 /= (float)C; s2 /= (float)C;
 #pragma unroll
-        for (int j = 0; j < LN_MAXCH; ++j) {
+        for (int j = 0; j < NCH; ++j) {
             int ch = lane + 16 * j;
             if (ch < C4) {
                 f4 r;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) r.v[k] = rstd * (g[j].v[k] - s1 - xh[j].v[k] * s2);
                 if (res) {
-                    const f4 rv = ld4(res + m * C + ch * 4);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) r.v[k] += rv.v[k];
+                    for (int k = 0; k < 4; ++k) r.v[k] += rin[t][j].v[k];
                 }
                 st4(dx + m * C + ch * 4, r);
             }
         }
+      }
     }
     // the four 16-lane row groups of a wave hold the same channels: butterfly over lane bits 4,5, then one LDS slot per wave (no
     // LDS float atomics: they cost tens of microseconds per block), summed over the waves by the first 2C threads
     const int wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
 #pragma unroll
-    for (int j = 0; j < LN_MAXCH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
         int ch = lane + 16 * j;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -464,8 +503,10 @@ static int layernorm_bwd_impl(const void* x, const void* dy, void* dx, int64_t M
     if (!tcct_skip_zero_fill() && (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess)) {
         tcct_set_error("layernorm_bwd: memset failed"); return -2;
     }
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_ln_bwd<T>, dim3(tcct_grid(M * 16, NBR, 512)), dim3(NBR), 0, st, (const T*)x,
-                                            (const T*)dy, (T*)dx, M, C, gamma, mean_rstd, dgamma, dbeta, (const T*)res));
+    const int nch = (C + 63) / 64;
+#define LNB(NC) hipLaunchKernelGGL((k_ln_bwd<T, NC>), dim3(tcct_grid((NC == 1 ? (M + 1) / 2 : M) * 16, NBR, 512)), dim3(NBR), 0, st, (const T*)x, (const T*)dy, (T*)dx, M, C, gamma, mean_rstd, dgamma, dbeta, (const T*)res)
+    TCCT_DISPATCH(dtype, if (nch == 1) LNB(1); else if (nch == 2) LNB(2); else LNB(3));
+#undef LNB
     TCCT_LAUNCH_OK();
 }
 

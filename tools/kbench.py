@@ -112,7 +112,7 @@ def dw_bench():
         print(f'dw {N}x{H}x{W}x{C} s{st}: fwd {m1:.3f} ms {(gx + gy) / m1 * 1e3:.0f} GB/s | dgrad {m2:.3f} ms {(gx + gy) / m2 * 1e3:.0f} GB/s | wgrad {m3:.3f} ms {(gx + gy) / m3 * 1e3:.0f} GB/s')
 
 
-if __name__ == "__main__" and not ({"pw", "bwd"} & set(sys.argv[1:])):
+if __name__ == "__main__" and not ({"pw", "bwd", "ln"} & set(sys.argv[1:])):
     if 'dw' in sys.argv[1:]:
         dw_bench()
         sys.exit(0)
@@ -167,3 +167,19 @@ def bwd_bench():
 
 if 'bwd' in sys.argv[1:]:
     bwd_bench()
+
+
+def ln_bench():
+    for (M, C) in [(8 * 400 * 552, 64), (8 * 200 * 276, 96), (8 * 100 * 138, 128)]:
+        x = torch.randn(M, C, device='cuda').to(dt); dy = torch.randn(M, C, device='cuda').to(dt); y = torch.empty_like(x); dx = torch.empty_like(x)
+        g = torch.ones(C, device='cuda'); b = torch.zeros(C, device='cuda'); mr = torch.empty(2 * M, device='cuda')
+        dg = torch.zeros(C, device='cuda'); db = torch.zeros(C, device='cuda')
+        t1 = timeit(lambda: lib.layernorm_fwd(x, y, M, C, g, b, 1e-6, mr, 1))
+        t2 = timeit(lambda: lib.layernorm_bwd(x, dy, dx, M, C, g, mr, dg, db, 1))
+        t3 = timeit(lambda: lib.layernorm_bwd_add(x, dy, y, dx, M, C, g, mr, dg, db, 1))
+        gb = M * C * 2 / 1e9
+        print(f'layernorm M={M} C={C}: fwd {t1:.3f} ms {2 * gb / t1 * 1e3:.0f} GB/s | bwd {t2:.3f} ms {3 * gb / t2 * 1e3:.0f} GB/s | bwd+res {t3:.3f} ms {4 * gb / t3 * 1e3:.0f} GB/s')
+
+
+if 'ln' in sys.argv[1:]:
+    ln_bench()
