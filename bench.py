@@ -138,8 +138,15 @@ def dominant_kernel_roofline(a, iters=20):
         w1 = torch.randn((64, 64), device='cuda') * 0.1; b1 = torch.zeros(64, device='cuda')
         t4 = timed(lambda: lib.pw_fwd(x1, w1, b1, y1, M1, 64, 64, 0, 1))
         b4 = 2.0 * x1.numel() * 2
-        others.append({'kernel': 'k_pw_fwd<2,bf16> (64->64 @L1)', 'ms_per_launch': round(t4, 4), 'algorithmic_bytes': int(b4),
+        others.append({'kernel': 'k_pw_fwd2<2,4> (64->64 @L1; tile-staged pointwise forward)', 'ms_per_launch': round(t4, 4), 'algorithmic_bytes': int(b4),
                        'achieved': round(b4 / (t4 * 1e-3) / 1e9, 1), 'frac': round(b4 / (t4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        # its whole backward in one launch (reads x and dy, writes dx; dW / db accumulate in fp32)
+        dy1 = torch.randn_like(x1); dx1 = torch.empty_like(x1)
+        dw1 = torch.zeros((64, 64), device='cuda'); db1 = torch.zeros(64, device='cuda')
+        t5 = timed(lambda: lib.pw_bwd(x1, dy1, w1, None, dx1, dw1, db1, M1, 64, 64))
+        b5 = 3.0 * x1.numel() * 2
+        others.append({'kernel': 'k_pw_bwd<2,4> (64->64 @L1; dx + dW + db in one pass)', 'ms_per_launch': round(t5, 4), 'algorithmic_bytes': int(b5),
+                       'achieved': round(b5 / (t5 * 1e-3) / 1e9, 1), 'frac': round(b5 / (t5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     bytes_alg = 2.0 * x.numel() * x.element_size()
     ach, ach2 = bytes_alg / (ms * 1e-3) / 1e9, bytes_alg / (ms2 * 1e-3) / 1e9
     flops = 2.0 * 9 * 32 * 32 * a.bs * a.height * Wp
