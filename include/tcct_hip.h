@@ -231,6 +231,15 @@ int tcct_pw_fwd_bnstats(const void* x, const float* w, const float* bias, void* 
 /* first-layer helper: 4-channel NHWC image -> 32-channel 3x3 patch pixels (k = (ky*3+kx)*3+ch, zero for k >= 27) so that
  * CrossResNet.cnn[0] (nets/tcct.py:873) and MPViT stem[0] (stride 2, :674-681) run as 32->32 pointwise MFMA GEMMs */
 int tcct_im2col3x3_c3(const void* x4, void* out, int N, int H, int W, int stride, int dtype, tcct_stream_t stream);
+/* The same first layers WITHOUT the patch tensor (bf16): direct 3 -> 32 channel 3x3 convolution (pad 1, stride 1 or 2) of the 4-channel
+ * image x4 [B,H,W,4]; w fp32 [32,3,3,3] as stored by nn.Conv2d (reference nets/tcct.py:873 `self.cnn[0]`, :674-681 `stem[0]`), y bf16
+ * [B,Ho,Wo,32].  stats (nullable, fp64 [64], zero on entry): fused statistics of pre_act(y) for the train-mode BatchNorm behind it
+ * (nets/tcct.py:873, :80); ab / pre_act / post_act (inference, exclusive with stats): y = post(a[c]*pre(conv+bias)+b[c]), ab from tcct_bn_eval_ab */
+int tcct_c3_fwd(const void* x4, const float* w, const float* bias, void* y, int B, int H, int W, int stride, double* stats, int stat_pre,
+                const float* ab, int pre_act, int post_act, tcct_stream_t stream);
+/* its weight / bias gradient: dw fp32 [32,3,3,3], dbias fp32 [32] (nullable), overwritten; dy bf16 [B,Ho,Wo,32] (what autograd computes for
+ * `F.conv2d(x, w, b, stride, 1)` at nets/tcct.py:873 / :80; the image needs no gradient) */
+int tcct_c3_wgrad(const void* x4, const void* dy, float* dw, float* dbias, int B, int H, int W, int stride, tcct_stream_t stream);
 /* weight gradient of 1x1 convs with <= 8 outputs (5-class aux heads, nets/tcct.py:994-997); dy fp32 or bf16 */
 int tcct_pw_wgrad_smalln(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, int x_dtype,
                          int dy_dtype, tcct_stream_t stream);

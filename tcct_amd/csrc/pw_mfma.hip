@@ -32,12 +32,28 @@ __device__ __forceinline__ float rnd_out(float v, const float*) { return v; }
 // Concatenation-free operands (MHCA_stage.aggregate, reference nets/tcct.py:600-616: `cat([InvRes(x), Encoder(x)], 1)` -> 1x1 conv): the
 // input rows may live in TWO tensors (channels [0,K1) in x, [K1,K) in x2) and, for the input-gradient GEMM, the output rows may go
 // to two tensors (channels [0,N1) to y, [N1,N) to y2).  K1 / N1 are multiples of 32; x2 == NULL / y2 == NULL: ordinary operands.
-struct PwSplit { const bf16* x2; int K1; void* y2; int N1; const bf16* res; const float* rscale; int64_t per_sample; bf16* yplain; };
+// Direct 3-channel 3x3 convolution (C3 kernels below): x is the 4-channel NHWC image [B,H,W,4]; the "patch row" of an output pixel is
+// gathered on the fly instead of being read from an im2col copy, in the order k = 16*ky + 4*slot + ch with slot 0, 1, 2 = kx 0, 1, 2 and
+// slot 3 / channel 3 zero (K = 48): k-step ky of an MFMA is then, per lane half, two whole 8-byte pixels of ONE input row (kx 0,1 / kx 2,-)
+// and needs no repacking, and the row validity of a load is one compare per ky
+struct C3Geom { int H, W, Ho, Wo, stride; uint32_t bytes; int tpr; uint32_t m_tpr, m_ho, m_howo, m_wo; };   // tpr = 32-pixel tiles per output row; m_* = floor(2^32 / d)
+// n / d for n < 2^32 with m = floor(2^32 / d): the estimate is q or q - 1
+__device__ __forceinline__ uint32_t udiv_m(uint32_t n, uint32_t d, uint32_t m) {
+    uint32_t q = __umulhi(n, m);
+    if (n - q * d >= d) ++q;
+    return q;
+}
+struct PwSplit { const bf16* x2; int K1; void* y2; int N1; const bf16* res; const float* rscale; int64_t per_sample; bf16* yplain; C3Geom c3; };
 // res (inference-epilogue kernel only): y = res + rscale[m / per_sample] * (x W^T + bias), rscale nullable -- Mlp.fc2 with the
 // residual add and the DropPath scale of MHCABlock folded in (reference nets/tcct.py:468)
 // STATS: also accumulate per-channel sum / sum of squares of pre_act(y) (y as stored) into stats[0..N) / stats[N..2N): the
 // train-mode BatchNorm statistics of the consumer (Conv2d_BN, DWConv2d_BN.pwconv, tran_*; reference nets/tcct.py:80,125,966-974)
-template <int NT, typename Tout, bool STATS, bool AFF>
+// C3: the first layers of both encoders (cnn.0 / stem.0, reference nets/tcct.py:873,674-681), 3 -> 32 channels, 3x3, pad 1, stride 1 / 2:
+// `x` is the 4-channel image, `w` the convolution weight as stored ([32][3][3][3] fp32), K = 48 (order above), an M-tile = 32 consecutive
+// pixels of ONE output row.  Per tile a lane issues six branch-free 8-byte buffer loads (outside the image / beyond the last tile = out-of-
+// range offset = zeros) two tiles ahead -- a load inside a branch makes the compiler wait for ALL outstanding loads at the top of every
+// tile; epilogues (coalescing transpose, BatchNorm statistics, inference affine) are the pointwise kernel's.
+template <int NT, typename Tout, bool STATS, bool AFF, bool C3 = false>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, Tout* __restrict__ y,
          int64_t M, int K, int N, int transposed, double* __restrict__ stats, int stat_pre, const float* __restrict__ aff,
@@ -46,12 +62,21 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int SW = 2 * K + 16;                 // LDS row stride (bytes)
     const int scr_off = (NT * 32 * SW + 15) & ~15;   // per-wave epilogue transpose scratch (4 x 2560 B) behind the weights
+    // bias of this block's NT*32 output channels behind the scratch: a global load of bias[] in the epilogue costs an s_waitcnt vmcnt(0) per
+    // tile, i.e. it also waits for every activation load issued ahead
+    float* sbias = reinterpret_cast<float*>(smem + scr_off + 4 * 2560);
     const int n_base = blockIdx.y * NT * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
+    for (int i = tid; i < NT * 32; i += PWB) sbias[i] = (bias && n_base + i < N) ? bias[n_base + i] : 0.f;
     // stage weights: rows n_base .. n_base+NT*32-1 (zero beyond N), bf16 [row][K]; eight elements per thread and iteration, read
     // along the contiguous direction of w (the element-wise loop with a division per element was most of a small-M launch)
-    if (!transposed) {
+    if (C3) {                   // k = 16*ky + 4*kx + ch  <-  w[n][ch][ky][kx]
+        for (int i = tid; i < 32 * 48; i += PWB) {
+            const int row = i / 48, k = i - row * 48, ky = k >> 4, kx = (k >> 2) & 3, ch = k & 3;
+            *reinterpret_cast<bf16*>(smem + row * SW + k * 2) = __float2bfloat16((kx < 3 && ch < 3) ? w[row * 27 + ch * 9 + ky * 3 + kx] : 0.f);
+        }
+    } else if (!transposed) {
         const int K8 = K >> 3;
         for (int i = tid; i < NT * 32 * K8; i += PWB) {
             const int row = i / K8, c8 = i - row * K8, n = n_base + row;
@@ -89,10 +114,46 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
 #pragma unroll
         for (int k = 0; k < 8; ++k) ss[a][k] = sq[a][k] = 0.f;
     const int KT = K >> 5;
-    const int64_t mtiles = (M + 31) >> 5;
-    for (int64_t mt = (int64_t)blockIdx.x * 4 + wave; mt < mtiles; mt += (int64_t)gridDim.x * 4) {
-        const int64_t m = mt * 32 + r;
-        const bool ok = m < M;
+    const int64_t mtiles = C3 ? (M / sp.c3.Wo) * sp.c3.tpr : (M + 31) >> 5;        // C3: (B*Ho output rows) x (tiles per row)
+    uint32_t c3q[12], c3p[12];          // the lane's six pixels (ky = 0..2; kx = 0,1 in the lower lane half, kx = 2 in the upper) of the next two tiles of this wave
+    const __amdgpu_buffer_rsrc_t c3r = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, C3 ? sp.c3.bytes : 0u, 0x00020000);
+    // C3 tile -> output row (n*Ho + oy) and 32-pixel block inside the row
+    auto c3_tile = [&](int64_t mt_, uint32_t& row, uint32_t& xb) {
+        row = udiv_m((uint32_t)mt_, (uint32_t)sp.c3.tpr, sp.c3.m_tpr);
+        xb = (uint32_t)mt_ - row * (uint32_t)sp.c3.tpr;
+    };
+    auto c3_load = [&](uint32_t (&cq)[12], int64_t mt_) {       // no branches (see above): a tile beyond the last one loads zeros
+        const bool live = mt_ < mtiles;
+        uint32_t row, xb;
+        c3_tile(live ? mt_ : 0, row, xb);
+        const uint32_t n_ = udiv_m(row, (uint32_t)sp.c3.Ho, sp.c3.m_ho), oy = row - n_ * (uint32_t)sp.c3.Ho;
+        const int ox = (int)xb * 32 + r;
+        const int iy0 = (int)oy * sp.c3.stride - 1, ix0 = ox * sp.c3.stride - 1;
+        const bool in = live & (ox < sp.c3.Wo);
+        const int pa = ix0 + 2 * hh, pb = ix0 + 1;
+        const bool va = in & ((unsigned)pa < (unsigned)sp.c3.W), vb = in & (hh == 0) & ((unsigned)pb < (unsigned)sp.c3.W);
+        const int base = ((int)(n_ * (uint32_t)sp.c3.H) + iy0) * sp.c3.W;          // first pixel of input row iy0 (only used where that row exists)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const bool rv = (unsigned)(iy0 + ky) < (unsigned)sp.c3.H;
+            const uint32_t offa = (va & rv) ? (uint32_t)(base + ky * sp.c3.W + pa) * 8u : 0x80000000u;
+            const uint32_t offb = (vb & rv) ? (uint32_t)(base + ky * sp.c3.W + pb) * 8u : 0x80000000u;
+            const uint2 ta = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(c3r, offa, 0, 0));
+            const uint2 tb = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(c3r, offb, 0, 0));
+            cq[4 * ky] = ta.x; cq[4 * ky + 1] = ta.y; cq[4 * ky + 2] = tb.x; cq[4 * ky + 3] = tb.y;
+        }
+    };
+    const int64_t mstep = (int64_t)gridDim.x * 4;
+    auto do_tile = [&](int64_t mt, uint32_t (&cq)[12]) {
+        int64_t mbase = mt * 32, mlim = M;           // first pixel of the tile, one past its last valid pixel
+        if (C3) {
+            uint32_t row, xb;
+            c3_tile(mt, row, xb);
+            mbase = (int64_t)row * sp.c3.Wo + xb * 32;
+            mlim = mt < mtiles ? (int64_t)(row + 1) * sp.c3.Wo : 0;        // the unrolled loop below may run one tile past the end: nothing valid in it
+        }
+        const int64_t m = mbase + r;
+        const bool ok = m < mlim;
         const int64_t mrow = ok ? m : 0;
         const int KA = sp.x2 ? sp.K1 : K;              // row length of the first source
         const bf16* xr = x + mrow * KA + 16 * hh;
@@ -102,6 +163,18 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[nt][k] = 0.f;
+        if (C3) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const bf16x8 bv = __builtin_bit_cast(bf16x8, make_uint4(cq[4 * i], cq[4 * i + 1], cq[4 * i + 2], cq[4 * i + 3]));
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(smem + r * SW + (16 * i + 8 * hh) * 2);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[0], 0, 0, 0);
+            }
+            // two tiles ahead (a gather is latency, not bandwidth), into the registers the MFMAs have just read: loading them into fresh
+            // registers while these are live costs a copy at the loop's back edge, i.e. a wait for every load in flight
+            __builtin_amdgcn_sched_barrier(0);
+            c3_load(cq, mt + 2 * mstep);
+        } else
         for (int t = 0; t < KT; ++t) {
             // channels 32t + 16hh + [0,16): two k-steps
             uint4 u0 = make_uint4(0, 0, 0, 0), u1 = u0;
@@ -133,7 +206,7 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                     const int co = n_base + nt * 32 + 8 * q + 4 * hh;
                     float v[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = acc[nt][4 * q + k] + (bias ? bias[co + k] : 0.f);
+                    for (int k = 0; k < 4; ++k) v[k] = acc[nt][4 * q + k] + sbias[nt * 32 + 8 * q + 4 * hh + k];
                     if (AFF) {
                         float a4[4], b4[4];
 #pragma unroll
@@ -149,8 +222,8 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const int p = (lane >> 2) + 16 * h2, cch = lane & 3;
                     const uint4 o = *reinterpret_cast<const uint4*>(sc + p * 80 + cch * 16);
-                    const int64_t mm = mt * 32 + p;
-                    if (mm < M) {
+                    const int64_t mm = mbase + p;
+                    if (mm < mlim) {
                         const int n0 = n_base + nt * 32;
                         bf16* dst = (sp.y2 && n0 >= sp.N1) ? reinterpret_cast<bf16*>(sp.y2) + mm * (N - sp.N1) + (n0 - sp.N1)
                                                            : reinterpret_cast<bf16*>(y) + mm * (sp.y2 ? sp.N1 : N) + n0;
@@ -171,7 +244,7 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                             const uint32_t wv[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                const float u0 = act_fwd(stat_pre, __uint_as_float(wv[k] << 16)), u1 = act_fwd(stat_pre, __uint_as_float(wv[k] & 0xffff0000u));
+                                const float u0 = act_fwd(C3 ? 0 : stat_pre, __uint_as_float(wv[k] << 16)), u1 = act_fwd(C3 ? 0 : stat_pre, __uint_as_float(wv[k] & 0xffff0000u));
                                 ss[nt][2 * k] += u0; sq[nt][2 * k] += u0 * u0; ss[nt][2 * k + 1] += u1; sq[nt][2 * k + 1] += u1 * u1;
                             }
                         }
@@ -187,7 +260,7 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                     const int co = n_base + nt * 32 + 8 * q + 4 * hh;
                     float v[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = acc[nt][4 * q + k] + ((bias && co + k < N) ? bias[co + k] : 0.f);
+                    for (int k = 0; k < 4; ++k) v[k] = acc[nt][4 * q + k] + sbias[nt * 32 + 8 * q + 4 * hh + k];
                     if (AFF) {
                         float a4[4], b4[4];
 #pragma unroll
@@ -203,6 +276,19 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                 }
             }
         }
+    };
+    const int64_t mt0 = (int64_t)blockIdx.x * 4 + wave;
+    if (C3) {
+        c3_load(c3q, mt0);
+        __builtin_amdgcn_sched_barrier(0);      // keep the order of first use: the loop's waits are the tighter of "entered" and "came round"
+        c3_load(c3p, mt0 + mstep);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int64_t mt = mt0; mt < mtiles; mt += 2 * mstep) {      // two register sets, no branch around the second tile (see c3_load)
+            do_tile(mt, c3q);
+            do_tile(mt + mstep, c3p);
+        }
+    } else {
+        for (int64_t mt = mt0; mt < mtiles; mt += mstep) do_tile(mt, c3q);
     }
     if (STATS) {
         __syncthreads();
@@ -312,7 +398,7 @@ static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y
         NT = nn;
     }
     const int gy = (ntiles + NT - 1) / NT;
-    size_t lds = (((size_t)NT * 32 * (2 * K + 16) + 15) & ~(size_t)15) + 4 * 2560;
+    size_t lds = (((size_t)NT * 32 * (2 * K + 16) + 15) & ~(size_t)15) + 4 * 2560 + (size_t)NT * 32 * 4;
     TCCT_CHECK(lds <= 160 * 1024, "pw_fwd: weights need %zu B of LDS", lds);
     const int64_t mtiles = (M + 31) / 32;
     int64_t gx = (mtiles + 3) / 4;
@@ -356,6 +442,40 @@ static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y
     TCCT_LAUNCH_OK();
 }
 
+/* Direct 3 -> 32 channel 3x3 convolution (pad 1, stride 1 or 2) of the 4-channel bf16 NHWC image x4 [B,H,W,4] (channel 3 is padding):
+ * y [B,Ho,Wo,32] bf16 = conv(x4[..., :3], w) + bias, w fp32 [32,3,3,3] as stored by nn.Conv2d (reference nets/tcct.py:873 `cnn.0`,
+ * :674-681 `stem.0`).  stats (nullable, fp64 [64], zero on entry): sum / sum of squares of pre_act(y) for the train-mode BatchNorm that
+ * follows; ab / pre_act / post_act (inference): y = post(a[c] * pre(conv + bias) + b[c]) as in tcct_pw_fwd_affine.  stats and ab exclude
+ * each other.  Replaces tcct_im2col3x3_c3 + tcct_pw_fwd*: the 32-channel patch tensor is never written. */
+extern "C" int tcct_c3_fwd(const void* x4, const float* w, const float* bias, void* y, int B, int H, int W, int stride, double* stats,
+                           int stat_pre, const float* ab, int pre_act, int post_act, tcct_stream_t stream) {
+    TCCT_CHECK(stride == 1 || stride == 2, "c3_fwd: stride %d", stride);
+    TCCT_CHECK(!(stats && (ab || pre_act || post_act)), "c3_fwd: fused statistics and the inference epilogue exclude each other");
+    TCCT_CHECK(!stats || stat_pre == 0, "c3_fwd: the fused statistics are those of the raw output (both first layers feed a BatchNorm directly)");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const int64_t M = (int64_t)B * Ho * Wo, inb = (int64_t)B * H * W * 8;
+    TCCT_CHECK(M > 0 && M < (1ll << 31) - 64 && inb < (1ll << 31), "c3_fwd: image too large for 32-bit pixel offsets (B=%d H=%d W=%d)", B, H, W);
+    const int tpr = (Wo + 31) / 32;
+    auto magic = [](uint32_t d) { return d == 1 ? 0xffffffffu : (uint32_t)((1ull << 32) / d); };
+    PwSplit sp{nullptr, 0, nullptr, 0, nullptr, nullptr, 1, nullptr,
+               C3Geom{H, W, Ho, Wo, stride, (uint32_t)inb, tpr, magic((uint32_t)tpr), magic((uint32_t)Ho), magic((uint32_t)(Ho * Wo)), magic((uint32_t)Wo)}};
+    const size_t lds = (((size_t)32 * (2 * 48 + 16) + 15) & ~(size_t)15) + 4 * 2560 + 32 * 4;
+    const int64_t mtiles = (int64_t)B * Ho * tpr;
+    int64_t gx = (mtiles + 3) / 4;
+    if (gx > 256 * 4) gx = 256 * 4;        // (512 .. 2048 blocks: 0.148 - 0.157 ms at bs 8, 800x1104 -- the count does not matter)
+    hipStream_t st = (hipStream_t)stream;
+    if (stats)
+        hipLaunchKernelGGL((k_pw_fwd<1, bf16, true, false, true>), dim3((unsigned)gx, 1), dim3(PWB), lds, st, (const bf16*)x4, w, bias, (bf16*)y, M, 48, 32, 0,
+                           stats, stat_pre, nullptr, 0, 0, sp);
+    else if (ab || pre_act || post_act)
+        hipLaunchKernelGGL((k_pw_fwd<1, bf16, false, true, true>), dim3((unsigned)gx, 1), dim3(PWB), lds, st, (const bf16*)x4, w, bias, (bf16*)y, M, 48, 32, 0,
+                           nullptr, 0, ab, pre_act, post_act, sp);
+    else
+        hipLaunchKernelGGL((k_pw_fwd<1, bf16, false, false, true>), dim3((unsigned)gx, 1), dim3(PWB), lds, st, (const bf16*)x4, w, bias, (bf16*)y, M, 48, 32, 0,
+                           nullptr, 0, nullptr, 0, 0, sp);
+    TCCT_LAUNCH_OK();
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 __device__ __forceinline__ bf16x8 tr_load8g(const unsigned char* base, int stride, int P, int chan0, int lane) {
     // 16 consecutive LDS pixel rows P..P+15 (row stride `stride` bytes); returns pixels P+8*(lane>>5)+j (j=0..7) of
@@ -374,10 +494,13 @@ __device__ __forceinline__ bf16x8 tr_load8g(const unsigned char* base, int strid
 #define PW_DS 10    // max dy staging slots per thread (128 px * 20 chunks / 256)
 // Tiles are staged through registers one tile ahead (all global loads of tile i+1 are in flight while tile i is multiplied),
 // fragments are read with immediate offsets from per-lane bases and the two chunks of a wave are double-buffered.
-template <int NT, int KTB>
+// C3 (NT = 1, KTB = 2): weight gradient of the direct 3-channel convolution (k_pw_fwd<..., C3>): x is the 4-channel image, the 128 x 48 patch
+// tile (k = 16*ky + 4*kx + ch, see C3Geom) is gathered into LDS -- thread = (pixel, 16-byte chunk q: ky = q/2, kx = 0,1 (q even) or 2,- (q odd)),
+// chunk index wave-uniform -- and dw is the stored [32][3][3][3] layout
+template <int NT, int KTB, bool C3 = false>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias, int64_t M,
-           int K, int N, int SX, int SD, const bf16* __restrict__ x2, int K1, int64_t ldy) {
+           int K, int N, int SX, int SD, const bf16* __restrict__ x2, int K1, int64_t ldy, C3Geom g3 = C3Geom{0, 0, 0, 0, 0, 0u, 0, 0u, 0u, 0u, 0u}) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sX = smem;
     unsigned char* sD = smem + PW_P * SX;
@@ -399,14 +522,41 @@ k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __res
 #pragma unroll
     for (int a = 0; a < NT; ++a) bsum[a] = 0.f;
     // staging slots: slot j of the x image = (pixel xp[j], chunk xq[j]); packed as pixel<<8 | chunk, -1 = unused
-    int xsl[PW_XS], dsl[PW_DS];
+    constexpr int DSN = C3 ? 2 : PW_DS;         // dy staging slots in use (C3: 128 px x 4 chunks / 256 threads)
+    static_assert(!C3 || (NT == 1 && KTB == 2), "C3 weight gradient: 32 outputs, 48 (-> 64) patch elements");
+    int xsl[PW_XS], dsl[DSN];
 #pragma unroll
-    for (int j = 0; j < PW_XS; ++j) { int i = tid + j * PWB; xsl[j] = i < PW_P * xc ? ((i / xc) << 8) | (i % xc) : -1; }
+    for (int j = 0; j < PW_XS; ++j) {
+        int i = tid + j * PWB; xsl[j] = i < PW_P * xc ? ((i / xc) << 8) | (i % xc) : -1;
+        if (C3) xsl[j] = j < 3 ? ((tid & 127) << 8) | (2 * j + (tid >> 7)) : -1;       // pixel tid % 128, chunk 2j + tid / 128: input row ky = j
+    }
+    const __amdgpu_buffer_rsrc_t c3r = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, C3 ? g3.bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t c3d = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, C3 ? (uint32_t)(M * 64) : 0u, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < PW_DS; ++j) { int i = tid + j * PWB; dsl[j] = i < PW_P * dc ? ((i / dc) << 8) | (i % dc) : -1; }
-    uint4 px[PW_XS], pd[PW_DS];
+    for (int j = 0; j < DSN; ++j) { int i = tid + j * PWB; dsl[j] = i < PW_P * dc ? ((i / dc) << 8) | (i % dc) : -1; }
+    uint4 px[PW_XS], pd[DSN];
     auto prefetch = [&](int64_t tile) {
         const int64_t m0 = tile * PW_P;
+        if (C3) {       // px[ky] = input pixels (ky, kx = 0,1) for tid < 128, (ky, kx = 2) + zeros for tid >= 128, of output pixel m0 + tid % 128
+            const uint32_t mm = (uint32_t)(m0 + (tid & 127));
+            const bool in = m0 + (tid & 127) < M;
+            const uint32_t n_ = udiv_m(mm, (uint32_t)(g3.Ho * g3.Wo), g3.m_howo), rem = mm - n_ * (uint32_t)(g3.Ho * g3.Wo);
+            const uint32_t oy = udiv_m(rem, (uint32_t)g3.Wo, g3.m_wo), ox = rem - oy * (uint32_t)g3.Wo;
+            const int iy0 = (int)oy * g3.stride - 1, ix0 = (int)ox * g3.stride - 1;
+            const int hi = tid >> 7;
+            const int pa = ix0 + 2 * hi, pb = ix0 + 1;
+            const bool va = in & ((unsigned)pa < (unsigned)g3.W), vb = in & (hi == 0) & ((unsigned)pb < (unsigned)g3.W);
+            const int base = ((int)(n_ * (uint32_t)g3.H) + iy0) * g3.W;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const bool rv = (unsigned)(iy0 + ky) < (unsigned)g3.H;
+                const uint32_t offa = (va & rv) ? (uint32_t)(base + ky * g3.W + pa) * 8u : 0x80000000u;
+                const uint32_t offb = (vb & rv) ? (uint32_t)(base + ky * g3.W + pb) * 8u : 0x80000000u;
+                const uint2 ta = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(c3r, offa, 0, 0));
+                const uint2 tb = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(c3r, offb, 0, 0));
+                px[ky] = make_uint4(ta.x, ta.y, tb.x, tb.y);
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < PW_XS; ++j) {
             px[j] = make_uint4(0, 0, 0, 0);
@@ -414,7 +564,11 @@ k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __res
                 px[j] = *reinterpret_cast<const uint4*>(xsrc + (m0 + (xsl[j] >> 8)) * ldx + (xsl[j] & 255) * 8);
         }
 #pragma unroll
-        for (int j = 0; j < PW_DS; ++j) {
+        for (int j = 0; j < DSN; ++j) {
+            if (C3) {           // the 128 x 64 B tile of dy is one contiguous span: no branch, rows >= M read as zeros through the descriptor
+                pd[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(c3d, (uint32_t)m0 * 64u + (uint32_t)(tid + j * PWB) * 16u, 0, 0));
+                continue;
+            }
             pd[j] = make_uint4(0, 0, 0, 0);
             if (dsl[j] >= 0 && m0 + (dsl[j] >> 8) < M)
                 pd[j] = *reinterpret_cast<const uint4*>(dy + (m0 + (dsl[j] >> 8)) * ldy + (dsl[j] & 255) * 8);
@@ -452,17 +606,24 @@ k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __res
     };
     const int64_t tiles = (M + PW_P - 1) / PW_P;
     int64_t tile = blockIdx.x;
+    if (C3)         // patch elements 48..63 are never gathered: zero once
+        for (int i = tid; i < PW_P * 2; i += PWB) *reinterpret_cast<uint4*>(sX + (i >> 1) * SX + (6 + (i & 1)) * 16) = make_uint4(0, 0, 0, 0);
     if (tile < tiles) prefetch(tile);
     for (; tile < tiles; tile += gridDim.x) {
         __syncthreads();
+        if (C3) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (xsl[j] >= 0) *reinterpret_cast<uint4*>(sX + (tid & 127) * SX + (xsl[j] & 255) * 16) = px[j];
+        } else
 #pragma unroll
         for (int j = 0; j < PW_XS; ++j)
             if (xsl[j] >= 0) *reinterpret_cast<uint4*>(sX + (xsl[j] >> 8) * SX + (xsl[j] & 255) * 16) = px[j];
 #pragma unroll
-        for (int j = 0; j < PW_DS; ++j)
+        for (int j = 0; j < DSN; ++j)
             if (dsl[j] >= 0) *reinterpret_cast<uint4*>(sD + (dsl[j] >> 8) * SD + (dsl[j] & 255) * 16) = pd[j];
         __syncthreads();
-        if (tile + gridDim.x < tiles) prefetch(tile + gridDim.x);
+        if (C3 || tile + gridDim.x < tiles) prefetch(tile + gridDim.x);        // C3: branch-free loads, a tile past the end reads zeros
         WF f0, f1;
         load_chunk(f0, wave);
         load_chunk(f1, wave + 4);
@@ -492,6 +653,10 @@ k_pw_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __res
     }
     for (int i = tid; i < NT * 32 * KTB * 32; i += PWB) {
         const int co = i / (KTB * 32), cl = i - co * (KTB * 32);
+        if (C3) {       // patch element 16*ky + 4*kx + ch -> w[co][ch][ky][kx]
+            if (cl < 48 && ((cl >> 2) & 3) < 3 && (cl & 3) < 3) atomicAdd(&dw[co * 27 + (cl & 3) * 9 + (cl >> 4) * 3 + ((cl >> 2) & 3)], red[i]);
+        }
+        else
         if (co < N && ci_base + cl < K) atomicAdd(&dw[(int64_t)co * K + ci_base + cl], red[i]);
     }
     if (dbias && blockIdx.y == 0) {
@@ -553,6 +718,31 @@ static int pw_wgrad_impl(const void* x, const void* x2, int K1, const void* dy, 
     if (KTB == 2) { switch (NT) { case 1: WL(1, 2); break; default: WL(2, 2); break; } }
     else { switch (NT) { case 1: WL(1, 1); break; case 2: WL(2, 1); break; case 3: WL(3, 1); break; case 4: WL(4, 1); break; default: WL(5, 1); break; } }
 #undef WL
+    TCCT_LAUNCH_OK();
+}
+
+
+/* weight / bias gradient of tcct_c3_fwd: dw fp32 [32,3,3,3] and dbias fp32 [32] (nullable), both overwritten (left to the caller's zero
+ * pool when that is active); x4 the 4-channel bf16 image, dy bf16 [B,Ho,Wo,32]. */
+extern "C" int tcct_c3_wgrad(const void* x4, const void* dy, float* dw, float* dbias, int B, int H, int W, int stride, tcct_stream_t stream) {
+    TCCT_CHECK(stride == 1 || stride == 2, "c3_wgrad: stride %d", stride);
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const int64_t M = (int64_t)B * Ho * Wo, inb = (int64_t)B * H * W * 8;
+    TCCT_CHECK(M > 0 && M * 64 < (1ll << 31) && inb < (1ll << 31), "c3_wgrad: image too large for 32-bit byte offsets (B=%d H=%d W=%d)", B, H, W);
+    hipStream_t st = (hipStream_t)stream;
+    if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * 32 * 27, st) != hipSuccess) { tcct_set_error("c3_wgrad: memset failed"); return -2; }
+    if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("c3_wgrad: memset failed"); return -2; }
+    const int SX = 192, SD = 64;
+    const size_t lds = (size_t)PW_P * (SX + SD);
+    const int64_t tiles = (M + PW_P - 1) / PW_P;
+    // every block ends with 864 atomics on the same 864 addresses, which serialise: >= 48 tiles per block, between one and four blocks per CU
+    // (bs 8, 800x1104: stride 1 0.238 / 0.162 / 0.145 ms with 256 / 512 / 1024 blocks; stride 2 0.059 / 0.059 / 0.083 ms)
+    int gx = (int)(tiles / 48 < 256 ? 256 : (tiles / 48 > 1024 ? 1024 : tiles / 48));
+    if (gx > tiles) gx = (int)tiles;
+    auto magic = [](uint32_t d) { return d == 1 ? 0xffffffffu : (uint32_t)((1ull << 32) / d); };
+    hipLaunchKernelGGL((k_pw_wgrad<1, 2, true>), dim3(gx, 1), dim3(PWB), lds, st, (const bf16*)x4, (const bf16*)dy, dw, dbias, M, 64, 32, SX, SD,
+                       (const bf16*)nullptr, 0, (int64_t)32,
+                       C3Geom{H, W, Ho, Wo, stride, (uint32_t)inb, (Wo + 31) / 32, magic((uint32_t)((Wo + 31) / 32)), magic((uint32_t)Ho), magic((uint32_t)(Ho * Wo)), magic((uint32_t)Wo)});
     TCCT_LAUNCH_OK();
 }
 

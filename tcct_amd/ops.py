@@ -827,10 +827,69 @@ def im2col3x3_c3(x4, stride=1):
     return out
 
 
+C3_DIRECT = os.environ.get('TCCT_C3_DIRECT', '1') != '0'       # =0: im2col + pointwise GEMM for the 3-channel first layers (A/B timing)
+
+
+class _ConvC3(torch.autograd.Function):
+    """cnn.0 / stem.0 (reference nets/tcct.py:873, :674-681): 3 -> 32 channels, 3x3, pad 1, stride 1 / 2, straight from the 4-channel image
+    (tcct_c3_fwd / tcct_c3_wgrad): the patch rows are gathered inside the MFMA kernels, the 32-channel im2col tensor (452 MB at the bench
+    shape, written once and read twice) does not exist.  The image gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x4, w, bias, stride, stats_box):
+        _chk(x4, w, bias)
+        B, H, W, _ = x4.shape
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = torch.empty((B, Ho, Wo, 32), device=x4.device, dtype=torch.bfloat16)
+        sums = None
+        if stats_box is not None:
+            sums = ZERO.get((64,), torch.float64, x4.device) if ZERO.active else torch.zeros(64, device=x4.device, dtype=torch.float64)
+            stats_box[1] = sums
+        lib.c3_fwd(x4, w, bias, y, B, H, W, stride, sums, stats_box[0] if stats_box is not None else 0, None, 0, 0)
+        ctx.save_for_backward(x4)
+        ctx.cfg = (stride, w, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x4, = ctx.saved_tensors
+        stride, w, bias = ctx.cfg
+        dy = _c(dy)
+        B, H, W, _ = x4.shape
+        with _wgrad_stream(_slot_written(w, bias), x4, dy):
+            dw = _grad_out(w, tuple(w.shape))
+            db = _grad_out(bias) if bias is not None else None
+            lib.c3_wgrad(x4, dy, dw, db, B, H, W, stride)
+        return None, _ret(dw, w), _ret(db, bias), None, None
+
+
+def _c3_direct_ok(x4, w):
+    B, H, W, C = x4.shape
+    return (C3_DIRECT and x4.dtype == torch.bfloat16 and C == 4 and tuple(w.shape) == (32, 3, 3, 3) and w.dtype == torch.float32
+            and w.is_contiguous() and B * H * W * 64 < 2 ** 31)         # 32-bit byte offsets into the image and into the 32-channel output
+
+
 def conv3x3_c3(x4, w, bias, stride=1, stats_pre=None, infer_bn=None, post_act=None):
-    """3-channel 3x3 conv (pad 1) as im2col + 32->32 pointwise GEMM: w [32,3,3,3] is re-laid out to [32, 27->32] by view ops
+    """3-channel 3x3 conv (pad 1).  bf16, 32 output channels: the direct kernels (_ConvC3).  Otherwise (fp32 parity mode, other widths)
+    im2col + 32->32 pointwise GEMM: w [32,3,3,3] is re-laid out to [32, 27->32] by view ops
     (differentiable plumbing on 864 elements), so forward and weight gradient both run on the MFMA pointwise kernels.
     infer_bn (inference only): eval-mode BatchNorm tuple folded, with post_act, into the GEMM epilogue (see conv_bn_act)."""
+    if _c3_direct_ok(x4, w):
+        _chk(x4)
+        if infer_bn is not None:
+            if torch.is_grad_enabled() and w.requires_grad:
+                raise TcctError('conv3x3_c3(infer_bn=...) is inference-only (call it under torch.no_grad())')
+            B, H, W, _ = x4.shape
+            ab = torch.empty(64, device=x4.device, dtype=torch.float32)
+            lib.bn_eval_ab(32, infer_bn[0], infer_bn[1], float(infer_bn[4]), infer_bn[2], infer_bn[3], torch.empty(64, device=x4.device, dtype=torch.float32), ab)
+            y = torch.empty((B, (H - 1) // stride + 1, (W - 1) // stride + 1, 32), device=x4.device, dtype=torch.bfloat16)
+            lib.c3_fwd(x4, w, bias, y, B, H, W, stride, None, 0, ab, 0, ACT[post_act])
+            return y
+        box = [ACT[stats_pre], None] if stats_pre is not None else None
+        y = _ConvC3.apply(x4, w, bias, stride, box)
+        if box is not None and box[1] is not None:
+            y._bn_sums = (box[1], box[0])
+        return y
     w2 = torch.nn.functional.pad(w.permute(0, 2, 3, 1).reshape(w.shape[0], 27), (0, 5)).contiguous()
     if infer_bn is not None:
         return conv_bn_act(im2col3x3_c3(x4, stride), w2.view(w.shape[0], 32, 1, 1), bias, bn=infer_bn, post_act=post_act)

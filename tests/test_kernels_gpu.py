@@ -71,8 +71,43 @@ def test_conv2d(dt, cfg):
 
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('stride', [1, 2])
+@pytest.mark.parametrize('nhw', [(2, 18, 26), (3, 17, 45), (1, 5, 131)])
+def test_first_layer_direct_conv_with_statistics_and_inference_epilogue(dt, stride, nhw):
+    """cnn[0] / stem[0] (reference nets/tcct.py:873, :674-681): the direct 3-channel kernels (bf16; fp32 takes im2col + GEMM) with the fused
+    BatchNorm statistics, the inference epilogue and a bias-free layer; odd extents leave partial 32- and 128-pixel tiles"""
+    from tcct_amd import ops
+    N, H, W = nhw
+    x = rnd(N, 3, H, W, dt=dt)
+    w = (rnd(32, 3, 3, 3, seed=1) / 27 ** 0.5)
+    xd = nhwc(F.pad(x, (0, 0, 0, 0, 0, 1)), dt)
+    wd = w.cuda().requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, 1)
+    yd = ops.conv3x3_c3(xd, wd, None, stride, stats_pre='none')
+    t = tol(dt)
+    torch.testing.assert_close(nchw(yd), y, **t)
+    if dt == torch.bfloat16:
+        sums, pre = yd._bn_sums
+        ys = yd.detach().float().reshape(-1, 32).double()            # statistics of the values as stored
+        torch.testing.assert_close(sums[:32], ys.sum(0), rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(sums[32:], (ys * ys).sum(0), rtol=1e-4, atol=1e-3)
+    gy = rnd(*y.shape, seed=3, dt=dt)
+    yd.backward(nhwc(gy, dt))
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, None, stride, 1).backward(gy)
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, wr.grad.abs().max().item()))
+    # inference: BatchNorm (running statistics) + Hardswish in the epilogue
+    g, b_, rm, rv = rnd(32, seed=4).abs() + 0.5, rnd(32, seed=5), rnd(32, seed=6) * 0.1, rnd(32, seed=7).abs() + 0.5
+    ref = F.hardswish(F.batch_norm(y, rm, rv, g, b_, False, 0.1, 1e-5))
+    with torch.no_grad():
+        out = ops.conv3x3_c3(xd, wd, None, stride, infer_bn=(g.cuda(), b_.cuda(), rm.cuda(), rv.cuda(), 1e-5), post_act='hswish')
+    torch.testing.assert_close(nchw(out), ref, **t)
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('stride', [1, 2])
 def test_first_layer_im2col_conv(dt, stride):
-    """3-channel 3x3 conv as im2col + pointwise GEMM (cnn[0], stem[0]) incl. the weight-gradient remapping"""
+    """3-channel 3x3 conv (cnn[0], stem[0]) against F.conv2d incl. the weight / bias gradients: bf16 = the direct kernels
+    (tcct_c3_fwd / tcct_c3_wgrad), fp32 = im2col + pointwise GEMM with the weight-gradient remapping"""
     from tcct_amd import ops
     N, H, W = 2, 18, 26
     x = rnd(N, 3, H, W, dt=dt)

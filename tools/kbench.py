@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tcct_amd import ops
-from tcct_amd._lib import lib
+from tcct_amd._lib import lib, BF16
 
 B, H, W = 8, 800, 1104
 dt = torch.bfloat16
@@ -112,7 +112,7 @@ def dw_bench():
         print(f'dw {N}x{H}x{W}x{C} s{st}: fwd {m1:.3f} ms {(gx + gy) / m1 * 1e3:.0f} GB/s | dgrad {m2:.3f} ms {(gx + gy) / m2 * 1e3:.0f} GB/s | wgrad {m3:.3f} ms {(gx + gy) / m3 * 1e3:.0f} GB/s')
 
 
-if __name__ == "__main__" and not ({"pw", "bwd", "ln"} & set(sys.argv[1:])):
+if __name__ == "__main__" and not ({"pw", "bwd", "ln", "c3"} & set(sys.argv[1:])):
     if 'dw' in sys.argv[1:]:
         dw_bench()
         sys.exit(0)
@@ -183,3 +183,33 @@ def ln_bench():
 
 if 'ln' in sys.argv[1:]:
     ln_bench()
+
+
+def c3_bench():
+    """first layers: direct 3 -> 32 channel 3x3 convolution (tcct_c3_fwd / tcct_c3_wgrad) against im2col + pointwise GEMM"""
+    for (B, H, W, st) in [(8, 800, 1104, 1), (8, 800, 1104, 2)]:
+        Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+        x4 = torch.randn(B, H, W, 4, device='cuda').to(torch.bfloat16)
+        w = torch.randn(32, 3, 3, 3, device='cuda') * 0.2
+        b = torch.randn(32, device='cuda')
+        y = torch.empty(B, Ho, Wo, 32, device='cuda', dtype=torch.bfloat16)
+        dy = torch.randn_like(y)
+        sums = torch.zeros(64, device='cuda', dtype=torch.float64)
+        dw, db = torch.zeros_like(w), torch.zeros_like(b)
+        t1 = timeit(lambda: lib.c3_fwd(x4, w, b, y, B, H, W, st, sums, 0, None, 0, 0))
+        t2 = timeit(lambda: lib.c3_fwd(x4, w, b, y, B, H, W, st, None, 0, None, 0, 0))
+        t3 = timeit(lambda: lib.c3_wgrad(x4, dy, dw, db, B, H, W, st))
+        pat = torch.empty(B, Ho, Wo, 32, device='cuda', dtype=torch.bfloat16)
+        w2 = torch.randn(32, 32, device='cuda') * 0.2
+        dw2 = torch.zeros_like(w2)
+        M = B * Ho * Wo
+        t4 = timeit(lambda: lib.im2col3x3_c3(x4, pat, B, H, W, st, BF16))
+        t5 = timeit(lambda: lib.pw_fwd_bnstats(pat, w2, b, y, M, 32, 32, sums, 0))
+        t6 = timeit(lambda: lib.pw_wgrad(pat, dy, dw2, db, M, 32, 32))
+        gb = y.numel() * 2 / 1e9
+        print(f'c3 {B}x{H}x{W} stride {st}: fwd+stats {t1:.3f} ms ({gb / t1 * 1e3:.0f} GB/s written) | fwd {t2:.3f} | wgrad {t3:.3f} ms || '
+              f'im2col {t4:.3f} + gemm+stats {t5:.3f} | gemm wgrad {t6:.3f}')
+
+
+if 'c3' in sys.argv[1:]:
+    c3_bench()
