@@ -91,6 +91,18 @@ int tcct_bn_apply_train(const void* x, const void* res, void* y, int64_t M, int 
                         const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, float* mean_rstd, float* ab, int pre_act, int post_act, int dtype,
                         tcct_stream_t stream);
+/* The last BatchNorm of an encoder level and the `self.pool` behind it (reference nets/tcct.py:820-823 block5, :876-884 CrossResNet.forward:
+ * the level's output is kept AND pooled) in one pass: z [N,H,W,C] = post(BN_train(pre(x))), pooled [N,H/2,W/2,C] = MaxPool2d(2)(z), amax
+ * [N,H/2,W/2,C/4] bytes = positions of the window maxima (2 bits per channel) for the backward call; sums, running statistics, mean_rstd,
+ * ab as in tcct_bn_apply_train.  Even H, W; C/4 must divide 256. */
+int tcct_bn_pool_fwd_train(const void* x, void* z, void* pooled, void* amax, int N, int H, int W, int C, const double* sums, const float* gamma,
+                           const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, float* mean_rstd, float* ab, int pre_act, int post_act, int dtype,
+                           tcct_stream_t stream);
+/* its backward: dx = BatchNorm_backward(dskip + MaxPool_backward(dpool)) -- what autograd computes for the two consumers of z -- without
+ * writing that sum (dskip nullable); sums fp64 [2C] scratch, dgamma / dbeta fp32 [C] overwritten */
+int tcct_bn_pool_bwd(const void* x, const void* dpool, const void* dskip, const void* amax, void* dx, int N, int H, int W, int C, const float* mean_rstd,
+                     const float* ab, int pre_act, int post_act, double* sums, float* dgamma, float* dbeta, int dtype, tcct_stream_t stream);
 /* y = post(a*pre(x)+b) + res (res, y like x): the normalisation pass with the residual / branch sum that follows it folded in
  * (InvRes `x + conv2(f)`, nets/tcct.py:563-572; `tran_vit(x) + tran_cnn(c)`, :1012-1015) */
 int tcct_bn_apply_add(const void* x, const void* res, void* y, int64_t M, int C, const float* ab, int pre_act, int post_act, int dtype,

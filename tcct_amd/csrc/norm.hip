@@ -319,6 +319,212 @@ extern "C" int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_
     TCCT_LAUNCH_OK();
 }
 
+// ------------------------------------------------------------------ train-mode BatchNorm + MaxPool2d(2) (CrossResNet levels 0-3)
+// The last BatchNorm of an encoder level is followed by `self.pool` AND kept as the level's output (reference nets/tcct.py:876-884, block5 at
+// :820-823).  One pass writes both: z = post(BN(pre(x))) (full size) and pooled = maxpool2(z), plus one byte per (window, 4 channels) with
+// the positions of the maxima (2 bits per channel; ties and NaNs resolve like tcct_maxpool2_*: first maximum in (0,0),(0,1),(1,0),(1,1)
+// order).  The backward pass never materialises the gradient of z: dz = dskip + scatter(dpool) is rebuilt from its two sources inside the
+// BatchNorm reduction and inside the BatchNorm apply.  Against bn_apply + maxpool2_fwd | maxpool2_bwd_add + bn_bwd_reduce + bn_bwd_apply
+// that is 2.25 instead of 3.25 and 5.5 instead of 8.25 tensor passes.  Thread = (window column, 4-channel vector) as in k_maxpool2; C/4
+// divides the block size, so a thread's channels are fixed.  These kernels do ~2x the arithmetic per byte of the plain BatchNorm kernels:
+// the activation kinds are template constants for the combination the network uses (PRE/POST = -1: run-time kinds; the first version,
+// with act_fwd's per-element switch and the window maxima recomputed in both backward kernels, ran at 2.3 - 2.9 TB/s and was SLOWER than
+// the three separate kernels: 0.94 vs 0.68 ms at level 0).
+__device__ __forceinline__ float rnd_as(float v, const bf16*) { return __bfloat162float(__float2bfloat16(v)); }
+__device__ __forceinline__ float rnd_as(float v, const float*) { return v; }
+template <int KIND> __device__ __forceinline__ float act_grad_c(float x) {
+    if (KIND == TCCT_ACT_LRELU) return x > 0.f ? 1.f : 0.01f;
+    if (KIND == TCCT_ACT_HSWISH) return x < -3.f ? 0.f : (x <= 3.f ? (2.f * x + 3.f) * (1.f / 6.f) : 1.f);
+    if (KIND == TCCT_ACT_NONE) return 1.f;
+    return act_grad(KIND, x);
+}
+template <int K> __device__ __forceinline__ float actf(int rt, float x) { return K < 0 ? act_fwd(rt, x) : act_c<(K < 0 ? 0 : K)>(x); }
+template <int K> __device__ __forceinline__ float actg(int rt, float x) { return K < 0 ? act_grad(rt, x) : act_grad_c<(K < 0 ? 0 : K)>(x); }
+
+template <typename T, int PRE, int POST>
+__global__ void k_bn_pool_fwd(const T* __restrict__ x, T* __restrict__ zout, T* __restrict__ pooled, unsigned char* __restrict__ amax, int N, int H,
+                              int W, int C, int pre_act, int post_act, BnTrain tr) {
+    const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Wo * C4) return;
+    const int wo = i / C4, c0 = (i - wo * C4) * 4;
+    const int64_t M = (int64_t)N * H * W;
+    float a_[4], b_[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k;
+        float mean, rstd; double var;
+        bn_coeff(tr.sums, M, C, c, tr.gamma[c], tr.beta[c], tr.eps, mean, rstd, a_[k], b_[k], var);
+        if (blockIdx.y == 0 && wo == 0) {               // one thread per channel publishes the coefficients and moves the running stats
+            tr.mean_rstd[c] = mean; tr.mean_rstd[C + c] = rstd; tr.ab_out[c] = a_[k]; tr.ab_out[C + c] = b_[k];
+            if (tr.running_mean) {
+                const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+                tr.running_mean[c] = (1.f - tr.momentum) * tr.running_mean[c] + tr.momentum * mean;
+                tr.running_var[c] = (1.f - tr.momentum) * tr.running_var[c] + tr.momentum * (float)unb;
+            }
+            if (c == 0 && tr.nbt) *tr.nbt += 1;
+        }
+    }
+    for (int row = blockIdx.y; row < N * Ho; row += gridDim.y) {
+        const int n = row / Ho, ho = row - n * Ho;
+        const int64_t b00 = (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + c0;
+        const int64_t offs[4] = {b00, b00 + C, b00 + (int64_t)W * C, b00 + (int64_t)W * C + C};
+        f4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ld4(x + offs[q]);
+        f4 m;
+        unsigned am = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float z = rnd_as(actf<POST>(post_act, a_[k] * actf<PRE>(pre_act, v[q].v[k]) + b_[k]), (const T*)nullptr);
+                v[q].v[k] = z;
+                if (q == 0) m.v[k] = z;
+                else if (z > m.v[k] || z != z) { m.v[k] = z; am = (am & ~(3u << (2 * k))) | ((unsigned)q << (2 * k)); }
+            }
+            st4(zout + offs[q], v[q]);
+        }
+        const int64_t p = (int64_t)row * Wo + wo;
+        st4(pooled + p * C + c0, m);
+        amax[p * C4 + (c0 >> 2)] = (unsigned char)am;
+    }
+}
+// sums[0..C) += sum dz', sums[C..2C) += sum dz' * xhat with dz' = (dskip + scatter(dpool)) * post'(.)   (what k_bn_bwd_reduce computes from a stored dz)
+template <typename T, int PRE, int POST>
+__global__ void __launch_bounds__(NBR) k_bn_pool_bwd_reduce(const T* __restrict__ x, const T* __restrict__ dpool, const T* __restrict__ dskip,
+                                                            const unsigned char* __restrict__ amax, int N, int H, int W, int C,
+                                                            const float* __restrict__ mean_rstd, const float* __restrict__ ab, int pre_act,
+                                                            int post_act, double* __restrict__ sums) {
+    __shared__ float sm[NBR * 4];
+    const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+    const int R = NBR / C4;
+    const int t = threadIdx.x;
+    const bool active = t < R * C4;
+    const int cv = t % C4, r = t / C4, c0 = cv * 4;
+    float s[4], q2[4], mu[4], rs[4], a_[4], b_[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        s[k] = q2[k] = 0.f;
+        const int c = active ? c0 + k : 0;
+        mu[k] = mean_rstd[c]; rs[k] = mean_rstd[C + c]; a_[k] = ab[c]; b_[k] = ab[C + c];
+    }
+    if (active) {
+        for (int row = blockIdx.x; row < N * Ho; row += gridDim.x) {
+            const int n = row / Ho, ho = row - n * Ho;
+            for (int wo = r; wo < Wo; wo += R) {
+                const int64_t b00 = (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + c0;
+                const int64_t offs[4] = {b00, b00 + C, b00 + (int64_t)W * C, b00 + (int64_t)W * C + C};
+                f4 v[4], e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] = ld4(x + offs[q]); e[q] = dskip ? ld4(dskip + offs[q]) : f4zero(); }
+                const int64_t p = (int64_t)row * Wo + wo;
+                const f4 g = ld4(dpool + p * C + c0);
+                const unsigned am = amax[p * C4 + cv];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float u = actf<PRE>(pre_act, v[q].v[k]);
+                        float dz = e[q].v[k] + (((am >> (2 * k)) & 3u) == (unsigned)q ? g.v[k] : 0.f);
+                        if (POST != TCCT_ACT_NONE) dz *= actg<POST>(post_act, a_[k] * u + b_[k]);
+                        s[k] += dz; q2[k] += dz * (u - mu[k]) * rs[k];
+                    }
+            }
+        }
+    }
+    bn_block_reduce2<4>(sm, s, q2, t, C, C4, R, sums);
+}
+template <typename T, int PRE, int POST>
+__global__ void k_bn_pool_bwd_apply(const T* __restrict__ x, const T* __restrict__ dpool, const T* __restrict__ dskip,
+                                    const unsigned char* __restrict__ amax, T* __restrict__ dx, int N, int H, int W, int C,
+                                    const float* __restrict__ mean_rstd, const float* __restrict__ ab, const double* __restrict__ sums,
+                                    int pre_act, int post_act, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < C) { dbeta[threadIdx.x] = (float)sums[threadIdx.x]; dgamma[threadIdx.x] = (float)sums[C + threadIdx.x]; }
+    if (i >= Wo * C4) return;
+    const int wo = i / C4, c0 = (i - wo * C4) * 4;
+    const float invM = 1.f / (float)((int64_t)N * H * W);
+    float a_[4], b_[4], mu[4], rs[4], s1[4], s2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k;
+        a_[k] = ab[c]; b_[k] = ab[C + c]; mu[k] = mean_rstd[c]; rs[k] = mean_rstd[C + c];
+        s1[k] = (float)sums[c] * invM; s2[k] = (float)sums[C + c] * invM;
+    }
+    for (int row = blockIdx.y; row < N * Ho; row += gridDim.y) {
+        const int n = row / Ho, ho = row - n * Ho;
+        const int64_t b00 = (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + c0;
+        const int64_t offs[4] = {b00, b00 + C, b00 + (int64_t)W * C, b00 + (int64_t)W * C + C};
+        f4 v[4], e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = ld4(x + offs[q]); e[q] = dskip ? ld4(dskip + offs[q]) : f4zero(); }
+        const int64_t p = (int64_t)row * Wo + wo;
+        const f4 g = ld4(dpool + p * C + c0);
+        const unsigned am = amax[p * C4 + (c0 >> 2)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float u = actf<PRE>(pre_act, v[q].v[k]);
+                float dz = e[q].v[k] + (((am >> (2 * k)) & 3u) == (unsigned)q ? g.v[k] : 0.f);
+                if (POST != TCCT_ACT_NONE) dz *= actg<POST>(post_act, a_[k] * u + b_[k]);
+                const float xh = (u - mu[k]) * rs[k];
+                o.v[k] = a_[k] * (dz - s1[k] - xh * s2[k]);
+                if (PRE != TCCT_ACT_NONE) o.v[k] *= actg<PRE>(pre_act, v[q].v[k]);
+            }
+            st4(dx + offs[q], o);
+        }
+    }
+}
+static bool bn_pool_ok(int N, int H, int W, int C) { return C % 4 == 0 && C >= 4 && C <= NB && NB % (C / 4) == 0 && H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2 && N >= 1; }
+static inline dim3 bn_pool_grid(int per_row, int64_t rows) {
+    const int gx = (per_row + NB - 1) / NB;
+    int64_t gy = ((1 << 14) + gx - 1) / gx;
+    if (gy > rows) gy = rows;
+    if (gy > 65535) gy = 65535;
+    if (gy < 1) gy = 1;
+    return dim3((unsigned)gx, (unsigned)gy);
+}
+// the network's combination (LeakyReLU in front, nothing behind) with compile-time kinds, anything else with run-time kinds
+#define BN_POOL_KINDS(CALL) do { if (pre_act == TCCT_ACT_LRELU && post_act == TCCT_ACT_NONE) { constexpr int PRE = TCCT_ACT_LRELU, POST = TCCT_ACT_NONE; CALL; } \
+                                 else { constexpr int PRE = -1, POST = -1; CALL; } } while (0)
+/* z [N,H,W,C] = post(BN_train(pre(x))), pooled [N,H/2,W/2,C] = MaxPool2d(2)(z) and amax [N,H/2,W/2,C/4] (one byte per window and 4 channels:
+ * 2-bit position of the maximum per channel, for tcct_bn_pool_bwd) in one pass; statistics finalisation as tcct_bn_apply_train (sums fp64
+ * [2C] of pre(x); running stats / num_batches_tracked updated, mean_rstd [2C] and ab [2C] written for the backward kernels).
+ * Needs even H, W and C/4 dividing 256 (C = 32, 64, 128, 256 ...).  Reference nets/tcct.py:820-823 (block5) + :876-884 (`self.pool`). */
+extern "C" int tcct_bn_pool_fwd_train(const void* x, void* z, void* pooled, void* amax, int N, int H, int W, int C, const double* sums,
+                                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                      float* running_var, int64_t* num_batches_tracked, float* mean_rstd, float* ab, int pre_act, int post_act,
+                                      int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(bn_pool_ok(N, H, W, C), "bn_pool_fwd_train: needs even H, W and C/4 dividing 256 (got %d,%d,%d)", H, W, C);
+    TCCT_CHECK(sums && gamma && beta && mean_rstd && ab && amax, "bn_pool_fwd_train: NULL argument");
+    BnTrain tr{sums, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean_rstd, ab};
+    BN_POOL_KINDS(TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_pool_fwd<T, PRE, POST>), bn_pool_grid((W / 2) * (C / 4), (int64_t)N * (H / 2)), dim3(NB), 0,
+                                                          (hipStream_t)stream, (const T*)x, (T*)z, (T*)pooled, (unsigned char*)amax, N, H, W, C, pre_act, post_act, tr)));
+    TCCT_LAUNCH_OK();
+}
+/* backward of the pair: dx = BN_backward(dskip + maxpool2_backward(dpool)) without materialising that sum; dskip nullable (the full-size
+ * output had no other consumer); amax from the forward call.  sums fp64 [2C] is scratch (overwritten); dgamma / dbeta fp32 [C] overwritten. */
+extern "C" int tcct_bn_pool_bwd(const void* x, const void* dpool, const void* dskip, const void* amax, void* dx, int N, int H, int W, int C,
+                                const float* mean_rstd, const float* ab, int pre_act, int post_act, double* sums, float* dgamma, float* dbeta,
+                                int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(bn_pool_ok(N, H, W, C), "bn_pool_bwd: needs even H, W and C/4 dividing 256 (got %d,%d,%d)", H, W, C);
+    TCCT_CHECK(dpool != nullptr && amax != nullptr, "bn_pool_bwd: dpool / amax is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (!tcct_skip_zero_fill() && hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { tcct_set_error("bn_pool_bwd: memset failed"); return -2; }
+    const int64_t rows = (int64_t)N * (H / 2);
+    const int gr = rows < 512 ? (int)rows : 512;
+    BN_POOL_KINDS(TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_pool_bwd_reduce<T, PRE, POST>), dim3(gr), dim3(NBR), 0, st, (const T*)x, (const T*)dpool,
+                                                          (const T*)dskip, (const unsigned char*)amax, N, H, W, C, mean_rstd, ab, pre_act, post_act, sums)));
+    BN_POOL_KINDS(TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_pool_bwd_apply<T, PRE, POST>), bn_pool_grid((W / 2) * (C / 4), rows), dim3(NB), 0, st, (const T*)x,
+                                                          (const T*)dpool, (const T*)dskip, (const unsigned char*)amax, (T*)dx, N, H, W, C, mean_rstd, ab, sums,
+                                                          pre_act, post_act, dgamma, dbeta)));
+    TCCT_LAUNCH_OK();
+}
+
 // ------------------------------------------------------------------ LayerNorm over C (<= 192), 16 lanes per row
 #define LN_MAXCH 3   // vec4 chunks per lane: C <= 16*4*3 = 192
 // LN_TOK tokens per 16-lane group and iteration.  Measured at stage 0 (1 766 400 tokens x 64 channels, same box): 1 token 0.119 ms,

@@ -64,7 +64,10 @@ class CrossCNNBlock(nn.Module):
     def _ksize(ksize):
         return ksize
 
-    def forward(self, x):
+    def forward(self, x, pool=False):
+        """pool=True: return (maxpool2(out), out') -- the level's output also feeds `self.pool` (CrossResNet.forward, reference tcct.py:876-884)
+        and in training the last BatchNorm and the pooling share one pass (ops.batchnorm_maxpool2_fork); out' is the alias the other
+        consumers read"""
         tr = self.training
         m0 = self.block12[0]       # x feeds both branches: block34 reads the alias, its gradient is added in block12[0]'s dgrad epilogue
         a0, x2 = ops.conv2d_fork(x, m0.weight, m0.bias, m0.stride[0], tuple(m0.padding))
@@ -81,7 +84,16 @@ class CrossCNNBlock(nn.Module):
                 m1, m2 = self.block12[3], self.block34[4]
                 c = ops.bn2_add_act_eval(a, (m1.weight, m1.bias, m1.running_mean, m1.running_var, m1.eps),
                                          b, (m2.weight, m2.bias, m2.running_mean, m2.running_var, m2.eps))
-        return _conv_bn(self.block5[0], self.block5[2], c, pre='lrelu')
+        if not pool:
+            return _conv_bn(self.block5[0], self.block5[2], c, pre='lrelu')
+        mc, mb = self.block5[0], self.block5[2]
+        if mb.training:
+            y = _conv(mc, c, stats_pre='lrelu')
+            if ops.bn_pool_ok(y, True):
+                return ops.batchnorm_maxpool2_fork(y, mb.weight, mb.bias, mb.running_mean, mb.running_var, mb.num_batches_tracked, eps=mb.eps,
+                                                   momentum=mb.momentum, pre_act='lrelu')
+            return ops.maxpool2_fork(_bn(mb, y, pre='lrelu'))
+        return ops.maxpool2_fork(_conv_bn(mc, mb, c, pre='lrelu'))
 
 
 class PlainCNNBlock(CrossCNNBlock):
@@ -122,13 +134,13 @@ class CrossResNet(nn.Module):
             x = ops.conv3x3_c3(x, self.cnn[0].weight, self.cnn[0].bias, 1, infer_bn=(m.weight, m.bias, m.running_mean, m.running_var, m.eps))
         n = len(self.path_estan) if levels is None else int(levels)
         for i, enc in enumerate(self.path_estan[:n]):
-            x = enc(x)
             if i + 1 < n:               # the reference also pools after the last level; that result is unused
-                x, skip = ops.maxpool2_fork(x)      # skip aliases the level's output: its gradient is added inside the pooling backward
+                x, skip = enc(x, pool=True)         # skip aliases the level's output: its gradient is added inside the pooling backward
                 xs.append(skip)
                 if i == 0:              # data-parallel runs: the backward pass crossing this edge has finished levels 1-4 (tcct_amd/dist.py)
                     x = ops.grad_mark(x, 'deep')
             else:
+                x = enc(x)
                 xs.append(x)
             yield i
 

@@ -998,6 +998,70 @@ class _BatchNorm(torch.autograd.Function):
         return dx, _ret(dg, gamma), _ret(db, ctx.beta_param), None, None, None, None, None, None, None, None, (dy if ctx.has_res else None)
 
 
+BN_POOL_FUSE = os.environ.get('TCCT_BN_POOL', '1') != '0'      # =0: BatchNorm pass, then the pooling pass (A/B timing)
+
+
+class _BnPoolFork(torch.autograd.Function):
+    """(maxpool2(z), z) with z = post(BN_train(pre(x))) from ONE pass over x (tcct_bn_pool_fwd_train); in the backward pass the gradient of
+    z -- the skip consumers' gradient plus the pooling scatter -- is never written: both BatchNorm backward kernels rebuild it from its
+    two sources (tcct_bn_pool_bwd).  Encoder levels 0-3 (reference nets/tcct.py:820-823, :876-884)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, eps, momentum, pre, post):
+        ctx.set_materialize_grads(False)
+        _chk(x, gamma, beta)
+        N, H, W, C = x.shape
+        dc = dtype_code(x.dtype)
+        fused = getattr(x, '_bn_sums', None)
+        if fused is not None and fused[1] == pre and fused[0].numel() == 2 * C:
+            sums = fused[0]
+        else:
+            sums = ZERO.get((2 * C,), torch.float64, x.device)
+            lib.bn_stats(x, N * H * W, C, pre, sums, dc)
+        mean_rstd = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        ab = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        z = torch.empty_like(x)
+        pooled = torch.empty((N, H // 2, W // 2, C), device=x.device, dtype=x.dtype)
+        amax = torch.empty((N, H // 2, W // 2, C // 4), device=x.device, dtype=torch.uint8)        # 2-bit window positions of the maxima
+        lib.bn_pool_fwd_train(x, z, pooled, amax, N, H, W, C, sums, gamma, beta, eps, momentum, rm, rv, nbt, mean_rstd, ab, pre, post, dc)
+        ctx.save_for_backward(x, mean_rstd, ab, amax)
+        ctx.cfg = (pre, post, gamma, beta)
+        return pooled, z
+
+    @staticmethod
+    def backward(ctx, dpool, dskip):
+        x, mean_rstd, ab, amax = ctx.saved_tensors
+        pre, post, gamma, beta = ctx.cfg
+        N, H, W, C = x.shape
+        dc = dtype_code(x.dtype)
+        if dpool is None and dskip is None:
+            return (None,) * 10
+        if dpool is None:           # only the full-size output was used: a plain BatchNorm backward
+            dpool = ZERO.get((N, H // 2, W // 2, C), x.dtype, x.device)
+        dpool = _as(dpool, x.dtype)
+        if dskip is not None:
+            dskip = _as(dskip, x.dtype)
+        sums = ZERO.get((2 * C,), torch.float64, x.device)
+        dx = torch.empty_like(x)
+        dg = _grad_out(gamma) if ZERO.active and getattr(gamma, '_grad_slot', None) is not None else torch.empty(C, device=x.device, dtype=torch.float32)
+        db = _grad_out(beta) if ZERO.active and getattr(beta, '_grad_slot', None) is not None else torch.empty(C, device=x.device, dtype=torch.float32)
+        lib.bn_pool_bwd(x, dpool, dskip, amax, dx, N, H, W, C, mean_rstd, ab, pre, post, sums, dg, db, dc)
+        return dx, _ret(dg, gamma), _ret(db, beta), None, None, None, None, None, None, None
+
+
+def bn_pool_ok(x, training):
+    """shapes the fused BatchNorm + MaxPool2d(2) kernels take (train mode, gradients wanted): even extents, C/4 dividing 256"""
+    N, H, W, C = x.shape
+    return (BN_POOL_FUSE and training and torch.is_grad_enabled() and x.requires_grad and C % 4 == 0 and 256 % (C // 4) == 0
+            and H % 2 == 0 and W % 2 == 0 and H >= 2 and W >= 2)
+
+
+def batchnorm_maxpool2_fork(x, gamma, beta, running_mean, running_var, num_batches_tracked=None, eps=1e-5, momentum=0.1, pre_act=None,
+                            post_act=None):
+    """(maxpool2(z), z), z = post_act(BN_train(pre_act(x))): see _BnPoolFork; check bn_pool_ok(x, training) first"""
+    return _BnPoolFork.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, float(eps), float(momentum), ACT[pre_act], ACT[post_act])
+
+
 def batchnorm(x, gamma, beta, running_mean, running_var, num_batches_tracked=None, eps=1e-5, momentum=0.1,
               pre_act=None, post_act=None, training=True, residual=None):
     """y = post_act(BN(pre_act(x))) [+ residual] over the last (channel) dim, torch train-mode semantics incl. running stats."""

@@ -190,6 +190,57 @@ def test_batchnorm_train(dt, cfg):
 
 
 @pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('cfg', [(32, 'lrelu', None, 2, 12, 20), (64, None, 'hswish', 1, 6, 70), (128, 'lrelu', None, 3, 4, 2)])
+@pytest.mark.parametrize('skip_used', [True, False])
+def test_batchnorm_maxpool_fork(dt, cfg, skip_used):
+    """last BatchNorm of an encoder level + `self.pool` in one pass (reference nets/tcct.py:820-823, :876-884): both outputs and the running
+    statistics against torch (fp32) / bit for bit against the two-pass HIP path (bf16); gradient of the unmaterialised sum
+    dskip + maxpool_backward(dpool) through the BatchNorm against torch autograd"""
+    from tcct_amd import ops
+    C, pre, post, N, H, W = cfg
+    x = (rnd(N, C, H, W, dt=dt) * 1.5 + 0.3).to(dt).float().requires_grad_(True)
+    g = (1 + 0.1 * rnd(C, seed=1)).requires_grad_(True)
+    b = (0.1 * rnd(C, seed=2)).requires_grad_(True)
+    rm, rv = 0.05 * rnd(C, seed=3), 1 + 0.2 * rnd(C, seed=4).abs()
+    z = ACTS[post or 'none'](F.batch_norm(ACTS[pre or 'none'](x), rm.clone(), rv.clone(), g, b, True, 0.1, 1e-5))
+    pooled = F.max_pool2d(z, 2)
+    gp, gz = rnd(*pooled.shape, seed=5, dt=dt), rnd(*z.shape, seed=6, dt=dt)
+    ((pooled * gp).sum() + ((z * gz).sum() if skip_used else 0)).backward()
+
+    def run(fused):
+        xd = nhwc(x.detach(), dt).requires_grad_(True)
+        gd, bd = g.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+        rm_d, rv_d, nbt = rm.clone().cuda(), rv.clone().cuda(), torch.zeros((), dtype=torch.int64, device='cuda')
+        if fused:
+            assert ops.bn_pool_ok(xd, True)
+            pd, zd = ops.batchnorm_maxpool2_fork(xd, gd, bd, rm_d, rv_d, nbt, eps=1e-5, pre_act=pre, post_act=post)
+        else:
+            pd, zd = ops.maxpool2_fork(ops.batchnorm(xd, gd, bd, rm_d, rv_d, nbt, eps=1e-5, pre_act=pre, post_act=post, training=True))
+        loss = (pd.float() * nhwc(gp, torch.float32)).sum()
+        if skip_used:
+            loss = loss + (zd.float() * nhwc(gz, torch.float32)).sum()
+        loss.backward()
+        return pd.detach(), zd.detach(), xd.grad, gd.grad, bd.grad, rm_d, rv_d, nbt
+
+    pd, zd, dx, dg, db, rm_d, rv_d, nbt = run(True)
+    t = tol(dt)
+    torch.testing.assert_close(nchw(zd), z.detach(), **t)
+    torch.testing.assert_close(nchw(pd), pooled.detach(), **t)
+    torch.testing.assert_close(rm_d.cpu(), 0.9 * rm + 0.1 * ACTS[pre or 'none'](x.detach()).mean((0, 2, 3)), rtol=1e-4, atol=1e-5)
+    assert nbt.item() == 1
+    p2, z2, dx2, dg2, db2, rm2, rv2, _ = run(False)
+    assert torch.equal(zd, z2) and torch.equal(pd, p2) and torch.equal(rm_d, rm2) and torch.equal(rv_d, rv2)
+    if dt == torch.float32:
+        torch.testing.assert_close(nchw(dx), x.grad, **t)
+        torch.testing.assert_close(dg.cpu(), g.grad, rtol=t['rtol'], atol=t['atol'] * 10)
+        torch.testing.assert_close(db.cpu(), b.grad, rtol=t['rtol'], atol=t['atol'] * 10)
+    # bf16: the two-pass path rounds the summed gradient to bf16 before the BatchNorm backward, the fused one does not
+    torch.testing.assert_close(dx.float(), dx2.float(), **t)
+    torch.testing.assert_close(dg, dg2, rtol=t['rtol'], atol=t['atol'] * 10)
+    torch.testing.assert_close(db, db2, rtol=t['rtol'], atol=t['atol'] * 10)
+
+
+@pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('C', [64, 96, 128, 160])
 def test_layernorm(dt, C):
     from tcct_amd import ops

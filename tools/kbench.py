@@ -112,7 +112,7 @@ def dw_bench():
         print(f'dw {N}x{H}x{W}x{C} s{st}: fwd {m1:.3f} ms {(gx + gy) / m1 * 1e3:.0f} GB/s | dgrad {m2:.3f} ms {(gx + gy) / m2 * 1e3:.0f} GB/s | wgrad {m3:.3f} ms {(gx + gy) / m3 * 1e3:.0f} GB/s')
 
 
-if __name__ == "__main__" and not ({"pw", "bwd", "ln", "c3"} & set(sys.argv[1:])):
+if __name__ == "__main__" and not ({"pw", "bwd", "ln", "c3", "bnpool"} & set(sys.argv[1:])):
     if 'dw' in sys.argv[1:]:
         dw_bench()
         sys.exit(0)
@@ -213,3 +213,31 @@ def c3_bench():
 
 if 'c3' in sys.argv[1:]:
     c3_bench()
+
+
+def bnpool_bench():
+    """last BatchNorm of an encoder level + MaxPool2d(2): fused kernels against bn_apply + maxpool | maxpool_bwd_add + bn_bwd_reduce + bn_bwd_apply"""
+    for (H_, W_) in [(800, 1104), (400, 552)]:
+        C, M = 32, B * H_ * W_
+        x = torch.randn(B, H_, W_, C, device='cuda').to(dt)
+        z, dsk, dx, dz = torch.empty_like(x), torch.randn_like(x), torch.empty_like(x), torch.empty_like(x)
+        pooled = torch.empty(B, H_ // 2, W_ // 2, C, device='cuda', dtype=dt)
+        dpool = torch.randn_like(pooled)
+        amax = torch.empty(B, H_ // 2, W_ // 2, C // 4, device='cuda', dtype=torch.uint8)
+        sums = torch.zeros(2 * C, device='cuda', dtype=torch.float64); sums[C:] = M
+        g, bta = torch.ones(C, device='cuda'), torch.zeros(C, device='cuda')
+        mr, ab = torch.empty(2 * C, device='cuda'), torch.empty(2 * C, device='cuda')
+        s2 = torch.zeros(2 * C, device='cuda', dtype=torch.float64)
+        dg, db = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+        t1 = timeit(lambda: lib.bn_pool_fwd_train(x, z, pooled, amax, B, H_, W_, C, sums, g, bta, 1e-5, 0.1, None, None, None, mr, ab, 1, 0, BF16))
+        t2 = timeit(lambda: lib.bn_pool_bwd(x, dpool, dsk, amax, dx, B, H_, W_, C, mr, ab, 1, 0, s2, dg, db, BF16))
+        u1 = timeit(lambda: lib.bn_apply_train(x, None, z, M, C, sums, g, bta, 1e-5, 0.1, None, None, None, mr, ab, 1, 0, BF16))
+        u2 = timeit(lambda: lib.maxpool2_fwd(z, pooled, B, H_, W_, C, BF16))
+        u3 = timeit(lambda: lib.maxpool2_bwd_add(z, dpool, dsk, dz, B, H_, W_, C, BF16))
+        u4 = timeit(lambda: lib.bn_bwd_reduce(x, dz, M, C, mr, ab, 1, 0, s2, BF16))
+        u5 = timeit(lambda: lib.bn_bwd_apply(x, dz, dx, M, C, mr, ab, g, s2, 1, 0, dg, db, BF16))
+        print(f'bn+pool {B}x{H_}x{W_}x{C}: fused fwd {t1:.3f} bwd {t2:.3f} ms || separate fwd {u1:.3f}+{u2:.3f} bwd {u3:.3f}+{u4:.3f}+{u5:.3f} ms')
+
+
+if 'bnpool' in sys.argv[1:]:
+    bnpool_bench()
