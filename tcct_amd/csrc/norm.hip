@@ -734,7 +734,10 @@ __device__ __forceinline__ void bn_train_coeff(const BnTrain& tr, int64_t M, int
         if (c == 0 && tr.nbt) *tr.nbt += 1;
     }
 }
-template <typename T>
+// PRE / ACT: compile-time activation kinds for the network's combination (LeakyReLU in front of both BatchNorms, GELU behind the sum), -1 =
+// run-time kinds.  act_fwd / act_grad resolve the kind per ELEMENT with a chain of scalar branches; with three input streams that made the
+// backward reduction VALU-bound (3.3 TB/s at level 0)
+template <typename T, int PRE, int ACT>
 __global__ void k_bn2_add_act_fwd(const T* __restrict__ xa, const T* __restrict__ xb, T* __restrict__ y, int64_t M, int C,
                                   const float* __restrict__ abA, const float* __restrict__ abB, int pre_act, int act, BnTrain trA, BnTrain trB) {
     const int CV = C >> 2, R = NB / CV, t = threadIdx.x;
@@ -755,16 +758,18 @@ __global__ void k_bn2_add_act_fwd(const T* __restrict__ xa, const T* __restrict_
         f4 va = ld4(xa + o), vb = ld4(xb + o), q;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            q.v[k] = act_fwd(act, aA[k] * act_fwd(pre_act, va.v[k]) + bA[k] + aB[k] * act_fwd(pre_act, vb.v[k]) + bB[k]);
+            q.v[k] = actf<ACT>(act, aA[k] * actf<PRE>(pre_act, va.v[k]) + bA[k] + aB[k] * actf<PRE>(pre_act, vb.v[k]) + bB[k]);
         st4(y + o, q);
     }
 }
+#define JUNC_KINDS(CALL) do { if (pre_act == TCCT_ACT_LRELU && act == TCCT_ACT_GELU) { constexpr int PRE = TCCT_ACT_LRELU, ACT = TCCT_ACT_GELU; CALL; } \
+                              else { constexpr int PRE = -1, ACT = -1; CALL; } } while (0)
 static int bn2_fwd_impl(const void* xa, const void* xb, void* y, int64_t M, int C, const float* abA, const float* abB,
                         int pre_act, int act, int dtype, tcct_stream_t stream, BnTrain trA, BnTrain trB) {
     TCCT_CHECK(C % 4 == 0 && C >= 4 && C <= NB, "bn2_add_act_fwd: C=%d unsupported", C);
     int R = NB / (C / 4);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_bn2_add_act_fwd<T>, dim3(tcct_grid(M, R, 256 * 16)), dim3(NB), 0, (hipStream_t)stream,
-                                            (const T*)xa, (const T*)xb, (T*)y, M, C, abA, abB, pre_act, act, trA, trB));
+    JUNC_KINDS(TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn2_add_act_fwd<T, PRE, ACT>), dim3(tcct_grid(M, R, 256 * 16)), dim3(NB), 0, (hipStream_t)stream,
+                                                       (const T*)xa, (const T*)xb, (T*)y, M, C, abA, abB, pre_act, act, trA, trB)));
     TCCT_LAUNCH_OK();
 }
 extern "C" int tcct_bn2_add_act_fwd(const void* xa, const void* xb, void* y, int64_t M, int C, const float* abA, const float* abB,
@@ -786,7 +791,7 @@ extern "C" int tcct_bn2_add_act_train(const void* xa, const void* xb, void* y, i
 }
 
 // sums[4C] = { sum g, sum g*xhatA, (unused alias of sum g), sum g*xhatB } laid out as [C]:g, [C]:g*xhatA, [C]:g, [C]:g*xhatB
-template <typename T>
+template <typename T, int PRE, int ACT>
 __global__ void __launch_bounds__(NBR) k_bn2_add_act_bwd_reduce(const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ dy, int64_t M, int C,
                                          const float* __restrict__ mrA, const float* __restrict__ abA, const float* __restrict__ mrB,
                                          const float* __restrict__ abB, int pre_act, int act, double* __restrict__ sums) {
@@ -817,8 +822,8 @@ __global__ void __launch_bounds__(NBR) k_bn2_add_act_bwd_reduce(const T* __restr
                 if (m + j * step < M) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        float ua = act_fwd(pre_act, va[j].v[k]), ub = act_fwd(pre_act, vb[j].v[k]);
-                        float dz = g[j].v[k] * act_grad(act, aA[k] * ua + bA[k] + aB[k] * ub + bB[k]);
+                        float ua = actf<PRE>(pre_act, va[j].v[k]), ub = actf<PRE>(pre_act, vb[j].v[k]);
+                        float dz = g[j].v[k] * actg<ACT>(act, aA[k] * ua + bA[k] + aB[k] * ub + bB[k]);
                         s0[k] += dz; s1[k] += dz * (ua - muA[k]) * rsA[k]; s2[k] += dz * (ub - muB[k]) * rsB[k];
                     }
                 }
@@ -845,12 +850,12 @@ extern "C" int tcct_bn2_add_act_bwd_reduce(const void* xa, const void* xb, const
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && hipMemsetAsync(sums, 0, sizeof(double) * 4 * C, st) != hipSuccess) { tcct_set_error("bn2_add_act_bwd_reduce: memset failed"); return -2; }
     int R = NBR / (C / 4);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_bn2_add_act_bwd_reduce<T>, dim3(tcct_grid(M, R, 512)), dim3(NBR), 0, st, (const T*)xa,
-                                            (const T*)xb, (const T*)dy, M, C, mean_rstdA, abA, mean_rstdB, abB, pre_act, act, sums));
+    JUNC_KINDS(TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn2_add_act_bwd_reduce<T, PRE, ACT>), dim3(tcct_grid(M, R, 512)), dim3(NBR), 0, st, (const T*)xa,
+                                                       (const T*)xb, (const T*)dy, M, C, mean_rstdA, abA, mean_rstdB, abB, pre_act, act, sums)));
     TCCT_LAUNCH_OK();
 }
 
-template <typename T>
+template <typename T, int PRE, int ACT>
 __global__ void k_bn2_add_act_bwd_apply(const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ dy, T* __restrict__ dxa,
                                         T* __restrict__ dxb, int64_t M, int C, const float* __restrict__ mrA, const float* __restrict__ abA,
                                         const float* __restrict__ mrB, const float* __restrict__ abB, const double* __restrict__ sums,
@@ -876,10 +881,10 @@ __global__ void k_bn2_add_act_bwd_apply(const T* __restrict__ xa, const T* __res
         f4 va = ld4(xa + o), vb = ld4(xb + o), g = ld4(dy + o), qa, qb;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float ua = act_fwd(pre_act, va.v[k]), ub = act_fwd(pre_act, vb.v[k]);
-            float dz = g.v[k] * act_grad(act, aA[k] * ua + bA[k] + aB[k] * ub + bB[k]);
-            qa.v[k] = aA[k] * (dz - s0[k] - (ua - muA[k]) * rsA[k] * s1[k]) * act_grad(pre_act, va.v[k]);
-            qb.v[k] = aB[k] * (dz - s0[k] - (ub - muB[k]) * rsB[k] * s2[k]) * act_grad(pre_act, vb.v[k]);
+            float ua = actf<PRE>(pre_act, va.v[k]), ub = actf<PRE>(pre_act, vb.v[k]);
+            float dz = g.v[k] * actg<ACT>(act, aA[k] * ua + bA[k] + aB[k] * ub + bB[k]);
+            qa.v[k] = aA[k] * (dz - s0[k] - (ua - muA[k]) * rsA[k] * s1[k]) * actg<PRE>(pre_act, va.v[k]);
+            qb.v[k] = aB[k] * (dz - s0[k] - (ub - muB[k]) * rsB[k] * s2[k]) * actg<PRE>(pre_act, vb.v[k]);
         }
         st4(dxa + o, qa); st4(dxb + o, qb);
     }
@@ -890,8 +895,8 @@ extern "C" int tcct_bn2_add_act_bwd_apply(const void* xa, const void* xb, const 
                                           float* dbetaB, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(C % 4 == 0 && C >= 4 && C <= NB, "bn2_add_act_bwd_apply: C=%d unsupported", C);
     int R = NB / (C / 4);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_bn2_add_act_bwd_apply<T>, dim3(tcct_grid(M, R, 256 * 16)), dim3(NB), 0, (hipStream_t)stream,
-                                            (const T*)xa, (const T*)xb, (const T*)dy, (T*)dxa, (T*)dxb, M, C, mean_rstdA, abA, mean_rstdB,
-                                            abB, sums, pre_act, act, dgammaA, dbetaA, dgammaB, dbetaB));
+    JUNC_KINDS(TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn2_add_act_bwd_apply<T, PRE, ACT>), dim3(tcct_grid(M, R, 256 * 16)), dim3(NB), 0, (hipStream_t)stream,
+                                                       (const T*)xa, (const T*)xb, (const T*)dy, (T*)dxa, (T*)dxb, M, C, mean_rstdA, abA, mean_rstdB,
+                                                       abB, sums, pre_act, act, dgammaA, dbetaA, dgammaB, dbetaB)));
     TCCT_LAUNCH_OK();
 }
