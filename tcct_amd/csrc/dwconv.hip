@@ -46,9 +46,15 @@ __device__ __forceinline__ bool dw_pos(int C, int VEC, int Ho, int Wo, int segh,
 
 // raw (as loaded) channel vector: kept packed in registers and unpacked at use, so that a chunk of rows fits in few VGPRs
 template <typename T, int VEC> struct Raw;
+typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int dw_u32x2;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int dw_u32x4;
+#define DW_OOB 0x80000000u      // a byte offset beyond every buffer these kernels bind: the load returns zeros, the store is dropped
 template <> struct Raw<bf16, 4> {
     uint2 v;
     __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const uint2*>(p); }
+    __device__ __forceinline__ void loadb(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+        const dw_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); v.x = t[0]; v.y = t[1];
+    }
     __device__ __forceinline__ void zero() { v.x = 0u; v.y = 0u; }
     __device__ __forceinline__ float get(int k) const {
         const uint32_t w = k < 2 ? v.x : v.y;
@@ -58,16 +64,29 @@ template <> struct Raw<bf16, 4> {
 template <> struct Raw<float, 4> {
     float4 v;
     __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void loadb(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+        const dw_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        v = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
+    }
     __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ float get(int k) const { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
 };
 template <typename T> struct Raw<T, 1> {
     float v;
     __device__ __forceinline__ void load(const T* p) { v = ldf(p); }
+    __device__ __forceinline__ void loadb(__amdgpu_buffer_rsrc_t, uint32_t) { v = 0.f; }        // (the scalar kernels keep pointer loads)
     __device__ __forceinline__ void zero() { v = 0.f; }
     __device__ __forceinline__ float get(int) const { return v; }
 };
 
+__device__ __forceinline__ void dw_storeb(__amdgpu_buffer_rsrc_t r, uint32_t off, const float* o, const bf16*) {
+    dw_u32x2 t; t[0] = pack_bf16x2(o[0], o[1]); t[1] = pack_bf16x2(o[2], o[3]);
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, off, 0, 0);
+}
+__device__ __forceinline__ void dw_storeb(__amdgpu_buffer_rsrc_t r, uint32_t off, const float* o, const float*) {
+    dw_u32x4 t; t[0] = __float_as_uint(o[0]); t[1] = __float_as_uint(o[1]); t[2] = __float_as_uint(o[2]); t[3] = __float_as_uint(o[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, off, 0, 0);
+}
 // one input row: the three columns wi0, wi0+1, wi0+2 of input row hi (zeros outside the image)
 template <typename T, int VEC, int NC = 3>
 __device__ __forceinline__ void dw_load_row(Raw<T, VEC> (&r)[NC], const T* __restrict__ img, int hi, int H, int W, int C, int wi0) {
@@ -116,6 +135,78 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
     constexpr int RBC = CPT == 1 ? K::RB : 2;              // output rows per chunk (two with several columns: register budget)
     constexpr int NEWC = RBC * STRIDE, ROWSC = K::CARRY + NEWC;
     Raw<T, VEC> R[ROWSC][NC], NX[NEWC][NC];
+    if (VEC == 4) {
+        // Channel vectors go through buffer descriptors (one per image): a pixel outside the image, a row of the next strip or a column
+        // beyond Wo is an out-of-range offset -- zeros / dropped store -- so the marching loop has NO branch around a memory operation.
+        // With `if (inside) load` hipcc cannot count the loads in flight and waits with vmcnt(0): the ISA of the pointer version waited
+        // for the just-issued next-chunk rows before EVERY output pixel (its residual load sat in a branch), i.e. nothing overlapped.
+        const uint32_t ES = sizeof(T), in_bytes = (uint32_t)H * W * C * ES, out_bytes = (uint32_t)Ho * Wo * C * ES;
+        // (the image index is block-uniform, but it comes out of dw_pos() behind a per-thread early return: without readfirstlane the
+        // compiler treats the descriptors as divergent and wraps every buffer access in a waterfall loop)
+        const int nu = __builtin_amdgcn_readfirstlane(p.n);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)nu * H * W * C), 0, in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (int64_t)nu * Ho * Wo * C), 0, out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)((res ? res : y) + (int64_t)nu * Ho * Wo * C), 0, res ? out_bytes : 0u, 0x00020000);
+        uint32_t cin[NC], cout[CPT];        // byte offset of the thread's channels in column wi0 + kx of an input row / wo + cc of an output row
+#pragma unroll
+        for (int kx = 0; kx < NC; ++kx) cin[kx] = (unsigned)(wi0 + kx) < (unsigned)W ? (uint32_t)((wi0 + kx) * C + p.c) * ES : DW_OOB;
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) cout[cc] = p.wo + cc < Wo ? (uint32_t)((p.wo + cc) * C + p.c) * ES : DW_OOB;
+        auto load_row = [&](Raw<T, VEC> (&r)[NC], int hi, bool live) {
+            const bool rok = live && (unsigned)hi < (unsigned)H;
+            const uint32_t ro = (uint32_t)hi * (uint32_t)(W * C) * ES;
+#pragma unroll
+            for (int kx = 0; kx < NC; ++kx) r[kx].loadb(rx, (rok && cin[kx] != DW_OOB) ? ro + cin[kx] : DW_OOB);
+        };
+        Raw<T, VEC> RS[RBC][CPT], RSN[RBC][CPT];            // the second gradient (res) of the current / next chunk
+        auto load_res = [&](Raw<T, VEC> (&q)[RBC][CPT], int ho) {
+#pragma unroll
+            for (int j = 0; j < RBC; ++j)
+#pragma unroll
+                for (int cc = 0; cc < CPT; ++cc)
+                    q[j][cc].loadb(rr, (ho + j < p.ho1 && cout[cc] != DW_OOB) ? (uint32_t)(ho + j) * (uint32_t)(Wo * C) * ES + cout[cc] : DW_OOB);
+        };
+#pragma unroll
+        for (int i = 0; i < ROWSC; ++i) load_row(R[i], p.ho0 * STRIDE - 1 + i, true);
+        load_res(RS, p.ho0);
+        for (int ho = p.ho0; ho < p.ho1; ho += RBC) {
+            const bool more = ho + RBC < p.ho1;           // rows of a chunk beyond the strip are not fetched
+#pragma unroll
+            for (int i = 0; i < NEWC; ++i) load_row(NX[i], (ho + RBC) * STRIDE - 1 + K::CARRY + i, more);
+            load_res(RSN, ho + RBC);
+#pragma unroll
+            for (int j = 0; j < RBC; ++j) {
+#pragma unroll
+                for (int cc = 0; cc < CPT; ++cc) {
+                    float acc[VEC];
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        float a = bv[k] + RS[j][cc].get(k);
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) a += R[j * STRIDE + ky][cc + kx].get(k) * wk[ky * 3 + kx][k];
+                        if (add_input) a += R[j * STRIDE + 1][cc + 1].get(k);
+                        acc[k] = a;
+                    }
+                    dw_storeb(ry, (ho + j < p.ho1 && cout[cc] != DW_OOB) ? (uint32_t)(ho + j) * (uint32_t)(Wo * C) * ES + cout[cc] : DW_OOB, acc, (const T*)nullptr);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < K::CARRY; ++i)
+#pragma unroll
+                for (int kx = 0; kx < NC; ++kx) R[i][kx] = R[NEWC + i][kx];
+#pragma unroll
+            for (int i = 0; i < NEWC; ++i)
+#pragma unroll
+                for (int kx = 0; kx < NC; ++kx) R[K::CARRY + i][kx] = NX[i][kx];
+#pragma unroll
+            for (int j = 0; j < RBC; ++j)
+#pragma unroll
+                for (int cc = 0; cc < CPT; ++cc) RS[j][cc] = RSN[j][cc];
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < ROWSC; ++i) dw_load_row<T, VEC, NC>(R[i], img, p.ho0 * STRIDE - 1 + i, H, W, C, wi0);
     for (int ho = p.ho0; ho < p.ho1; ho += RBC) {
@@ -194,6 +285,7 @@ extern "C" int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bi
     int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     int vec = (C % 4 == 0) ? 4 : 1;
     TCCT_CHECK(C / vec <= DB, "dwconv3x3_fwd: C=%d too large", C);
+    TCCT_CHECK((int64_t)H * W * C * 4 < (1ll << 31), "dwconv3x3_fwd: one image of %d x %d x %d elements exceeds the 32-bit byte offsets of the kernels", H, W, C);
     hipStream_t st = (hipStream_t)stream;
     if (vec == 4) { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, false>(x, w, bias, y, N, H, W, C, stride, Ho, Wo, add_input, st))); }
     else { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 1, false>(x, w, bias, y, N, H, W, C, stride, Ho, Wo, add_input, st))); }
@@ -292,6 +384,7 @@ static int dw_dgrad_impl(const void* dy, const float* w, const void* res, void* 
     int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     int vec = (C % 4 == 0) ? 4 : 1;
     TCCT_CHECK(C / vec <= DB, "dwconv3x3_dgrad: C=%d too large", C);
+    TCCT_CHECK((int64_t)H * W * C * 4 < (1ll << 31), "dwconv3x3_dgrad: one image of %d x %d x %d elements exceeds the 32-bit byte offsets of the kernels", H, W, C);
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1) {      // dx = conv(dy, flipped taps) (+ dy when the forward added its input) (+ res)
         if (vec == 4) { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, add_input, st, res))); }

@@ -190,6 +190,44 @@ def test_batchnorm_train(dt, cfg):
 
 
 @pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('kinds', [('lrelu', 'gelu'), ('none', 'hswish')])        # the network's combination (compile-time kinds) / run-time kinds
+def test_cnn_block_junction(dt, kinds):
+    """CrossCNNBlock junction (reference nets/tcct.py:825-827): act(BN_A(pre(a)) + BN_B(pre(b))), both BatchNorms in train mode, one pass
+    forward and two backward, against torch autograd incl. the four parameter gradients and the running statistics"""
+    from tcct_amd import ops
+    pre, act = kinds
+    N, C, H, W = 2, 32, 11, 14
+    gelu = lambda v: F.gelu(v)
+    A = dict(ACTS, gelu=gelu)
+    xa = (rnd(N, C, H, W, dt=dt) * 1.3 + 0.2).to(dt).float().requires_grad_(True)
+    xb = (rnd(N, C, H, W, seed=9, dt=dt) * 0.7 - 0.1).to(dt).float().requires_grad_(True)
+    ps = [(1 + 0.1 * rnd(C, seed=1)).requires_grad_(True), (0.1 * rnd(C, seed=2)).requires_grad_(True),
+          (1 + 0.1 * rnd(C, seed=3)).requires_grad_(True), (0.1 * rnd(C, seed=4)).requires_grad_(True)]
+    rms = [0.05 * rnd(C, seed=5), 1 + 0.2 * rnd(C, seed=6).abs(), 0.05 * rnd(C, seed=7), 1 + 0.2 * rnd(C, seed=8).abs()]
+    ref_rm = [t.clone() for t in rms]
+    y = A[act](F.batch_norm(A[pre](xa), ref_rm[0], ref_rm[1], ps[0], ps[1], True, 0.1, 1e-5)
+               + F.batch_norm(A[pre](xb), ref_rm[2], ref_rm[3], ps[2], ps[3], True, 0.1, 1e-5))
+    gy = rnd(*y.shape, seed=10, dt=dt)
+    y.backward(gy)
+    xad, xbd = nhwc(xa.detach(), dt).requires_grad_(True), nhwc(xb.detach(), dt).requires_grad_(True)
+    pd = [p.detach().cuda().requires_grad_(True) for p in ps]
+    rd = [t.clone().cuda() for t in rms]
+    nbt = [torch.zeros((), dtype=torch.int64, device='cuda') for _ in range(2)]
+    yd = ops.bn2_add_act(xad, (pd[0], pd[1], rd[0], rd[1], nbt[0], 1e-5, 0.1), xbd, (pd[2], pd[3], rd[2], rd[3], nbt[1], 1e-5, 0.1),
+                         pre_act=pre, act_kind=act)
+    t = tol(dt)
+    torch.testing.assert_close(nchw(yd), y.detach(), **t)
+    for a, b in zip(rd, ref_rm):
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-4, atol=1e-5)
+    assert nbt[0].item() == 1 and nbt[1].item() == 1
+    yd.backward(nhwc(gy, dt))
+    torch.testing.assert_close(nchw(xad.grad), xa.grad, **t)
+    torch.testing.assert_close(nchw(xbd.grad), xb.grad, **t)
+    for a, b in zip(pd, ps):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=t['rtol'], atol=t['atol'] * 10)
+
+
+@pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('cfg', [(32, 'lrelu', None, 2, 12, 20), (64, None, 'hswish', 1, 6, 70), (128, 'lrelu', None, 3, 4, 2)])
 @pytest.mark.parametrize('skip_used', [True, False])
 def test_batchnorm_maxpool_fork(dt, cfg, skip_used):
