@@ -315,6 +315,62 @@ __global__ void __launch_bounds__(DB) k_dw_dgrad_s2(const T* __restrict__ dy, co
     T* out = dx + (int64_t)p.n * H * W * C + p.c;
     const T* rin = res ? res + (int64_t)p.n * H * W * C + p.c : nullptr;
     const int b = p.wo;
+    if (VEC == 4) {         // branch-free memory operations through buffer descriptors (see k_dw_fwd)
+        const uint32_t ES = sizeof(T), in_bytes = (uint32_t)H * W * C * ES;
+        const int nu = __builtin_amdgcn_readfirstlane(p.n);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)nu * Ho * Wo * C), 0, (uint32_t)Ho * Wo * C * ES, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(dx + (int64_t)nu * H * W * C), 0, in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)((res ? res : dx) + (int64_t)nu * H * W * C), 0, res ? in_bytes : 0u, 0x00020000);
+        const uint32_t cg0 = (uint32_t)(b * C + p.c) * ES, cg1 = b + 1 < Wo ? cg0 + (uint32_t)C * ES : DW_OOB;
+        const uint32_t co0 = (uint32_t)(2 * b * C + p.c) * ES, co1 = 2 * b + 1 < W ? co0 + (uint32_t)C * ES : DW_OOB;
+        auto ldb = [&](Raw<T, VEC> (&d)[2], int a) {
+            const bool rok = a < Ho;
+            const uint32_t r0 = (uint32_t)a * (uint32_t)(Wo * C) * ES;
+            d[0].loadb(rg, rok ? r0 + cg0 : DW_OOB);
+            d[1].loadb(rg, (rok && cg1 != DW_OOB) ? r0 + cg1 : DW_OOB);
+        };
+        auto ldr = [&](Raw<T, VEC> (&q)[4], int a, bool live) {       // the second gradient of the quad's four pixels
+            const uint32_t r0 = (uint32_t)(2 * a) * (uint32_t)(W * C) * ES, r1 = r0 + (uint32_t)(W * C) * ES;
+            const bool row1 = live && 2 * a + 1 < H;
+            q[0].loadb(rr, live ? r0 + co0 : DW_OOB);
+            q[1].loadb(rr, (live && co1 != DW_OOB) ? r0 + co1 : DW_OOB);
+            q[2].loadb(rr, row1 ? r1 + co0 : DW_OOB);
+            q[3].loadb(rr, (row1 && co1 != DW_OOB) ? r1 + co1 : DW_OOB);
+        };
+        auto emitb = [&](const Raw<T, VEC> (&u)[2], const Raw<T, VEC> (&v)[2], const Raw<T, VEC> (&q)[4], int a, bool live) {
+            float o00[VEC], o01[VEC], o10[VEC], o11[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float u0 = u[0].get(k), u1 = u[1].get(k), v0 = v[0].get(k), v1 = v[1].get(k);
+                o00[k] = u0 * wk[4][k] + q[0].get(k);
+                o01[k] = u0 * wk[5][k] + u1 * wk[3][k] + q[1].get(k);
+                o10[k] = u0 * wk[7][k] + v0 * wk[1][k] + q[2].get(k);
+                o11[k] = u0 * wk[8][k] + u1 * wk[6][k] + v0 * wk[2][k] + v1 * wk[0][k] + q[3].get(k);
+            }
+            const uint32_t r0 = (uint32_t)(2 * a) * (uint32_t)(W * C) * ES, r1 = r0 + (uint32_t)(W * C) * ES;
+            const bool row1 = live && 2 * a + 1 < H;
+            dw_storeb(ro, live ? r0 + co0 : DW_OOB, o00, (const T*)nullptr);
+            dw_storeb(ro, (live && co1 != DW_OOB) ? r0 + co1 : DW_OOB, o01, (const T*)nullptr);
+            dw_storeb(ro, row1 ? r1 + co0 : DW_OOB, o10, (const T*)nullptr);
+            dw_storeb(ro, (row1 && co1 != DW_OOB) ? r1 + co1 : DW_OOB, o11, (const T*)nullptr);
+        };
+        // two quad rows per iteration, the dy rows and the second gradient of the NEXT pair requested before this pair is computed
+        Raw<T, VEC> d0[2], d1[2], d2[2], n1[2], n2[2], q0[4], q1[4], m0[4], m1[4];
+        ldb(d0, p.ho0); ldb(d1, p.ho0 + 1); ldb(d2, p.ho0 + 2);
+        ldr(q0, p.ho0, true); ldr(q1, p.ho0 + 1, p.ho0 + 1 < p.ho1);
+        for (int a = p.ho0; a < p.ho1; a += 2) {
+            const bool more = a + 2 < p.ho1;
+            ldb(n1, more ? a + 3 : Ho); ldb(n2, more ? a + 4 : Ho);
+            ldr(m0, a + 2, more); ldr(m1, a + 3, a + 3 < p.ho1);
+            emitb(d0, d1, q0, a, true);
+            emitb(d1, d2, q1, a + 1, a + 1 < p.ho1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { d0[j] = d2[j]; d1[j] = n1[j]; d2[j] = n2[j]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { q0[j] = m0[j]; q1[j] = m1[j]; }
+        }
+        return;
+    }
     auto ld = [&](float (&d)[2][VEC], int a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -431,6 +487,57 @@ __global__ void __launch_bounds__(DB) k_dw_wgrad(const T* __restrict__ x, const 
         const T* gimg = dy + (int64_t)p.n * Ho * Wo * C + p.c;
         const int wi0 = p.wo * STRIDE - 1;
         Raw<T, VEC> R[K::ROWS][3], NX[K::NEW][3], G[K::RB], GX[K::RB];
+      if (VEC == 4) {       // branch-free loads through buffer descriptors (see k_dw_fwd)
+        const uint32_t ES = sizeof(T);
+        const int nu = __builtin_amdgcn_readfirstlane(p.n);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)nu * H * W * C), 0, (uint32_t)H * W * C * ES, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)nu * Ho * Wo * C), 0, (uint32_t)Ho * Wo * C * ES, 0x00020000);
+        uint32_t cin[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) cin[kx] = (unsigned)(wi0 + kx) < (unsigned)W ? (uint32_t)((wi0 + kx) * C + p.c) * ES : DW_OOB;
+        const uint32_t cg = (uint32_t)(p.wo * C + p.c) * ES;
+        auto load_row = [&](Raw<T, VEC> (&r)[3], int hi, bool live) {
+            const bool rok = live && (unsigned)hi < (unsigned)H;
+            const uint32_t ro = (uint32_t)hi * (uint32_t)(W * C) * ES;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) r[kx].loadb(rx, (rok && cin[kx] != DW_OOB) ? ro + cin[kx] : DW_OOB);
+        };
+        auto load_g = [&](Raw<T, VEC> (&g)[K::RB], int ho) {
+#pragma unroll
+            for (int j = 0; j < K::RB; ++j) g[j].loadb(rg, ho + j < p.ho1 ? (uint32_t)(ho + j) * (uint32_t)(Wo * C) * ES + cg : DW_OOB);
+        };
+#pragma unroll
+        for (int i = 0; i < K::ROWS; ++i) load_row(R[i], p.ho0 * STRIDE - 1 + i, true);
+        load_g(G, p.ho0);
+        for (int ho = p.ho0; ho < p.ho1; ho += K::RB) {
+            const bool more = ho + K::RB < p.ho1;
+#pragma unroll
+            for (int i = 0; i < K::NEW; ++i) load_row(NX[i], (ho + K::RB) * STRIDE - 1 + K::CARRY + i, more);
+            load_g(GX, ho + K::RB);
+#pragma unroll
+            for (int j = 0; j < K::RB; ++j) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const float g = G[j].get(k);
+                    acc[9][k] += g;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx][k] += R[j * STRIDE + ky][kx].get(k) * g;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < K::CARRY; ++i)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) R[i][kx] = R[K::NEW + i][kx];
+#pragma unroll
+            for (int i = 0; i < K::NEW; ++i)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) R[K::CARRY + i][kx] = NX[i][kx];
+#pragma unroll
+            for (int j = 0; j < K::RB; ++j) G[j] = GX[j];
+        }
+      } else {
 #pragma unroll
         for (int i = 0; i < K::ROWS; ++i) dw_load_row<T, VEC>(R[i], img, p.ho0 * STRIDE - 1 + i, H, W, C, wi0);
 #pragma unroll
@@ -472,6 +579,7 @@ __global__ void __launch_bounds__(DB) k_dw_wgrad(const T* __restrict__ x, const 
 #pragma unroll
             for (int j = 0; j < K::RB; ++j) G[j] = GX[j];
         }
+      }
     }
 #pragma unroll
     for (int a = 0; a < 10; ++a)
@@ -495,6 +603,7 @@ extern "C" int tcct_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, fl
     int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     int vec = (C % 4 == 0) ? 4 : 1;
     TCCT_CHECK(C / vec <= DB, "dwconv3x3_wgrad: C=%d too large", C);
+    TCCT_CHECK((int64_t)H * W * C * 4 < (1ll << 31), "dwconv3x3_wgrad: one image of %d x %d x %d elements exceeds the 32-bit byte offsets of the kernels", H, W, C);
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * C * 9, st) != hipSuccess) { tcct_set_error("dwconv3x3_wgrad: memset failed"); return -2; }
     if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) { tcct_set_error("dwconv3x3_wgrad: memset failed"); return -2; }
