@@ -2,6 +2,7 @@
 // align_corners conventions) and per-pixel L2 normalisation.  All HBM-bound gather stencils on NHWC, atomic-free
 // (backward passes are written output-stationary).
 #include "common.h"
+#include <cstdlib>
 
 #define PB 256
 
@@ -186,7 +187,17 @@ __global__ void k_bilinear_fwd(const T* __restrict__ x, T* __restrict__ y, int N
         const T* r0 = x + ((int64_t)n * H + a.i0) * W * C;
         const T* r1 = x + ((int64_t)n * H + a.i1) * W * C;
         T* yo = y + ((int64_t)row * Wo + wo) * C + c;
-        if (VEC == 4) {
+        if (VEC == 8) {             // bf16, 16 bytes per lane: half the load / store instructions of the 4-element form
+            float v00[8], v01[8], v10[8], v11[8], t[8], e[8];
+            ldv<8>(r0 + o0, v00); ldv<8>(r0 + o1, v01); ldv<8>(r1 + o0, v10); ldv<8>(r1 + o1, v11);
+            if (res) ldv<8>(res + ((int64_t)row * Wo + wo) * C + c, e);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                t[k] = a.l0 * (b.l0 * v00[k] + b.l1 * v01[k]) + a.l1 * (b.l0 * v10[k] + b.l1 * v11[k]);
+                if (res) t[k] += e[k];
+            }
+            stv<8>(yo, t);
+        } else if (VEC == 4) {
             f4 v00 = ld4(r0 + o0), v01 = ld4(r0 + o1), v10 = ld4(r1 + o0), v11 = ld4(r1 + o1), t;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -308,20 +319,46 @@ __global__ void __launch_bounds__(PB) k_bilinear_bwd_tab(const T* __restrict__ d
         float acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        T* o = out + ((int64_t)hi * W + wi) * C + cv * VEC;
+        if (VEC >= 4 && nr <= 4 && nc <= 4) {
+            // x2 upsampling: at most 4 x 4 contributing outputs.  Fixed trip counts with zero-weight padding: the 16 loads are independent and
+            // all in flight together; the run-time loops below wait for every load before the next one is issued (1.96 TB/s at level 0)
+            int rI[4], cI[4]; float rW[4], cW[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                rI[a] = a < nr ? ri[a] : ri[0]; rW[a] = a < nr ? rw[a] : 0.f;
+                cI[a] = a < nc ? ci[a] : ci[0]; cW[a] = a < nc ? cw[a] : 0.f;
+            }
+            float v[4][4][VEC];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) ldv<VEC>(g + ((int64_t)rI[a] * Wo + cI[b]) * C + cv * VEC, v[a][b]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float gw = rW[a] * cW[b];
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += gw * v[a][b][k];
+                }
+            stv<VEC>(o, acc);
+            continue;
+        }
         for (int a = 0; a < nr; ++a) {
             const T* row = g + (int64_t)ri[a] * Wo * C + cv * VEC;
             const float wh = rw[a];
             for (int b = 0; b < nc; ++b) {
                 const float gw = wh * cw[b];
-                if (VEC == 4) {
-                    f4 v = ld4(row + (int64_t)ci[b] * C);
+                if (VEC >= 4) {
+                    float v[VEC];
+                    ldv<VEC>(row + (int64_t)ci[b] * C, v);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[k] += gw * v.v[k];
+                    for (int k = 0; k < VEC; ++k) acc[k] += gw * v[k];
                 } else acc[0] += gw * ldf(row + (int64_t)ci[b] * C);
             }
         }
-        T* o = out + ((int64_t)hi * W + wi) * C + cv * VEC;
-        if (VEC == 4) { f4 q; q.v[0] = acc[0]; q.v[1] = acc[1]; q.v[2] = acc[2]; q.v[3] = acc[3]; st4(o, q); }
+        if (VEC >= 4) stv<VEC>(o, acc);
         else stf(o, acc[0]);
     }
 }
@@ -411,6 +448,12 @@ static int bilinear_fwd_impl(const void* x, const void* res, void* y, int N, int
     float sw = align_corners ? (Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f) : (float)W / (float)Wo;
     int vec = (C % 4 == 0) ? 4 : 1;
     hipStream_t st = (hipStream_t)stream;
+    static int v8 = -1;         // TCCT_BILINEAR_VEC8=0: 8-byte accesses for bf16 as well (A/B timing)
+    if (v8 < 0) { const char* e_ = getenv("TCCT_BILINEAR_VEC8"); v8 = (e_ && e_[0] == '0') ? 0 : 1; }
+    if (v8 && dtype == TCCT_BF16 && C % 8 == 0) {
+        hipLaunchKernelGGL((k_bilinear_fwd<bf16, 8>), row_grid(Wo * (C / 8), (int64_t)N * Ho), dim3(PB), 0, st, (const bf16*)x, (bf16*)y, N, H, W, C, Ho, Wo, sh, sw, align_corners, (const bf16*)res);
+        TCCT_LAUNCH_OK();
+    }
     if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_fwd<T, 4>), row_grid(Wo * (C / 4), (int64_t)N * Ho), dim3(PB), 0, st, (const T*)x, (T*)y, N, H, W, C, Ho, Wo, sh, sw, align_corners, (const T*)res)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_fwd<T, 1>), row_grid(Wo * C, (int64_t)N * Ho), dim3(PB), 0, st, (const T*)x, (T*)y, N, H, W, C, Ho, Wo, sh, sw, align_corners, (const T*)res)); }
     TCCT_LAUNCH_OK();
@@ -432,6 +475,12 @@ extern "C" int tcct_bilinear_bwd(const void* dy, void* dx, int N, int H, int W, 
         const int64_t blocks = (int64_t)N * tilesW * tilesH;
         TCCT_CHECK(blocks < 0x7fffffffLL, "bilinear_bwd: grid too large");
         const size_t lds = sizeof(int) * ((size_t)2 * (BT_DH + DW) * KT + BT_DH + DW);
+        static int v8 = -1;         // TCCT_BILINEAR_VEC8=0: 8-byte accesses for bf16 as well (A/B timing)
+        if (v8 < 0) { const char* e_ = getenv("TCCT_BILINEAR_VEC8"); v8 = (e_ && e_[0] == '0') ? 0 : 1; }
+        if (v8 && dtype == TCCT_BF16 && C % 8 == 0) {
+            hipLaunchKernelGGL((k_bilinear_bwd_tab<bf16, 8>), dim3((unsigned)blocks), dim3(PB), lds, st, (const bf16*)dy, (bf16*)dx, N, H, W, C, Ho, Wo, sh, sw, align_corners, DW, KT, tilesW, tilesH);
+            TCCT_LAUNCH_OK();
+        }
         if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_bwd_tab<T, 4>), dim3((unsigned)blocks), dim3(PB), lds, st, (const T*)dy, (T*)dx, N, H, W, C, Ho, Wo, sh, sw, align_corners, DW, KT, tilesW, tilesH)); }
         else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_bwd_tab<T, 1>), dim3((unsigned)blocks), dim3(PB), lds, st, (const T*)dy, (T*)dx, N, H, W, C, Ho, Wo, sh, sw, align_corners, DW, KT, tilesW, tilesH)); }
         TCCT_LAUNCH_OK();
