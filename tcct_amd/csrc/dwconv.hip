@@ -468,10 +468,14 @@ extern "C" int tcct_dwconv3x3_dgrad_add(const void* dy, const float* w, const vo
 // dw[c][ky][kx] = sum_p x[p@tap][c] * dy[p][c];  dbias[c] = sum_p dy[p][c].  Same marching window as the forward kernel with
 // 10*VEC register sums per thread; LDS combine over the columns of the block, then one fp32 atomic per (channel, tap) per block.
 // Few, tall strips (about 1024 blocks) keep the number of same-address atomics low.
-template <typename T, int VEC, int STRIDE>
+// CPT (VEC == 4, stride 1): the thread owns CPT consecutive output columns and loads CPT + 2 input columns per row, so an input element is
+// requested by (CPT + 2) / CPT instead of three threads (the requests are L1 hits, but the address / tag pipeline pays for each)
+template <typename T, int VEC, int STRIDE, int CPT = 1>
 __global__ void __launch_bounds__(DB) k_dw_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
                                                  float* __restrict__ dbias, int N, int H, int W, int C, int Ho, int Wo, int segh,
                                                  int wblocks, int hstrips) {
+    static_assert(CPT == 1 || (STRIDE == 1 && VEC == 4), "several columns per thread: stride 1, 4-channel vectors");
+    constexpr int NC = CPT + 2;
     extern __shared__ float sm[];   // [DB][10*VEC]
     const int CV = C / VEC, PW = DB / CV;
     const int t = threadIdx.x;
@@ -482,29 +486,33 @@ __global__ void __launch_bounds__(DB) k_dw_wgrad(const T* __restrict__ x, const 
         for (int k = 0; k < VEC; ++k) acc[a][k] = 0.f;
     typedef DwChunk<STRIDE> K;
     DwPos p;
-    if (dw_pos(C, VEC, Ho, Wo, segh, wblocks, hstrips, p)) {
+    if (dw_pos(C, VEC, Ho, Wo, segh, wblocks, hstrips, p, CPT)) {
         const T* img = x + (int64_t)p.n * H * W * C + p.c;
         const T* gimg = dy + (int64_t)p.n * Ho * Wo * C + p.c;
         const int wi0 = p.wo * STRIDE - 1;
-        Raw<T, VEC> R[K::ROWS][3], NX[K::NEW][3], G[K::RB], GX[K::RB];
       if (VEC == 4) {       // branch-free loads through buffer descriptors (see k_dw_fwd)
+        Raw<T, VEC> R[K::ROWS][NC], NX[K::NEW][NC], G[K::RB][CPT], GX[K::RB][CPT];
         const uint32_t ES = sizeof(T);
         const int nu = __builtin_amdgcn_readfirstlane(p.n);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)nu * H * W * C), 0, (uint32_t)H * W * C * ES, 0x00020000);
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)nu * Ho * Wo * C), 0, (uint32_t)Ho * Wo * C * ES, 0x00020000);
-        uint32_t cin[3];
+        uint32_t cin[NC], cg[CPT];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) cin[kx] = (unsigned)(wi0 + kx) < (unsigned)W ? (uint32_t)((wi0 + kx) * C + p.c) * ES : DW_OOB;
-        const uint32_t cg = (uint32_t)(p.wo * C + p.c) * ES;
-        auto load_row = [&](Raw<T, VEC> (&r)[3], int hi, bool live) {
+        for (int kx = 0; kx < NC; ++kx) cin[kx] = (unsigned)(wi0 + kx) < (unsigned)W ? (uint32_t)((wi0 + kx) * C + p.c) * ES : DW_OOB;
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) cg[cc] = p.wo + cc < Wo ? (uint32_t)((p.wo + cc) * C + p.c) * ES : DW_OOB;
+        auto load_row = [&](Raw<T, VEC> (&r)[NC], int hi, bool live) {
             const bool rok = live && (unsigned)hi < (unsigned)H;
             const uint32_t ro = (uint32_t)hi * (uint32_t)(W * C) * ES;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) r[kx].loadb(rx, (rok && cin[kx] != DW_OOB) ? ro + cin[kx] : DW_OOB);
+            for (int kx = 0; kx < NC; ++kx) r[kx].loadb(rx, (rok && cin[kx] != DW_OOB) ? ro + cin[kx] : DW_OOB);
         };
-        auto load_g = [&](Raw<T, VEC> (&g)[K::RB], int ho) {
+        auto load_g = [&](Raw<T, VEC> (&g)[K::RB][CPT], int ho) {
 #pragma unroll
-            for (int j = 0; j < K::RB; ++j) g[j].loadb(rg, ho + j < p.ho1 ? (uint32_t)(ho + j) * (uint32_t)(Wo * C) * ES + cg : DW_OOB);
+            for (int j = 0; j < K::RB; ++j)
+#pragma unroll
+                for (int cc = 0; cc < CPT; ++cc)
+                    g[j][cc].loadb(rg, (ho + j < p.ho1 && cg[cc] != DW_OOB) ? (uint32_t)(ho + j) * (uint32_t)(Wo * C) * ES + cg[cc] : DW_OOB);
         };
 #pragma unroll
         for (int i = 0; i < K::ROWS; ++i) load_row(R[i], p.ho0 * STRIDE - 1 + i, true);
@@ -517,27 +525,33 @@ __global__ void __launch_bounds__(DB) k_dw_wgrad(const T* __restrict__ x, const 
 #pragma unroll
             for (int j = 0; j < K::RB; ++j) {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    const float g = G[j].get(k);
-                    acc[9][k] += g;
+                for (int cc = 0; cc < CPT; ++cc) {
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
+                    for (int k = 0; k < VEC; ++k) {
+                        const float g = G[j][cc].get(k);
+                        acc[9][k] += g;
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx][k] += R[j * STRIDE + ky][kx].get(k) * g;
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx][k] += R[j * STRIDE + ky][cc + kx].get(k) * g;
+                    }
                 }
             }
 #pragma unroll
             for (int i = 0; i < K::CARRY; ++i)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) R[i][kx] = R[K::NEW + i][kx];
+                for (int kx = 0; kx < NC; ++kx) R[i][kx] = R[K::NEW + i][kx];
 #pragma unroll
             for (int i = 0; i < K::NEW; ++i)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) R[K::CARRY + i][kx] = NX[i][kx];
+                for (int kx = 0; kx < NC; ++kx) R[K::CARRY + i][kx] = NX[i][kx];
 #pragma unroll
-            for (int j = 0; j < K::RB; ++j) G[j] = GX[j];
+            for (int j = 0; j < K::RB; ++j)
+#pragma unroll
+                for (int cc = 0; cc < CPT; ++cc) G[j][cc] = GX[j][cc];
         }
       } else {
+        Raw<T, VEC> R[K::ROWS][3], NX[K::NEW][3], G[K::RB], GX[K::RB];
 #pragma unroll
         for (int i = 0; i < K::ROWS; ++i) dw_load_row<T, VEC>(R[i], img, p.ho0 * STRIDE - 1 + i, H, W, C, wi0);
 #pragma unroll
@@ -608,9 +622,17 @@ extern "C" int tcct_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, fl
     if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * C * 9, st) != hipSuccess) { tcct_set_error("dwconv3x3_wgrad: memset failed"); return -2; }
     if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) { tcct_set_error("dwconv3x3_wgrad: memset failed"); return -2; }
     int segh, wblocks, hstrips;
+    size_t lds = sizeof(float) * DB * 10 * vec;
+    static int cpt_on = -1;     // TCCT_DW_WGRAD_CPT=0: one column per thread for every shape (A/B timing)
+    if (cpt_on < 0) { const char* e = getenv("TCCT_DW_WGRAD_CPT"); cpt_on = (e && e[0] == '0') ? 0 : 1; }
+    if (cpt_on && vec == 4 && stride == 1 && dtype == TCCT_BF16 && Wo >= 128 && C >= 32) {
+        dw_geometry(N, Ho, Wo, C, vec, 512, 128, segh, wblocks, hstrips, 2);
+        hipLaunchKernelGGL((k_dw_wgrad<bf16, 4, 1, 2>), dim3((unsigned)((int64_t)N * wblocks * hstrips)), dim3(DB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias,
+                           N, H, W, C, Ho, Wo, segh, wblocks, hstrips);
+        TCCT_LAUNCH_OK();
+    }
     dw_geometry(N, Ho, Wo, C, vec, 512, 128, segh, wblocks, hstrips);
     dim3 grid((unsigned)((int64_t)N * wblocks * hstrips));
-    size_t lds = sizeof(float) * DB * 10 * vec;
 #define DWG(V, S) hipLaunchKernelGGL((k_dw_wgrad<T, V, S>), grid, dim3(DB), lds, st, (const T*)x, (const T*)dy, dw, dbias, N, H, W, C, Ho, Wo, segh, wblocks, hstrips)
     if (vec == 4) { TCCT_DISPATCH(dtype, if (stride == 1) DWG(4, 1); else DWG(4, 2)); }
     else { TCCT_DISPATCH(dtype, if (stride == 1) DWG(1, 1); else DWG(1, 2)); }
