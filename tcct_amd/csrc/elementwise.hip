@@ -203,6 +203,10 @@ __global__ void k_map3(const T* __restrict__ x, const T* __restrict__ z, const T
 
 struct FAct { int kind; __device__ float operator()(float x) const { return act_fwd(kind, x); } };
 struct FActBwd { int kind; __device__ float operator()(float x, float dy) const { return dy * act_grad(kind, x); } };
+// the activation the training step actually maps over whole tensors (Mlp: GELU behind fc1, reference nets/tcct.py:29-53) with a compile-time
+// kind: act_fwd / act_grad resolve a run-time kind per element with a chain of scalar branches
+struct FGelu { __device__ float operator()(float x) const { return act_c<TCCT_ACT_GELU>(x); } };
+struct FGeluBwd { __device__ float operator()(float x, float dy) const { float c, p; gauss_cdf_pdf(x, c, p); return dy * (c + x * p); } };
 struct FAdd { __device__ float operator()(float a, float b) const { return a + b; } };
 struct FAddAct { int kind; __device__ float operator()(float a, float b) const { return act_fwd(kind, a + b); } };
 struct FAddActBwd { int kind; __device__ float operator()(float a, float b, float dy) const { return dy * act_grad(kind, a + b); } };
@@ -212,11 +216,13 @@ struct FScale { float alpha; __device__ float operator()(float a) const { return
 #define EW_GRID(n) dim3(tcct_grid(((n) >> 2) + 1, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream
 
 extern "C" int tcct_act_fwd(const void* x, void* y, int64_t n, int kind, int dtype, tcct_stream_t stream) {
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_map1<T, FAct>), EW_GRID(n), (const T*)x, (T*)y, n, FAct{kind}));
+    if (kind == TCCT_ACT_GELU) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_map1<T, FGelu>), EW_GRID(n), (const T*)x, (T*)y, n, FGelu{})); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_map1<T, FAct>), EW_GRID(n), (const T*)x, (T*)y, n, FAct{kind})); }
     TCCT_LAUNCH_OK();
 }
 extern "C" int tcct_act_bwd(const void* x, const void* dy, void* dx, int64_t n, int kind, int dtype, tcct_stream_t stream) {
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_map2<T, FActBwd>), EW_GRID(n), (const T*)x, (const T*)dy, (T*)dx, n, FActBwd{kind}));
+    if (kind == TCCT_ACT_GELU) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_map2<T, FGeluBwd>), EW_GRID(n), (const T*)x, (const T*)dy, (T*)dx, n, FGeluBwd{})); }
+    else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_map2<T, FActBwd>), EW_GRID(n), (const T*)x, (const T*)dy, (T*)dx, n, FActBwd{kind})); }
     TCCT_LAUNCH_OK();
 }
 extern "C" int tcct_add(const void* a, const void* b, void* y, int64_t n, int dtype, tcct_stream_t stream) {
