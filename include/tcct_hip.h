@@ -259,6 +259,10 @@ int tcct_pw_wgrad_smalln(const void* x, const void* dy, float* dw, float* dbias,
 /* ---- depthwise 3x3 (nets/tcct.py:114-122,206,535-543; nets/reg.py:66-67,72,74 as C=1 / groups=C) -------- */
 int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
                        int stride, int add_input, int dtype, tcct_stream_t stream);
+/* forward + fused statistics of the train-mode BatchNorm behind it (ResBlock: `self.dwconv` -> `self.norm`, reference nets/tcct.py:548-551,565):
+ * stats fp64 [2C] (zero on entry) += {sum, sum of squares} per channel of y as stored -- replaces a tcct_bn_stats pass; C % 4 == 0 */
+int tcct_dwconv3x3_fwd_bnstats(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C, int stride,
+                               int add_input, double* stats, int dtype, tcct_stream_t stream);
 int tcct_dwconv3x3_dgrad(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride,
                          int add_input, int dtype, tcct_stream_t stream);
 /* input gradient + res [N,H,W,C]: the gradient reaching the convolution's input through its other consumers (the stage input

@@ -10,6 +10,7 @@
 // XCDs (1.4-1.8 TB/s effective).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 #define DB 256
 // (forcing 4 waves per SIMD with __launch_bounds__(256, 4) spills ~10 registers in the marching loop: 0.166 -> 0.262 ms at level 1)
@@ -110,17 +111,29 @@ template <int STRIDE> struct DwChunk {
     static constexpr int ROWS = CARRY + NEW;
 };
 
+// stats != NULL (VEC == 4 only): also accumulate per-channel sum / sum of squares of y AS STORED into stats[0..C) / stats[C..2C) (fp64, zero on
+// entry) -- the statistics of the train-mode BatchNorm behind the convolution (InvRes: dwconv -> norm, reference nets/tcct.py:548-551), which
+// otherwise cost a separate pass over y
+__device__ __forceinline__ float dw_rnd(float v, const bf16*) { return __bfloat162float(__float2bfloat16(v)); }
+__device__ __forceinline__ float dw_rnd(float v, const float*) { return v; }
 template <typename T, int VEC, int STRIDE, bool FLIP, int CPT = 1>
 __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, int add_input,
-                                               int segh, int wblocks, int hstrips, const T* __restrict__ res) {
+                                               int segh, int wblocks, int hstrips, const T* __restrict__ res, double* __restrict__ stats = nullptr) {
+    typedef typename std::conditional<sizeof(T) == 4, double, float>::type SAcc;       // fp32 parity mode: fp64 partial sums, like tcct_bn_stats' block combine
+    __shared__ SAcc s_red[VEC == 4 ? DB * 8 : 1];
     // res != NULL (output-shaped): y += res -- as input gradient: the gradient reaching the convolution's input through its other consumers
     // CPT > 1 (stride 1 only): the thread owns CPT consecutive output columns and loads CPT + 2 input columns per row
     static_assert(CPT == 1 || STRIDE == 1, "several columns per thread: stride 1 only");
     constexpr int NC = CPT + 2;
     typedef DwChunk<STRIDE> K;
     DwPos p;
-    if (!dw_pos(C, VEC, Ho, Wo, segh, wblocks, hstrips, p, CPT)) return;
+    const bool has_work = dw_pos(C, VEC, Ho, Wo, segh, wblocks, hstrips, p, CPT);
+    if (!has_work && !(VEC == 4 && stats)) return;
+    SAcc st_s[VEC], st_q[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) st_s[k] = st_q[k] = 0;
+    if (has_work) {
     float wk[9][VEC], bv[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
@@ -189,7 +202,12 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
                         if (add_input) a += R[j * STRIDE + 1][cc + 1].get(k);
                         acc[k] = a;
                     }
-                    dw_storeb(ry, (ho + j < p.ho1 && cout[cc] != DW_OOB) ? (uint32_t)(ho + j) * (uint32_t)(Wo * C) * ES + cout[cc] : DW_OOB, acc, (const T*)nullptr);
+                    const bool live = ho + j < p.ho1 && cout[cc] != DW_OOB;
+                    dw_storeb(ry, live ? (uint32_t)(ho + j) * (uint32_t)(Wo * C) * ES + cout[cc] : DW_OOB, acc, (const T*)nullptr);
+                    if (stats && live) {
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) { const SAcc r = dw_rnd(acc[k], (const T*)nullptr); st_s[k] += r; st_q[k] += r * r; }
+                    }
                 }
             }
 #pragma unroll
@@ -205,8 +223,7 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
 #pragma unroll
                 for (int cc = 0; cc < CPT; ++cc) RS[j][cc] = RSN[j][cc];
         }
-        return;
-    }
+    } else {
 #pragma unroll
     for (int i = 0; i < ROWSC; ++i) dw_load_row<T, VEC, NC>(R[i], img, p.ho0 * STRIDE - 1 + i, H, W, C, wi0);
     for (int ho = p.ho0; ho < p.ho1; ho += RBC) {
@@ -246,6 +263,20 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
 #pragma unroll
             for (int kx = 0; kx < NC; ++kx) R[K::CARRY + i][kx] = NX[i][kx];
     }
+    }       // VEC == 4 / scalar
+    }       // has_work
+    if (VEC == 4 && stats) {        // threads t, t + CV, t + 2 CV ... hold the same four channels: LDS, then one fp64 atomic per channel and block
+        const int CV = C / VEC, PW = DB / CV, t = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { s_red[t * 8 + k] = st_s[k]; s_red[t * 8 + 4 + k] = st_q[k]; }
+        __syncthreads();
+        if (t < C) {
+            const int cvv = t / VEC, k = t % VEC;
+            double a = 0.0, b = 0.0;
+            for (int pp = 0; pp < PW; ++pp) { a += (double)s_red[(pp * CV + cvv) * 8 + k]; b += (double)s_red[(pp * CV + cvv) * 8 + 4 + k]; }
+            atomicAdd(&stats[t], a); atomicAdd(&stats[C + t], b);
+        }
+    }
 }
 
 // strip height: 32 output rows when that still leaves >= 1024 blocks, else 16, else 8 (the halo re-read is 2/segh)
@@ -260,7 +291,7 @@ static void dw_geometry(int N, int Ho, int Wo, int C, int vec, int target_blocks
 
 template <typename T, int VEC, bool FLIP>
 static void dw_fwd_launch(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C, int stride,
-                          int Ho, int Wo, int add_input, hipStream_t st, const void* res = nullptr) {
+                          int Ho, int Wo, int add_input, hipStream_t st, const void* res = nullptr, double* stats = nullptr) {
     int segh, wblocks, hstrips;
     // four columns per thread for the wide bf16 stride-1 images (levels 1-2 of the ViT branch); TCCT_DW_CPT=1 keeps one column (A/B)
     static int cpt_on = -1;
@@ -268,13 +299,13 @@ static void dw_fwd_launch(const void* x, const float* w, const float* bias, void
     if (stride == 1 && VEC == 4 && sizeof(T) == 2 && cpt_on && Wo >= 128 && C >= 32) {      // measured +4 % at 64 channels, slower at 4
         dw_geometry(N, Ho, Wo, C, VEC, 1024, 32, segh, wblocks, hstrips, 4);
         dim3 g4((unsigned)((int64_t)N * wblocks * hstrips));
-        hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP, (VEC == 4 ? 4 : 1)>), g4, dim3(DB), 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res);
+        hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP, (VEC == 4 ? 4 : 1)>), g4, dim3(DB), 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats);
         return;
     }
     dw_geometry(N, Ho, Wo, C, VEC, 1024, 32, segh, wblocks, hstrips);
     dim3 g((unsigned)((int64_t)N * wblocks * hstrips)), b(DB);
-    if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res);
-    else hipLaunchKernelGGL((k_dw_fwd<T, VEC, 2, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res);
+    if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats);
+    else hipLaunchKernelGGL((k_dw_fwd<T, VEC, 2, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats);
 }
 
 extern "C" int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
@@ -289,6 +320,18 @@ extern "C" int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bi
     hipStream_t st = (hipStream_t)stream;
     if (vec == 4) { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, false>(x, w, bias, y, N, H, W, C, stride, Ho, Wo, add_input, st))); }
     else { TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 1, false>(x, w, bias, y, N, H, W, C, stride, Ho, Wo, add_input, st))); }
+    TCCT_LAUNCH_OK();
+}
+/* forward + fused statistics of the train-mode BatchNorm that consumes y (ResBlock: dwconv -> norm, reference nets/tcct.py:548-551): stats fp64
+ * [2C] (zero on entry) += {sum, sum of squares} of y as stored.  C % 4 == 0, C <= 256. */
+extern "C" int tcct_dwconv3x3_fwd_bnstats(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C, int stride,
+                                          int add_input, double* stats, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(stride == 1 || stride == 2, "dwconv3x3_fwd_bnstats: stride %d", stride);
+    TCCT_CHECK(!(add_input && stride != 1), "dwconv3x3_fwd_bnstats: add_input needs stride 1");
+    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1 && C >= 4 && C % 4 == 0 && C <= DB && stats != nullptr, "dwconv3x3_fwd_bnstats: needs C %% 4 == 0, C <= 256, stats");
+    TCCT_CHECK((int64_t)H * W * C * 4 < (1ll << 31), "dwconv3x3_fwd_bnstats: one image of %d x %d x %d elements exceeds the 32-bit byte offsets of the kernels", H, W, C);
+    int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, false>(x, w, bias, y, N, H, W, C, stride, Ho, Wo, add_input, (hipStream_t)stream, nullptr, stats)));
     TCCT_LAUNCH_OK();
 }
 

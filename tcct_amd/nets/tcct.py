@@ -23,8 +23,8 @@ def _conv(m, x, out_dtype=None, stats_pre=None):
     return ops.conv2d(x, m.weight, m.bias, stride=m.stride[0], pad=tuple(m.padding), out_dtype=out_dtype, stats_pre=stats_pre)
 
 
-def _dw(m, x, add_input=False):
-    return ops.dwconv3x3(x, m.weight, m.bias, stride=m.stride[0], add_input=add_input)
+def _dw(m, x, add_input=False, bn_stats=False):
+    return ops.dwconv3x3(x, m.weight, m.bias, stride=m.stride[0], add_input=add_input, bn_stats=bn_stats)
 
 
 def _bn(m, x, pre=None, post=None, residual=None):
@@ -347,7 +347,7 @@ class ResBlock(nn.Module):
         return self.tail(self.conv1(x), x)
 
     def tail(self, f, x):
-        f = _bn(self.norm, _dw(self.dwconv, f), post='hswish')
+        f = _bn(self.norm, _dw(self.dwconv, f, bn_stats=self.norm.training), post='hswish')       # statistics out of the convolution's launch
         return self.conv2(f, residual=x)          # x + BN(conv2(f)): the add rides on the normalisation pass
 
 

@@ -898,14 +898,20 @@ def conv3x3_c3(x4, w, bias, stride=1, stats_pre=None, infer_bn=None, post_act=No
 
 class _DwConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, add_input, fork=False):
-        """fork: also return an alias of x for its other consumers; their gradient is added inside the input-gradient kernel"""
+    def forward(ctx, x, w, bias, stride, add_input, fork=False, stats_box=None):
+        """fork: also return an alias of x for its other consumers; their gradient is added inside the input-gradient kernel.
+        stats_box ([None]): the kernel also accumulates the statistics of the train-mode BatchNorm that consumes the output"""
         ctx.set_materialize_grads(False)      # an unused output must arrive as None in backward(), not as a zero-filled tensor
         _chk(x, w, bias)
         N, H, W, C = x.shape
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         y = torch.empty((N, Ho, Wo, C), device=x.device, dtype=x.dtype)
-        lib.dwconv3x3_fwd(x, w, bias, y, N, H, W, C, stride, int(add_input), dtype_code(x.dtype))
+        if stats_box is not None and C % 4 == 0 and C <= 256:
+            sums = ZERO.get((2 * C,), torch.float64, x.device) if ZERO.active else torch.zeros(2 * C, device=x.device, dtype=torch.float64)
+            lib.dwconv3x3_fwd_bnstats(x, w, bias, y, N, H, W, C, stride, int(add_input), sums, dtype_code(x.dtype))
+            stats_box[0] = sums
+        else:
+            lib.dwconv3x3_fwd(x, w, bias, y, N, H, W, C, stride, int(add_input), dtype_code(x.dtype))
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, add_input, bias is not None)
         ctx.bias_param = bias
@@ -916,7 +922,7 @@ class _DwConv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, add_input, has_bias = ctx.cfg
         if dy is None:
-            return dskip, None, None, None, None, None
+            return dskip, None, None, None, None, None, None
         dy = _as(dy, x.dtype)
         N, H, W, C = x.shape
         dx = dw = db = None
@@ -930,10 +936,17 @@ class _DwConv(torch.autograd.Function):
             dw = _grad_out(w)
             db = _grad_out(ctx.bias_param) if has_bias else None
             lib.dwconv3x3_wgrad(x, dy, dw, db, N, H, W, C, stride, dtype_code(x.dtype))
-        return dx, _ret(dw, w), _ret(db, ctx.bias_param), None, None, None
+        return dx, _ret(dw, w), _ret(db, ctx.bias_param), None, None, None, None
 
 
-def dwconv3x3(x, w, bias=None, stride=1, add_input=False):
+def dwconv3x3(x, w, bias=None, stride=1, add_input=False, bn_stats=False):
+    """bn_stats: a train-mode BatchNorm (no activation in front) consumes the output: its statistics come out of the same launch (`_bn_sums`)"""
+    if bn_stats:
+        box = [None]
+        y = _DwConv.apply(x, w, bias, stride, add_input, False, box)
+        if box[0] is not None:
+            y._bn_sums = (box[0], ACT['none'])
+        return y
     return _DwConv.apply(x, w, bias, stride, add_input, False)
 
 

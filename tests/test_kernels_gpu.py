@@ -156,6 +156,25 @@ def test_dwconv(dt, cfg, hw):
         torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, b.grad.abs().max().item()))
 
 
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('cfg', [(64, 1, (37, 45)), (96, 2, (21, 131)), (32, 1, (9, 258))])
+def test_dwconv_with_batchnorm_statistics(dt, cfg):
+    """ResBlock: dwconv -> norm (reference nets/tcct.py:548-551,565): the convolution's launch also delivers the sum / sum of squares of its
+    output as stored, which the train-mode BatchNorm behind it then uses instead of a pass of its own"""
+    from tcct_amd import ops
+    C, s_, (H, W) = cfg
+    x = nhwc(rnd(2, C, H, W, dt=dt), dt)
+    w = rnd(C, 1, 3, 3, seed=1).cuda()
+    y = ops.dwconv3x3(x, w, None, stride=s_, bn_stats=True)
+    y0 = ops.dwconv3x3(x, w, None, stride=s_)
+    assert torch.equal(y, y0)
+    sums, pre = y._bn_sums
+    assert pre == 0 and sums.shape == (2 * C,)
+    ys = y.float().reshape(-1, C).double()
+    torch.testing.assert_close(sums[:C], ys.sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(sums[C:], (ys * ys).sum(0), rtol=1e-4, atol=1e-3)
+
+
 ACTS = {'none': lambda v: v, 'lrelu': lambda v: F.leaky_relu(v, 0.01), 'hswish': F.hardswish}
 
 
