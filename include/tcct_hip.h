@@ -186,6 +186,11 @@ int tcct_conv32_pack_weights_sub(const float* w, void* wp, int KH, int KW, int t
                                  tcct_stream_t stream);
 int tcct_conv32_fwd_strided(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
                             int PW, int xs, int xo, int ys, int yo, int accumulate, tcct_stream_t stream);
+/* the same slab call + the statistics of the train-mode BatchNorm behind the wide convolution (MPViT stem[1], nets/tcct.py:682-689 with the
+ * BatchNorm of Conv2d_BN :80): use it for the LAST input slab of an output slab; stats fp64 {sum[ys], sum of squares[ys]} of the whole tensor,
+ * zero before the first slab */
+int tcct_conv32_fwd_strided_bnstats(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
+                                    int PW, int xs, int xo, int ys, int yo, int accumulate, double* stats, int pre_act, tcct_stream_t stream);
 int tcct_conv32_wgrad_strided(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH,
                               int PW, int xs, int xo, int ds, int dof, int cin_total, int o_off, int i_off, tcct_stream_t stream);
 /* weight/bias gradient of the same family (ds_read_b64_tr_b16 transposing LDS reads feed the pixel-contraction MFMA);

@@ -68,7 +68,9 @@ __global__ void __launch_bounds__(MB, 2)
 k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
               int N, int H, int W, int KHr, int KWr, int PH, int PW, int tilesH, int tilesW, int ntiles, int xs, int xo, int ys,
               int yo, int accum, double* __restrict__ stats, int stat_pre, const float* __restrict__ aff, int aff_post,
-              const bf16* yadd) {
+              const bf16* yadd, int stats_sq_off) {
+    // stats_sq_off: the sums of squares go to stats[stats_sq_off ..+32) (32 for a 32-channel tensor; C when this launch covers a 32-channel
+    // slab of a C-channel tensor whose statistics buffer is {sum[C], sum of squares[C]} and `stats` points at the slab's first channel)
     // xs/xo, ys/yo: channels per pixel in memory and channel offset of the 32-channel slab read / written; accum: y = result + yadd
     // (yadd == NULL: + the previous contents of y; same layout as y)
     // stats != NULL (STATS): also accumulate per-channel sum / sum-of-squares of pre_act(y) (y as stored, i.e. bf16-rounded) into
@@ -311,7 +313,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
             }
         }
         __syncthreads();
-        if (tid < 64) atomicAdd(&stats[tid], (double)red[tid] + (double)red[64 + tid] + (double)red[128 + tid] + (double)red[192 + tid]);
+        if (tid < 64) atomicAdd(&stats[tid < 32 ? tid : stats_sq_off + tid - 32], (double)red[tid] + (double)red[64 + tid] + (double)red[128 + tid] + (double)red[192 + tid]);
     }
 }
 
@@ -319,7 +321,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
  * size requires PH = (KH-1)/2 etc. but any PH <= KH-1, PW <= KW-1 with "same" output extent H x W is accepted. */
 static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
                            int PH, int PW, int xs, int xo, int ys, int yo, int accum, double* stats, int stat_pre, tcct_stream_t stream,
-                           const float* aff = nullptr, int aff_post = 0, bool affine = false, const void* yadd = nullptr);
+                           const float* aff = nullptr, int aff_post = 0, bool affine = false, const void* yadd = nullptr, int stats_sq_off = 32);
 extern "C" int tcct_conv32_fwd(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
                                int PH, int PW, tcct_stream_t stream) {
     return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, 0, nullptr, 0, stream);
@@ -351,9 +353,18 @@ extern "C" int tcct_conv32_fwd_strided(const void* x, const void* wp, const floa
     TCCT_CHECK(xs % 8 == 0 && xo % 8 == 0 && ys % 4 == 0 && yo % 4 == 0 && xo + 32 <= xs && yo + 32 <= ys, "conv32_fwd_strided: bad slab");
     return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, xs, xo, ys, yo, accumulate, nullptr, 0, stream);
 }
+/* tcct_conv32_fwd_strided + the statistics of the train-mode BatchNorm behind the WIDE convolution (MPViT stem[1]: 32 -> 64, 3x3, reference
+ * nets/tcct.py:682-689 / :80): call it for the LAST input slab of an output slab (the accumulated value is what gets counted); stats fp64
+ * {sum[ys], sum of squares[ys]} of the whole ys-channel tensor, zero before the first slab */
+extern "C" int tcct_conv32_fwd_strided_bnstats(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH,
+                                               int KW, int PH, int PW, int xs, int xo, int ys, int yo, int accumulate, double* stats,
+                                               int pre_act, tcct_stream_t stream) {
+    TCCT_CHECK(xs % 8 == 0 && xo % 8 == 0 && ys % 4 == 0 && yo % 4 == 0 && xo + 32 <= xs && yo + 32 <= ys && stats, "conv32_fwd_strided_bnstats: bad slab");
+    return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, xs, xo, ys, yo, accumulate, stats + yo, pre_act, stream, nullptr, 0, false, nullptr, ys);
+}
 static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
                            int PH, int PW, int xs, int xo, int ys, int yo, int accum, double* stats, int stat_pre, tcct_stream_t stream,
-                           const float* aff, int aff_post, bool affine, const void* yadd) {
+                           const float* aff, int aff_post, bool affine, const void* yadd, int stats_sq_off) {
     TCCT_CHECK(KH >= 1 && KW >= 1 && KH * KW <= 13 * 13, "conv32_fwd: bad kernel %dx%d", KH, KW);
     TCCT_CHECK(2 * PH == KH - 1 && 2 * PW == KW - 1, "conv32_fwd: only 'same' padding (got pad %d,%d for %dx%d)", PH, PW, KH, KW);
     const bool vert = (KW == 1 && KH > 1);
@@ -376,7 +387,7 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
         static bool attr = false;                                                                                           \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_mfma<V, S, KHT, KWT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
         hipLaunchKernelGGL((k_conv32_mfma<V, S, KHT, KWT>), dim3(grid), dim3(MB), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, \
-                           KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum, stats, stat_pre, aff, aff_post, (const bf16*)yadd);                \
+                           KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo, accum, stats, stat_pre, aff, aff_post, (const bf16*)yadd, stats_sq_off);                \
     } while (0)
 #define CF_S(V, KHT, KWT)                                                                                   \
     do {                                                                                                    \

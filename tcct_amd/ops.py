@@ -247,7 +247,7 @@ def _mfma_slabs_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
             and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
 
 
-def _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, transposed):
+def _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, transposed, stats=None, stat_pre=0):
     """y[..., Cout] = conv(x[..., Cin]) via 32x32 sub-GEMMs; transposed=True computes the input gradient (x=dy, w OIHW [Cin_orig=Cout
     here][...]) i.e. roles of the weight's O/I dims swap"""
     wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
@@ -258,7 +258,10 @@ def _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, trans
             else:       # w is OIHW [Cin(this call's input = orig Cout)][Cout(this call's output = orig Cin)]
                 lib.conv32_pack_weights_sub(w, wp, KH, KW, 1, Cout, 32 * ih, 32 * oh)
             b = bias[32 * oh:32 * oh + 32] if (bias is not None and ih == 0) else None
-            lib.conv32_fwd_strided(x, wp, b, y, N, H, W, KH, KW, padh, padw, Cin, 32 * ih, Cout, 32 * oh, 1 if ih > 0 else 0)
+            if stats is not None and ih == Cin // 32 - 1:       # the last input slab: the accumulated output is what the BatchNorm statistics count
+                lib.conv32_fwd_strided_bnstats(x, wp, b, y, N, H, W, KH, KW, padh, padw, Cin, 32 * ih, Cout, 32 * oh, 1 if ih > 0 else 0, stats, stat_pre)
+            else:
+                lib.conv32_fwd_strided(x, wp, b, y, N, H, W, KH, KW, padh, padw, Cin, 32 * ih, Cout, 32 * oh, 1 if ih > 0 else 0)
             if ih + 1 < Cin // 32 or oh + 1 < Cout // 32:
                 wp = torch.empty_like(wp)
 
@@ -306,7 +309,11 @@ class _Conv2d(torch.autograd.Function):
             else:
                 lib.pw_fwd(x, w, bias, y, N * H * W, Cin, Cout, 0, dtype_code(odt))
         elif _mfma_slabs_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
-            _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, False)
+            sums = None
+            if stats_box is not None:       # fused train-mode BN statistics of the consumer (MPViT stem[1])
+                sums = ZERO.get((2 * Cout,), torch.float64, x.device) if ZERO.active else torch.zeros(2 * Cout, device=x.device, dtype=torch.float64)
+                stats_box[1] = sums
+            _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, False, sums, stats_box[0] if stats_box is not None else 0)
         elif mfma:
             if ctx.needs_input_grad[0]:     # the input-gradient pack of the same weights comes out of the same launch (used by backward())
                 wp2 = torch.empty(2 * KH * KW * 1024, device=x.device, dtype=torch.bfloat16)

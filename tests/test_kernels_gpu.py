@@ -156,6 +156,25 @@ def test_dwconv(dt, cfg, hw):
         torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=t['rtol'], atol=t['atol'] * max(1.0, b.grad.abs().max().item()))
 
 
+@pytest.mark.parametrize('cfg', [(32, 64, 3, 3, 'none', 19, 70), (64, 96, 1, 9, 'lrelu', 9, 33), (96, 32, 3, 3, 'none', 10, 14), (32, 32, 3, 3, 'lrelu', 21, 37),
+                                 (64, 64, 1, 1, 'none', 40, 55)])
+def test_convolutions_deliver_the_batchnorm_statistics_of_their_consumer(cfg):
+    """conv2d(..., stats_pre=...) tags its bf16 output with per-channel sum / sum of squares of pre_act(y) as stored, for every MFMA family:
+    32 -> 32 (conv32), wide convolutions as 32-channel slabs (MPViT stem[1] 32 -> 64; the stc_tb encoder), pointwise GEMMs"""
+    from tcct_amd import ops
+    Ci, Co, KH, KW, pre, H, W = cfg
+    x = nhwc(rnd(2, Ci, H, W, dt=torch.bfloat16), torch.bfloat16)
+    w = (rnd(Co, Ci, KH, KW, seed=1) / (Ci * KH * KW) ** 0.5).cuda()
+    b = rnd(Co, seed=2).cuda()
+    y = ops.conv2d(x, w, b, pad=(KH // 2, KW // 2), stats_pre=pre)
+    assert torch.equal(y, ops.conv2d(x, w, b, pad=(KH // 2, KW // 2)))
+    sums, code = y._bn_sums
+    assert code == ops.ACT[pre] and sums.shape == (2 * Co,)
+    u = ACTS[pre](y.float()).reshape(-1, Co).double()
+    torch.testing.assert_close(sums[:Co], u.sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(sums[Co:], (u * u).sum(0), rtol=1e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('cfg', [(64, 1, (37, 45)), (96, 2, (21, 131)), (32, 1, (9, 258))])
 def test_dwconv_with_batchnorm_statistics(dt, cfg):
