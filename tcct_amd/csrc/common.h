@@ -203,6 +203,16 @@ __device__ __forceinline__ Lerp src_index(int o, float scale, int in, int align)
     return r;
 }
 
+// Sum over each aligned group of 16 lanes, result in all 16: four DPP adds (xor 1 and xor 2 as quad permutes, then mirror inside each
+// 8 and inside each 16 -- after the first two steps every lane of a quad holds the quad's sum, so a mirrored partner is as good as an
+// xor partner).  The __shfl_xor form is a ds_bpermute per step: address arithmetic + an LDS round trip, ~4x the instructions.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));    // row_mirror
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -546,7 +546,15 @@ __global__ void k_ln_fwd(const T* __restrict__ x, T* __restrict__ y, int64_t M, 
     const int lane = threadIdx.x & 15;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
-    for (int64_t m0 = grp * LN_TOK; m0 < M; m0 += ngrp * LN_TOK) {     // all 16 lanes of a group share m0: no divergence inside shuffles
+    float gam[NCH][4], bet[NCH][4];       // the lane's channels are fixed: scale / shift live in registers (8 loads per row before)
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = lane + 16 * j;
+            gam[j][k] = ch < C4 ? gamma[ch * 4 + k] : 0.f; bet[j][k] = ch < C4 ? beta[ch * 4 + k] : 0.f;
+        }
+    for (int64_t m0 = grp * LN_TOK; m0 < M; m0 += ngrp * LN_TOK) {     // all 16 lanes of a group share m0: no divergence inside the lane exchanges
         f4 v[LN_TOK][NCH];
 #pragma unroll
         for (int t = 0; t < LN_TOK; ++t)
@@ -561,8 +569,7 @@ __global__ void k_ln_fwd(const T* __restrict__ x, T* __restrict__ y, int64_t M, 
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < NCH; ++j) s += v[t][j].v[0] + v[t][j].v[1] + v[t][j].v[2] + v[t][j].v[3];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            s = row16_sum(s);
             float mean = s / (float)C, q = 0.f;
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
@@ -572,8 +579,7 @@ __global__ void k_ln_fwd(const T* __restrict__ x, T* __restrict__ y, int64_t M, 
                     for (int k = 0; k < 4; ++k) { float d = v[t][j].v[k] - mean; q += d * d; }
                 }
             }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            q = row16_sum(q);
             float rstd = rsqrtf(q / (float)C + eps);
             if (m < M) {
                 if (lane == 0) { mean_rstd[2 * m] = mean; mean_rstd[2 * m + 1] = rstd; }
@@ -583,7 +589,7 @@ __global__ void k_ln_fwd(const T* __restrict__ x, T* __restrict__ y, int64_t M, 
                     if (ch < C4) {
                         f4 r;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) r.v[k] = (v[t][j].v[k] - mean) * rstd * gamma[ch * 4 + k] + beta[ch * 4 + k];
+                        for (int k = 0; k < 4; ++k) r.v[k] = (v[t][j].v[k] - mean) * rstd * gam[j][k] + bet[j][k];
                         st4(y + m * C + ch * 4, r);
                     }
                 }
@@ -656,8 +662,7 @@ __global__ void __launch_bounds__(NBR) k_ln_bwd(const T* __restrict__ x, const T
                 }
             }
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s1 = row16_sum(s1); s2 = row16_sum(s2);
         s1 /= (float)C; s2 /= (float)C;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
