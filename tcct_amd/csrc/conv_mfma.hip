@@ -380,7 +380,7 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
     TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32_fwd: bad tile count");
     TCCT_CHECK((int64_t)H * W * xs * 2 < (1LL << 31) && (int64_t)H * W * ys * 2 < (1LL << 31),
                "conv32_fwd: one image of %d x %d x %d channels exceeds the 2 GiB buffer-descriptor range", H, W, xs > ys ? xs : ys);
-    int grid = (int)(nt < 512 ? nt : 512);
+    int grid = (int)(nt < 512 ? nt : 512);  // (256 / 384 / 768 blocks: 0.323 / 0.294 / 0.292 ms against 0.236 with 512 = two resident blocks per CU)
     hipStream_t st = (hipStream_t)stream;
 #define CF_LAUNCH(V, S, KHT, KWT)                                                                                           \
     do {                                                                                                                    \

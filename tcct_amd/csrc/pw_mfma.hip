@@ -971,6 +971,8 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
     const int64_t tiles = (M + PB_P - 1) / PB_P;
     int per_cu = (int)((160 * 1024) / (lds + 256));
     if (per_cu > 2) per_cu = 2;
+    // (one block per CU looked better in tools/kbench.py -- 64->64 @L1 0.135 -> 0.125 ms, 32->32 @L0 0.258 -> 0.235 -- but inside the training
+    // step, where the tensors are not the same two buffers over and over, it was slower: k_pw_bwd 2.46 -> 2.57 ms per step; two per CU stay)
     int64_t gx = 256 * per_cu;
     if (gx > tiles) gx = tiles;
 #define BL(NTV, KTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<NTV, KTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
@@ -1158,6 +1160,7 @@ static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const f
     const int64_t tiles = (M + PB_P - 1) / PB_P;
     int per_cu = (int)((160 * 1024) / (lds + 256));
     if (per_cu > 2) per_cu = 2;
+    // (as for k_pw_bwd: one block per CU won by 3-10 % in the micro-benchmark and lost inside the step -- the statistics variants by 60 %)
     int64_t gx = 256 * per_cu;
     if (gx > tiles) gx = tiles;
     hipStream_t st = (hipStream_t)stream;
