@@ -155,7 +155,7 @@ def bwd_bench():
     t3 = timeit(lambda: lib.conv32_bwd3x3(x, dy, wp, None, dx, dw, db, B, H, W))
     gb = x.numel() * 2 / 1e9
     print(f'conv32 3x3 @L0: dgrad {t1:.3f} + wgrad {t2:.3f} = {t1 + t2:.3f} ms | fused {t3:.3f} ms ({3 * gb / t3 * 1e3:.0f} GB/s algorithmic)')
-    for (M, K, N) in [(8 * 400 * 552, 64, 64), (8 * 400 * 552, 128, 96), (8 * 400 * 552, 96, 32), (8 * 800 * 1104, 32, 32), (8 * 200 * 276, 96, 96), (8 * 200 * 276, 128, 128), (8 * 100 * 138, 128, 128), (8 * 50 * 69, 160, 160) if False else (8 * 100 * 138, 96, 96)]:
+    for (M, K, N) in [(8 * 400 * 552, 64, 64), (8 * 400 * 552, 128, 96), (8 * 400 * 552, 96, 32), (8 * 800 * 1104, 32, 32), (8 * 200 * 276, 96, 96), (8 * 200 * 276, 128, 128), (8 * 100 * 138, 128, 128), (8 * 100 * 138, 96, 96)]:
         x = torch.randn(M, K, device='cuda').to(dt); dy = torch.randn(M, N, device='cuda').to(dt)
         w = torch.randn(N, K, device='cuda') * 0.1
         dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty(N, device='cuda')
