@@ -346,8 +346,8 @@ def reg_loss(sd, logits, onehot, eps_pred, eps_true, jit_true, jit_pred, train=T
     prob_true = prob_true.sum(1, keepdim=True).clamp_max(1)
 
     def lap_reg(x):
-        x = _conv(sd, 'lap_reg.0', x, pad=1, groups=4)
-        return _conv(sd, 'lap_reg.1', x, pad=1, groups=4).abs()
+        x = _conv(sd, 'lap_reg.0', x, pad=1, groups=x.shape[1])        # dim_reg = out_channels - 1 depthwise groups (reg.py:64-68)
+        return _conv(sd, 'lap_reg.1', x, pad=1, groups=x.shape[1]).abs()
 
     def sampling_softmax(x, eps):
         g = F.softmax(x - torch.log(-torch.log(eps)) / 2, dim=-2)

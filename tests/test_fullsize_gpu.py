@@ -209,6 +209,77 @@ def test_fullsize_forward_and_losses_match_the_oracle(dt, tmp_path):
     assert rel(edge, eb) <= 0.6 * rel(eb, e32) + 1e-3
 
 
+def test_fullsize_backward_matches_the_oracle(tmp_path):
+    """ONE B-scan at the full bench resolution (3 x 800 x 1104), fp32, full loss (Dice + reg + fpl), seeded default weights: the BACKWARD
+    pass against the oracle's CPU backward.  At this size every weight-gradient kernel accumulates over many tiles and blocks (level 4 is
+    50 x 69, level 0 is 1 725 tiles of 16 x 32) -- the multi-tile accumulation and the per-block atomics the small fixtures never reach.
+    Per-tensor relative L2 over all trained tensors above noise level and over a named list spanning CNN L0-L4, the ViT stages, the
+    decoder and the loss modules: median <= 1e-3, max <= 1e-2; total norm within 2e-3."""
+    import argparse
+    import os
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle'))
+    import tcct_oracle as O
+    from tcct_amd.nets import stc_tt, RegNet
+    from tcct_amd.kite import KiteSeg
+    H, W = 800, 1104
+    torch.manual_seed(0)
+    sd0 = {k: v.clone() for k, v in RegNet(stc_tt(5), con='cos', out_channels=5).state_dict().items()}
+    img3, lab = O.synth_batch(1, H, W, seed=78)
+    g = torch.Generator().manual_seed(10)
+    noise = (torch.rand(1, 4, H, W, generator=g), torch.rand(1, 4, H, W, generator=g), torch.rand(1, 1, H, 1, generator=g), torch.rand(1, 1, H, 1, generator=g))
+    model = RegNet(stc_tt(5, compute_dtype=torch.float32), con='cos', out_channels=5)
+    model.load_state_dict(sd0)
+
+    class DS:
+        out_channels = 5
+    args = argparse.Namespace(los='di', lr=1e-2, gpu='0', pl=False, bs=1, coff_ds=1, udh=True, reg=True, epl=False, coff_udh=1, coff_reg=.1,
+                              coff_epl=.1, bug=True)
+    k = KiteSeg(model=model, dataset=DS(), root=str(tmp_path), args=args)
+    model.train()
+    model.base.base_vit.drop_probs = [0.0] * 4
+    out = model(img3[:, :1].cuda())
+    tot = (k.grad_calc(out, lab.cuda(), ds=True, criterion=k.criterion) + model.regular_udh(out[0], lab.cuda())
+           + model.regular_reg(out[0], lab.cuda(), noise=noise) * 0.1)
+    k.optimG.zero_grad(set_to_none=True)
+    tot.backward()
+    gh = {n: p.grad.detach().double().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    # oracle backward on the CPU
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    sd = {kk: v.clone() for kk, v in sd0.items()}
+    for n, v in sd.items():
+        if v.is_floating_point() and not n.endswith(('running_mean', 'running_var')) and not n.startswith('fcp.'):
+            v.requires_grad_(True)
+    oh = torch.nn.functional.one_hot(lab, 5).permute(0, 3, 1, 2)
+    to, _, _, _ = O.total_loss(sd, img3, oh, udh=True, reg=True, noise=noise)
+    to.backward()
+    go = {n: v.grad.double() for n, v in sd.items() if getattr(v, 'grad', None) is not None}
+    assert set(gh) == set(go)
+    assert abs(tot.item() - to.item()) <= 1e-4 * abs(to.item())
+    gmaxn = max(v.norm().item() for v in go.values())
+    big = [n for n in sorted(go) if go[n].norm().item() > 1e-3 * gmaxn]
+    e = {n: (gh[n] - go[n]).norm().item() / go[n].norm().item() for n in big}
+    named = ['base.base_cnn.cnn.0.weight', 'base.base_cnn.path_estan.0.block12.0.weight', 'base.base_cnn.path_estan.0.block34.0.weight',
+             'base.base_cnn.path_estan.0.block34.1.weight', 'base.base_cnn.path_estan.0.block5.0.weight', 'base.base_cnn.path_estan.1.block12.1.weight',
+             'base.base_cnn.path_estan.2.block34.2.weight', 'base.base_cnn.path_estan.3.block5.0.weight', 'base.base_cnn.path_estan.4.block12.0.weight',
+             'base.base_vit.stem.0.conv.weight', 'base.base_vit.stem.1.conv.weight',
+             'base.base_vit.patch_embed_stages.0.patch_embeds.0.patch_conv.dwconv.weight', 'base.base_vit.mhca_stages.0.InvRes.conv1.conv.weight',
+             'base.base_vit.mhca_stages.0.aggregate.conv.weight', 'base.base_vit.mhca_stages.1.mhca_blks.0.MHCA_layers.0.mlp.fc1.weight',
+             'base.base_vit.mhca_stages.2.InvRes.dwconv.weight', 'base.base_vit.mhca_stages.3.mhca_blks.0.cpe.proj.weight',
+             'base.tran_vit0.0.weight', 'base.tran_cnn3.0.weight', 'base.head.0.weight', 'base.dec1.prep.0.weight', 'base.dec4.post.0.weight',
+             'base.t324.weight', 'base.aux0.weight', 'base.aux4.weight', 'lap_reg.0.weight', 'lap_map.0.weight']
+    en = {n: (gh[n] - go[n]).norm().item() / max(go[n].norm().item(), 1e-30) for n in named}
+    v = np.array(list(e.values()))
+    vn = np.array(list(en.values()))
+    print(f'full-size fp32 backward: {len(big)} tensors rel-L2 median {np.median(v):.2e} p90 {np.percentile(v, 90):.2e} max {v.max():.2e} '
+          f'({max(e, key=e.get)}); named {len(named)}: median {np.median(vn):.2e} max {vn.max():.2e} ({max(en, key=en.get)})')
+    assert len(named) >= 20 and np.median(vn) <= 1e-3 and vn.max() <= 1e-2, en
+    assert np.median(v) <= 1e-3 and v.max() <= 1e-2, sorted(e.items(), key=lambda t: -t[1])[:5]
+    tn = lambda d: sum((t ** 2).sum() for t in d.values()).sqrt().item()      # noqa: E731
+    assert abs(tn(gh) - tn(go)) <= 2e-3 * tn(go), (tn(gh), tn(go))
+
+
 def test_allocator_pool_stays_bounded_over_steps_fullsize(tmp_path):
     """bench shape, 26 training steps: the multi-stream step (encoders on two streams, weight gradients on a third) must not make the
     caching allocator grow step after step.  Activations / gradients handed to the weight-gradient stream are kept alive until the

@@ -520,6 +520,97 @@ def test_real_checkpoint_inference_matches_reference(name, dtype):
     assert len(np.unique(masks[0])) >= 4            # a real multi-layer segmentation, not a constant map
 
 
+def test_trained_weights_train_step_matches_reference(tmp_path):
+    """The WELL-CONDITIONED reference-held fixture (oracle/make_golden_duke_train.py): the reference's real trained checkpoint
+    (task1/onnx/tcct_duke.pt, 9 classes, bf16-rounded as in ckpt_duke.npz) in the real RegNet(stc_tt(9)), TRAIN mode, two 160x160 crops of
+    the reference's B-scan, forced DropPath masks, recorded noise: forward + Dice(ds) + udh + reg + backward + clip + AdamW
+    (reference kite/loop_seg.py:121-130,146-171).  With trained weights the train-mode network is well conditioned, so the literal 1e-3
+    fp32 contract is asserted against the REFERENCE's outputs on all four heads, `feats`, every loss part and the boundary coordinates,
+    and the parameter gradients at 1e-3 relative L2 per tensor -- no fp64 envelope, no exempted tensors beyond exact-zero-gradient biases."""
+    from tcct_amd import checkpoint as C
+    from tcct_amd.nets import stc_tt, RegNet
+    from tcct_amd.kite import KiteSeg
+    fx = np.load(os.path.join(GOLD, 'duke_train_2x160x160.npz'))
+    n_class = int(fx['n_class'])
+    model = RegNet(stc_tt(n_class), con='cos', out_channels=n_class)
+    missing, unexpected = C.load_reference_checkpoint(model, os.path.join(GOLD, 'ckpt_duke.npz'))
+    assert not missing
+    model = model.cuda().train()
+
+    class DS:
+        out_channels = n_class
+    args = argparse.Namespace(los='di', lr=1e-2, gpu='0', pl=False, bs=2, coff_ds=1, udh=True, reg=True, epl=False, coff_udh=1, coff_reg=.1,
+                              coff_epl=.1, bug=True)
+    k = KiteSeg(model=model, dataset=DS(), root=str(tmp_path), args=args)
+    model.train()
+    img = torch.from_numpy(fx['crops_u8']).permute(0, 3, 1, 2).float().div(255).cuda()
+    lab = torch.from_numpy(fx['lab']).long().cuda()
+    model.base.base_vit.forced_dp_masks = [torch.tensor(m, dtype=torch.float32) for m in fx['dp_masks']]
+    out = model(img)
+    parts = {'dice': k.grad_calc(out, lab, ds=True, criterion=k.criterion), 'udh': model.regular_udh(out[0], lab) * 1.0}
+    noise = tuple(torch.tensor(fx[f'noise{i}']) for i in range(4))
+    parts['reg'] = model.regular_reg(out[0], lab, noise=noise) * 0.1
+    total = sum(parts.values())
+    sub = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4))
+    errs = {'out0': relerr(out[0], fx['out0'])}
+    for i in (1, 2, 3):
+        errs[f'out{i}'] = relerr(out[i][sub], fx[f'out{i}'])
+    errs['feats'] = relerr(model.base.feats[0][sub], fx['feats'])
+    for nm in ('dice', 'udh', 'reg'):
+        errs['loss_' + nm] = relerr(parts[nm], fx['loss_' + nm])
+    errs['loss_total'] = relerr(total, fx['loss_total'])
+    errs['edge_pred'] = relerr(model.edge_pred.view(-1), fx['edge_pred'].reshape(-1))
+    errs['edge_true'] = relerr(model.edge_true.view(-1), fx['edge_true'].reshape(-1))
+    print('duke train-mode forward errs', {a: f'{b:.2e}' for a, b in errs.items()})
+    for a, b in errs.items():
+        assert b < 1e-3, (a, b)         # the literal contract, on everything
+    k.optimG.zero_grad(set_to_none=True)
+    total.backward()
+    named = dict(model.named_parameters())
+    names = [str(n) for n in fx['grad_names']]
+    assert sorted(n for n, p in named.items() if p.grad is not None) == sorted(names)
+    gmax = float(fx['grad_max'].max())
+    l2 = dict(zip(names, fx['grad_l2']))
+    worst, n_full = 0.0, 0
+    for key in fx.files:
+        if not key.startswith('grad:'):
+            continue
+        n = key[5:]
+        ref = torch.from_numpy(fx[key]).double()
+        if ref.abs().max().item() < 1e-4 * gmax:        # a bias in front of a train-mode BatchNorm: exact gradient 0, fp32 noise in the reference too
+            continue
+        e = (named[n].grad.double().cpu() - ref).norm().item() / ref.norm().item()
+        worst, n_full = max(worst, e), n_full + 1
+        assert e < 1e-3, (n, e)
+    assert n_full >= 20, n_full
+    # every trained tensor: gradient norm against the reference's (noise-level tensors excluded as above)
+    en = []
+    for n, gm in zip(names, fx['grad_max']):
+        if gm < 1e-4 * gmax:
+            continue
+        en.append(abs(named[n].grad.double().norm().item() - l2[n]) / l2[n])
+        assert en[-1] < 1e-3, (n, en[-1])
+    print(f'duke train-mode gradients: {n_full} full tensors worst rel-L2 {worst:.2e}; {len(en)} tensor norms worst {max(en):.2e}')
+    before = {n: named[n].detach().clone() for n in names}
+    k.optimG.step()
+    assert abs(k.optimG.last_total_norm.item() - float(fx['grad_total_norm'])) < 1e-3 * float(fx['grad_total_norm'])
+    lr = float(fx['lr'])
+    assert abs(k.optimG.param_groups[0]['lr'] - lr) < 1e-12
+    for key in fx.files:
+        if key.startswith('step:'):
+            n = key[5:]
+            gref = fx['grad:' + n]
+            if np.abs(gref).max() < 1e-4 * gmax:
+                continue
+            d = (named[n].detach().double() - before[n].double()).cpu().numpy() / lr
+            big = np.abs(gref) > 0.05 * np.abs(gref).max()      # step 1 of Adam is ~ -sign(g): compare away from the sign flips
+            assert np.abs(d - fx[key])[big].max() < 2e-2, (n, np.abs(d - fx[key])[big].max())
+    sd = model.state_dict()
+    for key in fx.files:
+        if key.startswith('buf:'):
+            assert relerr(sd[key[4:]].float(), fx[key].astype(np.float32)) < 1e-4, key
+
+
 @pytest.mark.parametrize('name', ['gtc_tt', 'cnnu', 'vitu', 'stc_tb', 'gtc_tb', 'pnnu'])
 def test_sibling_variants_match_reference(name, tmp_path):
     """gtc_tt / gtc_tb (GateFusion), stc_tb (wide CNN encoder), cnnu, pnnu, vitu (reference nets/tcct.py:1048-1061,1097-1102,

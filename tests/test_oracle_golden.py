@@ -71,6 +71,56 @@ def test_oracle_reproduces_reference_fixture(name):
     close(O.iou_scorem(mask, oh, 1), fx['iou_scorem'], 1e-6)
 
 
+def test_oracle_reproduces_trained_weights_train_fixture():
+    """tests/golden/duke_train_2x160x160.npz (oracle/make_golden_duke_train.py): the reference's real trained 9-class checkpoint in train
+    mode, full loss, backward -- the well-conditioned reference-held fixture.  The oracle must reproduce outputs, losses and gradients."""
+    torch.set_num_threads(4)
+    fx = np.load(os.path.join(GOLD, 'duke_train_2x160x160.npz'))
+    ck = np.load(os.path.join(GOLD, 'ckpt_duke.npz'))
+    sd = {}
+    for k in ck.files:
+        if k.startswith('w::'):
+            sd[k[3:]] = torch.from_numpy(ck[k].view(np.int16).copy()).view(torch.bfloat16).float()
+        elif k.startswith('i::'):
+            sd[k[3:]] = torch.from_numpy(ck[k].copy())
+    names = [str(n) for n in fx['grad_names']]
+    for n in names:
+        sd[n].requires_grad_(True)
+    C = int(fx['n_class'])
+    img = torch.from_numpy(fx['crops_u8']).permute(0, 3, 1, 2).float() / 255
+    oh = torch.nn.functional.one_hot(torch.from_numpy(fx['lab']).long(), C).permute(0, 3, 1, 2)
+    masks = [torch.tensor(m, dtype=torch.float32) for m in fx['dp_masks']]
+    noise = tuple(torch.tensor(fx[f'noise{i}']) for i in range(4))
+    want = {}
+    tot, parts, outs, feats = O.total_loss(sd, img, oh, udh=True, reg=True, dp_masks=masks, noise=noise, want=want)
+    sub = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4))
+
+    def close(a, b, tol=1e-4):
+        a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+        assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+    close(outs[0], fx['out0'])
+    for i in (1, 2, 3):
+        close(outs[i][sub], fx[f'out{i}'])
+    close(feats[sub], fx['feats'])
+    for nm in ('dice', 'udh', 'reg'):
+        close(parts[nm], fx['loss_' + nm], 2e-5)
+    close(tot, fx['loss_total'], 2e-5)
+    close(want['edge_pred'], fx['edge_pred'])
+    close(want['edge_true'], fx['edge_true'])
+    tot.backward()
+    gmax = float(fx['grad_max'].max())
+    n_full = 0
+    for key in fx.files:
+        if key.startswith('grad:'):
+            ref = torch.from_numpy(fx[key]).double()
+            if ref.abs().max().item() < 1e-4 * gmax:
+                continue
+            e = (sd[key[5:]].grad.double() - ref).norm().item() / ref.norm().item()
+            assert e < 1e-3, (key, e)
+            n_full += 1
+    assert n_full >= 20
+
+
 def test_oracle_known_answers():
     """known-answer checks that need no reference"""
     # MetaPool == 3x3 box over (token, channel) with valid-count divisor, minus identity
