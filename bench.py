@@ -282,6 +282,8 @@ def main():
     if os.environ.get('TCCT_DIST_BACKEND') == 'gloo':      # test mode: several ranks share the GPUs that exist (RCCL needs one GPU per rank)
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
+    torch.manual_seed(2023 + rank)          # per-rank noise stream (DropPath masks, Gumbel / jitter draws): seed = base + rank, SURVEY 8(e)
+    torch.cuda.manual_seed_all(2023 + rank)
     if a.roofline_only:
         print(json.dumps({'roofline': dominant_kernel_roofline(a)}), file=out_stream, flush=True)
         return

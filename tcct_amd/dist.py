@@ -52,6 +52,24 @@ def allreduce_sum_(flat):
     return flat
 
 
+def average_buffers_(model):
+    """mean over the ranks of every floating-point buffer (BatchNorm running_mean / running_var); integer buffers (num_batches_tracked)
+    are equal on all ranks already.  Called before validation so that all ranks evaluate one and the same model."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    bufs = [b for b in model.buffers() if b.is_floating_point()]
+    if not bufs:
+        return
+    flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    off = 0
+    with torch.no_grad():
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+
+
 N_BUCKETS = 3
 
 
@@ -91,9 +109,23 @@ class GradBuckets:
         self.armed = False
         self.overlap = True
         self.launch_log = []            # (bucket, 'backward' | 'step') of the last step: tests and bench read it
+        self.params = None
+        self.fallbacks = 0              # steps whose early launches were called off (a gradient arrived through autograd)
 
-    def bind(self, flat_g, sizes):
+    def bind(self, flat_g, sizes, params=None):
+        """params: the optimizer's parameters in flat-buffer order.  With them, a bucket only leaves DURING the backward pass when every one of
+        its gradients was written in place into the flat buffer (p.grad still None / already the slot): a gradient that arrived through
+        autograd (fp32 parity mode, an op without an in-place slot) is copied in by step(), i.e. after an early launch would have sent stale
+        data -- such a step falls back to launching everything in finish() (same decision on every rank: the code path is deterministic)"""
         self.flat = flat_g
+        self.params = None
+        if params is not None:
+            self.params, i = [], 0
+            for n in sizes:
+                grp, got = [], 0
+                while got < n:
+                    grp.append(params[i]); got += params[i].numel(); i += 1
+                self.params.append(grp)
         self.ranges, off = [], 0
         for n in sizes:
             self.ranges.append((off, off + n))
@@ -117,7 +149,12 @@ class GradBuckets:
         if b is None or not self.armed:
             return
         self.ready[b] = True
-        while self.launched < self.n_buckets - 1 and self.ready[self.launched]:
+        while self.armed and self.launched < self.n_buckets - 1 and self.ready[self.launched]:
+            if self.params is not None and not all(p.grad is None or (getattr(p, '_grad_slot', None) is not None and p.grad.data_ptr() == p._grad_slot.data_ptr())
+                                                   for p in self.params[self.launched]):
+                self.armed = False          # not every gradient of this bucket sits in the flat buffer yet: everything leaves in finish()
+                self.fallbacks += 1
+                break
             self._launch(self.launched, 'backward')
 
     def _launch(self, b, where):

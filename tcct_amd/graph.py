@@ -3,10 +3,21 @@ for 1.7 ms of GPU work at bs=1 -- the reference validates with bs=1, kite/loop_s
 per input shape with torch.cuda.CUDAGraph (hipGraph on ROCm; the library only launches on the stream it is given, so capture needs
 nothing special) and replayed.  Weights and BatchNorm buffers are read through their storage at replay time, so in-place updates
 (the fused optimizer, load_state_dict) are seen without re-capturing; a re-bound storage triggers a new capture."""
+import os
+
 import torch
 
 from . import ops
 from ._lib import TcctError
+
+
+_POOL = []
+
+
+def _shared_pool():
+    if not _POOL:
+        _POOL.append(torch.cuda.graph_pool_handle())
+    return _POOL[0]
 
 
 class GraphedPredict:
@@ -109,7 +120,12 @@ class GraphedTrainStep:
             self.s_img, self.s_lab = img.clone(), lab.clone()
             self.stream.wait_stream(cur)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self.stream):
+            kw = {}
+            if os.environ.get('TCCT_GRAPH_ERRMODE'):            # experiments on the late-capture crash
+                kw['capture_error_mode'] = os.environ['TCCT_GRAPH_ERRMODE']
+            if os.environ.get('TCCT_GRAPH_SHARED_POOL') == '1':
+                kw['pool'] = _shared_pool()
+            with torch.cuda.graph(g, stream=self.stream, **kw):
                 self.s_loss = k.train_step(self.s_img, self.s_lab)
             k.udh_out = None
             k.optimG._step -= 1         # the Python side of step() ran once while capturing; the replay below is the real step

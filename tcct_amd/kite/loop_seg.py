@@ -70,7 +70,10 @@ class KiteSeg(KiteBack):
             self.train(i)
             self.schedG.step()
             if i % 10 == 0 or (i > 0.5 * epochs and i % 5 == 0):
-                logs = self.val(epoch=i)            # every rank validates (identical weights): best_dice stays in step without a broadcast
+                if self.world > 1:                  # BatchNorm running statistics are per replica (each rank's own shard): average them so that every
+                    from .. import dist as tdist    # rank validates the SAME eval-mode model and rank 0's checkpoint is not shard-local
+                    tdist.average_buffers_(self.model)
+                logs = self.val(epoch=i)            # identical weights + identical buffers on every rank: best_dice stays in step
                 if logs['val_f1s'] > self.best_dice:
                     self.best_dice = logs['val_f1s']
                     if self.rank == 0:              # one writer per file; the others wait so that nobody reads a half-written checkpoint
@@ -122,8 +125,13 @@ class KiteSeg(KiteBack):
         self.optimG.step()          # clip_grad_norm_(12) is fused into the step kernel
         return losSum.detach()
 
+    def epoch_seed(self, epoch):
+        """reference loop_seg.py:109 seeds every epoch with epoch*311+2023; a data-parallel rank adds its rank (seed = base + rank)
+        so that the replicas draw DIFFERENT DropPath masks and Gumbel / jitter noise for their different shards (rank 0 == the reference)"""
+        return epoch * 311 + 2023 + self.rank
+
     def train(self, epoch, alpha=.9):
-        setup_seed(epoch * 311 + 2023)
+        setup_seed(epoch * 311 + 2023)          # reference loop_seg.py:109; also what a shuffling loader draws its order from: the same on every rank
         torch.set_grad_enabled(True)
         self.model.train()
         tot = torch.zeros((), device=self.device)
@@ -131,10 +139,15 @@ class KiteSeg(KiteBack):
         # contiguous slice of it (tcct_amd.dist.shard_batch; SURVEY 8(e): global 64 -> 8 x 8), so the ranks see different B-scans and run
         # the same number of steps.  A ragged last global batch that does not divide by the world size is dropped on every rank.
         from .. import dist as tdist
-        for i, imgs in enumerate(self.dataset.trainSet(bs=self.args.bs * self.world)):
+        batches = iter(self.dataset.trainSet(bs=self.args.bs * self.world))      # the loader's order is fixed here, identically on all ranks
+        if self.world > 1:
+            setup_seed(self.epoch_seed(epoch))  # from here on the per-rank noise stream (DropPath masks, Gumbel / jitter draws)
+        for i, imgs in enumerate(batches):
             img, lab, _, _ = self.dataset.parse(imgs)
             if self.world > 1:
                 if img.shape[0] % self.world:
+                    if self.rank == 0:
+                        print(f'\n(data parallel: ragged global batch of {img.shape[0]} dropped on all {self.world} ranks)')
                     continue
                 sl = tdist.shard_batch(img.shape[0], self.world, self.rank)
                 img, lab = img[sl], lab[sl]

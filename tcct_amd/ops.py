@@ -130,6 +130,7 @@ def end_step():
 # latency-bound weight gradients of the coarse levels overlap it.  TCCT_STREAMS=0 disables.
 _WGRAD_USED = {}
 _WGRAD_KEEP = []
+_WGRAD_FRESH_EVENT = os.environ.get('TCCT_WGRAD_FRESH_EVENT', '0') == '1'          # experiment on the late-capture crash
 _WGRAD_RECORD_STREAM = os.environ.get('TCCT_WGRAD_RECORD_STREAM', '0') == '1'      # the old behaviour, kept for A/B measurements only
 
 
@@ -163,6 +164,8 @@ class _wgrad_stream:
         if ent is None:         # the side stream and ONE reusable event for the cur -> side dependency (a wait captures the state of the
             ent = _SIDE_STREAMS[key] = (fresh_stream(cur.device), torch.cuda.Event())   # event at the time it is issued)
         self.side, ev = ent
+        if _WGRAD_FRESH_EVENT:
+            ev = torch.cuda.Event()
         ev.record(cur)
         self.side.wait_event(ev)
         # the block only launches this library's kernels into pre-allocated gradient slots: name the stream for them instead of
@@ -1057,7 +1060,7 @@ class _BnPoolFork(torch.autograd.Function):
         if dpool is None and dskip is None:
             return (None,) * 10
         if dpool is None:           # only the full-size output was used: a plain BatchNorm backward
-            dpool = ZERO.get((N, H // 2, W // 2, C), x.dtype, x.device)
+            dpool = torch.zeros((N, H // 2, W // 2, C), device=x.device, dtype=x.dtype)      # an INPUT of the kernel: must really be zero
         dpool = _as(dpool, x.dtype)
         if dskip is not None:
             dskip = _as(dskip, x.dtype)
@@ -1072,7 +1075,7 @@ class _BnPoolFork(torch.autograd.Function):
 def bn_pool_ok(x, training):
     """shapes the fused BatchNorm + MaxPool2d(2) kernels take (train mode, gradients wanted): even extents, C/4 dividing 256"""
     N, H, W, C = x.shape
-    return (BN_POOL_FUSE and training and torch.is_grad_enabled() and x.requires_grad and C % 4 == 0 and 256 % (C // 4) == 0
+    return (BN_POOL_FUSE and training and torch.is_grad_enabled() and x.requires_grad and C % 4 == 0 and C <= 256 and 256 % (C // 4) == 0
             and H % 2 == 0 and W % 2 == 0 and H >= 2 and W >= 2)
 
 

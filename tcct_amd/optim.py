@@ -53,7 +53,10 @@ class FlatAdamW(torch.optim.Optimizer):
         its optimizer (kite/loopback.py:56-59), so this is an addition, not a wire format"""
         sd = super().state_dict()
         if self._flat is not None:
-            sd['flat'] = dict(step=self._step, m=self._flat['m'].clone(), v=self._flat['v'].clone(), numel=self._flat['n'])
+            # `layout`: the order of the flat buffer (parameter shapes in buffer order).  It depends on which parameters had a gradient at
+            # the first step and, with TCCT_DP_OVERLAP=1, on the bucket sort: equal numel does not mean equal layout
+            sd['flat'] = dict(step=self._step, m=self._flat['m'].clone(), v=self._flat['v'].clone(), numel=self._flat['n'],
+                              layout=[tuple(p.shape) for p in self._flat['plist']])
         return sd
 
     def load_state_dict(self, sd):
@@ -65,6 +68,10 @@ class FlatAdamW(torch.optim.Optimizer):
                 raise TcctError('FlatAdamW.load_state_dict(): take one step first (the flat buffers are laid out at the first step)')
             if int(flat['numel']) != self._flat['n']:
                 raise TcctError(f"FlatAdamW.load_state_dict(): saved state has {flat['numel']} elements, this optimizer {self._flat['n']}")
+            layout = flat.get('layout')
+            if layout is not None and [tuple(x) for x in layout] != [tuple(p.shape) for p in self._flat['plist']]:
+                raise TcctError('FlatAdamW.load_state_dict(): the saved moments are laid out in another parameter order (saved with a different '
+                                'TCCT_DP_OVERLAP mode or another set of trained parameters); applying them would permute the AdamW state')
             self._flat['m'].copy_(flat['m'])
             self._flat['v'].copy_(flat['v'])
             self._step = int(flat['step'])
@@ -108,7 +115,7 @@ class FlatAdamW(torch.optim.Optimizer):
                           sumsq=torch.zeros((), device=dev, dtype=torch.float64),
                           norm=torch.zeros((), device=dev, dtype=torch.float32), n=n)
         if self.buckets is not None:
-            self.buckets.bind(flat_g, sizes)
+            self.buckets.bind(flat_g, sizes, plist)
 
     @property
     def flat_numel(self):

@@ -144,9 +144,36 @@ flat.copy_(per_sample[sl].sum(0))
 gb.on_mark('dec')
 gb.finish()
 assert gb.launch_log == [(0, 'step'), (1, 'step'), (2, 'step')] and torch.allclose(flat, per_sample.sum(0), atol=1e-5)
+# BatchNorm buffers averaged before validation: every rank evaluates the same model
+bn = torch.nn.BatchNorm2d(3)
+with torch.no_grad():
+    bn.running_mean.fill_(float(rank)); bn.running_var.fill_(1.0 + 2.0 * rank)
+tdist.average_buffers_(bn)
+assert torch.allclose(bn.running_mean, torch.full((3,), 0.5)) and torch.allclose(bn.running_var, torch.full((3,), 2.0)) and bn.num_batches_tracked.item() == 0
+# per-rank noise streams (SURVEY 8(e): seed = base + rank): the two replicas must draw DIFFERENT DropPath masks
+import types
+from tcct_amd.kite.loop_seg import KiteSeg
+from tcct_amd.kite.loopback import setup_seed
+from tcct_amd.nets.tcct import MPViT
+seed = KiteSeg.epoch_seed(types.SimpleNamespace(rank=rank), 3)
+assert seed == 3 * 311 + 2023 + rank
+setup_seed(seed)
+vit = MPViT().train()
+masks = torch.stack([torch.stack(pair) for pair in vit._dp_scales(64, torch.device('cpu')) if pair is not None]).reshape(-1)
+import torch.distributed as tdd
+both = [torch.zeros_like(masks) for _ in range(2)]
+tdd.all_gather(both, masks)
+assert not torch.equal(both[0], both[1]), 'both ranks drew the same DropPath masks'
 tdist.barrier()
 os.write(1, ('rank %%d ok\n' %% rank).encode())      # one atomic write: the two ranks share stdout
 '''
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        return s_.getsockname()[1]
 
 
 def test_data_parallel_plumbing_gloo_world2(tmp_path):
@@ -154,7 +181,7 @@ def test_data_parallel_plumbing_gloo_world2(tmp_path):
     script.write_text(DDP_SCRIPT % ROOT)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-                        '--master-port', '29613', str(script)], capture_output=True, text=True, env=env, timeout=240)
+                        '--master-port', str(_free_port()), str(script)], capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'rank 0 ok' in r.stdout and 'rank 1 ok' in r.stdout
 

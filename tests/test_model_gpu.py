@@ -803,6 +803,13 @@ tdist.barrier()
 """
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        return s_.getsockname()[1]
+
+
 def _split(flat, names, numels):
     out, off = {}, 0
     for n, k_ in zip(names, numels):
@@ -828,7 +835,7 @@ def test_two_ranks_average_gradients_like_one_process_on_the_mean(overlap, tmp_p
     script.write_text(DDP_GPU_SCRIPT % dict(root=root, tmp=str(tmp_path)))
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', TCCT_DIST_BACKEND='gloo', TCCT_DP_OVERLAP=overlap)
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-                        '--master-port', '29617' if overlap == '1' else '29619', str(script)], capture_output=True, text=True, env=env, timeout=900)
+                        '--master-port', str(_free_port()), str(script)], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     a, b = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
     assert torch.equal(a['p'], b['p']) and torch.equal(a['g'], b['g'])          # same summed gradient, same update, bit for bit

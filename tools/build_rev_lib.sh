@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build the kernels of another git revision (default HEAD) into ab/libtcct_REV.so for same-box A/B timing:
-#   bash tools/build_ref_lib.sh [REV]   ->  TCCT_LIB_PATH=ab/libtcct_REV.so python tools/kbench.py ...
+#   bash tools/build_rev_lib.sh [REV]   ->  TCCT_LIB_PATH=ab/libtcct_REV.so python tools/kbench.py ...
 set -e
 REV=${1:-HEAD}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
