@@ -112,6 +112,14 @@ int tcct_bn_bwd_reduce(const void* x, const void* dy, int64_t M, int C, const fl
 int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_t M, int C, const float* mean_rstd,
                       const float* ab, const float* gamma, const double* sums, int pre_act, int post_act,
                       float* dgamma, float* dbeta, int dtype, tcct_stream_t stream);
+/* per-channel constants of the train-mode BatchNorm backward for kernels that rebuild the input gradient on load instead of reading it from
+ * a tcct_bn_bwd_apply pass: du = a (dz' - S1/M - xhat S2/M) = c1 dz' + c2 y + c3 with y the BatchNorm input (pre = none).  sums [2][C] fp64
+ * = {S1 = sum dz', S2 = sum dz' xhat} (tcct_bn_bwd_reduce) or, raw = 1, {sum dz', sum dz' y} (reduction epilogues).  Writes coef [5][C] =
+ * {c1, c2, c3, a, b}, dgamma [C] = S2, dbeta [C] = S1. */
+int tcct_bn_bwd_coef(const double* sums, int raw, int64_t M, int C, const float* mean_rstd, const float* ab, float* coef, float* dgamma,
+                     float* dbeta, tcct_stream_t stream);
+/* {sum dz', sum dz' y} (raw, from a reduction epilogue) -> {S1, S2 = sum dz' xhat}: the form tcct_bn_bwd_apply reads */
+int tcct_bn_sums_from_raw(const double* raw, const float* mean_rstd, int C, double* sums, tcct_stream_t stream);
 
 /* fused CrossCNNBlock junction y = act(BN_A(pre(xa)) + BN_B(pre(xb))) (nets/tcct.py:811,817,825-826: LeakyReLU -> BN on both
  * branches, then F.gelu of the sum), train mode; abA, abB and mean_rstdA, mean_rstdB come from tcct_bn_finalize; sums fp64 [4C] */
@@ -221,6 +229,16 @@ int tcct_pw_bwd_cat2(const void* x1, const void* x2, const void* dy, const float
                      tcct_stream_t stream);
 int tcct_pw_bwd_residual2(const void* x, const void* dy, const float* w, const void* res, void* dx_sum, void* dx_plain, float* dw, float* dbias,
                           int64_t M, int K, int N, tcct_stream_t stream);
+/* Backward of z = post(BN_train(x W^T + bias)) [+ residual] (Conv2d_BN / DWConv2d_BN.pwconv / FTC.tran_*, reference nets/tcct.py:55-97,
+ * 124-126,966-974) given dz, the gradient of the BatchNorm OUTPUT: the BatchNorm backward apply pass is folded into the staging of this
+ * kernel (dy_conv = c1 dz post'(a y + b) + c2 y + c3 per element, coef [5][N] = {c1, c2, c3, a, b} from tcct_bn_bwd_coef), and, with
+ * red_post >= 0, the reduction pass of the BatchNorm IN FRONT of the convolution (x = post_prev(a_prev y_prev + b_prev), ab_prev [2][K]) is
+ * folded into its dx epilogue: sums_prev [2][K] fp64 += {sum dz', sum dz' y_prev} (raw form).  x2 / dx2 non-NULL: the concatenated operands
+ * of tcct_pw_bwd_cat2 (the reduction then covers the first half).  tcct_pw_bwd_bn_supported says which (K, N, kinds) have a kernel. */
+int64_t tcct_pw_bwd_bn_supported(int K, int N, int post, int red_post, int split);
+int tcct_pw_bwd_bn(const void* x, const void* x2, const void* dz, const void* y, const float* coef, int post, const float* w, const void* res,
+                   void* dx, void* dx2, float* dw, float* dbias, int64_t M, int K, int N, const void* y_prev, const float* ab_prev,
+                   int red_post, double* sums_prev, tcct_stream_t stream);
 /* the same for an N-column slab of a wider output: dy rows have stride ldy elements (multiple of 8) and dy / dw / dbias point at the slab
  * (nn.Linear(dim, 3 dim) of FactorAtt_ConvRelPosEnc, nets/tcct.py:307, runs as slabs of <= 160 columns) */
 int tcct_pw_wgrad_strided(const void* x, const void* dy, int64_t ldy, float* dw, float* dbias, int64_t M, int K, int N,

@@ -3,7 +3,7 @@
 //
 // FPL pipeline (per step, all classes at once because the label classes partition the pixels):
 //   key[p]  = (label[p] << 32) | ~bits(prob_label[p])          -> ascending sort == per class, descending prob
-//   sort    : rocPRIM device radix sort (35 significant bits) — the one library primitive used on the path
+//   sort    : rocPRIM device radix sort (36 significant bits: 4 class bits + 32 probability bits) — the one library primitive used on the path
 //   binmean : sorted position r of class c (segment offset off_c, n_c pixels, N_c = n_c/32) falls in bin r/N_c
 //             (tail n_c%32 dropped); 8 lanes gather one 32-channel feature row; register run-length accumulation,
 //             fp32 atomics per (class, bin) flush
@@ -14,7 +14,7 @@
 
 #define FB 256
 #define FPL_BINS 32
-#define FPL_MAXC 8
+#define FPL_MAXC 16     // classes (power of two): 5 for GOALS, 9 for the reference's Duke / HCMS models
 
 __global__ void k_fpl_keys(const uint8_t* __restrict__ lab, const float* __restrict__ prob, int64_t M,
                            unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ counts) {
@@ -36,7 +36,7 @@ extern "C" int64_t tcct_fpl_sort_workspace_bytes(int64_t M) {
     size_t bytes = 0;
     unsigned long long* k = nullptr;
     uint32_t* v = nullptr;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)M, 0, 35, (hipStream_t)0, false);
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)M, 0, 36, (hipStream_t)0, false);
     if (e != hipSuccess) return -1;
     return (int64_t)bytes;
 }
@@ -51,7 +51,7 @@ extern "C" int tcct_fpl_sort(const uint8_t* labels, const float* prob, int64_t M
     hipLaunchKernelGGL(k_fpl_keys, dim3(tcct_grid(M, FB, 2048)), dim3(FB), 0, st, labels, prob, M, (unsigned long long*)keys_in, vals_in, counts);
     size_t bytes = (size_t)workspace_bytes;
     hipError_t e = rocprim::radix_sort_pairs(workspace, bytes, (unsigned long long*)keys_in, (unsigned long long*)keys_out,
-                                             vals_in, vals_out, (size_t)M, 0, 35, st, false);
+                                             vals_in, vals_out, (size_t)M, 0, 36, st, false);
     if (e != hipSuccess) { tcct_set_error("fpl_sort: rocprim radix_sort_pairs failed: %s", hipGetErrorString(e)); return -2; }
     TCCT_LAUNCH_OK();
 }

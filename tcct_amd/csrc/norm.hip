@@ -325,6 +325,40 @@ extern "C" int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_
     TCCT_LAUNCH_OK();
 }
 
+// per-channel constants for consumers that rebuild du = a (dz' - S1/M - xhat S2/M) on load: du = c1 dz' + c2 y + c3 (pre-activation none)
+__global__ void k_bn_bwd_coef(const double* __restrict__ sums, int raw, int64_t M, int C, const float* __restrict__ mean_rstd,
+                              const float* __restrict__ ab, float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const double mu = mean_rstd[c], rs = mean_rstd[C + c];
+    const double S1 = sums[c];
+    const double S2 = raw ? (sums[C + c] - mu * S1) * rs : sums[C + c];        // raw: sum dz' y  ->  sum dz' (y - mu) rstd
+    dbeta[c] = (float)S1;
+    dgamma[c] = (float)S2;
+    const double a = ab[c], s1 = S1 / (double)M, s2 = S2 / (double)M;
+    coef[c] = (float)a;
+    coef[C + c] = (float)(-a * s2 * rs);
+    coef[2 * C + c] = (float)(a * (s2 * rs * mu - s1));
+    coef[3 * C + c] = ab[c];
+    coef[4 * C + c] = ab[C + c];
+}
+extern "C" int tcct_bn_bwd_coef(const double* sums, int raw, int64_t M, int C, const float* mean_rstd, const float* ab, float* coef,
+                                float* dgamma, float* dbeta, tcct_stream_t stream) {
+    TCCT_CHECK(C >= 1 && C <= NB && M > 0, "bn_bwd_coef: C=%d unsupported", C);
+    hipLaunchKernelGGL(k_bn_bwd_coef, dim3(1), dim3(NB), 0, (hipStream_t)stream, sums, raw, M, C, mean_rstd, ab, coef, dgamma, dbeta);
+    TCCT_LAUNCH_OK();
+}
+
+__global__ void k_bn_sums_from_raw(const double* __restrict__ raw, const float* __restrict__ mean_rstd, int C, double* __restrict__ out) {
+    const int c = threadIdx.x;
+    if (c < C) { out[c] = raw[c]; out[C + c] = (raw[C + c] - (double)mean_rstd[c] * raw[c]) * (double)mean_rstd[C + c]; }
+}
+extern "C" int tcct_bn_sums_from_raw(const double* raw, const float* mean_rstd, int C, double* sums, tcct_stream_t stream) {
+    TCCT_CHECK(C >= 1 && C <= NB, "bn_sums_from_raw: C=%d unsupported", C);
+    hipLaunchKernelGGL(k_bn_sums_from_raw, dim3(1), dim3(NB), 0, (hipStream_t)stream, raw, mean_rstd, C, sums);
+    TCCT_LAUNCH_OK();
+}
+
 // ------------------------------------------------------------------ train-mode BatchNorm + MaxPool2d(2) (CrossResNet levels 0-3)
 // The last BatchNorm of an encoder level is followed by `self.pool` AND kept as the level's output (reference nets/tcct.py:876-884, block5 at
 // :820-823).  One pass writes both: z = post(BN(pre(x))) (full size) and pooled = maxpool2(z), plus one byte per (window, 4 channels) with

@@ -760,11 +760,25 @@ extern "C" int tcct_c3_wgrad(const void* x4, const void* dy, float* dw, float* d
 #define PB_P 128
 // SPLIT: x = [x | x2] and dx = [dx | dx2] are two tensors of K/2 channels each (the aggregate convolution over a concatenation,
 // MHCA_stage, reference nets/tcct.py:600-616): no concat / split passes; x2 / dx2 then travel in the res / dx_plain arguments.
-template <int NT, int KT, bool SPLIT = false>
+// BNP >= 0: a train-mode BatchNorm sits behind this convolution (Conv2d_BN, DWConv2d_BN.pwconv, tran_*; reference nets/tcct.py:55-97,124-126,
+// 966-974) and `dy` is the gradient of the BatchNorm OUTPUT z = post(a y + b): the gradient of the convolution output is rebuilt while the
+// tile is staged, dy_conv = c1 dz' + c2 y + c3 with dz' = dz post'(a y + b) (the per-channel constants carry the two batch sums of the
+// BatchNorm backward, tcct_bn_bwd_coef) -- the separate BatchNorm backward apply pass (read dz, read y, write dy) is gone, this kernel reads
+// y in its place.  BNP = post activation kind (0 none, 2 hardswish).
+// REDP >= 0: the INPUT x is itself the output of a train-mode BatchNorm z_prev = post_prev(ap y_prev + bp) whose only remaining gradient is
+// this kernel's dx (+ res): the two batch sums of THAT BatchNorm's backward (sum dz', sum dz' y_prev per channel) are accumulated in the dx
+// epilogue, so its separate reduction pass (read dz, read y_prev) is gone as well.  REDP = post_prev kind (0 / 2).
+struct PwBnBwd { const bf16* y; const float* coef; const bf16* yprev; const float* abprev; double* sums_prev; };
+template <int KIND> __device__ __forceinline__ float pw_act_grad(float u) {
+    if (KIND == TCCT_ACT_HSWISH) return u < -3.f ? 0.f : (u <= 3.f ? (2.f * u + 3.f) * (1.f / 6.f) : 1.f);
+    return 1.f;
+}
+template <int NT, int KT, bool SPLIT = false, int BNP = -1, int REDP = -1>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ w, const bf16* __restrict__ res,
-         bf16* __restrict__ dx, bf16* __restrict__ dx_plain, float* __restrict__ dw, float* __restrict__ dbias, int64_t M) {
+         bf16* __restrict__ dx, bf16* __restrict__ dx_plain, float* __restrict__ dw, float* __restrict__ dbias, int64_t M, PwBnBwd bn) {
     constexpr int K = 32 * KT, N = 32 * NT;
+    constexpr bool BN = BNP >= 0, RED = REDP >= 0;
     constexpr int SX = 64 * KT + ((KT & 1) ? 0 : 64), SD = 64 * NT + ((NT & 1) ? 0 : 64);      // rows == 64 / 192 mod 256: conflict-free transposing reads
     constexpr int SW = 2 * N + 16;
     constexpr int XS = K / 16, DS = N / 16;                // 16-byte staging slots per thread (128 px x K/8 chunks / 256 threads)
@@ -773,6 +787,8 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
     unsigned char* sD = sX + PB_P * SX;
     unsigned char* sW = sD + PB_P * SD;
     unsigned char* sS = sW + ((K * SW + 15) & ~15);        // per-wave epilogue transpose scratch: 32 px x 80 B
+    float* sC = reinterpret_cast<float*>(sS + 4 * 2560);   // BN: [5][N] = c1, c2, c3, a, b;  RED: [2][K] = ap, bp behind it
+    float* sP = sC + (BN ? 5 * N : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     // W^T as bf16 [k][n]: w is [N][K] fp32; consecutive threads read consecutive k of one n (coalesced), transposed on the LDS side
@@ -780,6 +796,13 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
         const int n = i / K, k = i - n * K;
         *reinterpret_cast<bf16*>(sW + k * SW + n * 2) = __float2bfloat16(w[i]);
     }
+    if (BN) for (int i = tid; i < 5 * N; i += PWB) sC[i] = bn.coef[i];
+    if (RED) for (int i = tid; i < 2 * (SPLIT ? K / 2 : K); i += PWB) sP[i] = bn.abprev[i];
+    float rs[RED ? KT : 1][8], rq[RED ? KT : 1][8];        // RED: per-lane partial sums of dz' and dz' y_prev (channels 8 (lane & 3) + k of tile kt)
+#pragma unroll
+    for (int a = 0; a < (RED ? KT : 1); ++a)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rs[a][k] = rq[a][k] = 0.f;
     f32x16 accw[(NT * KT + 3) / 4];
 #pragma unroll
     for (int a = 0; a < (NT * KT + 3) / 4; ++a)
@@ -796,7 +819,9 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(res ? res : x), 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)dx, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(dx_plain ? dx_plain : dx), 0, xbytes, 0x00020000);
-    u32x4 px[XS], pd[DS];
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(BN ? bn.y : dy), 0, dbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ryp = __builtin_amdgcn_make_buffer_rsrc((void*)(RED ? bn.yprev : x), 0, xbytes, 0x00020000);
+    u32x4 px[XS], pd[DS], py[BN ? DS : 1];
     // a tile's rows are one contiguous span of memory: slot i of a thread = bytes [16 (tid + 256 i), +16) of it (fully coalesced);
     // rows beyond M fall outside the descriptor and read as zeros
     auto prefetch = [&](int64_t tile) {
@@ -808,8 +833,12 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
         }
 #pragma unroll
         for (int j = 0; j < DS; ++j) pd[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, bd + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
+        if (BN) {
+#pragma unroll
+            for (int j = 0; j < DS; ++j) py[j] = __builtin_amdgcn_raw_buffer_load_b128(ry, bd + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
+        }
     };
-    auto stage = [&]() {
+    auto stage = [&](int64_t tile) {        // tile: the tile whose registers are being staged (rows >= M of it must give dy = 0)
 #pragma unroll
         for (int j = 0; j < XS; ++j) {
             const int jj = (SPLIT && j >= XS / 2) ? j - XS / 2 : j;
@@ -819,7 +848,35 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
 #pragma unroll
         for (int j = 0; j < DS; ++j) {
             const int q = tid + j * PWB, p = q / (N / 8), c = q - p * (N / 8);
-            *reinterpret_cast<u32x4*>(sD + p * SD + c * 16) = pd[j];
+            u32x4 v = pd[j];
+            if (BN) {
+                // dy_conv = c1 dz post'(a y + b) + c2 y + c3, rounded to bf16 like the tensor the separate apply pass used to write
+                const bool live = tile * PB_P + p < M;
+                const float* cc = sC + c * 8;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 c1 = *reinterpret_cast<const float4*>(cc + 4 * h), c2 = *reinterpret_cast<const float4*>(cc + N + 4 * h);
+                    const float4 c3 = *reinterpret_cast<const float4*>(cc + 2 * N + 4 * h);
+                    float4 ca = c1, cb = c1;
+                    if (BNP != TCCT_ACT_NONE) { ca = *reinterpret_cast<const float4*>(cc + 3 * N + 4 * h); cb = *reinterpret_cast<const float4*>(cc + 4 * N + 4 * h); }
+                    const float k1[4] = {c1.x, c1.y, c1.z, c1.w}, k2[4] = {c2.x, c2.y, c2.z, c2.w}, k3[4] = {c3.x, c3.y, c3.z, c3.w};
+                    const float ka[4] = {ca.x, ca.y, ca.z, ca.w}, kb[4] = {cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const uint32_t gz = pd[j][2 * h + e2], gy = py[j][2 * h + e2];
+                        float z0 = __uint_as_float(gz << 16), z1 = __uint_as_float(gz & 0xffff0000u);
+                        const float y0 = __uint_as_float(gy << 16), y1 = __uint_as_float(gy & 0xffff0000u);
+                        if (BNP != TCCT_ACT_NONE) {
+                            z0 *= pw_act_grad<BNP>(ka[2 * e2] * y0 + kb[2 * e2]);
+                            z1 *= pw_act_grad<BNP>(ka[2 * e2 + 1] * y1 + kb[2 * e2 + 1]);
+                        }
+                        const float o0 = k1[2 * e2] * z0 + k2[2 * e2] * y0 + k3[2 * e2];
+                        const float o1 = k1[2 * e2 + 1] * z1 + k2[2 * e2 + 1] * y1 + k3[2 * e2 + 1];
+                        v[2 * h + e2] = live ? pack_bf16x2(o0, o1) : 0u;
+                    }
+                }
+            }
+            *reinterpret_cast<u32x4*>(sD + p * SD + c * 16) = v;
         }
     };
     // transposing-read lane bases (see k_pw_wgrad)
@@ -837,7 +894,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
     if (tile < tiles) {
         prefetch(tile);
         __syncthreads();            // weights staged
-        stage();
+        stage(tile);
         prefetch(tile + gridDim.x);                 // beyond the last tile: every row out of range, zeros, never used
     }
     __syncthreads();
@@ -877,7 +934,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
             }
         }
         __syncthreads();                              // every wave has read the staged tile
-        if (tile + (int64_t)gridDim.x < tiles) stage();
+        if (tile + (int64_t)gridDim.x < tiles) stage(tile + (int64_t)gridDim.x);
         prefetch(tile + 2 * (int64_t)gridDim.x);
         // ---- dx epilogue: per-wave LDS transpose -> 16-byte stores (16 whole 64-byte pixel segments per wave instruction)
         unsigned char* sc = sS + wave * 2560;
@@ -897,9 +954,24 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
                 const int p = (lane >> 2) + 16 * h2, cch = lane & 3;
                 u32x4 o = *reinterpret_cast<const u32x4*>(sc + p * 80 + cch * 16);
                 const int64_t mm = m0 + p;
+                auto red_acc = [&](const u32x4& ov, uint32_t offy, int kch) {     // kch: first channel of the lane's 8 inside x / y_prev rows
+                    const u32x4 yv = __builtin_amdgcn_raw_buffer_load_b128(ryp, offy, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float d0 = __uint_as_float(ov[k] << 16), d1 = __uint_as_float(ov[k] & 0xffff0000u);
+                        const float y0 = __uint_as_float(yv[k] << 16), y1 = __uint_as_float(yv[k] & 0xffff0000u);
+                        if (REDP != TCCT_ACT_NONE) {
+                            d0 *= pw_act_grad<REDP < 0 ? 0 : REDP>(sP[kch + 2 * k] * y0 + sP[KS + kch + 2 * k]);
+                            d1 *= pw_act_grad<REDP < 0 ? 0 : REDP>(sP[kch + 2 * k + 1] * y1 + sP[KS + kch + 2 * k + 1]);
+                        }
+                        rs[RED ? kt : 0][2 * k] += d0; rq[RED ? kt : 0][2 * k] += d0 * y0;
+                        rs[RED ? kt : 0][2 * k + 1] += d1; rq[RED ? kt : 0][2 * k + 1] += d1 * y1;
+                    }
+                };
                 if (SPLIT) {        // channels [0, K/2) -> dx, [K/2, K) -> dx2 (= dx_plain argument), rows of K/2 channels each
                     const uint32_t off2 = mm < M ? (uint32_t)((mm * KS + (kt * 32) % KS + cch * 8) * 2) : 0x80000000u;
                     __builtin_amdgcn_raw_buffer_store_b128(o, kt * 32 < KS ? ro : rp, off2, 0, 0);
+                    if (RED && kt * 32 < KS) red_acc(o, off2, kt * 32 + cch * 8);       // the BatchNorm sits in front of the FIRST half (x, not x2)
                     continue;
                 }
                 const uint32_t off = mm < M ? (uint32_t)((mm * K + kt * 32 + cch * 8) * 2) : 0x80000000u;
@@ -912,10 +984,39 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
                                            __uint_as_float(o[k] & 0xffff0000u) + __uint_as_float(rv[k] & 0xffff0000u));
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(o, ro, off, 0, 0);
+                if (RED) red_acc(o, off, kt * 32 + cch * 8);
             }
             wave_lds_fence();
         }
         __syncthreads();                              // the next tile's image is complete
+    }
+    if (RED) {
+        // lanes with equal (lane & 3) hold different pixels of the same 8 channels: butterfly over lane bits 2..5, per-wave LDS slots, fp64 atomics
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][K] (the staged tiles are dead)
+        constexpr int KR = SPLIT ? K / 2 : K;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt * 32 >= KR) break;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float a = rs[kt][k], b = rq[kt][k];
+#pragma unroll
+                for (int o = 32; o > 2; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (lane < 4) {
+                    red[wave * 2 * KR + kt * 32 + 8 * lane + k] = a;
+                    red[wave * 2 * KR + KR + kt * 32 + 8 * lane + k] = b;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i2 = tid; i2 < KR; i2 += PWB) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) { a += (double)red[wv * 2 * KR + i2]; b += (double)red[wv * 2 * KR + KR + i2]; }
+            atomicAdd(&bn.sums_prev[i2], a); atomicAdd(&bn.sums_prev[KR + i2], b);
+        }
+        __syncthreads();
     }
     // ---- weight-gradient tiles straight from the owning wave's registers: lanes r = 0..31 of a register are 128 contiguous bytes
 #pragma unroll
@@ -939,7 +1040,8 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
 /* Fused backward of y = x W^T + b for bf16 rows: dx [M,K] (= dy W, + res when res != NULL), dw [N,K] fp32 and dbias [N] fp32 (nullable)
  * are ACCUMULATED into after being cleared here (or by the caller: tcct_set_outputs_prezeroed).  K, N in {32, 64, 96, 128}. */
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
-                       int64_t M, int K, int N, tcct_stream_t stream, bool split = false);
+                       int64_t M, int K, int N, tcct_stream_t stream, bool split = false, int bnp = -1, int redp = -1,
+                       PwBnBwd bn = PwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr});
 /* the same over a concatenation: x = [x1 | x2], dx = [dx1 | dx2], each [M, K/2] (K = 128): backward of tcct_pw_fwd_cat2 */
 extern "C" int tcct_pw_bwd_cat2(const void* x1, const void* x2, const void* dy, const float* w, void* dx1, void* dx2, float* dw, int64_t M,
                                 int K, int N, tcct_stream_t stream) {
@@ -957,8 +1059,40 @@ extern "C" int tcct_pw_bwd_residual2(const void* x, const void* dy, const float*
     TCCT_CHECK(res != nullptr && dx_plain != nullptr && dx_plain != dx_sum, "pw_bwd_residual2: needs res and two distinct outputs");
     return pw_bwd_impl(x, dy, w, res, dx_sum, dx_plain, dw, dbias, M, K, N, stream);
 }
+/* Shapes / activation kinds for which tcct_pw_bwd_bn has a kernel (the host mirror asks before building its autograd node):
+ *   post (BatchNorm behind the convolution) and red_post (BatchNorm in front of it, -1: no reduction epilogue): TCCT_ACT_NONE / TCCT_ACT_HSWISH;
+ *   K = N in {64, 96, 128} (the reduction epilogue only at 64); N = 32 with K in {32, 96, 128} without the reduction; the concatenated K = 128 -> N = 96 form. */
+extern "C" int64_t tcct_pw_bwd_bn_supported(int K, int N, int post, int red_post, int split) {
+    const bool p_ok = post == TCCT_ACT_NONE || post == TCCT_ACT_HSWISH;
+    const bool r_ok = red_post == -1 || red_post == TCCT_ACT_NONE || red_post == TCCT_ACT_HSWISH;
+    if (!p_ok || !r_ok) return 0;
+    if (split) return K == 128 && N == 96 && post == TCCT_ACT_HSWISH && (red_post == -1 || red_post == TCCT_ACT_NONE);
+    // (the reduction epilogue keeps 16 more partial sums per 32 input channels in registers: beyond 64 channels the kernel spills -- 94 / 215 VGPRs
+    // at 96 / 128 channels -- and those BatchNorms sit on the small level-2 / level-3 maps anyway)
+    if (K == N && (K == 64 || K == 96 || K == 128)) return red_post == -1 || K == 64;
+    if (N == 32 && (K == 32 || K == 96 || K == 128)) return red_post == -1 && post == TCCT_ACT_NONE;
+    return 0;
+}
+/* Backward of  z = post(BN_train(x W^T + bias)) [+ residual]  given dz (the gradient of z), in ONE pass over dz and y:
+ *   dy_conv is rebuilt from (dz, y, coef) while the tiles are staged (coef [5][N] from tcct_bn_bwd_coef), then dx = dy_conv W (+ res),
+ *   dw += dy_conv^T x, dbias += sum dy_conv as in tcct_pw_bwd.  x2 / dx2 non-NULL: the concatenated form of tcct_pw_bwd_cat2.
+ *   red_post >= 0: x = post_prev(BN_prev(y_prev)) and dx (+ res) is the complete gradient of x -- sums_prev [2][K or K/2] (fp64, zero on entry)
+ *   receive {sum dz', sum dz' y_prev} of BN_prev's backward (raw form: tcct_bn_bwd_coef(raw = 1) converts), ab_prev = BN_prev's {a[K], b[K]}. */
+extern "C" int tcct_pw_bwd_bn(const void* x, const void* x2, const void* dz, const void* y, const float* coef, int post, const float* w,
+                              const void* res, void* dx, void* dx2, float* dw, float* dbias, int64_t M, int K, int N, const void* y_prev,
+                              const float* ab_prev, int red_post, double* sums_prev, tcct_stream_t stream) {
+    const bool split = x2 != nullptr;
+    TCCT_CHECK(tcct_pw_bwd_bn_supported(K, N, post, red_post, split ? 1 : 0), "pw_bwd_bn: K=%d N=%d post=%d red_post=%d split=%d unsupported", K, N, post,
+               red_post, (int)split);
+    TCCT_CHECK(y != nullptr && coef != nullptr && (red_post < 0 || (y_prev && ab_prev && sums_prev)), "pw_bwd_bn: NULL argument");
+    TCCT_CHECK(!split || (dx2 != nullptr && res == nullptr), "pw_bwd_bn: the concatenated form takes x2 / dx2 and no residual");
+    if (red_post >= 0 && !tcct_skip_zero_fill() &&
+        hipMemsetAsync(sums_prev, 0, sizeof(double) * 2 * (split ? K / 2 : K), (hipStream_t)stream) != hipSuccess) { tcct_set_error("pw_bwd_bn: memset failed"); return -2; }
+    return pw_bwd_impl(x, dz, w, split ? x2 : res, dx, split ? dx2 : nullptr, dw, dbias, M, K, N, stream, split, post, red_post,
+                       PwBnBwd{(const bf16*)y, coef, (const bf16*)y_prev, ab_prev, sums_prev});
+}
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
-                       int64_t M, int K, int N, tcct_stream_t stream, bool split) {
+                       int64_t M, int K, int N, tcct_stream_t stream, bool split, int bnp, int redp, PwBnBwd bn) {
     TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && K <= 128 && N <= 128, "pw_bwd: K=%d N=%d unsupported (32..128)", K, N);
     TCCT_CHECK(M > 0 && M * (int64_t)(K > N ? K : N) * 2 < (1LL << 31), "pw_bwd: tensor exceeds the 2 GiB buffer-descriptor range");
     hipStream_t st = (hipStream_t)stream;
@@ -966,7 +1100,8 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
     if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * N, st) != hipSuccess) { tcct_set_error("pw_bwd: memset failed"); return -2; }
     const int NT = N / 32, KT = K / 32;
     const int SX = 64 * KT + ((KT & 1) ? 0 : 64), SD = 64 * NT + ((NT & 1) ? 0 : 64), SW = 2 * N + 16;
-    const size_t lds = (size_t)PB_P * (SX + SD) + (((size_t)K * SW + 15) & ~(size_t)15) + 4 * 2560;
+    const size_t lds = (size_t)PB_P * (SX + SD) + (((size_t)K * SW + 15) & ~(size_t)15) + 4 * 2560 + (bnp >= 0 ? (size_t)5 * N * 4 : 0) +
+                       (redp >= 0 ? (size_t)2 * K * 4 : 0);
     TCCT_CHECK(lds <= 160 * 1024, "pw_bwd: %zu B of LDS", lds);
     const int64_t tiles = (M + PB_P - 1) / PB_P;
     int per_cu = (int)((160 * 1024) / (lds + 256));
@@ -975,15 +1110,36 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
     // step, where the tensors are not the same two buffers over and over, it was slower: k_pw_bwd 2.46 -> 2.57 ms per step; two per CU stay)
     int64_t gx = 256 * per_cu;
     if (gx > tiles) gx = tiles;
-#define BL(NTV, KTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<NTV, KTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
-        hipLaunchKernelGGL((k_pw_bwd<NTV, KTV>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M); }
-#define BLS(NTV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<NTV, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
-        hipLaunchKernelGGL((k_pw_bwd<NTV, 4, true>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M); }
+#define BLX(NTV, KTV, SPV, BNV, RDV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<NTV, KTV, SPV, BNV, RDV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_bwd<NTV, KTV, SPV, BNV, RDV>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M, bn); }
+    if (bnp >= 0) {
+        // the combinations the network has (tcct_pw_bwd_bn_supported): every extra instantiation of this kernel costs ~a minute of hipcc
+        const int H = TCCT_ACT_HSWISH;
+#define BN_SQ(T) \
+        if (bnp == 0 && redp < 0) BLX(T, T, false, 0, -1) else BLX(T, T, false, 2, -1)
+#define BN_SQR(T) \
+        if (bnp == 0 && redp == 0) BLX(T, T, false, 0, 0) else if (bnp == 0 && redp == H) BLX(T, T, false, 0, 2) \
+        else if (bnp == H && redp == 0) BLX(T, T, false, 2, 0) else BLX(T, T, false, 2, 2)
+        static_assert(TCCT_ACT_HSWISH == 2 && TCCT_ACT_NONE == 0, "activation codes are template arguments below");
+        if (split) { if (redp < 0) BLX(3, 4, true, 2, -1) else BLX(3, 4, true, 2, 0) }
+        else if (NT == 1 && KT == 1) BLX(1, 1, false, 0, -1)
+        else if (NT == 1 && KT == 3) BLX(1, 3, false, 0, -1)
+        else if (NT == 1 && KT == 4) BLX(1, 4, false, 0, -1)
+        else if (NT == 2) { if (redp < 0) { BN_SQ(2) } else { BN_SQR(2) } }
+        else if (NT == 3) { BN_SQ(3) }
+        else { BN_SQ(4) }
+#undef BN_SQ
+#undef BN_SQR
+        TCCT_LAUNCH_OK();
+    }
+#define BL(NTV, KTV) BLX(NTV, KTV, false, -1, -1)
+#define BLS(NTV) BLX(NTV, 4, true, -1, -1)
 #define BLK(NTV) switch (KT) { case 1: BL(NTV, 1) break; case 2: BL(NTV, 2) break; case 3: BL(NTV, 3) break; default: if (split) BLS(NTV) else BL(NTV, 4) break; }
     switch (NT) { case 1: BLK(1) break; case 2: BLK(2) break; case 3: BLK(3) break; default: BLK(4) break; }
 #undef BLK
 #undef BLS
 #undef BL
+#undef BLX
     TCCT_LAUNCH_OK();
 }
 

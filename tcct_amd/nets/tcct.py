@@ -32,9 +32,16 @@ def _bn(m, x, pre=None, post=None, residual=None):
                          momentum=m.momentum, pre_act=pre, post_act=post, training=m.training, residual=residual)
 
 
-def _conv_bn(mc, mb, x, pre=None, post=None, residual=None):
-    """post(BN(pre(conv(x)))).  Training: convolution with the BatchNorm statistics fused into its epilogue, then the BN pass;
+def _bn_args(m):
+    return (m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked, m.eps, m.momentum)
+
+
+def _conv_bn(mc, mb, x, pre=None, post=None, residual=None, x_final=False):
+    """post(BN(pre(conv(x)))).  Training: convolution with the BatchNorm statistics fused into its epilogue, then the BN pass -- as ONE autograd
+    node for the 1x1 convolutions (ops.pw_conv_bn: the BatchNorm backward rides on the convolution's backward kernel; x_final: see there);
     eval under no_grad: one kernel, BatchNorm and activations folded into the convolution epilogue (ops.conv_bn_act)."""
+    if ops.pw_conv_bn_ok(x, mc.weight, mc.bias, mb.training, pre, post) and mc.stride[0] == 1:
+        return ops.pw_conv_bn(x, mc.weight, mc.bias, _bn_args(mb), post, residual, x_final=x_final)
     if mb.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
         return _bn(mb, _conv(mc, x, stats_pre=(pre or 'none') if mb.training else None), pre=pre, post=post, residual=residual)
     y = ops.conv_bn_act(x, mc.weight, mc.bias, mc.stride[0], tuple(mc.padding),
@@ -157,7 +164,7 @@ class Conv2d_BN(nn.Module):
         self.conv.weight.data.normal_(0.0, math.sqrt(2.0 / fan_out))
         self.act = act
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, x_final=False):
         sp = 'none' if self.training else None
         if self.conv.in_channels == 3:          # stem[0]: 3-channel input -> im2col + pointwise MFMA
             if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
@@ -166,7 +173,7 @@ class Conv2d_BN(nn.Module):
             m = self.bn
             return ops.conv3x3_c3(x, self.conv.weight, None, self.conv.stride[0], post_act='hswish' if self.act else None,
                                   infer_bn=(m.weight, m.bias, m.running_mean, m.running_var, m.eps))
-        return _conv_bn(self.conv, self.bn, x, post='hswish' if self.act else None, residual=residual)
+        return _conv_bn(self.conv, self.bn, x, post='hswish' if self.act else None, residual=residual, x_final=x_final)
 
 
 class DWConv2d_BN(nn.Module):
@@ -348,7 +355,9 @@ class ResBlock(nn.Module):
 
     def tail(self, f, x):
         f = _bn(self.norm, _dw(self.dwconv, f, bn_stats=self.norm.training), post='hswish')       # statistics out of the convolution's launch
-        return self.conv2(f, residual=x)          # x + BN(conv2(f)): the add rides on the normalisation pass
+        # x + BN(conv2(f)): the add rides on the normalisation pass; conv2 is the only consumer of f, so the backward reduction of `norm`
+        # rides on conv2's input-gradient epilogue (x_final)
+        return self.conv2(f, residual=x, x_final=True)
 
 
 class MHCA_stage(nn.Module):
@@ -365,8 +374,12 @@ class MHCA_stage(nn.Module):
             # x has three consumers (InvRes.conv1, ConvPosEnc, the InvRes residual).  They read a chain of aliases so that each
             # input-gradient kernel adds the gradient of the consumers behind it: no separate accumulation passes over x
             c1 = self.InvRes.conv1
-            f, x1 = ops.conv2d_fork(x, c1.conv.weight, None, 1, 0, stats_pre='none' if c1.bn.training else None)
-            f = _bn(c1.bn, f, post='hswish')
+            if ops.pw_conv_bn_ok(x, c1.conv.weight, None, c1.bn.training, None, 'hswish'):
+                # conv1's input gradient + the alias' gradient is the complete gradient of x (= the patch embedding's BatchNorm output)
+                f, x1 = ops.pw_conv_bn(x, c1.conv.weight, None, _bn_args(c1.bn), 'hswish', fork=True, x_final=True)
+            else:
+                f, x1 = ops.conv2d_fork(x, c1.conv.weight, None, 1, 0, stats_pre='none' if c1.bn.training else None)
+                f = _bn(c1.bn, f, post='hswish')
             e, x2 = self.mhca_blks[0](x1, scales, fork=True)
             r = self.InvRes.tail(f, x2)
         else:
@@ -375,6 +388,9 @@ class MHCA_stage(nn.Module):
         ag = self.aggregate
         if ag.bn.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
             # cat([r, e]) -> 1x1 -> BN -> Hardswish with the concatenation folded into the GEMM operands (no concat / split passes)
+            if ops.pw_conv_bn_ok(r, ag.conv.weight, None, ag.bn.training, None, 'hswish', x2=e):
+                # r = x + BN(conv2(f)) is consumed here only: conv2.bn's backward reduction rides on this kernel's dx epilogue
+                return ops.pw_conv_bn(r, ag.conv.weight, None, _bn_args(ag.bn), 'hswish', x2=e, x_final=True)
             y = ops.conv1x1_cat2(r, e, ag.conv.weight, stats_pre='none' if ag.bn.training else None)
             return _bn(ag.bn, y, post='hswish')
         return ag(ops.concat2(r, e))

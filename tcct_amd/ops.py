@@ -970,7 +970,7 @@ def dwconv3x3_fork(x, w, bias=None, stride=1, add_input=False):
 # ------------------------------------------------------------------------------------------------- norms
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, nbt, eps, momentum, pre, post, training, res=None):
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, eps, momentum, pre, post, training, res=None, link=None):
         _chk(x, gamma, beta)
         C = x.shape[-1]
         M = x.numel() // C
@@ -1002,6 +1002,9 @@ class _BatchNorm(torch.autograd.Function):
             ctx.cfg = (pre, post)
             ctx.beta_param = beta
             ctx.has_res = res is not None
+            ctx.link = link
+            if link is not None:
+                link.y, link.ab = x, ab
         return y
 
     @staticmethod
@@ -1012,13 +1015,143 @@ class _BatchNorm(torch.autograd.Function):
         C = x.shape[-1]
         M = x.numel() // C
         dc = dtype_code(x.dtype)
-        sums = ZERO.get((2 * C,), torch.float64, x.device)
-        lib.bn_bwd_reduce(x, dy, M, C, mean_rstd, ab, pre, post, sums, dc)
+        link = getattr(ctx, 'link', None)
+        if link is not None and link.sums is not None:      # the consumer's input-gradient kernel accumulated the two batch sums (raw form)
+            sums = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+            lib.bn_sums_from_raw(link.sums, mean_rstd, C, sums)
+            link.sums = None
+        else:
+            sums = ZERO.get((2 * C,), torch.float64, x.device)
+            lib.bn_bwd_reduce(x, dy, M, C, mean_rstd, ab, pre, post, sums, dc)
         dx = torch.empty_like(x)
         dg = _grad_out(gamma) if ZERO.active and getattr(gamma, '_grad_slot', None) is not None else torch.empty(C, device=x.device, dtype=torch.float32)
         db = _grad_out(ctx.beta_param) if ZERO.active and getattr(ctx.beta_param, '_grad_slot', None) is not None else torch.empty(C, device=x.device, dtype=torch.float32)
         lib.bn_bwd_apply(x, dy, dx, M, C, mean_rstd, ab, gamma, sums, pre, post, dg, db, dc)
-        return dx, _ret(dg, gamma), _ret(db, ctx.beta_param), None, None, None, None, None, None, None, None, (dy if ctx.has_res else None)
+        return dx, _ret(dg, gamma), _ret(db, ctx.beta_param), None, None, None, None, None, None, None, None, (dy if ctx.has_res else None), None
+
+
+# ---- BatchNorm backward folded into the neighbouring pointwise-convolution kernels (round 3) ------------------------------------------
+# A train-mode BatchNorm costs 2 (apply) + 2 (backward reduce) + 3 (backward apply) tensor passes.  Where a 1x1 convolution PRODUCES the
+# BatchNorm's input (Conv2d_BN, DWConv2d_BN.pwconv, FTC.tran_*), the fused pointwise backward kernel rebuilds the convolution's output
+# gradient from (dz, y) while staging its tiles (tcct_pw_bwd_bn): the backward apply pass disappears (3 passes -> 1 extra read).  Where a
+# 1x1 convolution CONSUMES a BatchNorm's output as the last contributor to its gradient, the same kernel accumulates that BatchNorm's two
+# backward sums in its dx epilogue (`BnLink`): the backward reduce pass disappears too (2 passes -> 1 extra read).  TCCT_BN_FUSE=0 restores
+# the separate kernels (A/B timing, bisecting).
+BN_FUSE = os.environ.get('TCCT_BN_FUSE', '1') != '0'
+
+
+class BnLink:
+    """What a consumer needs to run the backward REDUCTION of the BatchNorm that produced its input: y (the BatchNorm input), ab = {a[C], b[C]},
+    the post-activation kind; `sums` is filled (raw form {sum dz', sum dz' y}, fp64 [2C]) by the consumer's backward, which autograd runs
+    before the BatchNorm's own backward node -- that node then skips its reduction kernel."""
+    __slots__ = ('y', 'ab', 'post', 'sums')
+
+    def __init__(self, y, ab, post):
+        self.y, self.ab, self.post, self.sums = y, ab, post, None
+
+
+def _bn_link_of(x, final):
+    """the BnLink of tensor x when x is the unmodified output of a BatchNorm node and the caller vouches (`final`) that its convolution's
+    input gradient (+ the forked alias' gradient) is the COMPLETE gradient of x"""
+    if not (final and BN_FUSE):
+        return None
+    return getattr(x, '_bn_link', None)
+
+
+class _PwConvBN(torch.autograd.Function):
+    """z = post(BN_train(conv1x1(x))) [+ res] as ONE autograd node (Conv2d_BN / DWConv2d_BN.pwconv / FTC.tran_*, reference nets/tcct.py:55-97,
+    124-126,966-974): forward = the GEMM with the statistics in its epilogue + the normalisation pass; backward = [reduction, unless a consumer
+    delivered the sums through `link`] + ONE kernel for BatchNorm backward apply, dx, dW, dbias (tcct_pw_bwd_bn), optionally with the reduction
+    of the BatchNorm in FRONT of the convolution in its epilogue (`prev`).  x2: second half of a concatenated input (MHCA_stage.aggregate)."""
+
+    @staticmethod
+    def forward(ctx, x, x2, w, bias, gamma, beta, rm, rv, nbt, eps, momentum, post, res, fork, link, prev):
+        ctx.set_materialize_grads(False)
+        _chk(x, x2, w, bias, gamma, beta, res)
+        K1 = x.shape[-1]
+        K = K1 + (x2.shape[-1] if x2 is not None else 0)
+        N = w.shape[0]
+        M = x.numel() // K1
+        y = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=x.dtype)
+        sums = ZERO.get((2 * N,), torch.float64, x.device) if ZERO.active else torch.zeros(2 * N, device=x.device, dtype=torch.float64)
+        if x2 is not None:
+            lib.pw_fwd_cat2(x, x2, K1, w, bias, y, M, K, N, sums, 0)
+        else:
+            lib.pw_fwd_bnstats(x, w, bias, y, M, K, N, sums, 0)
+        mean_rstd = torch.empty(2 * N, device=x.device, dtype=torch.float32)
+        ab = torch.empty(2 * N, device=x.device, dtype=torch.float32)
+        z = torch.empty_like(y)
+        lib.bn_apply_train(y, res, z, M, N, sums, gamma, beta, eps, momentum, rm, rv, nbt, mean_rstd, ab, 0, post, dtype_code(y.dtype))
+        ctx.save_for_backward(x, x2, w, y, mean_rstd, ab)
+        wsrc = w if hasattr(w, '_grad_slot') or w._base is None else w._base
+        ctx.cfg = (post, res is not None, wsrc, bias, gamma, beta, link, prev, M, K, N)
+        link.y, link.ab = y, ab
+        return (z, x.view_as(x)) if fork else z
+
+    @staticmethod
+    def backward(ctx, dz, dalias=None):
+        x, x2, w, y, mean_rstd, ab = ctx.saved_tensors
+        post, has_res, wsrc, bsrc, gamma, beta, link, prev, M, K, N = ctx.cfg
+        if dz is None:
+            return (dalias,) + (None,) * 15
+        dz = _as(dz, y.dtype)
+        if link.sums is not None:               # a consumer's dx epilogue already holds the two batch sums (raw form)
+            sums, raw = link.sums, 1
+            link.sums = None
+        else:
+            sums, raw = ZERO.get((2 * N,), torch.float64, y.device), 0
+            lib.bn_bwd_reduce(y, dz, M, N, mean_rstd, ab, 0, post, sums, dtype_code(y.dtype))
+        coef = torch.empty(5 * N, device=y.device, dtype=torch.float32)
+        dg = _grad_out(gamma) if ZERO.active and getattr(gamma, '_grad_slot', None) is not None else torch.empty(N, device=y.device, dtype=torch.float32)
+        db_ = _grad_out(beta) if ZERO.active and getattr(beta, '_grad_slot', None) is not None else torch.empty(N, device=y.device, dtype=torch.float32)
+        lib.bn_bwd_coef(sums, raw, M, N, mean_rstd, ab, coef, dg, db_)
+        dx = torch.empty_like(x)
+        dx2 = torch.empty_like(x2) if x2 is not None else None
+        dw = _grad_out(wsrc, tuple(w.shape))
+        dbias = _grad_out(bsrc) if bsrc is not None else None
+        ypv = abp = sp = None
+        redp = -1
+        if prev is not None:
+            redp = prev.post
+            ypv, abp = prev.y, prev.ab
+            sp = prev.sums = ZERO.get((2 * x.shape[-1],), torch.float64, y.device)
+        dskip = _as(dalias, x.dtype) if dalias is not None else None
+        lib.pw_bwd_bn(x, x2, dz, y, coef, post, w, dskip, dx, dx2, dw, dbias, M, K, N, ypv, abp, redp, sp)
+        return (dx, dx2, _ret(dw, wsrc), _ret(dbias, bsrc), _ret(dg, gamma), _ret(db_, beta), None, None, None, None, None, None,
+                (dz if has_res else None), None, None, None)
+
+
+def pw_conv_bn_ok(x, w, bias, bn_training, pre_act, post_act, x2=None, prev=None):
+    """shapes / modes the fused node takes: train mode with gradients, bf16 rows, 1x1 weights, K and N in the kernel's table"""
+    if not (BN_FUSE and FUSED_PW_BWD and bn_training and torch.is_grad_enabled() and ACT[pre_act] == 0):
+        return False
+    if x.dtype != torch.bfloat16 or x.dim() != 4 or not x.is_cuda or (w.dim() == 4 and tuple(w.shape[2:]) != (1, 1)):
+        return False
+    K = x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
+    N = w.shape[0]
+    if x2 is not None and not (x.shape[-1] == 64 and x2.shape == x.shape and x2.dtype == x.dtype):
+        return False
+    M = x.numel() // x.shape[-1]
+    if w.shape[1] != K or M * max(K, N) * 2 >= 2 ** 31:
+        return False
+    return bool(lib.pw_bwd_bn_supported(K, N, ACT[post_act], -1 if prev is None else prev.post, 1 if x2 is not None else 0))
+
+
+def pw_conv_bn(x, w, bias, bn, post_act=None, residual=None, fork=False, x2=None, x_final=False):
+    """post_act(BN_train(conv1x1(x [| x2]))) [+ residual]; bn = (gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum).
+    fork: also return an alias of x for its other consumers (their gradient is added in this node's dx epilogue).  x_final: this
+    convolution's input gradient (+ the alias') is the complete gradient of x -- when x came out of a BatchNorm node, that BatchNorm's
+    backward reduction rides on this node's kernel.  Check pw_conv_bn_ok first."""
+    gamma, beta, rm, rv, nbt, eps, mom = bn
+    prev = _bn_link_of(x, x_final)
+    if prev is not None and not pw_conv_bn_ok(x, w, bias, True, None, post_act, x2, prev):
+        prev = None
+    link = BnLink(None, None, ACT[post_act])
+    w4 = w.view(w.shape[0], w.shape[1], 1, 1) if w.dim() == 2 else w
+    out = _PwConvBN.apply(x, x2, w4, bias, gamma, beta, rm, rv, nbt, float(eps), float(mom), ACT[post_act], residual, fork, link, prev)
+    z = out[0] if fork else out
+    z._bn_link = link               # (with a residual folded in z is BN output + res, but the gradient of the BatchNorm output still is dz)
+    return out
 
 
 BN_POOL_FUSE = os.environ.get('TCCT_BN_POOL', '1') != '0'      # =0: BatchNorm pass, then the pooling pass (A/B timing)
@@ -1090,8 +1223,15 @@ def batchnorm(x, gamma, beta, running_mean, running_var, num_batches_tracked=Non
     """y = post_act(BN(pre_act(x))) [+ residual] over the last (channel) dim, torch train-mode semantics incl. running stats."""
     if not training and torch.is_grad_enabled() and x.requires_grad:
         raise TcctError('eval-mode batchnorm is inference-only here')
-    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, float(eps), float(momentum),
-                            ACT[pre_act], ACT[post_act], bool(training), residual)
+    link = None
+    if (BN_FUSE and training and torch.is_grad_enabled() and x.dtype == torch.bfloat16 and ACT[pre_act] == 0
+            and ACT[post_act] in (0, 2) and x.shape[-1] in (64, 96, 128)):
+        link = BnLink(None, None, ACT[post_act])       # a pointwise convolution that consumes the output may run this node's backward reduction
+    z = _BatchNorm.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, float(eps), float(momentum),
+                         ACT[pre_act], ACT[post_act], bool(training), residual, link)
+    if link is not None:
+        z._bn_link = link
+    return z
 
 
 class _Bn2AddAct(torch.autograd.Function):
@@ -1877,7 +2017,7 @@ class _Fpl(torch.autograd.Function):
         keys_out = torch.empty(M, device=dev, dtype=torch.int64)
         vals_in = torch.empty(M, device=dev, dtype=torch.int32)
         vals_out = torch.empty(M, device=dev, dtype=torch.int32)
-        counts = torch.empty(8, device=dev, dtype=torch.int32)
+        counts = torch.empty(16, device=dev, dtype=torch.int32)        # FPL_MAXC
         wsb = lib.fpl_sort_workspace_bytes(M)
         if wsb < 0:
             raise TcctError('fpl_sort_workspace_bytes failed')
