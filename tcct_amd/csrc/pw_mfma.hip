@@ -798,9 +798,10 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
     }
     if (BN) for (int i = tid; i < 5 * N; i += PWB) sC[i] = bn.coef[i];
     if (RED) for (int i = tid; i < 2 * (SPLIT ? K / 2 : K); i += PWB) sP[i] = bn.abprev[i];
-    float rs[RED ? KT : 1][8], rq[RED ? KT : 1][8];        // RED: per-lane partial sums of dz' and dz' y_prev (channels 8 (lane & 3) + k of tile kt)
+    constexpr int RKT = RED ? (SPLIT ? KT / 2 : KT) : 1;   // 32-channel tiles of x that carry the BatchNorm in front (split: the first half)
+    float rs[RKT][8], rq[RKT][8];                            // RED: per-lane partial sums of dz' and dz' y_prev (channels 8 (lane & 3) + k of tile kt)
 #pragma unroll
-    for (int a = 0; a < (RED ? KT : 1); ++a)
+    for (int a = 0; a < RKT; ++a)
 #pragma unroll
         for (int k = 0; k < 8; ++k) rs[a][k] = rq[a][k] = 0.f;
     f32x16 accw[(NT * KT + 3) / 4];
@@ -899,6 +900,17 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
     }
     __syncthreads();
     for (; tile < tiles; tile += gridDim.x) {
+        u32x4 yq[RKT][2];               // RED: the y_prev values the dx epilogue of this tile needs, requested before the MFMA phase
+        if (RED) {
+            const int64_t m0q = tile * PB_P + 32 * wave;
+#pragma unroll
+            for (int kt = 0; kt < RKT; ++kt)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int64_t mm = m0q + (lane >> 2) + 16 * h2;
+                    yq[kt][h2] = __builtin_amdgcn_raw_buffer_load_b128(ryp, mm < M ? (uint32_t)((mm * KS + kt * 32 + (lane & 3) * 8) * 2) : 0x80000000u, 0, 0);
+                }
+        }
         // ---- weight gradient: owned tiles, K-dim = the 128 staged pixels
 #pragma unroll
         for (int a = 0; a < (NT * KT + 3) / 4; ++a) {
@@ -954,8 +966,8 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
                 const int p = (lane >> 2) + 16 * h2, cch = lane & 3;
                 u32x4 o = *reinterpret_cast<const u32x4*>(sc + p * 80 + cch * 16);
                 const int64_t mm = m0 + p;
-                auto red_acc = [&](const u32x4& ov, uint32_t offy, int kch) {     // kch: first channel of the lane's 8 inside x / y_prev rows
-                    const u32x4 yv = __builtin_amdgcn_raw_buffer_load_b128(ryp, offy, 0, 0);
+                auto red_acc = [&](const u32x4& ov, int kch) {     // kch: first channel of the lane's 8 inside x / y_prev rows
+                    const u32x4 yv = yq[kt < RKT ? kt : 0][h2];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         float d0 = __uint_as_float(ov[k] << 16), d1 = __uint_as_float(ov[k] & 0xffff0000u);
@@ -964,14 +976,14 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
                             d0 *= pw_act_grad<REDP < 0 ? 0 : REDP>(sP[kch + 2 * k] * y0 + sP[KS + kch + 2 * k]);
                             d1 *= pw_act_grad<REDP < 0 ? 0 : REDP>(sP[kch + 2 * k + 1] * y1 + sP[KS + kch + 2 * k + 1]);
                         }
-                        rs[RED ? kt : 0][2 * k] += d0; rq[RED ? kt : 0][2 * k] += d0 * y0;
-                        rs[RED ? kt : 0][2 * k + 1] += d1; rq[RED ? kt : 0][2 * k + 1] += d1 * y1;
+                        rs[kt < RKT ? kt : 0][2 * k] += d0; rq[kt < RKT ? kt : 0][2 * k] += d0 * y0;
+                        rs[kt < RKT ? kt : 0][2 * k + 1] += d1; rq[kt < RKT ? kt : 0][2 * k + 1] += d1 * y1;
                     }
                 };
                 if (SPLIT) {        // channels [0, K/2) -> dx, [K/2, K) -> dx2 (= dx_plain argument), rows of K/2 channels each
                     const uint32_t off2 = mm < M ? (uint32_t)((mm * KS + (kt * 32) % KS + cch * 8) * 2) : 0x80000000u;
                     __builtin_amdgcn_raw_buffer_store_b128(o, kt * 32 < KS ? ro : rp, off2, 0, 0);
-                    if (RED && kt * 32 < KS) red_acc(o, off2, kt * 32 + cch * 8);       // the BatchNorm sits in front of the FIRST half (x, not x2)
+                    if (RED && kt < RKT) red_acc(o, kt * 32 + cch * 8);       // the BatchNorm sits in front of the FIRST half (x, not x2)
                     continue;
                 }
                 const uint32_t off = mm < M ? (uint32_t)((mm * K + kt * 32 + cch * 8) * 2) : 0x80000000u;
@@ -984,7 +996,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
                                            __uint_as_float(o[k] & 0xffff0000u) + __uint_as_float(rv[k] & 0xffff0000u));
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(o, ro, off, 0, 0);
-                if (RED) red_acc(o, off, kt * 32 + cch * 8);
+                if (RED) red_acc(o, kt * 32 + cch * 8);
             }
             wave_lds_fence();
         }
@@ -996,8 +1008,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
         float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][K] (the staged tiles are dead)
         constexpr int KR = SPLIT ? K / 2 : K;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            if (kt * 32 >= KR) break;
+        for (int kt = 0; kt < RKT; ++kt) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 float a = rs[kt][k], b = rq[kt][k];
@@ -1061,15 +1072,16 @@ extern "C" int tcct_pw_bwd_residual2(const void* x, const void* dy, const float*
 }
 /* Shapes / activation kinds for which tcct_pw_bwd_bn has a kernel (the host mirror asks before building its autograd node):
  *   post (BatchNorm behind the convolution) and red_post (BatchNorm in front of it, -1: no reduction epilogue): TCCT_ACT_NONE / TCCT_ACT_HSWISH;
- *   K = N in {64, 96, 128} (the reduction epilogue only at 64); N = 32 with K in {32, 96, 128} without the reduction; the concatenated K = 128 -> N = 96 form. */
+ *   K = N in {64, 96} (the reduction epilogue only at 64); N = 32 with K in {32, 96, 128} and the concatenated K = 128 -> N = 96 form without it. */
 extern "C" int64_t tcct_pw_bwd_bn_supported(int K, int N, int post, int red_post, int split) {
     const bool p_ok = post == TCCT_ACT_NONE || post == TCCT_ACT_HSWISH;
     const bool r_ok = red_post == -1 || red_post == TCCT_ACT_NONE || red_post == TCCT_ACT_HSWISH;
     if (!p_ok || !r_ok) return 0;
-    if (split) return K == 128 && N == 96 && post == TCCT_ACT_HSWISH && (red_post == -1 || red_post == TCCT_ACT_NONE);
-    // (the reduction epilogue keeps 16 more partial sums per 32 input channels in registers: beyond 64 channels the kernel spills -- 94 / 215 VGPRs
-    // at 96 / 128 channels -- and those BatchNorms sit on the small level-2 / level-3 maps anyway)
-    if (K == N && (K == 64 || K == 96 || K == 128)) return red_post == -1 || K == 64;
+    // Register budget (256 VGPRs at two blocks per CU): the reduction epilogue keeps 16 partial sums + 8 prefetched registers per 32 input
+    // channels, which only fits at K = N = 64 (the concatenated 128 -> 96 form spills 51 VGPRs with it, 96 / 128 square 94 / 215); the plain
+    // form spills 37 VGPRs at 128 x 128 and measured SLOWER than the separate kernels there (0.080 vs 0.045 + 0.02 ms at level 3): not offered.
+    if (split) return K == 128 && N == 96 && post == TCCT_ACT_HSWISH && red_post == -1;
+    if (K == N && (K == 64 || K == 96)) return red_post == -1 || K == 64;
     if (N == 32 && (K == 32 || K == 96 || K == 128)) return red_post == -1 && post == TCCT_ACT_NONE;
     return 0;
 }
@@ -1121,13 +1133,12 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
         if (bnp == 0 && redp == 0) BLX(T, T, false, 0, 0) else if (bnp == 0 && redp == H) BLX(T, T, false, 0, 2) \
         else if (bnp == H && redp == 0) BLX(T, T, false, 2, 0) else BLX(T, T, false, 2, 2)
         static_assert(TCCT_ACT_HSWISH == 2 && TCCT_ACT_NONE == 0, "activation codes are template arguments below");
-        if (split) { if (redp < 0) BLX(3, 4, true, 2, -1) else BLX(3, 4, true, 2, 0) }
+        if (split) BLX(3, 4, true, 2, -1)
         else if (NT == 1 && KT == 1) BLX(1, 1, false, 0, -1)
         else if (NT == 1 && KT == 3) BLX(1, 3, false, 0, -1)
         else if (NT == 1 && KT == 4) BLX(1, 4, false, 0, -1)
         else if (NT == 2) { if (redp < 0) { BN_SQ(2) } else { BN_SQR(2) } }
-        else if (NT == 3) { BN_SQ(3) }
-        else { BN_SQ(4) }
+        else { BN_SQ(3) }
 #undef BN_SQ
 #undef BN_SQR
         TCCT_LAUNCH_OK();

@@ -1038,6 +1038,7 @@ class _BatchNorm(torch.autograd.Function):
 # backward sums in its dx epilogue (`BnLink`): the backward reduce pass disappears too (2 passes -> 1 extra read).  TCCT_BN_FUSE=0 restores
 # the separate kernels (A/B timing, bisecting).
 BN_FUSE = os.environ.get('TCCT_BN_FUSE', '1') != '0'
+BN_FUSE_RED = os.environ.get('TCCT_BN_RED', '1') != '0'       # =0: keep the separate reduction kernels (A/B timing of the epilogue form)
 
 
 class BnLink:
@@ -1053,7 +1054,7 @@ class BnLink:
 def _bn_link_of(x, final):
     """the BnLink of tensor x when x is the unmodified output of a BatchNorm node and the caller vouches (`final`) that its convolution's
     input gradient (+ the forked alias' gradient) is the COMPLETE gradient of x"""
-    if not (final and BN_FUSE):
+    if not (final and BN_FUSE and BN_FUSE_RED):
         return None
     return getattr(x, '_bn_link', None)
 
