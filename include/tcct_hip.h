@@ -162,6 +162,15 @@ int tcct_conv2d_wgrad(const void* x, const void* dy, float* dw, float* dbias, in
                       int Cin_w, int Cout, int KH, int KW, int stride, int padh, int padw, int x_dtype, int dy_dtype,
                       tcct_stream_t stream);
 
+/* fp32 MFMA convolution of the parity mode (compute dtype float32): dense 32 -> 32 channels, stride 1, 'same' padding, 3x3 / 1xk / kx1 with
+ * k <= 13 (reference nets/tcct.py:808-822,892,978), fp32 NHWC tensors, v_mfma_f32_32x32x2_f32 (fp32 products, fp32 accumulation).
+ * pack: OIHW fp32 -> [tap][co][ci] fp32 (transposed = 1: flipped taps, co/ci swapped = the weights of the input-gradient convolution);
+ * fwd: y = conv(x) + bias [+ yadd] (yadd nullable: the gradient reaching x through its other consumers); wgrad: dw OIHW, dbias nullable. */
+int tcct_conv32f_pack_weights(const float* w, float* wp, int KH, int KW, int transposed, tcct_stream_t stream);
+int tcct_conv32f_fwd(const float* x, const float* wp, const float* bias, const float* yadd, float* y, int N, int H, int W, int KH, int KW, int PH,
+                     int PW, tcct_stream_t stream);
+int tcct_conv32f_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH, int PW,
+                       tcct_stream_t stream);
 /* MFMA implicit-GEMM path for the hot family: 32 -> 32 channels, stride 1, 'same' padding, bf16 NHWC, any KHxKW
  * (the 3x3 and 1xk / kx1 cross-convolutions of CrossCNNBlock, reference nets/tcct.py:808-822, and the decoder 3x3s).
  * wp = weights packed by tcct_conv32_pack_weights to bf16 [KH*KW][32 co][32 ci]; transposed=1 packs the flipped/transposed

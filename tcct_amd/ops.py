@@ -241,6 +241,15 @@ def _mfma32_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
             and 2 * padh == KH - 1 and 2 * padw == KW - 1 and KH * KW > 1 and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
 
 
+F32_MFMA = os.environ.get('TCCT_F32_MFMA', '1') != '0'        # =0: the VALU convolution for the fp32 parity mode (A/B timing, bisecting)
+
+
+def _mfma32f_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+    """the fp32 MFMA kernels (conv_f32_mfma.hip) cover fp32 32->32 stride-1 'same' convolutions (3x3, 1xk, kx1, k <= 13) of the parity mode"""
+    return (F32_MFMA and in_dt == torch.float32 and out_dt == torch.float32 and Cin == 32 and Cin_w == 32 and Cout == 32 and stride == 1
+            and 2 * padh == KH - 1 and 2 * padw == KW - 1 and 1 < KH * KW <= 13 and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
+
+
 def _mfma_slabs_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
     """wider bf16 stride-1 'same' convolutions (3x3, 1xk, kx1 with channel counts that are multiples of 32) as 32x32 sub-GEMMs of the
     conv32 kernels: MPViT stem[1] (32->64) and the wide CNN encoder of stc_tb / gtc_tb (32-64-96-128-256, nets/tcct.py:861-864)"""
@@ -331,6 +340,10 @@ class _Conv2d(torch.autograd.Function):
                 stats_box[1] = sums
             else:
                 lib.conv32_fwd(x, wp, bias, y, N, H, W, KH, KW, padh, padw)
+        elif _mfma32f_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+            wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.float32)
+            lib.conv32f_pack_weights(w, wp, KH, KW, 0)
+            lib.conv32f_fwd(x, wp, bias, None, y, N, H, W, KH, KW, padh, padw)
         else:
             lib.conv2d_fwd(x, w, bias, y, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
                            dtype_code(odt))
@@ -398,6 +411,11 @@ class _Conv2d(torch.autograd.Function):
                     dskip = None
                 else:
                     lib.conv32_fwd(dy, wp, None, dx, N, H, W, KH, KW, KH - 1 - padh, KW - 1 - padw)
+            elif _mfma32f_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
+                wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.float32)
+                lib.conv32f_pack_weights(w, wp, KH, KW, 1)
+                lib.conv32f_fwd(dy, wp, None, dskip, dx, N, H, W, KH, KW, KH - 1 - padh, KW - 1 - padw)
+                dskip = None
             else:
                 lib.conv2d_dgrad(dy, w, dx, N, H, W, Cin, Cout, KH, KW, padh, padw, dtype_code(dy.dtype), dtype_code(x.dtype))
             if dskip is not None:       # kernels without the fused epilogue: one explicit pass
@@ -412,6 +430,8 @@ class _Conv2d(torch.autograd.Function):
                 db = _grad_out(bsrc) if has_bias else None
                 if _mfma32_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
                     lib.conv32_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
+                elif _mfma32f_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+                    lib.conv32f_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
                 elif _mfma_slabs_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
                     if not ZERO.active:
                         dw.zero_()

@@ -2,7 +2,7 @@
 # Late hipGraph capture reproducer under several hypotheses; each variant is a fresh process.  A variant that is killed by its
 # timeout stops the script (no further GPU step after a hang); an ordinary failure / segfault is recorded and the next variant runs.
 mkdir -p gpurun_out
-FILES="tests/test_fullsize_gpu.py tests/test_kernels_gpu.py tests/test_model_gpu.py tests/repro_late_graph_capture.py"
+FILES="tests/test_fullsize_gpu.py tests/test_kernels_gpu.py tests/test_model_gpu.py tests/test_zz_late_graph_capture.py"
 run() {
   name=$1; shift
   echo "=== $name" | tee -a gpurun_out/graph_repro.log
