@@ -140,6 +140,14 @@ extern "C" int tcct_fpl_forward(const void* feat, const uint64_t* keys_sorted, c
     TCCT_LAUNCH_OK();
 }
 
+/* the loss part of tcct_fpl_forward alone, for bin sums that came out of tcct_fpl_select */
+extern "C" int tcct_fpl_loss(const float* pro_sum, const uint32_t* counts, const float* buf_grad, int C, float* pro, float* loss, float* dpro_over_n,
+                             tcct_stream_t stream) {
+    TCCT_CHECK(C >= 1 && C <= FPL_MAXC, "fpl_loss: C=%d unsupported", C);
+    hipLaunchKernelGGL(k_fpl_loss, dim3(1), dim3(FB), 0, (hipStream_t)stream, pro_sum, counts, buf_grad, C, pro, loss, dpro_over_n);
+    TCCT_LAUNCH_OK();
+}
+
 template <typename T>
 __global__ void k_fpl_bwd(const uint8_t* __restrict__ lab, const uint8_t* __restrict__ binmap, const float* __restrict__ dpro_over_n,
                           const float* __restrict__ gout, float gscale, int64_t M, T* __restrict__ dfeat) {

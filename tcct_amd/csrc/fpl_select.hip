@@ -1,0 +1,243 @@
+// Feature-polarization loss, bin assignment WITHOUT a sort (round 3; replaces the rocPRIM radix_sort_pairs call of fpl_optim.hip).
+//
+// Reference (nets/fcs.py:25-50, nets/reg.py:86-105): per class c, the n_c pixels labelled c are sorted by their detached softmax probability,
+// descending; the first 32 * N_c of them (N_c = n_c // 32, the tail is dropped) are cut into 32 consecutive bins of N_c pixels and every bin is
+// averaged over its 32-channel feature rows.  Only the BIN of a pixel is needed, i.e. its rank relative to the 32 boundaries r_b = (b + 1) N_c,
+// not its exact rank: a radix MULTI-SELECT finds the 32 boundary elements per class with histogram passes, most significant byte first.
+//
+//   key(p)  = (~bits(prob[p]) << IB) | p        unique 64-bit key; ascending key order == descending probability, ties by ascending pixel index
+//             (exactly the order the former stable sort of (label, ~prob) with the pixel index as value produced)
+//   level l : histogram of byte l of the key for every ACTIVE (class, prefix) slot -- level 0: one slot per class; later: the distinct prefixes
+//             that still contain an unresolved boundary (<= 32 per class) -- in LDS-private counters, merged with global atomics;
+//             a one-block kernel then walks every boundary one byte down (prefix scan of its slot's 256 counters) and resolves it as soon as
+//             its bucket holds ONE element (always at the last byte: keys are unique), and builds the next level's slot list
+//   assign  : bin(p) = #{b : key(p) >= key of boundary b} by binary search over the class's 32 (prefix, shift) pairs -- fused with the bin sums:
+//             the feature rows are read in PIXEL order (one coalesced pass; the sorted order forced a scattered 64-byte gather per pixel)
+//             and accumulated in LDS-private [class][bin][32] sums.
+// 4 probability bytes + ceil(log2 M / 8) index bytes = 7 levels at the bench shape; every launch has constant arguments (no host sync).
+#include "common.h"
+
+#define FS_MAXC 16
+#define FS_BINS 32
+#define FS_SLOTS 128            // slots histogrammed per pass of a level (128 x 256 counters x 4 B = 128 KB of LDS)
+#define FS_TB 1024
+
+struct FplState {
+    uint32_t nslots, pad0, pad1, pad2;
+    uint32_t slot_base[FS_MAXC + 1];                 // class c owns slots [slot_base[c], slot_base[c+1])
+    uint32_t counts[FS_MAXC], nb[FS_MAXC];           // n_c, N_c
+    uint64_t slot_prefix[FS_MAXC * FS_BINS];         // ascending inside a class
+    uint64_t bnd_prefix[FS_MAXC * FS_BINS];          // key >> bnd_shift >= bnd_prefix  <=>  key >= key of the boundary element
+    uint32_t bnd_resid[FS_MAXC * FS_BINS];           // rank of the boundary inside its current slot
+    int32_t bnd_slot[FS_MAXC * FS_BINS];
+    uint32_t bnd_shift[FS_MAXC * FS_BINS];
+    uint32_t bnd_state[FS_MAXC * FS_BINS];           // 0 unresolved, 1 resolved, 2 beyond the last element (+inf), 3 class has no full bin
+};
+
+__device__ __forceinline__ unsigned long long fs_key(float p, uint32_t i, int ib) {
+    return ((unsigned long long)(~__float_as_uint(p)) << ib) | (unsigned long long)i;        // prob >= 0: uint order == float order
+}
+
+// one pass of level `level` over the slots [slot_lo, slot_lo + FS_SLOTS)
+__global__ void __launch_bounds__(FS_TB) k_fs_hist(const uint8_t* __restrict__ lab, const float* __restrict__ prob, int64_t M, int C, int level,
+                                                   int ib, int tb, int slot_lo, const FplState* __restrict__ st, uint32_t* __restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* lh = reinterpret_cast<uint32_t*>(smem);                                   // [FS_SLOTS][256]
+    unsigned long long* sp = reinterpret_cast<unsigned long long*>(lh + FS_SLOTS * 256);   // [nslots] prefixes
+    uint32_t* sb = reinterpret_cast<uint32_t*>(sp + FS_MAXC * FS_BINS);                 // [C + 1]
+    const int nslots = level == 0 ? C : (int)st->nslots;
+    if (slot_lo >= nslots) return;                     // block-uniform: nothing left to count at this level
+    for (int i = threadIdx.x; i < FS_SLOTS * 256; i += FS_TB) lh[i] = 0;
+    if (level > 0) {
+        for (int i = threadIdx.x; i < nslots; i += FS_TB) sp[i] = st->slot_prefix[i];
+        if (threadIdx.x <= C) sb[threadIdx.x] = st->slot_base[threadIdx.x];
+    }
+    __syncthreads();
+    const int sh_pre = tb - 8 * level, sh_dig = tb - 8 * (level + 1);
+    for (int64_t i = (int64_t)blockIdx.x * FS_TB + threadIdx.x; i < M; i += (int64_t)gridDim.x * FS_TB) {
+        const int c = lab[i];
+        if (c >= C) continue;
+        const unsigned long long key = fs_key(prob[i], (uint32_t)i, ib);
+        int s;
+        if (level == 0) s = c;
+        else {
+            const unsigned long long pf = key >> sh_pre;
+            int lo = (int)sb[c], hi = (int)sb[c + 1];        // first slot with prefix >= pf
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (sp[mid] < pf) lo = mid + 1; else hi = mid; }
+            s = (lo < (int)sb[c + 1] && sp[lo] == pf) ? lo : -1;
+        }
+        if (s >= slot_lo && s < slot_lo + FS_SLOTS) atomicAdd(&lh[(s - slot_lo) * 256 + (int)((key >> sh_dig) & 255ull)], 1u);
+    }
+    __syncthreads();
+    const int nloc = min(FS_SLOTS, nslots - slot_lo) * 256;
+    for (int i = threadIdx.x; i < nloc; i += FS_TB)
+        if (lh[i]) atomicAdd(&hist[(size_t)slot_lo * 256 + i], lh[i]);
+}
+
+// one block: walk every unresolved boundary one byte down, build the slot list of the next level, clear the histogram for it
+__global__ void __launch_bounds__(FS_TB) k_fs_resolve(int C, int level, int nlevels, int tb, FplState* __restrict__ st, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t tot[FS_MAXC * FS_BINS];
+    __shared__ uint32_t ncls[FS_MAXC + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nslots = level == 0 ? C : (int)st->nslots;
+    if (level > 0 && nslots == 0) return;                          // everything was resolved earlier
+    // exclusive prefix sums of every slot's 256 counters, in place; tot[s] = the slot's element count (one wave per slot, 4 digits per lane)
+    for (int s = wave; s < nslots; s += FS_TB / 64) {
+        uint32_t* h = hist + (size_t)s * 256;
+        const uint4 v = reinterpret_cast<const uint4*>(h)[lane];
+        const uint32_t mine = v.x + v.y + v.z + v.w;
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        const uint32_t ex = inc - mine;
+        reinterpret_cast<uint4*>(h)[lane] = make_uint4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
+        if (lane == 63) tot[s] = inc;
+    }
+    __syncthreads();
+    if (tid < C * FS_BINS) {
+        const int c = tid / FS_BINS, b = tid % FS_BINS, id = c * FS_BINS + b;
+        uint32_t state, resid;
+        int slot;
+        unsigned long long pf;
+        if (level == 0) {
+            const uint32_t n = tot[c], nbin = n / FS_BINS;
+            if (b == 0) { st->counts[c] = n; st->nb[c] = nbin; }
+            const unsigned long long t = (unsigned long long)(b + 1) * nbin;
+            state = nbin == 0 ? 3u : (t >= n ? 2u : 0u);
+            resid = (uint32_t)t; slot = c; pf = 0;
+        } else { state = st->bnd_state[id]; resid = st->bnd_resid[id]; slot = st->bnd_slot[id]; pf = st->bnd_prefix[id]; }
+        if (state == 0) {
+            const uint32_t* h = hist + (size_t)slot * 256;
+            int lo = 0, hi = 255;                                  // largest digit d with excl[d] <= resid
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (h[mid] <= resid) lo = mid; else hi = mid - 1; }
+            const uint32_t cnt = (lo < 255 ? h[lo + 1] : tot[slot]) - h[lo];
+            pf = (pf << 8) | (unsigned long long)lo;
+            resid -= h[lo];
+            if (cnt == 1u || level + 1 == nlevels) state = 1u;
+            st->bnd_prefix[id] = pf; st->bnd_resid[id] = resid; st->bnd_shift[id] = (uint32_t)(tb - 8 * (level + 1));
+        }
+        st->bnd_state[id] = state;
+    }
+    __syncthreads();
+    // next level's slots: the distinct prefixes of the boundaries that are still open (boundaries of a class are ordered by rank, so equal
+    // prefixes are adjacent)
+    if (tid < C) {
+        uint32_t k = 0;
+        unsigned long long last = 0;
+        for (int b = 0; b < FS_BINS; ++b)
+            if (st->bnd_state[tid * FS_BINS + b] == 0) { const unsigned long long p = st->bnd_prefix[tid * FS_BINS + b]; if (k == 0 || p != last) { ++k; last = p; } }
+        ncls[tid] = k;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t a = 0;
+        for (int c = 0; c < C; ++c) { st->slot_base[c] = a; a += ncls[c]; }
+        st->slot_base[C] = a;
+        st->nslots = a;
+        ncls[FS_MAXC] = a;
+    }
+    __syncthreads();
+    if (tid < C) {
+        uint32_t k = st->slot_base[tid];
+        unsigned long long last = 0;
+        bool any = false;
+        for (int b = 0; b < FS_BINS; ++b) {
+            const int id = tid * FS_BINS + b;
+            if (st->bnd_state[id] == 0) {
+                const unsigned long long p = st->bnd_prefix[id];
+                if (!any || p != last) { st->slot_prefix[k] = p; ++k; last = p; any = true; }
+                st->bnd_slot[id] = (int)k - 1;
+            }
+        }
+    }
+    const uint32_t nz = ncls[FS_MAXC] * 256u;
+    for (uint32_t i = tid; i < nz; i += FS_TB) hist[i] = 0;            // counters of the next level (every read of this level is behind a barrier)
+}
+
+// bin of every pixel + the bin sums: 8 lanes per pixel, 4 channels each; LDS-private [C][32][32] accumulators
+template <typename T>
+__global__ void __launch_bounds__(FS_TB) k_fs_assign_binsum(const T* __restrict__ feat, const uint8_t* __restrict__ lab, const float* __restrict__ prob,
+                                                            int64_t M, int C, int ib, const FplState* __restrict__ st, uint8_t* __restrict__ binmap,
+                                                            float* __restrict__ pro_sum) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* acc = reinterpret_cast<float*>(smem);                                                    // [C * 32][32]
+    unsigned long long* tp = reinterpret_cast<unsigned long long*>(acc + C * FS_BINS * 32);      // [C][32] boundary prefixes
+    uint32_t* ts = reinterpret_cast<uint32_t*>(tp + C * FS_BINS);                                   // [C][32] shift (0xffffffff: never reached)
+    for (int i = threadIdx.x; i < C * FS_BINS * 32; i += FS_TB) acc[i] = 0.f;
+    for (int i = threadIdx.x; i < C * FS_BINS; i += FS_TB) {
+        const uint32_t s = st->bnd_state[i];
+        tp[i] = st->bnd_prefix[i];
+        ts[i] = s == 1u ? st->bnd_shift[i] : (s == 3u ? 0xfffffffeu : 0xffffffffu);
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 7;
+    for (int64_t p = ((int64_t)blockIdx.x * FS_TB + threadIdx.x) >> 3; p < M; p += ((int64_t)gridDim.x * FS_TB) >> 3) {
+        const int c = lab[p];
+        int bin = FS_BINS;
+        if (c < C && ts[c * FS_BINS] != 0xfffffffeu) {
+            const unsigned long long key = fs_key(prob[p], (uint32_t)p, ib);
+            int lo = 0, hi = FS_BINS;               // number of boundaries b with key >= boundary_b (monotone: boundaries ascend with b)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const uint32_t sh = ts[c * FS_BINS + mid];
+                const bool ge = sh != 0xffffffffu && (key >> sh) >= tp[c * FS_BINS + mid];
+                if (ge) lo = mid + 1; else hi = mid;
+            }
+            bin = lo;
+        }
+        if (sub == 0) binmap[p] = bin < FS_BINS ? (uint8_t)bin : (uint8_t)255;
+        if (bin < FS_BINS) {
+            const f4 v = ld4(feat + p * 32 + sub * 4);
+            float* a = acc + (c * FS_BINS + bin) * 32 + sub * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(a + k, v.v[k]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * FS_BINS * 32; i += FS_TB)
+        if (acc[i] != 0.f) atomicAdd(&pro_sum[i], acc[i]);
+}
+
+extern "C" int64_t tcct_fpl_select_workspace_bytes() {
+    return (int64_t)sizeof(FplState) + (int64_t)FS_MAXC * FS_BINS * 256 * sizeof(uint32_t);
+}
+
+/* labels uint8 [M], prob fp32 [M] (softmax probability of the labelled class, detached), feat [M,32]: binmap [M] (bin 0..31 of the pixel inside
+ * its class, 255 = dropped tail / class without a full bin), counts [16] uint32 (pixels per class), pro_sum [C][32][32] fp32 (feature sums per
+ * class and bin; cleared here).  workspace: tcct_fpl_select_workspace_bytes() bytes.  Replaces tcct_fpl_sort + the gather in tcct_fpl_forward. */
+extern "C" int tcct_fpl_select(const void* feat, const uint8_t* labels, const float* prob, int64_t M, int C, void* workspace, uint32_t* counts,
+                               uint8_t* binmap, float* pro_sum, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(C >= 1 && C <= FS_MAXC, "fpl_select: C=%d unsupported (1..%d)", C, FS_MAXC);
+    TCCT_CHECK(M > 0 && M < (1LL << 32), "fpl_select: M out of range");
+    hipStream_t st = (hipStream_t)stream;
+    FplState* state = (FplState*)workspace;
+    uint32_t* hist = (uint32_t*)((unsigned char*)workspace + sizeof(FplState));
+    int ib = 1;
+    while ((1LL << ib) < M) ++ib;
+    ib = (ib + 7) / 8 * 8;                                  // index bits, whole bytes
+    const int tb = 32 + ib, nlevels = tb / 8;
+    if (hipMemsetAsync(hist, 0, sizeof(uint32_t) * FS_MAXC * 256, st) != hipSuccess) { tcct_set_error("fpl_select: memset failed"); return -2; }
+    if (hipMemsetAsync(pro_sum, 0, sizeof(float) * C * FS_BINS * 32, st) != hipSuccess) { tcct_set_error("fpl_select: memset failed"); return -2; }
+    const size_t lds_h = (size_t)FS_SLOTS * 256 * 4 + (size_t)FS_MAXC * FS_BINS * 8 + (FS_MAXC + 1) * 4;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_fs_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    int grid = tcct_grid(M, FS_TB, 256);
+    const int passes = (C * FS_BINS + FS_SLOTS - 1) / FS_SLOTS;
+    for (int level = 0; level < nlevels; ++level) {
+        for (int ps = 0; ps < (level == 0 ? 1 : passes); ++ps)
+            hipLaunchKernelGGL(k_fs_hist, dim3(grid), dim3(FS_TB), lds_h, st, labels, prob, M, C, level, ib, tb, ps * FS_SLOTS, (const FplState*)state, hist);
+        hipLaunchKernelGGL(k_fs_resolve, dim3(1), dim3(FS_TB), 0, st, C, level, nlevels, tb, state, hist);
+    }
+    const size_t lds_a = (size_t)C * FS_BINS * 32 * 4 + (size_t)C * FS_BINS * 12;
+    if (dtype == TCCT_F32) {
+        static bool a32 = false;
+        if (!a32) { (void)hipFuncSetAttribute((const void*)k_fs_assign_binsum<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a32 = true; }
+        hipLaunchKernelGGL(k_fs_assign_binsum<float>, dim3(tcct_grid(M * 8, FS_TB, 256)), dim3(FS_TB), lds_a, st, (const float*)feat, labels, prob, M, C, ib, (const FplState*)state, binmap, pro_sum);
+    } else if (dtype == TCCT_BF16) {
+        static bool a16 = false;
+        if (!a16) { (void)hipFuncSetAttribute((const void*)k_fs_assign_binsum<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a16 = true; }
+        hipLaunchKernelGGL(k_fs_assign_binsum<bf16>, dim3(tcct_grid(M * 8, FS_TB, 256)), dim3(FS_TB), lds_a, st, (const bf16*)feat, labels, prob, M, C, ib, (const FplState*)state, binmap, pro_sum);
+    } else { tcct_set_error("fpl_select: bad dtype %d", dtype); return -1; }
+    if (hipMemcpyAsync(counts, state->counts, sizeof(uint32_t) * FS_MAXC, hipMemcpyDeviceToDevice, st) != hipSuccess) { tcct_set_error("fpl_select: copy failed"); return -2; }
+    TCCT_LAUNCH_OK();
+}

@@ -1397,3 +1397,51 @@ def test_pointwise_conv_batchnorm_fused_node(cfg, hw):
             for a, r, nm in zip(pf, pt, ('prev gamma', 'prev beta')):
                 close(a, r, 'fused vs torch ' + nm, ttol)
             close(gf['x'], gt['x'], 'fused vs torch x (through the BatchNorm in front)', 0.25)
+
+
+@pytest.mark.parametrize('cfg', [(2, 96, 160, 5, 0.0), (2, 64, 80, 9, 0.5), (1, 40, 50, 5, 4.0), (3, 33, 47, 9, 1.0), (1, 800, 1104, 5, 0.25)])
+def test_fpl_multiselect_equals_the_sorted_binning(cfg):
+    """tcct_fpl_select (round 3: radix multi-select of the bin boundaries, no sort) against the stable radix sort it replaces (TCCT_FPL_SORT=1
+    path): both order a class by (probability descending, pixel index ascending), so prototypes, loss and feature gradients must agree to
+    summation-order noise -- including HEAVY TIES (logits quantised to multiples of `q`: thousands of pixels share one probability, boundaries
+    fall inside tie groups and are resolved by the index bytes of the key), a class with fewer than 32 pixels (no full bin: NaN prototypes, as
+    in the reference), a class whose count is a multiple of 32 (no dropped tail) and 9 classes (the reference's Duke models)."""
+    from tcct_amd import ops
+    B, H, W, C, q = cfg
+    g = torch.Generator().manual_seed(B * 1000 + H + C)
+    lab = torch.randint(0, C, (B, H, W), generator=g)
+    lab[:, : H // 2] = torch.sort(lab[:, : H // 2], dim=1).values            # layered upper half, speckled lower half
+    if C == 9:
+        lab[lab == 7] = 6
+        lab.view(-1)[:20] = 7                                                   # class 7: 20 pixels only (< 32: no full bin)
+    n0 = int((lab == 0).sum())
+    extra = n0 % 32                                                             # make class 0's count a multiple of 32: no dropped tail
+    idx = (lab.view(-1) == 0).nonzero().view(-1)[:extra]
+    lab.view(-1)[idx] = 1
+    logits = torch.randn(B, C, H, W, generator=g) * 2
+    if q > 0:
+        logits = torch.round(logits / q) * q
+    feats = torch.randn(B, 32, H, W, generator=g)
+    buf = F.normalize(torch.rand(C, 32, generator=g), dim=-1).cuda()
+    labd = lab.to(torch.uint8).cuda()
+    res = []
+    for sort in (True, False):
+        ops.FPL_SORT = sort
+        try:
+            fd = nhwc(feats, torch.float32).requires_grad_(True)
+            ld, pro = ops.fpl(fd, nhwc(logits, torch.float32), labd, buf)
+            (ld * 0.7).backward()
+            res.append((ld.detach().cpu(), pro.detach().cpu(), fd.grad.cpu()))
+        finally:
+            ops.FPL_SORT = False
+    (l0, p0, g0), (l1, p1, g1) = res
+    fin = torch.isfinite(p0)
+    assert torch.equal(fin, torch.isfinite(p1))                                 # the same classes are NaN (no full bin) in both
+    if C == 9:
+        assert not fin[7].any() and fin[0].all()
+    assert torch.allclose(p0[fin], p1[fin], rtol=1e-4, atol=1e-5)
+    if fin.all():
+        assert torch.allclose(l0, l1, rtol=1e-5, atol=1e-6)
+    ok = torch.isfinite(g0) & torch.isfinite(g1)
+    assert torch.equal(torch.isfinite(g0), torch.isfinite(g1)) and torch.allclose(g0[ok], g1[ok], rtol=1e-4, atol=1e-9)
+    assert (g0[ok] != 0).any()
