@@ -171,6 +171,10 @@ int tcct_conv32f_fwd(const float* x, const float* wp, const float* bias, const f
                      int PW, tcct_stream_t stream);
 int tcct_conv32f_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH, int PW,
                        tcct_stream_t stream);
+/* ... and the 1x1 convolutions / nn.Linear of the same mode (nets/tcct.py:41-43,124,532-546,600,966-997): y [M,N] = x [M,K] W^T + bias with
+ * fp32 rows, K and N multiples of 32; transposed = 1 reads w as [K,N] (the input gradient dx = dy W); wgrad: dw [N,K], dbias [N] nullable, N <= 160 */
+int tcct_pwf_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int K, int N, int transposed, tcct_stream_t stream);
+int tcct_pwf_wgrad(const float* x, const float* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
 /* MFMA implicit-GEMM path for the hot family: 32 -> 32 channels, stride 1, 'same' padding, bf16 NHWC, any KHxKW
  * (the 3x3 and 1xk / kx1 cross-convolutions of CrossCNNBlock, reference nets/tcct.py:808-822, and the decoder 3x3s).
  * wp = weights packed by tcct_conv32_pack_weights to bf16 [KH*KW][32 co][32 ci]; transposed=1 packs the flipped/transposed

@@ -263,3 +263,180 @@ extern "C" int tcct_conv32f_wgrad(const float* x, const float* dy, float* dw, fl
     }
     TCCT_LAUNCH_OK();
 }
+
+// ------------------------------------------------------------------------------------------------ pointwise (1x1 / nn.Linear), fp32
+// Y[M,N] = X[M,K] W^T + bias with fp32 rows (the parity mode of nets/tcct.py:41-43,124,532-546,600,966-997), K and N multiples of 32.
+// 128-pixel tiles (32 per wave), up to PF_NTB 32-channel output tiles per block (blockIdx.y walks the rest), K in chunks of 32 staged through LDS
+// (rows of 144 bytes as above).  transposed = 1: the weight is read as [K][N], i.e. the input gradient dx = dy W of the same layer.
+#define PF_NTB 4
+__global__ void __launch_bounds__(CFB)
+k_pwf_mfma(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y, int64_t M, int K, int N,
+           int transposed, int64_t tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char sX[128 * CF_IPS];
+    __shared__ __attribute__((aligned(16))) unsigned char sW[PF_NTB * 32 * CF_IPS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int n0 = blockIdx.y * PF_NTB * 32;
+    const int ntb = min(PF_NTB, (N - n0) / 32);
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        f32x16 acc[PF_NTB];
+#pragma unroll
+        for (int t = 0; t < PF_NTB; ++t)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+        const int64_t m0 = tile * 128;
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            __syncthreads();
+            for (int i = tid; i < 128 * 8; i += CFB) {
+                const int p = i >> 3, c = i & 7;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m0 + p < M) v = *reinterpret_cast<const float4*>(x + (m0 + p) * K + k0 + c * 4);
+                *reinterpret_cast<float4*>(sX + p * CF_IPS + c * 16) = v;
+            }
+            for (int i = tid; i < ntb * 32 * 32; i += CFB) {
+                const int row = i >> 5, col = i & 31;           // row = output channel n0 + row, col = input channel k0 + col
+                const float v = transposed ? w[(int64_t)(k0 + col) * N + n0 + row] : w[(int64_t)(n0 + row) * K + k0 + col];
+                *reinterpret_cast<float*>(sW + row * CF_IPS + col * 4) = v;
+            }
+            __syncthreads();
+            float b[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(sX + (32 * wave + r) * CF_IPS + hh * 64 + q * 16);
+                b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int t = 0; t < PF_NTB; ++t) {
+                if (t < ntb) {
+                    float a[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4*>(sW + (32 * t + r) * CF_IPS + hh * 64 + q * 16);
+                        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        const int64_t m = m0 + 32 * wave + r;
+        if (m < M) {
+#pragma unroll
+            for (int t = 0; t < PF_NTB; ++t) {
+                if (t < ntb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int co = n0 + 32 * t + 8 * q + 4 * hh;
+                        float4 v = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+                        if (bias) { v.x += bias[co]; v.y += bias[co + 1]; v.z += bias[co + 2]; v.w += bias[co + 3]; }
+                        *reinterpret_cast<float4*>(y + m * N + co) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+/* y [M,N] = x [M,K] W^T + bias (fp32; w [N,K], or read as [K,N] when transposed = 1; bias nullable); K, N multiples of 32 */
+extern "C" int tcct_pwf_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int K, int N, int transposed, tcct_stream_t stream) {
+    TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && M > 0, "pwf_fwd: K=%d N=%d unsupported (multiples of 32)", K, N);
+    const int64_t tiles = (M + 127) / 128;
+    const int gy = (N / 32 + PF_NTB - 1) / PF_NTB;
+    int64_t gx = 1024 / gy;
+    if (gx > tiles) gx = tiles;
+    hipLaunchKernelGGL(k_pwf_mfma, dim3((unsigned)gx, gy), dim3(CFB), 0, (hipStream_t)stream, x, w, bias, y, M, K, N, transposed, tiles);
+    TCCT_LAUNCH_OK();
+}
+
+// dW[N][K] += dy^T x, dbias[N] += sum dy over 128-pixel tiles: a block owns all N/32 output-channel tiles x PF_KTB input-channel tiles
+// (blockIdx.y walks the rest of K), tile i of that set belongs to wave i % 4 (<= PF_WT accumulators per wave); K-dim = pixels, two per MFMA.
+#define PF_KTB 2
+#define PF_WT 3
+__global__ void __launch_bounds__(CFB)
+k_pwf_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias, int64_t M, int K, int N,
+            int64_t tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sD = reinterpret_cast<float*>(smem);                  // [128][N]
+    float* sX = sD + 128 * N;                                    // [128][32 * PF_KTB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int NT = N / 32;
+    const int k0 = blockIdx.y * PF_KTB * 32;
+    const int ktb = min(PF_KTB, (K - k0) / 32);
+    const int XW = 32 * PF_KTB;
+    const int ntl = NT * ktb;                                    // tiles of this block: index i = nt * ktb + kt
+    f32x16 acc[PF_WT];
+#pragma unroll
+    for (int t = 0; t < PF_WT; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    float bsum[PF_WT] = {0.f, 0.f, 0.f};
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t m0 = tile * 128;
+        __syncthreads();
+        for (int i = tid; i < 128 * (N / 4); i += CFB) {
+            const int p = i / (N / 4), c = i - p * (N / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + p < M) v = *reinterpret_cast<const float4*>(dy + (m0 + p) * N + c * 4);
+            *reinterpret_cast<float4*>(sD + p * N + c * 4) = v;
+        }
+        for (int i = tid; i < 128 * (ktb * 8); i += CFB) {
+            const int p = i / (ktb * 8), c = i - p * (ktb * 8);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + p < M) v = *reinterpret_cast<const float4*>(x + (m0 + p) * K + k0 + c * 4);
+            *reinterpret_cast<float4*>(sX + p * XW + c * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < PF_WT; ++t) {
+            const int ti = wave + 4 * t;
+            if (ti < ntl) {                             // wave-uniform
+                const int nt = ti / ktb, kt = ti - nt * ktb;
+#pragma unroll 4
+                for (int j = 0; j < 64; ++j) {
+                    const int q = 2 * j + hh;
+                    const float a = sD[q * N + 32 * nt + r];
+                    const float b = sX[q * XW + 32 * kt + r];
+                    if (kt == 0) bsum[t] += a;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < PF_WT; ++t) {
+        const int ti = wave + 4 * t;
+        if (ti < ntl) {
+            const int nt = ti / ktb, kt = ti - nt * ktb;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int co = 32 * nt + (k & 3) + 8 * (k >> 2) + 4 * hh;
+                atomicAdd(&dw[(int64_t)co * K + k0 + 32 * kt + r], acc[t][k]);
+            }
+            if (dbias && kt == 0 && blockIdx.y == 0) {
+                const float sb = bsum[t] + __shfl_xor(bsum[t], 32, 64);
+                if (lane < 32) atomicAdd(&dbias[32 * nt + r], sb);
+            }
+        }
+    }
+}
+/* dw [N,K] fp32 and dbias [N] (nullable) are cleared here (unless tcct_set_outputs_prezeroed) and accumulated into; N <= 160 */
+extern "C" int tcct_pwf_wgrad(const float* x, const float* dy, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream) {
+    TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && N <= 160 && M > 0, "pwf_wgrad: K=%d N=%d unsupported", K, N);
+    TCCT_CHECK((N / 32) * PF_KTB <= 4 * PF_WT, "pwf_wgrad: N=%d needs more accumulators than a block has", N);
+    hipStream_t st = (hipStream_t)stream;
+    if (!tcct_skip_zero_fill()) {
+        if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)N * K, st) != hipSuccess) { tcct_set_error("pwf_wgrad: memset failed"); return -2; }
+        if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * N, st) != hipSuccess) { tcct_set_error("pwf_wgrad: memset failed"); return -2; }
+    }
+    const size_t lds = (size_t)128 * (N + 32 * PF_KTB) * 4;
+    TCCT_CHECK(lds <= 160 * 1024, "pwf_wgrad: %zu B of LDS", lds);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_pwf_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const int64_t tiles = (M + 127) / 128;
+    const int gy = (K / 32 + PF_KTB - 1) / PF_KTB;
+    int64_t gx = 256 / gy;
+    if (gx < 32) gx = 32;
+    if (gx > tiles) gx = tiles;
+    hipLaunchKernelGGL(k_pwf_wgrad, dim3((unsigned)gx, gy), dim3(CFB), lds, st, x, dy, dw, dbias, M, K, N, tiles);
+    TCCT_LAUNCH_OK();
+}

@@ -21,6 +21,7 @@
 #define FS_BINS 32
 #define FS_SLOTS 128            // slots histogrammed per pass of a level (128 x 256 counters x 4 B = 128 KB of LDS)
 #define FS_TB 1024
+#define FS_RUN 32              // consecutive pixels per 8-lane group of the bin-sum pass
 
 struct FplState {
     uint32_t nslots, pad0, pad1, pad2;
@@ -66,7 +67,21 @@ __global__ void __launch_bounds__(FS_TB) k_fs_hist(const uint8_t* __restrict__ l
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (sp[mid] < pf) lo = mid + 1; else hi = mid; }
             s = (lo < (int)sb[c + 1] && sp[lo] == pf) ? lo : -1;
         }
-        if (s >= slot_lo && s < slot_lo + FS_SLOTS) atomicAdd(&lh[(s - slot_lo) * 256 + (int)((key >> sh_dig) & 255ull)], 1u);
+        // Counter index of this lane, -1: none.  Probabilities concentrate (a freshly initialised network gives ~1/C everywhere, a trained one 1.0):
+        // whole waves then hit ONE counter and same-address LDS atomics serialise lane by lane.  Up to four rounds of "the first live lane's
+        // counter takes all lanes that share it" turn those 64 atomics into one; what is left after four rounds is spread out and goes lane by lane.
+        int ci = (s >= slot_lo && s < slot_lo + FS_SLOTS) ? (s - slot_lo) * 256 + (int)((key >> sh_dig) & 255ull) : -1;
+#pragma unroll 1
+        for (int round = 0; round < 4; ++round) {
+            const unsigned long long live = __ballot(ci >= 0);
+            if (live == 0ull) break;
+            const int lead = __ffsll((long long)live) - 1;
+            const int cl = __shfl(ci, lead, 64);
+            const unsigned long long same = __ballot(ci == cl);
+            if ((int)(threadIdx.x & 63) == lead) atomicAdd(&lh[cl], (uint32_t)__popcll(same));
+            if (ci == cl) ci = -1;
+        }
+        if (ci >= 0) atomicAdd(&lh[ci], 1u);
     }
     __syncthreads();
     const int nloc = min(FS_SLOTS, nslots - slot_lo) * 256;
@@ -170,27 +185,50 @@ __global__ void __launch_bounds__(FS_TB) k_fs_assign_binsum(const T* __restrict_
         ts[i] = s == 1u ? st->bnd_shift[i] : (s == 3u ? 0xfffffffeu : 0xffffffffu);
     }
     __syncthreads();
+    // An 8-lane group walks FS_RUN consecutive pixels and keeps the running sum of its 4 channels in registers while (class, bin) stays the
+    // same: bins of tied probabilities are contiguous pixel ranges (ties break by index) and labels are layered, so neighbouring pixels
+    // usually share their bin -- eight groups of a wave adding to the SAME 32 LDS words would serialise, and ds_add_f32 is the slow path anyway.
     const int sub = threadIdx.x & 7;
-    for (int64_t p = ((int64_t)blockIdx.x * FS_TB + threadIdx.x) >> 3; p < M; p += ((int64_t)gridDim.x * FS_TB) >> 3) {
-        const int c = lab[p];
-        int bin = FS_BINS;
-        if (c < C && ts[c * FS_BINS] != 0xfffffffeu) {
-            const unsigned long long key = fs_key(prob[p], (uint32_t)p, ib);
-            int lo = 0, hi = FS_BINS;               // number of boundaries b with key >= boundary_b (monotone: boundaries ascend with b)
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                const uint32_t sh = ts[c * FS_BINS + mid];
-                const bool ge = sh != 0xffffffffu && (key >> sh) >= tp[c * FS_BINS + mid];
-                if (ge) lo = mid + 1; else hi = mid;
+    const int64_t ngroups = (M + FS_RUN - 1) / FS_RUN;
+    for (int64_t grp = ((int64_t)blockIdx.x * FS_TB + threadIdx.x) >> 3; grp < ngroups; grp += ((int64_t)gridDim.x * FS_TB) >> 3) {
+        const int64_t p0 = grp * FS_RUN, p1 = min(M, p0 + FS_RUN);
+        f4 run = f4zero();
+        int cur = -1;
+        for (int64_t p = p0; p < p1; ++p) {
+            const int c = lab[p];
+            int bin = FS_BINS;
+            if (c < C && ts[c * FS_BINS] != 0xfffffffeu) {
+                const unsigned long long key = fs_key(prob[p], (uint32_t)p, ib);
+                int lo = 0, hi = FS_BINS;           // number of boundaries b with key >= boundary_b (monotone: boundaries ascend with b)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const uint32_t sh = ts[c * FS_BINS + mid];
+                    const bool ge = sh != 0xffffffffu && (key >> sh) >= tp[c * FS_BINS + mid];
+                    if (ge) lo = mid + 1; else hi = mid;
+                }
+                bin = lo;
             }
-            bin = lo;
-        }
-        if (sub == 0) binmap[p] = bin < FS_BINS ? (uint8_t)bin : (uint8_t)255;
-        if (bin < FS_BINS) {
-            const f4 v = ld4(feat + p * 32 + sub * 4);
-            float* a = acc + (c * FS_BINS + bin) * 32 + sub * 4;
+            if (sub == 0) binmap[p] = bin < FS_BINS ? (uint8_t)bin : (uint8_t)255;
+            const int id = bin < FS_BINS ? c * FS_BINS + bin : -1;
+            if (id != cur) {
+                if (cur >= 0) {
+                    float* a = acc + cur * 32 + sub * 4;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(a + k, v.v[k]);
+                    for (int k = 0; k < 4; ++k) atomicAdd(a + k, run.v[k]);
+                }
+                run = f4zero();
+                cur = id;
+            }
+            if (id >= 0) {
+                const f4 v = ld4(feat + p * 32 + sub * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) run.v[k] += v.v[k];
+            }
+        }
+        if (cur >= 0) {
+            float* a = acc + cur * 32 + sub * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(a + k, run.v[k]);
         }
     }
     __syncthreads();
@@ -232,11 +270,11 @@ extern "C" int tcct_fpl_select(const void* feat, const uint8_t* labels, const fl
     if (dtype == TCCT_F32) {
         static bool a32 = false;
         if (!a32) { (void)hipFuncSetAttribute((const void*)k_fs_assign_binsum<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a32 = true; }
-        hipLaunchKernelGGL(k_fs_assign_binsum<float>, dim3(tcct_grid(M * 8, FS_TB, 256)), dim3(FS_TB), lds_a, st, (const float*)feat, labels, prob, M, C, ib, (const FplState*)state, binmap, pro_sum);
+        hipLaunchKernelGGL(k_fs_assign_binsum<float>, dim3(tcct_grid((M + FS_RUN - 1) / FS_RUN * 8, FS_TB, 512)), dim3(FS_TB), lds_a, st, (const float*)feat, labels, prob, M, C, ib, (const FplState*)state, binmap, pro_sum);
     } else if (dtype == TCCT_BF16) {
         static bool a16 = false;
         if (!a16) { (void)hipFuncSetAttribute((const void*)k_fs_assign_binsum<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a16 = true; }
-        hipLaunchKernelGGL(k_fs_assign_binsum<bf16>, dim3(tcct_grid(M * 8, FS_TB, 256)), dim3(FS_TB), lds_a, st, (const bf16*)feat, labels, prob, M, C, ib, (const FplState*)state, binmap, pro_sum);
+        hipLaunchKernelGGL(k_fs_assign_binsum<bf16>, dim3(tcct_grid((M + FS_RUN - 1) / FS_RUN * 8, FS_TB, 512)), dim3(FS_TB), lds_a, st, (const bf16*)feat, labels, prob, M, C, ib, (const FplState*)state, binmap, pro_sum);
     } else { tcct_set_error("fpl_select: bad dtype %d", dtype); return -1; }
     if (hipMemcpyAsync(counts, state->counts, sizeof(uint32_t) * FS_MAXC, hipMemcpyDeviceToDevice, st) != hipSuccess) { tcct_set_error("fpl_select: copy failed"); return -2; }
     TCCT_LAUNCH_OK();

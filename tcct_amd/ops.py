@@ -250,6 +250,12 @@ def _mfma32f_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
             and 2 * padh == KH - 1 and 2 * padw == KW - 1 and 1 < KH * KW <= 13 and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
 
 
+def _pwf_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+    """fp32 MFMA pointwise kernels (conv_f32_mfma.hip): fp32 1x1 convolutions / Linear with channel counts that are multiples of 32"""
+    return (F32_MFMA and in_dt == torch.float32 and out_dt == torch.float32 and KH == 1 and KW == 1 and stride == 1 and padh == 0 and padw == 0
+            and Cin == Cin_w and Cin % 32 == 0 and Cout % 32 == 0)
+
+
 def _mfma_slabs_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
     """wider bf16 stride-1 'same' convolutions (3x3, 1xk, kx1 with channel counts that are multiples of 32) as 32x32 sub-GEMMs of the
     conv32 kernels: MPViT stem[1] (32->64) and the wide CNN encoder of stc_tb / gtc_tb (32-64-96-128-256, nets/tcct.py:861-864)"""
@@ -344,6 +350,8 @@ class _Conv2d(torch.autograd.Function):
             wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.float32)
             lib.conv32f_pack_weights(w, wp, KH, KW, 0)
             lib.conv32f_fwd(x, wp, bias, None, y, N, H, W, KH, KW, padh, padw)
+        elif _pwf_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+            lib.pwf_fwd(x, w, bias, y, N * H * W, Cin, Cout, 0)
         else:
             lib.conv2d_fwd(x, w, bias, y, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
                            dtype_code(odt))
@@ -411,6 +419,8 @@ class _Conv2d(torch.autograd.Function):
                     dskip = None
                 else:
                     lib.conv32_fwd(dy, wp, None, dx, N, H, W, KH, KW, KH - 1 - padh, KW - 1 - padw)
+            elif _pwf_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
+                lib.pwf_fwd(dy, w, None, dx, N * H * W, Cout, Cin, 1)
             elif _mfma32f_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
                 wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.float32)
                 lib.conv32f_pack_weights(w, wp, KH, KW, 1)
@@ -432,6 +442,8 @@ class _Conv2d(torch.autograd.Function):
                     lib.conv32_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
                 elif _mfma32f_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
                     lib.conv32f_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
+                elif _pwf_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw) and Cout <= 160:
+                    lib.pwf_wgrad(x, dy, dw, db, N * H * W, Cin, Cout)
                 elif _mfma_slabs_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
                     if not ZERO.active:
                         dw.zero_()
