@@ -361,6 +361,12 @@ def main():
     dt = tdist.max_over_ranks(dt, torch.device('cuda', local))
     lossv = float(loss.item())
     devices = tdist.gather_strings(f'cuda:{local} ({torch.cuda.get_device_name(local)})')
+    ranks_seen = None
+    import torch.distributed as tdd0
+    if tdd0.is_initialized():       # evidence that a collective over ALL ranks really ran (every rank takes part): ones all-reduced == world size
+        one = torch.ones(1, device='cuda')
+        tdd0.all_reduce(one)
+        ranks_seen = int(one.item())
     tdist.barrier()
     if rank != 0:
         tdist.barrier()         # leave together with rank 0 (which still times the roofline kernels): no rank tears the group down early
@@ -385,10 +391,7 @@ def main():
     }
     import torch.distributed as tdd2
     if tdd2.is_initialized():
-        # evidence that a collective over ALL ranks really ran: a one-element all-reduce of ones must come back as the world size
-        one = torch.ones(1, device='cuda')
-        tdd2.all_reduce(one)
-        out['config']['allreduce_ranks_seen'] = int(one.item())
+        out['config']['allreduce_ranks_seen'] = ranks_seen
         try:
             out['config']['nccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version()) if tdd2.get_backend() == 'nccl' else None
         except Exception as e:                                  # noqa: BLE001

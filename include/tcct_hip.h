@@ -180,6 +180,9 @@ int tcct_pwf_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
  * wp = weights packed by tcct_conv32_pack_weights to bf16 [KH*KW][32 co][32 ci]; transposed=1 packs the flipped/transposed
  * weights so that the same kernel computes the input gradient (dx = conv32_fwd(dy, wp_T, NULL)). */
 int tcct_conv32_pack_weights(const float* w, void* wp, int KH, int KW, int transposed, tcct_stream_t stream);
+/* all 32 -> 32 convolution weights of a step in one launch: desc = device array of n records {const float* w (OIHW fp32); void* wp2 (2 KH KW 1024
+ * bf16: forward pack, then the flipped / transposed input-gradient pack); int64 KH; int64 KW} */
+int tcct_conv32_pack_weights_multi(const void* desc, int n, tcct_stream_t stream);
 /* both packs in one launch: wp2 [2][KH*KW*1024] = {forward pack, input-gradient pack}; the backward pass reuses the second half */
 int tcct_conv32_pack_weights_both(const float* w, void* wp2, int KH, int KW, tcct_stream_t stream);
 int tcct_conv32_fwd(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
@@ -252,6 +255,12 @@ int64_t tcct_pw_bwd_bn_supported(int K, int N, int post, int red_post, int split
 int tcct_pw_bwd_bn(const void* x, const void* x2, const void* dz, const void* y, const float* coef, int post, const float* w, const void* res,
                    void* dx, void* dx2, float* dw, float* dbias, int64_t M, int K, int N, const void* y_prev, const float* ab_prev,
                    int red_post, double* sums_prev, tcct_stream_t stream);
+/* ... with the constants derived inside the kernel from the BatchNorm's two batch sums (sums [2][N] fp64: {sum dz', sum dz' xhat} from
+ * tcct_bn_bwd_reduce, or raw = 1 {sum dz', sum dz' y} from a reduction epilogue); writes dgamma / dbeta [N]: one launch per BatchNorm fewer */
+int tcct_pw_bwd_bn_sums(const void* x, const void* x2, const void* dz, const void* y, const double* sums, int raw, const float* mean_rstd,
+                        const float* ab, float* dgamma, float* dbeta, int post, const float* w, const void* res, void* dx, void* dx2, float* dw,
+                        float* dbias, int64_t M, int K, int N, const void* y_prev, const float* ab_prev, int red_post, double* sums_prev,
+                        tcct_stream_t stream);
 /* the same for an N-column slab of a wider output: dy rows have stride ldy elements (multiple of 8) and dy / dw / dbias point at the slab
  * (nn.Linear(dim, 3 dim) of FactorAtt_ConvRelPosEnc, nets/tcct.py:307, runs as slabs of <= 160 columns) */
 int tcct_pw_wgrad_strided(const void* x, const void* dy, int64_t ldy, float* dw, float* dbias, int64_t M, int K, int N,

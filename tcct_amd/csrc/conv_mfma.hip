@@ -45,6 +45,25 @@ extern "C" int tcct_conv32_pack_weights_both(const float* w, void* wp2, int KH, 
     hipLaunchKernelGGL(k_pack_w32, dim3((total + MB - 1) / MB), dim3(MB), 0, (hipStream_t)stream, w, (bf16*)wp2, KH, KW, 2, 32, 0, 0);
     TCCT_LAUNCH_OK();
 }
+// every 32 -> 32 convolution weight of the network in ONE launch: desc[i] = {source fp32 OIHW pointer, destination (forward pack followed by the
+// flipped / transposed pack, 2 * KH*KW*1024 bf16), KH, KW}; blockIdx.y = convolution
+struct PackDesc { const float* w; bf16* wp; int64_t KH, KW; };
+__global__ void k_pack_w32_multi(const PackDesc* __restrict__ desc) {
+    const PackDesc d = desc[blockIdx.y];
+    const int KH = (int)d.KH, KW = (int)d.KW, total = KH * KW * 1024;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i & 31, co = (i >> 5) & 31, tap = i >> 10;
+        const int dy = tap / KW, dx = tap % KW;
+        d.wp[i] = __float2bfloat16(d.w[(((int64_t)co * 32 + ci) * KH + dy) * KW + dx]);
+        d.wp[total + i] = __float2bfloat16(d.w[(((int64_t)ci * 32 + co) * KH + (KH - 1 - dy)) * KW + (KW - 1 - dx)]);
+    }
+}
+/* desc: device array of n {const float* w; void* wp2; int64 KH; int64 KW} records (32 bytes each): tcct_conv32_pack_weights_both for all of them */
+extern "C" int tcct_conv32_pack_weights_multi(const void* desc, int n, tcct_stream_t stream) {
+    TCCT_CHECK(n >= 1 && n <= 65535 && desc != nullptr, "conv32_pack_weights_multi: bad count %d", n);
+    hipLaunchKernelGGL(k_pack_w32_multi, dim3(13 * 1024 / MB, n), dim3(MB), 0, (hipStream_t)stream, (const PackDesc*)desc);
+    TCCT_LAUNCH_OK();
+}
 extern "C" int tcct_conv32_pack_weights_sub(const float* w, void* wp, int KH, int KW, int transposed, int cin_total, int o_off,
                                             int i_off, tcct_stream_t stream) {
     int total = KH * KW * 1024;

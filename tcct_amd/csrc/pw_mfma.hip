@@ -768,7 +768,10 @@ extern "C" int tcct_c3_wgrad(const void* x4, const void* dy, float* dw, float* d
 // REDP >= 0: the INPUT x is itself the output of a train-mode BatchNorm z_prev = post_prev(ap y_prev + bp) whose only remaining gradient is
 // this kernel's dx (+ res): the two batch sums of THAT BatchNorm's backward (sum dz', sum dz' y_prev per channel) are accumulated in the dx
 // epilogue, so its separate reduction pass (read dz, read y_prev) is gone as well.  REDP = post_prev kind (0 / 2).
-struct PwBnBwd { const bf16* y; const float* coef; const bf16* yprev; const float* abprev; double* sums_prev; };
+// coef == NULL: the per-channel constants are derived in the kernel's prologue from the two batch sums (what tcct_bn_bwd_coef computes; one launch
+// fewer per BatchNorm), and block 0 writes dgamma / dbeta
+struct PwBnBwd { const bf16* y; const float* coef; const bf16* yprev; const float* abprev; double* sums_prev;
+                 const double* sums; int raw; const float* mean_rstd; const float* ab; float* dgamma; float* dbeta; };
 template <int KIND> __device__ __forceinline__ float pw_act_grad(float u) {
     if (KIND == TCCT_ACT_HSWISH) return u < -3.f ? 0.f : (u <= 3.f ? (2.f * u + 3.f) * (1.f / 6.f) : 1.f);
     return 1.f;
@@ -796,7 +799,19 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
         const int n = i / K, k = i - n * K;
         *reinterpret_cast<bf16*>(sW + k * SW + n * 2) = __float2bfloat16(w[i]);
     }
-    if (BN) for (int i = tid; i < 5 * N; i += PWB) sC[i] = bn.coef[i];
+    if (BN) {
+        if (bn.coef) { for (int i = tid; i < 5 * N; i += PWB) sC[i] = bn.coef[i]; }
+        else if (tid < N) {
+            const int c = tid;
+            const double mu = bn.mean_rstd[c], rs = bn.mean_rstd[N + c];
+            const double S1 = bn.sums[c];
+            const double S2 = bn.raw ? (bn.sums[N + c] - mu * S1) * rs : bn.sums[N + c];
+            if (blockIdx.x == 0) { bn.dbeta[c] = (float)S1; bn.dgamma[c] = (float)S2; }
+            const double a = bn.ab[c], s1 = S1 / (double)M, s2 = S2 / (double)M;
+            sC[c] = (float)a; sC[N + c] = (float)(-a * s2 * rs); sC[2 * N + c] = (float)(a * (s2 * rs * mu - s1));
+            sC[3 * N + c] = bn.ab[c]; sC[4 * N + c] = bn.ab[N + c];
+        }
+    }
     if (RED) for (int i = tid; i < 2 * (SPLIT ? K / 2 : K); i += PWB) sP[i] = bn.abprev[i];
     constexpr int RKT = RED ? (SPLIT ? KT / 2 : KT) : 1;   // 32-channel tiles of x that carry the BatchNorm in front (split: the first half)
     float rs[RKT][8], rq[RKT][8];                            // RED: per-lane partial sums of dz' and dz' y_prev (channels 8 (lane & 3) + k of tile kt)
@@ -1052,7 +1067,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
  * are ACCUMULATED into after being cleared here (or by the caller: tcct_set_outputs_prezeroed).  K, N in {32, 64, 96, 128}. */
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
                        int64_t M, int K, int N, tcct_stream_t stream, bool split = false, int bnp = -1, int redp = -1,
-                       PwBnBwd bn = PwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr});
+                       PwBnBwd bn = PwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr});
 /* the same over a concatenation: x = [x1 | x2], dx = [dx1 | dx2], each [M, K/2] (K = 128): backward of tcct_pw_fwd_cat2 */
 extern "C" int tcct_pw_bwd_cat2(const void* x1, const void* x2, const void* dy, const float* w, void* dx1, void* dx2, float* dw, int64_t M,
                                 int K, int N, tcct_stream_t stream) {
@@ -1090,18 +1105,36 @@ extern "C" int64_t tcct_pw_bwd_bn_supported(int K, int N, int post, int red_post
  *   dw += dy_conv^T x, dbias += sum dy_conv as in tcct_pw_bwd.  x2 / dx2 non-NULL: the concatenated form of tcct_pw_bwd_cat2.
  *   red_post >= 0: x = post_prev(BN_prev(y_prev)) and dx (+ res) is the complete gradient of x -- sums_prev [2][K or K/2] (fp64, zero on entry)
  *   receive {sum dz', sum dz' y_prev} of BN_prev's backward (raw form: tcct_bn_bwd_coef(raw = 1) converts), ab_prev = BN_prev's {a[K], b[K]}. */
+static int pw_bwd_bn_impl(const void* x, const void* x2, const void* dz, PwBnBwd bn, int post, const float* w, const void* res, void* dx, void* dx2,
+                          float* dw, float* dbias, int64_t M, int K, int N, int red_post, tcct_stream_t stream);
 extern "C" int tcct_pw_bwd_bn(const void* x, const void* x2, const void* dz, const void* y, const float* coef, int post, const float* w,
                               const void* res, void* dx, void* dx2, float* dw, float* dbias, int64_t M, int K, int N, const void* y_prev,
                               const float* ab_prev, int red_post, double* sums_prev, tcct_stream_t stream) {
+    TCCT_CHECK(coef != nullptr, "pw_bwd_bn: coef is NULL");
+    return pw_bwd_bn_impl(x, x2, dz, PwBnBwd{(const bf16*)y, coef, (const bf16*)y_prev, ab_prev, sums_prev, nullptr, 0, nullptr, nullptr, nullptr, nullptr},
+                          post, w, res, dx, dx2, dw, dbias, M, K, N, red_post, stream);
+}
+/* the same with the constants derived in the kernel from the BatchNorm's batch sums (sums [2][N] fp64 from tcct_bn_bwd_reduce, or raw = 1: from a
+ * reduction epilogue), mean_rstd / ab as saved by the forward; dgamma / dbeta [N] are written.  One launch instead of tcct_bn_bwd_coef + tcct_pw_bwd_bn. */
+extern "C" int tcct_pw_bwd_bn_sums(const void* x, const void* x2, const void* dz, const void* y, const double* sums, int raw, const float* mean_rstd,
+                                   const float* ab, float* dgamma, float* dbeta, int post, const float* w, const void* res, void* dx, void* dx2,
+                                   float* dw, float* dbias, int64_t M, int K, int N, const void* y_prev, const float* ab_prev, int red_post,
+                                   double* sums_prev, tcct_stream_t stream) {
+    TCCT_CHECK(sums && mean_rstd && ab && dgamma && dbeta, "pw_bwd_bn_sums: NULL argument");
+    return pw_bwd_bn_impl(x, x2, dz, PwBnBwd{(const bf16*)y, nullptr, (const bf16*)y_prev, ab_prev, sums_prev, sums, raw, mean_rstd, ab, dgamma, dbeta},
+                          post, w, res, dx, dx2, dw, dbias, M, K, N, red_post, stream);
+}
+static int pw_bwd_bn_impl(const void* x, const void* x2, const void* dz, PwBnBwd bn, int post, const float* w, const void* res, void* dx, void* dx2,
+                          float* dw, float* dbias, int64_t M, int K, int N, int red_post, tcct_stream_t stream) {
+    const void* y = bn.y; const void* y_prev = bn.yprev; const float* ab_prev = bn.abprev; double* sums_prev = bn.sums_prev;
     const bool split = x2 != nullptr;
     TCCT_CHECK(tcct_pw_bwd_bn_supported(K, N, post, red_post, split ? 1 : 0), "pw_bwd_bn: K=%d N=%d post=%d red_post=%d split=%d unsupported", K, N, post,
                red_post, (int)split);
-    TCCT_CHECK(y != nullptr && coef != nullptr && (red_post < 0 || (y_prev && ab_prev && sums_prev)), "pw_bwd_bn: NULL argument");
+    TCCT_CHECK(y != nullptr && (red_post < 0 || (y_prev && ab_prev && sums_prev)), "pw_bwd_bn: NULL argument");
     TCCT_CHECK(!split || (dx2 != nullptr && res == nullptr), "pw_bwd_bn: the concatenated form takes x2 / dx2 and no residual");
     if (red_post >= 0 && !tcct_skip_zero_fill() &&
         hipMemsetAsync(sums_prev, 0, sizeof(double) * 2 * (split ? K / 2 : K), (hipStream_t)stream) != hipSuccess) { tcct_set_error("pw_bwd_bn: memset failed"); return -2; }
-    return pw_bwd_impl(x, dz, w, split ? x2 : res, dx, split ? dx2 : nullptr, dw, dbias, M, K, N, stream, split, post, red_post,
-                       PwBnBwd{(const bf16*)y, coef, (const bf16*)y_prev, ab_prev, sums_prev});
+    return pw_bwd_impl(x, dz, w, split ? x2 : res, dx, split ? dx2 : nullptr, dw, dbias, M, K, N, stream, split, post, red_post, bn);
 }
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
                        int64_t M, int K, int N, tcct_stream_t stream, bool split, int bnp, int redp, PwBnBwd bn) {

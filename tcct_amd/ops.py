@@ -58,12 +58,55 @@ class _ZeroPool:
 ZERO = _ZeroPool()
 
 
+# ---- one weight-pack launch per step (round 3) -----------------------------------------------------------------------------------------
+# The bf16 [tap][co][ci] packs (+ the flipped / transposed input-gradient packs) of the ~40 dense 32 -> 32 convolutions used to be made by one
+# small launch per convolution per step (39 x ~5 us on the critical stream).  Convolutions seen during a pooled step are remembered; from the
+# next step on begin_step() re-packs ALL of them with one launch (the optimizer has just changed the weights) and the forward pass picks its
+# pack out of the cache.  TCCT_PACK_ALL=0 restores the per-call launches.
+PACK_ALL = os.environ.get('TCCT_PACK_ALL', '1') != '0'
+_PACKS = {'ent': {}, 'desc': None, 'sig': None, 'fresh': False}
+
+
+def _pack_lookup(w, KH, KW):
+    """(forward pack, input-gradient pack) of weight w made by this step's pack-all launch, or None"""
+    if not (PACK_ALL and ZERO.active):
+        return None
+    ent = _PACKS['ent'].get(id(w))
+    if ent is None or ent[0] is not w or ent[3] != w.data_ptr():
+        wp2 = torch.empty(2 * KH * KW * 1024, device=w.device, dtype=torch.bfloat16)
+        _PACKS['ent'][id(w)] = (w, wp2, (KH, KW), w.data_ptr())
+        _PACKS['sig'] = None                    # the descriptor table is rebuilt at the next begin_step()
+        return None
+    if not _PACKS['fresh'] or _PACKS['sig'] is None:
+        return None
+    n = KH * KW * 1024
+    return ent[1][:n], ent[1][n:]
+
+
+def _pack_all(device):
+    ents = [e for e in _PACKS['ent'].values() if e[0].device == device and e[0].data_ptr() == e[3]]
+    _PACKS['fresh'] = False
+    if not (PACK_ALL and ents):
+        return
+    sig = tuple((e[3], e[1].data_ptr()) for e in ents)
+    if sig != _PACKS['sig']:
+        rows = [[e[3], e[1].data_ptr(), e[2][0], e[2][1]] for e in ents]
+        _PACKS['desc'] = torch.tensor(rows, dtype=torch.int64).to(device)
+        _PACKS['sig'] = sig
+    lib.conv32_pack_weights_multi(_PACKS['desc'], len(ents))
+    _PACKS['fresh'] = True
+
+
 def begin_step(device):
     """call once per training step before the forward (KiteSeg.train_step does): arms the zero pool"""
     device = torch.device(device)
     if device.type == 'cuda' and device.index is None:          # torch.device('cuda') != torch.device('cuda', 0): never re-allocate the pool for that
         device = torch.device('cuda', torch.cuda.current_device())
     ZERO.begin(device)
+    stale = [k for k, e in _PACKS['ent'].items() if e[0].data_ptr() != e[3]]        # storage re-bound (the flat optimizer buffer, load_state_dict)
+    for k in stale:
+        del _PACKS['ent'][k]
+    _pack_all(device)
     _STEP['main'] = torch.cuda.current_stream(device)
     for v in _STEP['marks'].values():
         v[0] = v[1] = 0
@@ -333,7 +376,10 @@ class _Conv2d(torch.autograd.Function):
                 stats_box[1] = sums
             _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, False, sums, stats_box[0] if stats_box is not None else 0)
         elif mfma:
-            if ctx.needs_input_grad[0]:     # the input-gradient pack of the same weights comes out of the same launch (used by backward())
+            cached = _pack_lookup(w, KH, KW)
+            if cached is not None:          # made by this step's single pack launch (begin_step)
+                wp, ctx.wp_t = cached
+            elif ctx.needs_input_grad[0]:   # the input-gradient pack of the same weights comes out of the same launch (used by backward())
                 wp2 = torch.empty(2 * KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
                 lib.conv32_pack_weights_both(w, wp2, KH, KW)
                 wp, ctx.wp_t = wp2[:KH * KW * 1024], wp2[KH * KW * 1024:]
@@ -1134,10 +1180,8 @@ class _PwConvBN(torch.autograd.Function):
         else:
             sums, raw = ZERO.get((2 * N,), torch.float64, y.device), 0
             lib.bn_bwd_reduce(y, dz, M, N, mean_rstd, ab, 0, post, sums, dtype_code(y.dtype))
-        coef = torch.empty(5 * N, device=y.device, dtype=torch.float32)
         dg = _grad_out(gamma) if ZERO.active and getattr(gamma, '_grad_slot', None) is not None else torch.empty(N, device=y.device, dtype=torch.float32)
         db_ = _grad_out(beta) if ZERO.active and getattr(beta, '_grad_slot', None) is not None else torch.empty(N, device=y.device, dtype=torch.float32)
-        lib.bn_bwd_coef(sums, raw, M, N, mean_rstd, ab, coef, dg, db_)
         dx = torch.empty_like(x)
         dx2 = torch.empty_like(x2) if x2 is not None else None
         dw = _grad_out(wsrc, tuple(w.shape))
@@ -1149,7 +1193,7 @@ class _PwConvBN(torch.autograd.Function):
             ypv, abp = prev.y, prev.ab
             sp = prev.sums = ZERO.get((2 * x.shape[-1],), torch.float64, y.device)
         dskip = _as(dalias, x.dtype) if dalias is not None else None
-        lib.pw_bwd_bn(x, x2, dz, y, coef, post, w, dskip, dx, dx2, dw, dbias, M, K, N, ypv, abp, redp, sp)
+        lib.pw_bwd_bn_sums(x, x2, dz, y, sums, raw, mean_rstd, ab, dg, db_, post, w, dskip, dx, dx2, dw, dbias, M, K, N, ypv, abp, redp, sp)
         return (dx, dx2, _ret(dw, wsrc), _ret(dbias, bsrc), _ret(dg, gamma), _ret(db_, beta), None, None, None, None, None, None,
                 (dz if has_res else None), None, None, None)
 
