@@ -285,6 +285,7 @@ def _mfma32_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
 
 
 F32_MFMA = os.environ.get('TCCT_F32_MFMA', '1') != '0'        # =0: the VALU convolution for the fp32 parity mode (A/B timing, bisecting)
+F32_PW = [True, True, True]            # bisecting: fp32 MFMA pointwise forward / input gradient / weight gradient
 
 
 def _mfma32f_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
@@ -396,7 +397,7 @@ class _Conv2d(torch.autograd.Function):
             wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.float32)
             lib.conv32f_pack_weights(w, wp, KH, KW, 0)
             lib.conv32f_fwd(x, wp, bias, None, y, N, H, W, KH, KW, padh, padw)
-        elif _pwf_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+        elif F32_PW[0] and _pwf_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
             lib.pwf_fwd(x, w, bias, y, N * H * W, Cin, Cout, 0)
         else:
             lib.conv2d_fwd(x, w, bias, y, N, H, W, Cin, Cin_w, Cout, KH, KW, stride, padh, padw, dtype_code(x.dtype),
@@ -465,7 +466,7 @@ class _Conv2d(torch.autograd.Function):
                     dskip = None
                 else:
                     lib.conv32_fwd(dy, wp, None, dx, N, H, W, KH, KW, KH - 1 - padh, KW - 1 - padw)
-            elif _pwf_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
+            elif F32_PW[1] and _pwf_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
                 lib.pwf_fwd(dy, w, None, dx, N * H * W, Cout, Cin, 1)
             elif _mfma32f_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
                 wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.float32)
@@ -488,7 +489,7 @@ class _Conv2d(torch.autograd.Function):
                     lib.conv32_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
                 elif _mfma32f_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
                     lib.conv32f_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
-                elif _pwf_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw) and Cout <= 160:
+                elif F32_PW[2] and _pwf_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw) and Cout <= 160:
                     lib.pwf_wgrad(x, dy, dw, db, N * H * W, Cin, Cout)
                 elif _mfma_slabs_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
                     if not ZERO.active:

@@ -38,7 +38,9 @@ def hip(mfma):
 
 
 g64, g32 = oracle(torch.float64), oracle(torch.float32)
-for mfma in (False, True):
+for mfma, pw in ((True, [False, False, False]), (True, [True, False, False]), (True, [False, True, False]), (True, [False, False, True])):
+    ops.F32_PW[:] = pw
+    print('F32_PW', pw)
     g = hip(mfma)
     rows = sorted(((g[n] - g64[n]).norm().item() / max(g64[n].norm().item(), 1e-30), (g32[n] - g64[n]).norm().item() / max(g64[n].norm().item(), 1e-30), n)
                   for n in names if g64[n].norm().item() > 1e-3 * max(v.norm().item() for v in g64.values()))
