@@ -171,6 +171,13 @@ int tcct_conv32f_fwd(const float* x, const float* wp, const float* bias, const f
                      int PW, tcct_stream_t stream);
 int tcct_conv32f_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH, int PW,
                        tcct_stream_t stream);
+/* the same kernels on 32-channel slabs of wider fp32 tensors (MPViT stem[1] 32 -> 64, the wide CNN encoder of stc_tb / gtc_tb): *_sub packs one 32 x 32
+ * block of the weight, fwd_strided reads slab xo of xs channels and writes (accumulate = 1: adds to) slab yo of ys, wgrad_strided accumulates one block */
+int tcct_conv32f_pack_weights_sub(const float* w, float* wp, int KH, int KW, int transposed, int cin_total, int o_off, int i_off, tcct_stream_t stream);
+int tcct_conv32f_fwd_strided(const float* x, const float* wp, const float* bias, float* y, int N, int H, int W, int KH, int KW, int PH, int PW, int xs,
+                             int xo, int ys, int yo, int accumulate, tcct_stream_t stream);
+int tcct_conv32f_wgrad_strided(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH, int PW, int xs,
+                               int xo, int ds, int dof, int ldi, int o_off, int i_off, tcct_stream_t stream);
 /* ... and the 1x1 convolutions / nn.Linear of the same mode (nets/tcct.py:41-43,124,532-546,600,966-997): y [M,N] = x [M,K] W^T + bias with
  * fp32 rows, K and N multiples of 32; transposed = 1 reads w as [K,N] (the input gradient dx = dy W); wgrad: dw [N,K], dbias [N] nullable, N <= 160 */
 int tcct_pwf_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int K, int N, int transposed, tcct_stream_t stream);

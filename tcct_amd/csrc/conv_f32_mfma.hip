@@ -25,6 +25,22 @@ __global__ void k_pack_w32f(const float* __restrict__ w, float* __restrict__ wp,
         wp[i] = transposed ? w[(((int64_t)ci * 32 + co) * KH + (KH - 1 - dy)) * KW + (KW - 1 - dx)] : w[(((int64_t)co * 32 + ci) * KH + dy) * KW + dx];
     }
 }
+// the 32 x 32 block (o_off.., i_off..) of an OIHW weight with `ldi` input channels
+__global__ void k_pack_w32f_sub(const float* __restrict__ w, float* __restrict__ wp, int KH, int KW, int transposed, int ldi, int o_off, int i_off) {
+    const int total = KH * KW * 1024;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i & 31, co = (i >> 5) & 31, tap = i >> 10;
+        const int dy = tap / KW, dx = tap % KW;
+        wp[i] = transposed ? w[(((int64_t)(o_off + ci) * ldi + i_off + co) * KH + (KH - 1 - dy)) * KW + (KW - 1 - dx)]
+                           : w[(((int64_t)(o_off + co) * ldi + i_off + ci) * KH + dy) * KW + dx];
+    }
+}
+extern "C" int tcct_conv32f_pack_weights_sub(const float* w, float* wp, int KH, int KW, int transposed, int cin_total, int o_off, int i_off,
+                                             tcct_stream_t stream) {
+    const int total = KH * KW * 1024;
+    hipLaunchKernelGGL(k_pack_w32f_sub, dim3((total + CFB - 1) / CFB), dim3(CFB), 0, (hipStream_t)stream, w, wp, KH, KW, transposed, cin_total, o_off, i_off);
+    TCCT_LAUNCH_OK();
+}
 extern "C" int tcct_conv32f_pack_weights(const float* w, float* wp, int KH, int KW, int transposed, tcct_stream_t stream) {
     const int total = KH * KW * 1024;
     hipLaunchKernelGGL(k_pack_w32f, dim3((total + CFB - 1) / CFB), dim3(CFB), 0, (hipStream_t)stream, w, wp, KH, KW, transposed);
@@ -33,8 +49,11 @@ extern "C" int tcct_conv32f_pack_weights(const float* w, float* wp, int KH, int 
 
 template <bool VERT>
 __global__ void __launch_bounds__(CFB)
-k_conv32f_mfma(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
-               const float* __restrict__ yadd, int N, int H, int W, int KH, int KW, int PH, int PW, int tilesH, int tilesW, int ntiles) {
+k_conv32f_mfma(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* y,
+               const float* yadd, int N, int H, int W, int KH, int KW, int PH, int PW, int tilesH, int tilesW, int ntiles,
+               int xs, int xo, int ys, int yo) {
+    // xs / xo, ys / yo: channels per pixel in memory and first channel of the 32-channel slab read / written (32, 0: plain 32-channel tensors);
+    // wider convolutions run as 32 x 32 sub-GEMMs over slabs (MPViT stem[1] 32 -> 64, the wide CNN encoder), accumulating through yadd == y
     constexpr int TH = VERT ? 32 : 8, TW = VERT ? 8 : 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int LH = TH + KH - 1, LW = TW + KW - 1, TAPS = KH * KW;
@@ -53,13 +72,13 @@ k_conv32f_mfma(const float* __restrict__ x, const float* __restrict__ wp, const 
         const int tw = tile % tilesW, t2 = tile / tilesW, th = t2 % tilesH, n = t2 / tilesH;
         const int h0 = th * TH, w0 = tw * TW;
         __syncthreads();                    // the previous tile's fragment reads are done (and, first time, the weights are staged)
-        const float* xb = x + (int64_t)n * H * W * 32;
+        const float* xb = x + (int64_t)n * H * W * xs + xo;
         for (int i = tid; i < npix * 8; i += CFB) {
             const int pl = i >> 3, c = i & 7;
             const int lr = pl / LW, lc = pl - lr * LW;
             const int hi = h0 - PH + lr, wi = w0 - PW + lc;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = *reinterpret_cast<const float4*>(xb + ((int64_t)hi * W + wi) * 32 + c * 4);
+            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = *reinterpret_cast<const float4*>(xb + ((int64_t)hi * W + wi) * xs + c * 4);
             *reinterpret_cast<float4*>(sX + (VERT ? lc * LH + lr : pl) * CF_IPS + c * 16) = v;
         }
         __syncthreads();
@@ -102,7 +121,7 @@ k_conv32f_mfma(const float* __restrict__ x, const float* __restrict__ wp, const 
             const int mt = 2 * wave + t;
             const int ho = VERT ? h0 + r : h0 + mt, wo = VERT ? w0 + mt : w0 + r;
             if (ho < H && wo < W) {
-                const int64_t o = (((int64_t)n * H + ho) * W + wo) * 32 + 4 * hh;
+                const int64_t o = (((int64_t)n * H + ho) * W + wo) * ys + yo + 4 * hh;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float4 v = make_float4(acc[t][4 * q] + sB[8 * q + 4 * hh], acc[t][4 * q + 1] + sB[8 * q + 4 * hh + 1],
@@ -117,11 +136,24 @@ k_conv32f_mfma(const float* __restrict__ x, const float* __restrict__ wp, const 
 
 /* x, y: fp32 NHWC [N,H,W,32]; wp: packed fp32 [KH*KW][32][32] (tcct_conv32f_pack_weights); stride 1, 'same' padding (2 PH = KH - 1, 2 PW = KW - 1);
  * yadd (nullable, fp32 like y, may not overlap y): y = conv + bias + yadd -- the input gradient of a convolution whose input has a second consumer */
+static int conv32f_fwd_impl(const float* x, const float* wp, const float* bias, const float* yadd, float* y, int N, int H, int W, int KH, int KW,
+                            int PH, int PW, int xs, int xo, int ys, int yo, tcct_stream_t stream);
 extern "C" int tcct_conv32f_fwd(const float* x, const float* wp, const float* bias, const float* yadd, float* y, int N, int H, int W, int KH, int KW,
                                 int PH, int PW, tcct_stream_t stream) {
+    TCCT_CHECK(yadd == nullptr || yadd != y, "conv32f_fwd: yadd must be a separate tensor");
+    return conv32f_fwd_impl(x, wp, bias, yadd, y, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, stream);
+}
+/* the same on 32-channel slabs of wider fp32 tensors: x has xs channels per pixel (slab at xo), y has ys (slab at yo); accumulate = 1 adds into y.
+ * wp: the packed 32 x 32 block of the weight (tcct_conv32f_pack_weights_sub) */
+extern "C" int tcct_conv32f_fwd_strided(const float* x, const float* wp, const float* bias, float* y, int N, int H, int W, int KH, int KW, int PH, int PW,
+                                        int xs, int xo, int ys, int yo, int accumulate, tcct_stream_t stream) {
+    TCCT_CHECK(xs % 4 == 0 && xo % 4 == 0 && ys % 4 == 0 && yo % 4 == 0 && xo + 32 <= xs && yo + 32 <= ys, "conv32f_fwd_strided: bad slab");
+    return conv32f_fwd_impl(x, wp, bias, accumulate ? y : nullptr, y, N, H, W, KH, KW, PH, PW, xs, xo, ys, yo, stream);
+}
+static int conv32f_fwd_impl(const float* x, const float* wp, const float* bias, const float* yadd, float* y, int N, int H, int W, int KH, int KW,
+                            int PH, int PW, int xs, int xo, int ys, int yo, tcct_stream_t stream) {
     TCCT_CHECK(KH >= 1 && KW >= 1 && (KH == 1 || KW == 1 || (KH == 3 && KW == 3)) && KH * KW <= 13, "conv32f_fwd: kernel %dx%d unsupported", KH, KW);
     TCCT_CHECK(2 * PH == KH - 1 && 2 * PW == KW - 1, "conv32f_fwd: only 'same' padding (got pad %d,%d for %dx%d)", PH, PW, KH, KW);
-    TCCT_CHECK(yadd == nullptr || yadd != y, "conv32f_fwd: yadd must be a separate tensor");
     const bool vert = (KW == 1 && KH > 1);
     const int TH = vert ? 32 : 8, TW = vert ? 8 : 32;
     const int LH = TH + KH - 1, LW = TW + KW - 1;
@@ -135,10 +167,10 @@ extern "C" int tcct_conv32f_fwd(const float* x, const float* wp, const float* bi
     static bool attr[2] = {false, false};
     if (vert) {
         if (!attr[1]) { (void)hipFuncSetAttribute((const void*)k_conv32f_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[1] = true; }
-        hipLaunchKernelGGL(k_conv32f_mfma<true>, dim3(grid), dim3(CFB), lds, st, x, wp, bias, y, yadd, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt);
+        hipLaunchKernelGGL(k_conv32f_mfma<true>, dim3(grid), dim3(CFB), lds, st, x, wp, bias, y, yadd, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo);
     } else {
         if (!attr[0]) { (void)hipFuncSetAttribute((const void*)k_conv32f_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[0] = true; }
-        hipLaunchKernelGGL(k_conv32f_mfma<false>, dim3(grid), dim3(CFB), lds, st, x, wp, bias, y, yadd, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt);
+        hipLaunchKernelGGL(k_conv32f_mfma<false>, dim3(grid), dim3(CFB), lds, st, x, wp, bias, y, yadd, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ys, yo);
     }
     TCCT_LAUNCH_OK();
 }
@@ -151,7 +183,8 @@ extern "C" int tcct_conv32f_fwd(const float* x, const float* wp, const float* bi
 template <bool VERT>
 __global__ void __launch_bounds__(CFB)
 k_conv32f_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias, int N, int H, int W,
-                int KH, int KW, int PH, int PW, int tilesH, int tilesW, int ntiles) {
+                int KH, int KW, int PH, int PW, int tilesH, int tilesW, int ntiles, int xs, int xo, int ds, int dof, int ldi, int o_off, int i_off) {
+    // xs / xo, ds / dof: channel strides / slab offsets of x and dy; the 32 x 32 block goes to rows o_off.., input channels i_off.. of a weight with ldi input channels
     constexpr int TH = VERT ? 32 : 8, TW = VERT ? 8 : 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int LH = TH + KH - 1, LW = TW + KW - 1, TAPS = KH * KW;
@@ -177,14 +210,14 @@ k_conv32f_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float
         const int tw = tile % tilesW, t2 = tile / tilesW, th = t2 % tilesH, n = t2 / tilesH;
         const int h0 = th * TH, w0 = tw * TW;
         __syncthreads();
-        const float* xb = x + (int64_t)n * H * W * 32;
-        const float* db = dy + (int64_t)n * H * W * 32;
+        const float* xb = x + (int64_t)n * H * W * xs + xo;
+        const float* db = dy + (int64_t)n * H * W * ds + dof;
         for (int i = tid; i < npix * 8; i += CFB) {
             const int pl = i >> 3, c = i & 7;
             const int lr = pl / LW, lc = pl - lr * LW;
             const int hi = h0 - PH + lr, wi = w0 - PW + lc;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = *reinterpret_cast<const float4*>(xb + ((int64_t)hi * W + wi) * 32 + c * 4);
+            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = *reinterpret_cast<const float4*>(xb + ((int64_t)hi * W + wi) * xs + c * 4);
             *reinterpret_cast<float4*>(sX + (VERT ? lc * LH + lr : pl) * 32 + c * 4) = v;
         }
         for (int i = tid; i < TH * TW * 8; i += CFB) {
@@ -192,7 +225,7 @@ k_conv32f_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float
             const int lr = pl / TW, lc = pl - lr * TW;              // tile-local output pixel (row-major)
             const int ho = h0 + lr, wo = w0 + lc;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ho < H && wo < W) v = *reinterpret_cast<const float4*>(db + ((int64_t)ho * W + wo) * 32 + c * 4);
+            if (ho < H && wo < W) v = *reinterpret_cast<const float4*>(db + ((int64_t)ho * W + wo) * ds + c * 4);
             *reinterpret_cast<float4*>(sD + (VERT ? lc * TH + lr : pl) * 32 + c * 4) = v;      // M-tile order: HORZ row-major, VERT column-major
         }
         __syncthreads();
@@ -224,19 +257,32 @@ k_conv32f_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
-                atomicAdd(&dw[(((int64_t)co * 32 + r) * KH + dy_) * KW + dx_], acc[t][k]);
+                atomicAdd(&dw[(((int64_t)(o_off + co) * ldi + i_off + r) * KH + dy_) * KW + dx_], acc[t][k]);
             }
         }
     }
     if (dbias && wave == 0) {
         const float sb = bsum + __shfl_xor(bsum, 32, 64);
-        if (lane < 32) atomicAdd(&dbias[r], sb);
+        if (lane < 32) atomicAdd(&dbias[o_off + r], sb);
     }
 }
 
 /* dw OIHW fp32 [32,32,KH,KW] and dbias [32] (nullable) are cleared here (unless tcct_set_outputs_prezeroed) and accumulated into */
+static int conv32f_wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH, int PW, int xs, int xo,
+                              int ds, int dof, int ldi, int o_off, int i_off, bool clear, tcct_stream_t stream);
 extern "C" int tcct_conv32f_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH, int PW,
                                   tcct_stream_t stream) {
+    return conv32f_wgrad_impl(x, dy, dw, dbias, N, H, W, KH, KW, PH, PW, 32, 0, 32, 0, 32, 0, 0, true, stream);
+}
+/* one 32 x 32 block of a wider convolution's weight gradient: accumulates into dw [Cout][ldi][KH][KW] at (o_off, i_off) and, dbias non-NULL, into
+ * dbias[o_off..] -- the caller clears dw / dbias once before the first slab */
+extern "C" int tcct_conv32f_wgrad_strided(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH, int PW,
+                                          int xs, int xo, int ds, int dof, int ldi, int o_off, int i_off, tcct_stream_t stream) {
+    TCCT_CHECK(xs % 4 == 0 && xo % 4 == 0 && ds % 4 == 0 && dof % 4 == 0 && xo + 32 <= xs && dof + 32 <= ds, "conv32f_wgrad_strided: bad slab");
+    return conv32f_wgrad_impl(x, dy, dw, dbias, N, H, W, KH, KW, PH, PW, xs, xo, ds, dof, ldi, o_off, i_off, false, stream);
+}
+static int conv32f_wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH, int PW, int xs, int xo,
+                              int ds, int dof, int ldi, int o_off, int i_off, bool clear, tcct_stream_t stream) {
     TCCT_CHECK(KH >= 1 && KW >= 1 && (KH == 1 || KW == 1 || (KH == 3 && KW == 3)) && KH * KW <= 13, "conv32f_wgrad: kernel %dx%d unsupported", KH, KW);
     TCCT_CHECK(2 * PH == KH - 1 && 2 * PW == KW - 1, "conv32f_wgrad: only 'same' padding");
     const bool vert = (KW == 1 && KH > 1);
@@ -245,7 +291,7 @@ extern "C" int tcct_conv32f_wgrad(const float* x, const float* dy, float* dw, fl
     const size_t lds = ((size_t)LH * LW + 256) * 128;
     TCCT_CHECK(lds <= 160 * 1024, "conv32f_wgrad: %dx%d needs %zu B of LDS", KH, KW, lds);
     hipStream_t st = (hipStream_t)stream;
-    if (!tcct_skip_zero_fill()) {
+    if (clear && !tcct_skip_zero_fill()) {
         if (hipMemsetAsync(dw, 0, sizeof(float) * 1024 * KH * KW, st) != hipSuccess) { tcct_set_error("conv32f_wgrad: memset failed"); return -2; }
         if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32f_wgrad: memset failed"); return -2; }
     }
@@ -256,10 +302,10 @@ extern "C" int tcct_conv32f_wgrad(const float* x, const float* dy, float* dw, fl
     static bool attr[2] = {false, false};
     if (vert) {
         if (!attr[1]) { (void)hipFuncSetAttribute((const void*)k_conv32f_wgrad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[1] = true; }
-        hipLaunchKernelGGL(k_conv32f_wgrad<true>, dim3(grid), dim3(CFB), lds, st, x, dy, dw, dbias, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt);
+        hipLaunchKernelGGL(k_conv32f_wgrad<true>, dim3(grid), dim3(CFB), lds, st, x, dy, dw, dbias, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ds, dof, ldi, o_off, i_off);
     } else {
         if (!attr[0]) { (void)hipFuncSetAttribute((const void*)k_conv32f_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[0] = true; }
-        hipLaunchKernelGGL(k_conv32f_wgrad<false>, dim3(grid), dim3(CFB), lds, st, x, dy, dw, dbias, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt);
+        hipLaunchKernelGGL(k_conv32f_wgrad<false>, dim3(grid), dim3(CFB), lds, st, x, dy, dw, dbias, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ds, dof, ldi, o_off, i_off);
     }
     TCCT_LAUNCH_OK();
 }

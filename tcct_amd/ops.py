@@ -285,7 +285,12 @@ def _mfma32_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
 
 
 F32_MFMA = os.environ.get('TCCT_F32_MFMA', '1') != '0'        # =0: the VALU convolution for the fp32 parity mode (A/B timing, bisecting)
-F32_PW = [True, True, True]            # bisecting: fp32 MFMA pointwise forward / input gradient / weight gradient
+# fp32 MFMA for the pointwise forward / input gradient / weight gradient.  The FORWARD stays on the sequential VALU kernel in the parity mode: on
+# the formula-weight fixtures some BatchNorm channels at the 2x2 / 4x4 levels have a batch variance at fp32 rounding level, and the MFMA summation
+# order (exact to 2-5e-7 against fp64, like the VALU kernel's) moved rstd enough to scale the whole CNN level-0 gradient by 0.93 -- outside the
+# envelope the fixtures assert, which is built from oneDNN's sequential order (tests/test_model_gpu.py, profiles/r03_parity.md).  TCCT_F32_PW_FWD=1
+# puts the forward on the matrix pipes as well (+~5 % fp32 throughput).
+F32_PW = [os.environ.get('TCCT_F32_PW_FWD', '0') == '1', True, True]
 
 
 def _mfma32f_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
@@ -307,6 +312,27 @@ def _mfma_slabs_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
             and 32 <= Cin <= 256 and 32 <= Cout <= 256 and (Cin, Cout) != (32, 32) and stride == 1
             and 2 * padh == KH - 1 and 2 * padw == KW - 1 and KH * KW > 1 and max(KH, KW) <= 13
             and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
+
+
+def _mfma_slabs_f32_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+    """wider fp32 stride-1 'same' convolutions as 32x32 sub-GEMMs of the fp32 MFMA kernels (MPViT stem[1] 32->64 is a third of the parity mode's
+    convolution time on the VALU kernel; the wide CNN encoder of stc_tb / gtc_tb)"""
+    return (F32_MFMA and in_dt == torch.float32 and out_dt == torch.float32 and Cin == Cin_w and Cin % 32 == 0 and Cout % 32 == 0
+            and 32 <= Cin <= 256 and 32 <= Cout <= 256 and (Cin, Cout) != (32, 32) and stride == 1
+            and 2 * padh == KH - 1 and 2 * padw == KW - 1 and 1 < KH * KW <= 13 and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
+
+
+def _conv_slabs_fwd_f32(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, transposed):
+    """fp32 counterpart of _conv_slabs_fwd (no fused statistics): transposed=True computes the input gradient (x = dy, w OIHW [Cin here][Cout here])"""
+    for oh in range(Cout // 32):
+        for ih in range(Cin // 32):
+            wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.float32)
+            if not transposed:
+                lib.conv32f_pack_weights_sub(w, wp, KH, KW, 0, Cin, 32 * oh, 32 * ih)
+            else:
+                lib.conv32f_pack_weights_sub(w, wp, KH, KW, 1, Cout, 32 * ih, 32 * oh)
+            b = bias[32 * oh:32 * oh + 32] if (bias is not None and ih == 0) else None
+            lib.conv32f_fwd_strided(x, wp, b, y, N, H, W, KH, KW, padh, padw, Cin, 32 * ih, Cout, 32 * oh, 1 if ih > 0 else 0)
 
 
 def _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, transposed, stats=None, stat_pre=0):
@@ -397,6 +423,8 @@ class _Conv2d(torch.autograd.Function):
             wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.float32)
             lib.conv32f_pack_weights(w, wp, KH, KW, 0)
             lib.conv32f_fwd(x, wp, bias, None, y, N, H, W, KH, KW, padh, padw)
+        elif _mfma_slabs_f32_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+            _conv_slabs_fwd_f32(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, False)
         elif F32_PW[0] and _pwf_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
             lib.pwf_fwd(x, w, bias, y, N * H * W, Cin, Cout, 0)
         else:
@@ -466,6 +494,8 @@ class _Conv2d(torch.autograd.Function):
                     dskip = None
                 else:
                     lib.conv32_fwd(dy, wp, None, dx, N, H, W, KH, KW, KH - 1 - padh, KW - 1 - padw)
+            elif _mfma_slabs_f32_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
+                _conv_slabs_fwd_f32(dy, w, None, dx, N, H, W, Cout, Cin, KH, KW, KH - 1 - padh, KW - 1 - padw, True)
             elif F32_PW[1] and _pwf_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
                 lib.pwf_fwd(dy, w, None, dx, N * H * W, Cout, Cin, 1)
             elif _mfma32f_ok(dy.dtype, x.dtype, Cout, Cout, Cin, KH, KW, stride, padh, padw):
@@ -489,6 +519,15 @@ class _Conv2d(torch.autograd.Function):
                     lib.conv32_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
                 elif _mfma32f_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
                     lib.conv32f_wgrad(x, dy, dw, db, N, H, W, KH, KW, padh, padw)
+                elif _mfma_slabs_f32_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
+                    if not ZERO.active:
+                        dw.zero_()
+                        if db is not None:
+                            db.zero_()
+                    for oh in range(Cout // 32):
+                        for ih in range(Cin // 32):
+                            lib.conv32f_wgrad_strided(x, dy, dw, db if ih == 0 else None, N, H, W, KH, KW, padh, padw, Cin, 32 * ih, Cout, 32 * oh,
+                                                      Cin, 32 * oh, 32 * ih)
                 elif F32_PW[2] and _pwf_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw) and Cout <= 160:
                     lib.pwf_wgrad(x, dy, dw, db, N * H * W, Cin, Cout)
                 elif _mfma_slabs_ok(x.dtype, dy.dtype, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):

@@ -157,17 +157,13 @@ def test_fp32_matches_reference_fixture(name, tmp_path):
     # fp32 noise envelope: two more, equally valid, fp32 evaluations by torch itself (channels_last kernels; input scaled by
     # 1+1e-7).  Measured in the build container: they sit up to 13x further from fp64 than the default-layout run.
     g32b, g32c = oracle_grads(torch.float32, channels_last=True), oracle_grads(torch.float32, perturb=1e-7)
-    # Round 3: how ill-conditioned these formula-weight fixtures are was MEASURED (profiles/r03_parity.md): in exact fp64 arithmetic a relative
-    # perturbation of 1e-7 / 3e-7 / 1e-6 of the weights moves the gradients of full_2x32x32 by 0.4 % / 1.7 % / 4.4 % (median per tensor; 3 % / 17 % /
-    # 37 % max) -- an amplification of ~4e4.  torch's three variants above only disturb the INPUT (which the first train-mode BatchNorm
-    # absorbs), so their spread (0.3 % median) understates what a different-but-equally-valid fp32 summation order inside the network does: the
-    # fp32 MFMA GEMMs (pairs of products per step instead of one sequential chain; exact to 2-5e-7 of max|y| against fp64, tools/dbg_pwf.py) land
-    # at 5 % median on this fixture while the sequential VALU kernels, whose order happens to match oneDNN's, land at 0.1 %.  The family of valid
-    # fp32 evaluations therefore gets a fourth member: the same graph with every weight disturbed at the 1e-6 level (fp64 evaluation, so that
-    # only the disturbance counts).  The literal 1e-3 gradient contract is asserted where it is meaningful: on the well-conditioned trained-weight
-    # fixture (test_trained_weights_train_step_matches_reference), the default-initialised network (test_bf16_matches_rounding_point_oracle) and at
-    # full size (tests/test_fullsize_gpu.py::test_fullsize_backward_matches_the_oracle).
-    g64n = oracle_grads(torch.float64, wnoise=1e-6)
+    # Round 3 (profiles/r03_parity.md): WHY these formula-weight fixtures are ill-conditioned was tracked down.  At the 2x2 / 4x4 levels some
+    # train-mode BatchNorm channels have a batch variance at fp32 ROUNDING level (8-32 nearly equal samples), so rstd -- and with it the gain of
+    # every gradient that flows back through that BatchNorm -- depends on the last bits of the 1x1 convolution in front of it.  With the fp32
+    # MFMA kernel in the pointwise FORWARD (pairs of products per step; exact to 2-5e-7 of max|y| against fp64, tools/dbg_pwf.py) the whole CNN
+    # level-0 gradient of full_2x32x32 comes out scaled by 0.93 at cosine 0.9999 (tools/dbg_fp32_grads.py) -- a legitimate fp32 result, but
+    # outside this envelope, which is built from evaluations that share oneDNN's sequential summation order.  The parity mode therefore keeps
+    # the sequential VALU kernel for the pointwise forward (ops.F32_PW) and uses the matrix pipes for everything else; bounds are unchanged.
     gmax = max(g.abs().max().item() for g in g64.values())
     worst, over = 0.0, []
     strict = name in ('full_2x32x32', 'full_2x64x64', 'di_2x64x64')
@@ -179,14 +175,14 @@ def test_fp32_matches_reference_fixture(name, tmp_path):
         # test_bf16_matches_rounding_point_oracle (seeded default weights: fp32 HIP vs oracle median 1e-5).
         big = [n for n in names if g64[n].norm().item() > 1e-3 * max(g.norm().item() for g in g64.values())]
         e = np.array([(named[n].grad.double().cpu() - g64[n]).norm().item() / g64[n].norm().item() for n in big])
-        e_t = np.array([max((g[n] - g64[n]).norm().item() for g in (g32, g32b, g32c, g64n)) / g64[n].norm().item() for n in big])
+        e_t = np.array([max((g[n] - g64[n]).norm().item() for g in (g32, g32b, g32c)) / g64[n].norm().item() for n in big])
         print(name, 'gradient rel-L2 vs fp64: HIP median / p90 / max', np.median(e), np.percentile(e, 90), e.max(), '; torch fp32 variants', np.median(e_t),
               np.percentile(e_t, 90), e_t.max())
         assert np.median(e) <= 4 * np.median(e_t) + 1e-3 and np.percentile(e, 90) <= 4 * np.percentile(e_t, 90) + 1e-3 and e.max() < 0.5
     for n, l2 in zip(names if strict else [], fx['grad_l2']):
         gh = named[n].grad.double().cpu()
         e_hip = (gh - g64[n]).norm().item()
-        e_ref = max((g[n] - g64[n]).norm().item() for g in (g32, g32b, g32c, g64n))
+        e_ref = max((g[n] - g64[n]).norm().item() for g in (g32, g32b, g32c))
         bound = 4 * e_ref + 2e-4 * g64[n].norm().item() + 1e-6 * gmax * gh.numel() ** 0.5
         worst = max(worst, e_hip / bound)
         # the envelope is the spread of THREE torch fp32 evaluations: for a noise-only tensor (a convolution bias in front of a
@@ -210,14 +206,13 @@ def test_fp32_matches_reference_fixture(name, tmp_path):
     tn32 = sum((g ** 2).sum() for g in g32.values()).sqrt().item()
     tn64 = sum((g ** 2).sum() for g in g64.values()).sqrt().item()
     if strict:
-        tnn = sum((g ** 2).sum() for g in g64n.values()).sqrt().item()
-        assert abs(tn_own - tn64) <= 4 * max(abs(tn32 - tn64), abs(tnn - tn64)) + 2e-3 * tn64, (tn_own, tn32, tnn, tn64, float(fx['grad_total_norm']))
+        assert abs(tn_own - tn64) <= 4 * abs(tn32 - tn64) + 2e-3 * tn64, (tn_own, tn32, tn64, float(fx['grad_total_norm']))
     else:
         # the two chaotic fixtures: torch's OWN fp32 total norm moves by several per cent between equally valid evaluations (full_2x128x128,
         # fp64 5978.8: default layout 5972.9, channels_last 6017.0, input x (1 +- 1e-7) 5802.2 / 5776.9, both 5577.7 -- measured in the build
         # container), so one torch sample is a lottery ticket: the bound is the spread of the three variants evaluated above.  (The total norm at
         # the literal 1e-3 is asserted on the well-conditioned fixture, test_trained_weights_train_step_matches_reference.)
-        spread = max(abs(sum((g ** 2).sum() for g in gv.values()).sqrt().item() - tn64) for gv in (g32, g32b, g32c, g64n))
+        spread = max(abs(sum((g ** 2).sum() for g in gv.values()).sqrt().item() - tn64) for gv in (g32, g32b, g32c))
         assert abs(tn_own - tn64) <= 1.5 * spread + 2e-3 * tn64, (tn_own, tn32, tn64, spread, float(fx['grad_total_norm']))
     lr = float(fx['lr'])
     assert abs(k.optimG.param_groups[0]['lr'] - lr) < 1e-12
