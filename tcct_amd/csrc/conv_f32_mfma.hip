@@ -68,20 +68,38 @@ k_conv32f_mfma(const float* __restrict__ x, const float* __restrict__ wp, const 
     }
     if (tid < 32) sB[tid] = bias ? bias[tid] : 0.f;
     const int npix = LH * LW;
+    // the NEXT tile's pixels are requested into registers before the MFMA phase of the current one (576 MFMAs per wave and tile: long enough to
+    // hide the whole memory latency) and written to LDS after it
+    float4 pre[CF_MAXL];
+    auto prefetch = [&](int tile) {
+        const int tw = tile % tilesW, t2 = tile / tilesW, th = t2 % tilesH, n = t2 / tilesH;
+        const int h0 = th * TH, w0 = tw * TW;
+        const float* xb = x + (int64_t)n * H * W * xs + xo;
+#pragma unroll
+        for (int j = 0; j < CF_MAXL; ++j) {
+            const int i = tid + j * CFB;
+            const int pl = i >> 3, c = i & 7;
+            const int lr = pl / LW, lc = pl - lr * LW;
+            const int hi = h0 - PH + lr, wi = w0 - PW + lc;
+            pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pl < npix && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                pre[j] = *reinterpret_cast<const float4*>(xb + ((int64_t)hi * W + wi) * xs + c * 4);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tw = tile % tilesW, t2 = tile / tilesW, th = t2 % tilesH, n = t2 / tilesH;
         const int h0 = th * TH, w0 = tw * TW;
         __syncthreads();                    // the previous tile's fragment reads are done (and, first time, the weights are staged)
-        const float* xb = x + (int64_t)n * H * W * xs + xo;
-        for (int i = tid; i < npix * 8; i += CFB) {
+#pragma unroll
+        for (int j = 0; j < CF_MAXL; ++j) {
+            const int i = tid + j * CFB;
             const int pl = i >> 3, c = i & 7;
             const int lr = pl / LW, lc = pl - lr * LW;
-            const int hi = h0 - PH + lr, wi = w0 - PW + lc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = *reinterpret_cast<const float4*>(xb + ((int64_t)hi * W + wi) * xs + c * 4);
-            *reinterpret_cast<float4*>(sX + (VERT ? lc * LH + lr : pl) * CF_IPS + c * 16) = v;
+            if (pl < npix) *reinterpret_cast<float4*>(sX + (VERT ? lc * LH + lr : pl) * CF_IPS + c * 16) = pre[j];
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
         f32x16 acc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -159,6 +177,7 @@ static int conv32f_fwd_impl(const float* x, const float* wp, const float* bias, 
     const int LH = TH + KH - 1, LW = TW + KW - 1;
     const size_t lds = (size_t)KH * KW * 32 * CF_IPS + (size_t)LH * LW * CF_IPS + 128;
     TCCT_CHECK(lds <= 160 * 1024, "conv32f_fwd: %dx%d needs %zu B of LDS", KH, KW, lds);
+    TCCT_CHECK(LH * LW * 8 <= CF_MAXL * CFB, "conv32f_fwd: %dx%d tile image exceeds the staging slots", KH, KW);
     const int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
     const int64_t nt = (int64_t)N * tilesH * tilesW;
     TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32f_fwd: bad tile count");
@@ -206,29 +225,51 @@ k_conv32f_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float
         poff[t] = tap < TAPS ? (VERT ? dx_ * LH + dy_ : dy_ * LW + dx_) * 32 : 0;
     }
     const int npix = LH * LW;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    float4 prex[CF_MAXL], pred[8];          // the next tile's x / dy pixels, requested before the MFMA phase of the current tile
+    auto prefetch = [&](int tile) {
         const int tw = tile % tilesW, t2 = tile / tilesW, th = t2 % tilesH, n = t2 / tilesH;
         const int h0 = th * TH, w0 = tw * TW;
-        __syncthreads();
         const float* xb = x + (int64_t)n * H * W * xs + xo;
         const float* db = dy + (int64_t)n * H * W * ds + dof;
-        for (int i = tid; i < npix * 8; i += CFB) {
+#pragma unroll
+        for (int j = 0; j < CF_MAXL; ++j) {
+            const int i = tid + j * CFB;
             const int pl = i >> 3, c = i & 7;
             const int lr = pl / LW, lc = pl - lr * LW;
             const int hi = h0 - PH + lr, wi = w0 - PW + lc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = *reinterpret_cast<const float4*>(xb + ((int64_t)hi * W + wi) * xs + c * 4);
-            *reinterpret_cast<float4*>(sX + (VERT ? lc * LH + lr : pl) * 32 + c * 4) = v;
+            prex[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pl < npix && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                prex[j] = *reinterpret_cast<const float4*>(xb + ((int64_t)hi * W + wi) * xs + c * 4);
         }
-        for (int i = tid; i < TH * TW * 8; i += CFB) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + j * CFB;
             const int pl = i >> 3, c = i & 7;
             const int lr = pl / TW, lc = pl - lr * TW;              // tile-local output pixel (row-major)
             const int ho = h0 + lr, wo = w0 + lc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ho < H && wo < W) v = *reinterpret_cast<const float4*>(db + ((int64_t)ho * W + wo) * ds + c * 4);
-            *reinterpret_cast<float4*>(sD + (VERT ? lc * TH + lr : pl) * 32 + c * 4) = v;      // M-tile order: HORZ row-major, VERT column-major
+            pred[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ho < H && wo < W) pred[j] = *reinterpret_cast<const float4*>(db + ((int64_t)ho * W + wo) * ds + c * 4);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CF_MAXL; ++j) {
+            const int i = tid + j * CFB;
+            const int pl = i >> 3, c = i & 7;
+            const int lr = pl / LW, lc = pl - lr * LW;
+            if (pl < npix) *reinterpret_cast<float4*>(sX + (VERT ? lc * LH + lr : pl) * 32 + c * 4) = prex[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + j * CFB;
+            const int pl = i >> 3, c = i & 7;
+            const int lr = pl / TW, lc = pl - lr * TW;
+            *reinterpret_cast<float4*>(sD + (VERT ? lc * TH + lr : pl) * 32 + c * 4) = pred[j];      // M-tile order: HORZ row-major, VERT column-major
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
         // pixel q of the tile in M-tile order: HORZ (row = q / 32, col = q % 32) -> image pixel row * LW + col; VERT (col = q / 32, row = q % 32)
         // -> image pixel col * LH + row: consecutive q inside an M-tile are consecutive image pixels in both layouts
         for (int mt = 0; mt < 8; ++mt) {
@@ -290,6 +331,7 @@ static int conv32f_wgrad_impl(const float* x, const float* dy, float* dw, float*
     const int LH = TH + KH - 1, LW = TW + KW - 1;
     const size_t lds = ((size_t)LH * LW + 256) * 128;
     TCCT_CHECK(lds <= 160 * 1024, "conv32f_wgrad: %dx%d needs %zu B of LDS", KH, KW, lds);
+    TCCT_CHECK(LH * LW * 8 <= CF_MAXL * CFB, "conv32f_wgrad: %dx%d tile image exceeds the staging slots", KH, KW);
     hipStream_t st = (hipStream_t)stream;
     if (clear && !tcct_skip_zero_fill()) {
         if (hipMemsetAsync(dw, 0, sizeof(float) * 1024 * KH * KW, st) != hipSuccess) { tcct_set_error("conv32f_wgrad: memset failed"); return -2; }

@@ -11,9 +11,9 @@
 //             that still contain an unresolved boundary (<= 32 per class) -- in LDS-private counters, merged with global atomics;
 //             a one-block kernel then walks every boundary one byte down (prefix scan of its slot's 256 counters) and resolves it as soon as
 //             its bucket holds ONE element (always at the last byte: keys are unique), and builds the next level's slot list
-//   assign  : bin(p) = #{b : key(p) >= key of boundary b} by binary search over the class's 32 (prefix, shift) pairs -- fused with the bin sums:
-//             the feature rows are read in PIXEL order (one coalesced pass; the sorted order forced a scattered 64-byte gather per pixel)
-//             and accumulated in LDS-private [class][bin][32] sums.
+//   assign  : bin(p) = #{b : key(p) >= key of boundary b} by binary search over the class's 32 (prefix, shift) pairs, one thread per pixel;
+//   bin sums: the feature rows are read in PIXEL order (one coalesced pass; the sorted order forced a scattered 64-byte gather per pixel)
+//             with run-length accumulation in registers and LDS-private [class][bin][32] sums.
 // 4 probability bytes + ceil(log2 M / 8) index bytes = 7 levels at the bench shape; every launch has constant arguments (no host sync).
 #include "common.h"
 
@@ -169,60 +169,81 @@ __global__ void __launch_bounds__(FS_TB) k_fs_resolve(int C, int level, int nlev
     for (uint32_t i = tid; i < nz; i += FS_TB) hist[i] = 0;            // counters of the next level (every read of this level is behind a barrier)
 }
 
-// bin of every pixel + the bin sums: 8 lanes per pixel, 4 channels each; LDS-private [C][32][32] accumulators
-template <typename T>
-__global__ void __launch_bounds__(FS_TB) k_fs_assign_binsum(const T* __restrict__ feat, const uint8_t* __restrict__ lab, const float* __restrict__ prob,
-                                                            int64_t M, int C, int ib, const FplState* __restrict__ st, uint8_t* __restrict__ binmap,
-                                                            float* __restrict__ pro_sum) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* acc = reinterpret_cast<float*>(smem);                                                    // [C * 32][32]
-    unsigned long long* tp = reinterpret_cast<unsigned long long*>(acc + C * FS_BINS * 32);      // [C][32] boundary prefixes
-    uint32_t* ts = reinterpret_cast<uint32_t*>(tp + C * FS_BINS);                                   // [C][32] shift (0xffffffff: never reached)
-    for (int i = threadIdx.x; i < C * FS_BINS * 32; i += FS_TB) acc[i] = 0.f;
+// bin of every pixel: one thread per pixel, binary search over the class's 32 (prefix, shift) boundary records
+__global__ void __launch_bounds__(FS_TB) k_fs_assign(const uint8_t* __restrict__ lab, const float* __restrict__ prob, int64_t M, int C, int ib,
+                                                     const FplState* __restrict__ st, uint8_t* __restrict__ binmap) {
+    __shared__ unsigned long long tp[FS_MAXC * FS_BINS];       // boundary prefixes
+    __shared__ uint32_t ts[FS_MAXC * FS_BINS];                 // shift (0xffffffff: never reached, 0xfffffffe: class without a full bin)
     for (int i = threadIdx.x; i < C * FS_BINS; i += FS_TB) {
         const uint32_t s = st->bnd_state[i];
         tp[i] = st->bnd_prefix[i];
         ts[i] = s == 1u ? st->bnd_shift[i] : (s == 3u ? 0xfffffffeu : 0xffffffffu);
     }
     __syncthreads();
-    // An 8-lane group walks FS_RUN consecutive pixels and keeps the running sum of its 4 channels in registers while (class, bin) stays the
-    // same: bins of tied probabilities are contiguous pixel ranges (ties break by index) and labels are layered, so neighbouring pixels
-    // usually share their bin -- eight groups of a wave adding to the SAME 32 LDS words would serialise, and ds_add_f32 is the slow path anyway.
-    const int sub = threadIdx.x & 7;
-    const int64_t ngroups = (M + FS_RUN - 1) / FS_RUN;
-    for (int64_t grp = ((int64_t)blockIdx.x * FS_TB + threadIdx.x) >> 3; grp < ngroups; grp += ((int64_t)gridDim.x * FS_TB) >> 3) {
-        const int64_t p0 = grp * FS_RUN, p1 = min(M, p0 + FS_RUN);
-        f4 run = f4zero();
-        int cur = -1;
-        for (int64_t p = p0; p < p1; ++p) {
-            const int c = lab[p];
-            int bin = FS_BINS;
-            if (c < C && ts[c * FS_BINS] != 0xfffffffeu) {
-                const unsigned long long key = fs_key(prob[p], (uint32_t)p, ib);
-                int lo = 0, hi = FS_BINS;           // number of boundaries b with key >= boundary_b (monotone: boundaries ascend with b)
-                while (lo < hi) {
+    for (int64_t p = (int64_t)blockIdx.x * FS_TB + threadIdx.x; p < M; p += (int64_t)gridDim.x * FS_TB) {
+        const int c = lab[p];
+        int bin = FS_BINS;
+        if (c < C && ts[c * FS_BINS] != 0xfffffffeu) {
+            const unsigned long long key = fs_key(prob[p], (uint32_t)p, ib);
+            int lo = 0, hi = FS_BINS;               // number of boundaries b with key >= boundary_b (monotone: boundaries ascend with b)
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                if (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     const uint32_t sh = ts[c * FS_BINS + mid];
                     const bool ge = sh != 0xffffffffu && (key >> sh) >= tp[c * FS_BINS + mid];
                     if (ge) lo = mid + 1; else hi = mid;
                 }
-                bin = lo;
             }
-            if (sub == 0) binmap[p] = bin < FS_BINS ? (uint8_t)bin : (uint8_t)255;
-            const int id = bin < FS_BINS ? c * FS_BINS + bin : -1;
-            if (id != cur) {
-                if (cur >= 0) {
-                    float* a = acc + cur * 32 + sub * 4;
+            bin = lo;
+        }
+        binmap[p] = bin < FS_BINS ? (uint8_t)bin : (uint8_t)255;
+    }
+}
+
+// bin sums in PIXEL order: an 8-lane group (4 channels per lane) walks FS_RUN consecutive pixels and keeps the running sum in registers while
+// (class, bin) stays the same -- bins of tied probabilities are contiguous pixel ranges (ties break by index) and labels are layered, so
+// neighbouring pixels usually share their bin; eight groups of a wave adding to the SAME 32 LDS words would serialise (the first version, one
+// pixel per group and an LDS atomic per value, took 1.34 ms at the bench shape against 0.61 ms for the gather it replaced).  The group's 32 labels
+// and bins are fetched with two 16-byte loads each, the feature rows four pixels ahead.
+template <typename T>
+__global__ void __launch_bounds__(FS_TB) k_fs_binsum(const T* __restrict__ feat, const uint8_t* __restrict__ lab, const uint8_t* __restrict__ binmap,
+                                                     int64_t M, int C, float* __restrict__ pro_sum) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* acc = reinterpret_cast<float*>(smem);                                                    // [C * 32][32]
+    for (int i = threadIdx.x; i < C * FS_BINS * 32; i += FS_TB) acc[i] = 0.f;
+    __syncthreads();
+    const int sub = threadIdx.x & 7;
+    const int64_t ngroups = M / FS_RUN;                 // whole runs (M % FS_RUN pixels are handled below, one by one)
+    for (int64_t grp = ((int64_t)blockIdx.x * FS_TB + threadIdx.x) >> 3; grp < ngroups; grp += ((int64_t)gridDim.x * FS_TB) >> 3) {
+        const int64_t p0 = grp * FS_RUN;
+        const uint4 l0 = *reinterpret_cast<const uint4*>(lab + p0), l1 = *reinterpret_cast<const uint4*>(lab + p0 + 16);
+        const uint4 b0 = *reinterpret_cast<const uint4*>(binmap + p0), b1 = *reinterpret_cast<const uint4*>(binmap + p0 + 16);
+        const uint32_t lw[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w}, bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        f4 run = f4zero();
+        int cur = -1;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) atomicAdd(a + k, run.v[k]);
+        for (int q4 = 0; q4 < FS_RUN / 4; ++q4) {
+            f4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ld4(feat + (p0 + 4 * q4 + j) * 32 + sub * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = (int)((lw[q4] >> (8 * j)) & 255u), bin = (int)((bw[q4] >> (8 * j)) & 255u);
+                const int id = (bin < FS_BINS && c < C) ? c * FS_BINS + bin : -1;
+                if (id != cur) {
+                    if (cur >= 0) {
+                        float* a = acc + cur * 32 + sub * 4;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) atomicAdd(a + k, run.v[k]);
+                    }
+                    run = f4zero();
+                    cur = id;
                 }
-                run = f4zero();
-                cur = id;
-            }
-            if (id >= 0) {
-                const f4 v = ld4(feat + p * 32 + sub * 4);
+                if (id >= 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) run.v[k] += v.v[k];
+                    for (int k = 0; k < 4; ++k) run.v[k] += v[j].v[k];
+                }
             }
         }
         if (cur >= 0) {
@@ -231,9 +252,100 @@ __global__ void __launch_bounds__(FS_TB) k_fs_assign_binsum(const T* __restrict_
             for (int k = 0; k < 4; ++k) atomicAdd(a + k, run.v[k]);
         }
     }
+    if (blockIdx.x == 0) {                              // the ragged tail (< FS_RUN pixels)
+        for (int64_t p = ngroups * FS_RUN + (threadIdx.x >> 3); p < M; p += FS_TB >> 3) {
+            const int c = lab[p], bin = binmap[p];
+            if (bin < FS_BINS && c < C) {
+                const f4 v = ld4(feat + p * 32 + sub * 4);
+                float* a = acc + (c * FS_BINS + bin) * 32 + sub * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(a + k, v.v[k]);
+            }
+        }
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < C * FS_BINS * 32; i += FS_TB)
         if (acc[i] != 0.f) atomicAdd(&pro_sum[i], acc[i]);
+}
+
+// The bin sums as a GEMM on the matrix pipes (bf16 features): pro_sum[class][bin][ch] = sum_p onehot[p][class, bin] feat[p][ch], i.e.
+// D[bin][ch] += A[bin][pixel] B[pixel][ch] per class with A the 0/1 indicator "pixel p belongs to (class, bin)" built in registers from the pixel's
+// id (8 compares per lane and 16-pixel step) and B the feature rows, transposed on the LDS read (ds_read_b64_tr_b16, as in the weight-gradient
+// kernels).  Products with 1.0 are exact and the accumulation is fp32, so this is the same sum as the scalar path -- without 226 M LDS float
+// atomics (ds_add_f32 of eight 8-lane groups landing on the same eight banks: 1.13 ms at the bench shape; this kernel: ~2.2 M MFMAs).
+// One M-tile per class (rows = its 32 bins), classes dealt to the four waves round-robin (<= 4 accumulators per wave for 16 classes).
+typedef __attribute__((ext_vector_type(8))) __bf16 fs_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float fs_f32x16;
+typedef __attribute__((ext_vector_type(4))) short fs_s16x4;
+typedef __attribute__((ext_vector_type(8))) short fs_s16x8;
+__global__ void __launch_bounds__(256) k_fs_binsum_mfma(const bf16* __restrict__ feat, const uint8_t* __restrict__ lab, const uint8_t* __restrict__ binmap,
+                                                        int64_t M, int C, float* __restrict__ pro_sum) {
+    __shared__ __attribute__((aligned(16))) unsigned char sX[128 * 64];      // 128 pixels x 32 channels bf16, linear rows
+    __shared__ __attribute__((aligned(16))) unsigned short sI[128];          // id = class * 32 + bin of the pixel, 0xffff: none
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    fs_f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    const int li = lane & 15, lq = li >> 2, lpp = li & 3, lg = lane >> 4;
+    const unsigned char* lbX = sX + (8 * (lg >> 1) + lq) * 64 + (16 * (lg & 1) + 4 * lpp) * 2;
+    const int64_t tiles = (M + 127) / 128;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t p0 = tile * 128;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = tid + j * 256;                    // 16-byte chunk q of the tile's contiguous 8 KB: pixel q / 4, chunk q % 4
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (p0 + (q >> 2) < M) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(feat) + (p0 * 64 + (int64_t)q * 16));
+            *reinterpret_cast<uint4*>(sX + q * 16) = v;
+        }
+        if (tid < 128) {
+            unsigned short id = 0xffffu;
+            if (p0 + tid < M) {
+                const int c = lab[p0 + tid], b = binmap[p0 + tid];
+                if (c < C && b < FS_BINS) id = (unsigned short)(c * FS_BINS + b);
+            }
+            sI[tid] = id;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const unsigned char* pb = lbX + ch * 16 * 64;
+            const fs_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fs_s16x4*)pb);
+            const fs_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fs_s16x4*)(pb + 4 * 64));
+            const fs_bf16x8 fb = __builtin_bit_cast(fs_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            const uint4 iv = *reinterpret_cast<const uint4*>(sI + ch * 16 + 8 * hh);       // the ids of this lane's 8 pixels
+            const uint32_t iw[4] = {iv.x, iv.y, iv.z, iv.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int cls = wave + 4 * t;
+                if (cls < C) {                          // wave-uniform
+                    const uint32_t want = (uint32_t)(cls * FS_BINS + r);
+                    fs_s16x8 a;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t id = (j & 1) ? (iw[j >> 1] >> 16) : (iw[j >> 1] & 0xffffu);
+                        a[j] = id == want ? (short)0x3f80 : (short)0;           // bf16 1.0 / 0.0
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(fs_bf16x8, a), fb, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int cls = wave + 4 * t;
+        if (cls < C) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int bin = (k & 3) + 8 * (k >> 2) + 4 * hh;
+                if (acc[t][k] != 0.f) atomicAdd(&pro_sum[((int64_t)cls * FS_BINS + bin) * 32 + r], acc[t][k]);
+            }
+        }
+    }
 }
 
 extern "C" int64_t tcct_fpl_select_workspace_bytes() {
@@ -266,15 +378,19 @@ extern "C" int tcct_fpl_select(const void* feat, const uint8_t* labels, const fl
             hipLaunchKernelGGL(k_fs_hist, dim3(grid), dim3(FS_TB), lds_h, st, labels, prob, M, C, level, ib, tb, ps * FS_SLOTS, (const FplState*)state, hist);
         hipLaunchKernelGGL(k_fs_resolve, dim3(1), dim3(FS_TB), 0, st, C, level, nlevels, tb, state, hist);
     }
-    const size_t lds_a = (size_t)C * FS_BINS * 32 * 4 + (size_t)C * FS_BINS * 12;
+    hipLaunchKernelGGL(k_fs_assign, dim3(tcct_grid(M, FS_TB, 1024)), dim3(FS_TB), 0, st, labels, prob, M, C, ib, (const FplState*)state, binmap);
+    const size_t lds_a = (size_t)C * FS_BINS * 32 * 4;
+    const int gb = tcct_grid((M / FS_RUN + 1) * 8, FS_TB, 512);
     if (dtype == TCCT_F32) {
         static bool a32 = false;
-        if (!a32) { (void)hipFuncSetAttribute((const void*)k_fs_assign_binsum<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a32 = true; }
-        hipLaunchKernelGGL(k_fs_assign_binsum<float>, dim3(tcct_grid((M + FS_RUN - 1) / FS_RUN * 8, FS_TB, 512)), dim3(FS_TB), lds_a, st, (const float*)feat, labels, prob, M, C, ib, (const FplState*)state, binmap, pro_sum);
+        if (!a32) { (void)hipFuncSetAttribute((const void*)k_fs_binsum<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a32 = true; }
+        hipLaunchKernelGGL(k_fs_binsum<float>, dim3(gb), dim3(FS_TB), lds_a, st, (const float*)feat, labels, (const uint8_t*)binmap, M, C, pro_sum);
     } else if (dtype == TCCT_BF16) {
         static bool a16 = false;
-        if (!a16) { (void)hipFuncSetAttribute((const void*)k_fs_assign_binsum<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a16 = true; }
-        hipLaunchKernelGGL(k_fs_assign_binsum<bf16>, dim3(tcct_grid((M + FS_RUN - 1) / FS_RUN * 8, FS_TB, 512)), dim3(FS_TB), lds_a, st, (const bf16*)feat, labels, prob, M, C, ib, (const FplState*)state, binmap, pro_sum);
+        if (!a16) { (void)hipFuncSetAttribute((const void*)k_fs_binsum<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a16 = true; }
+        (void)a16;
+        const int64_t tiles = (M + 127) / 128;
+        hipLaunchKernelGGL(k_fs_binsum_mfma, dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, st, (const bf16*)feat, labels, (const uint8_t*)binmap, M, C, pro_sum);
     } else { tcct_set_error("fpl_select: bad dtype %d", dtype); return -1; }
     if (hipMemcpyAsync(counts, state->counts, sizeof(uint32_t) * FS_MAXC, hipMemcpyDeviceToDevice, st) != hipSuccess) { tcct_set_error("fpl_select: copy failed"); return -2; }
     TCCT_LAUNCH_OK();

@@ -89,6 +89,8 @@ def _pack_all(device):
     if not (PACK_ALL and ents):
         return
     sig = tuple((e[3], e[1].data_ptr()) for e in ents)
+    if sig != _PACKS['sig'] and torch.cuda.is_current_stream_capturing():
+        return                      # the descriptor upload is a host-to-device copy: not inside a hipGraph capture (the convolutions pack per call then)
     if sig != _PACKS['sig']:
         rows = [[e[3], e[1].data_ptr(), e[2][0], e[2][1]] for e in ents]
         _PACKS['desc'] = torch.tensor(rows, dtype=torch.int64).to(device)
