@@ -197,9 +197,9 @@ static int conv32f_fwd_impl(const float* x, const float* wp, const float* bias, 
 // ------------------------------------------------------------------------------------------------ weight gradient
 // dW[tap][co][ci] = sum_p dy[p][co] x[p@tap][ci]: per tap one 32 x 32 accumulator, K = pixels, two per MFMA (lane half hh takes pixel 2 j + hh):
 // a lane reads dy[pixel][co = r] and x[pixel @ tap][ci = r] -- 32 consecutive floats per half wave, conflict-free plain ds_read_b32, no
-// transpose needed for 4-byte elements.  Taps are dealt to the four waves round-robin (<= 4 accumulators per wave); every block accumulates
-// over all its tiles in registers and ends with one fp32 atomic per weight element (and wave 0 with the bias gradient).
-template <bool VERT>
+// transpose needed for 4-byte elements.  Every wave keeps one accumulator per tap for its own quarter of the tile's pixels; a block accumulates
+// over all its tiles in registers and ends with one fp32 atomic per weight element and wave (and the bias gradient).
+template <bool VERT, int NTAP>
 __global__ void __launch_bounds__(CFB)
 k_conv32f_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias, int N, int H, int W,
                 int KH, int KW, int PH, int PW, int tilesH, int tilesW, int ntiles, int xs, int xo, int ds, int dof, int ldi, int o_off, int i_off) {
@@ -211,18 +211,19 @@ k_conv32f_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float
     float* sD = sX + LH * LW * 32;                                   // [256][32] in M-tile order: pixel index = 32 mt + r
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    f32x16 acc[4];
+    // every wave takes ALL taps for its own two M-tiles (64 of the tile's 256 pixels): 9 or 13 accumulators -- one wave per SIMD, so the whole
+    // 512-register file is available -- and the same number of MFMAs on every wave (dealing taps to waves gave wave 0 three of nine taps)
+    f32x16 acc[NTAP];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
     float bsum = 0.f;
-    int poff[4];
+    int poff[NTAP];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int tap = wave + 4 * t;
-        const int dy_ = tap / KW, dx_ = tap - dy_ * KW;
-        poff[t] = tap < TAPS ? (VERT ? dx_ * LH + dy_ : dy_ * LW + dx_) * 32 : 0;
+    for (int t = 0; t < NTAP; ++t) {
+        const int dy_ = t / KW, dx_ = t - dy_ * KW;
+        poff[t] = t < TAPS ? (VERT ? dx_ * LH + dy_ : dy_ * LW + dx_) * 32 : 0;
     }
     const int npix = LH * LW;
     float4 prex[CF_MAXL], pred[8];          // the next tile's x / dy pixels, requested before the MFMA phase of the current tile
@@ -272,17 +273,17 @@ k_conv32f_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float
         if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
         // pixel q of the tile in M-tile order: HORZ (row = q / 32, col = q % 32) -> image pixel row * LW + col; VERT (col = q / 32, row = q % 32)
         // -> image pixel col * LH + row: consecutive q inside an M-tile are consecutive image pixels in both layouts
-        for (int mt = 0; mt < 8; ++mt) {
+        for (int mt = 2 * wave; mt < 2 * wave + 2; ++mt) {
             const float* dbase = sD + mt * 32 * 32;
             const float* xbase = sX + (VERT ? mt * LH : mt * LW) * 32;
-#pragma unroll 4
+#pragma unroll 2
             for (int j = 0; j < 16; ++j) {
                 const int q = 2 * j + hh;
                 const float a = dbase[q * 32 + r];
-                if (wave == 0) bsum += a;
+                bsum += a;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (wave + 4 * t < TAPS) {          // wave-uniform
+                for (int t = 0; t < NTAP; ++t) {
+                    if (t < TAPS) {                     // block-uniform
                         const float b = xbase[q * 32 + poff[t] + r];
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
                     }
@@ -291,10 +292,9 @@ k_conv32f_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float
         }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int tap = wave + 4 * t;
-        if (tap < TAPS) {
-            const int dy_ = tap / KW, dx_ = tap - dy_ * KW;
+    for (int t = 0; t < NTAP; ++t) {
+        if (t < TAPS) {
+            const int dy_ = t / KW, dx_ = t - dy_ * KW;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
@@ -302,7 +302,7 @@ k_conv32f_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float
             }
         }
     }
-    if (dbias && wave == 0) {
+    if (dbias) {
         const float sb = bsum + __shfl_xor(bsum, 32, 64);
         if (lane < 32) atomicAdd(&dbias[o_off + r], sb);
     }
@@ -341,14 +341,12 @@ static int conv32f_wgrad_impl(const float* x, const float* dy, float* dw, float*
     const int64_t nt = (int64_t)N * tilesH * tilesW;
     TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32f_wgrad: bad tile count");
     const int grid = (int)(nt < 256 ? nt : 256);
-    static bool attr[2] = {false, false};
-    if (vert) {
-        if (!attr[1]) { (void)hipFuncSetAttribute((const void*)k_conv32f_wgrad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[1] = true; }
-        hipLaunchKernelGGL(k_conv32f_wgrad<true>, dim3(grid), dim3(CFB), lds, st, x, dy, dw, dbias, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ds, dof, ldi, o_off, i_off);
-    } else {
-        if (!attr[0]) { (void)hipFuncSetAttribute((const void*)k_conv32f_wgrad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[0] = true; }
-        hipLaunchKernelGGL(k_conv32f_wgrad<false>, dim3(grid), dim3(CFB), lds, st, x, dy, dw, dbias, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ds, dof, ldi, o_off, i_off);
-    }
+#define WG_L(V, NT) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_conv32f_wgrad<V, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_conv32f_wgrad<V, NT>), dim3(grid), dim3(CFB), lds, st, x, dy, dw, dbias, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ds, dof, ldi, o_off, i_off); }
+    const int taps = KH * KW;
+    if (vert) { if (taps <= 9) WG_L(true, 9) else WG_L(true, 13) }
+    else { if (taps <= 9) WG_L(false, 9) else WG_L(false, 13) }
+#undef WG_L
     TCCT_LAUNCH_OK();
 }
 
@@ -452,6 +450,7 @@ k_pwf_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __
     const int ktb = min(PF_KTB, (K - k0) / 32);
     const int XW = 32 * PF_KTB;
     const int ntl = NT * ktb;                                    // tiles of this block: index i = nt * ktb + kt
+    const int S = ntl == 1 ? 4 : (ntl == 2 ? 2 : 1);             // pixel splits per tile
     f32x16 acc[PF_WT];
 #pragma unroll
     for (int t = 0; t < PF_WT; ++t)
@@ -474,13 +473,16 @@ k_pwf_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __
             *reinterpret_cast<float4*>(sX + p * XW + c * 4) = v;
         }
         __syncthreads();
+        // units = tiles x pixel splits: with fewer than four tiles (32 -> 32: ONE) the 128 pixels are cut into S = 4 / ntl parts so that every wave works
 #pragma unroll
         for (int t = 0; t < PF_WT; ++t) {
-            const int ti = wave + 4 * t;
-            if (ti < ntl) {                             // wave-uniform
+            const int u = wave + 4 * t;
+            if (u < ntl * S) {                          // wave-uniform
+                const int ti = u % ntl, part = u / ntl;
                 const int nt = ti / ktb, kt = ti - nt * ktb;
+                const int j0 = part * (64 / S), j1 = j0 + 64 / S;
 #pragma unroll 4
-                for (int j = 0; j < 64; ++j) {
+                for (int j = j0; j < j1; ++j) {
                     const int q = 2 * j + hh;
                     const float a = sD[q * N + 32 * nt + r];
                     const float b = sX[q * XW + 32 * kt + r];
@@ -492,8 +494,9 @@ k_pwf_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __
     }
 #pragma unroll
     for (int t = 0; t < PF_WT; ++t) {
-        const int ti = wave + 4 * t;
-        if (ti < ntl) {
+        const int u = wave + 4 * t;
+        if (u < ntl * S) {
+            const int ti = u % ntl;
             const int nt = ti / ktb, kt = ti - nt * ktb;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {

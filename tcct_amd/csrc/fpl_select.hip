@@ -390,7 +390,7 @@ extern "C" int tcct_fpl_select(const void* feat, const uint8_t* labels, const fl
         if (!a16) { (void)hipFuncSetAttribute((const void*)k_fs_binsum<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a16 = true; }
         (void)a16;
         const int64_t tiles = (M + 127) / 128;
-        hipLaunchKernelGGL(k_fs_binsum_mfma, dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, st, (const bf16*)feat, labels, (const uint8_t*)binmap, M, C, pro_sum);
+        hipLaunchKernelGGL(k_fs_binsum_mfma, dim3((unsigned)(tiles < 1536 ? tiles : 1536)), dim3(256), 0, st, (const bf16*)feat, labels, (const uint8_t*)binmap, M, C, pro_sum);
     } else { tcct_set_error("fpl_select: bad dtype %d", dtype); return -1; }
     if (hipMemcpyAsync(counts, state->counts, sizeof(uint32_t) * FS_MAXC, hipMemcpyDeviceToDevice, st) != hipSuccess) { tcct_set_error("fpl_select: copy failed"); return -2; }
     TCCT_LAUNCH_OK();
