@@ -291,16 +291,31 @@ k_conv32f_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float
             }
         }
     }
+    // the four waves' partial sums are combined in LDS (the tiles are dead), wave after wave into the same slots, before ONE atomic per weight
+    // element and block: with every wave adding for itself, 256 blocks x 4 waves hit each of the 9 216 addresses 1 024 times -- same-address
+    // float atomics serialise at the memory side and cost a fixed ~0.3 ms per call, i.e. more than the whole kernel on the coarse levels
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);                // [TAPS][16][64]
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
 #pragma unroll
-    for (int t = 0; t < NTAP; ++t) {
-        if (t < TAPS) {
-            const int dy_ = t / KW, dx_ = t - dy_ * KW;
+            for (int t = 0; t < NTAP; ++t) {
+                if (t < TAPS) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
-                atomicAdd(&dw[(((int64_t)(o_off + co) * ldi + i_off + r) * KH + dy_) * KW + dx_], acc[t][k]);
+                    for (int k = 0; k < 16; ++k) {
+                        float* slot = red + (t * 16 + k) * 64 + lane;
+                        *slot = wv == 0 ? acc[t][k] : *slot + acc[t][k];
+                    }
+                }
             }
         }
+        __syncthreads();
+    }
+    for (int i = tid; i < TAPS * 1024; i += CFB) {
+        const int ln = i & 63, k = (i >> 6) & 15, t = i >> 10;
+        const int co = (k & 3) + 8 * (k >> 2) + 4 * (ln >> 5), ci = ln & 31;
+        const int dy_ = t / KW, dx_ = t - dy_ * KW;
+        atomicAdd(&dw[(((int64_t)(o_off + co) * ldi + i_off + ci) * KH + dy_) * KW + dx_], red[i]);
     }
     if (dbias) {
         const float sb = bsum + __shfl_xor(bsum, 32, 64);
@@ -329,7 +344,8 @@ static int conv32f_wgrad_impl(const float* x, const float* dy, float* dw, float*
     const bool vert = (KW == 1 && KH > 1);
     const int TH = vert ? 32 : 8, TW = vert ? 8 : 32;
     const int LH = TH + KH - 1, LW = TW + KW - 1;
-    const size_t lds = ((size_t)LH * LW + 256) * 128;
+    size_t lds = ((size_t)LH * LW + 256) * 128;
+    if (lds < (size_t)KH * KW * 4096) lds = (size_t)KH * KW * 4096;             // the cross-wave reduction of the accumulators reuses the tile area
     TCCT_CHECK(lds <= 160 * 1024, "conv32f_wgrad: %dx%d needs %zu B of LDS", KH, KW, lds);
     TCCT_CHECK(LH * LW * 8 <= CF_MAXL * CFB, "conv32f_wgrad: %dx%d tile image exceeds the staging slots", KH, KW);
     hipStream_t st = (hipStream_t)stream;
@@ -340,7 +356,8 @@ static int conv32f_wgrad_impl(const float* x, const float* dy, float* dw, float*
     const int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
     const int64_t nt = (int64_t)N * tilesH * tilesW;
     TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32f_wgrad: bad tile count");
-    const int grid = (int)(nt < 256 ? nt : 256);
+    int64_t g8 = (nt + 7) / 8;                  // >= 8 tiles per block: every block ends with KH*KW*1024 same-address atomics
+    const int grid = (int)(g8 < 1 ? 1 : (g8 > 256 ? 256 : g8));
 #define WG_L(V, NT) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_conv32f_wgrad<V, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
         hipLaunchKernelGGL((k_conv32f_wgrad<V, NT>), dim3(grid), dim3(CFB), lds, st, x, dy, dw, dbias, N, H, W, KH, KW, PH, PW, tilesH, tilesW, (int)nt, xs, xo, ds, dof, ldi, o_off, i_off); }
     const int taps = KH * KW;
@@ -527,7 +544,8 @@ extern "C" int tcct_pwf_wgrad(const float* x, const float* dy, float* dw, float*
     const int gy = (K / 32 + PF_KTB - 1) / PF_KTB;
     int64_t gx = 256 / gy;
     if (gx < 32) gx = 32;
-    if (gx > tiles) gx = tiles;
+    if (gx > (tiles + 7) / 8) gx = (tiles + 7) / 8;        // >= 8 tiles per block: every block ends with same-address atomics on all of dw
+    if (gx < 1) gx = 1;
     hipLaunchKernelGGL(k_pwf_wgrad, dim3((unsigned)gx, gy), dim3(CFB), lds, st, x, dy, dw, dbias, M, K, N, tiles);
     TCCT_LAUNCH_OK();
 }
