@@ -27,6 +27,7 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC for R
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+F32_MFMA_PEAK_TFLOPS = 157.3    # dense fp32 matrix peak (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU x 256 CUs x 2.4 GHz)
 
 
 def parse():
@@ -104,11 +105,13 @@ def dominant_kernel_roofline(a, iters=20):
         match = 'k_conv32_mfma<false, 0, 3, 3>'                  # the symbol as rocprofv3 prints it
         fn = lambda: lib.conv32_fwd(x, wp, b, y, a.bs, a.height, Wp, 3, 3, 1, 1)                              # noqa: E731
         fn2 = lambda: lib.conv32_wgrad(x, dy, dw, db, a.bs, a.height, Wp, 3, 3, 1, 1)                         # noqa: E731
-    else:
-        name, name2 = 'k_conv_fwd<float,float> (3x3 32->32 @L0)', 'k_conv_wgrad<float,float> (3x3 32->32 @L0)'
-        match = 'k_conv_fwd<float, float>'
-        fn = lambda: lib.conv2d_fwd(x, w, b, y, a.bs, a.height, Wp, 32, 32, 32, 3, 3, 1, 1, 1, 0, 0)          # noqa: E731
-        fn2 = lambda: lib.conv2d_wgrad(x, dy, dw, db, a.bs, a.height, Wp, 32, 32, 32, 3, 3, 1, 1, 1, 0, 0)   # noqa: E731
+    else:       # parity mode: the fp32 MFMA convolution (v_mfma_f32_32x32x2_f32), bound by the fp32 matrix rate, not by HBM
+        wpf = torch.empty(9 * 1024, device='cuda', dtype=torch.float32)
+        lib.conv32f_pack_weights(w, wpf, 3, 3, 0)
+        name, name2 = 'k_conv32f_mfma<false> (3x3 32->32 fwd/dgrad @L0, fp32 MFMA)', 'k_conv32f_wgrad<false,9> (3x3 32->32 @L0, fp32 MFMA)'
+        match = 'k_conv32f_mfma<false>'
+        fn = lambda: lib.conv32f_fwd(x, wpf, b, None, y, a.bs, a.height, Wp, 3, 3, 1, 1)                      # noqa: E731
+        fn2 = lambda: lib.conv32f_wgrad(x, dy, dw, db, a.bs, a.height, Wp, 3, 3, 1, 1)                       # noqa: E731
 
     def timed(f):
         for _ in range(2):
@@ -151,6 +154,12 @@ def dominant_kernel_roofline(a, iters=20):
     ach, ach2 = bytes_alg / (ms * 1e-3) / 1e9, bytes_alg / (ms2 * 1e-3) / 1e9
     flops = 2.0 * 9 * 32 * 32 * a.bs * a.height * Wp
     traffic, traffic_src = pmc_traffic(a, match)
+    if a.dtype != 'bf16':
+        tf, tf2 = flops / (ms * 1e-3) / 1e12, flops / (ms2 * 1e-3) / 1e12
+        return {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                'traffic': None, 'traffic_source': 'not collected for the parity mode', 'kernel': name, 'ms_per_launch': round(ms, 4), 'launches_timed': iters,
+                'algorithmic_flops': int(flops), 'hbm_GBs': round(ach, 1),
+                'second': {'kernel': name2, 'achieved': round(tf2, 2), 'frac': round(tf2 / F32_MFMA_PEAK_TFLOPS, 4), 'ms_per_launch': round(ms2, 4)}, 'others': others}
     return {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
             'traffic': traffic, 'traffic_source': traffic_src, 'kernel': name, 'ms_per_launch': round(ms, 4),
             'launches_timed': iters, 'algorithmic_bytes': int(bytes_alg), 'tflops': round(flops / (ms * 1e-3) / 1e12, 2),

@@ -542,7 +542,12 @@ extern "C" int tcct_pwf_wgrad(const float* x, const float* dy, float* dw, float*
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_pwf_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     const int64_t tiles = (M + 127) / 128;
     const int gy = (K / 32 + PF_KTB - 1) / PF_KTB;
-    int64_t gx = 256 / gy;
+    // no register prefetch in this kernel: several resident blocks per CU hide the load latency instead (48 KB of LDS at N = 32: three per CU;
+    // one block per CU left the level-0 32 -> 32 weight gradient at 2.1 ms for 0.13 ms of MFMA work)
+    int per_cu = (int)((160 * 1024) / (lds + 1024));
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    int64_t gx = 256 * per_cu / gy;
     if (gx < 32) gx = 32;
     if (gx > (tiles + 7) / 8) gx = (tiles + 7) / 8;        // >= 8 tiles per block: every block ends with same-address atomics on all of dw
     if (gx < 1) gx = 1;
