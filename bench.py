@@ -150,6 +150,36 @@ def dominant_kernel_roofline(a, iters=20):
         b5 = 3.0 * x1.numel() * 2
         others.append({'kernel': 'k_pw_bwd<2,4> (64->64 @L1; dx + dW + db in one pass)', 'ms_per_launch': round(t5, 4), 'algorithmic_bytes': int(b5),
                        'achieved': round(b5 / (t5 * 1e-3) / 1e9, 1), 'frac': round(b5 / (t5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+    if a.dtype == 'bf16' and ('fpl' in a.los or 'udh' in a.los or 'reg' in a.los):
+        # the loss-side kernels of BASELINE configs[2..3] (algorithmic bytes = inputs read once + outputs written once)
+        def entry(kernel, t, nbytes):
+            others.append({'kernel': kernel, 'ms_per_launch': round(t, 4), 'algorithmic_bytes': int(nbytes), 'achieved': round(nbytes / (t * 1e-3) / 1e9, 1),
+                           'frac': round(nbytes / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        B_, H_ = a.bs, a.height
+        if 'reg' in a.los:
+            xg = torch.randn((B_, H_, Wp, 4), device='cuda'); eg = torch.rand((B_, H_, Wp, 4), device='cuda')
+            og = torch.empty((B_, H_, Wp), device='cuda'); sg = torch.empty((B_ * Wp * 4, 3), device='cuda')
+            tg = timed(lambda: lib.gumbel_colsoftmax_fwd(xg, eg, og, sg, B_, H_, Wp, 4))
+            entry('k_gumbel_fwd<4> (sampling softmax over H + channel sum, fp32 [8,800,1104,4]; reads x and eps, three passes with recomputation)', tg,
+                  4.0 * (2 * xg.numel() + og.numel()))
+            del xg, eg, og, sg
+        if 'fpl' in a.los or 'udh' in a.los:
+            g1 = torch.randn((B_, H_ // 2, Wp // 2, 32), device='cuda').to(dt); g2 = torch.randn((B_, H_ // 4, Wp // 4, 32), device='cuda').to(dt)
+            i1 = torch.empty(g1.numel() // 32, device='cuda'); i2 = torch.empty(g2.numel() // 32, device='cuda')
+            tn = timed(lambda: lib.normadd_fwd(x, g1, g2, i1, i2, y, B_, H_, Wp, 32, H_ // 2, Wp // 2, H_ // 4, Wp // 4, 1e-12, 1))
+            entry('k_normadd_fwd<bf16> (+ 2 x k_invnorm): feats = mean of the three L2-normalised, resized decoder maps', tn,
+                  2.0 * (2 * x.numel() + g1.numel() + g2.numel()))
+            Mf = B_ * H_ * Wp
+            labf = torch.randint(0, 5, (Mf,), device='cuda', dtype=torch.uint8)
+            labf = torch.sort(labf.view(B_, H_, Wp), dim=1).values.contiguous().view(-1)          # layered labels, as B-scans have
+            probf = torch.rand(Mf, device='cuda') * 0.1 + 0.15                                     # ~1/C everywhere: the freshly initialised network of the bench
+            ws = torch.empty(int(lib.fpl_select_workspace_bytes()), device='cuda', dtype=torch.uint8)
+            cnt = torch.empty(16, device='cuda', dtype=torch.int32); bm = torch.empty(Mf, device='cuda', dtype=torch.uint8)
+            ps = torch.empty((5, 32, 32), device='cuda')
+            tf_ = timed(lambda: lib.fpl_select(x, labf, probf, Mf, 5, ws, cnt, bm, ps, 1))
+            entry('tcct_fpl_select: radix multi-select of the bin boundaries (k_fs_hist x 13, k_fs_resolve x 7, k_fs_assign) + bin sums on MFMA (k_fs_binsum_mfma); '
+                  'replaces rocPRIM radix_sort_pairs + the sorted gather', tf_, 2.0 * x.numel() + Mf * (1 + 4 + 1))
+            del g1, g2, i1, i2, labf, probf, ws, cnt, bm, ps
     bytes_alg = 2.0 * x.numel() * x.element_size()
     ach, ach2 = bytes_alg / (ms * 1e-3) / 1e9, bytes_alg / (ms2 * 1e-3) / 1e9
     flops = 2.0 * 9 * 32 * 32 * a.bs * a.height * Wp

@@ -12,12 +12,17 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -o write -- 
 # MFMA utilisation of the same loops (secondary evidence): busy cycles of the matrix pipes vs the GPU-active cycles
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_mfma -o mfma -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $OUT/${TAG}_mfma.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/${TAG}_sq -o sq -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only > $OUT/${TAG}_sq.log 2>&1
+# the loss-side kernels of BASELINE configs[2..3] (gumbel column softmax, norm_add, the FPL multi-select): durations + HBM traffic of the same loops
+TCCT_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stepfl -o stepfl -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --los=di+reg+fpl > $OUT/${TAG}_stepfl.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_lroof -o lroof -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only --los=di+reg+fpl > $OUT/${TAG}_lroof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_lfetch -o lfetch -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only --los=di+reg+fpl > $OUT/${TAG}_lfetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_lwrite -o lwrite -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only --los=di+reg+fpl > $OUT/${TAG}_lwrite.log 2>&1
 cd $GRAFT_REPO_ROOT
 python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-roofline --los=di+reg+fpl > $OUT/${TAG}_bench_fullloss.json 2>> $OUT/${TAG}_bench.err
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --dtype fp32 > $OUT/${TAG}_bench_fp32.json 2>> $OUT/${TAG}_bench.err
+python bench.py --steps 30 --warmup 10 --no-cpu-baseline --los=di+reg+fpl > $OUT/${TAG}_bench_fullloss.json 2>> $OUT/${TAG}_bench.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --dtype fp32 > $OUT/${TAG}_bench_fp32.json 2>> $OUT/${TAG}_bench.err
 python tools/infer_bench.py > $OUT/${TAG}_infer.txt 2>> $OUT/${TAG}_bench.err
 python tools/infer_bench.py --bs 1 >> $OUT/${TAG}_infer.txt 2>> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
 # keep only the small summaries
-find $OUT/${TAG}_step $OUT/${TAG}_roof $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_mfma $OUT/${TAG}_sq -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null
+find $OUT/${TAG}_step $OUT/${TAG}_stepfl $OUT/${TAG}_roof $OUT/${TAG}_lroof $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_lfetch $OUT/${TAG}_lwrite $OUT/${TAG}_mfma $OUT/${TAG}_sq -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null

@@ -87,6 +87,34 @@ if mf:
             wc = q.get('SQ_WAVE_CYCLES', 0.0)
             pct = lambda v: f'{100 * v / wc:.1f}' if wc else '-'
             L.append(f'| `{r["Name"].split("(")[0]}` | {busy:.3g} | {act:.3g} | {100 * busy / (act / 8 * 1024) if act else 0:.1f} | {pct(q.get("SQ_WAIT_ANY", 0))} | {pct(q.get("SQ_WAIT_INST_ANY", 0))} | {pct(q.get("SQ_ACTIVE_INST_ANY", 0))} |')
+# ---- loss-side kernels (BASELINE configs[2..3]): single-stream trace of the --los=di+reg+fpl step + the roofline loops of the same kernels
+if os.path.exists(f'{G}/{tag}_stepfl/stepfl_kernel_stats.csv'):
+    shutil.copy(f'{G}/{tag}_stepfl/stepfl_kernel_stats.csv', f'{P}/{tag}_fullloss_kernel_stats.csv')
+    sfl = list(csv.DictReader(open(f'{G}/{tag}_stepfl/stepfl_kernel_stats.csv')))
+    base = {r['Name']: float(r['TotalDurationNs']) for r in step}
+    tfl = sum(float(r['TotalDurationNs']) for r in sfl)
+    L.append(f'\n## `--los=di+reg+fpl` (BASELINE configs[3]) — single-stream kernel trace, {tfl / 1e6 / nsteps:.2f} ms/step (+{(tfl - tot) / 1e6 / nsteps:.2f} over `--los=di`); the kernels that only this configuration runs\n')
+    L.append('| kernel | calls / step | ms / step |\n|---|---|---|')
+    extra = sorted(((float(r['TotalDurationNs']) - base.get(r['Name'], 0.0), r) for r in sfl), key=lambda t: -t[0])
+    for d, r in extra[:16]:
+        if d > 0.02e6 * nsteps:
+            L.append(f'| `{r["Name"].split("(")[0][:80]}` | {int(r["Calls"]) // nsteps} | {d / 1e6 / nsteps:.3f} |')
+    L.append(f'\nrocPRIM symbols in this trace: {sum(1 for r in sfl if "rocprim" in r["Name"])} (the library sort is gone from the default path; `TCCT_FPL_SORT=1` restores it).')
+if os.path.exists(f'{G}/{tag}_lroof/lroof_kernel_stats.csv'):
+    lroof = list(csv.DictReader(open(f'{G}/{tag}_lroof/lroof_kernel_stats.csv')))
+    lp = {}
+    for kind in ('lfetch', 'lwrite'):
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(f'{G}/{tag}_{kind}/{kind}_counter_collection.csv')):
+            d[r['Kernel_Name']].append(float(r['Counter_Value']))
+        lp[kind] = {k: sum(v) / len(v) for k, v in d.items()}
+    L.append('\n### loss-side kernels alone — `bench.py --roofline-only --los=di+reg+fpl` under `--kernel-trace --stats`, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`\n')
+    L.append('| kernel | calls | avg us | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM MB / launch (2 x fetch + write) |\n|---|---|---|---|---|---|')
+    for r in lroof:
+        if re.search(r'k_gumbel|k_normadd|k_invnorm|k_fs_', r['Name']):
+            f, w = lp['lfetch'].get(r['Name'], 0.0), lp['lwrite'].get(r['Name'], 0.0)
+            L.append(f'| `{r["Name"].split("(")[0][:60]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e3:.1f} | {f:.1f} | {w:.1f} | {(2 * f + w) * 1024 / 1e6:.1f} |')
+    L.append(f'\nbench.py `roofline.others` of the full-loss line: {[(o["kernel"][:40], o["ms_per_launch"], o["frac"]) for o in bf.get("roofline", {}).get("others", [])]}')
 L.append(f'\nbench.py\'s own HIP-event timing of the same loops (un-profiled run): `roofline.ms_per_launch` = {b["roofline"]["ms_per_launch"]} ms '
          f'({b["roofline"]["achieved"]} GB/s algorithmic, frac {b["roofline"]["frac"]}), second = {b["roofline"]["second"]["ms_per_launch"]} ms, '
          f'others = {[(o["kernel"], o["ms_per_launch"]) for o in b["roofline"].get("others", [])]}.')
