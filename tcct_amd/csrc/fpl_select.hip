@@ -282,6 +282,7 @@ __global__ void __launch_bounds__(256) k_fs_binsum_mfma(const bf16* __restrict__
                                                         int64_t M, int C, float* __restrict__ pro_sum) {
     __shared__ __attribute__((aligned(16))) unsigned char sX[128 * 64];      // 128 pixels x 32 channels bf16, linear rows
     __shared__ __attribute__((aligned(16))) unsigned short sI[128];          // id = class * 32 + bin of the pixel, 0xffff: none
+    __shared__ uint32_t sMask[2];                                             // classes present in the tile (double-buffered by tile parity)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     fs_f32x16 acc[4];
@@ -292,9 +293,12 @@ __global__ void __launch_bounds__(256) k_fs_binsum_mfma(const bf16* __restrict__
     const int li = lane & 15, lq = li >> 2, lpp = li & 3, lg = lane >> 4;
     const unsigned char* lbX = sX + (8 * (lg >> 1) + lq) * 64 + (16 * (lg & 1) + 4 * lpp) * 2;
     const int64_t tiles = (M + 127) / 128;
-    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    int par = 0;
+    if (tid < 2) sMask[tid] = 0u;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x, par ^= 1) {
         const int64_t p0 = tile * 128;
         __syncthreads();
+        if (tid == 0) sMask[par ^ 1] = 0u;                  // the other buffer: read by nobody any more, written from the next tile on
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int q = tid + j * 256;                    // 16-byte chunk q of the tile's contiguous 8 KB: pixel q / 4, chunk q % 4
@@ -309,8 +313,18 @@ __global__ void __launch_bounds__(256) k_fs_binsum_mfma(const bf16* __restrict__
                 if (c < C && b < FS_BINS) id = (unsigned short)(c * FS_BINS + b);
             }
             sI[tid] = id;
+            // 128 consecutive pixels are a piece of ONE image row and the layers are horizontal bands: a tile usually holds one or two classes, and a
+            // wave skips the others (8 compares + an MFMA per class and 16-pixel step otherwise: the kernel was VALU-bound on building indicators)
+            const unsigned long long any = __ballot(id != 0xffffu);
+            if (any) {
+                uint32_t m = id != 0xffffu ? 1u << (id >> 5) : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o, 64);
+                if ((tid & 63) == 0) atomicOr(&sMask[par], m);
+            }
         }
         __syncthreads();
+        const uint32_t present = sMask[par];
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch) {
             const unsigned char* pb = lbX + ch * 16 * 64;
@@ -322,7 +336,7 @@ __global__ void __launch_bounds__(256) k_fs_binsum_mfma(const bf16* __restrict__
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int cls = wave + 4 * t;
-                if (cls < C) {                          // wave-uniform
+                if (cls < C && ((present >> cls) & 1u)) {       // wave-uniform
                     const uint32_t want = (uint32_t)(cls * FS_BINS + r);
                     fs_s16x8 a;
 #pragma unroll

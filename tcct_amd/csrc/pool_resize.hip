@@ -13,6 +13,11 @@
 // res / scale (both nullable): forward y = res + scale[b] * (box(x) - x) -- the token-mixer branch of MHCABlock with its residual add
 // and DropPath scale folded in (reference nets/tcct.py:464-465); backward dx = scale[b] * (box^T(dy) - dy) (the residual itself
 // passes dy through unchanged).
+// Round 3: marching window.  A thread owns a channel vector and a STRIP of consecutive tokens, keeps the weighted rows n-1, n, n+1 in registers
+// and loads every row once (the first version loaded the three rows of every token afresh -- L1 hits, but three requests per element: 0.20 ms
+// for the 452 MB of stage 0, 2.3 TB/s).  All lanes of a wave run the same trip count (tokens beyond N load nothing and store nothing), so the
+// lane shuffles that fetch the channel neighbours stay convergent.
+#define MP_STRIP 32
 template <typename T, bool BWD>
 __global__ void k_metapool(const T* __restrict__ x, T* __restrict__ y, int B, int N, int C, const T* __restrict__ res,
                            const float* __restrict__ scale) {
@@ -31,43 +36,48 @@ __global__ void k_metapool(const T* __restrict__ x, T* __restrict__ y, int B, in
     T* yb = y + (int64_t)blockIdx.y * N * C + c0;
     const T* rb = res ? res + (int64_t)blockIdx.y * N * C + c0 : nullptr;
     const float sc = scale ? scale[blockIdx.y] : 1.f;
-    for (int n = blockIdx.x * R + r; n < N; n += gridDim.x * R) {
-        const T* base = xb + (int64_t)n * C;
-        float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        f4 ctr = f4zero();
+    struct Row { float g[6]; f4 ctr; };
+    auto load_row = [&](int nn) {           // the six weighted values (left neighbour, 4 own channels, right neighbour) of token nn; zeros outside
+        Row o;
+        const bool in = nn >= 0 && nn < N;
+        const T* row = xb + (int64_t)(in ? nn : 0) * C;
+        f4 m = f4zero();
+        if (in) m = ld4(row);
+        const float ls = __shfl_up(m.v[3], 1, 64), rs = __shfl_down(m.v[0], 1, 64);
+        const float l = (hasl && in) ? (lane == 0 ? ldf(row - 1) : ls) : 0.f;
+        const float rr = (hasr && in) ? (lane == 63 ? ldf(row + 4) : rs) : 0.f;
+        float rw = 1.f;
+        if (BWD) { const int rn = 1 + (nn > 0) + (nn < N - 1); rw = 1.f / (float)rn; }
+        const float g[6] = {l, m.v[0], m.v[1], m.v[2], m.v[3], rr};
 #pragma unroll
-        for (int dn = -1; dn <= 1; ++dn) {
-            int nn = n + dn;
-            if (nn < 0 || nn >= N) continue;
-            const T* row = base + dn * C;
-            float rw = 1.f;
-            if (BWD) { int rn = 1 + (nn > 0) + (nn < N - 1); rw = 1.f / (float)rn; }
-            f4 m = ld4(row);
-            // channel neighbours c0-1 / c0+4 live in the adjacent lanes (same row): take them by shuffle; the first / last lane of a
-            // wave may have its neighbour in another wave (C/4 not a divisor of 64) and loads it instead
-            const float ls = __shfl_up(m.v[3], 1, 64), rs = __shfl_down(m.v[0], 1, 64);
-            float l = hasl ? (lane == 0 ? ldf(row - 1) : ls) : 0.f;
-            float rr = hasr ? (lane == 63 ? ldf(row + 4) : rs) : 0.f;
-            if (dn == 0) ctr = m;
-            float g[6] = {l, m.v[0], m.v[1], m.v[2], m.v[3], rr};
-#pragma unroll
-            for (int j = 0; j < 6; ++j) v[j] += g[j] * (BWD ? rw * cs[j] : 1.f);
-        }
+        for (int j = 0; j < 6; ++j) o.g[j] = in ? g[j] * (BWD ? rw * cs[j] : 1.f) : 0.f;
+        o.ctr = m;
+        return o;
+    };
+    const int n0 = (blockIdx.x * R + r) * MP_STRIP;
+    Row prev = load_row(n0 - 1), cur = load_row(n0);
+    for (int i = 0; i < MP_STRIP; ++i) {
+        const int n = n0 + i;
+        const Row nxt = load_row(n + 1);
         f4 o;
         const int rn = 1 + (n > 0) + (n < N - 1);
         const float rinv = 1.f / (float)rn;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float s = v[k] + v[k + 1] + v[k + 2];
-            if (!BWD) s *= rinv * cs[k];
-            o.v[k] = sc * (s - ctr.v[k]);
+            float s_ = (prev.g[k] + cur.g[k] + nxt.g[k]) + (prev.g[k + 1] + cur.g[k + 1] + nxt.g[k + 1]) + (prev.g[k + 2] + cur.g[k + 2] + nxt.g[k + 2]);
+            if (!BWD) s_ *= rinv * cs[k];
+            o.v[k] = sc * (s_ - cur.ctr.v[k]);
         }
-        if (rb) {
-            const f4 e = ld4(rb + (int64_t)n * C);
+        if (n < N) {
+            if (rb) {
+                const f4 e = ld4(rb + (int64_t)n * C);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o.v[k] += e.v[k];
+                for (int k = 0; k < 4; ++k) o.v[k] += e.v[k];
+            }
+            st4(yb + (int64_t)n * C, o);
         }
-        st4(yb + (int64_t)n * C, o);
+        prev = cur;
+        cur = nxt;
     }
 }
 static int metapool_launch(const void* x, void* y, int B, int64_t N, int C, int dtype, bool bwd, tcct_stream_t stream, const char* who,
@@ -75,7 +85,8 @@ static int metapool_launch(const void* x, void* y, int B, int64_t N, int C, int 
     if (!(C % 4 == 0 && C >= 4 && C / 4 <= PB)) { tcct_set_error("%s: C=%d", who, C); return -1; }
     if (!(B >= 1 && B <= 65535 && N >= 1 && N < (1LL << 30))) { tcct_set_error("%s: B=%d N=%lld out of range", who, B, (long long)N); return -1; }
     const int R = PB / (C / 4);
-    dim3 g((unsigned)tcct_grid(N, R, 4096), (unsigned)B);
+    const int64_t strips = (N + MP_STRIP - 1) / MP_STRIP;
+    dim3 g((unsigned)((strips + R - 1) / R), (unsigned)B);
     if (bwd) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_metapool<T, true>), g, dim3(PB), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, (int)N, C, (const T*)res, scale)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_metapool<T, false>), g, dim3(PB), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, (int)N, C, (const T*)res, scale)); }
     TCCT_LAUNCH_OK();
@@ -641,6 +652,7 @@ __global__ void k_invnorm(const T* __restrict__ x, float* __restrict__ inv, int6
         if (ok && (ii % LP) == 0) inv[ii / LP] = 1.f / fmaxf(sqrtf(ss), eps);
     }
 }
+#define NA_ROWS 8
 template <typename T>
 __global__ void k_normadd_fwd(const T* __restrict__ g0, const T* __restrict__ g1, const T* __restrict__ g2, const float* __restrict__ inv1,
                               const float* __restrict__ inv2, T* __restrict__ out, int N, int H, int W, int C, int h1, int w1, int h2, int w2,
@@ -650,7 +662,10 @@ __global__ void k_normadd_fwd(const T* __restrict__ g0, const T* __restrict__ g1
     const bool ok = i < W * LP;
     const int wo = ok ? i / LP : 0, c = ok ? (i - wo * LP) * 4 : 0;
     const Lerp b1 = src_index(wo, (float)w1 / (float)W, w1, 0), b2 = src_index(wo, (float)w2 / (float)W, w2, 0);
-    for (int row = blockIdx.y; row < N * H; row += gridDim.y) {
+    // a block walks a BAND of NA_ROWS consecutive output rows: the two coarse maps contribute 2 + 2 source rows to every output row, and with
+    // neighbouring rows spread over blocks on different XCDs those re-reads went to HBM (PMC: 1 805 MB moved for 1 045 MB algorithmic)
+    for (int row0 = blockIdx.y * NA_ROWS; row0 < N * H; row0 += gridDim.y * NA_ROWS)
+    for (int row = row0; row < min(row0 + NA_ROWS, N * H); ++row) {
         const int n = row / H, ho = row - n * H;
         const f4 v = ld4(g0 + ((int64_t)row * W + wo) * C + c);
         float ss = v.v[0] * v.v[0] + v.v[1] * v.v[1] + v.v[2] * v.v[2] + v.v[3] * v.v[3];
@@ -688,6 +703,6 @@ extern "C" int tcct_normadd_fwd(const void* g0, const void* g1, const void* g2, 
     hipStream_t st = (hipStream_t)stream;
     TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_invnorm<T>, dim3(tcct_grid((int64_t)N * h1 * w1 * LP, PB, 1 << 16)), dim3(PB), 0, st, (const T*)g1, inv1, (int64_t)N * h1 * w1, C, eps));
     TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_invnorm<T>, dim3(tcct_grid((int64_t)N * h2 * w2 * LP, PB, 1 << 16)), dim3(PB), 0, st, (const T*)g2, inv2, (int64_t)N * h2 * w2, C, eps));
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_normadd_fwd<T>, row_grid(W * LP, (int64_t)N * H, 8192), dim3(PB), 0, st, (const T*)g0, (const T*)g1, (const T*)g2, inv1, inv2, (T*)out, N, H, W, C, h1, w1, h2, w2, eps));
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_normadd_fwd<T>, row_grid(W * LP, ((int64_t)N * H + NA_ROWS - 1) / NA_ROWS, 8192), dim3(PB), 0, st, (const T*)g0, (const T*)g1, (const T*)g2, inv1, inv2, (T*)out, N, H, W, C, h1, w1, h2, w2, eps));
     TCCT_LAUNCH_OK();
 }
