@@ -539,6 +539,26 @@ def test_real_checkpoint_inference_matches_reference(name, dtype):
     assert len(np.unique(masks[0])) >= 4            # a real multi-layer segmentation, not a constant map
 
 
+def test_onnx_export_of_the_gpu_model_equals_its_hip_eval_forward(tmp_path):
+    """reference task1/onnx/onnx_save.py:4-15: the model object that lives on the GPU is exported, the file evaluated by the test-side ONNX
+    reader (tests/onnx_mini_runtime.py, torch CPU) -- equal to the HIP eval forward of the same model on a non-square batch"""
+    sys.path.insert(0, HERE)
+    import onnx_mini_runtime as R
+    import tcct_oracle as O
+    from tcct_amd.onnx_export import export_onnx
+    model, _ = build()
+    model.eval()
+    path = str(tmp_path / 'net.onnx')
+    export_onnx(model, path)
+    img, _ = O.synth_batch(2, 64, 96, seed=11)
+    with torch.no_grad():
+        outs = model(img.cuda())
+    got = R.run(R.load(path), {'input': img.numpy()})
+    for a, b in zip(outs, got):
+        a = a.float().cpu().numpy()
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-3 * max(1.0, np.abs(b).max())
+
+
 def test_trained_weights_train_step_matches_reference(tmp_path):
     """The WELL-CONDITIONED reference-held fixture (oracle/make_golden_duke_train.py): the reference's real trained checkpoint
     (task1/onnx/tcct_duke.pt, 9 classes, bf16-rounded as in ckpt_duke.npz) in the real RegNet(stc_tt(9)), TRAIN mode, two 160x160 crops of

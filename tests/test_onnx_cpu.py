@@ -1,0 +1,96 @@
+"""ONNX export (reference task1/onnx/onnx_save.py:4-15 + onnx_infer.py:13-30).  No onnx / onnxruntime in this image: the file
+is read back and evaluated by tests/onnx_mini_runtime.py (an independent wire-format decoder + the opset-11 operator semantics on torch CPU)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '..', 'oracle'))
+sys.path.insert(0, HERE)
+GOLD = os.path.join(HERE, 'golden')
+
+
+def _duke_state_dict():
+    ck = np.load(os.path.join(GOLD, 'ckpt_duke.npz'))
+    sd = {}
+    for k in ck.files:
+        if k.startswith('w::'):
+            sd[k[3:]] = torch.from_numpy(ck[k].view(np.int16).copy()).view(torch.bfloat16).float()
+        elif k.startswith('i::'):
+            sd[k[3:]] = torch.from_numpy(ck[k].copy())
+    return sd, ck
+
+
+def test_export_of_the_reference_checkpoint_reproduces_the_reference_logits(tmp_path):
+    """the reference's real trained Duke model (task1/onnx/tcct_duke.pt, bf16-rounded in ckpt_duke.npz) exported, read back, run on the
+    crop onnx_infer.py uses: `session.run(None, {'input': img})[0]` equals the logits the REAL reference computed for the same weights
+    (fixture `logits0`, oracle/make_golden_ckpt.py) and the masks its `predict` made of them"""
+    import onnx_mini_runtime as R
+    from tcct_amd.onnx_export import export_onnx
+    sd, ck = _duke_state_dict()
+    path = str(tmp_path / 'tcct_duke.onnx')
+    names = export_onnx(sd, path)
+    assert names[0] == 'output'
+    m = R.load(path)
+    g = m['graph']
+    assert [i['name'] for i in g['input']] == ['input'] and [o['name'] for o in g['output']] == names
+    dims = [d.get('dim_param', d.get('dim_value')) for d in g['input'][0]['type']['tensor_type']['shape']['dim']]
+    assert dims == ['batch', 3, 'height', 'width']                                   # the reference's dynamic_axes
+    odims = [d.get('dim_param', d.get('dim_value')) for d in g['output'][0]['type']['tensor_type']['shape']['dim']]
+    assert odims == ['batch', 9, 'height', 'width']
+    img = ck['input_u8'].transpose(2, 0, 1).reshape(1, 3, 160, 160).astype(np.float32) / 255      # onnx_infer.py:19-21
+    outs = R.run(m, {'input': img})
+    assert len(outs) == 4 and all(o.shape == (1, 9, 160, 160) for o in outs)
+    ref = ck['logits0']
+    err = np.abs(outs[0][0] - ref).max() / np.abs(ref).max()
+    assert err <= 1e-4, err
+    for i in range(4):                            # all four heads: the masks the reference's own predict made (softmax + argmax)
+        assert (outs[i][0].argmax(0) == ck['masks'][i]).mean() >= 0.9995, i
+
+
+def test_export_equals_the_oracle_on_other_shapes(tmp_path):
+    """dynamic batch / height / width: formula weights, 5 classes, a 2 x 3 x 48 x 80 batch -- all four outputs equal the oracle's eval forward"""
+    import onnx_mini_runtime as R
+    import tcct_oracle as O
+    from tcct_amd.onnx_export import export_onnx
+    sd = O.formula_state_dict([(k, tuple(s)) for k, s in json.load(open(os.path.join(GOLD, 'state_dict_keys.json')))])
+    path = str(tmp_path / 'net.onnx')
+    export_onnx(sd, path)
+    m = R.load(path)
+    img, _ = O.synth_batch(2, 48, 80, seed=5)
+    with torch.no_grad():
+        want, _ = O.ftc_forward({k: v.clone() for k, v in sd.items()}, img, train=False)
+    outs = R.run(m, {'input': img.numpy()})
+    for a, b in zip(outs, want):
+        b = b.numpy()
+        assert a.shape == b.shape
+        assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
+
+
+def test_export_from_a_model_object_and_loud_errors(tmp_path):
+    """`export_onnx(model, path)` takes the RegNet itself (any compute dtype) like the reference's to_onnx(net, ...); layouts that are not
+    exported fail loudly instead of writing a wrong graph"""
+    import onnx_mini_runtime as R
+    from tcct_amd.onnx_export import export_onnx
+    from tcct_amd.nets import stc_tt, RegNet
+    from tcct_amd._lib import TcctError
+    net = RegNet(stc_tt(5, compute_dtype=torch.bfloat16), out_channels=5)
+    path = str(tmp_path / 'm.onnx')
+    export_onnx(net, path)
+    m = R.load(path)
+    ops = {n['op_type'] for n in m['graph']['node']}
+    assert {'Conv', 'BatchNormalization', 'AveragePool', 'Resize', 'MatMul', 'Erf', 'HardSigmoid'} <= ops
+    assert m['opset_import'][0]['version'] == 11 and m['ir_version'] == 6
+    n_w = sum(int(np.prod(t['dims'])) for t in m['graph']['initializer'] if t['data_type'] == 1)
+    dead = ('.crpe.', '.cls_head.', 'base.fuse.', '.MHCA_layers.0.cpe.')               # parameters the reference's forward never reads / aliases
+    n_p = sum(v.numel() for k, v in net.state_dict().items() if k.startswith('base.') and v.is_floating_point()
+              and not any(d in k for d in dead))
+    assert abs(n_w - n_p) < 64                                                        # every live base.* tensor once (+ a few scalar constants)
+    with pytest.raises(TcctError):
+        export_onnx(RegNet(stc_tt(5, legacy_heads=True), out_channels=5), path)
+    with pytest.raises(TcctError):
+        export_onnx(net, path, in_channels=1)
