@@ -66,10 +66,14 @@ __device__ __forceinline__ f4 ld4(const bf16* p) {
 __device__ __forceinline__ void st4(float* p, const f4& a) {
     *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
 }
+// two fp32 -> one dword of two bf16 (round to nearest even): ONE `v_cvt_pk_bf16_f32` on gfx950.  The earlier form (two __float2bfloat16 and
+// shift / or by hand) compiled to two converts + lshl + and + or3 per dword: 5 VALU instructions where 1 does, in the epilogue of every
+// bf16-storing kernel (the MFMA convolutions issue VALU and MFMA through the same port: 160 of ~600 epilogue instructions per tile).
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    bf16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
-    return (uint32_t)(*reinterpret_cast<unsigned short*>(&a)) |
-           ((uint32_t)(*reinterpret_cast<unsigned short*>(&b)) << 16);
+    const f32x2_hw v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw));
 }
 __device__ __forceinline__ void st4(bf16* p, const f4& a) {
     uint2 t; t.x = pack_bf16x2(a.v[0], a.v[1]); t.y = pack_bf16x2(a.v[2], a.v[3]);

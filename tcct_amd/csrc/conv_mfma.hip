@@ -75,6 +75,43 @@ extern "C" int tcct_conv32_pack_weights_sub(const float* w, void* wp, int KH, in
 // Staging is software-pipelined across tiles: every thread owns up to MAXL fixed 16-byte slots of the LDS image (slot
 // geometry precomputed once), issues ALL its global loads for the NEXT tile into registers before the MFMA phase of the
 // current tile (one memory latency per tile instead of one per slot), and writes them to LDS after the barrier.
+// Tile order of the persistent convolution kernels.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own
+// 4 MB L2, so with the plain `tile = b + k * grid` walk the eight neighbours of a tile -- whose halos are the SAME pixels -- are
+// staged by eight different L2s at about the same time: the halo (1.195x for 16 x 32 tiles of a 3x3, 1.19x for 8 x 64 of a 1x13)
+// crossed the fabric once per reader (PMC: 1.26x the algorithmic reads).  Here XCD x owns the contiguous eighth [x*Q, (x+1)*Q) of a
+// tile SEQUENCE, its grid/8 resident blocks take consecutive sequence numbers per round, and the sequence walks the image in strips
+// of 8 tiles (column strips, row-major inside, for the horizontal / square tiles; row strips, column-major inside, for the 64 x 8
+// tiles of the k x 1 kernels): the 64 tiles an XCD has in flight form one 8 x 8 patch whose inner halos are L2 hits, and the next
+// round continues right below (beside) it.  Everything here is block-uniform (scalar unit).
+template <bool ROWSTRIP>
+struct TileSeq {
+    int base, loc, nl, Q, nt, tH, tW, per_img;
+    __device__ __forceinline__ TileSeq(int ntiles, int tilesH, int tilesW) {
+        nt = ntiles; tH = tilesH; tW = tilesW; per_img = tilesH * tilesW;
+        const int g = gridDim.x, b = blockIdx.x;
+        if ((g & 7) == 0) { nl = g >> 3; loc = b >> 3; Q = (ntiles + 7) >> 3; base = (b & 7) * Q; }
+        else { nl = g; loc = b; Q = ntiles; base = 0; }
+    }
+    // k-th tile of this block as the linear id (n * tilesH + th) * tilesW + tw, or -1 behind the end
+    __device__ __forceinline__ int at(int k) const {
+        const int q = k * nl + loc, seq = base + q;
+        if (q >= Q || seq >= nt) return -1;
+        const int n = seq / per_img, rem = seq - n * per_img;
+        const int L = ROWSTRIP ? tW : tH;               // strip length (tiles), strips are 8 tiles wide across the other axis
+        const int X = ROWSTRIP ? tH : tW;
+        const int full = X >> 3, A = L << 3;
+        int along, across;
+        if (rem >= full * A) {
+            const int wr = X - (full << 3), r2 = rem - full * A;
+            along = r2 / wr; across = (full << 3) + (r2 - along * wr);
+        } else {
+            const int sidx = rem / A, r2 = rem - sidx * A;
+            along = r2 >> 3; across = (sidx << 3) + (r2 & 7);
+        }
+        const int th = ROWSTRIP ? across : along, tw = ROWSTRIP ? along : across;
+        return (n * tH + th) * tW + tw;
+    }
+};
 #define MAXL 11
 #define IPS 80      // LDS bytes per image pixel: 64 B of channels + 16 B pad => conflict-free ds_read_b128 with LINEAR addressing
 // An ablation of the first version showed the kernel was instruction-bound, not memory-bound: with loads, stores and MFMAs all
@@ -99,6 +136,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
     // (4 x 128 / 128 x 4 tiles for the long 1-D kernels, halo 1.09x instead of 1.19x, measured the same as 8 x 64 / 64 x 8)
     constexpr bool SQ = !VERT && KH_ == 3 && KW_ == 3;
     constexpr int SEGS = SQ ? 1 : 2;                 // 32-pixel segments per tile row (HORZ) / tile column (VERT)
+    constexpr bool WIDE = SQ || (KH_ * KW_ >= 1 && KH_ * KW_ <= 11);      // epilogue scratch of 2 KB per wave (does not fit next to 13 taps + the 8 x 76 image)
     constexpr int TH = VERT ? 32 * SEGS : 16 / SEGS, TW = VERT ? 16 / SEGS : 32 * SEGS;
     const int KH = KH_ ? KH_ : KHr, KW = KH_ ? KW_ : KWr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -119,7 +157,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
     float* sB = reinterpret_cast<float*>(sX + LH * LW * IPS);
     if (tid < 32) sB[tid] = bias ? bias[tid] : 0.f;
     if (STATS == 4 && tid < 64) sB[32 + tid] = aff ? aff[tid] : (tid < 32 ? 1.f : 0.f);     // a[32], b[32] of the folded BatchNorm
-    unsigned char* sS = reinterpret_cast<unsigned char*>(sB + 96);          // epilogue transpose scratch: 4 waves x 1 KB
+    unsigned char* sS = reinterpret_cast<unsigned char*>(sB + 96);          // epilogue transpose scratch: 4 waves x 1 KB (2 KB: WIDE)
 
     // slot geometry (tile independent): slot j covers 16-byte chunk c of tile-local pixel (lr, lc); (lr,lc) packed in one int
     const int c = tid & 3;
@@ -151,7 +189,10 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
             const uint32_t base = (uint32_t)((hb * W + wb) * xs * 2 + c * 16), xs2 = (uint32_t)xs * 2u;
 #pragma unroll
             for (int j = 0; j < MAXL; ++j) {        // unused slots (lr = 0x3fff) land far beyond the image: out of range by construction
-                const uint32_t lr = (uint32_t)(s_rc[j] >> 16), lc = (uint32_t)(s_rc[j] & 0xffff);
+                int rc = s_rc[j];
+                asm volatile("" : "+v"(rc));        // opaque: or the per-slot offsets are hoisted out of the tile loop (11 more live VGPRs -> spills,
+                                                    // and a scratch reload waits with vmcnt(0), i.e. for the very loads issued just before it)
+                const uint32_t lr = (uint32_t)(rc >> 16), lc = (uint32_t)(rc & 0xffff);
                 pre[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lr == 0x3fffu ? OOB_OFF : base + (lr * (uint32_t)W + lc) * xs2, 0, 0);
             }
         } else {
@@ -167,7 +208,9 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
     auto stage = [&]() {        // registers of the prefetched tile -> LDS image
 #pragma unroll
         for (int j = 0; j < MAXL; ++j) {
-            const int lr = s_rc[j] >> 16, lc = s_rc[j] & 0xffff;
+            int rc = s_rc[j];
+            asm volatile("" : "+v"(rc));            // opaque, see prefetch(): recompute the LDS address instead of keeping 11 of them live
+            const int lr = rc >> 16, lc = rc & 0xffff;
             if (lr != 0x3fff) *reinterpret_cast<u32x4*>(sX + (VERT ? lc * LH + lr : lr * LW + lc) * IPS + c * 16) = pre[j];
         }
     };
@@ -190,26 +233,35 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
     //     MFMA(t) | barrier | registers of t+1 -> LDS | issue loads of t+2 | epilogue(t): stores | barrier | MFMA(t+1) ...
     // The wait for the loads of t+1 sits directly behind an MFMA phase: everything still in flight there (those loads, the stores
     // of t-1) was issued at least one whole MFMA phase earlier.  In the first version the wait followed the stores of the SAME tile.
-    int tile = blockIdx.x;
-    if (tile < ntiles) {
+    const TileSeq<VERT> seq(ntiles, tilesH, tilesW);
+    int tile = seq.at(0), tile1 = seq.at(1), tile2 = -1;
+    if (tile >= 0) {
         prefetch(tile);
         __syncthreads();        // weights / bias staged
         stage();
-        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        if (tile1 >= 0) prefetch(tile1);
     }
     __syncthreads();
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (int kt = 0; tile >= 0; tile = tile1, tile1 = tile2, ++kt) {
+        tile2 = seq.at(kt + 2);
         const int tw = tile % tilesW;
         const int t2 = tile / tilesW;
         const int th = t2 % tilesH;
         const int n = t2 / tilesH;
         const int h0 = th * TH, w0 = tw * TW;
 
+        // the accumulators start at the bias of this lane's 16 output channels (four LDS reads, one wait per tile): the epilogue --
+        // where the registers are scarce -- has no bias arithmetic left
         f32x16 acc[4];
+        {
+            float4 bq[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(sB + 8 * q + 4 * hh);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { acc[t][4 * q] = bq[q].x; acc[t][4 * q + 1] = bq[q].y; acc[t][4 * q + 2] = bq[q].z; acc[t][4 * q + 3] = bq[q].w; }
+        }
         // Fragment reads are software-pipelined one stage (= half a tap: 16 of the 32 input channels, 4 MFMAs) ahead of the MFMAs
         // that consume them: left to itself hipcc emits `ds_read; s_waitcnt lgkmcnt(0); v_mfma` per MFMA, exposing the full LDS
         // latency 72 times per tile.  Half-tap stages keep the double buffer at 2 x 20 VGPRs (whole taps: 2 x 40, which spilled
@@ -247,57 +299,50 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
                 }
         }
         __syncthreads();                                    // every wave has read its fragments: the image may be replaced
-        if (tile + (int)gridDim.x < ntiles) stage();
-        if (tile + 2 * (int)gridDim.x < ntiles) prefetch(tile + 2 * gridDim.x);
+        if (tile1 >= 0) stage();
+        if (tile2 >= 0) prefetch(tile2);
         // epilogue: lane owns pixel r of each M-tile and channels co = 8q + 4*hh + k.  The packed bf16 values go through a per-wave
-        // LDS transpose (16 pixels x 64 B per round, chunks XOR-swizzled) so that every lane stores 16 contiguous bytes and one
-        // wave instruction writes 16 whole pixels (1 KB contiguous for HORZ tiles) -- four 8-byte stores per lane, i.e. 16 B of
-        // every 64-B line per instruction, were the throughput limit of the store-heavy kernels.
+        // LDS transpose (chunks XOR-swizzled) so that every lane stores 16 contiguous bytes and one wave instruction writes 16 whole
+        // pixels (1 KB contiguous for HORZ tiles) -- four 8-byte stores per lane, i.e. 16 B of every 64-B line per instruction, were
+        // the throughput limit of the store-heavy kernels.
+        // The first version of this epilogue was one LDS round trip after the other: per M-tile four bias reads, each followed by
+        // `s_waitcnt lgkmcnt(0)` and a branch around the `accum` loads, then per 16-pixel round `4 writes; read; wait; store` under an
+        // exec-mask branch -- 24 exposed LDS latencies per tile and wave, as long as the whole MFMA phase.  Now: the bias is the initial
+        // value of the accumulators, the `accum` add as one block-uniform pre-pass, whole M-tiles per round
+        // where the LDS allows it (WIDE: 2 KB of scratch per wave, all lanes write, no exec masking), and the global store of a round
+        // is issued AFTER the pack arithmetic of the next one, which hides the round trip.
         const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (int64_t)n * H * W * ys + yo), 0, out_bytes, 0x00020000);
-        unsigned char* sc = sS + wave * 1024;
+        unsigned char* sc = sS + wave * (WIDE ? 2048 : 1024);
+        if (accum) {                                        // block-uniform: y = conv + bias + yadd
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            int mt = wave * 4 + t;
-            int a = mt / SEGS, seg = mt % SEGS;
-            uint2 o[4];
-            {
-                int ho = VERT ? h0 + seg * 32 + r : h0 + a;
-                int wo = VERT ? w0 + a : w0 + seg * 32 + r;
+            for (int t = 0; t < 4; ++t) {
+                const int mt = wave * 4 + t;
+                const int a = mt / SEGS, seg = mt % SEGS;
+                const int ho = VERT ? h0 + seg * 32 + r : h0 + a;
+                const int wo = VERT ? w0 + a : w0 + seg * 32 + r;
                 const bool inb = ho < H && wo < W;
                 const bf16* yold = (yadd ? yadd : y) + (((int64_t)n * H + (inb ? ho : 0)) * W + (inb ? wo : 0)) * ys + yo + 4 * hh;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 bq = *reinterpret_cast<const float4*>(sB + 8 * q + 4 * hh);
-                    float v0 = acc[t][4 * q] + bq.x, v1 = acc[t][4 * q + 1] + bq.y;
-                    float v2 = acc[t][4 * q + 2] + bq.z, v3 = acc[t][4 * q + 3] + bq.w;
-                    if (accum) { f4 old = ld4(yold + 8 * q); v0 += old.v[0]; v1 += old.v[1]; v2 += old.v[2]; v3 += old.v[3]; }
-                    if (STATS == 4) {
-                        const float4 aq = *reinterpret_cast<const float4*>(sB + 32 + 8 * q + 4 * hh);
-                        const float4 cq = *reinterpret_cast<const float4*>(sB + 64 + 8 * q + 4 * hh);
-                        float v4[4] = {v0, v1, v2, v3};
-                        const float a4[4] = {aq.x, aq.y, aq.z, aq.w}, b4[4] = {cq.x, cq.y, cq.z, cq.w};
-                        affine4(v4, a4, b4, stat_pre, aff_post);
-                        v0 = v4[0]; v1 = v4[1]; v2 = v4[2]; v3 = v4[3];
-                    }
-                    o[q].x = pack_bf16x2(v0, v1);
-                    o[q].y = pack_bf16x2(v2, v3);
+                    const f4 old = ld4(yold + 8 * q);
+                    acc[t][4 * q] += old.v[0]; acc[t][4 * q + 1] += old.v[1]; acc[t][4 * q + 2] += old.v[2]; acc[t][4 * q + 3] += old.v[3];
                 }
+                __builtin_amdgcn_sched_barrier(0);          // one M-tile's loads at a time (register pressure)
             }
+        }
+        constexpr int RND = WIDE ? 1 : 2, NPEND = WIDE ? 2 : 1;
+        u32x4 pend[NPEND];
+        auto flush = [&](int t, int h2) {       // global stores (+ statistics) of the round whose transposed chunks sit in pend[]
+            const int mt = wave * 4 + t;
+            const int a = mt / SEGS, seg = mt % SEGS;
+            const int p16 = lane >> 2, cch = lane & 3;
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                if ((r >> 4) == h2) {
-                    const int rr = r & 15, f = (rr >> 1) & 3;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(sc + rr * 64 + ((q ^ f) << 4) + hh * 8) = o[q];
-                }
-                // one wave writes and reads its own scratch: LDS operations of a wave complete in order (the fence is for the compiler)
-                wave_lds_fence();
-                const int p16 = lane >> 2, cch = lane & 3;
-                const u32x4 ov = *reinterpret_cast<const u32x4*>(sc + p16 * 64 + ((cch ^ ((p16 >> 1) & 3)) << 4));
-                const int pr = 16 * h2 + p16;                                   // pixel index inside the M-tile
+            for (int u = 0; u < NPEND; ++u) {
+                const int pr = 16 * (WIDE ? u : h2) + p16;                      // pixel index inside the M-tile
                 const int ho = VERT ? h0 + seg * 32 + pr : h0 + a;
                 const int wo = VERT ? w0 + a : w0 + seg * 32 + pr;
                 const bool inb = ho < H && wo < W;
+                const u32x4 ov = pend[u];
                 __builtin_amdgcn_raw_buffer_store_b128(ov, ws, inb ? (uint32_t)((ho * W + wo) * ys * 2 + cch * 16) : OOB_OFF, 0, 0);
                 if (STATS >= 1 && STATS <= 3) {
                     if (inb) {
@@ -305,15 +350,55 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             float u0 = __uint_as_float(wv[k] << 16), u1 = __uint_as_float(wv[k] & 0xffff0000u);
-                            if (STATS == 2) { u0 = u0 > 0.f ? u0 : 0.01f * u0; u1 = u1 > 0.f ? u1 : 0.01f * u1; }
+                            if (STATS == 2) { u0 = fmaxf(u0, 0.01f * u0); u1 = fmaxf(u1, 0.01f * u1); }      // LeakyReLU(u) == max(u, 0.01 u): mul + max instead of mul + cmp + select
                             else if (STATS == 3) { u0 = act_fwd(stat_pre, u0); u1 = act_fwd(stat_pre, u1); }
                             ss[2 * k] += u0; sq[2 * k] += u0 * u0; ss[2 * k + 1] += u1; sq[2 * k + 1] += u1 * u1;
                         }
                     }
                 }
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint2 o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v0 = acc[t][4 * q], v1 = acc[t][4 * q + 1], v2 = acc[t][4 * q + 2], v3 = acc[t][4 * q + 3];
+                if (STATS == 4) {
+                    const float4 aq = *reinterpret_cast<const float4*>(sB + 32 + 8 * q + 4 * hh);
+                    const float4 cq = *reinterpret_cast<const float4*>(sB + 64 + 8 * q + 4 * hh);
+                    float v4[4] = {v0, v1, v2, v3};
+                    const float a4[4] = {aq.x, aq.y, aq.z, aq.w}, b4[4] = {cq.x, cq.y, cq.z, cq.w};
+                    affine4(v4, a4, b4, stat_pre, aff_post);
+                    v0 = v4[0]; v1 = v4[1]; v2 = v4[2]; v3 = v4[3];
+                }
+                o[q].x = pack_bf16x2(v0, v1);
+                o[q].y = pack_bf16x2(v2, v3);
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < RND; ++h2) {
+                __builtin_amdgcn_sched_barrier(0);          // pack arithmetic above (behind the previous round's reads), stores below
+                if (t > 0 || h2 > 0) flush(h2 > 0 ? t : t - 1, h2 > 0 ? h2 - 1 : RND - 1);    // the previous round: its reads are long done
+                // one wave writes and reads its own scratch: LDS operations of a wave complete in order (the fences are for the compiler)
+                if (WIDE) {
+                    const int f = (r >> 1) & 3;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(sc + r * 64 + ((q ^ f) << 4) + hh * 8) = o[q];
+                } else if ((r >> 4) == h2) {
+                    const int rr = r & 15, f = (rr >> 1) & 3;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(sc + rr * 64 + ((q ^ f) << 4) + hh * 8) = o[q];
+                }
+                wave_lds_fence();
+                const int p16 = lane >> 2, cch = lane & 3;
+#pragma unroll
+                for (int u = 0; u < NPEND; ++u)
+                    pend[u] = *reinterpret_cast<const u32x4*>(sc + (16 * u + p16) * 64 + ((cch ^ ((p16 >> 1) & 3)) << 4));
                 wave_lds_fence();       // the next round's writes come after every lane's read of this round
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        flush(3, RND - 1);
         __syncthreads();                                    // the staged image of the next tile is complete
     }
     if (STATS >= 1 && STATS <= 3) {
@@ -391,7 +476,8 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
     const int segs = sq ? 1 : 2;
     const int TH = vert ? 32 * segs : 16 / segs, TW = vert ? 16 / segs : 32 * segs;
     const int LH = TH + KH - 1, LW = TW + KW - 1;
-    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * IPS + 384 + 4096;
+    const bool wide = sq || ((KH == 1 || KW == 1) && (KH * KW == 1 || KH * KW == 11));        // == the kernel's WIDE for the compile-time shapes
+    size_t lds = (size_t)KH * KW * 32 * 64 + (size_t)LH * LW * IPS + 384 + (wide ? 8192 : 4096);
     TCCT_CHECK(lds <= 80 * 1024, "conv32_fwd: %dx%d needs %zu B of LDS (> 80 KiB for 2 blocks/CU)", KH, KW, lds);
     TCCT_CHECK(LH * LW * 4 <= MAXL * MB, "conv32_fwd: %dx%d tile image exceeds the staging slots", KH, KW);
     int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
@@ -493,55 +579,82 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
     // staging slots (see k_conv32_mfma): x image slots and dy image slots, geometry fixed per thread
     const int c = tid & 3;
     const int npix = LH * LW;
-    int s_rc[MAXL], s_off[MAXL];
+    int s_rc[MAXL];
 #pragma unroll
     for (int j = 0; j < MAXL; ++j) {
         int pl = (tid >> 2) + j * (MB / 4);
         bool in = pl < npix;
         int lr = in ? pl / LW : 0x3fff, lc = in ? pl - (pl / LW) * LW : 0;
-        int p = VERT ? lc * LH + lr : pl;
         s_rc[j] = (lr << 16) | lc;
-        s_off[j] = in ? p * 64 + c * 16 : -1;
     }
-    uint4 prex[MAXL], pred[DSL];
+    // Global loads go through buffer descriptors like in k_conv32_mfma: an out-of-image pixel is an offset beyond the descriptor's range
+    // (the hardware returns zeros), so the staging code has no branches.  The first version tested every slot (`if (in image) load`): two
+    // branches and ~30 instructions of 64-bit address arithmetic per load, ~570 instructions per tile and wave in front of an MFMA phase of
+    // 80 MFMAs -- as long as the phase itself.  Interior tiles (block-uniform test) now cost one add per slot.
+    const uint32_t ximg_bytes = (uint32_t)H * (uint32_t)W * (uint32_t)xs * 2u - (uint32_t)xo * 2u;
+    const uint32_t dimg_bytes = (uint32_t)H * (uint32_t)W * (uint32_t)ds * 2u - (uint32_t)dof * 2u;
+    u32x4 prex[MAXL], pred[DSL];
     auto prefetch = [&](int tile) {
         const int tw = tile % tilesW;
         const int t2 = tile / tilesW;
         const int th = t2 % tilesH;
         const int n = t2 / tilesH;
         const int h0 = th * TH, w0 = tw * TW;
-        const bf16* xb = x + (int64_t)n * H * W * xs + xo + c * 8;
-        const bf16* db = dy + (int64_t)n * H * W * ds + dof + c * 8;
+        const int hb = h0 - PH, wb = w0 - PW;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * H * W * xs + xo), 0, ximg_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)n * H * W * ds + dof), 0, dimg_bytes, 0x00020000);
+        const uint32_t xs2 = (uint32_t)xs * 2u, ds2 = (uint32_t)ds * 2u;
+        if (hb >= 0 && wb >= 0 && hb + LH <= H && wb + LW <= W) {       // interior tile: x halo and dy tile lie inside the image
+            const uint32_t xbase = (uint32_t)((hb * W + wb) * xs * 2 + c * 16);
 #pragma unroll
-        for (int j = 0; j < MAXL; ++j) {
-            int hi = h0 - PH + (s_rc[j] >> 16), wi_ = w0 - PW + (s_rc[j] & 0xffff);
-            prex[j] = make_uint4(0, 0, 0, 0);
-            if (hi >= 0 && hi < H && wi_ >= 0 && wi_ < W)
-                prex[j] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hi * W + wi_) * xs);
-        }
+            for (int j = 0; j < MAXL; ++j) {
+                int rc = s_rc[j];
+                asm volatile("" : "+v"(rc));        // opaque: recompute the offsets per tile instead of keeping them live across the MFMA phase
+                const uint32_t lr = (uint32_t)(rc >> 16), lc = (uint32_t)(rc & 0xffff);
+                prex[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, lr == 0x3fffu ? OOB_OFF : xbase + (lr * (uint32_t)W + lc) * xs2, 0, 0);
+            }
+            const uint32_t dbase = (uint32_t)((h0 * W + w0) * ds * 2 + c * 16);
 #pragma unroll
-        for (int j = 0; j < DSL; ++j) {
-            const int pl = (tid >> 2) + j * (MB / 4);           // TW is a power of two: shifts, no tables
-            int ho = h0 + pl / TW, wo = w0 + (pl & (TW - 1));
-            pred[j] = make_uint4(0, 0, 0, 0);
-            if (ho < H && wo < W) pred[j] = *reinterpret_cast<const uint4*>(db + ((int64_t)ho * W + wo) * ds);
+            for (int j = 0; j < DSL; ++j) {
+                const uint32_t pl = (uint32_t)((tid >> 2) + j * (MB / 4));           // TW is a power of two: shifts, no tables
+                pred[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, dbase + ((pl / TW) * (uint32_t)W + (pl & (TW - 1))) * ds2, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < MAXL; ++j) {
+                const int hi = hb + (s_rc[j] >> 16), wi_ = wb + (s_rc[j] & 0xffff);
+                const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi_ < (unsigned)W;      // unused slots: lr = 0x3fff fails this
+                prex[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (uint32_t)((hi * W + wi_) * xs * 2 + c * 16) : OOB_OFF, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < DSL; ++j) {
+                const int pl = (tid >> 2) + j * (MB / 4);
+                const int ho = h0 + pl / TW, wo = w0 + (pl & (TW - 1));
+                pred[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, (ho < H && wo < W) ? (uint32_t)((ho * W + wo) * ds * 2 + c * 16) : OOB_OFF, 0, 0);
+            }
         }
     };
-    int tile = blockIdx.x;
-    if (tile < ntiles) prefetch(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
+    const TileSeq<VERT> seq(ntiles, tilesH, tilesW);
+    int tile = seq.at(0), tile1 = -1;
+    if (tile >= 0) prefetch(tile);
+    for (int kt = 0; tile >= 0; tile = tile1, ++kt) {
+        tile1 = seq.at(kt + 1);
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < MAXL; ++j)
-            if (s_off[j] >= 0) *reinterpret_cast<uint4*>(sX + s_off[j]) = prex[j];
+        for (int j = 0; j < MAXL; ++j) {
+            int rc = s_rc[j];
+            asm volatile("" : "+v"(rc));            // opaque: the LDS address is recomputed per tile, not kept live (11 VGPRs)
+            const int lr = rc >> 16, lc = rc & 0xffff;
+            if (lr != 0x3fff) *reinterpret_cast<u32x4*>(sX + (VERT ? lc * LH + lr : lr * LW + lc) * 64 + c * 16) = prex[j];
+        }
 #pragma unroll
         for (int j = 0; j < DSL; ++j) {
             const int pl = (tid >> 2) + j * (MB / 4);
             const int p = VERT ? (pl & (TW - 1)) * TH + pl / TW : pl;
-            *reinterpret_cast<uint4*>(sD + p * 64 + c * 16) = pred[j];
+            *reinterpret_cast<u32x4*>(sD + p * 64 + c * 16) = pred[j];
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        if (tile1 >= 0) prefetch(tile1);
         // chunks of 16 pixels; fragments of chunk i+1 are read while the MFMAs of chunk i run (sched_barrier pins the order)
         struct WFrag { bf16x8 a, b[TPW]; };
         auto load_chunk = [&](WFrag& f, int ch) {
@@ -575,7 +688,7 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
                 mma_chunk(f1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        } else {                            // 5 accumulators: a second fragment set would spill; read all 12 fragments, then 5 MFMAs
+        } else if (VERT) {                  // (the rotating form below spills in the 64 x 8 variant: levels 2-3 only, kept as it was)
             WFrag f0;
             for (int ch = wi; ch < 32; ch += WPG) {
                 load_chunk(f0, ch);
@@ -583,6 +696,35 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
                 mma_chunk(f0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
+            // 5 accumulators: a second fragment set would spill.  The first version read all 12 fragments of a chunk, waited, issued the 5 MFMAs,
+            // then read the next chunk: one exposed LDS round trip per chunk, 16 per tile and wave (ablation: the compute side alone took 0.178 of
+            // the 0.249 ms).  Now the registers rotate: the x fragment of tap t is reloaded for the NEXT chunk right behind the MFMA that consumed
+            // it (5 MFMAs = 160 cycles of cover), only the dy fragment -- read by all five -- has a second register set.
+            WFrag f0;
+            load_chunk(f0, wi);
+            int ch = wi;
+            for (; ch + WPG < 32; ch += WPG) {
+                const int nx = ch + WPG;
+                const int a_ = nx / CPR, s16 = (nx % CPR) * 16;
+                const int Pd = VERT ? a_ * TH + s16 : a_ * TW + s16;
+                const int Px = VERT ? a_ * LH + s16 : a_ * LW + s16;
+                const unsigned char* px = lbX + Px * 64;
+                const bf16x8 an = tr_load8p(lbD + Pd * 64);
+                if (tg == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum += (float)f0.a[j];
+                }
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap0 + t < TAPS) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.a, f0.b[t], acc[t], 0, 0, 0);
+                    f0.b[t] = tr_load8p(px + poff[t]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f0.a = an;
+            }
+            mma_chunk(f0);
         }
     }
     // block-level reduction of the WPG = 4/TG partial accumulators per tap in LDS: the waves of a tap group take turns (plain
@@ -651,6 +793,8 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
     int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
     int64_t nt = (int64_t)N * tilesH * tilesW;
     TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32_wgrad: bad tile count");
+    TCCT_CHECK((int64_t)H * W * xs * 2 < (1LL << 31) && (int64_t)H * W * ds * 2 < (1LL << 31),
+               "conv32_wgrad: one image of %d x %d x %d channels exceeds the 2 GiB buffer-descriptor range", H, W, xs > ds ? xs : ds);
     int grid = (int)(nt < 512 ? nt : 512);
     hipStream_t st = (hipStream_t)stream;
     if (zero) {
