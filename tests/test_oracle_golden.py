@@ -181,6 +181,17 @@ def test_goals_preprocessing_oracle_known_answers():
     assert back.shape == (2, 800, 1100) and (back[:, 608:] == 0).all() and set(np.unique(back)) <= {0, 30, 60, 90, 120}
     c = G.crop_flip(img, True, 3, 5, 256, 256, True, False)
     assert c.shape == (2, 256, 256, 3) and np.array_equal(c[0, 0, 0], img[0, 3, 5 + 255])
+    # secondary pin: an independent implementation of the same rule.  torch documents F.interpolate(mode='nearest') as
+    # the mode that "matches OpenCV's INTER_NEAREST" (as opposed to 'nearest-exact' = PIL / scikit-image); at the exact GOALS sizes
+    # (608 x 1100 -> 608 x 512 -> 608 x 1100) it picks the same source pixel as the restatement for every destination pixel
+    import torch.nn.functional as F
+    for dn, sn in ((512, 1100), (1100, 512), (608, 608)):
+        ref = F.interpolate(torch.arange(sn, dtype=torch.float64).view(1, 1, 1, sn), size=(1, dn), mode='nearest').view(-1).long().numpy()
+        assert np.array_equal(G.nn_index(dn, sn), ref), (dn, sn)
+    t_img = torch.from_numpy(img[:, :608]).permute(0, 3, 1, 2).double()
+    assert np.array_equal(F.interpolate(t_img, size=(608, 512), mode='nearest').permute(0, 2, 3, 1).numpy().astype(np.uint8), im2)
+    t_lab = torch.from_numpy(lab2.astype(np.float64) * 30)[:, None]
+    assert np.array_equal(F.interpolate(t_lab, size=(608, 1100), mode='nearest')[:, 0].numpy().astype(np.uint8), back[:, :608])
 
 
 @pytest.mark.parametrize('tag', ['fa64', 'fa96'])
