@@ -534,6 +534,13 @@ __device__ __forceinline__ const unsigned char* tr_lane_base(const unsigned char
     const int hh = g >> 1, cb = g & 1;
     return img + (8 * hh + q) * 64 + (16 * cb + 4 * pp) * 2;
 }
+// acc + v[2j] + v[2j+1] in one instruction (v_dot2c_f32_bf16 with a packed (1, 1) operand; exact products, fp32 accumulation)
+typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2_ones(const bf16x8& v, int j, float acc) {
+    const bf16x2_v p = {v[2 * j], v[2 * j + 1]};
+    const bf16x2_v one = {(__bf16)1.0f, (__bf16)1.0f};
+    return __builtin_amdgcn_fdot2_f32_bf16(p, one, acc, false);
+}
 __device__ __forceinline__ bf16x8 tr_load8p(const unsigned char* p) {
     // p = tr_lane_base(img) + P*64 for 16 consecutive LDS pixels P..P+15; returns pixels P+8*(lane>>5)+j (j=0..7) of channel lane&31
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
@@ -669,7 +676,7 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
         auto mma_chunk = [&](const WFrag& f) {
             if (tg == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bsum += (float)f.a[j];
+                for (int j = 0; j < 4; ++j) bsum = dot2_ones(f.a, j, bsum);      // 4 x v_dot2c_f32_bf16 instead of 8 x (unpack + add): the bias sum was 12 % of the compute side
             }
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
@@ -688,7 +695,9 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
                 mma_chunk(f1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        } else if (VERT) {                  // (the rotating form below spills in the 64 x 8 variant: levels 2-3 only, kept as it was)
+        } else {                            // 5 accumulators: a second fragment set would spill; read all 12 fragments, then 5 MFMAs
+            // (round 3: a rotating-register form -- the x fragment of tap t reloaded for the next chunk right behind the MFMA that consumed it --
+            // hid the LDS round trip per chunk and changed nothing: 0.176 ms with the loads ablated either way, 0.25-0.27 in full)
             WFrag f0;
             for (int ch = wi; ch < 32; ch += WPG) {
                 load_chunk(f0, ch);
@@ -696,35 +705,6 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
                 mma_chunk(f0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        } else {
-            // 5 accumulators: a second fragment set would spill.  The first version read all 12 fragments of a chunk, waited, issued the 5 MFMAs,
-            // then read the next chunk: one exposed LDS round trip per chunk, 16 per tile and wave (ablation: the compute side alone took 0.178 of
-            // the 0.249 ms).  Now the registers rotate: the x fragment of tap t is reloaded for the NEXT chunk right behind the MFMA that consumed
-            // it (5 MFMAs = 160 cycles of cover), only the dy fragment -- read by all five -- has a second register set.
-            WFrag f0;
-            load_chunk(f0, wi);
-            int ch = wi;
-            for (; ch + WPG < 32; ch += WPG) {
-                const int nx = ch + WPG;
-                const int a_ = nx / CPR, s16 = (nx % CPR) * 16;
-                const int Pd = VERT ? a_ * TH + s16 : a_ * TW + s16;
-                const int Px = VERT ? a_ * LH + s16 : a_ * LW + s16;
-                const unsigned char* px = lbX + Px * 64;
-                const bf16x8 an = tr_load8p(lbD + Pd * 64);
-                if (tg == 0) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bsum += (float)f0.a[j];
-                }
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (tap0 + t < TAPS) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.a, f0.b[t], acc[t], 0, 0, 0);
-                    f0.b[t] = tr_load8p(px + poff[t]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                f0.a = an;
-            }
-            mma_chunk(f0);
         }
     }
     // block-level reduction of the WPG = 4/TG partial accumulators per tap in LDS: the waves of a tap group take turns (plain
@@ -973,7 +953,7 @@ k_conv32_bwd33(const bf16* __restrict__ x, const bf16* __restrict__ dy, const bf
             auto mma_chunk = [&](const WF& f) {
                 if (tg == 0) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) bsum += (float)f.a[j];
+                    for (int j = 0; j < 4; ++j) bsum = dot2_ones(f.a, j, bsum);      // 4 x v_dot2c_f32_bf16 instead of 8 x (unpack + add): the bias sum was 12 % of the compute side
                 }
 #pragma unroll
                 for (int t = 0; t < 5; ++t)
