@@ -24,5 +24,7 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --dtype fp32 > $OUT/${TA
 python tools/infer_bench.py > $OUT/${TAG}_infer.txt 2>> $OUT/${TAG}_bench.err
 python tools/infer_bench.py --bs 1 >> $OUT/${TAG}_infer.txt 2>> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
+# HBM traffic of the whole step (every kernel, single stream)
+bash tools/step_traffic.sh ${TAG} > $OUT/${TAG}_traffic.txt 2>&1
 # keep only the small summaries
 find $OUT/${TAG}_step $OUT/${TAG}_stepfl $OUT/${TAG}_roof $OUT/${TAG}_lroof $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_lfetch $OUT/${TAG}_lwrite $OUT/${TAG}_mfma $OUT/${TAG}_sq -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null

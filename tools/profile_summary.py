@@ -118,6 +118,18 @@ if os.path.exists(f'{G}/{tag}_lroof/lroof_kernel_stats.csv'):
 L.append(f'\nbench.py\'s own HIP-event timing of the same loops (un-profiled run): `roofline.ms_per_launch` = {b["roofline"]["ms_per_launch"]} ms '
          f'({b["roofline"]["achieved"]} GB/s algorithmic, frac {b["roofline"]["frac"]}), second = {b["roofline"]["second"]["ms_per_launch"]} ms, '
          f'others = {[(o["kernel"], o["ms_per_launch"]) for o in b["roofline"].get("others", [])]}.')
+# ---- HBM traffic of the WHOLE step (tools/step_traffic.sh: PMC FETCH_SIZE / WRITE_SIZE over every kernel of the single-stream step)
+if os.path.exists(f'{G}/{tag}_traffic.txt'):
+    shutil.copy(f'{G}/{tag}_traffic.txt', f'{P}/{tag}_step_traffic.txt')
+    tl = open(f'{G}/{tag}_traffic.txt').read().splitlines()
+    head = [x for x in tl if x.startswith('total HBM traffic')]
+    if head:
+        gb = float(head[0].split(':')[1].split('GB')[0])
+        L.append(f'\n## HBM traffic of the whole step (`tools/step_traffic.sh`, PMC over every kernel, 2 x FETCH_SIZE + WRITE_SIZE)\n')
+        L.append(f'{head[0]}.  At the un-profiled {b["ms_per_step"]} ms/step that is **{gb / b["ms_per_step"]:.2f} TB/s on average** '
+                 f'(copy ceiling of this box: {b["roofline"].get("copy_ceiling", {}).get("GBs", "?")} GB/s; SURVEY 8(d) model bytes: '
+                 f'{b["roofline"].get("step_model_GBs", "?")} GB/s): the step as a whole moves its REAL bytes close to the achievable rate, '
+                 f'so what is left to gain is passes removed, not kernels tuned.  Per kernel: `profiles/{tag}_step_traffic.txt`.')
 open(f'{P}/{tag}_summary.md', 'w').write('\n'.join(L) + '\n')
 print('\n'.join(L)[:3000])
 # HBM traffic of the roofline kernels + the hash of the sources they were collected on -> profiles/TAG_pmc.json (bench.py's roofline.traffic)
