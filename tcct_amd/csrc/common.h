@@ -194,6 +194,14 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // no instruction: wave-scope ordering only constrains the optimizer
 }
 
+// Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2: blocks that share input rows (resize, stencils)
+// should be neighbours on ONE XCD.  xcd_band maps the hardware's linear block id to a logical one such that XCD x owns the contiguous band
+// [start(x), start(x) + count(x)) of logical ids (a bijection for every n).
+__device__ __forceinline__ unsigned xcd_band(unsigned b, unsigned n) {
+    const unsigned q = n >> 3, r = n & 7u, x = b & 7u, k = b >> 3;
+    return x * q + (x < r ? x : r) + k;
+}
+
 // ---------------------------------------------------------------- wave / block reductions (wave = 64)
 // source index / weights of torch's bilinear resize (F.interpolate / nn.Upsample) for output index o
 struct Lerp { int i0, i1; float l0, l1; };
