@@ -742,6 +742,211 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient, LDS-DMA form
+// Same arithmetic as k_conv32_wgrad, another load path.  Ablations of the register-staged kernel at the bench shape (0.25 ms): its loads
+// alone take 0.171 ms, its LDS / MFMA side alone 0.178 (of which the ds_write staging pass 0.030), and the two overlap badly because the one
+// tile a block can hold in registers (76 VGPRs) is issued only after the previous one has been written to LDS.  Here the tiles go
+// global -> LDS directly (`buffer_load_dwordx4 ... lds`: destination = wave-uniform base + 16 B x lane, per-lane SOURCE offset, out-of-range
+// lanes write zeros -- tools/probe/ldsdma_probe.hip), into TWO LDS buffers of one 8-wave block per CU: the DMA of tile t+1 is in flight during
+// the whole MFMA phase of tile t, no staging registers, no ds_write pass, and the freed registers double-buffer the fragments of all TPW taps.
+// Every wave issues exactly WD_PPW pieces (1 KB = 16 LDS pixels each) per tile, so `s_waitcnt vmcnt(WD_PPW)` retires tile t and leaves t+1 in
+// flight; the barriers are raw s_barrier (a __syncthreads() would drain the DMA with vmcnt(0)).
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane buffer offsets `voff` (descriptor `rsrc`, 4 SGPRs) to LDS bytes [lds_addr, lds_addr + 1024).
+// Inline asm on purpose: for the builtin form hipcc tracks the DMA as a pending LDS store and puts `s_waitcnt vmcnt(0)` in front of the next ds_read
+// -- which drains the tile that is meant to stay in flight.  M0 (the LDS destination base) is compiler-reserved: saved and restored inside
+// the statement; `s_nop 4`: SGPRs fresh from v_readfirstlane -> buffer instruction (cdna_hip_programming.md, "What hipcc does not do").
+__device__ __forceinline__ void lds_dma16(const u32x4& rsrc, uint32_t voff, uint32_t lds_addr) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ u32x4 make_rsrc_words(const void* base, uint32_t bytes) {
+    const uint64_t b = (uint64_t)base;
+    u32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    d[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);       // stride 0, no swizzle
+    d[2] = bytes;
+    d[3] = 0x00020000u;
+    return d;
+}
+#define WD_T 512
+#define WD_PPW 9                // pieces per wave and tile: (<= 39 x pieces + 32 dy pieces) / 8 waves, rounded up (spare slots repeat a piece)
+template <int TPW, bool VERT, bool SQ>
+__global__ void __launch_bounds__(WD_T, 1)
+k_conv32_wgrad_dma(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
+                   int N, int H, int W, int KH, int KW, int PH, int PW, int TG, int tilesH, int tilesW, int ntiles, int xs, int xo,
+                   int ds, int dof, int ldi, int o_off, int i_off) {
+    constexpr int TH = VERT ? 64 : (SQ ? 16 : 8), TW = VERT ? 8 : (SQ ? 32 : 64);
+    constexpr int CPR = (VERT ? TH : TW) / 16;     // 16-pixel chunks per tile row (HORZ) / column (VERT)
+    constexpr int NDP = TH * TW / 16;              // dy pieces per tile (32)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int LH = TH + KH - 1, LW = TW + KW - 1;
+    const int TAPS = KH * KW;
+    const int NPX = LH * LW, NXP = (NPX + 15) >> 4;            // x pixels / x pieces (the last piece may run into the pad behind the image)
+    const int XB = NXP * 1024, BUF = XB + TH * TW * 64;        // bytes of the x image (padded to whole pieces) and of one buffer
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int WPG = 8 / TG;
+    const int tg = wave / WPG, wi = wave % WPG;
+    const int tap0 = tg * TPW;
+    int poff[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        int tap = tap0 + t;
+        int dy_ = tap / KW, dx_ = tap - dy_ * KW;
+        poff[t] = (tap < KH * KW) ? (VERT ? dx_ * LH + dy_ : dy_ * LW + dx_) * 64 : 0;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    float bsum = 0.f;
+    const int lo = (int)(tr_lane_base(smem, lane) - smem);     // this lane's offset inside a transposing read
+
+    // piece geometry (tile independent): slot j of this wave is piece q = wave + 8 j (beyond the last piece: piece q - NP again, same bytes);
+    // lane -> pixel 16 q' + (lane >> 2), chunk lane & 3.  s_rc packs the pixel's tile coordinates; 0x3fff marks a lane without a source
+    const int c = lane & 3;
+    const int NP = NXP + NDP;
+    int s_rc[WD_PPW];
+#pragma unroll
+    for (int j = 0; j < WD_PPW; ++j) {
+        int q = wave + 8 * j;
+        if (q >= NP) q -= NP;
+        int lr, lc;
+        if (q < NXP) {
+            const int p = 16 * q + (lane >> 2);
+            if (p < NPX) { if (VERT) { lc = p / LH; lr = p - lc * LH; } else { lr = p / LW; lc = p - lr * LW; } }
+            else { lr = 0x3fff; lc = 0; }
+        } else {
+            const int pd = 16 * (q - NXP) + (lane >> 2);       // LDS pixel index of the dy image: HORZ row-major, VERT column-major
+            if (VERT) { lc = pd / TH; lr = pd - lc * TH; } else { lr = pd / TW; lc = pd - lr * TW; }
+        }
+        s_rc[j] = (lr << 16) | lc;
+    }
+    const uint32_t ximg_bytes = (uint32_t)H * (uint32_t)W * (uint32_t)xs * 2u - (uint32_t)xo * 2u;
+    const uint32_t dimg_bytes = (uint32_t)H * (uint32_t)W * (uint32_t)ds * 2u - (uint32_t)dof * 2u;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;     // LDS byte address of the dynamic segment
+    auto dma = [&](int tile, int buf) {
+        const int tw = tile % tilesW;
+        const int t2 = tile / tilesW;
+        const int th = t2 % tilesH;
+        const int n = t2 / tilesH;
+        const int h0 = th * TH, w0 = tw * TW;
+        const int hb = h0 - PH, wb = w0 - PW;
+        const u32x4 rx = make_rsrc_words(x + (int64_t)n * H * W * xs + xo, ximg_bytes);
+        const u32x4 rd = make_rsrc_words(dy + (int64_t)n * H * W * ds + dof, dimg_bytes);
+        const uint32_t base = lds0 + (uint32_t)(buf * BUF);
+#pragma unroll
+        for (int j = 0; j < WD_PPW; ++j) {
+            int q = wave + 8 * j;
+            if (q >= NP) q -= NP;
+            q = __builtin_amdgcn_readfirstlane(q);
+            const int lr = s_rc[j] >> 16, lc = s_rc[j] & 0xffff;
+            if (q < NXP) {                                      // wave-uniform
+                const int hi = hb + lr, wi_ = wb + lc;
+                const bool ok = lr != 0x3fff && (unsigned)hi < (unsigned)H && (unsigned)wi_ < (unsigned)W;
+                const uint32_t off = ok ? (uint32_t)((hi * W + wi_) * xs * 2 + c * 16) : OOB_OFF;
+                lds_dma16(rx, off, base + (uint32_t)(q * 1024));
+            } else {
+                const int ho = h0 + lr, wo = w0 + lc;
+                const uint32_t off = (ho < H && wo < W) ? (uint32_t)((ho * W + wo) * ds * 2 + c * 16) : OOB_OFF;
+                lds_dma16(rd, off, base + (uint32_t)(XB + (q - NXP) * 1024));
+            }
+        }
+    };
+    const TileSeq<VERT> seq(ntiles, tilesH, tilesW);
+    int tile = seq.at(0), tile1 = -1;
+    if (tile >= 0) dma(tile, 0);
+    for (int kt = 0; tile >= 0; tile = tile1, ++kt) {
+        tile1 = seq.at(kt + 1);
+        if (tile1 >= 0) {                                       // block-uniform
+            dma(tile1, (kt + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WD_PPW) : "memory");      // tile kt has landed (this wave's pieces), kt+1 stays in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                           // ... and every other wave's pieces of tile kt
+        const unsigned char* sX = smem + (kt & 1) * BUF;
+        const unsigned char* lbX = sX + lo;
+        const unsigned char* lbD = sX + XB + lo;
+        // chunks of 16 pixels; fragments of chunk i+1 are read while the MFMAs of chunk i run (sched_barrier pins the order)
+        struct WFrag { bf16x8 a, b[TPW]; };
+        auto load_chunk = [&](WFrag& f, int ch) {
+            const int a_ = ch / CPR, s16 = (ch % CPR) * 16;   // HORZ: row / col offset; VERT: col / row offset
+            const int Pd = VERT ? a_ * TH + s16 : a_ * TW + s16;
+            const int Px = VERT ? a_ * LH + s16 : a_ * LW + s16;
+            f.a = tr_load8p(lbD + Pd * 64);
+            const unsigned char* px = lbX + Px * 64;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) f.b[t] = tr_load8p(px + poff[t]);
+        };
+        auto mma_chunk = [&](const WFrag& f) {
+            if (tg == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bsum = dot2_ones(f.a, j, bsum);
+            }
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                if (tap0 + t < TAPS) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a, f.b[t], acc[t], 0, 0, 0);
+        };
+        WFrag f0, f1;                   // named buffers: a runtime-indexed array of fragments would live in scratch
+        load_chunk(f0, wi);
+        for (int ch = wi; ch < 32; ch += 2 * WPG) {           // 32 / WPG is even (WPG = 8, 4, 2)
+            load_chunk(f1, ch + WPG);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_chunk(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch + 2 * WPG < 32) load_chunk(f0, ch + 2 * WPG);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_chunk(f1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // every wave has read buffer kt & 1: the DMA of tile kt + 2 may overwrite it
+    }
+    // block-level reduction of the WPG partial accumulators per tap in LDS, then one atomic per element and block (as k_conv32_wgrad)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    for (int turn = 0; turn < WPG; ++turn) {
+        if (wi == turn) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int tap = tap0 + t;
+                if (tap < TAPS) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
+                        float* dst = &red[tap * 1024 + co * 32 + r];
+                        *dst = turn == 0 ? acc[t][k] : *dst + acc[t][k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < TAPS * 1024; i += WD_T) {
+        const int tap = i % TAPS, cc = i / TAPS;          // cc = co*32 + ci
+        const int co = cc >> 5, ci = cc & 31;
+        atomicAdd(&dw[((int64_t)(o_off + co) * ldi + i_off + ci) * TAPS + tap], red[tap * 1024 + cc]);
+    }
+    if (dbias && tg == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lane < 32) atomicAdd(&dbias[o_off + r], bsum);
+    }
+}
+
+// which weight-gradient kernel tcct_conv32_wgrad* launches: 0 = register-staged k_conv32_wgrad (default), 1 = k_conv32_wgrad_dma (LDS-DMA, two LDS
+// buffers; opt-in: same speed at the bench shape, kept as the base for B-fragment reuse across the dx taps -- DESIGN 3e).  -1 on entry = unset: the
+// environment variable TCCT_WGRAD_DMA=1 selects the DMA form.
+static int g_wgrad_mode = -1;
+extern "C" int64_t tcct_conv32_wgrad_mode(int mode) {
+    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] == '1') ? 1 : 0; }
+    const int prev = g_wgrad_mode;
+    if (mode == 0 || mode == 1) g_wgrad_mode = mode;
+    return prev;
+}
 /* dw OIHW fp32 [32,32,KH,KW] and dbias fp32 [32] (nullable) are overwritten. */
 static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH,
                              int PW, int xs, int xo, int ds, int dof, int ldi, int o_off, int i_off, int zero, tcct_stream_t stream);
@@ -780,6 +985,31 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
     if (zero) {
         if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * TAPS * 1024, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
         if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
+    }
+    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] == '1') ? 1 : 0; }
+    if (g_wgrad_mode == 1) {
+        // LDS-DMA form: one 8-wave block per CU, two LDS buffers; taps over TG wave groups (<= 5 accumulators per wave), WPG = 8 / TG waves per group
+        const int TGd = TAPS > 10 ? 4 : (TAPS > 5 ? 2 : 1);
+        const int tpwd = (TAPS + TGd - 1) / TGd;
+        const int nxp = (LH * LW + 15) / 16;
+        const size_t buf = (size_t)nxp * 1024 + (size_t)TH * TW * 64;
+        size_t ldsd = 2 * buf;
+        if (red > ldsd) ldsd = red;
+        if (ldsd <= 160 * 1024 && nxp + TH * TW / 16 <= 8 * WD_PPW) {
+            int gridd = (int)(nt < 256 ? nt : 256);
+#define WD_LAUNCH(TPW, V, Q)                                                                                                 \
+    do {                                                                                                                    \
+        static bool attr = false;                                                                                           \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad_dma<TPW, V, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((k_conv32_wgrad_dma<TPW, V, Q>), dim3(gridd), dim3(WD_T), ldsd, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W, KH, \
+                           KW, PH, PW, TGd, tilesH, tilesW, (int)nt, xs, xo, ds, dof, ldi, o_off, i_off);                                                       \
+    } while (0)
+            if (sq) WD_LAUNCH(5, false, true);
+            else if (tpwd <= 4) { if (vert) WD_LAUNCH(4, true, false); else WD_LAUNCH(4, false, false); }
+            else { if (vert) WD_LAUNCH(5, true, false); else WD_LAUNCH(5, false, false); }
+#undef WD_LAUNCH
+            TCCT_LAUNCH_OK();
+        }
     }
     // taps are split over TG wave groups so that <= 5 accumulators (80 VGPRs) live next to the prefetch registers: no spills
     const int TG = TAPS > 10 ? 4 : (TAPS > 5 ? 2 : 1);

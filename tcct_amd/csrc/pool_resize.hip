@@ -662,13 +662,15 @@ __global__ void k_normadd_fwd(const T* __restrict__ g0, const T* __restrict__ g1
                               const float* __restrict__ inv2, T* __restrict__ out, int N, int H, int W, int C, int h1, int w1, int h2, int w2,
                               float eps) {
     const int LP = C >> 2;                                  // lanes per pixel (power of two <= 64): the pixel's norm is a lane-group reduce
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;    // blockDim.x is a multiple of 64 -> lane groups stay inside a wave
+    const unsigned lb = xcd_band(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);     // neighbouring bands on ONE XCD (common.h)
+    const int bx = (int)(lb % gridDim.x), by = (int)(lb / gridDim.x);
+    const int i = bx * blockDim.x + threadIdx.x;            // blockDim.x is a multiple of 64 -> lane groups stay inside a wave
     const bool ok = i < W * LP;
     const int wo = ok ? i / LP : 0, c = ok ? (i - wo * LP) * 4 : 0;
     const Lerp b1 = src_index(wo, (float)w1 / (float)W, w1, 0), b2 = src_index(wo, (float)w2 / (float)W, w2, 0);
     // a block walks a BAND of NA_ROWS consecutive output rows: the two coarse maps contribute 2 + 2 source rows to every output row, and with
     // neighbouring rows spread over blocks on different XCDs those re-reads went to HBM (PMC: 1 805 MB moved for 1 045 MB algorithmic)
-    for (int row0 = blockIdx.y * NA_ROWS; row0 < N * H; row0 += gridDim.y * NA_ROWS)
+    for (int row0 = by * NA_ROWS; row0 < N * H; row0 += gridDim.y * NA_ROWS)
     for (int row = row0; row < min(row0 + NA_ROWS, N * H); ++row) {
         const int n = row / H, ho = row - n * H;
         const f4 v = ld4(g0 + ((int64_t)row * W + wo) * C + c);

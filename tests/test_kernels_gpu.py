@@ -69,6 +69,37 @@ def test_conv2d(dt, cfg):
         torch.testing.assert_close(nchw(xd.grad), x.grad, **t)
 
 
+@pytest.mark.parametrize('cfg', [(3, 3, 70, 130), (3, 3, 16, 33), (1, 13, 9, 200), (13, 1, 200, 9), (1, 11, 20, 150), (9, 1, 150, 20),
+                                 (1, 5, 8, 64), (7, 1, 33, 9), (1, 1, 19, 70), (3, 3, 3, 5)])
+def test_conv32_weight_gradient_lds_dma_form_equals_the_register_staged_one(cfg):
+    """tcct_conv32_wgrad_mode(1): the same weight / bias gradient from tiles that go global -> LDS directly (two LDS buffers, one 8-wave block per
+    CU); both forms against torch's fp32 convolution backward of the same bf16 operands, partial tiles at every image edge"""
+    from tcct_amd._lib import lib
+    KH, KW, H, W = cfg
+    N = 3
+    x = rnd(N, 32, H, W, dt=torch.bfloat16)
+    gy = rnd(N, 32, H, W, seed=3, dt=torch.bfloat16)
+    w = torch.zeros(32, 32, KH, KW, requires_grad=True)
+    b = torch.zeros(32, requires_grad=True)
+    F.conv2d(x.float(), w, b, 1, ((KH - 1) // 2, (KW - 1) // 2)).backward(gy.float())
+    xd, gd = nhwc(x, torch.bfloat16), nhwc(gy, torch.bfloat16)
+    outs = []
+    prev = lib.conv32_wgrad_mode(-1)
+    try:
+        for mode in (0, 1):
+            lib.conv32_wgrad_mode(mode)
+            dw = torch.full((32, 32, KH, KW), 7.0, device='cuda')
+            db = torch.full((32,), 7.0, device='cuda')
+            lib.conv32_wgrad(xd, gd, dw, db, N, H, W, KH, KW, (KH - 1) // 2, (KW - 1) // 2)
+            outs.append((dw.cpu(), db.cpu()))
+    finally:
+        lib.conv32_wgrad_mode(prev)
+    for dw, db in outs:
+        torch.testing.assert_close(dw, w.grad, rtol=2e-3, atol=2e-3 * max(1.0, w.grad.abs().max().item()))
+        torch.testing.assert_close(db, b.grad, rtol=2e-3, atol=2e-3 * max(1.0, b.grad.abs().max().item()))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-4 * max(1.0, w.grad.abs().max().item()))
+
+
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('stride', [1, 2])
 @pytest.mark.parametrize('nhw', [(2, 18, 26), (3, 17, 45), (1, 5, 131)])
