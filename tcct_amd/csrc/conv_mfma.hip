@@ -92,7 +92,8 @@ struct TileSeq {
         if ((g & 7) == 0) { nl = g >> 3; loc = b >> 3; Q = (ntiles + 7) >> 3; base = (b & 7) * Q; }
         else { nl = g; loc = b; Q = ntiles; base = 0; }
     }
-    // k-th tile of this block as the linear id (n * tilesH + th) * tilesW + tw, or -1 behind the end
+    // k-th tile of this block, packed (n << 20) | (th << 10) | tw (shifts to decode: a linear id cost the callers three more divisions per tile,
+    // and with two waves per SIMD every bookkeeping instruction is on the critical path), or -1 behind the end
     __device__ __forceinline__ int at(int k) const {
         const int q = k * nl + loc, seq = base + q;
         if (q >= Q || seq >= nt) return -1;
@@ -109,7 +110,26 @@ struct TileSeq {
             along = r2 >> 3; across = (sidx << 3) + (r2 & 7);
         }
         const int th = ROWSTRIP ? across : along, tw = ROWSTRIP ? along : across;
-        return (n * tH + th) * tW + tw;
+        return (n << 20) | (th << 10) | tw;
+    }
+    // the same, coordinates instead of the linear id (saves the caller three divisions per tile): false behind the end
+    __device__ __forceinline__ bool at3(int k, int& n, int& th, int& tw) const {
+        const int q = k * nl + loc, seq = base + q;
+        if (q >= Q || seq >= nt) return false;
+        n = seq / per_img;
+        const int rem = seq - n * per_img;
+        const int L = ROWSTRIP ? tW : tH, X = ROWSTRIP ? tH : tW;
+        const int full = X >> 3, A = L << 3;
+        int along, across;
+        if (rem >= full * A) {
+            const int wr = X - (full << 3), r2 = rem - full * A;
+            along = r2 / wr; across = (full << 3) + (r2 - along * wr);
+        } else {
+            const int sidx = rem / A, r2 = rem - sidx * A;
+            along = r2 >> 3; across = (sidx << 3) + (r2 & 7);
+        }
+        th = ROWSTRIP ? across : along; tw = ROWSTRIP ? along : across;
+        return true;
     }
 };
 #define MAXL 11
@@ -179,10 +199,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
     const uint32_t out_bytes = (uint32_t)H * (uint32_t)W * (uint32_t)ys * 2u - (uint32_t)yo * 2u;
     u32x4 pre[MAXL];
     auto prefetch = [&](int tile) {
-        const int tw = tile % tilesW;
-        const int t2 = tile / tilesW;
-        const int th = t2 % tilesH;
-        const int n = t2 / tilesH;
+        const int tw = tile & 1023, th = (tile >> 10) & 1023, n = tile >> 20;         // TileSeq::at packing
         const int hb = th * TH - PH, wb = tw * TW - PW;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * H * W * xs + xo), 0, img_bytes, 0x00020000);
         if (hb >= 0 && wb >= 0 && hb + LH <= H && wb + LW <= W) {      // interior tile (block-uniform): one add per slot
@@ -244,10 +261,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
     __syncthreads();
     for (int kt = 0; tile >= 0; tile = tile1, tile1 = tile2, ++kt) {
         tile2 = seq.at(kt + 2);
-        const int tw = tile % tilesW;
-        const int t2 = tile / tilesW;
-        const int th = t2 % tilesH;
-        const int n = t2 / tilesH;
+        const int tw = tile & 1023, th = (tile >> 10) & 1023, n = tile >> 20;         // TileSeq::at packing
         const int h0 = th * TH, w0 = tw * TW;
 
         // the accumulators start at the bias of this lane's 16 output channels (four LDS reads, one wait per tile): the epilogue --
@@ -483,6 +497,7 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
     int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
     int64_t nt = (int64_t)N * tilesH * tilesW;
     TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32_fwd: bad tile count");
+    TCCT_CHECK(tilesH < 1024 && tilesW < 1024 && N < 2048, "conv32_fwd: %d images of %d x %d tiles exceed the packed tile id (2047 images, 1023 x 1023 tiles)", N, tilesH, tilesW);
     TCCT_CHECK((int64_t)H * W * xs * 2 < (1LL << 31) && (int64_t)H * W * ys * 2 < (1LL << 31),
                "conv32_fwd: one image of %d x %d x %d channels exceeds the 2 GiB buffer-descriptor range", H, W, xs > ys ? xs : ys);
     int grid = (int)(nt < 512 ? nt : 512);  // (256 / 384 / 768 blocks: 0.323 / 0.294 / 0.292 ms against 0.236 with 512 = two resident blocks per CU)
@@ -602,10 +617,7 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
     const uint32_t dimg_bytes = (uint32_t)H * (uint32_t)W * (uint32_t)ds * 2u - (uint32_t)dof * 2u;
     u32x4 prex[MAXL], pred[DSL];
     auto prefetch = [&](int tile) {
-        const int tw = tile % tilesW;
-        const int t2 = tile / tilesW;
-        const int th = t2 % tilesH;
-        const int n = t2 / tilesH;
+        const int tw = tile & 1023, th = (tile >> 10) & 1023, n = tile >> 20;         // TileSeq::at packing
         const int h0 = th * TH, w0 = tw * TW;
         const int hb = h0 - PH, wb = w0 - PW;
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * H * W * xs + xo), 0, ximg_bytes, 0x00020000);
@@ -828,10 +840,7 @@ k_conv32_wgrad_dma(const bf16* __restrict__ x, const bf16* __restrict__ dy, floa
     const uint32_t dimg_bytes = (uint32_t)H * (uint32_t)W * (uint32_t)ds * 2u - (uint32_t)dof * 2u;
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;     // LDS byte address of the dynamic segment
     auto dma = [&](int tile, int buf) {
-        const int tw = tile % tilesW;
-        const int t2 = tile / tilesW;
-        const int th = t2 % tilesH;
-        const int n = t2 / tilesH;
+        const int tw = tile & 1023, th = (tile >> 10) & 1023, n = tile >> 20;         // TileSeq::at packing
         const int h0 = th * TH, w0 = tw * TW;
         const int hb = h0 - PH, wb = w0 - PW;
         const u32x4 rx = make_rsrc_words(x + (int64_t)n * H * W * xs + xo, ximg_bytes);
@@ -937,14 +946,187 @@ k_conv32_wgrad_dma(const bf16* __restrict__ x, const bf16* __restrict__ dy, floa
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 weight gradient, LDS-DMA + fragment reuse
+// The LDS array bounds both forms above: every x pixel is read from LDS once per TAP (the nine x fragments of a 16-pixel chunk are the same
+// pixels shifted by one row / one pixel) and dy once per tap group -- 786 KB of transposing reads per 72 KB tile.  Here one wave owns two output
+// rows of the 16 x 32 tile and ALL nine taps (9 accumulators; the DMA form has no staging registers in the way).  Per input row it reads three
+// fragments (pixels 0-15, 16-31, 32-47 of the 34-pixel halo row) and derives the dx = 1, 2 operands in registers: a lane holds 8 consecutive
+// pixels of one channel, so "shifted by one pixel" is a 16-bit funnel shift across its four dwords plus ONE incoming dword from the lane that
+// holds the next eight pixels (the other half-wave of the same fragment, or the first half-wave of the next one: v_permlane32_swap), and
+// "shifted by two" is a register rename.  Every input row serves up to two output rows x three dx.  LDS reads per tile: 128 KB instead of 786.
+__device__ __forceinline__ void shift_frags(const bf16x8& f, const bf16x8& fn, int hh, bf16x8& b1, bf16x8& b2) {
+    const u32x4 d = __builtin_bit_cast(u32x4, f), dn = __builtin_bit_cast(u32x4, fn);
+    const auto sw = __builtin_amdgcn_permlane32_swap(d[0], dn[0], false, false);    // sw[0] = (d0[0..31], dn0[0..31]), sw[1] = (d0[32..63], dn0[32..63])
+    const uint32_t e = hh ? sw[0] : sw[1];                                          // dword 0 of the lane that holds the NEXT eight pixels
+    u32x4 s1, s2;
+    s1[0] = __builtin_amdgcn_alignbit(d[1], d[0], 16); s1[1] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+    s1[2] = __builtin_amdgcn_alignbit(d[3], d[2], 16); s1[3] = __builtin_amdgcn_alignbit(e, d[3], 16);
+    s2[0] = d[1]; s2[1] = d[2]; s2[2] = d[3]; s2[3] = e;
+    b1 = __builtin_bit_cast(bf16x8, s1);
+    b2 = __builtin_bit_cast(bf16x8, s2);
+}
+__global__ void __launch_bounds__(WD_T, 1)
+k_conv32_wgrad33_dma(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
+                     int N, int H, int W, int tilesH, int tilesW, int ntiles) {
+    constexpr int TH = 16, TW = 32, LH = 18, LW = 34, TAPS = 9;
+    constexpr int NPX = LH * LW, NXP = (NPX + 15) >> 4, NDP = TH * TW / 16, NP = NXP + NDP;        // 612 px, 39 + 32 pieces
+    constexpr int XB = NXP * 1024, BUF = XB + TH * TW * 64;
+    static_assert(NP <= 8 * WD_PPW, "pieces per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    float bsum = 0.f;
+    const int lo = (int)(tr_lane_base(smem, lane) - smem);
+    const int c = lane & 3;
+    int s_rc[WD_PPW];
+#pragma unroll
+    for (int j = 0; j < WD_PPW; ++j) {
+        int q = wave + 8 * j;
+        if (q >= NP) q -= NP;
+        int lr, lc;
+        if (q < NXP) {
+            const int p = 16 * q + (lane >> 2);
+            if (p < NPX) { lr = p / LW; lc = p - lr * LW; } else { lr = 0x3fff; lc = 0; }
+        } else {
+            const int pd = 16 * (q - NXP) + (lane >> 2);
+            lr = pd / TW; lc = pd - lr * TW;
+        }
+        s_rc[j] = (lr << 16) | lc;
+    }
+    const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // The per-tile bookkeeping is on the critical path of a kernel with two waves per SIMD (an ablation with neither DMA nor compute -- tile
+    // sequence, piece addresses, two barriers -- took 0.086 of the 0.26 ms): per piece ONE add for interior tiles (offsets relative to the
+    // tile origin precomputed per slot; an unused lane's 0x80000000 keeps the sum out of range), descriptor / origin picked by scalar selects
+    // (x and dy pieces share the LDS formula base + 1 KB x q because the x image is padded to whole pieces), no re-decoding of a linear tile id.
+    uint32_t s_off[WD_PPW];
+    int s_q[WD_PPW];
+#pragma unroll
+    for (int j = 0; j < WD_PPW; ++j) {
+        int q = wave + 8 * j;
+        if (q >= NP) q -= NP;
+        s_q[j] = __builtin_amdgcn_readfirstlane(q);
+        const int lr = s_rc[j] >> 16, lc = s_rc[j] & 0xffff;
+        s_off[j] = lr == 0x3fff ? OOB_OFF : (uint32_t)((lr * W + lc) * 64 + c * 16);
+    }
+    auto dma = [&](int n, int th, int tw, int buf) {
+        const int h0 = th * TH, w0 = tw * TW;
+        const u32x4 rx = make_rsrc_words(x + (int64_t)n * H * W * 32, img_bytes);
+        const u32x4 rd = make_rsrc_words(dy + (int64_t)n * H * W * 32, img_bytes);
+        const uint32_t base = lds0 + (uint32_t)(buf * BUF);
+        if (h0 >= 1 && w0 >= 1 && h0 + TH + 1 <= H && w0 + TW + 1 <= W) {          // interior tile (block-uniform): halo and dy tile inside the image
+            const uint32_t bx = (uint32_t)(((h0 - 1) * W + (w0 - 1)) * 64), bd = (uint32_t)((h0 * W + w0) * 64);
+#pragma unroll
+            for (int j = 0; j < WD_PPW; ++j) {
+                const bool isx = s_q[j] < NXP;                  // wave-uniform
+                lds_dma16(isx ? rx : rd, (isx ? bx : bd) + s_off[j], base + (uint32_t)(s_q[j] * 1024));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WD_PPW; ++j) {
+                const int q = s_q[j];
+                const int lr = s_rc[j] >> 16, lc = s_rc[j] & 0xffff;
+                if (q < NXP) {
+                    const int hi = h0 - 1 + lr, wi_ = w0 - 1 + lc;
+                    const bool ok = lr != 0x3fff && (unsigned)hi < (unsigned)H && (unsigned)wi_ < (unsigned)W;
+                    lds_dma16(rx, ok ? (uint32_t)((hi * W + wi_) * 64 + c * 16) : OOB_OFF, base + (uint32_t)(q * 1024));
+                } else {
+                    const int ho = h0 + lr, wo = w0 + lc;
+                    lds_dma16(rd, (ho < H && wo < W) ? (uint32_t)((ho * W + wo) * 64 + c * 16) : OOB_OFF, base + (uint32_t)(q * 1024));
+                }
+            }
+        }
+    };
+    const TileSeq<false> seq(ntiles, tilesH, tilesW);
+    int tn, tth, ttw;
+    bool have = seq.at3(0, tn, tth, ttw);
+    if (have) dma(tn, tth, ttw, 0);
+    for (int kt = 0; have; ++kt) {
+        const bool more = seq.at3(kt + 1, tn, tth, ttw);
+        if (more) {
+            dma(tn, tth, ttw, (kt + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WD_PPW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        have = more;
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* sX = smem + (kt & 1) * BUF;
+        const unsigned char* lbX = sX + lo;
+        const unsigned char* lbD = sX + XB + lo;
+        // this wave: output rows y0 = 2 wave, y0 + 1; input (halo) rows 2 wave .. 2 wave + 3
+        bf16x8 A[2][2];
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                A[y][cc] = tr_load8p(lbD + ((2 * wave + y) * TW + 16 * cc) * 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bsum = dot2_ones(A[y][cc], j, bsum);
+            }
+#pragma unroll
+        for (int ir = 0; ir < 4; ++ir) {
+            const unsigned char* px = lbX + (2 * wave + ir) * LW * 64;
+            bf16x8 F[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) F[k] = tr_load8p(px + 16 * k * 64);        // pixels 32-47: 32, 33 are the halo, the rest is never used
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                bf16x8 b1, b2;
+                shift_frags(F[cc], F[cc + 1], hh, b1, b2);
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    const int dyi = ir - y;                                         // tap row of input row ir for output row y
+                    if (dyi >= 0 && dyi <= 2) {
+                        acc[dyi * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[y][cc], F[cc], acc[dyi * 3 + 0], 0, 0, 0);
+                        acc[dyi * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[y][cc], b1, acc[dyi * 3 + 1], 0, 0, 0);
+                        acc[dyi * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[y][cc], b2, acc[dyi * 3 + 2], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    for (int turn = 0; turn < 8; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
+                    float* dst = &red[t * 1024 + co * 32 + r];
+                    *dst = turn == 0 ? acc[t][k] : *dst + acc[t][k];
+                }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < TAPS * 1024; i += WD_T) {
+        const int tap = i % TAPS, cc = i / TAPS;          // cc = co*32 + ci
+        atomicAdd(&dw[(int64_t)cc * TAPS + tap], red[tap * 1024 + cc]);
+    }
+    if (dbias) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lane < 32) atomicAdd(&dbias[r], bsum);
+    }
+}
+
 // which weight-gradient kernel tcct_conv32_wgrad* launches: 0 = register-staged k_conv32_wgrad (default), 1 = k_conv32_wgrad_dma (LDS-DMA, two LDS
 // buffers; opt-in: same speed at the bench shape, kept as the base for B-fragment reuse across the dx taps -- DESIGN 3e).  -1 on entry = unset: the
 // environment variable TCCT_WGRAD_DMA=1 selects the DMA form.
 static int g_wgrad_mode = -1;
 extern "C" int64_t tcct_conv32_wgrad_mode(int mode) {
-    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] == '1') ? 1 : 0; }
+    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] >= '0' && e_[0] <= '2') ? e_[0] - '0' : 0; }
     const int prev = g_wgrad_mode;
-    if (mode == 0 || mode == 1) g_wgrad_mode = mode;
+    if (mode >= 0 && mode <= 2) g_wgrad_mode = mode;
     return prev;
 }
 /* dw OIHW fp32 [32,32,KH,KW] and dbias fp32 [32] (nullable) are overwritten. */
@@ -978,6 +1160,7 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
     int tilesH = (H + TH - 1) / TH, tilesW = (W + TW - 1) / TW;
     int64_t nt = (int64_t)N * tilesH * tilesW;
     TCCT_CHECK(nt > 0 && nt < (1LL << 31), "conv32_wgrad: bad tile count");
+    TCCT_CHECK(tilesH < 1024 && tilesW < 1024 && N < 2048, "conv32_wgrad: %d images of %d x %d tiles exceed the packed tile id (2047 images, 1023 x 1023 tiles)", N, tilesH, tilesW);
     TCCT_CHECK((int64_t)H * W * xs * 2 < (1LL << 31) && (int64_t)H * W * ds * 2 < (1LL << 31),
                "conv32_wgrad: one image of %d x %d x %d channels exceeds the 2 GiB buffer-descriptor range", H, W, xs > ds ? xs : ds);
     int grid = (int)(nt < 512 ? nt : 512);
@@ -986,7 +1169,15 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
         if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * TAPS * 1024, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
         if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
     }
-    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] == '1') ? 1 : 0; }
+    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] >= '0' && e_[0] <= '2') ? e_[0] - '0' : 0; }
+    if (g_wgrad_mode == 2 && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {      // plain 3x3: LDS-DMA + fragment reuse
+        constexpr size_t ldsr = 2 * ((size_t)((18 * 34 + 15) / 16) * 1024 + 16 * 32 * 64);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad33_dma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        hipLaunchKernelGGL(k_conv32_wgrad33_dma, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(WD_T), ldsr, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W,
+                           tilesH, tilesW, (int)nt);
+        TCCT_LAUNCH_OK();
+    }
     if (g_wgrad_mode == 1) {
         // LDS-DMA form: one 8-wave block per CU, two LDS buffers; taps over TG wave groups (<= 5 accumulators per wave), WPG = 8 / TG waves per group
         const int TGd = TAPS > 10 ? 4 : (TAPS > 5 ? 2 : 1);
