@@ -362,6 +362,10 @@ int tcct_l2norm_fwd(const void* x, void* y, int64_t M, int C, float eps, int dty
 int tcct_l2norm_bwd(const void* x, const void* dy, void* dx, int64_t M, int C, float eps, int dtype, tcct_stream_t stream);
 int tcct_l2norm_bwd_scaled(const void* x, const void* dy, void* dx, int64_t M, int C, float eps, float scale, int dtype,
                            tcct_stream_t stream);
+/* the same + res: the gradient that reaches x through its OTHER consumer (the inputs of norm_add, nets/tcct.py:937-942, also feed the aux heads
+ * :1035-1040) is added in this pass instead of by autograd's accumulation add */
+int tcct_l2norm_bwd_scaled_add(const void* x, const void* dy, const void* res, void* dx, int64_t M, int C, float eps, float scale, int dtype,
+                               tcct_stream_t stream);
 /* norm_add (nets/tcct.py:937-942), the `feats` side output of FTC.forward: out = (l2n(g0) + resize(l2n(g1)) + resize(l2n(g2))) / 3 with
  * F.interpolate(bilinear, align_corners=False) to g0's size, in one pass over g0 / out.  g0 [N,H,W,C], g1 [N,h1,w1,C], g2 [N,h2,w2,C];
  * inv1 / inv2: fp32 workspaces [N*h1*w1] / [N*h2*w2] (the coarse maps' inverse norms, written by a small pre-pass) */

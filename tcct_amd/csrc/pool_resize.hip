@@ -586,7 +586,8 @@ extern "C" int tcct_gate_fusion_bwd(const void* dy, const float* field, void* dx
 // ------------------------------------------------------------------------------------------ L2 normalise over C
 // LP = C/4 lanes per pixel (power of two <= 64)
 template <typename T, bool BWD>
-__global__ void k_l2norm(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, int64_t M, int C, float eps, float oscale) {
+__global__ void k_l2norm(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, int64_t M, int C, float eps, float oscale,
+                         const T* __restrict__ res = nullptr) {
     const int LP = C >> 2;
     const int64_t total = M * LP;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;     // multiple of 64 -> lanes of a pixel stay together
@@ -612,6 +613,11 @@ __global__ void k_l2norm(const T* __restrict__ x, const T* __restrict__ dy, T* _
             float coef = nrm > eps ? dot / (d * d * nrm) : 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) r.v[k] = oscale * (g.v[k] / d - v.v[k] * coef);
+            if (res) {          // + the gradient that reaches x through its other consumer (norm_add's inputs also feed the aux heads)
+                const f4 e = ld4(res + ii * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r.v[k] += e.v[k];
+            }
         }
         if (ok) st4(out + ii * 4, r);
     }
@@ -622,10 +628,11 @@ extern "C" int tcct_l2norm_fwd(const void* x, void* y, int64_t M, int C, float e
     TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_l2norm<T, false>), dim3(tcct_grid(M * LP, PB, 1 << 16)), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, (T*)y, M, C, eps, 1.f));
     TCCT_LAUNCH_OK();
 }
-static int l2norm_bwd_impl(const void* x, const void* dy, void* dx, int64_t M, int C, float eps, float oscale, int dtype, tcct_stream_t stream) {
+static int l2norm_bwd_impl(const void* x, const void* dy, void* dx, int64_t M, int C, float eps, float oscale, int dtype, tcct_stream_t stream,
+                           const void* res = nullptr) {
     int LP = C / 4;
     TCCT_CHECK(C % 4 == 0 && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, "l2norm_bwd: C=%d unsupported", C);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_l2norm<T, true>), dim3(tcct_grid(M * LP, PB, 1 << 16)), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, M, C, eps, oscale));
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_l2norm<T, true>), dim3(tcct_grid(M * LP, PB, 1 << 16)), dim3(PB), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, M, C, eps, oscale, (const T*)res));
     TCCT_LAUNCH_OK();
 }
 extern "C" int tcct_l2norm_bwd(const void* x, const void* dy, void* dx, int64_t M, int C, float eps, int dtype, tcct_stream_t stream) {
@@ -635,6 +642,14 @@ extern "C" int tcct_l2norm_bwd(const void* x, const void* dy, void* dx, int64_t 
 extern "C" int tcct_l2norm_bwd_scaled(const void* x, const void* dy, void* dx, int64_t M, int C, float eps, float scale, int dtype,
                                       tcct_stream_t stream) {
     return l2norm_bwd_impl(x, dy, dx, M, C, eps, scale, dtype, stream);
+}
+
+/* dx = scale * l2norm_bwd(x, dy) + res (res: same shape and dtype as x, may not be NULL): norm_add's inputs g_i also feed the aux heads
+ * (nets/tcct.py:1035-1040); the heads' gradient of g_i is added here instead of by an autograd accumulation pass */
+extern "C" int tcct_l2norm_bwd_scaled_add(const void* x, const void* dy, const void* res, void* dx, int64_t M, int C, float eps, float scale,
+                                          int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(res != nullptr && res != dx, "l2norm_bwd_scaled_add: res must be a separate tensor");
+    return l2norm_bwd_impl(x, dy, dx, M, C, eps, scale, dtype, stream, res);
 }
 
 // ------------------------------------------------- norm_add (nets/tcct.py:937-942): mean of three L2-normalised maps at the first one's size

@@ -540,6 +540,7 @@ class FTC(nn.Module):
         self.compute_dtype = compute_dtype
         self._feats_src = None
         self._feats = None
+        self.eager_feats = False        # True: norm_add is evaluated inside forward() (set by the training loop when the udh loss is on)
 
     @property
     def feats(self):
@@ -627,6 +628,13 @@ class FTC(nn.Module):
         # feature-polarization loss reads it; with --udh=false the six level-0 passes are simply never launched)
         self._feats_src = (g0, g1, g2, size)
         self._feats = None
+        if self.eager_feats and not self.legacy_heads:
+            # the loss WILL read `feats` (KiteSeg sets the flag with --udh): evaluate norm_add here and let the aux heads read aliases of g0..g2
+            # returned by its node, so that the heads' gradients are added inside norm_add's backward kernels (three accumulation passes fewer)
+            forked = ops.norm_add3_fork(g0, g1, g2)
+            if forked is not None:
+                feats, g0, g1, g2 = forked
+                self._feats, self._feats_src = [_nchw_view(feats)], None
         # aux heads: logits are produced and resized in fp32 in every mode (loss-side precision)
         f32 = torch.float32
         y0 = _conv(self.aux0, g0, out_dtype=f32)

@@ -1861,7 +1861,10 @@ class _NormAdd(torch.autograd.Function):
     (tcct_normadd_fwd); backward: the existing resize / normalise gradients with the 1/3 folded into the last kernel of each chain."""
 
     @staticmethod
-    def forward(ctx, g0, g1, g2, eps):
+    def forward(ctx, g0, g1, g2, eps, fork=False):
+        """fork: also return aliases of g0 / g1 / g2 for their other consumers (the aux heads); the gradients those deliver are added inside this
+        node's last backward kernels (tcct_l2norm_bwd_scaled_add) instead of by three autograd accumulation passes"""
+        ctx.set_materialize_grads(False)
         _chk(g0, g1, g2)
         N, H, W, C = g0.shape
         (_, h1, w1, _), (_, h2, w2, _) = g1.shape, g2.shape
@@ -1871,16 +1874,19 @@ class _NormAdd(torch.autograd.Function):
         lib.normadd_fwd(g0, g1, g2, inv1, inv2, out, N, H, W, C, h1, w1, h2, w2, eps, dtype_code(g0.dtype))
         ctx.save_for_backward(g0, g1, g2)
         ctx.eps = eps
-        return out
+        return (out, g0.view_as(g0), g1.view_as(g1), g2.view_as(g2)) if fork else out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *dalias):
         g0, g1, g2 = ctx.saved_tensors
+        dalias = tuple(dalias) + (None,) * (3 - len(dalias))
+        if dy is None:          # only the aliases were used downstream
+            return dalias[0], dalias[1], dalias[2], None, None
         dy = _as(dy, g0.dtype)
         N, H, W, C = g0.shape
         dc = dtype_code(g0.dtype)
         outs = []
-        for g in (g0, g1, g2):
+        for g, da in zip((g0, g1, g2), dalias):
             h, w = g.shape[1], g.shape[2]
             if (h, w) == (H, W):
                 dn = dy
@@ -1888,9 +1894,12 @@ class _NormAdd(torch.autograd.Function):
                 dn = torch.empty_like(g)
                 lib.bilinear_bwd(dy, dn, N, h, w, C, H, W, 0, dc)
             d = torch.empty_like(g)
-            lib.l2norm_bwd_scaled(g, dn, d, g.numel() // C, C, ctx.eps, 1.0 / 3.0, dc)
+            if da is not None:
+                lib.l2norm_bwd_scaled_add(g, dn, _c(_as(da, g.dtype)), d, g.numel() // C, C, ctx.eps, 1.0 / 3.0, dc)
+            else:
+                lib.l2norm_bwd_scaled(g, dn, d, g.numel() // C, C, ctx.eps, 1.0 / 3.0, dc)
             outs.append(d)
-        return outs[0], outs[1], outs[2], None
+        return outs[0], outs[1], outs[2], None, None
 
 
 def norm_add3(g0, g1, g2, eps=1e-12):
@@ -1903,6 +1912,19 @@ def norm_add3(g0, g1, g2, eps=1e-12):
         size = tuple(g0.shape[1:3])
         return add3_scale(l2norm(g0, eps), bilinear(l2norm(g1, eps), size, False), bilinear(l2norm(g2, eps), size, False), 1.0 / 3.0)
     return _NormAdd.apply(g0, g1, g2, float(eps))
+
+
+def norm_add3_fork(g0, g1, g2, eps=1e-12):
+    """(norm_add3(g0, g1, g2), g0', g1', g2'): the aliases are to be read by the other consumers of the three maps (the aux heads); returns None
+    when the fused form does not apply (the caller then uses norm_add3 and lets autograd accumulate)"""
+    C = g0.shape[-1]
+    lp = C // 4
+    ok = (g0.dim() == 4 and g1.shape[-1] == C and g2.shape[-1] == C and C % 4 == 0 and 1 <= lp <= 64 and lp & (lp - 1) == 0
+          and g0.dtype == g1.dtype == g2.dtype and tuple(g1.shape[1:3]) != tuple(g0.shape[1:3]) and tuple(g2.shape[1:3]) != tuple(g0.shape[1:3])
+          and torch.is_grad_enabled())
+    if not ok:
+        return None
+    return _NormAdd.apply(g0, g1, g2, float(eps), True)
 
 
 # ------------------------------------------------------------------------------------------------ losses

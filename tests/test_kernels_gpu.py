@@ -1166,6 +1166,41 @@ def test_norm_add_fused(dt, cfg):
         torch.testing.assert_close(ga[mask], gb[mask], rtol=t['rtol'], atol=t['atol'] * max(1e-3, gb[mask].abs().max().item()))
 
 
+@pytest.mark.parametrize('dt', DT)
+def test_norm_add_fork_adds_the_other_consumers_gradients(dt):
+    """norm_add3_fork: the three inputs also feed the aux heads (nets/tcct.py:1035-1040); the aliases' gradients are added inside norm_add's
+    backward kernels (tcct_l2norm_bwd_scaled_add) -- same totals as autograd's accumulation of the unforked form; an unused alias and an
+    unused `feats` both work"""
+    from tcct_amd import ops
+    C, H, W, N = 32, 24, 40, 2
+    gs = [nhwc(rnd(N, C, H >> i, W >> i, seed=i, dt=dt), dt) for i in range(3)]
+    go = nhwc(rnd(N, C, H, W, seed=5, dt=dt), dt)
+    extra = [nhwc(rnd(N, C, H >> i, W >> i, seed=7 + i, dt=dt), dt) for i in range(3)]
+    a = [g.clone().requires_grad_(True) for g in gs]
+    out = ops.norm_add3(*a)
+    (out * go).sum().backward(retain_graph=False)
+    want = [x.grad.float() + e.float() for x, e in zip(a, extra)]
+    b = [g.clone().requires_grad_(True) for g in gs]
+    out2, b0, b1, b2 = ops.norm_add3_fork(*b)
+    torch.testing.assert_close(out2, out)
+    ((out2 * go).sum() + (b0 * extra[0]).sum() + (b1 * extra[1]).sum() + (b2 * extra[2]).sum()).backward()
+    t = tol(dt)
+    for x, w in zip(b, want):
+        torch.testing.assert_close(x.grad.float(), w, rtol=t['rtol'], atol=2 * t['atol'] * max(1.0, w.abs().max().item()))
+    # one alias unused, and `feats` itself unused
+    c = [g.clone().requires_grad_(True) for g in gs]
+    out3, c0, c1, c2 = ops.norm_add3_fork(*c)
+    ((out3 * go).sum() + (c1 * extra[1]).sum()).backward()
+    torch.testing.assert_close(c[0].grad.float(), a[0].grad.float(), rtol=t['rtol'], atol=t['atol'])
+    torch.testing.assert_close(c[1].grad.float(), want[1], rtol=t['rtol'], atol=2 * t['atol'] * max(1.0, want[1].abs().max().item()))
+    d = [g.clone().requires_grad_(True) for g in gs]
+    _, d0, d1, d2 = ops.norm_add3_fork(*d)
+    ((d0 * extra[0]).sum() + (d2 * extra[2]).sum()).backward()
+    torch.testing.assert_close(d[0].grad, extra[0])
+    assert d[1].grad is None
+    torch.testing.assert_close(d[2].grad, extra[2])
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # factorised attention with convolutional relative position encoding (reference nets/tcct.py:219-341, SURVEY 8(f)4)
 def _oracle():
