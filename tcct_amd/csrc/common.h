@@ -225,6 +225,15 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));    // row_mirror
     return v;
 }
+// sum over each aligned group of LP lanes (LP a power of two <= 64), result in all of them: DPP steps up to 16 lanes, ds_bpermute beyond
+__device__ __forceinline__ float lane_group_sum(float v, int LP) {
+    if (LP >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    if (LP >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    if (LP >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    if (LP >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    for (int o = 16; o < LP; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -716,6 +716,65 @@ __global__ void k_normadd_fwd(const T* __restrict__ g0, const T* __restrict__ g1
     }
 }
 /* g0 [N,H,W,C], g1 [N,h1,w1,C], g2 [N,h2,w2,C] -> out [N,H,W,C]; inv1 / inv2: fp32 workspaces [N*h1*w1] / [N*h2*w2] (written here) */
+// The network's case -- g1 at half, g2 at a quarter of g0's height, H a multiple of 8 -- in bands of 8 output rows: a band reads six rows of g1 and four
+// of g2; each is interpolated HORIZONTALLY once (normalised on the fly) and kept in registers, the eight output rows only blend two cached rows per map.
+// The row-by-row kernel above issued 17 loads per output pixel and lane (k_normadd_fwd: 0.55 ms for 1 045 MB, 0.22 of the HBM peak -- load-issue bound);
+// here it is 6 per pixel.  Same arithmetic in the same association: the vertical weights still come from src_index(), only the row slots are
+// compile-time (output row 8k + r blends cache rows ((r + 1) >> 1, +1) of g1 and ((r + 2) >> 2, +1) of g2; rows beyond the map are clamped at load time,
+// where src_index() gives the clamped row a zero weight or the same row twice).
+template <typename T>
+__global__ void k_normadd_fwd_band(const T* __restrict__ g0, const T* __restrict__ g1, const T* __restrict__ g2, const float* __restrict__ inv1,
+                                   const float* __restrict__ inv2, T* __restrict__ out, int N, int H, int W, int C, int h1, int w1, int h2, int w2,
+                                   float eps) {
+    const int LP = C >> 2;
+    const unsigned lb = xcd_band(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int bx = (int)(lb % gridDim.x), by = (int)(lb / gridDim.x);
+    const int i = bx * blockDim.x + threadIdx.x;            // blockDim.x is a multiple of 64 -> lane groups stay inside a wave
+    const bool ok = i < W * LP;
+    const int wo = ok ? i / LP : 0, c = ok ? (i - wo * LP) * 4 : 0;
+    const Lerp b1 = src_index(wo, (float)w1 / (float)W, w1, 0), b2 = src_index(wo, (float)w2 / (float)W, w2, 0);
+    const int bands = H >> 3;
+    for (int band = by; band < N * bands; band += gridDim.y) {
+        const int n = band / bands, kb = band - n * bands;
+        f4 hx1[6], hx2[4];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int row = min(max(4 * kb - 1 + j, 0), h1 - 1);
+            const int64_t r0 = ((int64_t)n * h1 + row) * w1;
+            const f4 x0 = ld4(g1 + (r0 + b1.i0) * C + c), x1 = ld4(g1 + (r0 + b1.i1) * C + c);
+            const float i0 = inv1[r0 + b1.i0], i1 = inv1[r0 + b1.i1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hx1[j].v[k] = b1.l0 * (x0.v[k] * i0) + b1.l1 * (x1.v[k] * i1);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = min(max(2 * kb - 1 + j, 0), h2 - 1);
+            const int64_t r0 = ((int64_t)n * h2 + row) * w2;
+            const f4 x0 = ld4(g2 + (r0 + b2.i0) * C + c), x1 = ld4(g2 + (r0 + b2.i1) * C + c);
+            const float i0 = inv2[r0 + b2.i0], i1 = inv2[r0 + b2.i1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hx2[j].v[k] = b2.l0 * (x0.v[k] * i0) + b2.l1 * (x1.v[k] * i1);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int ho = 8 * kb + r;
+            const int64_t row = (int64_t)n * H + ho;
+            const f4 v = ld4(g0 + (row * W + wo) * C + c);
+            float ss = v.v[0] * v.v[0] + v.v[1] * v.v[1] + v.v[2] * v.v[2] + v.v[3] * v.v[3];
+            ss = lane_group_sum(ss, LP);        // (another summation order than the xor butterfly of the row-by-row kernel: last-bit differences)
+            const float id0 = 1.f / fmaxf(sqrtf(ss), eps);          // one division per pixel (the row-by-row kernel divides every channel: 0.5 ulp apart)
+            const Lerp a1 = src_index(ho, (float)h1 / (float)H, h1, 0), a2 = src_index(ho, (float)h2 / (float)H, h2, 0);
+            const f4 &p0 = hx1[(r + 1) >> 1], &p1 = hx1[((r + 1) >> 1) + 1], &q0 = hx2[(r + 2) >> 2], &q1 = hx2[((r + 2) >> 2) + 1];
+            f4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t = v.v[k] * id0 + (a1.l0 * p0.v[k] + a1.l1 * p1.v[k]);
+                o.v[k] = (t + (a2.l0 * q0.v[k] + a2.l1 * q1.v[k])) * (1.f / 3.f);
+            }
+            if (ok) st4(out + (row * W + wo) * C + c, o);
+        }
+    }
+}
 extern "C" int tcct_normadd_fwd(const void* g0, const void* g1, const void* g2, float* inv1, float* inv2, void* out, int N, int H, int W,
                                 int C, int h1, int w1, int h2, int w2, float eps, int dtype, tcct_stream_t stream) {
     const int LP = C / 4;
@@ -724,6 +783,12 @@ extern "C" int tcct_normadd_fwd(const void* g0, const void* g1, const void* g2, 
     hipStream_t st = (hipStream_t)stream;
     TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_invnorm<T>, dim3(tcct_grid((int64_t)N * h1 * w1 * LP, PB, 1 << 16)), dim3(PB), 0, st, (const T*)g1, inv1, (int64_t)N * h1 * w1, C, eps));
     TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_invnorm<T>, dim3(tcct_grid((int64_t)N * h2 * w2 * LP, PB, 1 << 16)), dim3(PB), 0, st, (const T*)g2, inv2, (int64_t)N * h2 * w2, C, eps));
+    static int banded = -1;         // TCCT_NORMADD_BAND=0: the row-by-row kernel for every shape (A/B timing)
+    if (banded < 0) { const char* e_ = getenv("TCCT_NORMADD_BAND"); banded = (e_ && e_[0] == '0') ? 0 : 1; }
+    if (banded && H == 2 * h1 && H == 4 * h2 && H % 8 == 0) {
+        TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_normadd_fwd_band<T>, row_grid(W * LP, (int64_t)N * (H / 8), 8192), dim3(PB), 0, st, (const T*)g0, (const T*)g1, (const T*)g2, inv1, inv2, (T*)out, N, H, W, C, h1, w1, h2, w2, eps));
+        TCCT_LAUNCH_OK();
+    }
     TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_normadd_fwd<T>, row_grid(W * LP, ((int64_t)N * H + NA_ROWS - 1) / NA_ROWS, 8192), dim3(PB), 0, st, (const T*)g0, (const T*)g1, (const T*)g2, inv1, inv2, (T*)out, N, H, W, C, h1, w1, h2, w2, eps));
     TCCT_LAUNCH_OK();
 }

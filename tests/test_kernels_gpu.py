@@ -1136,7 +1136,7 @@ def test_upsampled_dice_matches_interpolate_softmax_dice(cfg):
 
 
 @pytest.mark.parametrize('dt', DT)
-@pytest.mark.parametrize('cfg', [(32, 16, 24), (32, 40, 56), (16, 8, 8)])
+@pytest.mark.parametrize('cfg', [(32, 16, 24), (32, 40, 56), (16, 8, 8), (32, 20, 24), (32, 96, 72)])      # H % 8 != 0: the row-by-row kernel; else bands of 8 rows
 def test_norm_add_fused(dt, cfg):
     """norm_add (reference nets/tcct.py:937-942): (normalize(g0) + resize(normalize(g1)) + resize(normalize(g2))) / 3 in one pass, and
     its three input gradients"""
