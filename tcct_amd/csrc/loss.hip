@@ -113,7 +113,17 @@ k_gumbel_fwd(const float* __restrict__ x, const float* __restrict__ eps, float* 
     const int hs = (H + GSEG - 1) / GSEG;
     const int h0 = seg * hs, h1 = min(H, h0 + hs);
     float m = -INFINITY, Z = 0.f;
-    for (int h = h0; h < h1; ++h) {
+    // Rows in groups of four: a thread walks ~100 rows that lie 17.6 KB apart, and with one load pair outstanding per wave the walk is a chain
+    // of memory latencies.  The four rows of a group are loaded before any of them is used (hipcc refuses `#pragma unroll` on these loops).
+    auto zrow = [&](int h) { return gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]); };
+    int hq = h0;
+    for (; hq + 4 <= h1; hq += 4) {
+        const float z0 = zrow(hq), z1 = zrow(hq + 1), z2 = zrow(hq + 2), z3 = zrow(hq + 3);
+        const float mn = fmaxf(fmaxf(m, fmaxf(z0, z1)), fmaxf(z2, z3));
+        if (mn > -INFINITY) Z = Z * __expf(m - mn) + ((__expf(z0 - mn) + __expf(z1 - mn)) + (__expf(z2 - mn) + __expf(z3 - mn)));
+        m = mn;
+    }
+    for (int h = hq; h < h1; ++h) {
         // eps == 0 (probability 2^-24 per draw, i.e. a few per step at 8x800x1104x4) gives z = -inf: such an element contributes
         // exp(-inf) = 0, as in torch.softmax; while the running maximum is still -inf the rescale exp(m - mn) would be exp(NaN)
         float z = gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]);
@@ -131,7 +141,11 @@ k_gumbel_fwd(const float* __restrict__ x, const float* __restrict__ eps, float* 
     for (int g = 0; g < GSEG; ++g) if (sm[g][lane] > -INFINITY) Z += sz[g][lane] * __expf(sm[g][lane] - m);
     __syncthreads();
     float S = 0.f;
-    for (int h = h0; h < h1; ++h) S += __expf(gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]) - m) / Z;
+    for (hq = h0; hq + 4 <= h1; hq += 4) {
+        const float z0 = zrow(hq), z1 = zrow(hq + 1), z2 = zrow(hq + 2), z3 = zrow(hq + 3);
+        S += (__expf(z0 - m) / Z + __expf(z1 - m) / Z) + (__expf(z2 - m) / Z + __expf(z3 - m) / Z);
+    }
+    for (int h = hq; h < h1; ++h) S += __expf(zrow(h) - m) / Z;
     sm[seg][lane] = S;
     __syncthreads();
     S = 0.f;
@@ -139,8 +153,18 @@ k_gumbel_fwd(const float* __restrict__ x, const float* __restrict__ eps, float* 
     for (int g = 0; g < GSEG; ++g) S += sm[g][lane];
     if (ok && seg == 0) { stats[cc * 3] = m; stats[cc * 3 + 1] = Z; stats[cc * 3 + 2] = S; }
     const float den = 1.f / (1e-6f + S);
-    for (int h = h0; h < h1; ++h) {
-        float v = __expf(gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]) - m) / Z * den;
+    for (hq = h0; hq + 4 <= h1; hq += 4) {
+        float v[4] = {zrow(hq), zrow(hq + 1), zrow(hq + 2), zrow(hq + 3)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = __expf(v[j] - m) / Z * den;
+#pragma unroll
+            for (int o = CH >> 1; o > 0; o >>= 1) v[j] += __shfl_xor(v[j], o, 64);
+            if (ok && (wc % CH) == 0) out[(n * H + hq + j) * (int64_t)W + wc / CH] = v[j];
+        }
+    }
+    for (int h = hq; h < h1; ++h) {
+        float v = __expf(zrow(h) - m) / Z * den;
 #pragma unroll
         for (int o = CH >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if (ok && (wc % CH) == 0) out[(n * H + h) * (int64_t)W + wc / CH] = v;
@@ -169,7 +193,16 @@ k_gumbel_bwd(const float* __restrict__ x, const float* __restrict__ eps, const f
     const int hs = (H + GSEG - 1) / GSEG;
     const int h0 = seg * hs, h1 = min(H, h0 + hs);
     float D = 0.f;
-    for (int h = h0; h < h1; ++h) D += dp[(int64_t)h * W] * (__expf(gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]) - m) / Z);
+    auto grow = [&](int h) { return __expf(gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]) - m) / Z; };
+    int hq = h0;
+    for (; hq + 4 <= h1; hq += 4) {        // groups of four rows: see k_gumbel_fwd
+        const float x0 = xp[(int64_t)hq * WC], x1 = xp[(int64_t)(hq + 1) * WC], x2 = xp[(int64_t)(hq + 2) * WC], x3 = xp[(int64_t)(hq + 3) * WC];
+        const float e0 = ep[(int64_t)hq * WC], e1 = ep[(int64_t)(hq + 1) * WC], e2 = ep[(int64_t)(hq + 2) * WC], e3 = ep[(int64_t)(hq + 3) * WC];
+        const float d0 = dp[(int64_t)hq * W], d1 = dp[(int64_t)(hq + 1) * W], d2 = dp[(int64_t)(hq + 2) * W], d3 = dp[(int64_t)(hq + 3) * W];
+        D += (d0 * (__expf(gumbel_z(x0, e0) - m) / Z) + d1 * (__expf(gumbel_z(x1, e1) - m) / Z))
+           + (d2 * (__expf(gumbel_z(x2, e2) - m) / Z) + d3 * (__expf(gumbel_z(x3, e3) - m) / Z));
+    }
+    for (int h = hq; h < h1; ++h) D += dp[(int64_t)h * W] * grow(h);
     sd[seg][lane] = D;
     __syncthreads();
     D = 0.f;
@@ -177,11 +210,17 @@ k_gumbel_bwd(const float* __restrict__ x, const float* __restrict__ eps, const f
     for (int g = 0; g < GSEG; ++g) D += sd[g][lane];
     const float den = 1.f / (1e-6f + S);
     const float k2 = D * (1.f - S) * den * den;
-    if (ok)
-        for (int h = h0; h < h1; ++h) {
-            float g = __expf(gumbel_z(xp[(int64_t)h * WC], ep[(int64_t)h * WC]) - m) / Z;
-            dxp[(int64_t)h * WC] = g * ((dp[(int64_t)h * W] - D) * den - k2);
+    if (ok) {
+        for (hq = h0; hq + 4 <= h1; hq += 4) {
+            const float g0 = grow(hq), g1 = grow(hq + 1), g2 = grow(hq + 2), g3 = grow(hq + 3);
+            const float d0 = dp[(int64_t)hq * W], d1 = dp[(int64_t)(hq + 1) * W], d2 = dp[(int64_t)(hq + 2) * W], d3 = dp[(int64_t)(hq + 3) * W];
+            dxp[(int64_t)hq * WC] = g0 * ((d0 - D) * den - k2);
+            dxp[(int64_t)(hq + 1) * WC] = g1 * ((d1 - D) * den - k2);
+            dxp[(int64_t)(hq + 2) * WC] = g2 * ((d2 - D) * den - k2);
+            dxp[(int64_t)(hq + 3) * WC] = g3 * ((d3 - D) * den - k2);
         }
+        for (int h = hq; h < h1; ++h) dxp[(int64_t)h * WC] = grow(h) * ((dp[(int64_t)h * W] - D) * den - k2);
+    }
 }
 extern "C" int tcct_gumbel_colsoftmax_fwd(const float* x, const float* eps, float* out, float* stats, int N, int H, int W,
                                           int CH, tcct_stream_t stream) {
