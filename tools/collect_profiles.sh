@@ -18,7 +18,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_lroof -o lro
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_lfetch -o lfetch -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only --los=di+reg+fpl > $OUT/${TAG}_lfetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_lwrite -o lwrite -- python3 $GRAFT_REPO_ROOT/bench.py --roofline-only --los=di+reg+fpl > $OUT/${TAG}_lwrite.log 2>&1
 cd $GRAFT_REPO_ROOT
-python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+# the PMC traffic of the roofline kernels first (profiles/TAG_pmc.json in THIS copy of the tree), so that the bench lines below carry `roofline.traffic`
+python tools/pmc_json.py ${TAG} > /dev/null 2>> $OUT/${TAG}_bench.err
+python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2>> $OUT/${TAG}_bench.err
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --los=di+reg+fpl > $OUT/${TAG}_bench_fullloss.json 2>> $OUT/${TAG}_bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --dtype fp32 > $OUT/${TAG}_bench_fp32.json 2>> $OUT/${TAG}_bench.err
 python tools/infer_bench.py > $OUT/${TAG}_infer.txt 2>> $OUT/${TAG}_bench.err
