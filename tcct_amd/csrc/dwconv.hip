@@ -34,7 +34,9 @@ struct DwPos { int n, ho0, ho1, wo, c; };
 __device__ __forceinline__ bool dw_pos(int C, int VEC, int Ho, int Wo, int segh, int wblocks, int hstrips, DwPos& p, int cpt = 1) {
     const int CV = C / VEC, PW = DB / CV, t = threadIdx.x;
     if (t >= PW * CV) return false;
-    int bid = blockIdx.x;
+    // XCD-banded block order (common.h): vertically adjacent strips share their halo rows -- with the hardware's round-robin order they were
+    // fetched through different L2s (PMC: the stride-1 forward read 1.5x what it wrote)
+    int bid = (int)xcd_band(blockIdx.x, gridDim.x);
     const int wb = bid % wblocks; bid /= wblocks;
     const int hs = bid % hstrips;
     p.n = bid / hstrips;
