@@ -196,3 +196,52 @@ def test_token_mixer_and_mlp_store_points():
         e_one = _match(cpu(out), rb(cpu(t1) + lin))[0]
         print(f't + fc2(h) against a ONE-store model: {100 * e_one:.2f} %')
         assert e_one <= 0.9
+
+
+@pytest.mark.parametrize('kind', ['conv3x3_lrelu_bn', 'conv1x1_bn_hswish'])
+def test_backward_store_points(kind):
+    """The gradients are rounded where the forward tensors are stored (the backward of `_S`): the gradient of the convolution output is a bf16 tensor (or, in
+    the fused 1x1 node, a bf16 MFMA operand rebuilt on load), the input gradient is stored in bf16.  HIP dx against bf16(oracle dx): bit-identical on
+    nearly every element, and clearly further from the same backward WITHOUT the rounding of the convolution-output gradient; dW / dgamma / dbeta (fp32
+    accumulators) to 1e-3"""
+    import importlib
+    import tcct_oracle as O
+    T = importlib.import_module('tcct_amd.nets.tcct')
+    torch.manual_seed(4)
+    if kind == 'conv3x3_lrelu_bn':
+        conv, bn, x = nn.Conv2d(32, 32, 3, padding=1), nn.BatchNorm2d(32), _rnd(2, 32, 40, 56, seed=11)
+        kw = dict(pre='lrelu')
+    else:
+        conv, bn, x = nn.Conv2d(64, 64, 1, bias=False), nn.BatchNorm2d(64), _rnd(2, 64, 24, 40, seed=12)
+        kw = dict(post='hswish')
+    _bn_init(bn, 13)
+    sd = {**_sd('c', conv), **_sd('b', bn)}
+    gz = _rnd(*x.shape[:1], conv.out_channels, *x.shape[2:], seed=14)
+    conv, bn = conv.cuda(), bn.cuda().train()
+    xd = _nhwc(x).requires_grad_(True)
+    z = T._conv_bn(conv, bn, xd, **kw)
+    z.backward(_nhwc(gz))
+    hip_dx = _nchw(xd.grad)
+
+    def oracle(round_dy):
+        xo = x.clone().requires_grad_(True)
+        w = sd['c.weight'].clone().requires_grad_(True)
+        g, b = sd['b.weight'].clone().requires_grad_(True), sd['b.bias'].clone().requires_grad_(True)
+        y = F.conv2d(xo, O._RoundBf16Weight.apply(w), sd.get('c.bias'), 1, conv.padding)
+        y = O._RoundBf16.apply(y) if round_dy else y.detach().to(BF).float() + (y - y.detach())        # forward value rounded either way; backward rounded or not
+        u = F.leaky_relu(y, 0.01) if kind == 'conv3x3_lrelu_bn' else y
+        v = F.batch_norm(u, None, None, g, b, True, 0.1, 1e-5)
+        v = F.hardswish(v) if kind != 'conv3x3_lrelu_bn' else v
+        O._RoundBf16.apply(v).backward(gz)
+        return xo.grad, w.grad, g.grad, b.grad
+    dx1, dw1, dg1, db1 = oracle(True)
+    dx0 = oracle(False)[0]
+    e1, far, worst = _match(hip_dx, dx1.to(BF).float())
+    e0 = _match(hip_dx, dx0.to(BF).float())[0]
+    print(f'{kind} dx: bit-identical to the rounding-point backward on {100 * e1:.2f} % ({100 * far:.3f} % beyond 2 ulp, worst {worst:.1e}); without the rounding of '
+          f'the convolution-output gradient {100 * e0:.2f} %')
+    assert e1 >= 0.97 and far <= 2e-3 and e1 - e0 >= 0.1, (e1, far, e0)
+    for name, hip, ref in (('dW', conv.weight.grad, dw1), ('dgamma', bn.weight.grad, dg1), ('dbeta', bn.bias.grad, db1)):
+        err = (hip.detach().float().cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+        print(f'  {name}: max rel err {err:.1e}')
+        assert err <= 2e-3, (name, err)
