@@ -43,7 +43,8 @@ L.append(f'Un-profiled bench lines: `profiles/{tag}_bench.json` ({b["value"]} B-
          f'inference (`tools/infer_bench.py`): `profiles/{tag}_infer.txt`.\n')
 L.append(f'## whole step — `TCCT_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline`')
 L.append('(traced on ONE stream so that kernel durations add up; the bench lines above run the CNN / ViT encoders and the weight gradients on side streams, which hides ~2.5 ms of this sum)')
-L.append(f'{nsteps} steps traced; GPU busy {tot / 1e6:.1f} ms = {tot / 1e6 / nsteps:.2f} ms/step.\n')
+L.append(f'{nsteps} steps traced; GPU busy {tot / 1e6:.1f} ms = {tot / 1e6 / nsteps:.2f} ms/step.  (These are the FIRST steps of a process: the 35 per-convolution weight packs '
+         f'`k_pack_w32` (~0.13 ms/step) and the model upload copies in the `rocclr` row belong to start-up; from the third step on one `k_pack_w32_multi` launch packs all weights.)\n')
 L.append('| family | ms/step | % |\n|---|---|---|')
 for n, t in sorted(acc.items(), key=lambda x: -x[1]):
     L.append(f'| {n} | {t / 1e6 / nsteps:.2f} | {100 * t / tot:.1f} |')
