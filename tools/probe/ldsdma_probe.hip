@@ -1,5 +1,5 @@
 // LDS-DMA probe (gfx950): buffer_load_dwordx4 ... lds -- destination layout and the out-of-range behaviour
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/ldsdma_probe tools/probe/ldsdma_probe.hip && /tmp/ldsdma_probe
+//   hipcc --offload-arch=gfx950 -O3 -o tools/probe/ldsdma_probe.bin tools/probe/ldsdma_probe.hip && ./tools/probe/ldsdma_probe.bin   (measured: OK)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
