@@ -1119,14 +1119,163 @@ k_conv32_wgrad33_dma(const bf16* __restrict__ x, const bf16* __restrict__ dy, fl
     }
 }
 
+// The same data flow in the register-staged kernel's SHAPE: 4 waves per block, ONE LDS buffer (72 KB), two blocks per CU.  The 8-wave / two-buffer
+// form above holds a whole CU (145 KB of LDS) and runs its piece addressing and its MFMAs in the same waves one after the other; here a block's DMA
+// issue + wait overlaps the OTHER block's MFMA phase, and other kernels' blocks still fit beside it.  One wave: four output rows, six halo rows.
+__global__ void __launch_bounds__(MB, 2)
+k_conv32_wgrad33_dma4(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
+                      int N, int H, int W, int tilesH, int tilesW, int ntiles) {
+    constexpr int TH = 16, TW = 32, LH = 18, LW = 34, TAPS = 9, PPW = 18;
+    constexpr int NPX = LH * LW, NXP = (NPX + 15) >> 4, NDP = TH * TW / 16, NP = NXP + NDP;        // 612 px, 39 + 32 pieces
+    constexpr int XB = NXP * 1024;
+    static_assert(NP <= 4 * PPW, "pieces per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    float bsum = 0.f;
+    const int lo = (int)(tr_lane_base(smem, lane) - smem);
+    const int c = lane & 3;
+    // (no per-slot offset table here: with nine accumulators live every table costs spills; the piece's pixel is re-derived per tile --
+    // divisions by constants -- and that arithmetic runs beside the OTHER block's MFMA phase)
+    int s_q[PPW];
+    auto slot_rc = [&](int q, int& lr, int& lc) {
+        int l4 = lane >> 2;
+        asm volatile("" : "+v"(l4));            // opaque: re-derive per tile, never hoist 18 slots' worth of coordinates out of the tile loop
+        if (q < NXP) {
+            const int p = 16 * q + l4;
+            if (p < NPX) { lr = p / LW; lc = p - lr * LW; } else { lr = 0x3fff; lc = 0; }
+        } else {
+            const int pd = 16 * (q - NXP) + l4;
+            lr = pd / TW; lc = pd - lr * TW;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        int q = wave + 4 * j;
+        if (q >= NP) q -= NP;
+        s_q[j] = __builtin_amdgcn_readfirstlane(q);
+    }
+    const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto dma = [&](int n, int th, int tw) {
+        const int h0 = th * TH, w0 = tw * TW;
+        const u32x4 rx = make_rsrc_words(x + (int64_t)n * H * W * 32, img_bytes);
+        const u32x4 rd = make_rsrc_words(dy + (int64_t)n * H * W * 32, img_bytes);
+        if (h0 >= 1 && w0 >= 1 && h0 + TH + 1 <= H && w0 + TW + 1 <= W) {          // interior tile (block-uniform)
+            const uint32_t bx = (uint32_t)(((h0 - 1) * W + (w0 - 1)) * 64), bd = (uint32_t)((h0 * W + w0) * 64);
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                const bool isx = s_q[j] < NXP;                  // wave-uniform
+                int lr, lc;
+                slot_rc(s_q[j], lr, lc);
+                const uint32_t off = lr == 0x3fff ? OOB_OFF : (isx ? bx : bd) + (uint32_t)((lr * W + lc) * 64 + c * 16);
+                lds_dma16(isx ? rx : rd, off, lds0 + (uint32_t)(s_q[j] * 1024));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                const int q = s_q[j];
+                int lr, lc;
+                slot_rc(q, lr, lc);
+                if (q < NXP) {
+                    const int hi = h0 - 1 + lr, wi_ = w0 - 1 + lc;
+                    const bool ok = lr != 0x3fff && (unsigned)hi < (unsigned)H && (unsigned)wi_ < (unsigned)W;
+                    lds_dma16(rx, ok ? (uint32_t)((hi * W + wi_) * 64 + c * 16) : OOB_OFF, lds0 + (uint32_t)(q * 1024));
+                } else {
+                    const int ho = h0 + lr, wo = w0 + lc;
+                    lds_dma16(rd, (ho < H && wo < W) ? (uint32_t)((ho * W + wo) * 64 + c * 16) : OOB_OFF, lds0 + (uint32_t)(q * 1024));
+                }
+            }
+        }
+    };
+    const TileSeq<false> seq(ntiles, tilesH, tilesW);
+    const unsigned char* lbX = smem + lo;
+    const unsigned char* lbD = smem + XB + lo;
+    int tn, tth, ttw;
+    bool have = seq.at3(0, tn, tth, ttw);
+    for (int kt = 0; have; ++kt) {
+        dma(tn, tth, ttw);
+        have = seq.at3(kt + 1, tn, tth, ttw);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // the tile has landed (every wave's pieces)
+        // this wave: output rows 4 wave .. 4 wave + 3 in two pairs (a pair at a time keeps the dy fragments at 16 VGPRs next to the nine accumulators);
+        // a pair reads four halo rows
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const int row0 = 4 * wave + 2 * half;
+            bf16x8 A[2][2];
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    A[y][cc] = tr_load8p(lbD + ((row0 + y) * TW + 16 * cc) * 64);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bsum = dot2_ones(A[y][cc], j, bsum);
+                }
+#pragma unroll
+            for (int ir = 0; ir < 4; ++ir) {
+                const unsigned char* px = lbX + (row0 + ir) * LW * 64;
+                bf16x8 F[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) F[k] = tr_load8p(px + 16 * k * 64);
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    bf16x8 b1, b2;
+                    shift_frags(F[cc], F[cc + 1], hh, b1, b2);
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) {
+                        const int dyi = ir - y;                                         // tap row of input row ir for output row y
+                        if (dyi >= 0 && dyi <= 2) {
+                            acc[dyi * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[y][cc], F[cc], acc[dyi * 3 + 0], 0, 0, 0);
+                            acc[dyi * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[y][cc], b1, acc[dyi * 3 + 1], 0, 0, 0);
+                            acc[dyi * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[y][cc], b2, acc[dyi * 3 + 2], 0, 0, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);          // one halo row's fragments at a time
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // every wave has read the buffer: the next tile's DMA may overwrite it
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
+                    float* dst = &red[t * 1024 + co * 32 + r];
+                    *dst = turn == 0 ? acc[t][k] : *dst + acc[t][k];
+                }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < TAPS * 1024; i += MB) {
+        const int tap = i % TAPS, cc = i / TAPS;          // cc = co*32 + ci
+        atomicAdd(&dw[(int64_t)cc * TAPS + tap], red[tap * 1024 + cc]);
+    }
+    if (dbias) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lane < 32) atomicAdd(&dbias[r], bsum);
+    }
+}
+
 // which weight-gradient kernel tcct_conv32_wgrad* launches: 0 = register-staged k_conv32_wgrad (default), 1 = k_conv32_wgrad_dma (LDS-DMA, two LDS
 // buffers; opt-in: same speed at the bench shape, kept as the base for B-fragment reuse across the dx taps -- DESIGN 3e).  -1 on entry = unset: the
 // environment variable TCCT_WGRAD_DMA=1 selects the DMA form.
 static int g_wgrad_mode = -1;
 extern "C" int64_t tcct_conv32_wgrad_mode(int mode) {
-    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] >= '0' && e_[0] <= '2') ? e_[0] - '0' : 0; }
+    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] >= '0' && e_[0] <= '3') ? e_[0] - '0' : 0; }
     const int prev = g_wgrad_mode;
-    if (mode >= 0 && mode <= 2) g_wgrad_mode = mode;
+    if (mode >= 0 && mode <= 3) g_wgrad_mode = mode;
     return prev;
 }
 /* dw OIHW fp32 [32,32,KH,KW] and dbias fp32 [32] (nullable) are overwritten. */
@@ -1169,7 +1318,15 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
         if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * TAPS * 1024, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
         if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
     }
-    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] >= '0' && e_[0] <= '2') ? e_[0] - '0' : 0; }
+    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] >= '0' && e_[0] <= '3') ? e_[0] - '0' : 0; }
+    if (g_wgrad_mode == 3 && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {      // plain 3x3: LDS-DMA + fragment reuse, 4 waves x 2 blocks per CU
+        constexpr size_t lds3 = (size_t)((18 * 34 + 15) / 16) * 1024 + 16 * 32 * 64;
+        static bool attr3 = false;
+        if (!attr3) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad33_dma4, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr3 = true; }
+        hipLaunchKernelGGL(k_conv32_wgrad33_dma4, dim3((unsigned)(nt < 512 ? nt : 512)), dim3(MB), lds3, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W,
+                           tilesH, tilesW, (int)nt);
+        TCCT_LAUNCH_OK();
+    }
     if (g_wgrad_mode == 2 && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {      // plain 3x3: LDS-DMA + fragment reuse
         constexpr size_t ldsr = 2 * ((size_t)((18 * 34 + 15) / 16) * 1024 + 16 * 32 * 64);
         static bool attr = false;

@@ -86,7 +86,7 @@ def test_conv32_weight_gradient_lds_dma_form_equals_the_register_staged_one(cfg)
     outs = []
     prev = lib.conv32_wgrad_mode(-1)
     try:
-        for mode in (0, 1, 2):      # 2: LDS-DMA + fragment reuse across the dx taps (plain 3x3 only; other shapes take the default kernel)
+        for mode in (0, 1, 2, 3):   # 2 / 3: LDS-DMA + fragment reuse across the dx taps (plain 3x3 only; other shapes take the default kernel)
             lib.conv32_wgrad_mode(mode)
             dw = torch.full((32, 32, KH, KW), 7.0, device='cuda')
             db = torch.full((32,), 7.0, device='cuda')
