@@ -197,6 +197,8 @@ def attach(optimizer, model=None):
     30.62 ms single all-reduce, 31.68 ms three buckets all launched in step(), 32.02 ms three buckets overlapped with backward
     (gpurun_out/r02i_dp_ab.log): every extra collective costs ~0.35 ms of stream hand-offs for a transfer that takes tens of
     microseconds, and there is no bandwidth to hide at this message size."""
+    if model is not None:
+        optimizer.name_parameters(model.named_parameters())         # layout signature of FlatAdamW.state_dict() (names, not shapes)
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('TCCT_FORCE_DIST', '0') == '1'):
         optimizer.world = dist.get_world_size()
         optimizer.allreduce = allreduce_sum_

@@ -131,6 +131,7 @@ class GraphedTrainStep:
             k.optimG._step -= 1         # the Python side of step() ran once while capturing; the replay below is the real step
             self.graph = g
             ops.ZERO.frozen = True      # the graph holds pointers into the zero pool
+            ops.packs_freeze()          # ... and into the weight-pack descriptor table and the pack buffers it names
         else:
             self.s_img.copy_(img)
             self.s_lab.copy_(lab)

@@ -5,6 +5,7 @@ every arithmetic op of the hot path is a HIP kernel behind `tcct_amd._lib.lib`. 
 or a missing .so raises.  Activations are NHWC-contiguous (`[N,H,W,C]`, tokens `[B,N,C]` are the same memory).
 """
 import os
+import weakref
 
 import torch
 
@@ -64,7 +65,18 @@ ZERO = _ZeroPool()
 # next step on begin_step() re-packs ALL of them with one launch (the optimizer has just changed the weights) and the forward pass picks its
 # pack out of the cache.  TCCT_PACK_ALL=0 restores the per-call launches.
 PACK_ALL = os.environ.get('TCCT_PACK_ALL', '1') != '0'
-_PACKS = {'ent': {}, 'desc': None, 'sig': None, 'fresh': False}
+# ent: id(weight) -> [weakref(weight), pack buffer, (KH, KW), data_ptr, step last looked up].  Entries hold NO strong reference to the weight:
+# a dead model's entries disappear at the next begin_step(), as do entries no convolution asked for during the previous step.
+# frozen / keep: once a hipGraph has captured a step whose pack launch reads a descriptor table, that table and the pack buffers it names are kept
+# alive for the life of the process (`keep`) -- a replay reads their addresses -- and a changed entry set builds a NEW table beside them.
+_PACKS = {'ent': {}, 'desc': None, 'sig': None, 'fresh': False, 'step': 0, 'frozen': False, 'keep': []}
+
+
+def packs_freeze():
+    """called by tcct_amd.graph after a capture that contains the pack-all launch: pins the captured table and its pack buffers"""
+    _PACKS['frozen'] = True
+    if _PACKS['desc'] is not None:
+        _PACKS['keep'].append((_PACKS['desc'], [e[1] for e in _PACKS['ent'].values()]))
 
 
 def _pack_lookup(w, KH, KW):
@@ -72,19 +84,29 @@ def _pack_lookup(w, KH, KW):
     if not (PACK_ALL and ZERO.active):
         return None
     ent = _PACKS['ent'].get(id(w))
-    if ent is None or ent[0] is not w or ent[3] != w.data_ptr():
+    if ent is None or ent[0]() is not w or ent[3] != w.data_ptr() or ent[2] != (KH, KW):
         wp2 = torch.empty(2 * KH * KW * 1024, device=w.device, dtype=torch.bfloat16)
-        _PACKS['ent'][id(w)] = (w, wp2, (KH, KW), w.data_ptr())
+        _PACKS['ent'][id(w)] = [weakref.ref(w), wp2, (KH, KW), w.data_ptr(), _PACKS['step']]
         _PACKS['sig'] = None                    # the descriptor table is rebuilt at the next begin_step()
         return None
-    if not _PACKS['fresh'] or _PACKS['sig'] is None:
+    ent[4] = _PACKS['step']
+    if not _PACKS['fresh'] or _PACKS['sig'] is None or not ent[5:]:
         return None
     n = KH * KW * 1024
     return ent[1][:n], ent[1][n:]
 
 
+def _pack_evict():
+    """drop entries whose weight is gone, whose storage was re-bound (the flat optimizer buffer, load_state_dict) or that no convolution of the
+    previous step looked up (another model's step in between, a changed loss configuration)"""
+    step = _PACKS['step']
+    for k in [k for k, e in _PACKS['ent'].items() if e[0]() is None or e[0]().data_ptr() != e[3] or e[4] < step]:
+        del _PACKS['ent'][k]
+    _PACKS['step'] = step + 1
+
+
 def _pack_all(device):
-    ents = [e for e in _PACKS['ent'].values() if e[0].device == device and e[0].data_ptr() == e[3]]
+    ents = [e for e in _PACKS['ent'].values() if e[0]().device == device]
     _PACKS['fresh'] = False
     if not (PACK_ALL and ents):
         return
@@ -93,8 +115,12 @@ def _pack_all(device):
         return                      # the descriptor upload is a host-to-device copy: not inside a hipGraph capture (the convolutions pack per call then)
     if sig != _PACKS['sig']:
         rows = [[e[3], e[1].data_ptr(), e[2][0], e[2][1]] for e in ents]
-        _PACKS['desc'] = torch.tensor(rows, dtype=torch.int64).to(device)
+        _PACKS['desc'] = torch.tensor(rows, dtype=torch.int64).to(device)       # a NEW tensor: tables named by captured graphs stay in `keep`
         _PACKS['sig'] = sig
+    for e in _PACKS['ent'].values():
+        del e[5:]
+    for e in ents:
+        e.append(True)              # packed by this launch
     lib.conv32_pack_weights_multi(_PACKS['desc'], len(ents))
     _PACKS['fresh'] = True
 
@@ -105,9 +131,7 @@ def begin_step(device):
     if device.type == 'cuda' and device.index is None:          # torch.device('cuda') != torch.device('cuda', 0): never re-allocate the pool for that
         device = torch.device('cuda', torch.cuda.current_device())
     ZERO.begin(device)
-    stale = [k for k, e in _PACKS['ent'].items() if e[0].data_ptr() != e[3]]        # storage re-bound (the flat optimizer buffer, load_state_dict)
-    for k in stale:
-        del _PACKS['ent'][k]
+    _pack_evict()
     _pack_all(device)
     _STEP['main'] = torch.cuda.current_stream(device)
     for v in _STEP['marks'].values():

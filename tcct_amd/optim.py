@@ -21,6 +21,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.buckets = None          # tcct_amd.dist.GradBuckets: bucketed all-reduce overlapped with the backward pass
         self.allreduce_mode = 'none'
         self.last_total_norm = None
+        self.names = {}              # id(parameter) -> name, for the layout signature of state_dict()
         self._slots_live = False
         self.device_state = None     # [lr, steps taken] on the device once enable_device_state() was called (hipGraph-replayable step)
 
@@ -53,10 +54,10 @@ class FlatAdamW(torch.optim.Optimizer):
         its optimizer (kite/loopback.py:56-59), so this is an addition, not a wire format"""
         sd = super().state_dict()
         if self._flat is not None:
-            # `layout`: the order of the flat buffer (parameter shapes in buffer order).  It depends on which parameters had a gradient at
-            # the first step and, with TCCT_DP_OVERLAP=1, on the bucket sort: equal numel does not mean equal layout
-            sd['flat'] = dict(step=self._step, m=self._flat['m'].clone(), v=self._flat['v'].clone(), numel=self._flat['n'],
-                              layout=[tuple(p.shape) for p in self._flat['plist']])
+            # `layout`: the order of the flat buffer as (parameter NAME, shape) in buffer order.  It depends on which parameters had a gradient
+            # at the first step and, with TCCT_DP_OVERLAP=1, on the bucket sort: equal numel does not mean equal layout, and neither do equal
+            # shapes (dozens of tensors share 32x32x3x3 / [32]): the names decide
+            sd['flat'] = dict(step=self._step, m=self._flat['m'].clone(), v=self._flat['v'].clone(), numel=self._flat['n'], layout=self.layout())
         return sd
 
     def load_state_dict(self, sd):
@@ -69,7 +70,7 @@ class FlatAdamW(torch.optim.Optimizer):
             if int(flat['numel']) != self._flat['n']:
                 raise TcctError(f"FlatAdamW.load_state_dict(): saved state has {flat['numel']} elements, this optimizer {self._flat['n']}")
             layout = flat.get('layout')
-            if layout is not None and [tuple(x) for x in layout] != [tuple(p.shape) for p in self._flat['plist']]:
+            if layout is not None and [(str(n), tuple(x)) for n, x in layout] != self.layout():
                 raise TcctError('FlatAdamW.load_state_dict(): the saved moments are laid out in another parameter order (saved with a different '
                                 'TCCT_DP_OVERLAP mode or another set of trained parameters); applying them would permute the AdamW state')
             self._flat['m'].copy_(flat['m'])
@@ -77,6 +78,19 @@ class FlatAdamW(torch.optim.Optimizer):
             self._step = int(flat['step'])
             if self.device_state is not None:
                 self.device_state[1:2].fill_(float(self._step))
+
+    def layout(self):
+        """[(name, shape)] in flat-buffer order.  Names come from `named=` (tcct_amd.dist.attach passes model.named_parameters()); a parameter
+        without one is named by its position in the param groups, which is stable for a given model construction."""
+        if self._flat is None:
+            return []
+        pos = {id(p): i for i, p in enumerate(q for g in self.param_groups for q in g['params'])}
+        return [(self.names.get(id(p), f'#{pos[id(p)]}'), tuple(p.shape)) for p in self._flat['plist']]
+
+    def name_parameters(self, named):
+        """named: iterable of (name, parameter), e.g. model.named_parameters()"""
+        self.names.update({id(p): str(n) for n, p in named})
+        return self
 
     def _build(self):
         plist = [p for g in self.param_groups for p in g['params'] if p.grad is not None]

@@ -69,6 +69,40 @@ def test_conv2d(dt, cfg):
         torch.testing.assert_close(nchw(xd.grad), x.grad, **t)
 
 
+@pytest.mark.parametrize('cfg', [(128, 96, 6, 10), (320, 160, 4, 6), (160, 32, 4, 6), (32, 32, 19, 70), (64, 64, 21, 33), (96, 32, 9, 50), (192, 128, 10, 17),
+                                 (256, 160, 7, 9), (64, 96, 40, 55), (64, 64, 100, 138)])
+def test_pointwise_forward_on_the_fp32_matrix_pipes(cfg, monkeypatch):
+    """TCCT_F32_PW_FWD=1 (`ops.F32_PW[0]`): the fp32 1x1 convolution / Linear FORWARD on `k_pwf_mfma` (v_mfma_f32_32x32x2_f32) instead of the
+    sequential VALU kernel the parity mode uses by default -- the 1x1 shapes of test_conv2d (+ one level-3-sized map) against F.conv2d, forward and
+    both gradients, and the two forward kernels against each other at fp32 rounding level"""
+    from tcct_amd import ops
+    Cw, Co, H, W = cfg
+    N = 2
+    x = rnd(N, Cw, H, W).requires_grad_(True)
+    w = (rnd(Co, Cw, 1, 1, seed=1) / Cw ** 0.5).requires_grad_(True)
+    b = rnd(Co, seed=2).requires_grad_(True)
+    y = F.conv2d(x, w, b)
+    gy = rnd(*y.shape, seed=3)
+    y.backward(gy)
+    outs = {}
+    for fwd_mfma in (False, True):
+        monkeypatch.setattr(ops, 'F32_PW', [fwd_mfma, True, True])
+        xd = nhwc(x.detach(), torch.float32).requires_grad_(True)
+        wd = w.detach().cuda().requires_grad_(True)
+        bd = b.detach().cuda().requires_grad_(True)
+        yd = ops.conv2d(xd, wd, bd)
+        torch.testing.assert_close(nchw(yd), y.detach(), rtol=2e-4, atol=2e-4)
+        yd.backward(nhwc(gy, torch.float32))
+        torch.testing.assert_close(nchw(xd.grad), x.grad, rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=2e-4, atol=2e-4 * max(1.0, w.grad.abs().max().item()))
+        torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=2e-4, atol=2e-4 * max(1.0, b.grad.abs().max().item()))
+        outs[fwd_mfma] = yd.detach().double()
+    y64 = F.conv2d(x.detach().double(), w.detach().double(), b.detach().double())
+    e_valu = (nchw(outs[False].float()).double() - y64).abs().max().item()
+    e_mfma = (nchw(outs[True].float()).double() - y64).abs().max().item()
+    assert e_mfma < 4e-6 * max(1.0, y64.abs().max().item()) and e_mfma < 4 * e_valu + 1e-6, (e_valu, e_mfma)     # both are fp32-exact; only the order differs
+
+
 @pytest.mark.parametrize('cfg', [(3, 3, 70, 130), (3, 3, 16, 33), (3, 3, 50, 69), (3, 3, 100, 138), (1, 13, 9, 200), (13, 1, 200, 9), (1, 11, 20, 150), (9, 1, 150, 20),
                                  (1, 5, 8, 64), (7, 1, 33, 9), (1, 1, 19, 70), (3, 3, 3, 5)])
 def test_conv32_weight_gradient_lds_dma_form_equals_the_register_staged_one(cfg):
