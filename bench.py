@@ -62,6 +62,32 @@ def build_trainer(a, world):
     return k, ds, args
 
 
+class _StubTrainer:
+    """TCCT_BENCH_STUB=1 -- a REHEARSAL of the multi-rank plumbing on a machine without GPUs (tests/test_host_cpu.py runs `bench.py --gpus 8`
+    through the launcher here): every rank joins a gloo group and a "step" is the data-parallel part of the real one, i.e. ONE all-reduce of a flat
+    fp32 buffer of the real gradient size over tcct_amd.dist (802 298 elements) followed by the 1/world mean, and nothing else.  The printed line is
+    labelled as a stub in `metric` and `data`; it measures nothing about the product."""
+
+    def __init__(self, world, rank):
+        from tcct_amd import dist as tdist
+        self.tdist, self.world = tdist, world
+        self.flat = torch.full((802298,), float(rank + 1))
+        self.want = sum(range(1, world + 1)) / world
+
+        class _O:
+            allreduce_mode = 'single blocking all-reduce after backward (stub: gloo, CPU tensor)'
+            _flat = None
+        self.optimG = _O()
+
+    def train_step(self, img, lab):
+        self.flat.fill_(float(self.tdist.world_rank()[1] + 1))
+        self.tdist.allreduce_sum_(self.flat)
+        mean = self.flat / self.world
+        if abs(float(mean[0]) - self.want) > 1e-6 or abs(float(mean[-1]) - self.want) > 1e-6:
+            raise SystemExit(f'stub all-reduce: mean {float(mean[0])} != {self.want}')
+        return mean[:1].sum()
+
+
 def pmc_traffic(a, kernel_match):
     """`roofline.traffic`: HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of `bench.py --roofline-only`
     (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md), as recorded by
@@ -363,54 +389,66 @@ def main():
     world, rank, local = tdist.env_world()
     if world != a.gpus:
         raise SystemExit(f'--gpus={a.gpus} but WORLD_SIZE={world}: one rank per GPU, launch with --nproc-per-node={a.gpus}')
-    if not torch.cuda.is_available():
+    stub = os.environ.get('TCCT_BENCH_STUB') == '1'         # launcher / process-group rehearsal without GPUs (_StubTrainer)
+    if not stub and not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X')
-    if os.environ.get('TCCT_DIST_BACKEND') == 'gloo':      # test mode: several ranks share the GPUs that exist (RCCL needs one GPU per rank)
-        local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
+    sync = (lambda: None) if stub else torch.cuda.synchronize
+    dev = torch.device('cpu') if stub else None
+    if not stub:
+        if os.environ.get('TCCT_DIST_BACKEND') == 'gloo':      # test mode: several ranks share the GPUs that exist (RCCL needs one GPU per rank)
+            local = local % torch.cuda.device_count()
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
     torch.manual_seed(2023 + rank)          # per-rank noise stream (DropPath masks, Gumbel / jitter draws): seed = base + rank, SURVEY 8(e)
-    torch.cuda.manual_seed_all(2023 + rank)
+    if not stub:
+        torch.cuda.manual_seed_all(2023 + rank)
     if a.roofline_only:
         print(json.dumps({'roofline': dominant_kernel_roofline(a)}), file=out_stream, flush=True)
         return
     # The dominant-kernel timing runs BEFORE the training loop, on a quiet allocator: measured after it (27 GB pool live, two side streams
     # warm) the same kernel read 0.263 ms against 0.216-0.245 ms cold (round-2 review) -- ONE place, the cold one, is what the line reports.
     roof = copyc = None
-    if rank == 0 and not a.no_roofline:
+    if rank == 0 and not a.no_roofline and not stub:
         roof = dominant_kernel_roofline(a)
         copyc = copy_ceiling(a)
         torch.cuda.empty_cache()
-    k, ds, args = build_trainer(a, world)
-    k.model.train()
-    batch = ds.make_batch(a.bs, seed=2023 + rank)
-    img, lab, _, _ = ds.parse(batch)
-    img, lab = img.contiguous(), lab.contiguous()
-    torch.cuda.synchronize()
+    if stub:
+        tdist.init('gloo')
+        k, img, lab = _StubTrainer(world, rank), None, None
+    else:
+        k, ds, args = build_trainer(a, world)
+        k.model.train()
+        batch = ds.make_batch(a.bs, seed=2023 + rank)
+        img, lab, _, _ = ds.parse(batch)
+        img, lab = img.contiguous(), lab.contiguous()
+    sync()
     for _ in range(a.warmup):
         k.train_step(img, lab)
-    torch.cuda.synchronize()
+    sync()
     tdist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     loss = None
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # per-step GPU timeline (diagnostic; no host sync)
+    marks = [] if stub else [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # per-step GPU timeline (diagnostic; no host sync)
     host = [time.perf_counter()]
-    marks[0].record()
+    if marks:
+        marks[0].record()
     for i in range(a.steps):
         loss = k.train_step(img, lab)
-        marks[i + 1].record()
+        if marks:
+            marks[i + 1].record()
         host.append(time.perf_counter())
-    torch.cuda.synchronize()
+    sync()
     tdist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
-    dt = tdist.max_over_ranks(dt, torch.device('cuda', local))
+    dt = tdist.max_over_ranks(dt, dev)
     lossv = float(loss.item())
-    devices = tdist.gather_strings(f'cuda:{local} ({torch.cuda.get_device_name(local)})')
+    devices = tdist.gather_strings('cpu (stub)' if stub else f'cuda:{local} ({torch.cuda.get_device_name(local)})')
     ranks_seen = None
     import torch.distributed as tdd0
     if tdd0.is_initialized():       # evidence that a collective over ALL ranks really ran (every rank takes part): ones all-reduced == world size
-        one = torch.ones(1, device='cuda')
+        one = torch.ones(1, device=dev)
         tdd0.all_reduce(one)
         ranks_seen = int(one.item())
     tdist.barrier()
@@ -423,17 +461,19 @@ def main():
         raise SystemExit(f'--gpus={a.gpus} but the process group has {ranks} ranks')
     value = a.bs * world * a.steps / dt
     out = {
-        'metric': 'OCT B-scans/sec fwd+bwd(+clip+AdamW), stc_tt bs=8 1x800x1100', 'value': round(value, 3), 'unit': 'B-scans/s',
+        'metric': ('STUB (launcher rehearsal, no GPU work): ' if stub else '') + 'OCT B-scans/sec fwd+bwd(+clip+AdamW), stc_tt bs=8 1x800x1100',
+        'value': round(value, 3), 'unit': 'B-scans/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
+        'data': 'stub: one gloo all-reduce of the flat gradient size per step, CPU tensors' if stub else 'synthetic',
         'config': {'workload': f'stc_tt{"" if a.att == "pool" else "(att=" + a.att + ")"} --los={a.los} bs={a.bs}/GPU 1x{a.height}x{a.width} (net tensors 3x{a.height}x{(a.width + 15) // 16 * 16})',
                    'global_batch': a.bs * world, 'parallelism': f'dp{world}', 'ranks': ranks,
                    'backend': (tdd.get_backend() if tdd.is_initialized() else None), 'rank_devices': devices,
                    'grad_allreduce': getattr(k.optimG, 'allreduce_mode', 'none'), 'loss_last': round(lossv, 4),
-                   'step_ms_gpu_min_med_max': _min_med_max([marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]),
+                   'step_ms_gpu_min_med_max': _min_med_max([marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]) if marks else None,
                    'step_ms_host_enqueue_min_med_max': _min_med_max([1e3 * (host[i + 1] - host[i]) for i in range(a.steps)]),
                    'slowest_step': max(range(a.steps), key=lambda i: host[i + 1] - host[i]),
-                   'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2**30, 2)},
+                   'peak_mem_GB': None if stub else round(torch.cuda.max_memory_allocated() / 2**30, 2)},
     }
     import torch.distributed as tdd2
     if tdd2.is_initialized():
@@ -442,7 +482,7 @@ def main():
             out['config']['nccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version()) if tdd2.get_backend() == 'nccl' else None
         except Exception as e:                                  # noqa: BLE001
             out['config']['nccl_version'] = f'unavailable: {e}'
-    out['config']['clip_adamw_ms'] = optimizer_ms(k)
+    out['config']['clip_adamw_ms'] = None if stub else optimizer_ms(k)
     if roof is not None:
         out['roofline'] = roof
         out['roofline']['measured'] = 'before the training loop (quiet allocator), after a 120-copy spin-up (clock transient of the first ~10 ms of GPU activity: tools/dbg_iters.py)'
@@ -450,7 +490,7 @@ def main():
         # whole-step view against the layer-granular traffic model of SURVEY §8(d): 7.38 GB (bf16) / 14.8 GB (fp32) per B-scan
         per_img = 7.38e9 if a.dtype == 'bf16' else 14.8e9
         out['roofline']['step_model_GBs'] = round(per_img * value / world / 1e9, 1)
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and not stub:
         out['cpu_baseline'] = cpu_baseline(a)
     print(json.dumps(out), file=out_stream, flush=True)
     tdist.barrier()

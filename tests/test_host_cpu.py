@@ -275,3 +275,24 @@ def test_bench_launcher_starts_the_ranks_as_children_and_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'), timeout=300)
     assert r.returncode != 0 and '--gpus=4 but WORLD_SIZE=2' in r.stderr and '"metric"' not in r.stdout
+
+
+def test_bench_eight_ranks_through_the_launcher_stub_trainer():
+    """`python bench.py --gpus 8` end to end through the launcher -- child torch.distributed.run, 8 ranks, rendezvous on 127.0.0.1, process group,
+    barriers, max-over-ranks timing, one all-reduce of the real flat-gradient size per step, the rank-evidence all-reduce, rank 0 alone printing, all
+    ranks leaving together -- with the GPU work replaced by bench.py's stub trainer (TCCT_BENCH_STUB=1: gloo, CPU tensors).  The 5-rank rehearsal of
+    round 3 found a real deadlock in this sequence; 8 ranks is what the driver's SCALE run starts."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(TCCT_BENCH_STUB='1', OMP_NUM_THREADS='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1'],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                        # exactly ONE line on stdout
+    got = json.loads(lines[0])
+    assert got['n_gpus'] == 8 and got['config']['ranks'] == 8 and got['config']['allreduce_ranks_seen'] == 8
+    assert got['config']['global_batch'] == 64 and got['config']['parallelism'] == 'dp8' and got['scaling'] == 'weak'
+    assert got['config']['backend'] == 'gloo' and len(got['config']['rank_devices']) == 8
+    assert got['metric'].startswith('STUB') and got['data'].startswith('stub') and 'roofline' not in got and 'cpu_baseline' not in got
+    assert got['steps'] == 3 and got['value'] > 0

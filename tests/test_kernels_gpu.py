@@ -550,6 +550,38 @@ def test_clip_adamw():
             torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=1e-5, atol=1e-6)
 
 
+def test_flat_adamw_state_refuses_a_permuted_layout():
+    """FlatAdamW.state_dict() records the flat buffer's order by parameter NAME (not shape: dozens of tensors share 32x32x3x3 / [32]): moments saved
+    from one order must not be applied to another order of equally shaped tensors; the same order round-trips"""
+    from tcct_amd.optim import FlatAdamW
+    from tcct_amd._lib import TcctError
+    g = torch.Generator().manual_seed(0)
+
+    def make(order):
+        ps = {n: torch.nn.Parameter(torch.randn(32, 32, 3, 3, generator=g).cuda()) for n in ('a.weight', 'b.weight', 'c.weight')}
+        opt = FlatAdamW([ps[n] for n in order], lr=1e-3).name_parameters(ps.items())
+        for p in ps.values():
+            p.grad = torch.randn(p.shape, generator=g).cuda()
+        opt.step()
+        return opt
+    o1 = make(['a.weight', 'b.weight', 'c.weight'])
+    sd = o1.state_dict()
+    assert [n for n, _ in sd['flat']['layout']] == ['a.weight', 'b.weight', 'c.weight']
+    o2 = make(['a.weight', 'b.weight', 'c.weight'])
+    o2.load_state_dict(sd)
+    assert torch.equal(o2._flat['m'], o1._flat['m']) and o2._step == 1
+    o3 = make(['b.weight', 'a.weight', 'c.weight'])                 # same shapes, same numel, other order
+    with pytest.raises(TcctError, match='another parameter order'):
+        o3.load_state_dict(sd)
+    # unnamed parameters fall back to their position in the param groups
+    q = [torch.nn.Parameter(torch.randn(8, generator=g).cuda()) for _ in range(2)]
+    o4 = FlatAdamW(q, lr=1e-3)
+    for p in q:
+        p.grad = torch.ones_like(p)
+    o4.step()
+    assert o4.layout() == [('#0', (8,)), ('#1', (8,))]
+
+
 def test_fpl_matches_oracle():
     """fused FPL (sort + bin means + loss + backward) vs the oracle on a size where bins hold ~190 pixels"""
     from tcct_amd import ops
