@@ -433,23 +433,16 @@ int tcct_mse_bwd(const float* a, const float* b, int64_t n, const float* grad_ou
 
 /* ---- feature-polarization loss (RegNet.regular_udh nets/reg.py:86-105; points_selection_bins nets/fcs.py:25-50;
  * cosinesim fcs.py:63-80; FeatConPolar.choice nets/fcp.py:72-75) ------------------------------------------- */
-int64_t tcct_fpl_sort_workspace_bytes(int64_t M);
-int tcct_fpl_sort(const uint8_t* labels, const float* prob, int64_t M, uint64_t* keys_in, uint32_t* vals_in,
-                  uint64_t* keys_out, uint32_t* vals_out, uint32_t* counts /*[8]*/, void* workspace,
-                  int64_t workspace_bytes, tcct_stream_t stream);
 /* Bin assignment without a sort (round 3): radix multi-select of the 32 bin boundaries per class on the unique key (~prob, pixel index) --
- * the order the stable sort above produced -- then bin map + bin sums in ONE coalesced pass over the feature rows (reference nets/fcs.py:25-50).
+ * the order of a stable descending sort by probability -- then bin map + bin sums in ONE coalesced pass over the feature rows (reference nets/fcs.py:25-50).
  * counts [16] uint32, binmap [M] (255 = dropped), pro_sum [C][32][32] fp32 (cleared here); workspace: tcct_fpl_select_workspace_bytes(). */
 int64_t tcct_fpl_select_workspace_bytes();
 int tcct_fpl_select(const void* feat, const uint8_t* labels, const float* prob, int64_t M, int C, void* workspace, uint32_t* counts,
                     uint8_t* binmap, float* pro_sum, int dtype, tcct_stream_t stream);
-/* prototypes, loss and d loss / d prototype (already divided by the bin size) from the bin sums: the tail of tcct_fpl_forward */
+/* prototypes, loss and d loss / d prototype (already divided by the bin size) from the bin sums; pro_sum/pro/dpro_over_n fp32 [C,32,32] */
 int tcct_fpl_loss(const float* pro_sum, const uint32_t* counts, const float* buf_grad, int C, float* pro, float* loss, float* dpro_over_n,
                   tcct_stream_t stream);
-/* feat [M,32]; pro_sum/pro/dpro_over_n fp32 [C,32,32]; binmap uint8 [M] (bin 0..31, 255 = not selected) */
-int tcct_fpl_forward(const void* feat, const uint64_t* keys_sorted, const uint32_t* vals_sorted, const uint32_t* counts,
-                     int64_t M, int C, const float* buf_grad, float* pro_sum, float* pro, float* loss,
-                     float* dpro_over_n, uint8_t* binmap, int dtype, tcct_stream_t stream);
+/* binmap uint8 [M] (bin 0..31, 255 = not selected); dfeat [M,32] */
 int tcct_fpl_backward(const uint8_t* labels, const uint8_t* binmap, const float* dpro_over_n, const float* grad_out,
                       float grad_scale, int64_t M, void* dfeat, int dtype, tcct_stream_t stream);
 

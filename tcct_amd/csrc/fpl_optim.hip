@@ -2,108 +2,18 @@
 // clip_grad_norm_ + AdamW step (kite/loop_seg.py:128-130, kite/loopback.py:127).
 //
 // FPL pipeline (per step, all classes at once because the label classes partition the pixels):
-//   key[p]  = (label[p] << 32) | ~bits(prob_label[p])          -> ascending sort == per class, descending prob
-//   sort    : rocPRIM device radix sort (36 significant bits: 4 class bits + 32 probability bits) — the one library primitive used on the path
-//   binmean : sorted position r of class c (segment offset off_c, n_c pixels, N_c = n_c/32) falls in bin r/N_c
-//             (tail n_c%32 dropped); 8 lanes gather one 32-channel feature row; register run-length accumulation,
-//             fp32 atomics per (class, bin) flush
+//   bins    : fpl_select.hip -- radix multi-select of the 32 bin boundaries per class on the key (~prob, pixel index), i.e. the order a stable
+//             descending sort by probability gives (nets/fcs.py:25-50), bin map + one-hot MFMA bin sums; NO sort and no library primitive
+//             (rounds 1-2 used a rocPRIM radix sort here; round 4 removed it from the library -- the sorted binning lives on as the
+//             test-side reference of tests/test_kernels_gpu.py::test_fpl_multiselect_equals_the_sorted_binning)
+//   loss    : prototypes = bin sums / N_c, cosine term + MSE of the last class (this file)
 //   backward: dfeat[p] = dpro[label[p]][bin[p]] / N_c  (coalesced, bin map written in the forward)
 #include "common.h"
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #define FB 256
 #define FPL_BINS 32
 #define FPL_MAXC 16     // classes (power of two): 5 for GOALS, 9 for the reference's Duke / HCMS models
-
-__global__ void k_fpl_keys(const uint8_t* __restrict__ lab, const float* __restrict__ prob, int64_t M,
-                           unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ counts) {
-    __shared__ uint32_t sc[FPL_MAXC];
-    if (threadIdx.x < FPL_MAXC) sc[threadIdx.x] = 0;
-    __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t l = lab[i];
-        uint32_t b = ~__float_as_uint(prob[i]);           // prob >= 0: uint order == float order; ~ => descending
-        keys[i] = ((unsigned long long)l << 32) | b;
-        vals[i] = (uint32_t)i;
-        atomicAdd(&sc[l & (FPL_MAXC - 1)], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < FPL_MAXC && sc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], sc[threadIdx.x]);
-}
-
-extern "C" int64_t tcct_fpl_sort_workspace_bytes(int64_t M) {
-    size_t bytes = 0;
-    unsigned long long* k = nullptr;
-    uint32_t* v = nullptr;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)M, 0, 36, (hipStream_t)0, false);
-    if (e != hipSuccess) return -1;
-    return (int64_t)bytes;
-}
-
-/* keys/vals in -> sorted out.  counts[FPL_MAXC] (uint32) receives the per-class pixel counts. */
-extern "C" int tcct_fpl_sort(const uint8_t* labels, const float* prob, int64_t M, uint64_t* keys_in, uint32_t* vals_in,
-                             uint64_t* keys_out, uint32_t* vals_out, uint32_t* counts, void* workspace,
-                             int64_t workspace_bytes, tcct_stream_t stream) {
-    hipStream_t st = (hipStream_t)stream;
-    TCCT_CHECK(M > 0 && M < (1LL << 32), "fpl_sort: M out of range");
-    if (hipMemsetAsync(counts, 0, sizeof(uint32_t) * FPL_MAXC, st) != hipSuccess) { tcct_set_error("fpl_sort: memset failed"); return -2; }
-    hipLaunchKernelGGL(k_fpl_keys, dim3(tcct_grid(M, FB, 2048)), dim3(FB), 0, st, labels, prob, M, (unsigned long long*)keys_in, vals_in, counts);
-    size_t bytes = (size_t)workspace_bytes;
-    hipError_t e = rocprim::radix_sort_pairs(workspace, bytes, (unsigned long long*)keys_in, (unsigned long long*)keys_out,
-                                             vals_in, vals_out, (size_t)M, 0, 36, st, false);
-    if (e != hipSuccess) { tcct_set_error("fpl_sort: rocprim radix_sort_pairs failed: %s", hipGetErrorString(e)); return -2; }
-    TCCT_LAUNCH_OK();
-}
-
-// 8 lanes per sorted position; each 8-lane group walks RUN consecutive positions.
-#define FPL_RUN 64
-template <typename T>
-__global__ void k_fpl_binmean(const T* __restrict__ feat /*[M,32]*/, const unsigned long long* __restrict__ keys,
-                              const uint32_t* __restrict__ vals, const uint32_t* __restrict__ counts, int64_t M, int C,
-                              float* __restrict__ pro_sum /*[C][32][32]*/, uint8_t* __restrict__ binmap /*[M]*/) {
-    __shared__ uint32_t off[FPL_MAXC + 1];
-    if (threadIdx.x == 0) {
-        uint32_t a = 0;
-        for (int c = 0; c < FPL_MAXC; ++c) { off[c] = a; a += counts[c]; }
-        off[FPL_MAXC] = a;
-    }
-    __syncthreads();
-    const int sub = threadIdx.x & 7;
-    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-    const int64_t r0 = grp * FPL_RUN;
-    if (r0 >= M) return;
-    const int64_t r1 = min(M, r0 + FPL_RUN);
-    f4 acc = f4zero();
-    int cur = -1;     // class*32 + bin of the running accumulation
-    for (int64_t r = r0; r < r1; ++r) {
-        int c = (int)(keys[r] >> 32);
-        uint32_t pix = vals[r];
-        uint32_t nc = counts[c];
-        uint32_t Nb = nc / FPL_BINS;
-        uint32_t rr = (uint32_t)(r - off[c]);
-        int b = Nb ? (int)(rr / Nb) : FPL_BINS;
-        int id = (b < FPL_BINS && c < C) ? c * FPL_BINS + b : -1;
-        if (sub == 0) binmap[pix] = id >= 0 ? (uint8_t)b : (uint8_t)255;
-        if (id != cur) {
-            if (cur >= 0) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) atomicAdd(&pro_sum[cur * 32 + sub * 4 + k], acc.v[k]);
-            }
-            acc = f4zero();
-            cur = id;
-        }
-        if (id >= 0) {
-            f4 v = ld4(feat + (int64_t)pix * 32 + sub * 4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc.v[k] += v.v[k];
-        }
-    }
-    if (cur >= 0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(&pro_sum[cur * 32 + sub * 4 + k], acc.v[k]);
-    }
-}
 
 // pro = pro_sum / N_c ; loss = sum_c -(1/32) * mean_n(pro_c[n] . buf_c) + mse(pro_last, tgt_last) ; dpro (already / N_c)
 __global__ void k_fpl_loss(const float* __restrict__ pro_sum, const uint32_t* __restrict__ counts, const float* __restrict__ buf /*[C][32]*/,
@@ -126,21 +36,7 @@ __global__ void k_fpl_loss(const float* __restrict__ pro_sum, const uint32_t* __
     if (threadIdx.x == 0) *loss = part;
 }
 
-extern "C" int tcct_fpl_forward(const void* feat, const uint64_t* keys_sorted, const uint32_t* vals_sorted,
-                                const uint32_t* counts, int64_t M, int C, const float* buf_grad, float* pro_sum, float* pro,
-                                float* loss, float* dpro_over_n, uint8_t* binmap, int dtype, tcct_stream_t stream) {
-    hipStream_t st = (hipStream_t)stream;
-    TCCT_CHECK(C >= 1 && C <= FPL_MAXC, "fpl_forward: C=%d unsupported", C);
-    if (hipMemsetAsync(pro_sum, 0, sizeof(float) * C * 32 * 32, st) != hipSuccess) { tcct_set_error("fpl_forward: memset failed"); return -2; }
-    int64_t groups = (M + FPL_RUN - 1) / FPL_RUN;
-    int64_t threads = groups * 8;
-    int grid = (int)((threads + FB - 1) / FB);
-    TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_fpl_binmean<T>, dim3(grid), dim3(FB), 0, st, (const T*)feat, (const unsigned long long*)keys_sorted, vals_sorted, counts, M, C, pro_sum, binmap));
-    hipLaunchKernelGGL(k_fpl_loss, dim3(1), dim3(FB), 0, st, pro_sum, counts, buf_grad, C, pro, loss, dpro_over_n);
-    TCCT_LAUNCH_OK();
-}
-
-/* the loss part of tcct_fpl_forward alone, for bin sums that came out of tcct_fpl_select */
+/* prototypes, loss and d loss / d prototype from the bin sums of tcct_fpl_select */
 extern "C" int tcct_fpl_loss(const float* pro_sum, const uint32_t* counts, const float* buf_grad, int C, float* pro, float* loss, float* dpro_over_n,
                              tcct_stream_t stream) {
     TCCT_CHECK(C >= 1 && C <= FPL_MAXC, "fpl_loss: C=%d unsupported", C);

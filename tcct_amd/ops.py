@@ -2166,9 +2166,6 @@ def label_planes(labels, start, n, want_onehot=True, want_edge=True):
     return oh, ed
 
 
-FPL_SORT = os.environ.get('TCCT_FPL_SORT', '0') == '1'        # =1: the library radix sort of rounds 1-2 (A/B timing, bisecting)
-
-
 class _Fpl(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, logits, labels, buf_grad):
@@ -2187,22 +2184,10 @@ class _Fpl(torch.autograd.Function):
         dpro = torch.empty((C, 32, 32), device=dev, dtype=torch.float32)
         loss = torch.empty((), device=dev, dtype=torch.float32)
         binmap = torch.empty(M, device=dev, dtype=torch.uint8)
-        if FPL_SORT:        # round-1/2 form: one 36-bit rocPRIM radix sort of (label, ~prob) + a gather of the feature rows in sorted order
-            keys_in = torch.empty(M, device=dev, dtype=torch.int64)
-            keys_out = torch.empty(M, device=dev, dtype=torch.int64)
-            vals_in = torch.empty(M, device=dev, dtype=torch.int32)
-            vals_out = torch.empty(M, device=dev, dtype=torch.int32)
-            wsb = lib.fpl_sort_workspace_bytes(M)
-            if wsb < 0:
-                raise TcctError('fpl_sort_workspace_bytes failed')
-            ws = torch.empty(max(int(wsb), 16), device=dev, dtype=torch.uint8)
-            lib.fpl_sort(labels, prob, M, keys_in, vals_in, keys_out, vals_out, counts, ws, int(wsb))
-            lib.fpl_forward(feat, keys_out, vals_out, counts, M, C, buf_grad, pro_sum, pro, loss, dpro, binmap,
-                            dtype_code(feat.dtype))
-        else:               # radix multi-select of the 32 bin boundaries per class + bin sums in pixel order (fpl_select.hip): no sort, no gather
-            ws = torch.empty(int(lib.fpl_select_workspace_bytes()), device=dev, dtype=torch.uint8)
-            lib.fpl_select(feat, labels, prob, M, C, ws, counts, binmap, pro_sum, dtype_code(feat.dtype))
-            lib.fpl_loss(pro_sum, counts, buf_grad, C, pro, loss, dpro)
+        # radix multi-select of the 32 bin boundaries per class + bin sums in pixel order (fpl_select.hip): no sort, no gather
+        ws = torch.empty(int(lib.fpl_select_workspace_bytes()), device=dev, dtype=torch.uint8)
+        lib.fpl_select(feat, labels, prob, M, C, ws, counts, binmap, pro_sum, dtype_code(feat.dtype))
+        lib.fpl_loss(pro_sum, counts, buf_grad, C, pro, loss, dpro)
         ctx.save_for_backward(labels, binmap, dpro)
         ctx.cfg = (feat.shape, feat.dtype, M)
         ctx.mark_non_differentiable(pro)

@@ -1534,12 +1534,15 @@ def test_pointwise_conv_batchnorm_fused_node(cfg, hw):
 
 @pytest.mark.parametrize('cfg', [(2, 96, 160, 5, 0.0), (2, 64, 80, 9, 0.5), (1, 40, 50, 5, 4.0), (3, 33, 47, 9, 1.0), (1, 800, 1104, 5, 0.25)])
 def test_fpl_multiselect_equals_the_sorted_binning(cfg):
-    """tcct_fpl_select (round 3: radix multi-select of the bin boundaries, no sort) against the stable radix sort it replaces (TCCT_FPL_SORT=1
-    path): both order a class by (probability descending, pixel index ascending), so prototypes, loss and feature gradients must agree to
-    summation-order noise -- including HEAVY TIES (logits quantised to multiples of `q`: thousands of pixels share one probability, boundaries
-    fall inside tie groups and are resolved by the index bytes of the key), a class with fewer than 32 pixels (no full bin: NaN prototypes, as
-    in the reference), a class whose count is a multiple of 32 (no dropped tail) and 9 classes (the reference's Duke models)."""
+    """tcct_fpl_select (radix multi-select of the bin boundaries, no sort) against the STABLE SORT it replaces, restated here on the CPU: a class is
+    ordered by (probability descending, pixel index ascending) -- torch.sort(descending=True, stable=True) on the exact fp32 probabilities the
+    device computed -- and rank r falls into bin r // (n_c // 32), tail dropped (reference nets/fcs.py:25-50).  Prototypes, loss and feature
+    gradients must agree to summation-order noise -- including HEAVY TIES (logits quantised to multiples of `q`: thousands of pixels share one
+    probability, boundaries fall inside tie groups and are resolved by the index bytes of the key), a class with fewer than 32 pixels (no full bin:
+    NaN prototypes, as in the reference), a class whose count is a multiple of 32 (no dropped tail) and 9 classes (the reference's Duke models).
+    (Rounds 1-3 kept a rocPRIM radix sort in the library as the other arm of this test; round 4 removed it.)"""
     from tcct_amd import ops
+    from tcct_amd._lib import lib
     B, H, W, C, q = cfg
     g = torch.Generator().manual_seed(B * 1000 + H + C)
     lab = torch.randint(0, C, (B, H, W), generator=g)
@@ -1555,26 +1558,45 @@ def test_fpl_multiselect_equals_the_sorted_binning(cfg):
     if q > 0:
         logits = torch.round(logits / q) * q
     feats = torch.randn(B, 32, H, W, generator=g)
-    buf = F.normalize(torch.rand(C, 32, generator=g), dim=-1).cuda()
+    buf = F.normalize(torch.rand(C, 32, generator=g), dim=-1)
     labd = lab.to(torch.uint8).cuda()
-    res = []
-    for sort in (True, False):
-        ops.FPL_SORT = sort
-        try:
-            fd = nhwc(feats, torch.float32).requires_grad_(True)
-            ld, pro = ops.fpl(fd, nhwc(logits, torch.float32), labd, buf)
-            (ld * 0.7).backward()
-            res.append((ld.detach().cpu(), pro.detach().cpu(), fd.grad.cpu()))
-        finally:
-            ops.FPL_SORT = False
-    (l0, p0, g0), (l1, p1, g1) = res
+    fd = nhwc(feats, torch.float32).requires_grad_(True)
+    lgd = nhwc(logits, torch.float32)
+    ld, pro = ops.fpl(fd, lgd, labd, buf.cuda())
+    (ld * 0.7).backward()
+    l1, p1, g1 = ld.detach().cpu(), pro.detach().cpu(), fd.grad.cpu().reshape(-1, 32)
+    # ---- the sorted binning, on the probabilities the device path sorts by
+    M = B * H * W
+    prob = torch.empty(M, device='cuda', dtype=torch.float32)
+    lib.softmax_pick(lgd, labd, M, C, prob, None, 0)
+    prob, labf = prob.cpu(), lab.reshape(-1)
+    fr = feats.permute(0, 2, 3, 1).reshape(M, 32).double().requires_grad_(True)
+    los, pros = 0, []
+    for c in range(C):
+        pix = (labf == c).nonzero().view(-1)
+        order = torch.sort(prob[pix], descending=True, stable=True).indices       # ties keep ascending pixel index
+        n = pix.numel() // 32
+        if n == 0:
+            pros.append(torch.full((32, 32), float('nan'), dtype=torch.float64))
+            los = los + float('nan')
+            continue
+        pr = fr[pix[order][:32 * n]].view(32, n, 32).mean(1)
+        tgt = buf[c:c + 1].double().expand(32, -1)
+        los = los - torch.einsum('nc,kc->nk', pr, tgt).mean() / 32
+        pros.append(pr)
+    if n:
+        los = los + F.mse_loss(pr, tgt)
+    p0 = torch.stack([x.detach() for x in pros]).float()
     fin = torch.isfinite(p0)
     assert torch.equal(fin, torch.isfinite(p1))                                 # the same classes are NaN (no full bin) in both
     if C == 9:
         assert not fin[7].any() and fin[0].all()
     assert torch.allclose(p0[fin], p1[fin], rtol=1e-4, atol=1e-5)
     if fin.all():
-        assert torch.allclose(l0, l1, rtol=1e-5, atol=1e-6)
-    ok = torch.isfinite(g0) & torch.isfinite(g1)
-    assert torch.equal(torch.isfinite(g0), torch.isfinite(g1)) and torch.allclose(g0[ok], g1[ok], rtol=1e-4, atol=1e-9)
-    assert (g0[ok] != 0).any()
+        assert torch.allclose(los.detach().float(), l1, rtol=1e-5, atol=1e-6)
+        (los * 0.7).backward()
+        g0 = fr.grad.float()
+        assert torch.allclose(g0, g1, rtol=1e-4, atol=1e-9) and (g0 != 0).any()
+        assert torch.equal(g0 != 0, g1 != 0)                                    # exactly the same pixels were selected (bins incl. the tie groups)
+    else:   # a class without a full bin: the reference's loss is NaN; the selected pixels of the other classes still match by prototype
+        assert not torch.isfinite(l1)

@@ -100,7 +100,7 @@ if os.path.exists(f'{G}/{tag}_stepfl/stepfl_kernel_stats.csv'):
     for d, r in extra[:16]:
         if d > 0.02e6 * nsteps:
             L.append(f'| `{r["Name"].split("(")[0][:80]}` | {int(r["Calls"]) // nsteps} | {d / 1e6 / nsteps:.3f} |')
-    L.append(f'\nrocPRIM symbols in this trace: {sum(1 for r in sfl if "rocprim" in r["Name"])} (the library sort is gone from the default path; `TCCT_FPL_SORT=1` restores it).')
+    L.append(f'\nrocPRIM symbols in this trace: {sum(1 for r in sfl if "rocprim" in r["Name"])} (round 4: the library sort is gone from `libtcct_hip.so` altogether).')
 if os.path.exists(f'{G}/{tag}_lroof/lroof_kernel_stats.csv'):
     lroof = list(csv.DictReader(open(f'{G}/{tag}_lroof/lroof_kernel_stats.csv')))
     lp = {}
