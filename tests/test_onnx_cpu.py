@@ -94,3 +94,87 @@ def test_export_from_a_model_object_and_loud_errors(tmp_path):
         export_onnx(RegNet(stc_tt(5, legacy_heads=True), out_channels=5), path)
     with pytest.raises(TcctError):
         export_onnx(net, path, in_channels=1)
+
+
+def test_exported_file_passes_the_onnx_spec_structure_check(tmp_path):
+    """tests/onnx_spec_check.py: the file is decoded by Google's protobuf runtime against the message schemas of onnx.proto3 (a third-party reader
+    of the wire format, unlike tests/onnx_mini_runtime.py) and checked against the IR rules and the opset-11 operator schemas, all restated from
+    the ONNX specification -- field numbers, ir_version / opset_import, every node's op_type, arity, attribute names and types, topological
+    order, the dynamic-axis dim_params, plus a channel-count propagation through the convolutional part.  NOT onnx.checker / onnxruntime:
+    neither has ever opened a file written by the exporter."""
+    import onnx_spec_check as S
+    import tcct_oracle as O
+    from tcct_amd.onnx_export import export_onnx
+    sd, _ = _duke_state_dict()
+    path = str(tmp_path / 'duke.onnx')
+    names = export_onnx(sd, path)
+    dyn = ['batch', 9, 'height', 'width']
+    m, chan = S.check_model(path, opset=11, expect_inputs={'input': ['batch', 3, 'height', 'width']}, expect_outputs={n: dyn for n in names})
+    assert m.producer_name and len(m.graph.node) > 400 and all(chan[n] == 9 for n in names)
+    sd5 = O.formula_state_dict([(k, tuple(s)) for k, s in json.load(open(os.path.join(GOLD, 'state_dict_keys.json')))])
+    p5 = str(tmp_path / 'five.onnx')
+    S.check_model(p5 if export_onnx(sd5, p5) else p5, expect_outputs={n: ['batch', 5, 'height', 'width'] for n in names})
+
+
+def test_the_structure_check_rejects_malformed_files(tmp_path):
+    """the validator has teeth: each of these mutations of a good file must be reported"""
+    import onnx_spec_check as S
+    import tcct_oracle as O
+    from tcct_amd.onnx_export import export_onnx
+    sd = O.formula_state_dict([(k, tuple(s)) for k, s in json.load(open(os.path.join(GOLD, 'state_dict_keys.json')))])
+    path = str(tmp_path / 'net.onnx')
+    export_onnx(sd, path)
+    good = S.parse(path)
+
+    def mutated(fn):
+        m = S.parse(good.SerializeToString())
+        fn(m)
+        with pytest.raises(AssertionError) as e:
+            S.check_model(m.SerializeToString())
+        return str(e.value)
+    conv = next(i for i, n in enumerate(good.graph.node) if n.op_type == 'Conv')
+    rs = next(i for i, n in enumerate(good.graph.node) if n.op_type == 'Resize')
+
+    def swap(m):            # consumer before producer
+        nodes = list(m.graph.node)
+        j = next(i for i, n in enumerate(nodes) if nodes[conv].output[0] in n.input)
+        nodes[conv], nodes[j] = nodes[j], nodes[conv]
+        del m.graph.node[:]
+        m.graph.node.extend(nodes)
+    assert 'topological order' in mutated(swap)
+    assert 'ir_version' in mutated(lambda m: setattr(m, 'ir_version', 3))
+    assert 'opset_import' in mutated(lambda m: setattr(m.opset_import[0], 'version', 9))
+    assert 'not in the schema' in mutated(lambda m: setattr(m.graph.node[conv].attribute[0], 'name', 'kernel'))
+
+    def wrong_type(m):
+        a = next(a for a in m.graph.node[conv].attribute if a.name == 'group')
+        a.type = S.ATTR['FLOAT']
+    assert "schema says INT" in mutated(wrong_type)
+    assert 'operator not in the opset-11 table' in mutated(lambda m: setattr(m.graph.node[conv], 'op_type', 'ConvFancy'))
+    assert 'inputs, schema allows' in mutated(lambda m: m.graph.node[conv].input.append('input'))
+    assert 'SSA' in mutated(lambda m: m.graph.node[conv + 1].output.__setitem__(0, m.graph.node[conv].output[0]))
+    assert 'dim_value or dim_param' in mutated(lambda m: m.graph.input[0].type.tensor_type.shape.dim[0].ClearField('dim_param'))
+    assert 'not one of' in mutated(lambda m: [setattr(a, 's', b'bilinear') for a in m.graph.node[rs].attribute if a.name == 'mode'])
+
+    def both(m):            # Resize with scales AND sizes
+        n = m.graph.node[rs]
+        a, b = (m.graph.initializer.add(name='bogus_scales', data_type=1, dims=[4], raw_data=np.ones(4, np.float32).tobytes()),
+                m.graph.initializer.add(name='bogus_sizes', data_type=7, dims=[4], raw_data=np.ones(4, np.int64).tobytes()))
+        del n.input[2:]
+        n.input.extend([a.name, b.name])
+    assert 'exactly ONE of scales / sizes' in mutated(both)
+
+    def chans(m):           # a BatchNorm fed with the wrong number of channels
+        bn = next(n for n in m.graph.node if n.op_type == 'BatchNormalization')
+        for t in m.graph.initializer:
+            if t.name in list(bn.input[1:5]):
+                a = S.tensor_array(t)
+                t.dims[0] = a.shape[0] - 1
+                t.raw_data = a[:-1].tobytes()
+    assert 'statistics for' in mutated(chans)
+    # a field number the schema does not know (e.g. a writer that put op_type under 14): reported as unknown, not silently dropped
+    raw = bytearray(good.graph.node[conv].SerializeToString()) + bytes([14 << 3 | 2, 1, 65])
+    m = S.parse(good.SerializeToString())
+    m.graph.node[conv].ParseFromString(bytes(raw))
+    with pytest.raises(AssertionError, match='not in onnx.proto3'):
+        S.check_model(m.SerializeToString())
