@@ -135,8 +135,21 @@ class KiteSeg(KiteBack):
         so that the replicas draw DIFFERENT DropPath masks and Gumbel / jitter noise for their different shards (rank 0 == the reference)"""
         return epoch * 311 + 2023 + self.rank
 
-    def train(self, epoch, alpha=.9):
+    def _global_batches(self, epoch):
+        """iterator over the GLOBAL minibatches of one epoch, identical on every rank, with the process left on its PER-RANK noise stream.
+        The loader's order must be fixed BEFORE the per-rank reseed: a multi-worker DataLoader draws its base seed (and a shuffling sampler its
+        permutation seed) when the iterator is created, but with num_workers=0 RandomSampler draws its seed lazily at the first next() -- after a
+        per-rank reseed every rank would then shuffle differently and slice a different global batch (duplicated and omitted samples).  So the
+        first batch is pulled here, under the common seed."""
+        import itertools
         setup_seed(epoch * 311 + 2023)          # reference loop_seg.py:109; also what a shuffling loader draws its order from: the same on every rank
+        it = iter(self.dataset.trainSet(bs=self.args.bs * self.world))
+        first = next(it, None)                  # forces the sampler's seed draw (num_workers=0) under the common seed
+        if self.world > 1:
+            setup_seed(self.epoch_seed(epoch))  # from here on the per-rank noise stream (DropPath masks, Gumbel / jitter draws)
+        return it if first is None else itertools.chain([first], it)
+
+    def train(self, epoch, alpha=.9):
         torch.set_grad_enabled(True)
         self.model.train()
         tot = torch.zeros((), device=self.device)
@@ -144,9 +157,7 @@ class KiteSeg(KiteBack):
         # contiguous slice of it (tcct_amd.dist.shard_batch; SURVEY 8(e): global 64 -> 8 x 8), so the ranks see different B-scans and run
         # the same number of steps.  A ragged last global batch that does not divide by the world size is dropped on every rank.
         from .. import dist as tdist
-        batches = iter(self.dataset.trainSet(bs=self.args.bs * self.world))      # the loader's order is fixed here, identically on all ranks
-        if self.world > 1:
-            setup_seed(self.epoch_seed(epoch))  # from here on the per-rank noise stream (DropPath masks, Gumbel / jitter draws)
+        batches = self._global_batches(epoch)
         for i, imgs in enumerate(batches):
             img, lab, _, _ = self.dataset.parse(imgs)
             if self.world > 1:

@@ -296,3 +296,24 @@ def test_bench_eight_ranks_through_the_launcher_stub_trainer():
     assert got['config']['backend'] == 'gloo' and len(got['config']['rank_devices']) == 8
     assert got['metric'].startswith('STUB') and got['data'].startswith('stub') and 'roofline' not in got and 'cpu_baseline' not in got
     assert got['steps'] == 3 and got['value'] > 0
+
+
+def test_ranks_slice_the_same_shuffled_global_batches_with_a_single_process_loader():
+    """with `shuffle=True, num_workers=0` RandomSampler draws its seed lazily at the first next(); KiteSeg must fix the loader order
+    under the COMMON epoch seed before it switches to the per-rank noise seed, or every rank slices a different global batch"""
+    import types
+    from torch.utils.data import DataLoader, TensorDataset
+    from tcct_amd.kite.loop_seg import KiteSeg
+
+    class DS:
+        def trainSet(self, bs):
+            return DataLoader(TensorDataset(torch.arange(64)), batch_size=bs, shuffle=True, num_workers=0)
+    orders, noise = [], []
+    for rank in (0, 1, 2):
+        ns = types.SimpleNamespace(dataset=DS(), args=types.SimpleNamespace(bs=4), world=4, rank=rank)
+        ns.epoch_seed = lambda e, ns=ns: KiteSeg.epoch_seed(ns, e)
+        orders.append(torch.cat([b[0] for b in KiteSeg._global_batches(ns, 3)]))
+        noise.append(torch.rand(4))
+    assert sorted(orders[0].tolist()) == list(range(64)) and orders[0].tolist() != list(range(64))        # a permutation, shuffled
+    assert torch.equal(orders[0], orders[1]) and torch.equal(orders[0], orders[2])                       # the same on every rank
+    assert not torch.equal(noise[0], noise[1]) and not torch.equal(noise[1], noise[2])                   # ... while the noise streams differ

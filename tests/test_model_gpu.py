@@ -64,6 +64,10 @@ def run_losses(k, fx, img, lab):
 
 @pytest.mark.parametrize('name', ['full_2x32x32', 'full_2x64x64', 'di_2x64x64', 'reg_2x64x64', 'full_2x128x128'])
 def test_fp32_matches_reference_fixture(name, tmp_path):
+    """ILL-CONDITIONED CONTROL (round 4): the formula-weight fixtures.  Their train-mode network amplifies a 1e-7 disturbance ~4e4-fold (batch
+    variances at fp32 rounding level at the 2x2 / 4x4 maps, profiles/r03_parity.md 3), so heads / gradients are bounded by fp64 envelopes here.
+    The STRICT checks -- literal 1e-3 on everything against the reference, fp32 and bf16 -- are test_trained_weights_train_step_matches_reference
+    and test_bf16_train_step_against_the_reference on the reference-trained fixtures (5 classes: cfg1 / cfg3 / cfg4; 9 classes: Duke)."""
     fx = dict(np.load(os.path.join(GOLD, name + '.npz')))
     model, sd0 = build(torch.float32)
     udh, reg = bool(fx['flags'][0]), bool(fx['flags'][1])
@@ -136,12 +140,8 @@ def test_fp32_matches_reference_fixture(name, tmp_path):
     #     |g_hip - g64| <= 4 max_variants|g_fp32 - g64| + 2e-4 |g64| + 1e-6 max|g|
     # with g_fp32/g64 from the oracle (pinned to the reference at 2e-5 by oracle/make_golden.py), plus a direct check
     # of the HIP gradient norms against the reference's fixture at the noise level measured for that tensor.
-    def oracle_grads(dt, channels_last=False, perturb=0.0, wnoise=0.0):
+    def oracle_grads(dt, channels_last=False, perturb=0.0):
         sd = {kk: (v.to(dt) if v.is_floating_point() else v.clone()) for kk, v in O.formula_state_dict(keys()).items()}
-        if wnoise:
-            gen = torch.Generator().manual_seed(1)
-            for n in names:
-                sd[n] = sd[n] * (1 + wnoise * torch.randn(sd[n].shape, generator=gen).to(dt))
         for n in names:
             sd[n].requires_grad_(True)
         oh = torch.nn.functional.one_hot(lab.cpu(), 5).permute(0, 3, 1, 2)
