@@ -144,6 +144,26 @@ flat.copy_(per_sample[sl].sum(0))
 gb.on_mark('dec')
 gb.finish()
 assert gb.launch_log == [(0, 'step'), (1, 'step'), (2, 'step')] and torch.allclose(flat, per_sample.sum(0), atol=1e-5)
+# fallback: a gradient of bucket 0 arrived through autograd (p.grad is a tensor that is NOT its slot of the flat buffer) -> step() will copy it
+# in later, an early launch would send stale data: the early launches are called off, everything leaves in finish(), sums still right
+flat.copy_(per_sample[sl].sum(0))
+slot_p = torch.nn.Parameter(torch.zeros(300)); slot_p._grad_slot = flat[:300]; slot_p.grad = None           # written in place by a kernel
+auto_p = torch.nn.Parameter(torch.zeros(500)); auto_p._grad_slot = flat[300:800]; auto_p.grad = torch.ones(500)      # delivered by autograd
+tail_p = torch.nn.Parameter(torch.zeros(200)); tail_p._grad_slot = flat[800:]
+gb2 = tdist.GradBuckets()
+gb2.bind(flat, [300, 500, 200], [slot_p, auto_p, tail_p])
+gb2.begin_step(armed=True)
+gb2.on_mark('dec'); gb2.on_mark('deep')
+assert gb2.launch_log == [(0, 'backward')] and gb2.fallbacks == 1 and not gb2.armed, (gb2.launch_log, gb2.fallbacks)
+gb2.finish()
+assert gb2.launch_log == [(0, 'backward'), (1, 'step'), (2, 'step')] and torch.allclose(flat, per_sample.sum(0), atol=1e-5)
+gb2.begin_step(armed=True)                 # the same with the offending gradient in bucket 0: nothing leaves early
+flat.copy_(per_sample[sl].sum(0))
+slot_p.grad, auto_p.grad = torch.ones(300), None
+gb2.on_mark('dec'); gb2.on_mark('deep')
+assert gb2.launch_log == [] and gb2.fallbacks == 2
+gb2.finish()
+assert [w for _, w in gb2.launch_log] == ['step'] * 3 and torch.allclose(flat, per_sample.sum(0), atol=1e-5)
 # BatchNorm buffers averaged before validation: every rank evaluates the same model
 bn = torch.nn.BatchNorm2d(3)
 with torch.no_grad():
