@@ -309,6 +309,22 @@ int tcct_c3_fwd(const void* x4, const float* w, const float* bias, void* y, int 
 /* its weight / bias gradient: dw fp32 [32,3,3,3], dbias fp32 [32] (nullable), overwritten; dy bf16 [B,Ho,Wo,32] (what autograd computes for
  * `F.conv2d(x, w, b, stride, 1)` at nets/tcct.py:873 / :80; the image needs no gradient) */
 int tcct_c3_wgrad(const void* x4, const void* dy, float* dw, float* dbias, int B, int H, int W, int stride, tcct_stream_t stream);
+/* The same first layers TOGETHER with the train-mode BatchNorm behind them as one store (round 4; csrc/c3_bn.hip): `self.cnn = Sequential(Conv2d(3, 32,
+ * 3, 1, 1), BatchNorm2d(32))` (nets/tcct.py:873, post_act none) and `stem[0] = Conv2d_BN(3, 32, 3, 2, 1, act=Hardswish)` (nets/tcct.py:55-97,674-681,
+ * post_act hswish).  The convolution output y is recomputed from the 4-channel image instead of being stored and re-read:
+ *   fwd_train : statistics pass (no store) + normalising pass, z = post_act(a y + b) bf16 [B,Ho,Wo,32]; sums fp64 [64] (zero on entry) receives the
+ *               batch sums of y; running_mean / running_var / num_batches_tracked are updated (nullable); mean_rstd [64], ab [64] for the backward
+ *   bwd_reduce: raw fp64 [64] (zero on entry) = {sum dz', sum dz' y}, dz' = dz post_act'(a y + b); feed it to tcct_bn_bwd_coef(raw = 1), which
+ *               also writes dgamma / dbeta
+ *   bwd_wgrad : dw fp32 [32,3,3,3], dbias fp32 [32] (nullable) of the convolution from dy = c1 dz' + c2 y + c3 rebuilt in registers
+ *               (coef fp32 [160] = {c1, c2, c3, a, b} of tcct_bn_bwd_coef); both overwritten */
+int tcct_c3_bn_fwd_train(const void* x4, const float* w, const float* bias, void* z, int B, int H, int W, int stride, double* sums,
+                         const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                         int64_t* num_batches_tracked, float* mean_rstd, float* ab, int post_act, tcct_stream_t stream);
+int tcct_c3_bn_bwd_reduce(const void* x4, const float* w, const float* bias, const void* dz, int B, int H, int W, int stride, const float* ab,
+                          double* raw, int post_act, tcct_stream_t stream);
+int tcct_c3_bn_bwd_wgrad(const void* x4, const float* w, const float* bias, const void* dz, int B, int H, int W, int stride, const float* coef,
+                         float* dw, float* dbias, int post_act, tcct_stream_t stream);
 /* weight gradient of 1x1 convs with <= 8 outputs (5-class aux heads, nets/tcct.py:994-997); dy fp32 or bf16 */
 int tcct_pw_wgrad_smalln(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, int x_dtype,
                          int dy_dtype, tcct_stream_t stream);

@@ -117,7 +117,7 @@ def cross_block(sd, p, x, k, train):
 
 def cnn_branch(sd, p, x, train):
     """CrossResNet.forward, nets/tcct.py:877-885."""
-    x = _cba(sd, p + '.cnn.0', p + '.cnn.1', x, train, pad=1)
+    x = _cba(sd, p + '.cnn.0', p + '.cnn.1', x, train, pad=1, one_store=True)
     outs = []
     for i, k in enumerate(KSIZES):
         x = cross_block(sd, f'{p}.path_estan.{i}', x, k, train)
@@ -129,20 +129,22 @@ def cnn_branch(sd, p, x, train):
 _ACT = {None: _same, 'lrelu': lambda t: F.leaky_relu(t, 0.01), 'hswish': F.hardswish}
 
 
-def _cba(sd, pc, pb, x, train, pre=None, post=None, res=None, fusable=True, **conv_kw):
+def _cba(sd, pc, pb, x, train, pre=None, post=None, res=None, fusable=True, one_store=False, **conv_kw):
     """post(BN(pre(conv(x)))) [+ res]: the conv -> (activation) -> BatchNorm -> (activation) chains of the network as the HIP path
     stores them.  Training: the convolution output is stored, the normalisation pass (activations and residual add fused) stores
-    again.  Eval under no_grad (MODE.fused_eval, `fusable` kernels): the whole chain is the epilogue of the convolution kernel."""
-    y = _conv(sd, pc, x, store=train or not (MODE.fused_eval and fusable), **conv_kw)
+    again -- except `one_store` chains (the two 3-channel first layers, round 4: the convolution output is recomputed from the image, never
+    stored; statistics and normalisation see the fp32 accumulators).  Eval under no_grad (MODE.fused_eval, `fusable` kernels): the whole
+    chain is the epilogue of the convolution kernel."""
+    y = _conv(sd, pc, x, store=(train and not one_store) or not (train or (MODE.fused_eval and fusable)), **conv_kw)
     y = _ACT[post](_bn(sd, pb, _ACT[pre](y), train))
     if res is not None and not train and MODE.fused_eval and fusable:
         y = _S(y)                                            # eval: the residual is added by a separate pass over the stored result
     return _S(y if res is None else y + res)
 
 
-def _conv_bn(sd, p, x, train, stride=1, pad=0, act=True, res=None, fusable=True):
+def _conv_bn(sd, p, x, train, stride=1, pad=0, act=True, res=None, fusable=True, one_store=False):
     """Conv2d_BN, nets/tcct.py:55-97 (conv has no bias)."""
-    return _cba(sd, p + '.conv', p + '.bn', x, train, post='hswish' if act else None, res=res, fusable=fusable, stride=stride, pad=pad)
+    return _cba(sd, p + '.conv', p + '.bn', x, train, post='hswish' if act else None, res=res, fusable=fusable, one_store=one_store, stride=stride, pad=pad)
 
 
 def metapool(t):
@@ -230,7 +232,7 @@ def vit_stage(sd, p_pe, p_st, x, s, train, dp_masks):
 def vit_branch(sd, p, x, train, dp_masks=None):
     """MPViT.forward_features tcct.py:733-745 for mpvit_tiny (tcct.py:766-776).
     dp_masks: list of 6 [B] 0/1 masks in draw order (stages 1,2,3 x two branches) or None."""
-    x = _conv_bn(sd, p + '.stem.0', x, train, stride=2, pad=1)
+    x = _conv_bn(sd, p + '.stem.0', x, train, stride=2, pad=1, one_store=True)
     x = _conv_bn(sd, p + '.stem.1', x, train, pad=1, fusable=False)       # 32->64 3x3: sub-GEMM slabs, normalisation as its own pass
     outs = []
     for s in range(4):

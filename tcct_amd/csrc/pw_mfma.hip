@@ -7,6 +7,7 @@
 // wgrad: dW[co][ci] = sum_p dy[p][co] x[p][ci] with both tiles staged pixel-major in LDS and transposed on read by
 //   ds_read_b64_tr_b16 (same scheme as conv_mfma.hip).
 #include "common.h"
+#include "c3_geom.h"
 #include <cstdlib>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -36,13 +37,7 @@ __device__ __forceinline__ float rnd_out(float v, const float*) { return v; }
 // gathered on the fly instead of being read from an im2col copy, in the order k = 16*ky + 4*slot + ch with slot 0, 1, 2 = kx 0, 1, 2 and
 // slot 3 / channel 3 zero (K = 48): k-step ky of an MFMA is then, per lane half, two whole 8-byte pixels of ONE input row (kx 0,1 / kx 2,-)
 // and needs no repacking, and the row validity of a load is one compare per ky
-struct C3Geom { int H, W, Ho, Wo, stride; uint32_t bytes; int tpr; uint32_t m_tpr, m_ho, m_howo, m_wo; };   // tpr = 32-pixel tiles per output row; m_* = floor(2^32 / d)
-// n / d for n < 2^32 with m = floor(2^32 / d): the estimate is q or q - 1
-__device__ __forceinline__ uint32_t udiv_m(uint32_t n, uint32_t d, uint32_t m) {
-    uint32_t q = __umulhi(n, m);
-    if (n - q * d >= d) ++q;
-    return q;
-}
+// (C3Geom, udiv_m: c3_geom.h)
 struct PwSplit { const bf16* x2; int K1; void* y2; int N1; const bf16* res; const float* rscale; int64_t per_sample; bf16* yplain; C3Geom c3; };
 // res (inference-epilogue kernel only): y = res + rscale[m / per_sample] * (x W^T + bias), rscale nullable -- Mlp.fc2 with the
 // residual add and the DropPath scale of MHCABlock folded in (reference nets/tcct.py:468)

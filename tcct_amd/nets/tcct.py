@@ -135,7 +135,9 @@ class CrossResNet(nn.Module):
     def iter_levels(self, x, xs, levels=None):
         """generator form of forward(): appends one resolution level to `xs` per step (ops.run_interleaved alternates it with the ViT stages)"""
         m = self.cnn[1]
-        if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
+        if ops.conv3x3_c3_bn_ok(x, self.cnn[0].weight, m.training, None):       # conv + train-mode BatchNorm, the 452 MB conv output never stored
+            x = ops.conv3x3_c3_bn(x, self.cnn[0].weight, self.cnn[0].bias, _bn_args(m), 1)
+        elif self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
             x = _bn(m, ops.conv3x3_c3(x, self.cnn[0].weight, self.cnn[0].bias, 1, stats_pre='none' if self.training else None))
         else:
             x = ops.conv3x3_c3(x, self.cnn[0].weight, self.cnn[0].bias, 1, infer_bn=(m.weight, m.bias, m.running_mean, m.running_var, m.eps))
@@ -167,6 +169,8 @@ class Conv2d_BN(nn.Module):
     def forward(self, x, residual=None, x_final=False):
         sp = 'none' if self.training else None
         if self.conv.in_channels == 3:          # stem[0]: 3-channel input -> im2col + pointwise MFMA
+            if ops.conv3x3_c3_bn_ok(x, self.conv.weight, self.bn.training, 'hswish' if self.act else None):
+                return ops.conv3x3_c3_bn(x, self.conv.weight, None, _bn_args(self.bn), self.conv.stride[0], 'hswish' if self.act else None)
             if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
                 y = ops.conv3x3_c3(x, self.conv.weight, None, self.conv.stride[0], stats_pre=sp)
                 return _bn(self.bn, y, post='hswish' if self.act else None)
@@ -489,11 +493,12 @@ class MPUpBlock(nn.Module):
         self.prep = nn.Sequential(nn.Conv2d(in_ch, out_ch, 3, 1, 1), nn.BatchNorm2d(out_ch), nn.LeakyReLU(inplace=True))
         self.post = nn.Sequential(nn.Conv2d(out_ch, out_ch, 1, 1, 0))
 
-    def forward(self, x1, x2, with_sum=False):
-        """with_sum: also return x2 + output (the `x_i + y_i` of FTC.forward, tcct.py:1028-1031) from the same GEMM epilogue"""
+    def forward(self, x1, x2, with_sum=False, want_plain=True):
+        """with_sum: also return x2 + output (the `x_i + y_i` of FTC.forward, tcct.py:1028-1031) from the same GEMM epilogue;
+        want_plain=False: the block's own output is not needed by the caller (returned as None, never written)"""
         y = _conv_bn(self.prep[0], self.prep[1], x1, post='lrelu')
         if with_sum:
-            return ops.up_skip_conv(y, x2, self.post[0].weight, self.post[0].bias, True)
+            return ops.up_skip_conv(y, x2, self.post[0].weight, self.post[0].bias, True, want_plain=want_plain)
         u = ops.bilinear(y, (x1.shape[1] * 2, x1.shape[2] * 2), True, residual=x2)
         return _conv(self.post[0], u)
 
@@ -622,7 +627,7 @@ class FTC(nn.Module):
             d3, s3 = self.dec1(y8, f[3], with_sum=True)
             d2, s2 = self.dec2(d3, f[2], with_sum=True)
             d1, s1 = self.dec3(d2, f[1], with_sum=True)
-            d0, s0 = self.dec4(d1, f[0], with_sum=True)
+            d0, s0 = self.dec4(d1, f[0], with_sum=True, want_plain=False)      # only x_0 + y_0 is read below: d0 is never written
             g0, g1, g2, g3 = _conv(self.t324, s0), _conv(self.t323, s1), _conv(self.t322, s2), _conv(self.t321, s3)
         # norm_add([y0,y1,y2]) (reference tcct.py:937-942,1035) -> `self.feats`: evaluated lazily on first access (only the
         # feature-polarization loss reads it; with --udh=false the six level-0 passes are simply never launched)

@@ -827,7 +827,7 @@ class _UpSkipConv(torch.autograd.Function):
     input-gradient GEMM already summed (tcct_pw_dgrad_residual) -- autograd would otherwise add them in a separate pass."""
 
     @staticmethod
-    def forward(ctx, y, skip, w, bias, align):
+    def forward(ctx, y, skip, w, bias, align, want_plain=True):
         ctx.set_materialize_grads(False)      # an unused output must arrive as None in backward(), not as a zero-filled tensor
         _chk(y, skip, w, bias)
         N_, H, W_, C = y.shape
@@ -835,12 +835,16 @@ class _UpSkipConv(torch.autograd.Function):
         Cout = w.shape[0]
         u = torch.empty_like(skip)
         lib.bilinear_add_fwd(y, skip, u, N_, H, W_, C, Ho, Wo, int(align), dtype_code(y.dtype))
-        d = torch.empty((N_, Ho, Wo, Cout), device=y.device, dtype=y.dtype)
-        s_ = torch.empty_like(d)
+        s_ = torch.empty((N_, Ho, Wo, Cout), device=y.device, dtype=y.dtype)
+        # want_plain=False (the LAST decoder block: FTC.forward reads only x_0 + y_0, tcct.py:1031-1035): the 452 MB `d` of the bench shape is never written
+        d = torch.empty_like(s_) if want_plain else None
         lib.pw_fwd_residual(u, w, bias, skip, None, 1, s_, d, N_ * Ho * Wo, C, Cout)
         ctx.save_for_backward(u, w)
         ctx.params = (w, bias)
         ctx.cfg = (N_, H, W_, C, Ho, Wo, int(align))
+        if d is None:
+            d = s_.new_empty(0)
+            ctx.mark_non_differentiable(d)
         return d, s_
 
     @staticmethod
@@ -849,7 +853,7 @@ class _UpSkipConv(torch.autograd.Function):
         wsrc, bsrc = ctx.params
         N_, H, W_, C, Ho, Wo, align = ctx.cfg
         if gd is None and gs is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         if gd is None or gs is None:
             dz = _c(gd if gs is None else gs)
         else:
@@ -880,17 +884,19 @@ class _UpSkipConv(torch.autograd.Function):
                 dw = _grad_out(wsrc, tuple(w.shape))
                 db = _grad_out(bsrc)
                 lib.pw_wgrad(u, dz, dw, db, M, C, Cout)
-        return dy, dskip, _ret(dw, wsrc), _ret(db, bsrc), None
+        return dy, dskip, _ret(dw, wsrc), _ret(db, bsrc), None, None
 
 
-def up_skip_conv(y, skip, w, bias, align_corners=True):
-    """(d, d + skip) with d = conv1x1(resize(y -> skip's size) + skip); the fused node needs bf16 with square 1x1 weights"""
+def up_skip_conv(y, skip, w, bias, align_corners=True, want_plain=True):
+    """(d, d + skip) with d = conv1x1(resize(y -> skip's size) + skip); the fused node needs bf16 with square 1x1 weights.
+    want_plain=False: d is not needed (returned as None)"""
     ok = (y.dtype == torch.bfloat16 and skip.dtype == y.dtype and y.dim() == 4 and y.shape[-1] % 32 == 0 and y.shape[-1] <= 160
           and w.shape[0] == y.shape[-1] and w.shape[1] == y.shape[-1] and tuple(w.shape[2:]) == (1, 1) and bias is not None
           and skip.shape[-1] == y.shape[-1] and tuple(skip.shape[1:3]) != tuple(y.shape[1:3]) and torch.is_grad_enabled())
     if not ok:
         return conv1x1_and_sum(bilinear(y, tuple(skip.shape[1:3]), align_corners, residual=skip), w, bias, skip)
-    return _UpSkipConv.apply(y, skip, w, bias, bool(align_corners))
+    d, s_ = _UpSkipConv.apply(y, skip, w, bias, bool(align_corners), bool(want_plain))
+    return (d if want_plain else None), s_
 
 
 def conv1x1_and_sum(x, w, bias, res):
@@ -1048,6 +1054,62 @@ def conv3x3_c3(x4, w, bias, stride=1, stats_pre=None, infer_bn=None, post_act=No
     if infer_bn is not None:
         return conv_bn_act(im2col3x3_c3(x4, stride), w2.view(w.shape[0], 32, 1, 1), bias, bn=infer_bn, post_act=post_act)
     return conv2d(im2col3x3_c3(x4, stride), w2.view(w.shape[0], 32, 1, 1), bias, stats_pre=stats_pre)
+
+
+C3_BN_FUSE = os.environ.get('TCCT_C3_BN', '1') != '0'       # =0: convolution (+ statistics) and BatchNorm as separate nodes, the round-3 form (A/B timing)
+
+
+class _ConvC3BN(torch.autograd.Function):
+    """z = post(BN_train(conv3x3(x4) + bias)) for the two 3-channel first layers as ONE node whose convolution output is never stored
+    (csrc/c3_bn.hip; reference nets/tcct.py:873 `cnn.0 -> cnn.1`, :55-97 + :674-681 `stem[0]`): the input is the 4-channel image, 1/8 of the
+    bytes of the 32-channel output, so forward (statistics pass, normalising pass) and backward (reduction, weight gradient) recompute y on the
+    matrix pipes instead of writing it once and reading it three times."""
+
+    @staticmethod
+    def forward(ctx, x4, w, bias, gamma, beta, rm, rv, nbt, eps, momentum, stride, post):
+        _chk(x4, w, bias, gamma, beta)
+        B, H, W, _ = x4.shape
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        z = torch.empty((B, Ho, Wo, 32), device=x4.device, dtype=torch.bfloat16)
+        sums = ZERO.get((64,), torch.float64, x4.device) if ZERO.active else torch.zeros(64, device=x4.device, dtype=torch.float64)
+        mean_rstd = torch.empty(64, device=x4.device, dtype=torch.float32)
+        ab = torch.empty(64, device=x4.device, dtype=torch.float32)
+        lib.c3_bn_fwd_train(x4, w, bias, z, B, H, W, stride, sums, gamma, beta, eps, momentum, rm, rv, nbt, mean_rstd, ab, post)
+        ctx.save_for_backward(x4, mean_rstd, ab)
+        ctx.cfg = (stride, post, w, bias, gamma, beta)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x4, mean_rstd, ab = ctx.saved_tensors
+        stride, post, w, bias, gamma, beta = ctx.cfg
+        dz = _as(dz, torch.bfloat16)
+        B, H, W, _ = x4.shape
+        M = dz.numel() // 32
+        dev = x4.device
+        raw = ZERO.get((64,), torch.float64, dev) if ZERO.active else torch.zeros(64, device=dev, dtype=torch.float64)
+        coef = torch.empty(160, device=dev, dtype=torch.float32)
+        # nothing downstream waits for this node (the image has no gradient): all of it runs beside the other encoder's tail on the weight-gradient stream
+        with _wgrad_stream(_slot_written(w, bias, gamma, beta), x4, dz, coef, mean_rstd, ab):
+            lib.c3_bn_bwd_reduce(x4, w, bias, dz, B, H, W, stride, ab, raw, post)
+            dg = _grad_out(gamma) if ZERO.active and getattr(gamma, '_grad_slot', None) is not None else torch.empty(32, device=dev, dtype=torch.float32)
+            db_ = _grad_out(beta) if ZERO.active and getattr(beta, '_grad_slot', None) is not None else torch.empty(32, device=dev, dtype=torch.float32)
+            lib.bn_bwd_coef(raw, 1, M, 32, mean_rstd, ab, coef, dg, db_)
+            dw = _grad_out(w, tuple(w.shape))
+            dbias = _grad_out(bias) if bias is not None else None
+            lib.c3_bn_bwd_wgrad(x4, w, bias, dz, B, H, W, stride, coef, dw, dbias, post)
+        return None, _ret(dw, w), _ret(dbias, bias), _ret(dg, gamma), _ret(db_, beta), None, None, None, None, None, None, None
+
+
+def conv3x3_c3_bn_ok(x4, w, bn_training, post_act):
+    return (C3_BN_FUSE and bn_training and torch.is_grad_enabled() and _c3_direct_ok(x4, w) and ACT[post_act] in (0, ACT['hswish']))
+
+
+def conv3x3_c3_bn(x4, w, bias, bn, stride=1, post_act=None):
+    """post_act(BN_train(conv3x3_c3(x4))); bn = (gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum); check
+    conv3x3_c3_bn_ok first"""
+    gamma, beta, rm, rv, nbt, eps, mom = bn
+    return _ConvC3BN.apply(x4, w, bias, gamma, beta, rm, rv, nbt, float(eps), float(mom), int(stride), ACT[post_act])
 
 
 class _DwConv(torch.autograd.Function):

@@ -169,6 +169,63 @@ def test_first_layer_direct_conv_with_statistics_and_inference_epilogue(dt, stri
     torch.testing.assert_close(nchw(out), ref, **t)
 
 
+@pytest.mark.parametrize('cfg', [(1, False, True), (2, True, False)])       # (stride, Hardswish, bias): cnn.0 -> cnn.1 and stem[0]
+@pytest.mark.parametrize('nhw', [(2, 18, 26), (3, 17, 45), (1, 5, 131), (2, 64, 96), (1, 40, 300)])
+def test_first_layer_with_its_batchnorm_as_one_store(cfg, nhw):
+    """csrc/c3_bn.hip (round 4): z = post(BN_train(conv3x3(image) + bias)) for the two 3-channel first layers (reference nets/tcct.py:873 and
+    :55-97 / :674-681) with the convolution output recomputed instead of stored -- forward (batch statistics, running statistics, z), and the
+    backward (d weight, d bias, d gamma, d beta) against torch's fp32 conv -> batch_norm -> hardswish on the same bf16-representable image.
+    Odd extents leave partial 32-pixel row tiles and partial 128-pixel tiles; z is the only rounding point."""
+    from tcct_amd import ops
+    stride, hsw, has_bias = cfg
+    N, H, W = nhw
+    dt = torch.bfloat16
+    x = rnd(N, 3, H, W, dt=dt)
+    w = (rnd(32, 3, 3, 3, seed=1) / 27 ** 0.5).to(dt).float().requires_grad_(True)        # bf16-representable: the MFMA operand is the only weight rounding
+    b = rnd(32, seed=2).requires_grad_(True) if has_bias else None
+    g = (rnd(32, seed=4).abs() + 0.5).requires_grad_(True)
+    be = rnd(32, seed=5).requires_grad_(True)
+    rm, rv = rnd(32, seed=6) * 0.1, rnd(32, seed=7).abs() + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.conv2d(x, w, b, stride, 1)
+    zn = F.batch_norm(y, rm_ref, rv_ref, g, be, True, 0.1, 1e-5)
+    z = F.hardswish(zn) if hsw else zn
+    gz = rnd(*z.shape, seed=3, dt=dt)
+    z.backward(gz)
+    xd = nhwc(F.pad(x, (0, 0, 0, 0, 0, 1)), dt)
+    wd = w.detach().cuda().requires_grad_(True)
+    bd = b.detach().cuda().requires_grad_(True) if has_bias else None
+    gd, bed = g.detach().cuda().requires_grad_(True), be.detach().cuda().requires_grad_(True)
+    rmd, rvd, nbt = rm.cuda(), rv.cuda(), torch.zeros((), dtype=torch.int64, device='cuda')
+    assert ops.conv3x3_c3_bn_ok(xd, wd, True, 'hswish' if hsw else None)
+    zd = ops.conv3x3_c3_bn(xd, wd, bd, (gd, bed, rmd, rvd, nbt, 1e-5, 0.1), stride, 'hswish' if hsw else None)
+    assert zd.shape == (N, z.shape[2], z.shape[3], 32) and zd.dtype == dt
+    # forward: fp32 statistics of the unrounded convolution, ONE bf16 rounding of z
+    torch.testing.assert_close(nchw(zd), z.detach(), rtol=8e-3, atol=8e-3)
+    exact = (nchw(zd) == z.detach().to(dt).float()).float().mean().item()
+    assert exact > 0.97, exact                      # the fp32 reference rounded once: all but rounding-boundary cases agree bit for bit
+    torch.testing.assert_close(rmd.cpu(), rm_ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rvd.cpu(), rv_ref, rtol=1e-4, atol=1e-5)
+    assert nbt.item() == 1
+    zd.backward(nhwc(gz, dt))
+    sc = max(1.0, w.grad.abs().max().item())
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=2e-2, atol=2e-2 * sc)      # dy is rounded to bf16 as an MFMA operand, like every weight gradient
+    torch.testing.assert_close(gd.grad.cpu(), g.grad, rtol=2e-3, atol=2e-3 * max(1.0, g.grad.abs().max().item()))
+    torch.testing.assert_close(bed.grad.cpu(), be.grad, rtol=2e-3, atol=2e-3 * max(1.0, be.grad.abs().max().item()))
+    if has_bias:        # exact gradient 0 (the batch mean absorbs the bias): noise level only
+        assert bd.grad.abs().max().item() <= 2e-2 * max(1.0, gz.abs().sum().item() ** 0.5)
+    # and against the separate kernels of the same library (conv + statistics, BatchNorm node): same math, two rounding points there
+    w2, g2, be2 = w.detach().cuda().requires_grad_(True), g.detach().cuda().requires_grad_(True), be.detach().cuda().requires_grad_(True)
+    b2 = b.detach().cuda().requires_grad_(True) if has_bias else None
+    y2 = ops.conv3x3_c3(xd, w2, b2, stride, stats_pre='none')
+    z2 = ops.batchnorm(y2, g2, be2, rm.cuda(), rv.cuda(), torch.zeros((), dtype=torch.int64, device='cuda'), eps=1e-5, momentum=0.1,
+                       post_act='hswish' if hsw else None, training=True)
+    z2.backward(nhwc(gz, dt))
+    e_fused = (wd.grad.cpu() - w.grad).norm().item() / w.grad.norm().item()
+    e_sep = (w2.grad.cpu() - w.grad).norm().item() / w.grad.norm().item()
+    assert e_fused <= 1.5 * e_sep + 2e-3, (e_fused, e_sep)
+
+
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('stride', [1, 2])
 def test_first_layer_im2col_conv(dt, stride):

@@ -88,6 +88,31 @@ def test_conv_lrelu_batchnorm_store_points():
     _check('conv3x3 -> lrelu -> BN', hip, ref, ref0, 0.985, 0.15)
 
 
+@pytest.mark.parametrize('which', ['cnn', 'stem'])
+def test_first_layers_are_one_store(which):
+    """round 4 (csrc/c3_bn.hip): `cnn.0 -> cnn.1` (reference nets/tcct.py:873) and `stem[0]` = conv3x3 s2 -> BatchNorm -> Hardswish (:55-97,674-681)
+    keep NO store between the convolution and the normalisation -- the convolution output is recomputed from the image -- so the HIP result must be
+    bit-identical to the oracle's `one_store` chain and visibly further from the model that rounds the convolution output first (the round-3 form)"""
+    import tcct_oracle as O
+    from tcct_amd import ops
+    torch.manual_seed(2)
+    stride, hsw = (1, False) if which == 'cnn' else (2, True)
+    conv, bn = nn.Conv2d(3, 32, 3, stride, 1, bias=(which == 'cnn')), nn.BatchNorm2d(32)
+    _bn_init(bn, 7)
+    x = _rnd(2, 3, 48, 80, seed=4, scale=0.5)
+    sd = {**_sd('c', conv), **_sd('b', bn)}
+    conv, bn = conv.cuda(), bn.cuda().train()
+    x4 = _nhwc(F.pad(x, (0, 0, 0, 0, 0, 1)))
+    post = 'hswish' if hsw else None
+    assert ops.conv3x3_c3_bn_ok(x4, conv.weight, True, post)
+    hip = _nchw(ops.conv3x3_c3_bn(x4, conv.weight, conv.bias, (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum),
+                                  stride, post))
+    with torch.no_grad(), O.rounding_points('bf16'):
+        ref = O._cba(dict(sd), 'c', 'b', x, True, post=post, one_store=True, stride=stride, pad=1)
+        ref2 = O._cba(dict(sd), 'c', 'b', x, True, post=post, one_store=False, stride=stride, pad=1)       # a store after the convolution as well
+    _check(f'first layer ({which}): conv3x3 -> BN' + (' -> hswish' if hsw else ''), hip, ref, ref2, 0.985, 0.10)
+
+
 def test_pointwise_conv_batchnorm_hardswish_store_points():
     """Conv2d_BN (reference nets/tcct.py:55-97): 1x1 conv -> [store] -> BatchNorm -> Hardswish -> [store], the fused autograd node of round 3"""
     import tcct_oracle as O
