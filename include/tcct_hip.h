@@ -282,6 +282,13 @@ int tcct_pw_wgrad_strided(const void* x, const void* dy, int64_t ldy, float* dw,
  * `post` convolution whose output feeds both the next stage and `x_i + y_i` (nets/tcct.py:1028-1031) */
 int tcct_pw_fwd_residual(const void* x, const float* w, const float* bias, const void* res, const float* scale, int64_t per_sample,
                          void* y, void* y_plain, int64_t M, int K, int N, tcct_stream_t stream);
+/* Mlp (nets/tcct.py:29-53: fc1 -> GELU -> fc2) without the activation passes (round 4): x1 is the PRE-activation fc1 wrote; GELU is applied while the
+ * tile is staged, so h = gelu(x1) and, backwards, dh never exist in HBM.  K = N in {64, 96} (mpvit_tiny: hidden = dim; stages 0 and 1 = 97 % of the bytes).
+ *   fwd: y = res + scale[m / per_sample] * (gelu(x1) W^T + bias)   (fc2 + DropPath scale + residual, nets/tcct.py:468; scale nullable)
+ *   bwd: dx1 = (dy W) gelu'(x1), dw += dy^T gelu(x1), dbias += sum dy   (dw / dbias cleared here unless tcct_set_outputs_prezeroed) */
+int tcct_pw_fwd_gelu_residual(const void* x1, const float* w, const float* bias, const void* res, const float* scale, int64_t per_sample, void* y,
+                              int64_t M, int K, int N, tcct_stream_t stream);
+int tcct_pw_bwd_gelu(const void* x1, const void* dy, const float* w, void* dx1, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
 /* input gradient with a second gradient folded in: dx_plain = dy W, dx_sum = dy W + res (w [Nout,K] as stored; res, dx_* [M,K] bf16; dx_plain nullable):
  * backward of the decoder block tail (MPUpBlock, tcct.py:908-914): dx_plain continues into the resize, dx_sum is the skip's gradient */
 int tcct_pw_dgrad_residual(const void* dy, const float* w, const void* res, void* dx_sum, void* dx_plain, int64_t M, int Nout, int K,

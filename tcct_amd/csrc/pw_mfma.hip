@@ -753,6 +753,18 @@ extern "C" int tcct_c3_wgrad(const void* x4, const void* dy, float* dw, float* d
 // rows.  Same tile pipeline as k_conv32_mfma: the staging wait sits behind the MFMA phase, the dx stores of tile t are issued after
 // the loads of tile t+2.  Algorithmic bytes: M (2K + N) 2 B against M (2K + 2N) 2 B (or more) for the two-kernel form.
 #define PB_P 128
+
+// GX (round 4): the operand tensor holds the PRE-activation y1 of Mlp.fc1 (reference nets/tcct.py:29-53) and the kernel applies GELU while it stages the
+// tile -- h = bf16(gelu(y1)), bit-identical to the tensor the separate activation pass used to write (same gauss_cdf_pdf form, same rounding) -- so
+// neither h nor, in the backward pass, dh ever exist in HBM: the activation pass (read y1, write h) and its backward (read dh, read y1, write dy1) are gone.
+__device__ __forceinline__ u32x4 gelu8(u32x4 v) {
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        o[k] = pack_bf16x2(act_c<TCCT_ACT_GELU>(__uint_as_float(v[k] << 16)), act_c<TCCT_ACT_GELU>(__uint_as_float(v[k] & 0xffff0000u)));
+    return o;
+}
+__device__ __forceinline__ float gelu_grad1(float x) { float c, p; gauss_cdf_pdf(x, c, p); return c + x * p; }
 // SPLIT: x = [x | x2] and dx = [dx | dx2] are two tensors of K/2 channels each (the aggregate convolution over a concatenation,
 // MHCA_stage, reference nets/tcct.py:600-616): no concat / split passes; x2 / dx2 then travel in the res / dx_plain arguments.
 // BNP >= 0: a train-mode BatchNorm sits behind this convolution (Conv2d_BN, DWConv2d_BN.pwconv, tran_*; reference nets/tcct.py:55-97,124-126,
@@ -771,7 +783,7 @@ template <int KIND> __device__ __forceinline__ float pw_act_grad(float u) {
     if (KIND == TCCT_ACT_HSWISH) return u < -3.f ? 0.f : (u <= 3.f ? (2.f * u + 3.f) * (1.f / 6.f) : 1.f);
     return 1.f;
 }
-template <int NT, int KT, bool SPLIT = false, int BNP = -1, int REDP = -1>
+template <int NT, int KT, bool SPLIT = false, int BNP = -1, int REDP = -1, bool GX = false>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ w, const bf16* __restrict__ res,
          bf16* __restrict__ dx, bf16* __restrict__ dx_plain, float* __restrict__ dw, float* __restrict__ dbias, int64_t M, PwBnBwd bn) {
@@ -854,7 +866,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
         for (int j = 0; j < XS; ++j) {
             const int jj = (SPLIT && j >= XS / 2) ? j - XS / 2 : j;
             const int q = tid + jj * PWB, p = q / (KS / 8), c = q - p * (KS / 8);
-            *reinterpret_cast<u32x4*>(sX + p * SX + ((SPLIT && j >= XS / 2) ? KS * 2 : 0) + c * 16) = px[j];
+            *reinterpret_cast<u32x4*>(sX + p * SX + ((SPLIT && j >= XS / 2) ? KS * 2 : 0) + c * 16) = GX ? gelu8(px[j]) : px[j];
         }
 #pragma unroll
         for (int j = 0; j < DS; ++j) {
@@ -910,6 +922,17 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
     }
     __syncthreads();
     for (; tile < tiles; tile += gridDim.x) {
+        u32x4 xq[GX ? KT : 1][2];       // GX: the raw x (= y1) values the dx epilogue multiplies gelu'(y1) from, requested before the MFMA phase (L2 / MALL hits:
+        if (GX) {                       // the tile was staged from the same addresses two iterations ago)
+            const int64_t m0q = tile * PB_P + 32 * wave;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int64_t mm = m0q + (lane >> 2) + 16 * h2;
+                    xq[kt][h2] = __builtin_amdgcn_raw_buffer_load_b128(rx, mm < M ? (uint32_t)((mm * K + kt * 32 + (lane & 3) * 8) * 2) : 0x80000000u, 0, 0);
+                }
+        }
         u32x4 yq[RKT][2];               // RED: the y_prev values the dx epilogue of this tile needs, requested before the MFMA phase
         if (RED) {
             const int64_t m0q = tile * PB_P + 32 * wave;
@@ -997,6 +1020,13 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
                     continue;
                 }
                 const uint32_t off = mm < M ? (uint32_t)((mm * K + kt * 32 + cch * 8) * 2) : 0x80000000u;
+                if (GX) {           // dy1 = bf16(dh) gelu'(y1): what the separate activation backward computed from the stored dh
+                    const u32x4 xv = xq[GX ? kt : 0][h2];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        o[k] = pack_bf16x2(__uint_as_float(o[k] << 16) * gelu_grad1(__uint_as_float(xv[k] << 16)),
+                                           __uint_as_float(o[k] & 0xffff0000u) * gelu_grad1(__uint_as_float(xv[k] & 0xffff0000u)));
+                }
                 if (res) {          // block-uniform: dx = dy W + res (the gradient that reaches x through its other consumers)
                     if (dx_plain) __builtin_amdgcn_raw_buffer_store_b128(o, rp, off, 0, 0);      // dy W itself (decoder tail: continues into the resize)
                     const u32x4 rv = __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0);
@@ -1062,7 +1092,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
  * are ACCUMULATED into after being cleared here (or by the caller: tcct_set_outputs_prezeroed).  K, N in {32, 64, 96, 128}. */
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
                        int64_t M, int K, int N, tcct_stream_t stream, bool split = false, int bnp = -1, int redp = -1,
-                       PwBnBwd bn = PwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr});
+                       PwBnBwd bn = PwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr}, bool gelu_x = false);
 /* the same over a concatenation: x = [x1 | x2], dx = [dx1 | dx2], each [M, K/2] (K = 128): backward of tcct_pw_fwd_cat2 */
 extern "C" int tcct_pw_bwd_cat2(const void* x1, const void* x2, const void* dy, const float* w, void* dx1, void* dx2, float* dw, int64_t M,
                                 int K, int N, tcct_stream_t stream) {
@@ -1131,8 +1161,17 @@ static int pw_bwd_bn_impl(const void* x, const void* x2, const void* dz, PwBnBwd
         hipMemsetAsync(sums_prev, 0, sizeof(double) * 2 * (split ? K / 2 : K), (hipStream_t)stream) != hipSuccess) { tcct_set_error("pw_bwd_bn: memset failed"); return -2; }
     return pw_bwd_impl(x, dz, w, split ? x2 : res, dx, split ? dx2 : nullptr, dw, dbias, M, K, N, stream, split, post, red_post, bn);
 }
+/* Backward of  y = gelu(x1) W^T + b  given dy, with x1 the PRE-activation (Mlp.fc1's output, reference nets/tcct.py:29-53): dx1 = (dy W) gelu'(x1),
+ * dw += dy^T gelu(x1), dbias += sum dy in one pass; gelu(x1) is rebuilt while the tile is staged, the activation's own backward pass does not exist.
+ * K = N in {64, 96}. */
+extern "C" int tcct_pw_bwd_gelu(const void* x1, const void* dy, const float* w, void* dx1, float* dw, float* dbias, int64_t M, int K, int N,
+                                tcct_stream_t stream) {
+    TCCT_CHECK(K == N && (K == 64 || K == 96), "pw_bwd_gelu: K=%d N=%d unsupported (64 or 96 square; 128 spills 30 VGPRs)", K, N);
+    return pw_bwd_impl(x1, dy, w, nullptr, dx1, nullptr, dw, dbias, M, K, N, stream, false, -1, -1,
+                       PwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr}, true);
+}
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
-                       int64_t M, int K, int N, tcct_stream_t stream, bool split, int bnp, int redp, PwBnBwd bn) {
+                       int64_t M, int K, int N, tcct_stream_t stream, bool split, int bnp, int redp, PwBnBwd bn, bool gelu_x) {
     TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && K <= 128 && N <= 128, "pw_bwd: K=%d N=%d unsupported (32..128)", K, N);
     TCCT_CHECK(M > 0 && M * (int64_t)(K > N ? K : N) * 2 < (1LL << 31), "pw_bwd: tensor exceeds the 2 GiB buffer-descriptor range");
     hipStream_t st = (hipStream_t)stream;
@@ -1171,6 +1210,13 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
 #undef BN_SQR
         TCCT_LAUNCH_OK();
     }
+    if (gelu_x) {
+#define BLG(T) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<T, T, false, -1, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_bwd<T, T, false, -1, -1, true>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M, bn); }
+        if (NT == 2) BLG(2) else BLG(3)
+#undef BLG
+        TCCT_LAUNCH_OK();
+    }
 #define BL(NTV, KTV) BLX(NTV, KTV, false, -1, -1)
 #define BLS(NTV) BLX(NTV, 4, true, -1, -1)
 #define BLK(NTV) switch (KT) { case 1: BL(NTV, 1) break; case 2: BL(NTV, 2) break; case 3: BL(NTV, 3) break; default: if (split) BLS(NTV) else BL(NTV, 4) break; }
@@ -1193,7 +1239,7 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
 // RES: y = res + rscale[m / per_sample] * (x W^T + bias) with the product rounded to bf16 first, like the op-by-op path (Mlp.fc2 with the
 // residual add and the DropPath scale of MHCABlock folded in, reference nets/tcct.py:468); yplain (nullable) also receives the product.
 struct PwRes { const bf16* res; const float* rscale; int64_t per_sample; bf16* yplain; };
-template <int NT, int KT, bool STATS, bool SPLIT, bool RES = false>
+template <int NT, int KT, bool STATS, bool SPLIT, bool RES = false, bool GX = false>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* __restrict__ w, const float* __restrict__ bias,
           bf16* __restrict__ y, int64_t M, double* __restrict__ stats, int stat_pre, PwRes pr) {
@@ -1243,7 +1289,7 @@ k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* 
         for (int j = 0; j < XS; ++j) {
             const int jj = (SPLIT && j >= XS / 2) ? j - XS / 2 : j;
             const int q = tid + jj * PWB, p = q / (KS / 8), c = q - p * (KS / 8);
-            *reinterpret_cast<u32x4*>(sX + p * SX + ((SPLIT && j >= XS / 2) ? KS * 2 : 0) + c * 16) = px[j];
+            *reinterpret_cast<u32x4*>(sX + p * SX + ((SPLIT && j >= XS / 2) ? KS * 2 : 0) + c * 16) = GX ? gelu8(px[j]) : px[j];
         }
     };
     const unsigned char* bB = sX + (32 * wave + r) * SX + hh * 16;
@@ -1349,7 +1395,7 @@ static bool pw_fwd2_ok(int64_t M, int K, int N, int K1, bool has_x2) {
     return true;
 }
 static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
-                          int stat_pre, tcct_stream_t stream, PwRes pr) {
+                          int stat_pre, tcct_stream_t stream, PwRes pr, bool gelu_x = false) {
     const int NT = N / 32, KT = K / 32;
     const size_t lds = (size_t)PB_P * (2 * K + 16) + (size_t)N * (2 * K + 16) + (size_t)N * 4 + 4 * 2560;
     const int64_t tiles = (M + PB_P - 1) / PB_P;
@@ -1366,8 +1412,13 @@ static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const f
 #define F2K(NTV, SV) switch (KT) { case 2: F2(NTV, 2, SV, false) break; case 3: F2(NTV, 3, SV, false) break; default: if (x2) F2(NTV, 4, SV, true) else F2(NTV, 4, SV, false) break; }
 #define F2RK(NTV) switch (KT) { case 2: F2R(NTV, 2) break; case 3: F2R(NTV, 3) break; default: F2R(NTV, 4) break; }
 #define F2N(SV) switch (NT) { case 1: F2K(1, SV) break; case 2: F2K(2, SV) break; case 3: F2K(3, SV) break; default: F2K(4, SV) break; }
+#define F2G(T) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd2<T, T, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_fwd2<T, T, false, false, true, true>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)x2, w, bias, (bf16*)y, M, stats, stat_pre, pr); }
+    if (gelu_x) { if (NT == 2) F2G(2) else F2G(3) }
+    else
     if (pr.res) { switch (NT) { case 1: F2RK(1) break; case 2: F2RK(2) break; case 3: F2RK(3) break; default: F2RK(4) break; } }
     else if (stats) { F2N(true) } else { F2N(false) }
+#undef F2G
 #undef F2RK
 #undef F2R
 #undef F2N
@@ -1379,6 +1430,14 @@ static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const f
 static int pw_fwd2_route(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
                          int stat_pre, tcct_stream_t stream, const bf16* res, const float* rscale, int64_t per_sample, bf16* yplain) {
     return pw_fwd2_launch(x, x2, w, bias, y, M, K, N, stats, stat_pre, stream, PwRes{res, rscale, per_sample, yplain});
+}
+/* y = res + scale[m / per_sample] * (gelu(x1) W^T + bias) with x1 the PRE-activation of Mlp.fc1 (reference nets/tcct.py:29-53,468): Mlp.fc2 with the
+ * activation applied while the tile is staged and the DropPath scale + residual add in the epilogue; scale nullable.  K = N in {64, 96}. */
+extern "C" int tcct_pw_fwd_gelu_residual(const void* x1, const float* w, const float* bias, const void* res, const float* scale, int64_t per_sample,
+                                         void* y, int64_t M, int K, int N, tcct_stream_t stream) {
+    TCCT_CHECK(K == N && (K == 64 || K == 96), "pw_fwd_gelu_residual: K=%d N=%d unsupported (64 or 96 square, as tcct_pw_bwd_gelu)", K, N);
+    TCCT_CHECK(res != nullptr && per_sample >= 1 && M > 0 && M * (int64_t)K * 2 < (1LL << 31), "pw_fwd_gelu_residual: needs res, per_sample >= 1, < 2 GiB tensors");
+    return pw_fwd2_launch(x1, nullptr, w, bias, y, M, K, N, nullptr, 0, stream, PwRes{(const bf16*)res, scale, per_sample, nullptr}, true);
 }
 
 // ------------------------------------------------------------------------------------------------ first-layer im2col

@@ -321,7 +321,12 @@ class MHCABlock(nn.Module):
             t = ops.metapool_residual(cur, t, s1)       # t + dp(pool(LN1 t)): mixer, DropPath scale and residual in one pass
         cur, t = ops.layernorm_fork(t, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
-            h = ops.act(ops.conv2d(cur, self.mlp.fc1.weight, self.mlp.fc1.bias), 'gelu')
+            y1 = ops.conv2d(cur, self.mlp.fc1.weight, self.mlp.fc1.bias)
+            if ops.gelu_linear_residual_ok(y1, self.mlp.fc2.weight, self.mlp.fc2.bias, t):
+                # GELU applied while fc2's kernels stage their tiles: h and dh never exist in HBM (stages 0 and 1)
+                t = ops.gelu_linear_residual(y1, self.mlp.fc2.weight, self.mlp.fc2.bias, t, s2)
+                return (t.view(B, H, W, C), x_alias) if fork else t.view(B, H, W, C)
+            h = ops.act(y1, 'gelu')
         else:               # inference: GELU in the GEMM epilogue
             h = ops.conv_bn_act(cur, self.mlp.fc1.weight, self.mlp.fc1.bias, post_act='gelu')
         t = ops.linear_residual(h, self.mlp.fc2.weight, self.mlp.fc2.bias, t, s2)      # t + dp(fc2(h)) in the GEMM epilogue

@@ -777,6 +777,54 @@ class _LinearResidual(torch.autograd.Function):
         return dx, _ret(dw, wsrc), _ret(db, bsrc), dy, None
 
 
+MLP_GELU_FUSE = os.environ.get('TCCT_MLP_GELU', '1') != '0'         # =0: GELU as its own pass between fc1 and fc2 (round-3 form; A/B timing)
+
+
+class _GeluLinearResidual(torch.autograd.Function):
+    """res + scale[b] * (gelu(x1) W^T + bias) on tokens [B,N,C] with x1 the PRE-activation of Mlp.fc1 (reference nets/tcct.py:29-53,468): GELU is applied
+    while the GEMM kernels stage their tiles (tcct_pw_fwd_gelu_residual / tcct_pw_bwd_gelu), so neither h = gelu(x1) nor dh exist in HBM -- bit-identical
+    to act(x1, 'gelu') followed by linear_residual (same formula, same bf16 roundings), two tensor passes fewer forward and three fewer backward."""
+
+    @staticmethod
+    def forward(ctx, x1, w, bias, res, scale):
+        _chk(x1, w, bias, res, scale)
+        B, Nt, K = x1.shape
+        Cout = w.shape[0]
+        y = torch.empty((B, Nt, Cout), device=x1.device, dtype=x1.dtype)
+        lib.pw_fwd_gelu_residual(x1, w, bias, res, scale, Nt, y, B * Nt, K, Cout)
+        ctx.save_for_backward(x1, w)
+        ctx.scale, ctx.params = scale, (w, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, w = ctx.saved_tensors
+        wsrc, bsrc = ctx.params
+        dy = _c(dy)
+        B, Nt, K = x1.shape
+        Cout, M = w.shape[0], B * Nt
+        dz = dy
+        if ctx.scale is not None:
+            dz = torch.empty_like(dy)
+            lib.scale_rows(dy, ctx.scale, dz, B, dy.numel() // B, dtype_code(dy.dtype))
+        dx1 = torch.empty_like(x1)
+        dw = _grad_out(wsrc, tuple(w.shape))
+        db = _grad_out(bsrc)
+        lib.pw_bwd_gelu(x1, dz, w, dx1, dw, db, M, K, Cout)
+        return dx1, _ret(dw, wsrc), _ret(db, bsrc), dy, None
+
+
+def gelu_linear_residual_ok(x1, w, bias, res):
+    return (MLP_GELU_FUSE and FUSED_PW_BWD and torch.is_grad_enabled() and x1.dtype == torch.bfloat16 and x1.dim() == 3 and w.dim() == 2
+            and x1.shape[-1] in (64, 96) and w.shape[0] == x1.shape[-1] and w.shape[1] == x1.shape[-1] and bias is not None
+            and res.shape == x1.shape and x1.numel() * 2 < 2 ** 31)
+
+
+def gelu_linear_residual(x1, w, bias, res, scale=None):
+    """res + scale[b] * Linear(gelu(x1)); check gelu_linear_residual_ok first"""
+    return _GeluLinearResidual.apply(x1, w, bias, res, scale)
+
+
 class _Conv1x1AndSum(torch.autograd.Function):
     """(d, d + res) with d = conv1x1(x): both written by one GEMM epilogue (decoder `post` convolution + the `x_i + y_i` that follows)"""
 

@@ -607,6 +607,50 @@ def test_clip_adamw():
             torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize('cfg', [(64, 2, 700, True), (96, 3, 333, True), (64, 1, 128, False), (96, 2, 4100, False)])
+def test_mlp_gelu_applied_while_staging_is_bit_identical_to_the_separate_pass(cfg):
+    """round 4: Mlp (reference nets/tcct.py:29-53) = fc1 -> GELU -> fc2 with GELU applied while fc2's kernels stage their tiles
+    (tcct_pw_fwd_gelu_residual / tcct_pw_bwd_gelu): forward output, d(pre-activation), dW, db and the residual's gradient must equal the separate
+    activation pass + linear_residual BIT FOR BIT in the forward (same formula, same roundings) and to atomic-order noise in the weight gradient;
+    both against torch; ragged token counts, with and without the DropPath scale"""
+    from tcct_amd import ops
+    C, B, Nt, with_scale = cfg
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(C + Nt)
+    y1 = (torch.randn(B, Nt, C, generator=g) * 1.5).to(dt)
+    res = torch.randn(B, Nt, C, generator=g).to(dt)
+    w = (torch.randn(C, C, generator=g) / C ** 0.5)
+    b = torch.randn(C, generator=g) * 0.1
+    scale = (torch.tensor([1.0 / 0.9, 0.0, 1.0 / 0.9][:B]) if with_scale else None)
+    gy = torch.randn(B, Nt, C, generator=g).to(dt)
+    outs = []
+    for fused in (True, False):
+        yd = y1.cuda().requires_grad_(True)
+        rd = res.cuda().requires_grad_(True)
+        wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        sd = scale.cuda() if scale is not None else None
+        if fused:
+            assert ops.gelu_linear_residual_ok(yd, wd, bd, rd)
+            out = ops.gelu_linear_residual(yd, wd, bd, rd, sd)
+        else:
+            out = ops.linear_residual(ops.act(yd, 'gelu'), wd, bd, rd, sd)
+        out.backward(gy.cuda())
+        outs.append((out.detach().float().cpu(), yd.grad.float().cpu(), rd.grad.float().cpu(), wd.grad.cpu(), bd.grad.cpu()))
+    (o1, dy1, dr1, dw1, db1), (o0, dy0, dr0, dw0, db0) = outs
+    assert torch.equal(o1, o0) and torch.equal(dy1, dy0) and torch.equal(dr1, dr0)
+    torch.testing.assert_close(dw1, dw0, rtol=1e-4, atol=1e-4 * max(1.0, dw0.abs().max().item()))
+    torch.testing.assert_close(db1, db0, rtol=1e-4, atol=1e-4 * max(1.0, db0.abs().max().item()))
+    # torch reference (fp32 math on the same bf16 inputs)
+    yr, rr = y1.float().requires_grad_(True), res.float().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    lin = F.linear(F.gelu(yr), wr.to(dt).float(), br)
+    ref = rr + (lin * scale.view(B, 1, 1) if scale is not None else lin)
+    ref.backward(gy.float())
+    torch.testing.assert_close(o1, ref.detach(), rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(dy1, yr.grad, rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(dw1, wr.grad, rtol=3e-2, atol=3e-2 * max(1.0, wr.grad.abs().max().item()))
+
+
 def test_flat_adamw_state_refuses_a_permuted_layout():
     """FlatAdamW.state_dict() records the flat buffer's order by parameter NAME (not shape: dozens of tensors share 32x32x3x3 / [32]): moments saved
     from one order must not be applied to another order of equally shaped tensors; the same order round-trips"""

@@ -6,7 +6,9 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'k_clip_adamw' in r['Kernel_Name']]
-step = rows[idx[-2] + 1: idx[-1] + 1] if len(idx) >= 2 else rows
+# (bench.py times clip + AdamW alone at the end: 20 back-to-back k_clip_adamw launches -- the training step is the LONGEST segment between two of them)
+segs = [rows[a + 1: b + 1] for a, b in zip(idx[:-1], idx[1:])]
+step = max(segs, key=len) if segs else rows
 dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 short = lambda r: r['Kernel_Name'].split('(')[0].replace('void ', '').replace('__hip_bfloat16', 'bf16')
 print(f'{len(step)} launches, {sum(dur(r) for r in step) / 1e3:.2f} ms of kernel time in the last step')
