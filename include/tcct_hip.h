@@ -298,6 +298,16 @@ int tcct_pw_dgrad_residual(const void* dy, const float* w, const void* res, void
 int tcct_pw_fwd_cat2(const void* x1, const void* x2, int K1, const float* w, const float* bias, void* y, int64_t M, int K, int N,
                      double* stats, int pre_act, tcct_stream_t stream);
 int tcct_pw_dgrad_split2(const void* dy, const float* w, void* dx1, void* dx2, int K1, int64_t M, int Nout, int K, tcct_stream_t stream);
+/* fused backward over the concatenation incl. the bias gradient: dx1 | dx2 = dy W, dw += dy^T [x1 | x2], dbias += sum dy; two halves of 64 channels
+ * (K = 128) or, for N = 32, of 32 channels (K = 64: the decoder's composed tail below) */
+int tcct_pw_bwd_cat2_bias(const void* x1, const void* x2, const void* dy, const float* w, void* dx1, void* dx2, float* dw, float* dbias, int64_t M,
+                          int K, int N, tcct_stream_t stream);
+/* The last decoder block's tail as one GEMM (csrc/decoder_tail.hip): MPUpBlock.post (nets/tcct.py:913), `x_0 + y_0` (:1031) and t324 (:1035-1040) are
+ * 1x1 convolutions / adds with nothing nonlinear between them, so g0 = Wc [up(y) | skip] + c with Wc = [W2 W1 | W2 W1 + W2], c = W2 b1 + b2
+ * (w1, b1 = post; w2, b2 = t324; all fp32, 32 channels).  compose: Wc [32][64], c [32]; compose_bwd: the four gradients from dWc, dc. */
+int tcct_tail_compose(const float* w1, const float* b1, const float* w2, const float* b2, float* wc, float* c, tcct_stream_t stream);
+int tcct_tail_compose_bwd(const float* w1, const float* b1, const float* w2, const float* dwc, const float* dc, float* dw1, float* db1, float* dw2,
+                          float* db2, tcct_stream_t stream);
 int tcct_pw_wgrad_cat2(const void* x1, const void* x2, int K1, const void* dy, float* dw, float* dbias, int64_t M, int K, int N,
                        tcct_stream_t stream);
 /* pw_fwd + fused train-mode BatchNorm statistics of the consumer (bf16 output, N in {32,64,96,128}); stats fp64 [2N], zero on entry */

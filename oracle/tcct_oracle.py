@@ -272,8 +272,21 @@ def ftc_forward(sd, x, train=True, dp_masks=None, p='base', want=None):
     d3 = _up_block(sd, p + '.dec1', y8, f[3], train)
     d2 = _up_block(sd, p + '.dec2', d3, f[2], train)
     d1 = _up_block(sd, p + '.dec3', d2, f[1], train)
-    d0 = _up_block(sd, p + '.dec4', d1, f[0], train)
-    g0 = _conv(sd, p + '.t324', _S(f[0] + d0))
+    if train and MODE.store is not _same:
+        # rounding-point model of the training path, round 4: the last decoder block's `post` convolution, `x_0 + y_0` and t324 are ONE GEMM with
+        # composed weights over [up(y) | skip] (tcct_amd/csrc/decoder_tail.hip): stores after the resize and after g0 only; the composed weight
+        # [W2 W1 | W2 W1 + W2] is what gets rounded for the matrix pipes.  (Exact arithmetic: identical to the three steps below.)
+        yv = _cba(sd, p + '.dec4.prep.0', p + '.dec4.prep.1', d1, train, post='lrelu', pad=1)
+        vv = _S(F.interpolate(yv, scale_factor=2, mode='bilinear', align_corners=True))
+        w1, b1 = sd[p + '.dec4.post.0.weight'][:, :, 0, 0], sd[p + '.dec4.post.0.bias']
+        w2, b2 = sd[p + '.t324.weight'][:, :, 0, 0], sd[p + '.t324.bias']
+        A = w2 @ w1
+        wc = _W(torch.cat([A, A + w2], 1))
+        d0 = None
+        g0 = _S(F.conv2d(torch.cat([vv, f[0]], 1), wc[:, :, None, None], w2 @ b1 + b2))
+    else:
+        d0 = _up_block(sd, p + '.dec4', d1, f[0], train)
+        g0 = _conv(sd, p + '.t324', _S(f[0] + d0))
     g1 = _conv(sd, p + '.t323', _S(f[1] + d1))
     g2 = _conv(sd, p + '.t322', _S(f[2] + d2))
     g3 = _conv(sd, p + '.t321', _S(f[3] + d3))

@@ -1099,6 +1099,12 @@ extern "C" int tcct_pw_bwd_cat2(const void* x1, const void* x2, const void* dy, 
     TCCT_CHECK(K == 128 && x2 != nullptr && dx2 != nullptr, "pw_bwd_cat2: two halves of 64 channels only (K=%d)", K);
     return pw_bwd_impl(x1, dy, w, x2, dx1, dx2, dw, nullptr, M, K, N, stream, true);
 }
+/* the concatenated form with a bias gradient and two halves of 32 OR 64 channels (K = 64 / 128): the decoder's composed tail, tcct_tail_compose */
+extern "C" int tcct_pw_bwd_cat2_bias(const void* x1, const void* x2, const void* dy, const float* w, void* dx1, void* dx2, float* dw, float* dbias,
+                                     int64_t M, int K, int N, tcct_stream_t stream) {
+    TCCT_CHECK((K == 128 || (K == 64 && N == 32)) && x2 != nullptr && dx2 != nullptr, "pw_bwd_cat2_bias: K=%d N=%d (128 -> any, or 64 -> 32)", K, N);
+    return pw_bwd_impl(x1, dy, w, x2, dx1, dx2, dw, dbias, M, K, N, stream, true);
+}
 extern "C" int tcct_pw_bwd(const void* x, const void* dy, const float* w, const void* res, void* dx, float* dw, float* dbias, int64_t M,
                            int K, int N, tcct_stream_t stream) {
     return pw_bwd_impl(x, dy, w, res, dx, nullptr, dw, dbias, M, K, N, stream);
@@ -1217,6 +1223,7 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
 #undef BLG
         TCCT_LAUNCH_OK();
     }
+    if (split && KT == 2) { BLX(1, 2, true, -1, -1) TCCT_LAUNCH_OK(); }     // two halves of 32 channels (checked by the caller: N = 32)
 #define BL(NTV, KTV) BLX(NTV, KTV, false, -1, -1)
 #define BLS(NTV) BLX(NTV, 4, true, -1, -1)
 #define BLK(NTV) switch (KT) { case 1: BL(NTV, 1) break; case 2: BL(NTV, 2) break; case 3: BL(NTV, 3) break; default: if (split) BLS(NTV) else BL(NTV, 4) break; }

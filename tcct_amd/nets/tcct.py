@@ -507,6 +507,16 @@ class MPUpBlock(nn.Module):
         u = ops.bilinear(y, (x1.shape[1] * 2, x1.shape[2] * 2), True, residual=x2)
         return _conv(self.post[0], u)
 
+    def forward_through(self, x1, x2, t32):
+        """t32(x2 + forward(x1, x2)) for the LAST decoder block, whose own output nobody else reads (FTC.forward, reference tcct.py:1031-1040):
+        resize, `post`, the skip add and `t32` as ONE GEMM with composed weights (ops.up_skip_conv_t32), or None when that form does not apply"""
+        p, t = self.post[0], t32
+        probe = x1.new_empty((x1.shape[0], x1.shape[1], x1.shape[2], self.prep[0].out_channels))
+        if not (self.prep[1].training and ops.up_skip_conv_t32_ok(probe, x2, p.weight, p.bias, t.weight, t.bias)):
+            return None
+        y = _conv_bn(self.prep[0], self.prep[1], x1, post='lrelu')
+        return ops.up_skip_conv_t32(y, x2, p.weight, p.bias, t.weight, t.bias, True)
+
 
 class FTC(nn.Module):
     """reference nets/tcct.py:944-1046 with SimpleFusion (flag_gate=False)."""
@@ -632,8 +642,11 @@ class FTC(nn.Module):
             d3, s3 = self.dec1(y8, f[3], with_sum=True)
             d2, s2 = self.dec2(d3, f[2], with_sum=True)
             d1, s1 = self.dec3(d2, f[1], with_sum=True)
-            d0, s0 = self.dec4(d1, f[0], with_sum=True, want_plain=False)      # only x_0 + y_0 is read below: d0 is never written
-            g0, g1, g2, g3 = _conv(self.t324, s0), _conv(self.t323, s1), _conv(self.t322, s2), _conv(self.t321, s3)
+            g0 = self.dec4.forward_through(d1, f[0], self.t324)      # level 0: post, `x_0 + y_0` and t324 as one GEMM (u, d0, s0 never written)
+            if g0 is None:
+                d0, s0 = self.dec4(d1, f[0], with_sum=True, want_plain=False)      # only x_0 + y_0 is read below: d0 is never written
+                g0 = _conv(self.t324, s0)
+            g1, g2, g3 = _conv(self.t323, s1), _conv(self.t322, s2), _conv(self.t321, s3)
         # norm_add([y0,y1,y2]) (reference tcct.py:937-942,1035) -> `self.feats`: evaluated lazily on first access (only the
         # feature-polarization loss reads it; with --udh=false the six level-0 passes are simply never launched)
         self._feats_src = (g0, g1, g2, size)

@@ -947,6 +947,63 @@ def up_skip_conv(y, skip, w, bias, align_corners=True, want_plain=True):
     return (d if want_plain else None), s_
 
 
+TAIL_COMPOSE = os.environ.get('TCCT_TAIL_COMPOSE', '1') != '0'      # =0: resize + add, post convolution (+ sum), t324 as three kernels (round-3 form; A/B timing)
+
+
+class _UpSkipConvT32(torch.autograd.Function):
+    """g0 = t32(post(up(y) + skip) + skip) for the LAST decoder block (reference nets/tcct.py:908-914, :1031, :1035-1040) as ONE 64 -> 32 GEMM over the
+    never-materialised concatenation [up(y) | skip] with composed weights (csrc/decoder_tail.hip): u, d0 and s0 are not written, the backward pass is
+    one fused kernel + a 32 x 32 de-composition of the weight gradients."""
+
+    @staticmethod
+    def forward(ctx, y, skip, w1, b1, w2, b2, align):
+        _chk(y, skip, w1, b1, w2, b2)
+        N_, H, W_, C = y.shape
+        _, Ho, Wo, _ = skip.shape
+        dev = y.device
+        v = torch.empty_like(skip)
+        lib.bilinear_fwd(y, v, N_, H, W_, C, Ho, Wo, int(align), dtype_code(y.dtype))
+        wc = torch.empty((32, 64), device=dev, dtype=torch.float32)
+        c = torch.empty(32, device=dev, dtype=torch.float32)
+        lib.tail_compose(w1, b1, w2, b2, wc, c)
+        g = torch.empty_like(skip)
+        lib.pw_fwd_cat2(v, skip, 32, wc, c, g, N_ * Ho * Wo, 64, 32, None, 0)
+        ctx.save_for_backward(v, skip, wc)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.cfg = (N_, H, W_, C, Ho, Wo, int(align))
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        v, skip, wc = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        N_, H, W_, C, Ho, Wo, align = ctx.cfg
+        dg = _as(dg, v.dtype)
+        dev = v.device
+        M = N_ * Ho * Wo
+        dv, dskip = torch.empty_like(v), torch.empty_like(skip)
+        dwc = ZERO.get((32, 64), torch.float32, dev)
+        dc = ZERO.get((32,), torch.float32, dev)
+        lib.pw_bwd_cat2_bias(v, skip, dg, wc, dv, dskip, dwc, dc, M, 64, 32)
+        dy = torch.empty((N_, H, W_, C), device=dev, dtype=v.dtype)
+        lib.bilinear_bwd(dv, dy, N_, H, W_, C, Ho, Wo, align, dtype_code(v.dtype))
+        dw1, db1, dw2, db2 = _grad_out(w1, tuple(w1.shape)), _grad_out(b1), _grad_out(w2, tuple(w2.shape)), _grad_out(b2)
+        lib.tail_compose_bwd(w1, b1, w2, dwc, dc, dw1, db1, dw2, db2)
+        return dy, dskip, _ret(dw1, w1), _ret(db1, b1), _ret(dw2, w2), _ret(db2, b2), None
+
+
+def up_skip_conv_t32_ok(y, skip, w1, b1, w2, b2):
+    return (TAIL_COMPOSE and FUSED_PW_BWD and torch.is_grad_enabled() and y.dtype == torch.bfloat16 and skip.dtype == y.dtype and y.dim() == 4
+            and y.shape[-1] == 32 and skip.shape[-1] == 32 and tuple(skip.shape[1:3]) == (2 * y.shape[1], 2 * y.shape[2])
+            and tuple(w1.shape) == (32, 32, 1, 1) and tuple(w2.shape) == (32, 32, 1, 1) and b1 is not None and b2 is not None
+            and w1.is_contiguous() and w2.is_contiguous() and skip.numel() * 2 < 2 ** 31)
+
+
+def up_skip_conv_t32(y, skip, w1, b1, w2, b2, align_corners=True):
+    """t32(post(resize_x2(y) + skip) + skip) with post = (w1, b1), t32 = (w2, b2), both 1x1 32 -> 32; check up_skip_conv_t32_ok first"""
+    return _UpSkipConvT32.apply(y, skip, w1, b1, w2, b2, bool(align_corners))
+
+
 def conv1x1_and_sum(x, w, bias, res):
     """(conv1x1(x), conv1x1(x) + res); bf16 NHWC with channel counts multiples of 32 takes the double-store epilogue"""
     ok = (x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] % 32 == 0 and w.shape[0] % 32 == 0 and w.shape[0] <= 160

@@ -651,6 +651,36 @@ def test_mlp_gelu_applied_while_staging_is_bit_identical_to_the_separate_pass(cf
     torch.testing.assert_close(dw1, wr.grad, rtol=3e-2, atol=3e-2 * max(1.0, wr.grad.abs().max().item()))
 
 
+@pytest.mark.parametrize('nhw', [(2, 10, 14), (1, 33, 47), (3, 8, 72)])
+def test_decoder_tail_composed_gemm(nhw):
+    """csrc/decoder_tail.hip: g0 = t32(post(up(y) + skip) + skip) (reference nets/tcct.py:908-914,1031,1035-1040) as one GEMM with composed weights --
+    output and ALL gradients (y, skip, both weights, both biases) against torch's three-step chain in fp32 on the same bf16 inputs; partial tiles"""
+    from tcct_amd import ops
+    N, H, W = nhw
+    dt = torch.bfloat16
+    y = rnd(N, 32, H, W, dt=dt).requires_grad_(True)
+    skip = rnd(N, 32, 2 * H, 2 * W, seed=1, dt=dt).requires_grad_(True)
+    w1 = (rnd(32, 32, 1, 1, seed=2) / 32 ** 0.5).requires_grad_(True)
+    b1 = (rnd(32, seed=3) * 0.2).requires_grad_(True)
+    w2 = (rnd(32, 32, 1, 1, seed=4) / 32 ** 0.5).requires_grad_(True)
+    b2 = (rnd(32, seed=5) * 0.2).requires_grad_(True)
+    u = F.interpolate(y, scale_factor=2, mode='bilinear', align_corners=True) + skip
+    g = F.conv2d(skip + F.conv2d(u, w1, b1), w2, b2)
+    gg = rnd(*g.shape, seed=6, dt=dt)
+    g.backward(gg)
+    yd, sd_ = nhwc(y.detach(), dt).requires_grad_(True), nhwc(skip.detach(), dt).requires_grad_(True)
+    ps = [t.detach().cuda().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    assert ops.up_skip_conv_t32_ok(yd, sd_, *ps)
+    gd = ops.up_skip_conv_t32(yd, sd_, *ps)
+    torch.testing.assert_close(nchw(gd), g.detach(), rtol=3e-2, atol=3e-2)
+    gd.backward(nhwc(gg, dt))
+    torch.testing.assert_close(nchw(yd.grad), y.grad, rtol=3e-2, atol=3e-2 * max(1.0, y.grad.abs().max().item()))
+    torch.testing.assert_close(nchw(sd_.grad), skip.grad, rtol=3e-2, atol=3e-2 * max(1.0, skip.grad.abs().max().item()))
+    for got, ref, nm in zip(ps, (w1, b1, w2, b2), ('w1', 'b1', 'w2', 'b2')):
+        e = (got.grad.cpu() - ref.grad).norm().item() / ref.grad.norm().item()
+        assert e < 1.5e-2, (nm, e)
+
+
 def test_flat_adamw_state_refuses_a_permuted_layout():
     """FlatAdamW.state_dict() records the flat buffer's order by parameter NAME (not shape: dozens of tensors share 32x32x3x3 / [32]): moments saved
     from one order must not be applied to another order of equally shaped tensors; the same order round-trips"""

@@ -179,6 +179,33 @@ def test_decoder_block_store_points():
     _check('decoder block', hip, ref, ref0, 0.97, 0.15)
 
 
+def test_last_decoder_block_through_t32_is_one_gemm():
+    """round 4 (csrc/decoder_tail.hip): the last decoder block's `post` convolution, `x_0 + y_0` and FTC.t324 (reference nets/tcct.py:908-914, :1031,
+    :1035-1040) run as ONE 64 -> 32 GEMM over [up(y) | skip] with the composed weight [W2 W1 | W2 W1 + W2]: stores after the resize and after g0 only.
+    The HIP result must match the oracle's composed model bit for bit and sit visibly further from the three-store chain it replaces."""
+    import tcct_oracle as O
+    import importlib
+    T = importlib.import_module('tcct_amd.nets.tcct')
+    torch.manual_seed(4)
+    blk, t32 = T.MPUpBlock(32, 32), nn.Conv2d(32, 32, 1)
+    _bn_init(blk.prep[1], 13)
+    x1, x2 = _rnd(2, 32, 20, 28, seed=7), _rnd(2, 32, 40, 56, seed=8)
+    sd = {**_sd('d', blk), **_sd('t', t32)}
+    blk, t32 = blk.cuda().train(), t32.cuda()
+    g = blk.forward_through(_nhwc(x1), _nhwc(x2), t32)
+    assert g is not None
+    hip = _nchw(g)
+    with torch.no_grad(), O.rounding_points('bf16'):
+        yv = O._cba(dict(sd), 'd.prep.0', 'd.prep.1', x1, True, post='lrelu', pad=1)
+        vv = O._S(F.interpolate(yv, scale_factor=2, mode='bilinear', align_corners=True))
+        w1, b1, w2, b2 = sd['d.post.0.weight'][:, :, 0, 0], sd['d.post.0.bias'], sd['t.weight'][:, :, 0, 0], sd['t.bias']
+        A = w2 @ w1
+        ref = O._S(F.conv2d(torch.cat([vv, x2], 1), O._W(torch.cat([A, A + w2], 1))[:, :, None, None], w2 @ b1 + b2))
+        d0 = O._up_block(dict(sd), 'd', x1, x2, True)                 # the round-3 chain: u, d0 and s0 stored
+        ref3 = O._conv(sd, 't', O._S(x2 + d0))
+    _check('last decoder block -> t324 as one GEMM', hip, ref, ref3, 0.97, 0.10)
+
+
 def test_token_mixer_and_mlp_store_points():
     """MHCABlock (reference nets/tcct.py:457-469) with the pooling mixer, stage by stage (each stage of the model is fed the HIP path's own input of that
     stage: through two LayerNorms a single flipped bit moves a whole token row by fractions of an ulp, so the chain as a whole agrees on 96 % only):
