@@ -308,6 +308,14 @@ int tcct_pw_bwd_cat2_bias(const void* x1, const void* x2, const void* dy, const 
 int tcct_tail_compose(const float* w1, const float* b1, const float* w2, const float* b2, float* wc, float* c, tcct_stream_t stream);
 int tcct_tail_compose_bwd(const float* w1, const float* b1, const float* w2, const float* dwc, const float* dc, float* dw1, float* db1, float* dw2,
                           float* db2, tcct_stream_t stream);
+/* ... and through the level-0 aux head (FTC.aux0, nets/tcct.py:994,1041) when nothing else reads g0: logits0 = (W3 Wc) [up(y) | skip] + (W3 c + b3);
+ * w3 [C][32], b3 [C], C <= 8.  compose3: wcc [C][64] + its halves wa, wb [C][32] (what the small-N input-gradient kernel takes), ccc [C];
+ * compose3_bwd: the six gradients from d wcc (as halves dwa, dwb) and d ccc.  tcct_pw_fwd_cat2_f32: the forward GEMM with fp32 logits. */
+int tcct_tail_compose3(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int C, float* wcc, float* wa,
+                       float* wb, float* ccc, tcct_stream_t stream);
+int tcct_tail_compose3_bwd(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, int C, const float* dwa, const float* dwb,
+                           const float* dccc, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, tcct_stream_t stream);
+int tcct_pw_fwd_cat2_f32(const void* x1, const void* x2, int K1, const float* w, const float* bias, float* y, int64_t M, int K, int N, tcct_stream_t stream);
 int tcct_pw_wgrad_cat2(const void* x1, const void* x2, int K1, const void* dy, float* dw, float* dbias, int64_t M, int K, int N,
                        tcct_stream_t stream);
 /* pw_fwd + fused train-mode BatchNorm statistics of the consumer (bf16 output, N in {32,64,96,128}); stats fp64 [2N], zero on entry */

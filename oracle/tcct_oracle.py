@@ -258,7 +258,7 @@ def norm_add(xs):
     return _S(sum(xs) / len(xs))
 
 
-def ftc_forward(sd, x, train=True, dp_masks=None, p='base', want=None):
+def ftc_forward(sd, x, train=True, dp_masks=None, p='base', want=None, feats_used=True):
     """FTC.forward tcct.py:999-1046 -> ([y0,y1,y2,y4] logits at input size, feats [B,32,H,W]).
     `want`: optional dict that receives named intermediates (for fixtures)."""
     x = _S(x)                                                   # the image enters the network in the compute dtype
@@ -269,6 +269,7 @@ def ftc_forward(sd, x, train=True, dp_masks=None, p='base', want=None):
         tv = _cba(sd, f'{p}.tran_vit{j}.0', f'{p}.tran_vit{j}.1', v[j], train)
         f.append(_cba(sd, f'{p}.tran_cnn{j}.0', f'{p}.tran_cnn{j}.1', c[j + 1], train, res=tv))      # tv + tc: the add rides on tc's pass
     y8 = _cba(sd, p + '.head.0', p + '.head.1', f[4], train, post='lrelu', pad=1)
+    y0_direct = None
     d3 = _up_block(sd, p + '.dec1', y8, f[3], train)
     d2 = _up_block(sd, p + '.dec2', d3, f[2], train)
     d1 = _up_block(sd, p + '.dec3', d2, f[1], train)
@@ -284,6 +285,12 @@ def ftc_forward(sd, x, train=True, dp_masks=None, p='base', want=None):
         wc = _W(torch.cat([A, A + w2], 1))
         d0 = None
         g0 = _S(F.conv2d(torch.cat([vv, f[0]], 1), wc[:, :, None, None], w2 @ b1 + b2))
+        if not feats_used and sd[p + '.aux0.weight'].shape[0] <= 8:
+            # ... and through aux0 when the feature-polarization loss is off (nothing else reads g0): logits0 straight from [up(y) | skip] with the
+            # weight W3 [W2 W1 | W2 W1 + W2] rounded once; g0 above then only serves `feats` (rebuilt on demand, outside the gradient)
+            w3, b3 = sd[p + '.aux0.weight'][:, :, 0, 0], sd[p + '.aux0.bias']
+            y0_direct = F.conv2d(torch.cat([vv, f[0]], 1), _W(w3 @ torch.cat([A, A + w2], 1))[:, :, None, None], w3 @ (w2 @ b1 + b2) + b3)
+            g0 = g0.detach()
     else:
         d0 = _up_block(sd, p + '.dec4', d1, f[0], train)
         g0 = _conv(sd, p + '.t324', _S(f[0] + d0))
@@ -293,7 +300,7 @@ def ftc_forward(sd, x, train=True, dp_masks=None, p='base', want=None):
     feats = norm_add([g0, g1, g2])
     size = x.shape[-2:]
     # the four heads write fp32 logits in every mode (loss-side precision): bf16 GEMM weights, no store rounding
-    outs = [_conv(sd, p + '.aux0', g0, store=False)]
+    outs = [y0_direct if y0_direct is not None else _conv(sd, p + '.aux0', g0, store=False)]
     for name, g in (('aux1', g1), ('aux2', g2), ('aux4', g3)):
         outs.append(F.interpolate(_conv(sd, f'{p}.{name}', g, store=False), size=size, mode='bilinear',
                                   align_corners=False))
@@ -388,7 +395,7 @@ def reg_loss(sd, logits, onehot, eps_pred, eps_true, jit_true, jit_pred, train=T
 def total_loss(sd, img, onehot, udh=False, reg=False, coff_ds=1.0, coff_udh=1.0, coff_reg=0.1,
                dp_masks=None, noise=None, train=True, want=None):
     """KiteSeg.calc_loss kite/loop_seg.py:146-171: forward -> Dice(ds) -> udh -> reg."""
-    outs, feats = ftc_forward(sd, img, train, dp_masks, want=want)
+    outs, feats = ftc_forward(sd, img, train, dp_masks, want=want, feats_used=bool(udh))       # (feats_used only matters to the rounding-point model)
     parts = {'dice': deep_supervision(outs, onehot, coff_ds)}
     if udh:
         parts['udh'] = fpl_loss(sd, feats, outs[0], onehot, want) * coff_udh

@@ -71,3 +71,119 @@ extern "C" int tcct_tail_compose_bwd(const float* w1, const float* b1, const flo
     hipLaunchKernelGGL(k_tail_compose_bwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, w1, b1, w2, dwc, dc, dw1, db1, dw2, db2);
     TCCT_LAUNCH_OK();
 }
+
+// ---- the same tail THROUGH the level-0 aux head (FTC.aux0, 1x1 32 -> n_class, reference nets/tcct.py:994, :1041): when nothing else reads g0 (the
+// feature-polarization loss is off: `feats` is not evaluated), logits0 = W3 g0 + b3 = (W3 Wc) [up(y) | skip] + (W3 c + b3): g0 and dg0 -- two more 452 MB
+// tensors at the bench shape -- never exist, and the fused 64 -> 32 backward kernel is replaced by the small-N kernels of the aux heads.
+#define TAIL_MAXC 8
+__global__ void k_tail_compose3(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                const float* __restrict__ w3 /*[C][32]*/, const float* __restrict__ b3, int C, float* __restrict__ wcc /*[C][64]*/,
+                                float* __restrict__ wa /*[C][32]*/, float* __restrict__ wb /*[C][32]*/, float* __restrict__ ccc /*[C]*/) {
+    __shared__ float s1[32][33], s2[32][33], swc[32][65], sc[32], s3[TAIL_MAXC][33];
+    const int t = threadIdx.x, i = t >> 5, j = t & 31;
+    s1[i][j] = w1[t]; s2[i][j] = w2[t];
+    if (t < C * 32) s3[t >> 5][t & 31] = w3[t];
+    __syncthreads();
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) a += s2[i][k] * s1[k][j];
+    swc[i][j] = a; swc[i][32 + j] = a + s2[i][j];
+    if (t < 32) {
+        float v = b2[t];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v += s2[t][k] * b1[k];
+        sc[t] = v;
+    }
+    __syncthreads();
+    if (t < C * 64) {
+        const int c = t >> 6, q = t & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v += s3[c][k] * swc[k][q];
+        wcc[c * 64 + q] = v;
+        if (q < 32) wa[c * 32 + q] = v; else wb[c * 32 + q - 32] = v;
+    }
+    if (t < C) {
+        float v = b3[t];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v += s3[t][k] * sc[k];
+        ccc[t] = v;
+    }
+}
+/* wcc fp32 [C][64] = W3 [W2 W1 | W2 W1 + W2] (and its halves wa, wb [C][32]), ccc [C] = W3 (W2 b1 + b2) + b3; C <= 8 classes */
+extern "C" int tcct_tail_compose3(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int C,
+                                  float* wcc, float* wa, float* wb, float* ccc, tcct_stream_t stream) {
+    TCCT_CHECK(w1 && b1 && w2 && b2 && w3 && b3 && wcc && wa && wb && ccc, "tail_compose3: NULL argument");
+    TCCT_CHECK(C >= 1 && C <= TAIL_MAXC, "tail_compose3: C=%d (1..%d)", C, TAIL_MAXC);
+    hipLaunchKernelGGL(k_tail_compose3, dim3(1), dim3(1024), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3, C, wcc, wa, wb, ccc);
+    TCCT_LAUNCH_OK();
+}
+
+__global__ void k_tail_compose3_bwd(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                    const float* __restrict__ w3, int C, const float* __restrict__ dwa /*[C][32]*/, const float* __restrict__ dwb /*[C][32]*/,
+                                    const float* __restrict__ dccc /*[C]*/, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                    float* __restrict__ db2, float* __restrict__ dw3, float* __restrict__ db3) {
+    __shared__ float s1[32][33], s2[32][33], swc[32][65], sc[32], s3[TAIL_MAXC][33], sg[TAIL_MAXC][65], sgc[TAIL_MAXC], sdwc[32][65], sdc[32], sa[32][33], sb1[32];
+    const int t = threadIdx.x, i = t >> 5, j = t & 31;
+    s1[i][j] = w1[t]; s2[i][j] = w2[t];
+    if (t < C * 32) { s3[t >> 5][t & 31] = w3[t]; sg[t >> 5][t & 31] = dwa[t]; sg[t >> 5][32 + (t & 31)] = dwb[t]; }
+    if (t < C) sgc[t] = dccc[t];
+    if (t < 32) sb1[t] = b1[t];
+    __syncthreads();
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) a += s2[i][k] * s1[k][j];
+    swc[i][j] = a; swc[i][32 + j] = a + s2[i][j];
+    if (t < 32) {
+        float v = b2[t];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v += s2[t][k] * sb1[k];
+        sc[t] = v;
+    }
+    __syncthreads();
+    // dW3 = dWcc Wc^T + dccc c^T  [C][32];  dWc = W3^T dWcc  [32][64];  dc = W3^T dccc
+    if (t < C * 32) {
+        const int c = t >> 5, k2 = t & 31;
+        float v = sgc[c] * sc[k2];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) v += sg[c][q] * swc[k2][q];
+        dw3[t] = v;
+    }
+    if (t < C) db3[t] = sgc[t];
+    {
+        float v0 = 0.f, v1 = 0.f;
+        for (int c = 0; c < C; ++c) { v0 += s3[c][i] * sg[c][j]; v1 += s3[c][i] * sg[c][32 + j]; }
+        sdwc[i][j] = v0; sdwc[i][32 + j] = v1;
+    }
+    if (t < 32) {
+        float v = 0.f;
+        for (int c = 0; c < C; ++c) v += s3[c][t] * sgc[c];
+        sdc[t] = v;
+    }
+    __syncthreads();
+    // as k_tail_compose_bwd
+    const float g2 = sdwc[i][32 + j];
+    sa[i][j] = sdwc[i][j] + g2;
+    __syncthreads();
+    float x = g2 + sdc[i] * sb1[j], y = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { x += sa[i][k] * s1[j][k]; y += s2[k][i] * sa[k][j]; }
+    dw2[t] = x;
+    dw1[t] = y;
+    if (t < 32) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v += s2[k][t] * sdc[k];
+        db1[t] = v;
+        db2[t] = sdc[t];
+    }
+}
+/* gradients of the six tensors from those of the composed pair: dwa / dwb fp32 [C][32] (the two halves of d wcc), dccc [C]; all outputs overwritten */
+extern "C" int tcct_tail_compose3_bwd(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, int C, const float* dwa,
+                                      const float* dwb, const float* dccc, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
+                                      tcct_stream_t stream) {
+    TCCT_CHECK(w1 && b1 && w2 && b2 && w3 && dwa && dwb && dccc && dw1 && db1 && dw2 && db2 && dw3 && db3, "tail_compose3_bwd: NULL argument");
+    TCCT_CHECK(C >= 1 && C <= TAIL_MAXC, "tail_compose3_bwd: C=%d (1..%d)", C, TAIL_MAXC);
+    hipLaunchKernelGGL(k_tail_compose3_bwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, C, dwa, dwb, dccc, dw1, db1, dw2, db2, dw3, db3);
+    TCCT_LAUNCH_OK();
+}

@@ -344,6 +344,12 @@ extern "C" int tcct_pw_fwd_cat2(const void* x1, const void* x2, int K1, const fl
     if (stats) TCCT_CHECK(N % 32 == 0 && N <= 128, "pw_fwd_cat2: fused statistics need N in {32,64,96,128} (got %d)", N);
     return pw_fwd_impl(x1, w, bias, y, M, K, N, 0, TCCT_BF16, stats, pre_act, stream, nullptr, 0, 0, PwSplit{(const bf16*)x2, K1, nullptr, 0, nullptr, nullptr, 1, nullptr});
 }
+/* the same with fp32 output rows (N <= 32: the composed aux head over [up(y) | skip], csrc/decoder_tail.hip) */
+extern "C" int tcct_pw_fwd_cat2_f32(const void* x1, const void* x2, int K1, const float* w, const float* bias, float* y, int64_t M, int K, int N,
+                                    tcct_stream_t stream) {
+    TCCT_CHECK(x2 != nullptr && N >= 1 && N <= 32, "pw_fwd_cat2_f32: x2 is NULL or N=%d > 32", N);
+    return pw_fwd_impl(x1, w, bias, y, M, K, N, 0, TCCT_F32, nullptr, 0, stream, nullptr, 0, 0, PwSplit{(const bf16*)x2, K1, nullptr, 0, nullptr, nullptr, 1, nullptr});
+}
 /* input gradient of the same convolution: [dx1 | dx2] = dy W with w [Nout, K] (the weight as stored), dy [M, Nout]; dx1 [M,K1], dx2 [M,K-K1] */
 extern "C" int tcct_pw_dgrad_split2(const void* dy, const float* w, void* dx1, void* dx2, int K1, int64_t M, int Nout, int K,
                                     tcct_stream_t stream) {

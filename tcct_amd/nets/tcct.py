@@ -507,14 +507,18 @@ class MPUpBlock(nn.Module):
         u = ops.bilinear(y, (x1.shape[1] * 2, x1.shape[2] * 2), True, residual=x2)
         return _conv(self.post[0], u)
 
-    def forward_through(self, x1, x2, t32):
+    def forward_through(self, x1, x2, t32, aux=None):
         """t32(x2 + forward(x1, x2)) for the LAST decoder block, whose own output nobody else reads (FTC.forward, reference tcct.py:1031-1040):
-        resize, `post`, the skip add and `t32` as ONE GEMM with composed weights (ops.up_skip_conv_t32), or None when that form does not apply"""
+        resize, `post`, the skip add and `t32` as ONE GEMM with composed weights (ops.up_skip_conv_t32), or None when that form does not apply.
+        aux: the level-0 head when the caller needs only ITS output of g0 -> returns the tuple (fp32 logits NHWC, resized y) instead"""
         p, t = self.post[0], t32
         probe = x1.new_empty((x1.shape[0], x1.shape[1], x1.shape[2], self.prep[0].out_channels))
         if not (self.prep[1].training and ops.up_skip_conv_t32_ok(probe, x2, p.weight, p.bias, t.weight, t.bias)):
             return None
         y = _conv_bn(self.prep[0], self.prep[1], x1, post='lrelu')
+        if aux is not None and ops.up_skip_conv_t32_aux_ok(probe, x2, p.weight, p.bias, t.weight, t.bias, aux.weight, aux.bias):
+            # nothing but the aux head reads g0 in this step: (fp32 logits, resized y) -- g0 is never written
+            return ops.up_skip_conv_t32_aux(y, x2, p.weight, p.bias, t.weight, t.bias, aux.weight, aux.bias, True)
         return ops.up_skip_conv_t32(y, x2, p.weight, p.bias, t.weight, t.bias, True)
 
 
@@ -569,6 +573,8 @@ class FTC(nn.Module):
                 raise TcctError('the legacy-head layout (onnx/tcct_goals.py) is supported for inference and Dice/boundary training; its '
                                 'six-tensor `feats` (tcct_goals.py:1021) is not built')
             g0, g1, g2, size = self._feats_src
+            if callable(g0):            # the step composed the decoder tail through aux0 and never wrote g0: rebuild it (no gradient)
+                g0 = g0()
             self._feats = [_nchw_view(ops.norm_add3(g0, g1, g2))]
             self._feats_src = None
         return self._feats
@@ -642,7 +648,14 @@ class FTC(nn.Module):
             d3, s3 = self.dec1(y8, f[3], with_sum=True)
             d2, s2 = self.dec2(d3, f[2], with_sum=True)
             d1, s1 = self.dec3(d2, f[1], with_sum=True)
-            g0 = self.dec4.forward_through(d1, f[0], self.t324)      # level 0: post, `x_0 + y_0` and t324 as one GEMM (u, d0, s0 never written)
+            # level 0: post, `x_0 + y_0` and t324 as one GEMM (u, d0, s0 never written) -- and through aux0 as well when the feature-polarization
+            # loss is off (nothing else reads g0 then; `feats` rebuilds it on demand)
+            y0_direct = None
+            g0 = self.dec4.forward_through(d1, f[0], self.t324, aux=None if self.eager_feats else self.aux0)
+            if isinstance(g0, tuple):
+                y0_direct, v_up = g0
+                skip0, pw, tw = f[0], self.dec4.post[0], self.t324
+                g0 = lambda: ops.up_skip_conv_t32_from_v(v_up, skip0, pw.weight, pw.bias, tw.weight, tw.bias)      # noqa: E731
             if g0 is None:
                 d0, s0 = self.dec4(d1, f[0], with_sum=True, want_plain=False)      # only x_0 + y_0 is read below: d0 is never written
                 g0 = _conv(self.t324, s0)
@@ -660,7 +673,7 @@ class FTC(nn.Module):
                 self._feats, self._feats_src = [_nchw_view(feats)], None
         # aux heads: logits are produced and resized in fp32 in every mode (loss-side precision)
         f32 = torch.float32
-        y0 = _conv(self.aux0, g0, out_dtype=f32)
+        y0 = y0_direct if y0_direct is not None else _conv(self.aux0, g0, out_dtype=f32)
         if self.defer_aux_resize and torch.is_grad_enabled():
             # training loop (KiteSeg.calc_loss): the three aux heads stay at their own resolution; the Dice criterion resizes on the fly
             return [_nchw_view(y0)] + [ops.LowResLogits(_conv(m, g, out_dtype=f32), size) for m, g in ((self.aux1, g1), (self.aux2, g2), (self.aux4, g3))]

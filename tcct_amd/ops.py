@@ -1004,6 +1004,81 @@ def up_skip_conv_t32(y, skip, w1, b1, w2, b2, align_corners=True):
     return _UpSkipConvT32.apply(y, skip, w1, b1, w2, b2, bool(align_corners))
 
 
+class _UpSkipConvT32Aux(torch.autograd.Function):
+    """logits0 = aux0(t32(post(up(y) + skip) + skip)) (reference nets/tcct.py:908-914,1031,1035-1041) as ONE 64 -> n_class GEMM with fp32 output over
+    [up(y) | skip] (csrc/decoder_tail.hip, `compose3`): for steps in which nothing else reads g0 -- the feature-polarization loss is off.  g0 and dg0
+    never exist; the backward pass uses the small-N kernels of the aux heads on the two halves.  Returns (logits, v): v = up(y) (no gradient) lets
+    `FTC.feats` rebuild g0 on demand."""
+
+    @staticmethod
+    def forward(ctx, y, skip, w1, b1, w2, b2, w3, b3, align):
+        _chk(y, skip, w1, b1, w2, b2, w3, b3)
+        N_, H, W_, C = y.shape
+        _, Ho, Wo, _ = skip.shape
+        dev, nc = y.device, w3.shape[0]
+        v = torch.empty_like(skip)
+        lib.bilinear_fwd(y, v, N_, H, W_, C, Ho, Wo, int(align), dtype_code(y.dtype))
+        wcc = torch.empty((nc, 64), device=dev, dtype=torch.float32)
+        wa, wb = torch.empty((nc, 32, 1, 1), device=dev, dtype=torch.float32), torch.empty((nc, 32, 1, 1), device=dev, dtype=torch.float32)
+        ccc = torch.empty(nc, device=dev, dtype=torch.float32)
+        lib.tail_compose3(w1, b1, w2, b2, w3, b3, nc, wcc, wa, wb, ccc)
+        lg = torch.empty((N_, Ho, Wo, nc), device=dev, dtype=torch.float32)
+        lib.pw_fwd_cat2_f32(v, skip, 32, wcc, ccc, lg, N_ * Ho * Wo, 64, nc)
+        ctx.save_for_backward(v, skip, wa, wb)
+        ctx.params = (w1, b1, w2, b2, w3, b3)
+        ctx.cfg = (N_, H, W_, C, Ho, Wo, int(align), nc)
+        ctx.mark_non_differentiable(v)
+        return lg, v
+
+    @staticmethod
+    def backward(ctx, dl, _dv):
+        v, skip, wa, wb = ctx.saved_tensors
+        w1, b1, w2, b2, w3, b3 = ctx.params
+        N_, H, W_, C, Ho, Wo, align, nc = ctx.cfg
+        dl = _as(dl, torch.float32)
+        dev = v.device
+        M = N_ * Ho * Wo
+        dv, dskip = torch.empty_like(v), torch.empty_like(skip)
+        F32_, BF_ = dtype_code(torch.float32), dtype_code(v.dtype)
+        lib.conv2d_dgrad(dl, wa, dv, N_, Ho, Wo, 32, nc, 1, 1, 0, 0, F32_, BF_)
+        lib.conv2d_dgrad(dl, wb, dskip, N_, Ho, Wo, 32, nc, 1, 1, 0, 0, F32_, BF_)
+        dy = torch.empty((N_, H, W_, C), device=dev, dtype=v.dtype)
+        lib.bilinear_bwd(dv, dy, N_, H, W_, C, Ho, Wo, align, BF_)
+        params = (w1, b1, w2, b2, w3, b3)
+        with _wgrad_stream(_slot_written(*params), v, skip, dl, wa, wb):
+            dwa, dwb = ZERO.get((nc, 32), torch.float32, dev), ZERO.get((nc, 32), torch.float32, dev)
+            dccc = ZERO.get((nc,), torch.float32, dev)
+            lib.pw_wgrad_smalln(v, dl, dwa, dccc, M, 32, nc, BF_, F32_)
+            lib.pw_wgrad_smalln(skip, dl, dwb, None, M, 32, nc, BF_, F32_)
+            outs = [_grad_out(p, tuple(p.shape)) for p in params]
+            lib.tail_compose3_bwd(w1, b1, w2, b2, w3, nc, dwa, dwb, dccc, *outs)
+        return (dy, dskip) + tuple(_ret(o, p) for o, p in zip(outs, params)) + (None,)
+
+
+TAIL_AUX = os.environ.get('TCCT_TAIL_AUX', '1') != '0'       # =0: the composed tail stops at g0, aux0 stays its own kernels (A/B timing)
+
+
+def up_skip_conv_t32_aux_ok(y, skip, w1, b1, w2, b2, w3, b3):
+    return (TAIL_AUX and up_skip_conv_t32_ok(y, skip, w1, b1, w2, b2) and w3.dim() == 4 and tuple(w3.shape[1:]) == (32, 1, 1) and 2 <= w3.shape[0] <= 8
+            and b3 is not None and w3.is_contiguous())
+
+
+def up_skip_conv_t32_aux(y, skip, w1, b1, w2, b2, w3, b3, align_corners=True):
+    """(aux(t32(post(resize_x2(y) + skip) + skip)) as fp32 NHWC logits, resize_x2(y)); check up_skip_conv_t32_aux_ok first"""
+    return _UpSkipConvT32Aux.apply(y, skip, w1, b1, w2, b2, w3, b3, bool(align_corners))
+
+
+def up_skip_conv_t32_from_v(v, skip, w1, b1, w2, b2):
+    """g0 of the composed tail from an already resized v (no gradient): what `FTC.feats` needs when the step itself skipped g0"""
+    with torch.no_grad():
+        wc = torch.empty((32, 64), device=v.device, dtype=torch.float32)
+        c = torch.empty(32, device=v.device, dtype=torch.float32)
+        lib.tail_compose(w1, b1, w2, b2, wc, c)
+        g = torch.empty_like(skip)
+        lib.pw_fwd_cat2(v, skip, 32, wc, c, g, v.numel() // 32, 64, 32, None, 0)
+    return g
+
+
 def conv1x1_and_sum(x, w, bias, res):
     """(conv1x1(x), conv1x1(x) + res); bf16 NHWC with channel counts multiples of 32 takes the double-store epilogue"""
     ok = (x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] % 32 == 0 and w.shape[0] % 32 == 0 and w.shape[0] <= 160

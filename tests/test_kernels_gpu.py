@@ -681,6 +681,43 @@ def test_decoder_tail_composed_gemm(nhw):
         assert e < 1.5e-2, (nm, e)
 
 
+@pytest.mark.parametrize('nhw', [(2, 10, 14), (1, 33, 47)])
+@pytest.mark.parametrize('nc', [5, 8])
+def test_decoder_tail_composed_through_the_aux_head(nhw, nc):
+    """csrc/decoder_tail.hip, `compose3`: logits0 = aux0(t32(post(up(y) + skip) + skip)) as one 64 -> n_class GEMM with fp32 output -- logits and the
+    gradients of y, skip and all SIX parameter tensors against torch's four-step chain; plus g0 rebuilt on demand from the returned resize"""
+    from tcct_amd import ops
+    N, H, W = nhw
+    dt = torch.bfloat16
+    y = rnd(N, 32, H, W, dt=dt).requires_grad_(True)
+    skip = rnd(N, 32, 2 * H, 2 * W, seed=1, dt=dt).requires_grad_(True)
+    w1 = (rnd(32, 32, 1, 1, seed=2) / 32 ** 0.5).requires_grad_(True)
+    b1 = (rnd(32, seed=3) * 0.2).requires_grad_(True)
+    w2 = (rnd(32, 32, 1, 1, seed=4) / 32 ** 0.5).requires_grad_(True)
+    b2 = (rnd(32, seed=5) * 0.2).requires_grad_(True)
+    w3 = (rnd(nc, 32, 1, 1, seed=7) / 32 ** 0.5).requires_grad_(True)
+    b3 = (rnd(nc, seed=8) * 0.2).requires_grad_(True)
+    u = F.interpolate(y, scale_factor=2, mode='bilinear', align_corners=True) + skip
+    g = F.conv2d(skip + F.conv2d(u, w1, b1), w2, b2)
+    lg = F.conv2d(g, w3, b3)
+    gl = rnd(*lg.shape, seed=6)
+    lg.backward(gl)
+    yd, sd_ = nhwc(y.detach(), dt).requires_grad_(True), nhwc(skip.detach(), dt).requires_grad_(True)
+    ps = [t.detach().cuda().requires_grad_(True) for t in (w1, b1, w2, b2, w3, b3)]
+    assert ops.up_skip_conv_t32_aux_ok(yd, sd_, *ps)
+    ld, v = ops.up_skip_conv_t32_aux(yd, sd_, *ps)
+    assert ld.dtype == torch.float32 and not v.requires_grad
+    torch.testing.assert_close(nchw(ld), lg.detach(), rtol=3e-2, atol=3e-2)
+    ld.backward(nhwc(gl, torch.float32))
+    torch.testing.assert_close(nchw(yd.grad), y.grad, rtol=3e-2, atol=3e-2 * max(1.0, y.grad.abs().max().item()))
+    torch.testing.assert_close(nchw(sd_.grad), skip.grad, rtol=3e-2, atol=3e-2 * max(1.0, skip.grad.abs().max().item()))
+    for got, ref, nm in zip(ps, (w1, b1, w2, b2, w3, b3), ('w1', 'b1', 'w2', 'b2', 'w3', 'b3')):
+        e = (got.grad.cpu() - ref.grad).norm().item() / ref.grad.norm().item()
+        assert e < 1.5e-2, (nm, e)
+    g0 = ops.up_skip_conv_t32_from_v(v, sd_.detach(), *[p.detach() for p in ps[:4]])
+    torch.testing.assert_close(nchw(g0), g.detach(), rtol=3e-2, atol=3e-2)
+
+
 def test_flat_adamw_state_refuses_a_permuted_layout():
     """FlatAdamW.state_dict() records the flat buffer's order by parameter NAME (not shape: dozens of tensors share 32x32x3x3 / [32]): moments saved
     from one order must not be applied to another order of equally shaped tensors; the same order round-trips"""
