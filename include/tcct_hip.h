@@ -486,6 +486,13 @@ int tcct_fpl_loss(const float* pro_sum, const uint32_t* counts, const float* buf
 /* binmap uint8 [M] (bin 0..31, 255 = not selected); dfeat [M,32] */
 int tcct_fpl_backward(const uint8_t* labels, const uint8_t* binmap, const float* dpro_over_n, const float* grad_out,
                       float grad_scale, int64_t M, void* dfeat, int dtype, tcct_stream_t stream);
+/* norm_add's backward when its gradient is the feature-polarization loss's (round 4, csrc/pool_resize.hip): d loss / d feats is a function of two
+ * bytes per pixel (label, bin) and the [classes][32][32] table dpro_over_n, so it is looked up instead of being written by tcct_fpl_backward and read
+ * three times.  l2norm: dx = scale * l2norm_bwd(x, dfeat) (+ res); bilinear: dx [N,H,W,32] = resize_bwd(dfeat [N,Ho,Wo,32]); 32 feature channels. */
+int tcct_l2norm_bwd_fplgrad(const void* x, const uint8_t* labels, const uint8_t* binmap, const float* dpro_over_n, const float* grad_out,
+                            float grad_scale, int ncls, const void* res, void* dx, int64_t M, float eps, float scale, int dtype, tcct_stream_t stream);
+int tcct_bilinear_bwd_fplgrad(const uint8_t* labels, const uint8_t* binmap, const float* dpro_over_n, const float* grad_out, float grad_scale, int ncls,
+                              void* dx, int N, int H, int W, int Ho, int Wo, int align_corners, int dtype, tcct_stream_t stream);
 
 /* ---- factorised attention with convolutional relative position encoding: FactorAtt_ConvRelPosEnc.forward
  * nets/tcct.py:311-341 and ConvRelPosEnc.forward nets/tcct.py:265-287, the token mixer the reference keeps commented out in MHCABlock

@@ -652,6 +652,170 @@ extern "C" int tcct_l2norm_bwd_scaled_add(const void* x, const void* dy, const v
     return l2norm_bwd_impl(x, dy, dx, M, C, eps, scale, dtype, stream, res);
 }
 
+// ------------------------------------------------- backward of norm_add when its gradient comes from the feature-polarization loss (round 4)
+// d loss / d feats of RegNet.regular_udh (reference nets/reg.py:86-105, nets/fcs.py:25-50) is a pure function of TWO BYTES per pixel:
+//     dfeat[p][c] = g * dpro_over_n[label[p]][bin[p]][c]      (0 for pixels outside every bin; tcct_fpl_backward)
+// with a [classes][32][32] fp32 table.  Round 3 wrote that 452 MB tensor (bench shape) and read it three times -- the L2-normalise backward of g0
+// and the two bilinear backward passes to the coarser maps.  Here the three kernels look the rows up in LDS instead: dfeat is never written
+// (k_fpl_bwd is gone from the step) and the two resize gradients read 2 bytes per contributing pixel instead of 64.  Values are rounded to the
+// storage type first, exactly as the tensor used to hold them.
+#define FG_BINS 32
+template <typename T> __device__ __forceinline__ float fg_round(float v);
+template <> __device__ __forceinline__ float fg_round<float>(float v) { return v; }
+template <> __device__ __forceinline__ float fg_round<bf16>(float v) { return __bfloat162float(__float2bfloat16(v)); }
+
+// dx = oscale * l2norm_bwd(x, dfeat) + res  (C = 32: eight lanes per pixel)
+template <typename T>
+__global__ void k_l2norm_bwd_fplgrad(const T* __restrict__ x, const uint8_t* __restrict__ lab, const uint8_t* __restrict__ binmap,
+                                     const float* __restrict__ dpro, const float* __restrict__ gout, float gscale, int ncls, const T* __restrict__ res,
+                                     T* __restrict__ out, int64_t M, float eps, float oscale) {
+    extern __shared__ float stab[];         // [ncls][32][32]
+    for (int i = threadIdx.x; i < ncls * FG_BINS * 32; i += blockDim.x) stab[i] = dpro[i];
+    __syncthreads();
+    const float gs = gscale * (gout ? *gout : 1.f);
+    const int64_t total = M * 8;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t rounds = (total + stride - 1) / stride;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t it = 0; it < rounds; ++it, i += stride) {
+        const bool ok = i < total;
+        const int64_t ii = ok ? i : 0, p = ii >> 3;
+        const int sub = (int)(ii & 7);
+        const f4 v = ld4(x + ii * 4);
+        const int b = binmap[p], l = lab[p];
+        f4 g = f4zero();
+        if (b < FG_BINS && l < ncls) {
+            const float* d = stab + (l * FG_BINS + b) * 32 + sub * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g.v[k] = fg_round<T>(gs * d[k]);
+        }
+        float ss = v.v[0] * v.v[0] + v.v[1] * v.v[1] + v.v[2] * v.v[2] + v.v[3] * v.v[3];
+        float dot = v.v[0] * g.v[0] + v.v[1] * g.v[1] + v.v[2] * g.v[2] + v.v[3] * g.v[3];
+        for (int o = 4; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); dot += __shfl_xor(dot, o, 64); }
+        const float nrm = sqrtf(ss), dn = fmaxf(nrm, eps);
+        const float coef = nrm > eps ? dot / (dn * dn * nrm) : 0.f;
+        f4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.v[k] = oscale * (g.v[k] / dn - v.v[k] * coef);
+        if (res) {
+            const f4 e = ld4(res + ii * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r.v[k] += e.v[k];
+        }
+        if (ok) st4(out + ii * 4, r);
+    }
+}
+/* dx = scale * l2norm_bwd(x, dfeat) (+ res, nullable) with dfeat looked up from (labels, binmap, dpro_over_n [ncls][32][32]) instead of read: the
+ * level-0 branch of norm_add's backward under the feature-polarization loss.  x, res, dx [M,32]; grad_out: device scalar (nullable) */
+extern "C" int tcct_l2norm_bwd_fplgrad(const void* x, const uint8_t* labels, const uint8_t* binmap, const float* dpro_over_n, const float* grad_out,
+                                       float grad_scale, int ncls, const void* res, void* dx, int64_t M, float eps, float scale, int dtype,
+                                       tcct_stream_t stream) {
+    TCCT_CHECK(ncls >= 1 && ncls <= 16 && labels && binmap && dpro_over_n, "l2norm_bwd_fplgrad: bad arguments (ncls=%d)", ncls);
+    const size_t lds = sizeof(float) * (size_t)ncls * FG_BINS * 32;
+    TCCT_DISPATCH(dtype, {
+        static bool at_ = false;
+        if (!at_) { (void)hipFuncSetAttribute((const void*)k_l2norm_bwd_fplgrad<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); at_ = true; }
+        hipLaunchKernelGGL((k_l2norm_bwd_fplgrad<T>), dim3(tcct_grid(M * 8, PB, 2048)), dim3(PB), lds, (hipStream_t)stream, (const T*)x, labels, binmap,
+                           dpro_over_n, grad_out, grad_scale, ncls, (const T*)res, (T*)dx, M, eps, scale); });
+    TCCT_LAUNCH_OK();
+}
+
+// dx [N,H,W,32] = bilinear_bwd(dfeat [N,Ho,Wo,32]) with dfeat looked up: k_bilinear_bwd_tab with the 16 contributor loads replaced by (label, bin)
+// byte loads + LDS table rows
+template <typename T>
+__global__ void __launch_bounds__(PB) k_bilinear_bwd_fplgrad(const uint8_t* __restrict__ lab, const uint8_t* __restrict__ binmap, const float* __restrict__ dpro,
+                                                             const float* __restrict__ gout, float gscale, int ncls, T* __restrict__ dx, int N, int H,
+                                                             int W, int Ho, int Wo, float sh, float sw, int align, int DW, int KT, int tilesW,
+                                                             int tilesH) {
+    extern __shared__ int smem_i[];             // idx[(DH+DW)][KT], weights[(DH+DW)][KT], counts[DH+DW], then the table [ncls][32][32]
+    int* tidx = smem_i;
+    float* twt = reinterpret_cast<float*>(smem_i + (BT_DH + DW) * KT);
+    int* tcnt = smem_i + 2 * (BT_DH + DW) * KT;
+    float* stab = reinterpret_cast<float*>(smem_i + ((2 * (BT_DH + DW) * KT + BT_DH + DW + 3) & ~3));
+    const int t = threadIdx.x;
+    for (int i = t; i < ncls * FG_BINS * 32; i += PB) stab[i] = dpro[i];
+    int bid = blockIdx.x;
+    const int tw = bid % tilesW; bid /= tilesW;
+    const int th = bid % tilesH;
+    const int n = bid / tilesH;
+    const int hi0 = th * BT_DH, wi0 = tw * DW;
+    if (t < BT_DH + DW) {
+        const bool isrow = t < BT_DH;
+        const int i = isrow ? hi0 + t : wi0 + (t - BT_DH);
+        const int in = isrow ? H : W, out = isrow ? Ho : Wo;
+        const float sc = isrow ? sh : sw;
+        int cnt = 0;
+        if (i < in) {
+            int lo, hi;
+            cand_range(i, sc, out, align, lo, hi);
+            for (int o = lo; o <= hi && cnt < KT; ++o) {
+                Lerp a = src_index(o, sc, in, align);
+                float wgt = (a.i0 == i ? a.l0 : 0.f) + (a.i1 == i ? a.l1 : 0.f);
+                if (wgt != 0.f) { tidx[t * KT + cnt] = o; twt[t * KT + cnt] = wgt; ++cnt; }
+            }
+        }
+        tcnt[t] = cnt;
+    }
+    __syncthreads();
+    const float gs = gscale * (gout ? *gout : 1.f);
+    const uint8_t* L = lab + (int64_t)n * Ho * Wo;
+    const uint8_t* B = binmap + (int64_t)n * Ho * Wo;
+    T* out = dx + (int64_t)n * H * W * 32;
+    for (int i = t; i < BT_DH * DW * 4; i += PB) {
+        const int cv = i & 3, pix = i >> 2;
+        const int r = pix / DW, cc = pix - r * DW;
+        const int hi = hi0 + r, wi = wi0 + cc;
+        if (hi >= H || wi >= W) continue;
+        const int nr = tcnt[r], nc = tcnt[BT_DH + cc];
+        const int* ri = tidx + r * KT;
+        const float* rw = twt + r * KT;
+        const int* ci = tidx + (BT_DH + cc) * KT;
+        const float* cw = twt + (BT_DH + cc) * KT;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int a = 0; a < nr; ++a) {
+            const int64_t rowoff = (int64_t)ri[a] * Wo;
+            const float wh = rw[a];
+            for (int b = 0; b < nc; ++b) {
+                const int64_t q = rowoff + ci[b];
+                const int bb = B[q], ll = L[q];
+                if (bb < FG_BINS && ll < ncls) {
+                    const float gw = wh * cw[b];
+                    const float4 d0 = *reinterpret_cast<const float4*>(stab + (ll * FG_BINS + bb) * 32 + cv * 8);
+                    const float4 d1 = *reinterpret_cast<const float4*>(stab + (ll * FG_BINS + bb) * 32 + cv * 8 + 4);
+                    acc[0] += gw * fg_round<T>(gs * d0.x); acc[1] += gw * fg_round<T>(gs * d0.y); acc[2] += gw * fg_round<T>(gs * d0.z); acc[3] += gw * fg_round<T>(gs * d0.w);
+                    acc[4] += gw * fg_round<T>(gs * d1.x); acc[5] += gw * fg_round<T>(gs * d1.y); acc[6] += gw * fg_round<T>(gs * d1.z); acc[7] += gw * fg_round<T>(gs * d1.w);
+                }
+            }
+        }
+        T* o = out + ((int64_t)hi * W + wi) * 32 + cv * 8;
+        stv<4>(o, acc);
+        stv<4>(o + 4, acc + 4);
+    }
+}
+/* dx [N,H,W,32] = bilinear_bwd(dfeat), dfeat [N,Ho,Wo,32] looked up as above (align_corners as the forward resize of norm_add: 0) */
+extern "C" int tcct_bilinear_bwd_fplgrad(const uint8_t* labels, const uint8_t* binmap, const float* dpro_over_n, const float* grad_out, float grad_scale,
+                                         int ncls, void* dx, int N, int H, int W, int Ho, int Wo, int align_corners, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(H > 0 && W > 0 && Ho > 0 && Wo > 0 && ncls >= 1 && ncls <= 16, "bilinear_bwd_fplgrad: bad sizes");
+    const float sh = align_corners ? (Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f) : (float)H / (float)Ho;
+    const float sw = align_corners ? (Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f) : (float)W / (float)Wo;
+    const float smin = fminf(sh, sw);
+    const int KT = smin > 0.f ? (int)(2.f / smin) + 3 : BL_MAXC + 1;
+    TCCT_CHECK(KT <= BL_MAXC, "bilinear_bwd_fplgrad: scale factor out of range");
+    const int DW = 32;
+    const int tilesW = (W + DW - 1) / DW, tilesH = (H + BT_DH - 1) / BT_DH;
+    const int64_t blocks = (int64_t)N * tilesW * tilesH;
+    TCCT_CHECK(blocks < 0x7fffffffLL, "bilinear_bwd_fplgrad: grid too large");
+    const size_t lds = sizeof(int) * (((size_t)2 * (BT_DH + DW) * KT + BT_DH + DW + 3) & ~(size_t)3) + sizeof(float) * (size_t)ncls * FG_BINS * 32;
+    TCCT_DISPATCH(dtype, {
+        static bool at_ = false;
+        if (!at_) { (void)hipFuncSetAttribute((const void*)k_bilinear_bwd_fplgrad<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); at_ = true; }
+        hipLaunchKernelGGL((k_bilinear_bwd_fplgrad<T>), dim3((unsigned)blocks), dim3(PB), lds, (hipStream_t)stream, labels, binmap, dpro_over_n, grad_out,
+                           grad_scale, ncls, (T*)dx, N, H, W, Ho, Wo, sh, sw, align_corners, DW, KT, tilesW, tilesH); });
+    TCCT_LAUNCH_OK();
+}
+
 // ------------------------------------------------- norm_add (nets/tcct.py:937-942): mean of three L2-normalised maps at the first one's size
 // out = (l2n(g0) + resize(l2n(g1)) + resize(l2n(g2))) / 3 in ONE pass over g0 / out: the inverse norms of the two coarser maps come from a
 // small pre-pass (fp32 [N,h,w] each), the normalised coarse maps and both resized copies are never written.

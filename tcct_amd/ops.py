@@ -131,6 +131,7 @@ def begin_step(device):
     if device.type == 'cuda' and device.index is None:          # torch.device('cuda') != torch.device('cuda', 0): never re-allocate the pool for that
         device = torch.device('cuda', torch.cuda.current_device())
     ZERO.begin(device)
+    fpl_lazy_grad_reset()
     _pack_evict()
     _pack_all(device)
     _STEP['main'] = torch.cuda.current_stream(device)
@@ -2122,6 +2123,23 @@ def l2norm(x, eps=1e-12):
     return _L2Norm.apply(x, float(eps))
 
 
+# ---- the feature-polarization gradient without its tensor (round 4) ---------------------------------------------------------------------------
+# regular_udh's d loss / d feats is g * dpro[label[p]][bin[p]] -- a table lookup by two bytes per pixel.  When feats comes out of the fused norm_add
+# node and the FPL is its only differentiable consumer (how FTC / RegNet use it), _Fpl.backward returns a zero-stride placeholder of the right shape
+# and registers (labels, binmap, table, upstream gradient) under the placeholder's storage; _NormAdd.backward picks the recipe up and runs the
+# lookup forms of its three kernels (tcct_l2norm_bwd_fplgrad, tcct_bilinear_bwd_fplgrad): the 452 MB gradient (bench shape) is neither written nor
+# read three times.  A placeholder that autograd had to ADD to another gradient (a second differentiable consumer of feats) would lose the FPL part
+# silently -- so producers register only tensors handed out as `FTC.feats`, and TCCT_FPL_LAZY_GRAD=0 restores the dense tensor.
+FPL_LAZY_GRAD = os.environ.get('TCCT_FPL_LAZY_GRAD', '1') != '0'
+_FPL_LAZY = {'producers': set(), 'grads': {}}
+
+
+def fpl_lazy_grad_reset():
+    """per step (begin_step): forget last step's registrations (storage addresses are recycled by the allocator)"""
+    _FPL_LAZY['producers'].clear()
+    _FPL_LAZY['grads'].clear()
+
+
 class _NormAdd(torch.autograd.Function):
     """norm_add([g0, g1, g2]) (reference nets/tcct.py:937-942): mean of the three L2-normalised maps at g0's size.  Forward: one pass
     (tcct_normadd_fwd); backward: the existing resize / normalise gradients with the 1/3 folded into the last kernel of each chain."""
@@ -2140,6 +2158,8 @@ class _NormAdd(torch.autograd.Function):
         lib.normadd_fwd(g0, g1, g2, inv1, inv2, out, N, H, W, C, h1, w1, h2, w2, eps, dtype_code(g0.dtype))
         ctx.save_for_backward(g0, g1, g2)
         ctx.eps = eps
+        if fork and C == 32:
+            _FPL_LAZY['producers'].add(out.data_ptr())
         return (out, g0.view_as(g0), g1.view_as(g1), g2.view_as(g2)) if fork else out
 
     @staticmethod
@@ -2148,9 +2168,28 @@ class _NormAdd(torch.autograd.Function):
         dalias = tuple(dalias) + (None,) * (3 - len(dalias))
         if dy is None:          # only the aliases were used downstream
             return dalias[0], dalias[1], dalias[2], None, None
-        dy = _as(dy, g0.dtype)
         N, H, W, C = g0.shape
         dc = dtype_code(g0.dtype)
+        lazy = _FPL_LAZY['grads'].pop(dy.data_ptr(), None) if (dy.dim() == 4 and dy.stride(0) == 0) else None
+        if lazy is not None:    # the gradient is the feature-polarization loss's: looked up, never materialised
+            _, labels, binmap, dpro, gup, ncls = lazy
+            outs = []
+            for g, da in zip((g0, g1, g2), dalias):
+                h, w = g.shape[1], g.shape[2]
+                d = torch.empty_like(g)
+                da = _c(_as(da, g.dtype)) if da is not None else None
+                if (h, w) == (H, W):
+                    lib.l2norm_bwd_fplgrad(g, labels, binmap, dpro, gup, 1.0, ncls, da, d, g.numel() // C, ctx.eps, 1.0 / 3.0, dc)
+                else:
+                    dn = torch.empty_like(g)
+                    lib.bilinear_bwd_fplgrad(labels, binmap, dpro, gup, 1.0, ncls, dn, N, h, w, H, W, 0, dc)
+                    if da is not None:
+                        lib.l2norm_bwd_scaled_add(g, dn, da, d, g.numel() // C, C, ctx.eps, 1.0 / 3.0, dc)
+                    else:
+                        lib.l2norm_bwd_scaled(g, dn, d, g.numel() // C, C, ctx.eps, 1.0 / 3.0, dc)
+                outs.append(d)
+            return outs[0], outs[1], outs[2], None, None
+        dy = _c(_as(dy, g0.dtype))
         outs = []
         for g, da in zip((g0, g1, g2), dalias):
             h, w = g.shape[1], g.shape[2]
@@ -2432,6 +2471,8 @@ class _Fpl(torch.autograd.Function):
         lib.fpl_loss(pro_sum, counts, buf_grad, C, pro, loss, dpro)
         ctx.save_for_backward(labels, binmap, dpro)
         ctx.cfg = (feat.shape, feat.dtype, M)
+        # feat is the output of a norm_add node that can look its gradient up from (labels, bins, table) itself (FPL_LAZY_GRAD below)
+        ctx.lazy = FPL_LAZY_GRAD and feat.data_ptr() in _FPL_LAZY['producers'] and feat.shape[-1] == 32 and feat.is_contiguous()
         ctx.mark_non_differentiable(pro)
         return loss, pro
 
@@ -2442,6 +2483,12 @@ class _Fpl(torch.autograd.Function):
         if g is None:
             return None, None, None, None
         g = _as(g, torch.float32)
+        if ctx.lazy:
+            # d loss / d feat is a function of two bytes per pixel: hand norm_add's backward the recipe instead of the 452 MB tensor.  The returned
+            # gradient is a zero-stride expansion of one zero element (right shape and dtype, no memory); the consumer recognises its storage.
+            marker = torch.zeros(1, device=g.device, dtype=dt)
+            _FPL_LAZY['grads'][marker.data_ptr()] = (marker, labels, binmap, dpro, g, int(dpro.shape[0]))
+            return marker.expand(shape), None, None, None
         dfeat = torch.empty(shape, device=g.device, dtype=dt)
         lib.fpl_backward(labels, binmap, dpro, g, 1.0, M, dfeat, dtype_code(dt))
         return dfeat, None, None, None

@@ -718,6 +718,45 @@ def test_decoder_tail_composed_through_the_aux_head(nhw, nc):
     torch.testing.assert_close(nchw(g0), g.detach(), rtol=3e-2, atol=3e-2)
 
 
+@pytest.mark.parametrize('cfg', [(2, 32, 48, 5), (1, 64, 96, 9), (2, 16, 80, 5)])
+def test_fpl_gradient_looked_up_inside_norm_add_backward(cfg):
+    """round 4: with the feature-polarization loss as the only differentiable consumer of `feats`, its gradient is handed to norm_add's backward as a
+    recipe (labels, bins, table) instead of a tensor (ops.FPL_LAZY_GRAD): d g0 / d g1 / d g2 must equal the dense path's -- the same values rounded
+    at the same places -- including the aux-head gradients folded in through the aliases, pixels outside every bin, and 9 classes"""
+    from tcct_amd import ops
+    N, H, W, C = cfg
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(H + C)
+    g0 = torch.randn(N, H, W, 32, generator=g).to(dt)
+    g1 = torch.randn(N, H // 2, W // 2, 32, generator=g).to(dt)
+    g2 = torch.randn(N, H // 4, W // 4, 32, generator=g).to(dt)
+    lab = torch.randint(0, C, (N, H, W), generator=g)
+    lab[:, : H // 2] = torch.sort(lab[:, : H // 2], dim=1).values
+    logits = (torch.randn(N, H, W, C, generator=g) * 2)
+    buf = F.normalize(torch.rand(C, 32, generator=g), dim=-1).cuda()
+    wa = [torch.randn_like(t.float()).to(dt).cuda() for t in (g0, g1, g2)]            # stand-ins for the aux heads' gradients of the aliases
+    res = {}
+    for lazy in (True, False):
+        ops.FPL_LAZY_GRAD = lazy
+        try:
+            ops.fpl_lazy_grad_reset()
+            xs = [t.cuda().requires_grad_(True) for t in (g0, g1, g2)]
+            feats, a0, a1, a2 = ops.norm_add3_fork(*xs)
+            nchw_view = feats.permute(0, 3, 1, 2)                                       # what FTC.feats hands out
+            loss, _ = ops.fpl(nchw_view.permute(0, 2, 3, 1), logits.cuda(), lab.to(torch.uint8).cuda(), buf)
+            aux = sum((a.float() * w_.float()).sum() for a, w_ in zip((a0, a1, a2), wa)) * 1e-3
+            (loss * 1.7 + aux).backward()
+            res[lazy] = [x.grad.float().cpu() for x in xs]
+            assert not ops._FPL_LAZY['grads']                                           # the recipe was consumed (or never issued)
+        finally:
+            ops.FPL_LAZY_GRAD = True
+    for a, b, nm in zip(res[True], res[False], ('g0', 'g1', 'g2')):
+        assert torch.isfinite(a).all() and (a != 0).any()
+        torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-5 * max(1.0, b.abs().max().item()), msg=lambda m, nm=nm: nm + ': ' + m)
+        same = (a == b).float().mean().item()
+        assert same > 0.99, (nm, same)
+
+
 def test_flat_adamw_state_refuses_a_permuted_layout():
     """FlatAdamW.state_dict() records the flat buffer's order by parameter NAME (not shape: dozens of tensors share 32x32x3x3 / [32]): moments saved
     from one order must not be applied to another order of equally shaped tensors; the same order round-trips"""
