@@ -720,20 +720,26 @@ extern "C" int tcct_l2norm_bwd_fplgrad(const void* x, const uint8_t* labels, con
     TCCT_LAUNCH_OK();
 }
 
-// dx [N,H,W,32] = bilinear_bwd(dfeat [N,Ho,Wo,32]) with dfeat looked up: k_bilinear_bwd_tab with the 16 contributor loads replaced by (label, bin)
-// byte loads + LDS table rows
+// dx [N,H,W,32] = bilinear_bwd(dfeat [N,Ho,Wo,32]) with dfeat looked up: k_bilinear_bwd_tab with the contributor loads replaced by LDS reads.  Per tile
+// the (label, bin) bytes of the contributing output region (a contiguous rectangle: the contributors of neighbouring inputs overlap) are read ONCE,
+// coalesced, and kept as 16-bit row ids; the table is stored pre-scaled and pre-rounded (fg_round(g * dpro)), so the inner loop is two LDS reads and
+// eight FMAs per contributor.  (First version: two global byte loads per contributor and item, four items per pixel: 0.38 ms for the two calls of
+// the bench step, as slow as the dense gather it replaced.)
 template <typename T>
 __global__ void __launch_bounds__(PB) k_bilinear_bwd_fplgrad(const uint8_t* __restrict__ lab, const uint8_t* __restrict__ binmap, const float* __restrict__ dpro,
                                                              const float* __restrict__ gout, float gscale, int ncls, T* __restrict__ dx, int N, int H,
                                                              int W, int Ho, int Wo, float sh, float sw, int align, int DW, int KT, int tilesW,
-                                                             int tilesH) {
-    extern __shared__ int smem_i[];             // idx[(DH+DW)][KT], weights[(DH+DW)][KT], counts[DH+DW], then the table [ncls][32][32]
+                                                             int tilesH, int RMAX, int CMAX) {
+    extern __shared__ int smem_i[];             // idx[(DH+DW)][KT], weights[(DH+DW)][KT], counts[DH+DW], the table [ncls][32][32], ids [RMAX][CMAX] u16
     int* tidx = smem_i;
     float* twt = reinterpret_cast<float*>(smem_i + (BT_DH + DW) * KT);
     int* tcnt = smem_i + 2 * (BT_DH + DW) * KT;
     float* stab = reinterpret_cast<float*>(smem_i + ((2 * (BT_DH + DW) * KT + BT_DH + DW + 3) & ~3));
+    uint16_t* sid = reinterpret_cast<uint16_t*>(stab + ncls * FG_BINS * 32);
+    __shared__ int s_org[4];                    // first row / column of the contributing region and its extent
     const int t = threadIdx.x;
-    for (int i = t; i < ncls * FG_BINS * 32; i += PB) stab[i] = dpro[i];
+    const float gs = gscale * (gout ? *gout : 1.f);
+    for (int i = t; i < ncls * FG_BINS * 32; i += PB) stab[i] = fg_round<T>(gs * dpro[i]);
     int bid = blockIdx.x;
     const int tw = bid % tilesW; bid /= tilesW;
     const int th = bid % tilesH;
@@ -757,9 +763,23 @@ __global__ void __launch_bounds__(PB) k_bilinear_bwd_fplgrad(const uint8_t* __re
         tcnt[t] = cnt;
     }
     __syncthreads();
-    const float gs = gscale * (gout ? *gout : 1.f);
+    if (t == 0) {       // contributors are ascending per input and the inputs are ascending: first of the first / last of the last non-empty entry
+        int r0 = 0x7fffffff, r1 = -1, c0 = 0x7fffffff, c1 = -1;
+        for (int q = 0; q < BT_DH; ++q) if (tcnt[q]) { r0 = min(r0, tidx[q * KT]); r1 = max(r1, tidx[q * KT + tcnt[q] - 1]); }
+        for (int q = 0; q < DW; ++q) if (tcnt[BT_DH + q]) { c0 = min(c0, tidx[(BT_DH + q) * KT]); c1 = max(c1, tidx[(BT_DH + q) * KT + tcnt[BT_DH + q] - 1]); }
+        s_org[0] = r0; s_org[1] = c0; s_org[2] = r1 >= r0 ? min(r1 - r0 + 1, RMAX) : 0; s_org[3] = c1 >= c0 ? min(c1 - c0 + 1, CMAX) : 0;
+    }
+    __syncthreads();
+    const int r0 = s_org[0], c0 = s_org[1], RR = s_org[2], CC = s_org[3];
     const uint8_t* L = lab + (int64_t)n * Ho * Wo;
     const uint8_t* B = binmap + (int64_t)n * Ho * Wo;
+    for (int i = t; i < RR * CC; i += PB) {
+        const int rr = i / CC, cc = i - rr * CC;
+        const int64_t q = (int64_t)(r0 + rr) * Wo + (c0 + cc);
+        const int bb = B[q], ll = L[q];
+        sid[rr * CMAX + cc] = (bb < FG_BINS && ll < ncls) ? (uint16_t)(ll * FG_BINS + bb) : (uint16_t)0xffff;
+    }
+    __syncthreads();
     T* out = dx + (int64_t)n * H * W * 32;
     for (int i = t; i < BT_DH * DW * 4; i += PB) {
         const int cv = i & 3, pix = i >> 2;
@@ -775,17 +795,16 @@ __global__ void __launch_bounds__(PB) k_bilinear_bwd_fplgrad(const uint8_t* __re
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = 0.f;
         for (int a = 0; a < nr; ++a) {
-            const int64_t rowoff = (int64_t)ri[a] * Wo;
+            const uint16_t* srow = sid + (ri[a] - r0) * CMAX - c0;
             const float wh = rw[a];
             for (int b = 0; b < nc; ++b) {
-                const int64_t q = rowoff + ci[b];
-                const int bb = B[q], ll = L[q];
-                if (bb < FG_BINS && ll < ncls) {
+                const int id = srow[ci[b]];
+                if (id != 0xffff) {
                     const float gw = wh * cw[b];
-                    const float4 d0 = *reinterpret_cast<const float4*>(stab + (ll * FG_BINS + bb) * 32 + cv * 8);
-                    const float4 d1 = *reinterpret_cast<const float4*>(stab + (ll * FG_BINS + bb) * 32 + cv * 8 + 4);
-                    acc[0] += gw * fg_round<T>(gs * d0.x); acc[1] += gw * fg_round<T>(gs * d0.y); acc[2] += gw * fg_round<T>(gs * d0.z); acc[3] += gw * fg_round<T>(gs * d0.w);
-                    acc[4] += gw * fg_round<T>(gs * d1.x); acc[5] += gw * fg_round<T>(gs * d1.y); acc[6] += gw * fg_round<T>(gs * d1.z); acc[7] += gw * fg_round<T>(gs * d1.w);
+                    const float4 d0 = *reinterpret_cast<const float4*>(stab + id * 32 + cv * 8);
+                    const float4 d1 = *reinterpret_cast<const float4*>(stab + id * 32 + cv * 8 + 4);
+                    acc[0] += gw * d0.x; acc[1] += gw * d0.y; acc[2] += gw * d0.z; acc[3] += gw * d0.w;
+                    acc[4] += gw * d1.x; acc[5] += gw * d1.y; acc[6] += gw * d1.z; acc[7] += gw * d1.w;
                 }
             }
         }
@@ -807,12 +826,16 @@ extern "C" int tcct_bilinear_bwd_fplgrad(const uint8_t* labels, const uint8_t* b
     const int tilesW = (W + DW - 1) / DW, tilesH = (H + BT_DH - 1) / BT_DH;
     const int64_t blocks = (int64_t)N * tilesW * tilesH;
     TCCT_CHECK(blocks < 0x7fffffffLL, "bilinear_bwd_fplgrad: grid too large");
-    const size_t lds = sizeof(int) * (((size_t)2 * (BT_DH + DW) * KT + BT_DH + DW + 3) & ~(size_t)3) + sizeof(float) * (size_t)ncls * FG_BINS * 32;
+    // contributing region of a tile: its inputs span (BT_DH - 1) / sh resp. (DW - 1) / sw outputs plus one source pixel of reach on either side
+    const int RMAX = (int)((BT_DH - 1) / sh + 2.f / sh) + 4, CMAX = ((int)((DW - 1) / sw + 2.f / sw) + 4 + 1) & ~1;
+    const size_t lds = sizeof(int) * (((size_t)2 * (BT_DH + DW) * KT + BT_DH + DW + 3) & ~(size_t)3) + sizeof(float) * (size_t)ncls * FG_BINS * 32 +
+                       sizeof(uint16_t) * (size_t)RMAX * CMAX;
+    TCCT_CHECK(lds <= 150 * 1024, "bilinear_bwd_fplgrad: %zu B of LDS", lds);
     TCCT_DISPATCH(dtype, {
         static bool at_ = false;
-        if (!at_) { (void)hipFuncSetAttribute((const void*)k_bilinear_bwd_fplgrad<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); at_ = true; }
+        if (!at_) { (void)hipFuncSetAttribute((const void*)k_bilinear_bwd_fplgrad<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); at_ = true; }
         hipLaunchKernelGGL((k_bilinear_bwd_fplgrad<T>), dim3((unsigned)blocks), dim3(PB), lds, (hipStream_t)stream, labels, binmap, dpro_over_n, grad_out,
-                           grad_scale, ncls, (T*)dx, N, H, W, Ho, Wo, sh, sw, align_corners, DW, KT, tilesW, tilesH); });
+                           grad_scale, ncls, (T*)dx, N, H, W, Ho, Wo, sh, sw, align_corners, DW, KT, tilesW, tilesH, RMAX, CMAX); });
     TCCT_LAUNCH_OK();
 }
 
