@@ -282,6 +282,15 @@ int tcct_pw_wgrad_strided(const void* x, const void* dy, int64_t ldy, float* dw,
  * `post` convolution whose output feeds both the next stage and `x_i + y_i` (nets/tcct.py:1028-1031) */
 int tcct_pw_fwd_residual(const void* x, const float* w, const float* bias, const void* res, const float* scale, int64_t per_sample,
                          void* y, void* y_plain, int64_t M, int K, int N, tcct_stream_t stream);
+/* InvRes.norm -> conv2 (nets/tcct.py:563-572) without the normalisation pass (round 4): the convolution reads the BatchNorm's INPUT y_prev and applies
+ * z = hswish(a_prev y_prev + b_prev) while it stages its tiles, forward and backward; ab_prev = {a[K], b[K]} from tcct_bn_finalize.  K = N in {64, 96}.
+ *   fwd : y = z W^T + bias + batch statistics of y (stats fp64 [2N], zero on entry) for the BatchNorm behind
+ *   bwd : tcct_pw_bwd_bn_sums with x rebuilt from y_prev; red_post = TCCT_ACT_HSWISH (K = 64: + the reduction sums of the BatchNorm in front) or -1 (96) */
+int tcct_pw_fwd_bnstats_xaff(const void* y_prev, const float* ab_prev, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
+                             tcct_stream_t stream);
+int tcct_pw_bwd_bn_sums_xaff(const void* y_prev, const float* ab_prev, const void* dz, const void* y, const double* sums, int raw, const float* mean_rstd,
+                             const float* ab, float* dgamma, float* dbeta, const float* w, const void* res, void* dx, float* dw, float* dbias, int64_t M,
+                             int K, int N, int red_post, double* sums_prev, tcct_stream_t stream);
 /* Mlp (nets/tcct.py:29-53: fc1 -> GELU -> fc2) without the activation passes (round 4): x1 is the PRE-activation fc1 wrote; GELU is applied while the
  * tile is staged, so h = gelu(x1) and, backwards, dh never exist in HBM.  K = N in {64, 96} (mpvit_tiny: hidden = dim; stages 0 and 1 = 97 % of the bytes).
  *   fwd: y = res + scale[m / per_sample] * (gelu(x1) W^T + bias)   (fc2 + DropPath scale + residual, nets/tcct.py:468; scale nullable)

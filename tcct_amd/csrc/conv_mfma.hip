@@ -1271,11 +1271,165 @@ k_conv32_wgrad33_dma4(const bf16* __restrict__ x, const bf16* __restrict__ dy, f
 // which weight-gradient kernel tcct_conv32_wgrad* launches: 0 = register-staged k_conv32_wgrad (default), 1 = k_conv32_wgrad_dma (LDS-DMA, two LDS
 // buffers; opt-in: same speed at the bench shape, kept as the base for B-fragment reuse across the dx taps -- DESIGN 3e).  -1 on entry = unset: the
 // environment variable TCCT_WGRAD_DMA=1 selects the DMA form.
+// ------------------------------------------------------------------------------------------------ 3x3 weight gradient, rolling rows (round 4)
+// The register-staged kernel above reads every x pixel from LDS once per TAP and every dy pixel once per tap group: 192 transposing reads per
+// tile and wave, 393 KB per 72 KB tile and block -- at two blocks per CU the LDS array is ~80 % busy at the rate HBM could feed the kernel
+// (its loads alone take 0.171 ms, the whole kernel 0.234).  The LDS-DMA forms cut the reads with funnel shifts across the dx taps but paid for it
+// in per-tile bookkeeping.  This form cuts them with NO extra arithmetic, along the other axis: a wave owns ONE tap column dx and one 16-pixel
+// column chunk of the 16 x 32 tile and walks down the 18 halo rows; the x fragment of halo row a is the operand of tap dy = 0 for output row a,
+// of dy = 1 for row a - 1 and of dy = 2 for row a - 2, so it is read ONCE and multiplied with the three dy fragments of a rolling window that
+// lives in registers.  Per tile and wave: 18 x + 16 dy fragments (68 transposing reads instead of 192), 48 MFMAs, three accumulators.  Six waves
+// (3 tap columns x 2 column chunks) per block, two blocks per CU: 204 fragment reads per tile and block instead of 384, the matrix pipes see
+// the same 288 MFMAs.  Staging: the register-prefetch path of k_conv32_wgrad with 96 pixels per slot round.  Results are bit-compatible
+// with the other forms up to the order of the fp32 atomics.
+#define WR_T 384
+#define WR_XL 7                 // x staging slots per thread: 18 x 34 = 612 halo pixels / 96
+#define WR_DL 6                 // dy staging slots: 512 / 96 (the last one partial)
+__global__ void __launch_bounds__(WR_T, 3)      // HIP: second argument = waves per SIMD (2 blocks x 6 waves = 3 per SIMD: <= 168 VGPRs)
+k_conv32_wgrad33_roll(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
+                      int N, int H, int W, int tilesH, int tilesW, int ntiles) {
+    constexpr int TH = 16, TW = 32, LH = 18, LW = 34, NPX = LH * LW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;
+    unsigned char* sD = smem + NPX * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int g = wave >> 1, wi = wave & 1;             // tap column dx = g, column chunk wi
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    float bsum = 0.f;
+    const unsigned char* xcol = tr_lane_base(sX, lane) + (wi * 16 + g) * 64;
+    const unsigned char* dcol = tr_lane_base(sD, lane) + wi * 16 * 64;
+    const int c = tid & 3;
+    // halo pixel of staging slot j: pl = tid / 4 + 96 j -> (row, column) by a multiply-shift division (pl < 1024: pl * 241 >> 13 == pl / 34), recomputed
+    // per use: a table of 7 packed coordinates per thread pushed the kernel over the 168-VGPR budget of three waves per SIMD, and the 8-byte
+    // scratch reload that followed sat in the MIDDLE of the prefetch burst with an s_waitcnt vmcnt(0) in front of the remaining loads
+    auto slot_rc = [&](int j, uint32_t& lr, uint32_t& lc) {
+        uint32_t pl = (uint32_t)(tid >> 2) + (uint32_t)(j * (WR_T / 4));
+        asm volatile("" : "+v"(pl));
+        lr = (pl * 241u) >> 13;
+        lc = pl - lr * (uint32_t)LW;
+        return pl < (uint32_t)NPX;
+    };
+    const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
+    u32x4 prex[WR_XL], pred[WR_DL];
+    auto prefetch = [&](int tile) {
+        const int tw = tile & 1023, th = (tile >> 10) & 1023, n = tile >> 20;
+        const int h0 = th * TH, w0 = tw * TW;
+        const int hb = h0 - 1, wb = w0 - 1;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * H * W * 32), 0, img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)n * H * W * 32), 0, img_bytes, 0x00020000);
+        if (hb >= 0 && wb >= 0 && hb + LH <= H && wb + LW <= W) {       // interior tile
+            const uint32_t xbase = (uint32_t)((hb * W + wb) * 64 + c * 16);
+#pragma unroll
+            for (int j = 0; j < WR_XL; ++j) {
+                uint32_t lr, lc;
+                const bool in = slot_rc(j, lr, lc);
+                prex[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, in ? xbase + (lr * (uint32_t)W + lc) * 64u : OOB_OFF, 0, 0);
+            }
+            const uint32_t dbase = (uint32_t)((h0 * W + w0) * 64 + c * 16);
+#pragma unroll
+            for (int j = 0; j < WR_DL; ++j) {
+                const uint32_t pl = (uint32_t)((tid >> 2) + j * (WR_T / 4));
+                pred[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, pl < (uint32_t)(TH * TW) ? dbase + ((pl >> 5) * (uint32_t)W + (pl & 31u)) * 64u : OOB_OFF, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WR_XL; ++j) {
+                uint32_t lr, lc;
+                const bool in = slot_rc(j, lr, lc);
+                const int hi = hb + (int)lr, wi_ = wb + (int)lc;
+                const bool ok = in && (unsigned)hi < (unsigned)H && (unsigned)wi_ < (unsigned)W;
+                prex[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (uint32_t)((hi * W + wi_) * 64 + c * 16) : OOB_OFF, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < WR_DL; ++j) {
+                const int pl = (tid >> 2) + j * (WR_T / 4);
+                const int ho = h0 + (pl >> 5), wo = w0 + (pl & 31);
+                pred[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, (pl < TH * TW && ho < H && wo < W) ? (uint32_t)((ho * W + wo) * 64 + c * 16) : OOB_OFF, 0, 0);
+            }
+        }
+    };
+    const TileSeq<false> seq(ntiles, tilesH, tilesW);
+    int tile = seq.at(0), tile1 = -1;
+    if (tile >= 0) prefetch(tile);
+    for (int kt = 0; tile >= 0; tile = tile1, ++kt) {
+        tile1 = seq.at(kt + 1);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < WR_XL; ++j) {       // halo pixels are stored in (row, column) order: LDS pixel index == pl
+            const int pl = (tid >> 2) + j * (WR_T / 4);
+            if (pl < NPX) *reinterpret_cast<u32x4*>(sX + pl * 64 + c * 16) = prex[j];
+        }
+#pragma unroll
+        for (int j = 0; j < WR_DL; ++j) {
+            const int pl = (tid >> 2) + j * (WR_T / 4);
+            if (pl < TH * TW) *reinterpret_cast<u32x4*>(sD + pl * 64 + c * 16) = pred[j];
+        }
+        __syncthreads();
+        if (tile1 >= 0) prefetch(tile1);
+        // walk down the 18 halo rows: X[a] meets D[a] (tap dy 0), D[a-1] (dy 1), D[a-2] (dy 2); fragments of row a + 1 are requested before the MFMAs of row a
+        bf16x8 D[3], Xc, Xn, Dn;
+        Xc = tr_load8p(xcol);
+        D[0] = tr_load8p(dcol);
+#pragma unroll
+        for (int a = 0; a < LH; ++a) {
+            if (a + 1 < LH) Xn = tr_load8p(xcol + (a + 1) * LW * 64);
+            if (a + 1 < TH) Dn = tr_load8p(dcol + (a + 1) * TW * 64);
+            __builtin_amdgcn_sched_barrier(0);
+            if (a < TH) {
+                if (g == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bsum = dot2_ones(D[a % 3], j, bsum);
+                }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(D[a % 3], Xc, acc[0], 0, 0, 0);
+            }
+            if (a >= 1 && a - 1 < TH) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(D[(a + 2) % 3], Xc, acc[1], 0, 0, 0);
+            if (a >= 2) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(D[(a + 1) % 3], Xc, acc[2], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            Xc = Xn;
+            if (a + 1 < TH) D[(a + 1) % 3] = Dn;
+        }
+    }
+    // the two column-chunk waves of a tap column hold partial sums of the same three taps: they take turns in LDS (no LDS float atomics)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    for (int turn = 0; turn < 2; ++turn) {
+        if (wi == turn) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int tap = t * 3 + g;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
+                    float* dst = &red[tap * 1024 + co * 32 + r];
+                    *dst = turn == 0 ? acc[t][k] : *dst + acc[t][k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < 9 * 1024; i += WR_T) {
+        const int tap = i % 9, cc = i / 9;          // cc = co*32 + ci: OIHW-linear order, 256 contiguous bytes per wave instruction
+        atomicAdd(&dw[(int64_t)cc * 9 + tap], red[tap * 1024 + cc]);
+    }
+    if (dbias && g == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        __syncthreads();
+        if (lane < 32) red[wi * 32 + r] = bsum;
+    } else __syncthreads();
+    __syncthreads();
+    if (dbias && tid < 32) atomicAdd(&dbias[tid], red[tid] + red[32 + tid]);
+}
+
 static int g_wgrad_mode = -1;
 extern "C" int64_t tcct_conv32_wgrad_mode(int mode) {
-    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] >= '0' && e_[0] <= '3') ? e_[0] - '0' : 0; }
+    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] >= '0' && e_[0] <= '4') ? e_[0] - '0' : 0; }
     const int prev = g_wgrad_mode;
-    if (mode >= 0 && mode <= 3) g_wgrad_mode = mode;
+    if (mode >= 0 && mode <= 4) g_wgrad_mode = mode;
     return prev;
 }
 /* dw OIHW fp32 [32,32,KH,KW] and dbias fp32 [32] (nullable) are overwritten. */
@@ -1318,7 +1472,15 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
         if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * TAPS * 1024, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
         if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
     }
-    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] >= '0' && e_[0] <= '3') ? e_[0] - '0' : 0; }
+    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] >= '0' && e_[0] <= '4') ? e_[0] - '0' : 0; }
+    if (g_wgrad_mode == 4 && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {      // plain 3x3: rolling rows, 6 waves x 2 blocks per CU
+        constexpr size_t lds4 = (size_t)18 * 34 * 64 + 16 * 32 * 64;
+        static bool attr4 = false;
+        if (!attr4) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad33_roll, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr4 = true; }
+        hipLaunchKernelGGL(k_conv32_wgrad33_roll, dim3((unsigned)(nt < 512 ? nt : 512)), dim3(WR_T), lds4, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W,
+                           tilesH, tilesW, (int)nt);
+        TCCT_LAUNCH_OK();
+    }
     if (g_wgrad_mode == 3 && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {      // plain 3x3: LDS-DMA + fragment reuse, 4 waves x 2 blocks per CU
         constexpr size_t lds3 = (size_t)((18 * 34 + 15) / 16) * 1024 + 16 * 32 * 64;
         static bool attr3 = false;

@@ -771,6 +771,20 @@ __device__ __forceinline__ u32x4 gelu8(u32x4 v) {
     return o;
 }
 __device__ __forceinline__ float gelu_grad1(float x) { float c, p; gauss_cdf_pdf(x, c, p); return c + x * p; }
+// XAP >= 0 (round 4): the operand tensor holds the INPUT y_prev of a train-mode BatchNorm (+ activation XAP) whose output this convolution consumes as
+// its only reader (InvRes.norm -> conv2, reference nets/tcct.py:563-572): z = act(a[c] y_prev + b[c]) is applied while the tile is staged -- rounded to
+// bf16 exactly like the tensor the separate normalisation pass used to write -- so that pass (read y_prev, write z) and the tensor z do not exist.
+template <int KIND> __device__ __forceinline__ u32x4 affine8(u32x4 v, const float* __restrict__ a, const float* __restrict__ b) {
+    const float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(b), b1 = *reinterpret_cast<const float4*>(b + 4);
+    const float aa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        o[k] = pack_bf16x2(act_c<KIND>(aa[2 * k] * __uint_as_float(v[k] << 16) + bb[2 * k]),
+                           act_c<KIND>(aa[2 * k + 1] * __uint_as_float(v[k] & 0xffff0000u) + bb[2 * k + 1]));
+    return o;
+}
 // SPLIT: x = [x | x2] and dx = [dx | dx2] are two tensors of K/2 channels each (the aggregate convolution over a concatenation,
 // MHCA_stage, reference nets/tcct.py:600-616): no concat / split passes; x2 / dx2 then travel in the res / dx_plain arguments.
 // BNP >= 0: a train-mode BatchNorm sits behind this convolution (Conv2d_BN, DWConv2d_BN.pwconv, tran_*; reference nets/tcct.py:55-97,124-126,
@@ -789,7 +803,7 @@ template <int KIND> __device__ __forceinline__ float pw_act_grad(float u) {
     if (KIND == TCCT_ACT_HSWISH) return u < -3.f ? 0.f : (u <= 3.f ? (2.f * u + 3.f) * (1.f / 6.f) : 1.f);
     return 1.f;
 }
-template <int NT, int KT, bool SPLIT = false, int BNP = -1, int REDP = -1, bool GX = false>
+template <int NT, int KT, bool SPLIT = false, int BNP = -1, int REDP = -1, bool GX = false, int XAP = -1>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ w, const bf16* __restrict__ res,
          bf16* __restrict__ dx, bf16* __restrict__ dx_plain, float* __restrict__ dw, float* __restrict__ dbias, int64_t M, PwBnBwd bn) {
@@ -825,7 +839,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
             sC[3 * N + c] = bn.ab[c]; sC[4 * N + c] = bn.ab[N + c];
         }
     }
-    if (RED) for (int i = tid; i < 2 * (SPLIT ? K / 2 : K); i += PWB) sP[i] = bn.abprev[i];
+    if (RED || XAP >= 0) for (int i = tid; i < 2 * (SPLIT ? K / 2 : K); i += PWB) sP[i] = bn.abprev[i];
     constexpr int RKT = RED ? (SPLIT ? KT / 2 : KT) : 1;   // 32-channel tiles of x that carry the BatchNorm in front (split: the first half)
     float rs[RKT][8], rq[RKT][8];                            // RED: per-lane partial sums of dz' and dz' y_prev (channels 8 (lane & 3) + k of tile kt)
 #pragma unroll
@@ -872,7 +886,9 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
         for (int j = 0; j < XS; ++j) {
             const int jj = (SPLIT && j >= XS / 2) ? j - XS / 2 : j;
             const int q = tid + jj * PWB, p = q / (KS / 8), c = q - p * (KS / 8);
-            *reinterpret_cast<u32x4*>(sX + p * SX + ((SPLIT && j >= XS / 2) ? KS * 2 : 0) + c * 16) = GX ? gelu8(px[j]) : px[j];
+            u32x4 xv_ = GX ? gelu8(px[j]) : px[j];
+            if (XAP >= 0) xv_ = affine8<XAP < 0 ? 0 : XAP>(xv_, sP + c * 8, sP + KS + c * 8);       // x = act(a y_prev + b) (sP: a[K], b[K])
+            *reinterpret_cast<u32x4*>(sX + p * SX + ((SPLIT && j >= XS / 2) ? KS * 2 : 0) + c * 16) = xv_;
         }
 #pragma unroll
         for (int j = 0; j < DS; ++j) {
@@ -1098,7 +1114,8 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
  * are ACCUMULATED into after being cleared here (or by the caller: tcct_set_outputs_prezeroed).  K, N in {32, 64, 96, 128}. */
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
                        int64_t M, int K, int N, tcct_stream_t stream, bool split = false, int bnp = -1, int redp = -1,
-                       PwBnBwd bn = PwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr}, bool gelu_x = false);
+                       PwBnBwd bn = PwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr}, bool gelu_x = false,
+                       int xap = -1);
 /* the same over a concatenation: x = [x1 | x2], dx = [dx1 | dx2], each [M, K/2] (K = 128): backward of tcct_pw_fwd_cat2 */
 extern "C" int tcct_pw_bwd_cat2(const void* x1, const void* x2, const void* dy, const float* w, void* dx1, void* dx2, float* dw, int64_t M,
                                 int K, int N, tcct_stream_t stream) {
@@ -1161,6 +1178,18 @@ extern "C" int tcct_pw_bwd_bn_sums(const void* x, const void* x2, const void* dz
     return pw_bwd_bn_impl(x, x2, dz, PwBnBwd{(const bf16*)y, nullptr, (const bf16*)y_prev, ab_prev, sums_prev, sums, raw, mean_rstd, ab, dgamma, dbeta},
                           post, w, res, dx, dx2, dw, dbias, M, K, N, red_post, stream);
 }
+/* ... with x NOT materialised: `y_prev` is the input of the BatchNorm in front (train mode, Hardswish behind it) and x = hswish(a_prev y_prev + b_prev)
+ * is rebuilt while the tiles are staged (ab_prev = {a[K], b[K]}).  K = N = 64: with the reduction epilogue (red_post = TCCT_ACT_HSWISH, sums_prev as
+ * above); K = N = 96: without it (red_post = -1: the BatchNorm in front runs its own reduction).  post (the BatchNorm BEHIND) must be TCCT_ACT_NONE. */
+extern "C" int tcct_pw_bwd_bn_sums_xaff(const void* y_prev, const float* ab_prev, const void* dz, const void* y, const double* sums, int raw,
+                                        const float* mean_rstd, const float* ab, float* dgamma, float* dbeta, const float* w, const void* res, void* dx,
+                                        float* dw, float* dbias, int64_t M, int K, int N, int red_post, double* sums_prev, tcct_stream_t stream) {
+    TCCT_CHECK(y_prev && ab_prev && sums && mean_rstd && ab && dgamma && dbeta, "pw_bwd_bn_sums_xaff: NULL argument");
+    TCCT_CHECK(K == N && ((K == 64 && red_post == TCCT_ACT_HSWISH && sums_prev) || (K == 96 && red_post < 0)), "pw_bwd_bn_sums_xaff: K=%d N=%d red_post=%d unsupported", K, N, red_post);
+    if (red_post >= 0 && !tcct_skip_zero_fill() && hipMemsetAsync(sums_prev, 0, sizeof(double) * 2 * K, (hipStream_t)stream) != hipSuccess) { tcct_set_error("pw_bwd_bn_sums_xaff: memset failed"); return -2; }
+    return pw_bwd_impl(y_prev, dz, w, res, dx, nullptr, dw, dbias, M, K, N, stream, false, TCCT_ACT_NONE, red_post,
+                       PwBnBwd{(const bf16*)y, nullptr, (const bf16*)y_prev, ab_prev, sums_prev, sums, raw, mean_rstd, ab, dgamma, dbeta}, false, TCCT_ACT_HSWISH);
+}
 static int pw_bwd_bn_impl(const void* x, const void* x2, const void* dz, PwBnBwd bn, int post, const float* w, const void* res, void* dx, void* dx2,
                           float* dw, float* dbias, int64_t M, int K, int N, int red_post, tcct_stream_t stream) {
     const void* y = bn.y; const void* y_prev = bn.yprev; const float* ab_prev = bn.abprev; double* sums_prev = bn.sums_prev;
@@ -1183,7 +1212,7 @@ extern "C" int tcct_pw_bwd_gelu(const void* x1, const void* dy, const float* w, 
                        PwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr}, true);
 }
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
-                       int64_t M, int K, int N, tcct_stream_t stream, bool split, int bnp, int redp, PwBnBwd bn, bool gelu_x) {
+                       int64_t M, int K, int N, tcct_stream_t stream, bool split, int bnp, int redp, PwBnBwd bn, bool gelu_x, int xap) {
     TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && K <= 128 && N <= 128, "pw_bwd: K=%d N=%d unsupported (32..128)", K, N);
     TCCT_CHECK(M > 0 && M * (int64_t)(K > N ? K : N) * 2 < (1LL << 31), "pw_bwd: tensor exceeds the 2 GiB buffer-descriptor range");
     hipStream_t st = (hipStream_t)stream;
@@ -1192,7 +1221,7 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
     const int NT = N / 32, KT = K / 32;
     const int SX = 64 * KT + ((KT & 1) ? 0 : 64), SD = 64 * NT + ((NT & 1) ? 0 : 64), SW = 2 * N + 16;
     const size_t lds = (size_t)PB_P * (SX + SD) + (((size_t)K * SW + 15) & ~(size_t)15) + 4 * 2560 + (bnp >= 0 ? (size_t)5 * N * 4 : 0) +
-                       (redp >= 0 ? (size_t)2 * K * 4 : 0);
+                       ((redp >= 0 || xap >= 0) ? (size_t)2 * K * 4 : 0);
     TCCT_CHECK(lds <= 160 * 1024, "pw_bwd: %zu B of LDS", lds);
     const int64_t tiles = (M + PB_P - 1) / PB_P;
     int per_cu = (int)((160 * 1024) / (lds + 256));
@@ -1203,6 +1232,14 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
     if (gx > tiles) gx = tiles;
 #define BLX(NTV, KTV, SPV, BNV, RDV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<NTV, KTV, SPV, BNV, RDV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
         hipLaunchKernelGGL((k_pw_bwd<NTV, KTV, SPV, BNV, RDV>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M, bn); }
+    if (xap >= 0) {     // x = hswish(a y_prev + b) applied on load (InvRes.norm -> conv2): BN behind without activation; 64: + the reduction epilogue
+#define BLXA(NTV, RDV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<NTV, NTV, false, 0, RDV, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_bwd<NTV, NTV, false, 0, RDV, false, 2>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M, bn); }
+        if (NT == 2 && redp == TCCT_ACT_HSWISH) BLXA(2, 2) else if (NT == 3 && redp < 0) BLXA(3, -1)
+        else { tcct_set_error("pw_bwd: x-affine form K=N=%d red_post=%d has no kernel", K, redp); return -1; }
+#undef BLXA
+        TCCT_LAUNCH_OK();
+    }
     if (bnp >= 0) {
         // the combinations the network has (tcct_pw_bwd_bn_supported): every extra instantiation of this kernel costs ~a minute of hipcc
         const int H = TCCT_ACT_HSWISH;
@@ -1251,8 +1288,8 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
 // the next prefetch).  SPLIT: the rows are the concatenation [x | x2] of two tensors of K/2 channels each (MHCA_stage.aggregate).
 // RES: y = res + rscale[m / per_sample] * (x W^T + bias) with the product rounded to bf16 first, like the op-by-op path (Mlp.fc2 with the
 // residual add and the DropPath scale of MHCABlock folded in, reference nets/tcct.py:468); yplain (nullable) also receives the product.
-struct PwRes { const bf16* res; const float* rscale; int64_t per_sample; bf16* yplain; };
-template <int NT, int KT, bool STATS, bool SPLIT, bool RES = false, bool GX = false>
+struct PwRes { const bf16* res; const float* rscale; int64_t per_sample; bf16* yplain; const float* xab; };
+template <int NT, int KT, bool STATS, bool SPLIT, bool RES = false, bool GX = false, int XAP = -1>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* __restrict__ w, const float* __restrict__ bias,
           bf16* __restrict__ y, int64_t M, double* __restrict__ stats, int stat_pre, PwRes pr) {
@@ -1275,6 +1312,8 @@ k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* 
         *reinterpret_cast<uint4*>(sW + n * SW + c8 * 16) = o;
     }
     if (tid < N) sB[tid] = bias ? bias[tid] : 0.f;
+    float* sXA = reinterpret_cast<float*>(sS + 4 * 2560);             // XAP: a[K], b[K] of the BatchNorm in front
+    if (XAP >= 0) for (int i = tid; i < 2 * K; i += PWB) sXA[i] = pr.xab[i];
     float ss[STATS ? NT : 1][8], sq[STATS ? NT : 1][8];
 #pragma unroll
     for (int a = 0; a < (STATS ? NT : 1); ++a)
@@ -1302,7 +1341,9 @@ k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* 
         for (int j = 0; j < XS; ++j) {
             const int jj = (SPLIT && j >= XS / 2) ? j - XS / 2 : j;
             const int q = tid + jj * PWB, p = q / (KS / 8), c = q - p * (KS / 8);
-            *reinterpret_cast<u32x4*>(sX + p * SX + ((SPLIT && j >= XS / 2) ? KS * 2 : 0) + c * 16) = GX ? gelu8(px[j]) : px[j];
+            u32x4 xv_ = GX ? gelu8(px[j]) : px[j];
+            if (XAP >= 0) xv_ = affine8<XAP < 0 ? 0 : XAP>(xv_, sXA + c * 8, sXA + K + c * 8);
+            *reinterpret_cast<u32x4*>(sX + p * SX + ((SPLIT && j >= XS / 2) ? KS * 2 : 0) + c * 16) = xv_;
         }
     };
     const unsigned char* bB = sX + (32 * wave + r) * SX + hh * 16;
@@ -1410,7 +1451,7 @@ static bool pw_fwd2_ok(int64_t M, int K, int N, int K1, bool has_x2) {
 static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
                           int stat_pre, tcct_stream_t stream, PwRes pr, bool gelu_x = false) {
     const int NT = N / 32, KT = K / 32;
-    const size_t lds = (size_t)PB_P * (2 * K + 16) + (size_t)N * (2 * K + 16) + (size_t)N * 4 + 4 * 2560;
+    const size_t lds = (size_t)PB_P * (2 * K + 16) + (size_t)N * (2 * K + 16) + (size_t)N * 4 + 4 * 2560 + (pr.xab ? (size_t)2 * K * 4 : 0);
     const int64_t tiles = (M + PB_P - 1) / PB_P;
     int per_cu = (int)((160 * 1024) / (lds + 256));
     if (per_cu > 2) per_cu = 2;
@@ -1427,11 +1468,16 @@ static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const f
 #define F2N(SV) switch (NT) { case 1: F2K(1, SV) break; case 2: F2K(2, SV) break; case 3: F2K(3, SV) break; default: F2K(4, SV) break; }
 #define F2G(T) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd2<T, T, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
         hipLaunchKernelGGL((k_pw_fwd2<T, T, false, false, true, true>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)x2, w, bias, (bf16*)y, M, stats, stat_pre, pr); }
+#define F2A(T) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd2<T, T, true, false, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_fwd2<T, T, true, false, false, false, 2>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)x2, w, bias, (bf16*)y, M, stats, stat_pre, pr); }
+    if (pr.xab) { if (NT == 2) F2A(2) else F2A(3) }
+    else
     if (gelu_x) { if (NT == 2) F2G(2) else F2G(3) }
     else
     if (pr.res) { switch (NT) { case 1: F2RK(1) break; case 2: F2RK(2) break; case 3: F2RK(3) break; default: F2RK(4) break; } }
     else if (stats) { F2N(true) } else { F2N(false) }
 #undef F2G
+#undef F2A
 #undef F2RK
 #undef F2R
 #undef F2N
@@ -1443,6 +1489,15 @@ static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const f
 static int pw_fwd2_route(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
                          int stat_pre, tcct_stream_t stream, const bf16* res, const float* rscale, int64_t per_sample, bf16* yplain) {
     return pw_fwd2_launch(x, x2, w, bias, y, M, K, N, stats, stat_pre, stream, PwRes{res, rscale, per_sample, yplain});
+}
+/* y = hswish(a_prev y_prev + b_prev) W^T + bias with the statistics of y for the BatchNorm behind (stats fp64 [2N], zero on entry): the convolution
+ * whose input is a train-mode BatchNorm + Hardswish it alone consumes (InvRes.norm -> conv2, nets/tcct.py:563-572), the normalisation applied while the
+ * tile is staged; ab_prev = {a[K], b[K]}.  K = N in {64, 96}. */
+extern "C" int tcct_pw_fwd_bnstats_xaff(const void* y_prev, const float* ab_prev, const float* w, const float* bias, void* y, int64_t M, int K, int N,
+                                        double* stats, tcct_stream_t stream) {
+    TCCT_CHECK(K == N && (K == 64 || K == 96) && ab_prev && stats, "pw_fwd_bnstats_xaff: K=%d N=%d unsupported (64 or 96 square) or NULL argument", K, N);
+    TCCT_CHECK(M > 0 && M * (int64_t)K * 2 < (1LL << 31), "pw_fwd_bnstats_xaff: tensor exceeds the 2 GiB buffer-descriptor range");
+    return pw_fwd2_launch(y_prev, nullptr, w, bias, y, M, K, N, stats, 0, stream, PwRes{nullptr, nullptr, 1, nullptr, ab_prev});
 }
 /* y = res + scale[m / per_sample] * (gelu(x1) W^T + bias) with x1 the PRE-activation of Mlp.fc1 (reference nets/tcct.py:29-53,468): Mlp.fc2 with the
  * activation applied while the tile is staged and the DropPath scale + residual add in the epilogue; scale nullable.  K = N in {64, 96}. */

@@ -363,7 +363,14 @@ class ResBlock(nn.Module):
         return self.tail(self.conv1(x), x)
 
     def tail(self, f, x):
-        f = _bn(self.norm, _dw(self.dwconv, f, bn_stats=self.norm.training), post='hswish')       # statistics out of the convolution's launch
+        y = _dw(self.dwconv, f, bn_stats=self.norm.training)                                        # statistics out of the convolution's launch
+        c2, m = self.conv2, self.norm
+        if (ops.batchnorm_deferred_ok(y, m.training, 'hswish') and c2.bn.training and not c2.act
+                and ops.pw_conv_bn_ok(y, c2.conv.weight, None, True, None, None)):
+            # norm's normalisation + Hardswish is applied by conv2's kernels while they stage their tiles: the tensor between them never exists
+            ya, link = ops.batchnorm_deferred(y, m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked, m.eps, m.momentum, 'hswish')
+            return ops.pw_conv_bn(ya, c2.conv.weight, None, _bn_args(c2.bn), None, residual=x, deferred=link)
+        f = _bn(self.norm, y, post='hswish')
         # x + BN(conv2(f)): the add rides on the normalisation pass; conv2 is the only consumer of f, so the backward reduction of `norm`
         # rides on conv2's input-gradient epilogue (x_final)
         return self.conv2(f, residual=x, x_final=True)

@@ -1453,7 +1453,9 @@ class _PwConvBN(torch.autograd.Function):
     of the BatchNorm in FRONT of the convolution in its epilogue (`prev`).  x2: second half of a concatenated input (MHCA_stage.aggregate)."""
 
     @staticmethod
-    def forward(ctx, x, x2, w, bias, gamma, beta, rm, rv, nbt, eps, momentum, post, res, fork, link, prev):
+    def forward(ctx, x, x2, w, bias, gamma, beta, rm, rv, nbt, eps, momentum, post, res, fork, link, prev, xdef=None):
+        """xdef (round 4): x is NOT the convolution's input but y_prev, the input of a train-mode BatchNorm + Hardswish in front whose normalisation
+        was deferred (batchnorm_deferred): xdef = its {a[K], b[K]}; the kernels apply hswish(a y_prev + b) while they stage their tiles"""
         ctx.set_materialize_grads(False)
         _chk(x, x2, w, bias, gamma, beta, res)
         K1 = x.shape[-1]
@@ -1462,7 +1464,9 @@ class _PwConvBN(torch.autograd.Function):
         M = x.numel() // K1
         y = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=x.dtype)
         sums = ZERO.get((2 * N,), torch.float64, x.device) if ZERO.active else torch.zeros(2 * N, device=x.device, dtype=torch.float64)
-        if x2 is not None:
+        if xdef is not None:
+            lib.pw_fwd_bnstats_xaff(x, xdef, w, bias, y, M, K, N, sums)
+        elif x2 is not None:
             lib.pw_fwd_cat2(x, x2, K1, w, bias, y, M, K, N, sums, 0)
         else:
             lib.pw_fwd_bnstats(x, w, bias, y, M, K, N, sums, 0)
@@ -1473,6 +1477,7 @@ class _PwConvBN(torch.autograd.Function):
         ctx.save_for_backward(x, x2, w, y, mean_rstd, ab)
         wsrc = w if hasattr(w, '_grad_slot') or w._base is None else w._base
         ctx.cfg = (post, res is not None, wsrc, bias, gamma, beta, link, prev, M, K, N)
+        ctx.xdef = xdef
         link.y, link.ab = y, ab
         return (z, x.view_as(x)) if fork else z
 
@@ -1481,7 +1486,7 @@ class _PwConvBN(torch.autograd.Function):
         x, x2, w, y, mean_rstd, ab = ctx.saved_tensors
         post, has_res, wsrc, bsrc, gamma, beta, link, prev, M, K, N = ctx.cfg
         if dz is None:
-            return (dalias,) + (None,) * 15
+            return (dalias,) + (None,) * 16
         dz = _as(dz, y.dtype)
         if link.sums is not None:               # a consumer's dx epilogue already holds the two batch sums (raw form)
             sums, raw = link.sums, 1
@@ -1502,9 +1507,67 @@ class _PwConvBN(torch.autograd.Function):
             ypv, abp = prev.y, prev.ab
             sp = prev.sums = ZERO.get((2 * x.shape[-1],), torch.float64, y.device)
         dskip = _as(dalias, x.dtype) if dalias is not None else None
-        lib.pw_bwd_bn_sums(x, x2, dz, y, sums, raw, mean_rstd, ab, dg, db_, post, w, dskip, dx, dx2, dw, dbias, M, K, N, ypv, abp, redp, sp)
+        if ctx.xdef is not None:        # x is y_prev: the operand is rebuilt on load (dx is the gradient of the DEFERRED BatchNorm's output)
+            lib.pw_bwd_bn_sums_xaff(x, ctx.xdef, dz, y, sums, raw, mean_rstd, ab, dg, db_, w, dskip, dx, dw, dbias, M, K, N, redp, sp)
+        else:
+            lib.pw_bwd_bn_sums(x, x2, dz, y, sums, raw, mean_rstd, ab, dg, db_, post, w, dskip, dx, dx2, dw, dbias, M, K, N, ypv, abp, redp, sp)
         return (dx, dx2, _ret(dw, wsrc), _ret(dbias, bsrc), _ret(dg, gamma), _ret(db_, beta), None, None, None, None, None, None,
-                (dz if has_res else None), None, None, None)
+                (dz if has_res else None), None, None, None, None)
+
+
+BN_DEFER = os.environ.get('TCCT_BN_DEFER', '1') != '0'        # =0: InvRes.norm keeps its own normalisation pass (round-3 form; A/B timing)
+
+
+class _BatchNormDeferred(torch.autograd.Function):
+    """A train-mode BatchNorm (+ Hardswish) whose normalisation pass is NOT run (round 4): the node finalises the batch statistics (mean / rstd / a / b,
+    running statistics) and returns an ALIAS OF ITS INPUT; the one consumer -- a 1x1 convolution built with `xdef` (pw_conv_bn(..., deferred=link)) --
+    applies z = hswish(a y + b) while it stages its tiles.  The gradient that arrives here is the gradient of that virtual z, so the backward is the
+    ordinary BatchNorm backward (reduction, unless the consumer's epilogue delivered the sums through `link`, then the apply pass).
+    The alias must go to that consumer and nowhere else."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, eps, momentum, post, link):
+        _chk(x, gamma, beta)
+        C = x.shape[-1]
+        M = x.numel() // C
+        fused = getattr(x, '_bn_sums', None)
+        if fused is not None and fused[1] == 0 and fused[0].numel() == 2 * C:
+            sums = fused[0]
+        else:
+            sums = ZERO.get((2 * C,), torch.float64, x.device) if ZERO.active else torch.zeros(2 * C, device=x.device, dtype=torch.float64)
+            lib.bn_stats(x, M, C, 0, sums, dtype_code(x.dtype))
+        mean_rstd = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        ab = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        lib.bn_finalize(sums, M, C, gamma, beta, eps, momentum, rm, rv, nbt, mean_rstd, ab)
+        ctx.save_for_backward(x, gamma, mean_rstd, ab)
+        ctx.cfg = (0, post)
+        ctx.beta_param = beta
+        ctx.has_res = False
+        ctx.link = link
+        link.y, link.ab = x, ab
+        return x.view_as(x)
+
+    backward = None     # assigned below: _BatchNorm.backward with its return tuple cut to this node's inputs
+
+
+def _bn_deferred_backward(ctx, dy):
+    out = _BatchNorm.backward(ctx, dy)
+    return out[0], out[1], out[2], None, None, None, None, None, None, None
+
+
+_BatchNormDeferred.backward = staticmethod(_bn_deferred_backward)
+
+
+def batchnorm_deferred_ok(x, bn_training, post_act):
+    return (BN_DEFER and BN_FUSE and bn_training and torch.is_grad_enabled() and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] in (64, 96)
+            and ACT[post_act] == ACT['hswish'] and x.numel() * 2 < 2 ** 31)
+
+
+def batchnorm_deferred(x, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, post_act):
+    """-> (alias of x carrying the pending normalisation, link): hand both to pw_conv_bn(alias, ..., deferred=link) and to nothing else"""
+    link = BnLink(None, None, ACT[post_act])
+    y = _BatchNormDeferred.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, float(eps), float(momentum), ACT[post_act], link)
+    return y, link
 
 
 def pw_conv_bn_ok(x, w, bias, bn_training, pre_act, post_act, x2=None, prev=None):
@@ -1523,17 +1586,26 @@ def pw_conv_bn_ok(x, w, bias, bn_training, pre_act, post_act, x2=None, prev=None
     return bool(lib.pw_bwd_bn_supported(K, N, ACT[post_act], -1 if prev is None else prev.post, 1 if x2 is not None else 0))
 
 
-def pw_conv_bn(x, w, bias, bn, post_act=None, residual=None, fork=False, x2=None, x_final=False):
+def pw_conv_bn(x, w, bias, bn, post_act=None, residual=None, fork=False, x2=None, x_final=False, deferred=None):
     """post_act(BN_train(conv1x1(x [| x2]))) [+ residual]; bn = (gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum).
     fork: also return an alias of x for its other consumers (their gradient is added in this node's dx epilogue).  x_final: this
     convolution's input gradient (+ the alias') is the complete gradient of x -- when x came out of a BatchNorm node, that BatchNorm's
     backward reduction rides on this node's kernel.  Check pw_conv_bn_ok first."""
     gamma, beta, rm, rv, nbt, eps, mom = bn
+    link = BnLink(None, None, ACT[post_act])
+    w4 = w.view(w.shape[0], w.shape[1], 1, 1) if w.dim() == 2 else w
+    if deferred is not None:
+        # x is the alias batchnorm_deferred returned: y_prev with z = hswish(a y_prev + b) pending; K = N = 64 also carries that BatchNorm's
+        # backward reduction in its dx epilogue (the kernel table of tcct_pw_bwd_bn_sums_xaff), 96 leaves it to the BatchNorm's own node
+        if post_act is not None or fork or x2 is not None or x.shape[-1] != w.shape[0] or x.shape[-1] not in (64, 96):
+            raise TcctError('pw_conv_bn(deferred=...): square 64 / 96 convolution without activation, fork or concatenation only')
+        prev = deferred if (x.shape[-1] == 64 and BN_FUSE_RED) else None
+        out = _PwConvBN.apply(x, None, w4, bias, gamma, beta, rm, rv, nbt, float(eps), float(mom), 0, residual, False, link, prev, deferred.ab)
+        out._bn_link = link
+        return out
     prev = _bn_link_of(x, x_final)
     if prev is not None and not pw_conv_bn_ok(x, w, bias, True, None, post_act, x2, prev):
         prev = None
-    link = BnLink(None, None, ACT[post_act])
-    w4 = w.view(w.shape[0], w.shape[1], 1, 1) if w.dim() == 2 else w
     out = _PwConvBN.apply(x, x2, w4, bias, gamma, beta, rm, rv, nbt, float(eps), float(mom), ACT[post_act], residual, fork, link, prev)
     z = out[0] if fork else out
     z._bn_link = link               # (with a residual folded in z is BN output + res, but the gradient of the BatchNorm output still is dz)

@@ -120,7 +120,7 @@ def test_conv32_weight_gradient_lds_dma_form_equals_the_register_staged_one(cfg)
     outs = []
     prev = lib.conv32_wgrad_mode(-1)
     try:
-        for mode in (0, 1, 2, 3):   # 2 / 3: LDS-DMA + fragment reuse across the dx taps (plain 3x3 only; other shapes take the default kernel)
+        for mode in (0, 1, 2, 3, 4):   # 2 / 3: LDS-DMA + fragment reuse across the dx taps; 4: rolling rows (plain 3x3 only; other shapes take the default kernel)
             lib.conv32_wgrad_mode(mode)
             dw = torch.full((32, 32, KH, KW), 7.0, device='cuda')
             db = torch.full((32,), 7.0, device='cuda')
@@ -755,6 +755,51 @@ def test_fpl_gradient_looked_up_inside_norm_add_backward(cfg):
         torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-5 * max(1.0, b.abs().max().item()), msg=lambda m, nm=nm: nm + ': ' + m)
         same = (a == b).float().mean().item()
         assert same > 0.99, (nm, same)
+
+
+@pytest.mark.parametrize('dim', [64, 96])
+def test_invres_norm_applied_inside_conv2_equals_the_separate_pass(dim):
+    """round 4 (ops.batchnorm_deferred + pw_conv_bn(deferred=...)): InvRes.norm's BatchNorm + Hardswish (reference nets/tcct.py:563-572) is applied by
+    conv2's kernels while they stage their tiles, forward and backward, instead of by its own pass -- same values rounded at the same places, so the
+    block output, running statistics and every gradient must agree with the separate-pass form to atomic-order noise (64: with the reduction of
+    `norm` in conv2's dx epilogue; 96: with norm's own reduction kernel)"""
+    import importlib
+    from tcct_amd import ops
+    T = importlib.import_module('tcct_amd.nets.tcct')
+    torch.manual_seed(dim)
+    res = {}
+    f0 = rnd(2, dim, 24, 40, dt=torch.bfloat16)
+    x0 = rnd(2, dim, 24, 40, seed=1, dt=torch.bfloat16)
+    gy = rnd(2, dim, 24, 40, seed=2, dt=torch.bfloat16)
+    blk0 = T.ResBlock(dim)
+    with torch.no_grad():
+        for bn in (blk0.norm, blk0.conv2.bn):
+            bn.weight.copy_(1.0 + 0.2 * rnd(dim, seed=3)); bn.bias.copy_(0.1 * rnd(dim, seed=4))
+    sd = {k: v.clone() for k, v in blk0.state_dict().items()}
+    for defer in (True, False):
+        ops.BN_DEFER = defer
+        try:
+            blk = T.ResBlock(dim)
+            blk.load_state_dict(sd)
+            blk = blk.cuda().train()
+            f = nhwc(f0, torch.bfloat16).requires_grad_(True)
+            x = nhwc(x0, torch.bfloat16).requires_grad_(True)
+            out = blk.tail(f, x)
+            out.backward(nhwc(gy, torch.bfloat16))
+            res[defer] = dict(out=out.detach().float().cpu(), df=f.grad.float().cpu(), dx=x.grad.float().cpu(),
+                              rm=blk.norm.running_mean.cpu().clone(), rv=blk.norm.running_var.cpu().clone(), nbt=int(blk.norm.num_batches_tracked),
+                              **{'g:' + n: p.grad.float().cpu() for n, p in blk.named_parameters() if p.grad is not None})
+        finally:
+            ops.BN_DEFER = True
+    a, b = res[True], res[False]
+    assert set(a) == set(b) and a['nbt'] == b['nbt'] == 1
+    assert torch.equal(a['out'], b['out']) and torch.equal(a['rm'], b['rm']) and torch.equal(a['rv'], b['rv'])
+    for k in a:
+        if k in ('out', 'rm', 'rv', 'nbt'):
+            continue
+        e = (a[k] - b[k]).norm().item() / max(b[k].norm().item(), 1e-12)
+        assert e < 2e-3, (k, e)          # atomics reorder the fp32 sums; the input gradients see them through the BatchNorm coefficients
+    assert (a['df'] != 0).any() and 'g:dwconv.weight' in a and 'g:norm.weight' in a
 
 
 def test_flat_adamw_state_refuses_a_permuted_layout():
