@@ -3,8 +3,8 @@
 `RegNet.regular_udh` does NOT go through these methods: it evaluates all classes at once in the fused FPL kernels
 (`ops.fpl`: one key sort for the five classes, bin means, loss and its gradient).  The methods below give reference-side
 callers (`model.fcs.select1(feat, pred_i, true_i)`, `model.fcs.foreach_loss(pros, tgts)`, `model.fcs(q, k)`) the same
-names, arguments and results, for ONE class per call, on the same HIP kernels: key build + radix sort (`tcct_fpl_sort`),
-gather / bin means (`tcct_fpl_forward`), scatter of the bin gradients (`tcct_fpl_backward`).  The 32x32 dot product of
+names, arguments and results, for ONE class per call, on the same HIP kernels: radix multi-select of the bin boundaries + bin sums
+(`tcct_fpl_select`), prototypes (`tcct_fpl_loss`), scatter of the bin gradients (`tcct_fpl_backward`).  The 32x32 dot product of
 `cosinesim` is a single tiny matmul on the device."""
 import torch
 from torch import nn
@@ -28,23 +28,17 @@ class _SelectBins(torch.autograd.Function):
             raise TcctError('points_selection_bins: feat, prob and true must describe the same pixels')
         lab = (~sel).to(torch.uint8).contiguous()                 # class 0 = selected rows, class 1 = the rest (ignored: C = 1)
         prob = prob.reshape(-1).to(torch.float32).contiguous()
-        keys_in = torch.empty(M, device=dev, dtype=torch.int64)
-        keys_out = torch.empty(M, device=dev, dtype=torch.int64)
-        vals_in = torch.empty(M, device=dev, dtype=torch.int32)
-        vals_out = torch.empty(M, device=dev, dtype=torch.int32)
-        counts = torch.empty(8, device=dev, dtype=torch.int32)
-        wsb = lib.fpl_sort_workspace_bytes(M)
-        if wsb < 0:
-            raise TcctError('fpl_sort_workspace_bytes failed')
-        ws = torch.empty(max(int(wsb), 16), device=dev, dtype=torch.uint8)
-        lib.fpl_sort(lab, prob, M, keys_in, vals_in, keys_out, vals_out, counts, ws, int(wsb))
-        pro_sum = torch.empty((1, BINS, 32), device=dev, dtype=torch.float32)
-        pro = torch.empty((1, BINS, 32), device=dev, dtype=torch.float32)
-        scratch = torch.empty((1, BINS, 32), device=dev, dtype=torch.float32)
+        counts = torch.empty(16, device=dev, dtype=torch.int32)
+        pro_sum = torch.empty((2, BINS, 32), device=dev, dtype=torch.float32)       # class 1 (the unselected rows) is binned too and ignored
+        pro = torch.empty((2, BINS, 32), device=dev, dtype=torch.float32)
+        scratch = torch.empty((2, BINS, 32), device=dev, dtype=torch.float32)
         loss = torch.empty((), device=dev, dtype=torch.float32)
         binmap = torch.empty(M, device=dev, dtype=torch.uint8)
-        zero_proto = torch.zeros((1, 32), device=dev, dtype=torch.float32)
-        lib.fpl_forward(feat, keys_out, vals_out, counts, M, 1, zero_proto, pro_sum, pro, loss, scratch, binmap, dtype_code(feat.dtype))
+        zero_proto = torch.zeros((2, 32), device=dev, dtype=torch.float32)
+        ws = torch.empty(int(lib.fpl_select_workspace_bytes()), device=dev, dtype=torch.uint8)
+        lib.fpl_select(feat, lab, prob, M, 2, ws, counts, binmap, pro_sum, dtype_code(feat.dtype))
+        lib.fpl_loss(pro_sum, counts, zero_proto, 2, pro, loss, scratch)
+        binmap = torch.where(lab == 0, binmap, torch.full_like(binmap, 255))          # only the selected rows carry a gradient
         ctx.save_for_backward(lab, binmap, counts)
         ctx.cfg = (tuple(feat.shape), feat.dtype, M)
         return pro[0]

@@ -645,6 +645,7 @@ class FTC(nn.Module):
             (c1,), (v2, v3, v4, v5) = cs, vs
             f = [c1] + [_conv_bn(getattr(self, f'tran_vit{j}')[0], getattr(self, f'tran_vit{j}')[1], v) for j, v in enumerate((v2, v3, v4, v5))]
         y8 = _conv_bn(self.head[0], self.head[1], f[4], post='lrelu')
+        y0_direct = None            # level-0 logits when the decoder tail was composed through aux0 (below)
         if self.legacy_heads:       # tcct_goals.py:1027-1033: heads on the decoder outputs
             d3 = self.dec1(y8, f[3])
             d2 = self.dec2(d3, f[2])
@@ -657,7 +658,6 @@ class FTC(nn.Module):
             d1, s1 = self.dec3(d2, f[1], with_sum=True)
             # level 0: post, `x_0 + y_0` and t324 as one GEMM (u, d0, s0 never written) -- and through aux0 as well when the feature-polarization
             # loss is off (nothing else reads g0 then; `feats` rebuilds it on demand)
-            y0_direct = None
             g0 = self.dec4.forward_through(d1, f[0], self.t324, aux=None if self.eager_feats else self.aux0)
             if isinstance(g0, tuple):
                 y0_direct, v_up = g0

@@ -994,7 +994,7 @@ class _UpSkipConvT32(torch.autograd.Function):
 
 
 def up_skip_conv_t32_ok(y, skip, w1, b1, w2, b2):
-    return (TAIL_COMPOSE and FUSED_PW_BWD and torch.is_grad_enabled() and y.dtype == torch.bfloat16 and skip.dtype == y.dtype and y.dim() == 4
+    return (TAIL_COMPOSE and FUSED_PW_BWD and y.dtype == torch.bfloat16 and skip.dtype == y.dtype and y.dim() == 4       # (the caller requires a train-mode block)
             and y.shape[-1] == 32 and skip.shape[-1] == 32 and tuple(skip.shape[1:3]) == (2 * y.shape[1], 2 * y.shape[2])
             and tuple(w1.shape) == (32, 32, 1, 1) and tuple(w2.shape) == (32, 32, 1, 1) and b1 is not None and b2 is not None
             and w1.is_contiguous() and w2.is_contiguous() and skip.numel() * 2 < 2 ** 31)
@@ -1283,7 +1283,8 @@ class _ConvC3BN(torch.autograd.Function):
 
 
 def conv3x3_c3_bn_ok(x4, w, bn_training, post_act):
-    return (C3_BN_FUSE and bn_training and torch.is_grad_enabled() and _c3_direct_ok(x4, w) and ACT[post_act] in (0, ACT['hswish']))
+    # (train-mode BatchNorm, with or without autograd: a no_grad train-mode forward must round where the training step does)
+    return (C3_BN_FUSE and bn_training and _c3_direct_ok(x4, w) and ACT[post_act] in (0, ACT['hswish']))
 
 
 def conv3x3_c3_bn(x4, w, bias, bn, stride=1, post_act=None):
