@@ -881,15 +881,14 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
             for (int j = 0; j < DS; ++j) py[j] = __builtin_amdgcn_raw_buffer_load_b128(ry, bd + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
         }
     };
-    auto stage = [&](int64_t tile) {        // tile: the tile whose registers are being staged (rows >= M of it must give dy = 0)
-#pragma unroll
-        for (int j = 0; j < XS; ++j) {
-            const int jj = (SPLIT && j >= XS / 2) ? j - XS / 2 : j;
-            const int q = tid + jj * PWB, p = q / (KS / 8), c = q - p * (KS / 8);
-            u32x4 xv_ = GX ? gelu8(px[j]) : px[j];
-            if (XAP >= 0) xv_ = affine8<XAP < 0 ? 0 : XAP>(xv_, sP + c * 8, sP + KS + c * 8);       // x = act(a y_prev + b) (sP: a[K], b[K])
-            *reinterpret_cast<u32x4*>(sX + p * SX + ((SPLIT && j >= XS / 2) ? KS * 2 : 0) + c * 16) = xv_;
-        }
+    auto stage_x1 = [&](int j, u32x4 xv_) {
+        const int jj = (SPLIT && j >= XS / 2) ? j - XS / 2 : j;
+        const int q = tid + jj * PWB, p = q / (KS / 8), c = q - p * (KS / 8);
+        if (GX) xv_ = gelu8(xv_);
+        if (XAP >= 0) xv_ = affine8<XAP < 0 ? 0 : XAP>(xv_, sP + c * 8, sP + KS + c * 8);       // x = act(a y_prev + b) (sP: a[K], b[K])
+        *reinterpret_cast<u32x4*>(sX + p * SX + ((SPLIT && j >= XS / 2) ? KS * 2 : 0) + c * 16) = xv_;
+    };
+    auto stage_d = [&](int64_t tile) {      // tile: the tile whose registers are being staged (rows >= M of it must give dy = 0)
 #pragma unroll
         for (int j = 0; j < DS; ++j) {
             const int q = tid + j * PWB, p = q / (N / 8), c = q - p * (N / 8);
@@ -923,6 +922,11 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
             }
             *reinterpret_cast<u32x4*>(sD + p * SD + c * 16) = v;
         }
+    };
+    auto stage = [&](int64_t tile) {
+#pragma unroll
+        for (int j = 0; j < XS; ++j) stage_x1(j, px[j]);
+        stage_d(tile);
     };
     // transposing-read lane bases (see k_pw_wgrad)
     const int li = lane & 15, lq = li >> 2, lpp = li & 3, lg = lane >> 4;
@@ -1001,8 +1005,29 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
             }
         }
         __syncthreads();                              // every wave has read the staged tile
-        if (tile + (int64_t)gridDim.x < tiles) stage(tile + (int64_t)gridDim.x);
-        prefetch(tile + 2 * (int64_t)gridDim.x);
+        if ((GX || XAP >= 0) && !SPLIT) {
+            // on-load transform of the x tile (k_pw_fwd2): slot by slot -- copy the arrived registers, re-issue the slot's load for tile t + 2, then
+            // transform and store -- so that ~1000 cycles of VALU do not sit between this tile's last use and the next loads
+            const bool do_stage = tile + (int64_t)gridDim.x < tiles;
+            const int64_t tp = tile + 2 * (int64_t)gridDim.x;
+            const uint32_t bx = (uint32_t)(tp * PB_P * KS * 2), bd = (uint32_t)(tp * PB_P * N * 2);
+#pragma unroll
+            for (int j = 0; j < XS; ++j) {
+                const u32x4 xv_ = px[j];
+                px[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, bx + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
+                if (do_stage) stage_x1(j, xv_);
+            }
+            if (do_stage) stage_d(tile + (int64_t)gridDim.x);
+#pragma unroll
+            for (int j = 0; j < DS; ++j) pd[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, bd + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
+            if (BN) {
+#pragma unroll
+                for (int j = 0; j < DS; ++j) py[j] = __builtin_amdgcn_raw_buffer_load_b128(ry, bd + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
+            }
+        } else {
+            if (tile + (int64_t)gridDim.x < tiles) stage(tile + (int64_t)gridDim.x);
+            prefetch(tile + 2 * (int64_t)gridDim.x);
+        }
         // ---- dx epilogue: per-wave LDS transpose -> 16-byte stores (16 whole 64-byte pixel segments per wave instruction)
         unsigned char* sc = sS + wave * 2560;
         const int64_t m0 = tile * PB_P + 32 * wave;
@@ -1371,8 +1396,27 @@ k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* 
             }
         }
         __syncthreads();
-        if (tile + (int64_t)gridDim.x < tiles) stage();
-        prefetch(tile + 2 * (int64_t)gridDim.x);
+        if (GX || XAP >= 0) {
+            // the on-load transform (GELU / BatchNorm + Hardswish) is ~200 VALU instructions per slot: with stage() first and the prefetch behind it, the
+            // loads of tile t + 2 left ~1000 cycles late per tile and the kernel lost a quarter of its bandwidth (fc2 + GELU: 0.200 ms against
+            // 0.143 without the transform).  Slot by slot instead: copy the arrived registers, re-issue the slot's load, THEN transform and store.
+            const bool do_stage = tile + (int64_t)gridDim.x < tiles;
+            const uint32_t bx = (uint32_t)((tile + 2 * (int64_t)gridDim.x) * PB_P * KS * 2);
+#pragma unroll
+            for (int j = 0; j < XS; ++j) {
+                u32x4 xv_ = px[j];
+                px[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, bx + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
+                if (do_stage) {
+                    const int q = tid + j * PWB, p = q / (KS / 8), c = q - p * (KS / 8);
+                    if (GX) xv_ = gelu8(xv_);
+                    if (XAP >= 0) xv_ = affine8<XAP < 0 ? 0 : XAP>(xv_, sXA + c * 8, sXA + K + c * 8);
+                    *reinterpret_cast<u32x4*>(sX + p * SX + c * 16) = xv_;
+                }
+            }
+        } else {
+            if (tile + (int64_t)gridDim.x < tiles) stage();
+            prefetch(tile + 2 * (int64_t)gridDim.x);
+        }
         unsigned char* sc = sS + wave * 2560;
         const int64_t m0 = tile * PB_P + 32 * wave;
 #pragma unroll
