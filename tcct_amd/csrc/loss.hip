@@ -90,7 +90,7 @@ extern "C" int tcct_label_planes(const uint8_t* labels, float* onehot, float* ed
 // out[n,h,w] = sum_ch g/(1e-6 + S) with g = softmax_H(x - log(-log(eps))/2), S = sum_H g   (nets/reg.py:118-128)
 // stats[n,w,ch] = {m, Z, S}
 // Block = 64 columns (lanes, so the 4 channels of a pixel sit in adjacent lanes) x GSEG row segments: each thread walks H/GSEG
-// rows of its column (online max/sum), segment partials are merged through LDS.  z is recomputed per pass (2 x logf per element
+// rows of its column (online max/sum), segment partials are merged through LDS.  z is recomputed in the second pass (2 x logf per element
 // is cheaper than a third tensor round trip).
 #define GSEG 8
 __device__ __forceinline__ float gumbel_z(float x, float e) { return x - 0.5f * logf(-logf(e)); }
@@ -140,17 +140,10 @@ k_gumbel_fwd(const float* __restrict__ x, const float* __restrict__ eps, float* 
 #pragma unroll
     for (int g = 0; g < GSEG; ++g) if (sm[g][lane] > -INFINITY) Z += sz[g][lane] * __expf(sm[g][lane] - m);
     __syncthreads();
-    float S = 0.f;
-    for (hq = h0; hq + 4 <= h1; hq += 4) {
-        const float z0 = zrow(hq), z1 = zrow(hq + 1), z2 = zrow(hq + 2), z3 = zrow(hq + 3);
-        S += (__expf(z0 - m) / Z + __expf(z1 - m) / Z) + (__expf(z2 - m) / Z + __expf(z3 - m) / Z);
-    }
-    for (int h = hq; h < h1; ++h) S += __expf(zrow(h) - m) / Z;
-    sm[seg][lane] = S;
-    __syncthreads();
-    S = 0.f;
-#pragma unroll
-    for (int g = 0; g < GSEG; ++g) S += sm[g][lane];
+    // S = sum_h g[h] with g = exp(z - m) / Z is the sum of a softmax column: sum_h exp(z_h - m) IS Z, so S = 1 up to the rounding of whichever order
+    // the terms are added in (the reference's own value is 1 +- 1e-7).  Rounds 1-3 re-read both tensors to add the terms up again (a third of the
+    // kernel's traffic: 699 MB moved for 254 MB of inputs and outputs at the bench shape); the column total of the first pass is used instead.
+    const float S = 1.f;
     if (ok && seg == 0) { stats[cc * 3] = m; stats[cc * 3 + 1] = Z; stats[cc * 3 + 2] = S; }
     const float den = 1.f / (1e-6f + S);
     for (hq = h0; hq + 4 <= h1; hq += 4) {
