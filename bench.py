@@ -127,7 +127,7 @@ def dominant_kernel_roofline(a, iters=20):
     if a.dtype == 'bf16':
         wp = torch.empty(9 * 1024, device='cuda', dtype=torch.bfloat16)
         lib.conv32_pack_weights(w, wp, 3, 3, 0)
-        name, name2 = 'k_conv32_mfma<false,0,3,3> (3x3 32->32 fwd/dgrad @L0)', 'k_conv32_wgrad<5,false,true> (3x3 32->32 @L0)'
+        name, name2 = 'k_conv32_mfma<false,0,3,3> (3x3 32->32 fwd/dgrad @L0)', 'k_conv32_wgrad33_roll (3x3 32->32 weight gradient @L0, rolling rows)'
         match = 'k_conv32_mfma<false, 0, 3, 3>'                  # the symbol as rocprofv3 prints it
         fn = lambda: lib.conv32_fwd(x, wp, b, y, a.bs, a.height, Wp, 3, 3, 1, 1)                              # noqa: E731
         fn2 = lambda: lib.conv32_wgrad(x, dy, dw, db, a.bs, a.height, Wp, 3, 3, 1, 1)                         # noqa: E731

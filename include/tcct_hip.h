@@ -222,10 +222,10 @@ int tcct_conv32_fwd_strided(const void* x, const void* wp, const float* bias, vo
  * zero before the first slab */
 int tcct_conv32_fwd_strided_bnstats(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
                                     int PW, int xs, int xo, int ys, int yo, int accumulate, double* stats, int pre_act, tcct_stream_t stream);
-/* selects the kernel behind tcct_conv32_wgrad / _strided: 0 = register-staged tiles (default), 1 = LDS-DMA tiles (`buffer_load ... lds` into two LDS
- * buffers of one 8-wave block per CU), 2 / 3 = LDS-DMA + fragment reuse across the dx taps for the plain 3x3 (8 waves and two buffers / 4 waves and one
- * buffer, two blocks per CU; other shapes take the default); same results, opt-in, also TCCT_WGRAD_DMA=1|2|3; any other value only queries.  Returns the previous mode.
- * (No reference counterpart: the reference calls ATen's convolution backward, nets/tcct.py:808-822 through autograd.) */
+/* selects the kernel behind tcct_conv32_wgrad for plain 3x3 convolutions: 0 (default) = the rolling-row form (one x fragment per halo row meets a
+ * register window of three dy fragments: a third of the LDS fragment reads, 6 waves x 2 blocks per CU), 1 = the generic register-staged kernel every
+ * other shape takes (comparison arm of the bit-compatibility test; TCCT_WGRAD_GENERIC=1 for a whole run); any other value only queries.  Returns the
+ * previous mode.  (No reference counterpart: the reference calls ATen's convolution backward, nets/tcct.py:808-822 through autograd.) */
 int64_t tcct_conv32_wgrad_mode(int mode);
 int tcct_conv32_wgrad_strided(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH,
                               int PW, int xs, int xo, int ds, int dof, int cin_total, int o_off, int i_off, tcct_stream_t stream);

@@ -754,523 +754,10 @@ k_conv32_wgrad(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* _
     }
 }
 
-// ------------------------------------------------------------------------------------------------ weight gradient, LDS-DMA form
-// Same arithmetic as k_conv32_wgrad, another load path.  Ablations of the register-staged kernel at the bench shape (0.25 ms): its loads
-// alone take 0.171 ms, its LDS / MFMA side alone 0.178 (of which the ds_write staging pass 0.030), and the two overlap badly because the one
-// tile a block can hold in registers (76 VGPRs) is issued only after the previous one has been written to LDS.  Here the tiles go
-// global -> LDS directly (`buffer_load_dwordx4 ... lds`: destination = wave-uniform base + 16 B x lane, per-lane SOURCE offset, out-of-range
-// lanes write zeros -- tools/probe/ldsdma_probe.hip), into TWO LDS buffers of one 8-wave block per CU: the DMA of tile t+1 is in flight during
-// the whole MFMA phase of tile t, no staging registers, no ds_write pass, and the freed registers double-buffer the fragments of all TPW taps.
-// Every wave issues exactly WD_PPW pieces (1 KB = 16 LDS pixels each) per tile, so `s_waitcnt vmcnt(WD_PPW)` retires tile t and leaves t+1 in
-// flight; the barriers are raw s_barrier (a __syncthreads() would drain the DMA with vmcnt(0)).
-// One LDS-DMA piece: 64 lanes x 16 B from per-lane buffer offsets `voff` (descriptor `rsrc`, 4 SGPRs) to LDS bytes [lds_addr, lds_addr + 1024).
-// Inline asm on purpose: for the builtin form hipcc tracks the DMA as a pending LDS store and puts `s_waitcnt vmcnt(0)` in front of the next ds_read
-// -- which drains the tile that is meant to stay in flight.  M0 (the LDS destination base) is compiler-reserved: saved and restored inside
-// the statement; `s_nop 4`: SGPRs fresh from v_readfirstlane -> buffer instruction (cdna_hip_programming.md, "What hipcc does not do").
-__device__ __forceinline__ void lds_dma16(const u32x4& rsrc, uint32_t voff, uint32_t lds_addr) {
-    unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ u32x4 make_rsrc_words(const void* base, uint32_t bytes) {
-    const uint64_t b = (uint64_t)base;
-    u32x4 d;
-    d[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
-    d[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);       // stride 0, no swizzle
-    d[2] = bytes;
-    d[3] = 0x00020000u;
-    return d;
-}
-#define WD_T 512
-#define WD_PPW 9                // pieces per wave and tile: (<= 39 x pieces + 32 dy pieces) / 8 waves, rounded up (spare slots repeat a piece)
-template <int TPW, bool VERT, bool SQ>
-__global__ void __launch_bounds__(WD_T, 1)
-k_conv32_wgrad_dma(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
-                   int N, int H, int W, int KH, int KW, int PH, int PW, int TG, int tilesH, int tilesW, int ntiles, int xs, int xo,
-                   int ds, int dof, int ldi, int o_off, int i_off) {
-    constexpr int TH = VERT ? 64 : (SQ ? 16 : 8), TW = VERT ? 8 : (SQ ? 32 : 64);
-    constexpr int CPR = (VERT ? TH : TW) / 16;     // 16-pixel chunks per tile row (HORZ) / column (VERT)
-    constexpr int NDP = TH * TW / 16;              // dy pieces per tile (32)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int LH = TH + KH - 1, LW = TW + KW - 1;
-    const int TAPS = KH * KW;
-    const int NPX = LH * LW, NXP = (NPX + 15) >> 4;            // x pixels / x pieces (the last piece may run into the pad behind the image)
-    const int XB = NXP * 1024, BUF = XB + TH * TW * 64;        // bytes of the x image (padded to whole pieces) and of one buffer
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int WPG = 8 / TG;
-    const int tg = wave / WPG, wi = wave % WPG;
-    const int tap0 = tg * TPW;
-    int poff[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        int tap = tap0 + t;
-        int dy_ = tap / KW, dx_ = tap - dy_ * KW;
-        poff[t] = (tap < KH * KW) ? (VERT ? dx_ * LH + dy_ : dy_ * LW + dx_) * 64 : 0;
-    }
-    f32x16 acc[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
-    float bsum = 0.f;
-    const int lo = (int)(tr_lane_base(smem, lane) - smem);     // this lane's offset inside a transposing read
-
-    // piece geometry (tile independent): slot j of this wave is piece q = wave + 8 j (beyond the last piece: piece q - NP again, same bytes);
-    // lane -> pixel 16 q' + (lane >> 2), chunk lane & 3.  s_rc packs the pixel's tile coordinates; 0x3fff marks a lane without a source
-    const int c = lane & 3;
-    const int NP = NXP + NDP;
-    int s_rc[WD_PPW];
-#pragma unroll
-    for (int j = 0; j < WD_PPW; ++j) {
-        int q = wave + 8 * j;
-        if (q >= NP) q -= NP;
-        int lr, lc;
-        if (q < NXP) {
-            const int p = 16 * q + (lane >> 2);
-            if (p < NPX) { if (VERT) { lc = p / LH; lr = p - lc * LH; } else { lr = p / LW; lc = p - lr * LW; } }
-            else { lr = 0x3fff; lc = 0; }
-        } else {
-            const int pd = 16 * (q - NXP) + (lane >> 2);       // LDS pixel index of the dy image: HORZ row-major, VERT column-major
-            if (VERT) { lc = pd / TH; lr = pd - lc * TH; } else { lr = pd / TW; lc = pd - lr * TW; }
-        }
-        s_rc[j] = (lr << 16) | lc;
-    }
-    const uint32_t ximg_bytes = (uint32_t)H * (uint32_t)W * (uint32_t)xs * 2u - (uint32_t)xo * 2u;
-    const uint32_t dimg_bytes = (uint32_t)H * (uint32_t)W * (uint32_t)ds * 2u - (uint32_t)dof * 2u;
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;     // LDS byte address of the dynamic segment
-    auto dma = [&](int tile, int buf) {
-        const int tw = tile & 1023, th = (tile >> 10) & 1023, n = tile >> 20;         // TileSeq::at packing
-        const int h0 = th * TH, w0 = tw * TW;
-        const int hb = h0 - PH, wb = w0 - PW;
-        const u32x4 rx = make_rsrc_words(x + (int64_t)n * H * W * xs + xo, ximg_bytes);
-        const u32x4 rd = make_rsrc_words(dy + (int64_t)n * H * W * ds + dof, dimg_bytes);
-        const uint32_t base = lds0 + (uint32_t)(buf * BUF);
-#pragma unroll
-        for (int j = 0; j < WD_PPW; ++j) {
-            int q = wave + 8 * j;
-            if (q >= NP) q -= NP;
-            q = __builtin_amdgcn_readfirstlane(q);
-            const int lr = s_rc[j] >> 16, lc = s_rc[j] & 0xffff;
-            if (q < NXP) {                                      // wave-uniform
-                const int hi = hb + lr, wi_ = wb + lc;
-                const bool ok = lr != 0x3fff && (unsigned)hi < (unsigned)H && (unsigned)wi_ < (unsigned)W;
-                const uint32_t off = ok ? (uint32_t)((hi * W + wi_) * xs * 2 + c * 16) : OOB_OFF;
-                lds_dma16(rx, off, base + (uint32_t)(q * 1024));
-            } else {
-                const int ho = h0 + lr, wo = w0 + lc;
-                const uint32_t off = (ho < H && wo < W) ? (uint32_t)((ho * W + wo) * ds * 2 + c * 16) : OOB_OFF;
-                lds_dma16(rd, off, base + (uint32_t)(XB + (q - NXP) * 1024));
-            }
-        }
-    };
-    const TileSeq<VERT> seq(ntiles, tilesH, tilesW);
-    int tile = seq.at(0), tile1 = -1;
-    if (tile >= 0) dma(tile, 0);
-    for (int kt = 0; tile >= 0; tile = tile1, ++kt) {
-        tile1 = seq.at(kt + 1);
-        if (tile1 >= 0) {                                       // block-uniform
-            dma(tile1, (kt + 1) & 1);
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WD_PPW) : "memory");      // tile kt has landed (this wave's pieces), kt+1 stays in flight
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();                           // ... and every other wave's pieces of tile kt
-        const unsigned char* sX = smem + (kt & 1) * BUF;
-        const unsigned char* lbX = sX + lo;
-        const unsigned char* lbD = sX + XB + lo;
-        // chunks of 16 pixels; fragments of chunk i+1 are read while the MFMAs of chunk i run (sched_barrier pins the order)
-        struct WFrag { bf16x8 a, b[TPW]; };
-        auto load_chunk = [&](WFrag& f, int ch) {
-            const int a_ = ch / CPR, s16 = (ch % CPR) * 16;   // HORZ: row / col offset; VERT: col / row offset
-            const int Pd = VERT ? a_ * TH + s16 : a_ * TW + s16;
-            const int Px = VERT ? a_ * LH + s16 : a_ * LW + s16;
-            f.a = tr_load8p(lbD + Pd * 64);
-            const unsigned char* px = lbX + Px * 64;
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) f.b[t] = tr_load8p(px + poff[t]);
-        };
-        auto mma_chunk = [&](const WFrag& f) {
-            if (tg == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bsum = dot2_ones(f.a, j, bsum);
-            }
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
-                if (tap0 + t < TAPS) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a, f.b[t], acc[t], 0, 0, 0);
-        };
-        WFrag f0, f1;                   // named buffers: a runtime-indexed array of fragments would live in scratch
-        load_chunk(f0, wi);
-        for (int ch = wi; ch < 32; ch += 2 * WPG) {           // 32 / WPG is even (WPG = 8, 4, 2)
-            load_chunk(f1, ch + WPG);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_chunk(f0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ch + 2 * WPG < 32) load_chunk(f0, ch + 2 * WPG);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_chunk(f1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // every wave has read buffer kt & 1: the DMA of tile kt + 2 may overwrite it
-    }
-    // block-level reduction of the WPG partial accumulators per tap in LDS, then one atomic per element and block (as k_conv32_wgrad)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-    for (int turn = 0; turn < WPG; ++turn) {
-        if (wi == turn) {
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int tap = tap0 + t;
-                if (tap < TAPS) {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
-                        float* dst = &red[tap * 1024 + co * 32 + r];
-                        *dst = turn == 0 ? acc[t][k] : *dst + acc[t][k];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < TAPS * 1024; i += WD_T) {
-        const int tap = i % TAPS, cc = i / TAPS;          // cc = co*32 + ci
-        const int co = cc >> 5, ci = cc & 31;
-        atomicAdd(&dw[((int64_t)(o_off + co) * ldi + i_off + ci) * TAPS + tap], red[tap * 1024 + cc]);
-    }
-    if (dbias && tg == 0) {
-        bsum += __shfl_xor(bsum, 32, 64);
-        if (lane < 32) atomicAdd(&dbias[o_off + r], bsum);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ 3x3 weight gradient, LDS-DMA + fragment reuse
-// The LDS array bounds both forms above: every x pixel is read from LDS once per TAP (the nine x fragments of a 16-pixel chunk are the same
-// pixels shifted by one row / one pixel) and dy once per tap group -- 786 KB of transposing reads per 72 KB tile.  Here one wave owns two output
-// rows of the 16 x 32 tile and ALL nine taps (9 accumulators; the DMA form has no staging registers in the way).  Per input row it reads three
-// fragments (pixels 0-15, 16-31, 32-47 of the 34-pixel halo row) and derives the dx = 1, 2 operands in registers: a lane holds 8 consecutive
-// pixels of one channel, so "shifted by one pixel" is a 16-bit funnel shift across its four dwords plus ONE incoming dword from the lane that
-// holds the next eight pixels (the other half-wave of the same fragment, or the first half-wave of the next one: v_permlane32_swap), and
-// "shifted by two" is a register rename.  Every input row serves up to two output rows x three dx.  LDS reads per tile: 128 KB instead of 786.
-__device__ __forceinline__ void shift_frags(const bf16x8& f, const bf16x8& fn, int hh, bf16x8& b1, bf16x8& b2) {
-    const u32x4 d = __builtin_bit_cast(u32x4, f), dn = __builtin_bit_cast(u32x4, fn);
-    const auto sw = __builtin_amdgcn_permlane32_swap(d[0], dn[0], false, false);    // sw[0] = (d0[0..31], dn0[0..31]), sw[1] = (d0[32..63], dn0[32..63])
-    const uint32_t e = hh ? sw[0] : sw[1];                                          // dword 0 of the lane that holds the NEXT eight pixels
-    u32x4 s1, s2;
-    s1[0] = __builtin_amdgcn_alignbit(d[1], d[0], 16); s1[1] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
-    s1[2] = __builtin_amdgcn_alignbit(d[3], d[2], 16); s1[3] = __builtin_amdgcn_alignbit(e, d[3], 16);
-    s2[0] = d[1]; s2[1] = d[2]; s2[2] = d[3]; s2[3] = e;
-    b1 = __builtin_bit_cast(bf16x8, s1);
-    b2 = __builtin_bit_cast(bf16x8, s2);
-}
-__global__ void __launch_bounds__(WD_T, 1)
-k_conv32_wgrad33_dma(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
-                     int N, int H, int W, int tilesH, int tilesW, int ntiles) {
-    constexpr int TH = 16, TW = 32, LH = 18, LW = 34, TAPS = 9;
-    constexpr int NPX = LH * LW, NXP = (NPX + 15) >> 4, NDP = TH * TW / 16, NP = NXP + NDP;        // 612 px, 39 + 32 pieces
-    constexpr int XB = NXP * 1024, BUF = XB + TH * TW * 64;
-    static_assert(NP <= 8 * WD_PPW, "pieces per wave");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    f32x16 acc[TAPS];
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
-    float bsum = 0.f;
-    const int lo = (int)(tr_lane_base(smem, lane) - smem);
-    const int c = lane & 3;
-    int s_rc[WD_PPW];
-#pragma unroll
-    for (int j = 0; j < WD_PPW; ++j) {
-        int q = wave + 8 * j;
-        if (q >= NP) q -= NP;
-        int lr, lc;
-        if (q < NXP) {
-            const int p = 16 * q + (lane >> 2);
-            if (p < NPX) { lr = p / LW; lc = p - lr * LW; } else { lr = 0x3fff; lc = 0; }
-        } else {
-            const int pd = 16 * (q - NXP) + (lane >> 2);
-            lr = pd / TW; lc = pd - lr * TW;
-        }
-        s_rc[j] = (lr << 16) | lc;
-    }
-    const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    // The per-tile bookkeeping is on the critical path of a kernel with two waves per SIMD (an ablation with neither DMA nor compute -- tile
-    // sequence, piece addresses, two barriers -- took 0.086 of the 0.26 ms): per piece ONE add for interior tiles (offsets relative to the
-    // tile origin precomputed per slot; an unused lane's 0x80000000 keeps the sum out of range), descriptor / origin picked by scalar selects
-    // (x and dy pieces share the LDS formula base + 1 KB x q because the x image is padded to whole pieces), no re-decoding of a linear tile id.
-    uint32_t s_off[WD_PPW];
-    int s_q[WD_PPW];
-#pragma unroll
-    for (int j = 0; j < WD_PPW; ++j) {
-        int q = wave + 8 * j;
-        if (q >= NP) q -= NP;
-        s_q[j] = __builtin_amdgcn_readfirstlane(q);
-        const int lr = s_rc[j] >> 16, lc = s_rc[j] & 0xffff;
-        s_off[j] = lr == 0x3fff ? OOB_OFF : (uint32_t)((lr * W + lc) * 64 + c * 16);
-    }
-    auto dma = [&](int n, int th, int tw, int buf) {
-        const int h0 = th * TH, w0 = tw * TW;
-        const u32x4 rx = make_rsrc_words(x + (int64_t)n * H * W * 32, img_bytes);
-        const u32x4 rd = make_rsrc_words(dy + (int64_t)n * H * W * 32, img_bytes);
-        const uint32_t base = lds0 + (uint32_t)(buf * BUF);
-        if (h0 >= 1 && w0 >= 1 && h0 + TH + 1 <= H && w0 + TW + 1 <= W) {          // interior tile (block-uniform): halo and dy tile inside the image
-            const uint32_t bx = (uint32_t)(((h0 - 1) * W + (w0 - 1)) * 64), bd = (uint32_t)((h0 * W + w0) * 64);
-#pragma unroll
-            for (int j = 0; j < WD_PPW; ++j) {
-                const bool isx = s_q[j] < NXP;                  // wave-uniform
-                lds_dma16(isx ? rx : rd, (isx ? bx : bd) + s_off[j], base + (uint32_t)(s_q[j] * 1024));
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < WD_PPW; ++j) {
-                const int q = s_q[j];
-                const int lr = s_rc[j] >> 16, lc = s_rc[j] & 0xffff;
-                if (q < NXP) {
-                    const int hi = h0 - 1 + lr, wi_ = w0 - 1 + lc;
-                    const bool ok = lr != 0x3fff && (unsigned)hi < (unsigned)H && (unsigned)wi_ < (unsigned)W;
-                    lds_dma16(rx, ok ? (uint32_t)((hi * W + wi_) * 64 + c * 16) : OOB_OFF, base + (uint32_t)(q * 1024));
-                } else {
-                    const int ho = h0 + lr, wo = w0 + lc;
-                    lds_dma16(rd, (ho < H && wo < W) ? (uint32_t)((ho * W + wo) * 64 + c * 16) : OOB_OFF, base + (uint32_t)(q * 1024));
-                }
-            }
-        }
-    };
-    const TileSeq<false> seq(ntiles, tilesH, tilesW);
-    int tn, tth, ttw;
-    bool have = seq.at3(0, tn, tth, ttw);
-    if (have) dma(tn, tth, ttw, 0);
-    for (int kt = 0; have; ++kt) {
-        const bool more = seq.at3(kt + 1, tn, tth, ttw);
-        if (more) {
-            dma(tn, tth, ttw, (kt + 1) & 1);
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WD_PPW) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        have = more;
-        __builtin_amdgcn_s_barrier();
-        const unsigned char* sX = smem + (kt & 1) * BUF;
-        const unsigned char* lbX = sX + lo;
-        const unsigned char* lbD = sX + XB + lo;
-        // this wave: output rows y0 = 2 wave, y0 + 1; input (halo) rows 2 wave .. 2 wave + 3
-        bf16x8 A[2][2];
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                A[y][cc] = tr_load8p(lbD + ((2 * wave + y) * TW + 16 * cc) * 64);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bsum = dot2_ones(A[y][cc], j, bsum);
-            }
-#pragma unroll
-        for (int ir = 0; ir < 4; ++ir) {
-            const unsigned char* px = lbX + (2 * wave + ir) * LW * 64;
-            bf16x8 F[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) F[k] = tr_load8p(px + 16 * k * 64);        // pixels 32-47: 32, 33 are the halo, the rest is never used
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                bf16x8 b1, b2;
-                shift_frags(F[cc], F[cc + 1], hh, b1, b2);
-#pragma unroll
-                for (int y = 0; y < 2; ++y) {
-                    const int dyi = ir - y;                                         // tap row of input row ir for output row y
-                    if (dyi >= 0 && dyi <= 2) {
-                        acc[dyi * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[y][cc], F[cc], acc[dyi * 3 + 0], 0, 0, 0);
-                        acc[dyi * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[y][cc], b1, acc[dyi * 3 + 1], 0, 0, 0);
-                        acc[dyi * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[y][cc], b2, acc[dyi * 3 + 2], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-    for (int turn = 0; turn < 8; ++turn) {
-        if (wave == turn) {
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
-                    float* dst = &red[t * 1024 + co * 32 + r];
-                    *dst = turn == 0 ? acc[t][k] : *dst + acc[t][k];
-                }
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < TAPS * 1024; i += WD_T) {
-        const int tap = i % TAPS, cc = i / TAPS;          // cc = co*32 + ci
-        atomicAdd(&dw[(int64_t)cc * TAPS + tap], red[tap * 1024 + cc]);
-    }
-    if (dbias) {
-        bsum += __shfl_xor(bsum, 32, 64);
-        if (lane < 32) atomicAdd(&dbias[r], bsum);
-    }
-}
-
-// The same data flow in the register-staged kernel's SHAPE: 4 waves per block, ONE LDS buffer (72 KB), two blocks per CU.  The 8-wave / two-buffer
-// form above holds a whole CU (145 KB of LDS) and runs its piece addressing and its MFMAs in the same waves one after the other; here a block's DMA
-// issue + wait overlaps the OTHER block's MFMA phase, and other kernels' blocks still fit beside it.  One wave: four output rows, six halo rows.
-__global__ void __launch_bounds__(MB, 2)
-k_conv32_wgrad33_dma4(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
-                      int N, int H, int W, int tilesH, int tilesW, int ntiles) {
-    constexpr int TH = 16, TW = 32, LH = 18, LW = 34, TAPS = 9, PPW = 18;
-    constexpr int NPX = LH * LW, NXP = (NPX + 15) >> 4, NDP = TH * TW / 16, NP = NXP + NDP;        // 612 px, 39 + 32 pieces
-    constexpr int XB = NXP * 1024;
-    static_assert(NP <= 4 * PPW, "pieces per wave");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    f32x16 acc[TAPS];
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
-    float bsum = 0.f;
-    const int lo = (int)(tr_lane_base(smem, lane) - smem);
-    const int c = lane & 3;
-    // (no per-slot offset table here: with nine accumulators live every table costs spills; the piece's pixel is re-derived per tile --
-    // divisions by constants -- and that arithmetic runs beside the OTHER block's MFMA phase)
-    int s_q[PPW];
-    auto slot_rc = [&](int q, int& lr, int& lc) {
-        int l4 = lane >> 2;
-        asm volatile("" : "+v"(l4));            // opaque: re-derive per tile, never hoist 18 slots' worth of coordinates out of the tile loop
-        if (q < NXP) {
-            const int p = 16 * q + l4;
-            if (p < NPX) { lr = p / LW; lc = p - lr * LW; } else { lr = 0x3fff; lc = 0; }
-        } else {
-            const int pd = 16 * (q - NXP) + l4;
-            lr = pd / TW; lc = pd - lr * TW;
-        }
-    };
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-        int q = wave + 4 * j;
-        if (q >= NP) q -= NP;
-        s_q[j] = __builtin_amdgcn_readfirstlane(q);
-    }
-    const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    auto dma = [&](int n, int th, int tw) {
-        const int h0 = th * TH, w0 = tw * TW;
-        const u32x4 rx = make_rsrc_words(x + (int64_t)n * H * W * 32, img_bytes);
-        const u32x4 rd = make_rsrc_words(dy + (int64_t)n * H * W * 32, img_bytes);
-        if (h0 >= 1 && w0 >= 1 && h0 + TH + 1 <= H && w0 + TW + 1 <= W) {          // interior tile (block-uniform)
-            const uint32_t bx = (uint32_t)(((h0 - 1) * W + (w0 - 1)) * 64), bd = (uint32_t)((h0 * W + w0) * 64);
-#pragma unroll
-            for (int j = 0; j < PPW; ++j) {
-                const bool isx = s_q[j] < NXP;                  // wave-uniform
-                int lr, lc;
-                slot_rc(s_q[j], lr, lc);
-                const uint32_t off = lr == 0x3fff ? OOB_OFF : (isx ? bx : bd) + (uint32_t)((lr * W + lc) * 64 + c * 16);
-                lds_dma16(isx ? rx : rd, off, lds0 + (uint32_t)(s_q[j] * 1024));
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < PPW; ++j) {
-                const int q = s_q[j];
-                int lr, lc;
-                slot_rc(q, lr, lc);
-                if (q < NXP) {
-                    const int hi = h0 - 1 + lr, wi_ = w0 - 1 + lc;
-                    const bool ok = lr != 0x3fff && (unsigned)hi < (unsigned)H && (unsigned)wi_ < (unsigned)W;
-                    lds_dma16(rx, ok ? (uint32_t)((hi * W + wi_) * 64 + c * 16) : OOB_OFF, lds0 + (uint32_t)(q * 1024));
-                } else {
-                    const int ho = h0 + lr, wo = w0 + lc;
-                    lds_dma16(rd, (ho < H && wo < W) ? (uint32_t)((ho * W + wo) * 64 + c * 16) : OOB_OFF, lds0 + (uint32_t)(q * 1024));
-                }
-            }
-        }
-    };
-    const TileSeq<false> seq(ntiles, tilesH, tilesW);
-    const unsigned char* lbX = smem + lo;
-    const unsigned char* lbD = smem + XB + lo;
-    int tn, tth, ttw;
-    bool have = seq.at3(0, tn, tth, ttw);
-    for (int kt = 0; have; ++kt) {
-        dma(tn, tth, ttw);
-        have = seq.at3(kt + 1, tn, tth, ttw);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // the tile has landed (every wave's pieces)
-        // this wave: output rows 4 wave .. 4 wave + 3 in two pairs (a pair at a time keeps the dy fragments at 16 VGPRs next to the nine accumulators);
-        // a pair reads four halo rows
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            const int row0 = 4 * wave + 2 * half;
-            bf16x8 A[2][2];
-#pragma unroll
-            for (int y = 0; y < 2; ++y)
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    A[y][cc] = tr_load8p(lbD + ((row0 + y) * TW + 16 * cc) * 64);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bsum = dot2_ones(A[y][cc], j, bsum);
-                }
-#pragma unroll
-            for (int ir = 0; ir < 4; ++ir) {
-                const unsigned char* px = lbX + (row0 + ir) * LW * 64;
-                bf16x8 F[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) F[k] = tr_load8p(px + 16 * k * 64);
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    bf16x8 b1, b2;
-                    shift_frags(F[cc], F[cc + 1], hh, b1, b2);
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) {
-                        const int dyi = ir - y;                                         // tap row of input row ir for output row y
-                        if (dyi >= 0 && dyi <= 2) {
-                            acc[dyi * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[y][cc], F[cc], acc[dyi * 3 + 0], 0, 0, 0);
-                            acc[dyi * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[y][cc], b1, acc[dyi * 3 + 1], 0, 0, 0);
-                            acc[dyi * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[y][cc], b2, acc[dyi * 3 + 2], 0, 0, 0);
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);          // one halo row's fragments at a time
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // every wave has read the buffer: the next tile's DMA may overwrite it
-    }
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-    for (int turn = 0; turn < 4; ++turn) {
-        if (wave == turn) {
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
-                    float* dst = &red[t * 1024 + co * 32 + r];
-                    *dst = turn == 0 ? acc[t][k] : *dst + acc[t][k];
-                }
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < TAPS * 1024; i += MB) {
-        const int tap = i % TAPS, cc = i / TAPS;          // cc = co*32 + ci
-        atomicAdd(&dw[(int64_t)cc * TAPS + tap], red[tap * 1024 + cc]);
-    }
-    if (dbias) {
-        bsum += __shfl_xor(bsum, 32, 64);
-        if (lane < 32) atomicAdd(&dbias[r], bsum);
-    }
-}
-
-// which weight-gradient kernel tcct_conv32_wgrad* launches: 0 = register-staged k_conv32_wgrad (default), 1 = k_conv32_wgrad_dma (LDS-DMA, two LDS
-// buffers; opt-in: same speed at the bench shape, kept as the base for B-fragment reuse across the dx taps -- DESIGN 3e).  -1 on entry = unset: the
-// environment variable TCCT_WGRAD_DMA=1 selects the DMA form.
+// (Rounds 2-3 carried three more forms of this kernel -- tiles DMA'd global -> LDS into two buffers of one 8-wave block per CU, and two 3x3 forms that
+// derived the dx = 1, 2 operands from one fragment by funnel shifts + v_permlane32_swap.  All bit-compatible, none faster inside the step; round 4
+// deleted them when the rolling-row form below became the default.  What they taught is in DESIGN.md 3: the DMA path needs ~400 bookkeeping
+// instructions per tile and wave, and cutting LDS reads alone does not move a kernel that waits on one tile in flight per block.)
 // ------------------------------------------------------------------------------------------------ 3x3 weight gradient, rolling rows (round 4)
 // The register-staged kernel above reads every x pixel from LDS once per TAP and every dy pixel once per tap group: 192 transposing reads per
 // tile and wave, 393 KB per 72 KB tile and block -- at two blocks per CU the LDS array is ~80 % busy at the rate HBM could feed the kernel
@@ -1426,10 +913,12 @@ k_conv32_wgrad33_roll(const bf16* __restrict__ x, const bf16* __restrict__ dy, f
 }
 
 static int g_wgrad_mode = -1;
+/* 0 (default): plain 3x3 convolutions take the rolling-row kernel; 1: the generic register-staged kernel for every shape (the comparison arm of the
+ * bit-compatibility test; TCCT_WGRAD_GENERIC=1 selects it for a whole run).  Returns the previous mode; mode < 0 only queries. */
 extern "C" int64_t tcct_conv32_wgrad_mode(int mode) {
-    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] >= '0' && e_[0] <= '4') ? e_[0] - '0' : 0; }
+    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_GENERIC"); g_wgrad_mode = (e_ && e_[0] == '1') ? 1 : 0; }
     const int prev = g_wgrad_mode;
-    if (mode >= 0 && mode <= 4) g_wgrad_mode = mode;
+    if (mode == 0 || mode == 1) g_wgrad_mode = mode;
     return prev;
 }
 /* dw OIHW fp32 [32,32,KH,KW] and dbias fp32 [32] (nullable) are overwritten. */
@@ -1472,54 +961,14 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
         if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * TAPS * 1024, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
         if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
     }
-    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_DMA"); g_wgrad_mode = (e_ && e_[0] >= '0' && e_[0] <= '4') ? e_[0] - '0' : 0; }
-    if (g_wgrad_mode == 4 && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {      // plain 3x3: rolling rows, 6 waves x 2 blocks per CU
+    if (g_wgrad_mode < 0) (void)tcct_conv32_wgrad_mode(-1);
+    if (g_wgrad_mode == 0 && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {      // plain 3x3: rolling rows, 6 waves x 2 blocks per CU
         constexpr size_t lds4 = (size_t)18 * 34 * 64 + 16 * 32 * 64;
         static bool attr4 = false;
         if (!attr4) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad33_roll, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr4 = true; }
         hipLaunchKernelGGL(k_conv32_wgrad33_roll, dim3((unsigned)(nt < 512 ? nt : 512)), dim3(WR_T), lds4, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W,
                            tilesH, tilesW, (int)nt);
         TCCT_LAUNCH_OK();
-    }
-    if (g_wgrad_mode == 3 && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {      // plain 3x3: LDS-DMA + fragment reuse, 4 waves x 2 blocks per CU
-        constexpr size_t lds3 = (size_t)((18 * 34 + 15) / 16) * 1024 + 16 * 32 * 64;
-        static bool attr3 = false;
-        if (!attr3) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad33_dma4, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr3 = true; }
-        hipLaunchKernelGGL(k_conv32_wgrad33_dma4, dim3((unsigned)(nt < 512 ? nt : 512)), dim3(MB), lds3, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W,
-                           tilesH, tilesW, (int)nt);
-        TCCT_LAUNCH_OK();
-    }
-    if (g_wgrad_mode == 2 && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {      // plain 3x3: LDS-DMA + fragment reuse
-        constexpr size_t ldsr = 2 * ((size_t)((18 * 34 + 15) / 16) * 1024 + 16 * 32 * 64);
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad33_dma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-        hipLaunchKernelGGL(k_conv32_wgrad33_dma, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(WD_T), ldsr, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W,
-                           tilesH, tilesW, (int)nt);
-        TCCT_LAUNCH_OK();
-    }
-    if (g_wgrad_mode == 1) {
-        // LDS-DMA form: one 8-wave block per CU, two LDS buffers; taps over TG wave groups (<= 5 accumulators per wave), WPG = 8 / TG waves per group
-        const int TGd = TAPS > 10 ? 4 : (TAPS > 5 ? 2 : 1);
-        const int tpwd = (TAPS + TGd - 1) / TGd;
-        const int nxp = (LH * LW + 15) / 16;
-        const size_t buf = (size_t)nxp * 1024 + (size_t)TH * TW * 64;
-        size_t ldsd = 2 * buf;
-        if (red > ldsd) ldsd = red;
-        if (ldsd <= 160 * 1024 && nxp + TH * TW / 16 <= 8 * WD_PPW) {
-            int gridd = (int)(nt < 256 ? nt : 256);
-#define WD_LAUNCH(TPW, V, Q)                                                                                                 \
-    do {                                                                                                                    \
-        static bool attr = false;                                                                                           \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad_dma<TPW, V, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-        hipLaunchKernelGGL((k_conv32_wgrad_dma<TPW, V, Q>), dim3(gridd), dim3(WD_T), ldsd, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W, KH, \
-                           KW, PH, PW, TGd, tilesH, tilesW, (int)nt, xs, xo, ds, dof, ldi, o_off, i_off);                                                       \
-    } while (0)
-            if (sq) WD_LAUNCH(5, false, true);
-            else if (tpwd <= 4) { if (vert) WD_LAUNCH(4, true, false); else WD_LAUNCH(4, false, false); }
-            else { if (vert) WD_LAUNCH(5, true, false); else WD_LAUNCH(5, false, false); }
-#undef WD_LAUNCH
-            TCCT_LAUNCH_OK();
-        }
     }
     // taps are split over TG wave groups so that <= 5 accumulators (80 VGPRs) live next to the prefetch registers: no spills
     const int TG = TAPS > 10 ? 4 : (TAPS > 5 ? 2 : 1);

@@ -1,4 +1,5 @@
-"""A/B of the 3x3 32->32 weight-gradient forms at the bench shape (tcct_conv32_wgrad_mode 0..4), interleaved on one box:  python tools/wgrad_modes.py"""
+"""A/B of the two 3x3 32->32 weight-gradient forms at the bench shape (tcct_conv32_wgrad_mode 0 = rolling rows, 1 = generic), interleaved on one box:
+python tools/wgrad_modes.py"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
@@ -17,7 +18,7 @@ def t(mode, iters=30):
     for _ in range(iters): lib.conv32_wgrad(x, dy, dw, db, B, H, W, 3, 3, 1, 1)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-modes = [int(m) for m in sys.argv[1:]] or [0, 3, 4]
+modes = [int(m) for m in sys.argv[1:]] or [1, 0]
 for rep in range(3):
     print('  '.join(f'mode {m}: {t(m):.4f} ms' for m in modes), flush=True)
 lib.conv32_wgrad_mode(0)
