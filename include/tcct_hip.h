@@ -363,6 +363,9 @@ int tcct_c3_bn_bwd_wgrad(const void* x4, const float* w, const float* bias, cons
 int tcct_pw_wgrad_smalln(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, int x_dtype,
                          int dy_dtype, tcct_stream_t stream);
 
+/* achievable-bandwidth yardstick of bench.py (`roofline.copy_ceiling`): a streaming copy with 16-byte accesses, one 8 KB chunk per block */
+int tcct_stream_copy(const void* src, void* dst, int64_t nbytes, tcct_stream_t stream);
+
 /* ---- depthwise 3x3 (nets/tcct.py:114-122,206,535-543; nets/reg.py:66-67,72,74 as C=1 / groups=C) -------- */
 int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
                        int stride, int add_input, int dtype, tcct_stream_t stream);

@@ -320,3 +320,24 @@ extern "C" int tcct_axpy_f32(const float* x, float* y, int64_t n, float alpha, t
     hipLaunchKernelGGL(k_axpy_f32, dim3(tcct_grid(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, y, n, alpha);
     TCCT_LAUNCH_OK();
 }
+
+// ------------------------------------------------------------------------------------------- streaming-copy yardstick
+// The copy rate the streaming kernels of this library are compared with (bench.py `roofline.copy_ceiling`): 16-byte accesses, one block-contiguous
+// 8 KB chunk per block, a grid as large as the tensor (tools/probe/stream_probe.hip: 6.0 TB/s on the MI355X against 5.3 for persistent blocks and
+// 4.9 for hipMemcpyDtoD; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy).
+__global__ void __launch_bounds__(256) k_stream_copy(const uint4* __restrict__ x, uint4* __restrict__ y, int64_t n16) {
+    const int64_t base = (int64_t)blockIdx.x * 512 + threadIdx.x;
+    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+    if (base < n16) v0 = x[base];
+    if (base + 256 < n16) v1 = x[base + 256];
+    if (base < n16) y[base] = v0;
+    if (base + 256 < n16) y[base + 256] = v1;
+}
+/* dst[0..nbytes) = src[0..nbytes), nbytes a multiple of 16, both 16-byte aligned: the achievable-bandwidth yardstick (no reference counterpart) */
+extern "C" int tcct_stream_copy(const void* src, void* dst, int64_t nbytes, tcct_stream_t stream) {
+    TCCT_CHECK(nbytes > 0 && nbytes % 16 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "stream_copy: %lld bytes / alignment", (long long)nbytes);
+    const int64_t n16 = nbytes / 16, blocks = (n16 + 511) / 512;
+    TCCT_CHECK(blocks < 0x7fffffffLL, "stream_copy: too large");
+    hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, n16);
+    TCCT_LAUNCH_OK();
+}

@@ -21,6 +21,7 @@ cd $GRAFT_REPO_ROOT
 # the PMC traffic of the roofline kernels first (profiles/TAG_pmc.json in THIS copy of the tree), so that the bench lines below carry `roofline.traffic`
 python tools/pmc_json.py ${TAG} > /dev/null 2>> $OUT/${TAG}_bench.err
 python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2>> $OUT/${TAG}_bench.err
+python bench.py --steps 30 --warmup 10 --no-cpu-baseline --los=di+reg > $OUT/${TAG}_bench_reg.json 2>> $OUT/${TAG}_bench.err
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --los=di+reg+fpl > $OUT/${TAG}_bench_fullloss.json 2>> $OUT/${TAG}_bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --dtype fp32 > $OUT/${TAG}_bench_fp32.json 2>> $OUT/${TAG}_bench.err
 python tools/infer_bench.py > $OUT/${TAG}_infer.txt 2>> $OUT/${TAG}_bench.err

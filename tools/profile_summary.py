@@ -6,12 +6,13 @@ step = list(csv.DictReader(open(f'{G}/{tag}_step/step_kernel_stats.csv')))
 roof = list(csv.DictReader(open(f'{G}/{tag}_roof/roof_kernel_stats.csv')))
 shutil.copy(f'{G}/{tag}_step/step_kernel_stats.csv', f'{P}/{tag}_kernel_stats.csv')
 shutil.copy(f'{G}/{tag}_roof/roof_kernel_stats.csv', f'{P}/{tag}_roofline_only_kernel_stats.csv')
-for n in ('bench', 'bench_fullloss', 'bench_fp32'):
-    shutil.copy(f'{G}/{tag}_{n}.json', f'{P}/{tag}_{n}.json')
+for n in ('bench', 'bench_reg', 'bench_fullloss', 'bench_fp32'):
+    if os.path.exists(f'{G}/{tag}_{n}.json'):
+        shutil.copy(f'{G}/{tag}_{n}.json', f'{P}/{tag}_{n}.json')
 shutil.copy(f'{G}/{tag}_infer.txt', f'{P}/{tag}_infer.txt')
 nsteps = 3
 tot = sum(float(r['TotalDurationNs']) for r in step)
-fams = [('BatchNorm (k_bn*)', r'k_bn'), ('pointwise fused backward (k_pw_bwd)', r'k_pw_bwd'), ('pointwise fwd/dgrad (k_pw_fwd, k_pw_fwd2)', r'k_pw_fwd'),
+fams = [('first layers: conv + train-mode BatchNorm, conv output recomputed (k_c3_bn*)', r'k_c3_bn'), ('BatchNorm (k_bn*)', r'k_bn'), ('pointwise fused backward (k_pw_bwd)', r'k_pw_bwd'), ('pointwise fwd/dgrad (k_pw_fwd, k_pw_fwd2)', r'k_pw_fwd'),
         ('conv32 fwd/dgrad (k_conv32_mfma)', r'k_conv32_mfma'), ('conv32 fused backward (k_conv32_bwd33)', r'k_conv32_bwd33'),
         ('conv32 wgrad (k_conv32_wgrad)', r'k_conv32_wgrad'), ('pointwise wgrad (k_pw_wgrad*)', r'k_pw_wgrad'), ('depthwise (k_dw*)', r'k_dw'),
         ('bilinear', r'k_bilinear'), ('LayerNorm', r'k_ln_'), ('softmax-Dice', r'k_dice'), ('elementwise (k_map*, residual, concat)', r'k_map|k_residual|k_concat|k_split'),
@@ -30,6 +31,7 @@ acc['other (pool, im2col, pack, optimizer, ...)'] = other
 b = json.load(open(f'{G}/{tag}_bench.json'))
 bf = json.load(open(f'{G}/{tag}_bench_fullloss.json'))
 b32 = json.load(open(f'{G}/{tag}_bench_fp32.json'))
+br = json.load(open(f'{G}/{tag}_bench_reg.json')) if os.path.exists(f'{G}/{tag}_bench_reg.json') else None
 pm = {}
 for kind in ('fetch', 'write'):
     d = collections.defaultdict(list)
@@ -39,7 +41,8 @@ for kind in ('fetch', 'write'):
 L = []
 L.append(f'# {tag}: MI355X, bf16, bs=8 1x800x1100\n')
 L.append(f'Un-profiled bench lines: `profiles/{tag}_bench.json` ({b["value"]} B-scans/s, {b["ms_per_step"]} ms/step, `--los=di`); '
-         f'`--los=di+reg+fpl`: {bf["value"]} B-scans/s, {bf["ms_per_step"]} ms/step; fp32 parity mode: {b32["value"]} B-scans/s; '
+         + (f'`--los=di+reg` (BASELINE configs[2]): {br["value"]} B-scans/s, {br["ms_per_step"]} ms/step (`profiles/{tag}_bench_reg.json`); ' if br else '') +
+         f'`--los=di+reg+fpl` (configs[3]): {bf["value"]} B-scans/s, {bf["ms_per_step"]} ms/step; fp32 parity mode: {b32["value"]} B-scans/s; '
          f'inference (`tools/infer_bench.py`): `profiles/{tag}_infer.txt`.\n')
 L.append(f'## whole step — `TCCT_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline`')
 L.append('(traced on ONE stream so that kernel durations add up; the bench lines above run the CNN / ViT encoders and the weight gradients on side streams, which hides ~2.5 ms of this sum)')
@@ -54,10 +57,10 @@ for r in sorted(step, key=lambda r: -float(r['TotalDurationNs']))[:28]:
 L.append(f'\n## roofline kernels alone — `rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-only` and, in separate passes, `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`\n')
 L.append('HBM bytes = 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE, counters in KiB, per launch.\n')
 L.append('| kernel | calls | avg us (rocprof) | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM MB / launch | algorithmic MB | ratio |\n|---|---|---|---|---|---|---|---|')
-alg = {'k_conv32_mfma': 904.3968, 'k_conv32_wgrad': 904.3968, 'k_bn_bwd_reduce': 904.3968, 'k_pw_fwd': 452.1984, 'k_pw_fwd2': 452.1984, 'k_pw_bwd': 678.2976}
+alg = {'k_conv32_mfma': 904.3968, 'k_conv32_wgrad33_roll': 904.3968, 'k_conv32_wgrad': 904.3968, 'k_bn_bwd_reduce': 904.3968, 'k_pw_fwd': 452.1984, 'k_pw_fwd2': 452.1984, 'k_pw_bwd': 678.2976}
 for r in roof:
     for key, a in alg.items():
-        if key + '<' in r['Name']:
+        if key + '<' in r['Name'] or key + '(' in r['Name']:
             f = pm['fetch'].get(r['Name']); w = pm['write'].get(r['Name'])
             hbm = (2 * f + w) * 1024 / 1e6
             L.append(f'| `{r["Name"].split("(")[0]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e3:.1f} | {f:.1f} | {w:.1f} | {hbm:.1f} | {a:.1f} | {hbm / a:.2f} |')
@@ -79,7 +82,7 @@ if mf:
              '(which assumes 2.4 GHz). These kernels are HBM-bound (SURVEY 8(d)): the matrix pipes idle most of the time by construction; the wave-cycle split shows where waves wait.\n')
     L.append('| kernel | MFMA busy cycles | GUI active cycles | MFMA busy % | wave cycles: waiting (s_waitcnt/barrier) % | issue-stalled % | issuing % |\n|---|---|---|---|---|---|---|')
     for r in roof:
-        if any(key + '<' in r['Name'] for key in alg):
+        if any(key + '<' in r['Name'] or key + '(' in r['Name'] for key in alg):
             m = mf.get(r['Name'])
             if not m:
                 continue
