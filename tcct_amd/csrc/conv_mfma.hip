@@ -912,6 +912,187 @@ k_conv32_wgrad33_roll(const bf16* __restrict__ x, const bf16* __restrict__ dy, f
     if (dbias && tid < 32) atomicAdd(&dbias[tid], red[tid] + red[32 + tid]);
 }
 
+// ------------------------------------------------------------------------------------------------ 1 x K / K x 1 weight gradient, shifted lines (round 4)
+// The generic kernel reads one x fragment per TAP and 16-pixel chunk: 13 taps = 1088 transposing reads per 8 x 64 tile and block, and the time of
+// the 13-tap calls scales with exactly that (0.36 ms at level 0 against 0.22 for nine taps): the LDS array, not HBM, is the limit.  Along a line
+// (a tile row for 1 x K, a tile column for K x 1; the staging puts either into consecutive LDS pixels) the x operand of tap t is the operand of
+// tap 0 moved by t pixels, so all K operands of a chunk are windows of the SAME 32 pixels: two fragments (the second is the next chunk's first).
+// A lane holds 8 consecutive pixels of one channel; its window of tap t is pixels [t, t + 8) of three octets -- its own, the one behind it (the other
+// lane half's: one v_permlane32_swap + select per register) and the next fragment's -- cut out with v_alignbit_b32 (odd t) or by register choice
+// (even t).  Per line: 5 x fragments + 4 dy fragments instead of 4 x (K + 1).  Taps are split over two wave groups (7 + 6 accumulators for K = 13),
+// lines over the two waves of a group: 36 fragments = 72 transposing reads per wave and tile (288 per block instead of 1088), the matrix pipes see the same MFMAs.
+// Results are bit-compatible with the generic kernel up to the order of the fp32 sums.
+template <int S>
+__device__ __forceinline__ bf16x8 line_window(const u32x4& o0, const u32x4& o1, const u32x4& o2) {
+    static_assert(S >= 0 && S <= 15, "window offset");
+    const uint32_t E[12] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3], o2[0], o2[1], o2[2], o2[3]};
+    constexpr int b = S / 2;
+    u32x4 rr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rr[i] = (S & 1) ? __builtin_amdgcn_alignbit(E[b + i + 1], E[b + i], 16) : E[b + i];
+    return __builtin_bit_cast(bf16x8, rr);
+}
+__device__ __forceinline__ u32x4 tr_load8u(const unsigned char* p) { return __builtin_bit_cast(u32x4, tr_load8p(p)); }
+
+template <int K, int T0, int NT>        // taps T0 .. T0 + NT - 1 of lines 4 lg .. 4 lg + 3
+__device__ __forceinline__ void line_phase(f32x16 (&acc)[(K + 1) / 2], float& bsum, const unsigned char* xl0, const unsigned char* dl0, int hh) {
+    constexpr int LL = 64 + K - 1;
+    u32x4 X0 = tr_load8u(xl0), X1 = tr_load8u(xl0 + 16 * 64), D = tr_load8u(dl0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int li = s >> 2, c = s & 3;
+        const unsigned char* xl = xl0 + li * LL * 64;
+        const unsigned char* dl = dl0 + li * 64 * 64;
+        u32x4 Xa, Xb, Dn;               // next step's fragments, requested before this step's MFMAs
+        if (c < 3) { Xa = tr_load8u(xl + (16 * c + 32) * 64); Dn = tr_load8u(dl + (16 * c + 16) * 64); }
+        else if (li < 3) { Xa = tr_load8u(xl + LL * 64); Xb = tr_load8u(xl + LL * 64 + 16 * 64); Dn = tr_load8u(dl + 64 * 64); }
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 o1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t a_ = X0[d], b_ = X1[d];
+            const auto sw = __builtin_amdgcn_permlane32_swap(a_, b_, false, false);
+            const uint32_t s0 = sw[0], s1 = sw[1];          // (scalars first: hipcc 7.2 turns an indexed element of the pair inside a cast into element 0)
+            o1[d] = hh ? s0 : s1;
+        }
+        const bf16x8 Df = __builtin_bit_cast(bf16x8, D);
+        if (T0 == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bsum = dot2_ones(Df, j, bsum);
+        }
+        // (a lambda with a template parameter would do; spelled out so that every window offset is a literal)
+#define LINE_MMA(T) if (T < NT) acc[T < NT ? T : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Df, line_window<(T < NT ? T0 + T : 0)>(X0, o1, X1), acc[T < NT ? T : 0], 0, 0, 0)
+        LINE_MMA(0); LINE_MMA(1); LINE_MMA(2); LINE_MMA(3); LINE_MMA(4); LINE_MMA(5); LINE_MMA(6);
+#undef LINE_MMA
+        __builtin_amdgcn_sched_barrier(0);
+        if (c < 3) { X0 = X1; X1 = Xa; D = Dn; }
+        else if (li < 3) { X0 = Xa; X1 = Xb; D = Dn; }
+    }
+}
+
+#define WL_XL 10                // x staging slots per thread: 8 lines x (64 + K - 1 <= 76) pixels x 4 quarters / 256
+template <int K, bool VERT>
+__global__ void __launch_bounds__(MB, 2)
+k_conv32_wgrad_line(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
+                    int N, int H, int W, int tilesH, int tilesW, int ntiles) {
+    constexpr int TPW = (K + 1) / 2, LL = 64 + K - 1, P = K / 2;
+    constexpr int TH = VERT ? 64 : 8, TW = VERT ? 8 : 64;
+    constexpr int LH = VERT ? LL : 8, LW = VERT ? 8 : LL, NPX = 8 * LL;
+    static_assert(TPW <= 7 && NPX * 4 <= WL_XL * MB, "line kernel: K <= 13");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;
+    unsigned char* sD = smem + (NPX + 16) * 64;          // the last line's fifth fragment reads up to 80 - LL pixels past its end (never multiplied: no window reaches them)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int tg = wave >> 1, lg = wave & 1;
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    float bsum = 0.f;
+    const unsigned char* xl0 = tr_lane_base(sX, lane) + lg * 4 * LL * 64;
+    const unsigned char* dl0 = tr_lane_base(sD, lane) + lg * 4 * 64 * 64;
+    const int c = tid & 3;
+    // halo pixel of staging slot j in GLOBAL order (consecutive slots = consecutive pixels of an image row): (lr, lc); its LDS pixel = line * LL + position
+    auto slot_rc = [&](int j, uint32_t& lr, uint32_t& lc) {
+        uint32_t pl = (uint32_t)(tid >> 2) + (uint32_t)(j * (MB / 4));
+        asm volatile("" : "+v"(pl));
+        lr = pl / (uint32_t)LW;
+        lc = pl - lr * (uint32_t)LW;
+        return pl < (uint32_t)NPX;
+    };
+    const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
+    u32x4 prex[WL_XL], pred[8];
+    auto prefetch = [&](int tile) {
+        const int tw = tile & 1023, th = (tile >> 10) & 1023, n = tile >> 20;
+        const int h0 = th * TH, w0 = tw * TW;
+        const int hb = h0 - (VERT ? P : 0), wb = w0 - (VERT ? 0 : P);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)n * H * W * 32), 0, img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)n * H * W * 32), 0, img_bytes, 0x00020000);
+        if (hb >= 0 && wb >= 0 && hb + LH <= H && wb + LW <= W) {       // interior tile
+            const uint32_t xbase = (uint32_t)((hb * W + wb) * 64 + c * 16);
+#pragma unroll
+            for (int j = 0; j < WL_XL; ++j) {
+                uint32_t lr, lc;
+                const bool in = slot_rc(j, lr, lc);
+                prex[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, in ? xbase + (lr * (uint32_t)W + lc) * 64u : OOB_OFF, 0, 0);
+            }
+            const uint32_t dbase = (uint32_t)((h0 * W + w0) * 64 + c * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t pl = (uint32_t)((tid >> 2) + j * (MB / 4));
+                pred[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, dbase + ((pl / TW) * (uint32_t)W + (pl & (TW - 1))) * 64u, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WL_XL; ++j) {
+                uint32_t lr, lc;
+                const bool in = slot_rc(j, lr, lc);
+                const int hi = hb + (int)lr, wi_ = wb + (int)lc;
+                const bool ok = in && (unsigned)hi < (unsigned)H && (unsigned)wi_ < (unsigned)W;
+                prex[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (uint32_t)((hi * W + wi_) * 64 + c * 16) : OOB_OFF, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pl = (tid >> 2) + j * (MB / 4);
+                const int ho = h0 + pl / TW, wo = w0 + (pl & (TW - 1));
+                pred[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, (ho < H && wo < W) ? (uint32_t)((ho * W + wo) * 64 + c * 16) : OOB_OFF, 0, 0);
+            }
+        }
+    };
+    const TileSeq<VERT> seq(ntiles, tilesH, tilesW);
+    int tile = seq.at(0), tile1 = -1;
+    if (tile >= 0) prefetch(tile);
+    for (int kt = 0; tile >= 0; tile = tile1, ++kt) {
+        tile1 = seq.at(kt + 1);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < WL_XL; ++j) {
+            uint32_t lr, lc;
+            if (slot_rc(j, lr, lc)) *reinterpret_cast<u32x4*>(sX + (VERT ? lc * LL + lr : lr * LL + lc) * 64 + c * 16) = prex[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pl = (tid >> 2) + j * (MB / 4);
+            const int p = VERT ? (pl & (TW - 1)) * TH + pl / TW : pl;
+            *reinterpret_cast<u32x4*>(sD + p * 64 + c * 16) = pred[j];
+        }
+        __syncthreads();
+        if (tile1 >= 0) prefetch(tile1);
+        if (tg == 0) line_phase<K, 0, TPW>(acc, bsum, xl0, dl0, hh);
+        else line_phase<K, TPW, K - TPW>(acc, bsum, xl0, dl0, hh);
+    }
+    // the two line-group waves of a tap group hold partial sums of the same taps: they take turns in LDS (as in k_conv32_wgrad)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    for (int turn = 0; turn < 2; ++turn) {
+        if (lg == turn) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int tap = tg * TPW + t;
+                if (tap < K) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
+                        float* dst = &red[tap * 1024 + co * 32 + r];
+                        *dst = turn == 0 ? acc[t][k] : *dst + acc[t][k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < K * 1024; i += MB) {
+        const int tap = i % K, cc = i / K;          // cc = co*32 + ci: OIHW-linear order
+        atomicAdd(&dw[(int64_t)cc * K + tap], red[tap * 1024 + cc]);
+    }
+    if (dbias && tg == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lane < 32) atomicAdd(&dbias[r], bsum);
+    }
+}
+
 static int g_wgrad_mode = -1;
 /* 0 (default): plain 3x3 convolutions take the rolling-row kernel; 1: the generic register-staged kernel for every shape (the comparison arm of the
  * bit-compatibility test; TCCT_WGRAD_GENERIC=1 selects it for a whole run).  Returns the previous mode; mode < 0 only queries. */
@@ -968,6 +1149,22 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
         if (!attr4) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad33_roll, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr4 = true; }
         hipLaunchKernelGGL(k_conv32_wgrad33_roll, dim3((unsigned)(nt < 512 ? nt : 512)), dim3(WR_T), lds4, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W,
                            tilesH, tilesW, (int)nt);
+        TCCT_LAUNCH_OK();
+    }
+    static const bool line_on = [] { const char* e_ = getenv("TCCT_WGRAD_LINE"); return !(e_ && e_[0] == '0'); }();      // TCCT_WGRAD_LINE=0: A/B arm
+    if (line_on && g_wgrad_mode == 0 && (KH == 1 || KW == 1) && (TAPS == 13 || TAPS == 11 || TAPS == 9) && xs == 32 && ds == 32 && ldi == 32 && o_off == 0 && i_off == 0 &&
+        xo == 0 && dof == 0) {      // 1 x K / K x 1 at levels 0-2: shifted lines
+#define WL_LAUNCH(KK, V)                                                                                                     \
+    do {                                                                                                                    \
+        static bool attr = false;                                                                                           \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad_line<KK, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+        hipLaunchKernelGGL((k_conv32_wgrad_line<KK, V>), dim3(grid), dim3(MB), (size_t)(8 * (64 + KK - 1) + 16) * 64 + 512 * 64, st, (const bf16*)x, (const bf16*)dy, \
+                           dw, dbias, N, H, W, tilesH, tilesW, (int)nt);                                                    \
+    } while (0)
+        if (TAPS == 13) { if (vert) WL_LAUNCH(13, true); else WL_LAUNCH(13, false); }
+        else if (TAPS == 11) { if (vert) WL_LAUNCH(11, true); else WL_LAUNCH(11, false); }
+        else { if (vert) WL_LAUNCH(9, true); else WL_LAUNCH(9, false); }
+#undef WL_LAUNCH
         TCCT_LAUNCH_OK();
     }
     // taps are split over TG wave groups so that <= 5 accumulators (80 VGPRs) live next to the prefetch registers: no spills

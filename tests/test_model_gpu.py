@@ -539,6 +539,37 @@ def test_real_checkpoint_inference_matches_reference(name, dtype):
     assert len(np.unique(masks[0])) >= 4            # a real multi-layer segmentation, not a constant map
 
 
+@pytest.mark.parametrize('name', ['duke', 'goals_legacy'])
+def test_fused_inference_epilogues_keep_the_masks_of_trained_weights(name):
+    """Floor on what the inference-time epilogue fusion (BatchNorm + activation folded into the convolution kernels, ops.INFER_FUSE) may
+    change: on the reference's REAL trained weights the bf16 argmax masks of the fused and of the op-by-op eval forward agree on
+    >= 99.9 % of the pixels, and each agrees with the reference's fp32 masks as well as the other does (+- 0.1 %).  (On random-init
+    weights, whose logits are near ties everywhere, the same comparison ranges 98.5-100 % between runs: tools/infer_bench.py prints it,
+    nothing is asserted there.)"""
+    import numpy as np
+    from tcct_amd import checkpoint as C, ops
+    path = os.path.join(os.path.dirname(__file__), 'golden', f'ckpt_{name}.npz')
+    z = np.load(path)
+    x = torch.from_numpy(z['input_u8']).permute(2, 0, 1)[None].float().div(255).cuda()
+    x = torch.cat([x, x.flip(3)], 0)                # a second, mirrored B-scan: 2 x 160 x 160
+    masks = {}
+    old = ops.INFER_FUSE
+    try:
+        for fuse in (True, False):
+            ops.INFER_FUSE = fuse
+            net = C.model_from_checkpoint(path, compute_dtype=torch.bfloat16)
+            with torch.no_grad():
+                outs = net(x)
+            masks[fuse] = np.stack([o.float().softmax(1).argmax(1).cpu().numpy() for o in outs])
+    finally:
+        ops.INFER_FUSE = old
+    agree = (masks[True] == masks[False]).mean(axis=(1, 2, 3))
+    ref = [(masks[f][:, 0] == z['masks']).mean() for f in (True, False)]
+    print(name, 'fused vs op-by-op bf16 masks', agree, 'vs reference fp32 masks: fused', ref[0], 'op-by-op', ref[1])
+    assert agree.min() >= 0.999, agree
+    assert abs(ref[0] - ref[1]) <= 1e-3 and min(ref) > 0.998, ref
+
+
 def test_onnx_export_of_the_gpu_model_equals_its_hip_eval_forward(tmp_path):
     """reference task1/onnx/onnx_save.py:4-15: the model object that lives on the GPU is exported, the file evaluated by the test-side ONNX
     reader (tests/onnx_mini_runtime.py, torch CPU) -- equal to the HIP eval forward of the same model on a non-square batch"""
