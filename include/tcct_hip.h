@@ -325,6 +325,12 @@ int tcct_tail_compose3(const float* w1, const float* b1, const float* w2, const 
 int tcct_tail_compose3_bwd(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, int C, const float* dwa, const float* dwb,
                            const float* dccc, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, tcct_stream_t stream);
 int tcct_pw_fwd_cat2_f32(const void* x1, const void* x2, int K1, const float* w, const float* bias, float* y, int64_t M, int K, int N, tcct_stream_t stream);
+/* Levels 1-3, same idea (nets/tcct.py:1036-1044): when nothing but aux_i reads g_i = t32x(x_i + y_i), logits_i = (Wa Wt) s_i + (Wa bt + ba) is ONE
+ * 32 -> C pointwise convolution on s_i (tcct_pw_fwd with the composed weight); head_compose: wh [C][32], ch [C] from wt [32][32], bt [32] (t32x) and
+ * wa [C][32], ba [C] (aux_i), C <= 16; head_compose_bwd: the four gradients from dwh, dch (outputs overwritten). */
+int tcct_head_compose(const float* wt, const float* bt, const float* wa, const float* ba, int C, float* wh, float* ch, tcct_stream_t stream);
+int tcct_head_compose_bwd(const float* wt, const float* bt, const float* wa, int C, const float* dwh, const float* dch, float* dwt, float* dbt,
+                          float* dwa, float* dba, tcct_stream_t stream);
 int tcct_pw_wgrad_cat2(const void* x1, const void* x2, int K1, const void* dy, float* dw, float* dbias, int64_t M, int K, int N,
                        tcct_stream_t stream);
 /* pw_fwd + fused train-mode BatchNorm statistics of the consumer (bf16 output, N in {32,64,96,128}); stats fp64 [2N], zero on entry */
@@ -391,6 +397,13 @@ int tcct_metapool_bwd(const void* dy, void* dx, int B, int64_t N, int C, int dty
 int tcct_metapool_residual_fwd(const void* x, const void* res, const float* scale, void* y, int B, int64_t N, int C, int dtype,
                                tcct_stream_t stream);
 int tcct_metapool_scaled_bwd(const void* dy, const float* scale, void* dx, int B, int64_t N, int C, int dtype, tcct_stream_t stream);
+/* ... and with the LayerNorm in front of the mixer folded in (csrc/ln_pool.hip; nets/tcct.py:457-465): y = t + scale[b] * (pool(a) - a), a = LN(t; gamma, beta,
+ * eps) rounded to the activation type, in ONE pass (read t, write y); backward dt = dy + LN^T(scale[b] * (pool^T(dy) - dy)) in one pass (read dy, read t,
+ * write dt).  C a multiple of 8 in 16..128; mean_rstd fp32 [B*N*2] written by fwd and read by bwd; dgamma / dbeta fp32 [C] overwritten. */
+int tcct_ln_metapool_residual_fwd(const void* t, void* y, int B, int64_t N, int C, const float* gamma, const float* beta, float eps, const float* scale,
+                                  float* mean_rstd, int dtype, tcct_stream_t stream);
+int tcct_ln_metapool_residual_bwd(const void* t, const void* dy, void* dt, int B, int64_t N, int C, const float* gamma, const float* scale,
+                                  const float* mean_rstd, float* dgamma, float* dbeta, int dtype, tcct_stream_t stream);
 /* ---- nn.MaxPool2d(2) (nets/tcct.py:867,883); even H, W ---------------------------------------------------- */
 int tcct_maxpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, tcct_stream_t stream);
 int tcct_maxpool2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int dtype, tcct_stream_t stream);

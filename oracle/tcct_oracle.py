@@ -294,16 +294,25 @@ def ftc_forward(sd, x, train=True, dp_masks=None, p='base', want=None, feats_use
     else:
         d0 = _up_block(sd, p + '.dec4', d1, f[0], train)
         g0 = _conv(sd, p + '.t324', _S(f[0] + d0))
-    g1 = _conv(sd, p + '.t323', _S(f[1] + d1))
-    g2 = _conv(sd, p + '.t322', _S(f[2] + d2))
-    g3 = _conv(sd, p + '.t321', _S(f[3] + d3))
+    s1, s2, s3 = _S(f[1] + d1), _S(f[2] + d2), _S(f[3] + d3)
+    g1 = _conv(sd, p + '.t323', s1)
+    g2 = _conv(sd, p + '.t322', s2)
+    g3 = _conv(sd, p + '.t321', s3)
     feats = norm_add([g0, g1, g2])
     size = x.shape[-2:]
     # the four heads write fp32 logits in every mode (loss-side precision): bf16 GEMM weights, no store rounding
     outs = [y0_direct if y0_direct is not None else _conv(sd, p + '.aux0', g0, store=False)]
-    for name, g in (('aux1', g1), ('aux2', g2), ('aux4', g3)):
-        outs.append(F.interpolate(_conv(sd, f'{p}.{name}', g, store=False), size=size, mode='bilinear',
-                                  align_corners=False))
+    through = train and MODE.store is not _same and not feats_used and sd[p + '.aux1.weight'].shape[0] <= 8
+    for name, tname, g, s_ in (('aux1', 't323', g1, s1), ('aux2', 't322', g2, s2), ('aux4', 't321', g3, s3)):
+        if through:
+            # rounding-point model of the training path, round 4: with the feature-polarization loss off nothing but aux_i reads g_i, and the HIP path
+            # evaluates aux_i(t32x(s_i)) as ONE GEMM whose composed weight Wa Wt is rounded once (tcct_amd/csrc/decoder_tail.hip, head_compose)
+            wt, bt = sd[f'{p}.{tname}.weight'][:, :, 0, 0], sd[f'{p}.{tname}.bias']
+            wa, ba = sd[f'{p}.{name}.weight'][:, :, 0, 0], sd[f'{p}.{name}.bias']
+            lg = F.conv2d(s_, _W(wa @ wt)[:, :, None, None], wa @ bt + ba)
+        else:
+            lg = _conv(sd, f'{p}.{name}', g, store=False)
+        outs.append(F.interpolate(lg, size=size, mode='bilinear', align_corners=False))
     if want is not None:
         want.update(c1=c[0], c3=c[2], c5=c[4], v2=v[0], v5=v[3], f4=f[4], y8=y8, d0=d0, g0=g0, g2=g2)
     return outs, feats

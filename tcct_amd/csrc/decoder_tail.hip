@@ -187,3 +187,70 @@ extern "C" int tcct_tail_compose3_bwd(const float* w1, const float* b1, const fl
     hipLaunchKernelGGL(k_tail_compose3_bwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, C, dwa, dwb, dccc, dw1, db1, dw2, db2, dw3, db3);
     TCCT_LAUNCH_OK();
 }
+
+// ------------------------------------------------------------------------------------------------ levels 1-3: aux head composed through t32x
+// Reference nets/tcct.py:1036-1044: g_i = t32x(x_i + y_i), logits_i = aux_i(g_i).  When the feature-polarization loss is off nothing but aux_i reads
+// g_i, and both are 1x1 convolutions: logits_i = (Wa Wt) s_i + (Wa bt + ba) -- one 32 -> C GEMM on s_i with the composed weight; g_i and its gradient
+// (113 MB each at level 1 of the bench shape) are never written.  Gradients: dWt = Wa^T dWh, dWa = dWh Wt^T + dch bt^T, dbt = Wa^T dch, dba = dch.
+__global__ void k_head_compose(const float* __restrict__ wt, const float* __restrict__ bt, const float* __restrict__ wa, const float* __restrict__ ba,
+                               int C, float* __restrict__ wh /*[C][32]*/, float* __restrict__ ch /*[C]*/) {
+    __shared__ float st[32][33], sa[16][33];
+    const int t = threadIdx.x, i = t >> 5, j = t & 31;
+    st[i][j] = wt[t];
+    if (i < C) sa[i][j] = wa[i * 32 + j];
+    __syncthreads();
+    if (i < C) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) a += sa[i][k] * st[k][j];
+        wh[i * 32 + j] = a;
+    }
+    if (t < C) {
+        float v = ba[t];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v += sa[t][k] * bt[k];
+        ch[t] = v;
+    }
+}
+/* wh fp32 [C][32] = Wa Wt, ch [C] = Wa bt + ba (wt [32][32], bt [32] = the t32x convolution; wa [C][32], ba [C] = the aux head; C <= 16) */
+extern "C" int tcct_head_compose(const float* wt, const float* bt, const float* wa, const float* ba, int C, float* wh, float* ch, tcct_stream_t stream) {
+    TCCT_CHECK(wt && bt && wa && ba && wh && ch, "head_compose: NULL argument");
+    TCCT_CHECK(C >= 1 && C <= 16, "head_compose: C=%d unsupported (1..16)", C);
+    hipLaunchKernelGGL(k_head_compose, dim3(1), dim3(1024), 0, (hipStream_t)stream, wt, bt, wa, ba, C, wh, ch);
+    TCCT_LAUNCH_OK();
+}
+
+__global__ void k_head_compose_bwd(const float* __restrict__ wt, const float* __restrict__ bt, const float* __restrict__ wa, int C,
+                                   const float* __restrict__ dwh /*[C][32]*/, const float* __restrict__ dch /*[C]*/, float* __restrict__ dwt,
+                                   float* __restrict__ dbt, float* __restrict__ dwa, float* __restrict__ dba) {
+    __shared__ float st[32][33], sa[16][33], sg[16][33], sc[16], sb[32];
+    const int t = threadIdx.x, i = t >> 5, j = t & 31;
+    st[i][j] = wt[t];
+    if (i < C) { sa[i][j] = wa[i * 32 + j]; sg[i][j] = dwh[i * 32 + j]; }
+    if (t < C) sc[t] = dch[t];
+    if (t < 32) sb[t] = bt[t];
+    __syncthreads();
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += sa[c][i] * sg[c][j];            // (Wa^T dWh)[i][j]
+    dwt[t] = a;
+    if (i < C) {
+        float b = sc[i] * sb[j];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) b += sg[i][k] * st[j][k];       // (dWh Wt^T)[i][j] = sum_k dWh[i][k] Wt[j][k]
+        dwa[i * 32 + j] = b;
+    }
+    if (t < 32) {
+        float v = 0.f;
+        for (int c = 0; c < C; ++c) v += sa[c][t] * sc[c];
+        dbt[t] = v;
+    }
+    if (t < C) dba[t] = sc[t];
+}
+/* the four gradients from those of the composed pair (all outputs overwritten) */
+extern "C" int tcct_head_compose_bwd(const float* wt, const float* bt, const float* wa, int C, const float* dwh, const float* dch, float* dwt, float* dbt,
+                                     float* dwa, float* dba, tcct_stream_t stream) {
+    TCCT_CHECK(wt && bt && wa && dwh && dch && dwt && dbt && dwa && dba, "head_compose_bwd: NULL argument");
+    TCCT_CHECK(C >= 1 && C <= 16, "head_compose_bwd: C=%d unsupported (1..16)", C);
+    hipLaunchKernelGGL(k_head_compose_bwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, wt, bt, wa, C, dwh, dch, dwt, dbt, dwa, dba);
+    TCCT_LAUNCH_OK();
+}

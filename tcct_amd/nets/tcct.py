@@ -313,12 +313,16 @@ class MHCABlock(nn.Module):
         t = x.view(B, H * W, C)
         s1, s2 = scales if scales is not None else (None, None)
         # (the residual paths read aliases of t: their gradients are added inside the LayerNorm backward kernels)
-        cur, t = ops.layernorm_fork(t, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         att = getattr(self, 'att', None)
-        if att is not None:     # t + dp(proj(factor_att(LN1 t))): the projection GEMM carries the DropPath scale and the residual
-            t = ops.linear_residual(att.mix(cur, (H, W)), att.proj.weight, att.proj.bias, t, s1)
+        if att is None and ops.ln_metapool_residual_ok(t, self.norm1.weight, self.norm1.bias):
+            # t + dp(pool(LN1 t)): LayerNorm, mixer, DropPath scale and residual in ONE pass each way (the normalised tensor is never written)
+            t = ops.ln_metapool_residual(t, self.norm1.weight, self.norm1.bias, self.norm1.eps, s1)
         else:
-            t = ops.metapool_residual(cur, t, s1)       # t + dp(pool(LN1 t)): mixer, DropPath scale and residual in one pass
+            cur, t = ops.layernorm_fork(t, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            if att is not None:     # t + dp(proj(factor_att(LN1 t))): the projection GEMM carries the DropPath scale and the residual
+                t = ops.linear_residual(att.mix(cur, (H, W)), att.proj.weight, att.proj.bias, t, s1)
+            else:
+                t = ops.metapool_residual(cur, t, s1)       # t + dp(pool(LN1 t)): mixer, DropPath scale and residual in one pass
         cur, t = ops.layernorm_fork(t, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
             y1 = ops.conv2d(cur, self.mlp.fc1.weight, self.mlp.fc1.bias)
@@ -580,8 +584,8 @@ class FTC(nn.Module):
                 raise TcctError('the legacy-head layout (onnx/tcct_goals.py) is supported for inference and Dice/boundary training; its '
                                 'six-tensor `feats` (tcct_goals.py:1021) is not built')
             g0, g1, g2, size = self._feats_src
-            if callable(g0):            # the step composed the decoder tail through aux0 and never wrote g0: rebuild it (no gradient)
-                g0 = g0()
+            # the step composed a head through its t32x convolution and never wrote g_i: rebuild it (no gradient)
+            g0, g1, g2 = [g() if callable(g) else g for g in (g0, g1, g2)]
             self._feats = [_nchw_view(ops.norm_add3(g0, g1, g2))]
             self._feats_src = None
         return self._feats
@@ -652,6 +656,7 @@ class FTC(nn.Module):
             d1 = self.dec3(d2, f[1])
             d0 = self.dec4(d1, f[0])
             g0, g1, g2, g3 = d0, d1, d2, d3
+            lg_direct = [None, None, None]
         else:                       # x_i + y_i comes out of the decoder's last GEMM epilogue together with y_i
             d3, s3 = self.dec1(y8, f[3], with_sum=True)
             d2, s2 = self.dec2(d3, f[2], with_sum=True)
@@ -666,7 +671,16 @@ class FTC(nn.Module):
             if g0 is None:
                 d0, s0 = self.dec4(d1, f[0], with_sum=True, want_plain=False)      # only x_0 + y_0 is read below: d0 is never written
                 g0 = _conv(self.t324, s0)
-            g1, g2, g3 = _conv(self.t323, s1), _conv(self.t322, s2), _conv(self.t321, s3)
+            # levels 1-3: aux_i(t32x(s_i)) as one GEMM with the composed weight when nothing else reads g_i (feature-polarization loss off)
+            mids, lg_direct = [], []
+            for t, aux, s_ in ((self.t323, self.aux1, s1), (self.t322, self.aux2, s2), (self.t321, self.aux4, s3)):
+                if self.training and not self.eager_feats and ops.head_through_t32_ok(s_, t.weight, t.bias, aux.weight, aux.bias):
+                    lg_direct.append(ops.head_through_t32(s_, t.weight, t.bias, aux.weight, aux.bias))
+                    mids.append(lambda t=t, s_=s_: self._rebuild(t, s_))
+                else:
+                    lg_direct.append(None)
+                    mids.append(_conv(t, s_))
+            g1, g2, g3 = mids
         # norm_add([y0,y1,y2]) (reference tcct.py:937-942,1035) -> `self.feats`: evaluated lazily on first access (only the
         # feature-polarization loss reads it; with --udh=false the six level-0 passes are simply never launched)
         self._feats_src = (g0, g1, g2, size)
@@ -681,13 +695,16 @@ class FTC(nn.Module):
         # aux heads: logits are produced and resized in fp32 in every mode (loss-side precision)
         f32 = torch.float32
         y0 = y0_direct if y0_direct is not None else _conv(self.aux0, g0, out_dtype=f32)
+        low = [lg if lg is not None else _conv(m, g, out_dtype=f32) for m, g, lg in zip((self.aux1, self.aux2, self.aux4), (g1, g2, g3), lg_direct)]
         if self.defer_aux_resize and torch.is_grad_enabled():
             # training loop (KiteSeg.calc_loss): the three aux heads stay at their own resolution; the Dice criterion resizes on the fly
-            return [_nchw_view(y0)] + [ops.LowResLogits(_conv(m, g, out_dtype=f32), size) for m, g in ((self.aux1, g1), (self.aux2, g2), (self.aux4, g3))]
-        y1 = ops.bilinear(_conv(self.aux1, g1, out_dtype=f32), size, False)
-        y2 = ops.bilinear(_conv(self.aux2, g2, out_dtype=f32), size, False)
-        y4 = ops.bilinear(_conv(self.aux4, g3, out_dtype=f32), size, False)
-        return [_nchw_view(y0), _nchw_view(y1), _nchw_view(y2), _nchw_view(y4)]
+            return [_nchw_view(y0)] + [ops.LowResLogits(l_, size) for l_ in low]
+        return [_nchw_view(y0)] + [_nchw_view(ops.bilinear(l_, size, False)) for l_ in low]
+
+    @staticmethod
+    def _rebuild(t, s_):
+        with torch.no_grad():
+            return _conv(t, s_)
 
 
 def stc_tt(n_class=8, **args):

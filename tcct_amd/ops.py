@@ -1080,6 +1080,57 @@ def up_skip_conv_t32_from_v(v, skip, w1, b1, w2, b2):
     return g
 
 
+class _HeadThroughT32(torch.autograd.Function):
+    """logits_i = aux_i(t32x(s_i)) (reference nets/tcct.py:1036-1044, levels 1-3) as ONE 32 -> n_class GEMM with fp32 output and the composed weight
+    Wa Wt (csrc/decoder_tail.hip, `head_compose`): for steps in which nothing else reads g_i = t32x(s_i) -- the feature-polarization loss is off.
+    g_i and its gradient never exist; the backward pass runs the aux head's small-N kernels with the composed weight and de-composes the gradients."""
+
+    @staticmethod
+    def forward(ctx, s, wt, bt, wa, ba):
+        _chk(s, wt, bt, wa, ba)
+        N_, H, W_, _ = s.shape
+        dev, nc = s.device, wa.shape[0]
+        wh = torch.empty((nc, 32, 1, 1), device=dev, dtype=torch.float32)
+        ch = torch.empty(nc, device=dev, dtype=torch.float32)
+        lib.head_compose(wt, bt, wa, ba, nc, wh, ch)
+        lg = torch.empty((N_, H, W_, nc), device=dev, dtype=torch.float32)
+        lib.pw_fwd(s, wh, ch, lg, N_ * H * W_, 32, nc, 0, dtype_code(torch.float32))
+        ctx.save_for_backward(s, wh)
+        ctx.params = (wt, bt, wa, ba)
+        return lg
+
+    @staticmethod
+    def backward(ctx, dl):
+        s, wh = ctx.saved_tensors
+        wt, bt, wa, ba = ctx.params
+        N_, H, W_, _ = s.shape
+        nc, dev = wa.shape[0], s.device
+        dl = _as(dl, torch.float32)
+        F32_, BF_ = dtype_code(torch.float32), dtype_code(s.dtype)
+        ds = torch.empty_like(s)
+        lib.conv2d_dgrad(dl, wh, ds, N_, H, W_, 32, nc, 1, 1, 0, 0, F32_, BF_)
+        with _wgrad_stream(_slot_written(*ctx.params), s, dl, wh):
+            dwh, dch = ZERO.get((nc, 32), torch.float32, dev), ZERO.get((nc,), torch.float32, dev)
+            lib.pw_wgrad_smalln(s, dl, dwh, dch, N_ * H * W_, 32, nc, BF_, F32_)
+            outs = [_grad_out(p, tuple(p.shape)) for p in ctx.params]
+            lib.head_compose_bwd(wt, bt, wa, nc, dwh, dch, *outs)
+        return (ds,) + tuple(_ret(o, p) for o, p in zip(outs, ctx.params))
+
+
+HEAD_COMPOSE = os.environ.get('TCCT_HEAD_COMPOSE', '1') != '0'       # =0: t32x and aux_i stay two convolutions at levels 1-3 (A/B timing)
+
+
+def head_through_t32_ok(s, wt, bt, wa, ba):
+    return (HEAD_COMPOSE and s.dtype == torch.bfloat16 and s.dim() == 4 and s.shape[-1] == 32 and s.is_contiguous() and tuple(wt.shape) == (32, 32, 1, 1)
+            and bt is not None and wa.dim() == 4 and tuple(wa.shape[1:]) == (32, 1, 1) and 2 <= wa.shape[0] <= 8 and ba is not None
+            and wt.is_contiguous() and wa.is_contiguous() and s.numel() // 32 < 2 ** 31)
+
+
+def head_through_t32(s, wt, bt, wa, ba):
+    """aux(t32(s)) as fp32 NHWC logits from one GEMM with the composed weight; check head_through_t32_ok first"""
+    return _HeadThroughT32.apply(s, wt, bt, wa, ba)
+
+
 def conv1x1_and_sum(x, w, bias, res):
     """(conv1x1(x), conv1x1(x) + res); bf16 NHWC with channel counts multiples of 32 takes the double-store epilogue"""
     ok = (x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] % 32 == 0 and w.shape[0] % 32 == 0 and w.shape[0] <= 160
@@ -1999,6 +2050,45 @@ class _MetaPoolResidual(torch.autograd.Function):
 def metapool_residual(cur, t, scale=None):
     """t + scale[b] * MetaPool(cur) on tokens [B,N,C] (scale: fp32 [B] or None)"""
     return _MetaPoolResidual.apply(cur, t, scale)
+
+
+class _LnMetaPoolResidual(torch.autograd.Function):
+    """t + scale[b] * (pool(LN(t)) - LN(t)): MHCABlock's first half (reference nets/tcct.py:457-465, MetaPool :405-415) as ONE pass each way
+    (csrc/ln_pool.hip): the normalised tensor and its gradient are never written"""
+
+    @staticmethod
+    def forward(ctx, t, gamma, beta, eps, scale):
+        _chk(t, gamma, beta, scale)
+        B, N, C = t.shape
+        y = torch.empty_like(t)
+        mr = torch.empty(2 * B * N, device=t.device, dtype=torch.float32)
+        lib.ln_metapool_residual_fwd(t, y, B, N, C, gamma, beta, eps, scale, mr, dtype_code(t.dtype))
+        ctx.save_for_backward(t, gamma, mr)
+        ctx.beta_param, ctx.scale = beta, scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        t, gamma, mr = ctx.saved_tensors
+        dy = _as(dy, t.dtype)
+        B, N, C = t.shape
+        dt = torch.empty_like(t)
+        dg, db = _grad_out(gamma), _grad_out(ctx.beta_param)
+        lib.ln_metapool_residual_bwd(t, dy, dt, B, N, C, gamma, ctx.scale, mr, dg, db, dtype_code(t.dtype))
+        return dt, _ret(dg, gamma), _ret(db, ctx.beta_param), None, None
+
+
+LN_POOL_FUSE = os.environ.get('TCCT_LN_POOL', '1') != '0'       # =0: LayerNorm and the token mixer stay separate kernels (A/B timing)
+
+
+def ln_metapool_residual_ok(t, gamma, beta):
+    return (LN_POOL_FUSE and t.dim() == 3 and t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16) and t.shape[-1] % 8 == 0
+            and 16 <= t.shape[-1] <= 128 and t.shape[0] <= 65535 and t.shape[1] < 2 ** 30 and gamma is not None and beta is not None)
+
+
+def ln_metapool_residual(t, gamma, beta, eps=1e-6, scale=None):
+    """t + scale[b] * MetaPool(LayerNorm(t)) on tokens [B,N,C] in one pass (scale: fp32 [B] or None); check ln_metapool_residual_ok first"""
+    return _LnMetaPoolResidual.apply(t, gamma, beta, float(eps), scale)
 
 
 def metapool(x):

@@ -720,6 +720,42 @@ def test_decoder_tail_composed_through_the_aux_head(nhw, nc):
     torch.testing.assert_close(nchw(g0), g.detach(), rtol=3e-2, atol=3e-2)
 
 
+@pytest.mark.parametrize('nhw', [(2, 24, 40), (1, 50, 69), (3, 7, 5)])
+@pytest.mark.parametrize('nc', [5, 8, 2])
+def test_mid_level_aux_head_composed_through_t32(nhw, nc):
+    """csrc/decoder_tail.hip, `head_compose`: logits_i = aux_i(t32x(s_i)) as one 32 -> n_class GEMM with fp32 output and the composed weight Wa Wt --
+    logits and the gradients of s_i and of the four parameter tensors against torch's two convolutions; and bit-for-bit against the separate HIP
+    aux convolution fed the composed weight (the GEMM is the same kernel: only the weight composition is new)"""
+    from tcct_amd import ops
+    N, H, W = nhw
+    dt = torch.bfloat16
+    s = rnd(N, 32, H, W, dt=dt).requires_grad_(True)
+    wt = (rnd(32, 32, 1, 1, seed=2) / 32 ** 0.5).requires_grad_(True)
+    bt = (rnd(32, seed=3) * 0.2).requires_grad_(True)
+    wa = (rnd(nc, 32, 1, 1, seed=7) / 32 ** 0.5).requires_grad_(True)
+    ba = (rnd(nc, seed=8) * 0.2).requires_grad_(True)
+    lg = F.conv2d(F.conv2d(s, wt, bt), wa, ba)
+    gl = rnd(*lg.shape, seed=6)
+    lg.backward(gl)
+    sd_ = nhwc(s.detach(), dt).requires_grad_(True)
+    ps = [t.detach().cuda().requires_grad_(True) for t in (wt, bt, wa, ba)]
+    assert ops.head_through_t32_ok(sd_, *ps)
+    ld = ops.head_through_t32(sd_, *ps)
+    assert ld.dtype == torch.float32 and tuple(ld.shape) == (N, H, W, nc)
+    torch.testing.assert_close(nchw(ld), lg.detach(), rtol=2e-2, atol=2e-2)
+    ld.backward(nhwc(gl, torch.float32))
+    torch.testing.assert_close(nchw(sd_.grad), s.grad, rtol=3e-2, atol=3e-2 * max(1.0, s.grad.abs().max().item()))
+    for got, ref, nm in zip(ps, (wt, bt, wa, ba), ('wt', 'bt', 'wa', 'ba')):
+        e = (got.grad.cpu() - ref.grad).norm().item() / ref.grad.norm().item()
+        assert e < 1.5e-2, (nm, e)
+    wh = (wa.detach()[:, :, 0, 0].double() @ wt.detach()[:, :, 0, 0].double()).float()
+    ch = (wa.detach()[:, :, 0, 0].double() @ bt.detach().double() + ba.detach().double()).float()
+    ref2 = ops.conv2d(sd_.detach(), wh[:, :, None, None].contiguous().cuda(), ch.cuda(), out_dtype=torch.float32)
+    assert (ref2 - ld.detach()).abs().max().item() <= 2e-2            # the device composition sums in fp32, this one in fp64: a weight may round the other way
+    agree = (ref2 == ld.detach()).float().mean().item()
+    assert agree > 0.5, agree
+
+
 @pytest.mark.parametrize('cfg', [(2, 32, 48, 5), (1, 64, 96, 9), (2, 16, 80, 5)])
 def test_fpl_gradient_looked_up_inside_norm_add_backward(cfg):
     """round 4: with the feature-polarization loss as the only differentiable consumer of `feats`, its gradient is handed to norm_add's backward as a
@@ -1202,6 +1238,45 @@ def test_metapool_with_residual(dt, scaled):
     yd.backward(gy.to('cuda', dt))
     torch.testing.assert_close(cd.grad.float().cpu(), cur.grad, **tl)
     torch.testing.assert_close(td.grad.float().cpu(), t.grad, **tl)
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('cfg', [(3, 61, 64, True), (2, 200, 96, False), (2, 33, 128, True), (1, 1, 16, False), (2, 2, 64, True), (1, 97, 24, False)])
+def test_layernorm_token_mixer_residual_in_one_pass(dt, cfg):
+    """csrc/ln_pool.hip: t + s[b] * (pool(LN(t)) - LN(t)) (reference nets/tcct.py:457-465 with MetaPool :405-415) as one pass each way -- output and the
+    gradients of t, gamma, beta against torch; strips that end inside the image, images shorter than a strip, channel counts that leave lanes of a group idle
+    (96 on 16 lanes, 24 on 8); and, in bf16, against the two-kernel path it replaces (same rounding points: nearly every element bit-identical)"""
+    from tcct_amd import ops
+    B, Nt, C, scaled = cfg
+    t = rnd(B, Nt, C, dt=dt).requires_grad_(True)
+    gamma = (1.0 + 0.3 * rnd(C, seed=1)).requires_grad_(True)
+    beta = (0.2 * rnd(C, seed=2)).requires_grad_(True)
+    sc = torch.tensor([0.0, 1.25, 1.25][:B]) if scaled else None
+    a = F.layer_norm(t, (C,), gamma, beta, 1e-6)
+    pooled = F.avg_pool2d(a[:, None], 3, 1, 1, count_include_pad=False)[:, 0] - a
+    y = t + (pooled * sc.view(B, 1, 1) if scaled else pooled)
+    gy = rnd(*y.shape, seed=3, dt=dt)
+    y.backward(gy)
+    td = t.detach().to('cuda', dt).requires_grad_(True)
+    gd, bd = gamma.detach().cuda().requires_grad_(True), beta.detach().cuda().requires_grad_(True)
+    scd = sc.cuda() if scaled else None
+    assert ops.ln_metapool_residual_ok(td, gd, bd)
+    yd = ops.ln_metapool_residual(td, gd, bd, 1e-6, scd)
+    tl = tol(dt)
+    torch.testing.assert_close(yd.float().cpu(), y.detach(), **tl)
+    yd.backward(gy.to('cuda', dt))
+    torch.testing.assert_close(td.grad.float().cpu(), t.grad, rtol=tl['rtol'], atol=tl['atol'] * max(1.0, t.grad.abs().max().item()))
+    for got, ref in ((gd.grad, gamma.grad), (bd.grad, beta.grad)):
+        torch.testing.assert_close(got.cpu(), ref, rtol=2 * tl['rtol'], atol=2 * tl['atol'] * max(1.0, ref.abs().max().item()))
+    if dt == torch.bfloat16:
+        t2 = t.detach().to('cuda', dt).requires_grad_(True)
+        g2, b2 = gamma.detach().cuda().requires_grad_(True), beta.detach().cuda().requires_grad_(True)
+        cur, alias = ops.layernorm_fork(t2, g2, b2, 1e-6)
+        y2 = ops.metapool_residual(cur, alias, scd)
+        y2.backward(gy.to('cuda', dt))
+        same_y = (y2 == yd).float().mean().item()
+        same_g = (t2.grad == td.grad).float().mean().item()
+        assert same_y > 0.99 and same_g > 0.98, (same_y, same_g)
 
 
 @pytest.mark.parametrize('scaled', [False, True])

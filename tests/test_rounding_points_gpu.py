@@ -206,6 +206,29 @@ def test_last_decoder_block_through_t32_is_one_gemm():
     _check('last decoder block -> t324 as one GEMM', hip, ref, ref3, 0.97, 0.10)
 
 
+def test_mid_level_head_through_t32_rounds_the_composed_weight_once():
+    """round 4 (csrc/decoder_tail.hip, head_compose): with the feature-polarization loss off, aux_i(t32x(s_i)) at levels 1-3 (reference
+    nets/tcct.py:1036-1044) is ONE 32 -> n_class GEMM whose composed weight Wa Wt is rounded once for the matrix pipes; g_i is not stored.  The fp32
+    logits must sit an order of magnitude closer to the oracle's composed model than to the two-convolution chain with its bf16 store of g_i."""
+    import tcct_oracle as O
+    from tcct_amd import ops
+    torch.manual_seed(5)
+    t32, aux = nn.Conv2d(32, 32, 1), nn.Conv2d(32, 5, 1)
+    s = _rnd(2, 32, 40, 56, seed=9).to(BF).float()
+    sd = {**_sd('t', t32), **_sd('a', aux)}
+    t32, aux = t32.cuda(), aux.cuda()
+    assert ops.head_through_t32_ok(_nhwc(s), t32.weight, t32.bias, aux.weight, aux.bias)
+    with torch.no_grad():
+        hip = ops.head_through_t32(_nhwc(s), t32.weight, t32.bias, aux.weight, aux.bias).permute(0, 3, 1, 2).float().cpu()
+    with torch.no_grad(), O.rounding_points('bf16'):
+        wt, bt, wa, ba = sd['t.weight'][:, :, 0, 0], sd['t.bias'], sd['a.weight'][:, :, 0, 0], sd['a.bias']
+        ref = F.conv2d(s, O._W(wa @ wt)[:, :, None, None], wa @ bt + ba)
+        ref2 = O._conv(sd, 'a', O._conv(sd, 't', s), store=False)
+    e1, e2 = (hip - ref).abs().max().item(), (hip - ref2).abs().max().item()
+    print(f'mid-level head through t32x: max |diff| to the composed model {e1:.2e}, to the two-convolution chain {e2:.2e}')
+    assert e1 < 2e-5 * max(1.0, ref.abs().max().item()) and e2 > 10 * e1, (e1, e2)
+
+
 def test_token_mixer_and_mlp_store_points():
     """MHCABlock (reference nets/tcct.py:457-469) with the pooling mixer, stage by stage (each stage of the model is fed the HIP path's own input of that
     stage: through two LayerNorms a single flipped bit moves a whole token row by fractions of an ulp, so the chain as a whole agrees on 96 % only):
