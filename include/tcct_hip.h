@@ -399,11 +399,11 @@ int tcct_metapool_residual_fwd(const void* x, const void* res, const float* scal
 int tcct_metapool_scaled_bwd(const void* dy, const float* scale, void* dx, int B, int64_t N, int C, int dtype, tcct_stream_t stream);
 /* ... and with the LayerNorm in front of the mixer folded in (csrc/ln_pool.hip; nets/tcct.py:457-465): y = t + scale[b] * (pool(a) - a), a = LN(t; gamma, beta,
  * eps) rounded to the activation type, in ONE pass (read t, write y); backward dt = dy + LN^T(scale[b] * (pool^T(dy) - dy)) in one pass (read dy, read t,
- * write dt).  C a multiple of 8 in 16..128; mean_rstd fp32 [B*N*2] written by fwd and read by bwd; dgamma / dbeta fp32 [C] overwritten. */
+ * write dt; the LayerNorm statistics are recomputed from t).  C a multiple of 8 in 16..128; dgamma / dbeta fp32 [C] overwritten. */
 int tcct_ln_metapool_residual_fwd(const void* t, void* y, int B, int64_t N, int C, const float* gamma, const float* beta, float eps, const float* scale,
-                                  float* mean_rstd, int dtype, tcct_stream_t stream);
-int tcct_ln_metapool_residual_bwd(const void* t, const void* dy, void* dt, int B, int64_t N, int C, const float* gamma, const float* scale,
-                                  const float* mean_rstd, float* dgamma, float* dbeta, int dtype, tcct_stream_t stream);
+                                  int dtype, tcct_stream_t stream);
+int tcct_ln_metapool_residual_bwd(const void* t, const void* dy, void* dt, int B, int64_t N, int C, const float* gamma, float eps, const float* scale,
+                                  float* dgamma, float* dbeta, int dtype, tcct_stream_t stream);
 /* ---- nn.MaxPool2d(2) (nets/tcct.py:867,883); even H, W ---------------------------------------------------- */
 int tcct_maxpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, tcct_stream_t stream);
 int tcct_maxpool2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int dtype, tcct_stream_t stream);

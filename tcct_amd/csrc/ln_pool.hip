@@ -3,8 +3,10 @@
 // Until round 3 this was LayerNorm (read t, write a) + mixer (read a, read t, write t1) forward and mixer^T (read dt1, write da) + LayerNorm backward
 // (read t, read da, read dt1, write dt) backward: 11 tensor passes of 226 MB at stage 0 of the bench shape.  Here a group of LP lanes owns a strip of
 // consecutive tokens and marches down it with the three normalised rows n-1, n, n+1 in registers: forward = read t, write t1; backward = read dt1, read t,
-// write dt: 5 passes.  Lanes hold 8 channels (16-byte accesses: the 8-byte form of the older kernels runs at 0.54-0.70 of the 16-byte rate) and keep two
-// rows of loads in flight ahead of the row they work on.
+// write dt: 5 passes.  Lanes hold 8 channels (16-byte accesses: the 8-byte form of the older kernels runs at 0.54-0.70 of the 16-byte rate).  A marching
+// wave is latency-bound per row unless several rows are in flight: rows are requested LNP_PF iterations ahead into a ring of PACKED registers (4 VGPRs per
+// bf16 row) -- the first version kept two unpacked rows ahead and loaded the saved LayerNorm statistics right where it used them: 7 us per row backward.
+// The backward kernel recomputes mean / rstd from the row it reads anyway (the same instructions on the same data as forward: identical values).
 // Rounding: a = LN1(t) and da are rounded to the activation type in registers, where the two-kernel form stored them -- the values that enter the pooling
 // sums and the LayerNorm backward are the stored ones of the old path (up to the summation order of the LayerNorm statistics).
 #include "common.h"
@@ -48,13 +50,49 @@ __device__ __forceinline__ Row10 widen(const f8& m, bool hasl, bool hasr) {
     return o;
 }
 
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> { uint4 v; };
+template <> struct Raw8<float> { float4 a, b; };
+__device__ __forceinline__ Raw8<bf16> ldraw(const bf16* p) { return Raw8<bf16>{*reinterpret_cast<const uint4*>(p)}; }
+__device__ __forceinline__ Raw8<float> ldraw(const float* p) { return Raw8<float>{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)}; }
+__device__ __forceinline__ f8 unpack(const Raw8<bf16>& r) {
+    const uint4 t = r.v;
+    return f8{{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u),
+               __uint_as_float(t.z << 16), __uint_as_float(t.z & 0xffff0000u), __uint_as_float(t.w << 16), __uint_as_float(t.w & 0xffff0000u)}};
+}
+__device__ __forceinline__ f8 unpack(const Raw8<float>& r) { return f8{{r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w}}; }
+template <typename T> __device__ __forceinline__ Raw8<T> raw_zero();
+template <> __device__ __forceinline__ Raw8<bf16> raw_zero<bf16>() { return Raw8<bf16>{make_uint4(0u, 0u, 0u, 0u)}; }
+template <> __device__ __forceinline__ Raw8<float> raw_zero<float>() { return Raw8<float>{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}; }
+
+#define LNP_STRIP 32
+#define LNP_PF 4                // rows requested ahead (LNP_STRIP is a multiple)
+#ifndef LNP_PF_FWD
+#define LNP_PF_FWD 4
+#endif
+
+// mean and 1/std of one row held by the LP lanes of a group (inactive lanes hold zeros)
+template <int LP>
+__device__ __forceinline__ void row_stats(const f8& x, bool act, float invC, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += x.v[k];
+    s = lane_group_sum(s, LP);
+    mean = s * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float d = act ? x.v[k] - mean : 0.f; q += d * d; }
+    q = lane_group_sum(q, LP);
+    rstd = rsqrtf(q * invC + eps);
+}
+
 // ------------------------------------------------------------------------------------------------ forward
-// t, y: [B, N, C]; gamma, beta: [C]; scale: fp32 [B] or NULL (DropPath mask / keep); mean_rstd: fp32 [B*N][2] (written; read by the backward kernel)
+// t, y: [B, N, C]; gamma, beta: [C]; scale: fp32 [B] or NULL (DropPath mask / keep)
 template <typename T, int LP>
-__global__ void __launch_bounds__(LP_T)
-k_ln_metapool_fwd(const T* __restrict__ t, T* __restrict__ y, int N, int C, int S, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                  const float* __restrict__ scale, float* __restrict__ mean_rstd) {
-    constexpr int GPB = LP_T / LP;
+__global__ void __launch_bounds__(LP_T)       // (134 VGPRs in bf16: three waves per SIMD; forcing four with a launch bound made the kernel 40 % SLOWER)
+k_ln_metapool_fwd(const T* __restrict__ t, T* __restrict__ y, int N, int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                  const float* __restrict__ scale) {
+    constexpr int GPB = LP_T / LP, S = LNP_STRIP, PF = LNP_PF_FWD;
     const int gl = threadIdx.x % LP, grp = threadIdx.x / LP;
     const int c0 = gl * 8;
     const bool act = c0 < C;                    // C < 8 LP: the last lanes of a group idle (C = 96 on 16 lanes)
@@ -72,56 +110,53 @@ k_ln_metapool_fwd(const T* __restrict__ t, T* __restrict__ y, int N, int C, int 
     const float sc = scale ? scale[blockIdx.y] : 1.f;
     const float invC = 1.f / (float)C;
     const int n0 = (blockIdx.x * GPB + grp) * S;            // every lane of a group shares n0: the lane exchanges stay convergent
-    auto fetch = [&](int nn) { return (act && nn >= 0 && nn < N) ? ld8(tb + (int64_t)nn * C) : f8zero(); };
+    if (n0 >= N) return;                                   // (whole groups only)
+    auto fetch = [&](int nn) { return (act && nn >= 0 && nn < N) ? ldraw(tb + (int64_t)nn * C) : raw_zero<T>(); };
     auto normed = [&](const f8& x, int nn, f8& ctr) {        // LayerNorm of one row, rounded to T; zeros outside the image
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += x.v[k];
-        s = lane_group_sum(s, LP);
-        const float mean = s * invC;
-        float q = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const float d = act ? x.v[k] - mean : 0.f; q += d * d; }
-        q = lane_group_sum(q, LP);
-        const float rstd = rsqrtf(q * invC + eps);
+        float mean, rstd;
+        row_stats<LP>(x, act, invC, eps, mean, rstd);
         const bool in = nn >= 0 && nn < N;
-        if (in && gl == 0 && nn >= n0 && nn < n0 + S) { mean_rstd[2 * (img + nn)] = mean; mean_rstd[2 * (img + nn) + 1] = rstd; }
 #pragma unroll
         for (int k = 0; k < 8; ++k) ctr.v[k] = (in && act) ? round_to<T>((x.v[k] - mean) * rstd * gam[k] + bet[k]) : 0.f;
         return widen<LP>(ctr, hasl, hasr);
     };
-    if (n0 >= N) return;                                   // (whole groups only: n0 is group-uniform)
-    f8 x0 = fetch(n0 - 1), x1 = fetch(n0), x2 = fetch(n0 + 1), x3 = fetch(n0 + 2);
-    f8 cprev, ccur, cnxt;
-    Row10 prev = normed(x0, n0 - 1, cprev), cur = normed(x1, n0, ccur);
-    f8 e = x1;                                              // the residual: the raw row n
-    for (int i = 0; i < S; ++i) {
-        const int n = n0 + i;
-        const f8 x4 = fetch(n + 3);                         // two rows of loads in flight ahead of the row being normalised
-        const Row10 nxt = normed(x2, n + 1, cnxt);
-        if (n < N) {
-            const float rinv = 1.f / (float)(1 + (n > 0) + (n < N - 1));
-            f8 o;
+    const Raw8<T> r0 = fetch(n0 - 1), r1 = fetch(n0);
+    Raw8<T> ring[PF];                                       // ring[j]: row n0 + 1 + j, then the row PF further down each time it is consumed
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float s_ = (prev.g[k] + cur.g[k] + nxt.g[k]) + (prev.g[k + 1] + cur.g[k + 1] + nxt.g[k + 1]) + (prev.g[k + 2] + cur.g[k + 2] + nxt.g[k + 2]);
-                s_ *= rinv * cs[k];
-                o.v[k] = e.v[k] + sc * (s_ - ccur.v[k]);
+    for (int j = 0; j < PF; ++j) ring[j] = fetch(n0 + 1 + j);
+    f8 cprev, ccur, cnxt;
+    f8 e = unpack(r1);                                      // the residual: the raw row n
+    Row10 prev = normed(unpack(r0), n0 - 1, cprev), cur = normed(e, n0, ccur);
+    for (int i0 = 0; i0 < S; i0 += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int n = n0 + i0 + j;
+            const f8 xn = unpack(ring[j]);
+            ring[j] = fetch(n + 1 + PF);
+            const Row10 nxt = normed(xn, n + 1, cnxt);
+            if (n < N) {
+                const float rinv = 1.f / (float)(1 + (n > 0) + (n < N - 1));
+                f8 o;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float s_ = (prev.g[k] + cur.g[k] + nxt.g[k]) + (prev.g[k + 1] + cur.g[k + 1] + nxt.g[k + 1]) + (prev.g[k + 2] + cur.g[k + 2] + nxt.g[k + 2]);
+                    s_ *= rinv * cs[k];
+                    o.v[k] = e.v[k] + sc * (s_ - ccur.v[k]);
+                }
+                if (act) st8(yb + (int64_t)n * C, o);
             }
-            if (act) st8(yb + (int64_t)n * C, o);
+            prev = cur; cur = nxt; ccur = cnxt; e = xn;
         }
-        prev = cur; cur = nxt; ccur = cnxt;
-        e = x2; x2 = x3; x3 = x4;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
 // dt = dy + LN1^T(da),  da = scale[b] * (pool^T(dy) - dy) rounded to T;  dgamma / dbeta are ACCUMULATED (zero on entry)
 template <typename T, int LP>
-__global__ void __launch_bounds__(LP_T)
-k_ln_metapool_bwd(const T* __restrict__ t, const T* __restrict__ dy, T* __restrict__ dt, int N, int C, int S, const float* __restrict__ gamma,
-                  const float* __restrict__ scale, const float* __restrict__ mean_rstd, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    constexpr int GPB = LP_T / LP;
+__global__ void __launch_bounds__(LP_T, sizeof(T) == 2 ? 3 : 2)
+k_ln_metapool_bwd(const T* __restrict__ t, const T* __restrict__ dy, T* __restrict__ dt, int N, int C, const float* __restrict__ gamma, float eps,
+                  const float* __restrict__ scale, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    constexpr int GPB = LP_T / LP, S = LNP_STRIP, PF = LNP_PF;
     __shared__ float swv[(LP_T / 64) * 2 * 8 * LP];
     const int gl = threadIdx.x % LP, grp = threadIdx.x / LP;
     const int c0 = gl * 8;
@@ -145,7 +180,8 @@ k_ln_metapool_bwd(const T* __restrict__ t, const T* __restrict__ dy, T* __restri
     float ag[8], ab[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { ag[k] = 0.f; ab[k] = 0.f; }
-    auto fetch = [&](int nn) { return (act && nn >= 0 && nn < N) ? ld8(db + (int64_t)nn * C) : f8zero(); };
+    auto fetchd = [&](int nn) { return (act && nn >= 0 && nn < N) ? ldraw(db + (int64_t)nn * C) : raw_zero<T>(); };
+    auto fetchx = [&](int nn) { return (act && nn >= 0 && nn < N) ? ldraw(tb + (int64_t)nn * C) : raw_zero<T>(); };
     auto weighted = [&](const f8& d, int nn) {               // the row's gradient divided by the window sizes of ITS OWN position (pool^T)
         Row10 o = widen<LP>(d, hasl, hasr);
         const float rw = 1.f / (float)(1 + (nn > 0) + (nn < N - 1));
@@ -154,38 +190,44 @@ k_ln_metapool_bwd(const T* __restrict__ t, const T* __restrict__ dy, T* __restri
         return o;
     };
     if (n0 < N) {
-        f8 d0 = fetch(n0 - 1), d1 = fetch(n0), d2 = fetch(n0 + 1), d3 = fetch(n0 + 2);
-        f8 xc = (act && n0 < N) ? ld8(tb + (int64_t)n0 * C) : f8zero(), xn = (act && n0 + 1 < N) ? ld8(tb + (int64_t)(n0 + 1) * C) : f8zero();
-        Row10 prev = weighted(d0, n0 - 1), cur = weighted(d1, n0);
-        f8 dcur = d1;
-        for (int i = 0; i < S; ++i) {
-            const int n = n0 + i;
-            const f8 d4 = fetch(n + 3);
-            const f8 xn2 = (act && n + 2 < N) ? ld8(tb + (int64_t)(n + 2) * C) : f8zero();
-            const Row10 nxt = weighted(d2, n + 1);
-            if (n < N) {
-                const float mean = mean_rstd[2 * (img + n)], rstd = mean_rstd[2 * (img + n) + 1];
-                float g[8], xh[8], s1 = 0.f, s2 = 0.f;
+        const Raw8<T> q0 = fetchd(n0 - 1), q1 = fetchd(n0);
+        Raw8<T> dring[PF], xring[PF];                       // dring[j]: dy row n0 + 1 + j; xring[j]: t row n0 + j
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float s_ = (prev.g[k] + cur.g[k] + nxt.g[k]) + (prev.g[k + 1] + cur.g[k + 1] + nxt.g[k + 1]) + (prev.g[k + 2] + cur.g[k + 2] + nxt.g[k + 2]);
-                    const float da = act ? round_to<T>(sc * (s_ - dcur.v[k])) : 0.f;
-                    const float h = act ? (xc.v[k] - mean) * rstd : 0.f;
-                    xh[k] = h;
-                    ag[k] += da * h;
-                    ab[k] += da;
-                    g[k] = da * gam[k];
-                    s1 += g[k]; s2 += g[k] * h;
+        for (int j = 0; j < PF; ++j) { dring[j] = fetchd(n0 + 1 + j); xring[j] = fetchx(n0 + j); }
+        f8 dcur = unpack(q1);
+        Row10 prev = weighted(unpack(q0), n0 - 1), cur = weighted(dcur, n0);
+        for (int i0 = 0; i0 < S; i0 += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const int n = n0 + i0 + j;
+                const f8 dn = unpack(dring[j]);
+                dring[j] = fetchd(n + 1 + PF);
+                const f8 xc = unpack(xring[j]);
+                xring[j] = fetchx(n + PF);
+                const Row10 nxt = weighted(dn, n + 1);
+                float mean, rstd;
+                row_stats<LP>(xc, act, invC, eps, mean, rstd);          // (group-uniform control flow: the lane exchanges run for rows past the image as well)
+                if (n < N) {
+                    float g[8], xh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float s_ = (prev.g[k] + cur.g[k] + nxt.g[k]) + (prev.g[k + 1] + cur.g[k + 1] + nxt.g[k + 1]) + (prev.g[k + 2] + cur.g[k + 2] + nxt.g[k + 2]);
+                        const float da = act ? round_to<T>(sc * (s_ - dcur.v[k])) : 0.f;
+                        const float h = act ? (xc.v[k] - mean) * rstd : 0.f;
+                        xh[k] = h;
+                        ag[k] += da * h;
+                        ab[k] += da;
+                        g[k] = da * gam[k];
+                        s1 += g[k]; s2 += g[k] * h;
+                    }
+                    s1 = lane_group_sum(s1, LP) * invC; s2 = lane_group_sum(s2, LP) * invC;
+                    f8 o;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o.v[k] = rstd * (g[k] - s1 - xh[k] * s2) + dcur.v[k];
+                    if (act) st8(ob + (int64_t)n * C, o);
                 }
-                s1 = lane_group_sum(s1, LP) * invC; s2 = lane_group_sum(s2, LP) * invC;
-                f8 o;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) o.v[k] = rstd * (g[k] - s1 - xh[k] * s2) + dcur.v[k];
-                if (act) st8(ob + (int64_t)n * C, o);
+                prev = cur; cur = nxt; dcur = dn;
             }
-            prev = cur; cur = nxt; dcur = d2;
-            d2 = d3; d3 = d4;
-            xc = xn; xn = xn2;
         }
     }
     // the 64 / LP groups of a wave hold the same channels: butterfly over the lane bits above LP, one LDS slot per wave, 2C atomics per block
@@ -206,32 +248,31 @@ k_ln_metapool_bwd(const T* __restrict__ t, const T* __restrict__ dy, T* __restri
 }
 
 static bool ln_metapool_shape_ok(int B, int64_t N, int C) { return C % 8 == 0 && C >= 16 && C <= 128 && B >= 1 && B <= 65535 && N >= 1 && N < (1LL << 30); }
-#define LNP_STRIP 32
 /* y = t + scale[b] * (pool(a) - a), a = LayerNorm(t; gamma, beta, eps) rounded to the activation type: MHCABlock's first half (nets/tcct.py:457-465 with the
- * MetaPool mixer :405-415) in one pass.  t, y [B,N,C] (dtype 0 fp32 / 1 bf16), C a multiple of 8 in 16..128; scale fp32 [B] or NULL; mean_rstd fp32 [B*N*2] out. */
+ * MetaPool mixer :405-415) in one pass.  t, y [B,N,C] (dtype 0 fp32 / 1 bf16), C a multiple of 8 in 16..128; scale fp32 [B] or NULL. */
 extern "C" int tcct_ln_metapool_residual_fwd(const void* t, void* y, int B, int64_t N, int C, const float* gamma, const float* beta, float eps, const float* scale,
-                                             float* mean_rstd, int dtype, tcct_stream_t stream) {
+                                             int dtype, tcct_stream_t stream) {
     TCCT_CHECK(ln_metapool_shape_ok(B, N, C), "ln_metapool_residual_fwd: B=%d N=%lld C=%d unsupported (C %% 8 == 0, 16 <= C <= 128)", B, (long long)N, C);
-    TCCT_CHECK(t && y && gamma && beta && mean_rstd, "ln_metapool_residual_fwd: NULL argument");
+    TCCT_CHECK(t && y && gamma && beta, "ln_metapool_residual_fwd: NULL argument");
     const int64_t strips = (N + LNP_STRIP - 1) / LNP_STRIP;
 #define LNPF(LP_) hipLaunchKernelGGL((k_ln_metapool_fwd<T, LP_>), dim3((unsigned)((strips + LP_T / LP_ - 1) / (LP_T / LP_)), (unsigned)B), dim3(LP_T), 0, (hipStream_t)stream, \
-                                     (const T*)t, (T*)y, (int)N, C, LNP_STRIP, gamma, beta, eps, scale, mean_rstd)
+                                     (const T*)t, (T*)y, (int)N, C, gamma, beta, eps, scale)
     TCCT_DISPATCH(dtype, if (C <= 64) LNPF(8); else LNPF(16));
 #undef LNPF
     TCCT_LAUNCH_OK();
 }
-/* dt = dy + LN^T(da), da = scale[b] * (pool^T(dy) - dy); dgamma, dbeta [C] overwritten */
-extern "C" int tcct_ln_metapool_residual_bwd(const void* t, const void* dy, void* dt, int B, int64_t N, int C, const float* gamma, const float* scale,
-                                             const float* mean_rstd, float* dgamma, float* dbeta, int dtype, tcct_stream_t stream) {
+/* dt = dy + LN^T(da), da = scale[b] * (pool^T(dy) - dy); dgamma, dbeta [C] overwritten.  The LayerNorm statistics are recomputed from t. */
+extern "C" int tcct_ln_metapool_residual_bwd(const void* t, const void* dy, void* dt, int B, int64_t N, int C, const float* gamma, float eps, const float* scale,
+                                             float* dgamma, float* dbeta, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(ln_metapool_shape_ok(B, N, C), "ln_metapool_residual_bwd: B=%d N=%lld C=%d unsupported (C %% 8 == 0, 16 <= C <= 128)", B, (long long)N, C);
-    TCCT_CHECK(t && dy && dt && gamma && mean_rstd && dgamma && dbeta, "ln_metapool_residual_bwd: NULL argument");
+    TCCT_CHECK(t && dy && dt && gamma && dgamma && dbeta, "ln_metapool_residual_bwd: NULL argument");
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess)) {
         tcct_set_error("ln_metapool_residual_bwd: memset failed"); return -2;
     }
     const int64_t strips = (N + LNP_STRIP - 1) / LNP_STRIP;
 #define LNPB(LP_) hipLaunchKernelGGL((k_ln_metapool_bwd<T, LP_>), dim3((unsigned)((strips + LP_T / LP_ - 1) / (LP_T / LP_)), (unsigned)B), dim3(LP_T), 0, st, (const T*)t, \
-                                     (const T*)dy, (T*)dt, (int)N, C, LNP_STRIP, gamma, scale, mean_rstd, dgamma, dbeta)
+                                     (const T*)dy, (T*)dt, (int)N, C, gamma, eps, scale, dgamma, dbeta)
     TCCT_DISPATCH(dtype, if (C <= 64) LNPB(8); else LNPB(16));
 #undef LNPB
     TCCT_LAUNCH_OK();

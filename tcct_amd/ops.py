@@ -2061,20 +2061,19 @@ class _LnMetaPoolResidual(torch.autograd.Function):
         _chk(t, gamma, beta, scale)
         B, N, C = t.shape
         y = torch.empty_like(t)
-        mr = torch.empty(2 * B * N, device=t.device, dtype=torch.float32)
-        lib.ln_metapool_residual_fwd(t, y, B, N, C, gamma, beta, eps, scale, mr, dtype_code(t.dtype))
-        ctx.save_for_backward(t, gamma, mr)
-        ctx.beta_param, ctx.scale = beta, scale
+        lib.ln_metapool_residual_fwd(t, y, B, N, C, gamma, beta, eps, scale, dtype_code(t.dtype))
+        ctx.save_for_backward(t, gamma)
+        ctx.beta_param, ctx.scale, ctx.eps = beta, scale, eps
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        t, gamma, mr = ctx.saved_tensors
+        t, gamma = ctx.saved_tensors
         dy = _as(dy, t.dtype)
         B, N, C = t.shape
         dt = torch.empty_like(t)
         dg, db = _grad_out(gamma), _grad_out(ctx.beta_param)
-        lib.ln_metapool_residual_bwd(t, dy, dt, B, N, C, gamma, ctx.scale, mr, dg, db, dtype_code(t.dtype))
+        lib.ln_metapool_residual_bwd(t, dy, dt, B, N, C, gamma, ctx.eps, ctx.scale, dg, db, dtype_code(t.dtype))
         return dt, _ret(dg, gamma), _ret(db, ctx.beta_param), None, None
 
 
