@@ -402,6 +402,9 @@ int tcct_metapool_scaled_bwd(const void* dy, const float* scale, void* dx, int B
  * write dt; the LayerNorm statistics are recomputed from t).  C a multiple of 8 in 16..128; dgamma / dbeta fp32 [C] overwritten. */
 int tcct_ln_metapool_residual_fwd(const void* t, void* y, int B, int64_t N, int C, const float* gamma, const float* beta, float eps, const float* scale,
                                   int dtype, tcct_stream_t stream);
+/* ... and MHCABlock.norm2 of the row just produced (nets/tcct.py:466): y2 = LN(y; gamma2, beta2, eps2), mean_rstd2 fp32 [B*N*2] as tcct_layernorm_fwd writes it */
+int tcct_ln_metapool_residual_ln_fwd(const void* t, void* y, void* y2, int B, int64_t N, int C, const float* gamma, const float* beta, float eps,
+                                     const float* scale, const float* gamma2, const float* beta2, float eps2, float* mean_rstd2, int dtype, tcct_stream_t stream);
 int tcct_ln_metapool_residual_bwd(const void* t, const void* dy, void* dt, int B, int64_t N, int C, const float* gamma, float eps, const float* scale,
                                   float* dgamma, float* dbeta, int dtype, tcct_stream_t stream);
 /* ---- nn.MaxPool2d(2) (nets/tcct.py:867,883); even H, W ---------------------------------------------------- */

@@ -88,10 +88,13 @@ __device__ __forceinline__ void row_stats(const f8& x, bool act, float invC, flo
 
 // ------------------------------------------------------------------------------------------------ forward
 // t, y: [B, N, C]; gamma, beta: [C]; scale: fp32 [B] or NULL (DropPath mask / keep)
-template <typename T, int LP>
+// LN2: also write y2 = LayerNorm(y; gamma2, beta2, eps2) of the row just produced (MHCABlock.norm2, nets/tcct.py:466: the row is complete in the group's
+// registers) with its mean / rstd [B*N][2] for the separate backward kernel -- the stand-alone LayerNorm pass re-read y to do the same
+template <typename T, int LP, bool LN2>
 __global__ void __launch_bounds__(LP_T)       // (134 VGPRs in bf16: three waves per SIMD; forcing four with a launch bound made the kernel 40 % SLOWER)
 k_ln_metapool_fwd(const T* __restrict__ t, T* __restrict__ y, int N, int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                  const float* __restrict__ scale) {
+                  const float* __restrict__ scale, T* __restrict__ y2, const float* __restrict__ gamma2, const float* __restrict__ beta2, float eps2,
+                  float* __restrict__ mean_rstd2) {
     constexpr int GPB = LP_T / LP, S = LNP_STRIP, PF = LNP_PF_FWD;
     const int gl = threadIdx.x % LP, grp = threadIdx.x / LP;
     const int c0 = gl * 8;
@@ -104,6 +107,9 @@ k_ln_metapool_fwd(const T* __restrict__ t, T* __restrict__ y, int N, int C, cons
         const int c = c0 + k;
         cs[k] = 1.f / (float)(1 + (c > 0) + (c < C - 1));
     }
+    float gam2[8], bet2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { gam2[k] = (LN2 && act) ? gamma2[c0 + k] : 0.f; bet2[k] = (LN2 && act) ? beta2[c0 + k] : 0.f; }
     const int64_t img = (int64_t)blockIdx.y * N;
     const T* tb = t + img * C + c0;
     T* yb = y + img * C + c0;
@@ -144,6 +150,18 @@ k_ln_metapool_fwd(const T* __restrict__ t, T* __restrict__ y, int N, int C, cons
                     o.v[k] = e.v[k] + sc * (s_ - ccur.v[k]);
                 }
                 if (act) st8(yb + (int64_t)n * C, o);
+                if (LN2) {                                  // the second LayerNorm reads the STORED row: round first
+                    f8 orr;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) orr.v[k] = act ? round_to<T>(o.v[k]) : 0.f;
+                    float mean2, rstd2;
+                    row_stats<LP>(orr, act, invC, eps2, mean2, rstd2);
+                    if (gl == 0) { mean_rstd2[2 * (img + n)] = mean2; mean_rstd2[2 * (img + n) + 1] = rstd2; }
+                    f8 b;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) b.v[k] = (orr.v[k] - mean2) * rstd2 * gam2[k] + bet2[k];
+                    if (act) st8(y2 + (img + n) * C + c0, b);
+                }
             }
             prev = cur; cur = nxt; ccur = cnxt; e = xn;
         }
@@ -250,16 +268,28 @@ k_ln_metapool_bwd(const T* __restrict__ t, const T* __restrict__ dy, T* __restri
 static bool ln_metapool_shape_ok(int B, int64_t N, int C) { return C % 8 == 0 && C >= 16 && C <= 128 && B >= 1 && B <= 65535 && N >= 1 && N < (1LL << 30); }
 /* y = t + scale[b] * (pool(a) - a), a = LayerNorm(t; gamma, beta, eps) rounded to the activation type: MHCABlock's first half (nets/tcct.py:457-465 with the
  * MetaPool mixer :405-415) in one pass.  t, y [B,N,C] (dtype 0 fp32 / 1 bf16), C a multiple of 8 in 16..128; scale fp32 [B] or NULL. */
-extern "C" int tcct_ln_metapool_residual_fwd(const void* t, void* y, int B, int64_t N, int C, const float* gamma, const float* beta, float eps, const float* scale,
-                                             int dtype, tcct_stream_t stream) {
+static int ln_metapool_fwd_impl(const void* t, void* y, int B, int64_t N, int C, const float* gamma, const float* beta, float eps, const float* scale, void* y2,
+                                const float* gamma2, const float* beta2, float eps2, float* mean_rstd2, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(ln_metapool_shape_ok(B, N, C), "ln_metapool_residual_fwd: B=%d N=%lld C=%d unsupported (C %% 8 == 0, 16 <= C <= 128)", B, (long long)N, C);
     TCCT_CHECK(t && y && gamma && beta, "ln_metapool_residual_fwd: NULL argument");
     const int64_t strips = (N + LNP_STRIP - 1) / LNP_STRIP;
-#define LNPF(LP_) hipLaunchKernelGGL((k_ln_metapool_fwd<T, LP_>), dim3((unsigned)((strips + LP_T / LP_ - 1) / (LP_T / LP_)), (unsigned)B), dim3(LP_T), 0, (hipStream_t)stream, \
-                                     (const T*)t, (T*)y, (int)N, C, gamma, beta, eps, scale)
-    TCCT_DISPATCH(dtype, if (C <= 64) LNPF(8); else LNPF(16));
+#define LNPF(LP_, L2) hipLaunchKernelGGL((k_ln_metapool_fwd<T, LP_, L2>), dim3((unsigned)((strips + LP_T / LP_ - 1) / (LP_T / LP_)), (unsigned)B), dim3(LP_T), 0, \
+                                         (hipStream_t)stream, (const T*)t, (T*)y, (int)N, C, gamma, beta, eps, scale, (T*)y2, gamma2, beta2, eps2, mean_rstd2)
+    if (y2) { TCCT_DISPATCH(dtype, if (C <= 64) LNPF(8, true); else LNPF(16, true)); }
+    else { TCCT_DISPATCH(dtype, if (C <= 64) LNPF(8, false); else LNPF(16, false)); }
 #undef LNPF
     TCCT_LAUNCH_OK();
+}
+extern "C" int tcct_ln_metapool_residual_fwd(const void* t, void* y, int B, int64_t N, int C, const float* gamma, const float* beta, float eps, const float* scale,
+                                             int dtype, tcct_stream_t stream) {
+    return ln_metapool_fwd_impl(t, y, B, N, C, gamma, beta, eps, scale, nullptr, nullptr, nullptr, 0.f, nullptr, dtype, stream);
+}
+/* ... and y2 = LayerNorm(y; gamma2, beta2, eps2) from the same pass (MHCABlock.norm2, nets/tcct.py:466), mean_rstd2 fp32 [B*N*2] for tcct_layernorm_bwd[_add] */
+extern "C" int tcct_ln_metapool_residual_ln_fwd(const void* t, void* y, void* y2, int B, int64_t N, int C, const float* gamma, const float* beta, float eps,
+                                                const float* scale, const float* gamma2, const float* beta2, float eps2, float* mean_rstd2, int dtype,
+                                                tcct_stream_t stream) {
+    TCCT_CHECK(y2 && gamma2 && beta2 && mean_rstd2, "ln_metapool_residual_ln_fwd: NULL argument");
+    return ln_metapool_fwd_impl(t, y, B, N, C, gamma, beta, eps, scale, y2, gamma2, beta2, eps2, mean_rstd2, dtype, stream);
 }
 /* dt = dy + LN^T(da), da = scale[b] * (pool^T(dy) - dy); dgamma, dbeta [C] overwritten.  The LayerNorm statistics are recomputed from t. */
 extern "C" int tcct_ln_metapool_residual_bwd(const void* t, const void* dy, void* dt, int B, int64_t N, int C, const float* gamma, float eps, const float* scale,

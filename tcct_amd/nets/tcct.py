@@ -314,16 +314,24 @@ class MHCABlock(nn.Module):
         s1, s2 = scales if scales is not None else (None, None)
         # (the residual paths read aliases of t: their gradients are added inside the LayerNorm backward kernels)
         att = getattr(self, 'att', None)
+        cur2 = None
         if att is None and ops.ln_metapool_residual_ok(t, self.norm1.weight, self.norm1.bias):
-            # t + dp(pool(LN1 t)): LayerNorm, mixer, DropPath scale and residual in ONE pass each way (the normalised tensor is never written)
-            t = ops.ln_metapool_residual(t, self.norm1.weight, self.norm1.bias, self.norm1.eps, s1)
+            # t + dp(pool(LN1 t)): LayerNorm, mixer, DropPath scale and residual in ONE pass each way (the normalised tensor is never written) ...
+            if ops.LN_POOL_LN2:
+                # ... and LN2 of the row while it is in registers
+                t, cur2 = ops.ln_metapool_residual_ln(t, self.norm1.weight, self.norm1.bias, self.norm1.eps, s1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            else:
+                t = ops.ln_metapool_residual(t, self.norm1.weight, self.norm1.bias, self.norm1.eps, s1)
         else:
             cur, t = ops.layernorm_fork(t, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             if att is not None:     # t + dp(proj(factor_att(LN1 t))): the projection GEMM carries the DropPath scale and the residual
                 t = ops.linear_residual(att.mix(cur, (H, W)), att.proj.weight, att.proj.bias, t, s1)
             else:
                 t = ops.metapool_residual(cur, t, s1)       # t + dp(pool(LN1 t)): mixer, DropPath scale and residual in one pass
-        cur, t = ops.layernorm_fork(t, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        if cur2 is None:
+            cur, t = ops.layernorm_fork(t, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        else:
+            cur = cur2
         if self.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
             y1 = ops.conv2d(cur, self.mlp.fc1.weight, self.mlp.fc1.bias)
             if ops.gelu_linear_residual_ok(y1, self.mlp.fc2.weight, self.mlp.fc2.bias, t):

@@ -2077,6 +2077,48 @@ class _LnMetaPoolResidual(torch.autograd.Function):
         return dt, _ret(dg, gamma), _ret(db, ctx.beta_param), None, None
 
 
+class _LnMetaPoolResidualLn(torch.autograd.Function):
+    """(t1, LN2(t1)) with t1 = t + scale[b] * (pool(LN1(t)) - LN1(t)): MHCABlock up to the input of its Mlp (reference nets/tcct.py:457-466) from ONE forward
+    pass -- the second LayerNorm is taken of the row while it is in registers.  Backward: LayerNorm-2 backward (+ the residual path's gradient of t1), then
+    the one-pass backward of the first half."""
+
+    @staticmethod
+    def forward(ctx, t, g1, b1, eps1, scale, g2, b2, eps2):
+        ctx.set_materialize_grads(False)
+        _chk(t, g1, b1, scale, g2, b2)
+        B, N, C = t.shape
+        y, y2 = torch.empty_like(t), torch.empty_like(t)
+        mr2 = torch.empty(2 * B * N, device=t.device, dtype=torch.float32)
+        lib.ln_metapool_residual_ln_fwd(t, y, y2, B, N, C, g1, b1, eps1, scale, g2, b2, eps2, mr2, dtype_code(t.dtype))
+        ctx.save_for_backward(t, y, g1, g2, mr2)
+        ctx.beta = (b1, b2)
+        ctx.cfg = (eps1, scale)
+        return y, y2
+
+    @staticmethod
+    def backward(ctx, dres, dcur):
+        t, y, g1, g2, mr2 = ctx.saved_tensors
+        b1, b2 = ctx.beta
+        eps1, scale = ctx.cfg
+        B, N, C = t.shape
+        dc = dtype_code(t.dtype)
+        dg2 = db2 = None
+        if dcur is not None:
+            dcur = _as(dcur, t.dtype)
+            dt1 = torch.empty_like(t)
+            dg2, db2 = _grad_out(g2), _grad_out(b2)
+            if dres is None:
+                lib.layernorm_bwd(y, dcur, dt1, B * N, C, g2, mr2, dg2, db2, dc)
+            else:
+                lib.layernorm_bwd_add(y, dcur, _as(dres, t.dtype), dt1, B * N, C, g2, mr2, dg2, db2, dc)
+        else:
+            dt1 = _as(dres, t.dtype)
+        dt = torch.empty_like(t)
+        dg1, db1 = _grad_out(g1), _grad_out(b1)
+        lib.ln_metapool_residual_bwd(t, dt1, dt, B, N, C, g1, eps1, scale, dg1, db1, dc)
+        return dt, _ret(dg1, g1), _ret(db1, b1), None, None, _ret(dg2, g2), _ret(db2, b2), None
+
+
 LN_POOL_FUSE = os.environ.get('TCCT_LN_POOL', '1') != '0'       # =0: LayerNorm and the token mixer stay separate kernels (A/B timing)
 
 
@@ -2088,6 +2130,14 @@ def ln_metapool_residual_ok(t, gamma, beta):
 def ln_metapool_residual(t, gamma, beta, eps=1e-6, scale=None):
     """t + scale[b] * MetaPool(LayerNorm(t)) on tokens [B,N,C] in one pass (scale: fp32 [B] or None); check ln_metapool_residual_ok first"""
     return _LnMetaPoolResidual.apply(t, gamma, beta, float(eps), scale)
+
+
+LN_POOL_LN2 = os.environ.get('TCCT_LN_POOL_LN2', '1') != '0'       # =0: the second LayerNorm stays its own forward pass (A/B timing)
+
+
+def ln_metapool_residual_ln(t, g1, b1, eps1, scale, g2, b2, eps2):
+    """(t1, LayerNorm2(t1)), t1 = t + scale[b] * MetaPool(LayerNorm1(t)): one forward pass; check ln_metapool_residual_ok first"""
+    return _LnMetaPoolResidualLn.apply(t, g1, b1, float(eps1), scale, g2, b2, float(eps2))
 
 
 def metapool(x):

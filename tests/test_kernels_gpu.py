@@ -1268,14 +1268,37 @@ def test_layernorm_token_mixer_residual_in_one_pass(dt, cfg):
     torch.testing.assert_close(td.grad.float().cpu(), t.grad, rtol=tl['rtol'], atol=tl['atol'] * max(1.0, t.grad.abs().max().item()))
     for got, ref in ((gd.grad, gamma.grad), (bd.grad, beta.grad)):
         torch.testing.assert_close(got.cpu(), ref, rtol=2 * tl['rtol'], atol=2 * tl['atol'] * max(1.0, ref.abs().max().item()))
+    # ... and with MHCABlock.norm2 of the produced row taken in the same pass: (t1, LN2(t1)), both outputs carrying gradients
+    gamma2 = (1.0 - 0.2 * rnd(C, seed=4)).requires_grad_(True)
+    beta2 = (0.1 * rnd(C, seed=5)).requires_grad_(True)
+    t.grad = gamma.grad = beta.grad = None
+    a = F.layer_norm(t, (C,), gamma, beta, 1e-6)
+    pooled = F.avg_pool2d(a[:, None], 3, 1, 1, count_include_pad=False)[:, 0] - a
+    y = t + (pooled * sc.view(B, 1, 1) if scaled else pooled)
+    y_st = y.to(dt).float() if dt == torch.bfloat16 else y            # LN2 reads the stored row
+    y2 = F.layer_norm(y + (y_st - y).detach(), (C,), gamma2, beta2, 1e-6)
+    gy2 = rnd(*y.shape, seed=6, dt=dt)
+    (y * gy).sum().add((y2 * gy2).sum()).backward()
+    td = t.detach().to('cuda', dt).requires_grad_(True)
+    ps = [p_.detach().cuda().requires_grad_(True) for p_ in (gamma, beta, gamma2, beta2)]
+    yd, y2d = ops.ln_metapool_residual_ln(td, ps[0], ps[1], 1e-6, scd, ps[2], ps[3], 1e-6)
+    torch.testing.assert_close(yd.float().cpu(), y.detach(), **tl)
+    torch.testing.assert_close(y2d.float().cpu(), y2.detach(), rtol=2 * tl['rtol'], atol=2 * tl['atol'])
+    torch.autograd.backward([yd, y2d], [gy.to('cuda', dt), gy2.to('cuda', dt)])
+    torch.testing.assert_close(td.grad.float().cpu(), t.grad, rtol=2 * tl['rtol'], atol=2 * tl['atol'] * max(1.0, t.grad.abs().max().item()))
+    for got, ref in zip(ps, (gamma, beta, gamma2, beta2)):
+        torch.testing.assert_close(got.grad.cpu(), ref.grad, rtol=3 * tl['rtol'], atol=3 * tl['atol'] * max(1.0, ref.grad.abs().max().item()))
     if dt == torch.bfloat16:
         t2 = t.detach().to('cuda', dt).requires_grad_(True)
         g2, b2 = gamma.detach().cuda().requires_grad_(True), beta.detach().cuda().requires_grad_(True)
         cur, alias = ops.layernorm_fork(t2, g2, b2, 1e-6)
         y2 = ops.metapool_residual(cur, alias, scd)
         y2.backward(gy.to('cuda', dt))
-        same_y = (y2 == yd).float().mean().item()
-        same_g = (t2.grad == td.grad).float().mean().item()
+        t3 = t.detach().to('cuda', dt).requires_grad_(True)
+        y3 = ops.ln_metapool_residual(t3, g2.detach(), b2.detach(), 1e-6, scd)
+        y3.backward(gy.to('cuda', dt))
+        same_y = (y2 == y3).float().mean().item()
+        same_g = (t2.grad == t3.grad).float().mean().item()
         assert same_y > 0.99 and same_g > 0.98, (same_y, same_g)
 
 
