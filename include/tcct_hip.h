@@ -387,6 +387,13 @@ int tcct_dwconv3x3_dgrad_add(const void* dy, const float* w, const void* res, vo
                              int add_input, int dtype, tcct_stream_t stream);
 int tcct_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C,
                          int stride, int dtype, tcct_stream_t stream);
+/* The depthwise convolution behind a train-mode BatchNorm + Hardswish whose normalisation pass is not run (round 4; Conv2d_BN -> DWConv2d_BN.dwconv and
+ * InvRes.conv1 -> InvRes.dwconv, nets/tcct.py:55-97,114-122,535-543): x is that BatchNorm's INPUT y_prev, xab = {a[C], b[C]}; the kernels apply
+ * z = hswish(a y_prev + b) (rounded to the activation type, zero outside the image) when a row enters the register window.  C % 4 == 0, C <= 256. */
+int tcct_dwconv3x3_fwd_xaff(const void* x, const float* xab, const float* w, const float* bias, void* y, int N, int H, int W, int C, int stride,
+                            double* stats, int dtype, tcct_stream_t stream);
+int tcct_dwconv3x3_wgrad_xaff(const void* x, const float* xab, const void* dy, float* dw, float* dbias, int N, int H, int W, int C, int stride, int dtype,
+                              tcct_stream_t stream);
 
 /* ---- MetaPool on tokens [B,N,C] (nets/tcct.py:405-415,463): AvgPool2d(3,1,1,count_include_pad=False)(x) - x
  * taken over the (token, channel) plane, exactly as torch treats the 3-D tensor --------------------------- */

@@ -118,10 +118,31 @@ template <int STRIDE> struct DwChunk {
 // otherwise cost a separate pass over y
 __device__ __forceinline__ float dw_rnd(float v, const bf16*) { return __bfloat162float(__float2bfloat16(v)); }
 __device__ __forceinline__ float dw_rnd(float v, const float*) { return v; }
+// Round 4: the convolution's input may be y_prev, the input of a train-mode BatchNorm + Hardswish whose normalisation pass was never run (xab = {a[C], b[C]}):
+// z = hswish(a y_prev + b) is applied to every channel vector ONCE, when its row enters the register window, and rounded to the activation type -- the
+// value the separate normalisation pass stored.  Elements outside the image stay zero (the convolution pads z, not y_prev).
+__device__ __forceinline__ Raw<bf16, 4> dw_xf(const Raw<bf16, 4>& r, const float* xa, const float* xb, bool inside) {
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float z = act_c<TCCT_ACT_HSWISH>(xa[k] * r.get(k) + xb[k]); o[k] = inside ? z : 0.f; }
+    Raw<bf16, 4> q;
+    q.v.x = pack_bf16x2(o[0], o[1]); q.v.y = pack_bf16x2(o[2], o[3]);
+    return q;
+}
+__device__ __forceinline__ Raw<float, 4> dw_xf(const Raw<float, 4>& r, const float* xa, const float* xb, bool inside) {
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float z = act_c<TCCT_ACT_HSWISH>(xa[k] * r.get(k) + xb[k]); o[k] = inside ? z : 0.f; }
+    Raw<float, 4> q;
+    q.v = make_float4(o[0], o[1], o[2], o[3]);
+    return q;
+}
+template <typename T> __device__ __forceinline__ Raw<T, 1> dw_xf(const Raw<T, 1>& r, const float*, const float*, bool) { return r; }      // (4-channel vectors only)
 template <typename T, int VEC, int STRIDE, bool FLIP, int CPT = 1>
 __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, int add_input,
-                                               int segh, int wblocks, int hstrips, const T* __restrict__ res, double* __restrict__ stats = nullptr) {
+                                               int segh, int wblocks, int hstrips, const T* __restrict__ res, double* __restrict__ stats = nullptr,
+                                               const float* __restrict__ xab = nullptr) {
     typedef typename std::conditional<sizeof(T) == 4, double, float>::type SAcc;       // fp32 parity mode: fp64 partial sums, like tcct_bn_stats' block combine
     __shared__ SAcc s_red[VEC == 4 ? DB * 8 : 1];
     // res != NULL (output-shaped): y += res -- as input gradient: the gradient reaching the convolution's input through its other consumers
@@ -183,12 +204,28 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
         };
 #pragma unroll
         for (int i = 0; i < ROWSC; ++i) load_row(R[i], p.ho0 * STRIDE - 1 + i, true);
+        float xa[VEC], xb[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { xa[k] = xab ? xab[p.c + k] : 1.f; xb[k] = xab ? xab[C + p.c + k] : 0.f; }
+        auto xf_row = [&](Raw<T, VEC> (&r)[NC], int hi, bool live) {        // the pending normalisation of a freshly loaded row (see dw_xf)
+            const bool rok = live && (unsigned)hi < (unsigned)H;
+#pragma unroll
+            for (int kx = 0; kx < NC; ++kx) r[kx] = dw_xf(r[kx], xa, xb, rok && cin[kx] != DW_OOB);
+        };
+        if (xab) {      // the carried rows of the first chunk; its other rows -- like every later chunk's new rows -- are transformed at the top of the loop
+#pragma unroll
+            for (int i = 0; i < K::CARRY; ++i) xf_row(R[i], p.ho0 * STRIDE - 1 + i, true);
+        }
         load_res(RS, p.ho0);
         for (int ho = p.ho0; ho < p.ho1; ho += RBC) {
             const bool more = ho + RBC < p.ho1;           // rows of a chunk beyond the strip are not fetched
 #pragma unroll
             for (int i = 0; i < NEWC; ++i) load_row(NX[i], (ho + RBC) * STRIDE - 1 + K::CARRY + i, more);
             load_res(RSN, ho + RBC);
+            if (xab) {  // AFTER the next chunk's loads are in flight: transforming at the copy below left the VALU work with nothing outstanding (0.115 -> 0.150 ms)
+#pragma unroll
+                for (int i = 0; i < NEWC; ++i) xf_row(R[K::CARRY + i], ho * STRIDE - 1 + K::CARRY + i, true);
+            }
 #pragma unroll
             for (int j = 0; j < RBC; ++j) {
 #pragma unroll
@@ -293,7 +330,7 @@ static void dw_geometry(int N, int Ho, int Wo, int C, int vec, int target_blocks
 
 template <typename T, int VEC, bool FLIP>
 static void dw_fwd_launch(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C, int stride,
-                          int Ho, int Wo, int add_input, hipStream_t st, const void* res = nullptr, double* stats = nullptr) {
+                          int Ho, int Wo, int add_input, hipStream_t st, const void* res = nullptr, double* stats = nullptr, const float* xab = nullptr) {
     int segh, wblocks, hstrips;
     // four columns per thread for the wide bf16 stride-1 images (levels 1-2 of the ViT branch); TCCT_DW_CPT=1 keeps one column (A/B)
     static int cpt_on = -1;
@@ -301,13 +338,13 @@ static void dw_fwd_launch(const void* x, const float* w, const float* bias, void
     if (stride == 1 && VEC == 4 && sizeof(T) == 2 && cpt_on && Wo >= 128 && C >= 32) {      // measured +4 % at 64 channels, slower at 4
         dw_geometry(N, Ho, Wo, C, VEC, 1024, 32, segh, wblocks, hstrips, 4);
         dim3 g4((unsigned)((int64_t)N * wblocks * hstrips));
-        hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP, (VEC == 4 ? 4 : 1)>), g4, dim3(DB), 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats);
+        hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP, (VEC == 4 ? 4 : 1)>), g4, dim3(DB), 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab);
         return;
     }
     dw_geometry(N, Ho, Wo, C, VEC, 1024, 32, segh, wblocks, hstrips);
     dim3 g((unsigned)((int64_t)N * wblocks * hstrips)), b(DB);
-    if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats);
-    else hipLaunchKernelGGL((k_dw_fwd<T, VEC, 2, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats);
+    if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab);
+    else hipLaunchKernelGGL((k_dw_fwd<T, VEC, 2, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab);
 }
 
 extern "C" int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
@@ -334,6 +371,17 @@ extern "C" int tcct_dwconv3x3_fwd_bnstats(const void* x, const float* w, const f
     TCCT_CHECK((int64_t)H * W * C * 4 < (1ll << 31), "dwconv3x3_fwd_bnstats: one image of %d x %d x %d elements exceeds the 32-bit byte offsets of the kernels", H, W, C);
     int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, false>(x, w, bias, y, N, H, W, C, stride, Ho, Wo, add_input, (hipStream_t)stream, nullptr, stats)));
+    TCCT_LAUNCH_OK();
+}
+/* forward with the normalisation of the train-mode BatchNorm + Hardswish IN FRONT applied on load (round 4): x is that BatchNorm's input y_prev, xab = {a[C], b[C]}
+ * (z = hswish(a y_prev + b), rounded to the activation type, zero outside the image); stats nullable (as tcct_dwconv3x3_fwd_bnstats).  C % 4 == 0, C <= 256. */
+extern "C" int tcct_dwconv3x3_fwd_xaff(const void* x, const float* xab, const float* w, const float* bias, void* y, int N, int H, int W, int C, int stride,
+                                       double* stats, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(stride == 1 || stride == 2, "dwconv3x3_fwd_xaff: stride %d", stride);
+    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1 && C >= 4 && C % 4 == 0 && C <= DB && xab != nullptr, "dwconv3x3_fwd_xaff: needs C %% 4 == 0, C <= 256, xab");
+    TCCT_CHECK((int64_t)H * W * C * 4 < (1ll << 31), "dwconv3x3_fwd_xaff: one image of %d x %d x %d elements exceeds the 32-bit byte offsets of the kernels", H, W, C);
+    int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, false>(x, w, bias, y, N, H, W, C, stride, Ho, Wo, 0, (hipStream_t)stream, nullptr, stats, xab)));
     TCCT_LAUNCH_OK();
 }
 
@@ -518,7 +566,8 @@ extern "C" int tcct_dwconv3x3_dgrad_add(const void* dy, const float* w, const vo
 template <typename T, int VEC, int STRIDE, int CPT = 1>
 __global__ void __launch_bounds__(DB) k_dw_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
                                                  float* __restrict__ dbias, int N, int H, int W, int C, int Ho, int Wo, int segh,
-                                                 int wblocks, int hstrips) {
+                                                 int wblocks, int hstrips, const float* __restrict__ xab = nullptr) {
+    // xab != NULL (4-channel vectors): x is y_prev with z = hswish(a y_prev + b) pending (see dw_xf): the weight gradient is taken against z
     static_assert(CPT == 1 || (STRIDE == 1 && VEC == 4), "several columns per thread: stride 1, 4-channel vectors");
     constexpr int NC = CPT + 2;
     extern __shared__ float sm[];   // [DB][10*VEC]
@@ -561,12 +610,28 @@ __global__ void __launch_bounds__(DB) k_dw_wgrad(const T* __restrict__ x, const 
         };
 #pragma unroll
         for (int i = 0; i < K::ROWS; ++i) load_row(R[i], p.ho0 * STRIDE - 1 + i, true);
+        float xa[VEC], xb[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { xa[k] = xab ? xab[p.c + k] : 1.f; xb[k] = xab ? xab[C + p.c + k] : 0.f; }
+        auto xf_row = [&](Raw<T, VEC> (&r)[NC], int hi, bool live) {
+            const bool rok = live && (unsigned)hi < (unsigned)H;
+#pragma unroll
+            for (int kx = 0; kx < NC; ++kx) r[kx] = dw_xf(r[kx], xa, xb, rok && cin[kx] != DW_OOB);
+        };
+        if (xab) {
+#pragma unroll
+            for (int i = 0; i < K::CARRY; ++i) xf_row(R[i], p.ho0 * STRIDE - 1 + i, true);
+        }
         load_g(G, p.ho0);
         for (int ho = p.ho0; ho < p.ho1; ho += K::RB) {
             const bool more = ho + K::RB < p.ho1;
 #pragma unroll
             for (int i = 0; i < K::NEW; ++i) load_row(NX[i], (ho + K::RB) * STRIDE - 1 + K::CARRY + i, more);
             load_g(GX, ho + K::RB);
+            if (xab) {  // this chunk's new rows, with the next chunk's loads in flight (see k_dw_fwd)
+#pragma unroll
+                for (int i = 0; i < K::NEW; ++i) xf_row(R[K::CARRY + i], ho * STRIDE - 1 + K::CARRY + i, true);
+            }
 #pragma unroll
             for (int j = 0; j < K::RB; ++j) {
 #pragma unroll
@@ -655,8 +720,20 @@ __global__ void __launch_bounds__(DB) k_dw_wgrad(const T* __restrict__ x, const 
     }
 }
 
+static int dw_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C, int stride, int dtype, tcct_stream_t stream,
+                         const float* xab);
 extern "C" int tcct_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C,
                                     int stride, int dtype, tcct_stream_t stream) {
+    return dw_wgrad_impl(x, dy, dw, dbias, N, H, W, C, stride, dtype, stream, nullptr);
+}
+/* weight gradient against z = hswish(a y_prev + b) rebuilt on load from x = y_prev (see tcct_dwconv3x3_fwd_xaff); C % 4 == 0 */
+extern "C" int tcct_dwconv3x3_wgrad_xaff(const void* x, const float* xab, const void* dy, float* dw, float* dbias, int N, int H, int W, int C,
+                                         int stride, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(xab != nullptr && C % 4 == 0, "dwconv3x3_wgrad_xaff: needs xab and C %% 4 == 0");
+    return dw_wgrad_impl(x, dy, dw, dbias, N, H, W, C, stride, dtype, stream, xab);
+}
+static int dw_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C, int stride, int dtype, tcct_stream_t stream,
+                         const float* xab) {
     TCCT_CHECK(stride == 1 || stride == 2, "dwconv3x3_wgrad: stride %d", stride);
     TCCT_CHECK(N >= 1 && H >= 1 && W >= 1 && C >= 1, "dwconv3x3_wgrad: empty tensor");
     int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
@@ -673,12 +750,12 @@ extern "C" int tcct_dwconv3x3_wgrad(const void* x, const void* dy, float* dw, fl
     if (cpt_on && vec == 4 && stride == 1 && dtype == TCCT_BF16 && Wo >= 128 && C >= 32) {
         dw_geometry(N, Ho, Wo, C, vec, 512, 128, segh, wblocks, hstrips, 2);
         hipLaunchKernelGGL((k_dw_wgrad<bf16, 4, 1, 2>), dim3((unsigned)((int64_t)N * wblocks * hstrips)), dim3(DB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias,
-                           N, H, W, C, Ho, Wo, segh, wblocks, hstrips);
+                           N, H, W, C, Ho, Wo, segh, wblocks, hstrips, xab);
         TCCT_LAUNCH_OK();
     }
     dw_geometry(N, Ho, Wo, C, vec, 512, 128, segh, wblocks, hstrips);
     dim3 grid((unsigned)((int64_t)N * wblocks * hstrips));
-#define DWG(V, S) hipLaunchKernelGGL((k_dw_wgrad<T, V, S>), grid, dim3(DB), lds, st, (const T*)x, (const T*)dy, dw, dbias, N, H, W, C, Ho, Wo, segh, wblocks, hstrips)
+#define DWG(V, S) hipLaunchKernelGGL((k_dw_wgrad<T, V, S>), grid, dim3(DB), lds, st, (const T*)x, (const T*)dy, dw, dbias, N, H, W, C, Ho, Wo, segh, wblocks, hstrips, xab)
     if (vec == 4) { TCCT_DISPATCH(dtype, if (stride == 1) DWG(4, 1); else DWG(4, 2)); }
     else { TCCT_DISPATCH(dtype, if (stride == 1) DWG(1, 1); else DWG(1, 2)); }
 #undef DWG

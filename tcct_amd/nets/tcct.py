@@ -23,8 +23,8 @@ def _conv(m, x, out_dtype=None, stats_pre=None):
     return ops.conv2d(x, m.weight, m.bias, stride=m.stride[0], pad=tuple(m.padding), out_dtype=out_dtype, stats_pre=stats_pre)
 
 
-def _dw(m, x, add_input=False, bn_stats=False):
-    return ops.dwconv3x3(x, m.weight, m.bias, stride=m.stride[0], add_input=add_input, bn_stats=bn_stats)
+def _dw(m, x, add_input=False, bn_stats=False, deferred=None):
+    return ops.dwconv3x3(x, m.weight, m.bias, stride=m.stride[0], add_input=add_input, bn_stats=bn_stats, deferred=deferred)
 
 
 def _bn(m, x, pre=None, post=None, residual=None):
@@ -179,6 +179,17 @@ class Conv2d_BN(nn.Module):
                                   infer_bn=(m.weight, m.bias, m.running_mean, m.running_var, m.eps))
         return _conv_bn(self.conv, self.bn, x, post='hswish' if self.act else None, residual=residual, x_final=x_final)
 
+    def forward_deferred(self, x):
+        """(y, link) with the BatchNorm + Hardswish of this layer PENDING on y for the one consumer, a depthwise convolution (round 4: stem[1] -> the first
+        patch embedding), or None when that form does not apply"""
+        if not (ops.BN_DEFER_DW and self.act and self.bn.training and self.conv.in_channels != 3):
+            return None
+        y = _conv(self.conv, x, stats_pre='none')
+        m = self.bn
+        if not ops.batchnorm_deferred_ok(y, True, 'hswish'):
+            return _bn(m, y, post='hswish'), None
+        return ops.batchnorm_deferred(y, m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked, m.eps, m.momentum, 'hswish')
+
 
 class DWConv2d_BN(nn.Module):
     """reference nets/tcct.py:99-147: dw3x3 -> pw1x1 -> BN -> Hardswish"""
@@ -192,14 +203,15 @@ class DWConv2d_BN(nn.Module):
             n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
             m.weight.data.normal_(0, math.sqrt(2.0 / n))
 
-    def forward(self, x, fork=False):
+    def forward(self, x, fork=False, deferred=None):
         """fork: also return an alias of x for its other consumer (the stage output also feeds FTC's tran_vit convolution): that
-        gradient is added inside the depthwise input-gradient kernel"""
+        gradient is added inside the depthwise input-gradient kernel.  deferred: x carries a pending BatchNorm + Hardswish (ops.batchnorm_deferred)
+        that the depthwise kernels apply on load"""
         if fork:
             m = self.dwconv
             d, alias = ops.dwconv3x3_fork(x, m.weight, m.bias, stride=m.stride[0])
             return _conv_bn(self.pwconv, self.bn, d, post='hswish'), alias
-        return _conv_bn(self.pwconv, self.bn, _dw(self.dwconv, x), post='hswish')
+        return _conv_bn(self.pwconv, self.bn, _dw(self.dwconv, x, deferred=deferred), post='hswish')
 
 
 class DWCPatchEmbed(nn.Module):
@@ -209,8 +221,8 @@ class DWCPatchEmbed(nn.Module):
         super().__init__()
         self.patch_conv = DWConv2d_BN(embed_dim, embed_dim, 3, stride)
 
-    def forward(self, x, fork=False):
-        return self.patch_conv(x, fork)
+    def forward(self, x, fork=False, deferred=None):
+        return self.patch_conv(x, fork, deferred)
 
 
 class Patch_Embed_stage(nn.Module):
@@ -220,8 +232,8 @@ class Patch_Embed_stage(nn.Module):
         super().__init__()
         self.patch_embeds = nn.ModuleList([DWCPatchEmbed(embed_dim, 2 if isPool else 1)])
 
-    def forward(self, x, fork=False):
-        return self.patch_embeds[0](x, fork)
+    def forward(self, x, fork=False, deferred=None):
+        return self.patch_embeds[0](x, fork, deferred)
 
 
 class ConvPosEnc(nn.Module):
@@ -374,8 +386,9 @@ class ResBlock(nn.Module):
     def forward(self, x):
         return self.tail(self.conv1(x), x)
 
-    def tail(self, f, x):
-        y = _dw(self.dwconv, f, bn_stats=self.norm.training)                                        # statistics out of the convolution's launch
+    def tail(self, f, x, flink=None):
+        """flink: f is conv1's output with its BatchNorm + Hardswish pending (MHCA_stage.forward)"""
+        y = _dw(self.dwconv, f, bn_stats=self.norm.training, deferred=flink)                        # statistics out of the convolution's launch
         c2, m = self.conv2, self.norm
         if (ops.batchnorm_deferred_ok(y, m.training, 'hswish') and c2.bn.training and not c2.act
                 and ops.pw_conv_bn_ok(y, c2.conv.weight, None, True, None, None)):
@@ -402,14 +415,19 @@ class MHCA_stage(nn.Module):
             # x has three consumers (InvRes.conv1, ConvPosEnc, the InvRes residual).  They read a chain of aliases so that each
             # input-gradient kernel adds the gradient of the consumers behind it: no separate accumulation passes over x
             c1 = self.InvRes.conv1
+            flink = None
             if ops.pw_conv_bn_ok(x, c1.conv.weight, None, c1.bn.training, None, 'hswish'):
                 # conv1's input gradient + the alias' gradient is the complete gradient of x (= the patch embedding's BatchNorm output)
-                f, x1 = ops.pw_conv_bn(x, c1.conv.weight, None, _bn_args(c1.bn), 'hswish', fork=True, x_final=True)
+                if ops.BN_DEFER_DW and x.shape[-1] % 4 == 0 and x.shape[-1] <= 256:
+                    # ... and conv1's normalisation + Hardswish is applied by InvRes.dwconv's kernels as rows enter their window: f is never written
+                    (f, x1), flink = ops.pw_conv_bn(x, c1.conv.weight, None, _bn_args(c1.bn), 'hswish', fork=True, x_final=True, defer_apply=True)
+                else:
+                    f, x1 = ops.pw_conv_bn(x, c1.conv.weight, None, _bn_args(c1.bn), 'hswish', fork=True, x_final=True)
             else:
                 f, x1 = ops.conv2d_fork(x, c1.conv.weight, None, 1, 0, stats_pre='none' if c1.bn.training else None)
                 f = _bn(c1.bn, f, post='hswish')
             e, x2 = self.mhca_blks[0](x1, scales, fork=True)
-            r = self.InvRes.tail(f, x2)
+            r = self.InvRes.tail(f, x2, flink)
         else:
             r = self.InvRes(x)
             e = self.mhca_blks[0](x, scales)
@@ -491,14 +509,16 @@ class MPViT(nn.Module):
     def iter_stages(self, x, xs):
         """generator form of forward_features(): appends one stage output to `xs` per step"""
         scales = self._dp_scales(x.shape[0], x.device)
-        x = self.stem[1](self.stem[0](x))
+        x = self.stem[0](x)
+        d0 = self.stem[1].forward_deferred(x)       # stem[1]'s normalisation rides on the first patch embedding's depthwise kernels
+        x, link0 = d0 if d0 is not None else (self.stem[1](x), None)
         for i in range(4):
             if i == 1:                  # data-parallel runs: crossing this edge backwards means stages 1-3 are done (tcct_amd/dist.py)
                 x = ops.grad_mark(x, 'deep')
             if i > 0 and torch.is_grad_enabled() and x.requires_grad:
                 p, xs[-1] = self.patch_embed_stages[i](x, fork=True)    # the returned level is the alias (read by FTC.tran_vit)
             else:
-                p = self.patch_embed_stages[i](x)
+                p = self.patch_embed_stages[i](x, deferred=link0 if i == 0 else None)
             x = self.mhca_stages[i](p, scales[i])
             xs.append(x)
             yield i

@@ -1347,15 +1347,26 @@ def conv3x3_c3_bn(x4, w, bias, bn, stride=1, post_act=None):
 
 class _DwConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, add_input, fork=False, stats_box=None):
+    def forward(ctx, x, w, bias, stride, add_input, fork=False, stats_box=None, xab=None):
         """fork: also return an alias of x for its other consumers; their gradient is added inside the input-gradient kernel.
-        stats_box ([None]): the kernel also accumulates the statistics of the train-mode BatchNorm that consumes the output"""
+        stats_box ([None]): the kernel also accumulates the statistics of the train-mode BatchNorm that consumes the output.
+        xab (round 4): x is y_prev, the input of a train-mode BatchNorm + Hardswish in front whose normalisation pass was not run (xab = its {a[C], b[C]});
+        the kernels apply z = hswish(a y_prev + b) as rows enter their register window.  The gradient returned for x is the gradient of that z."""
         ctx.set_materialize_grads(False)      # an unused output must arrive as None in backward(), not as a zero-filled tensor
         _chk(x, w, bias)
         N, H, W, C = x.shape
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         y = torch.empty((N, Ho, Wo, C), device=x.device, dtype=x.dtype)
-        if stats_box is not None and C % 4 == 0 and C <= 256:
+        ctx.xab = xab
+        if xab is not None:
+            if add_input or fork or C % 4 or C > 256:
+                raise TcctError('dwconv3x3(deferred=...): plain convolution with C % 4 == 0, C <= 256 only')
+            sums = None
+            if stats_box is not None:
+                sums = ZERO.get((2 * C,), torch.float64, x.device) if ZERO.active else torch.zeros(2 * C, device=x.device, dtype=torch.float64)
+                stats_box[0] = sums
+            lib.dwconv3x3_fwd_xaff(x, xab, w, bias, y, N, H, W, C, stride, sums, dtype_code(x.dtype))
+        elif stats_box is not None and C % 4 == 0 and C <= 256:
             sums = ZERO.get((2 * C,), torch.float64, x.device) if ZERO.active else torch.zeros(2 * C, device=x.device, dtype=torch.float64)
             lib.dwconv3x3_fwd_bnstats(x, w, bias, y, N, H, W, C, stride, int(add_input), sums, dtype_code(x.dtype))
             stats_box[0] = sums
@@ -1371,7 +1382,7 @@ class _DwConv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, add_input, has_bias = ctx.cfg
         if dy is None:
-            return dskip, None, None, None, None, None, None
+            return dskip, None, None, None, None, None, None, None
         dy = _as(dy, x.dtype)
         N, H, W, C = x.shape
         dx = dw = db = None
@@ -1384,19 +1395,24 @@ class _DwConv(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw = _grad_out(w)
             db = _grad_out(ctx.bias_param) if has_bias else None
-            lib.dwconv3x3_wgrad(x, dy, dw, db, N, H, W, C, stride, dtype_code(x.dtype))
-        return dx, _ret(dw, w), _ret(db, ctx.bias_param), None, None, None, None
+            if ctx.xab is not None:
+                lib.dwconv3x3_wgrad_xaff(x, ctx.xab, dy, dw, db, N, H, W, C, stride, dtype_code(x.dtype))
+            else:
+                lib.dwconv3x3_wgrad(x, dy, dw, db, N, H, W, C, stride, dtype_code(x.dtype))
+        return dx, _ret(dw, w), _ret(db, ctx.bias_param), None, None, None, None, None
 
 
-def dwconv3x3(x, w, bias=None, stride=1, add_input=False, bn_stats=False):
-    """bn_stats: a train-mode BatchNorm (no activation in front) consumes the output: its statistics come out of the same launch (`_bn_sums`)"""
+def dwconv3x3(x, w, bias=None, stride=1, add_input=False, bn_stats=False, deferred=None):
+    """bn_stats: a train-mode BatchNorm (no activation in front) consumes the output: its statistics come out of the same launch (`_bn_sums`).
+    deferred: the BnLink of a BatchNorm + Hardswish whose normalisation is pending on x (batchnorm_deferred / pw_conv_bn(defer_apply=True))"""
+    xab = deferred.ab if deferred is not None else None
     if bn_stats:
         box = [None]
-        y = _DwConv.apply(x, w, bias, stride, add_input, False, box)
+        y = _DwConv.apply(x, w, bias, stride, add_input, False, box, xab)
         if box[0] is not None:
             y._bn_sums = (box[0], ACT['none'])
         return y
-    return _DwConv.apply(x, w, bias, stride, add_input, False)
+    return _DwConv.apply(x, w, bias, stride, add_input, False, None, xab)
 
 
 def dwconv3x3_fork(x, w, bias=None, stride=1, add_input=False):
@@ -1505,7 +1521,7 @@ class _PwConvBN(torch.autograd.Function):
     of the BatchNorm in FRONT of the convolution in its epilogue (`prev`).  x2: second half of a concatenated input (MHCA_stage.aggregate)."""
 
     @staticmethod
-    def forward(ctx, x, x2, w, bias, gamma, beta, rm, rv, nbt, eps, momentum, post, res, fork, link, prev, xdef=None):
+    def forward(ctx, x, x2, w, bias, gamma, beta, rm, rv, nbt, eps, momentum, post, res, fork, link, prev, xdef=None, defer_apply=False):
         """xdef (round 4): x is NOT the convolution's input but y_prev, the input of a train-mode BatchNorm + Hardswish in front whose normalisation
         was deferred (batchnorm_deferred): xdef = its {a[K], b[K]}; the kernels apply hswish(a y_prev + b) while they stage their tiles"""
         ctx.set_materialize_grads(False)
@@ -1524,8 +1540,12 @@ class _PwConvBN(torch.autograd.Function):
             lib.pw_fwd_bnstats(x, w, bias, y, M, K, N, sums, 0)
         mean_rstd = torch.empty(2 * N, device=x.device, dtype=torch.float32)
         ab = torch.empty(2 * N, device=x.device, dtype=torch.float32)
-        z = torch.empty_like(y)
-        lib.bn_apply_train(y, res, z, M, N, sums, gamma, beta, eps, momentum, rm, rv, nbt, mean_rstd, ab, 0, post, dtype_code(y.dtype))
+        if defer_apply:     # round 4: the normalisation pass is left to the one consumer (a depthwise convolution built with `deferred=link`): z is never written
+            lib.bn_finalize(sums, M, N, gamma, beta, eps, momentum, rm, rv, nbt, mean_rstd, ab)
+            z = y.view_as(y)
+        else:
+            z = torch.empty_like(y)
+            lib.bn_apply_train(y, res, z, M, N, sums, gamma, beta, eps, momentum, rm, rv, nbt, mean_rstd, ab, 0, post, dtype_code(y.dtype))
         ctx.save_for_backward(x, x2, w, y, mean_rstd, ab)
         wsrc = w if hasattr(w, '_grad_slot') or w._base is None else w._base
         ctx.cfg = (post, res is not None, wsrc, bias, gamma, beta, link, prev, M, K, N)
@@ -1538,7 +1558,7 @@ class _PwConvBN(torch.autograd.Function):
         x, x2, w, y, mean_rstd, ab = ctx.saved_tensors
         post, has_res, wsrc, bsrc, gamma, beta, link, prev, M, K, N = ctx.cfg
         if dz is None:
-            return (dalias,) + (None,) * 16
+            return (dalias,) + (None,) * 17
         dz = _as(dz, y.dtype)
         if link.sums is not None:               # a consumer's dx epilogue already holds the two batch sums (raw form)
             sums, raw = link.sums, 1
@@ -1564,9 +1584,10 @@ class _PwConvBN(torch.autograd.Function):
         else:
             lib.pw_bwd_bn_sums(x, x2, dz, y, sums, raw, mean_rstd, ab, dg, db_, post, w, dskip, dx, dx2, dw, dbias, M, K, N, ypv, abp, redp, sp)
         return (dx, dx2, _ret(dw, wsrc), _ret(dbias, bsrc), _ret(dg, gamma), _ret(db_, beta), None, None, None, None, None, None,
-                (dz if has_res else None), None, None, None, None)
+                (dz if has_res else None), None, None, None, None, None)
 
 
+BN_DEFER_DW = os.environ.get('TCCT_BN_DEFER_DW', '1') != '0'  # =0: the BatchNorms in front of the depthwise convolutions keep their normalisation pass (A/B timing)
 BN_DEFER = os.environ.get('TCCT_BN_DEFER', '1') != '0'        # =0: InvRes.norm keeps its own normalisation pass (round-3 form; A/B timing)
 
 
@@ -1638,7 +1659,7 @@ def pw_conv_bn_ok(x, w, bias, bn_training, pre_act, post_act, x2=None, prev=None
     return bool(lib.pw_bwd_bn_supported(K, N, ACT[post_act], -1 if prev is None else prev.post, 1 if x2 is not None else 0))
 
 
-def pw_conv_bn(x, w, bias, bn, post_act=None, residual=None, fork=False, x2=None, x_final=False, deferred=None):
+def pw_conv_bn(x, w, bias, bn, post_act=None, residual=None, fork=False, x2=None, x_final=False, deferred=None, defer_apply=False):
     """post_act(BN_train(conv1x1(x [| x2]))) [+ residual]; bn = (gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum).
     fork: also return an alias of x for its other consumers (their gradient is added in this node's dx epilogue).  x_final: this
     convolution's input gradient (+ the alias') is the complete gradient of x -- when x came out of a BatchNorm node, that BatchNorm's
@@ -1658,6 +1679,12 @@ def pw_conv_bn(x, w, bias, bn, post_act=None, residual=None, fork=False, x2=None
     prev = _bn_link_of(x, x_final)
     if prev is not None and not pw_conv_bn_ok(x, w, bias, True, None, post_act, x2, prev):
         prev = None
+    if defer_apply:
+        # the caller hands the result (y with the normalisation + Hardswish PENDING) and `link` to dwconv3x3(..., deferred=link) and to nothing else
+        if residual is not None or x2 is not None or ACT[post_act] != ACT['hswish']:
+            raise TcctError('pw_conv_bn(defer_apply=True): BatchNorm + Hardswish without residual / concatenation only')
+        out = _PwConvBN.apply(x, None, w4, bias, gamma, beta, rm, rv, nbt, float(eps), float(mom), ACT[post_act], None, fork, link, prev, None, True)
+        return out, link
     out = _PwConvBN.apply(x, x2, w4, bias, gamma, beta, rm, rv, nbt, float(eps), float(mom), ACT[post_act], residual, fork, link, prev)
     z = out[0] if fork else out
     z._bn_link = link               # (with a residual folded in z is BN output + res, but the gradient of the BatchNorm output still is dz)

@@ -1,6 +1,7 @@
 """HIP kernel parity (through the C-ABI) against plain PyTorch CPU fp32 references of the same op."""
 import pytest
 import torch
+import torch.nn as nn
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
@@ -838,6 +839,70 @@ def test_invres_norm_applied_inside_conv2_equals_the_separate_pass(dim):
         e = (a[k] - b[k]).norm().item() / max(b[k].norm().item(), 1e-12)
         assert e < 2e-3, (k, e)          # atomics reorder the fp32 sums; the input gradients see them through the BatchNorm coefficients
     assert (a['df'] != 0).any() and 'g:dwconv.weight' in a and 'g:norm.weight' in a
+
+
+@pytest.mark.parametrize('site', ['stage64', 'stage96', 'stem', 'stage64_odd'])
+def test_depthwise_applies_the_pending_batchnorm_equals_the_separate_pass(site):
+    """round 4 (ops.BN_DEFER_DW; tcct_dwconv3x3_fwd_xaff / _wgrad_xaff): the BatchNorm + Hardswish in front of a depthwise convolution -- InvRes.conv1.bn ->
+    InvRes.dwconv inside an MHCA stage, and stem[1].bn -> the first patch embedding's dwconv (reference nets/tcct.py:55-97,114-122,535-543,674-681) -- is
+    applied by the depthwise kernels when a row enters their register window, rounded to bf16 like the stored tensor it replaces, zero outside the image.
+    Outputs and running statistics must be IDENTICAL to the separate-pass form, gradients equal to atomic-order noise; odd image extents exercise the
+    padding mask (hswish(b) != 0 must not leak into the border taps)"""
+    import importlib
+    from tcct_amd import ops
+    T = importlib.import_module('tcct_amd.nets.tcct')
+    torch.manual_seed(11)
+    res = {}
+    if site == 'stem':
+        Hh, Ww, cin = 24, 40, 32
+    elif site == 'stage64_odd':
+        Hh, Ww, cin = 13, 21, 64
+    else:
+        Hh, Ww, cin = 24, 40, int(site[5:])
+    x0 = rnd(2, cin, Hh, Ww, dt=torch.bfloat16)
+
+    def build():
+        torch.manual_seed(5)
+        if site == 'stem':
+            m = nn.ModuleList([T.Conv2d_BN(32, 64, 3, 1, 1, act=True), T.Patch_Embed_stage(64)])
+        else:
+            m = T.MHCA_stage(cin, cin + 32, 4, 1, 0.0)
+        with torch.no_grad():
+            for i, bn in enumerate(mm for mm in m.modules() if isinstance(mm, nn.BatchNorm2d)):
+                bn.weight.copy_(1.0 + 0.2 * rnd(bn.num_features, seed=30 + i)); bn.bias.copy_(0.3 * rnd(bn.num_features, seed=60 + i))
+        return m
+    sd = {k: v.clone() for k, v in build().state_dict().items()}
+    for defer in (True, False):
+        ops.BN_DEFER_DW = defer
+        try:
+            m = build()
+            m.load_state_dict(sd)
+            m = m.cuda().train()
+            x = nhwc(x0, torch.bfloat16).requires_grad_(True)
+            if site == 'stem':
+                d0 = m[0].forward_deferred(x)
+                assert (d0 is not None and d0[1] is not None) == defer
+                h, link = d0 if d0 is not None else (m[0](x), None)
+                out = m[1](h, deferred=link)
+            else:
+                out = m(x, None)
+            gy = rnd(*out.shape, seed=9).permute(0, 3, 1, 2)
+            out.backward(gy.permute(0, 2, 3, 1).contiguous().to('cuda', torch.bfloat16))
+            res[defer] = dict(out=out.detach().float().cpu(), dx=x.grad.float().cpu(),
+                              **{'b:' + n: b_.float().cpu().clone() for n, b_ in m.named_buffers()},
+                              **{'g:' + n: p_.grad.float().cpu() for n, p_ in m.named_parameters() if p_.grad is not None})
+        finally:
+            ops.BN_DEFER_DW = True
+    a, b = res[True], res[False]
+    assert set(a) == set(b)
+    assert torch.equal(a['out'], b['out'])
+    for k in a:
+        if k.startswith('b:'):
+            assert torch.equal(a[k], b[k]), k
+        elif k != 'out':
+            e = (a[k] - b[k]).norm().item() / max(b[k].norm().item(), 1e-12)
+            assert e < 2e-3, (k, e)
+    assert (a['dx'] != 0).any() and any('dwconv.weight' in k for k in a)
 
 
 def test_flat_adamw_state_refuses_a_permuted_layout():
