@@ -288,8 +288,12 @@ def ftc_forward(sd, x, train=True, dp_masks=None, p='base', want=None, feats_use
         if not feats_used and sd[p + '.aux0.weight'].shape[0] <= 8:
             # ... and through aux0 when the feature-polarization loss is off (nothing else reads g0): logits0 straight from [up(y) | skip] with the
             # weight W3 [W2 W1 | W2 W1 + W2] rounded once; g0 above then only serves `feats` (rebuilt on demand, outside the gradient)
+            # The resize is taken BEHIND the convolution (bilinear interpolation is linear and per channel: W up(y) = up(W y)): z = (W3 A) y at the low
+            # resolution in fp32, logits0 = up(z) + W3 (A + W2) skip + const; the resized 32-channel tensor and its bf16 store do not exist on this path.
             w3, b3 = sd[p + '.aux0.weight'][:, :, 0, 0], sd[p + '.aux0.bias']
-            y0_direct = F.conv2d(torch.cat([vv, f[0]], 1), _W(w3 @ torch.cat([A, A + w2], 1))[:, :, None, None], w3 @ (w2 @ b1 + b2) + b3)
+            zlow = F.conv2d(yv, _W(w3 @ A)[:, :, None, None])
+            y0_direct = (F.interpolate(zlow, scale_factor=2, mode='bilinear', align_corners=True)
+                         + F.conv2d(f[0], _W(w3 @ (A + w2))[:, :, None, None], w3 @ (w2 @ b1 + b2) + b3))
             g0 = g0.detach()
     else:
         d0 = _up_block(sd, p + '.dec4', d1, f[0], train)

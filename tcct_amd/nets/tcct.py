@@ -556,8 +556,11 @@ class MPUpBlock(nn.Module):
             return None
         y = _conv_bn(self.prep[0], self.prep[1], x1, post='lrelu')
         if aux is not None and ops.up_skip_conv_t32_aux_ok(probe, x2, p.weight, p.bias, t.weight, t.bias, aux.weight, aux.bias):
-            # nothing but the aux head reads g0 in this step: (fp32 logits, resized y) -- g0 is never written
-            return ops.up_skip_conv_t32_aux(y, x2, p.weight, p.bias, t.weight, t.bias, aux.weight, aux.bias, True)
+            # nothing but the aux head reads g0 in this step: (fp32 logits, what `feats` would rebuild g0 from) -- g0 is never written
+            if ops.TAIL_AUX_LOW:    # ... and the resize is taken of the n_class-channel product at the low resolution: up(y) is never written either
+                return ops.up_skip_conv_t32_aux_low(y, x2, p.weight, p.bias, t.weight, t.bias, aux.weight, aux.bias, True), ('y', y.detach())
+            lg, v = ops.up_skip_conv_t32_aux(y, x2, p.weight, p.bias, t.weight, t.bias, aux.weight, aux.bias, True)
+            return lg, ('v', v)
         return ops.up_skip_conv_t32(y, x2, p.weight, p.bias, t.weight, t.bias, True)
 
 
@@ -693,9 +696,10 @@ class FTC(nn.Module):
             # loss is off (nothing else reads g0 then; `feats` rebuilds it on demand)
             g0 = self.dec4.forward_through(d1, f[0], self.t324, aux=None if self.eager_feats else self.aux0)
             if isinstance(g0, tuple):
-                y0_direct, v_up = g0
+                y0_direct, (kind, src) = g0
                 skip0, pw, tw = f[0], self.dec4.post[0], self.t324
-                g0 = lambda: ops.up_skip_conv_t32_from_v(v_up, skip0, pw.weight, pw.bias, tw.weight, tw.bias)      # noqa: E731
+                rebuild = ops.up_skip_conv_t32_from_v if kind == 'v' else ops.up_skip_conv_t32_from_y
+                g0 = lambda: rebuild(src, skip0, pw.weight, pw.bias, tw.weight, tw.bias)      # noqa: E731
             if g0 is None:
                 d0, s0 = self.dec4(d1, f[0], with_sum=True, want_plain=False)      # only x_0 + y_0 is read below: d0 is never written
                 g0 = _conv(self.t324, s0)

@@ -1056,6 +1056,75 @@ class _UpSkipConvT32Aux(torch.autograd.Function):
         return (dy, dskip) + tuple(_ret(o, p) for o, p in zip(outs, params)) + (None,)
 
 
+class _UpSkipConvT32AuxLow(torch.autograd.Function):
+    """The same logits0 = aux0(t32(post(up(y) + skip) + skip)) with the resize COMMUTED behind the 1x1 convolution (round 4): bilinear interpolation is linear
+    and acts per channel, so  W up(y) = up(W y):
+        logits0 = up(Wa y) + Wb skip + c,      Wa = W3 W2 W1 [C x 32] applied at the LOW resolution,  Wb = W3 (W2 W1 + W2),  c = W3 (W2 b1 + b2) + b3
+    z = Wa y is n_class channels at a quarter of the pixels (fp32); the resized 32-channel tensor v = up(y) (452 MB at the bench shape) is never written or
+    read, and neither is its gradient: backward = bilinear^T on n_class channels, two small-N input-gradient kernels, two small-N weight-gradient
+    kernels (one of them at the low resolution) and the de-composition of `compose3`."""
+
+    @staticmethod
+    def forward(ctx, y, skip, w1, b1, w2, b2, w3, b3, align):
+        _chk(y, skip, w1, b1, w2, b2, w3, b3)
+        N_, H, W_, C = y.shape
+        _, Ho, Wo, _ = skip.shape
+        dev, nc = y.device, w3.shape[0]
+        F32_ = dtype_code(torch.float32)
+        wcc = torch.empty((nc, 64), device=dev, dtype=torch.float32)
+        wa, wb = torch.empty((nc, 32, 1, 1), device=dev, dtype=torch.float32), torch.empty((nc, 32, 1, 1), device=dev, dtype=torch.float32)
+        ccc = torch.empty(nc, device=dev, dtype=torch.float32)
+        lib.tail_compose3(w1, b1, w2, b2, w3, b3, nc, wcc, wa, wb, ccc)
+        z = torch.empty((N_, H, W_, nc), device=dev, dtype=torch.float32)
+        lib.pw_fwd(y, wa, None, z, N_ * H * W_, 32, nc, 0, F32_)
+        lg = torch.empty((N_, Ho, Wo, nc), device=dev, dtype=torch.float32)
+        lib.pw_fwd(skip, wb, ccc, lg, N_ * Ho * Wo, 32, nc, 0, F32_)
+        lib.bilinear_add_fwd(z, lg, lg, N_, H, W_, nc, Ho, Wo, int(align), F32_)       # in place: every element reads its own addend, then is written
+        ctx.save_for_backward(y, skip, wa, wb)
+        ctx.params = (w1, b1, w2, b2, w3, b3)
+        ctx.cfg = (N_, H, W_, C, Ho, Wo, int(align), nc)
+        return lg
+
+    @staticmethod
+    def backward(ctx, dl):
+        y, skip, wa, wb = ctx.saved_tensors
+        N_, H, W_, C, Ho, Wo, align, nc = ctx.cfg
+        dl = _as(dl, torch.float32)
+        dev = y.device
+        F32_, BF_ = dtype_code(torch.float32), dtype_code(y.dtype)
+        dz = torch.empty((N_, H, W_, nc), device=dev, dtype=torch.float32)
+        lib.bilinear_bwd(dl, dz, N_, H, W_, nc, Ho, Wo, align, F32_)
+        dy, dskip = torch.empty_like(y), torch.empty_like(skip)
+        lib.conv2d_dgrad(dz, wa, dy, N_, H, W_, 32, nc, 1, 1, 0, 0, F32_, BF_)
+        lib.conv2d_dgrad(dl, wb, dskip, N_, Ho, Wo, 32, nc, 1, 1, 0, 0, F32_, BF_)
+        params = ctx.params
+        with _wgrad_stream(_slot_written(*params), y, skip, dl, dz, wa, wb):
+            dwa, dwb = ZERO.get((nc, 32), torch.float32, dev), ZERO.get((nc, 32), torch.float32, dev)
+            dccc = ZERO.get((nc,), torch.float32, dev)
+            lib.pw_wgrad_smalln(y, dz, dwa, None, N_ * H * W_, 32, nc, BF_, F32_)
+            lib.pw_wgrad_smalln(skip, dl, dwb, dccc, N_ * Ho * Wo, 32, nc, BF_, F32_)
+            outs = [_grad_out(p, tuple(p.shape)) for p in params]
+            lib.tail_compose3_bwd(params[0], params[1], params[2], params[3], params[4], nc, dwa, dwb, dccc, *outs)
+        return (dy, dskip) + tuple(_ret(o, p) for o, p in zip(outs, params)) + (None,)
+
+
+TAIL_AUX_LOW = os.environ.get('TCCT_TAIL_AUX_LOW', '1') != '0'   # =0: the composed head reads the resized 32-channel tensor (the first round-4 form; A/B timing)
+
+
+def up_skip_conv_t32_aux_low(y, skip, w1, b1, w2, b2, w3, b3, align_corners=True):
+    """aux(t32(post(resize_x2(y) + skip) + skip)) as fp32 NHWC logits, the resize taken of the n_class-channel product; check up_skip_conv_t32_aux_ok first"""
+    return _UpSkipConvT32AuxLow.apply(y, skip, w1, b1, w2, b2, w3, b3, bool(align_corners))
+
+
+def up_skip_conv_t32_from_y(y, skip, w1, b1, w2, b2, align_corners=True):
+    """g0 of the composed tail from the un-resized y (no gradient): what `FTC.feats` needs when the step itself never resized y"""
+    with torch.no_grad():
+        N_, H, W_, C = y.shape
+        v = torch.empty_like(skip)
+        lib.bilinear_fwd(y, v, N_, H, W_, C, skip.shape[1], skip.shape[2], int(align_corners), dtype_code(y.dtype))
+    return up_skip_conv_t32_from_v(v, skip, w1, b1, w2, b2)
+
+
 TAIL_AUX = os.environ.get('TCCT_TAIL_AUX', '1') != '0'       # =0: the composed tail stops at g0, aux0 stays its own kernels (A/B timing)
 
 

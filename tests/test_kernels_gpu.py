@@ -721,6 +721,51 @@ def test_decoder_tail_composed_through_the_aux_head(nhw, nc):
     torch.testing.assert_close(nchw(g0), g.detach(), rtol=3e-2, atol=3e-2)
 
 
+@pytest.mark.parametrize('nhw', [(2, 12, 20), (1, 25, 35), (2, 3, 5)])
+@pytest.mark.parametrize('nc', [5, 8])
+def test_decoder_tail_through_the_aux_head_with_the_resize_behind_the_convolution(nhw, nc):
+    """ops.up_skip_conv_t32_aux_low: logits0 = up(Wa y) + Wb skip + c -- the x2 bilinear resize (align_corners) taken of the n_class-channel product at the
+    low resolution instead of the 32-channel input (linear maps commute) -- against torch's four-step chain, logits and the gradients of y, skip and all six
+    parameter tensors; and against the form that resizes first (ops.up_skip_conv_t32_aux)"""
+    from tcct_amd import ops
+    N, H, W = nhw
+    dt = torch.bfloat16
+    y = rnd(N, 32, H, W, dt=dt).requires_grad_(True)
+    skip = rnd(N, 32, 2 * H, 2 * W, seed=1, dt=dt).requires_grad_(True)
+    w1 = (rnd(32, 32, 1, 1, seed=2) / 32 ** 0.5).requires_grad_(True)
+    b1 = (rnd(32, seed=3) * 0.2).requires_grad_(True)
+    w2 = (rnd(32, 32, 1, 1, seed=4) / 32 ** 0.5).requires_grad_(True)
+    b2 = (rnd(32, seed=5) * 0.2).requires_grad_(True)
+    w3 = (rnd(nc, 32, 1, 1, seed=7) / 32 ** 0.5).requires_grad_(True)
+    b3 = (rnd(nc, seed=8) * 0.2).requires_grad_(True)
+    u = F.interpolate(y, scale_factor=2, mode='bilinear', align_corners=True) + skip
+    lg = F.conv2d(F.conv2d(skip + F.conv2d(u, w1, b1), w2, b2), w3, b3)
+    gl = rnd(*lg.shape, seed=6)
+    lg.backward(gl)
+    res = {}
+    for low in (True, False):
+        yd, sd_ = nhwc(y.detach(), dt).requires_grad_(True), nhwc(skip.detach(), dt).requires_grad_(True)
+        ps = [t.detach().cuda().requires_grad_(True) for t in (w1, b1, w2, b2, w3, b3)]
+        assert ops.up_skip_conv_t32_aux_ok(yd, sd_, *ps)
+        ld = ops.up_skip_conv_t32_aux_low(yd, sd_, *ps) if low else ops.up_skip_conv_t32_aux(yd, sd_, *ps)[0]
+        assert ld.dtype == torch.float32
+        torch.testing.assert_close(nchw(ld), lg.detach(), rtol=3e-2, atol=3e-2)
+        ld.backward(nhwc(gl, torch.float32))
+        torch.testing.assert_close(nchw(yd.grad), y.grad, rtol=3e-2, atol=3e-2 * max(1.0, y.grad.abs().max().item()))
+        torch.testing.assert_close(nchw(sd_.grad), skip.grad, rtol=3e-2, atol=3e-2 * max(1.0, skip.grad.abs().max().item()))
+        for got, ref, nm in zip(ps, (w1, b1, w2, b2, w3, b3), ('w1', 'b1', 'w2', 'b2', 'w3', 'b3')):
+            e = (got.grad.cpu() - ref.grad).norm().item() / ref.grad.norm().item()
+            assert e < 1.5e-2, (low, nm, e)
+        res[low] = nchw(ld).clone()
+    # the low-resolution form keeps the product in fp32 where the other rounds up(y) to bf16 first: it must be at least as close to the fp32 chain
+    e_low, e_v = (res[True] - lg.detach()).abs().max().item(), (res[False] - lg.detach()).abs().max().item()
+    assert e_low <= e_v * 1.5 + 1e-3, (e_low, e_v)
+    if H > 4:
+        g0 = ops.up_skip_conv_t32_from_y(nhwc(y.detach(), dt), nhwc(skip.detach(), dt), *[t.detach().cuda() for t in (w1, b1, w2, b2)])
+        gref = F.conv2d(skip + F.conv2d(u, w1, b1), w2, b2)
+        torch.testing.assert_close(nchw(g0), gref.detach(), rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize('nhw', [(2, 24, 40), (1, 50, 69), (3, 7, 5)])
 @pytest.mark.parametrize('nc', [5, 8, 2])
 def test_mid_level_aux_head_composed_through_t32(nhw, nc):
