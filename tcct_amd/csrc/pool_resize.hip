@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(PB) k_bilinear_bwd_tab(const T* __restrict__ d
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
         T* o = out + ((int64_t)hi * W + wi) * C + cv * VEC;
-        if (VEC >= 4 && nr <= 4 && nc <= 4) {
+        if (nr <= 4 && nc <= 4) {      // (VEC == 1 as well: the n_class-channel fp32 logits of the level-0 head, round 4)
             // x2 upsampling: at most 4 x 4 contributing outputs.  Fixed trip counts with zero-weight padding: the 16 loads are independent and
             // all in flight together; the run-time loops below wait for every load before the next one is issued (1.96 TB/s at level 0)
             int rI[4], cI[4]; float rW[4], cW[4];
@@ -444,6 +444,9 @@ extern "C" int tcct_bilinear_bwd_separable(const float* dy, float* dx, float* wo
     TCCT_LAUNCH_OK();
 }
 
+// (Round 4 tried two other forms for the fp32 n_class-channel logits of the level-0 head, 0.129 ms in the element-per-lane form above: a pixel per thread
+// (20-byte lane stride) 0.159 ms, flat runs of four floats with 16-byte accesses for the addend and the result 0.139 ms -- the four scalar source gathers per
+// element, not the streams, are the cost; a separable two-pass form would halve them.)
 static int bilinear_fwd_impl(const void* x, const void* res, void* y, int N, int H, int W, int C, int Ho, int Wo, int align_corners,
                              int dtype, tcct_stream_t stream);
 extern "C" int tcct_bilinear_fwd(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int align_corners,

@@ -721,7 +721,7 @@ def test_decoder_tail_composed_through_the_aux_head(nhw, nc):
     torch.testing.assert_close(nchw(g0), g.detach(), rtol=3e-2, atol=3e-2)
 
 
-@pytest.mark.parametrize('nhw', [(2, 12, 20), (1, 25, 35), (2, 3, 5)])
+@pytest.mark.parametrize('nhw', [(2, 12, 20), (1, 25, 35), (2, 3, 5), (1, 6, 130)])
 @pytest.mark.parametrize('nc', [5, 8])
 def test_decoder_tail_through_the_aux_head_with_the_resize_behind_the_convolution(nhw, nc):
     """ops.up_skip_conv_t32_aux_low: logits0 = up(Wa y) + Wb skip + c -- the x2 bilinear resize (align_corners) taken of the n_class-channel product at the
