@@ -394,6 +394,10 @@ int tcct_dwconv3x3_fwd_xaff(const void* x, const float* xab, const float* w, con
                             double* stats, int dtype, tcct_stream_t stream);
 int tcct_dwconv3x3_wgrad_xaff(const void* x, const float* xab, const void* dy, float* dw, float* dbias, int N, int H, int W, int C, int stride, int dtype,
                               tcct_stream_t stream);
+/* ... and the stride-1 input gradient that also accumulates THAT BatchNorm's two backward sums (raw fp64 [2C], zero on entry: {sum dz', sum dz' y_prev} with
+ * dz' = dz hswish'(a y_prev + b), dz = dx as stored -- the form tcct_bn_sums_from_raw and tcct_pw_bwd_bn_sums(raw = 1) take): no separate reduction pass */
+int tcct_dwconv3x3_dgrad_bnred(const void* dy, const float* w, const void* y_prev, const float* ab_prev, void* dx, double* raw, int N, int H, int W, int C,
+                               int dtype, tcct_stream_t stream);
 
 /* ---- MetaPool on tokens [B,N,C] (nets/tcct.py:405-415,463): AvgPool2d(3,1,1,count_include_pad=False)(x) - x
  * taken over the (token, channel) plane, exactly as torch treats the 3-D tensor --------------------------- */

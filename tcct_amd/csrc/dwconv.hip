@@ -142,7 +142,10 @@ template <typename T, int VEC, int STRIDE, bool FLIP, int CPT = 1>
 __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, int add_input,
                                                int segh, int wblocks, int hstrips, const T* __restrict__ res, double* __restrict__ stats = nullptr,
-                                               const float* __restrict__ xab = nullptr) {
+                                               const float* __restrict__ xab = nullptr, int aux_mode = 0) {
+    // aux_mode (round 4, input-gradient launches): `res` is NOT added -- it is y_prev, the input of the train-mode BatchNorm + Hardswish (coefficients xab) whose
+    // output this convolution consumed: the kernel accumulates that BatchNorm's two backward sums {sum dz', sum dz' y_prev}, dz' = dz hswish'(a y_prev + b) with
+    // dz as stored, into `stats` (raw form, fp64 [2C]) -- its separate reduction pass (read dz, read y_prev) is gone
     typedef typename std::conditional<sizeof(T) == 4, double, float>::type SAcc;       // fp32 parity mode: fp64 partial sums, like tcct_bn_stats' block combine
     __shared__ SAcc s_red[VEC == 4 ? DB * 8 : 1];
     // res != NULL (output-shaped): y += res -- as input gradient: the gradient reaching the convolution's input through its other consumers
@@ -212,7 +215,7 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
 #pragma unroll
             for (int kx = 0; kx < NC; ++kx) r[kx] = dw_xf(r[kx], xa, xb, rok && cin[kx] != DW_OOB);
         };
-        if (xab) {      // the carried rows of the first chunk; its other rows -- like every later chunk's new rows -- are transformed at the top of the loop
+        if (xab && !aux_mode) {      // the carried rows of the first chunk; its other rows -- like every later chunk's new rows -- are transformed at the top of the loop
 #pragma unroll
             for (int i = 0; i < K::CARRY; ++i) xf_row(R[i], p.ho0 * STRIDE - 1 + i, true);
         }
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
 #pragma unroll
             for (int i = 0; i < NEWC; ++i) load_row(NX[i], (ho + RBC) * STRIDE - 1 + K::CARRY + i, more);
             load_res(RSN, ho + RBC);
-            if (xab) {  // AFTER the next chunk's loads are in flight: transforming at the copy below left the VALU work with nothing outstanding (0.115 -> 0.150 ms)
+            if (xab && !aux_mode) {  // AFTER the next chunk's loads are in flight: transforming at the copy below left the VALU work with nothing outstanding (0.115 -> 0.150 ms)
 #pragma unroll
                 for (int i = 0; i < NEWC; ++i) xf_row(R[K::CARRY + i], ho * STRIDE - 1 + K::CARRY + i, true);
             }
@@ -233,7 +236,7 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
                     float acc[VEC];
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
-                        float a = bv[k] + RS[j][cc].get(k);
+                        float a = bv[k] + (aux_mode ? 0.f : RS[j][cc].get(k));
 #pragma unroll
                         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -244,8 +247,17 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
                     const bool live = ho + j < p.ho1 && cout[cc] != DW_OOB;
                     dw_storeb(ry, live ? (uint32_t)(ho + j) * (uint32_t)(Wo * C) * ES + cout[cc] : DW_OOB, acc, (const T*)nullptr);
                     if (stats && live) {
+                        if (aux_mode) {
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) { const SAcc r = dw_rnd(acc[k], (const T*)nullptr); st_s[k] += r; st_q[k] += r * r; }
+                            for (int k = 0; k < VEC; ++k) {
+                                const float yv = RS[j][cc].get(k), u = xa[k] * yv + xb[k];
+                                const float d = dw_rnd(acc[k], (const T*)nullptr) * (u < -3.f ? 0.f : (u <= 3.f ? (2.f * u + 3.f) * (1.f / 6.f) : 1.f));
+                                st_s[k] += (SAcc)d; st_q[k] += (SAcc)d * (SAcc)yv;
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) { const SAcc r = dw_rnd(acc[k], (const T*)nullptr); st_s[k] += r; st_q[k] += r * r; }
+                        }
                     }
                 }
             }
@@ -330,7 +342,8 @@ static void dw_geometry(int N, int Ho, int Wo, int C, int vec, int target_blocks
 
 template <typename T, int VEC, bool FLIP>
 static void dw_fwd_launch(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C, int stride,
-                          int Ho, int Wo, int add_input, hipStream_t st, const void* res = nullptr, double* stats = nullptr, const float* xab = nullptr) {
+                          int Ho, int Wo, int add_input, hipStream_t st, const void* res = nullptr, double* stats = nullptr, const float* xab = nullptr,
+                          int aux_mode = 0) {
     int segh, wblocks, hstrips;
     // four columns per thread for the wide bf16 stride-1 images (levels 1-2 of the ViT branch); TCCT_DW_CPT=1 keeps one column (A/B)
     static int cpt_on = -1;
@@ -338,13 +351,13 @@ static void dw_fwd_launch(const void* x, const float* w, const float* bias, void
     if (stride == 1 && VEC == 4 && sizeof(T) == 2 && cpt_on && Wo >= 128 && C >= 32) {      // measured +4 % at 64 channels, slower at 4
         dw_geometry(N, Ho, Wo, C, VEC, 1024, 32, segh, wblocks, hstrips, 4);
         dim3 g4((unsigned)((int64_t)N * wblocks * hstrips));
-        hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP, (VEC == 4 ? 4 : 1)>), g4, dim3(DB), 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab);
+        hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP, (VEC == 4 ? 4 : 1)>), g4, dim3(DB), 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab, aux_mode);
         return;
     }
     dw_geometry(N, Ho, Wo, C, VEC, 1024, 32, segh, wblocks, hstrips);
     dim3 g((unsigned)((int64_t)N * wblocks * hstrips)), b(DB);
-    if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab);
-    else hipLaunchKernelGGL((k_dw_fwd<T, VEC, 2, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab);
+    if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab, aux_mode);
+    else hipLaunchKernelGGL((k_dw_fwd<T, VEC, 2, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab, aux_mode);
 }
 
 extern "C" int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
@@ -556,6 +569,17 @@ extern "C" int tcct_dwconv3x3_dgrad_add(const void* dy, const float* w, const vo
                                         int stride, int add_input, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(res != nullptr, "dwconv3x3_dgrad_add: res is NULL");
     return dw_dgrad_impl(dy, w, res, dx, N, H, W, C, stride, add_input, dtype, stream);
+}
+
+/* stride-1 input gradient + the backward REDUCTION of the train-mode BatchNorm + Hardswish whose output the convolution consumed (round 4): y_prev = that
+ * BatchNorm's input, ab_prev = {a[C], b[C]}; raw fp64 [2C] (zero on entry) += {sum dz', sum dz' y_prev}, dz' = dz hswish'(a y_prev + b), dz = dx as stored
+ * (the form tcct_bn_sums_from_raw / tcct_pw_bwd_bn_sums take).  C % 4 == 0, C <= 256. */
+extern "C" int tcct_dwconv3x3_dgrad_bnred(const void* dy, const float* w, const void* y_prev, const float* ab_prev, void* dx, double* raw, int N, int H, int W,
+                                          int C, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(N >= 1 && H >= 1 && W >= 1 && C >= 4 && C % 4 == 0 && C <= DB && y_prev && ab_prev && raw, "dwconv3x3_dgrad_bnred: needs C %% 4 == 0, C <= 256, y_prev, ab_prev, raw");
+    TCCT_CHECK((int64_t)H * W * C * 4 < (1ll << 31), "dwconv3x3_dgrad_bnred: one image of %d x %d x %d elements exceeds the 32-bit byte offsets of the kernels", H, W, C);
+    TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, 0, (hipStream_t)stream, y_prev, raw, ab_prev, 1)));
+    TCCT_LAUNCH_OK();
 }
 
 // dw[c][ky][kx] = sum_p x[p@tap][c] * dy[p][c];  dbias[c] = sum_p dy[p][c].  Same marching window as the forward kernel with

@@ -1416,7 +1416,7 @@ def conv3x3_c3_bn(x4, w, bias, bn, stride=1, post_act=None):
 
 class _DwConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, add_input, fork=False, stats_box=None, xab=None):
+    def forward(ctx, x, w, bias, stride, add_input, fork=False, stats_box=None, xab=None, xlink=None):
         """fork: also return an alias of x for its other consumers; their gradient is added inside the input-gradient kernel.
         stats_box ([None]): the kernel also accumulates the statistics of the train-mode BatchNorm that consumes the output.
         xab (round 4): x is y_prev, the input of a train-mode BatchNorm + Hardswish in front whose normalisation pass was not run (xab = its {a[C], b[C]});
@@ -1427,6 +1427,7 @@ class _DwConv(torch.autograd.Function):
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         y = torch.empty((N, Ho, Wo, C), device=x.device, dtype=x.dtype)
         ctx.xab = xab
+        ctx.xlink = xlink       # the BnLink of the BatchNorm pending on x: the input-gradient kernel delivers its backward sums through it
         if xab is not None:
             if add_input or fork or C % 4 or C > 256:
                 raise TcctError('dwconv3x3(deferred=...): plain convolution with C % 4 == 0, C <= 256 only')
@@ -1451,7 +1452,7 @@ class _DwConv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, add_input, has_bias = ctx.cfg
         if dy is None:
-            return dskip, None, None, None, None, None, None, None
+            return dskip, None, None, None, None, None, None, None, None
         dy = _as(dy, x.dtype)
         N, H, W, C = x.shape
         dx = dw = db = None
@@ -1459,6 +1460,11 @@ class _DwConv(torch.autograd.Function):
             dx = torch.empty_like(x)
             if dskip is not None:
                 lib.dwconv3x3_dgrad_add(dy, w, _as(dskip, x.dtype), dx, N, H, W, C, stride, int(add_input), dtype_code(x.dtype))
+            elif ctx.xab is not None and ctx.xlink is not None and stride == 1 and BN_FUSE_RED and BN_RED_DW:
+                # x is y_prev of the pending BatchNorm: its two backward sums come out of this launch (raw form), its own reduction pass is skipped
+                raw = ZERO.get((2 * C,), torch.float64, x.device) if ZERO.active else torch.zeros(2 * C, device=x.device, dtype=torch.float64)
+                lib.dwconv3x3_dgrad_bnred(dy, w, x, ctx.xab, dx, raw, N, H, W, C, dtype_code(x.dtype))
+                ctx.xlink.sums = raw
             else:
                 lib.dwconv3x3_dgrad(dy, w, dx, N, H, W, C, stride, int(add_input), dtype_code(x.dtype))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
@@ -1468,7 +1474,7 @@ class _DwConv(torch.autograd.Function):
                 lib.dwconv3x3_wgrad_xaff(x, ctx.xab, dy, dw, db, N, H, W, C, stride, dtype_code(x.dtype))
             else:
                 lib.dwconv3x3_wgrad(x, dy, dw, db, N, H, W, C, stride, dtype_code(x.dtype))
-        return dx, _ret(dw, w), _ret(db, ctx.bias_param), None, None, None, None, None
+        return dx, _ret(dw, w), _ret(db, ctx.bias_param), None, None, None, None, None, None
 
 
 def dwconv3x3(x, w, bias=None, stride=1, add_input=False, bn_stats=False, deferred=None):
@@ -1477,11 +1483,11 @@ def dwconv3x3(x, w, bias=None, stride=1, add_input=False, bn_stats=False, deferr
     xab = deferred.ab if deferred is not None else None
     if bn_stats:
         box = [None]
-        y = _DwConv.apply(x, w, bias, stride, add_input, False, box, xab)
+        y = _DwConv.apply(x, w, bias, stride, add_input, False, box, xab, deferred)
         if box[0] is not None:
             y._bn_sums = (box[0], ACT['none'])
         return y
-    return _DwConv.apply(x, w, bias, stride, add_input, False, None, xab)
+    return _DwConv.apply(x, w, bias, stride, add_input, False, None, xab, deferred)
 
 
 def dwconv3x3_fork(x, w, bias=None, stride=1, add_input=False):
@@ -1656,6 +1662,7 @@ class _PwConvBN(torch.autograd.Function):
                 (dz if has_res else None), None, None, None, None, None)
 
 
+BN_RED_DW = os.environ.get('TCCT_BN_RED_DW', '1') != '0'      # =0: the BatchNorms in front of the depthwise convolutions keep their backward reduction pass (A/B)
 BN_DEFER_DW = os.environ.get('TCCT_BN_DEFER_DW', '1') != '0'  # =0: the BatchNorms in front of the depthwise convolutions keep their normalisation pass (A/B timing)
 BN_DEFER = os.environ.get('TCCT_BN_DEFER', '1') != '0'        # =0: InvRes.norm keeps its own normalisation pass (round-3 form; A/B timing)
 
