@@ -694,27 +694,7 @@ class FTC(nn.Module):
             d1, s1 = self.dec3(d2, f[1], with_sum=True)
             # level 0: post, `x_0 + y_0` and t324 as one GEMM (u, d0, s0 never written) -- and through aux0 as well when the feature-polarization
             # loss is off (nothing else reads g0 then; `feats` rebuilds it on demand)
-            def mid_heads():
-                # levels 1-3: aux_i(t32x(s_i)) as one GEMM with the composed weight when nothing else reads g_i (feature-polarization loss off)
-                mids_, lg_ = [], []
-                for t, aux, s_ in ((self.t323, self.aux1, s1), (self.t322, self.aux2, s2), (self.t321, self.aux4, s3)):
-                    if self.training and not self.eager_feats and ops.head_through_t32_ok(s_, t.weight, t.bias, aux.weight, aux.bias):
-                        lg_.append(ops.head_through_t32(s_, t.weight, t.bias, aux.weight, aux.bias))
-                        mids_.append(lambda t=t, s_=s_: self._rebuild(t, s_))
-                    else:
-                        lg_.append(None)
-                        mids_.append(_conv(t, s_))
-                return mids_, lg_
-
-            def level0():
-                return self.dec4.forward_through(d1, f[0], self.t324, aux=None if self.eager_feats else self.aux0)
-            if ops.HEADS_SIDE and self.training and not self.eager_feats and torch.is_grad_enabled():
-                # the three coarse heads are launch-bound and independent of level 0: issued on a side stream, they (and, in the backward pass, their
-                # gradient kernels) run beside the bandwidth-bound level-0 head instead of behind it
-                g0, (mids, lg_direct) = ops.run_parallel('heads', level0, mid_heads)
-            else:
-                g0 = level0()
-                mids, lg_direct = mid_heads()
+            g0 = self.dec4.forward_through(d1, f[0], self.t324, aux=None if self.eager_feats else self.aux0)
             if isinstance(g0, tuple):
                 y0_direct, (kind, src) = g0
                 skip0, pw, tw = f[0], self.dec4.post[0], self.t324
@@ -723,6 +703,15 @@ class FTC(nn.Module):
             if g0 is None:
                 d0, s0 = self.dec4(d1, f[0], with_sum=True, want_plain=False)      # only x_0 + y_0 is read below: d0 is never written
                 g0 = _conv(self.t324, s0)
+            # levels 1-3: aux_i(t32x(s_i)) as one GEMM with the composed weight when nothing else reads g_i (feature-polarization loss off)
+            mids, lg_direct = [], []
+            for t, aux, s_ in ((self.t323, self.aux1, s1), (self.t322, self.aux2, s2), (self.t321, self.aux4, s3)):
+                if self.training and not self.eager_feats and ops.head_through_t32_ok(s_, t.weight, t.bias, aux.weight, aux.bias):
+                    lg_direct.append(ops.head_through_t32(s_, t.weight, t.bias, aux.weight, aux.bias))
+                    mids.append(lambda t=t, s_=s_: self._rebuild(t, s_))
+                else:
+                    lg_direct.append(None)
+                    mids.append(_conv(t, s_))
             g1, g2, g3 = mids
         # norm_add([y0,y1,y2]) (reference tcct.py:937-942,1035) -> `self.feats`: evaluated lazily on first access (only the
         # feature-polarization loss reads it; with --udh=false the six level-0 passes are simply never launched)

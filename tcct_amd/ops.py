@@ -621,7 +621,6 @@ def conv2d(x, w, bias=None, stride=1, pad=0, out_dtype=None, stats_pre=None):
 # as well gained nothing more).  Autograd replays every node on the stream of its forward, so
 # the backward pass overlaps the same way.  TCCT_STREAMS=0 issues everything on one stream.
 PARALLEL_BRANCHES = os.environ.get('TCCT_STREAMS', '1') != '0'
-HEADS_SIDE = os.environ.get('TCCT_HEADS_SIDE', '1') != '0'      # =0: the coarse aux heads stay on the main stream (A/B timing)
 _SIDE_STREAMS = {}
 
 
