@@ -138,11 +138,15 @@ __device__ __forceinline__ Raw<float, 4> dw_xf(const Raw<float, 4>& r, const flo
     return q;
 }
 template <typename T> __device__ __forceinline__ Raw<T, 1> dw_xf(const Raw<T, 1>& r, const float*, const float*, bool) { return r; }      // (4-channel vectors only)
-template <typename T, int VEC, int STRIDE, bool FLIP, int CPT = 1>
+// MODE (compile time: a run-time flag puts scalar branches into the marching loop and the compiler then waits for every load in flight at their joins):
+// 0 plain; 1 `xab` = the pending BatchNorm + Hardswish of the input, applied as rows enter the window; 2 (input-gradient launches) `res` is y_prev of that
+// BatchNorm and is NOT added -- its two backward sums are accumulated into `stats` (see below)
+template <typename T, int VEC, int STRIDE, bool FLIP, int CPT = 1, int MODE = 0>
 __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, int add_input,
                                                int segh, int wblocks, int hstrips, const T* __restrict__ res, double* __restrict__ stats = nullptr,
-                                               const float* __restrict__ xab = nullptr, int aux_mode = 0) {
+                                               const float* __restrict__ xab = nullptr) {
+    constexpr bool XAFF = MODE == 1, aux_mode = MODE == 2;
     // aux_mode (round 4, input-gradient launches): `res` is NOT added -- it is y_prev, the input of the train-mode BatchNorm + Hardswish (coefficients xab) whose
     // output this convolution consumed: the kernel accumulates that BatchNorm's two backward sums {sum dz', sum dz' y_prev}, dz' = dz hswish'(a y_prev + b) with
     // dz as stored, into `stats` (raw form, fp64 [2C]) -- its separate reduction pass (read dz, read y_prev) is gone
@@ -209,13 +213,13 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
         for (int i = 0; i < ROWSC; ++i) load_row(R[i], p.ho0 * STRIDE - 1 + i, true);
         float xa[VEC], xb[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) { xa[k] = xab ? xab[p.c + k] : 1.f; xb[k] = xab ? xab[C + p.c + k] : 0.f; }
+        for (int k = 0; k < VEC; ++k) { xa[k] = MODE ? xab[p.c + k] : 1.f; xb[k] = MODE ? xab[C + p.c + k] : 0.f; }
         auto xf_row = [&](Raw<T, VEC> (&r)[NC], int hi, bool live) {        // the pending normalisation of a freshly loaded row (see dw_xf)
             const bool rok = live && (unsigned)hi < (unsigned)H;
 #pragma unroll
             for (int kx = 0; kx < NC; ++kx) r[kx] = dw_xf(r[kx], xa, xb, rok && cin[kx] != DW_OOB);
         };
-        if (xab && !aux_mode) {      // the carried rows of the first chunk; its other rows -- like every later chunk's new rows -- are transformed at the top of the loop
+        if (XAFF) {      // the carried rows of the first chunk; its other rows -- like every later chunk's new rows -- are transformed at the top of the loop
 #pragma unroll
             for (int i = 0; i < K::CARRY; ++i) xf_row(R[i], p.ho0 * STRIDE - 1 + i, true);
         }
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(DB) k_dw_fwd(const T* __restrict__ x, const fl
 #pragma unroll
             for (int i = 0; i < NEWC; ++i) load_row(NX[i], (ho + RBC) * STRIDE - 1 + K::CARRY + i, more);
             load_res(RSN, ho + RBC);
-            if (xab && !aux_mode) {  // AFTER the next chunk's loads are in flight: transforming at the copy below left the VALU work with nothing outstanding (0.115 -> 0.150 ms)
+            if (XAFF) {  // AFTER the next chunk's loads are in flight: transforming at the copy below left the VALU work with nothing outstanding (0.115 -> 0.150 ms)
 #pragma unroll
                 for (int i = 0; i < NEWC; ++i) xf_row(R[K::CARRY + i], ho * STRIDE - 1 + K::CARRY + i, true);
             }
@@ -340,10 +344,9 @@ static void dw_geometry(int N, int Ho, int Wo, int C, int vec, int target_blocks
     hstrips = (Ho + segh - 1) / segh;
 }
 
-template <typename T, int VEC, bool FLIP>
+template <typename T, int VEC, bool FLIP, int MODE = 0>
 static void dw_fwd_launch(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C, int stride,
-                          int Ho, int Wo, int add_input, hipStream_t st, const void* res = nullptr, double* stats = nullptr, const float* xab = nullptr,
-                          int aux_mode = 0) {
+                          int Ho, int Wo, int add_input, hipStream_t st, const void* res = nullptr, double* stats = nullptr, const float* xab = nullptr) {
     int segh, wblocks, hstrips;
     // four columns per thread for the wide bf16 stride-1 images (levels 1-2 of the ViT branch); TCCT_DW_CPT=1 keeps one column (A/B)
     static int cpt_on = -1;
@@ -351,13 +354,13 @@ static void dw_fwd_launch(const void* x, const float* w, const float* bias, void
     if (stride == 1 && VEC == 4 && sizeof(T) == 2 && cpt_on && Wo >= 128 && C >= 32) {      // measured +4 % at 64 channels, slower at 4
         dw_geometry(N, Ho, Wo, C, VEC, 1024, 32, segh, wblocks, hstrips, 4);
         dim3 g4((unsigned)((int64_t)N * wblocks * hstrips));
-        hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP, (VEC == 4 ? 4 : 1)>), g4, dim3(DB), 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab, aux_mode);
+        hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP, (VEC == 4 ? 4 : 1), MODE>), g4, dim3(DB), 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab);
         return;
     }
     dw_geometry(N, Ho, Wo, C, VEC, 1024, 32, segh, wblocks, hstrips);
     dim3 g((unsigned)((int64_t)N * wblocks * hstrips)), b(DB);
-    if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab, aux_mode);
-    else hipLaunchKernelGGL((k_dw_fwd<T, VEC, 2, FLIP>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab, aux_mode);
+    if (stride == 1) hipLaunchKernelGGL((k_dw_fwd<T, VEC, 1, FLIP, 1, MODE>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab);
+    else hipLaunchKernelGGL((k_dw_fwd<T, VEC, 2, FLIP, 1, MODE>), g, b, 0, st, (const T*)x, w, bias, (T*)y, N, H, W, C, Ho, Wo, add_input, segh, wblocks, hstrips, (const T*)res, stats, xab);
 }
 
 extern "C" int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,
@@ -394,7 +397,7 @@ extern "C" int tcct_dwconv3x3_fwd_xaff(const void* x, const float* xab, const fl
     TCCT_CHECK(N >= 1 && H >= 1 && W >= 1 && C >= 4 && C % 4 == 0 && C <= DB && xab != nullptr, "dwconv3x3_fwd_xaff: needs C %% 4 == 0, C <= 256, xab");
     TCCT_CHECK((int64_t)H * W * C * 4 < (1ll << 31), "dwconv3x3_fwd_xaff: one image of %d x %d x %d elements exceeds the 32-bit byte offsets of the kernels", H, W, C);
     int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-    TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, false>(x, w, bias, y, N, H, W, C, stride, Ho, Wo, 0, (hipStream_t)stream, nullptr, stats, xab)));
+    TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, false, 1>(x, w, bias, y, N, H, W, C, stride, Ho, Wo, 0, (hipStream_t)stream, nullptr, stats, xab)));
     TCCT_LAUNCH_OK();
 }
 
@@ -578,7 +581,7 @@ extern "C" int tcct_dwconv3x3_dgrad_bnred(const void* dy, const float* w, const 
                                           int C, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(N >= 1 && H >= 1 && W >= 1 && C >= 4 && C % 4 == 0 && C <= DB && y_prev && ab_prev && raw, "dwconv3x3_dgrad_bnred: needs C %% 4 == 0, C <= 256, y_prev, ab_prev, raw");
     TCCT_CHECK((int64_t)H * W * C * 4 < (1ll << 31), "dwconv3x3_dgrad_bnred: one image of %d x %d x %d elements exceeds the 32-bit byte offsets of the kernels", H, W, C);
-    TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, true>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, 0, (hipStream_t)stream, y_prev, raw, ab_prev, 1)));
+    TCCT_DISPATCH(dtype, (dw_fwd_launch<T, 4, true, 2>(dy, w, nullptr, dx, N, H, W, C, 1, H, W, 0, (hipStream_t)stream, y_prev, raw, ab_prev)));
     TCCT_LAUNCH_OK();
 }
 
@@ -587,7 +590,7 @@ extern "C" int tcct_dwconv3x3_dgrad_bnred(const void* dy, const float* w, const 
 // Few, tall strips (about 1024 blocks) keep the number of same-address atomics low.
 // CPT (VEC == 4, stride 1): the thread owns CPT consecutive output columns and loads CPT + 2 input columns per row, so an input element is
 // requested by (CPT + 2) / CPT instead of three threads (the requests are L1 hits, but the address / tag pipeline pays for each)
-template <typename T, int VEC, int STRIDE, int CPT = 1>
+template <typename T, int VEC, int STRIDE, int CPT = 1, bool XAFF = false>
 __global__ void __launch_bounds__(DB) k_dw_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
                                                  float* __restrict__ dbias, int N, int H, int W, int C, int Ho, int Wo, int segh,
                                                  int wblocks, int hstrips, const float* __restrict__ xab = nullptr) {
@@ -636,13 +639,13 @@ __global__ void __launch_bounds__(DB) k_dw_wgrad(const T* __restrict__ x, const 
         for (int i = 0; i < K::ROWS; ++i) load_row(R[i], p.ho0 * STRIDE - 1 + i, true);
         float xa[VEC], xb[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) { xa[k] = xab ? xab[p.c + k] : 1.f; xb[k] = xab ? xab[C + p.c + k] : 0.f; }
+        for (int k = 0; k < VEC; ++k) { xa[k] = XAFF ? xab[p.c + k] : 1.f; xb[k] = XAFF ? xab[C + p.c + k] : 0.f; }
         auto xf_row = [&](Raw<T, VEC> (&r)[NC], int hi, bool live) {
             const bool rok = live && (unsigned)hi < (unsigned)H;
 #pragma unroll
             for (int kx = 0; kx < NC; ++kx) r[kx] = dw_xf(r[kx], xa, xb, rok && cin[kx] != DW_OOB);
         };
-        if (xab) {
+        if (XAFF) {
 #pragma unroll
             for (int i = 0; i < K::CARRY; ++i) xf_row(R[i], p.ho0 * STRIDE - 1 + i, true);
         }
@@ -652,7 +655,7 @@ __global__ void __launch_bounds__(DB) k_dw_wgrad(const T* __restrict__ x, const 
 #pragma unroll
             for (int i = 0; i < K::NEW; ++i) load_row(NX[i], (ho + K::RB) * STRIDE - 1 + K::CARRY + i, more);
             load_g(GX, ho + K::RB);
-            if (xab) {  // this chunk's new rows, with the next chunk's loads in flight (see k_dw_fwd)
+            if (XAFF) {  // this chunk's new rows, with the next chunk's loads in flight (see k_dw_fwd)
 #pragma unroll
                 for (int i = 0; i < K::NEW; ++i) xf_row(R[K::CARRY + i], ho * STRIDE - 1 + K::CARRY + i, true);
             }
@@ -773,15 +776,20 @@ static int dw_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias,
     if (cpt_on < 0) { const char* e = getenv("TCCT_DW_WGRAD_CPT"); cpt_on = (e && e[0] == '0') ? 0 : 1; }
     if (cpt_on && vec == 4 && stride == 1 && dtype == TCCT_BF16 && Wo >= 128 && C >= 32) {
         dw_geometry(N, Ho, Wo, C, vec, 512, 128, segh, wblocks, hstrips, 2);
-        hipLaunchKernelGGL((k_dw_wgrad<bf16, 4, 1, 2>), dim3((unsigned)((int64_t)N * wblocks * hstrips)), dim3(DB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias,
-                           N, H, W, C, Ho, Wo, segh, wblocks, hstrips, xab);
+        if (xab) hipLaunchKernelGGL((k_dw_wgrad<bf16, 4, 1, 2, true>), dim3((unsigned)((int64_t)N * wblocks * hstrips)), dim3(DB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias,
+                                    N, H, W, C, Ho, Wo, segh, wblocks, hstrips, xab);
+        else hipLaunchKernelGGL((k_dw_wgrad<bf16, 4, 1, 2>), dim3((unsigned)((int64_t)N * wblocks * hstrips)), dim3(DB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias,
+                                N, H, W, C, Ho, Wo, segh, wblocks, hstrips, xab);
         TCCT_LAUNCH_OK();
     }
     dw_geometry(N, Ho, Wo, C, vec, 512, 128, segh, wblocks, hstrips);
     dim3 grid((unsigned)((int64_t)N * wblocks * hstrips));
 #define DWG(V, S) hipLaunchKernelGGL((k_dw_wgrad<T, V, S>), grid, dim3(DB), lds, st, (const T*)x, (const T*)dy, dw, dbias, N, H, W, C, Ho, Wo, segh, wblocks, hstrips, xab)
-    if (vec == 4) { TCCT_DISPATCH(dtype, if (stride == 1) DWG(4, 1); else DWG(4, 2)); }
+#define DWGX(S) hipLaunchKernelGGL((k_dw_wgrad<T, 4, S, 1, true>), grid, dim3(DB), lds, st, (const T*)x, (const T*)dy, dw, dbias, N, H, W, C, Ho, Wo, segh, wblocks, hstrips, xab)
+    if (vec == 4 && xab) { TCCT_DISPATCH(dtype, if (stride == 1) DWGX(1); else DWGX(2)); }
+    else if (vec == 4) { TCCT_DISPATCH(dtype, if (stride == 1) DWG(4, 1); else DWG(4, 2)); }
     else { TCCT_DISPATCH(dtype, if (stride == 1) DWG(1, 1); else DWG(1, 2)); }
 #undef DWG
+#undef DWGX
     TCCT_LAUNCH_OK();
 }
