@@ -621,6 +621,10 @@ def test_mlp_gelu_applied_while_staging_is_bit_identical_to_the_separate_pass(cf
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(C + Nt)
     y1 = (torch.randn(B, Nt, C, generator=g) * 1.5).to(dt)
+    # zeros of both signs, denormal-small, saturating and huge pre-activations among the random ones
+    edge = torch.tensor([0.0, -0.0, 1e-8, -1e-8, 2.0 ** -20, -2.0 ** -20, 2.0 ** -21, 15.9375, -15.9375, 16.0, -16.0, 50.0, -50.0, 3e4, -3e4, 1e-30]).to(dt)
+    y1.view(-1)[7:7 + edge.numel()] = edge
+    y1.view(-1)[-edge.numel():] = edge.flip(0)
     res = torch.randn(B, Nt, C, generator=g).to(dt)
     w = (torch.randn(C, C, generator=g) / C ** 0.5)
     b = torch.randn(C, generator=g) * 0.1
