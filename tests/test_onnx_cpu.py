@@ -178,3 +178,23 @@ def test_the_structure_check_rejects_malformed_files(tmp_path):
     m.graph.node[conv].ParseFromString(bytes(raw))
     with pytest.raises(AssertionError, match='not in onnx.proto3'):
         S.check_model(m.SerializeToString())
+
+
+def test_exported_file_in_onnx_checker_and_onnxruntime_when_they_exist(tmp_path):
+    """What the reference's own consumer does (task1/onnx/onnx_infer.py:14-24: `onnxruntime.InferenceSession(...).run(None, {'input': img})`): runs ONLY where
+    `onnx` and `onnxruntime` are installed -- neither is in this image, so in this repository's CI the test is SKIPPED and compatibility with onnxruntime
+    remains unverified (README / DESIGN say so); the structural check against the spec above is what runs everywhere"""
+    onnx = pytest.importorskip('onnx')
+    ort = pytest.importorskip('onnxruntime')
+    from tcct_amd.onnx_export import export_onnx
+    sd, ck = _duke_state_dict()
+    path = str(tmp_path / 'tcct_duke.onnx')
+    export_onnx(sd, path)
+    onnx.checker.check_model(onnx.load(path))
+    sess = ort.InferenceSession(path, providers=['CPUExecutionProvider'])
+    img = ck['input_u8'].transpose(2, 0, 1).reshape(1, 3, 160, 160).astype(np.float32) / 255
+    outs = sess.run(None, {'input': img})
+    ref = ck['logits0']
+    assert np.abs(outs[0][0] - ref).max() / np.abs(ref).max() <= 1e-4
+    for i in range(4):
+        assert (outs[i][0].argmax(0) == ck['masks'][i]).mean() >= 0.9995, i
