@@ -297,6 +297,11 @@ int tcct_pw_bwd_bn_sums_xaff(const void* y_prev, const float* ab_prev, const voi
  *   bwd: dx1 = (dy W) gelu'(x1), dw += dy^T gelu(x1), dbias += sum dy   (dw / dbias cleared here unless tcct_set_outputs_prezeroed) */
 int tcct_pw_fwd_gelu_residual(const void* x1, const float* w, const float* bias, const void* res, const float* scale, int64_t per_sample, void* y,
                               int64_t M, int K, int N, tcct_stream_t stream);
+/* fused backward of Mlp.fc1 BEHIND MHCABlock.norm2 (nets/tcct.py:466-468): x = LN(t) as stored, t and mean_rstd [M][2] the LayerNorm's input and saved statistics,
+ * res = the gradient that reaches t through the residual path; dt = LN^T(dy W) + res (the gradient of x is never written), dw / dbias of the Linear, dgamma / dbeta
+ * [K] of the LayerNorm.  K = N = 64. */
+int tcct_pw_bwd_lnb(const void* x, const void* dy, const float* w, const void* t, const float* mean_rstd, const float* gamma, const void* res, void* dt,
+                    float* dw, float* dbias, float* dgamma, float* dbeta, int64_t M, int K, int N, tcct_stream_t stream);
 int tcct_pw_bwd_gelu(const void* x1, const void* dy, const float* w, void* dx1, float* dw, float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
 /* input gradient with a second gradient folded in: dx_plain = dy W, dx_sum = dy W + res (w [Nout,K] as stored; res, dx_* [M,K] bf16; dx_plain nullable):
  * backward of the decoder block tail (MPUpBlock, tcct.py:908-914): dx_plain continues into the resize, dx_sum is the skip's gradient */

@@ -803,7 +803,12 @@ template <int KIND> __device__ __forceinline__ float pw_act_grad(float u) {
     if (KIND == TCCT_ACT_HSWISH) return u < -3.f ? 0.f : (u <= 3.f ? (2.f * u + 3.f) * (1.f / 6.f) : 1.f);
     return 1.f;
 }
-template <int NT, int KT, bool SPLIT = false, int BNP = -1, int REDP = -1, bool GX = false, int XAP = -1>
+// LNB (round 4): x is the OUTPUT of a LayerNorm over the K channels of each row (MHCABlock.norm2 -> Mlp.fc1, reference nets/tcct.py:466-468) that only this
+// convolution reads.  The dx epilogue then runs that LayerNorm's backward on the spot -- dx as it would have been stored (bf16) is d; per row
+// g = d gamma, s1 = mean_c g, s2 = mean_c g xh, out = rstd (g - s1 - xh s2) + res with xh = (t - mean) rstd rebuilt from the LayerNorm's INPUT t (bn.yprev) and
+// its saved statistics (bn.mean_rstd [M][2]) -- and writes the gradient of t (+ res, the gradient that reaches t through the residual path); dgamma / dbeta
+// (bn.dgamma / bn.dbeta, fp32 [K], zero on entry) are accumulated.  The separate LayerNorm backward pass (read t, read d, read res, write) is gone.
+template <int NT, int KT, bool SPLIT = false, int BNP = -1, int REDP = -1, bool GX = false, int XAP = -1, bool LNB = false>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ w, const bf16* __restrict__ res,
          bf16* __restrict__ dx, bf16* __restrict__ dx_plain, float* __restrict__ dw, float* __restrict__ dbias, int64_t M, PwBnBwd bn) {
@@ -840,7 +845,8 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
         }
     }
     if (RED || XAP >= 0) for (int i = tid; i < 2 * (SPLIT ? K / 2 : K); i += PWB) sP[i] = bn.abprev[i];
-    constexpr int RKT = RED ? (SPLIT ? KT / 2 : KT) : 1;   // 32-channel tiles of x that carry the BatchNorm in front (split: the first half)
+    if (LNB) for (int i = tid; i < K; i += PWB) sP[i] = bn.abprev[i];          // gamma[K] of the LayerNorm in front
+    constexpr int RKT = LNB ? KT : (RED ? (SPLIT ? KT / 2 : KT) : 1);   // 32-channel tiles of x that carry the BatchNorm in front (split: the first half)
     float rs[RKT][8], rq[RKT][8];                            // RED: per-lane partial sums of dz' and dz' y_prev (channels 8 (lane & 3) + k of tile kt)
 #pragma unroll
     for (int a = 0; a < RKT; ++a)
@@ -863,7 +869,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)dx, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(dx_plain ? dx_plain : dx), 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(BN ? bn.y : dy), 0, dbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ryp = __builtin_amdgcn_make_buffer_rsrc((void*)(RED ? bn.yprev : x), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ryp = __builtin_amdgcn_make_buffer_rsrc((void*)((RED || LNB) ? bn.yprev : x), 0, xbytes, 0x00020000);
     u32x4 px[XS], pd[DS], py[BN ? DS : 1];
     // a tile's rows are one contiguous span of memory: slot i of a thread = bytes [16 (tid + 256 i), +16) of it (fully coalesced);
     // rows beyond M fall outside the descriptor and read as zeros
@@ -959,6 +965,19 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
                     xq[kt][h2] = __builtin_amdgcn_raw_buffer_load_b128(rx, mm < M ? (uint32_t)((mm * K + kt * 32 + (lane & 3) * 8) * 2) : 0x80000000u, 0, 0);
                 }
         }
+        u32x4 tq[LNB ? KT : 1][2];      // LNB: the LayerNorm input rows (and their statistics) the dx epilogue of this tile needs
+        float tmean[2] = {0.f, 0.f}, trstd[2] = {0.f, 0.f};
+        if (LNB) {
+            const int64_t m0q = tile * PB_P + 32 * wave;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int64_t mm = m0q + (lane >> 2) + 16 * h2;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+                    tq[kt][h2] = __builtin_amdgcn_raw_buffer_load_b128(ryp, mm < M ? (uint32_t)((mm * K + kt * 32 + (lane & 3) * 8) * 2) : 0x80000000u, 0, 0);
+                if (mm < M) { const float2 mr = *reinterpret_cast<const float2*>(bn.mean_rstd + 2 * mm); tmean[h2] = mr.x; trstd[h2] = mr.y; }
+            }
+        }
         u32x4 yq[RKT][2];               // RED: the y_prev values the dx epilogue of this tile needs, requested before the MFMA phase
         if (RED) {
             const int64_t m0q = tile * PB_P + 32 * wave;
@@ -1031,6 +1050,58 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
         // ---- dx epilogue: per-wave LDS transpose -> 16-byte stores (16 whole 64-byte pixel segments per wave instruction)
         unsigned char* sc = sS + wave * 2560;
         const int64_t m0 = tile * PB_P + 32 * wave;
+        if (LNB) {
+            u32x4 ov[KT][2];            // d = dx as stored, transposed: lane = (row p, 8 channels) of every 32-channel tile
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint2 o;
+                    o.x = pack_bf16x2(accd[kt][4 * q], accd[kt][4 * q + 1]);
+                    o.y = pack_bf16x2(accd[kt][4 * q + 2], accd[kt][4 * q + 3]);
+                    *reinterpret_cast<uint2*>(sc + r * 80 + (8 * q + 4 * hh) * 2) = o;
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) ov[kt][h2] = *reinterpret_cast<const u32x4*>(sc + ((lane >> 2) + 16 * h2) * 80 + (lane & 3) * 16);
+                wave_lds_fence();
+            }
+            const int cch = lane & 3;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int64_t mm = m0 + (lane >> 2) + 16 * h2;
+                const float mean = tmean[h2], rstd = trstd[h2];
+                float g[KT][8], xh[KT][8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const u32x4 tv = tq[kt][h2];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float d0 = __uint_as_float(ov[kt][h2][k] << 16), d1 = __uint_as_float(ov[kt][h2][k] & 0xffff0000u);
+                        const float h0 = (__uint_as_float(tv[k] << 16) - mean) * rstd, h1 = (__uint_as_float(tv[k] & 0xffff0000u) - mean) * rstd;
+                        const float g0 = d0 * sP[kt * 32 + cch * 8 + 2 * k], g1 = d1 * sP[kt * 32 + cch * 8 + 2 * k + 1];
+                        g[kt][2 * k] = g0; g[kt][2 * k + 1] = g1; xh[kt][2 * k] = h0; xh[kt][2 * k + 1] = h1;
+                        s1 += g0 + g1; s2 += g0 * h0 + g1 * h1;
+                        rs[kt][2 * k] += d0 * h0; rs[kt][2 * k + 1] += d1 * h1;         // dgamma
+                        rq[kt][2 * k] += d0; rq[kt][2 * k + 1] += d1;                   // dbeta
+                    }
+                }
+                s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);               // the four lanes of a row
+                s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+                s1 *= 1.f / (float)K; s2 *= 1.f / (float)K;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const uint32_t off = mm < M ? (uint32_t)((mm * K + kt * 32 + cch * 8) * 2) : 0x80000000u;
+                    const u32x4 rv = __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0);
+                    u32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        o[k] = pack_bf16x2(rstd * (g[kt][2 * k] - s1 - xh[kt][2 * k] * s2) + __uint_as_float(rv[k] << 16),
+                                           rstd * (g[kt][2 * k + 1] - s1 - xh[kt][2 * k + 1] * s2) + __uint_as_float(rv[k] & 0xffff0000u));
+                    __builtin_amdgcn_raw_buffer_store_b128(o, ro, off, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
@@ -1116,6 +1187,32 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
         }
         __syncthreads();
     }
+    if (LNB) {
+        // dgamma / dbeta: lanes with equal (lane & 3) hold different rows of the same 8 channels (see RED above)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][K]
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float a = rs[kt][k], b = rq[kt][k];
+#pragma unroll
+                for (int o = 32; o > 2; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (lane < 4) {
+                    red[wave * 2 * K + kt * 32 + 8 * lane + k] = a;
+                    red[wave * 2 * K + K + kt * 32 + 8 * lane + k] = b;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i2 = tid; i2 < K; i2 += PWB) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) { a += red[wv * 2 * K + i2]; b += red[wv * 2 * K + K + i2]; }
+            atomicAdd(&bn.dgamma[i2], a); atomicAdd(&bn.dbeta[i2], b);
+        }
+        __syncthreads();
+    }
     // ---- weight-gradient tiles straight from the owning wave's registers: lanes r = 0..31 of a register are 128 contiguous bytes
 #pragma unroll
     for (int a = 0; a < (NT * KT + 3) / 4; ++a) {
@@ -1140,7 +1237,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
                        int64_t M, int K, int N, tcct_stream_t stream, bool split = false, int bnp = -1, int redp = -1,
                        PwBnBwd bn = PwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr}, bool gelu_x = false,
-                       int xap = -1);
+                       int xap = -1, bool lnb = false);
 /* the same over a concatenation: x = [x1 | x2], dx = [dx1 | dx2], each [M, K/2] (K = 128): backward of tcct_pw_fwd_cat2 */
 extern "C" int tcct_pw_bwd_cat2(const void* x1, const void* x2, const void* dy, const float* w, void* dx1, void* dx2, float* dw, int64_t M,
                                 int K, int N, tcct_stream_t stream) {
@@ -1236,8 +1333,22 @@ extern "C" int tcct_pw_bwd_gelu(const void* x1, const void* dy, const float* w, 
     return pw_bwd_impl(x1, dy, w, nullptr, dx1, nullptr, dw, dbias, M, K, N, stream, false, -1, -1,
                        PwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr}, true);
 }
+/* Backward of  y = LN(t; gamma, beta) W^T + b  (MHCABlock.norm2 -> Mlp.fc1, reference nets/tcct.py:466-468) given dy, x = LN(t) as stored, t, the LayerNorm's
+ * saved statistics mean_rstd [M][2] and res = the gradient reaching t through the residual path: dt = LN^T(dy W) + res, dw, dbias as tcct_pw_bwd, dgamma / dbeta
+ * [K] of the LayerNorm (cleared here unless the outputs are pre-zeroed) -- one pass, the gradient of x is never written.  K = N = 64. */
+extern "C" int tcct_pw_bwd_lnb(const void* x, const void* dy, const float* w, const void* t, const float* mean_rstd, const float* gamma, const void* res,
+                               void* dt, float* dw, float* dbias, float* dgamma, float* dbeta, int64_t M, int K, int N, tcct_stream_t stream) {
+    TCCT_CHECK(K == 64 && N == 64, "pw_bwd_lnb: K=%d N=%d unsupported (64 x 64)", K, N);
+    TCCT_CHECK(t && mean_rstd && gamma && res && dgamma && dbeta, "pw_bwd_lnb: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (!tcct_skip_zero_fill() && (hipMemsetAsync(dgamma, 0, sizeof(float) * K, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * K, st) != hipSuccess)) {
+        tcct_set_error("pw_bwd_lnb: memset failed"); return -2;
+    }
+    return pw_bwd_impl(x, dy, w, res, dt, nullptr, dw, dbias, M, K, N, stream, false, -1, -1,
+                       PwBnBwd{nullptr, nullptr, (const bf16*)t, gamma, nullptr, nullptr, 0, mean_rstd, nullptr, dgamma, dbeta}, false, -1, true);
+}
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
-                       int64_t M, int K, int N, tcct_stream_t stream, bool split, int bnp, int redp, PwBnBwd bn, bool gelu_x, int xap) {
+                       int64_t M, int K, int N, tcct_stream_t stream, bool split, int bnp, int redp, PwBnBwd bn, bool gelu_x, int xap, bool lnb) {
     TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && K <= 128 && N <= 128, "pw_bwd: K=%d N=%d unsupported (32..128)", K, N);
     TCCT_CHECK(M > 0 && M * (int64_t)(K > N ? K : N) * 2 < (1LL << 31), "pw_bwd: tensor exceeds the 2 GiB buffer-descriptor range");
     hipStream_t st = (hipStream_t)stream;
@@ -1246,7 +1357,7 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
     const int NT = N / 32, KT = K / 32;
     const int SX = 64 * KT + ((KT & 1) ? 0 : 64), SD = 64 * NT + ((NT & 1) ? 0 : 64), SW = 2 * N + 16;
     const size_t lds = (size_t)PB_P * (SX + SD) + (((size_t)K * SW + 15) & ~(size_t)15) + 4 * 2560 + (bnp >= 0 ? (size_t)5 * N * 4 : 0) +
-                       ((redp >= 0 || xap >= 0) ? (size_t)2 * K * 4 : 0);
+                       ((redp >= 0 || xap >= 0 || lnb) ? (size_t)2 * K * 4 : 0);
     TCCT_CHECK(lds <= 160 * 1024, "pw_bwd: %zu B of LDS", lds);
     const int64_t tiles = (M + PB_P - 1) / PB_P;
     int per_cu = (int)((160 * 1024) / (lds + 256));
@@ -1257,6 +1368,13 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
     if (gx > tiles) gx = tiles;
 #define BLX(NTV, KTV, SPV, BNV, RDV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<NTV, KTV, SPV, BNV, RDV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
         hipLaunchKernelGGL((k_pw_bwd<NTV, KTV, SPV, BNV, RDV>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M, bn); }
+    if (lnb) {          // fc1 behind MHCABlock.norm2: the LayerNorm backward in the dx epilogue (K = N = 64)
+#define BLN(T) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<T, T, false, -1, -1, false, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_bwd<T, T, false, -1, -1, false, -1, true>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M, bn); }
+        BLN(2)
+#undef BLN
+        TCCT_LAUNCH_OK();
+    }
     if (xap >= 0) {     // x = hswish(a y_prev + b) applied on load (InvRes.norm -> conv2): BN behind without activation; 64: + the reduction epilogue
 #define BLXA(NTV, RDV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<NTV, NTV, false, 0, RDV, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
         hipLaunchKernelGGL((k_pw_bwd<NTV, NTV, false, 0, RDV, false, 2>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M, bn); }

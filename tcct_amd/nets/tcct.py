@@ -331,7 +331,13 @@ class MHCABlock(nn.Module):
             # t + dp(pool(LN1 t)): LayerNorm, mixer, DropPath scale and residual in ONE pass each way (the normalised tensor is never written) ...
             if ops.LN_POOL_LN2:
                 # ... and LN2 of the row while it is in registers
-                t, cur2 = ops.ln_metapool_residual_ln(t, self.norm1.weight, self.norm1.bias, self.norm1.eps, s1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+                t, cur2, mr2 = ops.ln_metapool_residual_ln(t, self.norm1.weight, self.norm1.bias, self.norm1.eps, s1, self.norm2.weight, self.norm2.bias,
+                                                           self.norm2.eps)
+                m_ = self.mlp
+                if ops.mlp_tail_ok(t, cur2, m_.fc1.weight, m_.fc1.bias, m_.fc2.weight, m_.fc2.bias):
+                    # fc1 -> GELU -> fc2 -> + t as one node: LayerNorm2's backward rides on fc1's input-gradient kernel
+                    t = ops.mlp_tail(t, cur2, mr2, self.norm2.weight, self.norm2.bias, m_.fc1.weight, m_.fc1.bias, m_.fc2.weight, m_.fc2.bias, s2)
+                    return (t.view(B, H, W, C), x_alias) if fork else t.view(B, H, W, C)
             else:
                 t = ops.ln_metapool_residual(t, self.norm1.weight, self.norm1.bias, self.norm1.eps, s1)
         else:

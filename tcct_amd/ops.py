@@ -815,6 +815,63 @@ class _GeluLinearResidual(torch.autograd.Function):
         return dx1, _ret(dw, wsrc), _ret(db, bsrc), dy, None
 
 
+class _MlpTail(torch.autograd.Function):
+    """t2 = t1 + scale[b] * fc2(gelu(fc1(cur2))) with cur2 = LayerNorm2(t1) as stored by the node in front (ln_metapool_residual_ln): MHCABlock's second half
+    (reference nets/tcct.py:466-468) as ONE autograd node, so that its backward can run LayerNorm2's backward in fc1's input-gradient epilogue
+    (tcct_pw_bwd_lnb): the gradient of cur2 is never written, the stand-alone LayerNorm backward pass does not run.  The node returns the COMPLETE gradient of
+    t1 (residual path + through LayerNorm2) and none for cur2; dgamma2 / dbeta2 come out of the same kernel."""
+
+    @staticmethod
+    def forward(ctx, t1, cur2, mr2, g2, b2, w1, bias1, w2, bias2, scale):
+        _chk(t1, cur2, mr2, g2, b2, w1, bias1, w2, bias2, scale)
+        B, Nt, K = t1.shape
+        M = B * Nt
+        y1 = torch.empty_like(t1)
+        lib.pw_fwd(cur2, w1, bias1, y1, M, K, K, 0, dtype_code(t1.dtype))
+        t2 = torch.empty_like(t1)
+        lib.pw_fwd_gelu_residual(y1, w2, bias2, t1, scale, Nt, t2, M, K, K)
+        ctx.save_for_backward(t1, cur2, mr2, y1, g2, w1, w2)
+        ctx.scale = scale
+        ctx.params = (g2, b2, w1, bias1, w2, bias2)
+        return t2
+
+    @staticmethod
+    def backward(ctx, dt2):
+        t1, cur2, mr2, y1, g2, w1, w2 = ctx.saved_tensors
+        g2p, b2p, w1p, bias1p, w2p, bias2p = ctx.params
+        dt2 = _as(dt2, t1.dtype)
+        B, Nt, K = t1.shape
+        M = B * Nt
+        dz = dt2
+        if ctx.scale is not None:
+            dz = torch.empty_like(dt2)
+            lib.scale_rows(dt2, ctx.scale, dz, B, dt2.numel() // B, dtype_code(dt2.dtype))
+        w1s = w1p if hasattr(w1p, '_grad_slot') or w1p._base is None else w1p._base
+        w2s = w2p if hasattr(w2p, '_grad_slot') or w2p._base is None else w2p._base
+        dy1 = torch.empty_like(y1)
+        dw2, db2 = _grad_out(w2s, tuple(w2.shape)), _grad_out(bias2p)
+        lib.pw_bwd_gelu(y1, dz, w2, dy1, dw2, db2, M, K, K)
+        dt1 = torch.empty_like(t1)
+        dw1, db1 = _grad_out(w1s, tuple(w1.shape)), _grad_out(bias1p)
+        dg2, dbeta2 = _grad_out(g2p), _grad_out(b2p)
+        lib.pw_bwd_lnb(cur2, dy1, w1, t1, mr2, g2, dt2, dt1, dw1, db1, dg2, dbeta2, M, K, K)
+        return (dt1, None, None, _ret(dg2, g2p), _ret(dbeta2, b2p), _ret(dw1, w1s), _ret(db1, bias1p), _ret(dw2, w2s), _ret(db2, bias2p), None)
+
+
+MLP_TAIL_FUSE = os.environ.get('TCCT_MLP_TAIL', '1') != '0'      # =0: LayerNorm2 keeps its own backward pass (A/B timing)
+
+
+def mlp_tail_ok(t1, cur2, w1, bias1, w2, bias2):
+    return (MLP_TAIL_FUSE and MLP_GELU_FUSE and FUSED_PW_BWD and torch.is_grad_enabled() and t1.dtype == torch.bfloat16 and t1.dim() == 3 and t1.shape[-1] == 64
+            and cur2.shape == t1.shape and tuple(w1.shape) == (64, 64) and tuple(w2.shape) == (64, 64) and bias1 is not None and bias2 is not None
+            and t1.is_contiguous() and cur2.is_contiguous() and t1.numel() * 2 < 2 ** 31)
+
+
+def mlp_tail(t1, cur2, mr2, g2, b2, w1, bias1, w2, bias2, scale=None):
+    """t1 + scale[b] * fc2(gelu(fc1(cur2))), cur2 = LayerNorm2(t1) with statistics mr2 (from ln_metapool_residual_ln); check mlp_tail_ok first"""
+    return _MlpTail.apply(t1, cur2, mr2, g2, b2, w1, bias1, w2, bias2, scale)
+
+
 def gelu_linear_residual_ok(x1, w, bias, res):
     return (MLP_GELU_FUSE and FUSED_PW_BWD and torch.is_grad_enabled() and x1.dtype == torch.bfloat16 and x1.dim() == 3 and w.dim() == 2
             and x1.shape[-1] in (64, 96) and w.shape[0] == x1.shape[-1] and w.shape[1] == x1.shape[-1] and bias is not None
@@ -2196,10 +2253,11 @@ class _LnMetaPoolResidualLn(torch.autograd.Function):
         ctx.save_for_backward(t, y, g1, g2, mr2)
         ctx.beta = (b1, b2)
         ctx.cfg = (eps1, scale)
-        return y, y2
+        ctx.mark_non_differentiable(mr2)
+        return y, y2, mr2
 
     @staticmethod
-    def backward(ctx, dres, dcur):
+    def backward(ctx, dres, dcur, _dmr=None):
         t, y, g1, g2, mr2 = ctx.saved_tensors
         b1, b2 = ctx.beta
         eps1, scale = ctx.cfg
@@ -2239,7 +2297,7 @@ LN_POOL_LN2 = os.environ.get('TCCT_LN_POOL_LN2', '1') != '0'       # =0: the sec
 
 
 def ln_metapool_residual_ln(t, g1, b1, eps1, scale, g2, b2, eps2):
-    """(t1, LayerNorm2(t1)), t1 = t + scale[b] * MetaPool(LayerNorm1(t)): one forward pass; check ln_metapool_residual_ok first"""
+    """(t1, LayerNorm2(t1), its statistics [B*N*2]), t1 = t + scale[b] * MetaPool(LayerNorm1(t)): one forward pass; check ln_metapool_residual_ok first"""
     return _LnMetaPoolResidualLn.apply(t, g1, b1, float(eps1), scale, g2, b2, float(eps2))
 
 

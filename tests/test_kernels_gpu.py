@@ -1395,7 +1395,7 @@ def test_layernorm_token_mixer_residual_in_one_pass(dt, cfg):
     (y * gy).sum().add((y2 * gy2).sum()).backward()
     td = t.detach().to('cuda', dt).requires_grad_(True)
     ps = [p_.detach().cuda().requires_grad_(True) for p_ in (gamma, beta, gamma2, beta2)]
-    yd, y2d = ops.ln_metapool_residual_ln(td, ps[0], ps[1], 1e-6, scd, ps[2], ps[3], 1e-6)
+    yd, y2d, _mr2 = ops.ln_metapool_residual_ln(td, ps[0], ps[1], 1e-6, scd, ps[2], ps[3], 1e-6)
     torch.testing.assert_close(yd.float().cpu(), y.detach(), **tl)
     torch.testing.assert_close(y2d.float().cpu(), y2.detach(), rtol=2 * tl['rtol'], atol=2 * tl['atol'])
     torch.autograd.backward([yd, y2d], [gy.to('cuda', dt), gy2.to('cuda', dt)])
@@ -1414,6 +1414,60 @@ def test_layernorm_token_mixer_residual_in_one_pass(dt, cfg):
         same_y = (y2 == y3).float().mean().item()
         same_g = (t2.grad == t3.grad).float().mean().item()
         assert same_y > 0.99 and same_g > 0.98, (same_y, same_g)
+
+
+@pytest.mark.parametrize('cfg', [(3, 61, True), (2, 300, False), (1, 129, True), (2, 2, False)])
+def test_mlp_half_of_the_block_with_layernorm_backward_in_the_fc1_epilogue(cfg):
+    """ops.mlp_tail (tcct_pw_bwd_lnb): t2 = t1 + s[b] * fc2(gelu(fc1(LN2(t1)))) (reference nets/tcct.py:466-468) as one node whose backward runs LayerNorm2's
+    backward inside fc1's input-gradient kernel.  Against the chain of separate nodes (LayerNorm backward as its own pass): forward identical, the gradient of
+    t1 equal on nearly every element (both round d(cur2) to bf16 at the same place), parameter gradients to atomic-order noise; and against torch in fp32."""
+    from tcct_amd import ops
+    B, Nt, scaled = cfg
+    C, dt = 64, torch.bfloat16
+    g = torch.Generator().manual_seed(Nt)
+    t0 = torch.randn(B, Nt, C, generator=g).to(dt)
+    g1, b1 = 1.0 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    g2, b2 = 1.0 - 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    w1, bb1 = torch.randn(C, C, generator=g) / C ** 0.5, 0.1 * torch.randn(C, generator=g)
+    w2, bb2 = torch.randn(C, C, generator=g) / C ** 0.5, 0.1 * torch.randn(C, generator=g)
+    sc = torch.tensor([1.0 / 0.9, 0.0, 1.0 / 0.9][:B]) if scaled else None
+    gy = torch.randn(B, Nt, C, generator=g).to(dt)
+    res = {}
+    for fused in (True, False):
+        td = t0.cuda().requires_grad_(True)
+        ps = [p_.clone().cuda().requires_grad_(True) for p_ in (g1, b1, g2, b2, w1, bb1, w2, bb2)]
+        scd = sc.cuda() if scaled else None
+        t1, cur2, mr2 = ops.ln_metapool_residual_ln(td, ps[0], ps[1], 1e-6, scd, ps[2], ps[3], 1e-6)
+        if fused:
+            assert ops.mlp_tail_ok(t1, cur2, ps[4], ps[5], ps[6], ps[7])
+            t2 = ops.mlp_tail(t1, cur2, mr2, ps[2], ps[3], ps[4], ps[5], ps[6], ps[7], scd)
+        else:
+            y1 = ops.conv2d(cur2, ps[4], ps[5])
+            t2 = ops.gelu_linear_residual(y1, ps[6], ps[7], t1, scd)
+        t2.backward(gy.cuda())
+        res[fused] = (t2.detach().float().cpu(), td.grad.float().cpu(), [p_.grad.float().cpu() for p_ in ps])
+    (o1, d1, p1), (o0, d0, p0) = res[True], res[False]
+    assert torch.equal(o1, o0)
+    same = (d1 == d0).float().mean().item()
+    assert same > 0.97, same
+    torch.testing.assert_close(d1, d0, rtol=2e-2, atol=2e-2 * max(1.0, d0.abs().max().item()))
+    for a, b_, nm in zip(p1, p0, ('g1', 'b1', 'g2', 'b2', 'w1', 'bb1', 'w2', 'bb2')):
+        e = (a - b_).norm().item() / max(b_.norm().item(), 1e-12)
+        assert e < 5e-3, (nm, e)
+    # torch, fp32 arithmetic on the same bf16 input
+    tr = t0.float().requires_grad_(True)
+    pr = [p_.clone().requires_grad_(True) for p_ in (g1, b1, g2, b2, w1, bb1, w2, bb2)]
+    a = F.layer_norm(tr, (C,), pr[0], pr[1], 1e-6)
+    pooled = F.avg_pool2d(a[:, None], 3, 1, 1, count_include_pad=False)[:, 0] - a
+    t1r = tr + (pooled * sc.view(B, 1, 1) if scaled else pooled)
+    mlp = F.linear(F.gelu(F.linear(F.layer_norm(t1r, (C,), pr[2], pr[3], 1e-6), pr[4], pr[5])), pr[6], pr[7])
+    t2r = t1r + (mlp * sc.view(B, 1, 1) if scaled else mlp)
+    t2r.backward(gy.float())
+    torch.testing.assert_close(o1, t2r.detach(), rtol=4e-2, atol=4e-2)
+    torch.testing.assert_close(d1, tr.grad, rtol=5e-2, atol=5e-2 * max(1.0, tr.grad.abs().max().item()))
+    for a_, r_, nm in zip(p1, pr, ('g1', 'b1', 'g2', 'b2', 'w1', 'bb1', 'w2', 'bb2')):
+        e = (a_ - r_.grad).norm().item() / max(r_.grad.norm().item(), 1e-12)
+        assert e < 3e-2, (nm, e)
 
 
 @pytest.mark.parametrize('scaled', [False, True])
