@@ -370,6 +370,11 @@ int tcct_c3_bn_bwd_reduce(const void* x4, const float* w, const float* bias, con
                           double* raw, int post_act, tcct_stream_t stream);
 int tcct_c3_bn_bwd_wgrad(const void* x4, const float* w, const float* bias, const void* dz, int B, int H, int W, int stride, const float* coef,
                          float* dw, float* dbias, int post_act, tcct_stream_t stream);
+/* ... or both in ONE pass over dz (round 4): dy = a (dz' - s1 - yh s2) is linear in per-pixel quantities, so dW = a (A1 - s2 A2 - s1 A3) with A1 = sum dz' patch,
+ * A2 = sum yh patch, A3 = sum patch accumulated together with the batch sums; work fp32 [4160] and sums fp64 [96] are scratch (zero on entry when the outputs are
+ * pre-zeroed, cleared here otherwise); dw [32,3,3,3], dbias [32] (nullable), dgamma, dbeta [32] are overwritten. */
+int tcct_c3_bn_bwd_onepass(const void* x4, const float* w, const float* bias, const void* dz, int B, int H, int W, int stride, const float* mean_rstd,
+                           const float* ab, float* work, double* sums, float* dw, float* dbias, float* dgamma, float* dbeta, int post_act, tcct_stream_t stream);
 /* weight gradient of 1x1 convs with <= 8 outputs (5-class aux heads, nets/tcct.py:994-997); dy fp32 or bf16 */
 int tcct_pw_wgrad_smalln(const void* x, const void* dy, float* dw, float* dbias, int64_t M, int K, int N, int x_dtype,
                          int dy_dtype, tcct_stream_t stream);

@@ -242,6 +242,9 @@ extern "C" int tcct_c3_bn_fwd_train(const void* x4, const float* w, const float*
 #define C3_SD 64            // dz rows
 // MODE 0: red fp64 [64] += {sum dz', sum dz' y} (raw form, see tcct_bn_sums_from_raw / tcct_bn_bwd_coef(raw = 1))
 // MODE 1: dw fp32 [32,3,3,3] += dy^T patch, dbias += sum dy with dy = c1 dz' + c2 y + c3 (coef = {c1[32], c2[32], c3[32], a[32], b[32]})
+// MODE 2 (round 4): BOTH in one pass over dz.  dy = a (dz' - s1 - yh s2) is LINEAR in the per-pixel quantities (s1 = mean dz', s2 = mean dz' yh, yh = (y - mean) rstd
+//         known from the forward), so dW = a (A1 - s2 A2 - s1 A3) with A1 = sum dz' patch, A2 = sum yh patch, A3 = sum patch: the kernel accumulates the three
+//         sums (dw = workspace fp32: A1 [32][64], A2 [32][64], A3 [64]) and red fp64 [96] += {sum dz', sum dz' yh, sum yh}; k_c3_bn_bwd_fin combines them.  coef = mean_rstd [64].
 template <int MODE, int POST>
 __global__ void __launch_bounds__(C3B, 2)
 k_c3_bn_bwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, const bf16* __restrict__ dz, int64_t M,
@@ -259,18 +262,20 @@ k_c3_bn_bwd(const bf16* __restrict__ x, const float* __restrict__ w, const float
     const float bias_r = bias ? bias[r] : 0.f;
     const float a_r = ab[r], b_r = ab[32 + r];
     const float c1 = MODE == 1 ? coef[r] : 0.f, c2 = MODE == 1 ? coef[32 + r] : 0.f, c3 = MODE == 1 ? coef[64 + r] : 0.f;
+    const float mu_r = MODE == 2 ? coef[r] : 0.f, rs_r = MODE == 2 ? coef[32 + r] : 0.f;
     __syncthreads();
     bf16x8 wf[3];           // the lane's weight fragments (B operand: k = 16 i + 8 hh .. + 7 of column co = r), resident
 #pragma unroll
     for (int i = 0; i < 3; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sW + r * C3_SW + (16 * i + 8 * hh) * 2);
-    f32x16 acc[2];
-    if (MODE == 1) {
+    f32x16 acc[2], acc2[MODE == 2 ? 2 : 1];
+    float a3[2] = {0.f, 0.f};       // MODE 2: sum over pixels of patch element 32 kt + r (this lane half's pixels)
+    if (MODE >= 1) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) acc[b][k] = 0.f;
+            for (int k = 0; k < 16; ++k) { acc[b][k] = 0.f; if (MODE == 2) acc2[b][k] = 0.f; }
     }
-    float s1 = 0.f, s2 = 0.f;       // MODE 0: sum dz', sum dz' y of channel r;  MODE 1: s1 = sum dy (bias gradient)
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;       // MODE 0: sum dz', sum dz' y of channel r;  MODE 1: s1 = sum dy (bias gradient);  MODE 2: sum dz', sum dz' yh, sum yh
     const __amdgpu_buffer_rsrc_t c3r = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g3.bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t c3d = __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, (uint32_t)(M * 64), 0x00020000);
     uint4 px[3], pd[2];
@@ -363,6 +368,26 @@ k_c3_bn_bwd(const bf16* __restrict__ x, const float* __restrict__ w, const float
                 // pixels beyond M were staged as zeros in dz: they add nothing
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { s1 += dv[j]; s2 += dv[j] * yf[c][j]; }
+            } else if (MODE == 2) {
+                const int64_t p0 = m0 + 16 * ch + 8 * hh;
+                uint32_t pk[4], ph[4];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const float h0 = p0 + j < M ? (yf[c][j] - mu_r) * rs_r : 0.f, h1 = p0 + j + 1 < M ? (yf[c][j + 1] - mu_r) * rs_r : 0.f;
+                    s1 += dv[j] + dv[j + 1]; s2 += dv[j] * h0 + dv[j + 1] * h1; s3 += h0 + h1;
+                    if (POST != TCCT_ACT_NONE) pk[j >> 1] = pack_bf16x2(dv[j], dv[j + 1]);
+                    ph[j >> 1] = pack_bf16x2(h0, h1);
+                }
+                const bf16x8 dzp = POST == TCCT_ACT_NONE ? dzf : __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));      // dz' = dz: the fragment as read
+                const bf16x8 yhp = __builtin_bit_cast(bf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const bf16x8 xf = tr2(lbX + ch * 16 * C3_SX + 64 * kt, C3_SX);      // (patch rows of pixels beyond M are zeros: nothing to mask in the products)
+                    acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dzp, xf, acc[kt], 0, 0, 0);
+                    acc2[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yhp, xf, acc2[kt], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a3[kt] += (float)xf[j];
+                }
             } else {
                 const int64_t p0 = m0 + 16 * ch + 8 * hh;
                 uint32_t pk[4];
@@ -393,6 +418,39 @@ k_c3_bn_bwd(const bf16* __restrict__ x, const float* __restrict__ w, const float
             double a = 0.0;
 #pragma unroll
             for (int wv = 0; wv < 4; ++wv) a += (double)redf[wv * 64 + tid];
+            atomicAdd(&red[tid], a);
+        }
+        return;
+    }
+    if (MODE == 2) {
+        // two [32 co][64 k] matrices + the 64 patch sums: the four waves take turns adding theirs into LDS, then one fp32 atomic per element and block into the workspace
+        for (int turn = 0; turn < 4; ++turn) {
+            if (wave == turn) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int co = (k & 3) + 8 * (k >> 2) + 4 * hh, o = co * 64 + kt * 32 + r;
+                        redf[o] = turn == 0 ? acc[kt][k] : redf[o] + acc[kt][k];
+                        redf[2048 + o] = turn == 0 ? acc2[kt][k] : redf[2048 + o] + acc2[kt][k];
+                    }
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const float v = a3[kt] + __shfl_xor(a3[kt], 32, 64);
+                    if (lane < 32) redf[4096 + kt * 32 + r] = turn == 0 ? v : redf[4096 + kt * 32 + r] + v;
+                }
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < 2 * 2048 + 64; i += C3B) atomicAdd(&dw[i], redf[i]);
+        __syncthreads();
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); s3 += __shfl_xor(s3, 32, 64);
+        if (lane < 32) { redf[wave * 96 + r] = s1; redf[wave * 96 + 32 + r] = s2; redf[wave * 96 + 64 + r] = s3; }
+        __syncthreads();
+        if (tid < 96) {
+            double a = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) a += (double)redf[wv * 96 + tid];
             atomicAdd(&red[tid], a);
         }
         return;
@@ -432,11 +490,12 @@ static int c3_bn_bwd_launch(int mode, const void* x4, const float* w, const floa
     const int64_t tiles = (M + C3_P - 1) / C3_P;
     // weight gradient: >= 24 tiles per block (every block ends with 864 same-address atomics), between one and four blocks per CU; the reduction ends
     // with 64 atomics per block: up to four blocks per CU whatever the size (stride 2 at the bench shape ran 287 blocks: 0.082 ms for a 127 MB read)
-    const int per = mode == 0 ? 8 : 24;
+    const int per = mode == 0 ? 8 : 24;          // (mode 2 ends with 6144 + 96 atomics per block: as few blocks as mode 1)
     int gx = (int)(tiles / per < 256 ? 256 : (tiles / per > 1024 ? 1024 : tiles / per));
     if (gx > tiles) gx = (int)tiles;
 #define C3L(MD, PA) hipLaunchKernelGGL((k_c3_bn_bwd<MD, PA>), dim3(gx), dim3(C3B), lds, st, (const bf16*)x4, w, bias, (const bf16*)dz, M, ab, coef, red, dw, dbias, g)
     if (mode == 0) { if (post_act == TCCT_ACT_HSWISH) C3L(0, TCCT_ACT_HSWISH); else C3L(0, TCCT_ACT_NONE); }
+    else if (mode == 2) { if (post_act == TCCT_ACT_HSWISH) C3L(2, TCCT_ACT_HSWISH); else C3L(2, TCCT_ACT_NONE); }
     else { if (post_act == TCCT_ACT_HSWISH) C3L(1, TCCT_ACT_HSWISH); else C3L(1, TCCT_ACT_NONE); }
 #undef C3L
     return 0;
@@ -470,5 +529,45 @@ extern "C" int tcct_c3_bn_bwd_wgrad(const void* x4, const float* w, const float*
     if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * 32 * 27, st) != hipSuccess) { tcct_set_error("c3_bn_bwd_wgrad: memset failed"); return -2; }
     if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("c3_bn_bwd_wgrad: memset failed"); return -2; }
     c3_bn_bwd_launch(1, x4, w, bias, dz, B, H, W, stride, coef + 96, coef, nullptr, dw, dbias, post_act, st);
+    TCCT_LAUNCH_OK();
+}
+
+// ---- single-pass backward (MODE 2): combination of the accumulated matrices
+__global__ void k_c3_bn_bwd_fin(const float* __restrict__ wk /*[2][32][64] + [64]*/, const double* __restrict__ red /*[96]*/, int64_t M, const float* __restrict__ ab,
+                                float* __restrict__ dw /*[32][3][3][3]*/, float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float sa[32], ss1[32], ss2[32];
+    const int t = threadIdx.x;
+    if (t < 32) {
+        const double S1 = red[t], S2 = red[32 + t], S3 = red[64 + t];
+        const double a = ab[t], s1 = S1 / (double)M, s2 = S2 / (double)M;
+        sa[t] = (float)a; ss1[t] = (float)s1; ss2[t] = (float)s2;
+        dbeta[t] = (float)S1; dgamma[t] = (float)S2;
+        if (dbias) dbias[t] = (float)(a * (S1 - s2 * S3 - s1 * (double)M));      // (mathematically zero: the BatchNorm removes a bias; kept as the sum it is)
+    }
+    __syncthreads();
+    for (int i = t; i < 32 * 27; i += blockDim.x) {
+        const int co = i / 27, j = i - co * 27, ch = j / 9, ky = (j - ch * 9) / 3, kx = j - ch * 9 - ky * 3;
+        const int cl = 16 * ky + 4 * kx + ch;       // patch element of w[co][ch][ky][kx]
+        dw[i] = sa[co] * (wk[co * 64 + cl] - ss2[co] * wk[2048 + co * 64 + cl] - ss1[co] * wk[4096 + cl]);
+    }
+}
+/* Backward of tcct_c3_bn_fwd_train in ONE pass over dz (+ a one-block combination): dw fp32 [32,3,3,3], dbias [32] (nullable), dgamma, dbeta [32] are
+ * overwritten; work fp32 [4160] and sums fp64 [96] are scratch (zero on entry unless the outputs are pre-zeroed: cleared here otherwise).
+ * mean_rstd [64] and ab [64] as written by the forward. */
+extern "C" int tcct_c3_bn_bwd_onepass(const void* x4, const float* w, const float* bias, const void* dz, int B, int H, int W, int stride, const float* mean_rstd,
+                                      const float* ab, float* work, double* sums, float* dw, float* dbias, float* dgamma, float* dbeta, int post_act,
+                                      tcct_stream_t stream) {
+    TCCT_CHECK(stride == 1 || stride == 2, "c3_bn_bwd_onepass: stride %d", stride);
+    TCCT_CHECK(post_act == TCCT_ACT_NONE || post_act == TCCT_ACT_HSWISH, "c3_bn_bwd_onepass: post_act %d (none or hswish)", post_act);
+    TCCT_CHECK(mean_rstd && ab && work && sums && dw && dgamma && dbeta, "c3_bn_bwd_onepass: NULL argument");
+    const C3Geom g = c3_geom(B, H, W, stride);
+    const int64_t M = (int64_t)B * g.Ho * g.Wo, inb = (int64_t)B * H * W * 8;
+    TCCT_CHECK(M > 0 && M * 64 < (1ll << 31) && inb < (1ll << 31), "c3_bn_bwd_onepass: image too large for 32-bit byte offsets (B=%d H=%d W=%d)", B, H, W);
+    hipStream_t st = (hipStream_t)stream;
+    if (!tcct_skip_zero_fill() && (hipMemsetAsync(work, 0, sizeof(float) * (2 * 2048 + 64), st) != hipSuccess || hipMemsetAsync(sums, 0, sizeof(double) * 96, st) != hipSuccess)) {
+        tcct_set_error("c3_bn_bwd_onepass: memset failed"); return -2;
+    }
+    c3_bn_bwd_launch(2, x4, w, bias, dz, B, H, W, stride, ab, mean_rstd, sums, work, nullptr, post_act, st);
+    hipLaunchKernelGGL(k_c3_bn_bwd_fin, dim3(1), dim3(256), 0, st, (const float*)work, (const double*)sums, M, ab, dw, dbias, dgamma, dbeta);
     TCCT_LAUNCH_OK();
 }

@@ -1449,14 +1449,22 @@ class _ConvC3BN(torch.autograd.Function):
         coef = torch.empty(160, device=dev, dtype=torch.float32)
         # nothing downstream waits for this node (the image has no gradient): all of it runs beside the other encoder's tail on the weight-gradient stream
         with _wgrad_stream(_slot_written(w, bias, gamma, beta), x4, dz, coef, mean_rstd, ab):
-            lib.c3_bn_bwd_reduce(x4, w, bias, dz, B, H, W, stride, ab, raw, post)
             dg = _grad_out(gamma) if ZERO.active and getattr(gamma, '_grad_slot', None) is not None else torch.empty(32, device=dev, dtype=torch.float32)
             db_ = _grad_out(beta) if ZERO.active and getattr(beta, '_grad_slot', None) is not None else torch.empty(32, device=dev, dtype=torch.float32)
-            lib.bn_bwd_coef(raw, 1, M, 32, mean_rstd, ab, coef, dg, db_)
             dw = _grad_out(w, tuple(w.shape))
             dbias = _grad_out(bias) if bias is not None else None
-            lib.c3_bn_bwd_wgrad(x4, w, bias, dz, B, H, W, stride, coef, dw, dbias, post)
+            if C3_ONEPASS:      # reduction and weight gradient from ONE pass over dz (the BatchNorm backward is linear in per-pixel quantities)
+                work = ZERO.get((4160,), torch.float32, dev) if ZERO.active else torch.zeros(4160, device=dev, dtype=torch.float32)
+                s96 = ZERO.get((96,), torch.float64, dev) if ZERO.active else torch.zeros(96, device=dev, dtype=torch.float64)
+                lib.c3_bn_bwd_onepass(x4, w, bias, dz, B, H, W, stride, mean_rstd, ab, work, s96, dw, dbias, dg, db_, post)
+            else:
+                lib.c3_bn_bwd_reduce(x4, w, bias, dz, B, H, W, stride, ab, raw, post)
+                lib.bn_bwd_coef(raw, 1, M, 32, mean_rstd, ab, coef, dg, db_)
+                lib.c3_bn_bwd_wgrad(x4, w, bias, dz, B, H, W, stride, coef, dw, dbias, post)
         return None, _ret(dw, w), _ret(dbias, bias), _ret(dg, gamma), _ret(db_, beta), None, None, None, None, None, None, None
+
+
+C3_ONEPASS = os.environ.get('TCCT_C3_ONEPASS', '1') != '0'      # =0: BatchNorm reduction and weight gradient of the first layers as two passes over dz (A/B timing)
 
 
 def conv3x3_c3_bn_ok(x4, w, bn_training, post_act):
