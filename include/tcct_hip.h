@@ -66,6 +66,9 @@ int tcct_residual_fwd(const void* x, const void* z, const float* scale, void* y,
 int tcct_scale_rows(const void* x, const float* scale, void* y, int B, int64_t per_sample, int dtype,
                     tcct_stream_t stream);
 /* y = alpha * (a + b + c)  (norm_add mean, nets/tcct.py:942);  y = alpha * x */
+/* z = (a1[c] y1 + b1[c]) + (a2[c] y2 + b2[c]), ab = {a[C], b[C]}: the encoder fusion BN(tran_vit(v)) + BN(tran_cnn(c)) (nets/tcct.py:1016-1024) with both
+ * train-mode BatchNorms applied in ONE pass; C % 8 == 0 */
+int tcct_affine2_add(const void* y1, const float* ab1, const void* y2, const float* ab2, void* z, int64_t M, int C, int dtype, tcct_stream_t stream);
 int tcct_add3_scale(const void* a, const void* b, const void* c, void* y, int64_t n, float alpha, int dtype,
                     tcct_stream_t stream);
 int tcct_scale(const void* x, void* y, int64_t n, float alpha, int dtype, tcct_stream_t stream);

@@ -266,6 +266,12 @@ def ftc_forward(sd, x, train=True, dp_masks=None, p='base', want=None, feats_use
     v = vit_branch(sd, p + '.base_vit', x, train, dp_masks)
     f = [c[0]]
     for j in range(4):
+        if train and MODE.store is not _same:
+            # rounding-point model of the training path, round 4: both convolution outputs are stored, ONE pass applies both BatchNorms and adds them
+            yv = _conv(sd, f'{p}.tran_vit{j}.0', v[j], store=True)
+            yc = _conv(sd, f'{p}.tran_cnn{j}.0', c[j + 1], store=True)
+            f.append(_S(_bn(sd, f'{p}.tran_vit{j}.1', yv, train) + _bn(sd, f'{p}.tran_cnn{j}.1', yc, train)))
+            continue
         tv = _cba(sd, f'{p}.tran_vit{j}.0', f'{p}.tran_vit{j}.1', v[j], train)
         f.append(_cba(sd, f'{p}.tran_cnn{j}.0', f'{p}.tran_cnn{j}.1', c[j + 1], train, res=tv))      # tv + tc: the add rides on tc's pass
     y8 = _cba(sd, p + '.head.0', p + '.head.1', f[4], train, post='lrelu', pad=1)

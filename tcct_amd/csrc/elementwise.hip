@@ -322,6 +322,32 @@ extern "C" int tcct_axpy_f32(const float* x, float* y, int64_t n, float alpha, t
 }
 
 // ------------------------------------------------------------------------------------------- streaming-copy yardstick
+// z = (a1[c] y1 + b1[c]) + (a2[c] y2 + b2[c]): the encoder fusion f_j = BN(tran_vit(v)) + BN(tran_cnn(c)) (SimpleFusion, reference nets/tcct.py:1016-1024) with
+// BOTH train-mode BatchNorms applied in one pass (round 4: before, one normalisation pass wrote BN(tran_vit(v)) and the second read it back as a residual).
+// ab1, ab2 = {a[C], b[C]} of the two BatchNorms; bf16: 8 channels per thread (C % 8 == 0), fp32: 4.
+template <typename T, int VEC>
+__global__ void k_affine2_add(const T* __restrict__ y1, const float* __restrict__ ab1, const T* __restrict__ y2, const float* __restrict__ ab2, T* __restrict__ z,
+                              int64_t nvec, int C) {
+    const int CV = C / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % CV) * VEC;
+        float u[VEC], v[VEC], o[VEC];
+        ldv<VEC>(y1 + i * VEC, u); ldv<VEC>(y2 + i * VEC, v);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o[k] = (ab1[c0 + k] * u[k] + ab1[C + c0 + k]) + (ab2[c0 + k] * v[k] + ab2[C + c0 + k]);
+        stv<VEC>(z + i * VEC, o);
+    }
+}
+extern "C" int tcct_affine2_add(const void* y1, const float* ab1, const void* y2, const float* ab2, void* z, int64_t M, int C, int dtype, tcct_stream_t stream) {
+    TCCT_CHECK(y1 && ab1 && y2 && ab2 && z && M > 0 && C >= 8 && C % 8 == 0, "affine2_add: NULL argument or C=%d (multiple of 8)", C);
+    const int64_t n = M * C;
+    if (dtype == TCCT_BF16) hipLaunchKernelGGL((k_affine2_add<bf16, 8>), dim3(tcct_grid(n / 8, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, (const bf16*)y1, ab1,
+                                               (const bf16*)y2, ab2, (bf16*)z, n / 8, C);
+    else hipLaunchKernelGGL((k_affine2_add<float, 4>), dim3(tcct_grid(n / 4, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, (const float*)y1, ab1,
+                            (const float*)y2, ab2, (float*)z, n / 4, C);
+    TCCT_LAUNCH_OK();
+}
+
 // The copy rate the streaming kernels of this library are compared with (bench.py `roofline.copy_ceiling`): 16-byte accesses, one block-contiguous
 // 8 KB chunk per block, a grid as large as the tensor (tools/probe/stream_probe.hip: 6.0 TB/s on the MI355X against 5.3 for persistent blocks and
 // 4.9 for hipMemcpyDtoD; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy).

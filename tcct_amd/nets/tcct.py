@@ -674,6 +674,12 @@ class FTC(nn.Module):
                     half = torch.empty_like(sm)
                     ops.lib.scale(sm, half, sm.numel(), 0.5, ops.dtype_code(sm.dtype))
                     f.append(half)
+                elif (ops.TRAN_FUSE and c.shape[-1] % 8 == 0 and ops.pw_conv_bn_ok(v, tv[0].weight, tv[0].bias, tv[1].training, None, None)
+                      and ops.pw_conv_bn_ok(c, tc[0].weight, tc[0].bias, tc[1].training, None, None)):
+                    # both BatchNorms applied by ONE pass that also adds them: BN(tran_vit(v)) is never written and read back
+                    yv, lv = ops.pw_conv_bn(v, tv[0].weight, tv[0].bias, _bn_args(tv[1]), None, defer_apply=True)
+                    yc, lc = ops.pw_conv_bn(c, tc[0].weight, tc[0].bias, _bn_args(tc[1]), None, defer_apply=True)
+                    f.append(ops.affine2_add(yv, lv, yc, lc))
                 else:
                     f.append(_conv_bn(tc[0], tc[1], c, residual=_conv_bn(tv[0], tv[1], v)))
         elif self.flag_cnn:

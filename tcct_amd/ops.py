@@ -1727,6 +1727,33 @@ class _PwConvBN(torch.autograd.Function):
                 (dz if has_res else None), None, None, None, None, None)
 
 
+class _Affine2Add(torch.autograd.Function):
+    """z = BN1(y1) + BN2(y2) with both normalisations PENDING on their inputs (pw_conv_bn(defer_apply=True) with no activation): one pass; the gradient of z is
+    the gradient of both BatchNorm outputs"""
+
+    @staticmethod
+    def forward(ctx, y1, ab1, y2, ab2):
+        _chk(y1, ab1, y2, ab2)
+        z = torch.empty_like(y1)
+        C = y1.shape[-1]
+        lib.affine2_add(y1, ab1, y2, ab2, z, y1.numel() // C, C, dtype_code(y1.dtype))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        return dz, None, dz, None
+
+
+TRAN_FUSE = os.environ.get('TCCT_TRAN_FUSE', '1') != '0'      # =0: the two BatchNorms of the encoder fusion keep their own normalisation passes (A/B timing)
+
+
+def affine2_add(y1, link1, y2, link2):
+    """BN1(y1) + BN2(y2) for two tensors that carry a pending train-mode BatchNorm (links from pw_conv_bn(..., defer_apply=True))"""
+    if y1.shape != y2.shape or y1.dtype != y2.dtype or y1.shape[-1] % 8:
+        raise TcctError('affine2_add: two NHWC tensors of one shape and dtype, channels a multiple of 8')
+    return _Affine2Add.apply(y1, link1.ab, y2, link2.ab)
+
+
 BN_RED_DW = os.environ.get('TCCT_BN_RED_DW', '1') != '0'      # =0: the BatchNorms in front of the depthwise convolutions keep their backward reduction pass (A/B)
 BN_DEFER_DW = os.environ.get('TCCT_BN_DEFER_DW', '1') != '0'  # =0: the BatchNorms in front of the depthwise convolutions keep their normalisation pass (A/B timing)
 BN_DEFER = os.environ.get('TCCT_BN_DEFER', '1') != '0'        # =0: InvRes.norm keeps its own normalisation pass (round-3 form; A/B timing)
@@ -1822,8 +1849,8 @@ def pw_conv_bn(x, w, bias, bn, post_act=None, residual=None, fork=False, x2=None
         prev = None
     if defer_apply:
         # the caller hands the result (y with the normalisation + Hardswish PENDING) and `link` to dwconv3x3(..., deferred=link) and to nothing else
-        if residual is not None or x2 is not None or ACT[post_act] != ACT['hswish']:
-            raise TcctError('pw_conv_bn(defer_apply=True): BatchNorm + Hardswish without residual / concatenation only')
+        if residual is not None or x2 is not None or ACT[post_act] not in (ACT['hswish'], ACT['none']):
+            raise TcctError('pw_conv_bn(defer_apply=True): BatchNorm (+ Hardswish) without residual / concatenation only')
         out = _PwConvBN.apply(x, None, w4, bias, gamma, beta, rm, rv, nbt, float(eps), float(mom), ACT[post_act], None, fork, link, prev, None, True)
         return out, link
     out = _PwConvBN.apply(x, x2, w4, bias, gamma, beta, rm, rv, nbt, float(eps), float(mom), ACT[post_act], residual, fork, link, prev)

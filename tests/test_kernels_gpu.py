@@ -954,6 +954,73 @@ def test_depthwise_applies_the_pending_batchnorm_equals_the_separate_pass(site):
     assert (a['dx'] != 0).any() and any('dwconv.weight' in k for k in a)
 
 
+@pytest.mark.parametrize('dt', DT)
+def test_encoder_fusion_with_both_batchnorms_in_one_pass(dt):
+    """ops.affine2_add (tcct_affine2_add): f_j = BN(tran_vit(v)) + BN(tran_cnn(c)) (SimpleFusion, reference nets/tcct.py:1016-1024) with both train-mode
+    BatchNorms pending on their convolution outputs and applied by ONE pass -- output, running statistics and every gradient against the two-pass form
+    (fp32: to rounding; bf16: the two-pass form rounds BN(tran_vit(v)) once more) and against torch"""
+    import importlib
+    from tcct_amd import ops
+    T = importlib.import_module('tcct_amd.nets.tcct')
+    torch.manual_seed(3)
+    v0, c0 = rnd(2, 96, 12, 20, dt=dt), rnd(2, 32, 12, 20, seed=1, dt=dt)
+    gy = rnd(2, 32, 12, 20, seed=2, dt=dt)
+
+    def build():
+        torch.manual_seed(9)
+        m = nn.ModuleList([nn.Sequential(nn.Conv2d(96, 32, 1), nn.BatchNorm2d(32)), nn.Sequential(nn.Conv2d(32, 32, 1), nn.BatchNorm2d(32))])
+        with torch.no_grad():
+            for i, s_ in enumerate(m):
+                s_[1].weight.copy_(1.0 + 0.2 * rnd(32, seed=20 + i)); s_[1].bias.copy_(0.2 * rnd(32, seed=30 + i))
+        return m
+    res = {}
+    for fused in (True, False):
+        m = build().cuda().train()
+        v, c = nhwc(v0, dt).requires_grad_(True), nhwc(c0, dt).requires_grad_(True)
+        tv, tc = m[0], m[1]
+        if fused:
+            if dt == torch.bfloat16:
+                assert ops.pw_conv_bn_ok(v, tv[0].weight, tv[0].bias, True, None, None) and ops.pw_conv_bn_ok(c, tc[0].weight, tc[0].bias, True, None, None)
+                yv, lv = ops.pw_conv_bn(v, tv[0].weight, tv[0].bias, T._bn_args(tv[1]), None, defer_apply=True)
+                yc, lc = ops.pw_conv_bn(c, tc[0].weight, tc[0].bias, T._bn_args(tc[1]), None, defer_apply=True)
+                out = ops.affine2_add(yv, lv, yc, lc)
+            else:       # fp32 has no fused convolution + BatchNorm node: the kernel itself on explicit coefficients
+                yv, yc = T._conv(tv[0], v), T._conv(tc[0], c)
+                ab = []
+                for y_, bn in ((yv, tv[1]), (yc, tc[1])):
+                    mu, var = y_.detach().float().mean((0, 1, 2)), y_.detach().float().var((0, 1, 2), unbiased=False)
+                    a_ = bn.weight.detach() / torch.sqrt(var + bn.eps)
+                    ab.append(torch.cat([a_, bn.bias.detach() - mu * a_]).contiguous())
+                out = ops._Affine2Add.apply(yv, ab[0], yc, ab[1])
+                ref = T._bn(tv[1], yv.detach()) + T._bn(tc[1], yc.detach())
+                torch.testing.assert_close(out.detach(), ref, rtol=1e-5, atol=1e-5)
+                return
+        else:
+            out = T._conv_bn(tc[0], tc[1], c, residual=T._conv_bn(tv[0], tv[1], v))
+        out.backward(nhwc(gy, dt))
+        res[fused] = dict(out=out.detach().float().cpu(), dv=v.grad.float().cpu(), dc=c.grad.float().cpu(),
+                          **{'b:' + n: b_.float().cpu().clone() for n, b_ in m.named_buffers()},
+                          **{'g:' + n: p_.grad.float().cpu() for n, p_ in m.named_parameters()})
+    a, b = res[True], res[False]
+    assert set(a) == set(b)
+    for k in a:
+        if k.startswith('b:'):
+            assert torch.equal(a[k], b[k]), k
+        else:
+            e = (a[k] - b[k]).norm().item() / max(b[k].norm().item(), 1e-12)
+            assert e < 6e-3, (k, e)          # (the two-pass form rounds one of the two addends to bf16 first)
+    # torch
+    vr, cr = v0.float().requires_grad_(True), c0.float().requires_grad_(True)
+    mr = build().train()
+    with torch.no_grad():
+        for s_ in mr:
+            s_[0].weight.copy_(s_[0].weight.to(torch.bfloat16).float())
+    o = mr[0](vr) + mr[1](cr)
+    o.backward(gy.float())
+    torch.testing.assert_close(nchw(nhwc(a['out'].permute(0, 3, 1, 2), dt)), o.detach(), rtol=4e-2, atol=4e-2)
+    torch.testing.assert_close(a['dv'].permute(0, 3, 1, 2), vr.grad, rtol=5e-2, atol=5e-2 * max(1.0, vr.grad.abs().max().item()))
+
+
 def test_flat_adamw_state_refuses_a_permuted_layout():
     """FlatAdamW.state_dict() records the flat buffer's order by parameter NAME (not shape: dozens of tensors share 32x32x3x3 / [32]): moments saved
     from one order must not be applied to another order of equally shaped tensors; the same order round-trips"""
