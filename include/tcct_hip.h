@@ -300,6 +300,10 @@ int tcct_pw_bwd_bn_sums_xaff(const void* y_prev, const float* ab_prev, const voi
  *   bwd: dx1 = (dy W) gelu'(x1), dw += dy^T gelu(x1), dbias += sum dy   (dw / dbias cleared here unless tcct_set_outputs_prezeroed) */
 int tcct_pw_fwd_gelu_residual(const void* x1, const float* w, const float* bias, const void* res, const float* scale, int64_t per_sample, void* y,
                               int64_t M, int K, int N, tcct_stream_t stream);
+/* tcct_pw_bwd_residual2 for the decoder blocks whose output has TWO gradients (its own consumer and `x_i + y_i`): dy = dy_a + dy_b is summed while the tile is
+ * staged, no separate add pass; K = N = 32 */
+int tcct_pw_bwd_residual2_sum(const void* x, const void* dy_a, const void* dy_b, const float* w, const void* res, void* dx_sum, void* dx_plain, float* dw,
+                              float* dbias, int64_t M, int K, int N, tcct_stream_t stream);
 /* fused backward of Mlp.fc1 BEHIND MHCABlock.norm2 (nets/tcct.py:466-468): x = LN(t) as stored, t and mean_rstd [M][2] the LayerNorm's input and saved statistics,
  * res = the gradient that reaches t through the residual path; dt = LN^T(dy W) + res (the gradient of x is never written), dw / dbias of the Linear, dgamma / dbeta
  * [K] of the LayerNorm.  K = N = 64. */

@@ -808,7 +808,9 @@ template <int KIND> __device__ __forceinline__ float pw_act_grad(float u) {
 // g = d gamma, s1 = mean_c g, s2 = mean_c g xh, out = rstd (g - s1 - xh s2) + res with xh = (t - mean) rstd rebuilt from the LayerNorm's INPUT t (bn.yprev) and
 // its saved statistics (bn.mean_rstd [M][2]) -- and writes the gradient of t (+ res, the gradient that reaches t through the residual path); dgamma / dbeta
 // (bn.dgamma / bn.dbeta, fp32 [K], zero on entry) are accumulated.  The separate LayerNorm backward pass (read t, read d, read res, write) is gone.
-template <int NT, int KT, bool SPLIT = false, int BNP = -1, int REDP = -1, bool GX = false, int XAP = -1, bool LNB = false>
+// DY2 (round 4): dy = dy + dy2 (bn.y carries dy2), rounded to bf16 as the tensor a separate add pass used to write -- the decoder block's two output gradients
+// (MPUpBlock's own output and `x_i + y_i`, reference nets/tcct.py:908-914,1028-1031) are summed while the tile is staged
+template <int NT, int KT, bool SPLIT = false, int BNP = -1, int REDP = -1, bool GX = false, int XAP = -1, bool LNB = false, bool DY2 = false>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ w, const bf16* __restrict__ res,
          bf16* __restrict__ dx, bf16* __restrict__ dx_plain, float* __restrict__ dw, float* __restrict__ dbias, int64_t M, PwBnBwd bn) {
@@ -868,9 +870,9 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(res ? res : x), 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)dx, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(dx_plain ? dx_plain : dx), 0, xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(BN ? bn.y : dy), 0, dbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)((BN || DY2) ? bn.y : dy), 0, dbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ryp = __builtin_amdgcn_make_buffer_rsrc((void*)((RED || LNB) ? bn.yprev : x), 0, xbytes, 0x00020000);
-    u32x4 px[XS], pd[DS], py[BN ? DS : 1];
+    u32x4 px[XS], pd[DS], py[(BN || DY2) ? DS : 1];
     // a tile's rows are one contiguous span of memory: slot i of a thread = bytes [16 (tid + 256 i), +16) of it (fully coalesced);
     // rows beyond M fall outside the descriptor and read as zeros
     auto prefetch = [&](int64_t tile) {
@@ -882,7 +884,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
         }
 #pragma unroll
         for (int j = 0; j < DS; ++j) pd[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, bd + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
-        if (BN) {
+        if (BN || DY2) {
 #pragma unroll
             for (int j = 0; j < DS; ++j) py[j] = __builtin_amdgcn_raw_buffer_load_b128(ry, bd + (uint32_t)(tid + j * PWB) * 16u, 0, 0);
         }
@@ -899,6 +901,12 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
         for (int j = 0; j < DS; ++j) {
             const int q = tid + j * PWB, p = q / (N / 8), c = q - p * (N / 8);
             u32x4 v = pd[j];
+            if (DY2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    v[k] = pack_bf16x2(__uint_as_float(pd[j][k] << 16) + __uint_as_float(py[j][k] << 16),
+                                       __uint_as_float(pd[j][k] & 0xffff0000u) + __uint_as_float(py[j][k] & 0xffff0000u));
+            }
             if (BN) {
                 // dy_conv = c1 dz post'(a y + b) + c2 y + c3, rounded to bf16 like the tensor the separate apply pass used to write
                 const bool live = tile * PB_P + p < M;
@@ -1237,7 +1245,7 @@ k_pw_bwd(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* _
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
                        int64_t M, int K, int N, tcct_stream_t stream, bool split = false, int bnp = -1, int redp = -1,
                        PwBnBwd bn = PwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr}, bool gelu_x = false,
-                       int xap = -1, bool lnb = false);
+                       int xap = -1, bool lnb = false, bool dy2 = false);
 /* the same over a concatenation: x = [x1 | x2], dx = [dx1 | dx2], each [M, K/2] (K = 128): backward of tcct_pw_fwd_cat2 */
 extern "C" int tcct_pw_bwd_cat2(const void* x1, const void* x2, const void* dy, const float* w, void* dx1, void* dx2, float* dw, int64_t M,
                                 int K, int N, tcct_stream_t stream) {
@@ -1333,6 +1341,14 @@ extern "C" int tcct_pw_bwd_gelu(const void* x1, const void* dy, const float* w, 
     return pw_bwd_impl(x1, dy, w, nullptr, dx1, nullptr, dw, dbias, M, K, N, stream, false, -1, -1,
                        PwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr}, true);
 }
+/* tcct_pw_bwd_residual2 with dy = dy_a + dy_b summed while the tile is staged (rounded to bf16 like the tensor a separate add pass wrote); K = N = 32 */
+extern "C" int tcct_pw_bwd_residual2_sum(const void* x, const void* dy_a, const void* dy_b, const float* w, const void* res, void* dx_sum, void* dx_plain, float* dw,
+                                         float* dbias, int64_t M, int K, int N, tcct_stream_t stream) {
+    TCCT_CHECK(K == 32 && N == 32, "pw_bwd_residual2_sum: K=%d N=%d unsupported (32 x 32)", K, N);
+    TCCT_CHECK(dy_b != nullptr && res != nullptr && dx_plain != nullptr && dx_plain != dx_sum, "pw_bwd_residual2_sum: needs dy_b, res and two distinct outputs");
+    return pw_bwd_impl(x, dy_a, w, res, dx_sum, dx_plain, dw, dbias, M, K, N, stream, false, -1, -1,
+                       PwBnBwd{(const bf16*)dy_b, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr}, false, -1, false, true);
+}
 /* Backward of  y = LN(t; gamma, beta) W^T + b  (MHCABlock.norm2 -> Mlp.fc1, reference nets/tcct.py:466-468) given dy, x = LN(t) as stored, t, the LayerNorm's
  * saved statistics mean_rstd [M][2] and res = the gradient reaching t through the residual path: dt = LN^T(dy W) + res, dw, dbias as tcct_pw_bwd, dgamma / dbeta
  * [K] of the LayerNorm (cleared here unless the outputs are pre-zeroed) -- one pass, the gradient of x is never written.  K = N = 64. */
@@ -1348,7 +1364,7 @@ extern "C" int tcct_pw_bwd_lnb(const void* x, const void* dy, const float* w, co
                        PwBnBwd{nullptr, nullptr, (const bf16*)t, gamma, nullptr, nullptr, 0, mean_rstd, nullptr, dgamma, dbeta}, false, -1, true);
 }
 static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void* res, void* dx, void* dx_plain, float* dw, float* dbias,
-                       int64_t M, int K, int N, tcct_stream_t stream, bool split, int bnp, int redp, PwBnBwd bn, bool gelu_x, int xap, bool lnb) {
+                       int64_t M, int K, int N, tcct_stream_t stream, bool split, int bnp, int redp, PwBnBwd bn, bool gelu_x, int xap, bool lnb, bool dy2) {
     TCCT_CHECK(K % 32 == 0 && N % 32 == 0 && K >= 32 && N >= 32 && K <= 128 && N <= 128, "pw_bwd: K=%d N=%d unsupported (32..128)", K, N);
     TCCT_CHECK(M > 0 && M * (int64_t)(K > N ? K : N) * 2 < (1LL << 31), "pw_bwd: tensor exceeds the 2 GiB buffer-descriptor range");
     hipStream_t st = (hipStream_t)stream;
@@ -1368,6 +1384,11 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
     if (gx > tiles) gx = tiles;
 #define BLX(NTV, KTV, SPV, BNV, RDV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<NTV, KTV, SPV, BNV, RDV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
         hipLaunchKernelGGL((k_pw_bwd<NTV, KTV, SPV, BNV, RDV>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M, bn); }
+    if (dy2) {          // decoder block tail: the two output gradients summed on load (K = N = 32)
+        { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<1, 1, false, -1, -1, false, -1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; }
+          hipLaunchKernelGGL((k_pw_bwd<1, 1, false, -1, -1, false, -1, false, true>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M, bn); }
+        TCCT_LAUNCH_OK();
+    }
     if (lnb) {          // fc1 behind MHCABlock.norm2: the LayerNorm backward in the dx epilogue (K = N = 64)
 #define BLN(T) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_bwd<T, T, false, -1, -1, false, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
         hipLaunchKernelGGL((k_pw_bwd<T, T, false, -1, -1, false, -1, true>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)dy, w, (const bf16*)res, (bf16*)dx, (bf16*)dx_plain, dw, dbias, M, bn); }

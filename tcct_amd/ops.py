@@ -960,12 +960,22 @@ class _UpSkipConv(torch.autograd.Function):
         N_, H, W_, C, Ho, Wo, align = ctx.cfg
         if gd is None and gs is None:
             return None, None, None, None, None, None
+        Cout, M = w.shape[0], N_ * Ho * Wo
+        if (gd is not None and gs is not None and DY2_FUSE and FUSED_PW_BWD and C == 32 and Cout == 32 and u.dtype == torch.bfloat16
+                and _pw_bwd_ok(u, _c(gs), C, C, Cout, 1, 1, 1, 0, 0)):
+            # the two output gradients are summed while the backward kernel stages its tiles: no add pass
+            gd, gs = _c(gd), _c(gs)
+            du, dskip = torch.empty_like(u), torch.empty_like(u)
+            dw, db = _grad_out(wsrc, tuple(w.shape)), _grad_out(bsrc)
+            lib.pw_bwd_residual2_sum(u, gd, gs, w, gs, dskip, du, dw, db, M, C, Cout)
+            dy = torch.empty((N_, H, W_, C), device=u.device, dtype=u.dtype)
+            lib.bilinear_bwd(du, dy, N_, H, W_, C, Ho, Wo, align, dtype_code(u.dtype))
+            return dy, dskip, _ret(dw, wsrc), _ret(db, bsrc), None, None
         if gd is None or gs is None:
             dz = _c(gd if gs is None else gs)
         else:
             dz = torch.empty_like(gs)
             lib.add(_c(gd), _c(gs), dz, dz.numel(), dtype_code(dz.dtype))
-        Cout, M = w.shape[0], N_ * Ho * Wo
         du = torch.empty_like(u)
         fused = FUSED_PW_BWD and _pw_bwd_ok(u, dz, C, C, Cout, 1, 1, 1, 0, 0)
         if fused:       # both input gradients and the weight / bias gradients from ONE pass over dz
@@ -991,6 +1001,9 @@ class _UpSkipConv(torch.autograd.Function):
                 db = _grad_out(bsrc)
                 lib.pw_wgrad(u, dz, dw, db, M, C, Cout)
         return dy, dskip, _ret(dw, wsrc), _ret(db, bsrc), None, None
+
+
+DY2_FUSE = os.environ.get('TCCT_DY2', '1') != '0'      # =0: the decoder blocks add their two output gradients in a separate pass (A/B timing)
 
 
 def up_skip_conv(y, skip, w, bias, align_corners=True, want_plain=True):

@@ -1684,7 +1684,7 @@ def test_forked_consumers_fold_the_gradient_accumulation(dt, cfg):
 
 
 @pytest.mark.parametrize('dt', DT)
-@pytest.mark.parametrize('cfg', [(32, 9, 14), (64, 6, 10), (96, 5, 4)])
+@pytest.mark.parametrize('cfg', [(32, 9, 14), (32, 33, 41), (64, 6, 10), (96, 5, 4)])
 def test_decoder_tail_node_and_layernorm_fork(dt, cfg):
     """up_skip_conv = conv1x1(resize_x2(y) + skip) and + skip as one autograd node (MPUpBlock tail, reference tcct.py:908-914,1028-1031):
     outputs and all four gradients vs torch; layernorm_fork: x + f(LN(x)) with the residual gradient added in the LN backward kernel"""
