@@ -318,6 +318,9 @@ int tcct_pw_dgrad_residual(const void* dy, const float* w, const void* res, void
  * BN statistics), input gradient written to two tensors, weight gradient -- the channel concatenation is never materialised */
 int tcct_pw_fwd_cat2(const void* x1, const void* x2, int K1, const float* w, const float* bias, void* y, int64_t M, int K, int N,
                      double* stats, int pre_act, tcct_stream_t stream);
+/* y fp32 [B*2uH*2uW, N] = x W^T + bias + resize_x2(up)[..., :N] (bilinear, align_corners=True), N <= 8; up fp32 [B,uH,uW,8] (channels >= N zero): the level-0 aux
+ * head with the resize commuted behind the convolution adds the low-resolution product in the epilogue of the full-resolution GEMM */
+int tcct_pw_fwd_f32_upadd(const void* x, const float* w, const float* bias, float* y, int B, int uH, int uW, int K, int N, const float* up, tcct_stream_t stream);
 int tcct_pw_dgrad_split2(const void* dy, const float* w, void* dx1, void* dx2, int K1, int64_t M, int Nout, int K, tcct_stream_t stream);
 /* fused backward over the concatenation incl. the bias gradient: dx1 | dx2 = dy W, dw += dy^T [x1 | x2], dbias += sum dy; two halves of 64 channels
  * (K = 128) or, for N = 32, of 32 channels (K = 64: the decoder's composed tail below) */

@@ -38,7 +38,10 @@ __device__ __forceinline__ float rnd_out(float v, const float*) { return v; }
 // slot 3 / channel 3 zero (K = 48): k-step ky of an MFMA is then, per lane half, two whole 8-byte pixels of ONE input row (kx 0,1 / kx 2,-)
 // and needs no repacking, and the row validity of a load is one compare per ky
 // (C3Geom, udiv_m: c3_geom.h)
-struct PwSplit { const bf16* x2; int K1; void* y2; int N1; const bf16* res; const float* rscale; int64_t per_sample; bf16* yplain; C3Geom c3; };
+// up (round 4, fp32 output with N <= 8): y += resize_x2(up) with align_corners, up fp32 [B, uH, uW, 8] at half the resolution (channels >= N zero) -- the level-0 head
+// with the resize commuted behind the convolution adds up(Wa y) to Wb skip + c in the epilogue of the skip GEMM instead of in a pass of its own
+struct PwUp { const float* p; int uH, uW, Ho, Wo; float sh, sw; uint32_t m_howo, m_wo; };
+struct PwSplit { const bf16* x2; int K1; void* y2; int N1; const bf16* res; const float* rscale; int64_t per_sample; bf16* yplain; C3Geom c3; PwUp up; };
 // res (inference-epilogue kernel only): y = res + rscale[m / per_sample] * (x W^T + bias), rscale nullable -- Mlp.fc2 with the
 // residual add and the DropPath scale of MHCABlock folded in (reference nets/tcct.py:468)
 // STATS: also accumulate per-channel sum / sum of squares of pre_act(y) (y as stored) into stats[0..N) / stats[N..2N): the
@@ -262,6 +265,20 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                         for (int k = 0; k < 4; ++k) { a4[k] = (aff && co + k < N) ? aff[co + k] : 1.f; b4[k] = (aff && co + k < N) ? aff[N + co + k] : 0.f; }
                         affine4(v, a4, b4, aff_pre, aff_post);
                     }
+                    if (sizeof(Tout) == 4 && sp.up.p && q == 0) {          // (block-uniform) + bilinear x2 of the low-resolution addend: the lane's pixel m, channels 4 hh + k
+                        const uint32_t mm = (uint32_t)m, howo = (uint32_t)(sp.up.Ho * sp.up.Wo);
+                        const uint32_t n_ = udiv_m(mm, howo, sp.up.m_howo), rem = mm - n_ * howo;
+                        const uint32_t ho = udiv_m(rem, (uint32_t)sp.up.Wo, sp.up.m_wo), wo = rem - ho * (uint32_t)sp.up.Wo;
+                        const Lerp a = src_index((int)ho, sp.up.sh, sp.up.uH, 1), b = src_index((int)wo, sp.up.sw, sp.up.uW, 1);
+                        const float* r0 = sp.up.p + ((int64_t)n_ * sp.up.uH + a.i0) * sp.up.uW * 8 + 4 * hh;
+                        const float* r1 = sp.up.p + ((int64_t)n_ * sp.up.uH + a.i1) * sp.up.uW * 8 + 4 * hh;
+                        const float4 v00 = *reinterpret_cast<const float4*>(r0 + b.i0 * 8), v01 = *reinterpret_cast<const float4*>(r0 + b.i1 * 8);
+                        const float4 v10 = *reinterpret_cast<const float4*>(r1 + b.i0 * 8), v11 = *reinterpret_cast<const float4*>(r1 + b.i1 * 8);
+                        const float t0[4] = {v00.x, v00.y, v00.z, v00.w}, t1[4] = {v01.x, v01.y, v01.z, v01.w};
+                        const float t2[4] = {v10.x, v10.y, v10.z, v10.w}, t3[4] = {v11.x, v11.y, v11.z, v11.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = (a.l0 * (b.l0 * t0[k] + b.l1 * t1[k]) + a.l1 * (b.l0 * t2[k] + b.l1 * t3[k])) + v[k];       // the order of tcct_bilinear_add_fwd
+                    }
                     if (co + 3 < N && (N & 3) == 0) st_out4(y + m * N + co, v[0], v[1], v[2], v[3]);
                     else {
 #pragma unroll
@@ -351,6 +368,19 @@ extern "C" int tcct_pw_fwd_cat2_f32(const void* x1, const void* x2, int K1, cons
     return pw_fwd_impl(x1, w, bias, y, M, K, N, 0, TCCT_F32, nullptr, 0, stream, nullptr, 0, 0, PwSplit{(const bf16*)x2, K1, nullptr, 0, nullptr, nullptr, 1, nullptr});
 }
 /* input gradient of the same convolution: [dx1 | dx2] = dy W with w [Nout, K] (the weight as stored), dy [M, Nout]; dx1 [M,K1], dx2 [M,K-K1] */
+/* y fp32 [M,N] = x W^T + bias + resize_x2(up)[..., :N] (bilinear, align_corners=True) for N <= 8: x bf16 [B*Ho*Wo, K] at the full resolution, up fp32 [B,uH,uW,8]
+ * at half of it (Ho = 2 uH, Wo = 2 uW; channels >= N zero).  The level-0 aux head with the resize commuted behind the convolution (nets/tcct.py:908-914,1031-1041). */
+extern "C" int tcct_pw_fwd_f32_upadd(const void* x, const float* w, const float* bias, float* y, int B, int uH, int uW, int K, int N, const float* up,
+                                     tcct_stream_t stream) {
+    TCCT_CHECK(N >= 1 && N <= 8 && up != nullptr && B >= 1 && uH >= 1 && uW >= 1, "pw_fwd_f32_upadd: N=%d (1..8), up, B, uH, uW", N);
+    const int Ho = 2 * uH, Wo = 2 * uW;
+    const int64_t M = (int64_t)B * Ho * Wo;
+    TCCT_CHECK(M < (1ll << 31), "pw_fwd_f32_upadd: %lld pixels exceed the 32-bit index arithmetic", (long long)M);
+    PwSplit sp{nullptr, 0, nullptr, 0, nullptr, nullptr, 1, nullptr};
+    sp.up = PwUp{up, uH, uW, Ho, Wo, Ho > 1 ? (float)(uH - 1) / (float)(Ho - 1) : 0.f, Wo > 1 ? (float)(uW - 1) / (float)(Wo - 1) : 0.f,
+                 (uint32_t)((1ull << 32) / (uint64_t)(Ho * Wo)), (uint32_t)((1ull << 32) / (uint64_t)Wo)};
+    return pw_fwd_impl(x, w, bias, y, M, K, N, 0, TCCT_F32, nullptr, 0, stream, nullptr, 0, 0, sp);
+}
 extern "C" int tcct_pw_dgrad_split2(const void* dy, const float* w, void* dx1, void* dx2, int K1, int64_t M, int Nout, int K,
                                     tcct_stream_t stream) {
     TCCT_CHECK(dx2 != nullptr, "pw_dgrad_split2: dx2 is NULL");

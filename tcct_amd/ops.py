@@ -1142,14 +1142,20 @@ class _UpSkipConvT32AuxLow(torch.autograd.Function):
         dev, nc = y.device, w3.shape[0]
         F32_ = dtype_code(torch.float32)
         wcc = torch.empty((nc, 64), device=dev, dtype=torch.float32)
-        wa, wb = torch.empty((nc, 32, 1, 1), device=dev, dtype=torch.float32), torch.empty((nc, 32, 1, 1), device=dev, dtype=torch.float32)
+        wa8 = torch.zeros((8, 32, 1, 1), device=dev, dtype=torch.float32)        # rows >= n_class stay zero: the low-resolution product has 8 channels (16-byte taps)
+        wa, wb = wa8[:nc], torch.empty((nc, 32, 1, 1), device=dev, dtype=torch.float32)
         ccc = torch.empty(nc, device=dev, dtype=torch.float32)
         lib.tail_compose3(w1, b1, w2, b2, w3, b3, nc, wcc, wa, wb, ccc)
-        z = torch.empty((N_, H, W_, nc), device=dev, dtype=torch.float32)
-        lib.pw_fwd(y, wa, None, z, N_ * H * W_, 32, nc, 0, F32_)
         lg = torch.empty((N_, Ho, Wo, nc), device=dev, dtype=torch.float32)
-        lib.pw_fwd(skip, wb, ccc, lg, N_ * Ho * Wo, 32, nc, 0, F32_)
-        lib.bilinear_add_fwd(z, lg, lg, N_, H, W_, nc, Ho, Wo, int(align), F32_)       # in place: every element reads its own addend, then is written
+        if HEAD_UPADD and align and Ho == 2 * H and Wo == 2 * W_:
+            z8 = torch.empty((N_, H, W_, 8), device=dev, dtype=torch.float32)
+            lib.pw_fwd(y, wa8, None, z8, N_ * H * W_, 32, 8, 0, F32_)
+            lib.pw_fwd_f32_upadd(skip, wb, ccc, lg, N_, H, W_, 32, nc, z8)             # up(z) added in the epilogue of the full-resolution GEMM
+        else:
+            z = torch.empty((N_, H, W_, nc), device=dev, dtype=torch.float32)
+            lib.pw_fwd(y, wa, None, z, N_ * H * W_, 32, nc, 0, F32_)
+            lib.pw_fwd(skip, wb, ccc, lg, N_ * Ho * Wo, 32, nc, 0, F32_)
+            lib.bilinear_add_fwd(z, lg, lg, N_, H, W_, nc, Ho, Wo, int(align), F32_)   # in place: every element reads its own addend, then is written
         ctx.save_for_backward(y, skip, wa, wb)
         ctx.params = (w1, b1, w2, b2, w3, b3)
         ctx.cfg = (N_, H, W_, C, Ho, Wo, int(align), nc)
@@ -1178,6 +1184,7 @@ class _UpSkipConvT32AuxLow(torch.autograd.Function):
         return (dy, dskip) + tuple(_ret(o, p) for o, p in zip(outs, params)) + (None,)
 
 
+HEAD_UPADD = os.environ.get('TCCT_HEAD_UPADD', '1') != '0'       # =0: the resized low-resolution product is added by its own pass (A/B timing)
 TAIL_AUX_LOW = os.environ.get('TCCT_TAIL_AUX_LOW', '1') != '0'   # =0: the composed head reads the resized 32-channel tensor (the first round-4 form; A/B timing)
 
 
