@@ -488,6 +488,11 @@ int tcct_updice_fwd(const float* low, const uint8_t* labels, int B, int h, int w
                     tcct_stream_t stream);
 int tcct_updice_bwd(const float* low, const uint8_t* labels, int B, int h, int w, int H, int W, int C, const double* sums,
                     const float* grad_out, float grad_scale, float* ws, float* dlow, tcct_stream_t stream);
+/* the whole deep-supervision criterion of KiteSeg.grad_calc (kite/loopback.py:62-73) in one launch sequence: loss = sum_{i=3,2,1} coff * Dice(resize(low_i)) +
+ * Dice(logits), fp32 scalar arithmetic in the reference's order; one memset, one finalisation.  low_i fp32 [B,h_i,w_i,C], nullable from the back; sums fp64 [4*3C]
+ * (head i at i*3C: pass the slices to tcct_softmax_dice_bwd / tcct_updice_bwd with grad_scale = coff). */
+int tcct_dice_ds_fwd(const void* logits, int dtype, const uint8_t* labels, int B, int H, int W, int C, const float* low1, int h1, int w1, const float* low2,
+                     int h2, int w2, const float* low3, int h3, int w3, float coff, double* sums, float* loss, tcct_stream_t stream);
 /* softmax prob of the labelled class (regular_udh sort key, nets/reg.py:89) and/or argmax class (KiteSeg.predict,
  * kite/loop_seg.py:32); either output may be NULL */
 int tcct_softmax_pick(const void* logits, const uint8_t* labels, int64_t M, int C, float* prob_lab, uint8_t* argmax,

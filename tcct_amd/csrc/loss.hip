@@ -26,6 +26,19 @@ extern "C" int tcct_updice_fwd(const float* low, const uint8_t* labels, int B, i
 extern "C" int tcct_updice_bwd(const float* low, const uint8_t* labels, int B, int h, int w, int H, int W, int C, const double* sums, const float* grad_out, float grad_scale, float* ws, float* dlow, tcct_stream_t stream) {
     return C <= 8 ? mc8::tcct_updice_bwd_impl(low, labels, B, h, w, H, W, C, sums, grad_out, grad_scale, ws, dlow, stream) : mc16::tcct_updice_bwd_impl(low, labels, B, h, w, H, W, C, sums, grad_out, grad_scale, ws, dlow, stream);
 }
+/* KiteSeg.grad_calc with MultiLoss(DiceLoss) and deep supervision (reference kite/loopback.py:62-73, kite/losses/loss.py:15-32,83-99):
+ *   loss = sum_{i = 3, 2, 1} coff * Dice(resize(low_i)) + Dice(logits)      (fp32 scalar arithmetic in that order)
+ * logits [B,H,W,C] (dtype), low_i fp32 [B,h_i,w_i,C] (nullable from the back: low3 == NULL -> two heads, ...), labels uint8 [B,H,W];
+ * sums fp64 [4 * 3C] (cleared here; head i at offset i * 3C, kept for tcct_softmax_dice_bwd / tcct_updice_bwd with grad_scale = coff). */
+extern "C" int tcct_dice_ds_fwd(const void* logits, int dtype, const uint8_t* labels, int B, int H, int W, int C, const float* low1, int h1, int w1,
+                                const float* low2, int h2, int w2, const float* low3, int h3, int w3, float coff, double* sums, float* loss,
+                                tcct_stream_t stream) {
+    const float* lows[3] = {low1, low2, low3};
+    const int lh[3] = {h1, h2, h3}, lw[3] = {w1, w2, w3};
+    const int nlow = low1 ? (low2 ? (low3 ? 3 : 2) : 1) : 0;
+    return C <= 8 ? mc8::tcct_dice_ds_fwd_impl(logits, dtype, labels, B, H, W, C, lows, lh, lw, nlow, coff, sums, loss, stream)
+                  : mc16::tcct_dice_ds_fwd_impl(logits, dtype, labels, B, H, W, C, lows, lh, lw, nlow, coff, sums, loss, stream);
+}
 extern "C" int tcct_softmax_pick(const void* logits, const uint8_t* labels, int64_t M, int C, float* prob_lab, uint8_t* argmax, int dtype, tcct_stream_t stream) {
     return C <= 8 ? mc8::tcct_softmax_pick_impl(logits, labels, M, C, prob_lab, argmax, dtype, stream) : mc16::tcct_softmax_pick_impl(logits, labels, M, C, prob_lab, argmax, dtype, stream);
 }

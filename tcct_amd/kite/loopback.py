@@ -12,8 +12,10 @@ import torch
 from torch.optim import lr_scheduler
 
 from .. import dist as tdist
+from .. import ops
 from ..optim import FlatAdamW
 from .losses import get_loss
+from .losses.loss import MultiLoss, as_nhwc, as_label_index
 
 
 def setup_seed(seed):
@@ -51,6 +53,11 @@ class KiteBack(object):
     def grad_calc(self, outs, true, ds=True, criterion=None):
         """deep supervision, reference loopback.py:62-73: sum_{i=3,2,1} coff_ds*crit(outs[i]) + crit(outs[0])"""
         losSum = 0
+        if ds and isinstance(criterion, MultiLoss) and ops.deep_supervision_dice_ok(outs, self.args.coff_ds) and torch.is_grad_enabled():
+            # the whole deep-supervision criterion as one node (same sum, same order, no scalar torch kernels between the Dice kernels)
+            logits0 = as_nhwc(outs[0])
+            if logits0.shape[1:3] == tuple(outs[1].size) and logits0.shape[-1] <= 8:
+                return ops.deep_supervision_dice(logits0, as_label_index(true), list(outs[1:]), self.args.coff_ds)
         if isinstance(outs, (list, tuple)):
             if ds:
                 for i in range(len(outs) - 1, 0, -1):

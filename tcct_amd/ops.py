@@ -2715,6 +2715,58 @@ class _UpDice(torch.autograd.Function):
         return d, None, None, None
 
 
+class _DeepSupervisionDice(torch.autograd.Function):
+    """KiteSeg.grad_calc with MultiLoss(DiceLoss) (reference kite/loopback.py:62-73): sum_{i=3,2,1} coff * Dice(resize(low_i)) + Dice(logits0) as ONE node: one
+    memset, four sums kernels, one finalisation; the scalar multiplications and additions of the loop (a dozen 5-us launches on the single-stream stretch of the
+    step, each way) are arithmetic inside the finalisation kernel / the grad_scale argument of the backward kernels."""
+
+    @staticmethod
+    def forward(ctx, logits0, labels, coff, H, W, *lows):
+        _chk(logits0, labels, *lows)
+        B, _, _, C = logits0.shape
+        sums = torch.empty(4 * 3 * C, device=logits0.device, dtype=torch.float64)
+        loss = torch.empty((), device=logits0.device, dtype=torch.float32)
+        a = []
+        for i in range(3):
+            a += [lows[i], lows[i].shape[1], lows[i].shape[2]] if i < len(lows) else [None, 0, 0]
+        lib.dice_ds_fwd(logits0, dtype_code(logits0.dtype), labels, B, H, W, C, *a, coff, sums, loss)
+        ctx.save_for_backward(logits0, labels, sums, *lows)
+        ctx.cfg = (coff, H, W)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits0, labels, sums, *lows = ctx.saved_tensors
+        coff, H, W = ctx.cfg
+        B, _, _, C = logits0.shape
+        g = _as(g, torch.float32)
+        d0 = torch.empty_like(logits0)
+        lib.softmax_dice_bwd(logits0, labels, logits0.numel() // C, C, sums[:3 * C], g, 1.0, d0, dtype_code(logits0.dtype))
+        dl = []
+        for i, low in enumerate(lows):
+            _, h, w, _ = low.shape
+            ws = torch.empty((B, H, w, C), device=low.device, dtype=torch.float32)
+            d = torch.empty_like(low)
+            lib.updice_bwd(low, labels, B, h, w, H, W, C, sums[(i + 1) * 3 * C:(i + 2) * 3 * C], g, coff, ws, d)
+            dl.append(d)
+        return (d0, None, None, None, None) + tuple(dl)
+
+
+DS_DICE_FUSE = os.environ.get('TCCT_DS_DICE', '1') != '0'        # =0: one criterion node per head + torch scalar arithmetic (A/B timing)
+
+
+def deep_supervision_dice_ok(outs, coff):
+    """outs = [logits0 (NCHW view of NHWC memory or NHWC), LowResLogits x 1..3]"""
+    return (DS_DICE_FUSE and isinstance(outs, (list, tuple)) and 2 <= len(outs) <= 4 and all(isinstance(o, LowResLogits) and o.fusable() for o in outs[1:])
+            and torch.is_tensor(outs[0]) and outs[0].dim() == 4 and len({o.size for o in outs[1:]}) == 1)
+
+
+def deep_supervision_dice(logits0_nhwc, labels, lows, coff):
+    """sum_{i = n..1} coff * Dice(resize(lows[i-1])) + Dice(logits0): lows = [LowResLogits of outs[1], outs[2], ...] (the reference's loop runs from the last)"""
+    H, W = lows[0].size
+    return _DeepSupervisionDice.apply(logits0_nhwc, labels, float(coff), H, W, *[l_.low for l_ in lows])
+
+
 class LowResLogits:
     """A deep-supervision head before its resize: `low` fp32 NHWC [B,h,w,C] + the target size.  FTC.forward returns these instead of
     the resized tensors when `defer_aux_resize` is set (KiteSeg.calc_loss does, in training); the Dice criterion consumes them with the

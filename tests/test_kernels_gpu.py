@@ -1021,6 +1021,40 @@ def test_encoder_fusion_with_both_batchnorms_in_one_pass(dt):
     torch.testing.assert_close(a['dv'].permute(0, 3, 1, 2), vr.grad, rtol=5e-2, atol=5e-2 * max(1.0, vr.grad.abs().max().item()))
 
 
+@pytest.mark.parametrize('C', [5, 8])
+def test_deep_supervision_dice_as_one_node(C):
+    """ops.deep_supervision_dice (tcct_dice_ds_fwd): sum_{i=3,2,1} coff * Dice(resize(low_i)) + Dice(logits0) (reference kite/loopback.py:62-73) as one node
+    against the four criterion nodes + torch scalar arithmetic it replaces: the loss bit for bit, every gradient bit for bit (same kernels, the factor
+    coff applied inside them instead of by a torch multiply -- compared with a tolerance of one fp32 rounding)"""
+    from tcct_amd import ops
+    B, H, W = 2, 32, 48
+    g = torch.Generator().manual_seed(C)
+    lab = torch.randint(0, C, (B, H, W), generator=g).to(torch.uint8).cuda()
+    l0 = torch.randn(B, H, W, C, generator=g)
+    lows = [torch.randn(B, H // s_, W // s_, C, generator=g) for s_ in (2, 4, 8)]
+    coff = 0.7
+    res = {}
+    for fused in (True, False):
+        x0 = l0.cuda().requires_grad_(True)
+        xs = [t.cuda().requires_grad_(True) for t in lows]
+        lr = [ops.LowResLogits(t, (H, W)) for t in xs]
+        if fused:
+            assert ops.deep_supervision_dice_ok([x0.permute(0, 3, 1, 2)] + lr, coff)
+            loss = ops.deep_supervision_dice(x0, lab, lr, coff)
+        else:
+            loss = 0
+            for i in (2, 1, 0):
+                loss = loss + ops.softmax_dice_upsampled(lr[i], lab) * coff
+            loss = loss + ops.softmax_dice(x0, lab)
+        (loss * 1.5).backward()
+        res[fused] = (loss.detach().cpu(), x0.grad.cpu(), [t.grad.cpu() for t in xs])
+    (la, ga, gsa), (lb, gb, gsb) = res[True], res[False]
+    assert torch.equal(la, lb), (la, lb)
+    assert torch.equal(ga, gb)
+    for a, b in zip(gsa, gsb):
+        torch.testing.assert_close(a, b, rtol=3e-7, atol=0)
+
+
 def test_flat_adamw_state_refuses_a_permuted_layout():
     """FlatAdamW.state_dict() records the flat buffer's order by parameter NAME (not shape: dozens of tensors share 32x32x3x3 / [32]): moments saved
     from one order must not be applied to another order of equally shaped tensors; the same order round-trips"""
