@@ -3,6 +3,13 @@
 #include "common.h"
 
 #define LB 256
+// The class-count bound MAXC sizes every per-class register array and loop of loss_classes.inc (entries beyond C are predicated off, not skipped): the
+// benchmark's 5 classes ran the 8-wide code with 3 of 8 exponentials / accumulators wasted, so 5 has its own instantiation (round 4)
+#define MAXC 5
+#define MCNS mc5
+#include "loss_classes.inc"
+#undef MCNS
+#undef MAXC
 #define MAXC 8
 
 #define MCNS mc8
@@ -15,16 +22,16 @@
 #undef MCNS
 
 extern "C" int tcct_softmax_dice_fwd(const void* logits, const uint8_t* labels, int64_t M, int C, double* sums, float* loss, int dtype, tcct_stream_t stream) {
-    return C <= 8 ? mc8::tcct_softmax_dice_fwd_impl(logits, labels, M, C, sums, loss, dtype, stream) : mc16::tcct_softmax_dice_fwd_impl(logits, labels, M, C, sums, loss, dtype, stream);
+    return C == 5 ? mc5::tcct_softmax_dice_fwd_impl(logits, labels, M, C, sums, loss, dtype, stream) : (C <= 8 ? mc8::tcct_softmax_dice_fwd_impl(logits, labels, M, C, sums, loss, dtype, stream) : mc16::tcct_softmax_dice_fwd_impl(logits, labels, M, C, sums, loss, dtype, stream));
 }
 extern "C" int tcct_softmax_dice_bwd(const void* logits, const uint8_t* labels, int64_t M, int C, const double* sums, const float* grad_out, float grad_scale, void* dlogits, int dtype, tcct_stream_t stream) {
-    return C <= 8 ? mc8::tcct_softmax_dice_bwd_impl(logits, labels, M, C, sums, grad_out, grad_scale, dlogits, dtype, stream) : mc16::tcct_softmax_dice_bwd_impl(logits, labels, M, C, sums, grad_out, grad_scale, dlogits, dtype, stream);
+    return C == 5 ? mc5::tcct_softmax_dice_bwd_impl(logits, labels, M, C, sums, grad_out, grad_scale, dlogits, dtype, stream) : (C <= 8 ? mc8::tcct_softmax_dice_bwd_impl(logits, labels, M, C, sums, grad_out, grad_scale, dlogits, dtype, stream) : mc16::tcct_softmax_dice_bwd_impl(logits, labels, M, C, sums, grad_out, grad_scale, dlogits, dtype, stream));
 }
 extern "C" int tcct_updice_fwd(const float* low, const uint8_t* labels, int B, int h, int w, int H, int W, int C, double* sums, float* loss, tcct_stream_t stream) {
-    return C <= 8 ? mc8::tcct_updice_fwd_impl(low, labels, B, h, w, H, W, C, sums, loss, stream) : mc16::tcct_updice_fwd_impl(low, labels, B, h, w, H, W, C, sums, loss, stream);
+    return C == 5 ? mc5::tcct_updice_fwd_impl(low, labels, B, h, w, H, W, C, sums, loss, stream) : (C <= 8 ? mc8::tcct_updice_fwd_impl(low, labels, B, h, w, H, W, C, sums, loss, stream) : mc16::tcct_updice_fwd_impl(low, labels, B, h, w, H, W, C, sums, loss, stream));
 }
 extern "C" int tcct_updice_bwd(const float* low, const uint8_t* labels, int B, int h, int w, int H, int W, int C, const double* sums, const float* grad_out, float grad_scale, float* ws, float* dlow, tcct_stream_t stream) {
-    return C <= 8 ? mc8::tcct_updice_bwd_impl(low, labels, B, h, w, H, W, C, sums, grad_out, grad_scale, ws, dlow, stream) : mc16::tcct_updice_bwd_impl(low, labels, B, h, w, H, W, C, sums, grad_out, grad_scale, ws, dlow, stream);
+    return C == 5 ? mc5::tcct_updice_bwd_impl(low, labels, B, h, w, H, W, C, sums, grad_out, grad_scale, ws, dlow, stream) : (C <= 8 ? mc8::tcct_updice_bwd_impl(low, labels, B, h, w, H, W, C, sums, grad_out, grad_scale, ws, dlow, stream) : mc16::tcct_updice_bwd_impl(low, labels, B, h, w, H, W, C, sums, grad_out, grad_scale, ws, dlow, stream));
 }
 /* KiteSeg.grad_calc with MultiLoss(DiceLoss) and deep supervision (reference kite/loopback.py:62-73, kite/losses/loss.py:15-32,83-99):
  *   loss = sum_{i = 3, 2, 1} coff * Dice(resize(low_i)) + Dice(logits)      (fp32 scalar arithmetic in that order)
@@ -36,8 +43,7 @@ extern "C" int tcct_dice_ds_fwd(const void* logits, int dtype, const uint8_t* la
     const float* lows[3] = {low1, low2, low3};
     const int lh[3] = {h1, h2, h3}, lw[3] = {w1, w2, w3};
     const int nlow = low1 ? (low2 ? (low3 ? 3 : 2) : 1) : 0;
-    return C <= 8 ? mc8::tcct_dice_ds_fwd_impl(logits, dtype, labels, B, H, W, C, lows, lh, lw, nlow, coff, sums, loss, stream)
-                  : mc16::tcct_dice_ds_fwd_impl(logits, dtype, labels, B, H, W, C, lows, lh, lw, nlow, coff, sums, loss, stream);
+    return C == 5 ? mc5::tcct_dice_ds_fwd_impl(logits, dtype, labels, B, H, W, C, lows, lh, lw, nlow, coff, sums, loss, stream) : (C <= 8 ? mc8::tcct_dice_ds_fwd_impl(logits, dtype, labels, B, H, W, C, lows, lh, lw, nlow, coff, sums, loss, stream) : mc16::tcct_dice_ds_fwd_impl(logits, dtype, labels, B, H, W, C, lows, lh, lw, nlow, coff, sums, loss, stream));
 }
 extern "C" int tcct_softmax_pick(const void* logits, const uint8_t* labels, int64_t M, int C, float* prob_lab, uint8_t* argmax, int dtype, tcct_stream_t stream) {
     return C <= 8 ? mc8::tcct_softmax_pick_impl(logits, labels, M, C, prob_lab, argmax, dtype, stream) : mc16::tcct_softmax_pick_impl(logits, labels, M, C, prob_lab, argmax, dtype, stream);
