@@ -490,6 +490,18 @@ class MPViT(nn.Module):
         """DropPath (timm, reference tcct.py:452,465,468): per-sample Bernoulli(keep)/keep, train mode only."""
         out = []
         forced = list(self.forced_dp_masks) if self.forced_dp_masks is not None else None
+        if forced is None and self.training and any(p > 0.0 for p in self.drop_probs):
+            # all masks of the step from ONE draw (the draws used to be a dozen 2-us launches in front of the first kernel of the step); the RNG stream is not
+            # pinned to the reference's (timm's DropPath version is not, either): parity tests force the masks
+            act = [s for s in range(4) if self.drop_probs[s] > 0.0]
+            key = (device, B, tuple(self.drop_probs))
+            if getattr(self, '_dp_keep', (None,))[0] != key:
+                keep = torch.tensor([1.0 - self.drop_probs[s] for s in act for _ in range(2)], device=device, dtype=torch.float32).view(-1, 1)
+                self._dp_keep = (key, keep)
+            keep = self._dp_keep[1]
+            m = (torch.rand((2 * len(act), B), device=device) < keep).to(torch.float32) / keep
+            it = iter(range(len(act)))
+            return [((m[2 * i], m[2 * i + 1]) if self.drop_probs[s] > 0.0 else None) for s in range(4) for i in ([next(it)] if self.drop_probs[s] > 0.0 else [None])]
         for s in range(4):
             p = self.drop_probs[s]
             if p == 0.0 or not self.training:
