@@ -122,6 +122,9 @@ int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_t M, int C,
 int tcct_bn_bwd_coef(const double* sums, int raw, int64_t M, int C, const float* mean_rstd, const float* ab, float* coef, float* dgamma,
                      float* dbeta, tcct_stream_t stream);
 /* {sum dz', sum dz' y} (raw, from a reduction epilogue) -> {S1, S2 = sum dz' xhat}: the form tcct_bn_bwd_apply reads */
+/* two BatchNorms (no activation) whose outputs were added and so share dz: raw_i fp64 [2C] (zero on entry) += {sum dz, sum dz y_i} from one pass (the raw form
+ * tcct_bn_sums_from_raw / tcct_pw_bwd_bn_sums(raw = 1) take); C % 4 == 0 */
+int tcct_bn_bwd_reduce2_raw(const void* y1, const void* y2, const void* dz, int64_t M, int C, double* raw1, double* raw2, int dtype, tcct_stream_t stream);
 int tcct_bn_sums_from_raw(const double* raw, const float* mean_rstd, int C, double* sums, tcct_stream_t stream);
 
 /* fused CrossCNNBlock junction y = act(BN_A(pre(xa)) + BN_B(pre(xb))) (nets/tcct.py:811,817,825-826: LeakyReLU -> BN on both

@@ -260,6 +260,46 @@ __global__ void __launch_bounds__(NBR) k_bn_bwd_reduce(const T* __restrict__ x, 
     }
     bn_block_reduce2<VEC>(sm, s, q, t, C, CV, R, sums);
 }
+// Two train-mode BatchNorms (no activation) whose outputs were ADDED (the encoder fusion BN(tran_vit(v)) + BN(tran_cnn(c)), reference nets/tcct.py:1016-1024)
+// receive the same gradient dz: their backward sums in raw form, raw_i = {sum dz, sum dz y_i}, from ONE pass over dz, y1, y2 (round 4; two reduction passes read
+// dz twice)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(NBR) k_bn_bwd_reduce2_raw(const T* __restrict__ y1, const T* __restrict__ y2, const T* __restrict__ dz, int64_t M, int C,
+                                                            double* __restrict__ raw1, double* __restrict__ raw2) {
+    __shared__ float sm[NBR * VEC];
+    const int CV = C / VEC;
+    const int R = NBR / CV;
+    const int t = threadIdx.x;
+    const bool active = t < R * CV;
+    const int cv = t % CV, r = t / CV;
+    float s[VEC], q1[VEC], q2[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s[k] = q1[k] = q2[k] = 0.f;
+    if (active) {
+        for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += (int64_t)gridDim.x * R) {
+            const int64_t off = m * C + cv * VEC;
+            float a[VEC], b[VEC], g[VEC];
+            ldv<VEC>(y1 + off, a); ldv<VEC>(y2 + off, b); ldv<VEC>(dz + off, g);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { s[k] += g[k]; q1[k] += g[k] * a[k]; q2[k] += g[k] * b[k]; }
+        }
+    }
+    bn_block_reduce2<VEC>(sm, s, q1, t, C, CV, R, raw1);
+    __syncthreads();
+    bn_block_reduce2<VEC>(sm, s, q2, t, C, CV, R, raw2);
+}
+extern "C" int tcct_bn_bwd_reduce2_raw(const void* y1, const void* y2, const void* dz, int64_t M, int C, double* raw1, double* raw2, int dtype,
+                                       tcct_stream_t stream) {
+    TCCT_CHECK(C >= 4 && C % 4 == 0 && C <= NB && y1 && y2 && dz && raw1 && raw2, "bn_bwd_reduce2_raw: C=%d (multiple of 4, <= 256) or NULL argument", C);
+    hipStream_t st = (hipStream_t)stream;
+    if (!tcct_skip_zero_fill() && (hipMemsetAsync(raw1, 0, sizeof(double) * 2 * C, st) != hipSuccess || hipMemsetAsync(raw2, 0, sizeof(double) * 2 * C, st) != hipSuccess)) {
+        tcct_set_error("bn_bwd_reduce2_raw: memset failed"); return -2;
+    }
+    const int R = NBR / (C / 4);
+    const int grid = tcct_grid(M, R, 512);
+    TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce2_raw<T, 4>), dim3(grid), dim3(NBR), 0, st, (const T*)y1, (const T*)y2, (const T*)dz, M, C, raw1, raw2));
+    TCCT_LAUNCH_OK();
+}
 extern "C" int tcct_bn_bwd_reduce(const void* x, const void* dy, int64_t M, int C, const float* mean_rstd, const float* ab,
                                   int pre_act, int post_act, double* sums, int dtype, tcct_stream_t stream) {
     TCCT_CHECK(C >= 1 && C <= NB, "bn_bwd_reduce: C=%d unsupported", C);

@@ -1752,18 +1752,33 @@ class _Affine2Add(torch.autograd.Function):
     the gradient of both BatchNorm outputs"""
 
     @staticmethod
-    def forward(ctx, y1, ab1, y2, ab2):
+    def forward(ctx, y1, ab1, y2, ab2, link1=None, link2=None):
         _chk(y1, ab1, y2, ab2)
         z = torch.empty_like(y1)
         C = y1.shape[-1]
         lib.affine2_add(y1, ab1, y2, ab2, z, y1.numel() // C, C, dtype_code(y1.dtype))
+        ctx.links = (link1, link2)
+        if link1 is not None and link2 is not None:
+            ctx.save_for_backward(y1, y2)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        return dz, None, dz, None
+        l1, l2 = ctx.links
+        if l1 is not None and l2 is not None and BN_FUSE_RED and TRAN_RED2:
+            # both BatchNorms receive dz: their backward sums (raw form, through the links) from ONE pass over dz, y1, y2
+            y1, y2 = ctx.saved_tensors
+            dz = _as(dz, y1.dtype)
+            C = y1.shape[-1]
+            dev = y1.device
+            r1 = ZERO.get((2 * C,), torch.float64, dev) if ZERO.active else torch.zeros(2 * C, device=dev, dtype=torch.float64)
+            r2 = ZERO.get((2 * C,), torch.float64, dev) if ZERO.active else torch.zeros(2 * C, device=dev, dtype=torch.float64)
+            lib.bn_bwd_reduce2_raw(y1, y2, dz, y1.numel() // C, C, r1, r2, dtype_code(y1.dtype))
+            l1.sums, l2.sums = r1, r2
+        return dz, None, dz, None, None, None
 
 
+TRAN_RED2 = os.environ.get('TCCT_TRAN_RED2', '1') != '0'      # =0: the two fused BatchNorms keep separate backward reduction passes (A/B timing)
 TRAN_FUSE = os.environ.get('TCCT_TRAN_FUSE', '1') != '0'      # =0: the two BatchNorms of the encoder fusion keep their own normalisation passes (A/B timing)
 
 
@@ -1771,7 +1786,7 @@ def affine2_add(y1, link1, y2, link2):
     """BN1(y1) + BN2(y2) for two tensors that carry a pending train-mode BatchNorm (links from pw_conv_bn(..., defer_apply=True))"""
     if y1.shape != y2.shape or y1.dtype != y2.dtype or y1.shape[-1] % 8:
         raise TcctError('affine2_add: two NHWC tensors of one shape and dtype, channels a multiple of 8')
-    return _Affine2Add.apply(y1, link1.ab, y2, link2.ab)
+    return _Affine2Add.apply(y1, link1.ab, y2, link2.ab, link1, link2)
 
 
 BN_RED_DW = os.environ.get('TCCT_BN_RED_DW', '1') != '0'      # =0: the BatchNorms in front of the depthwise convolutions keep their backward reduction pass (A/B)
