@@ -912,6 +912,147 @@ k_conv32_wgrad33_roll(const bf16* __restrict__ x, const bf16* __restrict__ dy, f
     if (dbias && tid < 32) atomicAdd(&dbias[tid], red[tid] + red[32 + tid]);
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 weight gradient, wave-private row streams (round 4)
+// Every tiled form above keeps ONE tile per block in flight and hands it over through block barriers: the bytes in flight per CU swing between a full
+// tile set and nothing, and the three forms tie at ~0.23 ms whatever their LDS / instruction budget is.  Here nothing is shared between waves: a wave
+// owns a 16-pixel-wide column strip of one image and walks down its rows.  Row a of the strip (18 x pixels with the two halo columns + 16 dy pixels,
+// 2176 B) travels global -> LDS by three `buffer_load_dwordx4 ... lds` pieces into a wave-private ring of WS_R rows; WS_P rows are always in flight
+// (issued one per row consumed: `s_waitcnt vmcnt(3 (WS_P - 1))` retires exactly the next row), so the memory pipe sees a steady stream instead of tile
+// bursts.  Per row: the three dx operands are three transposing reads of the same LDS row at pixel offsets 0, 1, 2, the dy fragments of rows a, a - 1,
+// a - 2 roll through registers, nine MFMAs into nine accumulators (all taps in one wave: 144 accumulator registers, two waves per SIMD).  No block
+// barrier until the final reduction.  Out-of-image rows / columns and the dy rows behind a segment's end are buffer-range misses (the DMA writes zeros).
+// Work: the strips of all images form one sequence of N * strips * H rows, cut into equal runs of rows per wave (a run may continue into the next strip).
+#define WS_T 256
+#define WS_R 9                  // ring rows per wave (a multiple of 3: ring slot and dy-window position are compile-time in the 9-fold unrolled body)
+#define WS_P 7                  // rows in flight
+#define WS_ROWB 2176            // 18 x pixels (1152 B) + 16 dy pixels (1024 B)
+#define WS_MIN_RUN 32            // rows per wave below which the pipeline fill (7 rows per segment) costs more than the tiles' barriers: levels 0-1 stream, 2-4 roll
+__device__ __forceinline__ void lds_dma16(const u32x4& rsrc, uint32_t voff, uint32_t lds_addr) {
+    // 64 lanes x 16 B from per-lane buffer offsets to LDS bytes [lds_addr + 16 lane ..): inline asm on purpose -- the builtin form makes hipcc treat the DMA as a
+    // pending LDS store and drain it (vmcnt(0)) in front of the next ds_read.  M0 (the LDS base) is compiler-reserved: saved and restored.
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ u32x4 make_rsrc_words(const void* base, uint32_t bytes) {
+    const uint64_t b = (uint64_t)base;
+    u32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    d[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);
+    d[2] = __builtin_amdgcn_readfirstlane(bytes);
+    d[3] = 0x00020000u;
+    return d;
+}
+__global__ void __launch_bounds__(WS_T, 2)
+k_conv32_wgrad33_stream(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
+                        int N, int H, int W, int strips, int run) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    unsigned char* ring = smem + wave * (WS_R * WS_ROWB);
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)ring);
+    const unsigned char* xb = tr_lane_base(ring, lane);
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    float bsum = 0.f;
+    const int64_t total = (int64_t)N * strips * H;
+    const int gw = blockIdx.x * (WS_T / 64) + wave;
+    int64_t cur = (int64_t)gw * run;
+    const int64_t end = cur + run < total ? cur + run : total;
+    const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
+    const uint32_t rowb = (uint32_t)W * 64u;
+    const int px = lane >> 2, c = lane & 3;
+    while (cur < end) {
+        const int sidx = (int)(cur / H), r0 = (int)(cur - (int64_t)sidx * H);
+        const int n = sidx / strips, s = sidx - n * strips;
+        const int left = (int)(end - cur);
+        const int L = __builtin_amdgcn_readfirstlane(H - r0 < left ? H - r0 : left);      // dy rows r0 .. r0 + L - 1; x rows r0 - 1 .. r0 + L
+        const int w0 = s * 16;
+        const u32x4 rx = make_rsrc_words(x + (int64_t)n * H * W * 32, img_bytes);
+        const u32x4 rd = make_rsrc_words(dy + (int64_t)n * H * W * 32, img_bytes);
+        const int cx1 = w0 - 1 + px, cx2 = w0 + 15 + px, cd = w0 + px;
+        const uint32_t ox1 = (cx1 >= 0 && cx1 < W) ? (uint32_t)(cx1 * 64 + c * 16) : OOB_OFF;
+        const uint32_t ox2 = (cx2 < W) ? (uint32_t)(cx2 * 64 + c * 16) : OOB_OFF;
+        const uint32_t od = (cd < W) ? (uint32_t)(cd * 64 + c * 16) : OOB_OFF;
+        const uint32_t row0 = (uint32_t)(r0 - 1) * rowb;            // r0 = 0: wraps far beyond the descriptor range -> zeros (the padding row)
+        // halo row a of the segment -> ring slot `slot`; rows behind the segment (a > L + 1) and dy rows a >= L are all-miss pieces (zeros, no HBM traffic)
+        auto issue = [&](int a, int slot) {
+            const uint32_t ro = row0 + (uint32_t)a * rowb;
+            const bool xin = a <= L + 1, din = a < L;
+            const uint32_t base = ring_lds + (uint32_t)(slot * WS_ROWB);
+            lds_dma16(rx, xin ? ox1 + ro : OOB_OFF, base);
+            if (lane < 8) lds_dma16(rx, xin ? ox2 + ro : OOB_OFF, base + 1024u);
+            lds_dma16(rd, din ? od + ro + rowb : OOB_OFF, base + 1152u);
+        };
+#pragma unroll
+        for (int a = 0; a < WS_P; ++a) issue(a, a);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (WS_P - 1)) : "memory");
+        bf16x8 X[3], D[3], Xn[3], Dn;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) X[d] = tr_load8p(xb + d * 64);
+        D[0] = tr_load8p(xb + 1152);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { D[1][k] = (__bf16)0.f; D[2][k] = (__bf16)0.f; }
+        const int groups = (L + 2 + WS_R - 1) / WS_R;
+        for (int g = 0; g < groups; ++g) {
+#pragma unroll
+            for (int j = 0; j < WS_R; ++j) {
+                const int a = g * WS_R + j;
+                issue(a + WS_P, (j + WS_P) % WS_R);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (WS_P - 1)) : "memory");         // row a + 1 has landed
+                const unsigned char* nx = xb + ((j + 1) % WS_R) * WS_ROWB;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) Xn[d] = tr_load8p(nx + d * 64);
+                Dn = tr_load8p(nx + 1152);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bsum = dot2_ones(D[j % 3], q, bsum);
+#pragma unroll
+                for (int t = 0; t < 3; ++t)             // tap row t: x halo row a against dy row a - t
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) acc[t * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(D[(j + 3 - t) % 3], X[d], acc[t * 3 + d], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) X[d] = Xn[d];
+                D[(j + 1) % 3] = Dn;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the all-miss pieces behind the segment: the next segment reuses their slots
+        cur += L;
+    }
+    // the four waves of a block take turns adding their nine 32 x 32 partial sums into one LDS image (no LDS float atomics), then one atomic per element
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    for (int turn = 0; turn < WS_T / 64; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
+                    float* dst = &red[t * 1024 + co * 32 + r];
+                    *dst = turn == 0 ? acc[t][k] : *dst + acc[t][k];
+                }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < 9 * 1024; i += WS_T) {
+        const int tap = i % 9, cc = i / 9;          // OIHW-linear order: 256 contiguous bytes per wave instruction
+        atomicAdd(&dw[(int64_t)cc * 9 + tap], red[tap * 1024 + cc]);
+    }
+    __syncthreads();
+    if (dbias) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lane < 32) red[wave * 32 + r] = bsum;
+        __syncthreads();
+        if (tid < 32) atomicAdd(&dbias[tid], red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ 1 x K / K x 1 weight gradient, shifted lines (round 4)
 // The generic kernel reads one x fragment per TAP and 16-pixel chunk: 13 taps = 1088 transposing reads per 8 x 64 tile and block, and the time of
 // the 13-tap calls scales with exactly that (0.36 ms at level 0 against 0.22 for nine taps): the LDS array, not HBM, is the limit.  Along a line
@@ -1099,7 +1240,7 @@ static int g_wgrad_mode = -1;
 extern "C" int64_t tcct_conv32_wgrad_mode(int mode) {
     if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_GENERIC"); g_wgrad_mode = (e_ && e_[0] == '1') ? 1 : 0; }
     const int prev = g_wgrad_mode;
-    if (mode == 0 || mode == 1) g_wgrad_mode = mode;
+    if (mode >= 0 && mode <= 2) g_wgrad_mode = mode;
     return prev;
 }
 /* dw OIHW fp32 [32,32,KH,KW] and dbias fp32 [32] (nullable) are overwritten. */
@@ -1143,7 +1284,23 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
         if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
     }
     if (g_wgrad_mode < 0) (void)tcct_conv32_wgrad_mode(-1);
-    if (g_wgrad_mode == 0 && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {      // plain 3x3: rolling rows, 6 waves x 2 blocks per CU
+    static const int stream_on = [] { const char* e_ = getenv("TCCT_WGRAD_STREAM"); return e_ ? atoi(e_) : 1; }();      // TCCT_WGRAD_STREAM=0: A/B arm (rolling rows at every level)
+    if ((g_wgrad_mode == 2 || (g_wgrad_mode == 0 && stream_on)) && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {
+        const int strips = (W + 15) / 16;
+        const int64_t rows = (int64_t)N * strips * H;
+        int blocks = 512;
+        int64_t run = (rows + blocks * 4 - 1) / (blocks * 4);
+        if (g_wgrad_mode == 2 || run >= WS_MIN_RUN) {
+            if (run < 12) run = 12;                 // small maps: fewer, longer runs (the pipeline fill is 7 rows)
+            blocks = (int)((rows + run * 4 - 1) / (run * 4));
+            constexpr size_t ldss = (size_t)(WS_T / 64) * WS_R * WS_ROWB;
+            static bool attrs = false;
+            if (!attrs) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad33_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attrs = true; }
+            hipLaunchKernelGGL(k_conv32_wgrad33_stream, dim3((unsigned)blocks), dim3(WS_T), ldss, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W, strips, (int)run);
+            TCCT_LAUNCH_OK();
+        }
+    }
+    if ((g_wgrad_mode == 0 || g_wgrad_mode == 2) && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {      // plain 3x3: rolling rows, 6 waves x 2 blocks per CU
         constexpr size_t lds4 = (size_t)18 * 34 * 64 + 16 * 32 * 64;
         static bool attr4 = false;
         if (!attr4) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad33_roll, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr4 = true; }
@@ -1152,7 +1309,7 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
         TCCT_LAUNCH_OK();
     }
     static const bool line_on = [] { const char* e_ = getenv("TCCT_WGRAD_LINE"); return !(e_ && e_[0] == '0'); }();      // TCCT_WGRAD_LINE=0: A/B arm
-    if (line_on && g_wgrad_mode == 0 && (KH == 1 || KW == 1) && (TAPS == 13 || TAPS == 11 || TAPS == 9) && xs == 32 && ds == 32 && ldi == 32 && o_off == 0 && i_off == 0 &&
+    if (line_on && g_wgrad_mode != 1 && (KH == 1 || KW == 1) && (TAPS == 13 || TAPS == 11 || TAPS == 9) && xs == 32 && ds == 32 && ldi == 32 && o_off == 0 && i_off == 0 &&
         xo == 0 && dof == 0) {      // 1 x K / K x 1 at levels 0-2: shifted lines
 #define WL_LAUNCH(KK, V)                                                                                                     \
     do {                                                                                                                    \

@@ -123,7 +123,7 @@ def test_conv32_weight_gradient_rolling_row_form_equals_the_generic_one(cfg):
     outs = []
     prev = lib.conv32_wgrad_mode(-1)
     try:
-        for mode in (1, 0):      # 1: generic register-staged kernel; 0: rolling rows (3x3) / shifted lines (1 x K, K x 1)
+        for mode in ((1, 0, 2) if (KH, KW) == (3, 3) else (1, 0)):      # 1: generic register-staged kernel; 0: rolling rows (3x3) / shifted lines (1 x K, K x 1); 2: row streams (3x3)
             lib.conv32_wgrad_mode(mode)
             dw = torch.full((32, 32, KH, KW), 7.0, device='cuda')
             db = torch.full((32,), 7.0, device='cuda')
