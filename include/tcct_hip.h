@@ -228,11 +228,16 @@ int tcct_conv32_fwd_strided(const void* x, const void* wp, const float* bias, vo
  * zero before the first slab */
 int tcct_conv32_fwd_strided_bnstats(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
                                     int PW, int xs, int xo, int ys, int yo, int accumulate, double* stats, int pre_act, tcct_stream_t stream);
-/* selects the kernel behind tcct_conv32_wgrad for plain 3x3 convolutions: 0 (default) = the rolling-row form (one x fragment per halo row meets a
- * register window of three dy fragments: a third of the LDS fragment reads, 6 waves x 2 blocks per CU), 1 = the generic register-staged kernel every
- * other shape takes (comparison arm of the bit-compatibility test; TCCT_WGRAD_GENERIC=1 for a whole run); any other value only queries.  Returns the
- * previous mode.  (No reference counterpart: the reference calls ATen's convolution backward, nets/tcct.py:808-822 through autograd.) */
+/* selects the kernel behind tcct_conv32_wgrad for plain 3x3 convolutions: 0 (default) = wave-private row streams where a wave gets >= 32 rows (levels 0-1;
+ * TCCT_WGRAD_STREAM=0: never), else the rolling-row form (one x fragment per halo row meets a register window of three dy fragments, 6 waves x 2 blocks per
+ * CU); 1 = the generic register-staged kernel every other shape takes (comparison arm of the bit-compatibility test; TCCT_WGRAD_GENERIC=1 for a whole run);
+ * 2 = row streams for every plain 3x3; any other value only queries.  Returns the previous mode.  (No reference counterpart: the reference calls ATen's
+ * convolution backward, nets/tcct.py:808-822 through autograd.) */
 int64_t tcct_conv32_wgrad_mode(int mode);
+/* the same for the plain 32-channel 3x3 forward / input gradient (tcct_conv32_fwd, tcct_conv32_fwd_bnstats with no / LeakyReLU pre-activation): 0 (default) =
+ * the row-stream kernel where a wave gets >= 48 rows (TCCT_CONV_STREAM=0: never), 1 = the tiled kernel everywhere, 2 = the row-stream kernel for every
+ * plain 3x3.  The two kernels give bit-identical outputs.  Returns the previous mode; any other value only queries. */
+int64_t tcct_conv32_fwd_mode(int mode);
 int tcct_conv32_wgrad_strided(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH,
                               int PW, int xs, int xo, int ds, int dof, int cin_total, int o_off, int i_off, tcct_stream_t stream);
 /* weight/bias gradient of the same family (ds_read_b64_tr_b16 transposing LDS reads feed the pixel-contraction MFMA);

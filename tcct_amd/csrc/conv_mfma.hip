@@ -437,6 +437,17 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
 
 /* x, y: bf16 NHWC [N,H,W,32]; wp: packed bf16 [KH*KW][32][32] from tcct_conv32_pack_weights; stride 1; output size == input
  * size requires PH = (KH-1)/2 etc. but any PH <= KH-1, PW <= KW-1 with "same" output extent H x W is accepted. */
+static bool conv32_fwd33_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, double* stats, int stat_code, int stats_sq_off,
+                                       bool force, hipStream_t st);
+static int g_fwd_mode = -1;
+/* 0 (default): plain 3x3 convolutions whose waves get >= FS_MIN_RUN rows take the row-stream kernel (TCCT_CONV_STREAM=0: never); 1: the tiled kernel for every
+ * shape; 2: the row-stream kernel for every plain 3x3 (the comparison arms of the bit-identity test).  Returns the previous mode; mode < 0 only queries. */
+extern "C" int64_t tcct_conv32_fwd_mode(int mode) {
+    if (g_fwd_mode < 0) { const char* e_ = getenv("TCCT_CONV_STREAM"); g_fwd_mode = (e_ && e_[0] == '0') ? 1 : 0; }
+    const int prev = g_fwd_mode;
+    if (mode >= 0 && mode <= 2) g_fwd_mode = mode;
+    return prev;
+}
 static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
                            int PH, int PW, int xs, int xo, int ys, int yo, int accum, double* stats, int stat_pre, tcct_stream_t stream,
                            const float* aff = nullptr, int aff_post = 0, bool affine = false, const void* yadd = nullptr, int stats_sq_off = 32);
@@ -502,6 +513,11 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
                "conv32_fwd: one image of %d x %d x %d channels exceeds the 2 GiB buffer-descriptor range", H, W, xs > ys ? xs : ys);
     int grid = (int)(nt < 512 ? nt : 512);  // (256 / 384 / 768 blocks: 0.323 / 0.294 / 0.292 ms against 0.236 with 512 = two resident blocks per CU)
     hipStream_t st = (hipStream_t)stream;
+    if (g_fwd_mode < 0) (void)tcct_conv32_fwd_mode(-1);
+    if (g_fwd_mode != 1 && sq && xs == 32 && xo == 0 && ys == 32 && yo == 0 && !accum && !affine && !yadd &&
+        (!stats || stat_pre == TCCT_ACT_NONE || stat_pre == TCCT_ACT_LRELU)) {
+        if (conv32_fwd33_stream_launch(x, wp, bias, y, N, H, W, stats, !stats ? 0 : (stat_pre == TCCT_ACT_NONE ? 1 : 2), stats_sq_off, g_fwd_mode == 2, st)) TCCT_LAUNCH_OK();
+    }
 #define CF_LAUNCH(V, S, KHT, KWT)                                                                                           \
     do {                                                                                                                    \
         static bool attr = false;                                                                                           \
@@ -958,18 +974,20 @@ k_conv32_wgrad33_stream(const bf16* __restrict__ x, const bf16* __restrict__ dy,
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
     float bsum = 0.f;
-    const int64_t total = (int64_t)N * strips * H;
-    const int gw = blockIdx.x * (WS_T / 64) + wave;
-    int64_t cur = (int64_t)gw * run;
+    // the four waves of a block walk four ADJACENT strips over the same rows (4 KB of every x / dy row between them at about the same time)
+    const int sgroups = (strips + 3) >> 2;
+    const int64_t total = (int64_t)N * sgroups * H;
+    int64_t cur = (int64_t)blockIdx.x * run;
     const int64_t end = cur + run < total ? cur + run : total;
     const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
     const uint32_t rowb = (uint32_t)W * 64u;
     const int px = lane >> 2, c = lane & 3;
     while (cur < end) {
         const int sidx = (int)(cur / H), r0 = (int)(cur - (int64_t)sidx * H);
-        const int n = sidx / strips, s = sidx - n * strips;
+        const int n = sidx / sgroups, s = (sidx - n * sgroups) * 4 + wave;
         const int left = (int)(end - cur);
         const int L = __builtin_amdgcn_readfirstlane(H - r0 < left ? H - r0 : left);      // dy rows r0 .. r0 + L - 1; x rows r0 - 1 .. r0 + L
+        if (s >= strips) { cur += L; continue; }
         const int w0 = s * 16;
         const u32x4 rx = make_rsrc_words(x + (int64_t)n * H * W * 32, img_bytes);
         const u32x4 rd = make_rsrc_words(dy + (int64_t)n * H * W * 32, img_bytes);
@@ -1051,6 +1069,224 @@ k_conv32_wgrad33_stream(const bf16* __restrict__ x, const bf16* __restrict__ dy,
         __syncthreads();
         if (tid < 32) atomicAdd(&dbias[tid], red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3 forward / input gradient, wave-private row streams (round 4)
+// The row-stream structure of k_conv32_wgrad33_stream for the convolution itself (same arithmetic as k_conv32_mfma<false, STATS, 3, 3> on plain 32-channel
+// tensors, results BIT-IDENTICAL: every output pixel sums bias, then taps in (dy, dx, half) order, on the same MFMA).  A wave owns a 32-pixel-wide strip and
+// walks down it; halo row a (34 pixels, 2176 B, three LDS-DMA pieces) feeds the three output rows a - 2, a - 1, a, whose accumulators roll through
+// registers: six B fragments (3 dx x 2 halves of the input channels) are read ONCE per halo row instead of once per output row, the 18 weight fragments
+// live in registers for the whole kernel (no weight image in LDS), output row a - 2 is complete after the row's MFMAs and leaves through the per-wave
+// transpose (in the ring slot that is free at that moment) as two 1 KB stores.  The DMA pieces put chunk c of ring pixel P at position c ^ ((P >> 2) & 3)
+// (the permutation is applied to the SOURCE offsets): conflict-free ds_read_b128 at any dx on linear 64-byte pixel rows.  Every row issues exactly
+// 3 DMA pieces + 2 stores (invalid ones with out-of-range offsets), so `s_waitcnt vmcnt(5 (FS_P - 1))` retires exactly the next row.
+#define FS_T 256
+#define FS_R 9
+#define FS_P 7
+#define FS_ROWB 2176            // 34 halo pixels x 64 B
+#define FS_MIN_RUN 48
+#ifndef FS_SYNC
+#define FS_SYNC 0
+#endif
+template <int STATS>            // 0: none; 1: statistics of y; 2: of LeakyReLU(y) (y as stored) -> stats[0..31], stats[stats_sq_off ..+32) (fp64 atomics)
+__global__ void __launch_bounds__(FS_T, 2)      // two waves per SIMD: <= 256 VGPRs
+k_conv32_fwd33_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
+                      int N, int H, int W, int strips, int run, double* __restrict__ stats, int stats_sq_off) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int nw = blockDim.x >> 6;             // waves = adjacent strips per block (4)
+    unsigned char* ring = smem + wave * (FS_R * FS_ROWB);
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)ring);
+    float* sB = reinterpret_cast<float*>(smem + nw * FS_R * FS_ROWB);          // bias[32], then the statistics partials [nw][64]
+    bf16x8 Wf[9][2];            // A operands: row co = r, input channels 8 hh + 16 half ..+7 of tap t
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) Wf[t][kc] = *reinterpret_cast<const bf16x8*>(wp + (t * 32 + r) * 32 + (hh + 2 * kc) * 8);
+    if (tid < 32) sB[tid] = bias ? bias[tid] : 0.f;
+    __syncthreads();
+    const unsigned char* xB[3][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) { const int P = r + d; xB[d][kc] = ring + P * 64 + (((hh + 2 * kc) ^ ((P >> 2) & 3)) << 4); }
+    float ss[STATS ? 8 : 1], sq[STATS ? 8 : 1];
+#pragma unroll
+    for (int k = 0; k < (STATS ? 8 : 1); ++k) ss[k] = sq[k] = 0.f;
+    // the waves of a block walk ADJACENT strips over the same rows (nw x 2 KB of every image row between them, at about the same time)
+    const int sgroups = (strips + nw - 1) / nw;
+    const int64_t total = (int64_t)N * sgroups * H;
+    int64_t cur = (int64_t)blockIdx.x * run;
+    const int64_t end = cur + run < total ? cur + run : total;
+    const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
+    const uint32_t rowb = (uint32_t)W * 64u;
+    const int pq = lane >> 2, cs = (lane & 3) ^ ((lane >> 4) & 3);          // LDS position lane & 3 of ring pixel 16 piece + pq holds chunk cs
+    const int p16 = lane >> 2, cch = lane & 3;
+    while (cur < end) {
+        const int sidx = (int)(cur / H), r0 = (int)(cur - (int64_t)sidx * H);
+        const int n = sidx / sgroups, s = (sidx - n * sgroups) * nw + wave;
+        const int left = (int)(end - cur);
+        const int L = __builtin_amdgcn_readfirstlane(H - r0 < left ? H - r0 : left);      // output rows r0 .. r0 + L - 1; halo rows r0 - 1 .. r0 + L
+        if (s >= strips) {
+#if FS_SYNC
+            for (int g = 0; g < (L + 2 + FS_R - 1) / FS_R; ++g) __builtin_amdgcn_s_barrier();
+#endif
+            cur += L; continue;
+        }
+        const int w0 = s * 32;
+        const u32x4 rx = make_rsrc_words(x + (int64_t)n * H * W * 32, img_bytes);
+        const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (int64_t)n * H * W * 32), 0, img_bytes, 0x00020000);
+        const int c0 = w0 - 1 + pq, c1 = w0 + 15 + pq, c2 = w0 + 31 + pq;
+        const uint32_t o0 = (c0 >= 0 && c0 < W) ? (uint32_t)(c0 * 64 + cs * 16) : OOB_OFF;
+        const uint32_t o1 = (c1 < W) ? (uint32_t)(c1 * 64 + cs * 16) : OOB_OFF;
+        const uint32_t o2 = (c2 < W) ? (uint32_t)(c2 * 64 + cs * 16) : OOB_OFF;
+        uint32_t so[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int wo = w0 + 16 * u + p16; so[u] = wo < W ? (uint32_t)(wo * 64 + cch * 16) : OOB_OFF; }
+        const uint32_t row0 = (uint32_t)(r0 - 1) * rowb;
+        auto issue = [&](int a, int slot) {
+            const uint32_t ro = row0 + (uint32_t)a * rowb;
+            const bool xin = a <= L + 1;
+            const uint32_t base = ring_lds + (uint32_t)(slot * FS_ROWB);
+            lds_dma16(rx, xin ? o0 + ro : OOB_OFF, base);
+            lds_dma16(rx, xin ? o1 + ro : OOB_OFF, base + 1024u);
+            if (lane < 8) lds_dma16(rx, xin ? o2 + ro : OOB_OFF, base + 2048u);
+        };
+        const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int a = 0; a < FS_P; ++a) {
+            issue(a, a);
+            __builtin_amdgcn_raw_buffer_store_b128(zero4, ws, OOB_OFF, 0, 0);          // two dropped stores per row keep the vmcnt arithmetic uniform
+            __builtin_amdgcn_raw_buffer_store_b128(zero4, ws, OOB_OFF, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (FS_P - 1) + 2 * FS_P) : "memory");
+        bf16x8 X[3][2], Xn[3][2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) X[d][kc] = *reinterpret_cast<const bf16x8*>(xB[d][kc]);
+        f32x16 acc[3];
+        const int groups = (L + 2 + FS_R - 1) / FS_R;
+        for (int g = 0; g < groups; ++g) {
+#if FS_SYNC
+            __builtin_amdgcn_s_barrier();           // keeps the four strips of a block on the same rows (no data is shared)
+#endif
+#pragma unroll
+            for (int j = 0; j < FS_R; ++j) {
+                const int a = g * FS_R + j;
+                issue(a + FS_P, (j + FS_P) % FS_R);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(5 * (FS_P - 1)) : "memory");         // halo row a + 1 has landed
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc) Xn[d][kc] = *reinterpret_cast<const bf16x8*>(xB[d][kc] + ((j + 1) % FS_R) * FS_ROWB);
+                {           // output row a starts at the bias of this lane's 16 channels
+                    float4 bq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(sB + 8 * q + 4 * hh);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { acc[j % 3][4 * q] = bq[q].x; acc[j % 3][4 * q + 1] = bq[q].y; acc[j % 3][4 * q + 2] = bq[q].z; acc[j % 3][4 * q + 3] = bq[q].w; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)          // halo row a is tap row dy of output row a - dy
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+#pragma unroll
+                        for (int kc = 0; kc < 2; ++kc)
+                            acc[(j + 3 - dy) % 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[dy * 3 + d][kc], X[d][kc], acc[(j + 3 - dy) % 3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // output row a - 2 is complete: pack, transpose through the free ring slot (the one halo row a + 8 will land in), two 1 KB stores
+                const int orow = a - 2;
+                const bool ovalid = orow >= 0 && orow < L;
+                const f32x16& A = acc[(j + 1) % 3];
+                unsigned char* sc = ring + ((j + 8) % FS_R) * FS_ROWB;
+                uint2 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { o[q].x = pack_bf16x2(A[4 * q], A[4 * q + 1]); o[q].y = pack_bf16x2(A[4 * q + 2], A[4 * q + 3]); }
+                const int f = (r >> 1) & 3;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(sc + r * 64 + ((q ^ f) << 4) + hh * 8) = o[q];
+                wave_lds_fence();
+                u32x4 pend[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) pend[u] = *reinterpret_cast<const u32x4*>(sc + (16 * u + p16) * 64 + ((cch ^ ((p16 >> 1) & 3)) << 4));
+                wave_lds_fence();
+                const uint32_t oro = (uint32_t)(r0 + orow) * rowb;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bool inb = ovalid && so[u] != OOB_OFF;
+                    __builtin_amdgcn_raw_buffer_store_b128(pend[u], ws, inb ? so[u] + oro : OOB_OFF, 0, 0);
+                    if (STATS) {
+                        if (inb) {
+                            const uint32_t wv[4] = {pend[u][0], pend[u][1], pend[u][2], pend[u][3]};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                float u0 = __uint_as_float(wv[k] << 16), u1 = __uint_as_float(wv[k] & 0xffff0000u);
+                                if (STATS == 2) { u0 = fmaxf(u0, 0.01f * u0); u1 = fmaxf(u1, 0.01f * u1); }
+                                ss[2 * k] += u0; sq[2 * k] += u0 * u0; ss[2 * k + 1] += u1; sq[2 * k + 1] += u1 * u1;
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc) X[d][kc] = Xn[d][kc];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cur += L;
+    }
+    if (STATS) {
+        // a lane owns channels 8 (lane & 3) ..+7 of the pixels it stored: butterfly over lane bits 2..5, per-wave LDS slots, fp64 atomics (as k_conv32_mfma)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float* red = sB + 32;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float a = ss[k], b = sq[k];
+#pragma unroll
+            for (int o = 32; o > 2; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            if (lane < 4) {
+                red[wave * 64 + 8 * lane + k] = a;
+                red[wave * 64 + 32 + 8 * lane + k] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double t = 0.0;
+            for (int w = 0; w < nw; ++w) t += (double)red[w * 64 + tid];
+            atomicAdd(&stats[tid < 32 ? tid : stats_sq_off + tid - 32], t);
+        }
+    }
+}
+/* plain 32-channel 3x3 (no slabs, no accumulate, STATS 0-2): true when the row-stream kernel was launched */
+static bool conv32_fwd33_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, double* stats, int stat_code, int stats_sq_off,
+                                       bool force, hipStream_t st) {
+    const int strips = (W + 31) / 32;
+    const int nw = 4;           // 4 waves x 2 blocks per CU (7 or 8 waves in one block per CU: 0.197 ms against 0.190 at level 0)
+    const int64_t rows = (int64_t)N * ((strips + nw - 1) / nw) * H;            // rows of strip GROUPS (adjacent strips, one per wave of a block)
+    int blocks = 512;
+    int64_t run = (rows + blocks - 1) / blocks;
+    if (!force && run < FS_MIN_RUN) return false;
+    if (run < 12) run = 12;
+    blocks = (int)((rows + run - 1) / run);
+    const size_t lds = (size_t)nw * FS_R * FS_ROWB + 128 + (size_t)nw * 256;
+#define FS_LAUNCH(S)                                                                                                                                          \
+    do {                                                                                                                                                      \
+        static bool attr = false;                                                                                                                             \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_fwd33_stream<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+        hipLaunchKernelGGL((k_conv32_fwd33_stream<S>), dim3((unsigned)blocks), dim3(64 * nw), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, strips, \
+                           (int)run, stats, stats_sq_off);                                                                                                  \
+    } while (0)
+    if (stat_code == 0) FS_LAUNCH(0);
+    else if (stat_code == 1) FS_LAUNCH(1);
+    else FS_LAUNCH(2);
+#undef FS_LAUNCH
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------ 1 x K / K x 1 weight gradient, shifted lines (round 4)
@@ -1287,12 +1523,12 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
     static const int stream_on = [] { const char* e_ = getenv("TCCT_WGRAD_STREAM"); return e_ ? atoi(e_) : 1; }();      // TCCT_WGRAD_STREAM=0: A/B arm (rolling rows at every level)
     if ((g_wgrad_mode == 2 || (g_wgrad_mode == 0 && stream_on)) && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {
         const int strips = (W + 15) / 16;
-        const int64_t rows = (int64_t)N * strips * H;
+        const int64_t rows = (int64_t)N * ((strips + 3) / 4) * H;            // rows of strip groups (four adjacent strips, one per wave of a block)
         int blocks = 512;
-        int64_t run = (rows + blocks * 4 - 1) / (blocks * 4);
+        int64_t run = (rows + blocks - 1) / blocks;
         if (g_wgrad_mode == 2 || run >= WS_MIN_RUN) {
             if (run < 12) run = 12;                 // small maps: fewer, longer runs (the pipeline fill is 7 rows)
-            blocks = (int)((rows + run * 4 - 1) / (run * 4));
+            blocks = (int)((rows + run - 1) / run);
             constexpr size_t ldss = (size_t)(WS_T / 64) * WS_R * WS_ROWB;
             static bool attrs = false;
             if (!attrs) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad33_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attrs = true; }

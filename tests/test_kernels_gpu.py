@@ -138,6 +138,50 @@ def test_conv32_weight_gradient_rolling_row_form_equals_the_generic_one(cfg):
         torch.testing.assert_close(outs[0][0], o[0], rtol=1e-4, atol=1e-4 * max(1.0, w.grad.abs().max().item()))
 
 
+@pytest.mark.parametrize('stat', [None, 0, 1])
+@pytest.mark.parametrize('nhw', [(3, 70, 130), (2, 16, 33), (3, 50, 69), (1, 3, 5), (2, 100, 138), (1, 1, 1), (1, 40, 32), (2, 9, 65), (5, 31, 97)])
+def test_conv32_row_stream_kernel_is_bit_identical_to_the_tiled_one(nhw, stat):
+    """tcct_conv32_fwd_mode: the plain 32-channel 3x3 convolution (reference nets/tcct.py:808-822, forward and -- on the flipped pack -- input gradient) as
+    wave-private row streams (mode 2) against the tiled kernel (mode 1): the SAME bits out (bias first, then taps in (dy, dx, half) order on the same MFMA), the
+    fused BatchNorm statistics (none / of y / of LeakyReLU(y)) equal up to the order of the fp32 partial sums; strips narrower than 32 pixels, runs that continue
+    into the next strip and the next image, single-row and single-pixel images; both against torch's convolution of the same bf16 operands"""
+    from tcct_amd._lib import lib
+    N, H, W = nhw
+    x = rnd(N, 32, H, W, dt=torch.bfloat16)
+    w = (rnd(32, 32, 3, 3, seed=1) / 288 ** 0.5)
+    b = rnd(32, seed=2)
+    ref = F.conv2d(x.float(), w.bfloat16().float(), b, 1, 1)
+    xd = nhwc(x, torch.bfloat16)
+    wd, bd = w.cuda(), b.cuda()
+    wp = torch.empty(9 * 1024, device='cuda', dtype=torch.bfloat16)
+    lib.conv32_pack_weights(wd, wp, 3, 3, 0)
+    outs = []
+    prev = lib.conv32_fwd_mode(-1)
+    try:
+        for mode in (1, 2):
+            lib.conv32_fwd_mode(mode)
+            y = torch.full((N, H, W, 32), 7.0, device='cuda', dtype=torch.bfloat16)
+            sums = torch.zeros(64, device='cuda', dtype=torch.float64)
+            if stat is None:
+                lib.conv32_fwd(xd, wp, bd, y, N, H, W, 3, 3, 1, 1)
+            else:
+                lib.conv32_fwd_bnstats(xd, wp, bd, y, N, H, W, 3, 3, 1, 1, sums, stat)
+            outs.append((y, sums))
+    finally:
+        lib.conv32_fwd_mode(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0])
+    got = outs[1][0].permute(0, 3, 1, 2).float().cpu()
+    torch.testing.assert_close(got, ref, rtol=1e-2, atol=1e-2 * max(1.0, ref.abs().max().item()))
+    if stat is not None:
+        z = outs[1][0].double()
+        if stat == 1:
+            z = torch.where(z > 0, z, 0.01 * z)         # the kernels sum fp32 max(u, 0.01 u) of the stored bf16 values
+        want = torch.cat([z.sum((0, 1, 2)), (z * z).sum((0, 1, 2))])
+        for o in outs:
+            torch.testing.assert_close(o[1], want, rtol=2e-5, atol=2e-5 * max(1.0, want.abs().max().item()))
+
+
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('stride', [1, 2])
 @pytest.mark.parametrize('nhw', [(2, 18, 26), (3, 17, 45), (1, 5, 131)])
