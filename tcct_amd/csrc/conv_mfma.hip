@@ -1078,15 +1078,15 @@ k_conv32_wgrad33_stream(const bf16* __restrict__ x, const bf16* __restrict__ dy,
 // registers: six B fragments (3 dx x 2 halves of the input channels) are read ONCE per halo row instead of once per output row, the 18 weight fragments
 // live in registers for the whole kernel (no weight image in LDS), output row a - 2 is complete after the row's MFMAs and leaves through the per-wave
 // transpose (in the ring slot that is free at that moment) as two 1 KB stores.  The DMA pieces put chunk c of ring pixel P at position c ^ ((P >> 2) & 3)
-// (the permutation is applied to the SOURCE offsets): conflict-free ds_read_b128 at any dx on linear 64-byte pixel rows.  Every row issues exactly
-// 3 DMA pieces + 2 stores (invalid ones with out-of-range offsets), so `s_waitcnt vmcnt(5 (FS_P - 1))` retires exactly the next row.
+// (the permutation is applied to the SOURCE offsets): conflict-free ds_read_b128 at any dx on linear 64-byte pixel rows.  Every row issues
+// exactly 3 DMA pieces; `s_waitcnt vmcnt(3 (FS_P - 1))` retires the next row whatever the stores in between do.
 #define FS_T 256
 #define FS_R 9
 #define FS_P 7
 #define FS_ROWB 2176            // 34 halo pixels x 64 B
-#define FS_MIN_RUN 48
+#define FS_MIN_RUN 24
 #ifndef FS_SYNC
-#define FS_SYNC 0
+#define FS_SYNC 1
 #endif
 template <int STATS>            // 0: none; 1: statistics of y; 2: of LeakyReLU(y) (y as stored) -> stats[0..31], stats[stats_sq_off ..+32) (fp64 atomics)
 __global__ void __launch_bounds__(FS_T, 2)      // two waves per SIMD: <= 256 VGPRs
@@ -1153,14 +1153,9 @@ k_conv32_fwd33_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, c
             lds_dma16(rx, xin ? o1 + ro : OOB_OFF, base + 1024u);
             if (lane < 8) lds_dma16(rx, xin ? o2 + ro : OOB_OFF, base + 2048u);
         };
-        const u32x4 zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int a = 0; a < FS_P; ++a) {
-            issue(a, a);
-            __builtin_amdgcn_raw_buffer_store_b128(zero4, ws, OOB_OFF, 0, 0);          // two dropped stores per row keep the vmcnt arithmetic uniform
-            __builtin_amdgcn_raw_buffer_store_b128(zero4, ws, OOB_OFF, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (FS_P - 1) + 2 * FS_P) : "memory");
+        for (int a = 0; a < FS_P; ++a) issue(a, a);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (FS_P - 1)) : "memory");
         bf16x8 X[3][2], Xn[3][2];
 #pragma unroll
         for (int d = 0; d < 3; ++d)
@@ -1176,7 +1171,10 @@ k_conv32_fwd33_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, c
             for (int j = 0; j < FS_R; ++j) {
                 const int a = g * FS_R + j;
                 issue(a + FS_P, (j + FS_P) % FS_R);
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(5 * (FS_P - 1)) : "memory");         // halo row a + 1 has landed
+                // Halo row a + 1 has landed once at most the 3 (FS_P - 1) younger DMA pieces are outstanding.  The 2 (FS_P - 1) younger stores are NOT added to the
+                // count: loads retire in order among loads, but a store whose lanes are all out of range (rows behind the segment, the upper half of a narrow last
+                // strip) is dropped and acknowledged at once -- counting it let the fragment reads of the first rows of a segment overtake their DMA (full-size test).
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (FS_P - 1)) : "memory");
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
 #pragma unroll

@@ -104,7 +104,7 @@ def test_pointwise_forward_on_the_fp32_matrix_pipes(cfg, monkeypatch):
     assert e_mfma < 4e-6 * max(1.0, y64.abs().max().item()) and e_mfma < 4 * e_valu + 1e-6, (e_valu, e_mfma)     # both are fp32-exact; only the order differs
 
 
-@pytest.mark.parametrize('cfg', [(3, 3, 70, 130), (3, 3, 16, 33), (3, 3, 50, 69), (3, 3, 100, 138), (1, 13, 9, 200), (13, 1, 200, 9), (1, 11, 20, 150), (9, 1, 150, 20),
+@pytest.mark.parametrize('cfg', [(3, 3, 70, 130), (3, 3, 16, 33), (3, 3, 50, 69), (3, 3, 100, 138), (3, 3, 400, 552), (1, 13, 9, 200), (13, 1, 200, 9), (1, 11, 20, 150), (9, 1, 150, 20),
                                  (1, 13, 70, 300), (13, 1, 300, 70), (11, 1, 131, 19), (1, 9, 17, 129), (1, 13, 5, 7), (13, 1, 7, 5),
                                  (1, 5, 8, 64), (7, 1, 33, 9), (1, 1, 19, 70), (3, 3, 3, 5)])
 def test_conv32_weight_gradient_rolling_row_form_equals_the_generic_one(cfg):
@@ -139,12 +139,13 @@ def test_conv32_weight_gradient_rolling_row_form_equals_the_generic_one(cfg):
 
 
 @pytest.mark.parametrize('stat', [None, 0, 1])
-@pytest.mark.parametrize('nhw', [(3, 70, 130), (2, 16, 33), (3, 50, 69), (1, 3, 5), (2, 100, 138), (1, 1, 1), (1, 40, 32), (2, 9, 65), (5, 31, 97)])
+@pytest.mark.parametrize('nhw', [(3, 70, 130), (2, 16, 33), (3, 50, 69), (1, 3, 5), (2, 100, 138), (1, 1, 1), (1, 40, 32), (2, 9, 65), (5, 31, 97), (2, 400, 552), (1, 700, 300)])
 def test_conv32_row_stream_kernel_is_bit_identical_to_the_tiled_one(nhw, stat):
     """tcct_conv32_fwd_mode: the plain 32-channel 3x3 convolution (reference nets/tcct.py:808-822, forward and -- on the flipped pack -- input gradient) as
     wave-private row streams (mode 2) against the tiled kernel (mode 1): the SAME bits out (bias first, then taps in (dy, dx, half) order on the same MFMA), the
     fused BatchNorm statistics (none / of y / of LeakyReLU(y)) equal up to the order of the fp32 partial sums; strips narrower than 32 pixels, runs that continue
-    into the next strip and the next image, single-row and single-pixel images; both against torch's convolution of the same bf16 operands"""
+    into the next strip and the next image, single-row and single-pixel images, long runs (many ring revolutions; the first version's wait counted stores
+    that the hardware drops at once and read the first rows of a run too early -- only at these sizes); both against torch's convolution of the same bf16 operands"""
     from tcct_amd._lib import lib
     N, H, W = nhw
     x = rnd(N, 32, H, W, dt=torch.bfloat16)
