@@ -110,7 +110,7 @@ def pmc_traffic(a, kernel_match):
 def dominant_kernel_roofline(a, iters=20):
     """HIP-event timing of the dominant kernel of the step at the bench shapes, on the stream it is launched on (torch's
     current stream == the stream every tcct_* call receives).  Dominant kernel by total time (profiles/r01_*): the MFMA
-    implicit-GEMM convolution k_conv32_mfma<false,false> (forward and input-gradient of the 3x3 / 1xk 32->32 convolutions);
+    implicit-GEMM convolution (k_conv32_fwd33_stream / k_conv32_mfma: forward and input-gradient of the 3x3 / 1xk 32->32 convolutions);
     timed on its most frequent instance, the 3x3 at level 0 ([bs,800,1104,32]).  Algorithmic bytes per launch = read x once +
     write y once (SURVEY §8(d) layer-granular model) = 2 * bs*H*W*32 * sizeof(dtype); the 18 KB of packed weights are noise.
     The weight-gradient kernel (second by total time) is reported next to it as `second`."""
@@ -127,8 +127,12 @@ def dominant_kernel_roofline(a, iters=20):
     if a.dtype == 'bf16':
         wp = torch.empty(9 * 1024, device='cuda', dtype=torch.bfloat16)
         lib.conv32_pack_weights(w, wp, 3, 3, 0)
-        name, name2 = 'k_conv32_mfma<false,0,3,3> (3x3 32->32 fwd/dgrad @L0)', 'k_conv32_wgrad33_roll (3x3 32->32 weight gradient @L0, rolling rows)'
-        match = 'k_conv32_mfma<false, 0, 3, 3>'                  # the symbol as rocprofv3 prints it
+        name, name2 = 'k_conv32_fwd33_stream<0> (3x3 32->32 fwd/dgrad @L0, row streams)', 'k_conv32_wgrad33_stream (3x3 32->32 weight gradient @L0, row streams)'
+        match = 'k_conv32_fwd33_stream<0>'                      # the symbol as rocprofv3 prints it
+        if os.environ.get('TCCT_CONV_STREAM', '1') == '0':      # the A/B arm: the tiled kernel
+            name, match = 'k_conv32_mfma<false,0,3,3> (3x3 32->32 fwd/dgrad @L0, tiles)', 'k_conv32_mfma<false, 0, 3, 3>'
+        if os.environ.get('TCCT_WGRAD_STREAM', '1') == '0':
+            name2 = 'k_conv32_wgrad33_roll (3x3 32->32 weight gradient @L0, rolling rows)'
         fn = lambda: lib.conv32_fwd(x, wp, b, y, a.bs, a.height, Wp, 3, 3, 1, 1)                              # noqa: E731
         fn2 = lambda: lib.conv32_wgrad(x, dy, dw, db, a.bs, a.height, Wp, 3, 3, 1, 1)                         # noqa: E731
     else:       # parity mode: the fp32 MFMA convolution (v_mfma_f32_32x32x2_f32), bound by the fp32 matrix rate, not by HBM

@@ -977,8 +977,8 @@ k_conv32_wgrad33_stream(const bf16* __restrict__ x, const bf16* __restrict__ dy,
     // the four waves of a block walk four ADJACENT strips over the same rows (4 KB of every x / dy row between them at about the same time)
     const int sgroups = (strips + 3) >> 2;
     const int64_t total = (int64_t)N * sgroups * H;
-    int64_t cur = (int64_t)blockIdx.x * run;
-    const int64_t end = cur + run < total ? cur + run : total;
+    int64_t cur = (int64_t)blockIdx.x * run;        // (a row-major block order -- the strip groups of one run of image rows on consecutive blocks -- pays for the
+    const int64_t end = cur + run < total ? cur + run : total;      //  forward kernel below, not here: 0.176 ms either way)
     const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
     const uint32_t rowb = (uint32_t)W * 64u;
     const int px = lane >> 2, c = lane & 3;
@@ -1091,7 +1091,7 @@ k_conv32_wgrad33_stream(const bf16* __restrict__ x, const bf16* __restrict__ dy,
 template <int STATS>            // 0: none; 1: statistics of y; 2: of LeakyReLU(y) (y as stored) -> stats[0..31], stats[stats_sq_off ..+32) (fp64 atomics)
 __global__ void __launch_bounds__(FS_T, 2)      // two waves per SIMD: <= 256 VGPRs
 k_conv32_fwd33_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
-                      int N, int H, int W, int strips, int run, double* __restrict__ stats, int stats_sq_off) {
+                      int N, int H, int W, int strips, int run, int rpi, double* __restrict__ stats, int stats_sq_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -1116,9 +1116,15 @@ k_conv32_fwd33_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, c
     for (int k = 0; k < (STATS ? 8 : 1); ++k) ss[k] = sq[k] = 0.f;
     // the waves of a block walk ADJACENT strips over the same rows (nw x 2 KB of every image row between them, at about the same time)
     const int sgroups = (strips + nw - 1) / nw;
-    const int64_t total = (int64_t)N * sgroups * H;
-    int64_t cur = (int64_t)blockIdx.x * run;
-    const int64_t end = cur + run < total ? cur + run : total;
+    // Row-major block order: consecutive blocks take the strip groups of ONE run of image rows, so whole image rows are in flight together (0.1838 ms at
+    // level 0 against 0.1893 for runs cut from the strip-major sequence of rows).  rpi = runs per image; a block has one run of one strip group.
+    int64_t cur, end;
+    {
+        const int q = blockIdx.x / sgroups, grp = blockIdx.x - q * sgroups;
+        const int n_ = q / rpi, r_ = (q - n_ * rpi) * run;
+        cur = ((int64_t)n_ * sgroups + grp) * H + r_;
+        end = cur + (H - r_ < run ? H - r_ : run);
+    }
     const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
     const uint32_t rowb = (uint32_t)W * 64u;
     const int pq = lane >> 2, cs = (lane & 3) ^ ((lane >> 4) & 3);          // LDS position lane & 3 of ring pixel 16 piece + pq holds chunk cs
@@ -1266,19 +1272,22 @@ static bool conv32_fwd33_stream_launch(const void* x, const void* wp, const floa
                                        bool force, hipStream_t st) {
     const int strips = (W + 31) / 32;
     const int nw = 4;           // 4 waves x 2 blocks per CU (7 or 8 waves in one block per CU: 0.197 ms against 0.190 at level 0)
-    const int64_t rows = (int64_t)N * ((strips + nw - 1) / nw) * H;            // rows of strip GROUPS (adjacent strips, one per wave of a block)
-    int blocks = 512;
-    int64_t run = (rows + blocks - 1) / blocks;
-    if (!force && run < FS_MIN_RUN) return false;
-    if (run < 12) run = 12;
-    blocks = (int)((rows + run - 1) / run);
+    const int sg = (strips + nw - 1) / nw;
+    // runs per image: as many as fill the 512 block slots, each at least FS_MIN_RUN rows long (the pipeline fill is FS_P rows per run)
+    int rpi = 512 / (N * sg);
+    if (rpi > H / FS_MIN_RUN) rpi = H / FS_MIN_RUN;
+    if (rpi < 1) rpi = 1;
+    const int run = (H + rpi - 1) / rpi;
+    rpi = (H + run - 1) / run;
+    const int blocks = N * rpi * sg;
+    if (!force && (H < FS_MIN_RUN || blocks < 384)) return false;       // small maps: the tiled kernel
     const size_t lds = (size_t)nw * FS_R * FS_ROWB + 128 + (size_t)nw * 256;
 #define FS_LAUNCH(S)                                                                                                                                          \
     do {                                                                                                                                                      \
         static bool attr = false;                                                                                                                             \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_fwd33_stream<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
         hipLaunchKernelGGL((k_conv32_fwd33_stream<S>), dim3((unsigned)blocks), dim3(64 * nw), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, strips, \
-                           (int)run, stats, stats_sq_off);                                                                                                  \
+                           run, rpi, stats, stats_sq_off);                                                                                                  \
     } while (0)
     if (stat_code == 0) FS_LAUNCH(0);
     else if (stat_code == 1) FS_LAUNCH(1);
