@@ -439,6 +439,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
  * size requires PH = (KH-1)/2 etc. but any PH <= KH-1, PW <= KW-1 with "same" output extent H x W is accepted. */
 static bool conv32_fwd33_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, double* stats, int stat_code, int stats_sq_off,
                                        bool force, hipStream_t st);
+static bool conv32_fwd1k_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int K, bool force, hipStream_t st);
 static int g_fwd_mode = -1;
 /* 0 (default): plain 3x3 convolutions whose waves get >= FS_MIN_RUN rows take the row-stream kernel (TCCT_CONV_STREAM=0: never); 1: the tiled kernel for every
  * shape; 2: the row-stream kernel for every plain 3x3 (the comparison arms of the bit-identity test).  Returns the previous mode; mode < 0 only queries. */
@@ -517,6 +518,9 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
     if (g_fwd_mode != 1 && sq && xs == 32 && xo == 0 && ys == 32 && yo == 0 && !accum && !affine && !yadd &&
         (!stats || stat_pre == TCCT_ACT_NONE || stat_pre == TCCT_ACT_LRELU)) {
         if (conv32_fwd33_stream_launch(x, wp, bias, y, N, H, W, stats, !stats ? 0 : (stat_pre == TCCT_ACT_NONE ? 1 : 2), stats_sq_off, g_fwd_mode == 2, st)) TCCT_LAUNCH_OK();
+    }
+    if (g_fwd_mode != 1 && KH == 1 && (KW == 13 || KW == 11 || KW == 9) && xs == 32 && xo == 0 && ys == 32 && yo == 0 && !accum && !affine && !yadd && !stats) {
+        if (conv32_fwd1k_stream_launch(x, wp, bias, y, N, H, W, KW, g_fwd_mode == 2, st)) TCCT_LAUNCH_OK();
     }
 #define CF_LAUNCH(V, S, KHT, KWT)                                                                                           \
     do {                                                                                                                    \
@@ -1293,6 +1297,160 @@ static bool conv32_fwd33_stream_launch(const void* x, const void* wp, const floa
     else if (stat_code == 1) FS_LAUNCH(1);
     else FS_LAUNCH(2);
 #undef FS_LAUNCH
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ 1 x K forward / input gradient, wave-private row streams (round 4)
+// The horizontal cross convolutions (reference nets/tcct.py:814-818; K = 13, 11, 9 at levels 0, 1, 2) in the row-stream structure of k_conv32_fwd33_stream.  A row is
+// self-contained here (no rolling window): halo row = 32 + K - 1 pixels, one accumulator, 2 K MFMAs per row in the tiled kernel's (dx, half) order on the same
+// MFMA => BIT-IDENTICAL to k_conv32_mfma<false, 0, 1, K>.  The 2 K weight fragments and the 2 K per-lane fragment addresses live in registers; ring of 7 rows, 5 in flight.
+#define F1_R 7
+#define F1_P 5
+template <int K>
+__global__ void __launch_bounds__(FS_T, 2)
+k_conv32_fwd1k_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
+                      int N, int H, int W, int strips, int run, int rpi) {
+    constexpr int LWP = 32 + K - 1, ROWB = LWP * 64, TAIL = LWP - 32;         // halo pixels per row, ring bytes per row, pixels of the third DMA piece
+    static_assert(TAIL >= 1 && TAIL <= 16 && ROWB >= 2048, "1 x K row streams: 3 <= K <= 17");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int nw = blockDim.x >> 6;
+    unsigned char* ring = smem + wave * (F1_R * ROWB);
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)ring);
+    float* sB = reinterpret_cast<float*>(smem + nw * F1_R * ROWB);
+    bf16x8 Wf[K][2];
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) Wf[t][kc] = *reinterpret_cast<const bf16x8*>(wp + (t * 32 + r) * 32 + (hh + 2 * kc) * 8);
+    if (tid < 32) sB[tid] = bias ? bias[tid] : 0.f;
+    __syncthreads();
+    uint32_t xo_[K][2];          // byte offset in a ring row of this lane's fragment of tap dx, half kc (chunk c of ring pixel P sits at position c ^ ((P >> 2) & 3))
+#pragma unroll
+    for (int d = 0; d < K; ++d)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) { const int P = r + d; xo_[d][kc] = (uint32_t)(P * 64 + (((hh + 2 * kc) ^ ((P >> 2) & 3)) << 4)); }
+    const int sgroups = (strips + nw - 1) / nw;
+    int64_t cur, end;
+    {
+        const int q = blockIdx.x / sgroups, grp = blockIdx.x - q * sgroups;
+        const int n_ = q / rpi, r_ = (q - n_ * rpi) * run;
+        cur = ((int64_t)n_ * sgroups + grp) * H + r_;
+        end = cur + (H - r_ < run ? H - r_ : run);
+    }
+    const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
+    const uint32_t rowb = (uint32_t)W * 64u;
+    const int pq = lane >> 2, cs = (lane & 3) ^ ((lane >> 4) & 3);
+    const int p16 = lane >> 2, cch = lane & 3;
+    constexpr int PADL = (K - 1) / 2;
+    while (cur < end) {
+        const int sidx = (int)(cur / H), r0 = (int)(cur - (int64_t)sidx * H);
+        const int n = sidx / sgroups, s = (sidx - n * sgroups) * nw + wave;
+        const int left = (int)(end - cur);
+        const int L = __builtin_amdgcn_readfirstlane(H - r0 < left ? H - r0 : left);      // rows r0 .. r0 + L - 1
+        if (s >= strips) { cur += L; continue; }
+        const int w0 = s * 32;
+        const u32x4 rx = make_rsrc_words(x + (int64_t)n * H * W * 32, img_bytes);
+        const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (int64_t)n * H * W * 32), 0, img_bytes, 0x00020000);
+        const int c0 = w0 - PADL + pq, c1 = c0 + 16, c2 = c0 + 32;
+        const uint32_t o0 = (c0 >= 0 && c0 < W) ? (uint32_t)(c0 * 64 + cs * 16) : OOB_OFF;
+        const uint32_t o1 = (c1 >= 0 && c1 < W) ? (uint32_t)(c1 * 64 + cs * 16) : OOB_OFF;
+        const uint32_t o2 = (c2 < W) ? (uint32_t)(c2 * 64 + cs * 16) : OOB_OFF;
+        uint32_t so[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int wo = w0 + 16 * u + p16; so[u] = wo < W ? (uint32_t)(wo * 64 + cch * 16) : OOB_OFF; }
+        const uint32_t row0 = (uint32_t)r0 * rowb;
+        auto issue = [&](int a, int slot) {
+            const uint32_t ro = row0 + (uint32_t)a * rowb;
+            const bool xin = a < L;
+            const uint32_t base = ring_lds + (uint32_t)(slot * ROWB);
+            lds_dma16(rx, xin ? o0 + ro : OOB_OFF, base);
+            lds_dma16(rx, xin ? o1 + ro : OOB_OFF, base + 1024u);
+            if (lane < 4 * TAIL) lds_dma16(rx, xin ? o2 + ro : OOB_OFF, base + 2048u);
+        };
+#pragma unroll
+        for (int a = 0; a < F1_P; ++a) issue(a, a);
+        const int groups = (L + F1_R - 1) / F1_R;
+        for (int g = 0; g < groups; ++g) {
+#pragma unroll
+            for (int j = 0; j < F1_R; ++j) {
+                const int a = g * F1_R + j;
+                // row a has landed once only the 3 (F1_P - 1) pieces of rows a + 1 .. a + F1_P - 1 are outstanding (stores are not counted: k_conv32_fwd33_stream)
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (F1_P - 1)) : "memory");
+                const unsigned char* rowp = ring + j * ROWB;
+                f32x16 acc;
+                {
+                    float4 bq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(sB + 8 * q + 4 * hh);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { acc[4 * q] = bq[q].x; acc[4 * q + 1] = bq[q].y; acc[4 * q + 2] = bq[q].z; acc[4 * q + 3] = bq[q].w; }
+                }
+                bf16x8 F[2][2];
+                F[0][0] = *reinterpret_cast<const bf16x8*>(rowp + xo_[0][0]);
+                F[0][1] = *reinterpret_cast<const bf16x8*>(rowp + xo_[0][1]);
+#pragma unroll
+                for (int d = 0; d < K; ++d) {
+                    if (d + 1 < K) {
+                        F[(d + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(rowp + xo_[d + 1][0]);
+                        F[(d + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(rowp + xo_[d + 1][1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[d][0], F[d & 1][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[d][1], F[d & 1][1], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the row's fragments are in registers: its slot takes row a + F1_R - 1 ... no: the DMA of row a + F1_P goes to slot (j + F1_P) % F1_R, the slot
+                // (j + F1_R - 1) % F1_R (row a - 1) is the transpose scratch of this row
+                issue(a + F1_P, (j + F1_P) % F1_R);
+                const bool ovalid = a < L;
+                unsigned char* sc = ring + ((j + F1_R - 1) % F1_R) * ROWB;
+                uint2 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { o[q].x = pack_bf16x2(acc[4 * q], acc[4 * q + 1]); o[q].y = pack_bf16x2(acc[4 * q + 2], acc[4 * q + 3]); }
+                const int f = (r >> 1) & 3;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(sc + r * 64 + ((q ^ f) << 4) + hh * 8) = o[q];
+                wave_lds_fence();
+                u32x4 pend[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) pend[u] = *reinterpret_cast<const u32x4*>(sc + (16 * u + p16) * 64 + ((cch ^ ((p16 >> 1) & 3)) << 4));
+                wave_lds_fence();
+                const uint32_t oro = (uint32_t)(r0 + a) * rowb;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) __builtin_amdgcn_raw_buffer_store_b128(pend[u], ws, (ovalid && so[u] != OOB_OFF) ? so[u] + oro : OOB_OFF, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cur += L;
+    }
+}
+/* plain 32-channel 1 x K (K = 13, 11, 9; no slabs, no accumulate, no statistics): true when the row-stream kernel was launched */
+static bool conv32_fwd1k_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int K, bool force, hipStream_t st) {
+    const int strips = (W + 31) / 32;
+    const int nw = 4;
+    const int sg = (strips + nw - 1) / nw;
+    int rpi = 512 / (N * sg);
+    if (rpi > H / FS_MIN_RUN) rpi = H / FS_MIN_RUN;
+    if (rpi < 1) rpi = 1;
+    const int run = (H + rpi - 1) / rpi;
+    rpi = (H + run - 1) / run;
+    const int blocks = N * rpi * sg;
+    if (!force && (H < FS_MIN_RUN || blocks < 384)) return false;
+#define F1_LAUNCH(KK)                                                                                                                                          \
+    do {                                                                                                                                                      \
+        static bool attr = false;                                                                                                                             \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_fwd1k_stream<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+        hipLaunchKernelGGL((k_conv32_fwd1k_stream<KK>), dim3((unsigned)blocks), dim3(64 * nw), (size_t)nw * F1_R * (32 + KK - 1) * 64 + 128, st, (const bf16*)x, (const bf16*)wp, \
+                           bias, (bf16*)y, N, H, W, strips, run, rpi);                                                                                      \
+    } while (0)
+    if (K == 13) F1_LAUNCH(13);
+    else if (K == 11) F1_LAUNCH(11);
+    else if (K == 9) F1_LAUNCH(9);
+    else return false;
+#undef F1_LAUNCH
     return true;
 }
 
