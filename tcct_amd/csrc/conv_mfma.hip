@@ -440,6 +440,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
 static bool conv32_fwd33_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, double* stats, int stat_code, int stats_sq_off,
                                        bool force, hipStream_t st);
 static bool conv32_fwd1k_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int K, bool force, hipStream_t st);
+static bool conv32_fwdk1_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int K, bool force, hipStream_t st);
 static int g_fwd_mode = -1;
 /* 0 (default): plain 3x3 convolutions whose waves get >= FS_MIN_RUN rows take the row-stream kernel (TCCT_CONV_STREAM=0: never); 1: the tiled kernel for every
  * shape; 2: the row-stream kernel for every plain 3x3 (the comparison arms of the bit-identity test).  Returns the previous mode; mode < 0 only queries. */
@@ -521,6 +522,9 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
     }
     if (g_fwd_mode != 1 && KH == 1 && (KW == 13 || KW == 11 || KW == 9) && xs == 32 && xo == 0 && ys == 32 && yo == 0 && !accum && !affine && !yadd && !stats) {
         if (conv32_fwd1k_stream_launch(x, wp, bias, y, N, H, W, KW, g_fwd_mode == 2, st)) TCCT_LAUNCH_OK();
+    }
+    if (g_fwd_mode != 1 && KW == 1 && (KH == 13 || KH == 11 || KH == 9) && xs == 32 && xo == 0 && ys == 32 && yo == 0 && !accum && !affine && !yadd && !stats) {
+        if (conv32_fwdk1_stream_launch(x, wp, bias, y, N, H, W, KH, g_fwd_mode == 2, st)) TCCT_LAUNCH_OK();
     }
 #define CF_LAUNCH(V, S, KHT, KWT)                                                                                           \
     do {                                                                                                                    \
@@ -1451,6 +1455,168 @@ static bool conv32_fwd1k_stream_launch(const void* x, const void* wp, const floa
     else if (K == 9) F1_LAUNCH(9);
     else return false;
 #undef F1_LAUNCH
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ K x 1 forward / input gradient, wave-private row streams (round 4)
+// The vertical cross convolutions.  A strip row is exactly 32 pixels (no column halo: two DMA pieces); output row o needs the K halo rows o .. o + K - 1, so the B
+// fragments of the last K rows stay in a REGISTER window (K x 2 fragments, 104 VGPRs for K = 13; the unrolled body's position j = a mod K names the registers) and
+// each halo row is read from LDS exactly once; the 2 K weight fragments come from a block-shared LDS image (the tiled kernel's swizzled rows) per output row.
+// MFMAs in the tiled kernel's (dy, half) order => BIT-IDENTICAL to k_conv32_mfma<true, 0, K, 1>.  Ring of 6 rows per wave (runtime slot index), 4 in flight.
+#define FV_R 6
+#define FV_P 4
+template <int K>
+__global__ void __launch_bounds__(FS_T, 2)
+k_conv32_fwdk1_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
+                      int N, int H, int W, int strips, int run, int rpi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int nw = blockDim.x >> 6;
+    unsigned char* sW = smem;                                   // K taps x 32 rows x 64 B, chunks XOR-swizzled by (row >> 2) & 3
+    unsigned char* ring = smem + K * 2048 + wave * (FV_R * 2048);
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)ring);
+    float* sB = reinterpret_cast<float*>(smem + K * 2048 + nw * FV_R * 2048);
+    for (int i = tid; i < K * 32 * 4; i += blockDim.x) {
+        const int row = i >> 2, c = i & 3;
+        *reinterpret_cast<uint4*>(sW + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = reinterpret_cast<const uint4*>(wp)[i];
+    }
+    if (tid < 32) sB[tid] = bias ? bias[tid] : 0.f;
+    __syncthreads();
+    const int wsw = (r >> 2) & 3;
+    const unsigned char* wA[2] = {sW + r * 64 + ((hh ^ wsw) << 4), sW + r * 64 + (((2 + hh) ^ wsw) << 4)};
+    uint32_t xo_[2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) xo_[kc] = (uint32_t)(r * 64 + (((hh + 2 * kc) ^ ((r >> 2) & 3)) << 4));
+    const int sgroups = (strips + nw - 1) / nw;
+    int64_t cur, end;
+    {
+        const int q = blockIdx.x / sgroups, grp = blockIdx.x - q * sgroups;
+        const int n_ = q / rpi, r_ = (q - n_ * rpi) * run;
+        cur = ((int64_t)n_ * sgroups + grp) * H + r_;
+        end = cur + (H - r_ < run ? H - r_ : run);
+    }
+    const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
+    const uint32_t rowb = (uint32_t)W * 64u;
+    const int pq = lane >> 2, cs = (lane & 3) ^ ((lane >> 4) & 3);
+    const int p16 = lane >> 2, cch = lane & 3;
+    constexpr int PADT = (K - 1) / 2;
+    while (cur < end) {
+        const int sidx = (int)(cur / H), r0 = (int)(cur - (int64_t)sidx * H);
+        const int n = sidx / sgroups, s = (sidx - n * sgroups) * nw + wave;
+        const int left = (int)(end - cur);
+        const int L = __builtin_amdgcn_readfirstlane(H - r0 < left ? H - r0 : left);      // output rows r0 .. r0 + L - 1; halo rows r0 - PADT .. r0 + L - 1 + PADT
+        if (s >= strips) { cur += L; continue; }
+        const int w0 = s * 32;
+        const u32x4 rx = make_rsrc_words(x + (int64_t)n * H * W * 32, img_bytes);
+        const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (int64_t)n * H * W * 32), 0, img_bytes, 0x00020000);
+        const int c0 = w0 + pq, c1 = c0 + 16;
+        const uint32_t o0 = c0 < W ? (uint32_t)(c0 * 64 + cs * 16) : OOB_OFF;
+        const uint32_t o1 = c1 < W ? (uint32_t)(c1 * 64 + cs * 16) : OOB_OFF;
+        uint32_t so[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int wo = w0 + 16 * u + p16; so[u] = wo < W ? (uint32_t)(wo * 64 + cch * 16) : OOB_OFF; }
+        const uint32_t row0 = (uint32_t)(r0 - PADT) * rowb;        // rows above the image wrap far beyond the descriptor range: zeros (the padding rows)
+        const int nh = L + K - 1;                                   // halo rows of the run
+        int slot_i = 0, slot_d = FV_P % FV_R;                       // ring slots of the row consumed / issued next (runtime: K and FV_R are coprime)
+        auto issue = [&](int a, int slot) {
+            const uint32_t ro = row0 + (uint32_t)a * rowb;
+            const bool xin = a < nh;
+            const uint32_t base = ring_lds + (uint32_t)(slot * 2048);
+            lds_dma16(rx, xin ? o0 + ro : OOB_OFF, base);
+            lds_dma16(rx, xin ? o1 + ro : OOB_OFF, base + 1024u);
+        };
+#pragma unroll
+        for (int a = 0; a < FV_P; ++a) issue(a, a);
+        bf16x8 Xw[K][2];
+#pragma unroll
+        for (int t = 0; t < K; ++t)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { Xw[t][0][k] = (__bf16)0.f; Xw[t][1][k] = (__bf16)0.f; }
+        const int groups = (nh + K - 1) / K;
+        for (int g = 0; g < groups; ++g) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int a = g * K + j;
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (FV_P - 1)) : "memory");         // halo row a has landed (DMA pieces only are counted)
+                const unsigned char* rowp = ring + slot_i * 2048;
+                Xw[j][0] = *reinterpret_cast<const bf16x8*>(rowp + xo_[0]);
+                Xw[j][1] = *reinterpret_cast<const bf16x8*>(rowp + xo_[1]);
+                f32x16 acc;
+                {
+                    float4 bq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(sB + 8 * q + 4 * hh);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { acc[4 * q] = bq[q].x; acc[4 * q + 1] = bq[q].y; acc[4 * q + 2] = bq[q].z; acc[4 * q + 3] = bq[q].w; }
+                }
+                // output row o = a - (K - 1): tap dy reads halo row o + dy = window position (j + 1 + dy) mod K
+                bf16x8 Af[2][2];
+                Af[0][0] = *reinterpret_cast<const bf16x8*>(wA[0]);
+                Af[0][1] = *reinterpret_cast<const bf16x8*>(wA[1]);
+#pragma unroll
+                for (int dy = 0; dy < K; ++dy) {
+                    if (dy + 1 < K) {
+                        Af[(dy + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(wA[0] + (dy + 1) * 2048);
+                        Af[(dy + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(wA[1] + (dy + 1) * 2048);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[dy & 1][0], Xw[(j + 1 + dy) % K][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[dy & 1][1], Xw[(j + 1 + dy) % K][1], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                issue(a + FV_P, slot_d);
+                const int orow = a - (K - 1);
+                const bool ovalid = orow >= 0 && orow < L;
+                int sc_i = slot_i - 1; if (sc_i < 0) sc_i += FV_R;                  // the slot of halo row a - 1: free until the DMA of row a + FV_R - 1
+                unsigned char* sc = ring + sc_i * 2048;
+                uint2 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { o[q].x = pack_bf16x2(acc[4 * q], acc[4 * q + 1]); o[q].y = pack_bf16x2(acc[4 * q + 2], acc[4 * q + 3]); }
+                const int f = (r >> 1) & 3;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(sc + r * 64 + ((q ^ f) << 4) + hh * 8) = o[q];
+                wave_lds_fence();
+                u32x4 pend[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) pend[u] = *reinterpret_cast<const u32x4*>(sc + (16 * u + p16) * 64 + ((cch ^ ((p16 >> 1) & 3)) << 4));
+                wave_lds_fence();
+                const uint32_t oro = (uint32_t)(r0 + orow) * rowb;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) __builtin_amdgcn_raw_buffer_store_b128(pend[u], ws, (ovalid && so[u] != OOB_OFF) ? so[u] + oro : OOB_OFF, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                slot_i = slot_i + 1 == FV_R ? 0 : slot_i + 1;
+                slot_d = slot_d + 1 == FV_R ? 0 : slot_d + 1;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cur += L;
+    }
+}
+/* plain 32-channel K x 1 (K = 13, 11, 9): true when the row-stream kernel was launched */
+static bool conv32_fwdk1_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int K, bool force, hipStream_t st) {
+    const int strips = (W + 31) / 32;
+    const int nw = 4;
+    const int sg = (strips + nw - 1) / nw;
+    int rpi = 512 / (N * sg);
+    if (rpi > H / (2 * FS_MIN_RUN)) rpi = H / (2 * FS_MIN_RUN);         // a run re-reads K - 1 halo rows: at least 48 rows long
+    if (rpi < 1) rpi = 1;
+    const int run = (H + rpi - 1) / rpi;
+    rpi = (H + run - 1) / run;
+    const int blocks = N * rpi * sg;
+    if (!force && (H < 2 * FS_MIN_RUN || blocks < 384)) return false;
+#define FV_LAUNCH(KK)                                                                                                                                          \
+    do {                                                                                                                                                      \
+        static bool attr = false;                                                                                                                             \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_fwdk1_stream<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+        hipLaunchKernelGGL((k_conv32_fwdk1_stream<KK>), dim3((unsigned)blocks), dim3(64 * nw), (size_t)KK * 2048 + (size_t)nw * FV_R * 2048 + 128, st, (const bf16*)x, \
+                           (const bf16*)wp, bias, (bf16*)y, N, H, W, strips, run, rpi);                                                                     \
+    } while (0)
+    if (K == 13) FV_LAUNCH(13);
+    else if (K == 11) FV_LAUNCH(11);
+    else if (K == 9) FV_LAUNCH(9);
+    else return false;
+#undef FV_LAUNCH
     return true;
 }
 

@@ -183,28 +183,31 @@ def test_conv32_row_stream_kernel_is_bit_identical_to_the_tiled_one(nhw, stat):
             torch.testing.assert_close(o[1], want, rtol=2e-5, atol=2e-5 * max(1.0, want.abs().max().item()))
 
 
+@pytest.mark.parametrize('vert', [False, True])
 @pytest.mark.parametrize('K', [13, 11, 9])
 @pytest.mark.parametrize('nhw', [(3, 70, 130), (2, 16, 33), (1, 3, 5), (2, 100, 138), (1, 1, 1), (1, 40, 32), (2, 9, 65), (2, 400, 552), (1, 700, 300)])
-def test_conv32_1xK_row_stream_kernel_is_bit_identical_to_the_tiled_one(nhw, K):
-    """the horizontal cross convolutions (reference nets/tcct.py:814-818) as wave-private row streams (tcct_conv32_fwd_mode 2) against the tiled kernel (mode 1):
-    the same bits; narrow last strips, single rows, long runs; both against torch's convolution of the same bf16 operands"""
+def test_conv32_cross_conv_row_stream_kernels_are_bit_identical_to_the_tiled_one(nhw, K, vert):
+    """the horizontal / vertical cross convolutions (reference nets/tcct.py:814-818) as wave-private row streams (tcct_conv32_fwd_mode 2) against the tiled
+    kernel (mode 1): the same bits; narrow last strips, single rows, images shorter than the kernel, long runs (the K x 1 form keeps a K-row register window
+    across many ring revolutions); both against torch's convolution of the same bf16 operands"""
     from tcct_amd._lib import lib
     N, H, W = nhw
+    KH, KW = (K, 1) if vert else (1, K)
     x = rnd(N, 32, H, W, dt=torch.bfloat16)
-    w = (rnd(32, 32, 1, K, seed=1) / (32 * K) ** 0.5)
+    w = (rnd(32, 32, KH, KW, seed=1) / (32 * K) ** 0.5)
     b = rnd(32, seed=2)
-    ref = F.conv2d(x.float(), w.bfloat16().float(), b, 1, (0, K // 2))
+    ref = F.conv2d(x.float(), w.bfloat16().float(), b, 1, (KH // 2, KW // 2))
     xd = nhwc(x, torch.bfloat16)
     wd, bd = w.cuda(), b.cuda()
     wp = torch.empty(K * 1024, device='cuda', dtype=torch.bfloat16)
-    lib.conv32_pack_weights(wd, wp, 1, K, 0)
+    lib.conv32_pack_weights(wd, wp, KH, KW, 0)
     outs = []
     prev = lib.conv32_fwd_mode(-1)
     try:
         for mode in (1, 2):
             lib.conv32_fwd_mode(mode)
             y = torch.full((N, H, W, 32), 7.0, device='cuda', dtype=torch.bfloat16)
-            lib.conv32_fwd(xd, wp, bd, y, N, H, W, 1, K, 0, K // 2)
+            lib.conv32_fwd(xd, wp, bd, y, N, H, W, KH, KW, KH // 2, KW // 2)
             outs.append(y)
     finally:
         lib.conv32_fwd_mode(prev)
