@@ -13,7 +13,7 @@ shutil.copy(f'{G}/{tag}_infer.txt', f'{P}/{tag}_infer.txt')
 nsteps = 3
 tot = sum(float(r['TotalDurationNs']) for r in step)
 fams = [('first layers: conv + train-mode BatchNorm, conv output recomputed (k_c3_bn*)', r'k_c3_bn'), ('BatchNorm (k_bn*)', r'k_bn'), ('pointwise fused backward (k_pw_bwd)', r'k_pw_bwd'), ('pointwise fwd/dgrad (k_pw_fwd, k_pw_fwd2)', r'k_pw_fwd'),
-        ('conv32 fwd/dgrad (k_conv32_mfma, k_conv32_fwd33_stream)', r'k_conv32_mfma|k_conv32_fwd33_stream'), ('conv32 fused backward (k_conv32_bwd33)', r'k_conv32_bwd33'),
+        ('conv32 fwd/dgrad (k_conv32_mfma, k_conv32_fwd*_stream)', r'k_conv32_mfma|k_conv32_fwd'), ('conv32 fused backward (k_conv32_bwd33)', r'k_conv32_bwd33'),
         ('conv32 wgrad (k_conv32_wgrad)', r'k_conv32_wgrad'), ('pointwise wgrad (k_pw_wgrad*)', r'k_pw_wgrad'), ('depthwise (k_dw*)', r'k_dw'),
         ('bilinear', r'k_bilinear'), ('LayerNorm', r'k_ln_'), ('softmax-Dice', r'k_dice'), ('elementwise (k_map*, residual, concat)', r'k_map|k_residual|k_concat|k_split'),
         ('torch (autograd grad accumulation adds etc.)', r'at::native'), ('memset/copy (rocclr)', r'rocclr')]
