@@ -176,7 +176,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
     // bias lives in LDS (behind the input image) and is re-read in the epilogue: 16 fewer live VGPRs in the MFMA loop
     float* sB = reinterpret_cast<float*>(sX + LH * LW * IPS);
     if (tid < 32) sB[tid] = bias ? bias[tid] : 0.f;
-    if (STATS == 4 && tid < 64) sB[32 + tid] = aff ? aff[tid] : (tid < 32 ? 1.f : 0.f);     // a[32], b[32] of the folded BatchNorm
+    if (STATS >= 4 && tid < 64) sB[32 + tid] = aff ? aff[tid] : (tid < 32 ? 1.f : 0.f);     // a[32], b[32] of the folded BatchNorm
     unsigned char* sS = reinterpret_cast<unsigned char*>(sB + 96);          // epilogue transpose scratch: 4 waves x 1 KB (2 KB: WIDE)
 
     // slot geometry (tile independent): slot j covers 16-byte chunk c of tile-local pixel (lr, lc); (lr,lc) packed in one int
@@ -438,7 +438,7 @@ k_conv32_mfma(const bf16* __restrict__ x, const bf16* __restrict__ wp, const flo
 /* x, y: bf16 NHWC [N,H,W,32]; wp: packed bf16 [KH*KW][32][32] from tcct_conv32_pack_weights; stride 1; output size == input
  * size requires PH = (KH-1)/2 etc. but any PH <= KH-1, PW <= KW-1 with "same" output extent H x W is accepted. */
 static bool conv32_fwd33_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, double* stats, int stat_code, int stats_sq_off,
-                                       bool force, hipStream_t st);
+                                       bool force, hipStream_t st, const float* aff = nullptr);
 static bool conv32_fwd1k_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int K, bool force, hipStream_t st);
 static bool conv32_fwdk1_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int K, bool force, hipStream_t st);
 static int g_fwd_mode = -1;
@@ -516,9 +516,12 @@ static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, voi
     int grid = (int)(nt < 512 ? nt : 512);  // (256 / 384 / 768 blocks: 0.323 / 0.294 / 0.292 ms against 0.236 with 512 = two resident blocks per CU)
     hipStream_t st = (hipStream_t)stream;
     if (g_fwd_mode < 0) (void)tcct_conv32_fwd_mode(-1);
-    if (g_fwd_mode != 1 && sq && xs == 32 && xo == 0 && ys == 32 && yo == 0 && !accum && !affine && !yadd &&
-        (!stats || stat_pre == TCCT_ACT_NONE || stat_pre == TCCT_ACT_LRELU)) {
-        if (conv32_fwd33_stream_launch(x, wp, bias, y, N, H, W, stats, !stats ? 0 : (stat_pre == TCCT_ACT_NONE ? 1 : 2), stats_sq_off, g_fwd_mode == 2, st)) TCCT_LAUNCH_OK();
+    const int aff_code = !affine ? -1 : (stat_pre == TCCT_ACT_NONE && aff_post == TCCT_ACT_NONE) ? 4 : (stat_pre == TCCT_ACT_NONE && aff_post == TCCT_ACT_LRELU) ? 5 :
+                         (stat_pre == TCCT_ACT_LRELU && aff_post == TCCT_ACT_NONE) ? 6 : 0;      // 0: an epilogue the row-stream kernel has no instance for
+    if (g_fwd_mode != 1 && sq && xs == 32 && xo == 0 && ys == 32 && yo == 0 && !accum && !yadd &&
+        (affine ? aff_code > 0 : (!stats || stat_pre == TCCT_ACT_NONE || stat_pre == TCCT_ACT_LRELU))) {
+        if (conv32_fwd33_stream_launch(x, wp, bias, y, N, H, W, affine ? nullptr : stats, affine ? aff_code : (!stats ? 0 : (stat_pre == TCCT_ACT_NONE ? 1 : 2)), stats_sq_off,
+                                       g_fwd_mode == 2, st, aff)) TCCT_LAUNCH_OK();
     }
     if (g_fwd_mode != 1 && KH == 1 && (KW == 13 || KW == 11 || KW == 9) && xs == 32 && xo == 0 && ys == 32 && yo == 0 && !accum && !affine && !yadd && !stats) {
         if (conv32_fwd1k_stream_launch(x, wp, bias, y, N, H, W, KW, g_fwd_mode == 2, st)) TCCT_LAUNCH_OK();
@@ -1096,10 +1099,14 @@ k_conv32_wgrad33_stream(const bf16* __restrict__ x, const bf16* __restrict__ dy,
 #ifndef FS_SYNC
 #define FS_SYNC 1
 #endif
-template <int STATS>            // 0: none; 1: statistics of y; 2: of LeakyReLU(y) (y as stored) -> stats[0..31], stats[stats_sq_off ..+32) (fp64 atomics)
+template <int STATS>            // 0: none; 1: statistics of y; 2: of LeakyReLU(y) (y as stored) -> stats[0..31], stats[stats_sq_off ..+32) (fp64 atomics);
+                                // 4 / 5 / 6: inference epilogue y = post(a[c] * pre(conv + bias) + b[c]) (eval-mode BatchNorm folded in, as k_conv32_mfma<.., 4, ..>) with
+                                // (pre, post) = (none, none) / (none, LeakyReLU) / (LeakyReLU, none) -- compile-time: the run-time switch of affine4(), unrolled 9 x 4
+                                // times, made an 18 000-line kernel with scratch that ran SLOWER than the tiled one
 __global__ void __launch_bounds__(FS_T, 2)      // two waves per SIMD: <= 256 VGPRs
 k_conv32_fwd33_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y,
-                      int N, int H, int W, int strips, int run, int rpi, double* __restrict__ stats, int stats_sq_off) {
+                      int N, int H, int W, int strips, int run, int rpi, double* __restrict__ stats, int stats_sq_off,
+                      const float* __restrict__ aff) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -1113,15 +1120,17 @@ k_conv32_fwd33_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, c
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) Wf[t][kc] = *reinterpret_cast<const bf16x8*>(wp + (t * 32 + r) * 32 + (hh + 2 * kc) * 8);
     if (tid < 32) sB[tid] = bias ? bias[tid] : 0.f;
+    if (STATS >= 4 && tid < 64) sB[32 + tid] = aff ? aff[tid] : (tid < 32 ? 1.f : 0.f);     // a[32], b[32] of the folded BatchNorm (the statistics partials' place)
     __syncthreads();
     const unsigned char* xB[3][2];
 #pragma unroll
     for (int d = 0; d < 3; ++d)
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) { const int P = r + d; xB[d][kc] = ring + P * 64 + (((hh + 2 * kc) ^ ((P >> 2) & 3)) << 4); }
-    float ss[STATS ? 8 : 1], sq[STATS ? 8 : 1];
+    constexpr bool ST = STATS >= 1 && STATS <= 2;
+    float ss[ST ? 8 : 1], sq[ST ? 8 : 1];
 #pragma unroll
-    for (int k = 0; k < (STATS ? 8 : 1); ++k) ss[k] = sq[k] = 0.f;
+    for (int k = 0; k < (ST ? 8 : 1); ++k) ss[k] = sq[k] = 0.f;
     // the waves of a block walk ADJACENT strips over the same rows (nw x 2 KB of every image row between them, at about the same time)
     const int sgroups = (strips + nw - 1) / nw;
     // Row-major block order: consecutive blocks take the strip groups of ONE run of image rows, so whole image rows are in flight together (0.1838 ms at
@@ -1216,7 +1225,16 @@ k_conv32_fwd33_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, c
                 unsigned char* sc = ring + ((j + 8) % FS_R) * FS_ROWB;
                 uint2 o[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { o[q].x = pack_bf16x2(A[4 * q], A[4 * q + 1]); o[q].y = pack_bf16x2(A[4 * q + 2], A[4 * q + 3]); }
+                for (int q = 0; q < 4; ++q) {
+                    float v4[4] = {A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};
+                    if (STATS >= 4) {
+                        const float4 aq = *reinterpret_cast<const float4*>(sB + 32 + 8 * q + 4 * hh);
+                        const float4 cq = *reinterpret_cast<const float4*>(sB + 64 + 8 * q + 4 * hh);
+                        const float a4[4] = {aq.x, aq.y, aq.z, aq.w}, b4[4] = {cq.x, cq.y, cq.z, cq.w};
+                        affine4_c<(STATS == 6 ? TCCT_ACT_LRELU : TCCT_ACT_NONE), (STATS == 5 ? TCCT_ACT_LRELU : TCCT_ACT_NONE)>(v4, a4, b4);
+                    }
+                    o[q].x = pack_bf16x2(v4[0], v4[1]); o[q].y = pack_bf16x2(v4[2], v4[3]);
+                }
                 const int f = (r >> 1) & 3;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(sc + r * 64 + ((q ^ f) << 4) + hh * 8) = o[q];
@@ -1230,7 +1248,7 @@ k_conv32_fwd33_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, c
                 for (int u = 0; u < 2; ++u) {
                     const bool inb = ovalid && so[u] != OOB_OFF;
                     __builtin_amdgcn_raw_buffer_store_b128(pend[u], ws, inb ? so[u] + oro : OOB_OFF, 0, 0);
-                    if (STATS) {
+                    if (ST) {
                         if (inb) {
                             const uint32_t wv[4] = {pend[u][0], pend[u][1], pend[u][2], pend[u][3]};
 #pragma unroll
@@ -1252,7 +1270,7 @@ k_conv32_fwd33_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         cur += L;
     }
-    if (STATS) {
+    if (ST) {
         // a lane owns channels 8 (lane & 3) ..+7 of the pixels it stored: butterfly over lane bits 2..5, per-wave LDS slots, fp64 atomics (as k_conv32_mfma)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1277,7 +1295,7 @@ k_conv32_fwd33_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, c
 }
 /* plain 32-channel 3x3 (no slabs, no accumulate, STATS 0-2): true when the row-stream kernel was launched */
 static bool conv32_fwd33_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, double* stats, int stat_code, int stats_sq_off,
-                                       bool force, hipStream_t st) {
+                                       bool force, hipStream_t st, const float* aff) {
     const int strips = (W + 31) / 32;
     const int nw = 4;           // 4 waves x 2 blocks per CU (7 or 8 waves in one block per CU: 0.197 ms against 0.190 at level 0)
     const int sg = (strips + nw - 1) / nw;
@@ -1295,11 +1313,14 @@ static bool conv32_fwd33_stream_launch(const void* x, const void* wp, const floa
         static bool attr = false;                                                                                                                             \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_fwd33_stream<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
         hipLaunchKernelGGL((k_conv32_fwd33_stream<S>), dim3((unsigned)blocks), dim3(64 * nw), lds, st, (const bf16*)x, (const bf16*)wp, bias, (bf16*)y, N, H, W, strips, \
-                           run, rpi, stats, stats_sq_off);                                                                                                  \
+                           run, rpi, stats, stats_sq_off, aff);                                                                                                  \
     } while (0)
     if (stat_code == 0) FS_LAUNCH(0);
     else if (stat_code == 1) FS_LAUNCH(1);
-    else FS_LAUNCH(2);
+    else if (stat_code == 2) FS_LAUNCH(2);
+    else if (stat_code == 4) FS_LAUNCH(4);
+    else if (stat_code == 5) FS_LAUNCH(5);
+    else FS_LAUNCH(6);
 #undef FS_LAUNCH
     return true;
 }

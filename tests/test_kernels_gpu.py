@@ -183,6 +183,41 @@ def test_conv32_row_stream_kernel_is_bit_identical_to_the_tiled_one(nhw, stat):
             torch.testing.assert_close(o[1], want, rtol=2e-5, atol=2e-5 * max(1.0, want.abs().max().item()))
 
 
+@pytest.mark.parametrize('acts', [(0, 0), (0, 1), (0, 2), (1, 0)])
+@pytest.mark.parametrize('nhw', [(2, 100, 138), (1, 40, 32), (2, 400, 552)])
+def test_conv32_row_stream_inference_epilogue_is_bit_identical_to_the_tiled_one(nhw, acts):
+    """tcct_conv32_fwd_affine (eval-mode BatchNorm + activations folded into the convolution's epilogue, KiteSeg.predict) through the row-stream kernel (mode 2)
+    and the tiled one (mode 1): the same bits; against conv -> pre-activation -> a y + b -> post-activation in fp32"""
+    from tcct_amd._lib import lib
+    N, H, W = nhw
+    pre, post = acts
+    x = rnd(N, 32, H, W, dt=torch.bfloat16)
+    w = (rnd(32, 32, 3, 3, seed=1) / 288 ** 0.5)
+    b = rnd(32, seed=2)
+    ab = torch.cat([1.0 + 0.3 * rnd(32, seed=3), 0.2 * rnd(32, seed=4)])
+    act = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.01), 2: F.hardswish}
+    ref = F.conv2d(x.float(), w.bfloat16().float(), b, 1, 1)
+    ref = act[post](act[pre](ref) * ab[:32].view(1, -1, 1, 1) + ab[32:].view(1, -1, 1, 1))
+    xd = nhwc(x, torch.bfloat16)
+    wp = torch.empty(9 * 1024, device='cuda', dtype=torch.bfloat16)
+    lib.conv32_pack_weights(w.cuda(), wp, 3, 3, 0)
+    bd, abd = b.cuda(), ab.cuda()
+    outs = []
+    prev = lib.conv32_fwd_mode(-1)
+    try:
+        for mode in (1, 2):
+            lib.conv32_fwd_mode(mode)
+            y = torch.full((N, H, W, 32), 7.0, device='cuda', dtype=torch.bfloat16)
+            lib.conv32_fwd_affine(xd, wp, bd, y, N, H, W, 3, 3, 1, 1, abd, pre, post)
+            outs.append(y)
+    finally:
+        lib.conv32_fwd_mode(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    got = outs[1].permute(0, 3, 1, 2).float().cpu()
+    torch.testing.assert_close(got, ref, rtol=1e-2, atol=1e-2 * max(1.0, ref.abs().max().item()))
+
+
 @pytest.mark.parametrize('vert', [False, True])
 @pytest.mark.parametrize('K', [13, 11, 9])
 @pytest.mark.parametrize('nhw', [(3, 70, 130), (2, 16, 33), (1, 3, 5), (2, 100, 138), (1, 1, 1), (1, 40, 32), (2, 9, 65), (2, 400, 552), (1, 700, 300)])
