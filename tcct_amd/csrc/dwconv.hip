@@ -775,14 +775,14 @@ static int dw_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias,
     static int cpt_on = -1;     // TCCT_DW_WGRAD_CPT=0: one column per thread for every shape (A/B timing)
     if (cpt_on < 0) { const char* e = getenv("TCCT_DW_WGRAD_CPT"); cpt_on = (e && e[0] == '0') ? 0 : 1; }
     if (cpt_on && vec == 4 && stride == 1 && dtype == TCCT_BF16 && Wo >= 128 && C >= 32) {
-        dw_geometry(N, Ho, Wo, C, vec, 512, 128, segh, wblocks, hstrips, 2);
+        dw_geometry(N, Ho, Wo, C, vec, 256, 128, segh, wblocks, hstrips, 2);     // (256 blocks: 0.080 -> 0.060 ms at level 2, 0.119 -> 0.103 stride 2 at level 1; 512 the same at level 1 stride 1)
         if (xab) hipLaunchKernelGGL((k_dw_wgrad<bf16, 4, 1, 2, true>), dim3((unsigned)((int64_t)N * wblocks * hstrips)), dim3(DB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias,
                                     N, H, W, C, Ho, Wo, segh, wblocks, hstrips, xab);
         else hipLaunchKernelGGL((k_dw_wgrad<bf16, 4, 1, 2>), dim3((unsigned)((int64_t)N * wblocks * hstrips)), dim3(DB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias,
                                 N, H, W, C, Ho, Wo, segh, wblocks, hstrips, xab);
         TCCT_LAUNCH_OK();
     }
-    dw_geometry(N, Ho, Wo, C, vec, 512, 128, segh, wblocks, hstrips);
+    dw_geometry(N, Ho, Wo, C, vec, 256, 128, segh, wblocks, hstrips);
     dim3 grid((unsigned)((int64_t)N * wblocks * hstrips));
 #define DWG(V, S) hipLaunchKernelGGL((k_dw_wgrad<T, V, S>), grid, dim3(DB), lds, st, (const T*)x, (const T*)dy, dw, dbias, N, H, W, C, Ho, Wo, segh, wblocks, hstrips, xab)
 #define DWGX(S) hipLaunchKernelGGL((k_dw_wgrad<T, 4, S, 1, true>), grid, dim3(DB), lds, st, (const T*)x, (const T*)dy, dw, dbias, N, H, W, C, Ho, Wo, segh, wblocks, hstrips, xab)

@@ -6,15 +6,18 @@ torch.manual_seed(0)
 side = torch.cuda.Stream()
 big = torch.randn(64 * 1024 * 1024, device='cuda'); big2 = torch.empty_like(big)
 bad_total = 0
-for (B, H, W, stat) in [(8, 800, 1104, None), (8, 800, 1100, 1), (8, 400, 550, None), (3, 800, 1072, 0), (8, 800, 1104, 1)]:
+ab = torch.cat([1 + 0.3 * torch.randn(32, device='cuda'), 0.2 * torch.randn(32, device='cuda')])
+for (B, H, W, stat, KH, KW) in [(8, 800, 1104, None, 3, 3), (8, 800, 1100, 1, 3, 3), (8, 400, 550, None, 3, 3), (3, 800, 1072, 0, 3, 3), (8, 800, 1104, 1, 3, 3),
+                                (8, 800, 1104, None, 1, 13), (8, 800, 1100, None, 13, 1), (8, 400, 550, None, 1, 11), (8, 800, 1104, 'aff', 3, 3)]:
     x = torch.randn((B, H, W, 32), device='cuda').bfloat16()
-    w = torch.randn((32, 32, 3, 3), device='cuda') / 17
+    w = torch.randn((32, 32, KH, KW), device='cuda') / 17
     b = torch.randn(32, device='cuda')
-    wp = torch.empty(9 * 1024, device='cuda', dtype=torch.bfloat16)
-    lib.conv32_pack_weights(w, wp, 3, 3, 0)
+    wp = torch.empty(KH * KW * 1024, device='cuda', dtype=torch.bfloat16)
+    lib.conv32_pack_weights(w, wp, KH, KW, 0)
     sums = torch.zeros(64, device='cuda', dtype=torch.float64)
     def run(y):
-        if stat is None: lib.conv32_fwd(x, wp, b, y, B, H, W, 3, 3, 1, 1)
+        if stat is None: lib.conv32_fwd(x, wp, b, y, B, H, W, KH, KW, KH // 2, KW // 2)
+        elif stat == 'aff': lib.conv32_fwd_affine(x, wp, b, y, B, H, W, 3, 3, 1, 1, ab, 1, 0)
         else: lib.conv32_fwd_bnstats(x, wp, b, y, B, H, W, 3, 3, 1, 1, sums, stat)
     lib.conv32_fwd_mode(1)
     ref = torch.empty_like(x); run(ref); torch.cuda.synchronize()
@@ -28,7 +31,7 @@ for (B, H, W, stat) in [(8, 800, 1104, None), (8, 800, 1100, 1), (8, 400, 550, N
         run(y)
         torch.cuda.synchronize()
         nbad += int((y != ref).any(dim=3).sum())
-    print((B, H, W, stat), 'mismatching pixels over 25 runs:', nbad, flush=True)
+    print((B, H, W, stat, KH, KW), 'mismatching pixels over 25 runs:', nbad, flush=True)
     bad_total += nbad
 lib.conv32_fwd_mode(0)
 print('TOTAL', bad_total)
