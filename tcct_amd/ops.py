@@ -200,6 +200,7 @@ def end_step():
 # latency-bound weight gradients of the coarse levels overlap it.  TCCT_STREAMS=0 disables.
 _WGRAD_USED = {}
 _WGRAD_KEEP = []
+DW_WGRAD_SIDE = os.environ.get('TCCT_DW_WGRAD_SIDE', '1') != '0'
 _WGRAD_FRESH_EVENT = os.environ.get('TCCT_WGRAD_FRESH_EVENT', '0') == '1'          # experiment on the late-capture crash
 _WGRAD_RECORD_STREAM = os.environ.get('TCCT_WGRAD_RECORD_STREAM', '0') == '1'      # the old behaviour, kept for A/B measurements only
 
@@ -1553,12 +1554,16 @@ class _DwConv(torch.autograd.Function):
             else:
                 lib.dwconv3x3_dgrad(dy, w, dx, N, H, W, C, stride, int(add_input), dtype_code(x.dtype))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw = _grad_out(w)
-            db = _grad_out(ctx.bias_param) if has_bias else None
-            if ctx.xab is not None:
-                lib.dwconv3x3_wgrad_xaff(x, ctx.xab, dy, dw, db, N, H, W, C, stride, dtype_code(x.dtype))
-            else:
-                lib.dwconv3x3_wgrad(x, dy, dw, db, N, H, W, C, stride, dtype_code(x.dtype))
+            # on the weight-gradient side stream like the dense convolutions' (round 4, last day: the ten depthwise weight gradients were 0.85 ms of the
+            # ViT branch's input-gradient chain; TCCT_DW_WGRAD_SIDE=0 keeps them inline)
+            keep = (x, dy) if ctx.xab is None else (x, dy, ctx.xab)
+            with _wgrad_stream(DW_WGRAD_SIDE and _slot_written(w, ctx.bias_param if has_bias else None), *keep):
+                dw = _grad_out(w)
+                db = _grad_out(ctx.bias_param) if has_bias else None
+                if ctx.xab is not None:
+                    lib.dwconv3x3_wgrad_xaff(x, ctx.xab, dy, dw, db, N, H, W, C, stride, dtype_code(x.dtype))
+                else:
+                    lib.dwconv3x3_wgrad(x, dy, dw, db, N, H, W, C, stride, dtype_code(x.dtype))
         return dx, _ret(dw, w), _ret(db, ctx.bias_param), None, None, None, None, None, None
 
 
