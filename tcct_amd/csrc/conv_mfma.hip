@@ -1426,8 +1426,7 @@ k_conv32_fwd1k_stream(const bf16* __restrict__ x, const bf16* __restrict__ wp, c
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[d][1], F[d & 1][1], acc, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // the row's fragments are in registers: its slot takes row a + F1_R - 1 ... no: the DMA of row a + F1_P goes to slot (j + F1_P) % F1_R, the slot
-                // (j + F1_R - 1) % F1_R (row a - 1) is the transpose scratch of this row
+                // the DMA of row a + F1_P goes to slot (j + F1_P) % F1_R; slot (j + F1_R - 1) % F1_R (row a - 1, consumed) is the transpose scratch of this row
                 issue(a + F1_P, (j + F1_P) % F1_R);
                 const bool ovalid = a < L;
                 unsigned char* sc = ring + ((j + F1_R - 1) % F1_R) * ROWB;
