@@ -139,7 +139,7 @@ def test_conv32_weight_gradient_rolling_row_form_equals_the_generic_one(cfg):
 
 
 @pytest.mark.parametrize('stat', [None, 0, 1])
-@pytest.mark.parametrize('nhw', [(3, 70, 130), (2, 16, 33), (3, 50, 69), (1, 3, 5), (2, 100, 138), (1, 1, 1), (1, 40, 32), (2, 9, 65), (5, 31, 97), (2, 400, 552), (1, 700, 300)])
+@pytest.mark.parametrize('nhw', [(3, 70, 130), (2, 16, 33), (3, 50, 69), (1, 3, 5), (2, 100, 138), (1, 1, 1), (1, 40, 32), (2, 9, 65), (5, 31, 97), (2, 400, 552), (1, 700, 300), (600, 4, 20), (130, 30, 130)])
 def test_conv32_row_stream_kernel_is_bit_identical_to_the_tiled_one(nhw, stat):
     """tcct_conv32_fwd_mode: the plain 32-channel 3x3 convolution (reference nets/tcct.py:808-822, forward and -- on the flipped pack -- input gradient) as
     wave-private row streams (mode 2) against the tiled kernel (mode 1): the SAME bits out (bias first, then taps in (dy, dx, half) order on the same MFMA), the
@@ -220,7 +220,7 @@ def test_conv32_row_stream_inference_epilogue_is_bit_identical_to_the_tiled_one(
 
 @pytest.mark.parametrize('vert', [False, True])
 @pytest.mark.parametrize('K', [13, 11, 9])
-@pytest.mark.parametrize('nhw', [(3, 70, 130), (2, 16, 33), (1, 3, 5), (2, 100, 138), (1, 1, 1), (1, 40, 32), (2, 9, 65), (2, 400, 552), (1, 700, 300)])
+@pytest.mark.parametrize('nhw', [(3, 70, 130), (2, 16, 33), (1, 3, 5), (2, 100, 138), (1, 1, 1), (1, 40, 32), (2, 9, 65), (2, 400, 552), (1, 700, 300), (600, 4, 20)])
 def test_conv32_cross_conv_row_stream_kernels_are_bit_identical_to_the_tiled_one(nhw, K, vert):
     """the horizontal / vertical cross convolutions (reference nets/tcct.py:814-818) as wave-private row streams (tcct_conv32_fwd_mode 2) against the tiled
     kernel (mode 1): the same bits; narrow last strips, single rows, images shorter than the kernel, long runs (the K x 1 form keeps a K-row register window
