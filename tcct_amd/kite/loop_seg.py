@@ -39,10 +39,13 @@ class KiteSeg(KiteBack):
         self.world, self.rank = (tdist.world_rank() if args.pl else (1, 0))
         self.fuse_aux_loss = os.environ.get('TCCT_FUSE_AUX', '1') != '0'
         # --udh: the loss reads `feats` (norm_add of three decoder maps) every step -> evaluated inside the forward, with the aux heads'
-        # gradients folded into its backward kernels (FTC.eager_feats; TCCT_EAGER_FEATS=0: lazy evaluation + autograd accumulation)
+        # gradients folded into its backward kernels (FTC.eager_feats; TCCT_EAGER_FEATS=0: lazy evaluation + autograd accumulation, `feats` still
+        # differentiable).  Without --udh nothing differentiates `feats`: the aux heads may be composed through t32x (FTC.compose_heads).
         base = getattr(self.model, 'base', None)
         if base is not None and hasattr(base, 'eager_feats'):
-            base.eager_feats = bool(getattr(args, 'udh', False)) and os.environ.get('TCCT_EAGER_FEATS', '1') != '0'
+            udh = bool(getattr(args, 'udh', False))
+            base.eager_feats = udh and os.environ.get('TCCT_EAGER_FEATS', '1') != '0'
+            base.compose_heads = not udh
 
     def predict(self, img, softmax=True, *args):
         """reference loop_seg.py:21-33: one_hot(argmax(softmax(out[0]))).  Returns a lazy MaskOneHot (class-index map;

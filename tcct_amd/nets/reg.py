@@ -88,7 +88,7 @@ class RegNet(nn.Module):
         los = 0
         for feat in self.base.feats:
             f = as_nhwc(feat)
-            l, pro = ops.fpl(f, logits, lab, self.fcp.buf_grad)
+            l, pro = ops.fpl(f, logits, lab, self.fcp.buf_grad, allow_lazy=not ops.grad_is_watched(feat))
             los = los + l
             self.emb_list = [pro[i] for i in range(pro.shape[0])]
             self.tgt_list = [self.fcp.choice(pro[i], i) for i in range(pro.shape[0])]

@@ -569,7 +569,7 @@ class MPUpBlock(nn.Module):
         resize, `post`, the skip add and `t32` as ONE GEMM with composed weights (ops.up_skip_conv_t32), or None when that form does not apply.
         aux: the level-0 head when the caller needs only ITS output of g0 -> returns the tuple (fp32 logits NHWC, resized y) instead"""
         p, t = self.post[0], t32
-        probe = x1.new_empty((x1.shape[0], x1.shape[1], x1.shape[2], self.prep[0].out_channels))
+        probe = torch.empty((x1.shape[0], x1.shape[1], x1.shape[2], self.prep[0].out_channels), dtype=x1.dtype, device='meta')    # shape / dtype only: no device memory
         if not (self.prep[1].training and ops.up_skip_conv_t32_ok(probe, x2, p.weight, p.bias, t.weight, t.bias)):
             return None
         y = _conv_bn(self.prep[0], self.prep[1], x1, post='lrelu')
@@ -625,6 +625,10 @@ class FTC(nn.Module):
         self._feats_src = None
         self._feats = None
         self.eager_feats = False        # True: norm_add is evaluated inside forward() (set by the training loop when the udh loss is on)
+        # True: the owner PROMISES that `feats` will not be differentiated in this configuration (KiteSeg sets it when --udh is off): the aux heads
+        # are then composed through the t32x convolutions, g0..g2 are never written and `feats` rebuilds them on demand WITHOUT gradient.
+        # Default False: `feats` carries gradient as the reference's does (RegNet(stc_tt()) + regular_udh used directly, without KiteSeg).
+        self.compose_heads = False
 
     @property
     def feats(self):
@@ -633,7 +637,7 @@ class FTC(nn.Module):
                 raise TcctError('the legacy-head layout (onnx/tcct_goals.py) is supported for inference and Dice/boundary training; its '
                                 'six-tensor `feats` (tcct_goals.py:1021) is not built')
             g0, g1, g2, size = self._feats_src
-            # the step composed a head through its t32x convolution and never wrote g_i: rebuild it (no gradient)
+            # a step with `compose_heads` composed a head through its t32x convolution and never wrote g_i: rebuild it (no gradient -- the owner's promise)
             g0, g1, g2 = [g() if callable(g) else g for g in (g0, g1, g2)]
             self._feats = [_nchw_view(ops.norm_add3(g0, g1, g2))]
             self._feats_src = None
@@ -718,7 +722,8 @@ class FTC(nn.Module):
             d1, s1 = self.dec3(d2, f[1], with_sum=True)
             # level 0: post, `x_0 + y_0` and t324 as one GEMM (u, d0, s0 never written) -- and through aux0 as well when the feature-polarization
             # loss is off (nothing else reads g0 then; `feats` rebuilds it on demand)
-            g0 = self.dec4.forward_through(d1, f[0], self.t324, aux=None if self.eager_feats else self.aux0)
+            compose = self.compose_heads and not self.eager_feats
+            g0 = self.dec4.forward_through(d1, f[0], self.t324, aux=self.aux0 if compose else None)
             if isinstance(g0, tuple):
                 y0_direct, (kind, src) = g0
                 skip0, pw, tw = f[0], self.dec4.post[0], self.t324
@@ -730,7 +735,7 @@ class FTC(nn.Module):
             # levels 1-3: aux_i(t32x(s_i)) as one GEMM with the composed weight when nothing else reads g_i (feature-polarization loss off)
             mids, lg_direct = [], []
             for t, aux, s_ in ((self.t323, self.aux1, s1), (self.t322, self.aux2, s2), (self.t321, self.aux4, s3)):
-                if self.training and not self.eager_feats and ops.head_through_t32_ok(s_, t.weight, t.bias, aux.weight, aux.bias):
+                if self.training and compose and ops.head_through_t32_ok(s_, t.weight, t.bias, aux.weight, aux.bias):
                     lg_direct.append(ops.head_through_t32(s_, t.weight, t.bias, aux.weight, aux.bias))
                     mids.append(lambda t=t, s_=s_: self._rebuild(t, s_))
                 else:

@@ -2576,16 +2576,19 @@ def l2norm(x, eps=1e-12):
 # node and the FPL is its only differentiable consumer (how FTC / RegNet use it), _Fpl.backward returns a zero-stride placeholder of the right shape
 # and registers (labels, binmap, table, upstream gradient) under the placeholder's storage; _NormAdd.backward picks the recipe up and runs the
 # lookup forms of its three kernels (tcct_l2norm_bwd_fplgrad, tcct_bilinear_bwd_fplgrad): the 452 MB gradient (bench shape) is neither written nor
-# read three times.  A placeholder that autograd had to ADD to another gradient (a second differentiable consumer of feats) would lose the FPL part
-# silently -- so producers register only tensors handed out as `FTC.feats`, and TCCT_FPL_LAZY_GRAD=0 restores the dense tensor.
+# read three times.  A placeholder that autograd had to ADD to another gradient (a second differentiable consumer of feats, the FPL evaluated twice
+# on the same feats) arrives as a dense tensor without the FPL part: every recipe is therefore ALSO filed under its producer (`pending`), and a
+# producer whose incoming gradient is not the single placeholder materialises the pending recipes (tcct_fpl_backward) and adds them.  A feats tensor
+# with hooks / retain_grad (somebody wants to SEE the gradient) never takes the lazy path.  TCCT_FPL_LAZY_GRAD=0 restores the dense tensor everywhere.
 FPL_LAZY_GRAD = os.environ.get('TCCT_FPL_LAZY_GRAD', '1') != '0'
-_FPL_LAZY = {'producers': set(), 'grads': {}}
+_FPL_LAZY = {'producers': set(), 'grads': {}, 'pending': {}}
 
 
 def fpl_lazy_grad_reset():
     """per step (begin_step): forget last step's registrations (storage addresses are recycled by the allocator)"""
     _FPL_LAZY['producers'].clear()
     _FPL_LAZY['grads'].clear()
+    _FPL_LAZY['pending'].clear()
 
 
 class _NormAdd(torch.autograd.Function):
@@ -2606,6 +2609,7 @@ class _NormAdd(torch.autograd.Function):
         lib.normadd_fwd(g0, g1, g2, inv1, inv2, out, N, H, W, C, h1, w1, h2, w2, eps, dtype_code(g0.dtype))
         ctx.save_for_backward(g0, g1, g2)
         ctx.eps = eps
+        ctx.out_ptr = out.data_ptr()
         if fork and C == 32:
             _FPL_LAZY['producers'].add(out.data_ptr())
         return (out, g0.view_as(g0), g1.view_as(g1), g2.view_as(g2)) if fork else out
@@ -2614,11 +2618,22 @@ class _NormAdd(torch.autograd.Function):
     def backward(ctx, dy, *dalias):
         g0, g1, g2 = ctx.saved_tensors
         dalias = tuple(dalias) + (None,) * (3 - len(dalias))
-        if dy is None:          # only the aliases were used downstream
+        pending = _FPL_LAZY['pending'].pop(ctx.out_ptr, [])        # recipes of every _Fpl node that consumed THIS node's output
+        if dy is None and not pending:          # only the aliases were used downstream
             return dalias[0], dalias[1], dalias[2], None, None
         N, H, W, C = g0.shape
         dc = dtype_code(g0.dtype)
-        lazy = _FPL_LAZY['grads'].pop(dy.data_ptr(), None) if (dy.dim() == 4 and dy.stride(0) == 0) else None
+        lazy = None
+        if dy is not None and len(pending) == 1 and dy.dim() == 4 and dy.stride(0) == 0 and dy.data_ptr() == pending[0][0].data_ptr():
+            lazy = _FPL_LAZY['grads'].pop(dy.data_ptr(), None)     # the single placeholder, untouched by autograd
+        elif pending:
+            # autograd ADDED the placeholder(s) to another gradient (or to each other): the dense sum lacks the FPL part -- materialise it
+            dy = None if dy is None else _c(_as(dy, g0.dtype))
+            for marker, labels, binmap, dpro, gup, ncls in pending:
+                _FPL_LAZY['grads'].pop(marker.data_ptr(), None)
+                dfeat = torch.empty_like(g0)
+                lib.fpl_backward(labels, binmap, dpro, gup, 1.0, int(labels.numel()), dfeat, dc)
+                dy = dfeat if dy is None else add(dy, dfeat)
         if lazy is not None:    # the gradient is the feature-polarization loss's: looked up, never materialised
             _, labels, binmap, dpro, gup, ncls = lazy
             outs = []
@@ -2949,7 +2964,7 @@ def label_planes(labels, start, n, want_onehot=True, want_edge=True):
 
 class _Fpl(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, logits, labels, buf_grad):
+    def forward(ctx, feat, logits, labels, buf_grad, allow_lazy=True):
         ctx.set_materialize_grads(False)      # an unused output must arrive as None in backward(), not as a zero-filled tensor
         _chk(feat, logits, labels, buf_grad)
         C = logits.shape[-1]
@@ -2972,7 +2987,8 @@ class _Fpl(torch.autograd.Function):
         ctx.save_for_backward(labels, binmap, dpro)
         ctx.cfg = (feat.shape, feat.dtype, M)
         # feat is the output of a norm_add node that can look its gradient up from (labels, bins, table) itself (FPL_LAZY_GRAD below)
-        ctx.lazy = FPL_LAZY_GRAD and feat.data_ptr() in _FPL_LAZY['producers'] and feat.shape[-1] == 32 and feat.is_contiguous()
+        ctx.lazy = (FPL_LAZY_GRAD and allow_lazy and feat.data_ptr() in _FPL_LAZY['producers'] and feat.shape[-1] == 32 and feat.is_contiguous())
+        ctx.producer = feat.data_ptr()
         ctx.mark_non_differentiable(pro)
         return loss, pro
 
@@ -2981,20 +2997,27 @@ class _Fpl(torch.autograd.Function):
         labels, binmap, dpro = ctx.saved_tensors
         shape, dt, M = ctx.cfg
         if g is None:
-            return None, None, None, None
+            return None, None, None, None, None
         g = _as(g, torch.float32)
         if ctx.lazy:
             # d loss / d feat is a function of two bytes per pixel: hand norm_add's backward the recipe instead of the 452 MB tensor.  The returned
             # gradient is a zero-stride expansion of one zero element (right shape and dtype, no memory); the consumer recognises its storage.
             marker = torch.zeros(1, device=g.device, dtype=dt)
-            _FPL_LAZY['grads'][marker.data_ptr()] = (marker, labels, binmap, dpro, g, int(dpro.shape[0]))
-            return marker.expand(shape), None, None, None
+            recipe = (marker, labels, binmap, dpro, g, int(dpro.shape[0]))
+            _FPL_LAZY['grads'][marker.data_ptr()] = recipe
+            _FPL_LAZY['pending'].setdefault(ctx.producer, []).append(recipe)
+            return marker.expand(shape), None, None, None, None
         dfeat = torch.empty(shape, device=g.device, dtype=dt)
         lib.fpl_backward(labels, binmap, dpro, g, 1.0, M, dfeat, dtype_code(dt))
-        return dfeat, None, None, None
+        return dfeat, None, None, None, None
 
 
-def fpl(feat, logits, labels, buf_grad):
+def grad_is_watched(t):
+    """somebody hooks `t` or retains its gradient, i.e. wants to SEE d loss / d t"""
+    return bool(getattr(t, 'retains_grad', False)) or bool(getattr(t, '_backward_hooks', None))
+
+
+def fpl(feat, logits, labels, buf_grad, allow_lazy=True):
     """regular_udh: feat NHWC [N,H,W,32], logits NHWC [N,H,W,C] (no grad flows to them), labels uint8 [N,H,W],
-    buf_grad fp32 [C,32] -> (loss, prototypes [C,32,32])"""
-    return _Fpl.apply(feat, logits.detach(), labels, buf_grad)
+    buf_grad fp32 [C,32] -> (loss, prototypes [C,32,32]).  allow_lazy=False (or a watched `feat`): the gradient wrt feat is the dense tensor."""
+    return _Fpl.apply(feat, logits.detach(), labels, buf_grad, bool(allow_lazy) and not grad_is_watched(feat))

@@ -70,7 +70,7 @@ class FlatAdamW(torch.optim.Optimizer):
             if int(flat['numel']) != self._flat['n']:
                 raise TcctError(f"FlatAdamW.load_state_dict(): saved state has {flat['numel']} elements, this optimizer {self._flat['n']}")
             layout = flat.get('layout')
-            if layout is not None and [(str(n), tuple(x)) for n, x in layout] != self.layout():
+            if layout is not None and not self._same_layout(layout):
                 raise TcctError('FlatAdamW.load_state_dict(): the saved moments are laid out in another parameter order (saved with a different '
                                 'TCCT_DP_OVERLAP mode or another set of trained parameters); applying them would permute the AdamW state')
             self._flat['m'].copy_(flat['m'])
@@ -78,6 +78,21 @@ class FlatAdamW(torch.optim.Optimizer):
             self._step = int(flat['step'])
             if self.device_state is not None:
                 self.device_state[1:2].fill_(float(self._step))
+
+    def _same_layout(self, saved):
+        """saved: a `layout` entry of state_dict().  Two formats exist: [(name, shape)] (round 4 on) and the older [shape].  Names are compared only
+        where BOTH sides have real ones ('#pos' stands for "attached without a model"); shapes and positions always."""
+        mine = self.layout()
+        if len(saved) != len(mine):
+            return False
+        for entry, (name, shape) in zip(saved, mine):
+            legacy = len(entry) == 0 or not isinstance(entry[0], str)          # a plain shape tuple / list / torch.Size
+            sname, sshape = (None, tuple(entry)) if legacy else (str(entry[0]), tuple(entry[1]))
+            if tuple(int(d) for d in sshape) != shape:
+                return False
+            if sname is not None and not sname.startswith('#') and not name.startswith('#') and sname != name:
+                return False
+        return True
 
     def layout(self):
         """[(name, shape)] in flat-buffer order.  Names come from `named=` (tcct_amd.dist.attach passes model.named_parameters()); a parameter

@@ -959,6 +959,55 @@ def test_fpl_gradient_looked_up_inside_norm_add_backward(cfg):
         assert same > 0.99, (nm, same)
 
 
+@pytest.mark.parametrize('case', ['second_consumer', 'fpl_twice', 'retain_grad'])
+def test_fpl_lazy_gradient_survives_other_consumers_of_feats(case):
+    """round 5 (advisor): the placeholder `_Fpl.backward` returns must never lose the FPL gradient.  A second differentiable consumer of `feats`
+    (autograd ADDS the placeholder to a dense gradient), the FPL evaluated twice on the same feats (two placeholders added to each other) and a
+    caller who retains the gradient of feats: d g0 / d g1 / d g2 must equal the dense path's (TCCT_FPL_LAZY_GRAD=0), and feats.grad must be the
+    real gradient, not zeros."""
+    from tcct_amd import ops
+    N, H, W, C = 2, 32, 48, 5
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(77)
+    g0 = torch.randn(N, H, W, 32, generator=g).to(dt)
+    g1 = torch.randn(N, H // 2, W // 2, 32, generator=g).to(dt)
+    g2 = torch.randn(N, H // 4, W // 4, 32, generator=g).to(dt)
+    lab = torch.randint(0, C, (N, H, W), generator=g).to(torch.uint8).cuda()
+    logits = (torch.randn(N, H, W, C, generator=g) * 2).cuda()
+    buf = F.normalize(torch.rand(C, 32, generator=g), dim=-1).cuda()
+    wside = torch.randn(N, H, W, 32, generator=g).cuda()
+    res, fgrad = {}, {}
+    for lazy in (True, False):
+        ops.FPL_LAZY_GRAD = lazy
+        try:
+            ops.fpl_lazy_grad_reset()
+            xs = [t.cuda().requires_grad_(True) for t in (g0, g1, g2)]
+            feats, a0, a1, a2 = ops.norm_add3_fork(*xs)
+            view = feats.permute(0, 3, 1, 2)
+            if case == 'retain_grad':
+                view.retain_grad()
+            loss, _ = ops.fpl(view.permute(0, 2, 3, 1), logits, lab, buf, allow_lazy=not ops.grad_is_watched(view))
+            total = loss * 1.7
+            if case == 'second_consumer':
+                total = total + (feats.float() * wside).sum() * 1e-3
+            if case == 'fpl_twice':
+                loss2, _ = ops.fpl(view.permute(0, 2, 3, 1), logits * 0.5, lab, buf)
+                total = total + loss2 * 0.6
+            total.backward()
+            res[lazy] = [x.grad.float().cpu() for x in xs]
+            if case == 'retain_grad':
+                fgrad[lazy] = view.grad.float().cpu()
+            assert not ops._FPL_LAZY['grads'] and not ops._FPL_LAZY['pending']
+        finally:
+            ops.FPL_LAZY_GRAD = True
+    for a, b, nm in zip(res[True], res[False], ('g0', 'g1', 'g2')):
+        assert torch.isfinite(a).all() and (a != 0).any()
+        torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-5 * max(1.0, b.abs().max().item()), msg=lambda m, nm=nm: nm + ': ' + m)
+    if case == 'retain_grad':
+        assert (fgrad[True] != 0).any()
+        torch.testing.assert_close(fgrad[True], fgrad[False], rtol=0, atol=0)
+
+
 @pytest.mark.parametrize('dim', [64, 96])
 def test_invres_norm_applied_inside_conv2_equals_the_separate_pass(dim):
     """round 4 (ops.batchnorm_deferred + pw_conv_bn(deferred=...)): InvRes.norm's BatchNorm + Hardswish (reference nets/tcct.py:563-572) is applied by
@@ -1199,6 +1248,20 @@ def test_flat_adamw_state_refuses_a_permuted_layout():
         p.grad = torch.ones_like(p)
     o4.step()
     assert o4.layout() == [('#0', (8,)), ('#1', (8,))]
+    # round 5 (advisor): the round-3 format [shape] still loads (shapes + positions compared), and a checkpoint saved WITH names resumes on an
+    # optimizer attached WITHOUT them (and the reverse) when shapes and positions agree
+    legacy = dict(sd)
+    legacy['flat'] = dict(sd['flat'], layout=[tuple(s) for _, s in sd['flat']['layout']])
+    o5 = make(['a.weight', 'b.weight', 'c.weight'])
+    o5.load_state_dict(legacy)
+    assert torch.equal(o5._flat['m'], o1._flat['m'])
+    o6 = make(['a.weight', 'b.weight', 'c.weight'])
+    o6.names.clear()
+    o6.load_state_dict(sd)
+    bad = dict(sd)
+    bad['flat'] = dict(sd['flat'], layout=[(32, 32, 3, 3), (32, 32, 3, 3), (32, 32, 1, 1)])
+    with pytest.raises(TcctError, match='another parameter order'):
+        make(['a.weight', 'b.weight', 'c.weight']).load_state_dict(bad)
 
 
 def test_fpl_matches_oracle():
