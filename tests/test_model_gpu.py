@@ -809,6 +809,152 @@ def test_trained_weights_train_step_matches_reference(name, tmp_path):
             assert relerr(sd[key[4:]].float(), fx[key].astype(np.float32)) < 1e-4, key
 
 
+# ---- round 5: FIVE consecutive steps against the reference's own loop (tests/golden/traj5_*.npz, oracle/make_golden_traj5.py) -------------------------
+# fp32: the literal 1e-3 on every per-step loss part and total norm; after step 5 the weights' DISPLACEMENT from the start (what five updates did),
+# Adam's moments, every BatchNorm buffer.  bf16: frozen bounds (`TRAJ_BF16`), set from the measurement recorded in profiles/r05_parity.md.
+TRAJ_FP32 = dict(loss=1e-3, norm=1e-3, disp=3e-2, m=2e-2, v=2e-2, buf=1e-3)
+TRAJ_BF16 = dict(loss=2e-2, norm=5e-2, disp=0.35, m=0.3, v=0.5, buf=3e-2)
+
+
+def _traj_run(name, dtype, tmp_path):
+    """ckpt_trained5 -> five train steps of KiteSeg's own loop pieces (zero_grad, forward, losses, backward, fused clip + AdamW; CyclicLR stepped where
+    the reference stepped it) on the fixture's inputs, forced DropPath masks and recorded noise"""
+    from tcct_amd import checkpoint as C, ops
+    from tcct_amd.nets import stc_tt, RegNet
+    from tcct_amd.kite import KiteSeg
+    fx = np.load(os.path.join(GOLD, name + '.npz'))
+    n_class = int(fx['n_class'])
+    udh, reg = bool(fx['flags'][0]), bool(fx['flags'][1])
+    model = RegNet(stc_tt(n_class, compute_dtype=dtype), con='cos', out_channels=n_class)
+    missing, _ = C.load_reference_checkpoint(model, os.path.join(GOLD, 'ckpt_trained5.npz'))
+    assert not missing
+    model = model.cuda().train()
+
+    class DS:
+        out_channels = n_class
+    args = argparse.Namespace(los='di', lr=1e-2, gpu='0', pl=False, bs=2, coff_ds=1, udh=udh, reg=reg, epl=False, coff_udh=1, coff_reg=.1,
+                              coff_epl=.1, bug=True)
+    k = KiteSeg(model=model, dataset=DS(), root=str(tmp_path), args=args)
+    model.train()
+    sd0 = {n: v.detach().clone() for n, v in model.state_dict().items()}
+    k.optimG.param_groups[0]['lr'] = float(fx['lr'][0])
+    steps = []
+    for t in range(int(fx['n_steps'])):
+        img = torch.from_numpy(fx['img'][t]).cuda()
+        lab = torch.from_numpy(fx['lab'][t]).long().cuda()
+        model.base.base_vit.forced_dp_masks = [torch.tensor(m, dtype=torch.float32) for m in fx['dp_masks'][t]]
+        assert abs(k.optimG.param_groups[0]['lr'] - float(fx['lr'][t])) < 1e-12, (t, k.optimG.param_groups[0]['lr'])
+        k.optimG.zero_grad(set_to_none=True)
+        ops.begin_step(k.device)
+        try:
+            base = model.base
+            base.defer_aux_resize = True            # as KiteSeg.calc_loss does
+            try:
+                out = model(img)
+            finally:
+                base.defer_aux_resize = False
+            parts = {'dice': k.grad_calc(out, lab, ds=True, criterion=k.criterion)}
+            if udh:
+                parts['udh'] = model.regular_udh(out[0], lab) * 1.0
+            if reg:
+                noise = tuple(torch.tensor(fx[f'noise{t}_{j}']) for j in range(4))
+                parts['reg'] = model.regular_reg(out[0], lab, noise=noise) * 0.1
+            total = sum(parts.values())
+            total.backward()
+        finally:
+            ops.end_step()
+        k.optimG.step()
+        if t + 1 == int(fx['sched_after']):
+            k.schedG.step()
+        steps.append(dict(total=total.item(), norm=k.optimG.last_total_norm.item(), **{a: b.item() for a, b in parts.items()}))
+    model.base.base_vit.forced_dp_masks = None
+    return fx, model, k, sd0, steps
+
+
+def _traj_errors(fx, model, k, sd0, steps):
+    udh, reg = bool(fx['flags'][0]), bool(fx['flags'][1])
+    e = dict(loss=0.0, norm=0.0, disp=0.0, m=0.0, v=0.0, buf=0.0)
+    for t, s in enumerate(steps):
+        for key, fk in (('total', 'loss_total'), ('dice', 'loss_dice')) + ((('udh', 'loss_udh'),) if udh else ()) + ((('reg', 'loss_reg'),) if reg else ()):
+            ref = float(fx[fk][t])
+            e['loss'] = max(e['loss'], abs(s[key] - ref) / max(1.0, abs(ref)))
+        e['norm'] = max(e['norm'], abs(s['norm'] - float(fx['grad_total_norm'][t])) / float(fx['grad_total_norm'][t]))
+    names = [str(n) for n in fx['names']]
+    signal = dict(zip(names, fx['signal']))
+    named = dict(model.named_parameters())
+    f = k.optimG._flat
+    worst = {}
+    n_w = 0
+    for key in fx.files:
+        if key[:2] not in ('w:', 'm:', 'v:'):
+            continue
+        n = key[2:]
+        if not signal[n]:       # exact-zero gradient (a bias in front of a train-mode BatchNorm): rounding noise through Adam, in the reference too
+            continue
+        ref = torch.from_numpy(fx[key]).double()
+        p = named[n]
+        if key[0] == 'w':
+            d_ref, d = ref - sd0[n].double().cpu(), p.detach().double().cpu() - sd0[n].double().cpu()
+            err = (d - d_ref).norm().item() / d_ref.norm().item()
+            kind = 'disp'
+            n_w += 1
+        else:
+            off = (p.data_ptr() - f['p'].data_ptr()) // 4
+            got = f[key[0]][off:off + p.numel()].view_as(p).double().cpu()
+            err = (got - ref).norm().item() / ref.norm().item()
+            kind = key[0]
+        if err > e[kind]:
+            e[kind], worst[kind] = err, n
+    assert n_w >= 25
+    sd5 = model.state_dict()
+    lr_sum = float(fx['lr'].sum())
+    n_buf = 0
+    for key in fx.files:
+        if key.startswith('buf:'):
+            ref, got = torch.from_numpy(np.asarray(fx[key])), sd5[key[4:]].cpu()
+            if key.endswith('num_batches_tracked'):
+                assert int(got) == int(ref), key
+            else:       # running means carry the +-lr random walk of the zero-gradient biases in front of them (see tests/test_oracle_golden.py)
+                slack = 0.5 * lr_sum if key.endswith('running_mean') else 0.0
+                err = max(0.0, (got.double() - ref.double()).abs().max().item() - slack) / max(1.0, ref.abs().max().item())
+                if err > e['buf']:
+                    e['buf'], worst['buf'] = err, key[4:]
+            n_buf += 1
+    assert n_buf >= 150
+    # every trained tensor: displacement norm against the reference's
+    dn = 0.0
+    for n, dl2 in zip(names, fx['disp_l2']):
+        if signal[n]:
+            dn = max(dn, abs((named[n].detach().double().cpu() - sd0[n].double().cpu()).norm().item() - dl2) / dl2)
+    e['disp_norm'] = dn
+    return e, worst
+
+
+@pytest.mark.parametrize('name', ['traj5_di', 'traj5_reg', 'traj5_full'])
+def test_five_step_trajectory_matches_the_reference_fp32(name, tmp_path):
+    """Five consecutive steps of the reference's own loop (kite/loop_seg.py:108-142; AdamW + clip + CyclicLR, kite/loopback.py:102-128) from the
+    reference-trained checkpoint, per loss configuration (BASELINE cfg1-2 / cfg3 / cfg4): every per-step loss part and total gradient norm at the
+    literal 1e-3; after step 5 the weights' displacement, Adam's first and second moments (bias correction at t >= 2, lr changed by the scheduler
+    after step 3), every BatchNorm running mean / variance at 1e-3 and num_batches_tracked exactly (lap_map's BatchNorm runs twice per step)."""
+    fx, model, k, sd0, steps = _traj_run(name, torch.float32, tmp_path)
+    e, worst = _traj_errors(fx, model, k, sd0, steps)
+    print(name, 'fp32 five-step trajectory vs the reference:', {a: f'{b:.2e}' for a, b in e.items()}, worst)
+    for key, bound in TRAJ_FP32.items():
+        assert e[key] <= bound, (key, e[key], worst.get(key))
+    assert e['disp_norm'] <= TRAJ_FP32['disp']
+
+
+@pytest.mark.parametrize('name', ['traj5_di', 'traj5_reg', 'traj5_full'])
+def test_five_step_trajectory_bf16_against_the_reference(name, tmp_path):
+    """the benchmarked precision on the same five reference steps, frozen bounds (TRAJ_BF16): the loss trajectory within 2 %, the total norm
+    within 5 %, and the displacement / moments pointing the reference's way"""
+    fx, model, k, sd0, steps = _traj_run(name, torch.bfloat16, tmp_path)
+    e, worst = _traj_errors(fx, model, k, sd0, steps)
+    print(name, 'bf16 five-step trajectory vs the reference:', {a: f'{b:.2e}' for a, b in e.items()}, worst)
+    for key, bound in TRAJ_BF16.items():
+        assert e[key] <= bound, (key, e[key], worst.get(key))
+
+
 @pytest.mark.parametrize('name', ['full_trained_2x64x64', 'duke_train_2x160x160'])
 def test_fp32_pointwise_forward_on_matrix_pipes_meets_the_literal_contract(name, tmp_path, monkeypatch):
     """`TCCT_F32_PW_FWD=1` (the fp32 pointwise FORWARD on `k_pwf_mfma`) through the whole train step on the well-conditioned reference-held

@@ -183,6 +183,89 @@ def test_oracle_reproduces_trained5_fixture(name):
     close(O.iou_scorem(mask, oh, 1), fx['iou_scorem'], 1e-6)
 
 
+@pytest.mark.parametrize('name', ['traj5_di', 'traj5_reg', 'traj5_full'])
+def test_oracle_follows_the_reference_for_five_steps(name):
+    """tests/golden/traj5_*.npz (oracle/make_golden_traj5.py): FIVE consecutive steps of the real reference's own loop from ckpt_trained5 (its
+    calc_loss, backward, clip_grad_norm_(12), AdamW(wd 2e-4); lr 1e-3 for three steps, then its CyclicLR's 2.575e-5; kite/loop_seg.py:108-142,
+    kite/loopback.py:102-128).  The oracle runs the five steps FREELY -- its own weights, Adam moments and BatchNorm buffers, never re-synchronised --
+    and must stay on the reference's trajectory: per-step loss parts and gradient norms, the weights' displacement after step 5, the moments, every
+    BatchNorm running statistic and num_batches_tracked (lap_map's BatchNorm runs twice per step)."""
+    torch.set_num_threads(4)
+    fx = np.load(os.path.join(GOLD, name + '.npz'))
+    ck = np.load(os.path.join(GOLD, 'ckpt_trained5.npz'))
+    sd = {}
+    for k in ck.files:
+        if k.startswith('w::'):
+            sd[k[3:]] = torch.from_numpy(ck[k].view(np.int16).copy()).view(torch.bfloat16).float()
+        elif k.startswith('i::'):
+            sd[k[3:]] = torch.from_numpy(np.asarray(ck[k]).copy())
+    sd0 = {k: v.clone() for k, v in sd.items()}
+    names = [str(n) for n in fx['names']]
+    udh, reg = bool(fx['flags'][0]), bool(fx['flags'][1])
+    m = {n: torch.zeros_like(sd[n]) for n in names}
+    v = {n: torch.zeros_like(sd[n]) for n in names}
+    for t in range(int(fx['n_steps'])):
+        for n in names:
+            sd[n] = sd[n].detach().requires_grad_(True)
+        img = torch.tensor(fx['img'][t]).repeat(1, 3, 1, 1)
+        oh = torch.nn.functional.one_hot(torch.from_numpy(fx['lab'][t]).long(), 5).permute(0, 3, 1, 2)
+        masks = [torch.tensor(x, dtype=torch.float32) for x in fx['dp_masks'][t]]
+        noise = tuple(torch.tensor(fx[f'noise{t}_{j}']) for j in range(4)) if reg else None
+        tot, parts, _, _ = O.total_loss(sd, img, oh, udh=udh, reg=reg, dp_masks=masks, noise=noise)
+        tot.backward()
+        assert sorted(n for n in sd if getattr(sd[n], 'grad', None) is not None) == sorted(names)
+        total = O.clip_adamw_step([sd[n].data for n in names], [sd[n].grad for n in names], [m[n] for n in names], [v[n] for n in names],
+                                  t + 1, float(fx['lr'][t]))
+        for n in names:
+            sd[n] = sd[n].detach()
+        assert abs(tot.item() - float(fx['loss_total'][t])) <= 1e-4 * max(1.0, abs(float(fx['loss_total'][t]))), (t, tot.item())
+        assert abs(parts['dice'].item() - float(fx['loss_dice'][t])) <= 1e-4
+        if udh:
+            assert abs(parts['udh'].item() - float(fx['loss_udh'][t])) <= 1e-4
+        if reg:
+            assert abs(parts['reg'].item() - float(fx['loss_reg'][t])) <= 1e-4
+        assert abs(total.item() - float(fx['grad_total_norm'][t])) <= 1e-3 * float(fx['grad_total_norm'][t]), (t, total.item())
+    signal = dict(zip(names, fx['signal']))
+    n_w = 0
+    for key in fx.files:
+        if key[:2] not in ('w:', 'm:', 'v:'):
+            continue
+        n = key[2:]
+        if not signal[n]:               # exact-zero gradient (a bias in front of a train-mode BatchNorm): rounding noise through Adam, also in the reference
+            continue
+        ref = torch.from_numpy(fx[key]).double()
+        if key[0] == 'w':
+            d_ref, d = ref - sd0[n].double(), sd[n].double() - sd0[n].double()
+            assert (d - d_ref).norm().item() <= 2e-2 * d_ref.norm().item(), (key, (d - d_ref).norm().item() / d_ref.norm().item())
+            n_w += 1
+        else:
+            got = (m if key[0] == 'm' else v)[n].double()
+            assert (got - ref).norm().item() <= 5e-3 * ref.norm().item(), (key, (got - ref).norm().item() / ref.norm().item())
+    assert n_w >= 25
+    lr_sum = float(fx['lr'].sum())
+    for n, l2, dl2 in zip(names, fx['w_l2'], fx['disp_l2']):
+        disp = (sd[n].double() - sd0[n].double()).norm().item()
+        if signal[n]:
+            assert abs(sd[n].double().norm().item() - l2) <= 1e-4 * max(l2, 1e-3), n
+            assert abs(disp - dl2) <= 2e-2 * dl2, n
+        else:       # Adam turns rounding-level gradients into steps of at most lr per element and step, in the reference (dl2) as here
+            bound = 1.02 * lr_sum * sd[n].numel() ** 0.5 + 1e-3 * sd0[n].double().norm().item() * lr_sum
+            assert disp <= bound and dl2 <= bound, (n, disp, dl2, bound)
+    n_buf = 0
+    for key in fx.files:
+        if key.startswith('buf:'):
+            ref, got = torch.from_numpy(np.asarray(fx[key])), sd[key[4:]]
+            if key.endswith('num_batches_tracked'):
+                assert int(got) == int(ref), key
+            else:
+                # a running MEAN also carries the convolution bias in front of its BatchNorm, whose gradient is exactly zero: Adam walks it by +-lr of
+                # random sign per step in the reference and here alike, and the 0.1-momentum average picks up to (1 - 0.9^5) of that difference up
+                slack = 0.5 * lr_sum if key.endswith('running_mean') else 0.0
+                assert (got.double() - ref.double()).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item()) + slack, key
+            n_buf += 1
+    assert n_buf >= 150 and int(sd['lap_map.1.num_batches_tracked']) - int(sd0['lap_map.1.num_batches_tracked']) == (10 if reg else 0)
+
+
 def test_oracle_known_answers():
     """known-answer checks that need no reference"""
     # MetaPool == 3x3 box over (token, channel) with valid-count divisor, minus identity
