@@ -216,6 +216,13 @@ int tcct_pw_fwd_affine(const void* x, const float* w, const float* bias, void* y
  * a second consumer (CrossCNNBlock: x feeds block12 and block34, nets/tcct.py:826) -- no separate gradient accumulation pass */
 int tcct_conv32_fwd_add(const void* x, const void* wp, const float* bias, const void* res, void* y, int N, int H, int W, int KH, int KW,
                         int PH, int PW, tcct_stream_t stream);
+/* Two dense 3x3 32 -> 32 convolutions with nothing between them as ONE launch (csrc/conv_chain.hip, round 5): y = conv(conv(x; wp1, bias1); wp2, bias2),
+ * mid = the first convolution's output -- written (the backward pass needs it) but not read back, the second convolution takes it from LDS.  Replaces
+ * nn.Conv2d -> nn.Conv2d of CrossCNNBlock.block12 (reference nets/tcct.py:808-810: no nonlinearity between the two) and, with the flipped / transposed
+ * packs, the input-gradient chain of the same pair.  stats (fp64 [64] zero on entry, or NULL): += {sum, sum of squares} per channel of LeakyReLU(y) as
+ * stored (the BatchNorm behind block12, :811); res (or NULL): y += res before the store (as tcct_conv32_fwd_add).  Bit-identical to two tcct_conv32_fwd calls. */
+int tcct_conv32_chain33(const void* x, const void* wp1, const float* bias1, void* mid, const void* wp2, const float* bias2, void* y,
+                        const void* res, int N, int H, int W, double* stats, tcct_stream_t stream);
 /* the same kernels on 32-channel slabs of wider NHWC tensors (x: xs channels/pixel, slab at xo; y: ys, yo; accumulate adds
  * into y) and on 32x32 sub-blocks (o_off, i_off) of an OIHW weight with cin_total input channels: 32->64 / 64->32 convolutions
  * (MPViT stem[1], nets/tcct.py:682-689) run as 32x32 sub-GEMMs.  wgrad_strided ACCUMULATES: zero dw/dbias first. */

@@ -77,8 +77,13 @@ class CrossCNNBlock(nn.Module):
         consumers read"""
         tr = self.training
         m0 = self.block12[0]       # x feeds both branches: block34 reads the alias, its gradient is added in block12[0]'s dgrad epilogue
-        a0, x2 = ops.conv2d_fork(x, m0.weight, m0.bias, m0.stride[0], tuple(m0.padding))
-        a = _conv(self.block12[1], a0, stats_pre='lrelu' if tr else None)
+        m1c = self.block12[1]
+        if ops.conv3x3_chain_ok(x, m0.weight, m0.bias, m1c.weight, m1c.bias, m0.stride[0], m0.padding, m1c.stride[0], m1c.padding):
+            # conv3x3 -> conv3x3, nothing in between (reference tcct.py:808-810): one launch each way, the intermediate is not read back
+            a, x2 = ops.conv3x3_chain(x, m0.weight, m0.bias, m1c.weight, m1c.bias, stats_pre='lrelu' if tr else None, fork=True)
+        else:
+            a0, x2 = ops.conv2d_fork(x, m0.weight, m0.bias, m0.stride[0], tuple(m0.padding))
+            a = _conv(m1c, a0, stats_pre='lrelu' if tr else None)
         b = _conv(self.block34[2], _conv(self.block34[1], _conv(self.block34[0], x2)), stats_pre='lrelu' if tr else None)
         if tr:      # fused junction: gelu(BN(lrelu(a)) + BN(lrelu(b))) in one pass over a, b (and one fused backward)
             m1, m2 = self.block12[3], self.block34[4]

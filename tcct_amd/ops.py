@@ -616,6 +616,104 @@ def conv2d(x, w, bias=None, stride=1, pad=0, out_dtype=None, stats_pre=None):
     return y
 
 
+# ---- conv3x3 -> conv3x3 with nothing between them as ONE launch each way (round 5, csrc/conv_chain.hip) ---------------------------------------
+# CrossCNNBlock.block12 (reference nets/tcct.py:808-810).  Forward: the intermediate is written once (the backward pass needs it) and not read back;
+# backward: the input-gradient chain dy -> d mid -> dx the same way (d mid is the dy operand of the first convolution's weight gradient).  Results
+# bit-identical to the two-launch path (TCCT_CONV_CHAIN=0), so no rounding point moves.
+CONV_CHAIN = os.environ.get('TCCT_CONV_CHAIN', '1') != '0'
+# Levels 0-1 only: on the small maps two launches of the tiled kernel are faster than one row-stream chain (8 x 200 x 276: 0.037 vs 0.040 ms,
+# 8 x 100 x 138: 0.017 vs 0.029; `tools/chain_bench.py`) -- a wave walking down a strip is a long serial chain, and the small maps have few strips
+CHAIN_MIN_PIXELS = 1 << 20
+
+
+def conv3x3_chain_ok(x, w1, b1, w2, b2, stride1, pad1, stride2, pad2):
+    return (CONV_CHAIN and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_cuda and x.shape[-1] == 32 and torch.is_grad_enabled()
+            and tuple(w1.shape) == (32, 32, 3, 3) and tuple(w2.shape) == (32, 32, 3, 3) and stride1 == 1 and stride2 == 1
+            and tuple(pad1) == (1, 1) and tuple(pad2) == (1, 1) and x.shape[1] * x.shape[2] * 64 < 2 ** 31
+            and x.shape[0] * x.shape[1] * x.shape[2] >= CHAIN_MIN_PIXELS)
+
+
+def _packs33(ctx_w, need_t):
+    """(forward pack, input-gradient pack or None) of a 3x3 32 -> 32 weight: this step's pack-all launch, or packed here"""
+    cached = _pack_lookup(ctx_w, 3, 3)
+    if cached is not None:
+        return cached
+    if need_t:
+        wp2 = torch.empty(2 * 9 * 1024, device=ctx_w.device, dtype=torch.bfloat16)
+        lib.conv32_pack_weights_both(ctx_w, wp2, 3, 3)
+        return wp2[:9 * 1024], wp2[9 * 1024:]
+    wp = torch.empty(9 * 1024, device=ctx_w.device, dtype=torch.bfloat16)
+    lib.conv32_pack_weights(ctx_w, wp, 3, 3, 0)
+    return wp, None
+
+
+class _ConvChain33(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, stats_box, fork):
+        ctx.set_materialize_grads(False)
+        _chk(x, w1, b1, w2, b2)
+        N, H, W, _ = x.shape
+        mid, y = torch.empty_like(x), torch.empty_like(x)
+        need_t = ctx.needs_input_grad[0]
+        wp1, ctx.wp_t1 = _packs33(w1, need_t)
+        wp2, ctx.wp_t2 = _packs33(w2, True)             # d mid is always needed: it is the dy operand of the first convolution's weight gradient
+        sums = None
+        if stats_box is not None:
+            sums = ZERO.get((64,), torch.float64, x.device) if ZERO.active else torch.zeros(64, device=x.device, dtype=torch.float64)
+            stats_box[1] = sums
+        lib.conv32_chain33(x, wp1, b1, mid, wp2, b2, y, None, N, H, W, sums)
+        ctx.save_for_backward(x, mid, w1, w2)
+        ctx.params = (w1, b1, w2, b2)
+        return (y, x.view_as(x)) if fork else y
+
+    @staticmethod
+    def backward(ctx, dy, dskip=None):
+        x, mid, w1, w2 = ctx.saved_tensors
+        p1, pb1, p2, pb2 = ctx.params
+        if dy is None:          # only the alias was used downstream
+            return dskip, None, None, None, None, None, None
+        dy = _c(dy)
+        N, H, W, _ = x.shape
+        dmid = torch.empty_like(x)
+        wt2 = ctx.wp_t2
+        if wt2 is None:
+            wt2 = torch.empty(9 * 1024, device=x.device, dtype=torch.bfloat16)
+            lib.conv32_pack_weights(w2, wt2, 3, 3, 1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt1 = ctx.wp_t1
+            if wt1 is None:
+                wt1 = torch.empty(9 * 1024, device=x.device, dtype=torch.bfloat16)
+                lib.conv32_pack_weights(w1, wt1, 3, 3, 1)
+            dx = torch.empty_like(x)
+            lib.conv32_chain33(dy, wt2, None, dmid, wt1, None, dx, _as(dskip, x.dtype) if dskip is not None else None, N, H, W, None)
+        else:
+            lib.conv32_fwd(dy, wt2, None, dmid, N, H, W, 3, 3, 1, 1)
+            dx = dskip
+        with _wgrad_stream(_slot_written(p1, pb1, p2, pb2), x, mid, dy, dmid):
+            dw2, db2 = _grad_out(p2, tuple(w2.shape)), (_grad_out(pb2) if pb2 is not None else None)
+            lib.conv32_wgrad(mid, dy, dw2, db2, N, H, W, 3, 3, 1, 1)
+            dw1, db1 = _grad_out(p1, tuple(w1.shape)), (_grad_out(pb1) if pb1 is not None else None)
+            lib.conv32_wgrad(x, dmid, dw1, db1, N, H, W, 3, 3, 1, 1)
+        return dx, _ret(dw1, p1), _ret(db1, pb1), _ret(dw2, p2), _ret(db2, pb2), None, None
+
+
+def conv3x3_chain(x, w1, b1, w2, b2, stats_pre=None, fork=False):
+    """conv3x3(conv3x3(x; w1, b1); w2, b2), both 32 -> 32 'same' (check conv3x3_chain_ok first).  stats_pre: None or 'lrelu' (the train-mode BatchNorm that
+    consumes the output: its statistics come out of the same launch, `_bn_sums`).  fork: also return an alias of x for the OTHER consumers of x, whose
+    gradient is then added inside the input-gradient chain's epilogue."""
+    if stats_pre not in (None, 'lrelu'):
+        raise TcctError('conv3x3_chain: fused statistics only behind LeakyReLU')
+    box = [ACT[stats_pre], None] if stats_pre is not None else None
+    if fork and x.requires_grad:
+        y, alias = _ConvChain33.apply(x, w1, b1, w2, b2, box, True)
+    else:
+        y, alias = _ConvChain33.apply(x, w1, b1, w2, b2, box, False), x
+    if box is not None and box[1] is not None:
+        y._bn_sums = (box[1], box[0])
+    return (y, alias) if fork else y
+
+
 # The two encoders (CNN / ViT) only share the input and are issued on separate HIP streams:
 # the launch-latency-bound kernels of the coarse levels then overlap other work instead of running one after another on an
 # otherwise idle chip (-2.5 ms/step; forking block12/block34 and InvRes/token-mixer

@@ -138,6 +138,80 @@ def test_conv32_weight_gradient_rolling_row_form_equals_the_generic_one(cfg):
         torch.testing.assert_close(outs[0][0], o[0], rtol=1e-4, atol=1e-4 * max(1.0, w.grad.abs().max().item()))
 
 
+@pytest.mark.parametrize('mode', ['plain', 'stats', 'res'])
+@pytest.mark.parametrize('nhw', [(3, 70, 130), (2, 16, 33), (3, 50, 69), (1, 3, 5), (2, 100, 138), (1, 1, 1), (1, 40, 30), (2, 9, 61), (5, 31, 97), (2, 400, 552), (1, 700, 300), (40, 4, 20)])
+def test_conv3x3_chain_is_bit_identical_to_two_launches(nhw, mode):
+    """round 5, csrc/conv_chain.hip: conv3x3 -> conv3x3 of CrossCNNBlock.block12 (reference nets/tcct.py:808-810: nothing between the two) as ONE launch --
+    a producer wave per strip computes the first convolution and hands its packed rows to a consumer wave through LDS; the intermediate is written but not
+    read back.  Against tcct_conv32_fwd twice: the intermediate AND the output bit for bit (zero padding of the intermediate at the image border, strips of
+    30 pixels that do not divide the width, runs shorter than the pipeline, one-pixel images), the fused statistics of LeakyReLU(y) up to the order of the fp32
+    partial sums, the residual form (the input gradient of a convolution whose input has a second consumer); and against torch on the same bf16 operands"""
+    from tcct_amd._lib import lib
+    N, H, W = nhw
+    x = rnd(N, 32, H, W, dt=torch.bfloat16)
+    w1, w2 = rnd(32, 32, 3, 3, seed=1) / 288 ** 0.5, rnd(32, 32, 3, 3, seed=3) / 288 ** 0.5
+    b1, b2 = rnd(32, seed=2), rnd(32, seed=4)
+    res = rnd(N, 32, H, W, seed=5, dt=torch.bfloat16)
+    xd, rd = nhwc(x, torch.bfloat16), nhwc(res, torch.bfloat16)
+    packs = []
+    for w in (w1, w2):
+        wp = torch.empty(9 * 1024, device='cuda', dtype=torch.bfloat16)
+        lib.conv32_pack_weights(w.cuda(), wp, 3, 3, 0)
+        packs.append(wp)
+    b1d, b2d = b1.cuda(), b2.cuda()
+    mid_a, y_a = (torch.full((N, H, W, 32), 7.0, device='cuda', dtype=torch.bfloat16) for _ in range(2))
+    mid_b, y_b = (torch.full((N, H, W, 32), 9.0, device='cuda', dtype=torch.bfloat16) for _ in range(2))
+    s_a, s_b = (torch.zeros(64, device='cuda', dtype=torch.float64) for _ in range(2))
+    lib.conv32_fwd(xd, packs[0], b1d, mid_a, N, H, W, 3, 3, 1, 1)
+    if mode == 'stats':
+        lib.conv32_fwd_bnstats(mid_a, packs[1], b2d, y_a, N, H, W, 3, 3, 1, 1, s_a, 1)
+    elif mode == 'res':
+        lib.conv32_fwd_add(mid_a, packs[1], b2d, rd, y_a, N, H, W, 3, 3, 1, 1)
+    else:
+        lib.conv32_fwd(mid_a, packs[1], b2d, y_a, N, H, W, 3, 3, 1, 1)
+    lib.conv32_chain33(xd, packs[0], b1d, mid_b, packs[1], b2d, y_b, rd if mode == 'res' else None, N, H, W, s_b if mode == 'stats' else None)
+    torch.cuda.synchronize()
+    assert torch.equal(mid_a, mid_b)
+    assert torch.equal(y_a, y_b)
+    if mode == 'stats':
+        torch.testing.assert_close(s_b, s_a, rtol=1e-5, atol=1e-5 * max(1.0, s_a.abs().max().item()))
+    m_ref = F.conv2d(x.float(), w1.bfloat16().float(), b1, 1, 1).bfloat16().float()
+    y_ref = F.conv2d(m_ref, w2.bfloat16().float(), b2, 1, 1) + (res.float() if mode == 'res' else 0)
+    got = y_b.permute(0, 3, 1, 2).float().cpu()
+    torch.testing.assert_close(got, y_ref, rtol=2e-2, atol=2e-2 * max(1.0, y_ref.abs().max().item()))
+
+
+@pytest.mark.parametrize('shape', [(2, 48, 66), (1, 100, 138)])
+def test_conv3x3_chain_node_equals_the_two_node_path(shape, monkeypatch):
+    """ops.conv3x3_chain (forward + the input-gradient chain + both weight gradients, the second consumer's gradient of x added in the chain's epilogue) against
+    conv2d_fork -> conv2d: same outputs and input gradient bit for bit, weight / bias gradients to atomic-order noise"""
+    from tcct_amd import ops
+    N, H, W = shape
+    x0 = rnd(N, 32, H, W, dt=torch.bfloat16)
+    gy = rnd(N, 32, H, W, seed=7, dt=torch.bfloat16)
+    gx2 = rnd(N, 32, H, W, seed=8, dt=torch.bfloat16)
+    ws = [(rnd(32, 32, 3, 3, seed=1) / 17).cuda(), rnd(32, seed=2).cuda(), (rnd(32, 32, 3, 3, seed=3) / 17).cuda(), rnd(32, seed=4).cuda()]
+    res = {}
+    monkeypatch.setattr(ops, 'CHAIN_MIN_PIXELS', 0)         # the training path takes the chain on the large maps only
+    for chain in (True, False):
+        ps = [torch.nn.Parameter(w.clone()) for w in ws]
+        x = nhwc(x0, torch.bfloat16).requires_grad_(True)
+        if chain:
+            assert ops.conv3x3_chain_ok(x, ps[0], ps[1], ps[2], ps[3], 1, (1, 1), 1, (1, 1))
+            y, x2 = ops.conv3x3_chain(x, ps[0], ps[1], ps[2], ps[3], stats_pre='lrelu', fork=True)
+        else:
+            a0, x2 = ops.conv2d_fork(x, ps[0], ps[1], 1, (1, 1))
+            y = ops.conv2d(a0, ps[2], ps[3], 1, (1, 1), stats_pre='lrelu')
+        sums = y._bn_sums[0].clone()
+        torch.autograd.backward([y, x2], [nhwc(gy, torch.bfloat16), nhwc(gx2, torch.bfloat16)])
+        torch.cuda.synchronize()
+        res[chain] = (y.detach(), x.grad, [p.grad for p in ps], sums)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    torch.testing.assert_close(res[True][3], res[False][3], rtol=1e-5, atol=1e-5 * res[False][3].abs().max().item())
+    for a, b in zip(res[True][2], res[False][2]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * max(1.0, b.abs().max().item()))
+
+
 @pytest.mark.parametrize('stat', [None, 0, 1])
 @pytest.mark.parametrize('nhw', [(3, 70, 130), (2, 16, 33), (3, 50, 69), (1, 3, 5), (2, 100, 138), (1, 1, 1), (1, 40, 32), (2, 9, 65), (5, 31, 97), (2, 400, 552), (1, 700, 300), (600, 4, 20), (130, 30, 130)])
 def test_conv32_row_stream_kernel_is_bit_identical_to_the_tiled_one(nhw, stat):
