@@ -129,10 +129,6 @@ def dominant_kernel_roofline(a, iters=20):
         lib.conv32_pack_weights(w, wp, 3, 3, 0)
         name, name2 = 'k_conv32_fwd33_stream<0> (3x3 32->32 fwd/dgrad @L0, row streams)', 'k_conv32_wgrad33_stream (3x3 32->32 weight gradient @L0, row streams)'
         match = 'k_conv32_fwd33_stream<0>'                      # the symbol as rocprofv3 prints it
-        if os.environ.get('TCCT_CONV_STREAM', '1') == '0':      # the A/B arm: the tiled kernel
-            name, match = 'k_conv32_mfma<false,0,3,3> (3x3 32->32 fwd/dgrad @L0, tiles)', 'k_conv32_mfma<false, 0, 3, 3>'
-        if os.environ.get('TCCT_WGRAD_STREAM', '1') == '0':
-            name2 = 'k_conv32_wgrad33_roll (3x3 32->32 weight gradient @L0, rolling rows)'
         fn = lambda: lib.conv32_fwd(x, wp, b, y, a.bs, a.height, Wp, 3, 3, 1, 1)                              # noqa: E731
         fn2 = lambda: lib.conv32_wgrad(x, dy, dw, db, a.bs, a.height, Wp, 3, 3, 1, 1)                         # noqa: E731
     else:       # parity mode: the fp32 MFMA convolution (v_mfma_f32_32x32x2_f32), bound by the fp32 matrix rate, not by HBM

@@ -445,7 +445,7 @@ static int g_fwd_mode = -1;
 /* 0 (default): plain 3x3 convolutions whose waves get >= FS_MIN_RUN rows take the row-stream kernel (TCCT_CONV_STREAM=0: never); 1: the tiled kernel for every
  * shape; 2: the row-stream kernel for every plain 3x3 (the comparison arms of the bit-identity test).  Returns the previous mode; mode < 0 only queries. */
 extern "C" int64_t tcct_conv32_fwd_mode(int mode) {
-    if (g_fwd_mode < 0) { const char* e_ = getenv("TCCT_CONV_STREAM"); g_fwd_mode = (e_ && e_[0] == '0') ? 1 : 0; }
+    if (g_fwd_mode < 0) g_fwd_mode = 0;
     const int prev = g_fwd_mode;
     if (mode >= 0 && mode <= 2) g_fwd_mode = mode;
     return prev;
@@ -1825,7 +1825,7 @@ static int g_wgrad_mode = -1;
 /* 0 (default): plain 3x3 convolutions take the rolling-row kernel; 1: the generic register-staged kernel for every shape (the comparison arm of the
  * bit-compatibility test; TCCT_WGRAD_GENERIC=1 selects it for a whole run).  Returns the previous mode; mode < 0 only queries. */
 extern "C" int64_t tcct_conv32_wgrad_mode(int mode) {
-    if (g_wgrad_mode < 0) { const char* e_ = getenv("TCCT_WGRAD_GENERIC"); g_wgrad_mode = (e_ && e_[0] == '1') ? 1 : 0; }
+    if (g_wgrad_mode < 0) g_wgrad_mode = 0;
     const int prev = g_wgrad_mode;
     if (mode >= 0 && mode <= 2) g_wgrad_mode = mode;
     return prev;
@@ -1871,7 +1871,7 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
         if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * 32, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
     }
     if (g_wgrad_mode < 0) (void)tcct_conv32_wgrad_mode(-1);
-    static const int stream_on = [] { const char* e_ = getenv("TCCT_WGRAD_STREAM"); return e_ ? atoi(e_) : 1; }();      // TCCT_WGRAD_STREAM=0: A/B arm (rolling rows at every level)
+    constexpr int stream_on = 1;
     if ((g_wgrad_mode == 2 || (g_wgrad_mode == 0 && stream_on)) && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {
         const int strips = (W + 15) / 16;
         const int64_t rows = (int64_t)N * ((strips + 3) / 4) * H;            // rows of strip groups (four adjacent strips, one per wave of a block)
@@ -1895,7 +1895,7 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
                            tilesH, tilesW, (int)nt);
         TCCT_LAUNCH_OK();
     }
-    static const bool line_on = [] { const char* e_ = getenv("TCCT_WGRAD_LINE"); return !(e_ && e_[0] == '0'); }();      // TCCT_WGRAD_LINE=0: A/B arm
+    constexpr bool line_on = true;
     if (line_on && g_wgrad_mode != 1 && (KH == 1 || KW == 1) && (TAPS == 13 || TAPS == 11 || TAPS == 9) && xs == 32 && ds == 32 && ldi == 32 && o_off == 0 && i_off == 0 &&
         xo == 0 && dof == 0) {      // 1 x K / K x 1 at levels 0-2: shifted lines
 #define WL_LAUNCH(KK, V)                                                                                                     \

@@ -350,7 +350,7 @@ static void dw_fwd_launch(const void* x, const float* w, const float* bias, void
     int segh, wblocks, hstrips;
     // four columns per thread for the wide bf16 stride-1 images (levels 1-2 of the ViT branch); TCCT_DW_CPT=1 keeps one column (A/B)
     static int cpt_on = -1;
-    if (cpt_on < 0) { const char* e = getenv("TCCT_DW_CPT"); cpt_on = (e && e[0] == '1') ? 0 : 1; }
+    if (cpt_on < 0) cpt_on = 1;
     if (stride == 1 && VEC == 4 && sizeof(T) == 2 && cpt_on && Wo >= 128 && C >= 32) {      // measured +4 % at 64 channels, slower at 4
         dw_geometry(N, Ho, Wo, C, VEC, 1024, 32, segh, wblocks, hstrips, 4);
         dim3 g4((unsigned)((int64_t)N * wblocks * hstrips));
@@ -773,7 +773,7 @@ static int dw_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias,
     int segh, wblocks, hstrips;
     size_t lds = sizeof(float) * DB * 10 * vec;
     static int cpt_on = -1;     // TCCT_DW_WGRAD_CPT=0: one column per thread for every shape (A/B timing)
-    if (cpt_on < 0) { const char* e = getenv("TCCT_DW_WGRAD_CPT"); cpt_on = (e && e[0] == '0') ? 0 : 1; }
+    if (cpt_on < 0) cpt_on = 1;
     if (cpt_on && vec == 4 && stride == 1 && dtype == TCCT_BF16 && Wo >= 128 && C >= 32) {
         dw_geometry(N, Ho, Wo, C, vec, 256, 128, segh, wblocks, hstrips, 2);     // (256 blocks: 0.080 -> 0.060 ms at level 2, 0.119 -> 0.103 stride 2 at level 1; 512 the same at level 1 stride 1)
         if (xab) hipLaunchKernelGGL((k_dw_wgrad<bf16, 4, 1, 2, true>), dim3((unsigned)((int64_t)N * wblocks * hstrips)), dim3(DB), lds, st, (const bf16*)x, (const bf16*)dy, dw, dbias,

@@ -20,7 +20,7 @@
 // apply at 64 channels already streams at 5.8 TB/s with persistent blocks.  Not kept.
 static inline int bn_vec(int C, int dtype) {
     static int v8 = -1;
-    if (v8 < 0) { const char* e = getenv("TCCT_BN_VEC8"); v8 = (e && e[0] == '1') ? 1 : 0; }
+    if (v8 < 0) v8 = 0;
     return (v8 && dtype == TCCT_BF16 && C % 8 == 0) ? 8 : ((C % 4 == 0) ? 4 : 1);
 }
 

@@ -341,7 +341,7 @@ static int pw_fwd2_route(const void* x, const void* x2, const float* w, const fl
                          int stat_pre, tcct_stream_t stream, const bf16* res, const float* rscale, int64_t per_sample, bf16* yplain);
 static bool pw_fwd2_enabled() {         // TCCT_PW_FWD2=0: the direct-from-global forward kernel for every shape (A/B timing)
     static int on = -1;
-    if (on < 0) { const char* e = getenv("TCCT_PW_FWD2"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (on < 0) on = 1;
     return on == 1;
 }
 extern "C" int tcct_pw_fwd(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,

@@ -208,8 +208,7 @@ def attach(optimizer, model=None):
             for name, p in model.named_parameters():
                 p._tcct_bucket = bucket_of(name)
             optimizer.buckets = GradBuckets()
-            if os.environ.get('TCCT_DP_MARKS', '1') != '0':      # =0: buckets still leave separately, but all of them in step() (A/B timing)
-                ops.set_grad_mark_listener(optimizer.buckets.on_mark)
+            ops.set_grad_mark_listener(optimizer.buckets.on_mark)
             optimizer.allreduce_mode = f'{N_BUCKETS} buckets (decoder | deep encoder levels | level 0 + stems) on a comm stream, overlapped with backward'
     return optimizer
 

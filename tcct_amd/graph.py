@@ -120,12 +120,7 @@ class GraphedTrainStep:
             self.s_img, self.s_lab = img.clone(), lab.clone()
             self.stream.wait_stream(cur)
             g = torch.cuda.CUDAGraph()
-            kw = {}
-            if os.environ.get('TCCT_GRAPH_ERRMODE'):            # experiments on the late-capture crash
-                kw['capture_error_mode'] = os.environ['TCCT_GRAPH_ERRMODE']
-            if os.environ.get('TCCT_GRAPH_SHARED_POOL') == '1':
-                kw['pool'] = _shared_pool()
-            with torch.cuda.graph(g, stream=self.stream, **kw):
+            with torch.cuda.graph(g, stream=self.stream):
                 self.s_loss = k.train_step(self.s_img, self.s_lab)
             k.udh_out = None
             k.optimG._step -= 1         # the Python side of step() ran once while capturing; the replay below is the real step

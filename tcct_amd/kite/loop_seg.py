@@ -37,7 +37,7 @@ class KiteSeg(KiteBack):
         self.use_graph = os.environ.get('TCCT_GRAPH', '0') == '1'
         from .. import dist as tdist
         self.world, self.rank = (tdist.world_rank() if args.pl else (1, 0))
-        self.fuse_aux_loss = os.environ.get('TCCT_FUSE_AUX', '1') != '0'
+        self.fuse_aux_loss = True
         # --udh: the loss reads `feats` (norm_add of three decoder maps) every step -> evaluated inside the forward, with the aux heads'
         # gradients folded into its backward kernels (FTC.eager_feats; TCCT_EAGER_FEATS=0: lazy evaluation + autograd accumulation, `feats` still
         # differentiable).  Without --udh nothing differentiates `feats`: the aux heads may be composed through t32x (FTC.compose_heads).

@@ -64,7 +64,7 @@ ZERO = _ZeroPool()
 # small launch per convolution per step (39 x ~5 us on the critical stream).  Convolutions seen during a pooled step are remembered; from the
 # next step on begin_step() re-packs ALL of them with one launch (the optimizer has just changed the weights) and the forward pass picks its
 # pack out of the cache.  TCCT_PACK_ALL=0 restores the per-call launches.
-PACK_ALL = os.environ.get('TCCT_PACK_ALL', '1') != '0'
+PACK_ALL = True
 # ent: id(weight) -> [weakref(weight), pack buffer, (KH, KW), data_ptr, step last looked up].  Entries hold NO strong reference to the weight:
 # a dead model's entries disappear at the next begin_step(), as do entries no convolution asked for during the previous step.
 # frozen / keep: once a hipGraph has captured a step whose pack launch reads a descriptor table, that table and the pack buffers it names are kept
@@ -200,9 +200,9 @@ def end_step():
 # latency-bound weight gradients of the coarse levels overlap it.  TCCT_STREAMS=0 disables.
 _WGRAD_USED = {}
 _WGRAD_KEEP = []
-DW_WGRAD_SIDE = os.environ.get('TCCT_DW_WGRAD_SIDE', '1') != '0'
-_WGRAD_FRESH_EVENT = os.environ.get('TCCT_WGRAD_FRESH_EVENT', '0') == '1'          # experiment on the late-capture crash
-_WGRAD_RECORD_STREAM = os.environ.get('TCCT_WGRAD_RECORD_STREAM', '0') == '1'      # the old behaviour, kept for A/B measurements only
+DW_WGRAD_SIDE = True
+_WGRAD_FRESH_EVENT = False          # experiment on the late-capture crash
+_WGRAD_RECORD_STREAM = False      # the old behaviour, kept for A/B measurements only
 
 
 def fresh_stream(device=None, avoid=()):
@@ -312,7 +312,7 @@ def _mfma32_ok(in_dt, out_dt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
             and 2 * padh == KH - 1 and 2 * padw == KW - 1 and KH * KW > 1 and (KH == 1 or KW == 1 or (KH == 3 and KW == 3)))
 
 
-F32_MFMA = os.environ.get('TCCT_F32_MFMA', '1') != '0'        # =0: the VALU convolution for the fp32 parity mode (A/B timing, bisecting)
+F32_MFMA = True        # False: the VALU convolution for the fp32 parity mode (A/B timing, bisecting)
 # fp32 MFMA for the pointwise forward / input gradient / weight gradient.  The FORWARD stays on the sequential VALU kernel in the parity mode: on
 # the formula-weight fixtures some BatchNorm channels at the 2x2 / 4x4 levels have a batch variance at fp32 rounding level, and the MFMA summation
 # order (exact to 2-5e-7 against fp64, like the VALU kernel's) moved rstd enough to scale the whole CNN level-0 gradient by 0.93 -- outside the
@@ -386,8 +386,8 @@ def _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, trans
 # the separate input-gradient / weight-gradient kernels at level 0, and inside the step it gains nothing (29.3 vs 29.3 ms, same box): the
 # separate weight gradient runs on the side stream beside the input-gradient chain, the fused kernel sits on the critical path and is
 # bound by the latency of its one 8-wave block per CU (111 KB of LDS), not by HBM.  TCCT_FUSED_CONV_BWD=1 enables it.
-FUSED_CONV_BWD = os.environ.get('TCCT_FUSED_CONV_BWD', '0') == '1'
-FUSED_PW_BWD = os.environ.get('TCCT_FUSED_PW_BWD', '1') != '0'        # =0: separate input-gradient / weight-gradient kernels (A/B timing)
+FUSED_CONV_BWD = False
+FUSED_PW_BWD = True        # False: separate input-gradient / weight-gradient kernels (A/B timing)
 
 
 def _pw_bwd_ok(x, dy, Cin, Cin_w, Cout, KH, KW, stride, padh, padw):
@@ -877,7 +877,7 @@ class _LinearResidual(torch.autograd.Function):
         return dx, _ret(dw, wsrc), _ret(db, bsrc), dy, None
 
 
-MLP_GELU_FUSE = os.environ.get('TCCT_MLP_GELU', '1') != '0'         # =0: GELU as its own pass between fc1 and fc2 (round-3 form; A/B timing)
+MLP_GELU_FUSE = True         # False: GELU as its own pass between fc1 and fc2 (round-3 form; A/B timing)
 
 
 class _GeluLinearResidual(torch.autograd.Function):
@@ -957,7 +957,7 @@ class _MlpTail(torch.autograd.Function):
         return (dt1, None, None, _ret(dg2, g2p), _ret(dbeta2, b2p), _ret(dw1, w1s), _ret(db1, bias1p), _ret(dw2, w2s), _ret(db2, bias2p), None)
 
 
-MLP_TAIL_FUSE = os.environ.get('TCCT_MLP_TAIL', '1') != '0'      # =0: LayerNorm2 keeps its own backward pass (A/B timing)
+MLP_TAIL_FUSE = True      # False: LayerNorm2 keeps its own backward pass (A/B timing)
 
 
 def mlp_tail_ok(t1, cur2, w1, bias1, w2, bias2):
@@ -1102,7 +1102,7 @@ class _UpSkipConv(torch.autograd.Function):
         return dy, dskip, _ret(dw, wsrc), _ret(db, bsrc), None, None
 
 
-DY2_FUSE = os.environ.get('TCCT_DY2', '1') != '0'      # =0: the decoder blocks add their two output gradients in a separate pass (A/B timing)
+DY2_FUSE = True      # False: the decoder blocks add their two output gradients in a separate pass (A/B timing)
 
 
 def up_skip_conv(y, skip, w, bias, align_corners=True, want_plain=True):
@@ -1117,7 +1117,7 @@ def up_skip_conv(y, skip, w, bias, align_corners=True, want_plain=True):
     return (d if want_plain else None), s_
 
 
-TAIL_COMPOSE = os.environ.get('TCCT_TAIL_COMPOSE', '1') != '0'      # =0: resize + add, post convolution (+ sum), t324 as three kernels (round-3 form; A/B timing)
+TAIL_COMPOSE = True      # False: resize + add, post convolution (+ sum), t324 as three kernels (round-3 form; A/B timing)
 
 
 class _UpSkipConvT32(torch.autograd.Function):
@@ -1283,8 +1283,8 @@ class _UpSkipConvT32AuxLow(torch.autograd.Function):
         return (dy, dskip) + tuple(_ret(o, p) for o, p in zip(outs, params)) + (None,)
 
 
-HEAD_UPADD = os.environ.get('TCCT_HEAD_UPADD', '1') != '0'       # =0: the resized low-resolution product is added by its own pass (A/B timing)
-TAIL_AUX_LOW = os.environ.get('TCCT_TAIL_AUX_LOW', '1') != '0'   # =0: the composed head reads the resized 32-channel tensor (the first round-4 form; A/B timing)
+HEAD_UPADD = True       # False: the resized low-resolution product is added by its own pass (A/B timing)
+TAIL_AUX_LOW = True   # False: the composed head reads the resized 32-channel tensor (the first round-4 form; A/B timing)
 
 
 def up_skip_conv_t32_aux_low(y, skip, w1, b1, w2, b2, w3, b3, align_corners=True):
@@ -1301,7 +1301,7 @@ def up_skip_conv_t32_from_y(y, skip, w1, b1, w2, b2, align_corners=True):
     return up_skip_conv_t32_from_v(v, skip, w1, b1, w2, b2)
 
 
-TAIL_AUX = os.environ.get('TCCT_TAIL_AUX', '1') != '0'       # =0: the composed tail stops at g0, aux0 stays its own kernels (A/B timing)
+TAIL_AUX = True       # False: the composed tail stops at g0, aux0 stays its own kernels (A/B timing)
 
 
 def up_skip_conv_t32_aux_ok(y, skip, w1, b1, w2, b2, w3, b3):
@@ -1362,7 +1362,7 @@ class _HeadThroughT32(torch.autograd.Function):
         return (ds,) + tuple(_ret(o, p) for o, p in zip(outs, ctx.params))
 
 
-HEAD_COMPOSE = os.environ.get('TCCT_HEAD_COMPOSE', '1') != '0'       # =0: t32x and aux_i stay two convolutions at levels 1-3 (A/B timing)
+HEAD_COMPOSE = True       # False: t32x and aux_i stay two convolutions at levels 1-3 (A/B timing)
 
 
 def head_through_t32_ok(s, wt, bt, wa, ba):
@@ -1464,7 +1464,7 @@ def im2col3x3_c3(x4, stride=1):
     return out
 
 
-C3_DIRECT = os.environ.get('TCCT_C3_DIRECT', '1') != '0'       # =0: im2col + pointwise GEMM for the 3-channel first layers (A/B timing)
+C3_DIRECT = True       # False: im2col + pointwise GEMM for the 3-channel first layers (A/B timing)
 
 
 class _ConvC3(torch.autograd.Function):
@@ -1533,7 +1533,7 @@ def conv3x3_c3(x4, w, bias, stride=1, stats_pre=None, infer_bn=None, post_act=No
     return conv2d(im2col3x3_c3(x4, stride), w2.view(w.shape[0], 32, 1, 1), bias, stats_pre=stats_pre)
 
 
-C3_BN_FUSE = os.environ.get('TCCT_C3_BN', '1') != '0'       # =0: convolution (+ statistics) and BatchNorm as separate nodes, the round-3 form (A/B timing)
+C3_BN_FUSE = True       # False: convolution (+ statistics) and BatchNorm as separate nodes, the round-3 form (A/B timing)
 
 
 class _ConvC3BN(torch.autograd.Function):
@@ -1583,7 +1583,7 @@ class _ConvC3BN(torch.autograd.Function):
         return None, _ret(dw, w), _ret(dbias, bias), _ret(dg, gamma), _ret(db_, beta), None, None, None, None, None, None, None
 
 
-C3_ONEPASS = os.environ.get('TCCT_C3_ONEPASS', '1') != '0'      # =0: BatchNorm reduction and weight gradient of the first layers as two passes over dz (A/B timing)
+C3_ONEPASS = True      # False: BatchNorm reduction and weight gradient of the first layers as two passes over dz (A/B timing)
 
 
 def conv3x3_c3_bn_ok(x4, w, bn_training, post_act):
@@ -1755,8 +1755,8 @@ class _BatchNorm(torch.autograd.Function):
 # 1x1 convolution CONSUMES a BatchNorm's output as the last contributor to its gradient, the same kernel accumulates that BatchNorm's two
 # backward sums in its dx epilogue (`BnLink`): the backward reduce pass disappears too (2 passes -> 1 extra read).  TCCT_BN_FUSE=0 restores
 # the separate kernels (A/B timing, bisecting).
-BN_FUSE = os.environ.get('TCCT_BN_FUSE', '1') != '0'
-BN_FUSE_RED = os.environ.get('TCCT_BN_RED', '1') != '0'       # =0: keep the separate reduction kernels (A/B timing of the epilogue form)
+BN_FUSE = True
+BN_FUSE_RED = True       # False: keep the separate reduction kernels (A/B timing of the epilogue form)
 
 
 class BnLink:
@@ -1881,8 +1881,8 @@ class _Affine2Add(torch.autograd.Function):
         return dz, None, dz, None, None, None
 
 
-TRAN_RED2 = os.environ.get('TCCT_TRAN_RED2', '1') != '0'      # =0: the two fused BatchNorms keep separate backward reduction passes (A/B timing)
-TRAN_FUSE = os.environ.get('TCCT_TRAN_FUSE', '1') != '0'      # =0: the two BatchNorms of the encoder fusion keep their own normalisation passes (A/B timing)
+TRAN_RED2 = True      # False: the two fused BatchNorms keep separate backward reduction passes (A/B timing)
+TRAN_FUSE = True      # False: the two BatchNorms of the encoder fusion keep their own normalisation passes (A/B timing)
 
 
 def affine2_add(y1, link1, y2, link2):
@@ -1892,9 +1892,9 @@ def affine2_add(y1, link1, y2, link2):
     return _Affine2Add.apply(y1, link1.ab, y2, link2.ab, link1, link2)
 
 
-BN_RED_DW = os.environ.get('TCCT_BN_RED_DW', '1') != '0'      # =0: the BatchNorms in front of the depthwise convolutions keep their backward reduction pass (A/B)
-BN_DEFER_DW = os.environ.get('TCCT_BN_DEFER_DW', '1') != '0'  # =0: the BatchNorms in front of the depthwise convolutions keep their normalisation pass (A/B timing)
-BN_DEFER = os.environ.get('TCCT_BN_DEFER', '1') != '0'        # =0: InvRes.norm keeps its own normalisation pass (round-3 form; A/B timing)
+BN_RED_DW = True      # False: the BatchNorms in front of the depthwise convolutions keep their backward reduction pass (A/B)
+BN_DEFER_DW = True  # False: the BatchNorms in front of the depthwise convolutions keep their normalisation pass (A/B timing)
+BN_DEFER = True        # False: InvRes.norm keeps its own normalisation pass (round-3 form; A/B timing)
 
 
 class _BatchNormDeferred(torch.autograd.Function):
@@ -1997,7 +1997,7 @@ def pw_conv_bn(x, w, bias, bn, post_act=None, residual=None, fork=False, x2=None
     return out
 
 
-BN_POOL_FUSE = os.environ.get('TCCT_BN_POOL', '1') != '0'      # =0: BatchNorm pass, then the pooling pass (A/B timing)
+BN_POOL_FUSE = True      # False: BatchNorm pass, then the pooling pass (A/B timing)
 
 
 class _BnPoolFork(torch.autograd.Function):
@@ -2453,7 +2453,7 @@ class _LnMetaPoolResidualLn(torch.autograd.Function):
         return dt, _ret(dg1, g1), _ret(db1, b1), None, None, _ret(dg2, g2), _ret(db2, b2), None
 
 
-LN_POOL_FUSE = os.environ.get('TCCT_LN_POOL', '1') != '0'       # =0: LayerNorm and the token mixer stay separate kernels (A/B timing)
+LN_POOL_FUSE = True       # False: LayerNorm and the token mixer stay separate kernels (A/B timing)
 
 
 def ln_metapool_residual_ok(t, gamma, beta):
@@ -2466,7 +2466,7 @@ def ln_metapool_residual(t, gamma, beta, eps=1e-6, scale=None):
     return _LnMetaPoolResidual.apply(t, gamma, beta, float(eps), scale)
 
 
-LN_POOL_LN2 = os.environ.get('TCCT_LN_POOL_LN2', '1') != '0'       # =0: the second LayerNorm stays its own forward pass (A/B timing)
+LN_POOL_LN2 = True       # False: the second LayerNorm stays its own forward pass (A/B timing)
 
 
 def ln_metapool_residual_ln(t, g1, b1, eps1, scale, g2, b2, eps2):
@@ -2678,7 +2678,7 @@ def l2norm(x, eps=1e-12):
 # on the same feats) arrives as a dense tensor without the FPL part: every recipe is therefore ALSO filed under its producer (`pending`), and a
 # producer whose incoming gradient is not the single placeholder materialises the pending recipes (tcct_fpl_backward) and adds them.  A feats tensor
 # with hooks / retain_grad (somebody wants to SEE the gradient) never takes the lazy path.  TCCT_FPL_LAZY_GRAD=0 restores the dense tensor everywhere.
-FPL_LAZY_GRAD = os.environ.get('TCCT_FPL_LAZY_GRAD', '1') != '0'
+FPL_LAZY_GRAD = True
 _FPL_LAZY = {'producers': set(), 'grads': {}, 'pending': {}}
 
 
@@ -2885,7 +2885,7 @@ class _DeepSupervisionDice(torch.autograd.Function):
         return (d0, None, None, None, None) + tuple(dl)
 
 
-DS_DICE_FUSE = os.environ.get('TCCT_DS_DICE', '1') != '0'        # =0: one criterion node per head + torch scalar arithmetic (A/B timing)
+DS_DICE_FUSE = True        # False: one criterion node per head + torch scalar arithmetic (A/B timing)
 
 
 def deep_supervision_dice_ok(outs, coff):
