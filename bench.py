@@ -45,6 +45,8 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--roofline-only', action='store_true', help='only run the dominant-kernel timing loop (for rocprofv3)')
+    p.add_argument('--wgrad-mode', type=int, default=0, help='A/B arms of the weight-gradient kernels (tcct_conv32_wgrad_mode: 0 default, 4 = shifted lines for 1xK / Kx1)')
+    p.add_argument('--conv-mode', type=int, default=0, help='A/B arms of the 3x3 forward kernels (tcct_conv32_fwd_mode: 0 default, 1 = tiled)')
     return p.parse_args()
 
 
@@ -409,6 +411,10 @@ def main():
     torch.manual_seed(2023 + rank)          # per-rank noise stream (DropPath masks, Gumbel / jitter draws): seed = base + rank, SURVEY 8(e)
     if not stub:
         torch.cuda.manual_seed_all(2023 + rank)
+    if not stub and (a.wgrad_mode or a.conv_mode):
+        from tcct_amd._lib import lib as _lib
+        _lib.conv32_wgrad_mode(a.wgrad_mode)
+        _lib.conv32_fwd_mode(a.conv_mode)
     if a.roofline_only:
         print(json.dumps({'roofline': dominant_kernel_roofline(a)}), file=out_stream, flush=True)
         return

@@ -1821,13 +1821,176 @@ k_conv32_wgrad_line(const bf16* __restrict__ x, const bf16* __restrict__ dy, flo
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 1 x K / K x 1 weight gradient, wave-private row streams, ONE wave per SIMD (round 5)
+// The row-stream structure of k_conv32_wgrad33_stream for the cross convolutions (reference nets/tcct.py:814-816).  All K accumulators (K x 16 registers: 208 for
+// K = 13) stay in ONE wave, so the kernel runs one wave per SIMD (launch bounds (256, 1): the 512-register budget) -- the form DESIGN 3b (round 4) left untried
+// after the wave-pair split (7 + 6 taps on two waves that stream the same strip twice) had lost to the shifted lines.  A wave owns a 16-pixel strip.
+//   1 x K: ring row = 16 + K - 1 x pixels + 16 dy pixels (three DMA pieces); the x operand of tap t is ONE transposing read of the row at pixel offset t
+//          (the row sits in LDS once; the shifted-line kernel's register surgery is not needed when nothing but this wave's reads competes for its LDS port);
+//   K x 1: ring row = 16 x pixels + 16 dy pixels (two DMA pieces); x row b meets the dy fragments of rows b - t + (K - 1) / 2, kept in a register window
+//          of the last K dy rows (K x 4 registers), body unrolled K-fold so that window positions are compile-time; ring slot by run-time index.
+// 14 / 18 ring rows per wave, all but two in flight (one wave per SIMD has nobody to hide its latency behind: the depth does; 12 rows: 0.224 / 0.210 ms).  Same products and fp32 accumulation as
+// the other weight-gradient kernels, summed in another order: bit-compatible up to that (tests/test_kernels_gpu.py).
+#define WK_T 256
+template <int K, bool VERT>
+__global__ void __launch_bounds__(WK_T, 1)
+k_conv32_wgradk_stream(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
+                       int N, int H, int W, int strips, int run) {
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int XP = VERT ? 16 : 16 + K - 1;                  // x pixels per ring row
+    constexpr int ROWB = (XP + 16) * 64;
+    constexpr int NPIECE = VERT ? 2 : 3;
+    constexpr int WK_R = 8, WK_P = 6;      // ring rows per wave / rows in flight (64 / 88 KB of LDS per block: the other streams' kernels still fit on the CU)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    unsigned char* ring = smem + wave * (WK_R * ROWB);
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)ring);
+    const unsigned char* xb = tr_lane_base(ring, lane);
+    f32x16 acc[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    float bsum = 0.f;
+    const int sgroups = (strips + 3) >> 2;
+    const int64_t total = (int64_t)N * sgroups * H;
+    int64_t cur = (int64_t)blockIdx.x * run;
+    const int64_t end = cur + run < total ? cur + run : total;
+    const uint32_t img_bytes = (uint32_t)H * (uint32_t)W * 64u;
+    const uint32_t rowb = (uint32_t)W * 64u;
+    const int px = lane >> 2, c = lane & 3;
+    while (cur < end) {
+        const int sidx = (int)(cur / H), r0 = (int)(cur - (int64_t)sidx * H);
+        const int n = sidx / sgroups, s = (sidx - n * sgroups) * 4 + wave;
+        const int left = (int)(end - cur);
+        const int L = __builtin_amdgcn_readfirstlane(H - r0 < left ? H - r0 : left);      // dy rows r0 .. r0 + L - 1
+        if (s >= strips) { cur += L; continue; }
+        const int w0 = s * 16;
+        const u32x4 rx = make_rsrc_words(x + (int64_t)n * H * W * 32, img_bytes);
+        const u32x4 rd = make_rsrc_words(dy + (int64_t)n * H * W * 32, img_bytes);
+        const int cd = w0 + px;
+        const uint32_t od = (cd < W) ? (uint32_t)(cd * 64 + c * 16) : OOB_OFF;
+        if constexpr (!VERT) {
+            // ring x pixel i <-> image column w0 - PAD + i; tap t pairs dy pixel j with x pixel j + t
+            const int cx1 = w0 - PAD + px, cx2 = cx1 + 16;
+            const uint32_t ox1 = (cx1 >= 0 && cx1 < W) ? (uint32_t)(cx1 * 64 + c * 16) : OOB_OFF;
+            const uint32_t ox2 = (px < XP - 16 && cx2 >= 0 && cx2 < W) ? (uint32_t)(cx2 * 64 + c * 16) : OOB_OFF;
+            const uint32_t row0 = (uint32_t)r0 * rowb;
+            auto issue = [&](int a, int slot) {
+                const uint32_t ro = row0 + (uint32_t)a * rowb;
+                const bool in = a < L;
+                const uint32_t base = ring_lds + (uint32_t)(slot * ROWB);
+                lds_dma16(rx, in ? ox1 + ro : OOB_OFF, base);
+                if (lane < 4 * (XP - 16)) lds_dma16(rx, in ? ox2 + ro : OOB_OFF, base + 1024u);
+                lds_dma16(rd, in ? od + ro : OOB_OFF, base + (uint32_t)(XP * 64));
+            };
+#pragma unroll
+            for (int a = 0; a < WK_P; ++a) issue(a, a);
+            const int groups = (L + WK_R - 1) / WK_R;
+            for (int g = 0; g < groups; ++g) {
+#pragma unroll
+                for (int j = 0; j < WK_R; ++j) {
+                    const int a = g * WK_R + j;
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPIECE * (WK_P - 1)) : "memory");         // row a has landed
+                    const unsigned char* row = xb + j * ROWB;
+                    const bf16x8 D = tr_load8p(row + XP * 64);
+                    bf16x8 X0 = tr_load8p(row), X1 = tr_load8p(row + 64);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bsum = dot2_ones(D, q, bsum);
+#pragma unroll
+                    for (int t = 0; t < K; ++t) {
+                        bf16x8 X2 = X1;
+                        if (t + 2 < K) X2 = tr_load8p(row + (t + 2) * 64);          // two operands ahead of the matrix pipe
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(D, X0, acc[t], 0, 0, 0);
+                        X0 = X1; X1 = X2;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(a + WK_P, (j + WK_P) % WK_R);                 // rows a + 1 .. a + WK_P - 1 are in flight in the slots behind this one; two slots stay free
+                }
+            }
+        } else {
+            // x halo row a of the segment = image row r0 - PAD + a (a = 0 .. L + K - 2); dy row a = image row r0 + a rides in the same ring row
+            const int cx = w0 + px;
+            const uint32_t ox = (cx < W) ? (uint32_t)(cx * 64 + c * 16) : OOB_OFF;
+            const int nh = L + K - 1;
+            int slot_i = 0, slot_d = WK_P % WK_R;
+            auto issue = [&](int a, int slot) {
+                const int xr = r0 - PAD + a;
+                const bool xin = a < nh && xr >= 0 && xr < H, din = a < L;
+                const uint32_t base = ring_lds + (uint32_t)(slot * ROWB);
+                lds_dma16(rx, xin ? ox + (uint32_t)xr * rowb : OOB_OFF, base);
+                lds_dma16(rd, din ? od + (uint32_t)(r0 + a) * rowb : OOB_OFF, base + 1024u);
+            };
+#pragma unroll
+            for (int a = 0; a < WK_P; ++a) issue(a, a);
+            bf16x8 Dw[K];
+#pragma unroll
+            for (int t = 0; t < K; ++t)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) Dw[t][k] = (__bf16)0.f;
+            const int groups = (nh + K - 1) / K;
+            for (int g = 0; g < groups; ++g) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int a = g * K + j;
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPIECE * (WK_P - 1)) : "memory");
+                    const unsigned char* row = xb + slot_i * ROWB;
+                    const bf16x8 X = tr_load8p(row);
+                    Dw[j] = tr_load8p(row + 1024);                      // dy row a (zeros behind the segment)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bsum = dot2_ones(Dw[j], q, bsum);
+#pragma unroll
+                    for (int t = 0; t < K; ++t)                         // x row a is tap row t of dy row a - t: window position (j - t) mod K
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Dw[(j + K - t) % K], X, acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(a + WK_P, slot_d);
+                    slot_i = slot_i + 1 == WK_R ? 0 : slot_i + 1;
+                    slot_d = slot_d + 1 == WK_R ? 0 : slot_d + 1;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cur += L;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);                    // [K][32 co][32 ci]
+    for (int turn = 0; turn < WK_T / 64; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int t = 0; t < K; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int co = (k & 3) + 8 * (k >> 2) + 4 * hh;
+                    float* dst = &red[t * 1024 + co * 32 + r];
+                    *dst = turn == 0 ? acc[t][k] : *dst + acc[t][k];
+                }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < K * 1024; i += WK_T) {
+        const int tap = i % K, cc = i / K;
+        atomicAdd(&dw[(int64_t)cc * K + tap], red[tap * 1024 + cc]);
+    }
+    __syncthreads();
+    if (dbias) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lane < 32) red[wave * 32 + r] = bsum;
+        __syncthreads();
+        if (tid < 32) atomicAdd(&dbias[tid], red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]);
+    }
+}
+
 static int g_wgrad_mode = -1;
-/* 0 (default): plain 3x3 convolutions take the rolling-row kernel; 1: the generic register-staged kernel for every shape (the comparison arm of the
- * bit-compatibility test; TCCT_WGRAD_GENERIC=1 selects it for a whole run).  Returns the previous mode; mode < 0 only queries. */
+/* 0 (default): the fastest kernel per shape (3x3: row streams at levels 0-1, rolling rows below; 1 x K / K x 1 with 13 / 11 taps: one-wave-per-SIMD row streams
+ * at levels 0-1, shifted lines below); 1: the generic register-staged kernel for every shape (the comparison arm of the bit-compatibility tests); 2: the 3x3 row
+ * streams at every size; 3: the 1 x K / K x 1 row streams at every size; 4: the shifted-line kernel instead of them (A/B).  Returns the previous mode; mode < 0
+ * only queries. */
 extern "C" int64_t tcct_conv32_wgrad_mode(int mode) {
     if (g_wgrad_mode < 0) g_wgrad_mode = 0;
     const int prev = g_wgrad_mode;
-    if (mode >= 0 && mode <= 2) g_wgrad_mode = mode;
+    if (mode >= 0 && mode <= 4) g_wgrad_mode = mode;
     return prev;
 }
 /* dw OIHW fp32 [32,32,KH,KW] and dbias fp32 [32] (nullable) are overwritten. */
@@ -1872,12 +2035,13 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
     }
     if (g_wgrad_mode < 0) (void)tcct_conv32_wgrad_mode(-1);
     constexpr int stream_on = 1;
-    if ((g_wgrad_mode == 2 || (g_wgrad_mode == 0 && stream_on)) && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {
+    const int m33 = g_wgrad_mode >= 3 ? 0 : g_wgrad_mode;           // modes 3 / 4 only concern the cross convolutions
+    if ((m33 == 2 || (m33 == 0 && stream_on)) && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {
         const int strips = (W + 15) / 16;
         const int64_t rows = (int64_t)N * ((strips + 3) / 4) * H;            // rows of strip groups (four adjacent strips, one per wave of a block)
         int blocks = 512;
         int64_t run = (rows + blocks - 1) / blocks;
-        if (g_wgrad_mode == 2 || run >= WS_MIN_RUN) {
+        if (m33 == 2 || run >= WS_MIN_RUN) {
             if (run < 12) run = 12;                 // small maps: fewer, longer runs (the pipeline fill is 7 rows)
             blocks = (int)((rows + run - 1) / run);
             constexpr size_t ldss = (size_t)(WS_T / 64) * WS_R * WS_ROWB;
@@ -1887,13 +2051,37 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
             TCCT_LAUNCH_OK();
         }
     }
-    if ((g_wgrad_mode == 0 || g_wgrad_mode == 2) && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {      // plain 3x3: rolling rows, 6 waves x 2 blocks per CU
+    if ((m33 == 0 || m33 == 2) && sq && ldi == 32 && o_off == 0 && i_off == 0 && xo == 0 && dof == 0) {      // plain 3x3: rolling rows, 6 waves x 2 blocks per CU
         constexpr size_t lds4 = (size_t)18 * 34 * 64 + 16 * 32 * 64;
         static bool attr4 = false;
         if (!attr4) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad33_roll, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr4 = true; }
         hipLaunchKernelGGL(k_conv32_wgrad33_roll, dim3((unsigned)(nt < 512 ? nt : 512)), dim3(WR_T), lds4, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W,
                            tilesH, tilesW, (int)nt);
         TCCT_LAUNCH_OK();
+    }
+    // 1 x K / K x 1 with K = 13, 11 on maps whose waves get long runs (levels 0-1): all taps in one wave per SIMD (mode 3 forces it, mode 4 keeps the shifted lines)
+    if ((g_wgrad_mode == 0 || g_wgrad_mode == 3) && (KH == 1 || KW == 1) && (TAPS == 13 || TAPS == 11) && xs == 32 && ds == 32 && ldi == 32 && o_off == 0 && i_off == 0 &&
+        xo == 0 && dof == 0) {
+        const int strips = (W + 15) / 16;
+        const int64_t rows = (int64_t)N * ((strips + 3) / 4) * H;
+        int blocks = 256;                           // one block (four waves, one per SIMD) per CU
+        int64_t run = (rows + blocks - 1) / blocks;
+        if (g_wgrad_mode == 3 || run >= 96) {
+            if (run < 16) run = 16;
+            blocks = (int)((rows + run - 1) / run);
+#define WK_LAUNCH(KK, V)                                                                                                     \
+    do {                                                                                                                    \
+        constexpr size_t ring = (size_t)(WK_T / 64) * 8 * ((V ? 16 : 16 + KK - 1) + 16) * 64, redb = (size_t)KK * 4096;                                     \
+        constexpr size_t ldsk = ring > redb ? ring : redb;                                                                                                     \
+        static bool attr = false;                                                                                           \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_wgradk_stream<KK, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((k_conv32_wgradk_stream<KK, V>), dim3((unsigned)blocks), dim3(WK_T), ldsk, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W, strips, (int)run); \
+    } while (0)
+            if (TAPS == 13) { if (vert) WK_LAUNCH(13, true); else WK_LAUNCH(13, false); }
+            else { if (vert) WK_LAUNCH(11, true); else WK_LAUNCH(11, false); }
+#undef WK_LAUNCH
+            TCCT_LAUNCH_OK();
+        }
     }
     constexpr bool line_on = true;
     if (line_on && g_wgrad_mode != 1 && (KH == 1 || KW == 1) && (TAPS == 13 || TAPS == 11 || TAPS == 9) && xs == 32 && ds == 32 && ldi == 32 && o_off == 0 && i_off == 0 &&

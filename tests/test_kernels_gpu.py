@@ -106,11 +106,13 @@ def test_pointwise_forward_on_the_fp32_matrix_pipes(cfg, monkeypatch):
 
 @pytest.mark.parametrize('cfg', [(3, 3, 70, 130), (3, 3, 16, 33), (3, 3, 50, 69), (3, 3, 100, 138), (3, 3, 400, 552), (1, 13, 9, 200), (13, 1, 200, 9), (1, 11, 20, 150), (9, 1, 150, 20),
                                  (1, 13, 70, 300), (13, 1, 300, 70), (11, 1, 131, 19), (1, 9, 17, 129), (1, 13, 5, 7), (13, 1, 7, 5),
-                                 (1, 5, 8, 64), (7, 1, 33, 9), (1, 1, 19, 70), (3, 3, 3, 5)])
+                                 (1, 5, 8, 64), (7, 1, 33, 9), (1, 1, 19, 70), (3, 3, 3, 5), (1, 13, 400, 552), (13, 1, 400, 552), (1, 11, 1, 1), (11, 1, 40, 16),
+                                 (1, 11, 33, 97), (13, 1, 97, 33)])
 def test_conv32_weight_gradient_rolling_row_form_equals_the_generic_one(cfg):
     """tcct_conv32_wgrad_mode: the default kernels -- plain 3x3 convolutions: rolling rows (an x fragment per halo row against a register window of
     three dy fragments); 1 x K / K x 1 with K = 9, 11, 13: shifted lines (the K operands of a chunk cut out of two fragments in registers) -- and the
-    generic register-staged kernel (mode 1; every other shape takes it in both modes) give the same weight / bias gradient; both against torch's fp32 convolution backward of the same bf16 operands, partial tiles at every image edge"""
+    generic register-staged kernel (mode 1; every other shape takes it in both modes) give the same weight / bias gradient; both against torch's fp32 convolution backward of the same bf16 operands, partial tiles at every image edge.
+    Round 5: the 13- / 11-tap cross convolutions also as wave-private row streams with ALL accumulators in one wave per SIMD (mode 3; the default on the large maps)"""
     from tcct_amd._lib import lib
     KH, KW, H, W = cfg
     N = 3
@@ -123,7 +125,8 @@ def test_conv32_weight_gradient_rolling_row_form_equals_the_generic_one(cfg):
     outs = []
     prev = lib.conv32_wgrad_mode(-1)
     try:
-        for mode in ((1, 0, 2) if (KH, KW) == (3, 3) else (1, 0)):      # 1: generic register-staged kernel; 0: rolling rows (3x3) / shifted lines (1 x K, K x 1); 2: row streams (3x3)
+        # 1: generic register-staged kernel; 0: the default per shape; 2: row streams (3x3); 4: shifted lines and 3: one-wave-per-SIMD row streams (1 x K / K x 1, 13 / 11 taps)
+        for mode in ((1, 0, 2) if (KH, KW) == (3, 3) else ((1, 0, 4, 3) if KH * KW in (11, 13) else (1, 0))):
             lib.conv32_wgrad_mode(mode)
             dw = torch.full((32, 32, KH, KW), 7.0, device='cuda')
             db = torch.full((32,), 7.0, device='cuda')

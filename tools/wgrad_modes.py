@@ -20,7 +20,7 @@ def t(mode, iters=30):
     for _ in range(iters): lib.conv32_wgrad(x, dy, dw, db, B, H, W, KH, KW, KH // 2, KW // 2)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-modes = [1, 0, 2] if (KH, KW) == (3, 3) else [1, 0]          # 2: wave-private row streams (3x3)
+modes = [1, 0, 2] if (KH, KW) == (3, 3) else ([1, 4, 3] if KH * KW in (11, 13) else [1, 0])          # 2: row streams (3x3); 4: shifted lines, 3: one-wave-per-SIMD row streams (13 / 11 taps)
 for rep in range(3):
     print('  '.join(f'mode {m}: {t(m):.4f} ms' for m in modes), flush=True)
 lib.conv32_wgrad_mode(0)
