@@ -185,6 +185,20 @@ def dominant_kernel_roofline(a, iters=20):
         b5 = 3.0 * x1.numel() * 2
         others.append({'kernel': 'k_pw_bwd<2,4> (64->64 @L1; dx + dW + db in one pass)', 'ms_per_launch': round(t5, 4), 'algorithmic_bytes': int(b5),
                        'achieved': round(b5 / (t5 * 1e-3) / 1e9, 1), 'frac': round(b5 / (t5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        # round 5: conv3x3 -> conv3x3 of CrossCNNBlock.block12 as one launch (reads x, writes the intermediate and y: 3 tensors instead of 4) and the 13-tap
+        # weight gradients as one-wave-per-SIMD row streams (read x and dy)
+        midc = torch.empty_like(x)
+        t6 = timed(lambda: lib.conv32_chain33(x, wp, b, midc, wp, b, y, None, a.bs, a.height, Wp, None))
+        b6 = 3.0 * x.numel() * 2
+        others.append({'kernel': 'k_conv32_chain33<0> (3x3 -> 3x3 @L0 in one launch; algorithmic bytes = x + intermediate + y)', 'ms_per_launch': round(t6, 4),
+                       'algorithmic_bytes': int(b6), 'achieved': round(b6 / (t6 * 1e-3) / 1e9, 1), 'frac': round(b6 / (t6 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        del midc
+        for kh, kw, nm in ((1, 13, 'k_conv32_wgradk_stream<13,false> (1x13 weight gradient @L0)'), (13, 1, 'k_conv32_wgradk_stream<13,true> (13x1 weight gradient @L0)')):
+            dwk = torch.empty(32, 32, kh, kw, device='cuda')
+            t7 = timed(lambda: lib.conv32_wgrad(x, dy, dwk, db, a.bs, a.height, Wp, kh, kw, kh // 2, kw // 2))
+            b7 = 2.0 * x.numel() * 2
+            others.append({'kernel': nm, 'ms_per_launch': round(t7, 4), 'algorithmic_bytes': int(b7), 'achieved': round(b7 / (t7 * 1e-3) / 1e9, 1),
+                           'frac': round(b7 / (t7 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     if a.dtype == 'bf16' and ('fpl' in a.los or 'udh' in a.los or 'reg' in a.los):
         # the loss-side kernels of BASELINE configs[2..3] (algorithmic bytes = inputs read once + outputs written once)
         def entry(kernel, t, nbytes):
@@ -214,7 +228,12 @@ def dominant_kernel_roofline(a, iters=20):
             tf_ = timed(lambda: lib.fpl_select(x, labf, probf, Mf, 5, ws, cnt, bm, ps, 1))
             entry('tcct_fpl_select: radix multi-select of the bin boundaries (k_fs_hist x 13, k_fs_resolve x 7, k_fs_assign) + bin sums on MFMA (k_fs_binsum_mfma); '
                   'replaces rocPRIM radix_sort_pairs + the sorted gather', tf_, 2.0 * x.numel() + Mf * (1 + 4 + 1))
-            del g1, g2, i1, i2, labf, probf, ws, cnt, bm, ps
+            # the same on a TRAINED network's distribution: saturated, tie-heavy probabilities (most pixels at exactly 1.0, the rest spread): more radix
+            # levels have to be resolved before the boundaries separate
+            probt = torch.sigmoid(8.0 * torch.randn(Mf, device='cuda'))
+            tf2_ = timed(lambda: lib.fpl_select(x, labf, probt, Mf, 5, ws, cnt, bm, ps, 1))
+            entry('tcct_fpl_select on a trained-network distribution (prob = sigmoid(8 N(0,1)): saturated, tie-heavy)', tf2_, 2.0 * x.numel() + Mf * (1 + 4 + 1))
+            del g1, g2, i1, i2, labf, probf, probt, ws, cnt, bm, ps
     bytes_alg = 2.0 * x.numel() * x.element_size()
     ach, ach2 = bytes_alg / (ms * 1e-3) / 1e9, bytes_alg / (ms2 * 1e-3) / 1e9
     flops = 2.0 * 9 * 32 * 32 * a.bs * a.height * Wp

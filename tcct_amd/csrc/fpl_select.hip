@@ -15,11 +15,15 @@
 //   bin sums: the feature rows are read in PIXEL order (one coalesced pass; the sorted order forced a scattered 64-byte gather per pixel)
 //             with run-length accumulation in registers and LDS-private [class][bin][32] sums.
 // 4 probability bytes + ceil(log2 M / 8) index bytes = 7 levels at the bench shape; every launch has constant arguments (no host sync).
+// Round 5: ONE launch per level (was two histogram passes + a one-block resolve kernel: 13 + 7 launches): the block-private counters are 16 bits wide (a block
+// sees < 65536 pixels), so all 160 slots of five classes fit one pass, and the block that takes the LAST ticket of a level (atomic counter behind a
+// __threadfence) runs the resolve step itself, reading the merged histogram with agent-scope loads.
 #include "common.h"
 
 #define FS_MAXC 16
 #define FS_BINS 32
-#define FS_SLOTS 128            // slots histogrammed per pass of a level (128 x 256 counters x 4 B = 128 KB of LDS)
+#define FS_SLOTS 160            // slots histogrammed per pass of a level: 160 x 256 16-bit counters (two per LDS word) = 80 KB; 5 classes x 32 bins in ONE pass
+#define FS_BLOCK_PIX 60000      // pixels per block at most: a 16-bit LDS counter cannot overflow
 #define FS_TB 1024
 #define FS_RUN 32              // consecutive pixels per 8-lane group of the bin-sum pass
 
@@ -40,25 +44,44 @@ __device__ __forceinline__ unsigned long long fs_key(float p, uint32_t i, int ib
 }
 
 // one pass of level `level` over the slots [slot_lo, slot_lo + FS_SLOTS)
+__device__ void fs_resolve_body(int C, int level, int nlevels, int tb, FplState* __restrict__ st, uint32_t* __restrict__ hist);
+
 __global__ void __launch_bounds__(FS_TB) k_fs_hist(const uint8_t* __restrict__ lab, const float* __restrict__ prob, int64_t M, int C, int level,
-                                                   int ib, int tb, int slot_lo, const FplState* __restrict__ st, uint32_t* __restrict__ hist) {
+                                                   int ib, int tb, int passes, int nlevels, FplState* __restrict__ st, uint32_t* __restrict__ hist,
+                                                   uint32_t* __restrict__ tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* lh = reinterpret_cast<uint32_t*>(smem);                                   // [FS_SLOTS][256]
-    unsigned long long* sp = reinterpret_cast<unsigned long long*>(lh + FS_SLOTS * 256);   // [nslots] prefixes
+    uint32_t* lh = reinterpret_cast<uint32_t*>(smem);                                   // [FS_SLOTS][128]: two 16-bit counters per word
+    unsigned long long* sp = reinterpret_cast<unsigned long long*>(lh + FS_SLOTS * 128);   // [nslots] prefixes
     uint32_t* sb = reinterpret_cast<uint32_t*>(sp + FS_MAXC * FS_BINS);                 // [C + 1]
+    __shared__ uint32_t s_last;
     const int nslots = level == 0 ? C : (int)st->nslots;
-    if (slot_lo >= nslots) return;                     // block-uniform: nothing left to count at this level
-    for (int i = threadIdx.x; i < FS_SLOTS * 256; i += FS_TB) lh[i] = 0;
+    const int pass = blockIdx.y, slot_lo = pass * FS_SLOTS;
+    const bool counting = slot_lo < nslots;            // block-uniform: a pass with nothing left to count only takes its ticket
+    if (counting) {
+    for (int i = threadIdx.x; i < FS_SLOTS * 128; i += FS_TB) lh[i] = 0;
     if (level > 0) {
         for (int i = threadIdx.x; i < nslots; i += FS_TB) sp[i] = st->slot_prefix[i];
         if (threadIdx.x <= C) sb[threadIdx.x] = st->slot_base[threadIdx.x];
     }
     __syncthreads();
     const int sh_pre = tb - 8 * level, sh_dig = tb - 8 * (level + 1);
-    for (int64_t i = (int64_t)blockIdx.x * FS_TB + threadIdx.x; i < M; i += (int64_t)gridDim.x * FS_TB) {
-        const int c = lab[i];
+    // four pixels per thread and round, their eight loads issued together: one dependent load pair per round (27 rounds per block at the bench shape) made
+    // the pass latency-bound (~40 us per level for 35 MB)
+    const int64_t stride = (int64_t)gridDim.x * FS_TB;
+    for (int64_t base = (int64_t)blockIdx.x * FS_TB; base < M; base += 4 * stride) {
+        int cq[4]; float pq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t iu = base + u * stride + threadIdx.x;
+            cq[u] = iu < M ? (int)lab[iu] : 255;
+            pq[u] = iu < M ? prob[iu] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * stride + threadIdx.x;
+        const int c = cq[u];
         if (c >= C) continue;
-        const unsigned long long key = fs_key(prob[i], (uint32_t)i, ib);
+        const unsigned long long key = fs_key(pq[u], (uint32_t)i, ib);
         int s;
         if (level == 0) s = c;
         else {
@@ -78,19 +101,38 @@ __global__ void __launch_bounds__(FS_TB) k_fs_hist(const uint8_t* __restrict__ l
             const int lead = __ffsll((long long)live) - 1;
             const int cl = __shfl(ci, lead, 64);
             const unsigned long long same = __ballot(ci == cl);
-            if ((int)(threadIdx.x & 63) == lead) atomicAdd(&lh[cl], (uint32_t)__popcll(same));
+            if ((int)(threadIdx.x & 63) == lead) atomicAdd(&lh[cl >> 1], (uint32_t)__popcll(same) << (16 * (cl & 1)));
             if (ci == cl) ci = -1;
         }
-        if (ci >= 0) atomicAdd(&lh[ci], 1u);
+        if (ci >= 0) atomicAdd(&lh[ci >> 1], 1u << (16 * (ci & 1)));
+        }
     }
     __syncthreads();
-    const int nloc = min(FS_SLOTS, nslots - slot_lo) * 256;
-    for (int i = threadIdx.x; i < nloc; i += FS_TB)
-        if (lh[i]) atomicAdd(&hist[(size_t)slot_lo * 256 + i], lh[i]);
+    const int nloc = min(FS_SLOTS, nslots - slot_lo) * 128;
+    // every block merges the same counters and all blocks get here at about the same time: each starts somewhere else (same-address global atomics serialise:
+    // level 2 of the bench distribution -- ~40 K busy counters, 256 adders each -- took 140 us of a 55 us average)
+    const int rot = nloc > 0 ? (int)(((unsigned)blockIdx.x * 2654435761u) % (unsigned)nloc) & ~63 : 0;
+    for (int k = threadIdx.x; k < nloc; k += FS_TB) {
+        int i = k + rot;
+        if (i >= nloc) i -= nloc;
+        const uint32_t v = lh[i];
+        if (v & 0xffffu) atomicAdd(&hist[(size_t)slot_lo * 256 + 2 * i], v & 0xffffu);
+        if (v >> 16) atomicAdd(&hist[(size_t)slot_lo * 256 + 2 * i + 1], v >> 16);
+    }
+    }
+    // The block that takes the last ticket of this level has every other block's counts behind it: it walks the boundaries one digit down.  Ordering: the
+    // histogram atomics execute at the memory side; a wave's `s_waitcnt vmcnt(0)` returns when they have been acknowledged, the barrier collects the waves,
+    // then ONE lane takes the ticket.  (__threadfence() here -- an L2 write-back + invalidate per wave, 4096 of them per launch -- made the whole select
+    // 1.08 ms instead of 0.69.)  The last block reads counters that no L2 has cached during this kernel (only atomics touched them): plain loads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&tickets[level], 1u) == (uint32_t)(gridDim.x * gridDim.y) - 1u ? 1u : 0u;
+    __syncthreads();
+    if (s_last) fs_resolve_body(C, level, nlevels, tb, st, hist);
 }
 
-// one block: walk every unresolved boundary one byte down, build the slot list of the next level, clear the histogram for it
-__global__ void __launch_bounds__(FS_TB) k_fs_resolve(int C, int level, int nlevels, int tb, FplState* __restrict__ st, uint32_t* __restrict__ hist) {
+// one block (the last one of a level's histogram launch): walk every unresolved boundary one byte down, build the slot list of the next level, clear the histogram for it
+__device__ void fs_resolve_body(int C, int level, int nlevels, int tb, FplState* __restrict__ st, uint32_t* __restrict__ hist) {
     __shared__ uint32_t tot[FS_MAXC * FS_BINS];
     __shared__ uint32_t ncls[FS_MAXC + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -295,23 +337,32 @@ __global__ void __launch_bounds__(256) k_fs_binsum_mfma(const bf16* __restrict__
     const int64_t tiles = (M + 127) / 128;
     int par = 0;
     if (tid < 2) sMask[tid] = 0u;
-    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x, par ^= 1) {
-        const int64_t p0 = tile * 128;
-        __syncthreads();
-        if (tid == 0) sMask[par ^ 1] = 0u;                  // the other buffer: read by nobody any more, written from the next tile on
+    // the NEXT tile's 8 KB of feature rows and its (label, bin) bytes are requested while this tile's MFMAs run (round 5: the kernel waited a full memory
+    // latency per tile between two block barriers: 0.249 ms for 0.47 GB)
+    uint4 nv[2];
+    int nc = 255, nb = 255;
+    auto fetch = [&](int64_t tile) {
+        const int64_t q0 = tile * 128;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int q = tid + j * 256;                    // 16-byte chunk q of the tile's contiguous 8 KB: pixel q / 4, chunk q % 4
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (p0 + (q >> 2) < M) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(feat) + (p0 * 64 + (int64_t)q * 16));
-            *reinterpret_cast<uint4*>(sX + q * 16) = v;
+            nv[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (tile < tiles && q0 + (q >> 2) < M) nv[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(feat) + (q0 * 64 + (int64_t)q * 16));
         }
+        nc = nb = 255;
+        if (tid < 128 && tile < tiles && q0 + tid < M) { nc = lab[q0 + tid]; nb = binmap[q0 + tid]; }
+    };
+    fetch(blockIdx.x);
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x, par ^= 1) {
+        __syncthreads();
+        if (tid == 0) sMask[par ^ 1] = 0u;                  // the other buffer: read by nobody any more, written from the next tile on
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<uint4*>(sX + (tid + j * 256) * 16) = nv[j];
+        const int cc_ = nc, cb_ = nb;
+        fetch(tile + gridDim.x);
         if (tid < 128) {
             unsigned short id = 0xffffu;
-            if (p0 + tid < M) {
-                const int c = lab[p0 + tid], b = binmap[p0 + tid];
-                if (c < C && b < FS_BINS) id = (unsigned short)(c * FS_BINS + b);
-            }
+            if (cc_ < C && cb_ < FS_BINS) id = (unsigned short)(cc_ * FS_BINS + cb_);
             sI[tid] = id;
             // 128 consecutive pixels are a piece of ONE image row and the layers are horizontal bands: a tile usually holds one or two classes, and a
             // wave skips the others (8 compares + an MFMA per class and 16-pixel step otherwise: the kernel was VALU-bound on building indicators)
@@ -363,7 +414,7 @@ __global__ void __launch_bounds__(256) k_fs_binsum_mfma(const bf16* __restrict__
 }
 
 extern "C" int64_t tcct_fpl_select_workspace_bytes() {
-    return (int64_t)sizeof(FplState) + (int64_t)FS_MAXC * FS_BINS * 256 * sizeof(uint32_t);
+    return (int64_t)sizeof(FplState) + (int64_t)FS_MAXC * FS_BINS * 256 * sizeof(uint32_t) + 8 * sizeof(uint32_t);
 }
 
 /* labels uint8 [M], prob fp32 [M] (softmax probability of the labelled class, detached), feat [M,32]: binmap [M] (bin 0..31 of the pixel inside
@@ -380,18 +431,19 @@ extern "C" int tcct_fpl_select(const void* feat, const uint8_t* labels, const fl
     while ((1LL << ib) < M) ++ib;
     ib = (ib + 7) / 8 * 8;                                  // index bits, whole bytes
     const int tb = 32 + ib, nlevels = tb / 8;
+    uint32_t* tickets = hist + (size_t)FS_MAXC * FS_BINS * 256;          // [8] level tickets behind the histogram
     if (hipMemsetAsync(hist, 0, sizeof(uint32_t) * FS_MAXC * 256, st) != hipSuccess) { tcct_set_error("fpl_select: memset failed"); return -2; }
+    if (hipMemsetAsync(tickets, 0, sizeof(uint32_t) * 8, st) != hipSuccess) { tcct_set_error("fpl_select: memset failed"); return -2; }
     if (hipMemsetAsync(pro_sum, 0, sizeof(float) * C * FS_BINS * 32, st) != hipSuccess) { tcct_set_error("fpl_select: memset failed"); return -2; }
-    const size_t lds_h = (size_t)FS_SLOTS * 256 * 4 + (size_t)FS_MAXC * FS_BINS * 8 + (FS_MAXC + 1) * 4;
+    const size_t lds_h = (size_t)FS_SLOTS * 128 * 4 + (size_t)FS_MAXC * FS_BINS * 8 + (FS_MAXC + 1) * 4;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_fs_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    int grid = tcct_grid(M, FS_TB, 256);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_fs_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }      // + ~2 KB static (the resolve step)
+    int grid = tcct_grid(M, FS_TB, 256);            // one 1024-thread block per CU (128 blocks: 0.46 ms for the seven levels against 0.33)
+    if ((M + grid - 1) / grid > FS_BLOCK_PIX) grid = (int)((M + FS_BLOCK_PIX - 1) / FS_BLOCK_PIX);       // 16-bit block-private counters
+    TCCT_CHECK(nlevels <= 8, "fpl_select: %d radix levels", nlevels);
     const int passes = (C * FS_BINS + FS_SLOTS - 1) / FS_SLOTS;
-    for (int level = 0; level < nlevels; ++level) {
-        for (int ps = 0; ps < (level == 0 ? 1 : passes); ++ps)
-            hipLaunchKernelGGL(k_fs_hist, dim3(grid), dim3(FS_TB), lds_h, st, labels, prob, M, C, level, ib, tb, ps * FS_SLOTS, (const FplState*)state, hist);
-        hipLaunchKernelGGL(k_fs_resolve, dim3(1), dim3(FS_TB), 0, st, C, level, nlevels, tb, state, hist);
-    }
+    for (int level = 0; level < nlevels; ++level)           // histogram of the level + (in its last block) the resolve step: one launch
+        hipLaunchKernelGGL(k_fs_hist, dim3(grid, level == 0 ? 1 : passes), dim3(FS_TB), lds_h, st, labels, prob, M, C, level, ib, tb, passes, nlevels, state, hist, tickets);
     hipLaunchKernelGGL(k_fs_assign, dim3(tcct_grid(M, FS_TB, 1024)), dim3(FS_TB), 0, st, labels, prob, M, C, ib, (const FplState*)state, binmap);
     const size_t lds_a = (size_t)C * FS_BINS * 32 * 4;
     const int gb = tcct_grid((M / FS_RUN + 1) * 8, FS_TB, 512);
