@@ -893,17 +893,18 @@ __global__ void __launch_bounds__(NBR) k_bn2_add_act_bwd_reduce(const T* __restr
         s0[k] = s1[k] = s2[k] = 0.f;
     }
     if (active) {
-        // two rows per iteration: three input streams and one resident 1024-thread block per CU need the extra loads in flight
+        // JR rows per iteration: three input streams and one resident 1024-thread block per CU need the extra loads in flight
+        constexpr int JR = 2;          // (4 rows in flight: 0.44 ms against 0.41 at level 0)
         const int64_t step = (int64_t)gridDim.x * R;
-        for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += 2 * step) {
-            f4 va[2], vb[2], g[2];
+        for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += JR * step) {
+            f4 va[JR], vb[JR], g[JR];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < JR; ++j) {
                 const int64_t mj = m + j * step;
                 if (mj < M) { const int64_t o = mj * C + cv * 4; va[j] = ld4(xa + o); vb[j] = ld4(xb + o); g[j] = ld4(dy + o); }
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < JR; ++j) {
                 if (m + j * step < M) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {

@@ -115,7 +115,7 @@ def dw_bench():
         print(f'dw {N}x{H}x{W}x{C} s{st}: fwd {m1:.3f} ms {(gx + gy) / m1 * 1e3:.0f} GB/s | dgrad {m2:.3f} ms {(gx + gy) / m2 * 1e3:.0f} GB/s | wgrad {m3:.3f} ms {(gx + gy) / m3 * 1e3:.0f} GB/s')
 
 
-if __name__ == "__main__" and not ({"pw", "bwd", "ln", "c3", "bnpool"} & set(sys.argv[1:])):
+if __name__ == "__main__" and not ({"pw", "bwd", "ln", "c3", "bnpool", "junction"} & set(sys.argv[1:])):
     if 'dw' in sys.argv[1:]:
         dw_bench()
         sys.exit(0)
@@ -244,3 +244,23 @@ def bnpool_bench():
 
 if 'bnpool' in sys.argv[1:]:
     bnpool_bench()
+
+
+def junction_bench():
+    """CrossCNN junction backward (two BatchNorms + GELU): the reduction and the apply pass at levels 0 / 1"""
+    for (H_, W_) in [(800, 1104), (400, 552)]:
+        C, M = 32, B * H_ * W_
+        xa, xb, dyj = (torch.randn(B, H_, W_, C, device='cuda').to(dt) for _ in range(3))
+        dxa, dxb = torch.empty_like(xa), torch.empty_like(xa)
+        mr = torch.zeros(2 * C, device='cuda'); mr[C:] = 1
+        ab = torch.ones(2 * C, device='cuda'); ab[C:] = 0
+        s4 = torch.zeros(4 * C, device='cuda', dtype=torch.float64)
+        dgs = [torch.empty(C, device='cuda') for _ in range(4)]
+        t1 = timeit(lambda: lib.bn2_add_act_bwd_reduce(xa, xb, dyj, M, C, mr, ab, mr, ab, 1, 3, s4, BF16), iters=20)
+        t2 = timeit(lambda: lib.bn2_add_act_bwd_apply(xa, xb, dyj, dxa, dxb, M, C, mr, ab, mr, ab, s4, 1, 3, dgs[0], dgs[1], dgs[2], dgs[3], BF16), iters=20)
+        gb = xa.numel() * 2 / 1e9
+        print(f'junction bwd {B}x{H_}x{W_}x{C}: reduce {t1:.3f} ms ({3 * gb / t1:.2f} TB/s)  apply {t2:.3f} ms ({5 * gb / t2:.2f} TB/s)')
+
+
+if 'junction' in sys.argv[1:]:
+    junction_bench()
