@@ -815,8 +815,10 @@ def test_trained_weights_train_step_matches_reference(name, tmp_path):
 # ---- round 5: FIVE consecutive steps against the reference's own loop (tests/golden/traj5_*.npz, oracle/make_golden_traj5.py) -------------------------
 # fp32: the literal 1e-3 on every per-step loss part and total norm; after step 5 the weights' DISPLACEMENT from the start (what five updates did),
 # Adam's moments, every BatchNorm buffer.  bf16: frozen bounds (`TRAJ_BF16`), set from the measurement recorded in profiles/r05_parity.md.
-TRAJ_FP32 = dict(loss=1e-3, norm=1e-3, disp=3e-2, m=2e-2, v=2e-2, buf=1e-3)
-TRAJ_BF16 = dict(loss=2e-2, norm=5e-2, disp=0.35, m=0.3, v=0.5, buf=3e-2)
+# measured (profiles/r05_parity.md): fp32 loss <= 4.1e-6, norm <= 1.3e-4, displacement rel-L2 <= 1.1e-3, m <= 1.9e-3, v <= 1.2e-3, buffers <= 3.6e-5;
+# bf16 loss <= 4.4e-3, norm <= 2.2e-2, displacement <= 0.29, m <= 0.29, v <= 0.33, buffers <= 7.8e-3 (worst tensors: BatchNorm biases at the 4 x 4 level)
+TRAJ_FP32 = dict(loss=1e-3, norm=1e-3, disp=5e-3, m=1e-2, v=1e-2, buf=1e-3)
+TRAJ_BF16 = dict(loss=1e-2, norm=4e-2, disp=0.4, m=0.4, v=0.5, buf=2e-2)
 
 
 def _traj_run(name, dtype, tmp_path):
