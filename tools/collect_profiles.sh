@@ -29,5 +29,8 @@ python tools/infer_bench.py --bs 1 >> $OUT/${TAG}_infer.txt 2>> $OUT/${TAG}_benc
 tail -c 600 $OUT/${TAG}_bench.json
 # HBM traffic of the whole step (every kernel, single stream)
 bash tools/step_traffic.sh ${TAG} > $OUT/${TAG}_traffic.txt 2>&1
+# STEADY-STATE per-launch trace (3 warm-up + 3 traced steps, cut at the optimizer kernel): family table, launch-duration histogram, short launches by symbol
+bash tools/steady_trace.sh ${TAG} > $OUT/${TAG}_steady.out 2>&1
+rm -rf $OUT/${TAG}_steady
 # keep only the small summaries
 find $OUT/${TAG}_step $OUT/${TAG}_stepfl $OUT/${TAG}_roof $OUT/${TAG}_lroof $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_lfetch $OUT/${TAG}_lwrite $OUT/${TAG}_mfma $OUT/${TAG}_sq -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null

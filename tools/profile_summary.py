@@ -44,20 +44,20 @@ L.append(f'Un-profiled bench lines: `profiles/{tag}_bench.json` ({b["value"]} B-
          + (f'`--los=di+reg` (BASELINE configs[2]): {br["value"]} B-scans/s, {br["ms_per_step"]} ms/step (`profiles/{tag}_bench_reg.json`); ' if br else '') +
          f'`--los=di+reg+fpl` (configs[3]): {bf["value"]} B-scans/s, {bf["ms_per_step"]} ms/step; fp32 parity mode: {b32["value"]} B-scans/s; '
          f'inference (`tools/infer_bench.py`): `profiles/{tag}_infer.txt`.\n')
-L.append(f'## whole step — `TCCT_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline`')
-L.append('(traced on ONE stream so that kernel durations add up; the bench lines above run the CNN / ViT encoders and the weight gradients on side streams, which hides ~2.5 ms of this sum)')
-L.append(f'{nsteps} steps traced; GPU busy {tot / 1e6:.1f} ms = {tot / 1e6 / nsteps:.2f} ms/step.  (These are the FIRST steps of a process: the 35 per-convolution weight packs '
-         f'`k_pack_w32` (~0.13 ms/step) and the model upload copies in the `rocclr` row belong to start-up; from the third step on one `k_pack_w32_multi` launch packs all weights.)\n')
-L.append('| family | ms/step | % |\n|---|---|---|')
-for n, t in sorted(acc.items(), key=lambda x: -x[1]):
-    L.append(f'| {n} | {t / 1e6 / nsteps:.2f} | {100 * t / tot:.1f} |')
-L.append('\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|')
-for r in sorted(step, key=lambda r: -float(r['TotalDurationNs']))[:28]:
-    L.append(f'| `{r["Name"].split("(")[0][:72]}` | {r["Calls"]} | {float(r["TotalDurationNs"]) / 1e6:.2f} | {float(r["AverageNs"]) / 1e3:.1f} | {float(r["Percentage"]):.1f} |')
+# ---- the whole step, STEADY STATE (round 5): tools/steady_trace.sh -- the last three of six steps, cut at the optimizer kernel, so the model upload copies and the first
+# steps' per-convolution weight packs are not in the table (the --stats CSV of the 3-step run above still is profiles/TAG_kernel_stats.csv)
+st = f'{G}/{tag}_steady_summary.md'
+if os.path.exists(st):
+    shutil.copy(st, f'{P}/{tag}_steady_summary.md')
+    L.append(f'## whole step, steady state — `bash tools/steady_trace.sh {tag}` (`TCCT_STREAMS=0`, one stream so that kernel durations add up; the bench lines above run the CNN / ViT encoders and the weight gradients on side streams)\n')
+    body = open(st).read().splitlines()
+    L.extend(body[2:])
+else:
+    L.append(f'(no steady-state trace collected; start-up-inclusive totals: {tot / 1e6 / nsteps:.2f} ms/step over {nsteps} steps)')
 L.append(f'\n## roofline kernels alone — `rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-only` and, in separate passes, `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`\n')
 L.append('HBM bytes = 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE, counters in KiB, per launch.\n')
 L.append('| kernel | calls | avg us (rocprof) | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM MB / launch | algorithmic MB | ratio |\n|---|---|---|---|---|---|---|---|')
-alg = {'k_conv32_mfma': 904.3968, 'k_conv32_fwd33_stream': 904.3968, 'k_conv32_wgrad33_stream': 904.3968, 'k_conv32_wgrad33_roll': 904.3968, 'k_conv32_wgrad': 904.3968, 'k_bn_bwd_reduce': 904.3968, 'k_pw_fwd': 452.1984, 'k_pw_fwd2': 452.1984, 'k_pw_bwd': 678.2976}
+alg = {'k_conv32_chain33': 1356.5952, 'k_conv32_wgradk_stream': 904.3968, 'k_conv32_mfma': 904.3968, 'k_conv32_fwd33_stream': 904.3968, 'k_conv32_wgrad33_stream': 904.3968, 'k_conv32_wgrad33_roll': 904.3968, 'k_conv32_wgrad': 904.3968, 'k_bn_bwd_reduce': 904.3968, 'k_pw_fwd': 452.1984, 'k_pw_fwd2': 452.1984, 'k_pw_bwd': 678.2976}
 for r in roof:
     for key, a in alg.items():
         if key + '<' in r['Name'] or key + '(' in r['Name']:

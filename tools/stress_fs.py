@@ -34,5 +34,32 @@ for (B, H, W, stat, KH, KW) in [(8, 800, 1104, None, 3, 3), (8, 800, 1100, 1, 3,
     print((B, H, W, stat, KH, KW), 'mismatching pixels over 25 runs:', nbad, flush=True)
     bad_total += nbad
 lib.conv32_fwd_mode(0)
+# round 5: conv3x3 -> conv3x3 in one launch (producer / consumer waves, one row barrier per row; the producer's waits count DMA pieces like the kernels above)
+for (B, H, W, mode) in [(8, 800, 1104, 'plain'), (8, 800, 1100, 'stats'), (8, 400, 552, 'res'), (8, 800, 1104, 'res'), (3, 800, 1072, 'stats')]:
+    x = torch.randn((B, H, W, 32), device='cuda').bfloat16()
+    res = torch.randn((B, H, W, 32), device='cuda').bfloat16()
+    packs = []
+    for sd in (1, 2):
+        w = torch.randn((32, 32, 3, 3), device='cuda') / 17
+        wp = torch.empty(9 * 1024, device='cuda', dtype=torch.bfloat16)
+        lib.conv32_pack_weights(w, wp, 3, 3, 0)
+        packs.append((wp, torch.randn(32, device='cuda')))
+    sums = torch.zeros(64, device='cuda', dtype=torch.float64)
+    mid_ref, ref = torch.empty_like(x), torch.empty_like(x)
+    lib.conv32_fwd(x, packs[0][0], packs[0][1], mid_ref, B, H, W, 3, 3, 1, 1)
+    if mode == 'res': lib.conv32_fwd_add(mid_ref, packs[1][0], packs[1][1], res, ref, B, H, W, 3, 3, 1, 1)
+    else: lib.conv32_fwd(mid_ref, packs[1][0], packs[1][1], ref, B, H, W, 3, 3, 1, 1)
+    torch.cuda.synchronize()
+    nbad = 0
+    for it in range(25):
+        mid, y = torch.full_like(x, 777.0), torch.full_like(x, 555.0)
+        if it % 2:
+            with torch.cuda.stream(side):
+                for _ in range(6): big2.copy_(big)
+        lib.conv32_chain33(x, packs[0][0], packs[0][1], mid, packs[1][0], packs[1][1], y, res if mode == 'res' else None, B, H, W, sums if mode == 'stats' else None)
+        torch.cuda.synchronize()
+        nbad += int((y != ref).any(dim=3).sum()) + int((mid != mid_ref).any(dim=3).sum())
+    print('chain33', (B, H, W, mode), 'mismatching pixels over 25 runs:', nbad, flush=True)
+    bad_total += nbad
 print('TOTAL', bad_total)
 sys.exit(1 if bad_total else 0)
