@@ -562,14 +562,6 @@ int tcct_fpl_select(const void* feat, const uint8_t* labels, const float* prob, 
 /* prototypes, loss and d loss / d prototype (already divided by the bin size) from the bin sums; pro_sum/pro/dpro_over_n fp32 [C,32,32] */
 int tcct_fpl_loss(const float* pro_sum, const uint32_t* counts, const float* buf_grad, int C, float* pro, float* loss, float* dpro_over_n,
                   tcct_stream_t stream);
-/* RegNet.lap_reg (reference nets/reg.py:66-74, applied at :115-116 to the logits without class 0 and to the one-hot label planes): |dw3x3(dw3x3(x; w1, b1); w2, b2)| as
- * ONE kernel each way (csrc/lapreg.hip, round 5) instead of dw -> dw -> |.| and |.|' -> dw^T -> dw^T + two weight-gradient passes.  x, out, dout, dx: fp32 NHWC [N,H,W,C],
- * C = 4 or 8; w*: [C,1,3,3] fp32, b*: [C].  The backward recomputes the intermediates from x: dx may be NULL (the label planes need none); sums fp32 [C][20] = per channel
- * {dW1[9], db1, dW2[9], db2}. */
-int tcct_lapreg_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* out, int N, int H, int W, int C,
-                    tcct_stream_t stream);
-int tcct_lapreg_bwd(const float* x, const float* dout, const float* w1, const float* b1, const float* w2, const float* b2, float* dx, float* sums,
-                    int N, int H, int W, int C, tcct_stream_t stream);
 /* binmap uint8 [M] (bin 0..31, 255 = not selected); dfeat [M,32] */
 int tcct_fpl_backward(const uint8_t* labels, const uint8_t* binmap, const float* dpro_over_n, const float* grad_out,
                       float grad_scale, int64_t M, void* dfeat, int dtype, tcct_stream_t stream);

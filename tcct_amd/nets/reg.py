@@ -96,9 +96,6 @@ class RegNet(nn.Module):
 
     # ------------------------------------------------------------------ boundary regression (reference reg.py:109-156)
     def _lap_reg(self, x):
-        m0, m1 = self.lap_reg[0], self.lap_reg[1]
-        if ops.lap_reg_ok(x, m0.weight, m1.weight):         # dw -> dw -> |.| as one kernel each way (csrc/lapreg.hip)
-            return ops.lap_reg(x, m0.weight, m0.bias, m1.weight, m1.bias)
         x = ops.dwconv3x3(x, self.lap_reg[0].weight, self.lap_reg[0].bias)
         return ops.act(ops.dwconv3x3(x, self.lap_reg[1].weight, self.lap_reg[1].bias), 'abs')
 

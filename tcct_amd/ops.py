@@ -2949,44 +2949,6 @@ def slice_channels_f32(x, start, n):
     return _Slice.apply(x, start, n)
 
 
-class _LapReg(torch.autograd.Function):
-    """|dw3x3(dw3x3(x; w1, b1); w2, b2)| (RegNet.lap_reg, reference nets/reg.py:66-74,115-116) as one kernel each way; the backward recomputes the intermediates from x"""
-
-    @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
-        _chk(x, w1, b1, w2, b2)
-        N, H, W, C = x.shape
-        out = torch.empty_like(x)
-        lib.lapreg_fwd(x, w1, b1, w2, b2, out, N, H, W, C)
-        ctx.save_for_backward(x, w1, b1, w2, b2)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        x, w1, b1, w2, b2 = ctx.saved_tensors
-        N, H, W, C = x.shape
-        dout = _c(_as(dout, torch.float32))
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        sums = ZERO.get((C, 20), torch.float32, x.device) if ZERO.active else torch.zeros((C, 20), device=x.device, dtype=torch.float32)
-        lib.lapreg_bwd(x, dout, w1, b1, w2, b2, dx, sums, N, H, W, C)
-        dw1, db1 = sums[:, 0:9].reshape(C, 1, 3, 3), sums[:, 9]
-        dw2, db2 = sums[:, 10:19].reshape(C, 1, 3, 3), sums[:, 19]
-        return dx, dw1, (db1 if b1 is not None else None), dw2, (db2 if b2 is not None else None)
-
-
-LAP_REG_FUSE = True         # False: dw3x3 -> dw3x3 -> |.| as three nodes (the comparison arm of tests/test_kernels_gpu.py::test_lap_reg_as_one_kernel)
-
-
-def lap_reg_ok(x, w1, w2):
-    return (LAP_REG_FUSE and x.dim() == 4 and x.dtype == torch.float32 and x.is_cuda and x.shape[-1] in (4, 8) and x.is_contiguous()
-            and tuple(w1.shape) == (x.shape[-1], 1, 3, 3) and tuple(w2.shape) == (x.shape[-1], 1, 3, 3))
-
-
-def lap_reg(x, w1, b1, w2, b2):
-    """|dw3x3(dw3x3(x))| on fp32 NHWC class planes (check lap_reg_ok first)"""
-    return _LapReg.apply(x, w1, b1, w2, b2)
-
-
 class _GumbelColSoftmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eps):

@@ -141,45 +141,6 @@ def test_conv32_weight_gradient_rolling_row_form_equals_the_generic_one(cfg):
         torch.testing.assert_close(outs[0][0], o[0], rtol=1e-4, atol=1e-4 * max(1.0, w.grad.abs().max().item()))
 
 
-@pytest.mark.parametrize('cfg', [(2, 37, 70, 4, True), (1, 8, 32, 4, True), (3, 5, 7, 8, True), (2, 64, 96, 8, False), (1, 1, 1, 4, True), (2, 100, 138, 4, True)])
-def test_lap_reg_as_one_kernel(cfg):
-    """round 5, csrc/lapreg.hip: RegNet.lap_reg (reference nets/reg.py:66-74,115-116: |dw3x3(dw3x3(x))| on the 4 or 8 class planes) as ONE kernel each way -- the
-    backward recomputes both intermediates from x and delivers dx, both weight gradients and both bias gradients -- against torch's fp32 chain (zero padding of the
-    INTERMEDIATE at the image border, tiles that do not divide the image, the label-plane call that wants no input gradient) and against the three-node path"""
-    from tcct_amd import ops
-    N, H, W, C, want_dx = cfg
-    g = torch.Generator().manual_seed(H * W + C)
-    x0 = torch.randn(N, C, H, W, generator=g)
-    ws = [torch.randn(C, 1, 3, 3, generator=g) * 0.5, torch.randn(C, generator=g) * 0.3, torch.randn(C, 1, 3, 3, generator=g) * 0.5, torch.randn(C, generator=g) * 0.3]
-    gy = torch.randn(N, C, H, W, generator=g)
-    pr = [w.clone().requires_grad_(True) for w in ws]
-    xr = x0.clone().requires_grad_(want_dx)
-    ref = F.conv2d(F.conv2d(xr, pr[0], pr[1], 1, 1, 1, C), pr[2], pr[3], 1, 1, 1, C).abs()
-    ref.backward(gy)
-    res = {}
-    for fused in (True, False):
-        ops.LAP_REG_FUSE = fused
-        try:
-            pd = [w.clone().cuda().requires_grad_(True) for w in ws]
-            xd = x0.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(want_dx)
-            if fused:
-                assert ops.lap_reg_ok(xd, pd[0], pd[2])
-                out = ops.lap_reg(xd, pd[0], pd[1], pd[2], pd[3])
-            else:
-                out = ops.act(ops.dwconv3x3(ops.dwconv3x3(xd, pd[0], pd[1]), pd[2], pd[3]), 'abs')
-            out.backward(gy.permute(0, 2, 3, 1).contiguous().cuda())
-            res[fused] = (out.detach().permute(0, 3, 1, 2).cpu(), xd.grad.permute(0, 3, 1, 2).cpu() if want_dx else None, [p.grad.cpu() for p in pd])
-        finally:
-            ops.LAP_REG_FUSE = True
-    for fused in (True, False):
-        out, dx, gs = res[fused]
-        torch.testing.assert_close(out, ref.detach(), rtol=1e-5, atol=1e-5)
-        if want_dx:
-            torch.testing.assert_close(dx, xr.grad, rtol=1e-4, atol=1e-5)
-        for a, b in zip(gs, [p.grad for p in pr]):
-            torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * max(1.0, b.abs().max().item()))
-
-
 @pytest.mark.parametrize('mode', ['plain', 'stats', 'res'])
 @pytest.mark.parametrize('nhw', [(3, 70, 130), (2, 16, 33), (3, 50, 69), (1, 3, 5), (2, 100, 138), (1, 1, 1), (1, 40, 30), (2, 9, 61), (5, 31, 97), (2, 400, 552), (1, 700, 300), (40, 4, 20)])
 def test_conv3x3_chain_is_bit_identical_to_two_launches(nhw, mode):
