@@ -220,7 +220,8 @@ int tcct_conv32_fwd_add(const void* x, const void* wp, const float* bias, const 
  * mid = the first convolution's output -- written (the backward pass needs it) but not read back, the second convolution takes it from LDS.  Replaces
  * nn.Conv2d -> nn.Conv2d of CrossCNNBlock.block12 (reference nets/tcct.py:808-810: no nonlinearity between the two) and, with the flipped / transposed
  * packs, the input-gradient chain of the same pair.  stats (fp64 [64] zero on entry, or NULL): += {sum, sum of squares} per channel of LeakyReLU(y) as
- * stored (the BatchNorm behind block12, :811); res (or NULL): y += res before the store (as tcct_conv32_fwd_add).  Bit-identical to two tcct_conv32_fwd calls. */
+ * stored (the BatchNorm behind block12, :811); res (or NULL): y += res before the store (as tcct_conv32_fwd_add); mid == NULL (inference): the intermediate is
+ * not written at all.  Bit-identical to two tcct_conv32_fwd calls. */
 int tcct_conv32_chain33(const void* x, const void* wp1, const float* bias1, void* mid, const void* wp2, const float* bias2, void* y,
                         const void* res, int N, int H, int W, double* stats, tcct_stream_t stream);
 /* the same kernels on 32-channel slabs of wider NHWC tensors (x: xs channels/pixel, slab at xo; y: ys, yo; accumulate adds

@@ -191,7 +191,7 @@ k_conv32_chain33(const bf16* __restrict__ x, const bf16* __restrict__ wp1, const
                 ch_u32x4 pend[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) pend[u] = *reinterpret_cast<const ch_u32x4*>(slot + sl[u]);
-                const bool own = m >= 1 && m <= L;
+                const bool own = m >= 1 && m <= L && mid != nullptr;      // mid == NULL (inference): the intermediate lives in LDS only
                 const uint32_t oro = (uint32_t)(own ? mrow : 0) * rowb;
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
@@ -318,14 +318,15 @@ k_conv32_chain33(const bf16* __restrict__ x, const bf16* __restrict__ wp1, const
     }
 }
 
-/* y = conv3x3(conv3x3(x; w1, b1); w2, b2) on bf16 NHWC [N,H,W,32], both 'same'; mid = the first convolution's output (written, never read here).
+/* y = conv3x3(conv3x3(x; w1, b1); w2, b2) on bf16 NHWC [N,H,W,32], both 'same'; mid = the first convolution's output (written, never read here; NULL: not
+ * written at all -- inference, where nothing needs it: 2 tensors of traffic instead of 4).
  * wp1 / wp2: packed bf16 [9][32][32] (tcct_conv32_pack_weights; the flipped / transposed packs for an input-gradient chain).  stats (fp64 [64], zero on entry,
  * or NULL): += {sum, sum of squares} per channel of LeakyReLU(y) as stored -- the train-mode BatchNorm behind block12 (reference nets/tcct.py:808-811).
  * res (or NULL): y += res before the store (a second consumer's gradient, as tcct_conv32_fwd_add).  stats and res exclude each other.
  * Replaces tcct_conv32_fwd(x -> mid) + tcct_conv32_fwd[_bnstats | _add](mid -> y): bit-identical results, `mid` is not read back from HBM. */
 extern "C" int tcct_conv32_chain33(const void* x, const void* wp1, const float* bias1, void* mid, const void* wp2, const float* bias2, void* y,
                                    const void* res, int N, int H, int W, double* stats, tcct_stream_t stream) {
-    TCCT_CHECK(x && wp1 && wp2 && mid && y && x != mid && mid != y && x != y, "conv32_chain33: x, mid, y must be three tensors");
+    TCCT_CHECK(x && wp1 && wp2 && y && x != mid && mid != y && x != y, "conv32_chain33: x, mid, y must be three tensors (mid may be NULL)");
     TCCT_CHECK(!(stats && res), "conv32_chain33: statistics and a residual exclude each other");
     TCCT_CHECK(N > 0 && H > 0 && W > 0 && (int64_t)H * W * 64 < (1LL << 31), "conv32_chain33: one image of %d x %d exceeds the 2 GiB buffer-descriptor range", H, W);
     const int strips = (W + CH_SW - 1) / CH_SW, pairs = (strips + 1) / 2;

@@ -81,6 +81,8 @@ class CrossCNNBlock(nn.Module):
         if ops.conv3x3_chain_ok(x, m0.weight, m0.bias, m1c.weight, m1c.bias, m0.stride[0], m0.padding, m1c.stride[0], m1c.padding):
             # conv3x3 -> conv3x3, nothing in between (reference tcct.py:808-810): one launch each way, the intermediate is not read back
             a, x2 = ops.conv3x3_chain(x, m0.weight, m0.bias, m1c.weight, m1c.bias, stats_pre='lrelu' if tr else None, fork=True)
+        elif not tr and ops.conv3x3_chain_infer_ok(x, m0.weight, m1c.weight, m0.stride[0], m0.padding, m1c.stride[0], m1c.padding):
+            a, x2 = ops.conv3x3_chain_infer(x, m0.weight, m0.bias, m1c.weight, m1c.bias), x      # inference: the intermediate is never written
         else:
             a0, x2 = ops.conv2d_fork(x, m0.weight, m0.bias, m0.stride[0], tuple(m0.padding))
             a = _conv(m1c, a0, stats_pre='lrelu' if tr else None)

@@ -698,6 +698,25 @@ class _ConvChain33(torch.autograd.Function):
         return dx, _ret(dw1, p1), _ret(db1, pb1), _ret(dw2, p2), _ret(db2, pb2), None, None
 
 
+def conv3x3_chain_infer_ok(x, w1, w2, stride1, pad1, stride2, pad2):
+    return (CONV_CHAIN and INFER_FUSE and not torch.is_grad_enabled() and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_cuda and x.shape[-1] == 32
+            and tuple(w1.shape) == (32, 32, 3, 3) and tuple(w2.shape) == (32, 32, 3, 3) and stride1 == 1 and stride2 == 1
+            and tuple(pad1) == (1, 1) and tuple(pad2) == (1, 1) and x.shape[1] * x.shape[2] * 64 < 2 ** 31
+            and x.shape[0] * x.shape[1] * x.shape[2] >= CHAIN_MIN_PIXELS)
+
+
+def conv3x3_chain_infer(x, w1, b1, w2, b2):
+    """inference (no_grad): conv3x3(conv3x3(x)) with the intermediate never written (check conv3x3_chain_infer_ok first)"""
+    _chk(x, w1, b1, w2, b2)
+    N, H, W, _ = x.shape
+    y = torch.empty_like(x)
+    wp = torch.empty(2 * 9 * 1024, device=x.device, dtype=torch.bfloat16)
+    lib.conv32_pack_weights(w1, wp[:9 * 1024], 3, 3, 0)
+    lib.conv32_pack_weights(w2, wp[9 * 1024:], 3, 3, 0)
+    lib.conv32_chain33(x, wp[:9 * 1024], b1, None, wp[9 * 1024:], b2, y, None, N, H, W, None)
+    return y
+
+
 def conv3x3_chain(x, w1, b1, w2, b2, stats_pre=None, fork=False):
     """conv3x3(conv3x3(x; w1, b1); w2, b2), both 32 -> 32 'same' (check conv3x3_chain_ok first).  stats_pre: None or 'lrelu' (the train-mode BatchNorm that
     consumes the output: its statistics come out of the same launch, `_bn_sums`).  fork: also return an alias of x for the OTHER consumers of x, whose

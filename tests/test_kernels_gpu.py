@@ -176,6 +176,11 @@ def test_conv3x3_chain_is_bit_identical_to_two_launches(nhw, mode):
     torch.cuda.synchronize()
     assert torch.equal(mid_a, mid_b)
     assert torch.equal(y_a, y_b)
+    if mode == 'plain':         # inference form: the intermediate is not written at all (mid == NULL)
+        y_c = torch.full((N, H, W, 32), 3.0, device='cuda', dtype=torch.bfloat16)
+        lib.conv32_chain33(xd, packs[0], b1d, None, packs[1], b2d, y_c, None, N, H, W, None)
+        torch.cuda.synchronize()
+        assert torch.equal(y_a, y_c)
     if mode == 'stats':
         torch.testing.assert_close(s_b, s_a, rtol=1e-5, atol=1e-5 * max(1.0, s_a.abs().max().item()))
     m_ref = F.conv2d(x.float(), w1.bfloat16().float(), b1, 1, 1).bfloat16().float()
