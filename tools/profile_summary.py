@@ -122,6 +122,21 @@ if os.path.exists(f'{G}/{tag}_lroof/lroof_kernel_stats.csv'):
 L.append(f'\nbench.py\'s own HIP-event timing of the same loops (un-profiled run): `roofline.ms_per_launch` = {b["roofline"]["ms_per_launch"]} ms '
          f'({b["roofline"]["achieved"]} GB/s algorithmic, frac {b["roofline"]["frac"]}), second = {b["roofline"]["second"]["ms_per_launch"]} ms, '
          f'others = {[(o["kernel"], o["ms_per_launch"]) for o in b["roofline"].get("others", [])]}.')
+# ---- per symbol: steady-state time joined with the PMC traffic of the same single-stream step -> TB/s on REAL bytes (round 5)
+sc, tc = f'{G}/{tag}_steady_symbols.csv', f'{G}/{tag}_traffic_symbols.csv'
+if os.path.exists(sc) and os.path.exists(tc):
+    tm = {r['symbol']: (float(r['calls_per_step']), float(r['ms_per_step'])) for r in csv.DictReader(open(sc))}
+    tr = {r['symbol']: float(r['mb_per_step']) for r in csv.DictReader(open(tc))}
+    L.append('\n## every large symbol of the step: time (steady-state trace) x bytes (PMC, 2 x FETCH_SIZE + WRITE_SIZE) -> TB/s on the bytes it REALLY moves\n')
+    L.append('| kernel | calls/step | ms/step | HBM MB/step | TB/s |\n|---|---|---|---|---|')
+    tot_ms = tot_mb = 0.0
+    for k, (c, ms) in sorted(tm.items(), key=lambda x: -x[1][1])[:45]:
+        mb = tr.get(k)
+        if mb is None:
+            continue
+        tot_ms += ms; tot_mb += mb
+        L.append(f'| `{k[:90]}` | {c:.0f} | {ms:.3f} | {mb:.0f} | {mb / ms / 1e3:.2f} |')
+    L.append(f'| (these rows) | | {tot_ms:.2f} | {tot_mb:.0f} | {tot_mb / tot_ms / 1e3:.2f} |')
 # ---- HBM traffic of the WHOLE step (tools/step_traffic.sh: PMC FETCH_SIZE / WRITE_SIZE over every kernel of the single-stream step)
 if os.path.exists(f'{G}/{tag}_traffic.txt'):
     shutil.copy(f'{G}/{tag}_traffic.txt', f'{P}/{tag}_step_traffic.txt')

@@ -58,6 +58,10 @@ L.append('\n## launches shorter than 20 us by symbol (grid sizes of those launch
 for k, (t, c, g) in sorted(sym.items(), key=lambda x: -sum(x[1][2].values()))[:30]:
     if g:
         L.append(f'| `{k[:90]}` | {sum(g.values()) / NS:.1f} | {dict(sorted(g.items())[:6])} |')
+with open(os.path.join(root, f'{tag}_steady_symbols.csv'), 'w') as fcsv:          # symbol -> calls / step, ms / step (joined with the PMC traffic by tools/profile_summary.py)
+    fcsv.write('symbol,calls_per_step,ms_per_step\n')
+    for k, (t, c, _) in sorted(sym.items(), key=lambda x: -x[1][0]):
+        fcsv.write('"%s",%.3f,%.5f\n' % (k.replace('"', "'"), c / NS, t / NS / 1e3))
 out = os.path.join(root, f'{tag}_steady_summary.md')
 open(out, 'w').write('\n'.join(L) + '\n')
 print('\n'.join(L[:28]))

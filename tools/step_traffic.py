@@ -15,6 +15,10 @@ for k in set(fe) | set(wr):
     mb = (2 * fe.get(k, 0) + wr.get(k, 0)) * 1024 / 1e6 / 3
     rows.append((mb, k, n[k] / 3, 2 * fe.get(k, 0) * 1024 / 1e6 / 3, wr.get(k, 0) * 1024 / 1e6 / 3))
 rows.sort(reverse=True)
+with open(os.path.join(root, f'{tag}_traffic_symbols.csv'), 'w') as fcsv:         # symbol (as steady_trace.py names it) -> MB / step
+    fcsv.write('symbol,calls_per_step,mb_per_step\n')
+    for mb, k, c, r_, w_ in rows:
+        fcsv.write('"%s",%.3f,%.3f\n' % (k.split('(')[0].replace('"', "'"), c, mb))
 tot = sum(r[0] for r in rows)
 print(f'total HBM traffic per step: {tot / 1e3:.2f} GB (reads {sum(r[3] for r in rows) / 1e3:.2f}, writes {sum(r[4] for r in rows) / 1e3:.2f})')
 for mb, k, c, r_, w_ in rows[:45]:
