@@ -236,14 +236,13 @@ int tcct_conv32_fwd_strided(const void* x, const void* wp, const float* bias, vo
  * zero before the first slab */
 int tcct_conv32_fwd_strided_bnstats(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
                                     int PW, int xs, int xo, int ys, int yo, int accumulate, double* stats, int pre_act, tcct_stream_t stream);
-/* selects the kernel behind tcct_conv32_wgrad for plain 3x3 convolutions: 0 (default) = wave-private row streams where a wave gets >= 32 rows (levels 0-1;
- * TCCT_WGRAD_STREAM=0: never), else the rolling-row form (one x fragment per halo row meets a register window of three dy fragments, 6 waves x 2 blocks per
- * CU); 1 = the generic register-staged kernel every other shape takes (comparison arm of the bit-compatibility test; TCCT_WGRAD_GENERIC=1 for a whole run);
+/* selects the kernel behind tcct_conv32_wgrad for plain 3x3 convolutions: 0 (default) = wave-private row streams where a wave gets >= 32 rows (levels 0-1), else the rolling-row form (one x fragment per halo row meets a register window of three dy fragments, 6 waves x 2 blocks per
+ * CU); 1 = the generic register-staged kernel every other shape takes (comparison arm of the bit-compatibility test; bench.py --wgrad-mode 1 for a whole run);
  * 2 = row streams for every plain 3x3; any other value only queries.  Returns the previous mode.  (No reference counterpart: the reference calls ATen's
  * convolution backward, nets/tcct.py:808-822 through autograd.) */
 int64_t tcct_conv32_wgrad_mode(int mode);
 /* the same for the plain 32-channel 3x3 forward / input gradient (tcct_conv32_fwd, tcct_conv32_fwd_bnstats with no / LeakyReLU pre-activation): 0 (default) =
- * the row-stream kernel where a wave gets >= 48 rows (TCCT_CONV_STREAM=0: never), 1 = the tiled kernel everywhere, 2 = the row-stream kernel for every
+ * the row-stream kernel where a wave gets >= 48 rows, 1 = the tiled kernel everywhere, 2 = the row-stream kernel for every
  * plain 3x3.  The two kernels give bit-identical outputs.  Returns the previous mode; any other value only queries. */
 int64_t tcct_conv32_fwd_mode(int mode);
 int tcct_conv32_wgrad_strided(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int KH, int KW, int PH,
@@ -407,6 +406,14 @@ int tcct_pw_wgrad_smalln(const void* x, const void* dy, float* dw, float* dbias,
 
 /* achievable-bandwidth yardstick of bench.py (`roofline.copy_ceiling`): a streaming copy with 16-byte accesses, one 8 KB chunk per block */
 int tcct_stream_copy(const void* src, void* dst, int64_t nbytes, tcct_stream_t stream);
+
+/* test tooling, no reference counterpart: number of launches of kernel family `which` since the last reset (0 k_conv32_chain33, 1 k_conv32_wgradk_stream,
+ * 2 k_conv32_wgrad33_stream, 3 k_conv32_fwd33_stream); reset != 0 clears it after reading; -1 for an unknown family.  The entry points choose a kernel per shape:
+ * tests/test_fullsize_gpu.py asserts with this that the bench-shape step was served by the row-stream / chain kernels it means to check. */
+int64_t tcct_kernel_census(int which, int reset);
+/* measurement tooling (tools/attrib_trace.py), no reference counterpart: an empty launch of `id` blocks x 64 threads -- the grid size is the only thing a
+ * kernel trace / PMC table records about a dispatch, so a marker in front of every C-ABI call lets the tables be cut into calls; 1 <= id < 2^20 */
+int tcct_marker(int id, tcct_stream_t stream);
 
 /* ---- depthwise 3x3 (nets/tcct.py:114-122,206,535-543; nets/reg.py:66-67,72,74 as C=1 / groups=C) -------- */
 int tcct_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C,

@@ -46,6 +46,8 @@ class TcctError(RuntimeError):
 
 
 _TLS = threading.local()
+# measurement tooling (tools/attrib_trace.py): a callable (symbol, [(ctype, argname)], args-with-stream) run in front of every C-ABI call that takes a stream
+_TRACE = [None]
 
 
 class launch_on:
@@ -103,7 +105,7 @@ class _Lib:
         is_ptr = tuple(ct is ctypes.c_void_p for ct, _ in sig)
         raw_stream, cur_dev, Tensor = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice, torch.Tensor
 
-        tls = _TLS
+        tls, trace = _TLS, _TRACE
 
         def call(*args):
             if has_stream and len(args) == n - 1:
@@ -111,6 +113,8 @@ class _Lib:
                 args = args + (getattr(tls, 'stream', None) or raw_stream(cur_dev()),)
             elif len(args) != n:
                 raise TypeError(f'{full}: expected {n} args ({[nm for _, nm in sig]}), got {len(args)}')
+            if has_stream and trace[0] is not None:
+                trace[0](full, sig, args)
             rc = fn(*[(a.data_ptr() if isinstance(a, Tensor) else a) if p and a is not None else a for a, p in zip(args, is_ptr)])
             if res_is_value:
                 return rc

@@ -9,6 +9,9 @@
 typedef __hip_bfloat16 bf16;
 
 void tcct_set_error(const char* fmt, ...);
+// launch census (tests only: "did the row-stream / chain kernel really run for this shape?"): host-side counters bumped next to the launch
+enum { TCCT_CENSUS_CHAIN33 = 0, TCCT_CENSUS_WGRADK_STREAM = 1, TCCT_CENSUS_WGRAD33_STREAM = 2, TCCT_CENSUS_FWD33_STREAM = 3, TCCT_CENSUS_N = 8 };
+void tcct_census_hit(int which);
 int tcct_skip_zero_fill();      // 1: the caller guarantees accumulation outputs are already zero (tcct_set_outputs_prezeroed)
 
 #define TCCT_CHECK(cond, ...)                                   \

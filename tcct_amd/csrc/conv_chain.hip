@@ -353,5 +353,6 @@ extern "C" int tcct_conv32_chain33(const void* x, const void* wp1, const float* 
     else if (res) CH_LAUNCH(3);
     else CH_LAUNCH(0);
 #undef CH_LAUNCH
+    tcct_census_hit(TCCT_CENSUS_CHAIN33);
     TCCT_LAUNCH_OK();
 }

@@ -442,7 +442,7 @@ static bool conv32_fwd33_stream_launch(const void* x, const void* wp, const floa
 static bool conv32_fwd1k_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int K, bool force, hipStream_t st);
 static bool conv32_fwdk1_stream_launch(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int K, bool force, hipStream_t st);
 static int g_fwd_mode = -1;
-/* 0 (default): plain 3x3 convolutions whose waves get >= FS_MIN_RUN rows take the row-stream kernel (TCCT_CONV_STREAM=0: never); 1: the tiled kernel for every
+/* 0 (default): plain 3x3 convolutions whose waves get >= FS_MIN_RUN rows take the row-stream kernel; 1: the tiled kernel for every
  * shape; 2: the row-stream kernel for every plain 3x3 (the comparison arms of the bit-identity test).  Returns the previous mode; mode < 0 only queries. */
 extern "C" int64_t tcct_conv32_fwd_mode(int mode) {
     if (g_fwd_mode < 0) g_fwd_mode = 0;
@@ -1322,6 +1322,7 @@ static bool conv32_fwd33_stream_launch(const void* x, const void* wp, const floa
     else if (stat_code == 5) FS_LAUNCH(5);
     else FS_LAUNCH(6);
 #undef FS_LAUNCH
+    tcct_census_hit(TCCT_CENSUS_FWD33_STREAM);
     return true;
 }
 
@@ -1829,9 +1830,13 @@ k_conv32_wgrad_line(const bf16* __restrict__ x, const bf16* __restrict__ dy, flo
 //          (the row sits in LDS once; the shifted-line kernel's register surgery is not needed when nothing but this wave's reads competes for its LDS port);
 //   K x 1: ring row = 16 x pixels + 16 dy pixels (two DMA pieces); x row b meets the dy fragments of rows b - t + (K - 1) / 2, kept in a register window
 //          of the last K dy rows (K x 4 registers), body unrolled K-fold so that window positions are compile-time; ring slot by run-time index.
-// 14 / 18 ring rows per wave, all but two in flight (one wave per SIMD has nobody to hide its latency behind: the depth does; 12 rows: 0.224 / 0.210 ms).  Same products and fp32 accumulation as
-// the other weight-gradient kernels, summed in another order: bit-compatible up to that (tests/test_kernels_gpu.py).
+// WK_R = 8 ring rows per wave, WK_P = 6 of them in flight (one wave per SIMD has nobody to hide its latency behind: the depth does; 12 / 18 rows measured no faster,
+// DESIGN 3b, and 150 KB of LDS per block would keep the other streams' kernels off the CU).  The counted `s_waitcnt vmcnt(NPIECE * (WK_P - 1))` and the slot
+// arithmetic rest on these two constants; the launch sizes the ring from WK_R.  Same products and fp32 accumulation as the other weight-gradient kernels, summed in
+// another order: bit-compatible up to that (tests/test_kernels_gpu.py).
 #define WK_T 256
+constexpr int WK_R = 8, WK_P = 6;           // ring rows per wave / rows in flight (64 / 88 KB of LDS per block)
+static_assert(WK_P <= WK_R - 2, "k_conv32_wgradk_stream: two ring slots stay free (the row being read and the one being issued into)");
 template <int K, bool VERT>
 __global__ void __launch_bounds__(WK_T, 1)
 k_conv32_wgradk_stream(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw, float* __restrict__ dbias,
@@ -1840,7 +1845,6 @@ k_conv32_wgradk_stream(const bf16* __restrict__ x, const bf16* __restrict__ dy, 
     constexpr int XP = VERT ? 16 : 16 + K - 1;                  // x pixels per ring row
     constexpr int ROWB = (XP + 16) * 64;
     constexpr int NPIECE = VERT ? 2 : 3;
-    constexpr int WK_R = 8, WK_P = 6;      // ring rows per wave / rows in flight (64 / 88 KB of LDS per block: the other streams' kernels still fit on the CU)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -2048,6 +2052,7 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
             static bool attrs = false;
             if (!attrs) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad33_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attrs = true; }
             hipLaunchKernelGGL(k_conv32_wgrad33_stream, dim3((unsigned)blocks), dim3(WS_T), ldss, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W, strips, (int)run);
+            tcct_census_hit(TCCT_CENSUS_WGRAD33_STREAM);
             TCCT_LAUNCH_OK();
         }
     }
@@ -2071,7 +2076,7 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
             blocks = (int)((rows + run - 1) / run);
 #define WK_LAUNCH(KK, V)                                                                                                     \
     do {                                                                                                                    \
-        constexpr size_t ring = (size_t)(WK_T / 64) * 8 * ((V ? 16 : 16 + KK - 1) + 16) * 64, redb = (size_t)KK * 4096;                                     \
+        constexpr size_t ring = (size_t)(WK_T / 64) * WK_R * ((V ? 16 : 16 + KK - 1) + 16) * 64, redb = (size_t)KK * 4096;                                     \
         constexpr size_t ldsk = ring > redb ? ring : redb;                                                                                                     \
         static bool attr = false;                                                                                           \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv32_wgradk_stream<KK, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
@@ -2080,6 +2085,7 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
             if (TAPS == 13) { if (vert) WK_LAUNCH(13, true); else WK_LAUNCH(13, false); }
             else { if (vert) WK_LAUNCH(11, true); else WK_LAUNCH(11, false); }
 #undef WK_LAUNCH
+            tcct_census_hit(TCCT_CENSUS_WGRADK_STREAM);
             TCCT_LAUNCH_OK();
         }
     }

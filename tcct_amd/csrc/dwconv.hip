@@ -348,7 +348,7 @@ template <typename T, int VEC, bool FLIP, int MODE = 0>
 static void dw_fwd_launch(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C, int stride,
                           int Ho, int Wo, int add_input, hipStream_t st, const void* res = nullptr, double* stats = nullptr, const float* xab = nullptr) {
     int segh, wblocks, hstrips;
-    // four columns per thread for the wide bf16 stride-1 images (levels 1-2 of the ViT branch); TCCT_DW_CPT=1 keeps one column (A/B)
+    // four columns per thread for the wide bf16 stride-1 images (levels 1-2 of the ViT branch); set cpt_on = 0 below to keep one column (A/B, rebuild)
     static int cpt_on = -1;
     if (cpt_on < 0) cpt_on = 1;
     if (stride == 1 && VEC == 4 && sizeof(T) == 2 && cpt_on && Wo >= 128 && C >= 32) {      // measured +4 % at 64 channels, slower at 4
@@ -772,7 +772,7 @@ static int dw_wgrad_impl(const void* x, const void* dy, float* dw, float* dbias,
     if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) { tcct_set_error("dwconv3x3_wgrad: memset failed"); return -2; }
     int segh, wblocks, hstrips;
     size_t lds = sizeof(float) * DB * 10 * vec;
-    static int cpt_on = -1;     // TCCT_DW_WGRAD_CPT=0: one column per thread for every shape (A/B timing)
+    static int cpt_on = -1;     // compile-time A/B switch (0: one column per thread for every shape)
     if (cpt_on < 0) cpt_on = 1;
     if (cpt_on && vec == 4 && stride == 1 && dtype == TCCT_BF16 && Wo >= 128 && C >= 32) {
         dw_geometry(N, Ho, Wo, C, vec, 256, 128, segh, wblocks, hstrips, 2);     // (256 blocks: 0.080 -> 0.060 ms at level 2, 0.119 -> 0.103 stride 2 at level 1; 512 the same at level 1 stride 1)

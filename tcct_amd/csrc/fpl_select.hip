@@ -16,8 +16,9 @@
 //             with run-length accumulation in registers and LDS-private [class][bin][32] sums.
 // 4 probability bytes + ceil(log2 M / 8) index bytes = 7 levels at the bench shape; every launch has constant arguments (no host sync).
 // Round 5: ONE launch per level (was two histogram passes + a one-block resolve kernel: 13 + 7 launches): the block-private counters are 16 bits wide (a block
-// sees < 65536 pixels), so all 160 slots of five classes fit one pass, and the block that takes the LAST ticket of a level (atomic counter behind a
-// __threadfence) runs the resolve step itself, reading the merged histogram with agent-scope loads.
+// sees < 65536 pixels), so all 160 slots of five classes fit one pass, and the block that takes the LAST ticket of a level (a relaxed atomic counter behind
+// `s_waitcnt vmcnt(0)` + the block barrier; no __threadfence on the release side) runs the resolve step itself behind ONE agent-scope acquire fence, then
+// reads the merged histogram with plain loads.
 #include "common.h"
 
 #define FS_MAXC 16
@@ -123,12 +124,16 @@ __global__ void __launch_bounds__(FS_TB) k_fs_hist(const uint8_t* __restrict__ l
     // The block that takes the last ticket of this level has every other block's counts behind it: it walks the boundaries one digit down.  Ordering: the
     // histogram atomics execute at the memory side; a wave's `s_waitcnt vmcnt(0)` returns when they have been acknowledged, the barrier collects the waves,
     // then ONE lane takes the ticket.  (__threadfence() here -- an L2 write-back + invalidate per wave, 4096 of them per launch -- made the whole select
-    // 1.08 ms instead of 0.69.)  The last block reads counters that no L2 has cached during this kernel (only atomics touched them): plain loads.
+    // 1.08 ms instead of 0.69.)  Acquire side: the last block alone, once per launch, invalidates what its caches may hold of the histogram and the state
+    // (an agent-scope acquire fence) before it reads them with plain loads -- one fence per launch instead of 4096.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(&tickets[level], 1u) == (uint32_t)(gridDim.x * gridDim.y) - 1u ? 1u : 0u;
     __syncthreads();
-    if (s_last) fs_resolve_body(C, level, nlevels, tb, st, hist);
+    if (s_last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        fs_resolve_body(C, level, nlevels, tb, st, hist);
+    }
 }
 
 // one block (the last one of a level's histogram launch): walk every unresolved boundary one byte down, build the slot list of the next level, clear the histogram for it

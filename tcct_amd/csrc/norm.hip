@@ -11,7 +11,7 @@
 // elements per thread.  4 (8-byte bf16 accesses) is what the kernels were tuned with; the 8-element instantiations (16 bytes per lane)
 // exist and are correct but measured NO better on the MI355X at level 0 (32 ch, 452 MB tensors, same box): bn_apply 0.193 vs 0.19 ms,
 // bn_bwd_apply 0.278 vs 0.24, bn_bwd_reduce 0.222 vs 0.172 ms -- twice the per-channel constants in registers costs occupancy in the
-// 1024-thread reduction blocks, and the 8-byte form already streams at 4.7-5.2 TB/s.  TCCT_BN_VEC8=1 selects them for A/B runs.
+// 1024-thread reduction blocks, and the 8-byte form already streams at 4.7-5.2 TB/s.  They were removed with the other round-3 A/B arms.
 // Also tried (round 2, tools/probe/stream_probe.hip): ONE block-contiguous 8 KB chunk per block instead of persistent blocks.  As a bare
 // y = a x + b kernel that reaches 6.0 TB/s on a 452 MB tensor against 5.3 TB/s for this file's layout (hipMemcpyDtoD: 4.9), and an eval-mode
 // bn_apply built that way ran 0.159 instead of 0.188 ms at level 0.  In the training step it gained nothing (kernel time 30.21 vs 30.18 ms,

@@ -466,7 +466,7 @@ static int bilinear_fwd_impl(const void* x, const void* res, void* y, int N, int
     float sw = align_corners ? (Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f) : (float)W / (float)Wo;
     int vec = (C % 4 == 0) ? 4 : 1;
     hipStream_t st = (hipStream_t)stream;
-    static int v8 = -1;         // TCCT_BILINEAR_VEC8=0: 8-byte accesses for bf16 as well (A/B timing)
+    static int v8 = -1;         // compile-time A/B switch (0: 8-byte accesses for bf16 as well)
     if (v8 < 0) v8 = 1;
     if (v8 && dtype == TCCT_BF16 && C % 8 == 0) {
         hipLaunchKernelGGL((k_bilinear_fwd<bf16, 8>), row_grid(Wo * (C / 8), (int64_t)N * Ho), dim3(PB), 0, st, (const bf16*)x, (bf16*)y, N, H, W, C, Ho, Wo, sh, sw, align_corners, (const bf16*)res);
@@ -493,7 +493,7 @@ extern "C" int tcct_bilinear_bwd(const void* dy, void* dx, int N, int H, int W, 
         const int64_t blocks = (int64_t)N * tilesW * tilesH;
         TCCT_CHECK(blocks < 0x7fffffffLL, "bilinear_bwd: grid too large");
         const size_t lds = sizeof(int) * ((size_t)2 * (BT_DH + DW) * KT + BT_DH + DW);
-        static int v8 = -1;         // TCCT_BILINEAR_VEC8=0: 8-byte accesses for bf16 as well (A/B timing)
+        static int v8 = -1;         // compile-time A/B switch (0: 8-byte accesses for bf16 as well)
         if (v8 < 0) v8 = 1;
         if (v8 && dtype == TCCT_BF16 && C % 8 == 0) {
             hipLaunchKernelGGL((k_bilinear_bwd_tab<bf16, 8>), dim3((unsigned)blocks), dim3(PB), lds, st, (const bf16*)dy, (bf16*)dx, N, H, W, C, Ho, Wo, sh, sw, align_corners, DW, KT, tilesW, tilesH);
@@ -973,7 +973,7 @@ extern "C" int tcct_normadd_fwd(const void* g0, const void* g1, const void* g2, 
     hipStream_t st = (hipStream_t)stream;
     TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_invnorm<T>, dim3(tcct_grid((int64_t)N * h1 * w1 * LP, PB, 1 << 16)), dim3(PB), 0, st, (const T*)g1, inv1, (int64_t)N * h1 * w1, C, eps));
     TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_invnorm<T>, dim3(tcct_grid((int64_t)N * h2 * w2 * LP, PB, 1 << 16)), dim3(PB), 0, st, (const T*)g2, inv2, (int64_t)N * h2 * w2, C, eps));
-    static int banded = -1;         // TCCT_NORMADD_BAND=0: the row-by-row kernel for every shape (A/B timing)
+    static int banded = -1;         // compile-time A/B switch (0: the row-by-row kernel for every shape)
     if (banded < 0) banded = 1;
     if (banded && H == 2 * h1 && H == 4 * h2 && H % 8 == 0) {
         TCCT_DISPATCH(dtype, hipLaunchKernelGGL(k_normadd_fwd_band<T>, row_grid(W * LP, (int64_t)N * (H / 8), 8192), dim3(PB), 0, st, (const T*)g0, (const T*)g1, (const T*)g2, inv1, inv2, (T*)out, N, H, W, C, h1, w1, h2, w2, eps));

@@ -339,7 +339,7 @@ static bool pw_fwd2_ok(int64_t M, int K, int N, int K1, bool has_x2);
 struct PwRes;
 static int pw_fwd2_route(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
                          int stat_pre, tcct_stream_t stream, const bf16* res, const float* rscale, int64_t per_sample, bf16* yplain);
-static bool pw_fwd2_enabled() {         // TCCT_PW_FWD2=0: the direct-from-global forward kernel for every shape (A/B timing)
+static bool pw_fwd2_enabled() {         // compile-time A/B switch (off: the direct-from-global forward kernel for every shape)
     static int on = -1;
     if (on < 0) on = 1;
     return on == 1;

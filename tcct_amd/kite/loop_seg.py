@@ -23,7 +23,7 @@ class KiteSeg(KiteBack):
                             # crash of DESIGN 5b is root-caused (the first validation of fit() is a capture late in a long process)
     _graphed = None
     _graphed_step = None    # --graph=true: tcct_amd.graph.GraphedTrainStep
-    fuse_aux_loss = True    # training: resize + softmax + Dice of the aux heads in one kernel (TCCT_FUSE_AUX=0 disables)
+    fuse_aux_loss = True    # training: resize + softmax + Dice of the aux heads in one kernel (set `KiteSeg.fuse_aux_loss = False` to disable)
 
     def __init__(self, args, **_args):
         self.args = args

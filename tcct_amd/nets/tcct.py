@@ -639,6 +639,8 @@ class FTC(nn.Module):
 
     @property
     def feats(self):
+        """[norm_add([y0, y1, y2])] (reference tcct.py:1035).  Inside a pooled training step the feature-polarization loss sends its gradient towards `feats` as a
+        recipe, not as a tensor (ops.grad_is_watched documents who still sees the dense d loss / d feats: retain_grad() / hooks set BEFORE the loss is formed)."""
         if self._feats is None and self._feats_src is not None:
             if self.legacy_heads:
                 raise TcctError('the legacy-head layout (onnx/tcct_goals.py) is supported for inference and Dice/boundary training; its '

@@ -63,7 +63,7 @@ ZERO = _ZeroPool()
 # The bf16 [tap][co][ci] packs (+ the flipped / transposed input-gradient packs) of the ~40 dense 32 -> 32 convolutions used to be made by one
 # small launch per convolution per step (39 x ~5 us on the critical stream).  Convolutions seen during a pooled step are remembered; from the
 # next step on begin_step() re-packs ALL of them with one launch (the optimizer has just changed the weights) and the forward pass picks its
-# pack out of the cache.  TCCT_PACK_ALL=0 restores the per-call launches.
+# pack out of the cache.  `PACK_ALL = False` (bench.py --set PACK_ALL=0) restores the per-call launches.
 PACK_ALL = True
 # ent: id(weight) -> [weakref(weight), pack buffer, (KH, KW), data_ptr, step last looked up].  Entries hold NO strong reference to the weight:
 # a dead model's entries disappear at the next begin_step(), as do entries no convolution asked for during the previous step.
@@ -385,7 +385,7 @@ def _conv_slabs_fwd(x, w, bias, y, N, H, W, Cin, Cout, KH, KW, padh, padw, trans
 # Fused 3x3 conv32 backward (tcct_conv32_bwd3x3): correct and tested, but OFF by default -- alone it takes 0.49 ms against 0.23 + 0.31 ms for
 # the separate input-gradient / weight-gradient kernels at level 0, and inside the step it gains nothing (29.3 vs 29.3 ms, same box): the
 # separate weight gradient runs on the side stream beside the input-gradient chain, the fused kernel sits on the critical path and is
-# bound by the latency of its one 8-wave block per CU (111 KB of LDS), not by HBM.  TCCT_FUSED_CONV_BWD=1 enables it.
+# bound by the latency of its one 8-wave block per CU (111 KB of LDS), not by HBM.  `bench.py --set FUSED_CONV_BWD=1` enables it.
 FUSED_CONV_BWD = False
 FUSED_PW_BWD = True        # False: separate input-gradient / weight-gradient kernels (A/B timing)
 
@@ -674,27 +674,40 @@ class _ConvChain33(torch.autograd.Function):
             return dskip, None, None, None, None, None, None
         dy = _c(dy)
         N, H, W, _ = x.shape
-        dmid = torch.empty_like(x)
-        wt2 = ctx.wp_t2
-        if wt2 is None:
-            wt2 = torch.empty(9 * 1024, device=x.device, dtype=torch.bfloat16)
-            lib.conv32_pack_weights(w2, wt2, 3, 3, 1)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            wt1 = ctx.wp_t1
-            if wt1 is None:
-                wt1 = torch.empty(9 * 1024, device=x.device, dtype=torch.bfloat16)
-                lib.conv32_pack_weights(w1, wt1, 3, 3, 1)
-            dx = torch.empty_like(x)
-            lib.conv32_chain33(dy, wt2, None, dmid, wt1, None, dx, _as(dskip, x.dtype) if dskip is not None else None, N, H, W, None)
+        # what is asked for (a frozen block12 must neither cost two full-resolution weight-gradient passes nor have its slots in the flat gradient
+        # buffer written -- AdamW would step a frozen parameter): as _Conv2d.backward, by ctx.needs_input_grad
+        nx, nw1, nb1, nw2, nb2 = ctx.needs_input_grad[:5]
+        g1, g2 = nw1 or (pb1 is not None and nb1), nw2 or (pb2 is not None and nb2)
+        need_mid = nx or g1             # d mid feeds the input-gradient chain and the first convolution's weight gradient
+        dx = dmid = None
+        if need_mid:
+            wt2 = ctx.wp_t2
+            if wt2 is None:
+                wt2 = torch.empty(9 * 1024, device=x.device, dtype=torch.bfloat16)
+                lib.conv32_pack_weights(w2, wt2, 3, 3, 1)
+            dmid = torch.empty_like(x) if g1 else None          # nobody reads d mid when the first convolution is frozen: the chain does not store it
+            if nx:
+                wt1 = ctx.wp_t1
+                if wt1 is None:
+                    wt1 = torch.empty(9 * 1024, device=x.device, dtype=torch.bfloat16)
+                    lib.conv32_pack_weights(w1, wt1, 3, 3, 1)
+                dx = torch.empty_like(x)
+                lib.conv32_chain33(dy, wt2, None, dmid, wt1, None, dx, _as(dskip, x.dtype) if dskip is not None else None, N, H, W, None)
+            else:
+                lib.conv32_fwd(dy, wt2, None, dmid, N, H, W, 3, 3, 1, 1)
+                dx = dskip
         else:
-            lib.conv32_fwd(dy, wt2, None, dmid, N, H, W, 3, 3, 1, 1)
             dx = dskip
-        with _wgrad_stream(_slot_written(p1, pb1, p2, pb2), x, mid, dy, dmid):
-            dw2, db2 = _grad_out(p2, tuple(w2.shape)), (_grad_out(pb2) if pb2 is not None else None)
-            lib.conv32_wgrad(mid, dy, dw2, db2, N, H, W, 3, 3, 1, 1)
-            dw1, db1 = _grad_out(p1, tuple(w1.shape)), (_grad_out(pb1) if pb1 is not None else None)
-            lib.conv32_wgrad(x, dmid, dw1, db1, N, H, W, 3, 3, 1, 1)
+        dw1 = db1 = dw2 = db2 = None
+        if g1 or g2:
+            with _wgrad_stream(_slot_written(p1 if g1 else None, pb1 if g1 else None, p2 if g2 else None, pb2 if g2 else None),
+                               *[t for t in (x, mid, dy, dmid) if t is not None]):
+                if g2:
+                    dw2, db2 = _grad_out(p2, tuple(w2.shape)), (_grad_out(pb2) if pb2 is not None else None)
+                    lib.conv32_wgrad(mid, dy, dw2, db2, N, H, W, 3, 3, 1, 1)
+                if g1:
+                    dw1, db1 = _grad_out(p1, tuple(w1.shape)), (_grad_out(pb1) if pb1 is not None else None)
+                    lib.conv32_wgrad(x, dmid, dw1, db1, N, H, W, 3, 3, 1, 1)
         return dx, _ret(dw1, p1), _ret(db1, pb1), _ret(dw2, p2), _ret(db2, pb2), None, None
 
 
@@ -1672,7 +1685,7 @@ class _DwConv(torch.autograd.Function):
                 lib.dwconv3x3_dgrad(dy, w, dx, N, H, W, C, stride, int(add_input), dtype_code(x.dtype))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             # on the weight-gradient side stream like the dense convolutions' (round 4, last day: the ten depthwise weight gradients were 0.85 ms of the
-            # ViT branch's input-gradient chain; TCCT_DW_WGRAD_SIDE=0 keeps them inline)
+            # ViT branch's input-gradient chain; `DW_WGRAD_SIDE = False` / bench.py --set DW_WGRAD_SIDE=0 keeps them inline)
             keep = (x, dy) if ctx.xab is None else (x, dy, ctx.xab)
             with _wgrad_stream(DW_WGRAD_SIDE and _slot_written(w, ctx.bias_param if has_bias else None), *keep):
                 dw = _grad_out(w)
@@ -1772,7 +1785,7 @@ class _BatchNorm(torch.autograd.Function):
 # BatchNorm's input (Conv2d_BN, DWConv2d_BN.pwconv, FTC.tran_*), the fused pointwise backward kernel rebuilds the convolution's output
 # gradient from (dz, y) while staging its tiles (tcct_pw_bwd_bn): the backward apply pass disappears (3 passes -> 1 extra read).  Where a
 # 1x1 convolution CONSUMES a BatchNorm's output as the last contributor to its gradient, the same kernel accumulates that BatchNorm's two
-# backward sums in its dx epilogue (`BnLink`): the backward reduce pass disappears too (2 passes -> 1 extra read).  TCCT_BN_FUSE=0 restores
+# backward sums in its dx epilogue (`BnLink`): the backward reduce pass disappears too (2 passes -> 1 extra read).  `BN_FUSE = False` (bench.py --set BN_FUSE=0) restores
 # the separate kernels (A/B timing, bisecting).
 BN_FUSE = True
 BN_FUSE_RED = True       # False: keep the separate reduction kernels (A/B timing of the epilogue form)
@@ -2696,7 +2709,7 @@ def l2norm(x, eps=1e-12):
 # read three times.  A placeholder that autograd had to ADD to another gradient (a second differentiable consumer of feats, the FPL evaluated twice
 # on the same feats) arrives as a dense tensor without the FPL part: every recipe is therefore ALSO filed under its producer (`pending`), and a
 # producer whose incoming gradient is not the single placeholder materialises the pending recipes (tcct_fpl_backward) and adds them.  A feats tensor
-# with hooks / retain_grad (somebody wants to SEE the gradient) never takes the lazy path.  TCCT_FPL_LAZY_GRAD=0 restores the dense tensor everywhere.
+# with hooks / retain_grad (somebody wants to SEE the gradient) never takes the lazy path.  `FPL_LAZY_GRAD = False` (bench.py --set FPL_LAZY_GRAD=0) restores the dense tensor everywhere.
 FPL_LAZY_GRAD = True
 _FPL_LAZY = {'producers': set(), 'grads': {}, 'pending': {}}
 
@@ -3130,7 +3143,12 @@ class _Fpl(torch.autograd.Function):
 
 
 def grad_is_watched(t):
-    """somebody hooks `t` or retains its gradient, i.e. wants to SEE d loss / d t"""
+    """somebody hooks `t` or retains its gradient, i.e. wants to SEE d loss / d t.
+
+    LIMITATION (only what exists when fpl() runs is visible here): `torch.autograd.grad(loss, feats)` and a hook registered on `feats` AFTER the loss was
+    formed are not: inside a pooled training step they receive the zero-stride all-zero PLACEHOLDER of the lazy route (the real gradient travels as a
+    (labels, bins, table) recipe into norm_add's backward kernels and still reaches every weight).  A caller who wants the dense d loss / d feats calls
+    `feats.retain_grad()` / registers the hook BEFORE `RegNet.regular_udh`, or `ops.fpl(..., allow_lazy=False)`, or sets `ops.FPL_LAZY_GRAD = False`."""
     return bool(getattr(t, 'retains_grad', False)) or bool(getattr(t, '_backward_hooks', None))
 
 

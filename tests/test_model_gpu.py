@@ -418,48 +418,48 @@ def test_bf16_dice_within_1e3_of_fp32(tmp_path):
         assert abs(d32 - d16) < 1e-3, (tag, d32, d16)
 
 
-@pytest.mark.parametrize('mode', ['no_kiteseg', 'kiteseg_lazy_feats', 'kiteseg_eager'])
-def test_feature_polarization_gradient_reaches_the_decoder(mode, tmp_path):
+def test_feature_polarization_gradient_reaches_the_decoder(tmp_path):
     """round 5 (advisor, high): `feats` must carry gradient whenever the feature-polarization loss can read it.  The aux heads are composed through
     the t32x convolutions (g0..g2 never written, `feats` rebuilt WITHOUT gradient) only when the owner set FTC.compose_heads -- KiteSeg does when
     --udh is off.  Reference-style use (RegNet(stc_tt()) + regular_udh without KiteSeg, reference nets/reg.py:86-105) and --udh with lazy feats
-    (TCCT_EAGER_FEATS=0) must deliver d udh / d decoder weights, equal to the eager route's."""
+    (TCCT_EAGER_FEATS=0) must deliver d udh / d decoder weights, equal to the eager route's.  The three routes run inside ONE test (round 6, advisor): the
+    cross-route comparison cannot be skipped by -k selection or test distribution."""
     import tcct_oracle as O
+    from tcct_amd import ops
     img, lab = O.synth_batch(2, 64, 64, seed=9)
     img, lab = img[:, :1].cuda(), lab.cuda()
-    model, _ = build(torch.float32)
-    model.base.base_vit.drop_probs = [0.0] * 4
-    if mode != 'no_kiteseg':
-        make_kite(model, tmp_path, True, False)
-        assert model.base.compose_heads is False
-        model.base.eager_feats = mode == 'kiteseg_eager'
-    else:
-        assert model.base.compose_heads is False and model.base.eager_feats is False      # the defaults a reference-style caller gets
-    from tcct_amd import ops
-    ops.begin_step(img.device)
-    try:
-        out = model(img)
-        feats = model.base.feats[0]
-        assert feats.requires_grad
-        los = model.regular_udh(out[0], lab)
-        los.backward()
-    finally:
-        ops.end_step()
     names = ('base.dec4.prep.0.weight', 'base.t324.weight', 'base.t323.weight', 'base.t322.weight', 'base.dec3.post.0.weight',
              'base.base_cnn.path_estan.0.block5.0.weight')
-    got = {n: p.grad for n, p in model.named_parameters() if n in names}
-    for n in names:
-        assert got[n] is not None and torch.isfinite(got[n]).all() and got[n].abs().max().item() > 0, n
-    # nothing but the FPL was differentiated: the aux heads (which only the Dice criterion reads) get no gradient
-    assert model.base.aux0.weight.grad is None or model.base.aux0.weight.grad.abs().max().item() == 0
-    ref = getattr(test_feature_polarization_gradient_reaches_the_decoder, '_ref', None)
-    cur = {n: got[n].detach().float().cpu() for n in names}
-    if ref is None:
-        test_feature_polarization_gradient_reaches_the_decoder._ref = cur
-    else:           # the three routes compute the same gradient
+    res = {}
+    for mode in ('no_kiteseg', 'kiteseg_lazy_feats', 'kiteseg_eager'):
+        model, _ = build(torch.float32)
+        model.base.base_vit.drop_probs = [0.0] * 4
+        if mode != 'no_kiteseg':
+            make_kite(model, tmp_path / mode, True, False)
+            assert model.base.compose_heads is False
+            model.base.eager_feats = mode == 'kiteseg_eager'
+        else:
+            assert model.base.compose_heads is False and model.base.eager_feats is False      # the defaults a reference-style caller gets
+        ops.begin_step(img.device)
+        try:
+            out = model(img)
+            feats = model.base.feats[0]
+            assert feats.requires_grad
+            los = model.regular_udh(out[0], lab)
+            los.backward()
+        finally:
+            ops.end_step()
+        got = {n: p.grad for n, p in model.named_parameters() if n in names}
+        for n in names:
+            assert got[n] is not None and torch.isfinite(got[n]).all() and got[n].abs().max().item() > 0, (mode, n)
+        # nothing but the FPL was differentiated: the aux heads (which only the Dice criterion reads) get no gradient
+        assert model.base.aux0.weight.grad is None or model.base.aux0.weight.grad.abs().max().item() == 0
+        res[mode] = {n: got[n].detach().float().cpu() for n in names}
+    ref = res['no_kiteseg']
+    for mode in ('kiteseg_lazy_feats', 'kiteseg_eager'):      # the three routes compute the same gradient
         for n in names:
             sc = ref[n].abs().max().item()
-            assert (cur[n] - ref[n]).abs().max().item() <= 2e-3 * sc, (mode, n)
+            assert (res[mode][n] - ref[n]).abs().max().item() <= 2e-3 * sc, (mode, n)
 
 
 def test_compose_heads_is_set_only_without_udh(tmp_path):
@@ -590,6 +590,36 @@ def test_real_checkpoint_inference_matches_reference(name, dtype):
     else:
         assert e < 0.02 and min(agree) > 0.998, (e, agree)
     assert len(np.unique(masks[0])) >= 4            # a real multi-layer segmentation, not a constant map
+    # round 6: the metric of the 1e-3 criterion itself -- MDiceLoss.scorem(start_idx=1), reference kite/losses/miou.py:87-91 -- in EVAL mode,
+    # the regime it is defined for.  The reference ships no ground truth for this B-scan, so the label is a segmentation the fixture holds: the reference's own level-1
+    # aux-head mask (an independent, coarser prediction of the same image).  Dice(reference mask, label) against Dice(HIP mask, label); and, printed beside it, the
+    # Dice of the HIP mask WITH the reference's mask as the label (1.0 = identical masks).
+    from tcct_amd.kite.losses import MDiceLoss, MaskOneHot
+    C_ = int(z['n_class'])
+    oh = lambda m: MaskOneHot(torch.from_numpy(np.ascontiguousarray(m[None])).cuda().to(torch.uint8), C_)      # noqa: E731
+    label = torch.from_numpy(np.ascontiguousarray(z['masks'][1][None])).long().cuda()
+    d_ref = MDiceLoss.scorem(oh(z['masks'][0]), label, start_idx=1).item()
+    d_hip = MDiceLoss.scorem(oh(masks[0].astype(np.uint8)), label, start_idx=1).item()
+    d_self = MDiceLoss.scorem(oh(masks[0].astype(np.uint8)), torch.from_numpy(np.ascontiguousarray(z['masks'][0][None])).long().cuda(), start_idx=1).item()
+    ref0 = torch.from_numpy(np.ascontiguousarray(z['masks'][0][None])).long().cuda()
+    per_class = MDiceLoss.scores(oh(masks[0].astype(np.uint8)), ref0)          # Dice of the HIP mask with the reference's mask as the label, class by class
+    npix = np.bincount(z['masks'][0].reshape(-1), minlength=C_)
+    flips = int((masks[0] != z['masks'][0]).sum())
+    print(name, dtype, f'eval-mode Dice vs the aux-head label: reference {d_ref:.6f}, HIP {d_hip:.6f} (delta {abs(d_ref - d_hip):.2e}); HIP mask vs reference mask {d_self:.6f}; '
+          f'{flips} of {masks[0].size} pixels differ; per class (reference pixels, Dice): {[(int(n_), round(d_, 4)) for n_, d_ in zip(npix, per_class)]}')
+    # MDiceLoss.scorem is a MEAN OVER CLASSES of (2I + 1) / (P + G + 1): a class the reference mask holds a handful of pixels of (or none: one stray pixel -> 0.5)
+    # moves the mean by several 1e-2 per flipped pixel.  Asserted: every class the reference gives >= 1 % of the image agrees to 5e-3; the 1e-3 criterion itself on the
+    # 5-class GOALS checkpoint (the BASELINE configuration: thick layers, no near-empty class); the 9-class Duke crop (classes of 0-60 pixels) is a FINDING with a
+    # frozen bound, like its train-mode counterpart (BF16_FINDINGS).
+    for c_ in range(1, C_):
+        if npix[c_] >= 0.01 * masks[0].size:
+            assert per_class[c_] >= 0.995, (c_, int(npix[c_]), per_class[c_])
+    if dtype == torch.float32:
+        assert flips == 0 and abs(d_ref - d_hip) <= 1e-6
+    elif name == 'goals_legacy':
+        assert abs(d_ref - d_hip) <= 1e-3 and d_self >= 0.999, (d_ref, d_hip, d_self)
+    else:
+        assert abs(d_ref - d_hip) <= 5e-3, (d_ref, d_hip)           # measured 3.2e-3 (12 of 25 600 pixels differ)
 
 
 @pytest.mark.parametrize('name', ['duke', 'goals_legacy'])
@@ -938,8 +968,10 @@ def _traj_errors(fx, model, k, sd0, steps):
 @pytest.mark.parametrize('name', ['traj5_di', 'traj5_reg', 'traj5_full'])
 def test_five_step_trajectory_matches_the_reference_fp32(name, tmp_path):
     """Five consecutive steps of the reference's own loop (kite/loop_seg.py:108-142; AdamW + clip + CyclicLR, kite/loopback.py:102-128) from the
-    reference-trained checkpoint, per loss configuration (BASELINE cfg1-2 / cfg3 / cfg4): every per-step loss part and total gradient norm at the
-    literal 1e-3; after step 5 the weights' displacement, Adam's first and second moments (bias correction at t >= 2, lr changed by the scheduler
+    reference-trained checkpoint, per loss configuration (BASELINE cfg1-2 / cfg3 / cfg4): the per-step loss TOTAL and total gradient norm are the reference's own
+    values; the per-step loss PARTS (Dice / udh / reg) are ORACLE values evaluated at the reference's state -- the reference's loop returns only the total
+    (kite/loop_seg.py:146-171), so oracle/make_golden_traj5.py:178-196 records the oracle's parts and asserts that they add up to the reference's total at 2e-5 --
+    all at the literal 1e-3; after step 5 the weights' displacement, Adam's first and second moments (bias correction at t >= 2, lr changed by the scheduler
     after step 3), every BatchNorm running mean / variance at 1e-3 and num_batches_tracked exactly (lap_map's BatchNorm runs twice per step)."""
     fx, model, k, sd0, steps = _traj_run(name, torch.float32, tmp_path)
     e, worst = _traj_errors(fx, model, k, sd0, steps)
