@@ -44,6 +44,7 @@ def parse():
                    help="token mixer: 'pool' = the reference's stc_tt (headline); 'factor' = its commented-out factorised attention (not the headline)")
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--no-other-workloads', action='store_true', help="skip the --los=di+reg / di+reg+fpl lines (`config.other_workloads`) that follow the headline loop at N=1")
     p.add_argument('--roofline-only', action='store_true', help='only run the dominant-kernel timing loop (for rocprofv3)')
     p.add_argument('--wgrad-mode', type=int, default=0, help='A/B arms of the weight-gradient kernels (tcct_conv32_wgrad_mode: 0 default, 4 = shifted lines for 1xK / Kx1)')
     p.add_argument('--conv-mode', type=int, default=0, help='A/B arms of the 3x3 forward kernels (tcct_conv32_fwd_mode: 0 default, 1 = tiled)')
@@ -142,7 +143,7 @@ def dominant_kernel_roofline(a, iters=20):
         fn = lambda: lib.conv32f_fwd(x, wpf, b, None, y, a.bs, a.height, Wp, 3, 3, 1, 1)                      # noqa: E731
         fn2 = lambda: lib.conv32f_wgrad(x, dy, dw, db, a.bs, a.height, Wp, 3, 3, 1, 1)                       # noqa: E731
 
-    # Spin-up: the first ~10 ms of GPU activity after an idle period are a clock / power-management transient (tools/dbg_iters.py: the same
+    # Spin-up: the first ~10 ms of GPU activity after an idle period are a clock / power-management transient (round 2's launch-by-launch timing: the same
     # launch reads 0.202 ms, climbs to 0.24 around launches 10-40 and settles at 0.197 from launch ~60 on, and stays there across short syncs).
     # A training step is 25 ms of back-to-back kernels, so the settled state is the representative one; a neutral kernel (a device copy) does the
     # spin-up so that EVERY launch of the timed kernels -- also the ones rocprofv3 averages over in `--roofline-only` -- is in that state.
@@ -227,7 +228,7 @@ def dominant_kernel_roofline(a, iters=20):
             cnt = torch.empty(16, device='cuda', dtype=torch.int32); bm = torch.empty(Mf, device='cuda', dtype=torch.uint8)
             ps = torch.empty((5, 32, 32), device='cuda')
             tf_ = timed(lambda: lib.fpl_select(x, labf, probf, Mf, 5, ws, cnt, bm, ps, 1))
-            entry('tcct_fpl_select: radix multi-select of the bin boundaries (k_fs_hist x 13, k_fs_resolve x 7, k_fs_assign) + bin sums on MFMA (k_fs_binsum_mfma); '
+            entry('tcct_fpl_select: radix multi-select of the bin boundaries (k_fs_hist x 7: one launch per radix level, the block with the last ticket resolves; k_fs_assign) + bin sums on MFMA (k_fs_binsum_mfma), 9 launches; '
                   'replaces rocPRIM radix_sort_pairs + the sorted gather', tf_, 2.0 * x.numel() + Mf * (1 + 4 + 1))
             # the same on a TRAINED network's distribution: saturated, tie-heavy probabilities (most pixels at exactly 1.0, the rest spread): more radix
             # levels have to be resolved before the boundaries separate
@@ -299,26 +300,38 @@ def optimizer_ms(k, iters=20):
     return round(e0.elapsed_time(e1) / iters, 4)
 
 
+def _cpu_model():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.lower().startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or 'unknown'
+
+
 def cpu_baseline(a):
     """oracle (CPU port of the reference path, pinned to the reference by tests/golden) on the host cores: full steps
     (fwd + Dice deep supervision [+reg+fpl] + bwd + clip + AdamW) on ONE full-size B-scan (3x800x1104 fp32).  The thread
-    count is calibrated first (torch's CPU backend gets SLOWER beyond 16-32 threads on the 2x64-core EPYC GPU boxes)."""
+    count is calibrated first (torch's CPU backend gets SLOWER beyond 16-32 threads on the 2x64-core EPYC GPU boxes).
+    BASELINE.md 3 also asks for BASELINE.json configs[0] exactly (bs 2, 64x64, --los=di: 5 warm-up + 20 timed steps) and for the full-loss
+    GOALS-shape line: both ride along as `cfg1` / `full_loss` (the headline `value` stays the workload of the GPU line)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import tcct_oracle as O
     keys = [(k, tuple(s)) for k, s in json.load(open(os.path.join(ROOT, 'tests', 'golden', 'state_dict_keys.json')))]
-    udh, reg = 'fpl' in a.los or 'udh' in a.los, 'reg' in a.los
     Wp = (a.width + 15) // 16 * 16
 
-    def one_step(H, W, state):
+    def one_step(H, W, state, udh, reg, bs=1):
         if state is None:
             sd = O.formula_state_dict(keys)
             names = [k for k, v in sd.items() if v.is_floating_point() and not k.endswith(('running_mean', 'running_var'))
                      and not k.startswith('fcp.')]                 # unused parameters simply end up with grad None
             for n in names:
                 sd[n].requires_grad_(True)
-            img, lab = O.synth_batch(1, H, W, seed=2023)
+            img, lab = O.synth_batch(bs, H, W, seed=2023)
             oh = torch.nn.functional.one_hot(lab, 5).permute(0, 3, 1, 2)
-            noise = (torch.rand(1, 4, H, W), torch.rand(1, 4, H, W), torch.rand(1, 1, H, 1), torch.rand(1, 1, H, 1)) if reg else None
+            noise = (torch.rand(bs, 4, H, W), torch.rand(bs, 4, H, W), torch.rand(1, 1, H, 1), torch.rand(1, 1, H, 1)) if reg else None
             state = dict(sd=sd, names=names, img=img, oh=oh, noise=noise, M=None, V=None, step=0)
         sd, names = state['sd'], state['names']
         for n in names:
@@ -334,26 +347,45 @@ def cpu_baseline(a):
         O.clip_adamw_step(P, [p.grad for p in P], state['M'], state['V'], state['step'], 1e-6)
         return time.time() - t0, state
 
+    def timed(H, W, udh, reg, bs, warm, n):
+        st = None
+        for _ in range(warm):
+            _, st = one_step(H, W, st, udh, reg, bs)
+        ts = []
+        for _ in range(n):
+            t, st = one_step(H, W, st, udh, reg, bs)
+            ts.append(t)
+        return sum(ts) / len(ts)
+
+    udh, reg = 'fpl' in a.los or 'udh' in a.los, 'reg' in a.los
     ncpu = os.cpu_count() or 1
+    model = _cpu_model()
     best, best_t = None, 1e30
     for th in (8, 16, 32, 64):
         if th > ncpu:
             break
         torch.set_num_threads(th)
-        _, st = one_step(208, 288, None)
-        t, _ = one_step(208, 288, st)
+        _, st = one_step(208, 288, None, udh, reg)
+        t, _ = one_step(208, 288, st, udh, reg)
         if t < best_t:
             best, best_t = th, t
     torch.set_num_threads(best)
-    _, st = one_step(a.height, Wp, None)          # warm-up (oneDNN primitive creation)
-    ts = []
-    for _ in range(3):
-        t, st = one_step(a.height, Wp, st)
-        ts.append(t)
-    dt = sum(ts) / len(ts)
-    return {'value': round(1.0 / dt, 4), 'unit': 'B-scans/s', 'cores': best, 'kind': 'port',
-            'sample': f'3 timed steps (after 1 warm-up), bs=1, 3x{a.height}x{Wp} fp32, --los={a.los}; oracle/tcct_oracle.py on torch CPU '
-                      f'{torch.__version__}; {best} threads = fastest of 8/16/32/64 on this {ncpu}-CPU host; {dt:.2f}s/step'}
+    dt = timed(a.height, Wp, udh, reg, 1, 1, 3)          # 1 warm-up (oneDNN primitive creation) + 3 timed
+    out = {'value': round(1.0 / dt, 4), 'unit': 'B-scans/s', 'cores': best, 'kind': 'port', 'cpu_model': model,
+           'sample': f'3 timed steps (after 1 warm-up), bs=1, 3x{a.height}x{Wp} fp32, --los={a.los}; oracle/tcct_oracle.py on torch CPU '
+                     f'{torch.__version__}; {best} threads = fastest of 8/16/32/64 on this {ncpu}-CPU host ({model}); {dt:.2f}s/step'}
+    # BASELINE.json configs[0] exactly: stc_tt --los=di, bs 2, 64 x 64 crops, fp32; 5 warm-up + 20 timed steps.  Small maps want few threads.
+    th1 = min(best, 8)
+    torch.set_num_threads(th1)
+    d1 = timed(64, 64, False, False, 2, 5, 20)
+    out['cfg1'] = {'value': round(2.0 / d1, 3), 'unit': 'B-scan crops/s', 'cores': th1, 'kind': 'port',
+                   'sample': f'BASELINE.json configs[0]: stc_tt --los=di bs=2 3x64x64 fp32, 5 warm-up + 20 timed steps, {d1 * 1e3:.1f} ms/step, {th1} threads'}
+    torch.set_num_threads(best)
+    if not (udh and reg):
+        d2 = timed(a.height, Wp, True, True, 1, 1, 2)
+        out['full_loss'] = {'value': round(1.0 / d2, 4), 'unit': 'B-scans/s', 'cores': best, 'kind': 'port',
+                            'sample': f'--los=di+reg+fpl (BASELINE.json configs[3] loss set), bs=1, 3x{a.height}x{Wp} fp32, 1 warm-up + 2 timed steps, {d2:.2f}s/step'}
+    return out
 
 
 _RESULT_OUT = None
@@ -523,9 +555,35 @@ def main():
         except Exception as e:                                  # noqa: BLE001
             out['config']['nccl_version'] = f'unavailable: {e}'
     out['config']['clip_adamw_ms'] = None if stub else optimizer_ms(k)
+    if world == 1 and not stub and not a.no_other_workloads and not a.no_cpu_baseline and a.los == 'di':      # (the profiling / A-B tools all pass --no-cpu-baseline)
+        # BASELINE.json configs[2] / [3] on the same box, in the same line (the headline `value` stays configs[1]): a fresh trainer per loss set -- the optimizer's
+        # flat layout and the model's head composition depend on the loss flags -- 3 warm-up + 10 timed steps each, the same barrier-free single-rank timing.
+        del k
+        torch.cuda.empty_cache()
+        others = []
+        for los in ('di+reg', 'di+reg+fpl'):
+            a2 = argparse.Namespace(**dict(vars(a), los=los))
+            k2, ds2, _ = build_trainer(a2, world)
+            k2.model.train()
+            b2 = ds2.make_batch(a.bs, seed=2023 + rank)
+            i2, l2, _, _ = ds2.parse(b2)
+            i2, l2 = i2.contiguous(), l2.contiguous()
+            for _ in range(3):
+                k2.train_step(i2, l2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                lz = k2.train_step(i2, l2)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t1
+            others.append({'workload': f'stc_tt --los={los} bs={a.bs}/GPU 1x{a.height}x{a.width}', 'ms_per_step': round(d2 / 10 * 1e3, 3),
+                           'value': round(a.bs * 10 / d2, 3), 'unit': 'B-scans/s', 'steps': 10, 'warmup': 3, 'loss_last': round(float(lz.item()), 4)})
+            del k2, ds2, i2, l2, b2
+            torch.cuda.empty_cache()
+        out['config']['other_workloads'] = others
     if roof is not None:
         out['roofline'] = roof
-        out['roofline']['measured'] = 'before the training loop (quiet allocator), after a 120-copy spin-up (clock transient of the first ~10 ms of GPU activity: tools/dbg_iters.py)'
+        out['roofline']['measured'] = 'before the training loop (quiet allocator), after a 120-copy spin-up (clock transient of the first ~10 ms of GPU activity, see dominant_kernel_roofline)'
         out['roofline']['copy_ceiling'] = copyc
         # whole-step view against the layer-granular traffic model of SURVEY §8(d): 7.38 GB (bf16) / 14.8 GB (fp32) per B-scan
         per_img = 7.38e9 if a.dtype == 'bf16' else 14.8e9
