@@ -48,7 +48,7 @@ def parse():
     p.add_argument('--roofline-only', action='store_true', help='only run the dominant-kernel timing loop (for rocprofv3)')
     p.add_argument('--wgrad-mode', type=int, default=0, help='A/B arms of the weight-gradient kernels (tcct_conv32_wgrad_mode: 0 default, 4 = shifted lines for 1xK / Kx1)')
     p.add_argument('--conv-mode', type=int, default=0, help='A/B arms of the 3x3 forward kernels (tcct_conv32_fwd_mode: 0 default, 1 = tiled)')
-    p.add_argument('--set', type=str, default='', help='A/B: comma-separated NAME=0|1 assignments of tcct_amd.ops module constants (e.g. FUSED_CONV_BWD=1)')
+    p.add_argument('--set', type=str, default='', help='A/B: comma-separated NAME=value assignments of tcct_amd.ops module constants (switches 0|1, e.g. FUSED_CONV_BWD=1; integer constants, e.g. STAGE_FORK_MAX_PIXELS=0)')
     return p.parse_args()
 
 
@@ -469,7 +469,8 @@ def main():
             k_, v_ = kv.split('=')
             if not hasattr(_ops, k_):
                 raise SystemExit(f'--set: tcct_amd.ops has no constant {k_}')
-            setattr(_ops, k_, bool(int(v_)))
+            cur_ = getattr(_ops, k_)
+            setattr(_ops, k_, int(v_) if isinstance(cur_, int) and not isinstance(cur_, bool) else bool(int(v_)))
     if not stub and (a.wgrad_mode or a.conv_mode):
         from tcct_amd._lib import lib as _lib
         _lib.conv32_wgrad_mode(a.wgrad_mode)

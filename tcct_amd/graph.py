@@ -27,6 +27,7 @@ class GraphedPredict:
     def __init__(self, model, warmup=2):
         self.model, self.warmup = model, warmup
         self._cache = {}
+        ops.graphs_exclude_stage_fork('GraphedPredict')
 
     def _capture(self, img):
         from ._lib import lib
@@ -88,6 +89,7 @@ class GraphedTrainStep:
         self.calls = 0
         self.graph = None
         self.stream = ops.fresh_stream()          # never an alias of the library's side streams (pool of 32 streams, round-robin)
+        ops.graphs_exclude_stage_fork('GraphedTrainStep')
         self.shape = None
 
     def __call__(self, img, lab):

@@ -35,6 +35,9 @@ class KiteSeg(KiteBack):
         self.best_dice = -1.0
         import os
         self.use_graph = os.environ.get('TCCT_GRAPH', '0') == '1'
+        if self.use_graph or getattr(args, 'graph', False):
+            from .. import ops
+            ops.graphs_exclude_stage_fork('KiteSeg(--graph=true / TCCT_GRAPH=1)')      # before the first step: captures and the nested stage fork exclude each other
         from .. import dist as tdist
         self.world, self.rank = (tdist.world_rank() if args.pl else (1, 0))
         self.fuse_aux_loss = True

@@ -439,8 +439,21 @@ class MHCA_stage(nn.Module):
             else:
                 f, x1 = ops.conv2d_fork(x, c1.conv.weight, None, 1, 0, stats_pre='none' if c1.bn.training else None)
                 f = _bn(c1.bn, f, post='hswish')
-            e, x2 = self.mhca_blks[0](x1, scales, fork=True)
-            r = self.InvRes.tail(f, x2, flink)
+            if ops.PARALLEL_BRANCHES and x.shape[0] * x.shape[1] * x.shape[2] <= ops.STAGE_FORK_MAX_PIXELS and torch.cuda.is_available():
+                # small maps (stages 2-3 at the bench shape): every launch of the stage is latency-bound and the two halves -- InvRes: dw -> norm -> conv2 (+ x);
+                # encoder: cpe -> LayerNorm / mixer -> Mlp -- only share x: the encoder goes to a stream of its own (autograd replays its backward there).  The
+                # aliases keep their order: x2 is a view of x1, no kernel of the encoder stands between conv1 and the InvRes tail.
+                x2h = []
+
+                def enc():
+                    e_, x2_ = self.mhca_blks[0](x1, scales, fork=True)
+                    x2h.append(x2_)             # the residual alias: a view made by the encoder's first node, no kernel behind it
+                    return e_
+                # run_parallel issues the encoder first (its stream), then the InvRes tail here, then joins
+                r, e = ops.run_parallel('vit_enc', lambda: self.InvRes.tail(f, x2h[0], flink), enc)
+            else:
+                e, x2 = self.mhca_blks[0](x1, scales, fork=True)
+                r = self.InvRes.tail(f, x2, flink)
         else:
             r = self.InvRes(x)
             e = self.mhca_blks[0](x, scales)

@@ -752,6 +752,22 @@ def conv3x3_chain(x, w1, b1, w2, b2, stats_pre=None, fork=False):
 # as well gained nothing more).  Autograd replays every node on the stream of its forward, so
 # the backward pass overlaps the same way.  TCCT_STREAMS=0 issues everything on one stream.
 PARALLEL_BRANCHES = os.environ.get('TCCT_STREAMS', '1') != '0'
+# round 6: inside an MHCA stage whose maps have at most this many pixels (B*H*W; stages 2-3 at the bench shape) the transformer half runs on its own stream
+# beside the InvRes half (MHCA_stage.forward); 0 disables.  tools/attrib_trace.sh: ViT L3-L4 are 2.4 ms of back-to-back 10-40 us launches in one stream
+STAGE_FORK_MAX_PIXELS = 120000
+
+
+def graphs_exclude_stage_fork(what):
+    """hipGraph capture and the nested stage fork exclude each other in one process: a graph captured AFTER the fork's stream has been used crashes inside
+    hipGraphLaunch at its first replay on ROCm 7.2 (tests/test_model_gpu.py::test_graphed_train_step_matches_eager; the same late-capture segfault as
+    profiles/HISTORY.md 5b, now with a trigger that reproduces).  tcct_amd.graph calls this before a capture: the fork is switched off for the rest of the
+    process, and a process that has already used it is refused loudly instead of crashing later."""
+    global STAGE_FORK_MAX_PIXELS
+    if any(k[0] == 'vit_enc' for k in _SIDE_STREAMS):
+        raise TcctError(f'{what}: this process has already run training steps with the nested stage fork (tcct_amd.ops.STAGE_FORK_MAX_PIXELS > 0); a hipGraph '
+                        'captured now crashes in hipGraphLaunch (DESIGN 6).  Set tcct_amd.ops.STAGE_FORK_MAX_PIXELS = 0 before the first step (KiteSeg does with '
+                        '--graph=true / TCCT_GRAPH=1) or capture in a fresh process.')
+    STAGE_FORK_MAX_PIXELS = 0
 _SIDE_STREAMS = {}
 
 

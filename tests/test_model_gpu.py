@@ -1093,9 +1093,79 @@ def test_sibling_variants_match_reference(name, tmp_path):
     assert l1 < l0 - 1e-2, (l0, l1)
 
 
+def test_stage_fork_changes_streams_not_results(tmp_path):
+    """round 6: inside the small ViT stages the transformer half runs on a stream of its own (MHCA_stage.forward, ops.STAGE_FORK_MAX_PIXELS).  Same kernels, same
+    arguments: heads and loss bit-identical with and without the fork, every gradient equal up to the order of the weight-gradient atomics -- in the pooled
+    training step (gradient slots, weight gradients on their side stream) at a shape whose stages 1-3 all fork"""
+    import tcct_oracle as O
+    from tcct_amd import ops
+    img, lab = O.synth_batch(2, 128, 160, seed=12)
+    img, lab = img[:, :1].cuda(), lab.cuda()
+    res = {}
+    old = ops.STAGE_FORK_MAX_PIXELS
+    try:
+        for fork in (120000, 0):
+            ops.STAGE_FORK_MAX_PIXELS = fork
+            model, _ = build(torch.bfloat16)
+            model.base.base_vit.drop_probs = [0.0] * 4
+            k = make_kite(model, tmp_path / f'f{fork}', False, False, lr=0.0)
+            for g in k.optimG.param_groups:
+                g['lr'] = 0.0
+            model.train()
+            k.train_step(img, lab)                      # lays out the flat gradient buffer (lr 0: the weights stay put)
+            k.optimG.zero_grad(set_to_none=True)
+            ops.begin_step(k.device)
+            try:
+                tot, _ = k.calc_loss(img, lab, want_log=False)
+                tot.backward()
+            finally:
+                ops.end_step()
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                heads = [o.float().cpu() for o in model(img)]
+            grads = {n: (p.grad if p.grad is not None else getattr(p, '_grad_slot', None)) for n, p in model.named_parameters()}
+            res[fork] = (tot.item(), heads, {n: g.detach().float().cpu().reshape(-1) for n, g in grads.items() if g is not None})
+    finally:
+        ops.STAGE_FORK_MAX_PIXELS = old
+    assert any(kk[0] == 'vit_enc' for kk in ops._SIDE_STREAMS)          # the fork really ran
+    (ta, ha, ga), (tb, hb, gb) = res[120000], res[0]
+    assert ta == tb and all(torch.equal(a, b) for a, b in zip(ha, hb))
+    assert set(ga) == set(gb)
+    for n in ga:
+        sc = max(gb[n].abs().max().item(), 1e-30)
+        assert (ga[n] - gb[n]).abs().max().item() <= 2e-3 * sc, n
+
+
+def test_graph_capture_after_the_stage_fork_is_refused(tmp_path):
+    """hipGraph capture and the nested stage fork exclude each other in one process (ops.graphs_exclude_stage_fork): a capture after the fork's stream has been used
+    crashed inside hipGraphLaunch; the library now refuses it with a message instead.  (The capture tests below run in fresh processes for the same reason.)"""
+    import tcct_oracle as O
+    from tcct_amd import ops
+    from tcct_amd._lib import TcctError
+    from tcct_amd.graph import GraphedTrainStep, GraphedPredict
+    if os.environ.get('TCCT_TEST_CHILD') == '1':
+        pytest.skip('parent-process test')
+    model, _ = build(torch.bfloat16)
+    k = make_kite(model, tmp_path, False, False)
+    model.train()
+    img, lab = O.synth_batch(2, 64, 96, seed=2)
+    if not any(kk[0] == 'vit_enc' for kk in ops._SIDE_STREAMS):
+        k.train_step(img[:, :1].cuda(), lab.cuda())
+    assert any(kk[0] == 'vit_enc' for kk in ops._SIDE_STREAMS)
+    before = ops.STAGE_FORK_MAX_PIXELS
+    with pytest.raises(TcctError, match='nested stage fork'):
+        GraphedTrainStep(k)
+    with pytest.raises(TcctError, match='nested stage fork'):
+        GraphedPredict(model)
+    assert ops.STAGE_FORK_MAX_PIXELS == before
+
+
 def test_graphed_predict_equals_eager_and_tracks_weight_updates(tmp_path):
     """hipGraph replay of the eval forward (tcct_amd/graph.py, used by KiteSeg.predict for bs <= 2): identical logits and masks to
     the eager path, and in-place weight updates (an optimizer step) are seen by the already captured graph"""
+    from conftest import run_in_fresh_process
+    if run_in_fresh_process(__file__, 'test_graphed_predict_equals_eager_and_tracks_weight_updates'):
+        return
     import tcct_oracle as O
     from tcct_amd.graph import GraphedPredict
     model, sd = build(torch.bfloat16)
@@ -1132,6 +1202,9 @@ def test_graphed_train_step_matches_eager(tmp_path):
     the eager step FROM THE SAME STATE, one step at a time (a multi-step trajectory comparison is meaningless: the order of the float
     atomics differs from run to run and bf16 rounding + batch-statistics BatchNorm amplify that to 1e-3 in the loss within 3 steps,
     eager against eager too)"""
+    from conftest import run_in_fresh_process
+    if run_in_fresh_process(__file__, 'test_graphed_train_step_matches_eager'):
+        return
     import tcct_oracle as O
     from tcct_amd.graph import GraphedTrainStep
     model, sd = build(torch.bfloat16)
@@ -1175,6 +1248,9 @@ def test_graphed_train_step_matches_eager(tmp_path):
 def test_cli_training_with_graph_flag(tmp_path):
     """`--graph=true` through the reference's entry point surface (kite/main.py flags + KiteSeg.train): a short synthetic epoch on
     256x256-like crops runs warm-up steps eagerly, captures, replays, and the loss stays finite and decreases"""
+    from conftest import run_in_fresh_process
+    if run_in_fresh_process(__file__, 'test_cli_training_with_graph_flag'):
+        return
     from tcct_amd.kite.main import parse_args
     from tcct_amd.kite import KiteSeg
     from tcct_amd.data import SynthOCT

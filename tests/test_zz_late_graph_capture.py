@@ -16,6 +16,21 @@ pytestmark = pytest.mark.gpu
 def test_zz_factor_attention_step_replays_from_a_hipgraph(tmp_path):
     import tcct_oracle as O
     from test_model_gpu import make_kite
+    from conftest import run_in_fresh_process
+    if run_in_fresh_process(__file__, 'test_zz_factor_attention_step_replays_from_a_hipgraph'):
+        return
+    # round 6: the capture runs LATE in a process of its own -- after eager steps of several shapes (allocator and stream history, as the suite used to provide)
+    # with the nested stage fork switched off first: late capture after the fork is the crash tcct_amd.graph now refuses (ops.graphs_exclude_stage_fork)
+    from tcct_amd import ops
+    ops.graphs_exclude_stage_fork('late-capture guard')
+    from tcct_amd.nets import stc_tt as _stc, RegNet as _Reg
+    for hw in ((64, 96), (128, 160), (96, 64)):
+        m0 = _Reg(_stc(5, compute_dtype=torch.bfloat16), con='cos', out_channels=5)
+        k0 = make_kite(m0.cuda().train(), tmp_path / f'pre{hw[0]}', True, True)
+        b0 = tuple(t.cuda() for t in O.synth_batch(2, hw[0], hw[1], seed=3))
+        for _ in range(3):
+            k0.train_step(*b0)
+        del m0, k0, b0
     if os.environ.get('FA_EMPTY_CACHE') == '1':          # hypothesis not yet tested: allocator state left by the full-size tests
         import gc
         gc.collect()
