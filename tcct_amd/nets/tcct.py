@@ -697,8 +697,7 @@ class FTC(nn.Module):
             ops.run_interleaved('vit', self.base_cnn.iter_levels(x, cs), self.base_vit.iter_stages(x, vs), vs)
             # data-parallel runs: once the backward pass has crossed these nine edges, every fusion / decoder / head gradient is final
             (c1, c2, c3, c4, c5), (v2, v3, v4, v5) = [ops.grad_mark(t, 'dec') for t in cs], [ops.grad_mark(t, 'dec') for t in vs]
-            f = [c1]
-            for j, (v, c) in enumerate(((v2, c2), (v3, c3), (v4, c4), (v5, c5))):
+            def fuse_level(j, v, c):
                 tv, tc = getattr(self, f'tran_vit{j}'), getattr(self, f'tran_cnn{j}')
                 if self.flag_gate and self.training:
                     # tcct.py:922-929: alpha = clamp(bicubic(rand(B,C,max(3,H/32),max(3,W/32))), 0, 1); the draw is an input here
@@ -706,20 +705,32 @@ class FTC(nn.Module):
                     B_, Hh, Ww, Cc = a1.shape
                     fields = self.forced_gate_fields
                     field = fields.pop(0) if fields else torch.rand((B_, max(3, Hh // 32), max(3, Ww // 32), Cc), device=a1.device)
-                    f.append(ops.gate_fusion(a1, a2, field.to(device=a1.device, dtype=torch.float32).contiguous()))
-                elif self.flag_gate:
+                    return ops.gate_fusion(a1, a2, field.to(device=a1.device, dtype=torch.float32).contiguous())
+                if self.flag_gate:
                     sm = _conv_bn(tc[0], tc[1], c, residual=_conv_bn(tv[0], tv[1], v))      # x1*0.5 + x2*0.5 == (x1+x2)*0.5 exactly
                     half = torch.empty_like(sm)
                     ops.lib.scale(sm, half, sm.numel(), 0.5, ops.dtype_code(sm.dtype))
-                    f.append(half)
-                elif (ops.TRAN_FUSE and c.shape[-1] % 8 == 0 and ops.pw_conv_bn_ok(v, tv[0].weight, tv[0].bias, tv[1].training, None, None)
-                      and ops.pw_conv_bn_ok(c, tc[0].weight, tc[0].bias, tc[1].training, None, None)):
+                    return half
+                if (ops.TRAN_FUSE and c.shape[-1] % 8 == 0 and ops.pw_conv_bn_ok(v, tv[0].weight, tv[0].bias, tv[1].training, None, None)
+                        and ops.pw_conv_bn_ok(c, tc[0].weight, tc[0].bias, tc[1].training, None, None)):
                     # both BatchNorms applied by ONE pass that also adds them: BN(tran_vit(v)) is never written and read back
                     yv, lv = ops.pw_conv_bn(v, tv[0].weight, tv[0].bias, _bn_args(tv[1]), None, defer_apply=True)
                     yc, lc = ops.pw_conv_bn(c, tc[0].weight, tc[0].bias, _bn_args(tc[1]), None, defer_apply=True)
-                    f.append(ops.affine2_add(yv, lv, yc, lc))
-                else:
-                    f.append(_conv_bn(tc[0], tc[1], c, residual=_conv_bn(tv[0], tv[1], v)))
+                    return ops.affine2_add(yv, lv, yc, lc)
+                return _conv_bn(tc[0], tc[1], c, residual=_conv_bn(tv[0], tv[1], v))
+            pairs = ((v2, c2), (v3, c3), (v4, c4), (v5, c5))
+            y8 = None
+            if ops.fusion_fork_ok(c5) and not self.flag_gate and self.training:
+                # round 6: the fusion of the two LARGE levels (bandwidth-bound) on a stream of its own beside the small ones + `head` (latency-bound launches).  The decoder
+                # needs f[2] / f[1] only at dec2 / dec3; in the backward pass (autograd replays a node on the stream of its forward) the large levels' fusion backward
+                # then runs beside the first encoder levels' backward instead of in front of it
+                def high():
+                    f3_, f4_ = fuse_level(2, *pairs[2]), fuse_level(3, *pairs[3])
+                    return f3_, f4_, _conv_bn(self.head[0], self.head[1], f4_, post='lrelu')
+                (f3, f4, y8), (f1, f2) = ops.run_parallel('fuse', high, lambda: (fuse_level(0, *pairs[0]), fuse_level(1, *pairs[1])))
+                f = [c1, f1, f2, f3, f4]
+            else:
+                f = [c1] + [fuse_level(j, v, c) for j, (v, c) in enumerate(pairs)]
         elif self.flag_cnn:
             # the reference also runs the ViT encoder and discards it (only its BatchNorm running statistics move); skipped here
             f = list(self.base_cnn(x))
@@ -729,7 +740,8 @@ class FTC(nn.Module):
             ops.run_interleaved('vit', self.base_cnn.iter_levels(x, cs, 1), self.base_vit.iter_stages(x, vs), vs)
             (c1,), (v2, v3, v4, v5) = cs, vs
             f = [c1] + [_conv_bn(getattr(self, f'tran_vit{j}')[0], getattr(self, f'tran_vit{j}')[1], v) for j, v in enumerate((v2, v3, v4, v5))]
-        y8 = _conv_bn(self.head[0], self.head[1], f[4], post='lrelu')
+        if not (self.flag_vit and self.flag_cnn) or y8 is None:
+            y8 = _conv_bn(self.head[0], self.head[1], f[4], post='lrelu')
         y0_direct = None            # level-0 logits when the decoder tail was composed through aux0 (below)
         if self.legacy_heads:       # tcct_goals.py:1027-1033: heads on the decoder outputs
             d3 = self.dec1(y8, f[3])

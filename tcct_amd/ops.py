@@ -757,13 +757,25 @@ PARALLEL_BRANCHES = os.environ.get('TCCT_STREAMS', '1') != '0'
 STAGE_FORK_MAX_PIXELS = 120000
 
 
+FUSION_FORK = True       # FTC.forward: tran_vit / tran_cnn fusion of levels 1-2 on its own stream beside levels 3-4 + head (training, bench-like shapes)
+
+
+def fusion_fork_ok(c5):
+    """c5: the coarsest CNN level [B,h,w,32].  Small crops are launch-bound on the HOST: another fork / join there costs more than it gives"""
+    return (FUSION_FORK and STAGE_FORK_MAX_PIXELS > 0 and PARALLEL_BRANCHES and torch.is_grad_enabled() and c5.is_cuda
+            and c5.shape[0] * c5.shape[1] * c5.shape[2] >= FUSION_FORK_MIN_PIXELS)
+
+
+FUSION_FORK_MIN_PIXELS = 4096       # coarsest level of 8 x 256 x 256 crops: 2048
+
+
 def graphs_exclude_stage_fork(what):
     """hipGraph capture and the nested stage fork exclude each other in one process: a graph captured AFTER the fork's stream has been used crashes inside
     hipGraphLaunch at its first replay on ROCm 7.2 (tests/test_model_gpu.py::test_graphed_train_step_matches_eager; the same late-capture segfault as
     profiles/HISTORY.md 5b, now with a trigger that reproduces).  tcct_amd.graph calls this before a capture: the fork is switched off for the rest of the
     process, and a process that has already used it is refused loudly instead of crashing later."""
     global STAGE_FORK_MAX_PIXELS
-    if any(k[0] == 'vit_enc' for k in _SIDE_STREAMS):
+    if any(k[0] in ('vit_enc', 'fuse') for k in _SIDE_STREAMS):
         raise TcctError(f'{what}: this process has already run training steps with the nested stage fork (tcct_amd.ops.STAGE_FORK_MAX_PIXELS > 0); a hipGraph '
                         'captured now crashes in hipGraphLaunch (DESIGN 6).  Set tcct_amd.ops.STAGE_FORK_MAX_PIXELS = 0 before the first step (KiteSeg does with '
                         '--graph=true / TCCT_GRAPH=1) or capture in a fresh process.')

@@ -1102,10 +1102,10 @@ def test_stage_fork_changes_streams_not_results(tmp_path):
     img, lab = O.synth_batch(2, 128, 160, seed=12)
     img, lab = img[:, :1].cuda(), lab.cuda()
     res = {}
-    old = ops.STAGE_FORK_MAX_PIXELS
+    old, old_min = ops.STAGE_FORK_MAX_PIXELS, ops.FUSION_FORK_MIN_PIXELS
     try:
         for fork in (120000, 0):
-            ops.STAGE_FORK_MAX_PIXELS = fork
+            ops.STAGE_FORK_MAX_PIXELS, ops.FUSION_FORK_MIN_PIXELS = fork, 0       # (the fusion fork of FTC.forward too: it follows the same switch; at this size only when forced)
             model, _ = build(torch.bfloat16)
             model.base.base_vit.drop_probs = [0.0] * 4
             k = make_kite(model, tmp_path / f'f{fork}', False, False, lr=0.0)
@@ -1126,8 +1126,8 @@ def test_stage_fork_changes_streams_not_results(tmp_path):
             grads = {n: (p.grad if p.grad is not None else getattr(p, '_grad_slot', None)) for n, p in model.named_parameters()}
             res[fork] = (tot.item(), heads, {n: g.detach().float().cpu().reshape(-1) for n, g in grads.items() if g is not None})
     finally:
-        ops.STAGE_FORK_MAX_PIXELS = old
-    assert any(kk[0] == 'vit_enc' for kk in ops._SIDE_STREAMS)          # the fork really ran
+        ops.STAGE_FORK_MAX_PIXELS, ops.FUSION_FORK_MIN_PIXELS = old, old_min
+    assert any(kk[0] == 'vit_enc' for kk in ops._SIDE_STREAMS) and any(kk[0] == 'fuse' for kk in ops._SIDE_STREAMS)          # the forks really ran
     (ta, ha, ga), (tb, hb, gb) = res[120000], res[0]
     assert ta == tb and all(torch.equal(a, b) for a, b in zip(ha, hb))
     assert set(ga) == set(gb)
