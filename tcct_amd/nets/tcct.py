@@ -454,6 +454,10 @@ class MHCA_stage(nn.Module):
             else:
                 e, x2 = self.mhca_blks[0](x1, scales, fork=True)
                 r = self.InvRes.tail(f, x2, flink)
+        elif (not torch.is_grad_enabled() and ops.PARALLEL_BRANCHES and x.is_cuda and x.shape[0] * x.shape[1] * x.shape[2] <= ops.STAGE_FORK_MAX_PIXELS
+              and x.shape[0] * x.shape[1] * x.shape[2] >= ops.FUSION_FORK_MIN_PIXELS and not torch.cuda.is_current_stream_capturing()):
+            # inference: the same two halves on two streams (no autograd, nothing to alias)
+            r, e = ops.run_parallel('vit_enc', lambda: self.InvRes(x), lambda: self.mhca_blks[0](x, scales))
         else:
             r = self.InvRes(x)
             e = self.mhca_blks[0](x, scales)

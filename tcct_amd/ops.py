@@ -752,9 +752,11 @@ def conv3x3_chain(x, w1, b1, w2, b2, stats_pre=None, fork=False):
 # as well gained nothing more).  Autograd replays every node on the stream of its forward, so
 # the backward pass overlaps the same way.  TCCT_STREAMS=0 issues everything on one stream.
 PARALLEL_BRANCHES = os.environ.get('TCCT_STREAMS', '1') != '0'
-# round 6: inside an MHCA stage whose maps have at most this many pixels (B*H*W; stages 2-3 at the bench shape) the transformer half runs on its own stream
-# beside the InvRes half (MHCA_stage.forward); 0 disables.  tools/attrib_trace.sh: ViT L3-L4 are 2.4 ms of back-to-back 10-40 us launches in one stream
-STAGE_FORK_MAX_PIXELS = 120000
+# round 6: inside an MHCA stage whose maps have at most this many pixels (B*H*W) the transformer half runs on its own stream beside the InvRes half
+# (MHCA_stage.forward); 0 disables.  tools/attrib_trace.sh: ViT L3-L4 are 2.4 ms of back-to-back 10-40 us launches in one stream -- but the fork pays at EVERY
+# stage (same-box A/B, ms per step: stages 2-3 only 21.31 -> 21.05; + stage 1 20.94 -> 20.78; all four 20.97 -> 20.67): the depthwise kernels of one half are
+# VALU-bound, the GEMMs of the other bandwidth-bound, and they fill each other's gaps.  Default: every stage.
+STAGE_FORK_MAX_PIXELS = 1 << 30
 
 
 FUSION_FORK = True       # FTC.forward: tran_vit / tran_cnn fusion of levels 1-2 on its own stream beside levels 3-4 + head (training, bench-like shapes)

@@ -1104,7 +1104,7 @@ def test_stage_fork_changes_streams_not_results(tmp_path):
     res = {}
     old, old_min = ops.STAGE_FORK_MAX_PIXELS, ops.FUSION_FORK_MIN_PIXELS
     try:
-        for fork in (120000, 0):
+        for fork in (1 << 30, 0):
             ops.STAGE_FORK_MAX_PIXELS, ops.FUSION_FORK_MIN_PIXELS = fork, 0       # (the fusion fork of FTC.forward too: it follows the same switch; at this size only when forced)
             model, _ = build(torch.bfloat16)
             model.base.base_vit.drop_probs = [0.0] * 4
@@ -1128,7 +1128,7 @@ def test_stage_fork_changes_streams_not_results(tmp_path):
     finally:
         ops.STAGE_FORK_MAX_PIXELS, ops.FUSION_FORK_MIN_PIXELS = old, old_min
     assert any(kk[0] == 'vit_enc' for kk in ops._SIDE_STREAMS) and any(kk[0] == 'fuse' for kk in ops._SIDE_STREAMS)          # the forks really ran
-    (ta, ha, ga), (tb, hb, gb) = res[120000], res[0]
+    (ta, ha, ga), (tb, hb, gb) = res[1 << 30], res[0]
     assert ta == tb and all(torch.equal(a, b) for a, b in zip(ha, hb))
     assert set(ga) == set(gb)
     for n in ga:
