@@ -391,6 +391,10 @@ int tcct_c3_wgrad(const void* x4, const void* dy, float* dw, float* dbias, int B
 int tcct_c3_bn_fwd_train(const void* x4, const float* w, const float* bias, void* z, int B, int H, int W, int stride, double* sums,
                          const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                          int64_t* num_batches_tracked, float* mean_rstd, float* ab, int post_act, tcct_stream_t stream);
+/* inference: z = post_act(a y + b) with the eval-mode coefficients ab fp32 [64] = {a[32], b[32]} (tcct_bn_eval_ab) -- `KiteSeg.predict` / `val`
+ * (kite/loop_seg.py:21-33,66-106) through the same first layers, one launch, y never stored */
+int tcct_c3_bn_fwd_eval(const void* x4, const float* w, const float* bias, void* z, int B, int H, int W, int stride, const float* ab, int post_act,
+                        tcct_stream_t stream);
 int tcct_c3_bn_bwd_reduce(const void* x4, const float* w, const float* bias, const void* dz, int B, int H, int W, int stride, const float* ab,
                           double* raw, int post_act, tcct_stream_t stream);
 int tcct_c3_bn_bwd_wgrad(const void* x4, const float* w, const float* bias, const void* dz, int B, int H, int W, int stride, const float* coef,

@@ -81,17 +81,19 @@ k_c3_bn_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float
                 }
                 if (tid == 0 && tr.nbt) *tr.nbt += 1;
             }
+        } else if (MODE == 2) {             // eval mode: a, b from the running statistics (tcct_bn_eval_ab), handed over in tr.ab_out
+            sA[tid] = tr.ab_out[tid]; sBb[tid] = tr.ab_out[32 + tid];
         }
     }
     __syncthreads();
     // the lane's 16 output channels are 8q + 4hh + k: bias (and a, b) of those channels in registers
-    float bz[16], ca[MODE == 1 ? 16 : 1], cb[MODE == 1 ? 16 : 1];
+    float bz[16], ca[MODE >= 1 ? 16 : 1], cb[MODE >= 1 ? 16 : 1];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             bz[4 * q + k] = sBias[8 * q + 4 * hh + k];
-            if (MODE == 1) { ca[4 * q + k] = sA[8 * q + 4 * hh + k]; cb[4 * q + k] = sBb[8 * q + 4 * hh + k]; }
+            if (MODE >= 1) { ca[4 * q + k] = sA[8 * q + 4 * hh + k]; cb[4 * q + k] = sBb[8 * q + 4 * hh + k]; }
         }
     float ss[MODE == 0 ? 16 : 1], sq[MODE == 0 ? 16 : 1];
     if (MODE == 0) {
@@ -233,6 +235,28 @@ extern "C" int tcct_c3_bn_fwd_train(const void* x4, const float* w, const float*
         hipLaunchKernelGGL((k_c3_bn_fwd<1, TCCT_ACT_HSWISH>), dim3((unsigned)gx), dim3(C3B), 0, st, (const bf16*)x4, w, bias, (bf16*)z, M, sums, tr, g);
     else
         hipLaunchKernelGGL((k_c3_bn_fwd<1, TCCT_ACT_NONE>), dim3((unsigned)gx), dim3(C3B), 0, st, (const bf16*)x4, w, bias, (bf16*)z, M, sums, tr, g);
+    TCCT_LAUNCH_OK();
+}
+
+/* inference (KiteSeg.predict / val, reference kite/loop_seg.py:21-33,66-106): the same one-store form with the EVAL-mode BatchNorm -- z = post_act(a y + b), ab fp32 [64]
+ * = {a[32], b[32]} from the running statistics (tcct_bn_eval_ab); one launch (the normalising pass of tcct_c3_bn_fwd_train), y never stored. */
+extern "C" int tcct_c3_bn_fwd_eval(const void* x4, const float* w, const float* bias, void* z, int B, int H, int W, int stride, const float* ab, int post_act,
+                                   tcct_stream_t stream) {
+    TCCT_CHECK(stride == 1 || stride == 2, "c3_bn_fwd_eval: stride %d", stride);
+    TCCT_CHECK(post_act == TCCT_ACT_NONE || post_act == TCCT_ACT_HSWISH, "c3_bn_fwd_eval: post_act %d (none or hswish)", post_act);
+    TCCT_CHECK(x4 && w && z && ab, "c3_bn_fwd_eval: NULL argument");
+    const C3Geom g = c3_geom(B, H, W, stride);
+    const int64_t M = (int64_t)B * g.Ho * g.Wo, inb = (int64_t)B * H * W * 8;
+    TCCT_CHECK(M > 0 && M * 64 < (1ll << 31) && inb < (1ll << 31), "c3_bn_fwd_eval: image too large for 32-bit byte offsets (B=%d H=%d W=%d)", B, H, W);
+    const int64_t mtiles = (int64_t)B * g.Ho * g.tpr;
+    int64_t gx = (mtiles + 3) / 4;
+    if (gx > 256 * 4) gx = 256 * 4;
+    C3BnTrain tr{nullptr, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, const_cast<float*>(ab)};
+    hipStream_t st = (hipStream_t)stream;
+    if (post_act == TCCT_ACT_HSWISH)
+        hipLaunchKernelGGL((k_c3_bn_fwd<2, TCCT_ACT_HSWISH>), dim3((unsigned)gx), dim3(C3B), 0, st, (const bf16*)x4, w, bias, (bf16*)z, M, (double*)nullptr, tr, g);
+    else
+        hipLaunchKernelGGL((k_c3_bn_fwd<2, TCCT_ACT_NONE>), dim3((unsigned)gx), dim3(C3B), 0, st, (const bf16*)x4, w, bias, (bf16*)z, M, (double*)nullptr, tr, g);
     TCCT_LAUNCH_OK();
 }
 

@@ -62,7 +62,15 @@ class KiteSeg(KiteBack):
                     self._graphed = GraphedPredict(self.model)
                 _, idx = self._graphed(img.float() if img.dtype != torch.float32 else img)
                 return MaskOneHot(idx.clone(), self.NB_CLASS)
-            pred = self.model(img)
+            base = getattr(self.model, 'base', None)
+            mho = base is not None and hasattr(base, 'main_head_only') and not self.model.training
+            if mho:                 # only `pred[0]` is read below (reference loop_seg.py:27-29): the deep-supervision heads are not evaluated
+                base.main_head_only = True
+            try:
+                pred = self.model(img)
+            finally:
+                if mho:
+                    base.main_head_only = False
             if isinstance(pred, (list, tuple)):
                 pred = pred[0]
             pred = pred.detach()

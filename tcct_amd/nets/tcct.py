@@ -594,7 +594,8 @@ class MPUpBlock(nn.Module):
         aux: the level-0 head when the caller needs only ITS output of g0 -> returns the tuple (fp32 logits NHWC, resized y) instead"""
         p, t = self.post[0], t32
         probe = torch.empty((x1.shape[0], x1.shape[1], x1.shape[2], self.prep[0].out_channels), dtype=x1.dtype, device='meta')    # shape / dtype only: no device memory
-        if not (self.prep[1].training and ops.up_skip_conv_t32_ok(probe, x2, p.weight, p.bias, t.weight, t.bias)):
+        # (train mode -- or inference with the fused epilogues: the composition needs no statistics, round 6)
+        if not ((self.prep[1].training or (ops.INFER_FUSE and not torch.is_grad_enabled())) and ops.up_skip_conv_t32_ok(probe, x2, p.weight, p.bias, t.weight, t.bias)):
             return None
         y = _conv_bn(self.prep[0], self.prep[1], x1, post='lrelu')
         if aux is not None and ops.up_skip_conv_t32_aux_ok(probe, x2, p.weight, p.bias, t.weight, t.bias, aux.weight, aux.bias):
@@ -653,6 +654,9 @@ class FTC(nn.Module):
         # are then composed through the t32x convolutions, g0..g2 are never written and `feats` rebuilds them on demand WITHOUT gradient.
         # Default False: `feats` carries gradient as the reference's does (RegNet(stc_tt()) + regular_udh used directly, without KiteSeg).
         self.compose_heads = False
+        # True (set by KiteSeg.predict around its forward, inference only): the caller reads head 0 alone (reference kite/loop_seg.py:27-29 `pred = pred[0]`) -- the
+        # three deep-supervision heads and their resizes are not evaluated, and the level-0 tail is composed through aux0 as in a --udh=false training step
+        self.main_head_only = False
 
     @property
     def feats(self):
@@ -696,6 +700,7 @@ class FTC(nn.Module):
     def forward(self, x):
         size = (x.shape[2], x.shape[3])
         x = self._to_nhwc4(x)
+        mho = self.main_head_only and not torch.is_grad_enabled() and not self.training     # inference, head 0 only (KiteSeg.predict)
         if self.flag_vit and self.flag_cnn:
             cs, vs = [], []
             ops.run_interleaved('vit', self.base_cnn.iter_levels(x, cs), self.base_vit.iter_stages(x, vs), vs)
@@ -760,7 +765,7 @@ class FTC(nn.Module):
             d1, s1 = self.dec3(d2, f[1], with_sum=True)
             # level 0: post, `x_0 + y_0` and t324 as one GEMM (u, d0, s0 never written) -- and through aux0 as well when the feature-polarization
             # loss is off (nothing else reads g0 then; `feats` rebuilds it on demand)
-            compose = self.compose_heads and not self.eager_feats
+            compose = (self.compose_heads and not self.eager_feats) or mho
             g0 = self.dec4.forward_through(d1, f[0], self.t324, aux=self.aux0 if compose else None)
             if isinstance(g0, tuple):
                 y0_direct, (kind, src) = g0
@@ -773,7 +778,10 @@ class FTC(nn.Module):
             # levels 1-3: aux_i(t32x(s_i)) as one GEMM with the composed weight when nothing else reads g_i (feature-polarization loss off)
             mids, lg_direct = [], []
             for t, aux, s_ in ((self.t323, self.aux1, s1), (self.t322, self.aux2, s2), (self.t321, self.aux4, s3)):
-                if self.training and compose and ops.head_through_t32_ok(s_, t.weight, t.bias, aux.weight, aux.bias):
+                if mho:                 # nobody reads g1..g3 or their heads in this forward (`feats` rebuilds what it needs on demand)
+                    lg_direct.append(None)
+                    mids.append(lambda t=t, s_=s_: self._rebuild(t, s_))
+                elif self.training and compose and ops.head_through_t32_ok(s_, t.weight, t.bias, aux.weight, aux.bias):
                     lg_direct.append(ops.head_through_t32(s_, t.weight, t.bias, aux.weight, aux.bias))
                     mids.append(lambda t=t, s_=s_: self._rebuild(t, s_))
                 else:
@@ -784,7 +792,7 @@ class FTC(nn.Module):
         # feature-polarization loss reads it; with --udh=false the six level-0 passes are simply never launched)
         self._feats_src = (g0, g1, g2, size)
         self._feats = None
-        if self.eager_feats and not self.legacy_heads:
+        if self.eager_feats and not self.legacy_heads and not mho:
             # the loss WILL read `feats` (KiteSeg sets the flag with --udh): evaluate norm_add here and let the aux heads read aliases of g0..g2
             # returned by its node, so that the heads' gradients are added inside norm_add's backward kernels (three accumulation passes fewer)
             forked = ops.norm_add3_fork(g0, g1, g2)
@@ -793,7 +801,9 @@ class FTC(nn.Module):
                 self._feats, self._feats_src = [_nchw_view(feats)], None
         # aux heads: logits are produced and resized in fp32 in every mode (loss-side precision)
         f32 = torch.float32
-        y0 = y0_direct if y0_direct is not None else _conv(self.aux0, g0, out_dtype=f32)
+        y0 = y0_direct if y0_direct is not None else _conv(self.aux0, g0() if callable(g0) else g0, out_dtype=f32)
+        if mho:
+            return [_nchw_view(y0)]
         low = [lg if lg is not None else _conv(m, g, out_dtype=f32) for m, g, lg in zip((self.aux1, self.aux2, self.aux4), (g1, g2, g3), lg_direct)]
         if self.defer_aux_resize and torch.is_grad_enabled():
             # training loop (KiteSeg.calc_loss): the three aux heads stay at their own resolution; the Dice criterion resizes on the fly
