@@ -212,6 +212,14 @@ int tcct_conv32_fwd_affine(const void* x, const void* wp, const float* bias, voi
                            int PH, int PW, const float* ab, int pre_act, int post_act, tcct_stream_t stream);
 int tcct_pw_fwd_affine(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, const float* ab,
                        int pre_act, int post_act, int out_dtype, tcct_stream_t stream);
+/* inference: y = res + (a[c] * (x W^T + bias[c]) + b[c]): `x + BN_eval(conv2(f))` of the InvRes block (nets/tcct.py:563-572) as one GEMM; K = N in {64, 96, 128}; ab as
+ * tcct_pw_fwd_affine (NULL: a = 1, b = 0) */
+int tcct_pw_fwd_affine_residual(const void* x, const float* w, const float* bias, const float* ab, const void* res, void* y, int64_t M, int K, int N,
+                                tcct_stream_t stream);
+/* inference: y = post_act(a[c] * ([x1 | x2] W^T + bias[c]) + b[c]) over the never-materialised concatenation of two 64-channel tensors, N = 96 (`aggregate` of MHCA stage 0,
+ * nets/tcct.py:600-616) */
+int tcct_pw_fwd_cat2_affine(const void* x1, const void* x2, const float* w, const float* bias, const float* ab, int post_act, void* y, int64_t M, int K, int N,
+                            tcct_stream_t stream);
 /* y = conv(x) + bias + res, res bf16 NHWC [N,H,W,32] (not overlapping y): used as the input gradient of a convolution whose input has
  * a second consumer (CrossCNNBlock: x feeds block12 and block34, nets/tcct.py:826) -- no separate gradient accumulation pass */
 int tcct_conv32_fwd_add(const void* x, const void* wp, const float* bias, const void* res, void* y, int N, int H, int W, int KH, int KW,

@@ -335,7 +335,16 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
 static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                        int out_dtype, double* stats, int stat_pre, tcct_stream_t stream, const float* aff = nullptr, int aff_pre = 0,
                        int aff_post = 0, PwSplit sp = PwSplit{nullptr, 0, nullptr, 0, nullptr, nullptr, 1, nullptr});
+struct PwRes { const bf16* res; const float* rscale; int64_t per_sample; bf16* yplain; const float* xab; const float* aff; int aff_post; int has_aff; };
 static bool pw_fwd2_ok(int64_t M, int K, int N, int K1, bool has_x2);
+// shapes of the tile-staged forward WITH the inference epilogue: square 64 / 96 / 128 (plain or with the residual), the concatenated 64 + 64 -> 96
+static bool pw_fwd2_aff_ok(int64_t M, int K, int N, bool has_x2, bool has_res) {
+    if (M * (int64_t)(K > N ? K : N) * 2 >= (1LL << 31)) return false;
+    if (has_x2) return K == 128 && N == 96 && !has_res;
+    return K == N && (K == 64 || K == 96 || K == 128);
+}
+static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
+                          int stat_pre, tcct_stream_t stream, PwRes pr, bool gelu_x = false);
 struct PwRes;
 static int pw_fwd2_route(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
                          int stat_pre, tcct_stream_t stream, const bf16* res, const float* rscale, int64_t per_sample, bf16* yplain);
@@ -408,8 +417,25 @@ extern "C" int tcct_pw_fwd_affine(const void* x, const float* w, const float* bi
                                   int pre_act, int post_act, int out_dtype, tcct_stream_t stream) {
     return pw_fwd_impl(x, w, bias, y, M, K, N, 0, out_dtype, nullptr, 0, stream, ab, pre_act, post_act);
 }
+/* inference: y = res + (a[c] * (x W^T + bias[c]) + b[c]) -- `x + BN_eval(conv2(f))` of the InvRes block (nets/tcct.py:563-572) as one GEMM, the normalised product rounded
+ * to bf16 before the add like the op-by-op path; K = N in {64, 96, 128}; ab NULL: a = 1, b = 0 */
+extern "C" int tcct_pw_fwd_affine_residual(const void* x, const float* w, const float* bias, const float* ab, const void* res, void* y, int64_t M, int K, int N,
+                                           tcct_stream_t stream) {
+    TCCT_CHECK(res != nullptr && pw_fwd2_aff_ok(M, K, N, false, true), "pw_fwd_affine_residual: K=%d N=%d unsupported (64, 96 or 128 square) or res NULL", K, N);
+    return pw_fwd2_launch(x, nullptr, w, bias, y, M, K, N, nullptr, 0, stream, PwRes{(const bf16*)res, nullptr, 1, nullptr, nullptr, ab, TCCT_ACT_NONE, 1});
+}
+/* inference: y = post_act(a[c] * ([x1 | x2] W^T + bias[c]) + b[c]) over the never-materialised concatenation of two 64-channel tensors, N = 96: `aggregate` of MHCA stage 0
+ * (nets/tcct.py:600-616) with its eval-mode BatchNorm + Hardswish in the epilogue */
+extern "C" int tcct_pw_fwd_cat2_affine(const void* x1, const void* x2, const float* w, const float* bias, const float* ab, int post_act, void* y, int64_t M, int K, int N,
+                                       tcct_stream_t stream) {
+    TCCT_CHECK(x2 != nullptr && pw_fwd2_aff_ok(M, K, N, true, false), "pw_fwd_cat2_affine: K=%d N=%d unsupported (64 + 64 -> 96)", K, N);
+    return pw_fwd2_launch(x1, x2, w, bias, y, M, K, N, nullptr, 0, stream, PwRes{nullptr, nullptr, 1, nullptr, nullptr, ab, post_act, 1});
+}
 static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, int transposed,
                        int out_dtype, double* stats, int stat_pre, tcct_stream_t stream, const float* aff, int aff_pre, int aff_post, PwSplit sp) {
+    if (!transposed && out_dtype == TCCT_BF16 && (aff || aff_post) && !aff_pre && !stats && !sp.y2 && !sp.yplain && !sp.rscale && pw_fwd2_enabled()
+        && pw_fwd2_aff_ok(M, K, N, sp.x2 != nullptr, sp.res != nullptr) && (!sp.x2 || sp.K1 == 64))
+        return pw_fwd2_launch(x, sp.x2, w, bias, y, M, K, N, nullptr, 0, stream, PwRes{sp.res, nullptr, 1, nullptr, nullptr, aff, aff_post, 1});
     if (!transposed && out_dtype == TCCT_BF16 && !aff && !aff_pre && !aff_post && !sp.y2 && pw_fwd2_enabled()
         && pw_fwd2_ok(M, K, N, sp.K1, sp.x2 != nullptr) && (!stats || N <= 128) && !(sp.res && (sp.x2 || stats)))
         return pw_fwd2_route(x, sp.x2, w, bias, y, M, K, N, stats, stat_pre, stream, sp.res, sp.rscale, sp.per_sample, sp.yplain);
@@ -1482,8 +1508,9 @@ static int pw_bwd_impl(const void* x, const void* dy, const float* w, const void
 // the next prefetch).  SPLIT: the rows are the concatenation [x | x2] of two tensors of K/2 channels each (MHCA_stage.aggregate).
 // RES: y = res + rscale[m / per_sample] * (x W^T + bias) with the product rounded to bf16 first, like the op-by-op path (Mlp.fc2 with the
 // residual add and the DropPath scale of MHCABlock folded in, reference nets/tcct.py:468); yplain (nullable) also receives the product.
-struct PwRes { const bf16* res; const float* rscale; int64_t per_sample; bf16* yplain; const float* xab; };
-template <int NT, int KT, bool STATS, bool SPLIT, bool RES = false, bool GX = false, int XAP = -1>
+// AFF (round 6, inference): y = act(aff_post, a[c] * (x W^T + bias[c]) + b[c]) in the epilogue, ab = {a[N], b[N]} from the eval-mode BatchNorm (NULL: a = 1, b = 0) --
+// what k_pw_fwd's affine epilogue does for the direct-from-global kernel (0.187 ms for 64 -> 64 at level 1 against 0.10 here); combines with RES and SPLIT.
+template <int NT, int KT, bool STATS, bool SPLIT, bool RES = false, bool GX = false, int XAP = -1, bool AFF = false>
 __global__ void __launch_bounds__(PWB, 2)
 k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* __restrict__ w, const float* __restrict__ bias,
           bf16* __restrict__ y, int64_t M, double* __restrict__ stats, int stat_pre, PwRes pr) {
@@ -1506,8 +1533,9 @@ k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* 
         *reinterpret_cast<uint4*>(sW + n * SW + c8 * 16) = o;
     }
     if (tid < N) sB[tid] = bias ? bias[tid] : 0.f;
-    float* sXA = reinterpret_cast<float*>(sS + 4 * 2560);             // XAP: a[K], b[K] of the BatchNorm in front
+    float* sXA = reinterpret_cast<float*>(sS + 4 * 2560);             // XAP: a[K], b[K] of the BatchNorm in front;  AFF: a[N], b[N] of the one behind
     if (XAP >= 0) for (int i = tid; i < 2 * K; i += PWB) sXA[i] = pr.xab[i];
+    if (AFF) for (int i = tid; i < 2 * N; i += PWB) sXA[i] = pr.aff ? pr.aff[i] : (i < N ? 1.f : 0.f);
     float ss[STATS ? NT : 1][8], sq[STATS ? NT : 1][8];
 #pragma unroll
     for (int a = 0; a < (STATS ? NT : 1); ++a)
@@ -1593,9 +1621,16 @@ k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bq = *reinterpret_cast<const float4*>(sB + nt * 32 + 8 * q + 4 * hh);
+                float v0 = acc[nt][4 * q] + bq.x, v1 = acc[nt][4 * q + 1] + bq.y, v2 = acc[nt][4 * q + 2] + bq.z, v3 = acc[nt][4 * q + 3] + bq.w;
+                if (AFF) {
+                    const float4 aq = *reinterpret_cast<const float4*>(sXA + nt * 32 + 8 * q + 4 * hh);
+                    const float4 cq = *reinterpret_cast<const float4*>(sXA + N + nt * 32 + 8 * q + 4 * hh);
+                    v0 = act_fwd(pr.aff_post, aq.x * v0 + cq.x); v1 = act_fwd(pr.aff_post, aq.y * v1 + cq.y);
+                    v2 = act_fwd(pr.aff_post, aq.z * v2 + cq.z); v3 = act_fwd(pr.aff_post, aq.w * v3 + cq.w);
+                }
                 uint2 o;
-                o.x = pack_bf16x2(acc[nt][4 * q] + bq.x, acc[nt][4 * q + 1] + bq.y);
-                o.y = pack_bf16x2(acc[nt][4 * q + 2] + bq.z, acc[nt][4 * q + 3] + bq.w);
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
                 *reinterpret_cast<uint2*>(sc + r * 80 + (8 * q + 4 * hh) * 2) = o;
             }
             wave_lds_fence();
@@ -1662,9 +1697,9 @@ static bool pw_fwd2_ok(int64_t M, int K, int N, int K1, bool has_x2) {
     return true;
 }
 static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
-                          int stat_pre, tcct_stream_t stream, PwRes pr, bool gelu_x = false) {
+                          int stat_pre, tcct_stream_t stream, PwRes pr, bool gelu_x) {
     const int NT = N / 32, KT = K / 32;
-    const size_t lds = (size_t)PB_P * (2 * K + 16) + (size_t)N * (2 * K + 16) + (size_t)N * 4 + 4 * 2560 + (pr.xab ? (size_t)2 * K * 4 : 0);
+    const size_t lds = (size_t)PB_P * (2 * K + 16) + (size_t)N * (2 * K + 16) + (size_t)N * 4 + 4 * 2560 + (pr.xab ? (size_t)2 * K * 4 : 0) + (pr.has_aff ? (size_t)2 * N * 4 : 0);
     const int64_t tiles = (M + PB_P - 1) / PB_P;
     int per_cu = (int)((160 * 1024) / (lds + 256));
     if (per_cu > 2) per_cu = 2;
@@ -1683,12 +1718,21 @@ static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const f
         hipLaunchKernelGGL((k_pw_fwd2<T, T, false, false, true, true>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)x2, w, bias, (bf16*)y, M, stats, stat_pre, pr); }
 #define F2A(T) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd2<T, T, true, false, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
         hipLaunchKernelGGL((k_pw_fwd2<T, T, true, false, false, false, 2>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)x2, w, bias, (bf16*)y, M, stats, stat_pre, pr); }
+#define F2F(NTV, KTV, SPV, RSV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd2<NTV, KTV, false, SPV, RSV, false, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_fwd2<NTV, KTV, false, SPV, RSV, false, -1, true>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)x2, w, bias, (bf16*)y, M, stats, stat_pre, pr); }
+    if (pr.has_aff) {           // inference epilogues (pw_fwd2_aff_ok lists the shapes)
+        if (x2) F2F(3, 4, true, false)
+        else if (pr.res) { if (NT == 2) F2F(2, 2, false, true) else if (NT == 3) F2F(3, 3, false, true) else F2F(4, 4, false, true) }
+        else { if (NT == 2) F2F(2, 2, false, false) else if (NT == 3) F2F(3, 3, false, false) else F2F(4, 4, false, false) }
+    }
+    else
     if (pr.xab) { if (NT == 2) F2A(2) else F2A(3) }
     else
     if (gelu_x) { if (NT == 2) F2G(2) else F2G(3) }
     else
     if (pr.res) { switch (NT) { case 1: F2RK(1) break; case 2: F2RK(2) break; case 3: F2RK(3) break; default: F2RK(4) break; } }
     else if (stats) { F2N(true) } else { F2N(false) }
+#undef F2F
 #undef F2G
 #undef F2A
 #undef F2RK

@@ -44,8 +44,10 @@ def _conv_bn(mc, mb, x, pre=None, post=None, residual=None, x_final=False):
         return ops.pw_conv_bn(x, mc.weight, mc.bias, _bn_args(mb), post, residual, x_final=x_final)
     if mb.training or torch.is_grad_enabled() or not ops.INFER_FUSE:
         return _bn(mb, _conv(mc, x, stats_pre=(pre or 'none') if mb.training else None), pre=pre, post=post, residual=residual)
-    y = ops.conv_bn_act(x, mc.weight, mc.bias, mc.stride[0], tuple(mc.padding),
-                        (mb.weight, mb.bias, mb.running_mean, mb.running_var, mb.eps), pre, post)
+    bn = (mb.weight, mb.bias, mb.running_mean, mb.running_var, mb.eps)
+    if ops.conv_bn_residual_eval_ok(x, mc.weight, mc.bias, mc.stride[0], mc.padding, pre, post, residual):
+        return ops.conv_bn_residual_eval(x, mc.weight, mc.bias, bn, residual)      # the residual add in the GEMM epilogue (round 6)
+    y = ops.conv_bn_act(x, mc.weight, mc.bias, mc.stride[0], tuple(mc.padding), bn, pre, post)
     return y if residual is None else ops.add(y, residual)
 
 
@@ -469,6 +471,9 @@ class MHCA_stage(nn.Module):
                 return ops.pw_conv_bn(r, ag.conv.weight, None, _bn_args(ag.bn), 'hswish', x2=e, x_final=True)
             y = ops.conv1x1_cat2(r, e, ag.conv.weight, stats_pre='none' if ag.bn.training else None)
             return _bn(ag.bn, y, post='hswish')
+        if ops.conv1x1_cat2_bn_act_eval_ok(r, e, ag.conv.weight, 'hswish'):       # stage 0: no concatenation pass, BatchNorm + Hardswish in the GEMM epilogue (round 6)
+            m = ag.bn
+            return ops.conv1x1_cat2_bn_act_eval(r, e, ag.conv.weight, (m.weight, m.bias, m.running_mean, m.running_var, m.eps), 'hswish')
         return ag(ops.concat2(r, e))
 
 

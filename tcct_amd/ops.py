@@ -882,6 +882,40 @@ def conv_bn_act(x, w, bias=None, stride=1, pad=0, bn=None, pre_act=None, post_ac
     return y.squeeze(2) if tok else y
 
 
+def _eval_ab(bn, C, device):
+    ab = torch.empty(2 * C, device=device, dtype=torch.float32)
+    lib.bn_eval_ab(C, bn[0], bn[1], float(bn[4]), bn[2], bn[3], torch.empty(2 * C, device=device, dtype=torch.float32), ab)
+    return ab
+
+
+def conv_bn_residual_eval_ok(x, w, bias, stride, pad, pre_act, post_act, residual):
+    """inference: residual + BN_eval(conv1x1(x)) as ONE GEMM (tcct_pw_fwd_affine_residual): bf16 rows, square 64 / 96 / 128, no activation"""
+    return (INFER_FUSE and not torch.is_grad_enabled() and residual is not None and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_cuda and stride == 1
+            and tuple(pad) == (0, 0) and ACT[pre_act] == 0 and ACT[post_act] == 0 and tuple(w.shape[2:]) == (1, 1) and w.shape[0] == w.shape[1] == x.shape[-1]
+            and x.shape[-1] in (64, 96, 128) and residual.shape == x.shape and residual.dtype == x.dtype and x.numel() * 2 < 2 ** 31)
+
+
+def conv_bn_residual_eval(x, w, bias, bn, residual):
+    _chk(x, w, bias, residual)
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    lib.pw_fwd_affine_residual(x, w, bias, _eval_ab(bn, C, x.device), residual, y, x.numel() // C, C, C)
+    return y
+
+
+def conv1x1_cat2_bn_act_eval_ok(x1, x2, w, post_act):
+    """inference: post_act(BN_eval(conv1x1(cat[x1, x2]))) without the concatenation (tcct_pw_fwd_cat2_affine): two 64-channel bf16 tensors, 96 outputs"""
+    return (INFER_FUSE and not torch.is_grad_enabled() and x1.dtype == torch.bfloat16 and x1.dim() == 4 and x1.is_cuda and x1.shape[-1] == 64 and x2.shape == x1.shape
+            and x2.dtype == x1.dtype and tuple(w.shape) == (96, 128, 1, 1) and x1.numel() * 4 < 2 ** 31)
+
+
+def conv1x1_cat2_bn_act_eval(x1, x2, w, bn, post_act):
+    _chk(x1, x2, w)
+    y = torch.empty(x1.shape[:-1] + (96,), device=x1.device, dtype=x1.dtype)
+    lib.pw_fwd_cat2_affine(x1, x2, w, None, _eval_ab(bn, 96, x1.device), ACT[post_act], y, x1.numel() // 64, 128, 96)
+    return y
+
+
 def bn2_add_act_eval(xa, bnA, xb, bnB, pre_act='lrelu', act_kind='gelu'):
     """Inference only: act(BN_A(pre(xa)) + BN_B(pre(xb))) with running statistics, one pass (CrossCNNBlock junction).
     bnA/bnB: (gamma, beta, running_mean, running_var, eps)."""

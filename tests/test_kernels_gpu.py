@@ -2480,3 +2480,61 @@ def test_fpl_multiselect_equals_the_sorted_binning(cfg):
         assert torch.equal(g0 != 0, g1 != 0)                                    # exactly the same pixels were selected (bins incl. the tie groups)
     else:   # a class without a full bin: the reference's loss is NaN; the selected pixels of the other classes still match by prototype
         assert not torch.isfinite(l1)
+
+
+@pytest.mark.parametrize('C', [64, 96, 128])
+@pytest.mark.parametrize('m', [1, 127, 128, 129, 5000, 70 * 130])
+def test_pointwise_forward_inference_epilogues_on_the_tile_staged_kernel(C, m):
+    """round 6, inference: the tile-staged pointwise forward (k_pw_fwd2) with the eval-mode BatchNorm + activation in its epilogue (AFF) -- what tcct_pw_fwd_affine routes
+    square 64 / 96 / 128 GEMMs to -- the residual form `x + BN_eval(conv2(f))` (tcct_pw_fwd_affine_residual, reference nets/tcct.py:563-572) and, for 64 + 64 -> 96, the
+    concatenated form with Hardswish (tcct_pw_fwd_cat2_affine, `aggregate` of stage 0, nets/tcct.py:600-616); against torch fp32 on the same bf16 operands, and against
+    the direct-from-global kernel's affine epilogue bit for bit where both exist (same MFMA K-order, same rounding points)."""
+    from tcct_amd._lib import lib
+    x = rnd(m, C, seed=1, dt=torch.bfloat16)
+    w = rnd(C, C, seed=2) / C ** 0.5
+    b = rnd(C, seed=3)
+    a, c = 1 + 0.3 * rnd(C, seed=4), 0.2 * rnd(C, seed=5)
+    res = rnd(m, C, seed=6, dt=torch.bfloat16)
+    xd, wd, bd, rd = x.cuda().bfloat16(), w.cuda(), b.cuda(), res.cuda().bfloat16()
+    ab = torch.cat([a, c]).cuda()
+    lin = x @ w.bfloat16().float().t() + b
+    for post, fn in ((2, F.hardswish), (3, lambda t: F.gelu(t)), (0, lambda t: t)):
+        y = torch.full((m, C), 7.0, device='cuda', dtype=torch.bfloat16)
+        lib.pw_fwd_affine(xd, wd, bd, y, m, C, C, ab, 0, post, 1)
+        want = fn(a * lin + c)
+        torch.testing.assert_close(y.float().cpu(), want, rtol=2e-2, atol=2e-2 * max(1.0, want.abs().max().item()))
+    y = torch.full((m, C), 7.0, device='cuda', dtype=torch.bfloat16)
+    lib.pw_fwd_affine(xd, wd, bd, y, m, C, C, None, 0, 3, 1)                      # Mlp.fc1 + GELU: no BatchNorm (a = 1, b = 0)
+    torch.testing.assert_close(y.float().cpu(), F.gelu(lin), rtol=2e-2, atol=2e-2 * max(1.0, lin.abs().max().item()))
+    y2 = torch.full((m, C), 7.0, device='cuda', dtype=torch.bfloat16)
+    lib.pw_fwd_affine_residual(xd, wd, bd, ab, rd, y2, m, C, C)
+    want = (a * lin + c).bfloat16().float() + res                                   # the normalised product is rounded before the add, like the op-by-op path
+    torch.testing.assert_close(y2.float().cpu(), want, rtol=2e-2, atol=2e-2 * max(1.0, want.abs().max().item()))
+    if C == 64:
+        x2 = rnd(m, 64, seed=7, dt=torch.bfloat16)
+        w2 = rnd(96, 128, seed=8) / 128 ** 0.5
+        a2, c2 = 1 + 0.3 * rnd(96, seed=9), 0.2 * rnd(96, seed=10)
+        y3 = torch.full((m, 96), 7.0, device='cuda', dtype=torch.bfloat16)
+        lib.pw_fwd_cat2_affine(xd, x2.cuda().bfloat16(), w2.cuda(), None, torch.cat([a2, c2]).cuda(), 2, y3, m, 128, 96)
+        want = F.hardswish(a2 * (torch.cat([x, x2], 1) @ w2.bfloat16().float().t()) + c2)
+        torch.testing.assert_close(y3.float().cpu(), want, rtol=2e-2, atol=2e-2 * max(1.0, want.abs().max().item()))
+
+
+def test_first_layers_eval_mode_one_store():
+    """round 6, inference: tcct_c3_bn_fwd_eval = the normalising pass of the recompute kernel with the eval-mode coefficients, against F.conv2d + affine + Hardswish"""
+    from tcct_amd._lib import lib
+    for stride, post in ((1, 0), (2, 2)):
+        B, H, W = 2, 38, 52
+        img = rnd(B, 3, H, W, seed=11, dt=torch.bfloat16)
+        w = rnd(32, 3, 3, 3, seed=12) / 27 ** 0.5
+        b = rnd(32, seed=13)
+        a, c = 1 + 0.3 * rnd(32, seed=14), 0.2 * rnd(32, seed=15)
+        x4 = torch.zeros((B, H, W, 4), device='cuda', dtype=torch.bfloat16)
+        x4[..., :3] = img.permute(0, 2, 3, 1).cuda().bfloat16()
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        z = torch.full((B, Ho, Wo, 32), 7.0, device='cuda', dtype=torch.bfloat16)
+        lib.c3_bn_fwd_eval(x4, w.cuda(), b.cuda(), z, B, H, W, stride, torch.cat([a, c]).cuda(), post)
+        y = F.conv2d(img, w.bfloat16().float(), b, stride, 1)
+        want = a.view(1, -1, 1, 1) * y + c.view(1, -1, 1, 1)
+        want = F.hardswish(want) if post == 2 else want
+        torch.testing.assert_close(nchw(z), want, rtol=2e-2, atol=2e-2 * max(1.0, want.abs().max().item()))
