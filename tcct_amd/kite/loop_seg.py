@@ -208,15 +208,26 @@ class KiteSeg(KiteBack):
         finally:
             if defer:
                 base.defer_aux_resize = False
-        losSum = self.grad_calc(out, lab, ds=True, criterion=self.criterion)
-        parts = [('los', losSum)]
-        if isinstance(out, (list, tuple)):
-            out = out[0]
-        self.udh_out, self.udh_lab = out, lab
-        if self.args.udh:
-            parts.append(('udh', self.model.regular_udh(out, lab) * self.args.coff_udh))
-        if self.args.reg:
-            parts.append(('reg', self.model.regular_reg(out, lab) * self.args.coff_reg))
+        from .. import ops
+        out0 = out[0] if isinstance(out, (list, tuple)) else out
+        self.udh_out, self.udh_lab = out0, lab
+
+        def dice_udh():
+            ps = [('los', self.grad_calc(out, lab, ds=True, criterion=self.criterion))]
+            if self.args.udh:
+                ps.append(('udh', self.model.regular_udh(out0, lab) * self.args.coff_udh))
+            return ps
+        if self.args.reg and ops.loss_fork_ok(out0):
+            # round 6: the boundary-regression loss (two chains of ~25 small fp32 launches each way, tools/attrib_trace.sh) only shares the logits with the Dice and
+            # feature-polarization terms: it runs on the 'vit_enc' stream (idle here) beside them, forward and (autograd replays a node on its forward stream) backward.
+            # The reference's order of evaluation Dice -> udh -> reg (kite/loop_seg.py:150-165) fixes the order of the RANDOM DRAWS only; all of them are reg's
+            parts, reg = ops.run_parallel(ops.FUSE_STREAM_TAG, dice_udh, lambda: self.model.regular_reg(out0, lab) * self.args.coff_reg)
+            parts.append(('reg', reg))
+        else:
+            parts = dice_udh()
+            if self.args.reg:
+                parts.append(('reg', self.model.regular_reg(out0, lab) * self.args.coff_reg))
+        losSum = parts[0][1]
         if getattr(self.args, 'epl', False):
             raise TcctError('--epl=true: RegNet.regular_epl does not exist in the reference either (loop_seg.py:167)')
         total = parts[0][1]

@@ -741,7 +741,7 @@ class FTC(nn.Module):
                 def high():
                     f3_, f4_ = fuse_level(2, *pairs[2]), fuse_level(3, *pairs[3])
                     return f3_, f4_, _conv_bn(self.head[0], self.head[1], f4_, post='lrelu')
-                (f3, f4, y8), (f1, f2) = ops.run_parallel('fuse', high, lambda: (fuse_level(0, *pairs[0]), fuse_level(1, *pairs[1])))
+                (f3, f4, y8), (f1, f2) = ops.run_parallel(ops.FUSE_STREAM_TAG, high, lambda: (fuse_level(0, *pairs[0]), fuse_level(1, *pairs[1])))
                 f = [c1, f1, f2, f3, f4]
             else:
                 f = [c1] + [fuse_level(j, v, c) for j, (v, c) in enumerate(pairs)]

@@ -777,7 +777,7 @@ def graphs_exclude_stage_fork(what):
     profiles/HISTORY.md 5b, now with a trigger that reproduces).  tcct_amd.graph calls this before a capture: the fork is switched off for the rest of the
     process, and a process that has already used it is refused loudly instead of crashing later."""
     global STAGE_FORK_MAX_PIXELS
-    if any(k[0] in ('vit_enc', 'fuse') for k in _SIDE_STREAMS):
+    if any(k[0] == 'vit_enc' for k in _SIDE_STREAMS):
         raise TcctError(f'{what}: this process has already run training steps with the nested stage fork (tcct_amd.ops.STAGE_FORK_MAX_PIXELS > 0); a hipGraph '
                         'captured now crashes in hipGraphLaunch (DESIGN 6).  Set tcct_amd.ops.STAGE_FORK_MAX_PIXELS = 0 before the first step (KiteSeg does with '
                         '--graph=true / TCCT_GRAPH=1) or capture in a fresh process.')
@@ -2997,6 +2997,18 @@ def deep_supervision_dice(logits0_nhwc, labels, lows, coff):
     """sum_{i = n..1} coff * Dice(resize(lows[i-1])) + Dice(logits0): lows = [LowResLogits of outs[1], outs[2], ...] (the reference's loop runs from the last)"""
     H, W = lows[0].size
     return _DeepSupervisionDice.apply(logits0_nhwc, labels, float(coff), H, W, *[l_.low for l_ in lows])
+
+
+# The HIP runtime multiplexes its streams onto FOUR hardware queues (GPU_MAX_HW_QUEUES; measured on the bench step: 3 queues 21.2 ms, 4 queues 20.26, 5 or more 24.6):
+# streams beyond the fourth share a queue with another one and serialise against it.  The step therefore uses exactly four streams -- current, 'vit', 'vit_enc',
+# 'wgrad' -- and the later forks REUSE the encoder streams, which are idle when the fusion / the losses run (forward: joined; backward: not started yet).
+FUSE_STREAM_TAG = 'vit_enc'
+LOSS_FORK = True         # KiteSeg.calc_loss: the boundary-regression loss on the (idle) 'vit_enc' stream beside Dice + feature polarization
+
+
+def loss_fork_ok(logits):
+    return (LOSS_FORK and STAGE_FORK_MAX_PIXELS > 0 and PARALLEL_BRANCHES and torch.is_grad_enabled() and logits.is_cuda and logits.requires_grad
+            and logits.shape[0] * logits.shape[2] * logits.shape[3] >= (1 << 20))
 
 
 class LowResLogits:

@@ -1127,7 +1127,7 @@ def test_stage_fork_changes_streams_not_results(tmp_path):
             res[fork] = (tot.item(), heads, {n: g.detach().float().cpu().reshape(-1) for n, g in grads.items() if g is not None})
     finally:
         ops.STAGE_FORK_MAX_PIXELS, ops.FUSION_FORK_MIN_PIXELS = old, old_min
-    assert any(kk[0] == 'vit_enc' for kk in ops._SIDE_STREAMS) and any(kk[0] == 'fuse' for kk in ops._SIDE_STREAMS)          # the forks really ran
+    assert any(kk[0] == 'vit_enc' for kk in ops._SIDE_STREAMS)          # the forks really ran (the fusion fork reuses the same stream)
     (ta, ha, ga), (tb, hb, gb) = res[1 << 30], res[0]
     assert ta == tb and all(torch.equal(a, b) for a, b in zip(ha, hb))
     assert set(ga) == set(gb)
