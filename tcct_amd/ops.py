@@ -806,8 +806,15 @@ def run_parallel(tag, fa, fb):
         rb = fb()
     ra = fa()
     cur.wait_stream(side)
-    for t in _tensors(rb):
-        t.record_stream(cur)        # allocated on the side stream, consumed on the current one
+    if ZERO.active:
+        # inside a pooled training step: keep what was allocated on the side stream and is consumed on the current one alive until end_step() instead of
+        # record_stream()ing it -- every later piece of side-stream work starts behind a `side.wait_stream(cur)`, i.e. behind the readers, so a block freed after
+        # the step's end cannot be overwritten early; record_stream() parks a freed block until the host-side event query sees the GPU catch up, and with the
+        # host a third of a step ahead the reserved pool grew by 0.4 GB per step (tests/test_fullsize_gpu.py::test_allocator_pool_stays_bounded_over_steps_fullsize)
+        _WGRAD_KEEP.extend(_tensors(rb))
+    else:
+        for t in _tensors(rb):
+            t.record_stream(cur)        # allocated on the side stream, consumed on the current one
     return ra, rb
 
 
