@@ -286,12 +286,11 @@ def test_fullsize_backward_matches_the_oracle(tmp_path):
 
 
 def test_allocator_pool_stays_bounded_over_steps_fullsize(tmp_path):
-    """bench shape, 70 training steps: the multi-stream step (round 6: four streams -- the two encoders, the transformer half of every ViT stage, the weight
-    gradients) must not make the caching allocator grow step after step.  The pool reaches its plateau after ~40 steps now (tools/memgrow.py: 15 -> 34.2 GB reserved
-    at step 40, unchanged to step 240; gradients that cross streams inside the backward pass are record_stream()ed by autograd itself and return to the pool a little
-    later): compared are steps 45 and 69.  Activations / gradients handed to the weight-gradient stream are kept alive until the
-    join instead of record_stream()ed: that grew the reserved pool by ~3.5 GB per step at this shape (124 GB after 30 steps) and
-    ended in multi-second free-and-retry stalls (TCCT_WGRAD_RECORD_STREAM=1 restores the old behaviour for comparison)"""
+    """bench shape, 140 training steps without a host sync: the multi-stream step (round 6: four streams -- the two encoders, the transformer half of every ViT stage,
+    the weight gradients) must not make the caching allocator grow step after step.  Gradients that cross streams inside the backward pass are record_stream()ed by
+    autograd itself and return to the pool a little later, so the pool needs ~60-80 steps to reach its plateau now (tools/memgrow.py, no syncs: 15 -> 43.3 GB reserved
+    at step 80, 43.3 at step 180, 44.6 at step 400: five more segments in 320 steps, against 3.5 GB per STEP when every activation was record_stream()ed in round 2):
+    compared are steps 100 and 139."""
     import argparse
     from tcct_amd.nets import stc_tt, RegNet
     from tcct_amd.kite import KiteSeg
@@ -305,9 +304,9 @@ def test_allocator_pool_stays_bounded_over_steps_fullsize(tmp_path):
     k.model.train()
     img, lab, _, _ = ds.parse(ds.make_batch(B, seed=5))
     stats = []
-    for it in range(70):
+    for it in range(140):
         loss = k.train_step(img, lab)
-        if it in (45, 69):
+        if it in (100, 139):
             ms = torch.cuda.memory_stats()
             stats.append((ms['num_device_alloc'], ms['reserved_bytes.all.current']))
     assert torch.isfinite(loss).item()

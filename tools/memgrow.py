@@ -6,9 +6,10 @@ k, ds, _ = bench.build_trainer(a, 1)
 k.model.train()
 img, lab, _, _ = ds.parse(ds.make_batch(8, seed=5))
 t0 = time.time()
-for it in range(241):
+for it in range(int(os.environ.get('MEMGROW_STEPS', '401'))):
     loss = k.train_step(img, lab)
     if it % 20 == 0:
-        torch.cuda.synchronize()
+        if os.environ.get('MEMGROW_SYNC', '0') == '1':
+            torch.cuda.synchronize()
         ms = torch.cuda.memory_stats()
         print(it, 'segments', ms['num_device_alloc'], 'reserved GB', round(ms['reserved_bytes.all.current'] / 2**30, 2), 'allocated GB', round(ms['allocated_bytes.all.current'] / 2**30, 2), 'retries', ms['num_alloc_retries'], round(time.time() - t0, 1), 's', flush=True)
