@@ -360,7 +360,7 @@ extern "C" int tcct_pw_fwd(const void* x, const float* w, const float* bias, voi
 /* forward + fused BatchNorm statistics of the consumer (bf16 output, N <= 128): stats fp64 [2N], zero on entry */
 extern "C" int tcct_pw_fwd_bnstats(const void* x, const float* w, const float* bias, void* y, int64_t M, int K, int N, double* stats,
                                    int pre_act, tcct_stream_t stream) {
-    TCCT_CHECK(N % 32 == 0 && N <= 128, "pw_fwd_bnstats: N=%d unsupported (32, 64, 96, 128)", N);
+    TCCT_CHECK(N % 32 == 0 && N <= 160, "pw_fwd_bnstats: N=%d unsupported (32, 64, 96, 128, 160)", N);
     return pw_fwd_impl(x, w, bias, y, M, K, N, 0, TCCT_BF16, stats, pre_act, stream);
 }
 /* y = [x1 | x2] W^T + bias without materialising the concatenation (x1 [M,K1], x2 [M,K-K1]); stats nullable (fused BN statistics) */
@@ -454,6 +454,7 @@ static int pw_fwd_impl(const void* x, const float* w, const float* bias, void* y
         while (nn > 1 && ntiles % nn != 0) --nn;
         NT = nn;
     }
+    if (stats && NT > 4) NT = 1;            // the statistics epilogue is instantiated for 1-4 N-tiles per block: 160 outputs run as five single-tile columns of blocks
     const int gy = (ntiles + NT - 1) / NT;
     size_t lds = (((size_t)NT * 32 * (2 * K + 16) + 15) & ~(size_t)15) + 4 * 2560 + (size_t)NT * 32 * 4;
     TCCT_CHECK(lds <= 160 * 1024, "pw_fwd: weights need %zu B of LDS", lds);

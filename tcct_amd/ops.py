@@ -418,7 +418,7 @@ class _Conv2d(torch.autograd.Function):
         y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=odt)
         mfma = _mfma32_ok(x.dtype, odt, Cin, Cin_w, Cout, KH, KW, stride, padh, padw)
         if _pw_ok(x.dtype, Cin, Cin_w, KH, KW, stride, padh, padw) and not mfma:
-            if stats_box is not None and odt == torch.bfloat16 and Cout % 32 == 0 and Cout <= 128:
+            if stats_box is not None and odt == torch.bfloat16 and Cout % 32 == 0 and Cout <= 160:
                 sums = ZERO.get((2 * Cout,), torch.float64, x.device) if ZERO.active else torch.zeros(2 * Cout, device=x.device, dtype=torch.float64)
                 lib.pw_fwd_bnstats(x, w, bias, y, N * H * W, Cin, Cout, sums, stats_box[0])
                 stats_box[1] = sums

@@ -479,10 +479,11 @@ def test_dwconv(dt, cfg, hw):
 
 
 @pytest.mark.parametrize('cfg', [(32, 64, 3, 3, 'none', 19, 70), (64, 96, 1, 9, 'lrelu', 9, 33), (96, 32, 3, 3, 'none', 10, 14), (32, 32, 3, 3, 'lrelu', 21, 37),
-                                 (64, 64, 1, 1, 'none', 40, 55)])
+                                 (64, 64, 1, 1, 'none', 40, 55), (160, 160, 1, 1, 'none', 50, 69), (160, 160, 1, 1, 'none', 300, 240), (128, 160, 1, 1, 'none', 13, 9)])
 def test_convolutions_deliver_the_batchnorm_statistics_of_their_consumer(cfg):
     """conv2d(..., stats_pre=...) tags its bf16 output with per-channel sum / sum of squares of pre_act(y) as stored, for every MFMA family:
-    32 -> 32 (conv32), wide convolutions as 32-channel slabs (MPViT stem[1] 32 -> 64; the stc_tb encoder), pointwise GEMMs"""
+    32 -> 32 (conv32), wide convolutions as 32-channel slabs (MPViT stem[1] 32 -> 64; the stc_tb encoder), pointwise GEMMs (round 6: also 160 outputs, MPViT stage 3 --
+    small maps as five single-tile block columns, large ones too: the statistics epilogue has no five-tile instantiation)"""
     from tcct_amd import ops
     Ci, Co, KH, KW, pre, H, W = cfg
     x = nhwc(rnd(2, Ci, H, W, dt=torch.bfloat16), torch.bfloat16)
