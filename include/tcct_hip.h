@@ -465,7 +465,7 @@ int tcct_metapool_residual_fwd(const void* x, const void* res, const float* scal
 int tcct_metapool_scaled_bwd(const void* dy, const float* scale, void* dx, int B, int64_t N, int C, int dtype, tcct_stream_t stream);
 /* ... and with the LayerNorm in front of the mixer folded in (csrc/ln_pool.hip; nets/tcct.py:457-465): y = t + scale[b] * (pool(a) - a), a = LN(t; gamma, beta,
  * eps) rounded to the activation type, in ONE pass (read t, write y); backward dt = dy + LN^T(scale[b] * (pool^T(dy) - dy)) in one pass (read dy, read t,
- * write dt; the LayerNorm statistics are recomputed from t).  C a multiple of 8 in 16..128; dgamma / dbeta fp32 [C] overwritten. */
+ * write dt; the LayerNorm statistics are recomputed from t).  C a multiple of 8 in 16..256; dgamma / dbeta fp32 [C] overwritten. */
 int tcct_ln_metapool_residual_fwd(const void* t, void* y, int B, int64_t N, int C, const float* gamma, const float* beta, float eps, const float* scale,
                                   int dtype, tcct_stream_t stream);
 /* ... and MHCABlock.norm2 of the row just produced (nets/tcct.py:466): y2 = LN(y; gamma2, beta2, eps2), mean_rstd2 fp32 [B*N*2] as tcct_layernorm_fwd writes it */

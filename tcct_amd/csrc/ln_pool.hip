@@ -265,18 +265,18 @@ k_ln_metapool_bwd(const T* __restrict__ t, const T* __restrict__ dy, T* __restri
     }
 }
 
-static bool ln_metapool_shape_ok(int B, int64_t N, int C) { return C % 8 == 0 && C >= 16 && C <= 128 && B >= 1 && B <= 65535 && N >= 1 && N < (1LL << 30); }
+static bool ln_metapool_shape_ok(int B, int64_t N, int C) { return C % 8 == 0 && C >= 16 && C <= 256 && B >= 1 && B <= 65535 && N >= 1 && N < (1LL << 30); }   // (round 6: 32-lane groups for 136..256 channels: MPViT stage 3 has 160)
 /* y = t + scale[b] * (pool(a) - a), a = LayerNorm(t; gamma, beta, eps) rounded to the activation type: MHCABlock's first half (nets/tcct.py:457-465 with the
- * MetaPool mixer :405-415) in one pass.  t, y [B,N,C] (dtype 0 fp32 / 1 bf16), C a multiple of 8 in 16..128; scale fp32 [B] or NULL. */
+ * MetaPool mixer :405-415) in one pass.  t, y [B,N,C] (dtype 0 fp32 / 1 bf16), C a multiple of 8 in 16..256 (groups of 8, 16 or 32 lanes); scale fp32 [B] or NULL. */
 static int ln_metapool_fwd_impl(const void* t, void* y, int B, int64_t N, int C, const float* gamma, const float* beta, float eps, const float* scale, void* y2,
                                 const float* gamma2, const float* beta2, float eps2, float* mean_rstd2, int dtype, tcct_stream_t stream) {
-    TCCT_CHECK(ln_metapool_shape_ok(B, N, C), "ln_metapool_residual_fwd: B=%d N=%lld C=%d unsupported (C %% 8 == 0, 16 <= C <= 128)", B, (long long)N, C);
+    TCCT_CHECK(ln_metapool_shape_ok(B, N, C), "ln_metapool_residual_fwd: B=%d N=%lld C=%d unsupported (C %% 8 == 0, 16 <= C <= 256)", B, (long long)N, C);
     TCCT_CHECK(t && y && gamma && beta, "ln_metapool_residual_fwd: NULL argument");
     const int64_t strips = (N + LNP_STRIP - 1) / LNP_STRIP;
 #define LNPF(LP_, L2) hipLaunchKernelGGL((k_ln_metapool_fwd<T, LP_, L2>), dim3((unsigned)((strips + LP_T / LP_ - 1) / (LP_T / LP_)), (unsigned)B), dim3(LP_T), 0, \
                                          (hipStream_t)stream, (const T*)t, (T*)y, (int)N, C, gamma, beta, eps, scale, (T*)y2, gamma2, beta2, eps2, mean_rstd2)
-    if (y2) { TCCT_DISPATCH(dtype, if (C <= 64) LNPF(8, true); else LNPF(16, true)); }
-    else { TCCT_DISPATCH(dtype, if (C <= 64) LNPF(8, false); else LNPF(16, false)); }
+    if (y2) { TCCT_DISPATCH(dtype, if (C <= 64) LNPF(8, true); else if (C <= 128) LNPF(16, true); else LNPF(32, true)); }
+    else { TCCT_DISPATCH(dtype, if (C <= 64) LNPF(8, false); else if (C <= 128) LNPF(16, false); else LNPF(32, false)); }
 #undef LNPF
     TCCT_LAUNCH_OK();
 }
@@ -294,7 +294,7 @@ extern "C" int tcct_ln_metapool_residual_ln_fwd(const void* t, void* y, void* y2
 /* dt = dy + LN^T(da), da = scale[b] * (pool^T(dy) - dy); dgamma, dbeta [C] overwritten.  The LayerNorm statistics are recomputed from t. */
 extern "C" int tcct_ln_metapool_residual_bwd(const void* t, const void* dy, void* dt, int B, int64_t N, int C, const float* gamma, float eps, const float* scale,
                                              float* dgamma, float* dbeta, int dtype, tcct_stream_t stream) {
-    TCCT_CHECK(ln_metapool_shape_ok(B, N, C), "ln_metapool_residual_bwd: B=%d N=%lld C=%d unsupported (C %% 8 == 0, 16 <= C <= 128)", B, (long long)N, C);
+    TCCT_CHECK(ln_metapool_shape_ok(B, N, C), "ln_metapool_residual_bwd: B=%d N=%lld C=%d unsupported (C %% 8 == 0, 16 <= C <= 256)", B, (long long)N, C);
     TCCT_CHECK(t && dy && dt && gamma && dgamma && dbeta, "ln_metapool_residual_bwd: NULL argument");
     hipStream_t st = (hipStream_t)stream;
     if (!tcct_skip_zero_fill() && (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess)) {
@@ -303,7 +303,7 @@ extern "C" int tcct_ln_metapool_residual_bwd(const void* t, const void* dy, void
     const int64_t strips = (N + LNP_STRIP - 1) / LNP_STRIP;
 #define LNPB(LP_) hipLaunchKernelGGL((k_ln_metapool_bwd<T, LP_>), dim3((unsigned)((strips + LP_T / LP_ - 1) / (LP_T / LP_)), (unsigned)B), dim3(LP_T), 0, st, (const T*)t, \
                                      (const T*)dy, (T*)dt, (int)N, C, gamma, eps, scale, dgamma, dbeta)
-    TCCT_DISPATCH(dtype, if (C <= 64) LNPB(8); else LNPB(16));
+    TCCT_DISPATCH(dtype, if (C <= 64) LNPB(8); else if (C <= 128) LNPB(16); else LNPB(32));
 #undef LNPB
     TCCT_LAUNCH_OK();
 }

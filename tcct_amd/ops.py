@@ -2564,7 +2564,7 @@ LN_POOL_FUSE = True       # False: LayerNorm and the token mixer stay separate k
 
 def ln_metapool_residual_ok(t, gamma, beta):
     return (LN_POOL_FUSE and t.dim() == 3 and t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16) and t.shape[-1] % 8 == 0
-            and 16 <= t.shape[-1] <= 128 and t.shape[0] <= 65535 and t.shape[1] < 2 ** 30 and gamma is not None and beta is not None)
+            and 16 <= t.shape[-1] <= 192 and t.shape[0] <= 65535 and t.shape[1] < 2 ** 30 and gamma is not None and beta is not None)
 
 
 def ln_metapool_residual(t, gamma, beta, eps=1e-6, scale=None):

@@ -1716,11 +1716,11 @@ def test_metapool_with_residual(dt, scaled):
 
 
 @pytest.mark.parametrize('dt', DT)
-@pytest.mark.parametrize('cfg', [(3, 61, 64, True), (2, 200, 96, False), (2, 33, 128, True), (1, 1, 16, False), (2, 2, 64, True), (1, 97, 24, False)])
+@pytest.mark.parametrize('cfg', [(3, 61, 64, True), (2, 200, 96, False), (2, 33, 128, True), (1, 1, 16, False), (2, 2, 64, True), (1, 97, 24, False), (2, 70, 160, True), (1, 33, 136, False)])
 def test_layernorm_token_mixer_residual_in_one_pass(dt, cfg):
     """csrc/ln_pool.hip: t + s[b] * (pool(LN(t)) - LN(t)) (reference nets/tcct.py:457-465 with MetaPool :405-415) as one pass each way -- output and the
     gradients of t, gamma, beta against torch; strips that end inside the image, images shorter than a strip, channel counts that leave lanes of a group idle
-    (96 on 16 lanes, 24 on 8); and, in bf16, against the two-kernel path it replaces (same rounding points: nearly every element bit-identical)"""
+    (96 on 16 lanes, 24 on 8; round 6: 160 and 136 on 32 lanes -- MPViT stage 3 has 160 channels); and, in bf16, against the two-kernel path it replaces (same rounding points: nearly every element bit-identical)"""
     from tcct_amd import ops
     B, Nt, C, scaled = cfg
     t = rnd(B, Nt, C, dt=dt).requires_grad_(True)
