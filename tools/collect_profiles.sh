@@ -32,5 +32,14 @@ bash tools/step_traffic.sh ${TAG} > $OUT/${TAG}_traffic.txt 2>&1
 # STEADY-STATE per-launch trace (3 warm-up + 3 traced steps, cut at the optimizer kernel): family table, launch-duration histogram, short launches by symbol
 bash tools/steady_trace.sh ${TAG} > $OUT/${TAG}_steady.out 2>&1
 rm -rf $OUT/${TAG}_steady
+# round 6: the step by level and branch (marker launches; kernel trace + the two PMC passes), for --los=di, the full loss and KiteSeg.predict; the multi-stream step's
+# level timeline from HIP events (no profiler); the allocator's plateau
+bash tools/attrib_trace.sh ${TAG} > $OUT/${TAG}_attrib.log 2>&1
+bash tools/attrib_trace.sh ${TAG}_fl --los di+reg+fpl >> $OUT/${TAG}_attrib.log 2>&1
+bash tools/attrib_trace.sh ${TAG}_inf --infer >> $OUT/${TAG}_attrib.log 2>&1
+python tools/level_timeline.py > $OUT/${TAG}_level_timeline.txt 2>> $OUT/${TAG}_bench.err
+python tools/level_timeline.py --los di+reg+fpl > $OUT/${TAG}_level_timeline_fullloss.txt 2>> $OUT/${TAG}_bench.err
+MEMGROW_STEPS=241 python tools/memgrow.py > $OUT/${TAG}_memgrow.txt 2>> $OUT/${TAG}_bench.err
+rm -rf $OUT/${TAG}_attrib_trace $OUT/${TAG}_attrib_fetch $OUT/${TAG}_attrib_write $OUT/${TAG}_fl_attrib_trace $OUT/${TAG}_fl_attrib_fetch $OUT/${TAG}_fl_attrib_write $OUT/${TAG}_inf_attrib_trace $OUT/${TAG}_inf_attrib_fetch $OUT/${TAG}_inf_attrib_write
 # keep only the small summaries
 find $OUT/${TAG}_step $OUT/${TAG}_stepfl $OUT/${TAG}_roof $OUT/${TAG}_lroof $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_lfetch $OUT/${TAG}_lwrite $OUT/${TAG}_mfma $OUT/${TAG}_sq -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null

@@ -149,6 +149,22 @@ if os.path.exists(f'{G}/{tag}_traffic.txt'):
                  f'(copy ceiling of this box: {b["roofline"].get("copy_ceiling", {}).get("GBs", "?")} GB/s; SURVEY 8(d) model bytes: '
                  f'{b["roofline"].get("step_model_GBs", "?")} GB/s): the step as a whole moves its REAL bytes close to the achievable rate, '
                  f'so what is left to gain is passes removed, not kernels tuned.  Per kernel: `profiles/{tag}_step_traffic.txt`.')
+# ---- round 6: the step by level and branch (tools/attrib_trace.sh), the level timeline of the multi-stream step, the allocator plateau
+for src, dst in ((f'{tag}_attrib_summary.md', f'{tag}_attrib_summary.md'), (f'{tag}_fl_attrib_summary.md', f'{tag}_attrib_fullloss_summary.md'),
+                 (f'{tag}_inf_attrib_summary.md', f'{tag}_attrib_infer_summary.md'), (f'{tag}_attrib_calls.csv', f'{tag}_attrib_calls.csv'),
+                 (f'{tag}_level_timeline.txt', f'{tag}_level_timeline.txt'), (f'{tag}_level_timeline_fullloss.txt', f'{tag}_level_timeline_fullloss.txt'),
+                 (f'{tag}_memgrow.txt', f'{tag}_memgrow.txt')):
+    if os.path.exists(f'{G}/{src}'):
+        shutil.copy(f'{G}/{src}', f'{P}/{dst}')
+if os.path.exists(f'{P}/{tag}_attrib_infer_summary.md'):
+    t_ = open(f'{P}/{tag}_attrib_infer_summary.md').read().replace('the training step by level and branch', 'KiteSeg.predict (eval forward + argmax mask) by level and branch')
+    open(f'{P}/{tag}_attrib_infer_summary.md', 'w').write(t_)
+if os.path.exists(f'{P}/{tag}_attrib_summary.md'):
+    L.append(f'\n## the step by level and branch (`tools/attrib_trace.sh`): `profiles/{tag}_attrib_summary.md` (`--los=di`), `profiles/{tag}_attrib_fullloss_summary.md`, '
+             f'`profiles/{tag}_attrib_infer_summary.md` (predict); per C-ABI call: `profiles/{tag}_attrib_calls.csv`; level timeline of the multi-stream step (HIP events, no profiler): '
+             f'`profiles/{tag}_level_timeline.txt`\n')
+    body = open(f'{P}/{tag}_attrib_summary.md').read().split('## levels 3-4 of the CNN encoder')[0].splitlines()
+    L.extend(body[3:])
 open(f'{P}/{tag}_summary.md', 'w').write('\n'.join(L) + '\n')
 print('\n'.join(L)[:3000])
 # HBM traffic of the roofline kernels + the hash of the sources they were collected on -> profiles/TAG_pmc.json (bench.py's roofline.traffic)
