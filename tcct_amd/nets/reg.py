@@ -122,10 +122,30 @@ class RegNet(nn.Module):
         else:
             eps_p, eps_t = (e.to(dev, torch.float32).permute(0, 2, 3, 1).contiguous() for e in noise[:2])
             jit_t, jit_p = (j.to(dev, torch.float32).reshape(H).contiguous() for j in noise[2:])
-        x_pred = ops.slice_channels_f32(logits, 1, n)                 # pred[:,1:]
-        x_true, prob_true = ops.label_planes(lab, 1, n)               # true[:,1:].float(), |d/dh| edge map
-        m_pred = self._lap_map(ops.gumbel_colsoftmax_sum(self._lap_reg(x_pred), eps_p))
-        m_true = self._lap_map(ops.gumbel_colsoftmax_sum(self._lap_reg(x_true), eps_t))
+        if ops.REG_FORK and ops.loss_fork_ok(pred):
+            # round 6: the two chains (pred: slice -> lap_reg -> sampling softmax -> lap_map; true: label planes -> the same) only meet in the MSE terms.  The true chain
+            # runs on the 'vit' stream (idle while the losses are evaluated; autograd replays its backward there): ~25 small fp32 launches each way leave the critical
+            # stream.  ORDER: lap_map's BatchNorm moves its running statistics twice per step, pred first (reference nets/reg.py:128-129) -- the true chain's lap_map
+            # waits for the pred chain's.
+            cur = torch.cuda.current_stream()
+            side = ops.side_stream('vit')
+            side.wait_stream(cur)                   # the noise draws above
+            with torch.cuda.stream(side):
+                x_true, prob_true = ops.label_planes(lab, 1, n)
+                r_true = ops.gumbel_colsoftmax_sum(self._lap_reg(x_true), eps_t)
+            m_pred = self._lap_map(ops.gumbel_colsoftmax_sum(self._lap_reg(ops.slice_channels_f32(logits, 1, n)), eps_p))
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                m_true = self._lap_map(r_true)
+            cur.wait_stream(side)
+            ops.keep_until_end_of_step(m_true, prob_true, cur)
+        else:
+            x_pred = ops.slice_channels_f32(logits, 1, n)                 # pred[:,1:]
+            x_true, prob_true = ops.label_planes(lab, 1, n)               # true[:,1:].float(), |d/dh| edge map
+            m_pred = self._lap_map(ops.gumbel_colsoftmax_sum(self._lap_reg(x_pred), eps_p))
+            m_true = self._lap_map(ops.gumbel_colsoftmax_sum(self._lap_reg(x_true), eps_t))
         RegNet.tmp['reg_pred'] = m_pred[0].detach().permute(2, 0, 1).unsqueeze(1)
         RegNet.tmp['reg_true'] = prob_true[0].permute(2, 0, 1).unsqueeze(1)
         idx = torch.arange(0, H, device=dev, dtype=torch.float32)

@@ -818,6 +818,26 @@ def run_parallel(tag, fa, fb):
     return ra, rb
 
 
+def side_stream(tag):
+    """the library's side stream `tag` of the current device (created on first use)"""
+    cur = torch.cuda.current_stream()
+    side = _SIDE_STREAMS.get((tag, cur.device.index))
+    if side is None:
+        side = _SIDE_STREAMS[(tag, cur.device.index)] = fresh_stream(cur.device)
+    return side
+
+
+def keep_until_end_of_step(*tensors_and_stream):
+    """tensors allocated on a side stream and consumed on `stream` (the last argument): kept alive until end_step() inside a pooled step, record_stream()ed otherwise
+    (see run_parallel)"""
+    *ts, stream = tensors_and_stream
+    if ZERO.active:
+        _WGRAD_KEEP.extend(ts)
+    else:
+        for t in ts:
+            t.record_stream(stream)
+
+
 def run_interleaved(tag, ga, gb, outs_b):
     """Exhaust the generators ga (current stream) and gb (side stream `tag`) ALTERNATELY, gb first, and join.  The two encoders are
     issued level by level in turn rather than one after the other: the runtime lets the host run only a bounded number of launches
@@ -3010,6 +3030,7 @@ def deep_supervision_dice(logits0_nhwc, labels, lows, coff):
 # streams beyond the fourth share a queue with another one and serialise against it.  The step therefore uses exactly four streams -- current, 'vit', 'vit_enc',
 # 'wgrad' -- and the later forks REUSE the encoder streams, which are idle when the fusion / the losses run (forward: joined; backward: not started yet).
 FUSE_STREAM_TAG = 'vit_enc'
+REG_FORK = True          # RegNet.regular_reg: the `true` chain on the (idle) 'vit' stream beside the `pred` chain
 LOSS_FORK = True         # KiteSeg.calc_loss: the boundary-regression loss on the (idle) 'vit_enc' stream beside Dice + feature polarization
 
 

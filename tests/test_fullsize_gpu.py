@@ -556,9 +556,11 @@ def test_fullsize_bf16_train_step_matches_the_rounding_point_oracle(tmp_path):
     assert len(named) >= 20
     for n in named:
         assert cos[n] >= 0.99, (n, cos[n])
-        # norm within 3 % of the rounding oracle's -- or within twice what the rounding model itself moves that tensor's norm against fp32, where that is more: HIP and
-        # the oracle round at the same points but sum in different orders, i.e. they are two realisations of the same storage noise (measured: the level-0
-        # cross-convolution weights 2.3-3.0 %, everything else <= 1 %)
-        assert abs(nrm[n] - 1.0) <= max(0.03, 2.0 * dev_model[n]), (n, nrm[n], dev_model[n])
+        # norm within 3 % of the rounding oracle's; 5 % for the CNN encoder's levels 0-1.  HIP and the oracle round at the same points but sum in different orders: two
+        # realisations of the same storage noise, which the junction's 1 / sigma of a BatchNorm amplifies for a whole branch at once (block34's three weights move
+        # together).  tools/grad_bias_probe.py (profiles/r06_grad_noise_probe.txt) at 2 x 256 x 256: the rounding model ITSELF moves these norms by -15 ... +9 % against
+        # fp32, HIP by -10 ... +5 %; the spread shrinks with 1 / sqrt(pixels) to the 2.3-3.2 % measured here over three runs (everything outside the CNN's levels 0-1: <= 1 %)
+        wide = n.startswith(('base.base_cnn.cnn.0', 'base.base_cnn.path_estan.0', 'base.base_cnn.path_estan.1'))
+        assert abs(nrm[n] - 1.0) <= (0.05 if wide else 0.03), (n, nrm[n], dev_model[n])
     tn = lambda d: sum((t ** 2).sum() for t in d.values()).sqrt().item()      # noqa: E731
     assert abs(tn(gh) - tn(go)) <= 3e-2 * tn(go), (tn(gh), tn(go))
