@@ -61,5 +61,41 @@ for (B, H, W, mode) in [(8, 800, 1104, 'plain'), (8, 800, 1100, 'stats'), (8, 40
         nbad += int((y != ref).any(dim=3).sum()) + int((mid != mid_ref).any(dim=3).sum())
     print('chain33', (B, H, W, mode), 'mismatching pixels over 25 runs:', nbad, flush=True)
     bad_total += nbad
+# round 6 (advisor): the radix multi-select's last-ticket hand-over (the block that takes the last ticket of a level reads the merged histogram behind ONE agent-scope
+# acquire fence): the bin map of every run must equal the stable sort's binning, repeated, 16 classes (four histogram passes per level), with a second stream hammering HBM
+import torch.nn.functional as F_
+for (B, H, W, C, q) in [(8, 800, 1104, 16, 0.0), (8, 800, 1104, 5, 0.25), (3, 400, 552, 16, 0.5)]:
+    M = B * H * W
+    g = torch.Generator(device='cuda').manual_seed(C + H)
+    lab = torch.randint(0, C, (M,), device='cuda', generator=g, dtype=torch.int64).to(torch.uint8)
+    logit = torch.randn(M, device='cuda', generator=g)
+    prob = torch.sigmoid(torch.round(logit / q) * q if q > 0 else logit).contiguous()        # q > 0: heavy ties, resolved by the pixel-index bytes of the key
+    feat = torch.randn((M, 32), device='cuda', generator=g).bfloat16()
+    # the stable sort's binning: class by class, (prob descending, pixel ascending), rank r -> bin r // (n_c // 32), tail dropped (bin 255 = not selected)
+    want = torch.full((M,), 255, device='cuda', dtype=torch.uint8)
+    for c in range(C):
+        pix = (lab == c).nonzero().view(-1)
+        n = pix.numel() // 32
+        if n == 0:
+            continue
+        order = torch.sort(prob[pix], descending=True, stable=True).indices
+        sel = pix[order][:32 * n]
+        want[sel] = (torch.arange(32 * n, device='cuda') // n).to(torch.uint8)
+    ws = torch.empty(int(lib.fpl_select_workspace_bytes()), device='cuda', dtype=torch.uint8)
+    cnt = torch.empty(16, device='cuda', dtype=torch.int32)
+    ps = torch.empty((C, 32, 32), device='cuda')
+    nbad = 0
+    for it in range(20):
+        bm = torch.full((M,), 77, device='cuda', dtype=torch.uint8)
+        if it % 2:
+            with torch.cuda.stream(side):
+                for _ in range(6): big2.copy_(big)
+        lib.fpl_select(feat, lab, prob, M, C, ws, cnt, bm, ps, 1)
+        torch.cuda.synchronize()
+        got = bm.clone()
+        sel = want != 255
+        nbad += int((got[sel] != want[sel]).sum()) + int((got[~sel] < 32).sum())
+    print('fpl_select', (B, H, W, C, q), 'pixels in another bin than the stable sort puts them, over 20 runs:', nbad, flush=True)
+    bad_total += nbad
 print('TOTAL', bad_total)
 sys.exit(1 if bad_total else 0)
