@@ -754,7 +754,8 @@ static int pw_wgrad_impl(const void* x, const void* x2, int K1, const void* dy, 
     if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)N * K, st) != hipSuccess) { tcct_set_error("pw_wgrad: memset failed"); return -2; }
     if (dbias && !tcct_skip_zero_fill() && hipMemsetAsync(dbias, 0, sizeof(float) * N, st) != hipSuccess) { tcct_set_error("pw_wgrad: memset failed"); return -2; }
     const int NT = N / 32, ktiles = K / 32;
-    const int KTB = (ktiles % 2 == 0 && NT <= 2) ? 2 : 1;       // <= 5 accumulators per wave next to the prefetch registers
+    const int KTB = (ktiles % 2 == 0 && NT <= 2) ? 2 : 1;       // <= 5 accumulators per wave next to the prefetch registers (round 6: two slabs at 96 / 128 outputs -- to re-read dy
+                                                                // half as often: stage 1's `aggregate` reads its 113 MB dy six times -- spill 22 / 139 VGPRs at two blocks per CU: not offered)
     const int gy = ktiles / KTB;
     TCCT_CHECK(!x2 || K1 % (KTB * 32) == 0, "pw_wgrad_cat2: K1=%d must be a multiple of %d for this shape", K1, KTB * 32);
     // row strides: S mod 256 in {64,192} keeps the 4-pixel x 64-byte footprint of a transposing read on distinct banks
