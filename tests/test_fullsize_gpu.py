@@ -439,7 +439,7 @@ def test_fullsize_bf16_train_step_matches_the_rounding_point_oracle(tmp_path):
     13-tap weight gradients take the row streams), full loss (Dice + reg + fpl), seeded default weights, against the oracle's rounding-point mode
     (`tcct_oracle.rounding_points('bf16')`: fp32 arithmetic, bf16 where the HIP path stores) forward AND backward on the CPU.  The launch census proves which
     kernels served the step.  Bounds for heads and loss parts as in tests/test_model_gpu.py::test_bf16_matches_rounding_point_oracle; named gradient tensors
-    spanning CNN L0-L4, the ViT stages and the decoder: direction and norm against the oracle's backward."""
+    spanning CNN L0-L4, the ViT stages and the decoder: direction (cosine >= 0.99; 0.985 for the CNN encoder, measured >= 0.9922) and norm against the oracle's backward."""
     import argparse
     import contextlib
     import os
@@ -555,7 +555,7 @@ def test_fullsize_bf16_train_step_matches_the_rounding_point_oracle(tmp_path):
     print('norm deviation of the rounding model from fp32 (named):', {n.replace('base.', ''): round(v, 4) for n, v in dev_model.items()})
     assert len(named) >= 20
     for n in named:
-        assert cos[n] >= 0.99, (n, cos[n])
+        assert cos[n] >= (0.985 if n.startswith('base.base_cnn') else 0.99), (n, cos[n])       # measured: CNN 0.9922-0.9997 (lowest: level 4's first 3x3), everything else >= 0.9993
         # norm within 3 % of the rounding oracle's; 5 % for the CNN encoder's levels 0-1.  HIP and the oracle round at the same points but sum in different orders: two
         # realisations of the same storage noise, which the junction's 1 / sigma of a BatchNorm amplifies for a whole branch at once (block34's three weights move
         # together).  tools/grad_bias_probe.py (profiles/r06_grad_noise_probe.txt) at 2 x 256 x 256: the rounding model ITSELF moves these norms by -15 ... +9 % against

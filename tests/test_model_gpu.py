@@ -617,7 +617,7 @@ def test_real_checkpoint_inference_matches_reference(name, dtype):
     if dtype == torch.float32:
         assert flips == 0 and abs(d_ref - d_hip) <= 1e-6
     elif name == 'goals_legacy':
-        assert abs(d_ref - d_hip) <= 1e-3 and d_self >= 0.999, (d_ref, d_hip, d_self)
+        assert abs(d_ref - d_hip) <= 1e-3 and d_self >= 0.998, (d_ref, d_hip, d_self)        # measured 4.8e-4 ... 6.2e-4 and 0.99905-0.99912 (8-9 pixels differ)
     else:
         assert abs(d_ref - d_hip) <= 5e-3, (d_ref, d_hip)           # measured 3.2e-3 (12 of 25 600 pixels differ)
 
