@@ -220,6 +220,10 @@ int tcct_pw_fwd_affine_residual(const void* x, const float* w, const float* bias
  * nets/tcct.py:600-616) */
 int tcct_pw_fwd_cat2_affine(const void* x1, const void* x2, const float* w, const float* bias, const float* ab, int post_act, void* y, int64_t M, int K, int N,
                             tcct_stream_t stream);
+/* inference: y = res + (a[c] * (hswish(a_prev[k] * y_prev + b_prev[k]) W^T + bias[c]) + b[c]): the InvRes tail (nets/tcct.py:563-572) as one GEMM over the depthwise
+ * convolution's raw output; ab_prev = {a[K], b[K]} of `norm`, ab = {a[N], b[N]} of conv2.bn (both eval mode); K = N in {64, 96, 128} */
+int tcct_pw_fwd_xaff_affine_residual(const void* y_prev, const float* ab_prev, const float* w, const float* bias, const float* ab, const void* res, void* y,
+                                     int64_t M, int K, int N, tcct_stream_t stream);
 /* y = conv(x) + bias + res, res bf16 NHWC [N,H,W,32] (not overlapping y): used as the input gradient of a convolution whose input has
  * a second consumer (CrossCNNBlock: x feeds block12 and block34, nets/tcct.py:826) -- no separate gradient accumulation pass */
 int tcct_conv32_fwd_add(const void* x, const void* wp, const float* bias, const void* res, void* y, int N, int H, int W, int KH, int KW,
@@ -244,6 +248,11 @@ int tcct_conv32_fwd_strided(const void* x, const void* wp, const float* bias, vo
  * zero before the first slab */
 int tcct_conv32_fwd_strided_bnstats(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH,
                                     int PW, int xs, int xo, int ys, int yo, int accumulate, double* stats, int pre_act, tcct_stream_t stream);
+/* inference: one 32-channel output slab of a wider convolution with ONE 32-channel input slab (MPViT stem[1], 32 -> 64 3x3, nets/tcct.py:682-689) with the eval-mode
+ * BatchNorm + activation of those channels in the epilogue; ab = {a[32], b[32]} of the slab (tcct_bn_eval_ab on the 32-channel slices).  Replaces
+ * tcct_conv32_fwd_strided + tcct_bn_apply in `KiteSeg.predict`. */
+int tcct_conv32_fwd_strided_affine(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH, int PW, int xs,
+                                   int xo, int ys, int yo, const float* ab, int pre_act, int post_act, tcct_stream_t stream);
 /* selects the kernel behind tcct_conv32_wgrad for plain 3x3 convolutions: 0 (default) = wave-private row streams where a wave gets >= 32 rows (levels 0-1), else the rolling-row form (one x fragment per halo row meets a register window of three dy fragments, 6 waves x 2 blocks per
  * CU); 1 = the generic register-staged kernel every other shape takes (comparison arm of the bit-compatibility test; bench.py --wgrad-mode 1 for a whole run);
  * 2 = row streams for every plain 3x3; any other value only queries.  Returns the previous mode.  (No reference counterpart: the reference calls ATen's

@@ -493,6 +493,14 @@ extern "C" int tcct_conv32_fwd_strided_bnstats(const void* x, const void* wp, co
     TCCT_CHECK(xs % 8 == 0 && xo % 8 == 0 && ys % 4 == 0 && yo % 4 == 0 && xo + 32 <= xs && yo + 32 <= ys && stats, "conv32_fwd_strided_bnstats: bad slab");
     return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, xs, xo, ys, yo, accumulate, stats + yo, pre_act, stream, nullptr, 0, false, nullptr, ys);
 }
+/* inference: one 32-channel OUTPUT slab of a wider convolution with a single 32-channel input slab (MPViT stem[1]: 32 -> 64, 3x3, nets/tcct.py:682-689) with the
+ * eval-mode BatchNorm + activation of those 32 channels in the epilogue: y[..., yo:yo+32] = post_act(a[c] * pre_act(conv(x[..., xo:xo+32]) + bias[c]) + b[c]),
+ * ab = {a[32], b[32]} of the slab's channels (tcct_bn_eval_ab on the 32-channel slices of the BatchNorm's tensors).  Replaces tcct_conv32_fwd_strided + tcct_bn_apply. */
+extern "C" int tcct_conv32_fwd_strided_affine(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW, int PH, int PW, int xs,
+                                              int xo, int ys, int yo, const float* ab, int pre_act, int post_act, tcct_stream_t stream) {
+    TCCT_CHECK(xs % 8 == 0 && xo % 8 == 0 && ys % 4 == 0 && yo % 4 == 0 && xo + 32 <= xs && yo + 32 <= ys, "conv32_fwd_strided_affine: bad slab");
+    return conv32_fwd_impl(x, wp, bias, y, N, H, W, KH, KW, PH, PW, xs, xo, ys, yo, 0, nullptr, pre_act, stream, ab, post_act, true);
+}
 static int conv32_fwd_impl(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int KH, int KW,
                            int PH, int PW, int xs, int xo, int ys, int yo, int accum, double* stats, int stat_pre, tcct_stream_t stream,
                            const float* aff, int aff_post, bool affine, const void* yadd, int stats_sq_off) {

@@ -424,6 +424,14 @@ extern "C" int tcct_pw_fwd_affine_residual(const void* x, const float* w, const 
     TCCT_CHECK(res != nullptr && pw_fwd2_aff_ok(M, K, N, false, true), "pw_fwd_affine_residual: K=%d N=%d unsupported (64, 96 or 128 square) or res NULL", K, N);
     return pw_fwd2_launch(x, nullptr, w, bias, y, M, K, N, nullptr, 0, stream, PwRes{(const bf16*)res, nullptr, 1, nullptr, nullptr, ab, TCCT_ACT_NONE, 1});
 }
+/* inference: y = res + (a[c] * (hswish(a_prev[k] * y_prev + b_prev[k]) W^T + bias[c]) + b[c]): the InvRes tail `x + BN(conv2(hswish(BN(dw))))` (nets/tcct.py:563-572) as ONE
+ * GEMM over the depthwise convolution's raw output -- `norm`'s eval-mode BatchNorm + Hardswish applied while the tile is staged, conv2's BatchNorm and the residual in the
+ * epilogue; ab_prev = {a[K], b[K]}, ab = {a[N], b[N]}; K = N in {64, 96, 128} */
+extern "C" int tcct_pw_fwd_xaff_affine_residual(const void* y_prev, const float* ab_prev, const float* w, const float* bias, const float* ab, const void* res, void* y,
+                                                int64_t M, int K, int N, tcct_stream_t stream) {
+    TCCT_CHECK(y_prev && ab_prev && res != nullptr && pw_fwd2_aff_ok(M, K, N, false, true), "pw_fwd_xaff_affine_residual: K=%d N=%d unsupported (64, 96 or 128 square) or NULL argument", K, N);
+    return pw_fwd2_launch(y_prev, nullptr, w, bias, y, M, K, N, nullptr, 0, stream, PwRes{(const bf16*)res, nullptr, 1, nullptr, ab_prev, ab, TCCT_ACT_NONE, 1});
+}
 /* inference: y = post_act(a[c] * ([x1 | x2] W^T + bias[c]) + b[c]) over the never-materialised concatenation of two 64-channel tensors, N = 96: `aggregate` of MHCA stage 0
  * (nets/tcct.py:600-616) with its eval-mode BatchNorm + Hardswish in the epilogue */
 extern "C" int tcct_pw_fwd_cat2_affine(const void* x1, const void* x2, const float* w, const float* bias, const float* ab, int post_act, void* y, int64_t M, int K, int N,
@@ -1537,7 +1545,8 @@ k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* 
     if (tid < N) sB[tid] = bias ? bias[tid] : 0.f;
     float* sXA = reinterpret_cast<float*>(sS + 4 * 2560);             // XAP: a[K], b[K] of the BatchNorm in front;  AFF: a[N], b[N] of the one behind
     if (XAP >= 0) for (int i = tid; i < 2 * K; i += PWB) sXA[i] = pr.xab[i];
-    if (AFF) for (int i = tid; i < 2 * N; i += PWB) sXA[i] = pr.aff ? pr.aff[i] : (i < N ? 1.f : 0.f);
+    float* sAF = sXA + (XAP >= 0 ? 2 * K : 0);                         // (both at once: InvRes.norm applied on load AND conv2.bn + residual in the epilogue, inference)
+    if (AFF) for (int i = tid; i < 2 * N; i += PWB) sAF[i] = pr.aff ? pr.aff[i] : (i < N ? 1.f : 0.f);
     float ss[STATS ? NT : 1][8], sq[STATS ? NT : 1][8];
 #pragma unroll
     for (int a = 0; a < (STATS ? NT : 1); ++a)
@@ -1625,8 +1634,8 @@ k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* 
                 const float4 bq = *reinterpret_cast<const float4*>(sB + nt * 32 + 8 * q + 4 * hh);
                 float v0 = acc[nt][4 * q] + bq.x, v1 = acc[nt][4 * q + 1] + bq.y, v2 = acc[nt][4 * q + 2] + bq.z, v3 = acc[nt][4 * q + 3] + bq.w;
                 if (AFF) {
-                    const float4 aq = *reinterpret_cast<const float4*>(sXA + nt * 32 + 8 * q + 4 * hh);
-                    const float4 cq = *reinterpret_cast<const float4*>(sXA + N + nt * 32 + 8 * q + 4 * hh);
+                    const float4 aq = *reinterpret_cast<const float4*>(sAF + nt * 32 + 8 * q + 4 * hh);
+                    const float4 cq = *reinterpret_cast<const float4*>(sAF + N + nt * 32 + 8 * q + 4 * hh);
                     v0 = act_fwd(pr.aff_post, aq.x * v0 + cq.x); v1 = act_fwd(pr.aff_post, aq.y * v1 + cq.y);
                     v2 = act_fwd(pr.aff_post, aq.z * v2 + cq.z); v3 = act_fwd(pr.aff_post, aq.w * v3 + cq.w);
                 }
@@ -1722,6 +1731,12 @@ static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const f
         hipLaunchKernelGGL((k_pw_fwd2<T, T, true, false, false, false, 2>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)x2, w, bias, (bf16*)y, M, stats, stat_pre, pr); }
 #define F2F(NTV, KTV, SPV, RSV) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd2<NTV, KTV, false, SPV, RSV, false, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
         hipLaunchKernelGGL((k_pw_fwd2<NTV, KTV, false, SPV, RSV, false, -1, true>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)x2, w, bias, (bf16*)y, M, stats, stat_pre, pr); }
+#define F2X(T) { static bool at_ = false; if (!at_) { (void)hipFuncSetAttribute((const void*)k_pw_fwd2<T, T, false, false, true, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at_ = true; } \
+        hipLaunchKernelGGL((k_pw_fwd2<T, T, false, false, true, false, 2, true>), dim3((unsigned)gx), dim3(PWB), lds, st, (const bf16*)x, (const bf16*)x2, w, bias, (bf16*)y, M, stats, stat_pre, pr); }
+    if (pr.has_aff && pr.xab) {           // inference: BatchNorm + Hardswish in front applied on load, BatchNorm behind + residual in the epilogue (square 64 / 96 / 128)
+        if (NT == 2) F2X(2) else if (NT == 3) F2X(3) else F2X(4)
+    }
+    else
     if (pr.has_aff) {           // inference epilogues (pw_fwd2_aff_ok lists the shapes)
         if (x2) F2F(3, 4, true, false)
         else if (pr.res) { if (NT == 2) F2F(2, 2, false, true) else if (NT == 3) F2F(3, 3, false, true) else F2F(4, 4, false, true) }
@@ -1734,6 +1749,7 @@ static int pw_fwd2_launch(const void* x, const void* x2, const float* w, const f
     else
     if (pr.res) { switch (NT) { case 1: F2RK(1) break; case 2: F2RK(2) break; case 3: F2RK(3) break; default: F2RK(4) break; } }
     else if (stats) { F2N(true) } else { F2N(false) }
+#undef F2X
 #undef F2F
 #undef F2G
 #undef F2A

@@ -410,6 +410,11 @@ class ResBlock(nn.Module):
             # norm's normalisation + Hardswish is applied by conv2's kernels while they stage their tiles: the tensor between them never exists
             ya, link = ops.batchnorm_deferred(y, m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked, m.eps, m.momentum, 'hswish')
             return ops.pw_conv_bn(ya, c2.conv.weight, None, _bn_args(c2.bn), None, residual=x, deferred=link)
+        if not m.training and not c2.bn.training and not c2.act and ops.invres_tail_eval_ok(y, c2.conv.weight, c2.conv.bias, x):
+            # inference (round 6): `norm` + Hardswish on conv2's load path, conv2.bn and the residual in its epilogue: the two passes between dwconv and the stage's sum disappear
+            mb = c2.bn
+            return ops.invres_tail_eval(y, (m.weight, m.bias, m.running_mean, m.running_var, m.eps), c2.conv.weight, c2.conv.bias,
+                                        (mb.weight, mb.bias, mb.running_mean, mb.running_var, mb.eps), x)
         f = _bn(self.norm, y, post='hswish')
         # x + BN(conv2(f)): the add rides on the normalisation pass; conv2 is the only consumer of f, so the backward reduction of `norm`
         # rides on conv2's input-gradient epilogue (x_final)

@@ -888,6 +888,18 @@ def conv_bn_act(x, w, bias=None, stride=1, pad=0, bn=None, pre_act=None, post_ac
     pre, post = ACT[pre_act], ACT[post_act]
     mfma = _mfma32_ok(x4.dtype, x4.dtype, Cin, Cin_w, Cout, KH, KW, stride, ph, pw)
     pwk = _pw_ok(x4.dtype, Cin, Cin_w, KH, KW, stride, ph, pw) and not mfma and (bn is not None or pre != 0 or post != 0)
+    if (not (mfma or pwk) and bn is not None and Cin == 32 and Cin_w == 32 and _mfma_slabs_ok(x4.dtype, x4.dtype, Cin, Cin_w, Cout, KH, KW, stride, ph, pw)):
+        # round 6: a wider convolution with ONE input slab (MPViT stem[1], 32 -> 64): every 32-channel output slab with its part of the eval-mode BatchNorm + activations
+        # in the epilogue (no separate normalisation pass over the 64-channel tensor)
+        y = torch.empty((N, H, W, Cout), device=x.device, dtype=x.dtype)
+        for oh in range(Cout // 32):
+            sl = slice(32 * oh, 32 * oh + 32)
+            ab = torch.empty(64, device=x.device, dtype=torch.float32)
+            lib.bn_eval_ab(32, bn[0][sl], bn[1][sl], float(bn[4]), bn[2][sl], bn[3][sl], torch.empty(64, device=x.device, dtype=torch.float32), ab)
+            wp = torch.empty(KH * KW * 1024, device=x.device, dtype=torch.bfloat16)
+            lib.conv32_pack_weights_sub(w4, wp, KH, KW, 0, Cin, 32 * oh, 0)
+            lib.conv32_fwd_strided_affine(x4, wp, bias[sl] if bias is not None else None, y, N, H, W, KH, KW, ph, pw, Cin, 0, Cout, 32 * oh, ab, pre, post)
+        return y.squeeze(2) if tok else y
     if not (mfma or pwk):
         y = conv2d(x, w, bias, stride, pad)
         if bn is not None:
@@ -928,6 +940,20 @@ def conv_bn_residual_eval(x, w, bias, bn, residual):
     y = torch.empty_like(x)
     lib.pw_fwd_affine_residual(x, w, bias, _eval_ab(bn, C, x.device), residual, y, x.numel() // C, C, C)
     return y
+
+
+def invres_tail_eval_ok(y_dw, w, bias, residual):
+    """inference: x + BN(conv2(hswish(BN(y_dw)))) as ONE GEMM (tcct_pw_fwd_xaff_affine_residual)"""
+    return (INFER_FUSE and not torch.is_grad_enabled() and y_dw.dtype == torch.bfloat16 and y_dw.dim() == 4 and y_dw.is_cuda and y_dw.shape[-1] in (64, 96, 128)
+            and tuple(w.shape) == (y_dw.shape[-1], y_dw.shape[-1], 1, 1) and residual.shape == y_dw.shape and residual.dtype == y_dw.dtype and y_dw.numel() * 2 < 2 ** 31)
+
+
+def invres_tail_eval(y_dw, bn_norm, w, bias, bn2, residual):
+    _chk(y_dw, w, bias, residual)
+    C = y_dw.shape[-1]
+    out = torch.empty_like(y_dw)
+    lib.pw_fwd_xaff_affine_residual(y_dw, _eval_ab(bn_norm, C, y_dw.device), w, bias, _eval_ab(bn2, C, y_dw.device), residual, out, y_dw.numel() // C, C, C)
+    return out
 
 
 def conv1x1_cat2_bn_act_eval_ok(x1, x2, w, post_act):

@@ -2539,3 +2539,36 @@ def test_first_layers_eval_mode_one_store():
         want = a.view(1, -1, 1, 1) * y + c.view(1, -1, 1, 1)
         want = F.hardswish(want) if post == 2 else want
         torch.testing.assert_close(nchw(z), want, rtol=2e-2, atol=2e-2 * max(1.0, want.abs().max().item()))
+
+
+@pytest.mark.parametrize('C', [64, 96, 128])
+def test_invres_tail_as_one_gemm_in_eval_mode(C):
+    """round 6, inference: x + BN2(conv2(hswish(BN1(y)))) (InvRes tail, reference nets/tcct.py:563-572) as ONE tile-staged GEMM -- BN1 + Hardswish while the tile is staged,
+    BN2 and the residual in the epilogue -- against torch fp32 with the op-by-op rounding points (f and the normalised product rounded to bf16)"""
+    from tcct_amd._lib import lib
+    m = 4321
+    y = rnd(m, C, seed=1, dt=torch.bfloat16)
+    w = rnd(C, C, seed=2) / C ** 0.5
+    a1, c1 = 1 + 0.3 * rnd(C, seed=3), 0.2 * rnd(C, seed=4)
+    a2, c2 = 1 + 0.3 * rnd(C, seed=5), 0.2 * rnd(C, seed=6)
+    res = rnd(m, C, seed=7, dt=torch.bfloat16)
+    out = torch.full((m, C), 7.0, device='cuda', dtype=torch.bfloat16)
+    lib.pw_fwd_xaff_affine_residual(y.cuda().bfloat16(), torch.cat([a1, c1]).cuda(), w.cuda(), None, torch.cat([a2, c2]).cuda(), res.cuda().bfloat16(), out, m, C, C)
+    f = F.hardswish(a1 * y + c1).bfloat16().float()
+    want = (a2 * (f @ w.bfloat16().float().t()) + c2).bfloat16().float() + res
+    torch.testing.assert_close(out.float().cpu(), want, rtol=2e-2, atol=2e-2 * max(1.0, want.abs().max().item()))
+
+
+def test_wide_convolution_output_slabs_with_eval_batchnorm_epilogue():
+    """round 6, inference: MPViT stem[1] (32 -> 64, 3x3) as two output slabs, each with its half of the eval-mode BatchNorm + Hardswish in the epilogue
+    (tcct_conv32_fwd_strided_affine through ops.conv_bn_act) against F.conv2d + affine + Hardswish"""
+    from tcct_amd import ops
+    x = rnd(2, 32, 21, 37, seed=1, dt=torch.bfloat16)
+    w = rnd(64, 32, 3, 3, seed=2) / 288 ** 0.5
+    gamma, beta = 1 + 0.3 * rnd(64, seed=3), 0.2 * rnd(64, seed=4)
+    rm, rv = 0.1 * rnd(64, seed=5), 1 + 0.5 * torch.rand(64)
+    with torch.no_grad():
+        y = ops.conv_bn_act(nhwc(x, torch.bfloat16), w.cuda(), None, 1, 1, (gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), 1e-5), None, 'hswish')
+    conv = F.conv2d(x, w.bfloat16().float(), None, 1, 1)
+    want = F.hardswish((conv - rm.view(1, -1, 1, 1)) / torch.sqrt(rv.view(1, -1, 1, 1) + 1e-5) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1))
+    torch.testing.assert_close(nchw(y), want, rtol=2e-2, atol=2e-2 * max(1.0, want.abs().max().item()))
