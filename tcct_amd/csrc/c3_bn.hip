@@ -269,7 +269,9 @@ extern "C" int tcct_c3_bn_fwd_eval(const void* x4, const float* w, const float* 
 // MODE 2 (round 4): BOTH in one pass over dz.  dy = a (dz' - s1 - yh s2) is LINEAR in the per-pixel quantities (s1 = mean dz', s2 = mean dz' yh, yh = (y - mean) rstd
 //         known from the forward), so dW = a (A1 - s2 A2 - s1 A3) with A1 = sum dz' patch, A2 = sum yh patch, A3 = sum patch: the kernel accumulates the three
 //         sums (dw = workspace fp32: A1 [32][64], A2 [32][64], A3 [64]) and red fp64 [96] += {sum dz', sum dz' yh, sum yh}; k_c3_bn_bwd_fin combines them.  coef = mean_rstd [64].
-template <int MODE, int POST>
+// PF: tiles requested ahead (register rings px / pd, the tile loop unrolled PF times).  Round 6: with ONE tile ahead and the two blocks per CU that MODE 2's ~190 VGPRs
+// allow, 28 KB per CU were in flight -- 2.2 TB/s at ~2.5 us of loaded HBM latency (Little's law), 0.276 ms for the CNN's first layer; MODE 2 runs with PF = 3.
+template <int MODE, int POST, int PF = 1>
 __global__ void __launch_bounds__(C3B, 2)
 k_c3_bn_bwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, const bf16* __restrict__ dz, int64_t M,
             const float* __restrict__ ab, const float* __restrict__ coef, double* __restrict__ red, float* __restrict__ dw, float* __restrict__ dbias,
@@ -302,8 +304,8 @@ k_c3_bn_bwd(const bf16* __restrict__ x, const float* __restrict__ w, const float
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;       // MODE 0: sum dz', sum dz' y of channel r;  MODE 1: s1 = sum dy (bias gradient);  MODE 2: sum dz', sum dz' yh, sum yh
     const __amdgpu_buffer_rsrc_t c3r = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g3.bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t c3d = __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, (uint32_t)(M * 64), 0x00020000);
-    uint4 px[3], pd[2];
-    auto prefetch = [&](int64_t tile) {     // thread = (pixel tid % 128, half tid / 128): input pixels (ky, kx = 0,1) or (ky, kx = 2) + zeros; branch-free
+    uint4 pxr[PF][3], pdr[PF][2];
+    auto prefetch = [&](int64_t tile, uint4 (&px)[3], uint4 (&pd)[2]) {     // thread = (pixel tid % 128, half tid / 128): input pixels (ky, kx = 0,1) or (ky, kx = 2) + zeros; branch-free
         const int64_t m0 = tile * C3_P;
         const uint32_t mm = (uint32_t)(m0 + (tid & 127));
         const bool in = m0 + (tid & 127) < M;
@@ -341,16 +343,21 @@ k_c3_bn_bwd(const bf16* __restrict__ x, const float* __restrict__ w, const float
     // the 32 rows of this wave's recompute GEMM: row i < 16 = pixel 16 wave + i (chunk `wave`), row i >= 16 = pixel 16 (wave + 4) + i - 16
     const int prow = r < 16 ? 16 * wave + r : 16 * (wave + 4) + (r - 16);
     const int64_t tiles = (M + C3_P - 1) / C3_P;
-    int64_t tile = blockIdx.x;
-    if (tile < tiles) prefetch(tile);
-    for (; tile < tiles; tile += gridDim.x) {
+    int64_t tile0 = blockIdx.x;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) prefetch(tile0 + (int64_t)u * gridDim.x, pxr[u], pdr[u]);       // branch-free loads: a tile past the end reads zeros
+    for (; tile0 < tiles; tile0 += (int64_t)PF * gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int64_t tile = tile0 + (int64_t)u * gridDim.x;
+        if (tile >= tiles) break;           // block-uniform
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 3; ++j) *reinterpret_cast<uint4*>(sX + (tid & 127) * C3_SX + (2 * j + (tid >> 7)) * 16) = px[j];
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<uint4*>(sX + (tid & 127) * C3_SX + (2 * j + (tid >> 7)) * 16) = pxr[u][j];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { const int i = tid + j * C3B; *reinterpret_cast<uint4*>(sD + (i >> 2) * C3_SD + (i & 3) * 16) = pd[j]; }
+        for (int j = 0; j < 2; ++j) { const int i = tid + j * C3B; *reinterpret_cast<uint4*>(sD + (i >> 2) * C3_SD + (i & 3) * 16) = pdr[u][j]; }
         __syncthreads();
-        prefetch(tile + gridDim.x);         // branch-free loads: a tile past the end reads zeros
+        prefetch(tile + (int64_t)PF * gridDim.x, pxr[u], pdr[u]);
         // ---- y of the wave's 32 pixels: D[pixel][co] = patch . W^T + bias: lane = channel r, rows 8q + 4hh + k
         f32x16 y;
 #pragma unroll
@@ -377,6 +384,7 @@ k_c3_bn_bwd(const bf16* __restrict__ x, const float* __restrict__ w, const float
                 yf[c][4 + k] = __uint_as_float(s1_);
             }
         const int64_t m0 = tile * C3_P;
+        const bool tail = m0 + C3_P > M;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int ch = wave + 4 * c;            // 16-pixel chunk of the tile
@@ -397,7 +405,8 @@ k_c3_bn_bwd(const bf16* __restrict__ x, const float* __restrict__ w, const float
                 uint32_t pk[4], ph[4];
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
-                    const float h0 = p0 + j < M ? (yf[c][j] - mu_r) * rs_r : 0.f, h1 = p0 + j + 1 < M ? (yf[c][j + 1] - mu_r) * rs_r : 0.f;
+                    // (pixels beyond M only exist in the last tile: a block-uniform flag keeps the 16 64-bit compares out of every other tile)
+                    const float h0 = (!tail || p0 + j < M) ? (yf[c][j] - mu_r) * rs_r : 0.f, h1 = (!tail || p0 + j + 1 < M) ? (yf[c][j + 1] - mu_r) * rs_r : 0.f;
                     s1 += dv[j] + dv[j + 1]; s2 += dv[j] * h0 + dv[j + 1] * h1; s3 += h0 + h1;
                     if (POST != TCCT_ACT_NONE) pk[j >> 1] = pack_bf16x2(dv[j], dv[j + 1]);
                     ph[j >> 1] = pack_bf16x2(h0, h1);
@@ -431,6 +440,7 @@ k_c3_bn_bwd(const bf16* __restrict__ x, const float* __restrict__ w, const float
                 }
             }
         }
+    }
     }
     __syncthreads();
     float* redf = reinterpret_cast<float*>(smem);
@@ -466,7 +476,12 @@ k_c3_bn_bwd(const bf16* __restrict__ x, const float* __restrict__ w, const float
             }
             __syncthreads();
         }
-        for (int i = tid; i < 2 * 2048 + 64; i += C3B) atomicAdd(&dw[i], redf[i]);
+        // only the 27 patch elements that are weights (k < 48, kx < 3, ch < 3) are read by k_c3_bn_bwd_fin: 1 755 atomics per block instead of 4 160 (round 6: with 512 blocks
+        // the closing atomics were ~18 us of the launch at either first layer)
+        for (int i = tid; i < 2 * 2048 + 64; i += C3B) {
+            const int cl = i & 63;
+            if (cl < 48 && ((cl >> 2) & 3) < 3 && (cl & 3) < 3) atomicAdd(&dw[i], redf[i]);
+        }
         __syncthreads();
         s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); s3 += __shfl_xor(s3, 32, 64);
         if (lane < 32) { redf[wave * 96 + r] = s1; redf[wave * 96 + 32 + r] = s2; redf[wave * 96 + 64 + r] = s3; }
@@ -506,6 +521,14 @@ k_c3_bn_bwd(const bf16* __restrict__ x, const float* __restrict__ w, const float
     }
 }
 
+static int g_c3_bwd_pf = 1;
+static int c3_bwd_pf() { return g_c3_bwd_pf; }
+/* kernel A/B (tools/c3bwd_bench.py): tiles requested ahead by the one-pass backward, 1..3; 0: one tile ahead on up to 1024 blocks (the round-5 launch); returns the previous value */
+extern "C" int64_t tcct_c3_bn_bwd_prefetch(int tiles_ahead) {
+    const int old = g_c3_bwd_pf;
+    if (tiles_ahead >= 0 && tiles_ahead <= 3) g_c3_bwd_pf = tiles_ahead;
+    return old;
+}
 static int c3_bn_bwd_launch(int mode, const void* x4, const float* w, const float* bias, const void* dz, int B, int H, int W, int stride,
                             const float* ab, const float* coef, double* red, float* dw, float* dbias, int post_act, hipStream_t st) {
     const C3Geom g = c3_geom(B, H, W, stride);
@@ -517,10 +540,15 @@ static int c3_bn_bwd_launch(int mode, const void* x4, const float* w, const floa
     const int per = mode == 0 ? 8 : 24;          // (mode 2 ends with 6144 + 96 atomics per block: as few blocks as mode 1)
     int gx = (int)(tiles / per < 256 ? 256 : (tiles / per > 1024 ? 1024 : tiles / per));
     if (gx > tiles) gx = (int)tiles;
-#define C3L(MD, PA) hipLaunchKernelGGL((k_c3_bn_bwd<MD, PA>), dim3(gx), dim3(C3B), lds, st, (const bf16*)x4, w, bias, (const bf16*)dz, M, ab, coef, red, dw, dbias, g)
-    if (mode == 0) { if (post_act == TCCT_ACT_HSWISH) C3L(0, TCCT_ACT_HSWISH); else C3L(0, TCCT_ACT_NONE); }
-    else if (mode == 2) { if (post_act == TCCT_ACT_HSWISH) C3L(2, TCCT_ACT_HSWISH); else C3L(2, TCCT_ACT_NONE); }
-    else { if (post_act == TCCT_ACT_HSWISH) C3L(1, TCCT_ACT_HSWISH); else C3L(1, TCCT_ACT_NONE); }
+#define C3L(MD, PA, PFD) hipLaunchKernelGGL((k_c3_bn_bwd<MD, PA, PFD>), dim3(gx), dim3(C3B), lds, st, (const bf16*)x4, w, bias, (const bf16*)dz, M, ab, coef, red, dw, dbias, g)
+    if (mode == 0) { if (post_act == TCCT_ACT_HSWISH) C3L(0, TCCT_ACT_HSWISH, 1); else C3L(0, TCCT_ACT_NONE, 1); }
+    else if (mode == 2) {
+        const int pf = c3_bwd_pf();
+        if (gx > 512 && pf > 0) gx = 512;   // two blocks per CU are resident (VGPRs): one round of blocks, half the closing atomics
+        if (post_act == TCCT_ACT_HSWISH) { if (pf <= 1) C3L(2, TCCT_ACT_HSWISH, 1); else if (pf == 2) C3L(2, TCCT_ACT_HSWISH, 2); else C3L(2, TCCT_ACT_HSWISH, 3); }
+        else { if (pf <= 1) C3L(2, TCCT_ACT_NONE, 1); else if (pf == 2) C3L(2, TCCT_ACT_NONE, 2); else C3L(2, TCCT_ACT_NONE, 3); }
+    }
+    else { if (post_act == TCCT_ACT_HSWISH) C3L(1, TCCT_ACT_HSWISH, 1); else C3L(1, TCCT_ACT_NONE, 1); }
 #undef C3L
     return 0;
 }
