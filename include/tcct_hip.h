@@ -416,7 +416,9 @@ int tcct_c3_bn_bwd_reduce(const void* x4, const float* w, const float* bias, con
                           double* raw, int post_act, tcct_stream_t stream);
 int tcct_c3_bn_bwd_wgrad(const void* x4, const float* w, const float* bias, const void* dz, int B, int H, int W, int stride, const float* coef,
                          float* dw, float* dbias, int post_act, tcct_stream_t stream);
-/* kernel A/B of the one-pass backward below (tools/c3bwd_bench.py): tiles requested ahead, 1..3 (default 1), 0 = one tile ahead on up to 1024 blocks (the round-5 launch); returns the previous value.  Test / measurement only. */
+/* kernel A/B of the one-pass backward below (tools/c3bwd_bench.py, tests): 4 (default) = wave-private 32-pixel tiles (k_c3_bn_bwd_wave, round 6); 1..3 = the block-tile kernel
+ * (128 pixels, two barriers per tile) with that many tiles requested ahead; 0 = the block-tile kernel on up to 1024 blocks (the round-5 launch); returns the previous value.
+ * Test / measurement only. */
 int64_t tcct_c3_bn_bwd_prefetch(int tiles_ahead);
 /* ... or both in ONE pass over dz (round 4): dy = a (dz' - s1 - yh s2) is linear in per-pixel quantities, so dW = a (A1 - s2 A2 - s1 A3) with A1 = sum dz' patch,
  * A2 = sum yh patch, A3 = sum patch accumulated together with the batch sums; work fp32 [4160] and sums fp64 [96] are scratch (zero on entry when the outputs are

@@ -521,12 +521,187 @@ k_c3_bn_bwd(const bf16* __restrict__ x, const float* __restrict__ w, const float
     }
 }
 
-static int g_c3_bwd_pf = 1;
+
+// ---- MODE 2 with WAVE-PRIVATE tiles (round 6).  k_c3_bn_bwd<2> stages 128 pixels per block and pays two block barriers per tile with two blocks per CU resident: its
+// eight waves per CU move in two lockstep groups and the VALU (286 instructions per tile and wave) idles about half of the time (profiles/r06_c3bwd_prefetch.txt).  Here a
+// wave owns 32 consecutive pixels per iteration -- its own 6 KB patch tile and 2 KB of dz in LDS, ordered by the wave's in-order LDS queue, no barrier in the loop -- and the
+// VALU work is cut: the patch sums A3 come out of a third MFMA with a fragment of ones (the matrix pipes were 30 % busy) instead of 64 conversions + adds per tile, the
+// masks of pixels beyond M exist in the last tile only (a wave-uniform branch).  Same sums, same fragment layouts and MFMA order per pixel as the block-tile kernel; the order
+// in which tiles are added differs (fp32 accumulators: ~1e-6 relative, as between two grid sizes of the old kernel).
+template <int POST>
+__global__ void __launch_bounds__(C3B, 2)
+k_c3_bn_bwd_wave(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, const bf16* __restrict__ dz, int64_t M,
+                 const float* __restrict__ ab, const float* __restrict__ coef, double* __restrict__ red, float* __restrict__ dw, C3Geom g3) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    unsigned char* sW = smem + 4 * 32 * (C3_SX + C3_SD);
+    unsigned char* sX = smem + wave * 32 * (C3_SX + C3_SD);
+    unsigned char* sD = sX + 32 * C3_SX;
+    c3_stage_weights(sW, w, tid);
+    // patch elements 48..63 of the wave's 32 rows: zero once
+    *reinterpret_cast<uint4*>(sX + r * C3_SX + (6 + hh) * 16) = make_uint4(0, 0, 0, 0);
+    // the bias never enters the loop: y' = patch . W^T (accumulators start at the inline constant 0) and y = y' + bias is folded into the lane constants
+    const float bias_r = bias ? bias[r] : 0.f;
+    const float a_r = ab[r], b_r = ab[32 + r] + ab[r] * bias_r;
+    const float rs_r = coef[32 + r], murs_r = (coef[r] - bias_r) * rs_r;
+    __syncthreads();
+    bf16x8 wf[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sW + r * C3_SW + (16 * i + 8 * hh) * 2);
+    bf16x8 ones;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ones[k] = (__bf16)1.0f;
+    f32x16 acc[2], acc2[2], acc3[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { acc[b][k] = 0.f; acc2[b][k] = 0.f; acc3[b][k] = 0.f; }
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const __amdgpu_buffer_rsrc_t c3r = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g3.bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t c3d = __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, (uint32_t)(M * 64), 0x00020000);
+    uint4 px[3], pd[2];
+    auto prefetch = [&](int64_t tile) {         // lane = (pixel lane % 32, half lane / 32): input pixels (ky, kx = 0, 1) or (ky, kx = 2) + zeros; branch-free
+        const int64_t m0 = tile * 32;
+        const uint32_t mm = (uint32_t)(m0 + r);
+        const bool in = m0 + r < M;
+        const uint32_t n_ = udiv_m(mm, (uint32_t)(g3.Ho * g3.Wo), g3.m_howo), rem = mm - n_ * (uint32_t)(g3.Ho * g3.Wo);
+        const uint32_t oy = udiv_m(rem, (uint32_t)g3.Wo, g3.m_wo), ox = rem - oy * (uint32_t)g3.Wo;
+        const int iy0 = (int)oy * g3.stride - 1, ix0 = (int)ox * g3.stride - 1;
+        const int pa = ix0 + 2 * hh, pb = ix0 + 1;
+        const bool va = in & ((unsigned)pa < (unsigned)g3.W), vb = in & (hh == 0) & ((unsigned)pb < (unsigned)g3.W);
+        const int base = ((int)(n_ * (uint32_t)g3.H) + iy0) * g3.W;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const bool rv = (unsigned)(iy0 + ky) < (unsigned)g3.H;
+            const uint32_t offa = (va & rv) ? (uint32_t)(base + ky * g3.W + pa) * 8u : 0x80000000u;
+            const uint32_t offb = (vb & rv) ? (uint32_t)(base + ky * g3.W + pb) * 8u : 0x80000000u;
+            const uint2 ta = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(c3r, offa, 0, 0));
+            const uint2 tb = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(c3r, offb, 0, 0));
+            px[ky] = make_uint4(ta.x, ta.y, tb.x, tb.y);
+        }
+        const bool live = m0 < M;               // (a tile past the end: offsets may wrap, read nothing)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)             // the 32 x 64 B tile of dz is one contiguous span; rows >= M read as zeros through the descriptor
+            pd[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(c3d, live ? (uint32_t)m0 * 64u + (uint32_t)(lane + j * 64) * 16u : 0x80000000u, 0, 0));
+    };
+    const int li = lane & 15, lq = li >> 2, lpp = li & 3, lg = lane >> 4;
+    const int lrow = 8 * (lg >> 1) + lq, lcol = (16 * (lg & 1) + 4 * lpp) * 2;
+    const unsigned char* lbX = sX + lrow * C3_SX + lcol;
+    const unsigned char* lbD = sD + lrow * C3_SD + lcol;
+    auto tr2 = [&](const unsigned char* p, int stride) {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * stride));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    const int64_t tiles = (M + 31) / 32;
+    const int64_t step = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    prefetch(tile);
+    for (; tile < tiles; tile += step) {
+        // the wave's LDS operations execute in order: these stores follow every read of the previous tile
+#pragma unroll
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<uint4*>(sX + r * C3_SX + (2 * j + hh) * 16) = px[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<uint4*>(sD + (lane + j * 64) * 16) = pd[j];
+        wave_lds_fence();
+        prefetch(tile + step);
+        f32x16 y = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const bf16x8 pv = *reinterpret_cast<const bf16x8*>(sX + r * C3_SX + (16 * i + 8 * hh) * 2);
+            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pv, wf[i], y, 0, 0, 0);
+        }
+        float yf[2][8];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float ylo = y[8 * c + k], yhi = y[8 * c + 4 + k];       // (scalars first: see k_c3_bn_bwd)
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ylo), __float_as_uint(yhi), false, false);
+                const uint32_t s0 = sw[0], s1_ = sw[1];
+                yf[c][k] = __uint_as_float(s0);
+                yf[c][4 + k] = __uint_as_float(s1_);
+            }
+        const int64_t m0 = tile * 32;
+        const bool tail = __builtin_amdgcn_readfirstlane((int)(m0 + 32 > M)) != 0;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const bf16x8 dzf = tr2(lbD + c * 16 * C3_SD, C3_SD);          // pixels 16 c + 8 hh + j of channel r
+            const s16x8 dzs = __builtin_bit_cast(s16x8, dzf);
+            float dv[8], hv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = __uint_as_float(((uint32_t)(uint16_t)dzs[j]) << 16);
+                dv[j] = POST == TCCT_ACT_NONE ? d : d * post_grad<POST>(a_r * yf[c][j] + b_r);
+                hv[j] = yf[c][j] * rs_r - murs_r;
+            }
+            if (tail) {         // wave-uniform: the last tile only
+                const int64_t p0 = m0 + 16 * c + 8 * hh;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (p0 + j >= M) hv[j] = 0.f;
+            }
+            uint32_t pk[4], ph[4];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                s1 += dv[j] + dv[j + 1]; s2 += dv[j] * hv[j] + dv[j + 1] * hv[j + 1]; s3 += hv[j] + hv[j + 1];
+                if (POST != TCCT_ACT_NONE) pk[j >> 1] = pack_bf16x2(dv[j], dv[j + 1]);
+                ph[j >> 1] = pack_bf16x2(hv[j], hv[j + 1]);
+            }
+            const bf16x8 dzp = POST == TCCT_ACT_NONE ? dzf : __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+            const bf16x8 yhp = __builtin_bit_cast(bf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const bf16x8 xf = tr2(lbX + c * 16 * C3_SX + 64 * kt, C3_SX);      // (patch rows of pixels beyond M are zeros)
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dzp, xf, acc[kt], 0, 0, 0);
+                acc2[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yhp, xf, acc2[kt], 0, 0, 0);
+                acc3[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, xf, acc3[kt], 0, 0, 0);      // every row = sum over the 16 pixels of the patch column
+            }
+        }
+    }
+    __syncthreads();
+    float* redf = reinterpret_cast<float*>(smem);
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int co = (k & 3) + 8 * (k >> 2) + 4 * hh, o = co * 64 + kt * 32 + r;
+                    redf[o] = turn == 0 ? acc[kt][k] : redf[o] + acc[kt][k];
+                    redf[2048 + o] = turn == 0 ? acc2[kt][k] : redf[2048 + o] + acc2[kt][k];
+                }
+            if (hh == 0) {      // row 0 of the ones product (k = 0, hh = 0): column kt * 32 + r
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) redf[4096 + kt * 32 + r] = turn == 0 ? acc3[kt][0] : redf[4096 + kt * 32 + r] + acc3[kt][0];
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < 2 * 2048 + 64; i += C3B) {
+        const int cl = i & 63;
+        if (cl < 48 && ((cl >> 2) & 3) < 3 && (cl & 3) < 3) atomicAdd(&dw[i], redf[i]);
+    }
+    __syncthreads();
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); s3 += __shfl_xor(s3, 32, 64);
+    if (lane < 32) { redf[wave * 96 + r] = s1; redf[wave * 96 + 32 + r] = s2; redf[wave * 96 + 64 + r] = s3; }
+    __syncthreads();
+    if (tid < 96) {
+        double a = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) a += (double)redf[wv * 96 + tid];
+        atomicAdd(&red[tid], a);
+    }
+}
+
+static int g_c3_bwd_pf = 4;
 static int c3_bwd_pf() { return g_c3_bwd_pf; }
-/* kernel A/B (tools/c3bwd_bench.py): tiles requested ahead by the one-pass backward, 1..3; 0: one tile ahead on up to 1024 blocks (the round-5 launch); returns the previous value */
+/* kernel A/B (tools/c3bwd_bench.py) of the one-pass backward: 4 = wave-private 32-pixel tiles (k_c3_bn_bwd_wave); 1..3 = the block-tile kernel with that many tiles requested
+ * ahead; 0 = the block-tile kernel, one tile ahead, on up to 1024 blocks (the round-5 launch); returns the previous value */
 extern "C" int64_t tcct_c3_bn_bwd_prefetch(int tiles_ahead) {
     const int old = g_c3_bwd_pf;
-    if (tiles_ahead >= 0 && tiles_ahead <= 3) g_c3_bwd_pf = tiles_ahead;
+    if (tiles_ahead >= 0 && tiles_ahead <= 4) g_c3_bwd_pf = tiles_ahead;
     return old;
 }
 static int c3_bn_bwd_launch(int mode, const void* x4, const float* w, const float* bias, const void* dz, int B, int H, int W, int stride,
@@ -542,6 +717,15 @@ static int c3_bn_bwd_launch(int mode, const void* x4, const float* w, const floa
     if (gx > tiles) gx = (int)tiles;
 #define C3L(MD, PA, PFD) hipLaunchKernelGGL((k_c3_bn_bwd<MD, PA, PFD>), dim3(gx), dim3(C3B), lds, st, (const bf16*)x4, w, bias, (const bf16*)dz, M, ab, coef, red, dw, dbias, g)
     if (mode == 0) { if (post_act == TCCT_ACT_HSWISH) C3L(0, TCCT_ACT_HSWISH, 1); else C3L(0, TCCT_ACT_NONE, 1); }
+    else if (mode == 2 && c3_bwd_pf() == 4) {
+        // wave-private tiles: 4 x 8 KB of tiles + the weights; one round of blocks (two per CU at ~220 VGPRs)
+        const size_t ldsw = (size_t)4 * 32 * (C3_SX + C3_SD) + 32 * C3_SW;
+        const int64_t t32 = (M + 31) / 32;
+        int gw = (int)((t32 + 3) / 4 < 512 ? (t32 + 3) / 4 : 512);
+        if (gw < 1) gw = 1;
+        if (post_act == TCCT_ACT_HSWISH) hipLaunchKernelGGL((k_c3_bn_bwd_wave<TCCT_ACT_HSWISH>), dim3(gw), dim3(C3B), ldsw, st, (const bf16*)x4, w, bias, (const bf16*)dz, M, ab, coef, red, dw, g);
+        else hipLaunchKernelGGL((k_c3_bn_bwd_wave<TCCT_ACT_NONE>), dim3(gw), dim3(C3B), ldsw, st, (const bf16*)x4, w, bias, (const bf16*)dz, M, ab, coef, red, dw, g);
+    }
     else if (mode == 2) {
         const int pf = c3_bwd_pf();
         if (gx > 512 && pf > 0) gx = 512;   // two blocks per CU are resident (VGPRs): one round of blocks, half the closing atomics

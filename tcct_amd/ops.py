@@ -1725,6 +1725,9 @@ class _ConvC3BN(torch.autograd.Function):
             dw = _grad_out(w, tuple(w.shape))
             dbias = _grad_out(bias) if bias is not None else None
             if C3_ONEPASS:      # reduction and weight gradient from ONE pass over dz (the BatchNorm backward is linear in per-pixel quantities)
+                if C3_BWD_FORM != _C3_FORM_SET[0]:
+                    lib.c3_bn_bwd_prefetch(C3_BWD_FORM)
+                    _C3_FORM_SET[0] = C3_BWD_FORM
                 work = ZERO.get((4160,), torch.float32, dev) if ZERO.active else torch.zeros(4160, device=dev, dtype=torch.float32)
                 s96 = ZERO.get((96,), torch.float64, dev) if ZERO.active else torch.zeros(96, device=dev, dtype=torch.float64)
                 lib.c3_bn_bwd_onepass(x4, w, bias, dz, B, H, W, stride, mean_rstd, ab, work, s96, dw, dbias, dg, db_, post)
@@ -1735,6 +1738,8 @@ class _ConvC3BN(torch.autograd.Function):
         return None, _ret(dw, w), _ret(dbias, bias), _ret(dg, gamma), _ret(db_, beta), None, None, None, None, None, None, None
 
 
+C3_BWD_FORM = 4        # kernel form of the one-pass backward (tcct_c3_bn_bwd_prefetch): 4 = wave-private 32-pixel tiles (round 6), 1 = block tiles of 128 pixels (A/B timing)
+_C3_FORM_SET = [4]
 C3_ONEPASS = True      # False: BatchNorm reduction and weight gradient of the first layers as two passes over dz (A/B timing)
 
 

@@ -370,11 +370,22 @@ def test_first_layer_direct_conv_with_statistics_and_inference_epilogue(dt, stri
 
 @pytest.mark.parametrize('cfg', [(1, False, True), (2, True, False)])       # (stride, Hardswish, bias): cnn.0 -> cnn.1 and stem[0]
 @pytest.mark.parametrize('nhw', [(2, 18, 26), (3, 17, 45), (1, 5, 131), (2, 64, 96), (1, 40, 300)])
-def test_first_layer_with_its_batchnorm_as_one_store(cfg, nhw):
+@pytest.mark.parametrize('form', [4, 1])         # the one-pass backward with wave-private 32-pixel tiles (round 6) / block tiles of 128 pixels
+def test_first_layer_with_its_batchnorm_as_one_store(cfg, nhw, form):
     """csrc/c3_bn.hip (round 4): z = post(BN_train(conv3x3(image) + bias)) for the two 3-channel first layers (reference nets/tcct.py:873 and
     :55-97 / :674-681) with the convolution output recomputed instead of stored -- forward (batch statistics, running statistics, z), and the
     backward (d weight, d bias, d gamma, d beta) against torch's fp32 conv -> batch_norm -> hardswish on the same bf16-representable image.
     Odd extents leave partial 32-pixel row tiles and partial 128-pixel tiles; z is the only rounding point."""
+    from tcct_amd import ops
+    from tcct_amd._lib import lib
+    prev_form = lib.c3_bn_bwd_prefetch(form)
+    try:
+        _first_layer_one_store(cfg, nhw)
+    finally:
+        lib.c3_bn_bwd_prefetch(prev_form)
+
+
+def _first_layer_one_store(cfg, nhw):
     from tcct_amd import ops
     stride, hsw, has_bias = cfg
     N, H, W = nhw

@@ -1,4 +1,4 @@
-"""One-pass backward of the first layers (k_c3_bn_bwd<2, POST, PF>) at the bench shapes: tiles requested ahead 1 / 2 / 3 and the round-5 launch (0) (tcct_c3_bn_bwd_prefetch), HIP events.
+"""One-pass backward of the first layers (k_c3_bn_bwd<2, POST, PF>) at the bench shapes: the wave-private kernel (4), the block-tile kernel with 1 / 3 tiles requested ahead and its round-5 launch (0) (tcct_c3_bn_bwd_prefetch), HIP events.
 
     python tools/c3bwd_bench.py     (gpurun: redirect into gpurun_out/)"""
 import os
@@ -31,7 +31,7 @@ def main():
         lib.c3_bn_fwd_train(x4, w, bias, z, B, H, W, stride, sums, gamma, beta, 1e-5, 0.1, rm, rv, nbt, mean_rstd, ab, post)
         dz = torch.randn(B, Ho, Wo, 32, device=dev).to(torch.bfloat16)
         outs = {}
-        for pf in (1, 0, 2, 3, 1, 0, 3):
+        for pf in (1, 4, 0, 3, 4, 1, 4):
             lib.c3_bn_bwd_prefetch(pf)
             work = torch.zeros(4160, device=dev)
             s96 = torch.zeros(96, device=dev, dtype=torch.float64)
@@ -42,16 +42,16 @@ def main():
                 lib.c3_bn_bwd_onepass(x4, w, bias, dz, B, H, W, stride, mean_rstd, ab, work, s96, dw, dbias, dg, db_, post)
             ms = timeit(run, iters=20, warm=3)
             mb = (M * 64 + B * H * W * 8) / 1e6
-            print(f'{name}: tiles ahead {pf}: {ms:.3f} ms (incl. two tiny memsets)  {mb / ms / 1e3:.2f} TB/s on dz + image ({mb:.0f} MB)', flush=True)
+            print(f'{name}: form {pf}: {ms:.3f} ms (incl. two tiny memsets)  {mb / ms / 1e3:.2f} TB/s on dz + image ({mb:.0f} MB)', flush=True)
             torch.cuda.synchronize()
             if pf in outs:
                 continue
             outs[pf] = (dw.clone(), dg.clone(), db_.clone())
-        for pf in (2, 3):
+        for pf in (3, 4):
             for a, b, nm in zip(outs[1], outs[pf], ('dw', 'dgamma', 'dbeta')):
                 err = float((a - b).abs().max() / (a.abs().max() + 1e-12))
-                print(f'    tiles ahead {pf} vs 1: {nm} max rel diff {err:.2e}')
-                assert err < 1e-3, (pf, nm, err)
+                print(f'    form {pf} vs 1: {nm} max rel diff {err:.2e}')
+                assert err < 2e-3, (pf, nm, err)
     lib.c3_bn_bwd_prefetch(1)
 
 
