@@ -124,9 +124,11 @@ template <int VEC> __device__ __forceinline__ void stv(bf16* p, const float* v) 
 // ---------------------------------------------------------------- activations (kinds: TCCT_ACT_*)
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 round-off level): 1 rcp + 1 exp + 6 FMAs instead of the ~40
 // instruction libm erff -- the GELU junction kernels of the CNN blocks were VALU-bound on it (0.49 ms for a 1.36 GB reduction).
+// (round 6: the reciprocal is v_rcp_f32 (1 ulp) -- `__frcp_rn` compiled to the 10-instruction IEEE division sequence (v_div_scale x2, v_rcp, 4 FMAs, v_div_fmas,
+// v_div_fixup + hazard nops), a quarter of the VALU instructions of the GELU junction kernels; the polynomial's own error is 1.5e-7)
 __device__ __forceinline__ float erf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(1.f + 0.3275911f * ax);
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float r = 1.f - poly * __expf(-ax * ax);
     return copysignf(r, x);
@@ -134,7 +136,7 @@ __device__ __forceinline__ float erf_fast(float x) {
 // Phi(x) = 0.5 (1 + erf(x / sqrt 2)) and phi(x) from ONE exponential: erf's A&S tail factor exp(-(x/sqrt2)^2) is exp(-x^2/2) = sqrt(2 pi) phi(x)
 __device__ __forceinline__ void gauss_cdf_pdf(float x, float& cdf, float& pdf) {
     const float e = __expf(-0.5f * x * x);
-    const float t = __frcp_rn(1.f + 0.23164189f * fabsf(x));            // 0.3275911 / sqrt(2)
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.23164189f * fabsf(x));            // 0.3275911 / sqrt(2)
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float h = 0.5f * poly * e;                                    // upper tail Q(|x|)
     cdf = x >= 0.f ? 1.f - h : h;
