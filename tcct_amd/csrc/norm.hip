@@ -144,6 +144,27 @@ struct BnTrain {        // sums != NULL: train-mode apply with the statistics fi
     const double* sums; const float* gamma; const float* beta; float eps, momentum;
     float* running_mean; float* running_var; int64_t* nbt; float* mean_rstd; float* ab_out;
 };
+// Train-mode coefficients of ALL channels, once per block (round 6): thread c < C derives channel c (bn_coeff: two fp64 divisions, an fp64 square root and an fp64
+// reciprocal, ~100 fp64 instructions) into LDS; `publish` (one block of the launch) also writes mean / rstd / a / b for the backward kernels and moves the running
+// statistics.  Every thread used to derive the coefficients of ITS 4-8 channels itself: ~800 fp64 instructions in front of a loop of ~1800 fp32 ones at level 0, and
+// nearly all of a thread's work at levels 3-4, where it normalises one or two rows.  Same expressions, same bits.  Ends with a block barrier (C <= NB).
+__device__ __forceinline__ void bn_block_coeffs(const BnTrain& tr, int64_t M, int C, bool publish, float* __restrict__ s_a, float* __restrict__ s_b) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float mean, rstd, a, b; double var;
+        bn_coeff(tr.sums, M, C, c, tr.gamma[c], tr.beta[c], tr.eps, mean, rstd, a, b, var);
+        s_a[c] = a; s_b[c] = b;
+        if (publish) {
+            tr.mean_rstd[c] = mean; tr.mean_rstd[C + c] = rstd; tr.ab_out[c] = a; tr.ab_out[C + c] = b;
+            if (tr.running_mean) {
+                const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+                tr.running_mean[c] = (1.f - tr.momentum) * tr.running_mean[c] + tr.momentum * mean;
+                tr.running_var[c] = (1.f - tr.momentum) * tr.running_var[c] + tr.momentum * (float)unb;
+            }
+            if (c == 0 && tr.nbt) *tr.nbt += 1;
+        }
+    }
+    __syncthreads();
+}
 template <typename T, int VEC>
 __global__ void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t M, int C, const float* __restrict__ ab,
                            int pre_act, int post_act, const T* __restrict__ res, BnTrain tr) {
@@ -152,25 +173,16 @@ __global__ void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t M
     const int CV = C / VEC;
     const int R = NB / CV;
     const int t = threadIdx.x;
+    __shared__ float s_a[NB], s_b[NB];
+    if (tr.sums) bn_block_coeffs(tr, M, C, blockIdx.x == 0, s_a, s_b);        // (block-uniform; one block publishes the coefficients and moves the running stats)
     if (t >= R * CV) return;
     const int cv = t % CV, r = t / CV;
     float a_[VEC], b_[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         const int c = cv * VEC + k;
-        if (tr.sums) {
-            float mean, rstd; double var;
-            bn_coeff(tr.sums, M, C, c, tr.gamma[c], tr.beta[c], tr.eps, mean, rstd, a_[k], b_[k], var);
-            if (blockIdx.x == 0 && r == 0) {            // one thread per channel publishes the coefficients and moves the running stats
-                tr.mean_rstd[c] = mean; tr.mean_rstd[C + c] = rstd; tr.ab_out[c] = a_[k]; tr.ab_out[C + c] = b_[k];
-                if (tr.running_mean) {
-                    const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
-                    tr.running_mean[c] = (1.f - tr.momentum) * tr.running_mean[c] + tr.momentum * mean;
-                    tr.running_var[c] = (1.f - tr.momentum) * tr.running_var[c] + tr.momentum * (float)unb;
-                }
-                if (c == 0 && tr.nbt) *tr.nbt += 1;
-            }
-        } else { a_[k] = ab[c]; b_[k] = ab[C + c]; }
+        if (tr.sums) { a_[k] = s_a[c]; b_[k] = s_b[c]; }
+        else { a_[k] = ab[c]; b_[k] = ab[C + c]; }
     }
     const int64_t step = (int64_t)gridDim.x * R;
     for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += 2 * step) {
@@ -426,25 +438,14 @@ __global__ void k_bn_pool_fwd(const T* __restrict__ x, T* __restrict__ zout, T* 
                               int W, int C, int pre_act, int post_act, BnTrain tr) {
     const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t M = (int64_t)N * H * W;
+    __shared__ float s_a[NB], s_b[NB];
+    bn_block_coeffs(tr, M, C, blockIdx.x == 0 && blockIdx.y == 0, s_a, s_b);
     if (i >= Wo * C4) return;
     const int wo = i / C4, c0 = (i - wo * C4) * 4;
-    const int64_t M = (int64_t)N * H * W;
     float a_[4], b_[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = c0 + k;
-        float mean, rstd; double var;
-        bn_coeff(tr.sums, M, C, c, tr.gamma[c], tr.beta[c], tr.eps, mean, rstd, a_[k], b_[k], var);
-        if (blockIdx.y == 0 && wo == 0) {               // one thread per channel publishes the coefficients and moves the running stats
-            tr.mean_rstd[c] = mean; tr.mean_rstd[C + c] = rstd; tr.ab_out[c] = a_[k]; tr.ab_out[C + c] = b_[k];
-            if (tr.running_mean) {
-                const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
-                tr.running_mean[c] = (1.f - tr.momentum) * tr.running_mean[c] + tr.momentum * mean;
-                tr.running_var[c] = (1.f - tr.momentum) * tr.running_var[c] + tr.momentum * (float)unb;
-            }
-            if (c == 0 && tr.nbt) *tr.nbt += 1;
-        }
-    }
+    for (int k = 0; k < 4; ++k) { a_[k] = s_a[c0 + k]; b_[k] = s_b[c0 + k]; }
     for (int row = blockIdx.y; row < N * Ho; row += gridDim.y) {
         const int n = row / Ho, ho = row - n * Ho;
         const int64_t b00 = (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + c0;
@@ -806,19 +807,6 @@ static int layernorm_bwd_impl(const void* x, const void* dy, void* dx, int64_t M
 // Forward reads the two raw conv outputs once and writes y once (instead of 2 x bn_apply + add_act: 7 tensor passes -> 3);
 // backward recomputes the junction from xa, xb: one reduction pass (4 per-channel sums) + one apply pass writing both input
 // gradients (13 tensor passes -> 8).  Same fixed-channel-thread layout as the plain BN kernels.
-__device__ __forceinline__ void bn_train_coeff(const BnTrain& tr, int64_t M, int C, int c, bool publish, float& a, float& b) {
-    float mean, rstd; double var;
-    bn_coeff(tr.sums, M, C, c, tr.gamma[c], tr.beta[c], tr.eps, mean, rstd, a, b, var);
-    if (publish) {
-        tr.mean_rstd[c] = mean; tr.mean_rstd[C + c] = rstd; tr.ab_out[c] = a; tr.ab_out[C + c] = b;
-        if (tr.running_mean) {
-            const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
-            tr.running_mean[c] = (1.f - tr.momentum) * tr.running_mean[c] + tr.momentum * mean;
-            tr.running_var[c] = (1.f - tr.momentum) * tr.running_var[c] + tr.momentum * (float)unb;
-        }
-        if (c == 0 && tr.nbt) *tr.nbt += 1;
-    }
-}
 // PRE / ACT: compile-time activation kinds for the network's combination (LeakyReLU in front of both BatchNorms, GELU behind the sum), -1 =
 // run-time kinds.  act_fwd / act_grad resolve the kind per ELEMENT with a chain of scalar branches; with three input streams that made the
 // backward reduction VALU-bound (3.3 TB/s at level 0)
@@ -826,16 +814,19 @@ template <typename T, int PRE, int ACT>
 __global__ void k_bn2_add_act_fwd(const T* __restrict__ xa, const T* __restrict__ xb, T* __restrict__ y, int64_t M, int C,
                                   const float* __restrict__ abA, const float* __restrict__ abB, int pre_act, int act, BnTrain trA, BnTrain trB) {
     const int CV = C >> 2, R = NB / CV, t = threadIdx.x;
+    __shared__ float s_aA[NB], s_bA[NB], s_aB[NB], s_bB[NB];
+    if (trA.sums) {             // train mode: both statistics finalisations folded into this launch, once per block (bn_block_coeffs)
+        bn_block_coeffs(trA, M, C, blockIdx.x == 0, s_aA, s_bA);
+        bn_block_coeffs(trB, M, C, blockIdx.x == 0, s_aB, s_bB);
+    }
     if (t >= R * CV) return;
     const int cv = t % CV, r = t / CV;
     float aA[4], bA[4], aB[4], bB[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = cv * 4 + k;
-        if (trA.sums) {         // train mode: both statistics finalisations folded into this launch
-            bn_train_coeff(trA, M, C, c, blockIdx.x == 0 && r == 0, aA[k], bA[k]);
-            bn_train_coeff(trB, M, C, c, blockIdx.x == 0 && r == 0, aB[k], bB[k]);
-        } else { aA[k] = abA[c]; bA[k] = abA[C + c]; aB[k] = abB[c]; bB[k] = abB[C + c]; }
+        if (trA.sums) { aA[k] = s_aA[c]; bA[k] = s_bA[c]; aB[k] = s_aB[c]; bB[k] = s_bB[c]; }
+        else { aA[k] = abA[c]; bA[k] = abA[C + c]; aB[k] = abB[c]; bB[k] = abB[C + c]; }
     }
     const int64_t step = (int64_t)gridDim.x * R;
     for (int64_t m = (int64_t)blockIdx.x * R + r; m < M; m += step) {
