@@ -127,6 +127,21 @@ extern "C" int tcct_bn_eval_ab(int C, const float* gamma, const float* beta, flo
     TCCT_LAUNCH_OK();
 }
 
+template <int KIND> __device__ __forceinline__ float act_grad_c(float x) {
+    if (KIND == TCCT_ACT_LRELU) return x > 0.f ? 1.f : 0.01f;
+    if (KIND == TCCT_ACT_HSWISH) return x < -3.f ? 0.f : (x <= 3.f ? (2.f * x + 3.f) * (1.f / 6.f) : 1.f);
+    if (KIND == TCCT_ACT_NONE) return 1.f;
+    return act_grad(KIND, x);
+}
+template <int K> __device__ __forceinline__ float actf(int rt, float x) { return K < 0 ? act_fwd(rt, x) : act_c<(K < 0 ? 0 : K)>(x); }
+template <int K> __device__ __forceinline__ float actg(int rt, float x) { return K < 0 ? act_grad(rt, x) : act_grad_c<(K < 0 ? 0 : K)>(x); }
+// Compile-time activation kinds for the combinations the networks use (round 6): act_fwd / act_grad resolve a RUN-TIME kind per element with a chain of scalar
+// compare-and-branch pairs (five per call, two or three calls per element); the generic BatchNorm kernels ran at 2.9 (backward reduction) / 3.65 (apply) TB/s on that,
+// the junction kernels had the same problem in round 3.  -1 = run-time kinds (everything else).
+#define BN_KINDS(CALL) do { if (pre_act == TCCT_ACT_NONE && post_act == TCCT_ACT_HSWISH) { constexpr int PRE = TCCT_ACT_NONE, POST = TCCT_ACT_HSWISH; CALL; } \
+                            else if (pre_act == TCCT_ACT_NONE && post_act == TCCT_ACT_NONE) { constexpr int PRE = TCCT_ACT_NONE, POST = TCCT_ACT_NONE; CALL; } \
+                            else if (pre_act == TCCT_ACT_LRELU && post_act == TCCT_ACT_NONE) { constexpr int PRE = TCCT_ACT_LRELU, POST = TCCT_ACT_NONE; CALL; } \
+                            else { constexpr int PRE = -1, POST = -1; CALL; } } while (0)
 // ------------------------------------------------------------------ BN apply: y = post(a*pre(x)+b)
 // train-mode coefficients of channel c from the batch sums (what k_bn_finalize computes), in double like it
 __device__ __forceinline__ void bn_coeff(const double* __restrict__ sums, int64_t M, int C, int c, float gamma, float beta, float eps,
@@ -165,7 +180,7 @@ __device__ __forceinline__ void bn_block_coeffs(const BnTrain& tr, int64_t M, in
     }
     __syncthreads();
 }
-template <typename T, int VEC>
+template <typename T, int VEC, int PRE = -1, int POST = -1>
 __global__ void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t M, int C, const float* __restrict__ ab,
                            int pre_act, int post_act, const T* __restrict__ res, BnTrain tr) {
     // res != NULL: y = post(a*pre(x)+b) + res  (InvRes `x + conv2(f)` and the tran_vit + tran_cnn sum without a separate add pass)
@@ -195,8 +210,8 @@ __global__ void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t M
         if (res) { ldv<VEC>(res + o1, e1); if (two) ldv<VEC>(res + o2, e2); }
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            v1[k] = act_fwd(post_act, a_[k] * act_fwd(pre_act, v1[k]) + b_[k]) + (res ? e1[k] : 0.f);
-            if (two) v2[k] = act_fwd(post_act, a_[k] * act_fwd(pre_act, v2[k]) + b_[k]) + (res ? e2[k] : 0.f);
+            v1[k] = actf<POST>(post_act, a_[k] * actf<PRE>(pre_act, v1[k]) + b_[k]) + (res ? e1[k] : 0.f);
+            if (two) v2[k] = actf<POST>(post_act, a_[k] * actf<PRE>(pre_act, v2[k]) + b_[k]) + (res ? e2[k] : 0.f);
         }
         stv<VEC>(y + o1, v1);
         if (two) stv<VEC>(y + o2, v2);
@@ -233,13 +248,14 @@ static int bn_apply_impl(const void* x, const void* res, void* y, int64_t M, int
     int grid = tcct_grid(M, 2 * R, 256 * 16);
     hipStream_t st = (hipStream_t)stream;
     if (vec == 8) hipLaunchKernelGGL((k_bn_apply<bf16, 8>), dim3(grid), dim3(NB), 0, st, (const bf16*)x, (bf16*)y, M, C, ab, pre_act, post_act, (const bf16*)res, tr);
+    else if (vec == 4 && dtype == TCCT_BF16) { BN_KINDS(hipLaunchKernelGGL((k_bn_apply<bf16, 4, PRE, POST>), dim3(grid), dim3(NB), 0, st, (const bf16*)x, (bf16*)y, M, C, ab, pre_act, post_act, (const bf16*)res, tr)); }
     else if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act, (const T*)res, tr)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act, (const T*)res, tr)); }
     TCCT_LAUNCH_OK();
 }
 
 // ------------------------------------------------------------------ BN backward: reductions then apply
-template <typename T, int VEC>
+template <typename T, int VEC, int PRE = -1, int POST = -1>
 __global__ void __launch_bounds__(NBR) k_bn_bwd_reduce(const T* __restrict__ x, const T* __restrict__ dy, int64_t M, int C,
                                 const float* __restrict__ mean_rstd, const float* __restrict__ ab, int pre_act,
                                 int post_act, double* __restrict__ sums) {
@@ -264,8 +280,8 @@ __global__ void __launch_bounds__(NBR) k_bn_bwd_reduce(const T* __restrict__ x, 
             ldv<VEC>(dy + off, gv);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                float u = act_fwd(pre_act, xv[k]);
-                float dz = gv[k] * act_grad(post_act, a_[k] * u + b_[k]);
+                float u = actf<PRE>(pre_act, xv[k]);
+                float dz = gv[k] * actg<POST>(post_act, a_[k] * u + b_[k]);
                 s[k] += dz; q[k] += dz * (u - mu[k]) * rs[k];
             }
         }
@@ -321,12 +337,13 @@ extern "C" int tcct_bn_bwd_reduce(const void* x, const void* dy, int64_t M, int 
     int R = NBR / (C / vec);
     int grid = tcct_grid(M, R, 512);
     if (vec == 8) hipLaunchKernelGGL((k_bn_bwd_reduce<bf16, 8>), dim3(grid), dim3(NBR), 0, st, (const bf16*)x, (const bf16*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums);
+    else if (vec == 4 && dtype == TCCT_BF16) { BN_KINDS(hipLaunchKernelGGL((k_bn_bwd_reduce<bf16, 4, PRE, POST>), dim3(grid), dim3(NBR), 0, st, (const bf16*)x, (const bf16*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
     else if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce<T, 4>), dim3(grid), dim3(NBR), 0, st, (const T*)x, (const T*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce<T, 1>), dim3(grid), dim3(NBR), 0, st, (const T*)x, (const T*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
     TCCT_LAUNCH_OK();
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, int PRE = -1, int POST = -1>
 __global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t M, int C,
                                const float* __restrict__ mean_rstd, const float* __restrict__ ab,
                                const double* __restrict__ sums, int pre_act, int post_act, float* __restrict__ dgamma,
@@ -353,11 +370,11 @@ __global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy
         ldv<VEC>(dy + off, gv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            float u = act_fwd(pre_act, xv[k]);
-            float dz = gv[k] * act_grad(post_act, a_[k] * u + b_[k]);
+            float u = actf<PRE>(pre_act, xv[k]);
+            float dz = gv[k] * actg<POST>(post_act, a_[k] * u + b_[k]);
             float xh = (u - mu[k]) * rs[k];
             float du = a_[k] * (dz - s1[k] - xh * s2[k]);
-            o[k] = du * act_grad(pre_act, xv[k]);
+            o[k] = du * actg<PRE>(pre_act, xv[k]);
         }
         stv<VEC>(dx + off, o);
     }
@@ -372,6 +389,7 @@ extern "C" int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_
     int grid = tcct_grid(M, R, 256 * 16);
     hipStream_t st = (hipStream_t)stream;
     if (vec == 8) hipLaunchKernelGGL((k_bn_bwd_apply<bf16, 8>), dim3(grid), dim3(NB), 0, st, (const bf16*)x, (const bf16*)dy, (bf16*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta);
+    else if (vec == 4 && dtype == TCCT_BF16) { BN_KINDS(hipLaunchKernelGGL((k_bn_bwd_apply<bf16, 4, PRE, POST>), dim3(grid), dim3(NB), 0, st, (const bf16*)x, (const bf16*)dy, (bf16*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
     else if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (const T*)dy, (T*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (const T*)dy, (T*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
     TCCT_LAUNCH_OK();
@@ -424,14 +442,6 @@ extern "C" int tcct_bn_sums_from_raw(const double* raw, const float* mean_rstd, 
 // the three separate kernels: 0.94 vs 0.68 ms at level 0).
 __device__ __forceinline__ float rnd_as(float v, const bf16*) { return __bfloat162float(__float2bfloat16(v)); }
 __device__ __forceinline__ float rnd_as(float v, const float*) { return v; }
-template <int KIND> __device__ __forceinline__ float act_grad_c(float x) {
-    if (KIND == TCCT_ACT_LRELU) return x > 0.f ? 1.f : 0.01f;
-    if (KIND == TCCT_ACT_HSWISH) return x < -3.f ? 0.f : (x <= 3.f ? (2.f * x + 3.f) * (1.f / 6.f) : 1.f);
-    if (KIND == TCCT_ACT_NONE) return 1.f;
-    return act_grad(KIND, x);
-}
-template <int K> __device__ __forceinline__ float actf(int rt, float x) { return K < 0 ? act_fwd(rt, x) : act_c<(K < 0 ? 0 : K)>(x); }
-template <int K> __device__ __forceinline__ float actg(int rt, float x) { return K < 0 ? act_grad(rt, x) : act_grad_c<(K < 0 ? 0 : K)>(x); }
 
 template <typename T, int PRE, int POST>
 __global__ void k_bn_pool_fwd(const T* __restrict__ x, T* __restrict__ zout, T* __restrict__ pooled, unsigned char* __restrict__ amax, int N, int H,

@@ -242,7 +242,9 @@ k_pw_fwd(const bf16* __restrict__ x, const float* __restrict__ w, const float* _
                             const uint32_t wv[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                const float u0 = act_fwd(C3 ? 0 : stat_pre, __uint_as_float(wv[k] << 16)), u1 = act_fwd(C3 ? 0 : stat_pre, __uint_as_float(wv[k] & 0xffff0000u));
+                                // (stat_pre == none, the usual case, without act_fwd's per-value chain of scalar compares and branches)
+                                float u0 = __uint_as_float(wv[k] << 16), u1 = __uint_as_float(wv[k] & 0xffff0000u);
+                                if (!C3 && stat_pre != TCCT_ACT_NONE) { u0 = act_fwd(stat_pre, u0); u1 = act_fwd(stat_pre, u1); }
                                 ss[nt][2 * k] += u0; sq[nt][2 * k] += u0 * u0; ss[nt][2 * k + 1] += u1; sq[nt][2 * k + 1] += u1 * u1;
                             }
                         }
@@ -1666,7 +1668,8 @@ k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* 
                     if (inb) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const float u0 = act_fwd(stat_pre, __uint_as_float(o[k] << 16)), u1 = act_fwd(stat_pre, __uint_as_float(o[k] & 0xffff0000u));
+                            float u0 = __uint_as_float(o[k] << 16), u1 = __uint_as_float(o[k] & 0xffff0000u);
+                            if (stat_pre != TCCT_ACT_NONE) { u0 = act_fwd(stat_pre, u0); u1 = act_fwd(stat_pre, u1); }
                             ss[nt][2 * k] += u0; sq[nt][2 * k] += u0 * u0; ss[nt][2 * k + 1] += u1; sq[nt][2 * k + 1] += u1 * u1;
                         }
                     }
