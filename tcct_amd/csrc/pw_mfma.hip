@@ -1638,8 +1638,10 @@ k_pw_fwd2(const bf16* __restrict__ x, const bf16* __restrict__ x2, const float* 
                 if (AFF) {
                     const float4 aq = *reinterpret_cast<const float4*>(sAF + nt * 32 + 8 * q + 4 * hh);
                     const float4 cq = *reinterpret_cast<const float4*>(sAF + N + nt * 32 + 8 * q + 4 * hh);
-                    v0 = act_fwd(pr.aff_post, aq.x * v0 + cq.x); v1 = act_fwd(pr.aff_post, aq.y * v1 + cq.y);
-                    v2 = act_fwd(pr.aff_post, aq.z * v2 + cq.z); v3 = act_fwd(pr.aff_post, aq.w * v3 + cq.w);
+                    float v4[4] = {v0, v1, v2, v3};
+                    const float a4[4] = {aq.x, aq.y, aq.z, aq.w}, c4[4] = {cq.x, cq.y, cq.z, cq.w};
+                    affine4(v4, a4, c4, TCCT_ACT_NONE, pr.aff_post);      // (the kind resolved once per four values, not per value: common.h)
+                    v0 = v4[0]; v1 = v4[1]; v2 = v4[2]; v3 = v4[3];
                 }
                 uint2 o;
                 o.x = pack_bf16x2(v0, v1);
