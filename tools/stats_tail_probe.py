@@ -24,7 +24,7 @@ def main():
         t_plain = timeit(lambda: lib.pw_fwd(x, w, None, y, M, K, N, 0, 1), iters=50, warm=5)
         t_stats = timeit(lambda: lib.pw_fwd_bnstats(x, w, None, y, M, K, N, sums, 0), iters=50, warm=5)
         mb = M * (K + N) * 2 / 1e6
-        print(f'level {lv}: pointwise {K:3d} -> {N:3d}, M = {M:7d} ({mb:6.1f} MB): plain {t_plain * 1e3:6.1f} us, with statistics {t_stats * 1e3:6.1f} us (incl. a 0.5 KB memset)', flush=True)
+        print(f'level {lv}: pointwise {K:3d} -> {N:3d}, M = {M:7d} ({mb:6.1f} MB): plain {t_plain * 1e3:6.1f} us, with statistics {t_stats * 1e3:6.1f} us (incl. a 0.5 KB memset launch)', flush=True)
         mr = torch.zeros(2 * N, device=dev); mr[N:] = 1
         ab = torch.ones(2 * N, device=dev)
         dy = torch.randn(M, N, device=dev).to(torch.bfloat16)
