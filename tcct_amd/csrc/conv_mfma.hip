@@ -2039,7 +2039,9 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
     TCCT_CHECK(tilesH < 1024 && tilesW < 1024 && N < 2048, "conv32_wgrad: %d images of %d x %d tiles exceed the packed tile id (2047 images, 1023 x 1023 tiles)", N, tilesH, tilesW);
     TCCT_CHECK((int64_t)H * W * xs * 2 < (1LL << 31) && (int64_t)H * W * ds * 2 < (1LL << 31),
                "conv32_wgrad: one image of %d x %d x %d channels exceeds the 2 GiB buffer-descriptor range", H, W, xs > ds ? xs : ds);
-    int grid = (int)(nt < 512 ? nt : 512);
+    // every block of these kernels ends with TAPS x 1024 fp32 atomics on the same addresses: on small maps (levels 2-4: <= 1024 tiles) <= 128 blocks walk several tiles each
+    // instead of 512 blocks spending more time in that tail than in their one or two tiles (round 6; the large maps keep 512)
+    int grid = (int)(nt <= 1024 ? (nt < 128 ? nt : 128) : 512);
     hipStream_t st = (hipStream_t)stream;
     if (zero) {
         if (!tcct_skip_zero_fill() && hipMemsetAsync(dw, 0, sizeof(float) * TAPS * 1024, st) != hipSuccess) { tcct_set_error("conv32_wgrad: memset failed"); return -2; }
@@ -2068,7 +2070,9 @@ static int conv32_wgrad_impl(const void* x, const void* dy, float* dw, float* db
         constexpr size_t lds4 = (size_t)18 * 34 * 64 + 16 * 32 * 64;
         static bool attr4 = false;
         if (!attr4) { (void)hipFuncSetAttribute((const void*)k_conv32_wgrad33_roll, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr4 = true; }
-        hipLaunchKernelGGL(k_conv32_wgrad33_roll, dim3((unsigned)(nt < 512 ? nt : 512)), dim3(WR_T), lds4, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W,
+        // (`grid`: <= 128 blocks on the small maps this kernel serves -- 96-936 tiles at levels 2-4 --: one block per tile spent more time in the 9 216 closing atomics than in
+        // its tile, 4.7 M atomics at level 2)
+        hipLaunchKernelGGL(k_conv32_wgrad33_roll, dim3((unsigned)grid), dim3(WR_T), lds4, st, (const bf16*)x, (const bf16*)dy, dw, dbias, N, H, W,
                            tilesH, tilesW, (int)nt);
         TCCT_LAUNCH_OK();
     }
