@@ -137,10 +137,12 @@ template <int K> __device__ __forceinline__ float actf(int rt, float x) { return
 template <int K> __device__ __forceinline__ float actg(int rt, float x) { return K < 0 ? act_grad(rt, x) : act_grad_c<(K < 0 ? 0 : K)>(x); }
 // Compile-time activation kinds for the combinations the networks use (round 6): act_fwd / act_grad resolve a RUN-TIME kind per element with a chain of scalar
 // compare-and-branch pairs (five per call, two or three calls per element); the generic BatchNorm kernels ran at 2.9 (backward reduction) / 3.65 (apply) TB/s on that,
-// the junction kernels had the same problem in round 3.  -1 = run-time kinds (everything else).
+// the junction kernels had the same problem in round 3.  none + Hardswish (ViT), none + none, LeakyReLU + none (CNN block5), none + LeakyReLU (decoder); -1 = run-time kinds
+// (everything else).
 #define BN_KINDS(CALL) do { if (pre_act == TCCT_ACT_NONE && post_act == TCCT_ACT_HSWISH) { constexpr int PRE = TCCT_ACT_NONE, POST = TCCT_ACT_HSWISH; CALL; } \
                             else if (pre_act == TCCT_ACT_NONE && post_act == TCCT_ACT_NONE) { constexpr int PRE = TCCT_ACT_NONE, POST = TCCT_ACT_NONE; CALL; } \
                             else if (pre_act == TCCT_ACT_LRELU && post_act == TCCT_ACT_NONE) { constexpr int PRE = TCCT_ACT_LRELU, POST = TCCT_ACT_NONE; CALL; } \
+                            else if (pre_act == TCCT_ACT_NONE && post_act == TCCT_ACT_LRELU) { constexpr int PRE = TCCT_ACT_NONE, POST = TCCT_ACT_LRELU; CALL; } \
                             else { constexpr int PRE = -1, POST = -1; CALL; } } while (0)
 // ------------------------------------------------------------------ BN apply: y = post(a*pre(x)+b)
 // train-mode coefficients of channel c from the batch sums (what k_bn_finalize computes), in double like it

@@ -760,7 +760,9 @@ def test_metapool_maxpool_l2norm(dt):
 @pytest.mark.parametrize('cfg', [(32, 4, 6, 8, 12, True), (32, 8, 10, 16, 20, False), (5, 4, 6, 32, 48, False),
                                  (5, 8, 12, 16, 24, False), (32, 2, 3, 8, 12, False), (32, 1, 1, 2, 2, True),
                                  (5, 2, 2, 32, 32, False), (32, 20, 70, 40, 140, True), (5, 19, 41, 152, 328, False),
-                                 (32, 21, 37, 21, 37, False), (5, 10, 37, 40, 148, True), (64, 9, 35, 18, 70, True)])
+                                 (32, 21, 37, 21, 37, False), (5, 10, 37, 40, 148, True), (64, 9, 35, 18, 70, True),
+                                 # narrow tensors x2: the backward stages its window of dy in LDS (k_bilinear_bwd_tab_staged, round 6); several ragged tiles
+                                 (5, 19, 70, 38, 140, False), (3, 17, 45, 34, 90, False), (7, 16, 64, 32, 128, False), (5, 9, 33, 18, 66, True)])
 def test_bilinear(dt, cfg):
     from tcct_amd import ops
     C, H, W, Ho, Wo, align = cfg
