@@ -504,6 +504,9 @@ int tcct_bilinear_bwd_separable(const float* dy, float* dx, float* workspace, in
 /* y = resize(x) + res (res, y [N,Ho,Wo,C]): upsampling with the decoder's skip-connection add folded in (nets/tcct.py:908-912) */
 int tcct_bilinear_add_fwd(const void* x, const void* res, void* y, int N, int H, int W, int C, int Ho, int Wo, int align_corners,
                           int dtype, tcct_stream_t stream);
+/* kernel A/B of tcct_bilinear_bwd (tools/bilinear_bwd_bench.py, tests): 0 = exact x2 resizes (align_corners = 0) take the tiled gather kernel like every other scale instead of the
+ * separable lane-exchange kernel; returns the previous value.  Test / measurement only. */
+int64_t tcct_bilinear_bwd_x2(int on);
 int tcct_bilinear_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int align_corners, int dtype,
                       tcct_stream_t stream);
 /* ---- F.normalize(dim=channel, p=2, eps) (nets/tcct.py:940) ------------------------------------------------ */

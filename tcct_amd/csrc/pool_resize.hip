@@ -378,6 +378,125 @@ __global__ void __launch_bounds__(PB) k_bilinear_bwd_tab(const T* __restrict__ d
     }
 }
 
+// Exact x2, align_corners = False (every resize of the decoder and the level-0 head) -- round 6.  The transposed interpolation is separable with the fixed taps
+// {1/4, 3/4, 3/4, 1/4} over dy columns 2 wi - 1 .. 2 wi + 2 (rows alike; at the borders the outer tap vanishes and its inner neighbour weighs 1).  The tiled gather above
+// reads 16 dy vectors per dx vector (every dy element four times: L1 / L2 hits, but the CU takes only so many load instructions: 2.1-3.3 TB/s); here a lane owns low-resolution
+// column wi (NCH channels) of a strip of BX_SH output rows, loads ITS two dy columns of the 2 BX_SH + 2 rows the strip needs -- all requests issued before the first use --
+// and takes columns 2 wi - 1 / 2 wi + 2 from the adjacent lanes (`__shfl`; a lane at the edge of the wave's pixel run fetches that one column itself).  Every dy element
+// is loaded once (+ the strip halo rows).  The sums are formed column-first: ((1/4 l + 3/4 a) + 3/4 b) + 1/4 r per dy row, then the same over four rows -- a different
+// association than the gather's row-major sum of 16 products (fp32 accumulation either way: ~1e-7 relative).
+#define BX_SH 4
+#define BX_ROWS (2 * BX_SH + 2)
+template <typename T, int NCH> struct BxRaw;           // NCH channels of one dy pixel as loaded
+template <int NCH> struct BxRaw<float, NCH> {
+    float v[NCH];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) v[k] = 0.f;
+    }
+    __device__ __forceinline__ void load(const float* p) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) v[k] = p[k];
+    }
+    __device__ __forceinline__ float get(int k) const { return v[k]; }
+    __device__ __forceinline__ BxRaw shfl(int delta, bool up) const {
+        BxRaw r;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) r.v[k] = up ? __shfl_up(v[k], delta, 64) : __shfl_down(v[k], delta, 64);
+        return r;
+    }
+};
+template <> struct BxRaw<bf16, 8> {
+    uint4 q;
+    __device__ __forceinline__ void zero() { q = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ void load(const bf16* p) { q = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ float get(int k) const {
+        const uint32_t w = k < 2 ? q.x : (k < 4 ? q.y : (k < 6 ? q.z : q.w));
+        return (k & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+    }
+    __device__ __forceinline__ BxRaw shfl(int delta, bool up) const {
+        BxRaw r;
+        r.q.x = up ? __shfl_up(q.x, delta, 64) : __shfl_down(q.x, delta, 64);
+        r.q.y = up ? __shfl_up(q.y, delta, 64) : __shfl_down(q.y, delta, 64);
+        r.q.z = up ? __shfl_up(q.z, delta, 64) : __shfl_down(q.z, delta, 64);
+        r.q.w = up ? __shfl_up(q.w, delta, 64) : __shfl_down(q.w, delta, 64);
+        return r;
+    }
+};
+__device__ __forceinline__ void bx_store(float* p, const float* o, int n) { for (int k = 0; k < n; ++k) p[k] = o[k]; }
+__device__ __forceinline__ void bx_store(bf16* p, const float* o, int) {
+    uint4 t; t.x = pack_bf16x2(o[0], o[1]); t.y = pack_bf16x2(o[2], o[3]); t.z = pack_bf16x2(o[4], o[5]); t.w = pack_bf16x2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(p) = t;
+}
+// the lane's two adjacent dy pixels: fp32 narrow tensors -- 2 NCH contiguous floats, 8-byte aligned (Wo = 2 W) -> NCH 8-byte loads; bf16 -- two 16-byte loads C apart
+template <int NCH>
+__device__ __forceinline__ void bx_load_pair(const float* row, int, BxRaw<float, NCH>& a, BxRaw<float, NCH>& b) {
+    float tmp[2 * NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) { const float2 q = reinterpret_cast<const float2*>(row)[k]; tmp[2 * k] = q.x; tmp[2 * k + 1] = q.y; }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) { a.v[k] = tmp[k]; b.v[k] = tmp[NCH + k]; }
+}
+__device__ __forceinline__ void bx_load_pair(const bf16* row, int C, BxRaw<bf16, 8>& a, BxRaw<bf16, 8>& b) { a.load(row); b.load(row + C); }
+// HALO (one channel group per column, CV = 1: the narrow fp32 tensors): a wave covers 62 columns + one halo lane at either end, which loads and exchanges but stores nothing
+// (the adjacent wave owns its column) -- no edge fetches, 50 fewer registers; otherwise (bf16, CV channel vectors per column) the lanes at the ends of the wave's pixel run
+// fetch the one column no neighbour lane holds.
+template <typename T, int NCH, bool HALO>
+__global__ void __launch_bounds__(PB) k_bilinear_bwd_x2(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int wcols, int hstrips) {
+    const int CV = HALO ? 1 : C / NCH, PPW = 64 / CV;           // lanes of a wave: PPW consecutive columns x CV channel vectors
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * (PB / 64) + (int)(threadIdx.x >> 6);        // wave-uniform; no block-level synchronisation below
+    if (wv >= N * hstrips * wcols) return;
+    const int wc = wv % wcols, hs = (wv / wcols) % hstrips, n = wv / (wcols * hstrips);
+    const int pl = lane / CV, cv = lane - pl * CV;
+    const int wi = HALO ? wc * 62 - 1 + pl : wc * PPW + pl, c0 = cv * NCH;
+    const bool live = wi >= 0 && wi < W;
+    const bool writes = live && (!HALO || (pl >= 1 && pl <= 62));
+    const int hA = hs * BX_SH, hB = min(H, hA + BX_SH);
+    const int Ho = 2 * H, Wo = 2 * W;
+    const T* g = dy + (int64_t)n * Ho * Wo * C + c0;
+    const bool edge_l = !HALO && live && pl == 0 && wi > 0, edge_r = !HALO && live && pl == PPW - 1 && wi < W - 1;
+    BxRaw<T, NCH> A[BX_ROWS], Bq[BX_ROWS], E[HALO ? 1 : BX_ROWS];
+#pragma unroll
+    for (int i = 0; i < BX_ROWS; ++i) {
+        const int r = 2 * hA - 1 + i;
+        const bool rok = r >= 0 && r < Ho && r <= 2 * hB;       // (wave-uniform)
+        A[i].zero(); Bq[i].zero();
+        if (!HALO) E[i].zero();
+        if (rok && live) {
+            const T* row = g + ((int64_t)r * Wo + 2 * wi) * C;
+            bx_load_pair(row, C, A[i], Bq[i]);
+            if (!HALO) {
+                if (edge_l) E[i].load(row - C);
+                if (edge_r) E[i].load(row + 2 * C);
+            }
+        }
+    }
+    const float cw0 = wi > 0 ? 0.25f : 0.f, cw1 = wi > 0 ? 0.75f : 1.f, cw2 = wi < W - 1 ? 0.75f : 1.f, cw3 = wi < W - 1 ? 0.25f : 0.f;
+    float t[BX_ROWS][NCH];
+#pragma unroll
+    for (int i = 0; i < BX_ROWS; ++i) {
+        BxRaw<T, NCH> L = Bq[i].shfl(CV, true), Rr = A[i].shfl(CV, false);      // column 2 wi - 1 = the left lane's second column, 2 wi + 2 = the right lane's first
+        if (!HALO) {
+            if (edge_l) L = E[i];
+            if (edge_r) Rr = E[i];
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) t[i][k] = ((cw0 * L.get(k) + cw1 * A[i].get(k)) + cw2 * Bq[i].get(k)) + cw3 * Rr.get(k);
+    }
+    if (!writes) return;
+#pragma unroll
+    for (int j = 0; j < BX_SH; ++j) {
+        const int hi = hA + j;
+        if (hi >= hB) break;
+        const float rw0 = hi > 0 ? 0.25f : 0.f, rw1 = hi > 0 ? 0.75f : 1.f, rw2 = hi < H - 1 ? 0.75f : 1.f, rw3 = hi < H - 1 ? 0.25f : 0.f;
+        float o[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) o[k] = ((rw0 * t[2 * j][k] + rw1 * t[2 * j + 1][k]) + rw2 * t[2 * j + 2][k]) + rw3 * t[2 * j + 3][k];
+        bx_store(dx + (((int64_t)n * H + hi) * W + wi) * C + c0, o, NCH);
+    }
+}
+
 // Separable backward for narrow fp32 tensors (the 5-class aux logits resized x2 / x4 / x8 to the input size): the transposed
 // interpolation factors into a pass along W (dy [N,Ho,Wo,C] -> tmp [N,Ho,W,C], every dy element read once, coalesced) and a pass
 // along H (tmp -> dx [N,H,W,C]).  The 2-D gather reads (2/scale)^2 = 16 .. 256 dy elements per dx element one after another from a
@@ -476,6 +595,9 @@ static int bilinear_fwd_impl(const void* x, const void* res, void* y, int N, int
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bilinear_fwd<T, 1>), row_grid(Wo * C, (int64_t)N * Ho), dim3(PB), 0, st, (const T*)x, (T*)y, N, H, W, C, Ho, Wo, sh, sw, align_corners, (const T*)res)); }
     TCCT_LAUNCH_OK();
 }
+static int g_bilinear_x2 = 1;
+/* kernel A/B (tools/bilinear_bwd_bench.py, tests): 0 = exact x2 resizes take the tiled gather kernel like every other scale; returns the previous value */
+extern "C" int64_t tcct_bilinear_bwd_x2(int on) { const int old = g_bilinear_x2; g_bilinear_x2 = on ? 1 : 0; return old; }
 /* dy [N,Ho,Wo,C] -> dx [N,H,W,C] (H,W = forward input size) */
 extern "C" int tcct_bilinear_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int align_corners,
                                  int dtype, tcct_stream_t stream) {
@@ -485,6 +607,20 @@ extern "C" int tcct_bilinear_bwd(const void* dy, void* dx, int N, int H, int W, 
     int vec = (C % 4 == 0) ? 4 : 1;
     hipStream_t st = (hipStream_t)stream;
     // entries per table row: outputs within +-1 source pixel of an input index = 2/scale (+ slack); beyond BL_MAXC use the search kernel
+    if (!align_corners && Ho == 2 * H && Wo == 2 * W && g_bilinear_x2) {        // exact x2: the separable lane-exchange kernel
+        const int nch = (dtype == TCCT_BF16 && C % 8 == 0 && (C == 8 || C == 16 || C == 32 || C == 64)) ? 8 : ((dtype == TCCT_F32 && (C == 5 || C == 9)) ? C : 0);
+        if (nch) {
+            const int CV = C / nch, PPW = 64 / CV;
+            const int wcols = nch == 8 ? (W + PPW - 1) / PPW : (W + 61) / 62, hstrips = (H + BX_SH - 1) / BX_SH;
+            const int64_t waves = (int64_t)N * wcols * hstrips;
+            TCCT_CHECK(waves < 0x7fffffffLL, "bilinear_bwd: grid too large");
+            const dim3 grid((unsigned)((waves + PB / 64 - 1) / (PB / 64)));
+            if (nch == 8) hipLaunchKernelGGL((k_bilinear_bwd_x2<bf16, 8, false>), grid, dim3(PB), 0, st, (const bf16*)dy, (bf16*)dx, N, H, W, C, wcols, hstrips);
+            else if (nch == 5) hipLaunchKernelGGL((k_bilinear_bwd_x2<float, 5, true>), grid, dim3(PB), 0, st, (const float*)dy, (float*)dx, N, H, W, C, wcols, hstrips);
+            else hipLaunchKernelGGL((k_bilinear_bwd_x2<float, 9, true>), grid, dim3(PB), 0, st, (const float*)dy, (float*)dx, N, H, W, C, wcols, hstrips);
+            TCCT_LAUNCH_OK();
+        }
+    }
     const float smin = fminf(sh, sw);
     const int KT = smin > 0.f ? (int)(2.f / smin) + 3 : BL_MAXC + 1;
     if (KT <= BL_MAXC) {

@@ -125,12 +125,19 @@ def _pack_all(device):
     _PACKS['fresh'] = True
 
 
+BILINEAR_BWD_X2 = True      # exact x2 resizes: the separable lane-exchange backward (tcct_bilinear_bwd_x2; round 6); False: the tiled gather kernel (A/B timing)
+_BILINEAR_X2_SET = [True]
+
+
 def begin_step(device):
     """call once per training step before the forward (KiteSeg.train_step does): arms the zero pool"""
     device = torch.device(device)
     if device.type == 'cuda' and device.index is None:          # torch.device('cuda') != torch.device('cuda', 0): never re-allocate the pool for that
         device = torch.device('cuda', torch.cuda.current_device())
     ZERO.begin(device)
+    if BILINEAR_BWD_X2 != _BILINEAR_X2_SET[0]:          # kernel A/B (bench.py --set BILINEAR_BWD_X2=0): the library-wide switch follows the module constant
+        lib.bilinear_bwd_x2(int(BILINEAR_BWD_X2))
+        _BILINEAR_X2_SET[0] = BILINEAR_BWD_X2
     fpl_lazy_grad_reset()
     _pack_evict()
     _pack_all(device)

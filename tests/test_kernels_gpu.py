@@ -762,7 +762,11 @@ def test_metapool_maxpool_l2norm(dt):
                                  (5, 2, 2, 32, 32, False), (32, 20, 70, 40, 140, True), (5, 19, 41, 152, 328, False),
                                  (32, 21, 37, 21, 37, False), (5, 10, 37, 40, 148, True), (64, 9, 35, 18, 70, True),
                                  # narrow tensors x2: the backward stages its window of dy in LDS (k_bilinear_bwd_tab_staged, round 6); several ragged tiles
-                                 (5, 19, 70, 38, 140, False), (3, 17, 45, 34, 90, False), (7, 16, 64, 32, 128, False), (5, 9, 33, 18, 66, True)])
+                                 (5, 19, 70, 38, 140, False), (3, 17, 45, 34, 90, False), (7, 16, 64, 32, 128, False), (5, 9, 33, 18, 66, True),
+                                 # exact x2, align_corners = False: the separable lane-exchange backward (k_bilinear_bwd_x2, round 6) -- 5 / 9 fp32 channels (62-column wave
+                                 # tiles with halo lanes), 8-channel bf16 vectors of 16 / 32 / 64 channels (edge fetches); several waves per row, ragged strips of 4 rows
+                                 (5, 21, 131, 42, 262, False), (9, 10, 70, 20, 140, False), (32, 19, 70, 38, 140, False), (16, 5, 33, 10, 66, False),
+                                 (64, 6, 17, 12, 34, False), (5, 1, 1, 2, 2, False), (32, 1, 3, 2, 6, False)])
 def test_bilinear(dt, cfg):
     from tcct_amd import ops
     C, H, W, Ho, Wo, align = cfg
