@@ -43,7 +43,7 @@ __device__ __forceinline__ void bn_block_reduce2(float* sm, const float* s, cons
 }
 
 // ------------------------------------------------------------------ BN forward statistics: sum, sum of squares
-template <typename T, int VEC>
+template <typename T, int VEC, int PRE = -1>
 __global__ void __launch_bounds__(NBR) k_bn_stats(const T* __restrict__ x, int64_t M, int C, int pre_act, double* __restrict__ sums) {
     __shared__ float sm[NBR * VEC];     // one 32 KB array, used for the sums and then for the sums of squares (VEC = 8)
     const int CV = C / VEC;            // vectors per row
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(NBR) k_bn_stats(const T* __restrict__ x, int64
             float a[VEC];
             ldv<VEC>(x + m * C + cv * VEC, a);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) { float u = act_fwd(pre_act, a[k]); s[k] += u; q[k] += u * u; }
+            for (int k = 0; k < VEC; ++k) { float u = PRE == TCCT_ACT_NONE ? a[k] : act_fwd(pre_act, a[k]); s[k] += u; q[k] += u * u; }
         }
     }
     bn_block_reduce2<VEC>(sm, s, q, t, C, CV, R, sums);
@@ -73,6 +73,7 @@ extern "C" int tcct_bn_stats(const void* x, int64_t M, int C, int pre_act, doubl
     int R = NBR / (C / vec);
     int grid = tcct_grid(M, R, 512);
     if (vec == 8) hipLaunchKernelGGL((k_bn_stats<bf16, 8>), dim3(grid), dim3(NBR), 0, st, (const bf16*)x, M, C, pre_act, sums);
+    else if (vec == 4 && pre_act == TCCT_ACT_NONE) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_stats<T, 4, TCCT_ACT_NONE>), dim3(grid), dim3(NBR), 0, st, (const T*)x, M, C, pre_act, sums)); }     // (no per-element kind switch: the boundary loss's 4-channel fp32 BatchNorms ran at 0.7 TB/s)
     else if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_stats<T, 4>), dim3(grid), dim3(NBR), 0, st, (const T*)x, M, C, pre_act, sums)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_stats<T, 1>), dim3(grid), dim3(NBR), 0, st, (const T*)x, M, C, pre_act, sums)); }
     TCCT_LAUNCH_OK();
@@ -251,6 +252,7 @@ static int bn_apply_impl(const void* x, const void* res, void* y, int64_t M, int
     hipStream_t st = (hipStream_t)stream;
     if (vec == 8) hipLaunchKernelGGL((k_bn_apply<bf16, 8>), dim3(grid), dim3(NB), 0, st, (const bf16*)x, (bf16*)y, M, C, ab, pre_act, post_act, (const bf16*)res, tr);
     else if (vec == 4 && dtype == TCCT_BF16) { BN_KINDS(hipLaunchKernelGGL((k_bn_apply<bf16, 4, PRE, POST>), dim3(grid), dim3(NB), 0, st, (const bf16*)x, (bf16*)y, M, C, ab, pre_act, post_act, (const bf16*)res, tr)); }
+    else if (vec == 4 && dtype == TCCT_F32 && pre_act == TCCT_ACT_NONE && post_act == TCCT_ACT_NONE) { hipLaunchKernelGGL((k_bn_apply<float, 4, TCCT_ACT_NONE, TCCT_ACT_NONE>), dim3(grid), dim3(NB), 0, st, (const float*)x, (float*)y, M, C, ab, pre_act, post_act, (const float*)res, tr); }
     else if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act, (const T*)res, tr)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (T*)y, M, C, ab, pre_act, post_act, (const T*)res, tr)); }
     TCCT_LAUNCH_OK();
@@ -340,6 +342,7 @@ extern "C" int tcct_bn_bwd_reduce(const void* x, const void* dy, int64_t M, int 
     int grid = tcct_grid(M, R, 512);
     if (vec == 8) hipLaunchKernelGGL((k_bn_bwd_reduce<bf16, 8>), dim3(grid), dim3(NBR), 0, st, (const bf16*)x, (const bf16*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums);
     else if (vec == 4 && dtype == TCCT_BF16) { BN_KINDS(hipLaunchKernelGGL((k_bn_bwd_reduce<bf16, 4, PRE, POST>), dim3(grid), dim3(NBR), 0, st, (const bf16*)x, (const bf16*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
+    else if (vec == 4 && dtype == TCCT_F32 && pre_act == TCCT_ACT_NONE && post_act == TCCT_ACT_NONE) { hipLaunchKernelGGL((k_bn_bwd_reduce<float, 4, TCCT_ACT_NONE, TCCT_ACT_NONE>), dim3(grid), dim3(NBR), 0, st, (const float*)x, (const float*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums); }
     else if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce<T, 4>), dim3(grid), dim3(NBR), 0, st, (const T*)x, (const T*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_reduce<T, 1>), dim3(grid), dim3(NBR), 0, st, (const T*)x, (const T*)dy, M, C, mean_rstd, ab, pre_act, post_act, sums)); }
     TCCT_LAUNCH_OK();
@@ -392,6 +395,7 @@ extern "C" int tcct_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_
     hipStream_t st = (hipStream_t)stream;
     if (vec == 8) hipLaunchKernelGGL((k_bn_bwd_apply<bf16, 8>), dim3(grid), dim3(NB), 0, st, (const bf16*)x, (const bf16*)dy, (bf16*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta);
     else if (vec == 4 && dtype == TCCT_BF16) { BN_KINDS(hipLaunchKernelGGL((k_bn_bwd_apply<bf16, 4, PRE, POST>), dim3(grid), dim3(NB), 0, st, (const bf16*)x, (const bf16*)dy, (bf16*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
+    else if (vec == 4 && dtype == TCCT_F32 && pre_act == TCCT_ACT_NONE && post_act == TCCT_ACT_NONE) { hipLaunchKernelGGL((k_bn_bwd_apply<float, 4, TCCT_ACT_NONE, TCCT_ACT_NONE>), dim3(grid), dim3(NB), 0, st, (const float*)x, (const float*)dy, (float*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta); }
     else if (vec == 4) { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<T, 4>), dim3(grid), dim3(NB), 0, st, (const T*)x, (const T*)dy, (T*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
     else { TCCT_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<T, 1>), dim3(grid), dim3(NB), 0, st, (const T*)x, (const T*)dy, (T*)dx, M, C, mean_rstd, ab, sums, pre_act, post_act, dgamma, dbeta)); }
     TCCT_LAUNCH_OK();
