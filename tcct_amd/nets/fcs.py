@@ -10,11 +10,12 @@ import torch
 from torch import nn
 
 from .._lib import lib, dtype_code, TcctError
+from .. import ops
 
 BINS = 32        # reference fcs.py:35
 
 
-class _SelectBins(torch.autograd.Function):
+class _SelectBins(ops._FastFunction):
     """rows of feat [M,32] whose `true` > .5, ranked by `prob` (descending), averaged over 32 equal rank ranges -> [32,32]
     (reference fcs.py:25-50: the n % 32 lowest-probability rows are dropped; fewer than 32 rows give NaN like the reference's
     mean of an empty selection).  Gradient flows to `feat` only (the reference sorts detached probabilities, reg.py:89)."""

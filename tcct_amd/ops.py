@@ -168,7 +168,19 @@ def step_streams():
     return out
 
 
-class _GradMark(torch.autograd.Function):
+
+class _FastFunction(torch.autograd.Function):
+    """torch.autograd.Function whose `apply` goes straight to the C++ implementation (round 6).  `Function.apply` first checks for a `setup_context` override, asks whether
+    functorch transforms are active and runs `unwrap_dead_wrappers` over the arguments -- 6-8 us per call, ~130 calls per forward pass; the forward pass of the bench step is
+    HOST-bound (tools/host_profile.py: ~8 ms of enqueue for ~5.5 ms of kernels once the two encoders overlap), so this is step time, not bookkeeping.  None of these
+    Functions defines `setup_context` or is used under functorch transforms (vmap / grad / jvp)."""
+
+    @classmethod
+    def apply(cls, *args):
+        return super(torch.autograd.Function, cls).apply(*args)
+
+
+class _GradMark(_FastFunction):
     @staticmethod
     def forward(ctx, x, key):
         ctx.key = key
@@ -410,7 +422,7 @@ def _pw_ok(in_dt, Cin, Cin_w, KH, KW, stride, padh, padw):
             and Cin % 32 == 0)
 
 
-class _Conv2d(torch.autograd.Function):
+class _Conv2d(_FastFunction):
     @staticmethod
     def forward(ctx, x, w, bias, stride, padh, padw, out_dtype, stats_box, fork=False):
         """fork: also return an alias of x for the OTHER consumers of x -- their gradient then arrives in backward() and is added
@@ -654,7 +666,7 @@ def _packs33(ctx_w, need_t):
     return wp, None
 
 
-class _ConvChain33(torch.autograd.Function):
+class _ConvChain33(_FastFunction):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, stats_box, fork):
         ctx.set_materialize_grads(False)
@@ -994,7 +1006,7 @@ def bn2_add_act_eval(xa, bnA, xb, bnB, pre_act='lrelu', act_kind='gelu'):
     return y
 
 
-class _LinearResidual(torch.autograd.Function):
+class _LinearResidual(_FastFunction):
     """res + scale[b] * (x W^T + bias) on tokens [B,N,C] (Mlp.fc2 + DropPath scale + residual add in the GEMM epilogue)"""
 
     @staticmethod
@@ -1036,7 +1048,7 @@ class _LinearResidual(torch.autograd.Function):
 MLP_GELU_FUSE = True         # False: GELU as its own pass between fc1 and fc2 (round-3 form; A/B timing)
 
 
-class _GeluLinearResidual(torch.autograd.Function):
+class _GeluLinearResidual(_FastFunction):
     """res + scale[b] * (gelu(x1) W^T + bias) on tokens [B,N,C] with x1 the PRE-activation of Mlp.fc1 (reference nets/tcct.py:29-53,468): GELU is applied
     while the GEMM kernels stage their tiles (tcct_pw_fwd_gelu_residual / tcct_pw_bwd_gelu), so neither h = gelu(x1) nor dh exist in HBM -- bit-identical
     to act(x1, 'gelu') followed by linear_residual (same formula, same bf16 roundings), two tensor passes fewer forward and three fewer backward."""
@@ -1070,7 +1082,7 @@ class _GeluLinearResidual(torch.autograd.Function):
         return dx1, _ret(dw, wsrc), _ret(db, bsrc), dy, None
 
 
-class _MlpTail(torch.autograd.Function):
+class _MlpTail(_FastFunction):
     """t2 = t1 + scale[b] * fc2(gelu(fc1(cur2))) with cur2 = LayerNorm2(t1) as stored by the node in front (ln_metapool_residual_ln): MHCABlock's second half
     (reference nets/tcct.py:466-468) as ONE autograd node, so that its backward can run LayerNorm2's backward in fc1's input-gradient epilogue
     (tcct_pw_bwd_lnb): the gradient of cur2 is never written, the stand-alone LayerNorm backward pass does not run.  The node returns the COMPLETE gradient of
@@ -1138,7 +1150,7 @@ def gelu_linear_residual(x1, w, bias, res, scale=None):
     return _GeluLinearResidual.apply(x1, w, bias, res, scale)
 
 
-class _Conv1x1AndSum(torch.autograd.Function):
+class _Conv1x1AndSum(_FastFunction):
     """(d, d + res) with d = conv1x1(x): both written by one GEMM epilogue (decoder `post` convolution + the `x_i + y_i` that follows)"""
 
     @staticmethod
@@ -1181,7 +1193,7 @@ class _Conv1x1AndSum(torch.autograd.Function):
         return dx, _ret(dw, wsrc), _ret(db, bsrc), (None if gs is None else _c(gs))
 
 
-class _UpSkipConv(torch.autograd.Function):
+class _UpSkipConv(_FastFunction):
     """decoder block tail (MPUpBlock, reference tcct.py:908-914 + the `x_i + y_i` of FTC.forward :1028-1031) as one node:
          u = resize_x2(y) + skip;  d = conv1x1(u);  s = d + skip        -> (d, s)
     One node instead of bilinear + conv1x1_and_sum so that the skip tensor's two gradients (through u and through s) leave the
@@ -1276,7 +1288,7 @@ def up_skip_conv(y, skip, w, bias, align_corners=True, want_plain=True):
 TAIL_COMPOSE = True      # False: resize + add, post convolution (+ sum), t324 as three kernels (round-3 form; A/B timing)
 
 
-class _UpSkipConvT32(torch.autograd.Function):
+class _UpSkipConvT32(_FastFunction):
     """g0 = t32(post(up(y) + skip) + skip) for the LAST decoder block (reference nets/tcct.py:908-914, :1031, :1035-1040) as ONE 64 -> 32 GEMM over the
     never-materialised concatenation [up(y) | skip] with composed weights (csrc/decoder_tail.hip): u, d0 and s0 are not written, the backward pass is
     one fused kernel + a 32 x 32 de-composition of the weight gradients."""
@@ -1330,7 +1342,7 @@ def up_skip_conv_t32(y, skip, w1, b1, w2, b2, align_corners=True):
     return _UpSkipConvT32.apply(y, skip, w1, b1, w2, b2, bool(align_corners))
 
 
-class _UpSkipConvT32Aux(torch.autograd.Function):
+class _UpSkipConvT32Aux(_FastFunction):
     """logits0 = aux0(t32(post(up(y) + skip) + skip)) (reference nets/tcct.py:908-914,1031,1035-1041) as ONE 64 -> n_class GEMM with fp32 output over
     [up(y) | skip] (csrc/decoder_tail.hip, `compose3`): for steps in which nothing else reads g0 -- the feature-polarization loss is off.  g0 and dg0
     never exist; the backward pass uses the small-N kernels of the aux heads on the two halves.  Returns (logits, v): v = up(y) (no gradient) lets
@@ -1381,7 +1393,7 @@ class _UpSkipConvT32Aux(torch.autograd.Function):
         return (dy, dskip) + tuple(_ret(o, p) for o, p in zip(outs, params)) + (None,)
 
 
-class _UpSkipConvT32AuxLow(torch.autograd.Function):
+class _UpSkipConvT32AuxLow(_FastFunction):
     """The same logits0 = aux0(t32(post(up(y) + skip) + skip)) with the resize COMMUTED behind the 1x1 convolution (round 4): bilinear interpolation is linear
     and acts per channel, so  W up(y) = up(W y):
         logits0 = up(Wa y) + Wb skip + c,      Wa = W3 W2 W1 [C x 32] applied at the LOW resolution,  Wb = W3 (W2 W1 + W2),  c = W3 (W2 b1 + b2) + b3
@@ -1481,7 +1493,7 @@ def up_skip_conv_t32_from_v(v, skip, w1, b1, w2, b2):
     return g
 
 
-class _HeadThroughT32(torch.autograd.Function):
+class _HeadThroughT32(_FastFunction):
     """logits_i = aux_i(t32x(s_i)) (reference nets/tcct.py:1036-1044, levels 1-3) as ONE 32 -> n_class GEMM with fp32 output and the composed weight
     Wa Wt (csrc/decoder_tail.hip, `head_compose`): for steps in which nothing else reads g_i = t32x(s_i) -- the feature-polarization loss is off.
     g_i and its gradient never exist; the backward pass runs the aux head's small-N kernels with the composed weight and de-composes the gradients."""
@@ -1552,7 +1564,7 @@ def linear_residual(x, w, bias, res, scale=None):
     return _LinearResidual.apply(x, w, bias, res, scale)
 
 
-class _PwCat2(torch.autograd.Function):
+class _PwCat2(_FastFunction):
     """1x1 convolution over the channel concatenation [a | b] without materialising it (MHCA_stage.aggregate)"""
 
     @staticmethod
@@ -1623,7 +1635,7 @@ def im2col3x3_c3(x4, stride=1):
 C3_DIRECT = True       # False: im2col + pointwise GEMM for the 3-channel first layers (A/B timing)
 
 
-class _ConvC3(torch.autograd.Function):
+class _ConvC3(_FastFunction):
     """cnn.0 / stem.0 (reference nets/tcct.py:873, :674-681): 3 -> 32 channels, 3x3, pad 1, stride 1 / 2, straight from the 4-channel image
     (tcct_c3_fwd / tcct_c3_wgrad): the patch rows are gathered inside the MFMA kernels, the 32-channel im2col tensor (452 MB at the bench
     shape, written once and read twice) does not exist.  The image gets no gradient."""
@@ -1695,7 +1707,7 @@ def conv3x3_c3(x4, w, bias, stride=1, stats_pre=None, infer_bn=None, post_act=No
 C3_BN_FUSE = True       # False: convolution (+ statistics) and BatchNorm as separate nodes, the round-3 form (A/B timing)
 
 
-class _ConvC3BN(torch.autograd.Function):
+class _ConvC3BN(_FastFunction):
     """z = post(BN_train(conv3x3(x4) + bias)) for the two 3-channel first layers as ONE node whose convolution output is never stored
     (csrc/c3_bn.hip; reference nets/tcct.py:873 `cnn.0 -> cnn.1`, :55-97 + :674-681 `stem[0]`): the input is the 4-channel image, 1/8 of the
     bytes of the 32-channel output, so forward (statistics pass, normalising pass) and backward (reduction, weight gradient) recompute y on the
@@ -1762,7 +1774,7 @@ def conv3x3_c3_bn(x4, w, bias, bn, stride=1, post_act=None):
     return _ConvC3BN.apply(x4, w, bias, gamma, beta, rm, rv, nbt, float(eps), float(mom), int(stride), ACT[post_act])
 
 
-class _DwConv(torch.autograd.Function):
+class _DwConv(_FastFunction):
     @staticmethod
     def forward(ctx, x, w, bias, stride, add_input, fork=False, stats_box=None, xab=None, xlink=None):
         """fork: also return an alias of x for its other consumers; their gradient is added inside the input-gradient kernel.
@@ -1850,7 +1862,7 @@ def dwconv3x3_fork(x, w, bias=None, stride=1, add_input=False):
 
 
 # ------------------------------------------------------------------------------------------------- norms
-class _BatchNorm(torch.autograd.Function):
+class _BatchNorm(_FastFunction):
     @staticmethod
     def forward(ctx, x, gamma, beta, rm, rv, nbt, eps, momentum, pre, post, training, res=None, link=None):
         _chk(x, gamma, beta)
@@ -1941,7 +1953,7 @@ def _bn_link_of(x, final):
     return getattr(x, '_bn_link', None)
 
 
-class _PwConvBN(torch.autograd.Function):
+class _PwConvBN(_FastFunction):
     """z = post(BN_train(conv1x1(x))) [+ res] as ONE autograd node (Conv2d_BN / DWConv2d_BN.pwconv / FTC.tran_*, reference nets/tcct.py:55-97,
     124-126,966-974): forward = the GEMM with the statistics in its epilogue + the normalisation pass; backward = [reduction, unless a consumer
     delivered the sums through `link`] + ONE kernel for BatchNorm backward apply, dx, dW, dbias (tcct_pw_bwd_bn), optionally with the reduction
@@ -2014,7 +2026,7 @@ class _PwConvBN(torch.autograd.Function):
                 (dz if has_res else None), None, None, None, None, None)
 
 
-class _Affine2Add(torch.autograd.Function):
+class _Affine2Add(_FastFunction):
     """z = BN1(y1) + BN2(y2) with both normalisations PENDING on their inputs (pw_conv_bn(defer_apply=True) with no activation): one pass; the gradient of z is
     the gradient of both BatchNorm outputs"""
 
@@ -2061,7 +2073,7 @@ BN_DEFER_DW = True  # False: the BatchNorms in front of the depthwise convolutio
 BN_DEFER = True        # False: InvRes.norm keeps its own normalisation pass (round-3 form; A/B timing)
 
 
-class _BatchNormDeferred(torch.autograd.Function):
+class _BatchNormDeferred(_FastFunction):
     """A train-mode BatchNorm (+ Hardswish) whose normalisation pass is NOT run (round 4): the node finalises the batch statistics (mean / rstd / a / b,
     running statistics) and returns an ALIAS OF ITS INPUT; the one consumer -- a 1x1 convolution built with `xdef` (pw_conv_bn(..., deferred=link)) --
     applies z = hswish(a y + b) while it stages its tiles.  The gradient that arrives here is the gradient of that virtual z, so the backward is the
@@ -2164,7 +2176,7 @@ def pw_conv_bn(x, w, bias, bn, post_act=None, residual=None, fork=False, x2=None
 BN_POOL_FUSE = True      # False: BatchNorm pass, then the pooling pass (A/B timing)
 
 
-class _BnPoolFork(torch.autograd.Function):
+class _BnPoolFork(_FastFunction):
     """(maxpool2(z), z) with z = post(BN_train(pre(x))) from ONE pass over x (tcct_bn_pool_fwd_train); in the backward pass the gradient of
     z -- the skip consumers' gradient plus the pooling scatter -- is never written: both BatchNorm backward kernels rebuild it from its
     two sources (tcct_bn_pool_bwd).  Encoder levels 0-3 (reference nets/tcct.py:820-823, :876-884)."""
@@ -2241,7 +2253,7 @@ def batchnorm(x, gamma, beta, running_mean, running_var, num_batches_tracked=Non
     return z
 
 
-class _Bn2AddAct(torch.autograd.Function):
+class _Bn2AddAct(_FastFunction):
     """y = act(BN_A(pre(xa)) + BN_B(pre(xb))), both BatchNorms in train mode (CrossCNNBlock junction)"""
 
     @staticmethod
@@ -2300,7 +2312,7 @@ def bn2_add_act(xa, bnA, xb, bnB, pre_act='lrelu', act_kind='gelu'):
                             ACT[act_kind])
 
 
-class _LayerNorm(torch.autograd.Function):
+class _LayerNorm(_FastFunction):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, fork=False):
         """fork: also return an alias of x for the residual path around the normalisation; its gradient is then added inside the
@@ -2346,7 +2358,7 @@ def layernorm_fork(x, gamma, beta, eps=1e-6):
 
 
 # ------------------------------------------------------------------------------------------- elementwise
-class _Act(torch.autograd.Function):
+class _Act(_FastFunction):
     @staticmethod
     def forward(ctx, x, kind):
         _chk(x)
@@ -2369,7 +2381,7 @@ def act(x, kind):
     return _Act.apply(x, ACT[kind])
 
 
-class _AddAct(torch.autograd.Function):
+class _AddAct(_FastFunction):
     @staticmethod
     def forward(ctx, a, b, kind):
         _chk(a, b)
@@ -2402,7 +2414,7 @@ def add(a, b):
     return _AddAct.apply(a, b, 0)
 
 
-class _Residual(torch.autograd.Function):
+class _Residual(_FastFunction):
     @staticmethod
     def forward(ctx, x, z, scale):
         _chk(x, z, scale)
@@ -2429,7 +2441,7 @@ def residual(x, z, scale=None):
     return _Residual.apply(x, z, scale)
 
 
-class _Concat2(torch.autograd.Function):
+class _Concat2(_FastFunction):
     @staticmethod
     def forward(ctx, a, b):
         _chk(a, b)
@@ -2455,7 +2467,7 @@ def concat2(a, b):
     return _Concat2.apply(a, b)
 
 
-class _Add3Scale(torch.autograd.Function):
+class _Add3Scale(_FastFunction):
     @staticmethod
     def forward(ctx, a, b, c, alpha):
         _chk(a, b, c)
@@ -2472,7 +2484,7 @@ class _Add3Scale(torch.autograd.Function):
         return d, d, d, None
 
 
-class _GateFusion(torch.autograd.Function):
+class _GateFusion(_FastFunction):
     @staticmethod
     def forward(ctx, x1, x2, field):
         _chk(x1, x2, field)
@@ -2505,7 +2517,7 @@ def add3_scale(a, b, c, alpha):
 
 
 # -------------------------------------------------------------------------------------- pooling / resize
-class _MetaPool(torch.autograd.Function):
+class _MetaPool(_FastFunction):
     @staticmethod
     def forward(ctx, x):
         _chk(x)
@@ -2523,7 +2535,7 @@ class _MetaPool(torch.autograd.Function):
         return dx
 
 
-class _MetaPoolResidual(torch.autograd.Function):
+class _MetaPoolResidual(_FastFunction):
     """t + scale[b] * metapool(cur): mixer branch, DropPath scale and residual add in one pass (and one pass backward)"""
 
     @staticmethod
@@ -2549,7 +2561,7 @@ def metapool_residual(cur, t, scale=None):
     return _MetaPoolResidual.apply(cur, t, scale)
 
 
-class _LnMetaPoolResidual(torch.autograd.Function):
+class _LnMetaPoolResidual(_FastFunction):
     """t + scale[b] * (pool(LN(t)) - LN(t)): MHCABlock's first half (reference nets/tcct.py:457-465, MetaPool :405-415) as ONE pass each way
     (csrc/ln_pool.hip): the normalised tensor and its gradient are never written"""
 
@@ -2574,7 +2586,7 @@ class _LnMetaPoolResidual(torch.autograd.Function):
         return dt, _ret(dg, gamma), _ret(db, ctx.beta_param), None, None
 
 
-class _LnMetaPoolResidualLn(torch.autograd.Function):
+class _LnMetaPoolResidualLn(_FastFunction):
     """(t1, LN2(t1)) with t1 = t + scale[b] * (pool(LN1(t)) - LN1(t)): MHCABlock up to the input of its Mlp (reference nets/tcct.py:457-466) from ONE forward
     pass -- the second LayerNorm is taken of the row while it is in registers.  Backward: LayerNorm-2 backward (+ the residual path's gradient of t1), then
     the one-pass backward of the first half."""
@@ -2643,7 +2655,7 @@ def metapool(x):
     return _MetaPool.apply(x)
 
 
-class _FactorAtt(torch.autograd.Function):
+class _FactorAtt(_FastFunction):
     """FactorAtt_ConvRelPosEnc.forward between the qkv and proj Linear layers (reference nets/tcct.py:316-331 + ConvRelPosEnc.forward
     :265-287): out [B,N,C] = scale * q (softmax_N(k)^T v) + q * crpe(v), qkv [B,N,3C] (dormant in stc_tt)."""
 
@@ -2709,7 +2721,7 @@ def factor_att(qkv, size, heads, scale, crpe_convs):
     return _FactorAtt.apply(qkv, int(size[0]), int(size[1]), int(heads), float(scale), *wb)
 
 
-class _MaxPool2(torch.autograd.Function):
+class _MaxPool2(_FastFunction):
     @staticmethod
     def forward(ctx, x):
         _chk(x)
@@ -2729,7 +2741,7 @@ class _MaxPool2(torch.autograd.Function):
         return dx
 
 
-class _MaxPool2Fork(torch.autograd.Function):
+class _MaxPool2Fork(_FastFunction):
     """(maxpool2(x), x): the second output aliases x and is what the OTHER consumers of x read, so that in the backward pass their
     gradient arrives here and is added inside the pooling scatter kernel (autograd would otherwise run an accumulation pass)"""
 
@@ -2769,7 +2781,7 @@ def maxpool2_fork(x):
     return _MaxPool2Fork.apply(x)
 
 
-class _Bilinear(torch.autograd.Function):
+class _Bilinear(_FastFunction):
     @staticmethod
     def forward(ctx, x, Ho, Wo, align, res=None):
         _chk(x)
@@ -2808,7 +2820,7 @@ def bilinear(x, size, align_corners, residual=None):
     return _Bilinear.apply(x, int(size[0]), int(size[1]), bool(align_corners), residual)
 
 
-class _L2Norm(torch.autograd.Function):
+class _L2Norm(_FastFunction):
     @staticmethod
     def forward(ctx, x, eps):
         _chk(x)
@@ -2853,7 +2865,7 @@ def fpl_lazy_grad_reset():
     _FPL_LAZY['pending'].clear()
 
 
-class _NormAdd(torch.autograd.Function):
+class _NormAdd(_FastFunction):
     """norm_add([g0, g1, g2]) (reference nets/tcct.py:937-942): mean of the three L2-normalised maps at g0's size.  Forward: one pass
     (tcct_normadd_fwd); backward: the existing resize / normalise gradients with the 1/3 folded into the last kernel of each chain."""
 
@@ -2958,7 +2970,7 @@ def norm_add3_fork(g0, g1, g2, eps=1e-12):
 
 
 # ------------------------------------------------------------------------------------------------ losses
-class _SoftmaxDice(torch.autograd.Function):
+class _SoftmaxDice(_FastFunction):
     @staticmethod
     def forward(ctx, logits, labels):
         _chk(logits, labels)
@@ -2986,7 +2998,7 @@ def softmax_dice(logits, labels):
     return _SoftmaxDice.apply(logits, labels)
 
 
-class _UpDice(torch.autograd.Function):
+class _UpDice(_FastFunction):
     """MultiLoss(DiceLoss)(F.interpolate(low, size, 'bilinear'), labels) without materialising the resized logits (deep-supervision heads)"""
 
     @staticmethod
@@ -3012,7 +3024,7 @@ class _UpDice(torch.autograd.Function):
         return d, None, None, None
 
 
-class _DeepSupervisionDice(torch.autograd.Function):
+class _DeepSupervisionDice(_FastFunction):
     """KiteSeg.grad_calc with MultiLoss(DiceLoss) (reference kite/loopback.py:62-73): sum_{i=3,2,1} coff * Dice(resize(low_i)) + Dice(logits0) as ONE node: one
     memset, four sums kernels, one finalisation; the scalar multiplications and additions of the loop (a dozen 5-us launches on the single-stream stretch of the
     step, each way) are arithmetic inside the finalisation kernel / the grad_scale argument of the backward kernels."""
@@ -3101,7 +3113,7 @@ def softmax_dice_upsampled(lr, labels):
     return _UpDice.apply(lr.low, labels, lr.size[0], lr.size[1])
 
 
-class _Slice(torch.autograd.Function):
+class _Slice(_FastFunction):
     @staticmethod
     def forward(ctx, x, start, n):
         _chk(x)
@@ -3126,7 +3138,7 @@ def slice_channels_f32(x, start, n):
     return _Slice.apply(x, start, n)
 
 
-class _GumbelColSoftmax(torch.autograd.Function):
+class _GumbelColSoftmax(_FastFunction):
     @staticmethod
     def forward(ctx, x, eps):
         _chk(x, eps)
@@ -3152,7 +3164,7 @@ def gumbel_colsoftmax_sum(x, eps):
     return _GumbelColSoftmax.apply(x, eps)
 
 
-class _ColSoftmax(torch.autograd.Function):
+class _ColSoftmax(_FastFunction):
     @staticmethod
     def forward(ctx, x):
         _chk(x)
@@ -3177,7 +3189,7 @@ def colsoftmax(x):
     return _ColSoftmax.apply(x)
 
 
-class _ColWSum(torch.autograd.Function):
+class _ColWSum(_FastFunction):
     @staticmethod
     def forward(ctx, x, wts):
         _chk(x, wts)
@@ -3203,7 +3215,7 @@ def colwsum(x, wts):
     return _ColWSum.apply(x, wts)
 
 
-class _Mse(torch.autograd.Function):
+class _Mse(_FastFunction):
     @staticmethod
     def forward(ctx, a, b):
         _chk(a, b)
@@ -3237,7 +3249,7 @@ def label_planes(labels, start, n, want_onehot=True, want_edge=True):
     return oh, ed
 
 
-class _Fpl(torch.autograd.Function):
+class _Fpl(_FastFunction):
     @staticmethod
     def forward(ctx, feat, logits, labels, buf_grad, allow_lazy=True):
         ctx.set_materialize_grads(False)      # an unused output must arrive as None in backward(), not as a zero-filled tensor
