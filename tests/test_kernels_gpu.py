@@ -2071,7 +2071,9 @@ def test_gumbel_colsoftmax_with_zero_draws(hw):
     torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-3, atol=1e-6)
 
 
-@pytest.mark.parametrize('cfg', [(2, 5, 6, 10, 2), (1, 5, 5, 7, 4), (2, 5, 3, 4, 8), (1, 3, 1, 1, 2), (1, 8, 2, 3, 16)])
+@pytest.mark.parametrize('cfg', [(2, 5, 6, 10, 2), (1, 5, 5, 7, 4), (2, 5, 3, 4, 8), (1, 3, 1, 1, 2), (1, 8, 2, 3, 16),
+                                 # rows wider than one wave: the lane exchanges of the forward / backward kernels across 64-lane (forward) and 62-column (backward) wave tiles
+                                 (1, 5, 3, 70, 2), (2, 5, 2, 130, 4), (1, 5, 2, 63, 2), (1, 5, 1, 125, 8)])
 def test_upsampled_dice_matches_interpolate_softmax_dice(cfg):
     """deep-supervision heads (reference nets/tcct.py:1042-1044 + kite/losses/loss.py:83-99): F.interpolate(bilinear, align_corners=False)
     -> softmax -> batch-global Dice, fused so that the resized logits never exist; loss and the gradient w.r.t. the low-resolution logits"""
