@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(PB) k_bilinear_bwd_tab(const T* __restrict__ d
     }
 }
 
-// Exact x2, align_corners = False (every resize of the decoder and the level-0 head) -- round 6.  The transposed interpolation is separable with the fixed taps
+// Exact x2, align_corners = False (the level-0 head's resize; an align_corners = True resize has position-dependent taps and keeps the gather above) -- round 6.  The transposed interpolation is separable with the fixed taps
 // {1/4, 3/4, 3/4, 1/4} over dy columns 2 wi - 1 .. 2 wi + 2 (rows alike; at the borders the outer tap vanishes and its inner neighbour weighs 1).  The tiled gather above
 // reads 16 dy vectors per dx vector (every dy element four times: L1 / L2 hits, but the CU takes only so many load instructions: 2.1-3.3 TB/s); here a lane owns low-resolution
 // column wi (NCH channels) of a strip of BX_SH output rows, loads ITS two dy columns of the 2 BX_SH + 2 rows the strip needs -- all requests issued before the first use --
